@@ -1,0 +1,338 @@
+/*
+ * fasp_hip.h -- C-ABI of the MI355X-native AMG-preconditioned Krylov path.
+ *
+ * This header is the drop-in boundary of libfasp_hip.so.  Every type below is
+ * layout-identical to the SERIAL (non-OpenMP) build of the reference headers,
+ * and every `fasp_*` entry point keeps the reference's name, argument order,
+ * argument meaning and return convention, so that a program compiled against
+ * the reference's own `fasp.h` / `fasp_functs.h` can be linked against this
+ * library instead of libfasp for the path listed here.
+ *
+ *   reference type / function                       reference location
+ *   ------------------------------------------------------------------------
+ *   INT = int, REAL = double, SHORT = short         base/include/fasp.h:71-75
+ *   dCSRmat  {row,col,nnz,IA,JA,val}                base/include/fasp.h:151-180
+ *   dvector / ivector                               base/include/fasp.h:354-376
+ *   ITS_param                                       base/include/fasp.h:386-398
+ *   AMG_param                                       base/include/fasp.h:455-595
+ *   precond {data,fct}                              base/include/fasp.h:1095-1103
+ *   fasp_param_amg_init                             base/src/AuxParam.c:431
+ *   fasp_param_solver_init                          base/src/AuxParam.c:572
+ *   fasp_solver_dcsr_krylov_amg                     base/src/SolCSR.c:476
+ *   fasp_blas_dcsr_mxv / _aAxpy                     base/src/BlaSpmvCSR.c:242 / :494
+ *   fasp_blas_darray_{dotprod,norm2,norminf,axpy,axpby}
+ *                                                   base/src/BlaArray.c:771/691/719/90/620
+ *   fasp_smoother_dcsr_jacobi                       base/src/ItrSmootherCSR.c:98
+ *
+ * The `fasp_hip_*` functions are extensions (no reference counterpart): they
+ * expose the device-resident objects behind fasp_solver_dcsr_krylov_amg so a
+ * caller can set the hierarchy up once and solve many times, bind a GPU, join
+ * an RCCL communicator and read timing / roofline counters.
+ *
+ * No torch types, no C++ types: plain pointers and sizes only.
+ */
+#ifndef FASP_HIP_H
+#define FASP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* constants (values of base/include/fasp_const.h)                          */
+/* ------------------------------------------------------------------------ */
+#define FASP_SUCCESS            0
+#define ERROR_INPUT_PAR       (-13)
+#define ERROR_MAT_SIZE        (-15)
+#define ERROR_MISC            (-19)
+#define ERROR_ALLOC_MEM       (-20)
+#define ERROR_DATA_STRUCTURE  (-21)
+#define ERROR_AMG_INTERP_TYPE (-30)
+#define ERROR_AMG_SMOOTH_TYPE (-31)
+#define ERROR_AMG_COARSE_TYPE (-32)
+#define ERROR_AMG_SETUP       (-39)
+#define ERROR_SOLVER_TYPE     (-40)
+#define ERROR_SOLVER_PRECTYPE (-41)
+#define ERROR_SOLVER_STAG     (-42)
+#define ERROR_SOLVER_SOLSTAG  (-43)
+#define ERROR_SOLVER_TOLSMALL (-44)
+#define ERROR_SOLVER_MISC     (-46)
+#define ERROR_SOLVER_MAXIT    (-48)
+#define ERROR_UNKNOWN         (-99)
+
+#define PRINT_NONE 0
+#define PRINT_MIN  1
+#define PRINT_SOME 2
+#define PRINT_MORE 4
+#define PRINT_MOST 8
+#define PRINT_ALL  10
+
+#define SOLVER_DEFAULT 0
+#define SOLVER_CG      1
+#define SOLVER_VGMRES  5
+#define SOLVER_VFGMRES 6
+
+#define STOP_REL_RES     1
+#define STOP_REL_PRECRES 2
+#define STOP_MOD_REL_RES 3
+
+#define PREC_NULL 0
+#define PREC_DIAG 1
+#define PREC_AMG  2
+#define PREC_FMG  3
+
+#define CLASSIC_AMG 1
+#define SA_AMG      2
+#define UA_AMG      3
+
+#define V_CYCLE       1
+#define W_CYCLE       2
+#define AMLI_CYCLE    3
+#define NL_AMLI_CYCLE 4
+#define VW_CYCLE      12
+#define WV_CYCLE      21
+
+#define SMOOTHER_JACOBI  1
+#define SMOOTHER_GS      2
+#define SMOOTHER_SGS     3
+#define SMOOTHER_CG      4
+#define SMOOTHER_SOR     5
+#define SMOOTHER_SSOR    6
+#define SMOOTHER_GSOR    7
+#define SMOOTHER_SGSOR   8
+#define SMOOTHER_POLY    9
+#define SMOOTHER_L1DIAG  10
+#define SMOOTHER_JACOBIF 11
+#define SMOOTHER_GSF     12
+
+#define COARSE_RS  1
+#define COARSE_RSP 2
+#define COARSE_CR  3
+#define COARSE_AC  4
+#define COARSE_MIS 5
+
+#define INTERP_DIR 1
+#define INTERP_STD 2
+#define INTERP_ENG 3
+#define INTERP_RDC 4
+#define INTERP_EXT 6
+
+#define NO_ORDER 0
+#define CF_ORDER 1
+
+#define PAIRWISE 1
+#define VMB      2
+
+#define FASP_ILUk 1
+
+/* ------------------------------------------------------------------------ */
+/* types (serial layout of base/include/fasp.h; sizes checked in tests)     */
+/* ------------------------------------------------------------------------ */
+
+/* fasp.h:151  sizeof == 40 */
+typedef struct dCSRmat {
+    int     row;
+    int     col;
+    int     nnz;
+    int*    IA;  /* row+1 row pointers, 0-based */
+    int*    JA;  /* nnz column indices, unsorted within a row */
+    double* val; /* nnz values */
+} dCSRmat;
+
+/* fasp.h:354  sizeof == 16 */
+typedef struct dvector {
+    int     row;
+    double* val;
+} dvector;
+
+/* fasp.h:368  sizeof == 16 */
+typedef struct ivector {
+    int  row;
+    int* val;
+} ivector;
+
+/* fasp.h:386  sizeof == 40 */
+typedef struct {
+    short  print_level;
+    short  itsolver_type;
+    short  decoup_type;
+    short  precond_type;
+    short  stop_type;
+    int    restart;
+    int    maxit;
+    double tol;
+    double abstol;
+} ITS_param;
+
+/* fasp.h:455  sizeof == 224 */
+typedef struct {
+    short   AMG_type;
+    short   print_level;
+    int     maxit;
+    double  tol;
+    short   max_levels;
+    int     coarse_dof;
+    short   cycle_type;
+    double  quality_bound;
+    short   smoother;
+    short   smooth_order;
+    short   presmooth_iter;
+    short   postsmooth_iter;
+    double  relaxation;
+    short   polynomial_degree;
+    short   coarse_solver;
+    short   coarse_scaling;
+    short   amli_degree;
+    double* amli_coef;
+    short   nl_amli_krylov_type;
+    short   coarsening_type;
+    short   aggregation_type;
+    short   aggregation_norm_type;
+    short   interpolation_type;
+    double  strong_threshold;
+    double  max_row_sum;
+    double  truncation_threshold;
+    int     aggressive_level;
+    int     aggressive_path;
+    int     pair_number;
+    double  strong_coupled;
+    int     max_aggregation;
+    double  tentative_smooth;
+    short   smooth_filter;
+    short   smooth_restriction;
+    short   ILU_levels;
+    short   ILU_type;
+    int     ILU_lfil;
+    double  ILU_droptol;
+    double  ILU_relax;
+    double  ILU_permtol;
+    int     SWZ_levels;
+    int     SWZ_mmsize;
+    int     SWZ_maxlvl;
+    int     SWZ_type;
+    int     SWZ_blksolver;
+    double  theta;
+} AMG_param;
+
+/* fasp.h:1095  sizeof == 16 */
+typedef struct {
+    void* data;
+    void (*fct)(double*, double*, void*);
+} precond;
+
+/* ------------------------------------------------------------------------ */
+/* reference entry points kept by this library                              */
+/* ------------------------------------------------------------------------ */
+
+/* AuxParam.c:431 -- defaults: classical AMG, GS smoother with C/F order, V(1,1),
+ * coarse_dof 500, max_levels 20, theta 0.3, max_row_sum 0.9, trunc 0.2 ... */
+void fasp_param_amg_init(AMG_param* amgparam);
+
+/* AuxParam.c:572 -- defaults: CG, AMG precond, STOP_REL_RES, maxit 500,
+ * restart 25, tol 1e-6, abstol 1e-18 */
+void fasp_param_solver_init(ITS_param* itsparam);
+
+/* SolCSR.c:476 -- the drop-in entry point.  Host arrays in, host arrays out.
+ * Deep-copies A, builds the AMG hierarchy (host), uploads it, runs the whole
+ * Krylov loop on the bound MI355X, copies x back, frees everything.
+ * Returns the iteration count (>=0) or a negative ERROR_* code.  Parameter
+ * combinations this library has no device path for (ILU/Schwarz smoothers,
+ * AMLI cycles, direct coarse solvers, ...) return an error; they never fall
+ * back to a CPU solve. */
+int fasp_solver_dcsr_krylov_amg(dCSRmat* A, dvector* b, dvector* x,
+                                ITS_param* itparam, AMG_param* amgparam);
+
+/* Kernel-level operators of the path, same names and semantics as the
+ * reference, host pointers in/out (upload -> HIP kernel -> download).  They
+ * exist so the reference's own call sites / tests of these operators can be
+ * pointed at the device kernels; hot loops use the handle API below instead. */
+void   fasp_blas_dcsr_mxv(const dCSRmat* A, const double* x, double* y);              /* BlaSpmvCSR.c:242 */
+void   fasp_blas_dcsr_aAxpy(const double alpha, const dCSRmat* A, const double* x,
+                            double* y);                                               /* BlaSpmvCSR.c:494 */
+double fasp_blas_darray_dotprod(const int n, const double* x, const double* y);       /* BlaArray.c:771 */
+double fasp_blas_darray_norm2(const int n, const double* x);                          /* BlaArray.c:691 */
+double fasp_blas_darray_norminf(const int n, const double* x);                        /* BlaArray.c:719 */
+void   fasp_blas_darray_axpy(const int n, const double a, const double* x, double* y); /* BlaArray.c:90 */
+void   fasp_blas_darray_axpby(const int n, const double a, const double* x,
+                              const double b, double* y);                             /* BlaArray.c:620 */
+void   fasp_smoother_dcsr_jacobi(dvector* u, const int i_1, const int i_n, const int s,
+                                 dCSRmat* A, dvector* b, int L, const double w);      /* ItrSmootherCSR.c:98 */
+
+/* ------------------------------------------------------------------------ */
+/* extensions: device binding, resident hierarchy, instrumentation          */
+/* ------------------------------------------------------------------------ */
+
+/* Bind the calling process to one GPU (default: device 0 on first use). */
+int fasp_hip_set_device(int device);
+/* Number of visible GPUs, or a negative ERROR_* code. */
+int fasp_hip_device_count(void);
+/* 1 when a gfx950 device is usable, else 0 (never initialises a fallback). */
+int fasp_hip_available(void);
+
+typedef struct fasp_hip_amg fasp_hip_amg; /* opaque: host + device hierarchy */
+
+/* Host setup (classical RS, bit-compatible with PreAMGSetupRS.c:52) followed by
+ * upload of every level's A/R/P to HBM.  A is deep-copied.  amgparam is
+ * mutated exactly as the reference mutates it (tentative_smooth = 1.0 ...). */
+int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgparam);
+void fasp_hip_amg_destroy(fasp_hip_amg* h);
+
+/* Hierarchy inspection (parity tests compare these with the oracle). */
+int fasp_hip_amg_num_levels(const fasp_hip_amg* h);
+/* which: 0 = A_l, 1 = P_l, 2 = R_l.  Returns host views owned by the handle. */
+int fasp_hip_amg_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view);
+int fasp_hip_amg_get_cfmark(const fasp_hip_amg* h, int level, ivector* view);
+
+/* Per-solve statistics filled by fasp_hip_solve. */
+typedef struct {
+    int    iters;            /* return value of the Krylov method */
+    int    nhist;            /* entries written to hist */
+    double relres;           /* final relative residual (as printed by ITS_FINAL) */
+    double absres;           /* final ||r||_2 */
+    double normr0;           /* max(1e-20, ||r0||_2) */
+    double solve_seconds;    /* wall time of the Krylov loop, device-synchronised */
+    double upload_seconds;   /* H2D of b, x0 and D2H of x */
+    double spmv_ms;          /* mean duration of the level-0 A*p kernel (HIP events) */
+    long long spmv_launches; /* number of launches averaged in spmv_ms */
+    long long coarse_iters;  /* total coarsest-level SPCG iterations */
+    long long vcycles;       /* number of multigrid cycles executed */
+} fasp_hip_stats;
+
+/* Krylov solve on a resident hierarchy.  hist (may be NULL) receives the
+ * absolute residual norms ||r_k||_2, k = 0..iters, up to hist_cap entries. */
+int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_param* itparam,
+                   double* hist, int hist_cap, fasp_hip_stats* stats);
+
+/* One application of the AMG preconditioner z = B r (PreCSR.c:416) on the
+ * resident hierarchy; host vectors in/out. */
+int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z);
+
+/* Synthetic input of the headline benchmark: 3-D 7-point FD Poisson on the
+ * unit cube, nx*ny*nz interior points, lexicographic, x fastest; row layout and
+ * values as produced by test/src/FdmPoisson.c:439 + :731 of the reference.
+ * A, b, u are allocated with malloc and released by fasp_hip_free_system. */
+int  fasp_hip_poisson7pt(int nx, int ny, int nz, dCSRmat* A, dvector* b, dvector* u_exact);
+void fasp_hip_free_system(dCSRmat* A, dvector* b, dvector* u);
+
+/* Timed micro-benchmark of one device kernel class on the resident level-0
+ * matrix: returns mean milliseconds per launch over `reps` launches measured
+ * with HIP events on the launch stream.  kind: 0 = SpMV, 1 = aAxpy(-1),
+ * 2 = Jacobi sweep, 3 = dot, 4 = axpy. */
+double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps);
+
+/* Multi-GPU (1-D row partition, RCCL over xGMI).  The unique id is produced on
+ * rank 0 and distributed by the caller (e.g. torch.distributed broadcast). */
+#define FASP_HIP_UNIQUE_ID_BYTES 128
+int fasp_hip_comm_unique_id(char* id_out);
+int fasp_hip_comm_init(int rank, int nranks, const char* id);
+int fasp_hip_comm_finalize(void);
+int fasp_hip_comm_rank(void);
+int fasp_hip_comm_size(void);
+
+/* Library/version string. */
+const char* fasp_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASP_HIP_H */

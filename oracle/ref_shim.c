@@ -1,0 +1,170 @@
+/*
+ * ref_shim.c -- flat accessors around the REFERENCE library, for fixture
+ * generation and oracle validation.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is our own code.  It is compiled against the reference's headers
+ * where they lie (-I/root/reference/base/include ...) and linked with the
+ * reference's own objects into oracle/_ref/libfasp_ref.so by oracle/Makefile.
+ * It exists because ctypes cannot comfortably walk the reference's AMG_data
+ * (1104-byte struct with optional-solver members).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fasp.h"
+#include "fasp_functs.h"
+#include "poisson_fdm.h"
+
+/* ---- ABI facts ---------------------------------- */
+int ref_sizeof(int which)
+{
+    switch (which) {
+        case 0: return (int)sizeof(dCSRmat);
+        case 1: return (int)sizeof(dvector);
+        case 2: return (int)sizeof(ITS_param);
+        case 3: return (int)sizeof(AMG_param);
+        case 4: return (int)sizeof(AMG_data);
+        case 5: return (int)sizeof(precond_data);
+        case 6: return (int)sizeof(precond);
+        case 7: return (int)sizeof(ivector);
+        default: return -1;
+    }
+}
+int ref_offsetof_amgparam(int which)
+{
+    switch (which) {
+        case 0: return (int)offsetof(AMG_param, tol);
+        case 1: return (int)offsetof(AMG_param, coarse_dof);
+        case 2: return (int)offsetof(AMG_param, relaxation);
+        case 3: return (int)offsetof(AMG_param, amli_coef);
+        case 4: return (int)offsetof(AMG_param, strong_threshold);
+        case 5: return (int)offsetof(AMG_param, theta);
+        case 6: return (int)offsetof(AMG_param, smoother);
+        case 7: return (int)offsetof(AMG_param, ILU_levels);
+        case 8: return (int)offsetof(AMG_param, SWZ_levels);
+        default: return -1;
+    }
+}
+
+/* ---- synthetic input: the reference's own generator --------------------- */
+int ref_poisson7pt(int nx, int ny, int nz, dCSRmat* A, dvector* b, dvector* u)
+{
+    fsls_BandMatrix* B = NULL;
+    fsls_CSRMatrix*  C = NULL;
+    fsls_XVector *   f = NULL, *ue = NULL;
+    fsls_BuildLinearSystem_7pt3d(0, nx, ny, nz, &B, &f, &ue);
+    fsls_Band2CSRMatrix(B, &C);
+    const int n = fsls_CSRMatrixNumRows(C), nnz = fsls_CSRMatrixI(C)[n];
+    *A = fasp_dcsr_create(n, n, nnz);
+    memcpy(A->IA, fsls_CSRMatrixI(C), (size_t)(n + 1) * sizeof(int));
+    memcpy(A->JA, fsls_CSRMatrixJ(C), (size_t)nnz * sizeof(int));
+    memcpy(A->val, fsls_CSRMatrixData(C), (size_t)nnz * sizeof(double));
+    *b = fasp_dvec_create(n);
+    *u = fasp_dvec_create(n);
+    memcpy(b->val, fsls_XVectorData(f), (size_t)n * sizeof(double));
+    memcpy(u->val, fsls_XVectorData(ue), (size_t)n * sizeof(double));
+    fsls_BandMatrixDestroy(B);
+    fsls_CSRMatrixDestroy(C);
+    fsls_XVectorDestroy(f);
+    fsls_XVectorDestroy(ue);
+    return 0;
+}
+
+/* ---- classical setup ----------------------------------------------------- */
+void* ref_amg_setup_rs(dCSRmat* A, AMG_param* param)
+{
+    AMG_data* mgl = fasp_amg_data_create(param->max_levels);
+    mgl[0].A = fasp_dcsr_create(A->row, A->col, A->nnz);
+    fasp_dcsr_cp(A, &mgl[0].A);
+    mgl[0].b = fasp_dvec_create(A->col);
+    mgl[0].x = fasp_dvec_create(A->col);
+    if (fasp_amg_setup_rs(mgl, param) < 0) return NULL;
+    return mgl;
+}
+int ref_amg_num_levels(void* h) { return ((AMG_data*)h)[0].num_levels; }
+int ref_amg_get_matrix(void* h, int l, int which, dCSRmat* view)
+{
+    AMG_data* mgl = (AMG_data*)h;
+    *view = which == 0 ? mgl[l].A : which == 1 ? mgl[l].P : mgl[l].R;
+    return 0;
+}
+int* ref_amg_get_cfmark(void* h, int l) { return ((AMG_data*)h)[l].cfmark.val; }
+void ref_amg_free(void* h, AMG_param* param) { fasp_amg_data_free((AMG_data*)h, param); }
+
+/* z = B r through the reference's fasp_precond_amg (PreCSR.c:416) */
+void ref_precond_amg(void* h, AMG_param* param, double* r, double* z)
+{
+    AMG_data*    mgl = (AMG_data*)h;
+    precond_data pcdata;
+    fasp_param_amg_to_prec(&pcdata, param);
+    pcdata.max_levels = mgl[0].num_levels;
+    pcdata.mgl_data   = mgl;
+    fasp_precond_amg(r, z, &pcdata);
+}
+
+/* ---- full solve with a full-precision residual history ------------------ */
+typedef struct {
+    precond_data* pcdata;
+    double*       hist;
+    int           cap, n, m;
+} hist_pc;
+
+static void hist_pc_fct(double* r, double* z, void* data)
+{
+    hist_pc* h = (hist_pc*)data;
+    if (h->hist && h->n < h->cap) h->hist[h->n] = fasp_blas_darray_norm2(h->m, r);
+    h->n++;
+    fasp_precond_amg(r, z, h->pcdata);
+}
+
+/* Mirrors SolCSR.c:476-569 step by step, only swapping pc.fct for the recording
+ * wrapper above.  hist[k] = ||r_k||_2 for every r handed to the preconditioner
+ * (k = 0 .. iters-1); hist[iters] = ||b - A x||_2 recomputed from the returned x
+ * with the reference's own aAxpy + norm2 (what KryPcg.c:280-287 leaves in absres). */
+int ref_krylov_amg_hist(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam,
+                        AMG_param* amgparam, double* hist, int cap, int* nhist)
+{
+    const int m = A->row, n = A->col, nnz = A->nnz;
+    int       status;
+    AMG_data* mgl = fasp_amg_data_create(amgparam->max_levels);
+    mgl[0].A      = fasp_dcsr_create(m, n, nnz);
+    fasp_dcsr_cp(A, &mgl[0].A);
+    mgl[0].b = fasp_dvec_create(n);
+    mgl[0].x = fasp_dvec_create(n);
+    status   = fasp_amg_setup_rs(mgl, amgparam);
+    if (status < 0) goto FINISHED;
+
+    precond_data pcdata;
+    fasp_param_amg_to_prec(&pcdata, amgparam);
+    pcdata.max_levels = mgl[0].num_levels;
+    pcdata.mgl_data   = mgl;
+
+    hist_pc hp = {&pcdata, hist, cap, 0, m};
+    precond pc;
+    pc.data = &hp;
+    pc.fct  = hist_pc_fct;
+    status  = fasp_solver_dcsr_itsolver(A, b, x, &pc, itparam);
+    {
+        double* r = (double*)malloc((size_t)m * sizeof(double));
+        memcpy(r, b->val, (size_t)m * sizeof(double));
+        fasp_blas_dcsr_aAxpy(-1.0, A, x->val, r);
+        if (hist && hp.n < cap) hist[hp.n] = fasp_blas_darray_norm2(m, r);
+        hp.n++;
+        free(r);
+    }
+    if (nhist) *nhist = hp.n;
+FINISHED:
+    fasp_amg_data_free(mgl, amgparam);
+    return status;
+}
+
+/* coarsest-level solver exactly as PreMGUtil.inl:37 wires it */
+int ref_coarse_spcg(dCSRmat* A, dvector* b, dvector* x, double ctol)
+{
+    const int n     = A->row;
+    const int maxit = MAX(250, MIN(n * n, 1000));
+    return fasp_solver_dcsr_spcg(A, b, x, NULL, ctol, maxit, 1, 0);
+}

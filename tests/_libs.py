@@ -1,0 +1,196 @@
+"""Loaders for the checker libraries used by the tests (oracle, reference build)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from faspsolver_amd import _types as T  # noqa: E402
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libfasp_ref.so")
+REF_TREE = "/root/reference"
+
+_oracle = None
+_ref = None
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+
+
+def oracle():
+    """liboracle.so (CPU restatement).  Built on demand (gcc only)."""
+    global _oracle
+    if _oracle is None:
+        src = os.path.join(ROOT, "oracle", "fasp_oracle.c")
+        if (not os.path.exists(ORACLE_SO)
+                or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src)):
+            build_oracle()
+        lib = C.CDLL(ORACLE_SO)
+        lib.orc_dotprod.restype = C.c_double
+        lib.orc_norm2.restype = C.c_double
+        lib.orc_norminf.restype = C.c_double
+        lib.orc_dotprod.argtypes = [C.c_int, T.c_double_p, T.c_double_p]
+        lib.orc_norm2.argtypes = [C.c_int, T.c_double_p]
+        lib.orc_norminf.argtypes = [C.c_int, T.c_double_p]
+        lib.orc_axpy.argtypes = [C.c_int, C.c_double, T.c_double_p, T.c_double_p]
+        lib.orc_axpby.argtypes = [C.c_int, C.c_double, T.c_double_p, C.c_double, T.c_double_p]
+        lib.orc_aAxpy.argtypes = [C.c_double, C.POINTER(T.dCSRmat), T.c_double_p, T.c_double_p]
+        lib.orc_mxv.argtypes = [C.POINTER(T.dCSRmat), T.c_double_p, T.c_double_p]
+        lib.orc_smoother_jacobi.argtypes = [T.c_double_p, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(T.dCSRmat), T.c_double_p, C.c_int,
+                                            C.c_double]
+        lib.orc_smoother_sor.argtypes = lib.orc_smoother_jacobi.argtypes
+        lib.orc_smoother_gs.argtypes = [T.c_double_p, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(T.dCSRmat), T.c_double_p, C.c_int]
+        lib.orc_smoother_l1diag.argtypes = lib.orc_smoother_gs.argtypes
+        lib.orc_smoother_gs_cf.argtypes = [T.c_double_p, C.POINTER(T.dCSRmat), T.c_double_p,
+                                           C.c_int, T.c_int_p, C.c_int]
+        lib.orc_smoother_sgs.argtypes = [T.c_double_p, C.POINTER(T.dCSRmat), T.c_double_p,
+                                         C.c_int]
+        lib.orc_spcg.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(T.dvector),
+                                 C.POINTER(T.dvector), C.c_double, C.c_int, C.c_int, C.c_int]
+        lib.orc_precond_amg.argtypes = [C.c_void_p, C.POINTER(T.AMG_param), T.c_double_p,
+                                        T.c_double_p]
+        lib.orc_amg_setup_rs.argtypes = [C.c_void_p, C.POINTER(T.dCSRmat),
+                                         C.POINTER(T.AMG_param)]
+        lib.orc_amg_free.argtypes = [C.c_void_p]
+        _oracle = lib
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    """The reference compiled from its own sources (oracle/_ref), or None."""
+    global _ref
+    if _ref is None:
+        if not have_ref():
+            if os.path.isdir(REF_TREE):
+                build_oracle()
+            if not have_ref():
+                return None
+        lib = C.CDLL(REF_SO)
+        lib.ref_amg_setup_rs.restype = C.c_void_p
+        lib.ref_amg_setup_rs.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(T.AMG_param)]
+        lib.ref_amg_num_levels.argtypes = [C.c_void_p]
+        lib.ref_amg_get_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(T.dCSRmat)]
+        lib.ref_amg_get_cfmark.restype = T.c_int_p
+        lib.ref_amg_get_cfmark.argtypes = [C.c_void_p, C.c_int]
+        lib.ref_amg_free.argtypes = [C.c_void_p, C.POINTER(T.AMG_param)]
+        lib.ref_precond_amg.argtypes = [C.c_void_p, C.POINTER(T.AMG_param), T.c_double_p,
+                                        T.c_double_p]
+        lib.ref_coarse_spcg.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(T.dvector),
+                                        C.POINTER(T.dvector), C.c_double]
+        lib.fasp_blas_darray_dotprod.restype = C.c_double
+        lib.fasp_blas_darray_norm2.restype = C.c_double
+        lib.fasp_blas_darray_norminf.restype = C.c_double
+        _ref = lib
+    return _ref
+
+
+class OrcAMG:
+    """Owns an orc_amg hierarchy built by the oracle."""
+
+    def __init__(self, A, param):
+        lib = oracle()
+        self.lib = lib
+        self.buf = C.create_string_buffer(lib.orc_sizeof_amg())
+        self.status = lib.orc_amg_setup_rs(self.buf, C.byref(A), C.byref(param))
+        # struct orc_amg { int num_levels; orc_level L[20]; ... }
+        self.num_levels = C.cast(self.buf, T.c_int_p)[0]
+
+    def level(self, l):
+        """(A, P, R, cfmark) of level l as struct views."""
+        class Lvl(C.Structure):
+            _fields_ = [("A", T.dCSRmat), ("P", T.dCSRmat), ("R", T.dCSRmat),
+                        ("cfmark", T.ivector), ("b", T.dvector), ("x", T.dvector),
+                        ("w", T.dvector)]
+        base = C.addressof(self.buf) + 8  # int + padding
+        return Lvl.from_address(base + l * C.sizeof(Lvl))
+
+    def free(self):
+        if self.buf is not None:
+            self.lib.orc_amg_free(self.buf)
+            self.buf = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# --- data readers (formats of base/src/BlaIO.c:146-157: 1-based ASCII CSR) ----
+import numpy as np  # noqa: E402
+
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+
+
+def read_csr(path):
+    """fasp_dcsrvec_read2 matrix format: n, ia(n+1), ja(nnz), a(nnz), 1-based."""
+    tok = open(path).read().split()
+    n = int(tok[0])
+    ia = np.array(tok[1:n + 2], dtype=np.int64)
+    nnz = int(ia[-1] - ia[0])
+    ja = np.array(tok[n + 2:n + 2 + nnz], dtype=np.int64)
+    a = np.array(tok[n + 2 + nnz:n + 2 + 2 * nnz], dtype=np.float64)
+    return (ia - ia[0]).astype(np.int32), (ja - 1).astype(np.int32), a
+
+
+def read_vec(path):
+    tok = open(path).read().split()
+    n = int(tok[0])
+    return np.array(tok[1:n + 1], dtype=np.float64)
+
+
+def poisson7pt(n, lib=None):
+    """P7(n) through the oracle's generator; returns numpy (ia, ja, a, f, u)."""
+    lib = lib or oracle()
+    A = T.dCSRmat(); b = T.dvector(); u = T.dvector()
+    lib.orc_poisson7pt(n, n, n, C.byref(A), C.byref(b), C.byref(u))
+    ia, ja, a = T.csr_arrays(A)
+    f = np.ctypeslib.as_array(b.val, (b.row,)).copy()
+    ue = np.ctypeslib.as_array(u.val, (u.row,)).copy()
+    lib.orc_free_csr(C.byref(A)); lib.orc_free_vec(C.byref(b)); lib.orc_free_vec(C.byref(u))
+    return ia, ja, a, f, ue
+
+
+def orc_solve(ia, ja, a, f, itp, amgp, x0=None, cap=600):
+    """oracle fasp_solver_dcsr_krylov_amg; returns (status, x, hist, relres)."""
+    lib = oracle()
+    A, keep = T.as_csr(ia, ja, a)
+    x = np.zeros(len(f)) if x0 is None else x0.copy()
+    bv, fk = T.as_vec(f)
+    xv, x = T.as_vec(x)
+    hist = np.zeros(cap); nh = C.c_int(0); rr = C.c_double(0)
+    st = lib.orc_solver_dcsr_krylov_amg(C.byref(A), C.byref(bv), C.byref(xv), C.byref(itp),
+                                        C.byref(amgp), T.dp(hist), cap, C.byref(nh),
+                                        C.byref(rr))
+    return st, x, hist[:nh.value].copy(), rr.value
+
+
+def ref_solve(ia, ja, a, f, itp, amgp, x0=None, cap=600):
+    """reference fasp_solver_dcsr_krylov_amg with recorded history."""
+    lib = ref()
+    A, keep = T.as_csr(ia, ja, a)
+    x = np.zeros(len(f)) if x0 is None else x0.copy()
+    bv, fk = T.as_vec(f)
+    xv, x = T.as_vec(x)
+    hist = np.zeros(cap); nh = C.c_int(0)
+    st = lib.ref_krylov_amg_hist(C.byref(A), C.byref(bv), C.byref(xv), C.byref(itp),
+                                 C.byref(amgp), T.dp(hist), cap, C.byref(nh))
+    return st, x, hist[:nh.value].copy()
+
+
+def default_params(lib=None):
+    lib = lib or oracle()
+    itp = T.ITS_param(); amgp = T.AMG_param()
+    lib.orc_param_solver_init(C.byref(itp)); lib.orc_param_amg_init(C.byref(amgp))
+    return itp, amgp
