@@ -1,0 +1,208 @@
+"""faspsolver_amd -- host-side mirror of the C-ABI in include/fasp_hip.h.
+
+The product is libfasp_hip.so (C host code + hand-written HIP kernels for gfx950,
+built by faspsolver_amd/csrc/Makefile).  This module only binds it with ctypes and
+mirrors the reference's call signatures (same names, argument meaning and error
+behaviour as base/src/SolCSR.c:476, AuxParam.c:431/572, ...), so that parity tests
+read like the reference's own drivers.  It never computes anything itself and has no
+CPU fallback: if the shared library is missing it raises; if there is no GPU the
+library's compute entry points return ERROR_MISC.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _types as T
+from ._types import *  # noqa: F401,F403  (constants + struct mirrors)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfasp_hip.so")
+_lib = None
+
+EXPORTS = [  # every symbol include/fasp_hip.h declares
+    "fasp_param_amg_init", "fasp_param_solver_init", "fasp_solver_dcsr_krylov_amg",
+    "fasp_blas_dcsr_mxv", "fasp_blas_dcsr_aAxpy", "fasp_blas_darray_dotprod",
+    "fasp_blas_darray_norm2", "fasp_blas_darray_norminf", "fasp_blas_darray_axpy",
+    "fasp_blas_darray_axpby", "fasp_smoother_dcsr_jacobi",
+    "fasp_hip_set_device", "fasp_hip_device_count", "fasp_hip_available",
+    "fasp_hip_amg_create", "fasp_hip_amg_create_host", "fasp_hip_amg_upload",
+    "fasp_hip_amg_destroy", "fasp_hip_amg_num_levels", "fasp_hip_amg_get_matrix",
+    "fasp_hip_amg_get_cfmark", "fasp_hip_solve", "fasp_hip_precond_amg",
+    "fasp_hip_poisson7pt", "fasp_hip_free_system", "fasp_hip_time_kernel",
+    "fasp_hip_comm_unique_id", "fasp_hip_comm_init", "fasp_hip_comm_finalize",
+    "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version",
+]
+
+
+def build(verbose=False):
+    """Compile libfasp_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.run(cmd, check=True)
+
+
+def lib():
+    """The loaded shared library (built on demand).  Raises if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    P = C.POINTER
+    L.fasp_param_amg_init.argtypes = [P(T.AMG_param)]
+    L.fasp_param_solver_init.argtypes = [P(T.ITS_param)]
+    L.fasp_solver_dcsr_krylov_amg.argtypes = [P(T.dCSRmat), P(T.dvector), P(T.dvector),
+                                              P(T.ITS_param), P(T.AMG_param)]
+    L.fasp_blas_dcsr_mxv.argtypes = [P(T.dCSRmat), T.c_double_p, T.c_double_p]
+    L.fasp_blas_dcsr_aAxpy.argtypes = [C.c_double, P(T.dCSRmat), T.c_double_p, T.c_double_p]
+    for f in ("fasp_blas_darray_dotprod", "fasp_blas_darray_norm2", "fasp_blas_darray_norminf"):
+        getattr(L, f).restype = C.c_double
+    L.fasp_blas_darray_dotprod.argtypes = [C.c_int, T.c_double_p, T.c_double_p]
+    L.fasp_blas_darray_norm2.argtypes = [C.c_int, T.c_double_p]
+    L.fasp_blas_darray_norminf.argtypes = [C.c_int, T.c_double_p]
+    L.fasp_blas_darray_axpy.argtypes = [C.c_int, C.c_double, T.c_double_p, T.c_double_p]
+    L.fasp_blas_darray_axpby.argtypes = [C.c_int, C.c_double, T.c_double_p, C.c_double,
+                                         T.c_double_p]
+    L.fasp_smoother_dcsr_jacobi.argtypes = [P(T.dvector), C.c_int, C.c_int, C.c_int,
+                                            P(T.dCSRmat), P(T.dvector), C.c_int, C.c_double]
+    L.fasp_hip_amg_create.argtypes = [P(C.c_void_p), P(T.dCSRmat), P(T.AMG_param)]
+    L.fasp_hip_amg_create_host.argtypes = L.fasp_hip_amg_create.argtypes
+    L.fasp_hip_amg_upload.argtypes = [C.c_void_p]
+    L.fasp_hip_amg_destroy.argtypes = [C.c_void_p]
+    L.fasp_hip_amg_destroy.restype = None
+    L.fasp_hip_amg_num_levels.argtypes = [C.c_void_p]
+    L.fasp_hip_amg_get_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int, P(T.dCSRmat)]
+    L.fasp_hip_amg_get_cfmark.argtypes = [C.c_void_p, C.c_int, P(T.ivector)]
+    L.fasp_hip_solve.argtypes = [C.c_void_p, P(T.dvector), P(T.dvector), P(T.ITS_param),
+                                 T.c_double_p, C.c_int, P(T.fasp_hip_stats)]
+    L.fasp_hip_precond_amg.argtypes = [C.c_void_p, T.c_double_p, T.c_double_p]
+    L.fasp_hip_poisson7pt.argtypes = [C.c_int, C.c_int, C.c_int, P(T.dCSRmat), P(T.dvector),
+                                      P(T.dvector)]
+    L.fasp_hip_free_system.argtypes = [P(T.dCSRmat), P(T.dvector), P(T.dvector)]
+    L.fasp_hip_free_system.restype = None
+    L.fasp_hip_time_kernel.restype = C.c_double
+    L.fasp_hip_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.fasp_hip_comm_unique_id.argtypes = [C.c_char_p]
+    L.fasp_hip_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p]
+    L.fasp_hip_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def available():
+    """True when a HIP device is usable by the library."""
+    return bool(lib().fasp_hip_available())
+
+
+# --- parameter constructors (AuxParam.c:431 / :572) ------------------------------
+def param_amg_init():
+    p = T.AMG_param()
+    lib().fasp_param_amg_init(C.byref(p))
+    return p
+
+
+def param_solver_init():
+    p = T.ITS_param()
+    lib().fasp_param_solver_init(C.byref(p))
+    return p
+
+
+def poisson7pt(nx, ny=None, nz=None):
+    """P7 synthetic system (test/src/FdmPoisson.c:439 + :731) -> (ia, ja, a, f, u_exact)."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    A = T.dCSRmat(); b = T.dvector(); u = T.dvector()
+    st = lib().fasp_hip_poisson7pt(nx, ny, nz, C.byref(A), C.byref(b), C.byref(u))
+    if st < 0:
+        raise RuntimeError(f"fasp_hip_poisson7pt failed: {st}")
+    ia, ja, a = T.csr_arrays(A)
+    f = np.ctypeslib.as_array(b.val, (b.row,)).copy()
+    ue = np.ctypeslib.as_array(u.val, (u.row,)).copy()
+    lib().fasp_hip_free_system(C.byref(A), C.byref(b), C.byref(u))
+    return ia, ja, a, f, ue
+
+
+def solver_dcsr_krylov_amg(ia, ja, a, b, x, itparam, amgparam):
+    """fasp_solver_dcsr_krylov_amg (SolCSR.c:476).  x is updated in place (numpy f64).
+    Returns the iteration count or a negative ERROR_* code."""
+    A, _keep = T.as_csr(ia, ja, a)
+    bv, _b = T.as_vec(b)
+    assert x.dtype == np.float64 and x.flags["C_CONTIGUOUS"]
+    xv = T.dvector(x.shape[0], x.ctypes.data_as(T.c_double_p))
+    return lib().fasp_solver_dcsr_krylov_amg(C.byref(A), C.byref(bv), C.byref(xv),
+                                             C.byref(itparam), C.byref(amgparam))
+
+
+class AMG:
+    """Resident hierarchy (fasp_hip_amg).  host_only=True skips the GPU upload."""
+
+    def __init__(self, ia, ja, a, amgparam, host_only=False):
+        self._A, self._keep = T.as_csr(ia, ja, a)
+        self.h = C.c_void_p()
+        fn = lib().fasp_hip_amg_create_host if host_only else lib().fasp_hip_amg_create
+        self.status = fn(C.byref(self.h), C.byref(self._A), C.byref(amgparam))
+        if self.status < 0:
+            self.h = C.c_void_p()
+            raise RuntimeError(f"fasp_hip_amg_create failed with status {self.status}")
+        self.n = self._A.row
+
+    @property
+    def num_levels(self):
+        return lib().fasp_hip_amg_num_levels(self.h)
+
+    def upload(self):
+        st = lib().fasp_hip_amg_upload(self.h)
+        if st < 0:
+            raise RuntimeError(f"fasp_hip_amg_upload failed with status {st}")
+
+    def matrix(self, level, which):
+        """which: 0 A, 1 P, 2 R -> (nrow, ncol, ia, ja, val) copies."""
+        v = T.dCSRmat()
+        st = lib().fasp_hip_amg_get_matrix(self.h, level, which, C.byref(v))
+        if st < 0:
+            raise IndexError((level, which))
+        ia, ja, val = T.csr_arrays(v)
+        return v.row, v.col, ia, ja, val
+
+    def cfmark(self, level):
+        v = T.ivector()
+        if lib().fasp_hip_amg_get_cfmark(self.h, level, C.byref(v)) < 0:
+            raise IndexError(level)
+        return np.ctypeslib.as_array(v.val, (v.row,)).copy()
+
+    def solve(self, b, itparam, x0=None, hist_cap=600):
+        """PCG on the resident hierarchy -> (status, x, hist, stats)."""
+        x = np.zeros(self.n) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        bv, _b = T.as_vec(b)
+        xv, x = T.as_vec(x)
+        hist = np.zeros(hist_cap)
+        stats = T.fasp_hip_stats()
+        st = lib().fasp_hip_solve(self.h, C.byref(bv), C.byref(xv), C.byref(itparam),
+                                  T.dp(hist), hist_cap, C.byref(stats))
+        return st, x, hist[:max(stats.nhist, 0)].copy(), stats
+
+    def precond(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        st = lib().fasp_hip_precond_amg(self.h, T.dp(r), T.dp(z))
+        if st < 0:
+            raise RuntimeError(f"fasp_hip_precond_amg failed: {st}")
+        return z
+
+    def time_kernel(self, kind, level=0, reps=20):
+        return lib().fasp_hip_time_kernel(self.h, kind, level, reps)
+
+    def close(self):
+        if self.h:
+            lib().fasp_hip_amg_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

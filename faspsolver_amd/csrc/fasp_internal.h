@@ -1,0 +1,100 @@
+// fasp_internal.h -- internal declarations shared by the host setup and the
+// device solver of libfasp_hip.so.  Not part of the public ABI (include/fasp_hip.h).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/fasp_hip.h"
+
+namespace fasp {
+
+constexpr double SMALLREAL  = 1e-20;  // fasp_const.h:256
+constexpr double SMALLREAL2 = 1e-40;  // fasp_const.h:257
+constexpr double BIGREAL    = 1e+20;  // fasp_const.h:255
+constexpr int    MIN_CDOF   = 20;     // fasp_const.h:260
+constexpr int    MAX_AMG_LVL = 20;    // fasp_const.h:259
+constexpr int    MAX_RESTART = 20;    // fasp_const.h:263
+constexpr int    MAX_STAG    = 20;    // fasp_const.h:264
+constexpr double STAG_RATIO  = 1e-4;  // fasp_const.h:265
+
+constexpr int UNPT = -1, FGPT = 0, CGPT = 1, ISPT = 2;  // fasp_const.h:231-235
+
+// Uninitialised, malloc-backed array (std::vector would zero-fill gigabytes).
+template <class T>
+struct Buf {
+    T*     p = nullptr;
+    size_t n = 0;
+    Buf() = default;
+    explicit Buf(size_t n_) { alloc(n_); }
+    Buf(const Buf&)            = delete;
+    Buf& operator=(const Buf&) = delete;
+    Buf(Buf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    Buf& operator=(Buf&& o) noexcept
+    {
+        if (this != &o) { std::free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~Buf() { std::free(p); }
+    void alloc(size_t n_)
+    {
+        std::free(p);
+        n = n_;
+        p = static_cast<T*>(std::malloc((n_ ? n_ : 1) * sizeof(T)));
+        if (!p) throw std::bad_alloc();
+    }
+    void zero() { std::memset(p, 0, n * sizeof(T)); }
+    void shrink(size_t n_)
+    {
+        T* q = static_cast<T*>(std::realloc(p, (n_ ? n_ : 1) * sizeof(T)));
+        if (q) p = q;
+        n = n_;
+    }
+    T&       operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T*       data() { return p; }
+    const T* data() const { return p; }
+};
+
+struct HostCSR {
+    int         row = 0, col = 0, nnz = 0;
+    Buf<int>    ia, ja;
+    Buf<double> val;
+    dCSRmat     view() const
+    {
+        dCSRmat v;
+        v.row = row; v.col = col; v.nnz = nnz;
+        v.IA = const_cast<int*>(ia.data());
+        v.JA = const_cast<int*>(ja.data());
+        v.val = const_cast<double*>(val.data());
+        return v;
+    }
+};
+
+struct HostLevel {
+    HostCSR  A, P, R;
+    Buf<int> cfmark;  // C/F marker of this level (size A.row) when a coarser level exists
+    bool     has_coarse = false;
+};
+
+struct HostHierarchy {
+    std::vector<HostLevel> L;
+    double setup_seconds = 0.0;
+};
+
+// Classical (Ruge-Stuben) AMG setup, host side.  Restates PreAMGSetupRS.c:52
+// (+ PreAMGCoarsenRS.c, PreAMGInterp.c, BlaSparseCSR.c transposes, BlaSpmvCSR.c RAP)
+// with the reference's serial arithmetic and ordering, parallelised only where the
+// result is order-independent.  Returns FASP_SUCCESS or a negative ERROR_* code.
+int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H);
+
+// Parameter screening: every AMG_param / ITS_param combination without a device
+// path returns a negative ERROR_* code here (never a silent CPU fallback).
+int check_supported(const ITS_param* itparam, const AMG_param* amgparam);
+
+double wall_seconds();
+
+}  // namespace fasp

@@ -1,0 +1,945 @@
+// host_setup.cpp -- host side of libfasp_hip.so: classical (Ruge-Stuben) AMG
+// setup producing the hierarchy the HIP solve phase runs on.
+//
+// The setup decides the hierarchy and therefore the Krylov iteration counts, so it
+// reproduces the reference's SERIAL algorithm exactly (same C/F splitting order,
+// same floating-point expressions, same column order inside every row).  It is
+// host code by design: the C/F splitting is an
+// inherently sequential greedy graph algorithm.  Everything that is row-independent
+// (strength of connection, interpolation weights, truncation, Galerkin product) runs
+// under OpenMP; results are bit-identical to the serial reference because each row is
+// still evaluated in the reference's order.
+//
+// Reference (paths relative to the reference tree):
+//   fasp_amg_setup_rs          base/src/PreAMGSetupRS.c:52
+//   fasp_amg_coarsening_rs     base/src/PreAMGCoarsenRS.c:76
+//     strong_couplings   :236   compress_S :403   cfsplitting_cls :507
+//     clean_ff_couplings :1709  form_P_pattern_dir :1891
+//   fasp_amg_interp / interp_DIR / amg_interp_trunc   base/src/PreAMGInterp.c:64/302/127
+//   fasp_icsr_trans / fasp_dcsr_trans                  base/src/BlaSparseCSR.c:875/952
+//   fasp_blas_dcsr_rap                                 base/src/BlaSpmvCSR.c:999
+//   list-of-lists helpers                              base/src/PreAMGUtil.inl:121,207
+#include <omp.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+
+#include "fasp_internal.h"
+
+namespace fasp {
+
+double wall_seconds()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+namespace {
+
+inline double dabs(double a) { return (a >= 0.0) ? a : -a; }  // ABS, fasp.h:84
+
+struct Pattern {  // integer CSR (iCSRmat without values)
+    int      row = 0, col = 0, nnz = 0;
+    Buf<int> ia, ja;
+};
+
+// ---------------------------------------------------------------------------
+// strength of connection + compression  (PreAMGCoarsenRS.c:321-384, :403-430)
+// ---------------------------------------------------------------------------
+// Per row i: row_sum = sum |a_ij| (diagonal included); row_scl = theta * max_{j!=i}|a_ij|;
+// diagonal is never strong; if row_sum < (2 - max_row_sum)*|a_ii| the whole row is weak;
+// otherwise j is weak when -a_ij <= row_scl.  a_ii = first diagonal hit, 0 if absent.
+// The compressed S keeps the surviving columns in storage order.
+int strength_compressed(const HostCSR& A, const AMG_param& param, Pattern& S)
+{
+    const int    row = A.row;
+    const double max_row_sum = param.max_row_sum, eps = param.strong_threshold;
+    const int *  ia = A.ia.data(), *ja = A.ja.data();
+    const double* aj = A.val.data();
+    const int nd = std::min(A.row, A.col);
+
+    Buf<unsigned char> strong((size_t)A.nnz);
+    Buf<int>           cnt((size_t)row + 1);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        const int b = ia[i], e = ia[i + 1];
+        double row_scl = 0.0, row_sum = 0.0, diag = 0.0;
+        bool   have_diag = false;
+        for (int j = b; j < e; ++j) {
+            row_sum += dabs(aj[j]);
+            if (ja[j] != i) row_scl = std::max(row_scl, dabs(aj[j]));
+            else if (!have_diag && i < nd) { diag = aj[j]; have_diag = true; }
+        }
+        row_scl *= eps;
+        int  c = 0;
+        const bool all_weak = row_sum < (2 - max_row_sum) * dabs(diag);
+        bool diag_removed = false;
+        for (int j = b; j < e; ++j) {
+            bool s = true;
+            if (ja[j] == i && !diag_removed) { s = false; diag_removed = true; }  // first diagonal hit only (:350-355)
+            if (all_weak) s = false;
+            else if (-aj[j] <= row_scl) s = false;
+            strong[j] = s;
+            c += s;
+        }
+        cnt[i] = c;
+    }
+    S.row = row; S.col = A.col;
+    S.ia.alloc((size_t)row + 1);
+    int acc = 0;
+    for (int i = 0; i < row; ++i) { S.ia[i] = acc; acc += cnt[i]; }
+    S.ia[row] = acc;
+    S.nnz = acc;
+    S.ja.alloc((size_t)acc);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        int o = S.ia[i];
+        for (int j = ia[i]; j < ia[i + 1]; ++j)
+            if (strong[j]) S.ja[o++] = ja[j];
+    }
+    return (S.nnz <= 0) ? ERROR_UNKNOWN : FASP_SUCCESS;
+}
+
+// stable counting transpose of a pattern (BlaSparseCSR.c:875-936): row j of the
+// transpose lists its sources in increasing i.
+void transpose_pattern(const Pattern& A, Pattern& AT)
+{
+    const int n = A.row, m = A.col, nnz = A.nnz;
+    AT.row = m; AT.col = n; AT.nnz = nnz;
+    AT.ia.alloc((size_t)m + 2);
+    AT.ja.alloc((size_t)nnz);
+    int* ia = AT.ia.data();
+    std::memset(ia, 0, ((size_t)m + 2) * sizeof(int));
+    for (int j = 0; j < nnz; ++j) ia[A.ja[j] + 2]++;
+    for (int i = 2; i <= m + 1; ++i) ia[i] += ia[i - 1];
+    for (int i = 0; i < n; ++i)
+        for (int p = A.ia[i]; p < A.ia[i + 1]; ++p) {
+            const int j = A.ja[p] + 1;
+            AT.ja[ia[j]++] = i;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// bucket lists by measure: one FIFO per measure value, append at the tail
+// (enter_list, PreAMGUtil.inl:264-271), the splitting takes the head of the highest
+// non-empty list (PreAMGCoarsenRS.c:654).  Arrays instead of heap nodes: O(1) updates.
+// ---------------------------------------------------------------------------
+struct Buckets {
+    std::vector<int> head, tail, next, prev;
+    int              cur_max = 0;
+    Buckets(int nvert, int cap) : head(cap + 1, -1), tail(cap + 1, -1), next(nvert), prev(nvert) {}
+    void enter(int m, int v)
+    {
+        if (m >= (int)head.size()) { head.resize(2 * m + 2, -1); tail.resize(2 * m + 2, -1); }
+        next[v] = -1;
+        prev[v] = tail[m];
+        if (tail[m] >= 0) next[tail[m]] = v; else head[m] = v;
+        tail[m] = v;
+        if (m > cur_max) cur_max = m;
+    }
+    void remove(int m, int v)
+    {
+        const int p = prev[v], n = next[v];
+        if (p >= 0) next[p] = n; else head[m] = n;
+        if (n >= 0) prev[n] = p; else tail[m] = p;
+    }
+    int top()
+    {
+        while (cur_max > 0 && head[cur_max] < 0) --cur_max;
+        return head[cur_max];
+    }
+};
+
+// C/F splitting, first pass + C1 second pass (PreAMGCoarsenRS.c:507-785, RS_C1 ON)
+int cfsplitting_cls(const Pattern& S, int* vec)
+{
+    const int row = S.row;
+    int       col = 0, num_left = 0;
+    Pattern   ST;
+    transpose_pattern(S, ST);
+
+    std::vector<int> lambda(row);
+    int              maxdeg = 0;
+    for (int i = 0; i < row; ++i) {
+        lambda[i] = ST.ia[i + 1] - ST.ia[i];
+        maxdeg    = std::max(maxdeg, lambda[i]);
+    }
+    for (int i = 0; i < row; ++i) {
+        if (S.ia[i + 1] == S.ia[i]) { vec[i] = ISPT; lambda[i] = 0; }
+        else { vec[i] = UNPT; ++num_left; }
+    }
+    Buckets B(row, 2 * maxdeg + 2);
+
+    for (int i = 0; i < row; ++i) {  // :614-648
+        if (vec[i] == ISPT) continue;
+        const int measure = lambda[i];
+        if (measure > 0) {
+            B.enter(measure, i);
+        } else {
+            if (measure < 0) std::printf("### WARNING: Negative lambda[%d]!\n", i);
+            vec[i] = FGPT;
+            --num_left;
+            for (int k = S.ia[i]; k < S.ia[i + 1]; ++k) {
+                const int j = S.ja[k];
+                if (vec[j] == ISPT) continue;
+                if (j < i) {
+                    if (lambda[j] > 0) B.remove(lambda[j], j);
+                    B.enter(++lambda[j], j);
+                } else {
+                    ++lambda[j];
+                }
+            }
+        }
+    }
+
+    while (num_left > 0) {  // :651-717
+        const int maxnode = B.top();
+        const int maxmeas = lambda[maxnode];
+        if (maxmeas == 0) std::printf("### WARNING: Head of the list has measure 0!\n");
+        vec[maxnode]    = CGPT;
+        lambda[maxnode] = 0;
+        --num_left;
+        B.remove(maxmeas, maxnode);
+        ++col;
+
+        for (int i = ST.ia[maxnode]; i < ST.ia[maxnode + 1]; ++i) {
+            const int j = ST.ja[i];
+            if (vec[j] != UNPT) continue;
+            vec[j] = FGPT;
+            B.remove(lambda[j], j);
+            --num_left;
+            for (int l = S.ia[j]; l < S.ia[j + 1]; ++l) {
+                const int k = S.ja[l];
+                if (vec[k] == UNPT) {
+                    B.remove(lambda[k], k);
+                    B.enter(++lambda[k], k);
+                }
+            }
+        }
+        for (int i = S.ia[maxnode]; i < S.ia[maxnode + 1]; ++i) {
+            const int j = S.ja[i];
+            if (vec[j] != UNPT) continue;
+            int measure = lambda[j];
+            B.remove(measure, j);
+            lambda[j] = --measure;
+            if (measure > 0) {
+                B.enter(measure, j);
+            } else {
+                vec[j] = FGPT;
+                --num_left;
+                for (int l = S.ia[j]; l < S.ia[j + 1]; ++l) {
+                    const int k = S.ja[l];
+                    if (vec[k] == UNPT) {
+                        B.remove(lambda[k], k);
+                        B.enter(++lambda[k], k);
+                    }
+                }
+            }
+        }
+    }
+
+    // C1 criterion, :719-763
+    std::vector<int>& graph_array = lambda;
+    std::fill(graph_array.begin(), graph_array.end(), -1);
+    int jkeep = 0;
+    for (int i = 0; i < row; ++i) {
+        if (vec[i] != FGPT) continue;
+        const int e = S.ia[i + 1];
+        for (int ji = S.ia[i]; ji < e; ++ji) {
+            const int j = S.ja[ji];
+            if (vec[j] == CGPT) graph_array[j] = i;
+        }
+        int cnt = 0;
+        for (int ji = S.ia[i]; ji < e; ++ji) {
+            const int j = S.ja[ji];
+            if (vec[j] != FGPT) continue;
+            bool set_empty = true;
+            for (int jj = S.ia[j]; jj < S.ia[j + 1]; ++jj)
+                if (graph_array[S.ja[jj]] == i) { set_empty = false; break; }
+            if (set_empty) {
+                if (cnt == 0) {
+                    vec[j] = CGPT;
+                    ++col;
+                    graph_array[j] = i;
+                    jkeep = j;
+                    cnt = 1;
+                } else {
+                    vec[i]     = CGPT;
+                    vec[jkeep] = FGPT;
+                    break;
+                }
+            }
+        }
+    }
+    return col;
+}
+
+// F-F couplings without a common C point (PreAMGCoarsenRS.c:1709-1781), with the
+// reference's "tentatively promote j, re-check i" roll-back (:1762-1769).
+int clean_ff_couplings(const Pattern& S, int* vec, int row, int col)
+{
+    std::vector<int> cindex(row, -1);
+    bool C_i_nonempty = false;
+    int  ci_tilde = -1, ci_tilde_mark = -1;
+    for (int i = 0; i < row; ++i) {
+        if (vec[i] != FGPT) continue;
+        for (int ji = S.ia[i]; ji < S.ia[i + 1]; ++ji) {
+            const int j = S.ja[ji];
+            cindex[j] = (vec[j] == CGPT) ? i : -1;
+        }
+        if (ci_tilde_mark != i) ci_tilde = -1;
+        for (int ji = S.ia[i]; ji < S.ia[i + 1]; ++ji) {
+            const int j = S.ja[ji];
+            if (vec[j] != FGPT) continue;
+            bool set_empty = true;
+            for (int jj = S.ia[j]; jj < S.ia[j + 1]; ++jj)
+                if (cindex[S.ja[jj]] == i) { set_empty = false; break; }
+            if (!set_empty) continue;
+            if (C_i_nonempty) {
+                vec[i] = CGPT;
+                ++col;
+                if (ci_tilde > -1) {
+                    vec[ci_tilde] = FGPT;
+                    --col;
+                    ci_tilde = -1;
+                }
+                C_i_nonempty = false;
+                break;
+            } else {
+                vec[j] = CGPT;
+                ++col;
+                ci_tilde      = j;
+                ci_tilde_mark = i;
+                C_i_nonempty  = true;
+                --i;  // re-check row i
+                break;
+            }
+        }
+    }
+    return col;
+}
+
+// ---------------------------------------------------------------------------
+// interpolation: pattern (PreAMGCoarsenRS.c:1891-1985), direct interpolation weights
+// (PreAMGInterp.c:411-487), coarse numbering (:491-517), truncation (:127-228)
+// ---------------------------------------------------------------------------
+void build_interp_dir(const HostCSR& A, const Pattern& S, const int* vec, const AMG_param& param,
+                      HostCSR& P)
+{
+    const int row = A.row;
+    const int *ia = A.ia.data(), *ja = A.ja.data();
+    const double* av = A.val.data();
+    const double eps_tr = param.truncation_threshold;
+
+    // pattern of the untruncated P, in fine-column indices
+    Buf<int> pia((size_t)row + 1);
+    pia[0] = 0;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        int c = 0;
+        if (vec[i] == FGPT) {
+            for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) c += (vec[S.ja[j]] == CGPT);
+        } else if (vec[i] == CGPT) {
+            c = 1;
+        }
+        pia[i + 1] = c;
+    }
+    for (int i = 0; i < row; ++i) pia[i + 1] += pia[i];
+    const int   pnnz = pia[row];
+    Buf<int>    pja((size_t)pnnz);
+    Buf<double> pval((size_t)pnnz);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        int o = pia[i];
+        if (vec[i] == FGPT) {
+            for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) {
+                const int k = S.ja[j];
+                if (vec[k] == CGPT) pja[o++] = k;
+            }
+        } else if (vec[i] == CGPT) {
+            pja[o++] = i;
+        }
+    }
+
+    // The reference keeps `aii` in a function-scope variable (PreAMGInterp.c:314): a row
+    // without a diagonal entry inherits the previous row's (possibly modified) value.
+    // Rows are independent only when every row has a diagonal; otherwise run serially.
+    bool all_diag = true;
+#pragma omp parallel for schedule(static) reduction(&& : all_diag)
+    for (int i = 0; i < row; ++i) {
+        bool f = false;
+        for (int k = ia[i]; k < ia[i + 1]; ++k)
+            if (ja[k] == i) { f = true; break; }
+        all_diag = all_diag && f;
+    }
+
+    auto weights_row = [&](int i, double& aii, int* mark) {
+        const int b = ia[i], e = ia[i + 1];
+        int idiag = b;
+        for (; idiag < e; ++idiag)
+            if (ja[idiag] == i) { aii = av[idiag]; break; }
+        if (vec[i] == FGPT) {
+            // mark[c] == i  <=>  c is a pattern (strong C) column of row i; the reference
+            // searches P's row linearly (:436-442) -- same predicate.
+            if (mark)
+                for (int k = pia[i]; k < pia[i + 1]; ++k) mark[pja[k]] = i;
+            double amN = 0.0, amP = 0.0, apN = 0.0, apP = 0.0;
+            int    num_pcouple = 0;
+            for (int j = b; j < e; ++j) {
+                if (j == idiag) continue;
+                bool is_strong = false;
+                if (mark) {
+                    is_strong = (mark[ja[j]] == i);
+                } else {
+                    for (int k = pia[i]; k < pia[i + 1]; ++k)
+                        if (pja[k] == ja[j]) { is_strong = true; break; }
+                }
+                if (av[j] > 0) {
+                    apN += av[j];
+                    if (is_strong) { apP += av[j]; ++num_pcouple; }
+                } else {
+                    amN += av[j];
+                    if (is_strong) amP += av[j];
+                }
+            }
+            amP = (amP < -SMALLREAL) ? amP : -SMALLREAL;
+            apP = (apP > SMALLREAL) ? apP : SMALLREAL;
+            const double alpha = amN / amP;
+            double       beta;
+            if (num_pcouple > 0) {
+                beta = apN / apP;
+            } else {
+                beta = 0.0;
+                aii += apN;
+            }
+            for (int j = pia[i]; j < pia[i + 1]; ++j) {
+                const int k = pja[j];
+                int       l = b;
+                for (; l < e; ++l)
+                    if (ja[l] == k) break;
+                if (av[l] > 0) pval[j] = -beta * av[l] / aii;
+                else pval[j] = -alpha * av[l] / aii;
+            }
+        } else if (vec[i] == CGPT) {
+            pval[pia[i]] = 1.0;
+        }
+    };
+
+    // marker arrays only pay off for long rows; short rows use the reference's linear search
+    const bool use_mark = (double)A.nnz / std::max(row, 1) > 16.0;
+    if (all_diag) {
+#pragma omp parallel
+        {
+            std::vector<int> mark;
+            if (use_mark) mark.assign(A.col, -1);
+#pragma omp for schedule(static)
+            for (int i = 0; i < row; ++i) {
+                double aii = 0.0;
+                weights_row(i, aii, use_mark ? mark.data() : nullptr);
+            }
+        }
+    } else {
+        std::vector<int> mark;
+        if (use_mark) mark.assign(A.col, -1);
+        double aii = 0.0;
+        for (int i = 0; i < row; ++i) weights_row(i, aii, use_mark ? mark.data() : nullptr);
+    }
+
+    // coarse numbering: C points in increasing fine index (:491-493)
+    std::vector<int> cindex(row, 0);
+    int              ncoarse = 0;
+    for (int i = 0; i < row; ++i)
+        if (vec[i] == CGPT) cindex[i] = ncoarse++;
+
+    // truncation (:127-228): two passes so rows can run in parallel; values per row are
+    // evaluated exactly as the reference's in-place sweep.
+    Buf<int> tia((size_t)row + 1);
+    tia[0] = 0;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        double Min_neg = 0, Max_pos = 0;
+        for (int j = pia[i]; j < pia[i + 1]; ++j) {
+            if (pval[j] > 0) Max_pos = std::max(Max_pos, pval[j]);
+            else Min_neg = std::min(Min_neg, pval[j]);
+        }
+        Max_pos *= eps_tr;
+        Min_neg *= eps_tr;
+        int c = 0;
+        for (int j = pia[i]; j < pia[i + 1]; ++j)
+            if (pval[j] >= Max_pos || pval[j] <= Min_neg) ++c;
+        tia[i + 1] = c;
+    }
+    for (int i = 0; i < row; ++i) tia[i + 1] += tia[i];
+    const int tnnz = tia[row];
+    P.row = row; P.col = ncoarse; P.nnz = tnnz;
+    P.ia = std::move(tia);
+    P.ja.alloc((size_t)tnnz);
+    P.val.alloc((size_t)tnnz);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        double Min_neg = 0, Max_pos = 0, Sum_neg = 0, Sum_pos = 0, TSum_neg = 0, TSum_pos = 0;
+        for (int j = pia[i]; j < pia[i + 1]; ++j) {
+            if (pval[j] > 0) {
+                Sum_pos += pval[j];
+                Max_pos = std::max(Max_pos, pval[j]);
+            } else {
+                Sum_neg += pval[j];
+                Min_neg = std::min(Min_neg, pval[j]);
+            }
+        }
+        Max_pos *= eps_tr;
+        Min_neg *= eps_tr;
+        for (int j = pia[i]; j < pia[i + 1]; ++j) {
+            if (pval[j] >= Max_pos) TSum_pos += pval[j];
+            else if (pval[j] <= Min_neg) TSum_neg += pval[j];
+        }
+        const double Fac_pos = (TSum_pos > SMALLREAL) ? Sum_pos / TSum_pos : 1.0;
+        const double Fac_neg = (TSum_neg < -SMALLREAL) ? Sum_neg / TSum_neg : 1.0;
+        int o = P.ia[i];
+        for (int j = pia[i]; j < pia[i + 1]; ++j) {
+            if (pval[j] >= Max_pos) {
+                P.ja[o] = cindex[pja[j]];
+                P.val[o++] = pval[j] * Fac_pos;
+            } else if (pval[j] <= Min_neg) {
+                P.ja[o] = cindex[pja[j]];
+                P.val[o++] = pval[j] * Fac_neg;
+            }
+        }
+    }
+}
+
+// stable counting transpose with values (BlaSparseCSR.c:952-1018)
+void transpose_csr(const HostCSR& A, HostCSR& AT)
+{
+    const int n = A.row, m = A.col, nnz = A.nnz;
+    AT.row = m; AT.col = n; AT.nnz = nnz;
+    Buf<int> cur((size_t)m + 2);
+    std::memset(cur.data(), 0, ((size_t)m + 2) * sizeof(int));
+    for (int j = 0; j < nnz; ++j) cur[A.ja[j] + 2]++;
+    for (int i = 2; i <= m + 1; ++i) cur[i] += cur[i - 1];
+    AT.ia.alloc((size_t)m + 1);
+    AT.ja.alloc((size_t)nnz);
+    AT.val.alloc((size_t)nnz);
+    for (int i = 0; i < n; ++i)
+        for (int p = A.ia[i]; p < A.ia[i + 1]; ++p) {
+            const int k = cur[A.ja[p] + 1]++;
+            AT.ja[k]  = i;
+            AT.val[k] = A.val[p];
+        }
+    // after the fill, cur[j+1] == end of row j == start of row j+1
+    AT.ia[0] = 0;
+    for (int j = 0; j < m; ++j) AT.ia[j + 1] = cur[j + 1];
+}
+
+// Galerkin product RAP (BlaSpmvCSR.c:1114-1142 symbolic, :1204-1244 numeric).  Every
+// coarse row starts with its diagonal slot (0.0, then accumulated); the other columns
+// are appended in discovery order of the loop R-row -> A-row -> P-row; products are
+// formed as (r*a)*p and accumulated with += in that order.  Rows are independent, so
+// they run in parallel with per-thread marker arrays (the reference's own OpenMP
+// branch does the same); the result is bit-identical to the serial sweep.
+void galerkin_rap(const HostCSR& R, const HostCSR& A, const HostCSR& P, HostCSR& C)
+{
+    const int nc = R.row, nf = A.row;
+    const int *Ri = R.ia.data(), *Rj = R.ja.data(), *Ai = A.ia.data(), *Aj = A.ja.data(),
+              *Pi = P.ia.data(), *Pj = P.ja.data();
+    const double *Rv = R.val.data(), *Av = A.val.data(), *Pv = P.val.data();
+    int nthreads = omp_get_max_threads();
+    if (nthreads > 32) nthreads = 32;  // marker memory: (nc + nf) ints per thread
+    if (nc < 2000) nthreads = 1;
+
+    Buf<int> cia((size_t)nc + 1);
+    cia[0] = 0;
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<int> pstamp(nc, -1), astamp(nf, -1);
+#pragma omp for schedule(dynamic, 256)
+        for (int ic = 0; ic < nc; ++ic) {
+            int cnt = 1;
+            pstamp[ic] = ic;
+            for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; ++j1) {
+                const int i1 = Rj[j1];
+                for (int j2 = Ai[i1]; j2 < Ai[i1 + 1]; ++j2) {
+                    const int i2 = Aj[j2];
+                    if (astamp[i2] != ic) {
+                        astamp[i2] = ic;
+                        for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) {
+                            const int i3 = Pj[j3];
+                            if (pstamp[i3] != ic) { pstamp[i3] = ic; ++cnt; }
+                        }
+                    }
+                }
+            }
+            cia[ic + 1] = cnt;
+        }
+    }
+    long long total = 0;
+    for (int ic = 0; ic < nc; ++ic) { total += cia[ic + 1]; }
+    if (total > 2147483647LL) throw std::bad_alloc();  // INT is 32-bit in the ABI
+    for (int ic = 0; ic < nc; ++ic) cia[ic + 1] += cia[ic];
+    const int cnnz = cia[nc];
+    C.row = nc; C.col = nc; C.nnz = cnnz;
+    C.ja.alloc((size_t)cnnz);
+    C.val.alloc((size_t)cnnz);
+    int*    Cj = C.ja.data();
+    double* Cv = C.val.data();
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<int> pstamp(nc, -1), ppos(nc, 0), astamp(nf, -1);
+#pragma omp for schedule(dynamic, 256)
+        for (int ic = 0; ic < nc; ++ic) {
+            int pos = cia[ic];
+            pstamp[ic] = ic;
+            ppos[ic]   = pos;
+            Cj[pos]    = ic;
+            Cv[pos]    = 0.0;
+            ++pos;
+            for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; ++j1) {
+                const double r_entry = Rv[j1];
+                const int    i1 = Rj[j1];
+                for (int j2 = Ai[i1]; j2 < Ai[i1 + 1]; ++j2) {
+                    const double ra = r_entry * Av[j2];
+                    const int    i2 = Aj[j2];
+                    if (astamp[i2] != ic) {
+                        astamp[i2] = ic;
+                        for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) {
+                            const double rap = ra * Pv[j3];
+                            const int    i3 = Pj[j3];
+                            if (pstamp[i3] != ic) {
+                                pstamp[i3] = ic;
+                                ppos[i3]   = pos;
+                                Cv[pos]    = rap;
+                                Cj[pos]    = i3;
+                                ++pos;
+                            } else {
+                                Cv[ppos[i3]] += rap;
+                            }
+                        }
+                    } else {
+                        for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) Cv[ppos[Pj[j3]]] += ra * Pv[j3];
+                    }
+                }
+            }
+        }
+    }
+    C.ia = std::move(cia);
+}
+
+void copy_csr(const dCSRmat* A, HostCSR& B)
+{
+    B.row = A->row; B.col = A->col; B.nnz = A->nnz;
+    B.ia.alloc((size_t)A->row + 1);
+    B.ja.alloc((size_t)A->nnz);
+    B.val.alloc((size_t)A->nnz);
+    std::memcpy(B.ia.data(), A->IA, ((size_t)A->row + 1) * sizeof(int));
+    std::memcpy(B.ja.data(), A->JA, (size_t)A->nnz * sizeof(int));
+    std::memcpy(B.val.data(), A->val, (size_t)A->nnz * sizeof(double));
+}
+
+// AuxMessage.c:84-123
+void print_complexity(const HostHierarchy& H, int prtlvl)
+{
+    if (prtlvl < PRINT_SOME) return;
+    double gridcom = 0.0, opcom = 0.0;
+    std::printf("-----------------------------------------------------------\n");
+    std::printf("  Level   Num of rows   Num of nonzeros   Avg. NNZ / row   \n");
+    std::printf("-----------------------------------------------------------\n");
+    for (size_t l = 0; l < H.L.size(); ++l) {
+        const HostCSR& A = H.L[l].A;
+        std::printf("%5d %13d %17d %14.2f\n", (int)l, A.row, A.nnz, (double)A.nnz / A.row);
+        gridcom += A.row;
+        opcom += A.nnz;
+    }
+    std::printf("-----------------------------------------------------------\n");
+    gridcom /= H.L[0].A.row;
+    opcom /= H.L[0].A.nnz;
+    std::printf("  Grid complexity = %.3f  |", gridcom);
+    std::printf("  Operator complexity = %.3f\n", opcom);
+    std::printf("-----------------------------------------------------------\n");
+}
+
+}  // namespace
+
+// Parameter combinations with a device path.  Anything else is refused loudly.
+int check_supported(const ITS_param* it, const AMG_param* amg)
+{
+    if (amg) {
+        if (amg->AMG_type != CLASSIC_AMG) {
+            std::printf("### ERROR: fasp_hip: AMG_type %d has no device path yet (classical RS only)\n",
+                        amg->AMG_type);
+            return ERROR_INPUT_PAR;
+        }
+        if (amg->coarsening_type != COARSE_RS) {
+            std::printf("### ERROR: fasp_hip: coarsening_type %d not supported (COARSE_RS only)\n",
+                        amg->coarsening_type);
+            return ERROR_AMG_COARSE_TYPE;
+        }
+        if (amg->interpolation_type != INTERP_DIR) {
+            std::printf("### ERROR: fasp_hip: interpolation_type %d not supported (INTERP_DIR only)\n",
+                        amg->interpolation_type);
+            return ERROR_AMG_INTERP_TYPE;
+        }
+        if (amg->ILU_levels > 0 || amg->SWZ_levels > 0) {
+            std::printf("### ERROR: fasp_hip: ILU / Schwarz smoothers have no device path\n");
+            return ERROR_INPUT_PAR;
+        }
+        switch (amg->cycle_type) {
+            case V_CYCLE: case W_CYCLE: case VW_CYCLE: case WV_CYCLE: break;
+            default:
+                std::printf("### ERROR: fasp_hip: cycle_type %d has no device path (V/W/VW/WV only)\n",
+                            amg->cycle_type);
+                return ERROR_INPUT_PAR;
+        }
+        switch (amg->smoother) {
+            case SMOOTHER_JACOBI: case SMOOTHER_L1DIAG: break;
+            default:
+                std::printf("### ERROR: fasp_hip: smoother %d has no device path yet "
+                            "(SMOOTHER_JACOBI, SMOOTHER_L1DIAG)\n", amg->smoother);
+                return ERROR_AMG_SMOOTH_TYPE;
+        }
+        if (amg->coarse_solver != SOLVER_DEFAULT) {
+            std::printf("### ERROR: fasp_hip: direct coarse solvers are not available\n");
+            return ERROR_INPUT_PAR;
+        }
+        if (amg->coarse_scaling != 0) {
+            std::printf("### ERROR: fasp_hip: coarse_scaling has no device path yet\n");
+            return ERROR_INPUT_PAR;
+        }
+        if (amg->max_levels < 1 || amg->max_levels > MAX_AMG_LVL) return ERROR_INPUT_PAR;
+    }
+    if (it) {
+        if (it->itsolver_type != SOLVER_CG) {
+            std::printf("### ERROR: Unknown iterative solver type %d! [%s]\n", it->itsolver_type,
+                        "fasp_solver_dcsr_itsolver");
+            return ERROR_SOLVER_TYPE;
+        }
+        if (it->precond_type == PREC_FMG) {
+            std::printf("### ERROR: fasp_hip: full-multigrid preconditioner has no device path\n");
+            return ERROR_SOLVER_PRECTYPE;
+        }
+        if (it->stop_type < STOP_REL_RES || it->stop_type > STOP_MOD_REL_RES) return ERROR_INPUT_PAR;
+    }
+    return FASP_SUCCESS;
+}
+
+int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
+{
+    const int    prtlvl   = param->print_level;
+    const int    min_cdof = std::max(param->coarse_dof, MIN_CDOF);
+    const double t0       = wall_seconds();
+    int          status   = FASP_SUCCESS;
+    int          max_lvls = param->max_levels;
+
+    if (!A || !A->IA || !A->JA || !A->val || A->row <= 0 || A->row != A->col) return ERROR_DATA_STRUCTURE;
+
+    H.L.clear();
+    H.L.reserve(MAX_AMG_LVL + 1);
+    H.L.emplace_back();
+    copy_csr(A, H.L[0].A);  // SolCSR.c:503-504: the callee works on a deep copy
+
+    if (prtlvl > PRINT_NONE) std::printf("\nSetting up Classical AMG ...\n");
+    param->tentative_smooth = 1.0;  // PreAMGSetupRS.c:83
+
+    std::vector<int> vertices(A->row);
+    int lvl = 0;
+    try {
+        while (H.L[lvl].A.row > min_cdof && lvl < max_lvls - 1) {
+            HostLevel& Lv = H.L[lvl];
+            Pattern    S;
+            status = strength_compressed(Lv.A, *param, S);
+            int col = -1;
+            if (status >= 0) col = cfsplitting_cls(S, vertices.data());
+            if (status < 0 || col <= 0) {  // Check 1, PreAMGSetupRS.c:162-173
+                if (prtlvl > PRINT_MIN) {
+                    std::printf("### WARNING: Could not find any C-variables!\n");
+                    std::printf("### WARNING: Stop coarsening on level=%d!\n", lvl);
+                }
+                status = FASP_SUCCESS;
+                break;
+            }
+            col = clean_ff_couplings(S, vertices.data(), Lv.A.row, col);
+            if (col < MIN_CDOF) break;  // Check 2, :176-181
+            if (Lv.A.row > col * 10.0) {  // Check 3, :184-195
+                if (prtlvl > PRINT_MIN) {
+                    std::printf("### WARNING: Coarsening might be too aggressive!\n");
+                    std::printf("### WARNING: Fine level = %d, coarse level = %d. Discard!\n",
+                                Lv.A.row, col);
+                }
+                break;
+            }
+            Lv.cfmark.alloc((size_t)Lv.A.row);  // :201-206
+            std::memcpy(Lv.cfmark.data(), vertices.data(), (size_t)Lv.A.row * sizeof(int));
+
+            build_interp_dir(Lv.A, S, vertices.data(), *param, Lv.P);  // :209
+            transpose_csr(Lv.P, Lv.R);                                 // :212
+            H.L.emplace_back();
+            galerkin_rap(H.L[lvl].R, H.L[lvl].A, H.L[lvl].P, H.L[lvl + 1].A);  // :213
+            H.L[lvl].has_coarse = true;
+            ++lvl;
+            const HostCSR& Ac = H.L[lvl].A;
+            if (Ac.nnz / Ac.row > Ac.col * 0.2) {  // Check 4, :261 (integer division)
+                if (prtlvl > PRINT_MIN) {
+                    std::printf("### WARNING: Coarse matrix is too dense!\n");
+                    std::printf("### WARNING: m = n = %d, nnz = %d!\n", Ac.col, Ac.nnz);
+                }
+                break;
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        std::printf("### ERROR: fasp_hip: host allocation failed during AMG setup\n");
+        return ERROR_ALLOC_MEM;
+    }
+    H.setup_seconds = wall_seconds() - t0;
+    if (prtlvl > PRINT_NONE) {
+        print_complexity(H, prtlvl);
+        std::printf("Classical AMG setup costs %.4f seconds.\n", H.setup_seconds);
+    }
+    return status;
+}
+
+}  // namespace fasp
+
+// ---------------------------------------------------------------------------
+// public host-only entry points
+// ---------------------------------------------------------------------------
+extern "C" {
+
+// AuxParam.c:431-489
+void fasp_param_amg_init(AMG_param* p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->AMG_type = CLASSIC_AMG;
+    p->print_level = PRINT_NONE;
+    p->maxit = 1;
+    p->tol = 1e-6;
+    p->max_levels = 20;
+    p->coarse_dof = 500;
+    p->cycle_type = V_CYCLE;
+    p->smoother = SMOOTHER_GS;
+    p->smooth_order = CF_ORDER;
+    p->presmooth_iter = 1;
+    p->postsmooth_iter = 1;
+    p->coarse_solver = SOLVER_DEFAULT;
+    p->relaxation = 1.0;
+    p->polynomial_degree = 3;
+    p->coarse_scaling = 0;
+    p->amli_degree = 2;
+    p->amli_coef = nullptr;
+    p->nl_amli_krylov_type = 7;  // SOLVER_GCG
+    p->coarsening_type = COARSE_RS;
+    p->interpolation_type = INTERP_DIR;
+    p->max_row_sum = 0.9;
+    p->strong_threshold = 0.3;
+    p->truncation_threshold = 0.2;
+    p->aggressive_level = 0;
+    p->aggressive_path = 1;
+    p->aggregation_type = PAIRWISE;
+    p->quality_bound = 10.0;
+    p->pair_number = 2;
+    p->strong_coupled = 0.08;
+    p->max_aggregation = 20;
+    p->tentative_smooth = 0.67;
+    p->smooth_filter = 1;
+    p->smooth_restriction = 1;
+    p->aggregation_norm_type = -1;
+    p->ILU_type = FASP_ILUk;
+    p->ILU_levels = 0;
+    p->ILU_lfil = 0;
+    p->ILU_droptol = 0.001;
+    p->ILU_relax = 0;
+    p->SWZ_levels = 0;
+    p->SWZ_mmsize = 200;
+    p->SWZ_maxlvl = 3;
+    p->SWZ_type = 1;
+    p->SWZ_blksolver = SOLVER_DEFAULT;
+    p->theta = -1.0;
+}
+
+// AuxParam.c:572-583
+void fasp_param_solver_init(ITS_param* p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->print_level = PRINT_NONE;
+    p->itsolver_type = SOLVER_CG;
+    p->decoup_type = 1;
+    p->precond_type = PREC_AMG;
+    p->stop_type = STOP_REL_RES;
+    p->maxit = 500;
+    p->restart = 25;
+    p->tol = 1e-6;
+    p->abstol = 1e-18;
+}
+
+// Synthetic input P7: test/src/FdmPoisson.c:439 (7-point band system on the unit cube,
+// couplings across the boundary zeroed) + :731 (band -> CSR: diagonal first, then the
+// offsets -1,+1,-nx,+nx,-nx*ny,+nx*ny; exact zeros deleted, :930).
+int fasp_hip_poisson7pt(int nx, int ny, int nz, dCSRmat* A, dvector* b, dvector* u)
+{
+    const double    PI = 3.1415926535897932;  // test/include/poisson_fdm.h:16
+    const long long ngrid = (long long)nx * ny * nz;
+    if (nx <= 0 || ny <= 0 || nz <= 0 || 7 * ngrid > 2147483647LL) return ERROR_INPUT_PAR;
+    const int    n = (int)ngrid, nplane = nx * ny;
+    const double hx = 1.0 / (double)(nx + 1), hy = 1.0 / (double)(ny + 1), hz = 1.0 / (double)(nz + 1);
+    const double hx2 = hx * hx, hy2 = hy * hy, hz2 = hz * hz;
+    const double fx = 1.0 / hx2, fy = 1.0 / hy2, fz = 1.0 / hz2;
+    const double dd = 2.0 * (fx + fy + fz);
+    const double constant = 3.0 * PI * PI;
+
+    auto rownnz = [&](int i, int j, int k) {
+        return 1 + (i > 0) + (i < nx - 1) + (j > 0) + (j < ny - 1) + (k > 0) + (k < nz - 1);
+    };
+    int* ia = (int*)std::malloc(((size_t)n + 1) * sizeof(int));
+    if (!ia) return ERROR_ALLOC_MEM;
+    // row offsets: closed form per (j,k) line keeps this O(n) and parallel
+    long long nnz = 0;
+    {
+        int row = 0;
+        for (int k = 0; k < nz; ++k)
+            for (int j = 0; j < ny; ++j)
+                for (int i = 0; i < nx; ++i) { ia[row++] = (int)nnz; nnz += rownnz(i, j, k); }
+        ia[n] = (int)nnz;
+    }
+    int*    ja = (int*)std::malloc((size_t)nnz * sizeof(int));
+    double* a  = (double*)std::malloc((size_t)nnz * sizeof(double));
+    double* f  = (double*)std::malloc((size_t)n * sizeof(double));
+    double* ue = (double*)std::malloc((size_t)n * sizeof(double));
+    if (!ja || !a || !f || !ue) { std::free(ia); std::free(ja); std::free(a); std::free(f); std::free(ue); return ERROR_ALLOC_MEM; }
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < nz; ++k) {
+        const double z = hz * (k + 1), ss = std::sin(PI * z);
+        for (int j = 0; j < ny; ++j) {
+            const double y = hy * (j + 1), s = ss * std::sin(PI * y);
+            for (int i = 0; i < nx; ++i) {
+                const int row = (k * ny + j) * nx + i;
+                int       c = ia[row];
+                ja[c] = row; a[c++] = dd;
+                if (i > 0)      { ja[c] = row - 1;      a[c++] = -fx; }
+                if (i < nx - 1) { ja[c] = row + 1;      a[c++] = -fx; }
+                if (j > 0)      { ja[c] = row - nx;     a[c++] = -fy; }
+                if (j < ny - 1) { ja[c] = row + nx;     a[c++] = -fy; }
+                if (k > 0)      { ja[c] = row - nplane; a[c++] = -fz; }
+                if (k < nz - 1) { ja[c] = row + nplane; a[c++] = -fz; }
+                const double x = hx * (i + 1);
+                const double tmp = s * std::sin(PI * x);
+                ue[row] = tmp * 1.0;
+                f[row]  = tmp * 0 + constant * ue[row];
+            }
+        }
+    }
+    A->row = A->col = n; A->nnz = (int)nnz; A->IA = ia; A->JA = ja; A->val = a;
+    b->row = n; b->val = f;
+    u->row = n; u->val = ue;
+    return FASP_SUCCESS;
+}
+
+void fasp_hip_free_system(dCSRmat* A, dvector* b, dvector* u)
+{
+    if (A) { std::free(A->IA); std::free(A->JA); std::free(A->val); A->IA = A->JA = nullptr; A->val = nullptr; }
+    if (b) { std::free(b->val); b->val = nullptr; }
+    if (u) { std::free(u->val); u->val = nullptr; }
+}
+
+const char* fasp_hip_version(void) { return "fasp_hip 0.1 (gfx950, HIP + RCCL)"; }
+
+}  // extern "C"

@@ -1,0 +1,326 @@
+// kernels.hip.h -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the
+// AMG-preconditioned Krylov hot path.  Everything here is HBM-bandwidth bound
+// (<= 2 flop per 12 bytes): no MFMA, the levers are coalesced row-block loads of
+// IA/JA/val, sub-wavefront shuffle reductions, LDS-staged block reductions,
+// non-temporal streaming of the matrix so the x vector stays in the XCD's L2, and an
+// XCD-aware blockIdx -> row-tile mapping (blocks b and b+8 share an XCD).
+//
+// Reference semantics (file:line relative to the reference tree):
+//   y = A x                 fasp_blas_dcsr_mxv      base/src/BlaSpmvCSR.c:242
+//   y += alpha A x          fasp_blas_dcsr_aAxpy    base/src/BlaSpmvCSR.c:494
+//   weighted Jacobi sweep   fasp_smoother_dcsr_jacobi  base/src/ItrSmootherCSR.c:98
+//   L1-diagonal sweep       fasp_smoother_dcsr_L1diag  base/src/ItrSmootherCSR.c:1509
+//   dot / norm2 / norminf   base/src/BlaArray.c:771 / :691 / :719
+//   axpy / axpby            base/src/BlaArray.c:90 / :620
+//
+// Compiled with -ffp-contract=off: the reference (gcc -O3, x86-64) has no FMA, so
+// every elementwise expression below rounds exactly like the reference's.  Row sums
+// and reductions are evaluated in a fixed tree order (deterministic run to run) that
+// differs from the reference's left-to-right order by O(1e-16) relative.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace fasp {
+
+constexpr int BLOCK   = 256;   // 4 wavefronts
+constexpr int MAXGRID = 2048;  // 256 CUs x 8 blocks: persistent grid, grid-stride inside
+
+enum RowOp : int {
+    OP_MXV = 0,     // y = t
+    OP_RESID,       // y = b - t            (w = b; w -= A x  of PreMGCycle.c:136-137, KryPcg.c:125-126)
+    OP_ADD,         // y += t               (aAxpy, alpha == 1: prolongation)
+    OP_SUB,         // y -= t               (aAxpy, alpha == -1)
+    OP_AXPY,        // y += t * alpha       (aAxpy, general alpha)
+    OP_JACOBI,      // y = (1-w) x_i + w (b_i - sum_{j!=i}) / d_i
+    OP_L1DIAG,      // y = x_i + (b_i - t) / l1_i
+    OP_MXV_DOT      // y = t and partial sums of t_i * dotv_i   (t = A p fused with (t,p))
+};
+
+struct CsrArgs {
+    int           nrow;
+    const int*    ia;
+    const int*    ja;
+    const double* val;
+    const double* x;     // gathered vector
+    double*       y;     // output
+    const double* b;     // rhs (RESID / JACOBI / L1DIAG)
+    const double* diag;  // a_ii (JACOBI) or sum_j |a_ij| (L1DIAG)
+    const double* dotv;  // OP_MXV_DOT: vector dotted with the result
+    double*       partials;  // OP_MXV_DOT: one partial per block
+    double        alpha;     // OP_AXPY
+    double        omega;     // OP_JACOBI
+    int           ntiles;
+    int           tiles_per_xcd;
+};
+
+template <int W>
+__device__ __forceinline__ double subwave_sum(double v)
+{
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) v += __shfl_down(v, off, W);
+    return v;
+}
+
+// Deterministic block reduction: wave shuffle tree, then the 4 wave results are added
+// in wave order by thread 0.
+__device__ __forceinline__ double block_sum(double v, double* lds /* >= 4 doubles */)
+{
+    v = subwave_sum<64>(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double* lds)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// CSR row kernel: L lanes cooperate on one row (L = 2..64, chosen per matrix from its
+// nnz/row), a 256-thread block covers 256/L consecutive rows per tile, so a wavefront's
+// val/JA loads cover one contiguous span of the CSR arrays.  The grid is persistent
+// (<= 2048 blocks); block b works on tiles of XCD slab (b & 7) so that each XCD
+// streams one contiguous eighth of the matrix and re-uses its part of x in its own L2.
+// val/JA are read exactly once per launch -> non-temporal loads.
+// ---------------------------------------------------------------------------
+template <int L, int OP>
+__global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
+{
+    constexpr int RPB = BLOCK / L;
+    const int sl   = threadIdx.x & (L - 1);
+    const int rloc = threadIdx.x / L;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, g8 = gridDim.x >> 3;
+    const int t0 = xcd * a.tiles_per_xcd;
+    const int t1 = min(t0 + a.tiles_per_xcd, a.ntiles);
+    double acc = 0.0;
+
+    for (int t = t0 + j; t < t1; t += g8) {
+        const int r = t * RPB + rloc;
+        if (r < a.nrow) {
+            const int kb = a.ia[r], ke = a.ia[r + 1];
+            double s = 0.0;
+            if (OP == OP_JACOBI) {
+                for (int k = kb + sl; k < ke; k += L) {
+                    const int    c = __builtin_nontemporal_load(a.ja + k);
+                    const double v = __builtin_nontemporal_load(a.val + k);
+                    if (c != r) s += v * a.x[c];
+                }
+            } else {
+                for (int k = kb + sl; k < ke; k += L) {
+                    const int    c = __builtin_nontemporal_load(a.ja + k);
+                    const double v = __builtin_nontemporal_load(a.val + k);
+                    s += v * a.x[c];
+                }
+            }
+            s = subwave_sum<L>(s);
+            if (sl == 0) {
+                if (OP == OP_MXV) a.y[r] = s;
+                else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
+                else if (OP == OP_ADD) a.y[r] += s;
+                else if (OP == OP_SUB) a.y[r] -= s;
+                else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
+                else if (OP == OP_JACOBI) {
+                    const double d = a.diag[r], xi = a.x[r];
+                    const double tt = a.b[r] - s;
+                    a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * tt / d : xi;
+                } else if (OP == OP_L1DIAG) {
+                    const double d = a.diag[r], xi = a.x[r];
+                    const double tt = a.b[r] - s;
+                    a.y[r] = (fabs(d) > 1e-20) ? xi + tt / d : xi;
+                } else if (OP == OP_MXV_DOT) {
+                    a.y[r] = s;
+                    acc += s * a.dotv[r];
+                }
+            }
+        }
+    }
+    if (OP == OP_MXV_DOT) {
+        __shared__ double lds[4];
+        const double tot = block_sum(acc, lds);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BLAS-1.  n is a double count; vectors come from hipMalloc (256-B aligned) so the
+// double2 path is always aligned; the odd tail element is handled by thread 0 of the
+// last block.  Partials layout: partials[q * gridDim.x + blockIdx.x].
+// ---------------------------------------------------------------------------
+struct Vec2 { double x, y; };
+
+// y += a*x   (a == +-1 round identically to the reference's y += x / y -= x branches)
+__global__ __launch_bounds__(BLOCK) void k_axpy(int n, double a, const double* __restrict__ x,
+                                                 double* __restrict__ y)
+{
+    const int n2 = n >> 1;
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    double2*       y2 = reinterpret_cast<double2*>(y);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n2; i += gridDim.x * BLOCK) {
+        double2 xv = x2[i], yv = y2[i];
+        yv.x += a * xv.x;
+        yv.y += a * xv.y;
+        y2[i] = yv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] += a * x[n - 1];
+}
+
+// y = a*x + b*y   (BlaArray.c:644)
+__global__ __launch_bounds__(BLOCK) void k_axpby(int n, double a, const double* __restrict__ x,
+                                                  double b, double* __restrict__ y)
+{
+    const int n2 = n >> 1;
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    double2*       y2 = reinterpret_cast<double2*>(y);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n2; i += gridDim.x * BLOCK) {
+        double2 xv = x2[i], yv = y2[i];
+        yv.x = a * xv.x + b * yv.x;
+        yv.y = a * xv.y + b * yv.y;
+        y2[i] = yv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = a * x[n - 1] + b * y[n - 1];
+}
+
+// first Jacobi sweep from a zero initial guess: (1-w)*0 + w*b_i/d_i  ==  (w*b_i)/d_i exactly
+// (ItrSmootherCSR.c:148-170 with u == 0: t_i = b_i, no matrix pass needed)
+__global__ __launch_bounds__(BLOCK) void k_jacobi_zero(int n, double w, const double* __restrict__ b,
+                                                        const double* __restrict__ d,
+                                                        double* __restrict__ x)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double di = d[i];
+        x[i] = (fabs(di) > 1e-20) ? (1 - w) * 0.0 + w * b[i] / di : 0.0;
+    }
+}
+// first L1-diag sweep from zero: x_i = 0 + b_i / l1_i
+__global__ __launch_bounds__(BLOCK) void k_l1_zero(int n, const double* __restrict__ b,
+                                                    const double* __restrict__ d,
+                                                    double* __restrict__ x)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double di = d[i];
+        x[i] = (fabs(di) > 1e-20) ? 0.0 + b[i] / di : 0.0;
+    }
+}
+
+// partial sums of x_i*y_i
+__global__ __launch_bounds__(BLOCK) void k_dot(int n, const double* __restrict__ x,
+                                                const double* __restrict__ y,
+                                                double* __restrict__ partials)
+{
+    __shared__ double lds[4];
+    double acc = 0.0;
+    const int n2 = n >> 1;
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n2; i += gridDim.x * BLOCK) {
+        const double2 xv = x2[i], yv = y2[i];
+        acc += xv.x * yv.x;
+        acc += xv.y * yv.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += x[n - 1] * y[n - 1];
+    const double tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// Krylov update fused with the norms the control flow needs (KryPcg.c:180-189,
+// KrySPcg.c:147-199):  alpha = temp1 / red[slot_tp];  u += alpha p;  r -= alpha t;
+// partial sums q0 = r.r, q1 = u.u, q2 = p.p, q3 = max|u| (max), q4 = #NaN in u.
+// If |(t,p)| <= 1e-40 (CG breakdown) nothing is updated; the host sees (t,p) itself.
+__global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const double* __restrict__ red_tp,
+                                                      const double* __restrict__ p,
+                                                      const double* __restrict__ t,
+                                                      double* __restrict__ u, double* __restrict__ r,
+                                                      double* __restrict__ partials, int full_norms)
+{
+    __shared__ double lds[4];
+    const double temp2 = *red_tp;
+    const bool   ok = fabs(temp2) > 1e-40;
+    const double alpha = ok ? temp1 / temp2 : 0.0;
+    double rr = 0.0, uu = 0.0, pp = 0.0, um = 0.0, nn = 0.0;
+    if (ok) {
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+            const double pi = p[i];
+            const double ui = u[i] + alpha * pi;
+            const double ri = r[i] + (-alpha) * t[i];
+            u[i] = ui;
+            r[i] = ri;
+            rr += ri * ri;
+            if (full_norms) {
+                uu += ui * ui;
+                pp += pi * pi;
+                um = fmax(um, fabs(ui));
+                nn += (ui != ui) ? 1.0 : 0.0;
+            }
+        }
+    }
+    const int G = gridDim.x;
+    double v = block_sum(rr, lds);
+    if (threadIdx.x == 0) partials[0 * G + blockIdx.x] = v;
+    if (full_norms) {
+        v = block_sum(uu, lds);
+        if (threadIdx.x == 0) partials[1 * G + blockIdx.x] = v;
+        v = block_sum(pp, lds);
+        if (threadIdx.x == 0) partials[2 * G + blockIdx.x] = v;
+        v = block_max(um, lds);
+        if (threadIdx.x == 0) partials[3 * G + blockIdx.x] = v;
+        v = block_sum(nn, lds);
+        if (threadIdx.x == 0) partials[4 * G + blockIdx.x] = v;
+    }
+}
+
+// norms of one vector: q0 = x.x, q1 = max|x|
+__global__ __launch_bounds__(BLOCK) void k_norms(int n, const double* __restrict__ x,
+                                                  double* __restrict__ partials)
+{
+    __shared__ double lds[4];
+    double ss = 0.0, mm = 0.0;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double v = x[i];
+        ss += v * v;
+        mm = fmax(mm, fabs(v));
+    }
+    const int G = gridDim.x;
+    double v = block_sum(ss, lds);
+    if (threadIdx.x == 0) partials[0 * G + blockIdx.x] = v;
+    v = block_max(mm, lds);
+    if (threadIdx.x == 0) partials[1 * G + blockIdx.x] = v;
+}
+
+// Final stage of every reduction: ONE block sums G partials per quantity in a fixed
+// order (thread i takes i, i+256, ...; then the block tree) and writes out[q].
+// Quantities with bit q set in maxmask are max-reduced instead of summed.
+__global__ __launch_bounds__(BLOCK) void k_finalize(const double* __restrict__ partials, int G,
+                                                     int nq, unsigned maxmask,
+                                                     double* __restrict__ out)
+{
+    __shared__ double lds[4];
+    for (int q = 0; q < nq; ++q) {
+        const double* p = partials + (size_t)q * G;
+        if ((maxmask >> q) & 1u) {
+            double m = 0.0;
+            for (int i = threadIdx.x; i < G; i += BLOCK) m = fmax(m, p[i]);
+            m = block_max(m, lds);
+            if (threadIdx.x == 0) out[q] = m;
+        } else {
+            double s = 0.0;
+            for (int i = threadIdx.x; i < G; i += BLOCK) s += p[i];
+            s = block_sum(s, lds);
+            if (threadIdx.x == 0) out[q] = s;
+        }
+    }
+}
+
+}  // namespace fasp

@@ -1,0 +1,1145 @@
+// solver.hip -- device-resident AMG hierarchy, multigrid cycle, coarse-level safe CG,
+// preconditioned CG driver and the C-ABI of libfasp_hip.so.
+//
+// Boundary (include/fasp_hip.h): fasp_solver_dcsr_krylov_amg() keeps the reference's
+// signature (base/src/SolCSR.c:476).  Inside it the host builds the hierarchy
+// (host_setup.cpp), uploads it once, and the whole Krylov loop runs on the GPU; only
+// reduction scalars cross back, through a pinned buffer.
+//
+// Reference control flow restated here (paths relative to the reference tree):
+//   fasp_solver_dcsr_pcg     base/src/KryPcg.c:96-362   (incl. stagnation / false-convergence)
+//   fasp_precond_amg         base/src/PreCSR.c:416-435  (tol NOT forwarded: coarse tol 1e-10)
+//   fasp_solver_mgcycle      base/src/PreMGCycle.c:48-274
+//   fasp_coarse_itsolver     base/src/PreMGUtil.inl:37-58
+//   fasp_solver_dcsr_spcg    base/src/KrySPcg.c:60-367  (pc == NULL)
+//
+// There is NO CPU fallback: without a usable gfx950 device every entry point that
+// computes returns ERROR_MISC after printing why.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "fasp_comm.h"
+#include "fasp_internal.h"
+#include "kernels.hip.h"
+
+namespace fasp {
+
+#define HIPCK(expr)                                                                        \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            std::fprintf(stderr, "### ERROR: fasp_hip: %s failed: %s [%s:%d]\n", #expr,    \
+                         hipGetErrorString(e_), __FILE__, __LINE__);                       \
+            return ERROR_MISC;                                                             \
+        }                                                                                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// device context (one per process: one process per GPU)
+// ---------------------------------------------------------------------------
+struct Ctx {
+    bool        ready  = false;
+    int         device = -1;
+    hipStream_t stream = nullptr;
+    double*     d_partials = nullptr;  // 8 quantities x MAXGRID
+    double*     d_red      = nullptr;  // reduced scalars (device)
+    double*     h_red      = nullptr;  // pinned host mirror
+    int         num_cu     = 256;
+};
+static Ctx g_ctx;
+static int g_requested_device = -1;
+
+constexpr int RED_SLOTS = 16;
+
+static int ctx_init()
+{
+    if (g_ctx.ready) return FASP_SUCCESS;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        std::fprintf(stderr, "### ERROR: fasp_hip: no HIP device available (%s). This library has "
+                             "no CPU fallback.\n", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return ERROR_MISC;
+    }
+    int dev = g_requested_device >= 0 ? g_requested_device : 0;
+    if (const char* lr = std::getenv("FASP_HIP_DEVICE")) dev = std::atoi(lr);
+    if (dev >= ndev) dev = dev % ndev;
+    HIPCK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCK(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        std::fprintf(stderr, "### WARNING: fasp_hip: device %d is %s; kernels are built for gfx950\n",
+                     dev, prop.gcnArchName);
+    g_ctx.num_cu = prop.multiProcessorCount;
+    g_ctx.device = dev;
+    HIPCK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    HIPCK(hipMalloc(&g_ctx.d_partials, sizeof(double) * 8 * MAXGRID));
+    HIPCK(hipMalloc(&g_ctx.d_red, sizeof(double) * RED_SLOTS));
+    HIPCK(hipHostMalloc(&g_ctx.h_red, sizeof(double) * RED_SLOTS, hipHostMallocDefault));
+    g_ctx.ready = true;
+    return FASP_SUCCESS;
+}
+
+static inline int vec_grid(int n)
+{
+    long long g = ((long long)n + BLOCK - 1) / BLOCK;
+    if (g > MAXGRID) g = MAXGRID;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// device matrices
+// ---------------------------------------------------------------------------
+struct DevCSR {
+    int     row = 0, col = 0, nnz = 0;
+    int*    ia  = nullptr;
+    int*    ja  = nullptr;
+    double* val = nullptr;
+    int     lanes = 8;  // lanes cooperating on one row
+    void    release()
+    {
+        if (ia) (void)hipFree(ia);
+        if (ja) (void)hipFree(ja);
+        if (val) (void)hipFree(val);
+        ia = ja = nullptr; val = nullptr;
+    }
+};
+
+static int pick_lanes(const DevCSR& M)
+{
+    const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
+    int L = 2;
+    while (L < 64 && L < avg) L <<= 1;  // smallest power of two >= avg nnz/row
+    if (const char* e = std::getenv("FASP_HIP_LANES")) {
+        const int v = std::atoi(e);
+        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L = v;
+    }
+    return L;
+}
+
+static int upload_csr(const HostCSR& H, DevCSR& D)
+{
+    D.row = H.row; D.col = H.col; D.nnz = H.nnz;
+    HIPCK(hipMalloc(&D.ia, sizeof(int) * ((size_t)H.row + 1)));
+    HIPCK(hipMalloc(&D.ja, sizeof(int) * std::max<size_t>(H.nnz, 1)));
+    HIPCK(hipMalloc(&D.val, sizeof(double) * std::max<size_t>(H.nnz, 1)));
+    HIPCK(hipMemcpyAsync(D.ia, H.ia.data(), sizeof(int) * ((size_t)H.row + 1), hipMemcpyHostToDevice, g_ctx.stream));
+    HIPCK(hipMemcpyAsync(D.ja, H.ja.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
+    HIPCK(hipMemcpyAsync(D.val, H.val.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
+    D.lanes = pick_lanes(D);
+    return FASP_SUCCESS;
+}
+
+template <int OP>
+static void launch_csr(const DevCSR& M, CsrArgs a)
+{
+    const int L = M.lanes;
+    const int rpb = BLOCK / L;
+    a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val;
+    a.ntiles = (M.row + rpb - 1) / rpb;
+    a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    int grid = std::min(MAXGRID, ((a.tiles_per_xcd + 0) * 8));
+    grid = std::max(8, (grid + 7) / 8 * 8);
+    hipStream_t s = g_ctx.stream;
+    switch (L) {
+        case 2:  hipLaunchKernelGGL((k_csr_rows<2, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case 4:  hipLaunchKernelGGL((k_csr_rows<4, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case 8:  hipLaunchKernelGGL((k_csr_rows<8, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_csr_rows<16, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((k_csr_rows<32, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_csr_rows<64, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+    }
+}
+// number of blocks launch_csr uses for M (needed by consumers of OP_MXV_DOT partials)
+static int csr_grid(const DevCSR& M)
+{
+    const int rpb = BLOCK / M.lanes;
+    const int ntiles = (M.row + rpb - 1) / rpb;
+    const int tpx = (ntiles + 7) / 8;
+    int grid = std::min(MAXGRID, tpx * 8);
+    return std::max(8, (grid + 7) / 8 * 8);
+}
+
+// y = A x
+static void d_mxv(const DevCSR& A, const double* x, double* y)
+{
+    CsrArgs a{}; a.x = x; a.y = y;
+    launch_csr<OP_MXV>(A, a);
+}
+// y = b - A x
+static void d_resid(const DevCSR& A, const double* x, const double* b, double* y)
+{
+    CsrArgs a{}; a.x = x; a.y = y; a.b = b;
+    launch_csr<OP_RESID>(A, a);
+}
+// y += alpha A x  (three rounding-distinct paths of BlaSpmvCSR.c:494)
+static void d_aAxpy(double alpha, const DevCSR& A, const double* x, double* y)
+{
+    CsrArgs a{}; a.x = x; a.y = y; a.alpha = alpha;
+    if (alpha == 1.0) launch_csr<OP_ADD>(A, a);
+    else if (alpha == -1.0) launch_csr<OP_SUB>(A, a);
+    else launch_csr<OP_AXPY>(A, a);
+}
+
+// --- reductions ----------------------------------------------------------------
+// local partials -> d_red[slot .. slot+nq) -> (all-reduce over ranks) .  Host copy on demand.
+static void d_finalize(int G, int nq, unsigned maxmask, int slot)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, g_ctx.stream, g_ctx.d_partials, G, nq,
+                       maxmask, g_ctx.d_red + slot);
+    if (comm_size() > 1) comm_allreduce(g_ctx.d_red + slot, nq, maxmask, g_ctx.stream);
+}
+static int fetch_red(int slot, int nq, double* out)
+{
+    HIPCK(hipMemcpyAsync(g_ctx.h_red + slot, g_ctx.d_red + slot, sizeof(double) * nq,
+                         hipMemcpyDeviceToHost, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    for (int q = 0; q < nq; ++q) out[q] = g_ctx.h_red[slot + q];
+    return FASP_SUCCESS;
+}
+static int d_dot(int n, const double* x, const double* y, double* out)
+{
+    const int G = vec_grid(n);
+    hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, g_ctx.stream, n, x, y, g_ctx.d_partials);
+    d_finalize(G, 1, 0u, 0);
+    return fetch_red(0, 1, out);
+}
+// out[0] = sum x^2, out[1] = max |x|
+static int d_norms(int n, const double* x, double* out)
+{
+    const int G = vec_grid(n);
+    hipLaunchKernelGGL(k_norms, dim3(G), dim3(BLOCK), 0, g_ctx.stream, n, x, g_ctx.d_partials);
+    d_finalize(G, 2, 0x2u, 0);
+    return fetch_red(0, 2, out);
+}
+static void d_axpy(int n, double a, const double* x, double* y)
+{
+    hipLaunchKernelGGL(k_axpy, dim3(vec_grid(n / 2 + 1)), dim3(BLOCK), 0, g_ctx.stream, n, a, x, y);
+}
+static void d_axpby(int n, double a, const double* x, double b, double* y)
+{
+    hipLaunchKernelGGL(k_axpby, dim3(vec_grid(n / 2 + 1)), dim3(BLOCK), 0, g_ctx.stream, n, a, x, b, y);
+}
+
+// ---------------------------------------------------------------------------
+// resident hierarchy
+// ---------------------------------------------------------------------------
+struct DevLevel {
+    DevCSR  A, P, R;
+    double* diag = nullptr;  // last diagonal hit per row (Jacobi: ItrSmootherCSR.c:160)
+    double* l1   = nullptr;  // sum_j |a_ij| (L1-diag: ItrSmootherCSR.c:1566)
+    double *b = nullptr, *xa = nullptr, *xb = nullptr, *w = nullptr;
+    double* x  = nullptr;    // current iterate: xa or xb
+    double* xo = nullptr;    // the other buffer
+    bool    x_zero = true;   // x is (conceptually) all zeros and not materialised
+    bool    owns_b = true;
+};
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace fasp
+
+using namespace fasp;
+
+struct fasp_hip_amg {
+    HostHierarchy         H;
+    std::vector<DevLevel> L;
+    AMG_param             param;  // copy of the user's parameters after setup
+    // Krylov work vectors on level 0
+    double *b = nullptr, *u = nullptr, *p = nullptr, *t = nullptr, *r = nullptr;
+    // coarse-level SPCG work vectors
+    double *cp = nullptr, *cr = nullptr, *ct = nullptr, *cbest = nullptr;
+    // instrumentation
+    std::vector<EventPair> ev;
+    int                    ev_used = 0;
+    long long              coarse_iters = 0, vcycles = 0;
+    double                 upload_seconds = 0.0;
+};
+
+namespace fasp {
+
+static void free_level(DevLevel& D)
+{
+    D.A.release(); D.P.release(); D.R.release();
+    if (D.diag) (void)hipFree(D.diag);
+    if (D.l1) (void)hipFree(D.l1);
+    if (D.b && D.owns_b) (void)hipFree(D.b);
+    if (D.xa) (void)hipFree(D.xa);
+    if (D.xb) (void)hipFree(D.xb);
+    if (D.w) (void)hipFree(D.w);
+    D = DevLevel();
+}
+
+static int alloc_vec(double** p, size_t n)
+{
+    HIPCK(hipMalloc(p, sizeof(double) * std::max<size_t>(n, 1)));
+    return FASP_SUCCESS;
+}
+
+// diag / l1 are derived on the host in the reference's order (one pass, setup time)
+static int upload_diag(const HostCSR& A, DevLevel& D)
+{
+    const int n = A.row;
+    std::vector<double> d(n, 0.0), s(n, 0.0);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        double di = 0.0, si = 0.0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            if (A.ja[k] == i) di = A.val[k];
+            si += (A.val[k] >= 0.0) ? A.val[k] : -A.val[k];
+        }
+        d[i] = di; s[i] = si;
+    }
+    if (alloc_vec(&D.diag, n) < 0 || alloc_vec(&D.l1, n) < 0) return ERROR_ALLOC_MEM;
+    HIPCK(hipMemcpy(D.diag, d.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(D.l1, s.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    return FASP_SUCCESS;
+}
+
+static int upload_hierarchy(fasp_hip_amg* h)
+{
+    const double t0 = wall_seconds();
+    const int nl = (int)h->H.L.size();
+    h->L.resize(nl);
+    for (int l = 0; l < nl; ++l) {
+        const HostLevel& HL = h->H.L[l];
+        DevLevel& D = h->L[l];
+        if (upload_csr(HL.A, D.A) < 0) return ERROR_ALLOC_MEM;
+        if (HL.has_coarse) {
+            if (upload_csr(HL.P, D.P) < 0) return ERROR_ALLOC_MEM;
+            if (upload_csr(HL.R, D.R) < 0) return ERROR_ALLOC_MEM;
+        }
+        HIPCK(hipStreamSynchronize(g_ctx.stream));
+        if (upload_diag(HL.A, D) < 0) return ERROR_ALLOC_MEM;
+        const size_t n = HL.A.row;
+        if (l > 0) { if (alloc_vec(&D.b, n) < 0) return ERROR_ALLOC_MEM; }
+        else D.owns_b = false;  // level-0 rhs aliases the Krylov residual (PreCSR.c:429 copy elided)
+        if (alloc_vec(&D.xa, n) < 0 || alloc_vec(&D.xb, n) < 0 || alloc_vec(&D.w, n) < 0) return ERROR_ALLOC_MEM;
+        D.x = D.xa; D.xo = D.xb; D.x_zero = true;
+    }
+    const size_t m = h->H.L[0].A.row;
+    if (alloc_vec(&h->b, m) < 0 || alloc_vec(&h->u, m) < 0 || alloc_vec(&h->p, m) < 0 ||
+        alloc_vec(&h->t, m) < 0 || alloc_vec(&h->r, m) < 0) return ERROR_ALLOC_MEM;
+    const size_t mc = h->H.L[nl - 1].A.row;
+    if (alloc_vec(&h->cp, mc) < 0 || alloc_vec(&h->cr, mc) < 0 || alloc_vec(&h->ct, mc) < 0 ||
+        alloc_vec(&h->cbest, mc) < 0) return ERROR_ALLOC_MEM;
+    h->ev.resize(64);
+    for (auto& e : h->ev) { HIPCK(hipEventCreate(&e.a)); HIPCK(hipEventCreate(&e.b)); }
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    h->upload_seconds = wall_seconds() - t0;
+    return FASP_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// smoothers on the resident level (PreMGSmoother.inl:49 / :155).  Jacobi and L1-diag
+// are order independent, so pre (ascending) and post (descending) sweeps coincide.
+// ---------------------------------------------------------------------------
+static void materialise_zero(DevLevel& D)
+{
+    if (D.x_zero) {
+        (void)hipMemsetAsync(D.x, 0, sizeof(double) * D.A.row, g_ctx.stream);
+        D.x_zero = false;
+    }
+}
+
+static void smooth(DevLevel& D, int smoother, int nsweeps, double relax)
+{
+    const int n = D.A.row;
+    for (int s = 0; s < nsweeps; ++s) {
+        if (D.x_zero) {
+            // zero initial guess: t_i = b_i exactly, no matrix pass
+            if (smoother == SMOOTHER_JACOBI)
+                hipLaunchKernelGGL(k_jacobi_zero, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, relax,
+                                   D.b, D.diag, D.x);
+            else
+                hipLaunchKernelGGL(k_l1_zero, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, D.b, D.l1, D.x);
+            D.x_zero = false;
+            continue;
+        }
+        CsrArgs a{};
+        a.x = D.x; a.y = D.xo; a.b = D.b; a.omega = relax;
+        if (smoother == SMOOTHER_JACOBI) { a.diag = D.diag; launch_csr<OP_JACOBI>(D.A, a); }
+        else { a.diag = D.l1; launch_csr<OP_L1DIAG>(D.A, a); }
+        std::swap(D.x, D.xo);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// coarsest level: safe-net CG without preconditioner (KrySPcg.c:60, called from
+// PreMGUtil.inl:47 with StopType = STOP_REL_RES, maxit = MAX(250, MIN(n*n, 1000))).
+// One host synchronisation per iteration: alpha is formed on the device.
+// ---------------------------------------------------------------------------
+static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
+{
+    const DevCSR& A = D.A;
+    const int m = A.row;
+    const int nn = (int)((unsigned)m * (unsigned)m);
+    const int MaxIt = std::max(250, std::min(nn, 1000));
+    const double maxdiff = tol * STAG_RATIO, sol_inf_tol = SMALLREAL;
+    int iter = 0, stag = 1, more_step = 1, iter_best = 0;
+    double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL, normr0 = BIGREAL;
+    double reldiff, factor, alpha = 0.0, beta, temp1, temp2, absres_best = BIGREAL;
+    double *p = h->cp, *r = h->cr, *t = h->ct, *u_best = h->cbest, *u = D.x;
+    const double* b = D.b;
+    const int G = vec_grid(m);
+    double red[8];
+    hipStream_t s = g_ctx.stream;
+    (void)prtlvl;
+
+    // u_best starts as zeros (calloc'ed work array, KrySPcg.c:88)
+    HIPCK(hipMemsetAsync(u_best, 0, sizeof(double) * m, s));
+
+    // r = b - A u  (u == 0 on entry from the cycle: r = b, no matrix pass)
+    if (D.x_zero) {
+        HIPCK(hipMemcpyAsync(r, b, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+        HIPCK(hipMemsetAsync(u, 0, sizeof(double) * m, s));
+        D.x_zero = false;
+    } else {
+        d_resid(A, u, b, r);
+    }
+    if (d_dot(m, r, r, red) < 0) return ERROR_MISC;  // z = r: (r,r) serves both ||r|| and (z,r)
+    absres0 = std::sqrt(red[0]);
+    normr0  = std::max(SMALLREAL, absres0);
+    relres  = absres0 / normr0;
+    if (relres < tol) goto FINISHED;
+    HIPCK(hipMemcpyAsync(p, r, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    temp1 = red[0];
+
+    while (iter++ < MaxIt) {
+        // t = A p fused with the partial sums of (t,p)
+        {
+            CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials;
+            launch_csr<OP_MXV_DOT>(A, a);
+            d_finalize(csr_grid(A), 1, 0u, 8);
+        }
+        // alpha on device; u += alpha p; r -= alpha t; norms of r, u, p; max|u|; NaN count
+        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, g_ctx.d_red + 8, p, t, u, r,
+                           g_ctx.d_partials, 1);
+        d_finalize(G, 5, 0x8u, 0);
+        HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * 9, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        for (int q = 0; q < 5; ++q) red[q] = g_ctx.h_red[q];
+        temp2 = g_ctx.h_red[8];
+        if (std::fabs(temp2) > SMALLREAL2) alpha = temp1 / temp2;
+        else goto RESTORE_BESTSOL;
+
+        absres = std::sqrt(red[0]);
+        relres = absres / normr0;
+        factor = absres / absres0;
+        (void)factor;
+        if (red[4] > 0.0) {  // fasp_dvec_isnan(u), KrySPcg.c:185
+            absres = BIGREAL;
+            goto RESTORE_BESTSOL;
+        }
+        if (absres < absres_best - maxdiff) {
+            absres_best = absres;
+            iter_best   = iter;
+            HIPCK(hipMemcpyAsync(u_best, u, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+        }
+        if (red[3] <= sol_inf_tol) {  // Check I
+            iter = ERROR_SOLVER_SOLSTAG;
+            break;
+        }
+        normu   = std::sqrt(red[1]);
+        reldiff = std::fabs(alpha) * std::sqrt(red[2]) / normu;
+        if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {  // Check II
+            d_resid(A, u, b, r);
+            if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+            absres = std::sqrt(red[0]);
+            relres = absres / normr0;
+            if (relres < tol) break;
+            if (stag >= MAX_STAG) { iter = ERROR_SOLVER_STAG; break; }
+            HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
+            ++stag;
+        }
+        if (relres < tol) {  // Check III: true residual
+            d_resid(A, u, b, r);
+            if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+            absres = std::sqrt(red[0]);
+            relres = absres / normr0;
+            if (relres < tol) break;
+            if (more_step >= MAX_RESTART) { iter = ERROR_SOLVER_TOLSMALL; break; }
+            HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
+            ++more_step;
+        }
+        absres0 = absres;
+        temp2   = red[0];  // (z,r) with z = r
+        beta    = temp2 / temp1;
+        temp1   = temp2;
+        d_axpby(m, 1.0, r, beta, p);  // p = z + beta p
+    }
+
+RESTORE_BESTSOL:
+    if (iter != iter_best) {
+        d_resid(A, u_best, b, r);
+        if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+        absres_best = std::sqrt(red[0]);
+        if (absres > absres_best + maxdiff || std::isnan(absres)) {
+            HIPCK(hipMemcpyAsync(u, u_best, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+            relres = absres_best / normr0;
+        }
+    }
+FINISHED:
+    if (iter > 0) h->coarse_iters += iter;
+    if (iter > MaxIt) return ERROR_SOLVER_MAXIT;
+    return iter;
+}
+
+// ---------------------------------------------------------------------------
+// one multigrid cycle on the resident hierarchy (PreMGCycle.c:48-274)
+// ---------------------------------------------------------------------------
+static int mgcycle(fasp_hip_amg* h, const AMG_param& param)
+{
+    const int nl = (int)h->L.size();
+    const int smoother = param.smoother, cycle_type = param.cycle_type;
+    const double relax = param.relaxation;
+    const double tol = param.tol * 1e-4;
+    int num_lvl[MAX_AMG_LVL] = {0}, ncycles[MAX_AMG_LVL], l = 0;
+    for (int i = 0; i < MAX_AMG_LVL; ++i) ncycles[i] = 1;
+    switch (cycle_type) {
+        case 12: for (int i = MAX_AMG_LVL - 2; i > 0; i -= 2) ncycles[i] = 2; break;
+        case 21: for (int i = MAX_AMG_LVL - 1; i > 0; i -= 2) ncycles[i] = 2; break;
+        default: for (int i = 0; i < MAX_AMG_LVL; ++i) ncycles[i] = cycle_type;
+    }
+    h->vcycles++;
+
+ForwardSweep:
+    while (l < nl - 1) {
+        DevLevel& D = h->L[l];
+        num_lvl[l]++;
+        smooth(D, smoother, param.presmooth_iter, relax);
+        // w = b - A x ; b_{l+1} = R w
+        if (D.x_zero) {
+            HIPCK(hipMemcpyAsync(D.w, D.b, sizeof(double) * D.A.row, hipMemcpyDeviceToDevice, g_ctx.stream));
+        } else {
+            d_resid(D.A, D.x, D.b, D.w);
+        }
+        d_mxv(D.R, D.w, h->L[l + 1].b);
+        ++l;
+        h->L[l].x_zero = true;  // fasp_dvec_set(x_{l}, 0): materialised lazily
+    }
+
+    {
+        const int st = coarse_spcg(h, h->L[nl - 1], tol, param.print_level);
+        if (st < 0) {
+            // the reference falls back to fasp_solver_dcsr_spvgmres here (PreMGUtil.inl:50-52);
+            // that safety net has no device path yet: fail loudly instead of differing silently.
+            std::fprintf(stderr, "### ERROR: fasp_hip: coarse-level safe CG failed (status %d); the SPVGMRES "
+                                 "safety net is not available on the device\n", st);
+            return ERROR_SOLVER_MISC;
+        }
+    }
+
+    while (l > 0) {
+        --l;
+        DevLevel& D = h->L[l];
+        materialise_zero(D);
+        d_aAxpy(1.0, D.P, h->L[l + 1].x, D.x);  // x_l += P x_{l+1}  (coarse_scaling OFF: alpha = 1)
+        smooth(D, smoother, param.postsmooth_iter, relax);
+        if (num_lvl[l] < ncycles[l]) break;
+        else num_lvl[l] = 0;
+    }
+    if (l > 0) goto ForwardSweep;
+    return FASP_SUCCESS;
+}
+
+// z = B r  (PreCSR.c:416-435).  The AMG_param used by the cycle is re-initialised and
+// only the fields of fasp_param_prec_to_amg (AuxParam.c:816-834) are carried over: tol
+// stays 1e-6.  r is used in place as the level-0 rhs and the result is left in the
+// level-0 iterate; *z receives that pointer (both copies of the reference are elided).
+static int precond_amg(fasp_hip_amg* h, double* r, double** z)
+{
+    AMG_param p;
+    fasp_param_amg_init(&p);
+    const AMG_param& u = h->param;
+    p.AMG_type = u.AMG_type; p.print_level = u.print_level; p.cycle_type = u.cycle_type;
+    p.smoother = u.smoother; p.smooth_order = u.smooth_order; p.presmooth_iter = u.presmooth_iter;
+    p.postsmooth_iter = u.postsmooth_iter; p.relaxation = u.relaxation;
+    p.polynomial_degree = u.polynomial_degree; p.coarse_solver = u.coarse_solver;
+    p.coarse_scaling = u.coarse_scaling; p.tentative_smooth = u.tentative_smooth;
+    DevLevel& D0 = h->L[0];
+    D0.b = r;
+    D0.x_zero = true;
+    for (int i = u.maxit; i--;) {
+        const int st = mgcycle(h, p);
+        if (st < 0) return st;
+    }
+    materialise_zero(D0);
+    *z = D0.x;
+    return FASP_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// preconditioned CG (KryPcg.c:96-362) on device vectors
+// ---------------------------------------------------------------------------
+struct Hist {
+    double* h; int cap; int n;
+    void push(double v) { if (h && n < cap) h[n] = v; ++n; }
+};
+
+static void itinfo(int ptrlvl, int stop_type, int iter, double relres, double absres, double factor)
+{  // AuxMessage.c:41-71
+    if (ptrlvl < PRINT_SOME) return;
+    if (iter > 0) {
+        std::printf("%6d | %13.6e   | %13.6e  | %10.4f\n", iter, relres, absres, factor);
+    } else {
+        std::printf("-----------------------------------------------------------\n");
+        switch (stop_type) {
+            case STOP_REL_RES: std::printf("It Num |   ||r||/||b||   |     ||r||      |  Conv. Factor\n"); break;
+            case STOP_REL_PRECRES: std::printf("It Num | ||r||_B/||b||_B |    ||r||_B     |  Conv. Factor\n"); break;
+            case STOP_MOD_REL_RES: std::printf("It Num |   ||r||/||x||   |     ||r||      |  Conv. Factor\n"); break;
+        }
+        std::printf("-----------------------------------------------------------\n");
+        std::printf("%6d | %13.6e   | %13.6e  |     -.-- \n", iter, relres, absres);
+    }
+}
+
+struct PcgOut { double relres, absres, normr0; };
+
+static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, int MaxIt, int StopType,
+                      int PrtLvl, Hist& hist, PcgOut& out)
+{
+    const DevCSR& A = h->L[0].A;
+    const int m = A.row;
+    const double maxdiff = tol * STAG_RATIO, sol_inf_tol = SMALLREAL;
+    int iter = 0, stag = 1, more_step = 1;
+    double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL, normr0 = BIGREAL;
+    double reldiff, factor, alpha = 0.0, beta, temp1 = 0.0, temp2, red[8];
+    double *p = h->p, *r = h->r, *t = h->t, *u = h->u, *z = nullptr;
+    const double* b = h->b;
+    hipStream_t s = g_ctx.stream;
+    const int G = vec_grid(m);
+    int st;
+
+    auto apply_pc = [&]() -> int {
+        if (use_pc) return precond_amg(h, r, &z);
+        z = r;
+        return FASP_SUCCESS;
+    };
+    // residual norm per stop type (KryPcg.c:186-203 and the three copies below it)
+    auto resnorm = [&](double rr_known, bool have_rr) -> int {
+        switch (StopType) {
+            case STOP_REL_RES:
+                if (!have_rr) { if (d_dot(m, r, r, red) < 0) return ERROR_MISC; rr_known = red[0]; }
+                absres = std::sqrt(rr_known);
+                relres = absres / normr0;
+                break;
+            case STOP_REL_PRECRES:
+                if ((st = apply_pc()) < 0) return st;
+                if (d_dot(m, z, r, red) < 0) return ERROR_MISC;
+                absres = std::sqrt(std::fabs(red[0]));
+                relres = absres / normr0;
+                break;
+            case STOP_MOD_REL_RES:
+                if (!have_rr) { if (d_dot(m, r, r, red) < 0) return ERROR_MISC; rr_known = red[0]; }
+                absres = std::sqrt(rr_known);
+                relres = absres / normu;
+                break;
+        }
+        return FASP_SUCCESS;
+    };
+
+    if (PrtLvl > PRINT_NONE) std::printf("\nCalling CG solver (CSR) ...\n");
+
+    d_resid(A, u, b, r);  // r = b - A u
+    if ((st = apply_pc()) < 0) return st;
+    switch (StopType) {
+        case STOP_REL_RES:
+            if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+            absres0 = std::sqrt(red[0]);
+            normr0  = std::max(SMALLREAL, absres0);
+            relres  = absres0 / normr0;
+            break;
+        case STOP_REL_PRECRES:
+            if (d_dot(m, r, z, red) < 0) return ERROR_MISC;
+            absres0 = std::sqrt(red[0]);
+            normr0  = std::max(SMALLREAL, absres0);
+            relres  = absres0 / normr0;
+            break;
+        case STOP_MOD_REL_RES:
+            if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+            absres0 = std::sqrt(red[0]);
+            if (d_dot(m, u, u, red) < 0) return ERROR_MISC;
+            normu  = std::max(SMALLREAL, std::sqrt(red[0]));
+            relres = absres0 / normu;
+            break;
+        default:
+            std::printf("### ERROR: Unknown stopping type! [%s]\n", "fasp_solver_dcsr_pcg");
+            goto FINISHED;
+    }
+    hist.push(absres0);
+    if (relres < tol || absres0 < abstol) goto FINISHED;
+
+    itinfo(PrtLvl, StopType, iter, relres, absres0, 0.0);
+    HIPCK(hipMemcpyAsync(p, z, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    if (d_dot(m, z, r, red) < 0) return ERROR_MISC;
+    temp1 = red[0];
+
+    while (iter++ < MaxIt) {
+        // t = A p with the partial sums of (t,p); timed for the roofline report
+        {
+            CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials;
+            EventPair* ep = h->ev_used < (int)h->ev.size() ? &h->ev[h->ev_used++] : nullptr;
+            if (ep) (void)hipEventRecord(ep->a, s);
+            launch_csr<OP_MXV_DOT>(A, a);
+            if (ep) (void)hipEventRecord(ep->b, s);
+            d_finalize(csr_grid(A), 1, 0u, 8);
+        }
+        // alpha = temp1/(t,p) on device; u += alpha p; r -= alpha t; partial ||r||^2
+        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, g_ctx.d_red + 8, p, t, u, r,
+                           g_ctx.d_partials, 0);
+        d_finalize(G, 1, 0u, 0);
+        HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * 9, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        temp2 = g_ctx.h_red[8];
+        if (std::fabs(temp2) > SMALLREAL2) {
+            alpha = temp1 / temp2;
+        } else {
+            std::printf("### WARNING: Divided by zero! [%s:%d]\n", "fasp_solver_dcsr_pcg", 175);
+            goto FINISHED;
+        }
+        if ((st = resnorm(g_ctx.h_red[0], true)) < 0) return st;
+        factor = absres / absres0;
+        itinfo(PrtLvl, StopType, iter, relres, absres, factor);
+        hist.push(absres);
+
+        if (factor > 0.9) {  // Check I / II, only when converging slowly
+            if (d_norms(m, u, red) < 0) return ERROR_MISC;
+            if (red[1] <= sol_inf_tol) {
+                if (PrtLvl > PRINT_MIN)
+                    std::printf("### WARNING: Iteration stopped -- solution almost zero! [%s:%d]\n",
+                                "fasp_solver_dcsr_pcg", 218);
+                iter = ERROR_SOLVER_SOLSTAG;
+                break;
+            }
+            normu = std::sqrt(red[0]);
+            if (d_dot(m, p, p, red) < 0) return ERROR_MISC;
+            reldiff = std::fabs(alpha) * std::sqrt(red[0]) / normu;
+            if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {
+                if (PrtLvl >= PRINT_MORE) {
+                    std::printf("||u-u'|| = %.10e and the comp. rel. res. = %.10e.\n", reldiff, relres);
+                    std::printf("### WARNING: Iteration restarted -- stagnation! [%s:%d]\n",
+                                "fasp_solver_dcsr_pcg", 232);
+                }
+                d_resid(A, u, b, r);
+                if ((st = resnorm(0.0, false)) < 0) return st;
+                if (PrtLvl >= PRINT_MORE)
+                    std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+                if (relres < tol) break;
+                if (stag >= MAX_STAG) {
+                    if (PrtLvl > PRINT_MIN)
+                        std::printf("### WARNING: Iteration stopped -- staggnation! [%s:%d]\n",
+                                    "fasp_solver_dcsr_pcg", 266);
+                    iter = ERROR_SOLVER_STAG;
+                    break;
+                }
+                HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
+                ++stag;
+            }
+        }
+
+        if (relres < tol) {  // Check III: prevent false convergence
+            const double updated_relres = relres;
+            d_resid(A, u, b, r);
+            if ((st = resnorm(0.0, false)) < 0) return st;
+            if (relres < tol) break;
+            if (PrtLvl >= PRINT_MORE) {
+                std::printf("### WARNING: The computed relative residual = %.10e!\n", updated_relres);
+                std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+            }
+            if (more_step >= MAX_RESTART) {
+                if (PrtLvl > PRINT_MIN)
+                    std::printf("### WARNING: The tolerence might be too small! [%s:%d]\n",
+                                "fasp_solver_dcsr_pcg", 315);
+                iter = ERROR_SOLVER_TOLSMALL;
+                break;
+            }
+            HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
+            ++more_step;
+        }
+
+        absres0 = absres;
+        if (StopType != STOP_REL_PRECRES)
+            if ((st = apply_pc()) < 0) return st;
+        if (d_dot(m, z, r, red) < 0) return ERROR_MISC;
+        temp2 = red[0];
+        beta  = temp2 / temp1;
+        temp1 = temp2;
+        d_axpby(m, 1.0, z, beta, p);  // p = z + beta p
+    }
+
+FINISHED:
+    if (PrtLvl > PRINT_NONE) {  // ITS_FINAL, KryUtil.inl:95-105
+        if (iter > MaxIt)
+            std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, relres);
+        else if (iter >= 0)
+            std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, relres);
+    }
+    hist.push(absres);  // trailing entry: absres at exit (true residual after Check III)
+    out.relres = relres; out.absres = absres; out.normr0 = normr0;
+    HIPCK(hipStreamSynchronize(s));
+    if (iter > MaxIt) return ERROR_SOLVER_MAXIT;
+    return iter;
+}
+
+}  // namespace fasp
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int fasp_hip_set_device(int device)
+{
+    if (g_ctx.ready && device != g_ctx.device) {
+        std::fprintf(stderr, "### ERROR: fasp_hip: device already bound to %d\n", g_ctx.device);
+        return ERROR_INPUT_PAR;
+    }
+    g_requested_device = device;
+    return ctx_init();
+}
+
+int fasp_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return ERROR_MISC;
+    return n;
+}
+
+int fasp_hip_available(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    return 1;
+}
+
+int fasp_hip_amg_create_host(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgparam)
+{
+    if (!out || !A || !amgparam) return ERROR_INPUT_PAR;
+    *out = nullptr;
+    int st = check_supported(nullptr, amgparam);
+    if (st < 0) return st;
+    fasp_hip_amg* h = new fasp_hip_amg();
+    st = host_setup_rs(A, amgparam, h->H);
+    if (st < 0) { delete h; return st; }
+    h->param = *amgparam;
+    *out = h;
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_amg_upload(fasp_hip_amg* h)
+{
+    if (!h) return ERROR_INPUT_PAR;
+    if (!h->L.empty()) return FASP_SUCCESS;
+    int st = ctx_init();
+    if (st < 0) return st;
+    return upload_hierarchy(h);
+}
+
+int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgparam)
+{
+    if (!out || !A || !amgparam) return ERROR_INPUT_PAR;
+    *out = nullptr;
+    int st = check_supported(nullptr, amgparam);
+    if (st < 0) return st;
+    if ((st = ctx_init()) < 0) return st;  // fail before the (long) host setup when there is no GPU
+    fasp_hip_amg* h = nullptr;
+    st = fasp_hip_amg_create_host(&h, A, amgparam);
+    if (st < 0) return st;
+    st = upload_hierarchy(h);
+    if (st < 0) { fasp_hip_amg_destroy(h); return st; }
+    *out = h;
+    return FASP_SUCCESS;
+}
+
+void fasp_hip_amg_destroy(fasp_hip_amg* h)
+{
+    if (!h) return;
+    if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+    for (auto& D : h->L) free_level(D);
+    double* v[] = {h->b, h->u, h->p, h->t, h->r, h->cp, h->cr, h->ct, h->cbest};
+    for (double* q : v)
+        if (q) (void)hipFree(q);
+    for (auto& e : h->ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete h;
+}
+
+int fasp_hip_amg_num_levels(const fasp_hip_amg* h) { return h ? (int)h->H.L.size() : ERROR_INPUT_PAR; }
+
+int fasp_hip_amg_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view)
+{
+    if (!h || !view || level < 0 || level >= (int)h->H.L.size()) return ERROR_INPUT_PAR;
+    const HostLevel& L = h->H.L[level];
+    if (which != 0 && !L.has_coarse) return ERROR_INPUT_PAR;
+    *view = which == 0 ? L.A.view() : which == 1 ? L.P.view() : L.R.view();
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_amg_get_cfmark(const fasp_hip_amg* h, int level, ivector* view)
+{
+    if (!h || !view || level < 0 || level >= (int)h->H.L.size() || !h->H.L[level].has_coarse)
+        return ERROR_INPUT_PAR;
+    view->row = h->H.L[level].A.row;
+    view->val = const_cast<int*>(h->H.L[level].cfmark.data());
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_param* itparam, double* hist,
+                   int hist_cap, fasp_hip_stats* stats)
+{
+    if (!h || !b || !x || !itparam) return ERROR_INPUT_PAR;
+    if (h->L.empty()) return ERROR_INPUT_PAR;  // hierarchy not uploaded
+    int st = check_supported(itparam, &h->param);
+    if (st < 0) return st;
+    const int m = h->L[0].A.row;
+    if (b->row != m || x->row != m) return ERROR_MAT_SIZE;
+    // ITS_CHECK, KryUtil.inl:71-83
+    if (itparam->tol < SMALLREAL)
+        std::printf("### WARNING: Convergence tolerance is too small! [%s:%d]\n", "ITS_CHECK", 74);
+    if (itparam->maxit <= 0)
+        std::printf("### WARNING: Max number of iterations must be POSITIVE! [%s:%d]\n", "ITS_CHECK", 78);
+
+    double t0 = wall_seconds();
+    HIPCK(hipMemcpyAsync(h->b, b->val, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
+    HIPCK(hipMemcpyAsync(h->u, x->val, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    double t_up = wall_seconds() - t0;
+
+    h->ev_used = 0;
+    const long long ci0 = h->coarse_iters, vc0 = h->vcycles;
+    Hist   H{hist, hist_cap, 0};
+    PcgOut po{BIGREAL, BIGREAL, BIGREAL};
+    t0 = wall_seconds();
+    // SolCSR.c:530-551: the AMG preconditioner is always installed on this path
+    st = pcg_device(h, true, itparam->tol, itparam->abstol, itparam->maxit, itparam->stop_type,
+                    itparam->print_level, H, po);
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    const double t_solve = wall_seconds() - t0;
+
+    t0 = wall_seconds();
+    HIPCK(hipMemcpyAsync(x->val, h->u, sizeof(double) * m, hipMemcpyDeviceToHost, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    t_up += wall_seconds() - t0;
+
+    if (stats) {
+        stats->iters = st; stats->nhist = H.n; stats->relres = po.relres; stats->absres = po.absres;
+        stats->normr0 = po.normr0; stats->solve_seconds = t_solve; stats->upload_seconds = t_up;
+        double ms = 0.0;
+        for (int i = 0; i < h->ev_used; ++i) {
+            float e = 0.f;
+            if (hipEventElapsedTime(&e, h->ev[i].a, h->ev[i].b) == hipSuccess) ms += e;
+        }
+        stats->spmv_launches = h->ev_used;
+        stats->spmv_ms = h->ev_used ? ms / h->ev_used : 0.0;
+        stats->coarse_iters = h->coarse_iters - ci0;
+        stats->vcycles = h->vcycles - vc0;
+    }
+    if (itparam->print_level >= PRINT_SOME && st >= 0)
+        std::printf("Iterative method costs %.4f seconds.\n", t_solve);
+    return st;
+}
+
+int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z)
+{
+    if (!h || !r || !z || h->L.empty()) return ERROR_INPUT_PAR;
+    const int m = h->L[0].A.row;
+    HIPCK(hipMemcpyAsync(h->r, r, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
+    double* dz = nullptr;
+    const int st = precond_amg(h, h->r, &dz);
+    if (st < 0) return st;
+    HIPCK(hipMemcpyAsync(z, dz, sizeof(double) * m, hipMemcpyDeviceToHost, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    return FASP_SUCCESS;
+}
+
+// SolCSR.c:476 -- the drop-in entry point
+int fasp_solver_dcsr_krylov_amg(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam, AMG_param* amgparam)
+{
+    if (!A || !b || !x || !itparam || !amgparam) return ERROR_INPUT_PAR;
+    const double t0 = wall_seconds();
+    int st = check_supported(itparam, amgparam);
+    if (st < 0) return st;
+    fasp_hip_amg* h = nullptr;
+    st = fasp_hip_amg_create(&h, A, amgparam);
+    if (st < 0) return st;
+    st = fasp_hip_solve(h, b, x, itparam, nullptr, 0, nullptr);
+    if (itparam->print_level >= PRINT_MIN)
+        std::printf("AMG_Krylov method totally costs %.4f seconds.\n", wall_seconds() - t0);
+    fasp_hip_amg_destroy(h);
+    return st;
+}
+
+// ---------------------------------------------------------------------------
+// kernel-level operators with host pointers (reference names, device kernels)
+// ---------------------------------------------------------------------------
+namespace {
+struct TmpCSR {
+    DevCSR D;
+    bool   ok = false;
+    explicit TmpCSR(const dCSRmat* A)
+    {
+        if (ctx_init() < 0) return;
+        D.row = A->row; D.col = A->col; D.nnz = A->nnz;
+        if (hipMalloc(&D.ia, sizeof(int) * ((size_t)A->row + 1)) != hipSuccess) return;
+        if (hipMalloc(&D.ja, sizeof(int) * std::max(A->nnz, 1)) != hipSuccess) return;
+        if (hipMalloc(&D.val, sizeof(double) * std::max(A->nnz, 1)) != hipSuccess) return;
+        (void)hipMemcpy(D.ia, A->IA, sizeof(int) * ((size_t)A->row + 1), hipMemcpyHostToDevice);
+        (void)hipMemcpy(D.ja, A->JA, sizeof(int) * (size_t)A->nnz, hipMemcpyHostToDevice);
+        (void)hipMemcpy(D.val, A->val, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice);
+        D.lanes = pick_lanes(D);
+        ok = true;
+    }
+    ~TmpCSR() { D.release(); }
+};
+struct TmpVec {
+    double* d = nullptr;
+    size_t  n;
+    TmpVec(const double* h, size_t n_) : n(n_)
+    {
+        if (hipMalloc(&d, sizeof(double) * std::max<size_t>(n, 1)) != hipSuccess) { d = nullptr; return; }
+        if (h) (void)hipMemcpy(d, h, sizeof(double) * n, hipMemcpyHostToDevice);
+    }
+    void get(double* h) { (void)hipStreamSynchronize(g_ctx.stream); (void)hipMemcpy(h, d, sizeof(double) * n, hipMemcpyDeviceToHost); }
+    ~TmpVec() { if (d) (void)hipFree(d); }
+};
+[[noreturn]] void die_no_device(const char* fn)
+{
+    std::fprintf(stderr, "### ERROR: %s: no usable HIP device and no CPU fallback in libfasp_hip\n", fn);
+    std::exit(ERROR_MISC);
+}
+}  // namespace
+
+void fasp_blas_dcsr_mxv(const dCSRmat* A, const double* x, double* y)
+{
+    TmpCSR M(A);
+    if (!M.ok) die_no_device(__func__);
+    TmpVec dx(x, A->col), dy(nullptr, A->row);
+    d_mxv(M.D, dx.d, dy.d);
+    dy.get(y);
+}
+
+void fasp_blas_dcsr_aAxpy(const double alpha, const dCSRmat* A, const double* x, double* y)
+{
+    TmpCSR M(A);
+    if (!M.ok) die_no_device(__func__);
+    TmpVec dx(x, A->col), dy(y, A->row);
+    d_aAxpy(alpha, M.D, dx.d, dy.d);
+    dy.get(y);
+}
+
+double fasp_blas_darray_dotprod(const int n, const double* x, const double* y)
+{
+    if (ctx_init() < 0) die_no_device(__func__);
+    TmpVec dx(x, n), dy(y, n);
+    double out = 0.0;
+    (void)d_dot(n, dx.d, dy.d, &out);
+    return out;
+}
+
+double fasp_blas_darray_norm2(const int n, const double* x)
+{
+    if (ctx_init() < 0) die_no_device(__func__);
+    TmpVec dx(x, n);
+    double out[2] = {0, 0};
+    (void)d_norms(n, dx.d, out);
+    return std::sqrt(out[0]);
+}
+
+double fasp_blas_darray_norminf(const int n, const double* x)
+{
+    if (ctx_init() < 0) die_no_device(__func__);
+    TmpVec dx(x, n);
+    double out[2] = {0, 0};
+    (void)d_norms(n, dx.d, out);
+    return out[1];
+}
+
+void fasp_blas_darray_axpy(const int n, const double a, const double* x, double* y)
+{
+    if (ctx_init() < 0) die_no_device(__func__);
+    TmpVec dx(x, n), dy(y, n);
+    d_axpy(n, a, dx.d, dy.d);
+    dy.get(y);
+}
+
+void fasp_blas_darray_axpby(const int n, const double a, const double* x, const double b, double* y)
+{
+    if (ctx_init() < 0) die_no_device(__func__);
+    TmpVec dx(x, n), dy(y, n);
+    d_axpby(n, a, dx.d, b, dy.d);
+    dy.get(y);
+}
+
+// ItrSmootherCSR.c:98 -- rows i_1..i_n (either direction) of the square system
+void fasp_smoother_dcsr_jacobi(dvector* u, const int i_1, const int i_n, const int s, dCSRmat* A, dvector* b,
+                               int L, const double w)
+{
+    (void)s;
+    TmpCSR M(A);
+    if (!M.ok) die_no_device(__func__);
+    const int n = A->row;
+    const int lo = std::min(i_1, i_n), hi = std::max(i_1, i_n);
+    if (lo != 0 || hi != n - 1) {
+        std::fprintf(stderr, "### ERROR: fasp_smoother_dcsr_jacobi (device): only full sweeps 0..n-1 supported\n");
+        std::exit(ERROR_INPUT_PAR);
+    }
+    std::vector<double> d(n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int k = A->IA[i]; k < A->IA[i + 1]; ++k)
+            if (A->JA[k] == i) d[i] = A->val[k];
+    TmpVec du(u->val, n), du2(nullptr, n), db(b->val, n), dd(d.data(), n);
+    double *x = du.d, *xo = du2.d;
+    while (L--) {
+        CsrArgs a{};
+        a.x = x; a.y = xo; a.b = db.d; a.diag = dd.d; a.omega = w;
+        launch_csr<OP_JACOBI>(M.D, a);
+        std::swap(x, xo);
+    }
+    (void)hipStreamSynchronize(g_ctx.stream);
+    (void)hipMemcpy(u->val, x, sizeof(double) * n, hipMemcpyDeviceToHost);
+}
+
+// timed micro-benchmark of one kernel class on a resident level
+double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps)
+{
+    if (!h || level < 0 || level >= (int)h->L.size() || reps <= 0) return -1.0;
+    DevLevel& D = h->L[level];
+    const int n = D.A.row;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+    double* x = D.xa; double* y = D.xb; double* w = D.w;
+    auto run = [&]() {
+        switch (kind) {
+            case 0: d_mxv(D.A, x, y); break;
+            case 1: d_aAxpy(-1.0, D.A, x, y); break;
+            case 2: { CsrArgs a{}; a.x = x; a.y = y; a.b = w; a.diag = D.diag; a.omega = 0.6667; launch_csr<OP_JACOBI>(D.A, a); } break;
+            case 3: hipLaunchKernelGGL(k_dot, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, x, y, g_ctx.d_partials); break;
+            case 4: d_axpy(n, 0.5, x, y); break;
+            case 5: { CsrArgs a{}; a.x = x; a.y = y; a.dotv = x; a.partials = g_ctx.d_partials; launch_csr<OP_MXV_DOT>(D.A, a); } break;
+            case 6: if (D.R.ia) d_mxv(D.R, w, h->L[level + 1].xa); break;
+            case 7: if (D.P.ia) d_aAxpy(1.0, D.P, h->L[level + 1].xa, y); break;
+            default: break;
+        }
+    };
+    (void)hipMemsetAsync(x, 0, sizeof(double) * n, g_ctx.stream);
+    (void)hipMemsetAsync(y, 0, sizeof(double) * n, g_ctx.stream);
+    (void)hipMemsetAsync(w, 0, sizeof(double) * n, g_ctx.stream);
+    run(); run();
+    (void)hipEventRecord(e0, g_ctx.stream);
+    for (int i = 0; i < reps; ++i) run();
+    (void)hipEventRecord(e1, g_ctx.stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return (double)ms / reps;
+}
+
+}  // extern "C"

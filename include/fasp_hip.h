@@ -275,6 +275,10 @@ typedef struct fasp_hip_amg fasp_hip_amg; /* opaque: host + device hierarchy */
  * upload of every level's A/R/P to HBM.  A is deep-copied.  amgparam is
  * mutated exactly as the reference mutates it (tentative_smooth = 1.0 ...). */
 int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgparam);
+/* The two halves of fasp_hip_amg_create: host setup only (needs no GPU; the handle
+ * can be inspected with the getters below) and the upload to the bound GPU. */
+int fasp_hip_amg_create_host(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgparam);
+int fasp_hip_amg_upload(fasp_hip_amg* h);
 void fasp_hip_amg_destroy(fasp_hip_amg* h);
 
 /* Hierarchy inspection (parity tests compare these with the oracle). */

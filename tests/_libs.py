@@ -150,6 +150,16 @@ def read_vec(path):
     return np.array(tok[1:n + 1], dtype=np.float64)
 
 
+def read_vecind(path):
+    """fasp_dvecind_read format (BlaIO.c:887): n, then `index value` pairs."""
+    tok = open(path).read().split()
+    n = int(tok[0])
+    v = np.zeros(n)
+    for k in range(n):
+        v[int(tok[1 + 2 * k])] = float(tok[2 + 2 * k])
+    return v
+
+
 def poisson7pt(n, lib=None):
     """P7(n) through the oracle's generator; returns numpy (ia, ja, a, f, u)."""
     lib = lib or oracle()
