@@ -31,7 +31,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_amg_destroy", "fasp_hip_amg_num_levels", "fasp_hip_amg_get_matrix",
     "fasp_hip_amg_get_cfmark", "fasp_hip_solve", "fasp_hip_precond_amg",
     "fasp_hip_poisson7pt", "fasp_hip_free_system", "fasp_hip_time_kernel",
-    "fasp_hip_comm_unique_id", "fasp_hip_comm_init", "fasp_hip_comm_finalize",
+    "fasp_hip_tune", "fasp_hip_comm_unique_id", "fasp_hip_comm_init", "fasp_hip_comm_finalize",
     "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version",
 ]
 
@@ -86,6 +86,7 @@ def lib():
     L.fasp_hip_free_system.restype = None
     L.fasp_hip_time_kernel.restype = C.c_double
     L.fasp_hip_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.fasp_hip_tune.argtypes = [C.c_char_p, C.c_int]
     L.fasp_hip_comm_unique_id.argtypes = [C.c_char_p]
     L.fasp_hip_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p]
     L.fasp_hip_version.restype = C.c_char_p

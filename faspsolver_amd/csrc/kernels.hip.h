@@ -46,13 +46,40 @@ struct CsrArgs {
     double*       y;     // output
     const double* b;     // rhs (RESID / JACOBI / L1DIAG)
     const double* diag;  // a_ii (JACOBI) or sum_j |a_ij| (L1DIAG)
+    const int*    dpos;  // JACOBI stream kernel: storage index of the (last) diagonal entry of each row, -1 if none
     const double* dotv;  // OP_MXV_DOT: vector dotted with the result
     double*       partials;  // OP_MXV_DOT: one partial per block
     double        alpha;     // OP_AXPY
     double        omega;     // OP_JACOBI
     int           ntiles;
     int           tiles_per_xcd;
+    int           xcd_map;  // 1: block b works on the tiles of XCD slab (b & 7); 0: plain grid-stride
+    int           nt;       // 1: non-temporal loads of JA / val
 };
+
+__device__ __forceinline__ int ld_ja(const CsrArgs& a, int k)
+{
+    return a.nt ? ld_ja(a, k) : a.ja[k];
+}
+__device__ __forceinline__ double ld_val(const CsrArgs& a, int k)
+{
+    return a.nt ? ld_val(a, k) : a.val[k];
+}
+// persistent-grid tile iteration space of this block: t = first; t < last; t += step
+__device__ __forceinline__ void tile_range(const CsrArgs& a, int& first, int& last, int& step)
+{
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int t0 = xcd * a.tiles_per_xcd;
+        first = t0 + j;
+        last  = min(t0 + a.tiles_per_xcd, a.ntiles);
+        step  = gridDim.x >> 3;
+    } else {
+        first = blockIdx.x;
+        last  = a.ntiles;
+        step  = gridDim.x;
+    }
+}
 
 template <int W>
 __device__ __forceinline__ double subwave_sum(double v)
@@ -102,28 +129,44 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
     constexpr int RPB = BLOCK / L;
     const int sl   = threadIdx.x & (L - 1);
     const int rloc = threadIdx.x / L;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, g8 = gridDim.x >> 3;
-    const int t0 = xcd * a.tiles_per_xcd;
-    const int t1 = min(t0 + a.tiles_per_xcd, a.ntiles);
+    int tfirst, t1, g8;
+    tile_range(a, tfirst, t1, g8);
     double acc = 0.0;
 
-    for (int t = t0 + j; t < t1; t += g8) {
+    for (int t = tfirst; t < t1; t += g8) {
         const int r = t * RPB + rloc;
         if (r < a.nrow) {
             const int kb = a.ia[r], ke = a.ia[r + 1];
             double s = 0.0;
-            if (OP == OP_JACOBI) {
-                for (int k = kb + sl; k < ke; k += L) {
-                    const int    c = __builtin_nontemporal_load(a.ja + k);
-                    const double v = __builtin_nontemporal_load(a.val + k);
-                    if (c != r) s += v * a.x[c];
+            // 4 independent (JA, val) loads and x gathers in flight per lane; the adds stay
+            // in k order
+            int k = kb + sl;
+            for (; k + 3 * L < ke; k += 4 * L) {
+                const int    c0 = ld_ja(a, k);
+                const int    c1 = ld_ja(a, k + L);
+                const int    c2 = ld_ja(a, k + 2 * L);
+                const int    c3 = ld_ja(a, k + 3 * L);
+                const double v0 = ld_val(a, k);
+                const double v1 = ld_val(a, k + L);
+                const double v2 = ld_val(a, k + 2 * L);
+                const double v3 = ld_val(a, k + 3 * L);
+                const double x0 = a.x[c0], x1 = a.x[c1], x2 = a.x[c2], x3 = a.x[c3];
+                if (OP == OP_JACOBI) {
+                    if (c0 != r) s += v0 * x0;
+                    if (c1 != r) s += v1 * x1;
+                    if (c2 != r) s += v2 * x2;
+                    if (c3 != r) s += v3 * x3;
+                } else {
+                    s += v0 * x0;
+                    s += v1 * x1;
+                    s += v2 * x2;
+                    s += v3 * x3;
                 }
-            } else {
-                for (int k = kb + sl; k < ke; k += L) {
-                    const int    c = __builtin_nontemporal_load(a.ja + k);
-                    const double v = __builtin_nontemporal_load(a.val + k);
-                    s += v * a.x[c];
-                }
+            }
+            for (; k < ke; k += L) {
+                const int    c = ld_ja(a, k);
+                const double v = ld_val(a, k);
+                if (OP != OP_JACOBI || c != r) s += v * a.x[c];
             }
             s = subwave_sum<L>(s);
             if (sl == 0) {
@@ -150,6 +193,214 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
     if (OP == OP_MXV_DOT) {
         __shared__ double lds[4];
         const double tot = block_sum(acc, lds);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// CSR "stream" kernel for short rows (<= ~48 nnz/row: the fine levels, R and P, which
+// hold 3/4 of all nonzeros).  A block owns a tile of R consecutive rows (R = 256..1024):
+//   phase 1  all 256 threads sweep the tile's contiguous span of val/JA with unit-stride
+//            loads (fully coalesced whatever the row lengths), gather x through L2 and
+//            park the products val[k]*x[JA[k]] in LDS, <= CAP entries per chunk;
+//   phase 2  thread i sums the products of rows i, i+256, ... from LDS in storage order,
+//            starting from 0.0 (or from b_i for Jacobi): the same left-to-right sum as the
+//            reference's scalar loops (BlaSpmvCSR.c:414-416, ItrSmootherCSR.c:151-160), so
+//            row results are bit-identical to the reference's;
+//   epilogue consecutive threads own consecutive rows: b, diag, x, y are all coalesced.
+// ---------------------------------------------------------------------------
+constexpr int STREAM_CAP  = 4096;  // products per chunk (32 KiB of LDS)
+constexpr int STREAM_MAXR = 1024;  // rows per tile upper bound
+
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void k_csr_stream(CsrArgs a, int R)
+{
+    __shared__ double prod[STREAM_CAP];
+    __shared__ int    rowptr[STREAM_MAXR + 1];
+    __shared__ int    colidx[OP == OP_JACOBI ? STREAM_CAP : 1];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    int tfirst, t1, g8;
+    tile_range(a, tfirst, t1, g8);
+    double dotacc = 0.0;
+
+    for (int t = tfirst; t < t1; t += g8) {
+        const int r0 = t * R;
+        const int nr = min(R, a.nrow - r0);
+        for (int i = tid; i <= nr; i += BLOCK) rowptr[i] = a.ia[r0 + i];
+        __syncthreads();
+        const int k0 = rowptr[0], k1 = rowptr[nr];
+
+        double acc[STREAM_MAXR / BLOCK];
+#pragma unroll
+        for (int q = 0; q < STREAM_MAXR / BLOCK; ++q) {
+            const int i = tid + q * BLOCK;
+            acc[q] = ((OP == OP_JACOBI || OP == OP_L1DIAG) && i < nr) ? a.b[r0 + i] : 0.0;
+        }
+
+        for (int lo = k0; lo < k1; lo += STREAM_CAP) {
+            const int hi = min(lo + STREAM_CAP, k1);
+            // phase 1: coalesced sweep of the chunk
+            for (int k = lo + tid; k < hi; k += BLOCK) {
+                const int    c = ld_ja(a, k);
+                const double v = ld_val(a, k);
+                prod[k - lo] = v * a.x[c];
+                if (OP == OP_JACOBI) colidx[k - lo] = c;
+            }
+            __syncthreads();
+            // phase 2: sequential per-row sums over the part of each row inside the chunk
+#pragma unroll
+            for (int q = 0; q < STREAM_MAXR / BLOCK; ++q) {
+                const int i = tid + q * BLOCK;
+                if (i < nr) {
+                    const int kb = max(rowptr[i], lo), ke = min(rowptr[i + 1], hi);
+                    double s = acc[q];
+                    if (OP == OP_JACOBI) {
+                        const int r = r0 + i;
+                        for (int k = kb; k < ke; ++k)
+                            if (colidx[k - lo] != r) s -= prod[k - lo];
+                    } else if (OP == OP_L1DIAG) {
+                        for (int k = kb; k < ke; ++k) s -= prod[k - lo];
+                    } else {
+                        for (int k = kb; k < ke; ++k) s += prod[k - lo];
+                    }
+                    acc[q] = s;
+                }
+            }
+            __syncthreads();
+        }
+        if (k0 >= k1) __syncthreads();  // rowptr is re-staged by the next tile
+
+        // epilogue: coalesced
+#pragma unroll
+        for (int q = 0; q < STREAM_MAXR / BLOCK; ++q) {
+            const int i = tid + q * BLOCK;
+            if (i < nr) {
+                const int    r = r0 + i;
+                const double s = acc[q];
+                if (OP == OP_MXV) a.y[r] = s;
+                else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
+                else if (OP == OP_ADD) a.y[r] += s;
+                else if (OP == OP_SUB) a.y[r] -= s;
+                else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
+                else if (OP == OP_JACOBI) {
+                    const double d = a.diag[r], xi = a.x[r];  // s == t_i of the reference
+                    a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * s / d : xi;
+                } else if (OP == OP_L1DIAG) {
+                    const double d = a.diag[r], xi = a.x[r];  // s == t_i of the reference
+                    a.y[r] = (fabs(d) > 1e-20) ? xi + s / d : xi;
+                } else if (OP == OP_MXV_DOT) {
+                    a.y[r] = s;
+                    dotacc += s * a.dotv[r];
+                }
+            }
+        }
+    }
+    if (OP == OP_MXV_DOT) {
+        const double tot = block_sum(dotacc, red);
+        if (tid == 0) a.partials[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Wavefront-level stream kernel: the same two phases as k_csr_stream, but every
+// wavefront owns its own tile of RW consecutive rows and its own LDS slab, so there is
+// no workgroup barrier anywhere: a wave's LDS traffic is ordered by the hardware, the
+// four waves of a block run fully decoupled and each keeps 8 (JA, val) pairs + 8 x
+// gathers in flight per lane.  Row sums are again the reference's left-to-right sums.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int OP, int RW, int CAPW>
+__global__ __launch_bounds__(BLOCK) void k_csr_wstream(CsrArgs a)
+{
+    // Jacobi skips the diagonal entry by its storage index (a.dpos), so no column staging
+    __shared__ double prod_all[4 * CAPW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* prod = prod_all + wave * CAPW;
+
+    int tfirst, t1, g8;
+    tile_range(a, tfirst, t1, g8);
+    double dotacc = 0.0;
+
+    for (int t = tfirst; t < t1; t += g8) {
+        const int r0 = (t * 4 + wave) * RW;
+        if (r0 >= a.nrow) continue;  // wave-uniform
+        const int nr = min(RW, a.nrow - r0);
+        int kb = 0, ke = 0;
+        if (lane < nr) {
+            kb = a.ia[r0 + lane];
+            ke = a.ia[r0 + lane + 1];
+        }
+        const int k0 = __shfl(kb, 0), k1 = __shfl(ke, nr - 1);
+        const int r = r0 + lane;
+        double acc = ((OP == OP_JACOBI || OP == OP_L1DIAG) && lane < nr) ? a.b[r] : 0.0;
+        const int dk = (OP == OP_JACOBI && lane < nr) ? a.dpos[r] : -1;
+
+        for (int lo = k0; lo < k1; lo += CAPW) {
+            const int hi = min(lo + CAPW, k1);
+            for (int base = lo; base < hi; base += 512) {
+                int    c[8];
+                double v[8], xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = base + lane + 64 * u;
+                    const bool ok = k < hi;
+                    c[u] = ok ? ld_ja(a, k) : 0;
+                    v[u] = ok ? ld_val(a, k) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = base + lane + 64 * u;
+                    if (k < hi) {
+                        prod[k - lo] = v[u] * xv[u];
+
+                    }
+                }
+            }
+            wave_lds_sync();
+            if (lane < nr) {
+                const int pb = max(kb, lo), pe = min(ke, hi);
+                if (OP == OP_JACOBI) {
+                    for (int k = pb; k < pe; ++k)
+                        if (k != dk) acc -= prod[k - lo];
+                } else if (OP == OP_L1DIAG) {
+                    for (int k = pb; k < pe; ++k) acc -= prod[k - lo];
+                } else {
+                    for (int k = pb; k < pe; ++k) acc += prod[k - lo];
+                }
+            }
+            wave_lds_sync();
+        }
+
+        if (lane < nr) {
+            const double s = acc;
+            if (OP == OP_MXV) a.y[r] = s;
+            else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
+            else if (OP == OP_ADD) a.y[r] += s;
+            else if (OP == OP_SUB) a.y[r] -= s;
+            else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
+            else if (OP == OP_JACOBI) {
+                const double d = a.diag[r], xi = a.x[r];
+                a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * s / d : xi;
+            } else if (OP == OP_L1DIAG) {
+                const double d = a.diag[r], xi = a.x[r];
+                a.y[r] = (fabs(d) > 1e-20) ? xi + s / d : xi;
+            } else if (OP == OP_MXV_DOT) {
+                a.y[r] = s;
+                dotacc += s * a.dotv[r];
+            }
+        }
+    }
+    if (OP == OP_MXV_DOT) {
+        const double tot = block_sum(dotacc, prod_all);  // block_sum barriers before writing
         if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
     }
 }

@@ -102,26 +102,37 @@ struct DevCSR {
     int*    ia  = nullptr;
     int*    ja  = nullptr;
     double* val = nullptr;
-    int     lanes = 8;  // lanes cooperating on one row
+    int*    dpos = nullptr;  // storage index of the last diagonal entry per row (-1: none); A matrices only
+    bool    dup_diag = false;  // some row stores its diagonal more than once
+    int     lanes = 8;       // vector kernel: lanes cooperating on one row
+    int     kind = 0;        // 0 vector, 1 block-level stream, 2 wave-level stream
+    int     tile_rows = 256; // block stream kernel: rows per block tile
+    int     wrows = 64, wcap = 512;  // wave stream kernel: rows per wave tile, LDS products per wave
     void    release()
     {
         if (ia) (void)hipFree(ia);
         if (ja) (void)hipFree(ja);
         if (val) (void)hipFree(val);
-        ia = ja = nullptr; val = nullptr;
+        if (dpos) (void)hipFree(dpos);
+        ia = ja = dpos = nullptr; val = nullptr;
     }
 };
 
-static int pick_lanes(const DevCSR& M)
+// Kernel family per matrix, from its mean row length (measured on MI355X, P7(256)
+// hierarchy, profiles/r01_kernel_sweep.md):
+//   <= 48 nnz/row : wave-level stream kernel, 64 rows / 512 products per wave
+//   longer rows   : sub-wavefront-per-row vector kernel with ~avg/4 lanes per row
+static void pick_kernel(DevCSR& M)
 {
     const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
-    int L = 2;
-    while (L < 64 && L < avg) L <<= 1;  // smallest power of two >= avg nnz/row
-    if (const char* e = std::getenv("FASP_HIP_LANES")) {
-        const int v = std::atoi(e);
-        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L = v;
-    }
-    return L;
+    M.kind = avg <= 48.0 ? 2 : 0;
+    M.lanes = avg < 128.0 ? 16 : avg < 300.0 ? 32 : 64;
+    if (avg < 48.0) M.lanes = avg < 6.0 ? 4 : 8;  // only used when kind is forced to 0
+    int R = 256;
+    while (R < STREAM_MAXR && R * 2 * avg <= 3072.0) R <<= 1;
+    M.tile_rows = R;
+    M.wrows = 64;
+    M.wcap  = 512;
 }
 
 static int upload_csr(const HostCSR& H, DevCSR& D)
@@ -133,38 +144,79 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
     HIPCK(hipMemcpyAsync(D.ia, H.ia.data(), sizeof(int) * ((size_t)H.row + 1), hipMemcpyHostToDevice, g_ctx.stream));
     HIPCK(hipMemcpyAsync(D.ja, H.ja.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
     HIPCK(hipMemcpyAsync(D.val, H.val.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
-    D.lanes = pick_lanes(D);
+    pick_kernel(D);
     return FASP_SUCCESS;
 }
 
-template <int OP>
-static void launch_csr(const DevCSR& M, CsrArgs a)
+// development knobs (fasp_hip_tune): -1 = automatic
+struct Tuning { int maxgrid = -1, xcd = 0, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1; };
+static Tuning g_tune;
+
+// Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
+// limits), from the occupancy API, cached per instantiation.  The persistent grids
+// below are sized to exactly this residency: a grid larger than what is resident
+// serialises into two rounds (measured: +35 % time), a smaller one leaves CUs idle.
+template <class K>
+static int resident_blocks_per_cu(K kernel)
 {
-    const int L = M.lanes;
-    const int rpb = BLOCK / L;
-    a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val;
+    static int cached = -1;
+    if (cached < 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+        cached = std::min(nb, 8);
+    }
+    return cached;
+}
+
+template <class K>
+static int launch_persistent(K kernel, int ntiles, CsrArgs& a)
+{
+    int cap = resident_blocks_per_cu(kernel) * g_ctx.num_cu;
+    if (g_tune.maxgrid > 0) cap = g_tune.maxgrid;
+    cap = std::min(cap, MAXGRID);
+    int grid = std::min(cap, ntiles);
+    grid = std::max(8, (grid + 7) / 8 * 8);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, a);
+    return grid;
+}
+
+// Launches the row kernel of family M.kind for operation OP; returns the grid size
+// (= number of per-block partials written by OP_MXV_DOT).
+template <int OP>
+static int launch_csr(const DevCSR& M0, CsrArgs a)
+{
+    DevCSR M = M0;  // shallow copy: tuning overrides
+    if (g_tune.kind >= 0) M.kind = g_tune.kind;
+    if (g_tune.lanes > 0) M.lanes = g_tune.lanes;
+    if (g_tune.wrows > 0) M.wrows = g_tune.wrows;
+    if (g_tune.wcap > 0) M.wcap = g_tune.wcap;
+    if (OP == OP_JACOBI && M.kind != 0 && (M.dup_diag || !M.dpos)) M.kind = 0;  // needs the c != r test
+    a.xcd_map = g_tune.xcd;
+    a.nt = g_tune.nt;
+    a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
+    const int rpb = M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : BLOCK / M.lanes;
     a.ntiles = (M.row + rpb - 1) / rpb;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
-    int grid = std::min(MAXGRID, ((a.tiles_per_xcd + 0) * 8));
-    grid = std::max(8, (grid + 7) / 8 * 8);
-    hipStream_t s = g_ctx.stream;
-    switch (L) {
-        case 2:  hipLaunchKernelGGL((k_csr_rows<2, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
-        case 4:  hipLaunchKernelGGL((k_csr_rows<4, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
-        case 8:  hipLaunchKernelGGL((k_csr_rows<8, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((k_csr_rows<16, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((k_csr_rows<32, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
-        default: hipLaunchKernelGGL((k_csr_rows<64, OP>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+    if (M.kind == 2) {
+        if (M.wrows == 64 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 64, 512>, a.ntiles, a);
+        if (M.wrows == 64) return launch_persistent(k_csr_wstream<OP, 64, 1024>, a.ntiles, a);
+        if (M.wrows == 32 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 32, 512>, a.ntiles, a);
+        return launch_persistent(k_csr_wstream<OP, 32, 1024>, a.ntiles, a);
     }
-}
-// number of blocks launch_csr uses for M (needed by consumers of OP_MXV_DOT partials)
-static int csr_grid(const DevCSR& M)
-{
-    const int rpb = BLOCK / M.lanes;
-    const int ntiles = (M.row + rpb - 1) / rpb;
-    const int tpx = (ntiles + 7) / 8;
-    int grid = std::min(MAXGRID, tpx * 8);
-    return std::max(8, (grid + 7) / 8 * 8);
+    if (M.kind == 1) {
+        int cap = g_tune.maxgrid > 0 ? g_tune.maxgrid : 4 * g_ctx.num_cu;
+        int grid = std::max(8, (std::min(std::min(cap, MAXGRID), a.ntiles) + 7) / 8 * 8);
+        hipLaunchKernelGGL((k_csr_stream<OP>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, a, M.tile_rows);
+        return grid;
+    }
+    switch (M.lanes) {
+        case 2:  return launch_persistent(k_csr_rows<2, OP>, a.ntiles, a);
+        case 4:  return launch_persistent(k_csr_rows<4, OP>, a.ntiles, a);
+        case 8:  return launch_persistent(k_csr_rows<8, OP>, a.ntiles, a);
+        case 16: return launch_persistent(k_csr_rows<16, OP>, a.ntiles, a);
+        case 32: return launch_persistent(k_csr_rows<32, OP>, a.ntiles, a);
+        default: return launch_persistent(k_csr_rows<64, OP>, a.ntiles, a);
+    }
 }
 
 // y = A x
@@ -288,15 +340,22 @@ static int upload_diag(const HostCSR& A, DevLevel& D)
 {
     const int n = A.row;
     std::vector<double> d(n, 0.0), s(n, 0.0);
-#pragma omp parallel for schedule(static)
+    std::vector<int>    dp(n, -1);
+    int                 ndup = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ndup)
     for (int i = 0; i < n; ++i) {
         double di = 0.0, si = 0.0;
+        int    hits = 0;
         for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
-            if (A.ja[k] == i) di = A.val[k];
+            if (A.ja[k] == i) { di = A.val[k]; dp[i] = k; ++hits; }
             si += (A.val[k] >= 0.0) ? A.val[k] : -A.val[k];
         }
         d[i] = di; s[i] = si;
+        if (hits > 1) ++ndup;
     }
+    D.A.dup_diag = ndup > 0;
+    HIPCK(hipMalloc(&D.A.dpos, sizeof(int) * std::max(n, 1)));
+    HIPCK(hipMemcpy(D.A.dpos, dp.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     if (alloc_vec(&D.diag, n) < 0 || alloc_vec(&D.l1, n) < 0) return ERROR_ALLOC_MEM;
     HIPCK(hipMemcpy(D.diag, d.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(D.l1, s.data(), sizeof(double) * n, hipMemcpyHostToDevice));
@@ -416,8 +475,8 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         // t = A p fused with the partial sums of (t,p)
         {
             CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials;
-            launch_csr<OP_MXV_DOT>(A, a);
-            d_finalize(csr_grid(A), 1, 0u, 8);
+            const int gdot = launch_csr<OP_MXV_DOT>(A, a);
+            d_finalize(gdot, 1, 0u, 8);
         }
         // alpha on device; u += alpha p; r -= alpha t; norms of r, u, p; max|u|; NaN count
         hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, g_ctx.d_red + 8, p, t, u, r,
@@ -688,9 +747,9 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
             CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials;
             EventPair* ep = h->ev_used < (int)h->ev.size() ? &h->ev[h->ev_used++] : nullptr;
             if (ep) (void)hipEventRecord(ep->a, s);
-            launch_csr<OP_MXV_DOT>(A, a);
+            const int gdot = launch_csr<OP_MXV_DOT>(A, a);
             if (ep) (void)hipEventRecord(ep->b, s);
-            d_finalize(csr_grid(A), 1, 0u, 8);
+            d_finalize(gdot, 1, 0u, 8);
         }
         // alpha = temp1/(t,p) on device; u += alpha p; r -= alpha t; partial ||r||^2
         hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, g_ctx.d_red + 8, p, t, u, r,
@@ -993,7 +1052,7 @@ struct TmpCSR {
         (void)hipMemcpy(D.ia, A->IA, sizeof(int) * ((size_t)A->row + 1), hipMemcpyHostToDevice);
         (void)hipMemcpy(D.ja, A->JA, sizeof(int) * (size_t)A->nnz, hipMemcpyHostToDevice);
         (void)hipMemcpy(D.val, A->val, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice);
-        D.lanes = pick_lanes(D);
+        pick_kernel(D);
         ok = true;
     }
     ~TmpCSR() { D.release(); }
@@ -1104,6 +1163,21 @@ void fasp_smoother_dcsr_jacobi(dvector* u, const int i_1, const int i_n, const i
     }
     (void)hipStreamSynchronize(g_ctx.stream);
     (void)hipMemcpy(u->val, x, sizeof(double) * n, hipMemcpyDeviceToHost);
+}
+
+// development knob: override kernel selection / launch geometry at run time
+int fasp_hip_tune(const char* key, int value)
+{
+    if (!key) return ERROR_INPUT_PAR;
+    if (!std::strcmp(key, "maxgrid")) g_tune.maxgrid = value;
+    else if (!std::strcmp(key, "xcd")) g_tune.xcd = value;
+    else if (!std::strcmp(key, "nt")) g_tune.nt = value;
+    else if (!std::strcmp(key, "kind")) g_tune.kind = value;
+    else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
+    else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;
+    else if (!std::strcmp(key, "wcap")) g_tune.wcap = value;
+    else return ERROR_INPUT_PAR;
+    return FASP_SUCCESS;
 }
 
 // timed micro-benchmark of one kernel class on a resident level

@@ -324,6 +324,10 @@ void fasp_hip_free_system(dCSRmat* A, dvector* b, dvector* u);
  * 2 = Jacobi sweep, 3 = dot, 4 = axpy. */
 double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps);
 
+/* Development knob: override kernel selection / launch geometry at run time
+ * (keys: maxgrid, xcd, nt, kind, lanes, wrows, wcap; value -1 = automatic). */
+int fasp_hip_tune(const char* key, int value);
+
 /* Multi-GPU (1-D row partition, RCCL over xGMI).  The unique id is produced on
  * rank 0 and distributed by the caller (e.g. torch.distributed broadcast). */
 #define FASP_HIP_UNIQUE_ID_BYTES 128
