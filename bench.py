@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- AMG-PCG solve throughput on the headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 3-D 7-point FD Poisson on the unit cube, 256^3
+interior points (16 777 216 DOF, 117 047 296 nnz), rhs from the reference's generator,
+x0 = 0, PCG rtol 1e-8, classical RS-AMG defaults with SMOOTHER_JACOBI, relaxation 0.6667,
+V(1,1).  One "step" = one complete fasp_solver_dcsr_krylov_amg-style
+Krylov solve (all PCG iterations, every V-cycle, the coarse-level safe CG) on the
+resident hierarchy, with b and x already in HBM.  The host-side AMG setup and the
+upload happen once, before the warm-up, and are reported separately.
+
+value   = DOF / s = (rows x K) / (time of K solves), whole job (all ranks)
+roofline: the level-0 SpMV kernel (t = A p fused with the (t,p) partial sums), algorithmic
+          bytes 12 nnz + 4 (m+1) + 8 m + 8 m per launch / mean launch time measured with
+          HIP events on the launch stream inside the timed solves.
+cpu_baseline: the oracle (oracle/liboracle.so, a plain-C restatement of the reference's
+          serial algorithm, OpenMP row loops) on the node's host cores, same problem,
+          same hierarchy, bounded number of PCG iterations scaled to the full solve.
+
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; the matrix is
+row-partitioned, halos and dot products go over RCCL (faspsolver_amd/csrc/dist.hip).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import faspsolver_amd as fa  # noqa: E402
+from faspsolver_amd import _types as T  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def spmv_bytes(m, ncol, nnz):
+    return 12 * nnz + 4 * (m + 1) + 8 * ncol + 8 * m
+
+
+def workload_params():
+    itp = fa.param_solver_init()
+    itp.tol = 1e-8
+    itp.maxit = 500
+    itp.print_level = 0
+    amgp = fa.param_amg_init()
+    amgp.smoother = T.SMOOTHER_JACOBI
+    amgp.relaxation = 0.6667
+    return itp, amgp
+
+
+def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s):
+    """Time the oracle on the host cores on a bounded sample of the same solve."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _libs
+    O = _libs.oracle()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    threads = max(1, min(cores, int(os.environ.get("BENCH_CPU_THREADS", "64"))))
+    O.orc_set_threads(threads)
+    nl = H.num_levels
+    buf = C.create_string_buffer(O.orc_sizeof_amg())
+    O.orc_amg_borrow_begin(buf, nl)
+    keep = []
+    for l in range(nl):
+        vA = T.dCSRmat(); fa.lib().fasp_hip_amg_get_matrix(H.h, l, 0, C.byref(vA))
+        if l < nl - 1:
+            vP = T.dCSRmat(); vR = T.dCSRmat(); cf = T.ivector()
+            fa.lib().fasp_hip_amg_get_matrix(H.h, l, 1, C.byref(vP))
+            fa.lib().fasp_hip_amg_get_matrix(H.h, l, 2, C.byref(vR))
+            fa.lib().fasp_hip_amg_get_cfmark(H.h, l, C.byref(cf))
+            O.orc_amg_borrow_level(buf, l, C.byref(vA), C.byref(vP), C.byref(vR), cf.val)
+            keep += [vA, vP, vR, cf]
+        else:
+            O.orc_amg_borrow_level(buf, l, C.byref(vA), None, None, None)
+            keep += [vA]
+    O.orc_amg_borrow_end(buf)
+    A, _k = T.as_csr(ia, ja, a)
+    bv, _f = T.as_vec(f)
+
+    def run(maxit):
+        itp, amgp = workload_params()
+        itp.maxit = maxit
+        x = np.zeros(len(f))
+        xv, x = T.as_vec(x)
+        hist = np.zeros(600); nh = C.c_int(0); rr = C.c_double(0)
+        t0 = time.perf_counter()
+        st = O.orc_solve_with_hierarchy(buf, C.byref(A), C.byref(bv), C.byref(xv), C.byref(itp),
+                                        C.byref(amgp), T.dp(hist), 600, C.byref(nh), C.byref(rr))
+        return time.perf_counter() - t0, st, hist[:nh.value].copy(), rr.value
+
+    t1, st1, h1, _ = run(1)  # 1 iteration (+ the initial preconditioner apply): sizes the sample
+    per_it = max(t1 / 2.0, 1e-6)
+    k = int(max(1, min(iters_gpu, budget_s / per_it)))
+    if k >= iters_gpu:
+        tk, stk, hk, rrk = run(500)
+        sample = f"full solve, {stk} PCG iterations"
+        t_full = tk
+        its_cpu = stk
+    else:
+        tk, stk, hk, rrk = run(k)
+        # k iterations contain k+1 preconditioner applies; the full solve iters+1
+        t_full = tk * (iters_gpu + 1.0) / (k + 1.0)
+        sample = (f"{k} of {iters_gpu} PCG iterations of the same solve "
+                  f"({tk:.2f} s), scaled by ({iters_gpu}+1)/({k}+1)")
+        its_cpu = None
+        rrk = None
+    ncmp = min(len(hk) - 1, len(hist_gpu) - 1)
+    hist_dev = float(np.max(np.abs(hk[:ncmp] - hist_gpu[:ncmp]) / hk[:ncmp])) if ncmp > 0 else None
+    O.orc_amg_borrow_free(buf)
+    return {"value": len(f) / t_full, "unit": "DOF/s", "cores": threads, "kind": "port",
+            "sample": sample, "seconds_full_solve_est": t_full}, its_cpu, rrk, hist_dev
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", "256")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log(f"WORLD_SIZE {world} != --gpus {args.gpus}; using WORLD_SIZE")
+    if world > 1:
+        import bench_dist
+        return bench_dist.main(args, rank, world, local_rank)
+
+    L = fa.lib()
+    if not fa.available():
+        log("bench.py: no HIP device; libfasp_hip has no CPU fallback")
+        sys.exit(2)
+    L.fasp_hip_set_device(local_rank)
+    # Device work is issued by libfasp_hip on its own HIP stream; torch is not involved in
+    # the single-GPU path, so the synchronisation bracket is the library's own stream sync
+    # (torch.cuda.synchronize() would only see torch's idle default stream).
+
+    n = args.n
+    t0 = time.perf_counter()
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    m, nnz = len(f), len(a)
+    log(f"P7({n}): {m} rows, {nnz} nnz, generated in {time.perf_counter()-t0:.2f} s")
+
+    itp, amgp = workload_params()
+    t0 = time.perf_counter()
+    H = fa.AMG(ia, ja, a, amgp)
+    t_setup = time.perf_counter() - t0
+    H.set_rhs(f)
+    log(f"AMG setup + upload: {t_setup:.2f} s, {H.num_levels} levels")
+
+    def sync():
+        L.fasp_hip_device_synchronize()
+
+    stats = None
+    for _ in range(args.warmup):
+        st, hist, stats = H.solve_resident(itp)
+    sync()
+    t0 = time.perf_counter()
+    spmv_ms = []
+    for _ in range(args.steps):
+        st, hist, stats = H.solve_resident(itp)
+        spmv_ms.append(stats.spmv_ms)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = m * args.steps / elapsed
+    x = H.get_solution()
+    log(f"solve: {st} iterations, relres {stats.relres:.10e}, {ms_per_step:.2f} ms/solve, "
+        f"coarse its {stats.coarse_iters}, max|x-u_exact| {np.max(np.abs(x-ue)):.3e}")
+
+    B = spmv_bytes(m, m, nnz)
+    kernel_ms = float(np.mean(spmv_ms))
+    achieved = B / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    out = {
+        "metric": "AMG-PCG solve DOF/s (3D 7-pt Poisson 256^3, classical AMG V(1,1) w-Jacobi + PCG, rtol 1e-8)",
+        "value": value, "unit": "DOF/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"P7({n}): 3-D 7-point Poisson {n}^3, {m} DOF, {nnz} nnz; "
+                               "PCG rtol 1e-8 + classical RS-AMG V(1,1), Jacobi w=0.6667; "
+                               "one step = one full solve on the resident hierarchy",
+                   "rows": m, "nnz": nnz, "levels": H.num_levels, "parallelism": "1 GPU"},
+        "iterations": int(st), "relres": stats.relres,
+        "setup_seconds": t_setup,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+                     "kernel": "k_csr_wstream<OP_MXV_DOT,64,512> (level-0 t = A p)",
+                     "bytes_per_launch": B, "ms_per_launch": kernel_ms,
+                     "launches_timed": int(stats.spmv_launches) * args.steps},
+    }
+    if not args.no_cpu_baseline:
+        try:
+            cb, its_cpu, rr_cpu, hist_dev = cpu_baseline(H, ia, ja, a, f, int(st), hist,
+                                                         float(os.environ.get("BENCH_CPU_BUDGET_S", "20")))
+            out["cpu_baseline"] = cb
+            out["parity"] = {"iters_gpu": int(st), "iters_cpu": its_cpu, "relres_gpu": stats.relres,
+                             "relres_cpu": rr_cpu, "max_rel_dev_residual_history": hist_dev}
+        except Exception as e:  # the baseline is a report, never a reason to lose the line
+            log(f"cpu_baseline failed: {e!r}")
+            out["cpu_baseline"] = None
+    H.close()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,11 @@ def lib():
     L.fasp_hip_amg_get_cfmark.argtypes = [C.c_void_p, C.c_int, P(T.ivector)]
     L.fasp_hip_solve.argtypes = [C.c_void_p, P(T.dvector), P(T.dvector), P(T.ITS_param),
                                  T.c_double_p, C.c_int, P(T.fasp_hip_stats)]
+    L.fasp_hip_set_rhs.argtypes = [C.c_void_p, P(T.dvector)]
+    L.fasp_hip_set_guess.argtypes = [C.c_void_p, P(T.dvector)]
+    L.fasp_hip_get_solution.argtypes = [C.c_void_p, P(T.dvector)]
+    L.fasp_hip_solve_resident.argtypes = [C.c_void_p, P(T.ITS_param), T.c_double_p, C.c_int,
+                                          P(T.fasp_hip_stats)]
     L.fasp_hip_precond_amg.argtypes = [C.c_void_p, T.c_double_p, T.c_double_p]
     L.fasp_hip_poisson7pt.argtypes = [C.c_int, C.c_int, C.c_int, P(T.dCSRmat), P(T.dvector),
                                       P(T.dvector)]
@@ -185,6 +190,31 @@ class AMG:
         st = lib().fasp_hip_solve(self.h, C.byref(bv), C.byref(xv), C.byref(itparam),
                                   T.dp(hist), hist_cap, C.byref(stats))
         return st, x, hist[:max(stats.nhist, 0)].copy(), stats
+
+    def set_rhs(self, b):
+        bv, _b = T.as_vec(b)
+        st = lib().fasp_hip_set_rhs(self.h, C.byref(bv))
+        if st < 0:
+            raise RuntimeError(f"fasp_hip_set_rhs failed: {st}")
+
+    def solve_resident(self, itparam, hist_cap=600):
+        """Zero initial guess, b and x stay in HBM -> (status, hist, stats)."""
+        st = lib().fasp_hip_set_guess(self.h, None)
+        if st < 0:
+            raise RuntimeError(f"fasp_hip_set_guess failed: {st}")
+        hist = np.zeros(hist_cap)
+        stats = T.fasp_hip_stats()
+        st = lib().fasp_hip_solve_resident(self.h, C.byref(itparam), T.dp(hist), hist_cap,
+                                           C.byref(stats))
+        return st, hist[:max(stats.nhist, 0)].copy(), stats
+
+    def get_solution(self):
+        x = np.zeros(self.n)
+        xv, x = T.as_vec(x)
+        st = lib().fasp_hip_get_solution(self.h, C.byref(xv))
+        if st < 0:
+            raise RuntimeError(f"fasp_hip_get_solution failed: {st}")
+        return x
 
     def precond(self, r):
         r = np.ascontiguousarray(r, dtype=np.float64)

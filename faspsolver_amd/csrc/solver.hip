@@ -950,46 +950,74 @@ int fasp_hip_amg_get_cfmark(const fasp_hip_amg* h, int level, ivector* view)
     return FASP_SUCCESS;
 }
 
-int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_param* itparam, double* hist,
-                   int hist_cap, fasp_hip_stats* stats)
+int fasp_hip_set_rhs(fasp_hip_amg* h, const dvector* b)
 {
-    if (!h || !b || !x || !itparam) return ERROR_INPUT_PAR;
+    if (!h || !b || h->L.empty()) return ERROR_INPUT_PAR;
+    const int m = h->L[0].A.row;
+    if (b->row != m) return ERROR_MAT_SIZE;
+    HIPCK(hipMemcpyAsync(h->b, b->val, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_set_guess(fasp_hip_amg* h, const dvector* x)
+{
+    if (!h || h->L.empty()) return ERROR_INPUT_PAR;
+    const int m = h->L[0].A.row;
+    if (x) {
+        if (x->row != m) return ERROR_MAT_SIZE;
+        HIPCK(hipMemcpyAsync(h->u, x->val, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
+    } else {
+        HIPCK(hipMemsetAsync(h->u, 0, sizeof(double) * m, g_ctx.stream));
+    }
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_get_solution(fasp_hip_amg* h, dvector* x)
+{
+    if (!h || !x || h->L.empty()) return ERROR_INPUT_PAR;
+    const int m = h->L[0].A.row;
+    if (x->row != m) return ERROR_MAT_SIZE;
+    HIPCK(hipMemcpyAsync(x->val, h->u, sizeof(double) * m, hipMemcpyDeviceToHost, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_device_synchronize(void)
+{
+    if (!g_ctx.ready) return FASP_SUCCESS;
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* hist, int hist_cap,
+                            fasp_hip_stats* stats)
+{
+    if (!h || !itparam) return ERROR_INPUT_PAR;
     if (h->L.empty()) return ERROR_INPUT_PAR;  // hierarchy not uploaded
     int st = check_supported(itparam, &h->param);
     if (st < 0) return st;
-    const int m = h->L[0].A.row;
-    if (b->row != m || x->row != m) return ERROR_MAT_SIZE;
     // ITS_CHECK, KryUtil.inl:71-83
     if (itparam->tol < SMALLREAL)
         std::printf("### WARNING: Convergence tolerance is too small! [%s:%d]\n", "ITS_CHECK", 74);
     if (itparam->maxit <= 0)
         std::printf("### WARNING: Max number of iterations must be POSITIVE! [%s:%d]\n", "ITS_CHECK", 78);
 
-    double t0 = wall_seconds();
-    HIPCK(hipMemcpyAsync(h->b, b->val, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
-    HIPCK(hipMemcpyAsync(h->u, x->val, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
-    HIPCK(hipStreamSynchronize(g_ctx.stream));
-    double t_up = wall_seconds() - t0;
-
     h->ev_used = 0;
     const long long ci0 = h->coarse_iters, vc0 = h->vcycles;
     Hist   H{hist, hist_cap, 0};
     PcgOut po{BIGREAL, BIGREAL, BIGREAL};
-    t0 = wall_seconds();
+    const double t0 = wall_seconds();
     // SolCSR.c:530-551: the AMG preconditioner is always installed on this path
     st = pcg_device(h, true, itparam->tol, itparam->abstol, itparam->maxit, itparam->stop_type,
                     itparam->print_level, H, po);
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     const double t_solve = wall_seconds() - t0;
 
-    t0 = wall_seconds();
-    HIPCK(hipMemcpyAsync(x->val, h->u, sizeof(double) * m, hipMemcpyDeviceToHost, g_ctx.stream));
-    HIPCK(hipStreamSynchronize(g_ctx.stream));
-    t_up += wall_seconds() - t0;
-
     if (stats) {
         stats->iters = st; stats->nhist = H.n; stats->relres = po.relres; stats->absres = po.absres;
-        stats->normr0 = po.normr0; stats->solve_seconds = t_solve; stats->upload_seconds = t_up;
+        stats->normr0 = po.normr0; stats->solve_seconds = t_solve; stats->upload_seconds = 0.0;
         double ms = 0.0;
         for (int i = 0; i < h->ev_used; ++i) {
             float e = 0.f;
@@ -1002,6 +1030,24 @@ int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_para
     }
     if (itparam->print_level >= PRINT_SOME && st >= 0)
         std::printf("Iterative method costs %.4f seconds.\n", t_solve);
+    return st;
+}
+
+int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_param* itparam, double* hist,
+                   int hist_cap, fasp_hip_stats* stats)
+{
+    if (!h || !b || !x || !itparam) return ERROR_INPUT_PAR;
+    double t0 = wall_seconds();
+    int st = fasp_hip_set_rhs(h, b);
+    if (st < 0) return st;
+    if ((st = fasp_hip_set_guess(h, x)) < 0) return st;
+    double t_up = wall_seconds() - t0;
+    st = fasp_hip_solve_resident(h, itparam, hist, hist_cap, stats);
+    t0 = wall_seconds();
+    const int st2 = fasp_hip_get_solution(h, x);
+    if (st2 < 0) return st2;
+    t_up += wall_seconds() - t0;
+    if (stats) stats->upload_seconds = t_up;
     return st;
 }
 

@@ -307,6 +307,16 @@ typedef struct {
 int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_param* itparam,
                    double* hist, int hist_cap, fasp_hip_stats* stats);
 
+/* The same solve in three steps, for callers that keep b and x resident in HBM:
+ * upload the right-hand side / initial guess (x == NULL: zeros), run the Krylov loop on
+ * the resident vectors, download the solution. */
+int fasp_hip_set_rhs(fasp_hip_amg* h, const dvector* b);
+int fasp_hip_set_guess(fasp_hip_amg* h, const dvector* x);
+int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* hist, int hist_cap,
+                            fasp_hip_stats* stats);
+int fasp_hip_get_solution(fasp_hip_amg* h, dvector* x);
+int fasp_hip_device_synchronize(void);
+
 /* One application of the AMG preconditioner z = B r (PreCSR.c:416) on the
  * resident hierarchy; host vectors in/out. */
 int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z);
