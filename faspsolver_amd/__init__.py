@@ -29,7 +29,9 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_set_device", "fasp_hip_device_count", "fasp_hip_available",
     "fasp_hip_amg_create", "fasp_hip_amg_create_host", "fasp_hip_amg_upload",
     "fasp_hip_amg_destroy", "fasp_hip_amg_num_levels", "fasp_hip_amg_get_matrix",
-    "fasp_hip_amg_get_cfmark", "fasp_hip_solve", "fasp_hip_precond_amg",
+    "fasp_hip_amg_get_cfmark", "fasp_hip_solve", "fasp_hip_set_rhs", "fasp_hip_set_guess",
+    "fasp_hip_solve_resident", "fasp_hip_get_solution", "fasp_hip_device_synchronize",
+    "fasp_hip_precond_amg",
     "fasp_hip_poisson7pt", "fasp_hip_free_system", "fasp_hip_time_kernel",
     "fasp_hip_tune", "fasp_hip_comm_unique_id", "fasp_hip_comm_init", "fasp_hip_comm_finalize",
     "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version",
@@ -51,7 +53,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(LIB_PATH)  # RTLD_LOCAL: the reference-named symbols must not interpose other libraries
     P = C.POINTER
     L.fasp_param_amg_init.argtypes = [P(T.AMG_param)]
     L.fasp_param_solver_init.argtypes = [P(T.ITS_param)]
