@@ -53,32 +53,35 @@ struct CsrArgs {
     double        omega;     // OP_JACOBI
     int           ntiles;
     int           tiles_per_xcd;
-    int           xcd_map;  // 1: block b works on the tiles of XCD slab (b & 7); 0: plain grid-stride
+    int           xcd_map;  // G > 0: an XCD works on runs of G consecutive tiles; 0: plain grid-stride
     int           nt;       // 1: non-temporal loads of JA / val
 };
 
 __device__ __forceinline__ int ld_ja(const CsrArgs& a, int k)
 {
-    return a.nt ? ld_ja(a, k) : a.ja[k];
+    return a.nt ? __builtin_nontemporal_load(a.ja + k) : a.ja[k];
 }
 __device__ __forceinline__ double ld_val(const CsrArgs& a, int k)
 {
-    return a.nt ? ld_val(a, k) : a.val[k];
+    return a.nt ? __builtin_nontemporal_load(a.val + k) : a.val[k];
 }
-// persistent-grid tile iteration space of this block: t = first; t < last; t += step
-__device__ __forceinline__ void tile_range(const CsrArgs& a, int& first, int& last, int& step)
+// Persistent-grid tile schedule.  Block b visits the virtual indices v = b, b + grid, ...;
+// v is mapped to a row tile so that the tiles an XCD works on (blocks b and b+8 share an
+// XCD) come in runs of G consecutive tiles: neighbouring rows, which gather the same x
+// entries, then hit the same XCD-private L2.  xcd_map = G (0: identity, plain grid-stride).
+__device__ __forceinline__ int tile_vmax(const CsrArgs& a)
 {
-    if (a.xcd_map) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int t0 = xcd * a.tiles_per_xcd;
-        first = t0 + j;
-        last  = min(t0 + a.tiles_per_xcd, a.ntiles);
-        step  = gridDim.x >> 3;
-    } else {
-        first = blockIdx.x;
-        last  = a.ntiles;
-        step  = gridDim.x;
-    }
+    if (a.xcd_map <= 0) return a.ntiles;
+    const int span = 8 * a.xcd_map;
+    return (a.ntiles + span - 1) / span * span;
+}
+__device__ __forceinline__ int tile_of(const CsrArgs& a, int v)
+{
+    if (a.xcd_map <= 0) return v;
+    const int G = a.xcd_map;
+    const int xcd = v & 7, q = v >> 3;
+    const int chunk = q / G, within = q - chunk * G;
+    return (chunk * 8 + xcd) * G + within;
 }
 
 template <int W>
@@ -129,11 +132,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
     constexpr int RPB = BLOCK / L;
     const int sl   = threadIdx.x & (L - 1);
     const int rloc = threadIdx.x / L;
-    int tfirst, t1, g8;
-    tile_range(a, tfirst, t1, g8);
+    const int vmax = tile_vmax(a);
     double acc = 0.0;
 
-    for (int t = tfirst; t < t1; t += g8) {
+    for (int v = blockIdx.x; v < vmax; v += gridDim.x) {
+        const int t = tile_of(a, v);
+        if (t >= a.ntiles) continue;
         const int r = t * RPB + rloc;
         if (r < a.nrow) {
             const int kb = a.ia[r], ke = a.ia[r + 1];
@@ -198,6 +202,62 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// One workgroup per row: for the few, very long rows of the coarsest levels (1000+ nnz
+// per row, < 64 K rows) a wavefront per row leaves the chip under-filled and serialises 20
+// dependent load rounds; with 256 lanes per row every lane issues its whole share of the
+// row (<= 8 loads) at once and the kernel is one memory round trip deep.
+// ---------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void k_csr_blockrow(CsrArgs a)
+{
+    __shared__ double lds[4];
+    double acc = 0.0;
+    for (int r = blockIdx.x; r < a.nrow; r += gridDim.x) {
+        const int kb = a.ia[r], ke = a.ia[r + 1];
+        double s = 0.0;
+        for (int base = kb + threadIdx.x; base < ke; base += 8 * BLOCK) {
+            int    c[8];
+            double v[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int  k = base + u * BLOCK;
+                const bool ok = k < ke;
+                c[u] = ok ? ld_ja(a, k) : 0;
+                v[u] = ok ? ld_val(a, k) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = base + u * BLOCK;
+                if (k < ke && (OP != OP_JACOBI || c[u] != r)) s += v[u] * xv[u];
+            }
+        }
+        s = block_sum(s, lds);
+        if (threadIdx.x == 0) {
+            if (OP == OP_MXV) a.y[r] = s;
+            else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
+            else if (OP == OP_ADD) a.y[r] += s;
+            else if (OP == OP_SUB) a.y[r] -= s;
+            else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
+            else if (OP == OP_JACOBI) {
+                const double d = a.diag[r], xi = a.x[r];
+                const double tt = a.b[r] - s;
+                a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * tt / d : xi;
+            } else if (OP == OP_L1DIAG) {
+                const double d = a.diag[r], xi = a.x[r];
+                const double tt = a.b[r] - s;
+                a.y[r] = (fabs(d) > 1e-20) ? xi + tt / d : xi;
+            } else if (OP == OP_MXV_DOT) {
+                a.y[r] = s;
+                acc += s * a.dotv[r];
+            }
+        }
+    }
+    if (OP == OP_MXV_DOT && threadIdx.x == 0) a.partials[blockIdx.x] = acc;
+}
+
+// ---------------------------------------------------------------------------
 // CSR "stream" kernel for short rows (<= ~48 nnz/row: the fine levels, R and P, which
 // hold 3/4 of all nonzeros).  A block owns a tile of R consecutive rows (R = 256..1024):
 //   phase 1  all 256 threads sweep the tile's contiguous span of val/JA with unit-stride
@@ -220,11 +280,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(CsrArgs a, int R)
     __shared__ int    colidx[OP == OP_JACOBI ? STREAM_CAP : 1];
     __shared__ double red[4];
     const int tid = threadIdx.x;
-    int tfirst, t1, g8;
-    tile_range(a, tfirst, t1, g8);
+    const int vmax = tile_vmax(a);
     double dotacc = 0.0;
 
-    for (int t = tfirst; t < t1; t += g8) {
+    for (int v = blockIdx.x; v < vmax; v += gridDim.x) {
+        const int t = tile_of(a, v);
+        if (t >= a.ntiles) continue;
         const int r0 = t * R;
         const int nr = min(R, a.nrow - r0);
         for (int i = tid; i <= nr; i += BLOCK) rowptr[i] = a.ia[r0 + i];
@@ -324,11 +385,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream(CsrArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* prod = prod_all + wave * CAPW;
 
-    int tfirst, t1, g8;
-    tile_range(a, tfirst, t1, g8);
+    const int vmax = tile_vmax(a);
     double dotacc = 0.0;
 
-    for (int t = tfirst; t < t1; t += g8) {
+    for (int v = blockIdx.x; v < vmax; v += gridDim.x) {
+        const int t = tile_of(a, v);
+        if (t >= a.ntiles) continue;
         const int r0 = (t * 4 + wave) * RW;
         if (r0 >= a.nrow) continue;  // wave-uniform
         const int nr = min(RW, a.nrow - r0);
@@ -487,20 +549,37 @@ __global__ __launch_bounds__(BLOCK) void k_dot(int n, const double* __restrict__
 }
 
 // Krylov update fused with the norms the control flow needs (KryPcg.c:180-189,
-// KrySPcg.c:147-199):  alpha = temp1 / red[slot_tp];  u += alpha p;  r -= alpha t;
+// KrySPcg.c:147-199):  alpha = temp1 / (t,p);  u += alpha p;  r -= alpha t;
 // partial sums q0 = r.r, q1 = u.u, q2 = p.p, q3 = max|u| (max), q4 = #NaN in u.
+// (t,p) comes either reduced from *red_tp (distributed levels: finalize + all-reduce), or
+// -- ntp > 0 -- as the ntp per-block partials of the producing SpMV, which every block sums
+// in the same fixed order (no separate finalize launch on the replicated coarse level).
 // If |(t,p)| <= 1e-40 (CG breakdown) nothing is updated; the host sees (t,p) itself.
 __global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const double* __restrict__ red_tp,
+                                                      const double* __restrict__ tp_partials, int ntp,
                                                       const double* __restrict__ p,
                                                       const double* __restrict__ t,
                                                       double* __restrict__ u, double* __restrict__ r,
-                                                      double* __restrict__ partials, int full_norms)
+                                                      double* __restrict__ partials, int full_norms,
+                                                      double* __restrict__ temp2_out)
 {
-    __shared__ double lds[4];
-    const double temp2 = *red_tp;
+    __shared__ double lds[5][4];
+    __shared__ double bcast;
+    double temp2;
+    if (ntp > 0) {
+        double sacc = 0.0;
+        for (int i = threadIdx.x; i < ntp; i += BLOCK) sacc += tp_partials[i];
+        sacc = block_sum(sacc, lds[0]);
+        if (threadIdx.x == 0) bcast = sacc;
+        __syncthreads();
+        temp2 = bcast;
+        if (temp2_out && blockIdx.x == 0 && threadIdx.x == 0) *temp2_out = temp2;
+    } else {
+        temp2 = *red_tp;
+    }
     const bool   ok = fabs(temp2) > 1e-40;
     const double alpha = ok ? temp1 / temp2 : 0.0;
-    double rr = 0.0, uu = 0.0, pp = 0.0, um = 0.0, nn = 0.0;
+    double q[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (ok) {
         for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
             const double pi = p[i];
@@ -508,27 +587,34 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const 
             const double ri = r[i] + (-alpha) * t[i];
             u[i] = ui;
             r[i] = ri;
-            rr += ri * ri;
+            q[0] += ri * ri;
             if (full_norms) {
-                uu += ui * ui;
-                pp += pi * pi;
-                um = fmax(um, fabs(ui));
-                nn += (ui != ui) ? 1.0 : 0.0;
+                q[1] += ui * ui;
+                q[2] += pi * pi;
+                q[3] = fmax(q[3], fabs(ui));
+                q[4] += (ui != ui) ? 1.0 : 0.0;
             }
         }
     }
-    const int G = gridDim.x;
-    double v = block_sum(rr, lds);
-    if (threadIdx.x == 0) partials[0 * G + blockIdx.x] = v;
-    if (full_norms) {
-        v = block_sum(uu, lds);
-        if (threadIdx.x == 0) partials[1 * G + blockIdx.x] = v;
-        v = block_sum(pp, lds);
-        if (threadIdx.x == 0) partials[2 * G + blockIdx.x] = v;
-        v = block_max(um, lds);
-        if (threadIdx.x == 0) partials[3 * G + blockIdx.x] = v;
-        v = block_sum(nn, lds);
-        if (threadIdx.x == 0) partials[4 * G + blockIdx.x] = v;
+    const int nq = full_norms ? 5 : 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    for (int k = 0; k < nq; ++k) {
+        double v = q[k];
+        if (k == 3) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+        } else {
+            v = subwave_sum<64>(v);
+        }
+        if (lane == 0) lds[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nq) {
+        const int k = threadIdx.x;
+        const double v = (k == 3) ? fmax(fmax(lds[k][0], lds[k][1]), fmax(lds[k][2], lds[k][3]))
+                                  : ((lds[k][0] + lds[k][1]) + lds[k][2]) + lds[k][3];
+        partials[k * gridDim.x + blockIdx.x] = v;
     }
 }
 

@@ -48,6 +48,8 @@ struct Ctx {
     int         device = -1;
     hipStream_t stream = nullptr;
     double*     d_partials = nullptr;  // 8 quantities x MAXGRID
+    double*     d_partials2 = nullptr; // second set (consumer kernels that read the first)
+    double*     h_part     = nullptr;  // pinned mirror of d_partials2
     double*     d_red      = nullptr;  // reduced scalars (device)
     double*     h_red      = nullptr;  // pinned host mirror
     int         num_cu     = 256;
@@ -80,6 +82,8 @@ static int ctx_init()
     g_ctx.device = dev;
     HIPCK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     HIPCK(hipMalloc(&g_ctx.d_partials, sizeof(double) * 8 * MAXGRID));
+    HIPCK(hipMalloc(&g_ctx.d_partials2, sizeof(double) * (8 * MAXGRID + 8)));
+    HIPCK(hipHostMalloc(&g_ctx.h_part, sizeof(double) * (8 * MAXGRID + 8), hipHostMallocDefault));
     HIPCK(hipMalloc(&g_ctx.d_red, sizeof(double) * RED_SLOTS));
     HIPCK(hipHostMalloc(&g_ctx.h_red, sizeof(double) * RED_SLOTS, hipHostMallocDefault));
     g_ctx.ready = true;
@@ -125,7 +129,7 @@ struct DevCSR {
 static void pick_kernel(DevCSR& M)
 {
     const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
-    M.kind = avg <= 48.0 ? 2 : 0;
+    M.kind = avg <= 48.0 ? 2 : 0;  // (kind 3, one workgroup per row, measured slower than L = 64: profiles/)
     M.lanes = avg < 128.0 ? 16 : avg < 300.0 ? 32 : 64;
     if (avg < 48.0) M.lanes = avg < 6.0 ? 4 : 8;  // only used when kind is forced to 0
     int R = 256;
@@ -149,7 +153,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int maxgrid = -1, xcd = 0, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1; };
+struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -194,7 +198,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
     a.xcd_map = g_tune.xcd;
     a.nt = g_tune.nt;
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
-    const int rpb = M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : BLOCK / M.lanes;
+    const int rpb = M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : M.kind == 3 ? 1 : BLOCK / M.lanes;
     a.ntiles = (M.row + rpb - 1) / rpb;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     if (M.kind == 2) {
@@ -203,6 +207,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
         if (M.wrows == 32 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 32, 512>, a.ntiles, a);
         return launch_persistent(k_csr_wstream<OP, 32, 1024>, a.ntiles, a);
     }
+    if (M.kind == 3) return launch_persistent(k_csr_blockrow<OP>, M.row, a);
     if (M.kind == 1) {
         int cap = g_tune.maxgrid > 0 ? g_tune.maxgrid : 4 * g_ctx.num_cu;
         int grid = std::max(8, (std::min(std::min(cap, MAXGRID), a.ntiles) + 7) / 8 * 8);
@@ -472,20 +477,27 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
     temp1 = red[0];
 
     while (iter++ < MaxIt) {
-        // t = A p fused with the partial sums of (t,p)
+        // t = A p fused with the partial sums of (t,p); the consumer sums the partials itself
+        // (the coarsest level is never distributed, so no all-reduce sits in between)
+        int gdot;
         {
             CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials;
-            const int gdot = launch_csr<OP_MXV_DOT>(A, a);
-            d_finalize(gdot, 1, 0u, 8);
+            gdot = launch_csr<OP_MXV_DOT>(A, a);
         }
-        // alpha on device; u += alpha p; r -= alpha t; norms of r, u, p; max|u|; NaN count
-        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, g_ctx.d_red + 8, p, t, u, r,
-                           g_ctx.d_partials, 1);
-        d_finalize(G, 5, 0x8u, 0);
-        HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * 9, hipMemcpyDeviceToHost, s));
+        // alpha on device; u += alpha p; r -= alpha t; norms of r, u, p; max|u|; NaN count.
+        // The G x 5 block partials and (t,p) travel to the host in one copy and are summed
+        // there in block order.
+        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, (const double*)nullptr,
+                           g_ctx.d_partials, gdot, p, t, u, r, g_ctx.d_partials2, 1, g_ctx.d_partials2 + 5 * G);
+        HIPCK(hipMemcpyAsync(g_ctx.h_part, g_ctx.d_partials2, sizeof(double) * (5 * G + 1), hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
-        for (int q = 0; q < 5; ++q) red[q] = g_ctx.h_red[q];
-        temp2 = g_ctx.h_red[8];
+        for (int q = 0; q < 5; ++q) {
+            double v = 0.0;
+            if (q == 3) { for (int i = 0; i < G; ++i) v = std::max(v, g_ctx.h_part[q * G + i]); }
+            else { for (int i = 0; i < G; ++i) v += g_ctx.h_part[q * G + i]; }
+            red[q] = v;
+        }
+        temp2 = g_ctx.h_part[5 * G];
         if (std::fabs(temp2) > SMALLREAL2) alpha = temp1 / temp2;
         else goto RESTORE_BESTSOL;
 
@@ -752,8 +764,8 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
             d_finalize(gdot, 1, 0u, 8);
         }
         // alpha = temp1/(t,p) on device; u += alpha p; r -= alpha t; partial ||r||^2
-        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, g_ctx.d_red + 8, p, t, u, r,
-                           g_ctx.d_partials, 0);
+        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, (const double*)(g_ctx.d_red + 8),
+                           (const double*)nullptr, 0, p, t, u, r, g_ctx.d_partials, 0, (double*)nullptr);
         d_finalize(G, 1, 0u, 0);
         HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * 9, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));

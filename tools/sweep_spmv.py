@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import faspsolver_amd as fa
 from faspsolver_amd import _types as T
 
-GRIDS = (512, 768, 1024, 1280, 1536, 1792, 2048)
+GRIDS = (-1,)
 NAMES = {0: "mxv", 1: "aAxpy-1", 2: "jacobi", 5: "mxv+dot", 6: "R mxv", 7: "P aAxpy"}
 
 def main():
@@ -31,6 +31,10 @@ def main():
             fams += [("ws 64/512", dict(kind=2, wrows=64, wcap=512)), ("ws 64/1024", dict(kind=2, wrows=64, wcap=1024)),
                      ("ws 32/512", dict(kind=2, wrows=32, wcap=512)), ("ws 32/1024", dict(kind=2, wrows=32, wcap=1024)),
                      ("ws 16/1024", dict(kind=2, wrows=16, wcap=1024))]
+        if avg > 300:
+            fams += [("blockrow", dict(kind=3))]
+        if avg <= 80:
+            fams = [(f"ws 64/512 G={g}", dict(kind=2, wrows=64, wcap=512, xcdg=g)) for g in (0, 2, 4, 8, 16, 32, 64, 128)] + [("vec L=4", dict(kind=0, lanes=4)), ("vec L=8", dict(kind=0, lanes=8))]
         for op in ops:
             if op in (6, 7) and l == H.num_levels - 1: continue
             for name, cfg in fams:
@@ -39,7 +43,8 @@ def main():
                     if (cfg.get("lanes") or 0) > 16 * max(avg, 1): continue
                 row = []
                 for g in GRIDS:
-                    tune(maxgrid=g, xcd=xcd, nt=1, **cfg)
+                    cfg2 = dict(cfg); xg = cfg2.pop("xcdg", xcd)
+                    tune(maxgrid=g, xcd=xg, nt=int(os.environ.get("SWEEP_NT", "1")), **cfg2)
                     row.append(H.time_kernel(op, l, 5) * 1e3)
                 print(f"  {NAMES[op]:8s} {name:11s} " + " ".join(f"{x:8.1f}" for x in row), flush=True)
     tune()
