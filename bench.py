@@ -29,6 +29,13 @@ import os
 import sys
 import time
 
+# torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the host-side AMG setup is
+# OpenMP code, so give each rank its share of the node's cores before any OpenMP runtime
+# is initialised (this must precede the numpy / torch imports).
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("BENCH_KEEP_OMP") is None:
+    _cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(32, _cores // int(os.environ["WORLD_SIZE"]))))
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -34,7 +34,9 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_precond_amg",
     "fasp_hip_poisson7pt", "fasp_hip_free_system", "fasp_hip_time_kernel",
     "fasp_hip_tune", "fasp_hip_comm_unique_id", "fasp_hip_comm_init", "fasp_hip_comm_finalize",
-    "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version",
+    "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version", "fasp_hip_comm_init_shm",
+    "fasp_hip_dist_plan", "fasp_hip_dist_level_info", "fasp_hip_dist_get_matrix",
+    "fasp_hip_dist_get_list",
 ]
 
 
@@ -97,6 +99,11 @@ def lib():
     L.fasp_hip_comm_unique_id.argtypes = [C.c_char_p]
     L.fasp_hip_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p]
     L.fasp_hip_version.restype = C.c_char_p
+    L.fasp_hip_comm_init_shm.argtypes = [C.c_int, C.c_int, C.c_char_p]
+    L.fasp_hip_dist_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.fasp_hip_dist_level_info.argtypes = [C.c_void_p, C.c_int, T.c_int_p]
+    L.fasp_hip_dist_get_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int, P(T.dCSRmat)]
+    L.fasp_hip_dist_get_list.argtypes = [C.c_void_p, C.c_int, C.c_int, P(T.ivector)]
     _lib = L
     return L
 
@@ -225,6 +232,34 @@ class AMG:
         if st < 0:
             raise RuntimeError(f"fasp_hip_precond_amg failed: {st}")
         return z
+
+    # --- row partition (host side) ---
+    def dist_plan(self, rank, nranks, min_rows):
+        st = lib().fasp_hip_dist_plan(self.h, rank, nranks, min_rows)
+        if st < 0:
+            raise RuntimeError(f"fasp_hip_dist_plan failed: {st}")
+
+    def dist_info(self, level):
+        info = (C.c_int * 8)()
+        if lib().fasp_hip_dist_level_info(self.h, level, info) < 0:
+            raise IndexError(level)
+        keys = ("replicated", "nglobal", "row0", "nloc", "nghost", "nsend", "first_replicated", "nranks")
+        return dict(zip(keys, list(info)))
+
+    def dist_matrix(self, level, which):
+        v = T.dCSRmat()
+        if lib().fasp_hip_dist_get_matrix(self.h, level, which, C.byref(v)) < 0:
+            raise IndexError((level, which))
+        ia, ja, val = T.csr_arrays(v)
+        return v.row, v.col, ia, ja, val
+
+    def dist_list(self, level, which):
+        v = T.ivector()
+        if lib().fasp_hip_dist_get_list(self.h, level, which, C.byref(v)) < 0:
+            raise IndexError((level, which))
+        if v.row == 0:
+            return np.zeros(0, np.int32)
+        return np.ctypeslib.as_array(v.val, (v.row,)).copy()
 
     def time_kernel(self, kind, level=0, reps=20):
         return lib().fasp_hip_time_kernel(self.h, kind, level, reps)

@@ -1,26 +1,48 @@
-// comm.cpp -- RCCL communicator (1-D row partition: halo exchange of x vectors with
-// the slab neighbours + scalar all-reduce of the Krylov dot products).  The reference
-// has no distributed path at all; this is new.
+// comm.cpp -- communicator of the multi-GPU path (1-D row partition: halo exchange of
+// vector entries with the slab neighbours, all-gather at the distributed -> replicated
+// level boundary, scalar all-reduce of the Krylov dot products).  The reference has no
+// distributed path at all; this is new.
+//
+// Two transports behind one interface:
+//   RCCL  (production): one process per GPU, grouped ncclSend/ncclRecv + ncclAllReduce on
+//         the compute stream, peer-to-peer over xGMI.  RCCL is dlopen'ed on first use so
+//         the single-GPU path does not depend on it.
+//   SHM   (validation): host-staged through a POSIX shared-memory segment.  It lets the
+//         whole distributed solver (partition, halo plans, replicated levels, replicated
+//         host control flow) be exercised by several processes that share ONE GPU, which
+//         is all the development box has.  Reductions are summed in rank order, so every
+//         rank obtains bit-identical scalars, exactly like an RCCL all-reduce.
 #include "fasp_comm.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "fasp_internal.h"
 
 namespace fasp {
 namespace {
 
+enum Backend { NONE = 0, RCCL = 1, SHM = 2 };
+Backend g_backend = NONE;
+int     g_rank = 0, g_size = 1;
+
+// ------------------------------------------------------------------ RCCL
 struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -30,7 +52,6 @@ struct Rccl {
 };
 Rccl       g_rccl;
 ncclComm_t g_comm = nullptr;
-int        g_rank = 0, g_size = 1;
 
 int load_rccl()
 {
@@ -54,7 +75,6 @@ int load_rccl()
     SYM(CommInitRank, "ncclCommInitRank")
     SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllReduce, "ncclAllReduce")
-    SYM(AllGather, "ncclAllGather")
     SYM(Broadcast, "ncclBroadcast")
     SYM(Send, "ncclSend")
     SYM(Recv, "ncclRecv")
@@ -75,6 +95,49 @@ int load_rccl()
         }                                                                                    \
     } while (0)
 
+#define HCK(expr)                                                                            \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            std::fprintf(stderr, "### ERROR: fasp_hip: %s failed: %s\n", #expr, hipGetErrorString(e_)); \
+            return ERROR_MISC;                                                               \
+        }                                                                                    \
+    } while (0)
+
+// ------------------------------------------------------------------ SHM
+constexpr size_t SHM_BOX_BYTES = 64u << 20;  // mailbox per rank
+struct ShmHeader {
+    std::atomic<int> arrive;
+    std::atomic<int> generation;
+    int              nranks;
+};
+struct ShmBoxHeader {
+    long long off[64];  // per destination: offset (in doubles) into this box's payload
+    long long cnt[64];
+};
+std::string g_shm_name;
+char*       g_shm_base = nullptr;
+size_t      g_shm_bytes = 0;
+double*     g_stage = nullptr;  // pinned host staging (SHM_BOX_BYTES)
+
+ShmHeader*    shm_hdr() { return reinterpret_cast<ShmHeader*>(g_shm_base); }
+char*         shm_box(int r) { return g_shm_base + 4096 + (size_t)r * SHM_BOX_BYTES; }
+ShmBoxHeader* box_hdr(int r) { return reinterpret_cast<ShmBoxHeader*>(shm_box(r)); }
+double*       box_data(int r) { return reinterpret_cast<double*>(shm_box(r) + sizeof(ShmBoxHeader)); }
+constexpr size_t box_cap() { return (SHM_BOX_BYTES - sizeof(ShmBoxHeader)) / sizeof(double); }
+
+void shm_barrier()
+{
+    ShmHeader* h = shm_hdr();
+    const int gen = h->generation.load(std::memory_order_acquire);
+    if (h->arrive.fetch_add(1, std::memory_order_acq_rel) == h->nranks - 1) {
+        h->arrive.store(0, std::memory_order_relaxed);
+        h->generation.store(gen + 1, std::memory_order_release);
+    } else {
+        while (h->generation.load(std::memory_order_acquire) == gen) usleep(20);
+    }
+}
+
 }  // namespace
 
 int comm_rank() { return g_rank; }
@@ -83,10 +146,28 @@ int comm_size() { return g_size; }
 int comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream)
 {
     if (g_size <= 1) return FASP_SUCCESS;
-    // contiguous runs of equal reduction op
+    if (g_backend == SHM) {
+        HCK(hipMemcpyAsync(g_stage, dbuf, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+        HCK(hipStreamSynchronize(stream));
+        std::memcpy(box_data(g_rank), g_stage, sizeof(double) * n);
+        shm_barrier();
+        for (int i = 0; i < n; ++i) {
+            const bool mx = (maxmask >> i) & 1u;
+            double v = mx ? 0.0 : 0.0;
+            for (int r = 0; r < g_size; ++r) {  // rank order: identical result on every rank
+                const double x = box_data(r)[i];
+                v = mx ? (x > v ? x : v) : v + x;
+            }
+            g_stage[i] = v;
+        }
+        shm_barrier();
+        HCK(hipMemcpyAsync(dbuf, g_stage, sizeof(double) * n, hipMemcpyHostToDevice, stream));
+        HCK(hipStreamSynchronize(stream));
+        return FASP_SUCCESS;
+    }
     int i = 0;
     NCK(g_rccl.GroupStart());
-    while (i < n) {
+    while (i < n) {  // contiguous runs of equal reduction op
         const bool mx = (maxmask >> i) & 1u;
         int j = i + 1;
         while (j < n && (((maxmask >> j) & 1u) != 0) == mx) ++j;
@@ -100,6 +181,39 @@ int comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream)
 int comm_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int nrecv, hipStream_t stream)
 {
     if (g_size <= 1) return FASP_SUCCESS;
+    if (g_backend == SHM) {
+        ShmBoxHeader* bh = box_hdr(g_rank);
+        size_t off = 0;
+        for (int q = 0; q < g_size; ++q) { bh->off[q] = 0; bh->cnt[q] = 0; }
+        for (int i = 0; i < nsend; ++i) {
+            if (off + sends[i].count > box_cap()) {
+                std::fprintf(stderr, "### ERROR: fasp_hip: shm mailbox too small\n");
+                return ERROR_MISC;
+            }
+            HCK(hipMemcpyAsync(g_stage + off, sends[i].buf, sizeof(double) * sends[i].count, hipMemcpyDeviceToHost, stream));
+            bh->off[sends[i].peer] = (long long)off;
+            bh->cnt[sends[i].peer] = (long long)sends[i].count;
+            off += sends[i].count;
+        }
+        HCK(hipStreamSynchronize(stream));
+        std::memcpy(box_data(g_rank), g_stage, sizeof(double) * off);
+        shm_barrier();
+        size_t roff = 0;
+        for (int i = 0; i < nrecv; ++i) {
+            const ShmBoxHeader* ph = box_hdr(recvs[i].peer);
+            if ((size_t)ph->cnt[g_rank] != recvs[i].count) {
+                std::fprintf(stderr, "### ERROR: fasp_hip: halo size mismatch: rank %d expects %zu from %d, offered %lld\n",
+                             g_rank, recvs[i].count, recvs[i].peer, ph->cnt[g_rank]);
+                return ERROR_MISC;
+            }
+            std::memcpy(g_stage + roff, box_data(recvs[i].peer) + ph->off[g_rank], sizeof(double) * recvs[i].count);
+            HCK(hipMemcpyAsync(recvs[i].buf, g_stage + roff, sizeof(double) * recvs[i].count, hipMemcpyHostToDevice, stream));
+            roff += recvs[i].count;
+        }
+        HCK(hipStreamSynchronize(stream));
+        shm_barrier();
+        return FASP_SUCCESS;
+    }
     NCK(g_rccl.GroupStart());
     for (int i = 0; i < nrecv; ++i)
         if (recvs[i].count) NCK(g_rccl.Recv(recvs[i].buf, recvs[i].count, ncclDouble, recvs[i].peer, g_comm, stream));
@@ -114,11 +228,26 @@ int comm_allgatherv(const double* sendbuf, int sendcount, double* recvbuf, const
 {
     if (g_size <= 1) {
         if (recvbuf + displs[0] != sendbuf)
-            (void)hipMemcpyAsync(recvbuf + displs[0], sendbuf, sizeof(double) * sendcount,
-                                 hipMemcpyDeviceToDevice, stream);
+            HCK(hipMemcpyAsync(recvbuf + displs[0], sendbuf, sizeof(double) * sendcount, hipMemcpyDeviceToDevice, stream));
         return FASP_SUCCESS;
     }
-    // allgatherv as a group of broadcasts (counts differ per rank)
+    if (g_backend == SHM) {
+        if ((size_t)sendcount > box_cap()) return ERROR_MISC;
+        HCK(hipMemcpyAsync(g_stage, sendbuf, sizeof(double) * sendcount, hipMemcpyDeviceToHost, stream));
+        HCK(hipStreamSynchronize(stream));
+        std::memcpy(box_data(g_rank), g_stage, sizeof(double) * sendcount);
+        shm_barrier();
+        for (int r = 0; r < g_size; ++r) {
+            if (r == g_rank || counts[r] == 0) continue;
+            HCK(hipMemcpy(recvbuf + displs[r], box_data(r), sizeof(double) * counts[r], hipMemcpyHostToDevice));
+        }
+        if (recvbuf + displs[g_rank] != sendbuf)
+            HCK(hipMemcpyAsync(recvbuf + displs[g_rank], sendbuf, sizeof(double) * sendcount, hipMemcpyDeviceToDevice, stream));
+        HCK(hipStreamSynchronize(stream));
+        shm_barrier();
+        return FASP_SUCCESS;
+    }
+    // all-gather with per-rank counts as a group of broadcasts
     NCK(g_rccl.GroupStart());
     for (int r = 0; r < g_size; ++r)
         if (counts[r])
@@ -147,24 +276,74 @@ int fasp_hip_comm_unique_id(char* id_out)
 
 int fasp_hip_comm_init(int rank, int nranks, const char* id_bytes)
 {
-    if (nranks <= 1) { g_rank = 0; g_size = 1; return FASP_SUCCESS; }
+    if (nranks <= 1) { g_rank = 0; g_size = 1; g_backend = NONE; return FASP_SUCCESS; }
     if (!id_bytes || rank < 0 || rank >= nranks) return ERROR_INPUT_PAR;
-    if (g_comm) return ERROR_INPUT_PAR;
+    if (g_backend != NONE) return ERROR_INPUT_PAR;
     if (load_rccl() < 0) return ERROR_MISC;
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, sizeof(id));
     NCK(g_rccl.CommInitRank(&g_comm, nranks, id, rank));
     g_rank = rank;
     g_size = nranks;
+    g_backend = RCCL;
+    return FASP_SUCCESS;
+}
+
+// Host-staged transport through the shared-memory segment /<name> (validation only).
+int fasp_hip_comm_init_shm(int rank, int nranks, const char* name)
+{
+    if (nranks <= 1) { g_rank = 0; g_size = 1; g_backend = NONE; return FASP_SUCCESS; }
+    if (!name || rank < 0 || rank >= nranks || nranks > 64 || g_backend != NONE) return ERROR_INPUT_PAR;
+    g_shm_name = std::string("/") + name;
+    g_shm_bytes = 4096 + (size_t)nranks * SHM_BOX_BYTES;
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(g_shm_name.c_str());
+        fd = shm_open(g_shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)g_shm_bytes) != 0) { std::perror("fasp_hip shm create"); return ERROR_MISC; }
+    } else {
+        for (int tries = 0; tries < 3000 && fd < 0; ++tries) {
+            fd = shm_open(g_shm_name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < g_shm_bytes)) { close(fd); fd = -1; }
+            if (fd < 0) usleep(10000);
+        }
+        if (fd < 0) { std::fprintf(stderr, "### ERROR: fasp_hip: cannot open shm segment %s\n", g_shm_name.c_str()); return ERROR_MISC; }
+    }
+    g_shm_base = (char*)mmap(nullptr, g_shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (g_shm_base == MAP_FAILED) { g_shm_base = nullptr; return ERROR_MISC; }
+    if (rank == 0) {
+        new (&shm_hdr()->arrive) std::atomic<int>(0);
+        new (&shm_hdr()->generation) std::atomic<int>(0);
+        shm_hdr()->nranks = nranks;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        reinterpret_cast<std::atomic<int>*>(g_shm_base + 2048)->store(0x5A5A, std::memory_order_release);
+    } else {
+        while (reinterpret_cast<std::atomic<int>*>(g_shm_base + 2048)->load(std::memory_order_acquire) != 0x5A5A) usleep(1000);
+    }
+    if (hipHostMalloc((void**)&g_stage, SHM_BOX_BYTES, hipHostMallocDefault) != hipSuccess) return ERROR_ALLOC_MEM;
+    g_rank = rank;
+    g_size = nranks;
+    g_backend = SHM;
+    shm_barrier();
     return FASP_SUCCESS;
 }
 
 int fasp_hip_comm_finalize(void)
 {
-    if (g_comm) {
+    if (g_backend == RCCL && g_comm) {
         NCK(g_rccl.CommDestroy(g_comm));
         g_comm = nullptr;
     }
+    if (g_backend == SHM && g_shm_base) {
+        shm_barrier();
+        munmap(g_shm_base, g_shm_bytes);
+        g_shm_base = nullptr;
+        if (g_rank == 0) shm_unlink(g_shm_name.c_str());
+        if (g_stage) { (void)hipHostFree(g_stage); g_stage = nullptr; }
+    }
+    g_backend = NONE;
     g_rank = 0;
     g_size = 1;
     return FASP_SUCCESS;

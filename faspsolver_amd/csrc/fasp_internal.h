@@ -85,6 +85,26 @@ struct HostHierarchy {
     double setup_seconds = 0.0;
 };
 
+// ---- 1-D row partition over the GPUs of a node (dist_plan.cpp) ----------------------
+struct DistLevel {
+    bool             replicated = true;  // every rank holds (and computes) the whole level
+    int              nglobal = 0;        // rows of the level
+    int              row0 = 0, nloc = 0; // owned rows [row0, row0 + nloc)  (replicated: all)
+    std::vector<int> start;              // nranks+1 ownership offsets of this level
+    std::vector<int> ghosts;             // sorted global ids of halo entries of this level's vectors
+    std::vector<int> recv_off;           // nranks+1: ghosts[recv_off[q] .. recv_off[q+1]) come from rank q
+    std::vector<int> send_off;           // nranks+1 offsets into send_idx
+    std::vector<int> send_idx;           // local ids (0..nloc) to send, grouped by destination rank
+    HostCSR          A, P, R;            // local rows, local column numbering (distributed levels only)
+};
+struct DistPlan {
+    int                    rank = 0, nranks = 1;
+    int                    first_replicated = 0;  // levels >= this are replicated
+    std::vector<DistLevel> L;
+};
+// Levels with fewer than min_rows rows are replicated.  Pure host code.
+int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, DistPlan& D);
+
 // Classical (Ruge-Stuben) AMG setup, host side.  Restates PreAMGSetupRS.c:52
 // (+ PreAMGCoarsenRS.c, PreAMGInterp.c, BlaSparseCSR.c transposes, BlaSpmvCSR.c RAP)
 // with the reference's serial arithmetic and ordering, parallelised only where the

@@ -247,11 +247,11 @@ static void d_aAxpy(double alpha, const DevCSR& A, const double* x, double* y)
 
 // --- reductions ----------------------------------------------------------------
 // local partials -> d_red[slot .. slot+nq) -> (all-reduce over ranks) .  Host copy on demand.
-static void d_finalize(int G, int nq, unsigned maxmask, int slot)
+static void d_finalize(int G, int nq, unsigned maxmask, int slot, bool dist)
 {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, g_ctx.stream, g_ctx.d_partials, G, nq,
                        maxmask, g_ctx.d_red + slot);
-    if (comm_size() > 1) comm_allreduce(g_ctx.d_red + slot, nq, maxmask, g_ctx.stream);
+    if (dist && comm_size() > 1) comm_allreduce(g_ctx.d_red + slot, nq, maxmask, g_ctx.stream);
 }
 static int fetch_red(int slot, int nq, double* out)
 {
@@ -261,19 +261,19 @@ static int fetch_red(int slot, int nq, double* out)
     for (int q = 0; q < nq; ++q) out[q] = g_ctx.h_red[slot + q];
     return FASP_SUCCESS;
 }
-static int d_dot(int n, const double* x, const double* y, double* out)
+static int d_dot(int n, const double* x, const double* y, double* out, bool dist = false)
 {
     const int G = vec_grid(n);
     hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, g_ctx.stream, n, x, y, g_ctx.d_partials);
-    d_finalize(G, 1, 0u, 0);
+    d_finalize(G, 1, 0u, 0, dist);
     return fetch_red(0, 1, out);
 }
 // out[0] = sum x^2, out[1] = max |x|
-static int d_norms(int n, const double* x, double* out)
+static int d_norms(int n, const double* x, double* out, bool dist = false)
 {
     const int G = vec_grid(n);
     hipLaunchKernelGGL(k_norms, dim3(G), dim3(BLOCK), 0, g_ctx.stream, n, x, g_ctx.d_partials);
-    d_finalize(G, 2, 0x2u, 0);
+    d_finalize(G, 2, 0x2u, 0, dist);
     return fetch_red(0, 2, out);
 }
 static void d_axpy(int n, double a, const double* x, double* y)
@@ -297,6 +297,16 @@ struct DevLevel {
     double* xo = nullptr;    // the other buffer
     bool    x_zero = true;   // x is (conceptually) all zeros and not materialised
     bool    owns_b = true;
+    // distribution (single GPU: nloc == nvec == rows, no halo)
+    bool    replicated = true;   // whole level on every rank, computed redundantly
+    int     nloc = 0;            // owned entries of this level's vectors
+    int     nvec = 0;            // vector length incl. ghost entries [nloc, nvec)
+    int     row0 = 0;            // global index of the first owned row
+    int     nglobal = 0;
+    std::vector<int> send_off, recv_off;  // nranks+1 each
+    int*    d_send_idx = nullptr;
+    double* d_sendbuf  = nullptr;
+    bool    has_halo() const { return !replicated && nvec > nloc; }
 };
 
 struct EventPair { hipEvent_t a, b; };
@@ -307,6 +317,8 @@ using namespace fasp;
 
 struct fasp_hip_amg {
     HostHierarchy         H;
+    DistPlan              dist;        // row partition (nranks == 1: trivial)
+    bool                  distributed = false;  // level 0 is row-partitioned over the ranks
     std::vector<DevLevel> L;
     AMG_param             param;  // copy of the user's parameters after setup
     // Krylov work vectors on level 0
@@ -331,6 +343,8 @@ static void free_level(DevLevel& D)
     if (D.xa) (void)hipFree(D.xa);
     if (D.xb) (void)hipFree(D.xb);
     if (D.w) (void)hipFree(D.w);
+    if (D.d_send_idx) (void)hipFree(D.d_send_idx);
+    if (D.d_sendbuf) (void)hipFree(D.d_sendbuf);
     D = DevLevel();
 }
 
@@ -367,36 +381,87 @@ static int upload_diag(const HostCSR& A, DevLevel& D)
     return FASP_SUCCESS;
 }
 
+// gather v[idx[i]] into a contiguous send buffer
+__global__ __launch_bounds__(BLOCK) void k_pack(int n, const int* __restrict__ idx,
+                                                 const double* __restrict__ v, double* __restrict__ out)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) out[i] = v[idx[i]];
+}
+
+// Refresh the ghost entries [nloc, nvec) of a level-l vector from their owners: pack the
+// entries the peers need, one grouped RCCL send/recv, receive straight into the ghost
+// slots (ghosts are sorted by owner, so every peer's block is contiguous).
+static int halo_exchange(DevLevel& D, double* v)
+{
+    if (!D.has_halo() && (D.send_off.empty() || D.send_off.back() == 0)) return FASP_SUCCESS;
+    const int P = comm_size(), me = comm_rank();
+    const int nsend = D.send_off.back();
+    if (nsend > 0)
+        hipLaunchKernelGGL(k_pack, dim3(vec_grid(nsend)), dim3(BLOCK), 0, g_ctx.stream, nsend, D.d_send_idx, v,
+                           D.d_sendbuf);
+    std::vector<CommXfer> sends, recvs;
+    for (int q = 0; q < P; ++q) {
+        if (q == me) continue;
+        const int ns = D.send_off[q + 1] - D.send_off[q], nr = D.recv_off[q + 1] - D.recv_off[q];
+        if (ns > 0) sends.push_back({q, D.d_sendbuf + D.send_off[q], (size_t)ns});
+        if (nr > 0) recvs.push_back({q, v + D.nloc + D.recv_off[q], (size_t)nr});
+    }
+    return comm_exchange(sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size(), g_ctx.stream);
+}
+
 static int upload_hierarchy(fasp_hip_amg* h)
 {
     const double t0 = wall_seconds();
     const int nl = (int)h->H.L.size();
     h->L.resize(nl);
+    int min_rows = 200000;
+    if (const char* e = std::getenv("FASP_HIP_DIST_MIN_ROWS")) min_rows = std::atoi(e);
+    {
+        const int st = build_dist_plan(h->H, comm_rank(), comm_size(), min_rows, h->dist);
+        if (st < 0) return st;
+    }
+    h->distributed = !h->dist.L[0].replicated;
     for (int l = 0; l < nl; ++l) {
         const HostLevel& HL = h->H.L[l];
+        const DistLevel& DL = h->dist.L[l];
         DevLevel& D = h->L[l];
-        if (upload_csr(HL.A, D.A) < 0) return ERROR_ALLOC_MEM;
+        D.replicated = DL.replicated;
+        D.nloc = DL.nloc; D.row0 = DL.row0; D.nglobal = DL.nglobal;
+        D.nvec = DL.replicated ? DL.nglobal : DL.nloc + (int)DL.ghosts.size();
+        const HostCSR& A = DL.replicated ? HL.A : DL.A;
+        if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;
         if (HL.has_coarse) {
-            if (upload_csr(HL.P, D.P) < 0) return ERROR_ALLOC_MEM;
-            if (upload_csr(HL.R, D.R) < 0) return ERROR_ALLOC_MEM;
+            if (upload_csr(DL.replicated ? HL.P : DL.P, D.P) < 0) return ERROR_ALLOC_MEM;
+            if (upload_csr(DL.replicated ? HL.R : DL.R, D.R) < 0) return ERROR_ALLOC_MEM;
         }
         HIPCK(hipStreamSynchronize(g_ctx.stream));
-        if (upload_diag(HL.A, D) < 0) return ERROR_ALLOC_MEM;
-        const size_t n = HL.A.row;
+        if (upload_diag(A, D) < 0) return ERROR_ALLOC_MEM;
+        const size_t n = D.nvec;
         if (l > 0) { if (alloc_vec(&D.b, n) < 0) return ERROR_ALLOC_MEM; }
         else D.owns_b = false;  // level-0 rhs aliases the Krylov residual (PreCSR.c:429 copy elided)
         if (alloc_vec(&D.xa, n) < 0 || alloc_vec(&D.xb, n) < 0 || alloc_vec(&D.w, n) < 0) return ERROR_ALLOC_MEM;
         D.x = D.xa; D.xo = D.xb; D.x_zero = true;
+        if (!DL.replicated) {
+            D.send_off = DL.send_off; D.recv_off = DL.recv_off;
+            const size_t ns = DL.send_idx.size();
+            HIPCK(hipMalloc(&D.d_send_idx, sizeof(int) * std::max<size_t>(ns, 1)));
+            HIPCK(hipMalloc(&D.d_sendbuf, sizeof(double) * std::max<size_t>(ns, 1)));
+            if (ns) HIPCK(hipMemcpy(D.d_send_idx, DL.send_idx.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
+        }
     }
-    const size_t m = h->H.L[0].A.row;
+    const size_t m = h->L[0].nvec;
     if (alloc_vec(&h->b, m) < 0 || alloc_vec(&h->u, m) < 0 || alloc_vec(&h->p, m) < 0 ||
         alloc_vec(&h->t, m) < 0 || alloc_vec(&h->r, m) < 0) return ERROR_ALLOC_MEM;
-    const size_t mc = h->H.L[nl - 1].A.row;
+    HIPCK(hipMemsetAsync(h->u, 0, sizeof(double) * m, g_ctx.stream));
+    HIPCK(hipMemsetAsync(h->p, 0, sizeof(double) * m, g_ctx.stream));
+    const size_t mc = h->L[nl - 1].nvec;
     if (alloc_vec(&h->cp, mc) < 0 || alloc_vec(&h->cr, mc) < 0 || alloc_vec(&h->ct, mc) < 0 ||
         alloc_vec(&h->cbest, mc) < 0) return ERROR_ALLOC_MEM;
     h->ev.resize(64);
     for (auto& e : h->ev) { HIPCK(hipEventCreate(&e.a)); HIPCK(hipEventCreate(&e.b)); }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
+    // the local copies of the partitioned operators are only needed for the upload
+    for (auto& DL : h->dist.L) { DL.A = HostCSR(); DL.P = HostCSR(); DL.R = HostCSR(); }
     h->upload_seconds = wall_seconds() - t0;
     return FASP_SUCCESS;
 }
@@ -408,7 +473,7 @@ static int upload_hierarchy(fasp_hip_amg* h)
 static void materialise_zero(DevLevel& D)
 {
     if (D.x_zero) {
-        (void)hipMemsetAsync(D.x, 0, sizeof(double) * D.A.row, g_ctx.stream);
+        (void)hipMemsetAsync(D.x, 0, sizeof(double) * D.nvec, g_ctx.stream);
         D.x_zero = false;
     }
 }
@@ -427,6 +492,7 @@ static void smooth(DevLevel& D, int smoother, int nsweeps, double relax)
             D.x_zero = false;
             continue;
         }
+        (void)halo_exchange(D, D.x);
         CsrArgs a{};
         a.x = D.x; a.y = D.xo; a.b = D.b; a.omega = relax;
         if (smoother == SMOOTHER_JACOBI) { a.diag = D.diag; launch_csr<OP_JACOBI>(D.A, a); }
@@ -590,9 +656,25 @@ ForwardSweep:
         if (D.x_zero) {
             HIPCK(hipMemcpyAsync(D.w, D.b, sizeof(double) * D.A.row, hipMemcpyDeviceToDevice, g_ctx.stream));
         } else {
+            if (halo_exchange(D, D.x) < 0) return ERROR_MISC;
             d_resid(D.A, D.x, D.b, D.w);
         }
-        d_mxv(D.R, D.w, h->L[l + 1].b);
+        if (halo_exchange(D, D.w) < 0) return ERROR_MISC;
+        {
+            DevLevel& C = h->L[l + 1];
+            if (!D.replicated && C.replicated) {
+                // first replicated level: every rank restricts onto the coarse rows it owns,
+                // one all-gather assembles the whole right-hand side on every rank
+                const std::vector<int>& cs = h->dist.L[l + 1].start;
+                std::vector<int> counts(comm_size());
+                for (int q = 0; q < comm_size(); ++q) counts[q] = cs[q + 1] - cs[q];
+                d_mxv(D.R, D.w, C.b + cs[comm_rank()]);
+                if (comm_allgatherv(C.b + cs[comm_rank()], counts[comm_rank()], C.b, counts.data(), cs.data(),
+                                    g_ctx.stream) < 0) return ERROR_MISC;
+            } else {
+                d_mxv(D.R, D.w, C.b);
+            }
+        }
         ++l;
         h->L[l].x_zero = true;  // fasp_dvec_set(x_{l}, 0): materialised lazily
     }
@@ -612,6 +694,7 @@ ForwardSweep:
         --l;
         DevLevel& D = h->L[l];
         materialise_zero(D);
+        if (halo_exchange(h->L[l + 1], h->L[l + 1].x) < 0) return ERROR_MISC;
         d_aAxpy(1.0, D.P, h->L[l + 1].x, D.x);  // x_l += P x_{l+1}  (coarse_scaling OFF: alpha = 1)
         smooth(D, smoother, param.postsmooth_iter, relax);
         if (num_lvl[l] < ncycles[l]) break;
@@ -678,7 +761,8 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
                       int PrtLvl, Hist& hist, PcgOut& out)
 {
     const DevCSR& A = h->L[0].A;
-    const int m = A.row;
+    const int m = A.row;             // owned rows
+    const bool dist = h->distributed; // reductions are all-reduced over the ranks
     const double maxdiff = tol * STAG_RATIO, sol_inf_tol = SMALLREAL;
     int iter = 0, stag = 1, more_step = 1;
     double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL, normr0 = BIGREAL;
@@ -698,18 +782,18 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
     auto resnorm = [&](double rr_known, bool have_rr) -> int {
         switch (StopType) {
             case STOP_REL_RES:
-                if (!have_rr) { if (d_dot(m, r, r, red) < 0) return ERROR_MISC; rr_known = red[0]; }
+                if (!have_rr) { if (d_dot(m, r, r, red, dist) < 0) return ERROR_MISC; rr_known = red[0]; }
                 absres = std::sqrt(rr_known);
                 relres = absres / normr0;
                 break;
             case STOP_REL_PRECRES:
                 if ((st = apply_pc()) < 0) return st;
-                if (d_dot(m, z, r, red) < 0) return ERROR_MISC;
+                if (d_dot(m, z, r, red, dist) < 0) return ERROR_MISC;
                 absres = std::sqrt(std::fabs(red[0]));
                 relres = absres / normr0;
                 break;
             case STOP_MOD_REL_RES:
-                if (!have_rr) { if (d_dot(m, r, r, red) < 0) return ERROR_MISC; rr_known = red[0]; }
+                if (!have_rr) { if (d_dot(m, r, r, red, dist) < 0) return ERROR_MISC; rr_known = red[0]; }
                 absres = std::sqrt(rr_known);
                 relres = absres / normu;
                 break;
@@ -719,25 +803,25 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
 
     if (PrtLvl > PRINT_NONE) std::printf("\nCalling CG solver (CSR) ...\n");
 
-    d_resid(A, u, b, r);  // r = b - A u
+    { if (halo_exchange(h->L[0], u) < 0) return ERROR_MISC; d_resid(A, u, b, r); }  // r = b - A u
     if ((st = apply_pc()) < 0) return st;
     switch (StopType) {
         case STOP_REL_RES:
-            if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+            if (d_dot(m, r, r, red, dist) < 0) return ERROR_MISC;
             absres0 = std::sqrt(red[0]);
             normr0  = std::max(SMALLREAL, absres0);
             relres  = absres0 / normr0;
             break;
         case STOP_REL_PRECRES:
-            if (d_dot(m, r, z, red) < 0) return ERROR_MISC;
+            if (d_dot(m, r, z, red, dist) < 0) return ERROR_MISC;
             absres0 = std::sqrt(red[0]);
             normr0  = std::max(SMALLREAL, absres0);
             relres  = absres0 / normr0;
             break;
         case STOP_MOD_REL_RES:
-            if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+            if (d_dot(m, r, r, red, dist) < 0) return ERROR_MISC;
             absres0 = std::sqrt(red[0]);
-            if (d_dot(m, u, u, red) < 0) return ERROR_MISC;
+            if (d_dot(m, u, u, red, dist) < 0) return ERROR_MISC;
             normu  = std::max(SMALLREAL, std::sqrt(red[0]));
             relres = absres0 / normu;
             break;
@@ -750,23 +834,24 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
 
     itinfo(PrtLvl, StopType, iter, relres, absres0, 0.0);
     HIPCK(hipMemcpyAsync(p, z, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
-    if (d_dot(m, z, r, red) < 0) return ERROR_MISC;
+    if (d_dot(m, z, r, red, dist) < 0) return ERROR_MISC;
     temp1 = red[0];
 
     while (iter++ < MaxIt) {
         // t = A p with the partial sums of (t,p); timed for the roofline report
         {
+            if (halo_exchange(h->L[0], p) < 0) return ERROR_MISC;
             CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials;
             EventPair* ep = h->ev_used < (int)h->ev.size() ? &h->ev[h->ev_used++] : nullptr;
             if (ep) (void)hipEventRecord(ep->a, s);
             const int gdot = launch_csr<OP_MXV_DOT>(A, a);
             if (ep) (void)hipEventRecord(ep->b, s);
-            d_finalize(gdot, 1, 0u, 8);
+            d_finalize(gdot, 1, 0u, 8, dist);
         }
         // alpha = temp1/(t,p) on device; u += alpha p; r -= alpha t; partial ||r||^2
         hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, (const double*)(g_ctx.d_red + 8),
                            (const double*)nullptr, 0, p, t, u, r, g_ctx.d_partials, 0, (double*)nullptr);
-        d_finalize(G, 1, 0u, 0);
+        d_finalize(G, 1, 0u, 0, dist);
         HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * 9, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
         temp2 = g_ctx.h_red[8];
@@ -782,7 +867,7 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
         hist.push(absres);
 
         if (factor > 0.9) {  // Check I / II, only when converging slowly
-            if (d_norms(m, u, red) < 0) return ERROR_MISC;
+            if (d_norms(m, u, red, dist) < 0) return ERROR_MISC;
             if (red[1] <= sol_inf_tol) {
                 if (PrtLvl > PRINT_MIN)
                     std::printf("### WARNING: Iteration stopped -- solution almost zero! [%s:%d]\n",
@@ -791,7 +876,7 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
                 break;
             }
             normu = std::sqrt(red[0]);
-            if (d_dot(m, p, p, red) < 0) return ERROR_MISC;
+            if (d_dot(m, p, p, red, dist) < 0) return ERROR_MISC;
             reldiff = std::fabs(alpha) * std::sqrt(red[0]) / normu;
             if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {
                 if (PrtLvl >= PRINT_MORE) {
@@ -799,7 +884,7 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
                     std::printf("### WARNING: Iteration restarted -- stagnation! [%s:%d]\n",
                                 "fasp_solver_dcsr_pcg", 232);
                 }
-                d_resid(A, u, b, r);
+                { if (halo_exchange(h->L[0], u) < 0) return ERROR_MISC; d_resid(A, u, b, r); }
                 if ((st = resnorm(0.0, false)) < 0) return st;
                 if (PrtLvl >= PRINT_MORE)
                     std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
@@ -818,7 +903,7 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
 
         if (relres < tol) {  // Check III: prevent false convergence
             const double updated_relres = relres;
-            d_resid(A, u, b, r);
+            { if (halo_exchange(h->L[0], u) < 0) return ERROR_MISC; d_resid(A, u, b, r); }
             if ((st = resnorm(0.0, false)) < 0) return st;
             if (relres < tol) break;
             if (PrtLvl >= PRINT_MORE) {
@@ -839,7 +924,7 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
         absres0 = absres;
         if (StopType != STOP_REL_PRECRES)
             if ((st = apply_pc()) < 0) return st;
-        if (d_dot(m, z, r, red) < 0) return ERROR_MISC;
+        if (d_dot(m, z, r, red, dist) < 0) return ERROR_MISC;
         temp2 = red[0];
         beta  = temp2 / temp1;
         temp1 = temp2;
@@ -965,9 +1050,9 @@ int fasp_hip_amg_get_cfmark(const fasp_hip_amg* h, int level, ivector* view)
 int fasp_hip_set_rhs(fasp_hip_amg* h, const dvector* b)
 {
     if (!h || !b || h->L.empty()) return ERROR_INPUT_PAR;
-    const int m = h->L[0].A.row;
-    if (b->row != m) return ERROR_MAT_SIZE;
-    HIPCK(hipMemcpyAsync(h->b, b->val, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
+    const DevLevel& D0 = h->L[0];
+    if (b->row != D0.nglobal) return ERROR_MAT_SIZE;  // host vectors are global; a rank uploads its rows
+    HIPCK(hipMemcpyAsync(h->b, b->val + D0.row0, sizeof(double) * D0.nloc, hipMemcpyHostToDevice, g_ctx.stream));
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     return FASP_SUCCESS;
 }
@@ -975,12 +1060,12 @@ int fasp_hip_set_rhs(fasp_hip_amg* h, const dvector* b)
 int fasp_hip_set_guess(fasp_hip_amg* h, const dvector* x)
 {
     if (!h || h->L.empty()) return ERROR_INPUT_PAR;
-    const int m = h->L[0].A.row;
+    const DevLevel& D0 = h->L[0];
     if (x) {
-        if (x->row != m) return ERROR_MAT_SIZE;
-        HIPCK(hipMemcpyAsync(h->u, x->val, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
+        if (x->row != D0.nglobal) return ERROR_MAT_SIZE;
+        HIPCK(hipMemcpyAsync(h->u, x->val + D0.row0, sizeof(double) * D0.nloc, hipMemcpyHostToDevice, g_ctx.stream));
     } else {
-        HIPCK(hipMemsetAsync(h->u, 0, sizeof(double) * m, g_ctx.stream));
+        HIPCK(hipMemsetAsync(h->u, 0, sizeof(double) * D0.nvec, g_ctx.stream));
     }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     return FASP_SUCCESS;
@@ -989,9 +1074,9 @@ int fasp_hip_set_guess(fasp_hip_amg* h, const dvector* x)
 int fasp_hip_get_solution(fasp_hip_amg* h, dvector* x)
 {
     if (!h || !x || h->L.empty()) return ERROR_INPUT_PAR;
-    const int m = h->L[0].A.row;
-    if (x->row != m) return ERROR_MAT_SIZE;
-    HIPCK(hipMemcpyAsync(x->val, h->u, sizeof(double) * m, hipMemcpyDeviceToHost, g_ctx.stream));
+    const DevLevel& D0 = h->L[0];
+    if (x->row != D0.nglobal) return ERROR_MAT_SIZE;  // a rank fills the rows it owns
+    HIPCK(hipMemcpyAsync(x->val + D0.row0, h->u, sizeof(double) * D0.nloc, hipMemcpyDeviceToHost, g_ctx.stream));
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     return FASP_SUCCESS;
 }
@@ -1066,13 +1151,54 @@ int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_para
 int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z)
 {
     if (!h || !r || !z || h->L.empty()) return ERROR_INPUT_PAR;
-    const int m = h->L[0].A.row;
+    const int m = h->L[0].nloc;
+    r += h->L[0].row0; z += h->L[0].row0;  // global host vectors, own rows
     HIPCK(hipMemcpyAsync(h->r, r, sizeof(double) * m, hipMemcpyHostToDevice, g_ctx.stream));
     double* dz = nullptr;
     const int st = precond_amg(h, h->r, &dz);
     if (st < 0) return st;
     HIPCK(hipMemcpyAsync(z, dz, sizeof(double) * m, hipMemcpyDeviceToHost, g_ctx.stream));
     HIPCK(hipStreamSynchronize(g_ctx.stream));
+    return FASP_SUCCESS;
+}
+
+// ---- row-partition inspection (host only; used by the CPU-side distributed tests) ----
+int fasp_hip_dist_plan(fasp_hip_amg* h, int rank, int nranks, int min_rows)
+{
+    if (!h) return ERROR_INPUT_PAR;
+    return build_dist_plan(h->H, rank, nranks, min_rows, h->dist);
+}
+
+int fasp_hip_dist_level_info(const fasp_hip_amg* h, int level, int* info)
+{
+    if (!h || !info || level < 0 || level >= (int)h->dist.L.size()) return ERROR_INPUT_PAR;
+    const DistLevel& D = h->dist.L[level];
+    info[0] = D.replicated; info[1] = D.nglobal; info[2] = D.row0; info[3] = D.nloc;
+    info[4] = (int)D.ghosts.size(); info[5] = (int)D.send_idx.size();
+    info[6] = h->dist.first_replicated; info[7] = h->dist.nranks;
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_dist_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view)
+{
+    if (!h || !view || level < 0 || level >= (int)h->dist.L.size()) return ERROR_INPUT_PAR;
+    const DistLevel& D = h->dist.L[level];
+    if (D.replicated) return fasp_hip_amg_get_matrix(h, level, which, view);
+    const HostCSR& M = which == 0 ? D.A : which == 1 ? D.P : D.R;
+    if (!M.ia.data()) return ERROR_INPUT_PAR;
+    *view = M.view();
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_dist_get_list(const fasp_hip_amg* h, int level, int which, ivector* view)
+{
+    if (!h || !view || level < 0 || level >= (int)h->dist.L.size()) return ERROR_INPUT_PAR;
+    const DistLevel& D = h->dist.L[level];
+    const std::vector<int>* v = which == 0 ? &D.ghosts : which == 1 ? &D.recv_off : which == 2 ? &D.send_off
+                              : which == 3 ? &D.send_idx : which == 4 ? &D.start : nullptr;
+    if (!v) return ERROR_INPUT_PAR;
+    view->row = (int)v->size();
+    view->val = const_cast<int*>(v->data());
     return FASP_SUCCESS;
 }
 

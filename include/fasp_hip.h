@@ -344,6 +344,21 @@ int fasp_hip_tune(const char* key, int value);
 int fasp_hip_comm_unique_id(char* id_out);
 int fasp_hip_comm_init(int rank, int nranks, const char* id);
 int fasp_hip_comm_finalize(void);
+/* Validation transport: host-staged through the POSIX shared-memory segment /<name>, so
+ * several processes sharing ONE GPU can run the distributed solver (tests only). */
+int fasp_hip_comm_init_shm(int rank, int nranks, const char* name);
+
+/* Row partition of a hierarchy over `nranks` GPUs as rank `rank` sees it (host only; levels
+ * with fewer than min_rows rows are replicated).  fasp_hip_amg_upload() builds the same
+ * plan from the communicator; these entry points expose it to tests.
+ * info = {replicated, nglobal, row0, nloc, nghost, nsend, first_replicated_level, nranks};
+ * get_matrix: the rank's local rows of A (0) / P (1) / R (2) in local column numbering;
+ * get_list:   0 ghost global ids, 1 recv offsets, 2 send offsets, 3 send local ids,
+ *             4 ownership offsets of the level. */
+int fasp_hip_dist_plan(fasp_hip_amg* h, int rank, int nranks, int min_rows);
+int fasp_hip_dist_level_info(const fasp_hip_amg* h, int level, int* info);
+int fasp_hip_dist_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view);
+int fasp_hip_dist_get_list(const fasp_hip_amg* h, int level, int which, ivector* view);
 int fasp_hip_comm_rank(void);
 int fasp_hip_comm_size(void);
 
