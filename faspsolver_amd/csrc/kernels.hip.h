@@ -618,6 +618,42 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const 
     }
 }
 
+// One modified-Gram-Schmidt step of GMRES (KryPvgmres.c:228-231) fused with the NEXT
+// reduction:  p_i += (-h) p_j  with h = *h_ptr (the dot product produced on the device by
+// the previous step), then the partial sums of (p_next, p_i) -- or of (p_i, p_i) when
+// p_next == nullptr (the norm that ends the orthogonalisation, :232).  The whole chain of
+// i dependent dot -> axpy pairs runs without a host round trip.
+__global__ __launch_bounds__(BLOCK) void k_mgs_step(int n, const double* __restrict__ h_ptr,
+                                                     const double* __restrict__ pj, double* __restrict__ pi,
+                                                     const double* __restrict__ pnext,
+                                                     double* __restrict__ partials)
+{
+    __shared__ double lds[4];
+    const double a = -(*h_ptr);
+    double acc = 0.0;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double v = pi[i] + a * pj[i];
+        pi[i] = v;
+        acc += (pnext ? pnext[i] : v) * v;
+    }
+    const double tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// x *= a  (fasp_blas_darray_ax, BlaArray.c:43; the caller skips a == 1)
+__global__ __launch_bounds__(BLOCK) void k_scale(int n, double a, double* __restrict__ x)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) x[i] *= a;
+}
+// y += a*y  (fasp_blas_darray_axpy called with x == y, KryPvgmres.c:395,398)
+__global__ __launch_bounds__(BLOCK) void k_axpy_self(int n, double a, double* __restrict__ y)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double v = y[i];
+        y[i] = v + a * v;
+    }
+}
+
 // norms of one vector: q0 = x.x, q1 = max|x|
 __global__ __launch_bounds__(BLOCK) void k_norms(int n, const double* __restrict__ x,
                                                   double* __restrict__ partials)

@@ -247,11 +247,15 @@ static void d_aAxpy(double alpha, const DevCSR& A, const double* x, double* y)
 
 // --- reductions ----------------------------------------------------------------
 // local partials -> d_red[slot .. slot+nq) -> (all-reduce over ranks) .  Host copy on demand.
-static void d_finalize(int G, int nq, unsigned maxmask, int slot, bool dist)
+static void d_finalize_to(int G, int nq, unsigned maxmask, double* out, bool dist)
 {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, g_ctx.stream, g_ctx.d_partials, G, nq,
-                       maxmask, g_ctx.d_red + slot);
-    if (dist && comm_size() > 1) comm_allreduce(g_ctx.d_red + slot, nq, maxmask, g_ctx.stream);
+                       maxmask, out);
+    if (dist && comm_size() > 1) comm_allreduce(out, nq, maxmask, g_ctx.stream);
+}
+static void d_finalize(int G, int nq, unsigned maxmask, int slot, bool dist)
+{
+    d_finalize_to(G, nq, maxmask, g_ctx.d_red + slot, dist);
 }
 static int fetch_red(int slot, int nq, double* out)
 {
@@ -325,6 +329,10 @@ struct fasp_hip_amg {
     double *b = nullptr, *u = nullptr, *p = nullptr, *t = nullptr, *r = nullptr;
     // coarse-level SPCG work vectors
     double *cp = nullptr, *cr = nullptr, *ct = nullptr, *cbest = nullptr;
+    // GMRES basis vectors (allocated on first use): level-0 set and coarse-level set
+    std::vector<double*> gm[2];
+    size_t               gm_len[2] = {0, 0};
+    double*              gm_hh = nullptr;  // device Hessenberg column
     // instrumentation
     std::vector<EventPair> ev;
     int                    ev_used = 0;
@@ -629,6 +637,315 @@ FINISHED:
     return iter;
 }
 
+// forward declarations (the coarse fallback and the preconditioner call each other's owners)
+static int precond_amg(fasp_hip_amg* h, double* r, double** z);
+static void itinfo(int ptrlvl, int stop_type, int iter, double relres, double absres, double factor);
+struct PcgOut { double relres, absres, normr0; };
+struct Hist {
+    double* h; int cap; int n;
+    void push(double v) { if (h && n < cap) h[n] = v; ++n; }
+};
+
+static void d_scale(int n, double a, double* x)
+{
+    if (a == 1.0) return;  // BlaArray.c:46
+    hipLaunchKernelGGL(k_scale, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, a, x);
+}
+
+// ---------------------------------------------------------------------------
+// Variable-restart right-preconditioned GMRES family on device vectors:
+//   mode 0  fasp_solver_dcsr_pvgmres    KryPvgmres.c:66-412
+//   mode 1  fasp_solver_dcsr_pvfgmres   KryPvfgmres.c:67-384   (flexible)
+//   mode 2  fasp_solver_dcsr_spvgmres   KrySPvgmres.c:68-441   (safe net; coarse-level fallback)
+// The scalar control flow (restart adaptation, Givens rotations, back substitution, false-
+// convergence check, best-iterate safety net) runs on the host exactly as in the reference;
+// the modified Gram-Schmidt chain runs on the device without host round trips (k_mgs_step).
+// `set` selects the workspace (0: level 0, 1: coarsest level); Lv is the level the operator
+// acts on (halo plan); use_pc applies the AMG preconditioner (level 0 only).
+// ---------------------------------------------------------------------------
+static int gmres_device(fasp_hip_amg* h, int set, DevLevel& Lv, const double* b, double* x, bool use_pc,
+                        int mode, double tol, double abstol, int MaxIt, int restart, int StopType,
+                        int PrtLvl, bool dist, Hist* hist, PcgOut* out)
+{
+    const DevCSR& A = Lv.A;
+    const int n = A.row;
+    const size_t nv = (size_t)Lv.nvec;
+    const int MIN_ITER = 0;
+    const double epsmac = SMALLREAL, cr_max = 0.99, cr_min = 0.174, maxdiff = tol * STAG_RATIO;
+    int iter = 0, i = 0, j, k, st;
+    double r_norm, r_normb, gamma, t, red[8];
+    double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL;
+    double b_norm = 0.0, den_norm = 0.0, epsilon = 0.0, cr = 1.0, r_norm_old = 0.0;
+    const int d = 3, restart_max = restart, restart_min = 3;
+    int Restart = restart;
+    const int Restart1 = Restart + 1;
+    int iter_best = 0;
+    double absres_best = BIGREAL;
+    hipStream_t s = g_ctx.stream;
+    const int G = vec_grid(n);
+
+    // workspace: p[0..Restart], w, x_best (mode 2), z[0..Restart) (mode 1)
+    const size_t need = (size_t)Restart1 + 2 + (mode == 1 ? (size_t)Restart1 : 0);
+    if (h->gm_len[set] != nv) {
+        for (double* q : h->gm[set]) if (q) (void)hipFree(q);
+        h->gm[set].clear();
+        h->gm_len[set] = nv;
+    }
+    while (h->gm[set].size() < need) {
+        double* q = nullptr;
+        HIPCK(hipMalloc(&q, sizeof(double) * std::max<size_t>(nv, 1)));
+        HIPCK(hipMemsetAsync(q, 0, sizeof(double) * nv, s));
+        h->gm[set].push_back(q);
+    }
+    if (!h->gm_hh) HIPCK(hipMalloc(&h->gm_hh, sizeof(double) * 1024));
+    if (Restart1 + 2 > 1024) return ERROR_INPUT_PAR;
+    std::vector<double*>& W = h->gm[set];
+    double** p = W.data();
+    double*  w = W[Restart1];
+    double*  x_best = W[Restart1 + 1];
+    double** z = mode == 1 ? W.data() + Restart1 + 2 : nullptr;
+    double*  r = nullptr;  // preconditioned / work vector (may alias an internal buffer)
+    std::vector<double> rs(Restart1 + 1, 0.0), c(Restart + 1, 0.0), sn(Restart + 1, 0.0);
+    std::vector<std::vector<double>> hh(Restart1, std::vector<double>(Restart + 1, 0.0));
+    std::vector<double> norms((size_t)MaxIt + 2, 0.0);
+
+    auto apply_pc = [&](double* in, double** outp) -> int {  // *outp = B in (pointer to the result)
+        if (use_pc) return precond_amg(h, in, outp);
+        *outp = in;
+        return FASP_SUCCESS;
+    };
+    auto true_residual = [&](const double* xx, double* rr) -> int {  // rr = b - A xx
+        if (halo_exchange(Lv, const_cast<double*>(xx)) < 0) return ERROR_MISC;
+        d_resid(A, xx, b, rr);
+        return FASP_SUCCESS;
+    };
+
+    if (PrtLvl > PRINT_NONE)
+        std::printf(mode == 0 ? "\nCalling VGMRes solver (CSR) ...\n"
+                    : mode == 1 ? "\nCalling VFGMRes solver (CSR) ...\n" : "\nCalling Safe VGMRes solver (CSR) ...\n");
+
+    if ((st = true_residual(x, p[0])) < 0) return st;
+    if (mode == 1) { if (d_dot(n, b, b, red, dist) < 0) return ERROR_MISC; b_norm = std::sqrt(red[0]); }
+    if (d_dot(n, p[0], p[0], red, dist) < 0) return ERROR_MISC;
+    r_norm = std::sqrt(red[0]);
+
+    if (mode == 1) {
+        norms[0] = r_norm;
+        if (PrtLvl >= PRINT_SOME) {
+            std::printf("L2 norm of %s = %.10e.\n", "right-hand side", b_norm);
+            std::printf("L2 norm of %s = %.10e.\n", "residual", r_norm);
+        }
+        den_norm = (b_norm > 0.0) ? b_norm : r_norm;
+        epsilon = tol * den_norm;
+        if (hist) hist->push(r_norm);
+        if (r_norm < epsilon || r_norm < abstol) goto FINISHED;
+        if (b_norm > 0.0) itinfo(PrtLvl, StopType, iter, norms[iter] / b_norm, norms[iter], 0);
+        else itinfo(PrtLvl, StopType, iter, norms[iter], norms[iter], 0);
+    } else {
+        switch (StopType) {
+            case STOP_REL_RES:
+                absres0 = std::max(SMALLREAL, r_norm);
+                relres = r_norm / absres0;
+                break;
+            case STOP_REL_PRECRES:
+                if ((st = apply_pc(p[0], &r)) < 0) return st;
+                if (d_dot(n, p[0], r, red, dist) < 0) return ERROR_MISC;
+                r_normb = std::sqrt(red[0]);
+                absres0 = std::max(SMALLREAL, r_normb);
+                relres = r_normb / absres0;
+                break;
+            case STOP_MOD_REL_RES:
+                if (d_dot(n, x, x, red, dist) < 0) return ERROR_MISC;
+                normu = std::max(SMALLREAL, std::sqrt(red[0]));
+                absres0 = r_norm;
+                relres = absres0 / normu;
+                break;
+            default:
+                std::printf("### ERROR: Unknown stopping type! [%s]\n", "fasp_solver_dcsr_pvgmres");
+                goto FINISHED;
+        }
+        if (hist) hist->push(r_norm);
+        if (mode == 0) { if (relres < tol || absres0 < abstol) goto FINISHED; }
+        else           { if (relres < tol) goto FINISHED; }
+        itinfo(PrtLvl, StopType, 0, relres, absres0, 0);
+        norms[0] = relres;
+    }
+
+    while (iter < MaxIt) {
+        rs[0] = r_norm_old = r_norm;
+        if (mode == 1 && r_norm == 0.0) { if (out) { out->relres = 0.0; out->absres = 0.0; out->normr0 = den_norm; } return iter; }
+        if (mode != 1) d_scale(n, 1.0 / r_norm, p[0]);
+
+        if (cr > cr_max || iter == 0) Restart = restart_max;
+        else if (cr < cr_min) { /* keep */ }
+        else { if (Restart - d > restart_min) Restart -= d; else Restart = restart_max; }
+
+        if (mode == 1) d_scale(n, 1.0 / r_norm, p[0]);
+
+        i = 0;
+        while (i < Restart && iter < MaxIt) {
+            i++; iter++;
+            if ((st = apply_pc(p[i - 1], &r)) < 0) return st;
+            if (mode == 1 && r != z[i - 1])
+                HIPCK(hipMemcpyAsync(z[i - 1], r, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            if (halo_exchange(Lv, r) < 0) return ERROR_MISC;
+            d_mxv(A, r, p[i]);
+            // modified Gram-Schmidt on the device: hh_0 = (p_0, p_i); then i fused steps
+            hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, s, n, p[0], p[i], g_ctx.d_partials);
+            d_finalize_to(G, 1, 0u, h->gm_hh, dist);
+            for (j = 0; j < i; j++) {
+                hipLaunchKernelGGL(k_mgs_step, dim3(G), dim3(BLOCK), 0, s, n, (const double*)(h->gm_hh + j),
+                                   (const double*)p[j], p[i], (const double*)(j + 1 < i ? p[j + 1] : nullptr),
+                                   g_ctx.d_partials);
+                d_finalize_to(G, 1, 0u, h->gm_hh + j + 1, dist);
+            }
+            HIPCK(hipMemcpyAsync(g_ctx.h_part, h->gm_hh, sizeof(double) * (i + 1), hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            for (j = 0; j < i; j++) hh[j][i - 1] = g_ctx.h_part[j];
+            t = std::sqrt(g_ctx.h_part[i]);
+            hh[i][i - 1] = t;
+            if (t != 0.0) d_scale(n, 1.0 / t, p[i]);
+            for (j = 1; j < i; ++j) {
+                t = hh[j - 1][i - 1];
+                hh[j - 1][i - 1] = sn[j - 1] * hh[j][i - 1] + c[j - 1] * t;
+                hh[j][i - 1] = -sn[j - 1] * t + c[j - 1] * hh[j][i - 1];
+            }
+            t = hh[i][i - 1] * hh[i][i - 1];
+            t += hh[i - 1][i - 1] * hh[i - 1][i - 1];
+            gamma = std::sqrt(t);
+            if (gamma == 0.0) gamma = epsmac;
+            c[i - 1] = hh[i - 1][i - 1] / gamma;
+            sn[i - 1] = hh[i][i - 1] / gamma;
+            rs[i] = -sn[i - 1] * rs[i - 1];
+            rs[i - 1] = c[i - 1] * rs[i - 1];
+            hh[i - 1][i - 1] = sn[i - 1] * hh[i][i - 1] + c[i - 1] * hh[i - 1][i - 1];
+            if (mode == 1) {
+                r_norm = std::fabs(rs[i]);
+                norms[iter] = r_norm;
+                if (b_norm > 0) itinfo(PrtLvl, StopType, iter, norms[iter] / b_norm, norms[iter], norms[iter] / norms[iter - 1]);
+                else itinfo(PrtLvl, StopType, iter, norms[iter], norms[iter], norms[iter] / norms[iter - 1]);
+                if (hist) hist->push(r_norm);
+                if (r_norm <= epsilon && iter >= MIN_ITER) break;
+            } else {
+                absres = r_norm = std::fabs(rs[i]);
+                relres = absres / absres0;
+                norms[iter] = relres;
+                itinfo(PrtLvl, StopType, iter, relres, absres, norms[iter] / norms[iter - 1]);
+                if (hist) hist->push(absres);
+                if (mode == 0) { if (relres < tol && iter >= MIN_ITER) break; }
+                else           { if (relres <= tol && iter >= MIN_ITER) break; }
+            }
+        }
+
+        // back substitution (host) and solution update
+        rs[i - 1] = rs[i - 1] / hh[i - 1][i - 1];
+        for (k = i - 2; k >= 0; k--) {
+            t = 0.0;
+            for (j = k + 1; j < i; j++) t -= hh[k][j] * rs[j];
+            t += rs[k];
+            rs[k] = t / hh[k][k];
+        }
+        if (mode == 1) {
+            HIPCK(hipMemcpyAsync(w, z[i - 1], sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            d_scale(n, rs[i - 1], w);
+            for (j = i - 2; j >= 0; j--) d_axpy(n, rs[j], z[j], w);
+            r = w;
+        } else {
+            HIPCK(hipMemcpyAsync(w, p[i - 1], sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            d_scale(n, rs[i - 1], w);
+            for (j = i - 2; j >= 0; j--) d_axpy(n, rs[j], p[j], w);
+            if ((st = apply_pc(w, &r)) < 0) return st;
+        }
+        d_axpy(n, 1.0, r, x);
+
+        if (mode == 2) {  // safety net, KrySPvgmres.c:287-299
+            if (d_norms(n, x, red, dist) < 0) return ERROR_MISC;
+            if (std::isnan(red[0])) { absres = BIGREAL; goto RESTORE_BESTSOL; }
+            if (absres < absres_best - maxdiff) {
+                absres_best = absres;
+                iter_best = iter;
+                HIPCK(hipMemcpyAsync(x_best, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            }
+        }
+
+        if ((mode == 0 && relres < tol && iter >= MIN_ITER) || (mode == 2 && relres <= tol && iter >= MIN_ITER) ||
+            (mode == 1 && r_norm <= epsilon && iter >= MIN_ITER)) {
+            const double computed_relres = relres;
+            if ((st = true_residual(x, w)) < 0) return st;
+            if (d_dot(n, w, w, red, dist) < 0) return ERROR_MISC;
+            r_norm = std::sqrt(red[0]);
+            switch (StopType) {
+                case STOP_REL_RES:
+                    if (mode == 1) relres = r_norm / den_norm;
+                    else { absres = r_norm; relres = absres / absres0; }
+                    break;
+                case STOP_REL_PRECRES: {
+                    double* zz = nullptr;
+                    if ((st = apply_pc(w, &zz)) < 0) return st;
+                    if (d_dot(n, zz, w, red, dist) < 0) return ERROR_MISC;
+                    if (mode == 1) { r_normb = std::sqrt(red[0]); relres = r_normb / den_norm; }
+                    else { absres = std::sqrt(red[0]); relres = absres / absres0; }
+                } break;
+                case STOP_MOD_REL_RES:
+                    if (d_dot(n, x, x, red, dist) < 0) return ERROR_MISC;
+                    normu = std::max(SMALLREAL, std::sqrt(red[0]));
+                    if (mode == 1) relres = r_norm / normu;
+                    else { absres = r_norm; relres = absres / normu; }
+                    break;
+            }
+            if (mode != 1) norms[iter] = relres;
+            if ((mode == 0 && relres < tol) || (mode != 0 && relres <= tol)) break;
+            if (mode == 1 && PrtLvl >= PRINT_SOME)
+                std::printf("### WARNING: False convergence! [%s:%d]\n", "fasp_solver_dcsr_pvfgmres", 328);
+            HIPCK(hipMemcpyAsync(p[0], w, sizeof(double) * n, hipMemcpyDeviceToDevice, s));  // restart from the true residual
+            i = 0;
+            if (mode == 0 && PrtLvl >= PRINT_MORE) {
+                std::printf("### WARNING: The computed relative residual = %.10e!\n", computed_relres);
+                std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+            }
+        }
+
+        // residual vector of the restart (KryPvgmres.c:390-401)
+        for (j = i; j > 0; j--) {
+            rs[j - 1] = -sn[j - 1] * rs[j];
+            rs[j] = c[j - 1] * rs[j];
+        }
+        if (i) hipLaunchKernelGGL(k_axpy_self, dim3(G), dim3(BLOCK), 0, s, n, rs[i] - 1.0, p[i]);
+        for (j = i - 1; j > 0; j--) d_axpy(n, rs[j], p[j], p[i]);
+        if (i) {
+            hipLaunchKernelGGL(k_axpy_self, dim3(G), dim3(BLOCK), 0, s, n, rs[0] - 1.0, p[0]);
+            d_axpy(n, 1.0, p[i], p[0]);
+        }
+        cr = r_norm / r_norm_old;
+    }
+
+RESTORE_BESTSOL:
+    if (mode == 2 && iter != iter_best) {  // KrySPvgmres.c:357-389
+        if ((st = true_residual(x_best, w)) < 0) return st;
+        if (d_dot(n, w, w, red, dist) < 0) return ERROR_MISC;
+        absres_best = std::sqrt(red[0]);
+        if (absres > absres_best + maxdiff || std::isnan(absres)) {
+            if (PrtLvl > PRINT_NONE)
+                std::printf("### WARNING: Discard current iteration. Restore iteration %d!\n", iter_best);
+            HIPCK(hipMemcpyAsync(x, x_best, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            relres = absres_best / absres0;
+        }
+    }
+
+FINISHED:
+    {
+        const double fr = (mode == 1) ? r_norm / den_norm : relres;
+        if (PrtLvl > PRINT_NONE) {
+            if (iter > MaxIt) std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, fr);
+            else if (iter >= 0) std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, fr);
+        }
+        if (out) { out->relres = fr; out->absres = r_norm; out->normr0 = (mode == 1) ? den_norm : absres0; }
+    }
+    HIPCK(hipStreamSynchronize(s));
+    if (iter >= MaxIt) return ERROR_SOLVER_MAXIT;
+    return iter;
+}
+
 // ---------------------------------------------------------------------------
 // one multigrid cycle on the resident hierarchy (PreMGCycle.c:48-274)
 // ---------------------------------------------------------------------------
@@ -680,13 +997,21 @@ ForwardSweep:
     }
 
     {
-        const int st = coarse_spcg(h, h->L[nl - 1], tol, param.print_level);
+        DevLevel& Lc = h->L[nl - 1];
+        int st = coarse_spcg(h, Lc, tol, param.print_level);
+        if (st == ERROR_MISC) return st;  // device failure, not a solver verdict
         if (st < 0) {
-            // the reference falls back to fasp_solver_dcsr_spvgmres here (PreMGUtil.inl:50-52);
-            // that safety net has no device path yet: fail loudly instead of differing silently.
-            std::fprintf(stderr, "### ERROR: fasp_hip: coarse-level safe CG failed (status %d); the SPVGMRES "
-                                 "safety net is not available on the device\n", st);
-            return ERROR_SOLVER_MISC;
+            // safety net of PreMGUtil.inl:50-52: fasp_solver_dcsr_spvgmres(A, b, x, NULL, ctol, maxit, 20, 1, ..)
+            const int m = Lc.A.row;
+            const int nn = (int)((unsigned)m * (unsigned)m);
+            const int maxit = std::max(250, std::min(nn, 1000));
+            st = gmres_device(h, 1, Lc, Lc.b, Lc.x, false, 2, tol, 0.0, maxit, 20, STOP_REL_RES,
+                              param.print_level - 4, false, nullptr, nullptr);
+            if (st == ERROR_MISC) return st;
+            if (st < 0 && param.print_level >= PRINT_MORE) {
+                std::printf("### WARNING: Coarse level solver did not converge!\n");
+                std::printf("### WARNING: Consider to increase maxit to %d!\n", 2 * maxit);
+            }
         }
     }
 
@@ -733,11 +1058,6 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
 // ---------------------------------------------------------------------------
 // preconditioned CG (KryPcg.c:96-362) on device vectors
 // ---------------------------------------------------------------------------
-struct Hist {
-    double* h; int cap; int n;
-    void push(double v) { if (h && n < cap) h[n] = v; ++n; }
-};
-
 static void itinfo(int ptrlvl, int stop_type, int iter, double relres, double absres, double factor)
 {  // AuxMessage.c:41-71
     if (ptrlvl < PRINT_SOME) return;
@@ -754,8 +1074,6 @@ static void itinfo(int ptrlvl, int stop_type, int iter, double relres, double ab
         std::printf("%6d | %13.6e   | %13.6e  |     -.-- \n", iter, relres, absres);
     }
 }
-
-struct PcgOut { double relres, absres, normr0; };
 
 static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, int MaxIt, int StopType,
                       int PrtLvl, Hist& hist, PcgOut& out)
@@ -1024,6 +1342,10 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
     for (double* q : v)
         if (q) (void)hipFree(q);
     for (auto& e : h->ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (int s = 0; s < 2; ++s)
+        for (double* q : h->gm[s])
+            if (q) (void)hipFree(q);
+    if (h->gm_hh) (void)hipFree(h->gm_hh);
     delete h;
 }
 
@@ -1106,9 +1428,19 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
     Hist   H{hist, hist_cap, 0};
     PcgOut po{BIGREAL, BIGREAL, BIGREAL};
     const double t0 = wall_seconds();
-    // SolCSR.c:530-551: the AMG preconditioner is always installed on this path
-    st = pcg_device(h, true, itparam->tol, itparam->abstol, itparam->maxit, itparam->stop_type,
-                    itparam->print_level, H, po);
+    // SolCSR.c:530-551: the AMG preconditioner is always installed on this path;
+    // SolCSR.c:84-130: dispatch on itsolver_type (restart is narrowed to SHORT, :62)
+    switch (itparam->itsolver_type) {
+        case SOLVER_VGMRES:
+        case SOLVER_VFGMRES:
+            st = gmres_device(h, 0, h->L[0], h->b, h->u, true, itparam->itsolver_type == SOLVER_VFGMRES ? 1 : 0,
+                              itparam->tol, itparam->abstol, itparam->maxit, (short)itparam->restart,
+                              itparam->stop_type, itparam->print_level, h->distributed, &H, &po);
+            break;
+        default:
+            st = pcg_device(h, true, itparam->tol, itparam->abstol, itparam->maxit, itparam->stop_type,
+                            itparam->print_level, H, po);
+    }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     const double t_solve = wall_seconds() - t0;
 

@@ -102,6 +102,11 @@ int orc_pcg(const dCSRmat* A, const dvector* b, dvector* u, orc_pc_fct pc, void*
 int orc_spcg(const dCSRmat* A, const dvector* b, dvector* u, double tol, int MaxIt,
              int StopType, int PrtLvl);                                        /* KrySPcg.c:60 (pc == NULL) */
 
+/* mode 0 pvgmres (KryPvgmres.c:66), 1 pvfgmres (KryPvfgmres.c:67), 2 spvgmres (KrySPvgmres.c:68) */
+int orc_gmres(int mode, const dCSRmat* A, const dvector* b, dvector* x, orc_pc_fct pc, void* pcdata,
+              double tol, double abstol, int MaxIt, int restart, int StopType, int PrtLvl,
+              double* final_relres);
+
 /* the entry point: SolCSR.c:476 (+ SolCSR.c:56 dispatch) */
 int orc_solver_dcsr_krylov_amg(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam,
                                AMG_param* amgparam, double* hist, int hist_cap, int* nhist,

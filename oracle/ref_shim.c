@@ -168,3 +168,9 @@ int ref_coarse_spcg(dCSRmat* A, dvector* b, dvector* x, double ctol)
     const int maxit = MAX(250, MIN(n * n, 1000));
     return fasp_solver_dcsr_spcg(A, b, x, NULL, ctol, maxit, 1, 0);
 }
+
+/* safety-net GMRES exactly as PreMGUtil.inl:51 wires it (pc == NULL, restart 20) */
+int ref_coarse_spvgmres(dCSRmat* A, dvector* b, dvector* x, double ctol, int maxit, int restart)
+{
+    return fasp_solver_dcsr_spvgmres(A, b, x, NULL, ctol, maxit, (SHORT)restart, 1, 0);
+}

@@ -150,6 +150,50 @@ def test_pcg_history_poisson(gpu, n, mod):
     _cmp_solve(gpu, ia, ja, a, f, mod)
 
 
+def _gm(solver, restart, stop=1, cyc=1):
+    def mod(itp, amgp):
+        _jac(itp, amgp); itp.itsolver_type = solver; itp.restart = restart; itp.stop_type = stop
+        amgp.cycle_type = cyc
+    return mod
+
+
+@pytest.mark.parametrize("n", [12, 32])
+@pytest.mark.parametrize("solver,restart,stop,cyc", [(5, 30, 1, 1), (5, 4, 1, 1), (6, 30, 1, 1), (6, 5, 1, 2),
+                                                      (5, 30, 2, 1), (6, 30, 3, 1)])
+def test_gmres_family(gpu, n, solver, restart, stop, cyc):
+    """VGMRES (KryPvgmres.c:66) / VFGMRES (KryPvfgmres.c:67) with the AMG preconditioner:
+    iteration count equal to the oracle's, solution and final residual to 1e-8."""
+    ia, ja, a, f, ue = poisson7pt(n)
+    mod = _gm(solver, restart, stop, cyc)
+    itp, amgp = default_params(); mod(itp, amgp)
+    itp2, amgp2 = default_params(); mod(itp2, amgp2)
+    s_ref, x_ref, h_ref, rr_ref = orc_solve(ia, ja, a, f, itp, amgp)
+    H = gpu.AMG(ia, ja, a, amgp2)
+    s, x, h, stats = H.solve(f, itp2)
+    H.close()
+    assert s == s_ref, (s, s_ref)
+    assert abs(stats.relres - rr_ref) <= 1e-8 * max(rr_ref, 1e-300) + 1e-16
+    assert np.max(np.abs(x - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
+    assert len(h) == s + 1  # one residual estimate per iteration + the initial one
+
+
+def test_coarse_fallback_spvgmres(gpu):
+    """STOP_MOD_REL_RES with x0 = 0 sends the coarse safe CG into ERROR_SOLVER_SOLSTAG; the
+    cycle must then run the SPVGMRES safety net (PreMGUtil.inl:50) like the reference."""
+    ia, ja, a, f, ue = poisson7pt(10)
+
+    def mod(itp, amgp):
+        _jac(itp, amgp); itp.stop_type = T.STOP_MOD_REL_RES
+    itp, amgp = default_params(); mod(itp, amgp)
+    itp2, amgp2 = default_params(); mod(itp2, amgp2)
+    s_ref, x_ref, h_ref, rr_ref = orc_solve(ia, ja, a, f, itp, amgp)
+    H = gpu.AMG(ia, ja, a, amgp2)
+    s, x, h, stats = H.solve(f, itp2)
+    H.close()
+    assert s == s_ref
+    assert np.max(np.abs(x - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
+
+
 def test_pcg_history_fe(gpu):
     ia, ja, a = read_csr(DATA + "/csrmat_FE.dat"); f = read_vec(DATA + "/rhs_FE.dat")
     _cmp_solve(gpu, ia, ja, a, f, _jac)
@@ -203,7 +247,7 @@ def test_unsupported_is_refused(gpu):
     x = np.zeros(len(f))
     assert gpu.solver_dcsr_krylov_amg(ia, ja, a, f, x, itp, amgp) == T.ERROR_AMG_SMOOTH_TYPE
     assert np.all(x == 0.0)
-    itp, amgp = default_params(); _jac(itp, amgp); itp.itsolver_type = 2  # BiCGstab
+    itp, amgp = default_params(); _jac(itp, amgp); itp.itsolver_type = 2  # BiCGstab: not on the path
     assert gpu.solver_dcsr_krylov_amg(ia, ja, a, f, x, itp, amgp) == T.ERROR_SOLVER_TYPE
 
 

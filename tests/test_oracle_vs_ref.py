@@ -33,10 +33,17 @@ def _mods():
     def theta(i, a): jac(i, a); a.strong_threshold = 0.6; a.truncation_threshold = 0.4
     def precres(i, a): jac(i, a); i.stop_type = T.STOP_REL_PRECRES
     def modres(i, a): jac(i, a); i.stop_type = T.STOP_MOD_REL_RES
-    # STOP_MOD_REL_RES with x0 = 0 drives the coarse safe CG into ERROR_SOLVER_SOLSTAG, where the
-    # reference falls back to fasp_solver_dcsr_spvgmres (PreMGUtil.inl:50): not restated yet.
+    # STOP_MOD_REL_RES with x0 = 0 drives the coarse safe CG into ERROR_SOLVER_SOLSTAG: this case
+    # exercises the SPVGMRES safety net of PreMGUtil.inl:50.
+    def vg(i, a): jac(i, a); i.itsolver_type = T.SOLVER_VGMRES; i.restart = 30
+    def vg4(i, a): jac(i, a); i.itsolver_type = T.SOLVER_VGMRES; i.restart = 4
+    def vfg(i, a): jac(i, a); i.itsolver_type = T.SOLVER_VFGMRES; i.restart = 30
+    def vfg5w(i, a): jac(i, a); i.itsolver_type = T.SOLVER_VFGMRES; i.restart = 5; a.cycle_type = T.W_CYCLE
+    def vgpre(i, a): vg(i, a); i.stop_type = T.STOP_REL_PRECRES
+    def vfgmod(i, a): vfg(i, a); i.stop_type = T.STOP_MOD_REL_RES
     return dict(jac=jac, jacw=jacw, vw=vw, l1=l1, gscf=gscf, gsn=gsn, sor=sor, ssor=ssor, sgs=sgs,
-                theta=theta, precres=precres)
+                theta=theta, precres=precres, modres=modres, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
+                vgpre=vgpre, vfgmod=vfgmod)
 
 
 @pytest.mark.parametrize("name", list(_mods().keys()))
@@ -49,7 +56,8 @@ def test_histories_bit_exact(R, n, name):
     s2, x2, h2 = ref_solve(ia, ja, a, f, i2, a2)
     assert s1 == s2
     assert np.array_equal(x1, x2)
-    if name != "precres":  # that stop type applies the preconditioner inside the norm: extra calls
+    if name in ("jac", "jacw", "vw", "l1", "gscf", "gsn", "sor", "ssor", "sgs", "theta"):
+        # PCG with STOP_REL_RES: the recorded preconditioner inputs are exactly the residuals
         assert np.array_equal(np.concatenate([h1[:-2], h1[-1:]]), h2)
 
 
@@ -77,6 +85,28 @@ def test_hierarchy_bit_exact_oracle_and_product(R, fa, n):
                 assert np.array_equal(x, y) and np.array_equal(x, z)
     R.ref_amg_free(hr, C.byref(a2)); O.free(); P.close()
     assert bytes(a1) == bytes(a2) == bytes(a3)  # the same mutations of AMG_param
+
+
+def test_coarse_spvgmres_bit_exact(R):
+    ia, ja, a, f, ue = poisson7pt(14)
+    i1, a1 = default_params(); a1.smoother = T.SMOOTHER_JACOBI
+    A, keep = T.as_csr(ia, ja, a)
+    O = OrcAMG(A, a1)
+    Ac = O.level(O.num_levels - 1).A
+    n = Ac.row
+    b = np.random.default_rng(3).standard_normal(n)
+    o = oracle()
+    o.orc_gmres.argtypes = [C.c_int, C.POINTER(T.dCSRmat), C.POINTER(T.dvector), C.POINTER(T.dvector), C.c_void_p,
+                            C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    R.ref_coarse_spvgmres.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(T.dvector), C.POINTER(T.dvector), C.c_double,
+                                      C.c_int, C.c_int]
+    for restart, maxit, tol in ((20, 1000, 1e-10), (5, 1000, 1e-10), (20, 7, 1e-10), (3, 50, 1e-14)):
+        x1 = np.zeros(n); x2 = np.zeros(n)
+        bv, bk = T.as_vec(b); xv1 = T.dvector(n, T.dp(x1)); xv2 = T.dvector(n, T.dp(x2))
+        s1 = o.orc_gmres(2, C.byref(Ac), C.byref(bv), C.byref(xv1), None, None, tol, 0.0, maxit, restart, 1, 0, None)
+        s2 = R.ref_coarse_spvgmres(C.byref(Ac), C.byref(bv), C.byref(xv2), tol, maxit, restart)
+        assert s1 == s2 and np.array_equal(x1, x2)
+    O.free()
 
 
 def test_coarse_spcg_bit_exact(R):
