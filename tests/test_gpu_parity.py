@@ -172,7 +172,9 @@ def test_gmres_family(gpu, n, solver, restart, stop, cyc):
     s, x, h, stats = H.solve(f, itp2)
     H.close()
     assert s == s_ref, (s, s_ref)
-    assert abs(stats.relres - rr_ref) <= 1e-8 * max(rr_ref, 1e-300) + 1e-16
+    # the final value is a TRUE residual (||b - A x|| at 1e-9 of ||b||: cancellation), so it
+    # carries ~1e-16 absolute noise; bar of BASELINE.json: 1e-10 absolute
+    assert abs(stats.relres - rr_ref) <= 1e-6 * rr_ref + 1e-15
     assert np.max(np.abs(x - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
     assert len(h) == s + 1  # one residual estimate per iteration + the initial one
 
