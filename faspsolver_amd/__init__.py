@@ -32,7 +32,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_amg_get_cfmark", "fasp_hip_solve", "fasp_hip_set_rhs", "fasp_hip_set_guess",
     "fasp_hip_solve_resident", "fasp_hip_get_solution", "fasp_hip_device_synchronize",
     "fasp_hip_precond_amg",
-    "fasp_hip_poisson7pt", "fasp_hip_free_system", "fasp_hip_time_kernel",
+    "fasp_hip_poisson7pt", "fasp_hip_aniso27pt", "fasp_hip_free_system", "fasp_hip_time_kernel",
     "fasp_hip_tune", "fasp_hip_comm_unique_id", "fasp_hip_comm_init", "fasp_hip_comm_finalize",
     "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version", "fasp_hip_comm_init_shm",
     "fasp_hip_dist_plan", "fasp_hip_dist_level_info", "fasp_hip_dist_get_matrix",
@@ -91,6 +91,7 @@ def lib():
     L.fasp_hip_precond_amg.argtypes = [C.c_void_p, T.c_double_p, T.c_double_p]
     L.fasp_hip_poisson7pt.argtypes = [C.c_int, C.c_int, C.c_int, P(T.dCSRmat), P(T.dvector),
                                       P(T.dvector)]
+    L.fasp_hip_aniso27pt.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, P(T.dCSRmat), P(T.dvector)]
     L.fasp_hip_free_system.argtypes = [P(T.dCSRmat), P(T.dvector), P(T.dvector)]
     L.fasp_hip_free_system.restype = None
     L.fasp_hip_time_kernel.restype = C.c_double
@@ -139,6 +140,18 @@ def poisson7pt(nx, ny=None, nz=None):
     ue = np.ctypeslib.as_array(u.val, (u.row,)).copy()
     lib().fasp_hip_free_system(C.byref(A), C.byref(b), C.byref(u))
     return ia, ja, a, f, ue
+
+
+def aniso27pt(n, kx=1.0, ky=1.0, kz=0.01):
+    """Config-5 synthetic system: Q1 FE, -div(diag(kx,ky,kz) grad u) = 1 -> (ia, ja, a, f)."""
+    A = T.dCSRmat(); b = T.dvector()
+    st = lib().fasp_hip_aniso27pt(n, kx, ky, kz, C.byref(A), C.byref(b))
+    if st < 0:
+        raise RuntimeError(f"fasp_hip_aniso27pt failed: {st}")
+    ia, ja, a = T.csr_arrays(A)
+    f = np.ctypeslib.as_array(b.val, (b.row,)).copy()
+    lib().fasp_hip_free_system(C.byref(A), C.byref(b), None)
+    return ia, ja, a, f
 
 
 def solver_dcsr_krylov_amg(ia, ja, a, b, x, itparam, amgparam):

@@ -91,9 +91,13 @@ int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, 
     D.L.clear();
     D.L.resize(nl);
 
-    // ownership ranges of every level
+    // ownership ranges of every level (classical AMG: coarse rows follow their C points;
+    // aggregation hierarchies carry no C/F marker -> they are not partitioned, only replicated)
+    bool can_partition = true;
+    for (int l = 0; l + 1 < nl; ++l)
+        if (H.L[l].cfmark.n != (size_t)H.L[l].A.row) can_partition = false;
     for (int l = 0; l < nl; ++l) D.L[l].start.assign(nranks + 1, 0);
-    {
+    if (can_partition) {
         const int n0 = H.L[0].A.row;
         for (int r = 0; r <= nranks; ++r) D.L[0].start[r] = (int)((long long)n0 * r / nranks);
         for (int l = 0; l + 1 < nl; ++l) {
@@ -112,7 +116,7 @@ int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, 
     // which levels are distributed: a prefix (once replicated, all coarser levels are too)
     int first_rep = nl;
     for (int l = 0; l < nl; ++l)
-        if (nranks == 1 || H.L[l].A.row < min_rows) { first_rep = l; break; }
+        if (nranks == 1 || !can_partition || H.L[l].A.row < min_rows) { first_rep = l; break; }
     // the coarsest level is always replicated: its safe-CG solve runs without communication
     if (nranks > 1 && first_rep > nl - 1) first_rep = nl - 1;
     D.first_replicated = first_rep;

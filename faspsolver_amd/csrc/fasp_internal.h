@@ -110,6 +110,8 @@ int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, 
 // with the reference's serial arithmetic and ordering, parallelised only where the
 // result is order-independent.  Returns FASP_SUCCESS or a negative ERROR_* code.
 int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H);
+// Smoothed aggregation (PreAMGSetupSA.c:63: VMB aggregation, smoothed P and R).
+int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H);
 
 // Parameter screening: every AMG_param / ITS_param combination without a device
 // path returns a negative ERROR_* code here (never a silent CPU fallback).

@@ -637,6 +637,178 @@ void copy_csr(const dCSRmat* A, HostCSR& B)
     std::memcpy(B.val.data(), A->val, (size_t)A->nnz * sizeof(double));
 }
 
+// ---------------------------------------------------------------------------
+// smoothed aggregation (PreAMGSetupSA.c:63 -> amg_setup_smoothP_smoothR :254)
+// ---------------------------------------------------------------------------
+void first_diag(const HostCSR& A, std::vector<double>& d)  // fasp_dcsr_getdiag(0, ..): first hit, 0 if absent
+{
+    const int n = std::min(A.row, A.col);
+    d.assign(std::max(A.row, 1), 0.0);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i)
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
+            if (A.ja[k] == i) { d[i] = A.val[k]; break; }
+}
+
+// VMB aggregation, PreAMGAggregation.inl:368-640.  The strongly-coupled neighbourhood
+// (a_ij^2 >= eps^2 |a_ii a_jj|, eps halved per level) is filtered in parallel; the three
+// aggregation sweeps are the reference's sequential greedy passes.
+int aggregation_vmb(const HostCSR& A, std::vector<int>& vv, const AMG_param& param, int NumLevels, HostCSR& N,
+                    int& NumAggregates)
+{
+    const int row = A.row;
+    const int max_aggregation = param.max_aggregation;
+    std::vector<double> diag;
+    first_diag(A, diag);
+    double strongly_coupled = param.strong_coupled;
+    if (param.tentative_smooth >= SMALLREAL) strongly_coupled = param.strong_coupled * ::pow(0.5, NumLevels - 1);
+    const double sc2 = ::pow(strongly_coupled, 2);
+
+    N.row = row; N.col = A.col;
+    N.ia.alloc((size_t)row + 1);
+    N.ia[0] = 0;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        int c = 0;
+        for (int j = A.ia[i]; j < A.ia[i + 1]; ++j)
+            c += (A.ja[j] == i) || (::pow(A.val[j], 2) >= sc2 * dabs(diag[i] * diag[A.ja[j]]));
+        N.ia[i + 1] = c;
+    }
+    for (int i = 0; i < row; ++i) N.ia[i + 1] += N.ia[i];
+    N.nnz = N.ia[row];
+    N.ja.alloc((size_t)N.nnz);
+    N.val.alloc((size_t)N.nnz);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        int o = N.ia[i];
+        for (int j = A.ia[i]; j < A.ia[i + 1]; ++j)
+            if ((A.ja[j] == i) || (::pow(A.val[j], 2) >= sc2 * dabs(diag[i] * diag[A.ja[j]]))) {
+                N.ja[o] = A.ja[j];
+                N.val[o++] = A.val[j];
+            }
+    }
+    const int *NIA = N.ia.data(), *NJA = N.ja.data();
+
+    vv.assign(row, -2);
+    NumAggregates = 0;
+    int num_left = row;
+    for (int i = 0; i < row; ++i) {  // Step 1
+        if (A.ia[i + 1] - A.ia[i] == 1) {
+            vv[i] = UNPT;
+            --num_left;
+            continue;
+        }
+        bool subset = true;
+        for (int j = NIA[i]; j < NIA[i + 1]; ++j)
+            if (vv[NJA[j]] >= UNPT) { subset = false; break; }
+        if (!subset) continue;
+        int count = 1;
+        vv[i] = NumAggregates;
+        --num_left;
+        for (int j = NIA[i]; j < NIA[i + 1]; ++j)
+            if (NJA[j] != i && count < max_aggregation) { vv[NJA[j]] = NumAggregates; --num_left; ++count; }
+        ++NumAggregates;
+    }
+    if (NumAggregates < MIN_CDOF) return -33;  // ERROR_AMG_COARSEING
+    std::vector<int> temp_C(vv), num_each_agg(NumAggregates, 0);  // Step 2
+    for (int i = row; i--;)
+        if (vv[i] >= 0) num_each_agg[vv[i]]++;
+    for (int i = 0; i < row; ++i) {
+        if (vv[i] >= UNPT) continue;
+        for (int j = NIA[i]; j < NIA[i + 1]; ++j) {
+            const int tc = temp_C[NJA[j]];
+            if (tc > UNPT && num_each_agg[tc] < max_aggregation) {
+                vv[i] = tc;
+                --num_left;
+                num_each_agg[tc]++;
+                break;
+            }
+        }
+    }
+    while (num_left > 0) {  // Step 3
+        for (int i = 0; i < row; ++i) {
+            if (vv[i] >= UNPT) continue;
+            int count = 1;
+            vv[i] = NumAggregates;
+            --num_left;
+            for (int j = NIA[i]; j < NIA[i + 1]; ++j)
+                if (NJA[j] != i && vv[NJA[j]] < UNPT && count < max_aggregation) {
+                    vv[NJA[j]] = NumAggregates;
+                    --num_left;
+                    ++count;
+                }
+            ++NumAggregates;
+        }
+    }
+    return FASP_SUCCESS;
+}
+
+// P = S * tentp with S = I - w D^-1 M (M = A, or A filtered onto the neighbourhood N);
+// smooth_agg :115 + form_tentative_p (PreAMGAggregationCSR.inl:40) + fasp_blas_dcsr_mxm
+// (BlaSpmvCSR.c:893): tentp has one unit entry per aggregated row, so row i of P collects,
+// in storage order of M's row, the aggregates of its neighbours (columns in discovery order,
+// values accumulated in that same order).
+void smoothed_prolongator(const HostCSR& A, HostCSR& N, const std::vector<int>& vv, int nagg,
+                          const AMG_param& param, HostCSR& P)
+{
+    const int row = A.row;
+    const double w = param.tentative_smooth;
+    const HostCSR* M = &A;
+    if (param.smooth_filter == 1) {
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < row; ++i) {
+            double sA = 0.0, sN = 0.0;
+            for (int j = A.ia[i]; j < A.ia[i + 1]; ++j) if (A.ja[j] != i) sA += A.val[j];
+            for (int j = N.ia[i]; j < N.ia[i + 1]; ++j) if (N.ja[j] != i) sN += N.val[j];
+            for (int j = N.ia[i]; j < N.ia[i + 1]; ++j) if (N.ja[j] == i) N.val[j] += sA - sN;
+        }
+        M = &N;
+    }
+    std::vector<double> diag;
+    first_diag(*M, diag);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) if (dabs(diag[i]) < 1e-6) diag[i] = 1.0;
+
+    auto sval = [&](int i, int j) {
+        return (M->ja[j] == i) ? 1 - w * M->val[j] / diag[i] : -w * M->val[j] / diag[i];
+    };
+    P.row = row; P.col = nagg;
+    P.ia.alloc((size_t)row + 1);
+    P.ia[0] = 0;
+#pragma omp parallel
+    {
+        std::vector<int> stamp(nagg, -1);
+#pragma omp for schedule(static)
+        for (int i = 0; i < row; ++i) {
+            int c = 0;
+            for (int j = M->ia[i]; j < M->ia[i + 1]; ++j) {
+                const int a = vv[M->ja[j]];
+                if (a > UNPT && stamp[a] != i) { stamp[a] = i; ++c; }
+            }
+            P.ia[i + 1] = c;
+        }
+    }
+    for (int i = 0; i < row; ++i) P.ia[i + 1] += P.ia[i];
+    P.nnz = P.ia[row];
+    P.ja.alloc((size_t)P.nnz);
+    P.val.alloc((size_t)P.nnz);
+#pragma omp parallel
+    {
+        std::vector<int> stamp(nagg, -1), pos(nagg, 0);
+#pragma omp for schedule(static)
+        for (int i = 0; i < row; ++i) {
+            int o = P.ia[i];
+            for (int j = M->ia[i]; j < M->ia[i + 1]; ++j) {
+                const int a = vv[M->ja[j]];
+                if (a <= UNPT) continue;
+                const double v = sval(i, j) * 1.0;  // S_ik * tentp_k,a
+                if (stamp[a] != i) { stamp[a] = i; pos[a] = o; P.ja[o] = a; P.val[o] = 0; P.val[o] += v; ++o; }
+                else P.val[pos[a]] += v;
+            }
+        }
+    }
+}
+
 // AuxMessage.c:84-123
 void print_complexity(const HostHierarchy& H, int prtlvl)
 {
@@ -665,17 +837,21 @@ void print_complexity(const HostHierarchy& H, int prtlvl)
 int check_supported(const ITS_param* it, const AMG_param* amg)
 {
     if (amg) {
-        if (amg->AMG_type != CLASSIC_AMG) {
-            std::printf("### ERROR: fasp_hip: AMG_type %d has no device path yet (classical RS only)\n",
+        if (amg->AMG_type != CLASSIC_AMG && amg->AMG_type != SA_AMG) {
+            std::printf("### ERROR: fasp_hip: AMG_type %d has no device path yet (classical RS and SA only)\n",
                         amg->AMG_type);
             return ERROR_INPUT_PAR;
         }
-        if (amg->coarsening_type != COARSE_RS) {
+        if (amg->AMG_type == SA_AMG && amg->smooth_restriction != 1) {
+            std::printf("### ERROR: fasp_hip: SA with unsmoothed restriction has no device path\n");
+            return ERROR_INPUT_PAR;
+        }
+        if (amg->AMG_type == CLASSIC_AMG && amg->coarsening_type != COARSE_RS) {
             std::printf("### ERROR: fasp_hip: coarsening_type %d not supported (COARSE_RS only)\n",
                         amg->coarsening_type);
             return ERROR_AMG_COARSE_TYPE;
         }
-        if (amg->interpolation_type != INTERP_DIR) {
+        if (amg->AMG_type == CLASSIC_AMG && amg->interpolation_type != INTERP_DIR) {
             std::printf("### ERROR: fasp_hip: interpolation_type %d not supported (INTERP_DIR only)\n",
                         amg->interpolation_type);
             return ERROR_AMG_INTERP_TYPE;
@@ -796,6 +972,63 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
     if (prtlvl > PRINT_NONE) {
         print_complexity(H, prtlvl);
         std::printf("Classical AMG setup costs %.4f seconds.\n", H.setup_seconds);
+    }
+    return status;
+}
+
+int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
+{
+    const int    prtlvl   = param->print_level;
+    const short  min_cdof = (short)std::max(param->coarse_dof, 50);  // SHORT in the reference (:260)
+    const double t0       = wall_seconds();
+    int          status   = FASP_SUCCESS;
+    const int    max_levels = param->max_levels;
+
+    if (!A || !A->IA || !A->JA || !A->val || A->row <= 0 || A->row != A->col) return ERROR_DATA_STRUCTURE;
+    H.L.clear();
+    H.L.reserve(MAX_AMG_LVL + 1);
+    H.L.emplace_back();
+    copy_csr(A, H.L[0].A);
+    if (prtlvl > PRINT_NONE) std::printf("\nSetting up SA AMG ...\n");
+    if (param->aggregation_type == PAIRWISE) param->pair_number = std::min<int>(param->pair_number, max_levels);
+
+    int lvl = 0;
+    try {
+        while (H.L[lvl].A.row > min_cdof && lvl < max_levels - 1) {
+            HostLevel& Lv = H.L[lvl];
+            HostCSR N;
+            std::vector<int> vv;
+            int nagg = 0;
+            status = aggregation_vmb(Lv.A, vv, *param, lvl + 1, N, nagg);
+            if (status < 0) {  // Check 1
+                if (prtlvl > PRINT_MIN) std::printf("### WARNING: Forming aggregates on level-%d failed!\n", lvl);
+                status = FASP_SUCCESS;
+                break;
+            }
+            smoothed_prolongator(Lv.A, N, vv, nagg, *param, Lv.P);
+            if (Lv.P.col < MIN_CDOF) { Lv.P = HostCSR(); break; }  // Check 2
+            if (Lv.P.row > Lv.P.col * 20.0) {                      // Check 3 (MAX_CRATE)
+                if (prtlvl > PRINT_MIN) {
+                    std::printf("### WARNING: Coarsening might be too aggressive!\n");
+                    std::printf("### WARNING: Fine level = %d, coarse level = %d. Discard!\n", Lv.P.row, Lv.P.col);
+                }
+                Lv.P = HostCSR();
+                break;
+            }
+            transpose_csr(Lv.P, Lv.R);
+            H.L.emplace_back();
+            galerkin_rap(H.L[lvl].R, H.L[lvl].A, H.L[lvl].P, H.L[lvl + 1].A);
+            H.L[lvl].has_coarse = true;
+            ++lvl;
+        }
+    } catch (const std::bad_alloc&) {
+        std::printf("### ERROR: fasp_hip: host allocation failed during AMG setup\n");
+        return ERROR_ALLOC_MEM;
+    }
+    H.setup_seconds = wall_seconds() - t0;
+    if (prtlvl > PRINT_NONE) {
+        print_complexity(H, prtlvl);
+        std::printf("Smoothed aggregation setup costs %.4f seconds.\n", H.setup_seconds);
     }
     return status;
 }
@@ -932,6 +1165,60 @@ int fasp_hip_poisson7pt(int nx, int ny, int nz, dCSRmat* A, dvector* b, dvector*
     A->row = A->col = n; A->nnz = (int)nnz; A->IA = ia; A->JA = ja; A->val = a;
     b->row = n; b->val = f;
     u->row = n; u->val = ue;
+    return FASP_SUCCESS;
+}
+
+
+/* Synthetic input of BASELINE config 5 (the reference ships no 3-D FE generator, SURVEY.md
+ * section 8d): Q1 trilinear finite elements for -div(K grad u) = 1 on the unit cube, K =
+ * diag(kx, ky, kz), homogeneous Dirichlet boundary, n^3 interior nodes, lexicographic, x
+ * fastest.  Tensor-product stencil: a(dx,dy,dz) = kx s(dx) m(dy) m(dz) + ky m(dx) s(dy) m(dz)
+ * + kz m(dx) m(dy) s(dz) with the 1-D stiffness s = (2,-1)/h and mass m = (4,1) h/6.
+ * Row entries in increasing column order; rhs b_i = h^3 (load vector of f = 1). */
+int fasp_hip_aniso27pt(int n, double kx, double ky, double kz, dCSRmat* A, dvector* b)
+{
+    const long long N = (long long)n * n * n;
+    if (n <= 0 || 27 * N > 2147483647LL) return ERROR_INPUT_PAR;
+    const double h = 1.0 / (double)(n + 1);
+    const double s[3] = {-1.0 / h, 2.0 / h, -1.0 / h};
+    const double m[3] = {h / 6.0, 4.0 * h / 6.0, h / 6.0};
+    int* ia = (int*)std::malloc(((size_t)N + 1) * sizeof(int));
+    long long nnz = 0;
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                const int cx = 3 - (i == 0) - (i == n - 1), cy = 3 - (j == 0) - (j == n - 1),
+                          cz = 3 - (k == 0) - (k == n - 1);
+                ia[(size_t)(k * n + j) * n + i] = (int)nnz;
+                nnz += (long long)cx * cy * cz;
+            }
+    ia[N] = (int)nnz;
+    int* ja = (int*)std::malloc((size_t)nnz * sizeof(int));
+    double* a = (double*)std::malloc((size_t)nnz * sizeof(double));
+    double* f = (double*)std::malloc((size_t)N * sizeof(double));
+    if (!ia || !ja || !a || !f) { std::free(ia); std::free(ja); std::free(a); std::free(f); return ERROR_ALLOC_MEM; }
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                const int row = (k * n + j) * n + i;
+                int c = ia[row];
+                for (int dz = -1; dz <= 1; ++dz) {
+                    if (k + dz < 0 || k + dz >= n) continue;
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        if (j + dy < 0 || j + dy >= n) continue;
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (i + dx < 0 || i + dx >= n) continue;
+                            ja[c] = row + (dz * n + dy) * n + dx;
+                            a[c] = kx * s[dx + 1] * m[dy + 1] * m[dz + 1] + ky * m[dx + 1] * s[dy + 1] * m[dz + 1] +
+                                   kz * m[dx + 1] * m[dy + 1] * s[dz + 1];
+                            ++c;
+                        }
+                    }
+                }
+                f[row] = h * h * h;
+            }
+    A->row = A->col = (int)N; A->nnz = (int)nnz; A->IA = ia; A->JA = ja; A->val = a;
+    b->row = (int)N; b->val = f;
     return FASP_SUCCESS;
 }
 

@@ -326,6 +326,10 @@ int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z);
  * values as produced by test/src/FdmPoisson.c:439 + :731 of the reference.
  * A, b, u are allocated with malloc and released by fasp_hip_free_system. */
 int  fasp_hip_poisson7pt(int nx, int ny, int nz, dCSRmat* A, dvector* b, dvector* u_exact);
+/* Synthetic input of config 5: Q1 trilinear FE matrix (27-point stencil) of
+ * -div(diag(kx,ky,kz) grad u) = 1 on the unit cube, n^3 interior nodes.  The reference has no
+ * 3-D FE generator; this one is ours.  Free with fasp_hip_free_system. */
+int  fasp_hip_aniso27pt(int n, double kx, double ky, double kz, dCSRmat* A, dvector* b);
 void fasp_hip_free_system(dCSRmat* A, dvector* b, dvector* u);
 
 /* Timed micro-benchmark of one device kernel class on the resident level-0

@@ -50,6 +50,8 @@ void orc_param_solver_init(ITS_param* p);
 
 /* synthetic input: test/src/FdmPoisson.c:439 (7-pt band system) + :731 (band->CSR) */
 int  orc_poisson7pt(int nx, int ny, int nz, dCSRmat* A, dvector* b, dvector* u);
+/* config-5 synthetic input: Q1 FE for -div(diag(kx,ky,kz) grad u) = 1 (our own generator) */
+int  orc_aniso27pt(int n, double kx, double ky, double kz, dCSRmat* A, dvector* b);
 void orc_free_csr(dCSRmat* A);
 void orc_free_vec(dvector* v);
 
@@ -83,6 +85,8 @@ void orc_dcsr_rap(const dCSRmat* R, const dCSRmat* A, const dCSRmat* P,
 /* classical AMG setup: PreAMGSetupRS.c:52 (+ PreAMGCoarsenRS.c, PreAMGInterp.c).
  * A is deep-copied into mgl->L[0].A.  Returns FASP_SUCCESS or an ERROR_* code. */
 int  orc_amg_setup_rs(orc_amg* mgl, const dCSRmat* A, AMG_param* param);
+/* smoothed aggregation: PreAMGSetupSA.c:63 (smoothed P, smoothed R; VMB aggregation) */
+int  orc_amg_setup_sa(orc_amg* mgl, const dCSRmat* A, AMG_param* param);
 void orc_amg_free(orc_amg* mgl);
 
 /* one multigrid cycle: PreMGCycle.c:48 */
