@@ -878,10 +878,6 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             std::printf("### ERROR: fasp_hip: direct coarse solvers are not available\n");
             return ERROR_INPUT_PAR;
         }
-        if (amg->coarse_scaling != 0) {
-            std::printf("### ERROR: fasp_hip: coarse_scaling has no device path yet\n");
-            return ERROR_INPUT_PAR;
-        }
         if (amg->max_levels < 1 || amg->max_levels > MAX_AMG_LVL) return ERROR_INPUT_PAR;
     }
     if (it) {

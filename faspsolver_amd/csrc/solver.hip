@@ -1019,8 +1019,22 @@ ForwardSweep:
         --l;
         DevLevel& D = h->L[l];
         materialise_zero(D);
-        if (halo_exchange(h->L[l + 1], h->L[l + 1].x) < 0) return ERROR_MISC;
-        d_aAxpy(1.0, D.P, h->L[l + 1].x, D.x);  // x_l += P x_{l+1}  (coarse_scaling OFF: alpha = 1)
+        DevLevel& C = h->L[l + 1];
+        if (halo_exchange(C, C.x) < 0) return ERROR_MISC;
+        double alpha = 1.0;
+        if (param.coarse_scaling == 1) {
+            // PreMGCycle.c:210-216: alpha = (x_c, b_c) / (A_c x_c, x_c), capped at 1
+            // (fasp_blas_dcsr_vmv, BlaSpmvCSR.c:839); C.w is free scratch on the way up
+            const bool cdist = !C.replicated && comm_size() > 1;
+            double red[2];
+            CsrArgs a{}; a.x = C.x; a.y = C.w; a.dotv = C.x; a.partials = g_ctx.d_partials;
+            const int gdot = launch_csr<OP_MXV_DOT>(C.A, a);
+            d_finalize(gdot, 1, 0u, 1, cdist);
+            if (fetch_red(1, 1, red + 1) < 0) return ERROR_MISC;
+            if (d_dot(C.A.row, C.x, C.b, red, cdist) < 0) return ERROR_MISC;
+            alpha = std::min(red[0] / red[1], 1.0);
+        }
+        d_aAxpy(alpha, D.P, C.x, D.x);  // x_l += alpha P x_{l+1}
         smooth(D, smoother, param.postsmooth_iter, relax);
         if (num_lvl[l] < ncycles[l]) break;
         else num_lvl[l] = 0;

@@ -141,8 +141,13 @@ def _jac22(itp, amgp):
     _jac(itp, amgp); amgp.presmooth_iter = 2; amgp.postsmooth_iter = 2
 
 
+def _jac_cs(itp, amgp):
+    _jac(itp, amgp); amgp.coarse_scaling = 1
+
+
 @pytest.mark.parametrize("n", [8, 16, 32, 48])
-@pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22], ids=["jacobi-V", "jacobi-W", "l1diag-V", "jacobi-V22"])
+@pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22, _jac_cs],
+                         ids=["jacobi-V", "jacobi-W", "l1diag-V", "jacobi-V22", "jacobi-V-coarse-scaling"])
 def test_pcg_history_poisson(gpu, n, mod):
     if n == 48 and mod is not _jac:
         pytest.skip("largest size only for the headline configuration")
