@@ -868,12 +868,16 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
                 return ERROR_INPUT_PAR;
         }
         switch (amg->smoother) {
-            case SMOOTHER_JACOBI: case SMOOTHER_L1DIAG: break;
+            case SMOOTHER_JACOBI: case SMOOTHER_L1DIAG:  // order independent: bandwidth-bound kernels
+            case SMOOTHER_GS: case SMOOTHER_SGS: case SMOOTHER_SOR: case SMOOTHER_SSOR:
+            case SMOOTHER_GSOR: case SMOOTHER_SGSOR:     // sequential sweeps: level-scheduled
+                break;
             default:
-                std::printf("### ERROR: fasp_hip: smoother %d has no device path yet "
-                            "(SMOOTHER_JACOBI, SMOOTHER_L1DIAG)\n", amg->smoother);
+                std::printf("### ERROR: fasp_hip: smoother %d has no device path\n", amg->smoother);
                 return ERROR_AMG_SMOOTH_TYPE;
         }
+        if (amg->smoother == SMOOTHER_GS && amg->smooth_order != NO_ORDER && amg->smooth_order != CF_ORDER)
+            return ERROR_INPUT_PAR;
         if (amg->coarse_solver != SOLVER_DEFAULT) {
             std::printf("### ERROR: fasp_hip: direct coarse solvers are not available\n");
             return ERROR_INPUT_PAR;

@@ -468,6 +468,49 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream(CsrArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Sequential sweeps (Gauss-Seidel / SOR family, ItrSmootherCSR.c:251-1040) by level
+// scheduling: the host groups the rows of a sweep into the levels of its dependency DAG
+// (a row depends on every coupled row that comes earlier in the sweep order), one launch
+// per DAG level updates all rows of that level in place; rows of a level are mutually
+// uncoupled, so the result equals the sequential sweep (row sums in a fixed tree order).
+//   form 0  u_i = t * (1/a_ii)                 fasp_smoother_dcsr_gs      :327-334
+//   form 1  u_i = t / a_ii                     _gs_cf :572-693, _sgs :845-880
+//   form 2  u_i = w (t / a_ii) + (1-w) u_i     _sor :981-993
+// with t = b_i - sum_{j != i} a_ij u_j.
+// ---------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(BLOCK) void k_seq_level(const int* __restrict__ order, int lo, int hi,
+                                                      const int* __restrict__ ia, const int* __restrict__ ja,
+                                                      const double* __restrict__ val,
+                                                      const double* __restrict__ b,
+                                                      const double* __restrict__ diag, double* u, int form,
+                                                      double w)
+{
+    constexpr int RPB = BLOCK / L;
+    const int sl = threadIdx.x & (L - 1);
+    const int rloc = threadIdx.x / L;
+    for (int idx = lo + blockIdx.x * RPB + rloc; idx < hi; idx += gridDim.x * RPB) {
+        const int r = order[idx];
+        const int kb = ia[r], ke = ia[r + 1];
+        double s = 0.0;
+        for (int k = kb + sl; k < ke; k += L) {
+            const int c = ja[k];
+            if (c != r) s += val[k] * u[c];
+        }
+        s = subwave_sum<L>(s);
+        if (sl == 0) {
+            const double d = diag[r];
+            const double t = b[r] - s;
+            if (fabs(d) > 1e-20) {
+                if (form == 0) u[r] = t * (1.0 / d);
+                else if (form == 1) u[r] = t / d;
+                else u[r] = w * (t / d) + (1 - w) * u[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // BLAS-1.  n is a double count; vectors come from hipMalloc (256-B aligned) so the
 // double2 path is always aligned; the odd tail element is handled by thread 0 of the
 // last block.  Partials layout: partials[q * gridDim.x + blockIdx.x].

@@ -311,6 +311,10 @@ struct DevLevel {
     int*    d_send_idx = nullptr;
     double* d_sendbuf  = nullptr;
     bool    has_halo() const { return !replicated && nvec > nloc; }
+    // level schedules of the sequential sweeps (built on first use): kind 0 ascending,
+    // 1 descending, 2 ascending C rows, 3 ascending F rows, 4 descending from row n-2
+    struct Sched { bool built = false; int* d_order = nullptr; std::vector<int> ptr; };
+    Sched   sched[5];
 };
 
 struct EventPair { hipEvent_t a, b; };
@@ -353,6 +357,7 @@ static void free_level(DevLevel& D)
     if (D.w) (void)hipFree(D.w);
     if (D.d_send_idx) (void)hipFree(D.d_send_idx);
     if (D.d_sendbuf) (void)hipFree(D.d_sendbuf);
+    for (auto& sc : D.sched) if (sc.d_order) (void)hipFree(sc.d_order);
     D = DevLevel();
 }
 
@@ -424,6 +429,9 @@ static int upload_hierarchy(fasp_hip_amg* h)
     h->L.resize(nl);
     int min_rows = 200000;
     if (const char* e = std::getenv("FASP_HIP_DIST_MIN_ROWS")) min_rows = std::atoi(e);
+    // sequential (Gauss-Seidel / SOR) sweeps couple all rows of a level: such hierarchies
+    // are not row-partitioned, every rank keeps (and computes) all levels
+    if (h->param.smoother != SMOOTHER_JACOBI && h->param.smoother != SMOOTHER_L1DIAG) min_rows = 2147483647;
     {
         const int st = build_dist_plan(h->H, comm_rank(), comm_size(), min_rows, h->dist);
         if (st < 0) return st;
@@ -486,27 +494,163 @@ static void materialise_zero(DevLevel& D)
     }
 }
 
-static void smooth(DevLevel& D, int smoother, int nsweeps, double relax)
+// Level schedule of one sequential sweep over the rows `seq` (in sweep order) of the host
+// matrix A: level(i) = 1 + max level of the rows coupled to i (pattern of A and of A^T) that
+// come earlier in the sweep.  Rows outside the sweep are not updated and impose nothing.
+static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLevel::Sched& S)
 {
-    const int n = D.A.row;
-    for (int s = 0; s < nsweeps; ++s) {
-        if (D.x_zero) {
-            // zero initial guess: t_i = b_i exactly, no matrix pass
-            if (smoother == SMOOTHER_JACOBI)
-                hipLaunchKernelGGL(k_jacobi_zero, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, relax,
-                                   D.b, D.diag, D.x);
-            else
-                hipLaunchKernelGGL(k_l1_zero, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, D.b, D.l1, D.x);
-            D.x_zero = false;
-            continue;
+    const int n = A.row;
+    std::vector<int> pos(n, -1), lev(n, 0);
+    for (int q = 0; q < (int)seq.size(); ++q) pos[seq[q]] = q;
+    // transpose pattern for the anti-dependencies of structurally unsymmetric matrices
+    std::vector<int> tia(n + 2, 0), tja(A.nnz);
+    for (int k = 0; k < A.nnz; ++k) if (A.ja[k] < n) tia[A.ja[k] + 2]++;
+    for (int i = 2; i <= n + 1; ++i) tia[i] += tia[i - 1];
+    for (int i = 0; i < n; ++i)
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
+            if (A.ja[k] < n) tja[tia[A.ja[k] + 1]++] = i;
+    int nlev = 0;
+    for (int q = 0; q < (int)seq.size(); ++q) {
+        const int i = seq[q];
+        int l = 0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            const int j = A.ja[k];
+            if (j != i && j < n && pos[j] >= 0 && pos[j] < q) l = std::max(l, lev[j]);
         }
-        (void)halo_exchange(D, D.x);
-        CsrArgs a{};
-        a.x = D.x; a.y = D.xo; a.b = D.b; a.omega = relax;
-        if (smoother == SMOOTHER_JACOBI) { a.diag = D.diag; launch_csr<OP_JACOBI>(D.A, a); }
-        else { a.diag = D.l1; launch_csr<OP_L1DIAG>(D.A, a); }
-        std::swap(D.x, D.xo);
+        for (int k = tia[i]; k < tia[i + 1]; ++k) {
+            const int j = tja[k];
+            if (j != i && pos[j] >= 0 && pos[j] < q) l = std::max(l, lev[j]);
+        }
+        lev[i] = l + 1;
+        nlev = std::max(nlev, l + 1);
     }
+    S.ptr.assign(nlev + 1, 0);
+    for (int i : seq) S.ptr[lev[i]]++;
+    for (int l = 0; l < nlev; ++l) S.ptr[l + 1] += S.ptr[l];
+    std::vector<int> cur(S.ptr.begin(), S.ptr.end() - 1), order(seq.size());
+    for (int i : seq) order[cur[lev[i] - 1]++] = i;
+    HIPCK(hipMalloc(&S.d_order, sizeof(int) * std::max<size_t>(order.size(), 1)));
+    if (!order.empty()) HIPCK(hipMemcpy(S.d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
+    S.built = true;
+    return FASP_SUCCESS;
+}
+
+// one sequential sweep of schedule `kind` with update formula `form` (see k_seq_level)
+static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
+{
+    DevLevel& D = h->L[level];
+    DevLevel::Sched& S = D.sched[kind];
+    if (!S.built) {
+        const HostCSR& A = h->H.L[level].A;
+        const int n = A.row;
+        std::vector<int> seq;
+        seq.reserve(n);
+        const int* cf = h->H.L[level].cfmark.n ? h->H.L[level].cfmark.data() : nullptr;
+        switch (kind) {
+            case 0: for (int i = 0; i < n; ++i) seq.push_back(i); break;
+            case 1: for (int i = n - 1; i >= 0; --i) seq.push_back(i); break;
+            case 2: for (int i = 0; i < n; ++i) if (cf && cf[i] == 1) seq.push_back(i); break;
+            case 3: for (int i = 0; i < n; ++i) if (!cf || cf[i] != 1) seq.push_back(i); break;
+            default: for (int i = n - 2; i >= 0; --i) seq.push_back(i); break;
+        }
+        const int st = build_schedule(A, seq, S);
+        if (st < 0) return st;
+    }
+    materialise_zero(D);
+    const int L = D.A.lanes;
+    const int nlev = (int)S.ptr.size() - 1;
+    for (int l = 0; l < nlev; ++l) {
+        const int lo = S.ptr[l], hi = S.ptr[l + 1];
+        const int rpb = BLOCK / L;
+        const int grid = std::max(1, std::min(MAXGRID, (hi - lo + rpb - 1) / rpb));
+#define SEQ_LAUNCH(LL) hipLaunchKernelGGL((k_seq_level<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, \
+        (const int*)S.d_order, lo, hi, (const int*)D.A.ia, (const int*)D.A.ja, (const double*)D.A.val,    \
+        (const double*)D.b, (const double*)D.diag, D.x, form, w)
+        switch (L) {
+            case 2: SEQ_LAUNCH(2); break;
+            case 4: SEQ_LAUNCH(4); break;
+            case 8: SEQ_LAUNCH(8); break;
+            case 16: SEQ_LAUNCH(16); break;
+            case 32: SEQ_LAUNCH(32); break;
+            default: SEQ_LAUNCH(64); break;
+        }
+#undef SEQ_LAUNCH
+    }
+    return FASP_SUCCESS;
+}
+
+// Smoother dispatch of PreMGSmoother.inl:49 (pre) / :155 (post).  Jacobi and L1-diag are
+// order independent, so their pre (ascending) and post (descending) sweeps coincide; the
+// Gauss-Seidel / SOR family runs as level-scheduled sequential sweeps.
+static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order, int nsweeps, double relax)
+{
+    DevLevel& D = h->L[level];
+    const int n = D.A.row;
+    if (smoother == SMOOTHER_JACOBI || smoother == SMOOTHER_L1DIAG) {
+        for (int s = 0; s < nsweeps; ++s) {
+            if (D.x_zero) {
+                // zero initial guess: t_i = b_i exactly, no matrix pass
+                if (smoother == SMOOTHER_JACOBI)
+                    hipLaunchKernelGGL(k_jacobi_zero, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, relax,
+                                       D.b, D.diag, D.x);
+                else
+                    hipLaunchKernelGGL(k_l1_zero, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, D.b, D.l1, D.x);
+                D.x_zero = false;
+                continue;
+            }
+            if (halo_exchange(D, D.x) < 0) return ERROR_MISC;
+            CsrArgs a{};
+            a.x = D.x; a.y = D.xo; a.b = D.b; a.omega = relax;
+            if (smoother == SMOOTHER_JACOBI) { a.diag = D.diag; launch_csr<OP_JACOBI>(D.A, a); }
+            else { a.diag = D.l1; launch_csr<OP_L1DIAG>(D.A, a); }
+            std::swap(D.x, D.xo);
+        }
+        return FASP_SUCCESS;
+    }
+    if (!D.replicated) return ERROR_AMG_SMOOTH_TYPE;  // sequential sweeps are not distributed
+    const bool has_cf = h->H.L[level].cfmark.n == (size_t)n;
+    auto rep = [&](int kind, int form, double w) -> int {  // nsweeps repetitions, as the `while (L--)` loops
+        for (int s = 0; s < nsweeps; ++s) { const int st = seq_sweep(h, level, kind, form, w); if (st < 0) return st; }
+        return FASP_SUCCESS;
+    };
+    int st = FASP_SUCCESS;
+    switch (smoother) {
+        case SMOOTHER_GS:
+            if (order == NO_ORDER || !has_cf) st = rep(post ? 1 : 0, 0, 0.0);
+            else if (order == CF_ORDER) {  // fasp_smoother_dcsr_gs_cf: pre C then F, post F then C
+                for (int s = 0; s < nsweeps && st >= 0; ++s) {
+                    st = seq_sweep(h, level, post ? 3 : 2, 1, 0.0);
+                    if (st >= 0) st = seq_sweep(h, level, post ? 2 : 3, 1, 0.0);
+                }
+            }
+            break;
+        case SMOOTHER_SGS:
+            for (int s = 0; s < nsweeps && st >= 0; ++s) {
+                st = seq_sweep(h, level, 0, 1, 0.0);
+                if (st >= 0) st = seq_sweep(h, level, 4, 1, 0.0);
+            }
+            break;
+        case SMOOTHER_SOR: st = rep(post ? 1 : 0, 2, relax); break;
+        case SMOOTHER_SSOR:
+            st = rep(0, 2, relax);
+            if (st >= 0) st = rep(1, 2, relax);
+            break;
+        case SMOOTHER_GSOR:
+            if (!post) { st = rep(0, 0, 0.0); if (st >= 0) st = rep(1, 2, relax); }
+            else       { st = rep(0, 2, relax); if (st >= 0) st = rep(1, 0, 0.0); }
+            break;
+        case SMOOTHER_SGSOR:
+            if (!post) {
+                st = rep(0, 0, 0.0); if (st >= 0) st = rep(1, 0, 0.0);
+                if (st >= 0) st = rep(0, 2, relax); if (st >= 0) st = rep(1, 2, relax);
+            } else {
+                st = rep(0, 2, relax); if (st >= 0) st = rep(1, 2, relax);
+                if (st >= 0) st = rep(0, 0, 0.0); if (st >= 0) st = rep(1, 0, 0.0);
+            }
+            break;
+        default: return ERROR_AMG_SMOOTH_TYPE;
+    }
+    return st;
 }
 
 // ---------------------------------------------------------------------------
@@ -963,12 +1107,13 @@ static int mgcycle(fasp_hip_amg* h, const AMG_param& param)
         default: for (int i = 0; i < MAX_AMG_LVL; ++i) ncycles[i] = cycle_type;
     }
     h->vcycles++;
+    int st0 = FASP_SUCCESS;
 
 ForwardSweep:
     while (l < nl - 1) {
         DevLevel& D = h->L[l];
         num_lvl[l]++;
-        smooth(D, smoother, param.presmooth_iter, relax);
+        if ((st0 = smooth(h, l, false, smoother, param.smooth_order, param.presmooth_iter, relax)) < 0) return st0;
         // w = b - A x ; b_{l+1} = R w
         if (D.x_zero) {
             HIPCK(hipMemcpyAsync(D.w, D.b, sizeof(double) * D.A.row, hipMemcpyDeviceToDevice, g_ctx.stream));
@@ -1035,7 +1180,7 @@ ForwardSweep:
             alpha = std::min(red[0] / red[1], 1.0);
         }
         d_aAxpy(alpha, D.P, C.x, D.x);  // x_l += alpha P x_{l+1}
-        smooth(D, smoother, param.postsmooth_iter, relax);
+        if ((st0 = smooth(h, l, true, smoother, param.smooth_order, param.postsmooth_iter, relax)) < 0) return st0;
         if (num_lvl[l] < ncycles[l]) break;
         else num_lvl[l] = 0;
     }

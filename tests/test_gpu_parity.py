@@ -248,9 +248,59 @@ def test_entry_point_krylov_amg(gpu):
     assert np.max(np.abs(x - x_ref)) <= 1e-9 * np.max(np.abs(x_ref))
 
 
+def _gs_default(itp, amgp):
+    itp.tol = 1e-8  # reference defaults: GS smoother with C/F ordering
+
+
+def _gs_nat(itp, amgp):
+    itp.tol = 1e-8; amgp.smooth_order = T.NO_ORDER
+
+
+def _sgs(itp, amgp):
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_SGS
+
+
+def _sor(itp, amgp):
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_SOR; amgp.relaxation = 1.1
+
+
+def _ssor2(itp, amgp):
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_SSOR; amgp.relaxation = 1.2; amgp.presmooth_iter = 2
+
+
+def _gsor_w(itp, amgp):
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_GSOR; amgp.relaxation = 0.9; amgp.cycle_type = T.W_CYCLE
+
+
+def _sgsor(itp, amgp):
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_SGSOR; amgp.relaxation = 1.05
+
+
+@pytest.mark.parametrize("n", [10, 24])
+@pytest.mark.parametrize("mod", [_gs_default, _gs_nat, _sgs, _sor, _ssor2, _gsor_w, _sgsor],
+                         ids=["gs-cf(default)", "gs-natural", "sgs", "sor1.1", "ssor-2sweeps", "gsor-W", "sgsor"])
+def test_sequential_smoothers(gpu, n, mod):
+    """Gauss-Seidel / SOR family (ItrSmootherCSR.c:251-1040) as level-scheduled sweeps:
+    same iteration counts and residual histories as the sequential oracle."""
+    ia, ja, a, f, ue = poisson7pt(n)
+    _cmp_solve(gpu, ia, ja, a, f, mod)
+
+
+def test_regression_defaults_fe(gpu):
+    """test/main/regression.c:658-671 'AMG preconditioned CG' with pure defaults on csrmat_FE:
+    golden test/out/reg.out:574-579 -> 6 iterations, relres 2.728796e-11."""
+    ia, ja, a = read_csr(DATA + "/csrmat_FE.dat"); f = read_vec(DATA + "/rhs_FE.dat")
+    sol = read_vecind(DATA + "/sol_FE.dat")
+    itp, amgp = default_params(); itp.tol = 1e-10; itp.maxit = 500
+    x = np.zeros(len(f))
+    it = gpu.solver_dcsr_krylov_amg(ia, ja, a, f, x, itp, amgp)
+    assert it == 6
+    assert np.max(np.abs(x - sol)) < 1e-4
+
+
 def test_unsupported_is_refused(gpu):
     ia, ja, a, f, ue = poisson7pt(6)
-    itp, amgp = default_params()  # default smoother is GS (sequential): no device path yet
+    itp, amgp = default_params(); amgp.smoother = 9  # SMOOTHER_POLY: not on the path
     x = np.zeros(len(f))
     assert gpu.solver_dcsr_krylov_amg(ia, ja, a, f, x, itp, amgp) == T.ERROR_AMG_SMOOTH_TYPE
     assert np.all(x == 0.0)

@@ -30,6 +30,8 @@ def _mods():
     def sor(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_SOR; a.relaxation = 1.1
     def ssor(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_SSOR; a.relaxation = 1.2
     def sgs(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_SGS
+    def gsor(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_GSOR; a.relaxation = 0.9; a.cycle_type = T.W_CYCLE
+    def sgsor(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_SGSOR; a.relaxation = 1.05
     def theta(i, a): jac(i, a); a.strong_threshold = 0.6; a.truncation_threshold = 0.4
     def precres(i, a): jac(i, a); i.stop_type = T.STOP_REL_PRECRES
     def modres(i, a): jac(i, a); i.stop_type = T.STOP_MOD_REL_RES
@@ -42,7 +44,7 @@ def _mods():
     def vgpre(i, a): vg(i, a); i.stop_type = T.STOP_REL_PRECRES
     def vfgmod(i, a): vfg(i, a); i.stop_type = T.STOP_MOD_REL_RES
     return dict(jac=jac, jacw=jacw, vw=vw, l1=l1, gscf=gscf, gsn=gsn, sor=sor, ssor=ssor, sgs=sgs,
-                theta=theta, precres=precres, modres=modres, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
+                theta=theta, precres=precres, modres=modres, gsor=gsor, sgsor=sgsor, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
                 vgpre=vgpre, vfgmod=vfgmod)
 
 
@@ -56,7 +58,7 @@ def test_histories_bit_exact(R, n, name):
     s2, x2, h2 = ref_solve(ia, ja, a, f, i2, a2)
     assert s1 == s2
     assert np.array_equal(x1, x2)
-    if name in ("jac", "jacw", "vw", "l1", "gscf", "gsn", "sor", "ssor", "sgs", "theta"):
+    if name in ("jac", "jacw", "vw", "l1", "gscf", "gsn", "sor", "ssor", "sgs", "theta", "gsor", "sgsor"):
         # PCG with STOP_REL_RES: the recorded preconditioner inputs are exactly the residuals
         assert np.array_equal(np.concatenate([h1[:-2], h1[-1:]]), h2)
 
