@@ -26,6 +26,8 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_blas_dcsr_mxv", "fasp_blas_dcsr_aAxpy", "fasp_blas_darray_dotprod",
     "fasp_blas_darray_norm2", "fasp_blas_darray_norminf", "fasp_blas_darray_axpy",
     "fasp_blas_darray_axpby", "fasp_smoother_dcsr_jacobi",
+    "fasp_blas_dbsr_mxv", "fasp_blas_dbsr_aAxpy", "fasp_dbsr_getdiaginv", "fasp_smoother_dbsr_jacobi1",
+    "fasp_hip_time_bsr_mxv",
     "fasp_hip_set_device", "fasp_hip_device_count", "fasp_hip_available",
     "fasp_hip_amg_create", "fasp_hip_amg_create_host", "fasp_hip_amg_upload",
     "fasp_hip_amg_destroy", "fasp_hip_amg_num_levels", "fasp_hip_amg_get_matrix",
@@ -73,6 +75,13 @@ def lib():
                                          T.c_double_p]
     L.fasp_smoother_dcsr_jacobi.argtypes = [P(T.dvector), C.c_int, C.c_int, C.c_int,
                                             P(T.dCSRmat), P(T.dvector), C.c_int, C.c_double]
+    L.fasp_blas_dbsr_mxv.argtypes = [P(T.dBSRmat), T.c_double_p, T.c_double_p]
+    L.fasp_blas_dbsr_aAxpy.argtypes = [C.c_double, P(T.dBSRmat), T.c_double_p, T.c_double_p]
+    L.fasp_dbsr_getdiaginv.argtypes = [P(T.dBSRmat)]
+    L.fasp_dbsr_getdiaginv.restype = T.dvector
+    L.fasp_smoother_dbsr_jacobi1.argtypes = [P(T.dBSRmat), P(T.dvector), P(T.dvector), T.c_double_p]
+    L.fasp_hip_time_bsr_mxv.argtypes = [P(T.dBSRmat), C.c_int]
+    L.fasp_hip_time_bsr_mxv.restype = C.c_double
     L.fasp_hip_amg_create.argtypes = [P(C.c_void_p), P(T.dCSRmat), P(T.AMG_param)]
     L.fasp_hip_amg_create_host.argtypes = L.fasp_hip_amg_create.argtypes
     L.fasp_hip_amg_upload.argtypes = [C.c_void_p]

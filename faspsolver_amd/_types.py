@@ -45,6 +45,11 @@ class dCSRmat(C.Structure):
                 ("IA", c_int_p), ("JA", c_int_p), ("val", c_double_p)]
 
 
+class dBSRmat(C.Structure):
+    _fields_ = [("ROW", C.c_int), ("COL", C.c_int), ("NNZ", C.c_int), ("nb", C.c_int),
+                ("storage_manner", C.c_int), ("val", c_double_p), ("IA", c_int_p), ("JA", c_int_p)]
+
+
 class dvector(C.Structure):
     _fields_ = [("row", C.c_int), ("val", c_double_p)]
 
@@ -102,6 +107,17 @@ def as_csr(ia, ja, val, ncol=None):
     A = dCSRmat(n, n if ncol is None else ncol, int(ia[-1]),
                 ia.ctypes.data_as(c_int_p), ja.ctypes.data_as(c_int_p),
                 val.ctypes.data_as(c_double_p))
+    return A, (ia, ja, val)
+
+
+def as_bsr(ia, ja, val, nb, ncol=None):
+    """Wrap numpy arrays in a dBSRmat (row-major nb x nb blocks).  Returns (struct, keepalive)."""
+    ia = np.ascontiguousarray(ia, dtype=np.int32)
+    ja = np.ascontiguousarray(ja, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64).reshape(-1)
+    n = ia.shape[0] - 1
+    A = dBSRmat(n, n if ncol is None else ncol, int(ia[-1]), nb, 0, val.ctypes.data_as(c_double_p),
+                ia.ctypes.data_as(c_int_p), ja.ctypes.data_as(c_int_p))
     return A, (ia, ja, val)
 
 

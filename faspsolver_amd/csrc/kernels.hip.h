@@ -468,6 +468,103 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream(CsrArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// BSR (block CSR, nb x nb row-major blocks) row kernel, wave-level stream design: a wavefront
+// owns 64/NB consecutive block rows; phase 1 sweeps the tile's contiguous span of block
+// values into the wave's LDS slab with unit-stride loads; phase 2 lane (block row, r) walks
+// the blocks of its row in storage order and adds (A_r0 x_0 + A_r1 x_1 + ...) -- inner sum
+// first, as fasp_blas_smat_ypAx (BlaSmallMat.c:779) -- so results are bit-identical to
+// fasp_blas_dbsr_mxv / _aAxpy / fasp_smoother_dbsr_jacobi1 for nb <= 7.
+//   OP 0: y = A x     OP 1: y = alpha ((1/alpha) y + A x)     OP 2: u' = Dinv (b - sum_{j != i} A_ij u_j)
+// ---------------------------------------------------------------------------
+struct BsrArgs {
+    int           ROW;
+    const int*    ia;
+    const int*    ja;
+    const double* val;
+    const double* x;     // gathered vector (OP 2: the old iterate u)
+    double*       y;     // output
+    const double* b;     // OP 2: right-hand side
+    const double* dinv;  // OP 2: inverse diagonal blocks
+    double        alpha; // OP 1
+    int           ntiles;
+};
+
+template <int NB, int OP>
+__global__ __launch_bounds__(BLOCK) void k_bsr_wstream(BsrArgs a)
+{
+    constexpr int NB2 = NB * NB;
+    constexpr int RW = 64 / NB;                 // block rows per wave tile
+    constexpr int CAPB = 2048 / NB2;            // blocks per LDS chunk (<= 16 KiB per wave)
+    __shared__ double lds_all[4 * CAPB * NB2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* lds = lds_all + wave * CAPB * NB2;
+    const int lb = lane / NB, r = lane - lb * NB;
+
+    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const int br0 = (t * 4 + wave) * RW;
+        if (br0 >= a.ROW) continue;
+        const int nbr = min(RW, a.ROW - br0);
+        const bool act = lb < nbr;
+        const int br = br0 + lb;
+        int kb = 0, ke = 0;
+        if (act) { kb = a.ia[br]; ke = a.ia[br + 1]; }
+        const int k0 = __shfl(kb, 0), k1 = __shfl(ke, (nbr - 1) * NB);
+        const size_t row = (size_t)br * NB + r;
+        double acc = 0.0;
+        if (act) {
+            if (OP == 1) acc = (a.alpha != 1.0) ? a.y[row] * (1.0 / a.alpha) : a.y[row];
+            if (OP == 2) acc = a.b[row];
+        }
+        for (int lo = k0; lo < k1; lo += CAPB) {
+            const int hi = min(lo + CAPB, k1);
+            const int ne = (hi - lo) * NB2;
+            const double* src = a.val + (size_t)lo * NB2;
+            for (int base = 0; base < ne; base += 512) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + lane + 64 * u;
+                    v[u] = (e < ne) ? __builtin_nontemporal_load(src + e) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + lane + 64 * u;
+                    if (e < ne) lds[e] = v[u];
+                }
+            }
+            wave_lds_sync();
+            if (act) {
+                const int pb = max(kb, lo), pe = min(ke, hi);
+                for (int k = pb; k < pe; ++k) {
+                    const int j = a.ja[k];
+                    if (OP == 2 && j == br) continue;
+                    const double* A = lds + (k - lo) * NB2 + r * NB;
+                    const double* xb = a.x + (size_t)j * NB;
+                    double s = A[0] * xb[0];
+#pragma unroll
+                    for (int c = 1; c < NB; ++c) s = s + A[c] * xb[c];
+                    if (OP == 2) acc -= s; else acc += s;
+                }
+            }
+            wave_lds_sync();
+        }
+        if (OP == 2) {
+            // u_i = Dinv_i * bt_i (fasp_blas_smat_mxv): bt lives in the NB lanes of the block row
+            double out = 0.0;
+            const double* D = a.dinv + (size_t)(act ? br : 0) * NB2 + r * NB;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const double btc = __shfl(acc, lb * NB + c);
+                if (act) out = (c == 0) ? D[0] * btc : out + D[c] * btc;
+            }
+            if (act) a.y[row] = out;
+        } else if (act) {
+            a.y[row] = (OP == 1 && a.alpha != 1.0) ? acc * a.alpha : acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Sequential sweeps (Gauss-Seidel / SOR family, ItrSmootherCSR.c:251-1040) by level
 // scheduling: the host groups the rows of a sweep into the levels of its dependency DAG
 // (a row depends on every coupled row that comes earlier in the sweep order), one launch

@@ -1424,6 +1424,59 @@ FINISHED:
 
 }  // namespace fasp
 
+// ---------------------------------------------------------------------------
+// BSR operators (config 3): host pointers in/out, device kernels
+// ---------------------------------------------------------------------------
+namespace fasp_bsr {
+struct TmpBSR {
+    int ROW = 0, nb = 0, NNZ = 0;
+    int *ia = nullptr, *ja = nullptr;
+    double* val = nullptr;
+    bool ok = false;
+    explicit TmpBSR(const dBSRmat* A)
+    {
+        if (ctx_init() < 0 || !A || A->nb < 1 || A->nb > 7 || A->storage_manner != 0) return;
+        ROW = A->ROW; nb = A->nb; NNZ = A->NNZ;
+        const size_t nv = (size_t)NNZ * nb * nb;
+        if (hipMalloc(&ia, sizeof(int) * ((size_t)ROW + 1)) != hipSuccess) return;
+        if (hipMalloc(&ja, sizeof(int) * std::max(NNZ, 1)) != hipSuccess) return;
+        if (hipMalloc(&val, sizeof(double) * std::max<size_t>(nv, 1)) != hipSuccess) return;
+        (void)hipMemcpy(ia, A->IA, sizeof(int) * ((size_t)ROW + 1), hipMemcpyHostToDevice);
+        (void)hipMemcpy(ja, A->JA, sizeof(int) * (size_t)NNZ, hipMemcpyHostToDevice);
+        (void)hipMemcpy(val, A->val, sizeof(double) * nv, hipMemcpyHostToDevice);
+        ok = true;
+    }
+    ~TmpBSR() { if (ia) (void)hipFree(ia); if (ja) (void)hipFree(ja); if (val) (void)hipFree(val); }
+};
+
+template <int OP>
+void launch_bsr(const TmpBSR& M, BsrArgs a)
+{
+    a.ROW = M.ROW; a.ia = M.ia; a.ja = M.ja; a.val = M.val;
+    const int rw = 64 / M.nb;
+    a.ntiles = (M.ROW + 4 * rw - 1) / (4 * rw);
+#define BSR_CASE(NBV)                                                                              \
+    case NBV: {                                                                                    \
+        int cap = resident_blocks_per_cu(k_bsr_wstream<NBV, OP>) * g_ctx.num_cu;                   \
+        const int grid = std::max(1, std::min(std::min(cap, MAXGRID), a.ntiles));                  \
+        hipLaunchKernelGGL((k_bsr_wstream<NBV, OP>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, a); \
+    } break;
+    switch (M.nb) {
+        BSR_CASE(1) BSR_CASE(2) BSR_CASE(3) BSR_CASE(4) BSR_CASE(5) BSR_CASE(6) BSR_CASE(7)
+        default: break;
+    }
+#undef BSR_CASE
+}
+[[noreturn]] void die_bsr(const char* fn)
+{
+    std::fprintf(stderr, "### ERROR: %s: needs a HIP device, storage_manner 0 and 1 <= nb <= 7 "
+                         "(libfasp_hip has no CPU fallback)\n", fn);
+    std::exit(ERROR_MISC);
+}
+}  // namespace fasp_bsr
+using namespace fasp_bsr;
+
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -1810,6 +1863,104 @@ void fasp_blas_darray_axpby(const int n, const double a, const double* x, const 
     TmpVec dx(x, n), dy(y, n);
     d_axpby(n, a, dx.d, b, dy.d);
     dy.get(y);
+}
+
+void fasp_blas_dbsr_mxv(const dBSRmat* A, const double* x, double* y)
+{
+    TmpBSR M(A);
+    if (!M.ok) die_bsr(__func__);
+    TmpVec dx(x, (size_t)A->COL * A->nb), dy(nullptr, (size_t)A->ROW * A->nb);
+    BsrArgs a{}; a.x = dx.d; a.y = dy.d;
+    launch_bsr<0>(M, a);
+    dy.get(y);
+}
+
+void fasp_blas_dbsr_aAxpy(const double alpha, const dBSRmat* A, const double* x, double* y)
+{
+    if (alpha == 0.0) return;  // BlaSpmvBSR.c:548
+    TmpBSR M(A);
+    if (!M.ok) die_bsr(__func__);
+    TmpVec dx(x, (size_t)A->COL * A->nb), dy(y, (size_t)A->ROW * A->nb);
+    BsrArgs a{}; a.x = dx.d; a.y = dy.d; a.alpha = alpha;
+    launch_bsr<1>(M, a);
+    dy.get(y);
+}
+
+// BlaSparseBSR.c:543 (host): diagonal blocks inverted with the reference's closed forms
+// (fasp_smat_inv_nc2 / _nc3, BlaSmallMatInv.c:33 / :67); nb == 1: reciprocals
+dvector fasp_dbsr_getdiaginv(const dBSRmat* A)
+{
+    dvector out{0, nullptr};
+    if (!A || A->nb < 1 || A->nb > 3) {
+        std::fprintf(stderr, "### ERROR: fasp_dbsr_getdiaginv: block size %d not supported (1..3)\n", A ? A->nb : -1);
+        return out;
+    }
+    const int nb = A->nb, nb2 = nb * nb;
+    out.row = A->ROW * nb2;
+    out.val = (double*)std::calloc((size_t)std::max(out.row, 1), sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < A->ROW; ++i) {
+        double* a = out.val + (size_t)i * nb2;
+        for (int k = A->IA[i]; k < A->IA[i + 1]; ++k)
+            if (A->JA[k] == i) std::memcpy(a, A->val + (size_t)k * nb2, sizeof(double) * nb2);
+        if (nb == 1) {
+            a[0] = 1.0 / a[0];
+        } else if (nb == 2) {
+            const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+            const double det = a0 * a3 - a1 * a2;
+            if (std::fabs(det) < SMALLREAL) { a[0] = 1.0; a[1] = 0.0; a[2] = 0.0; a[3] = 1.0; }
+            else {
+                const double det_inv = 1.0 / det;
+                a[0] = a3 * det_inv; a[1] = -a1 * det_inv; a[2] = -a2 * det_inv; a[3] = a0 * det_inv;
+            }
+        } else {
+            const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8];
+            const double M0 = a4 * a8 - a5 * a7, M3 = a2 * a7 - a1 * a8, M6 = a1 * a5 - a2 * a4;
+            const double M1 = a5 * a6 - a3 * a8, M4 = a0 * a8 - a2 * a6, M7 = a2 * a3 - a0 * a5;
+            const double M2 = a3 * a7 - a4 * a6, M5 = a1 * a6 - a0 * a7, M8 = a0 * a4 - a1 * a3;
+            const double det = a0 * M0 + a3 * M3 + a6 * M6;
+            if (std::fabs(det) < SMALLREAL) {
+                a[0] = 1.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0; a[4] = 1.0; a[5] = 0.0; a[6] = 0.0; a[7] = 0.0; a[8] = 1.0;
+            } else {
+                const double det_inv = 1.0 / det;
+                a[0] = M0 * det_inv; a[1] = M3 * det_inv; a[2] = M6 * det_inv;
+                a[3] = M1 * det_inv; a[4] = M4 * det_inv; a[5] = M7 * det_inv;
+                a[6] = M2 * det_inv; a[7] = M5 * det_inv; a[8] = M8 * det_inv;
+            }
+        }
+    }
+    return out;
+}
+
+void fasp_smoother_dbsr_jacobi1(dBSRmat* A, dvector* b, dvector* u, double* diaginv)
+{
+    TmpBSR M(A);
+    if (!M.ok) die_bsr(__func__);
+    const size_t n = (size_t)A->ROW * A->nb;
+    TmpVec du(u->val, n), dun(nullptr, n), db(b->val, n), dd(diaginv, (size_t)A->ROW * A->nb * A->nb);
+    BsrArgs a{}; a.x = du.d; a.y = dun.d; a.b = db.d; a.dinv = dd.d;
+    launch_bsr<2>(M, a);
+    dun.get(u->val);
+}
+
+double fasp_hip_time_bsr_mxv(const dBSRmat* A, int reps)
+{
+    TmpBSR M(A);
+    if (!M.ok || reps <= 0) return -1.0;
+    TmpVec dx(nullptr, (size_t)A->COL * A->nb), dy(nullptr, (size_t)A->ROW * A->nb);
+    (void)hipMemsetAsync(dx.d, 0, sizeof(double) * dx.n, g_ctx.stream);
+    BsrArgs a{}; a.x = dx.d; a.y = dy.d;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    launch_bsr<0>(M, a); launch_bsr<0>(M, a);
+    (void)hipEventRecord(e0, g_ctx.stream);
+    for (int i = 0; i < reps; ++i) launch_bsr<0>(M, a);
+    (void)hipEventRecord(e1, g_ctx.stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return (double)ms / reps;
 }
 
 // ItrSmootherCSR.c:98 -- rows i_1..i_n (either direction) of the square system

@@ -139,6 +139,19 @@ typedef struct dCSRmat {
     double* val; /* nnz values */
 } dCSRmat;
 
+/* fasp_block.h:34  sizeof == 48.  Block CSR: ROW x COL blocks of nb x nb, NNZ stored blocks,
+ * val[NNZ*nb*nb] with every block row-major (storage_manner 0). */
+typedef struct dBSRmat {
+    int     ROW;
+    int     COL;
+    int     NNZ;
+    int     nb;
+    int     storage_manner;
+    double* val;
+    int*    IA;
+    int*    JA;
+} dBSRmat;
+
 /* fasp.h:354  sizeof == 16 */
 typedef struct dvector {
     int     row;
@@ -257,6 +270,17 @@ void   fasp_blas_darray_axpby(const int n, const double a, const double* x,
                               const double b, double* y);                             /* BlaArray.c:620 */
 void   fasp_smoother_dcsr_jacobi(dvector* u, const int i_1, const int i_n, const int s,
                                  dCSRmat* A, dvector* b, int L, const double w);      /* ItrSmootherCSR.c:98 */
+
+/* Block (BSR) operators of config 3, same conventions (host pointers, device kernels).
+ * nb <= 7: every block contributes y_r += (A_r0 x_0 + A_r1 x_1 + ...), inner sum first, exactly
+ * as fasp_blas_smat_ypAx (BlaSmallMat.c:779). */
+void   fasp_blas_dbsr_mxv(const dBSRmat* A, const double* x, double* y);              /* BlaSpmvBSR.c:1055 */
+void   fasp_blas_dbsr_aAxpy(const double alpha, const dBSRmat* A, const double* x,
+                            double* y);                                               /* BlaSpmvBSR.c:514 */
+dvector fasp_dbsr_getdiaginv(const dBSRmat* A);                                       /* BlaSparseBSR.c:543 (host; nb <= 3) */
+void   fasp_smoother_dbsr_jacobi1(dBSRmat* A, dvector* b, dvector* u, double* diaginv); /* ItrSmootherBSR.c:263 */
+/* mean milliseconds per launch of the BSR SpMV kernel on a resident copy of A (HIP events) */
+double fasp_hip_time_bsr_mxv(const dBSRmat* A, int reps);
 
 /* ------------------------------------------------------------------------ */
 /* extensions: device binding, resident hierarchy, instrumentation          */

@@ -64,6 +64,13 @@ double orc_norminf(int n, const double* x);                                    /
 void   orc_axpy(int n, double a, const double* x, double* y);                  /* BlaArray.c:90 */
 void   orc_axpby(int n, double a, const double* x, double b, double* y);       /* BlaArray.c:620 */
 
+/* block (BSR) operators: BlaSpmvBSR.c:1055 / :514, BlaSparseBSR.c:543, ItrSmootherBSR.c:263 */
+void    orc_bsr_mxv(const dBSRmat* A, const double* x, double* y);
+void    orc_bsr_aAxpy(double alpha, const dBSRmat* A, const double* x, double* y);
+double* orc_bsr_getdiaginv(const dBSRmat* A);
+void    orc_bsr_jacobi1(const dBSRmat* A, const double* b, double* u, const double* diaginv);
+void    orc_free(void* p);
+
 /* smoothers: ItrSmootherCSR.c */
 void orc_smoother_jacobi(double* u, int i_1, int i_n, int s, const dCSRmat* A,
                          const double* b, int L, double w);                    /* :98 */

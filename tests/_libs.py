@@ -204,3 +204,26 @@ def default_params(lib=None):
     itp = T.ITS_param(); amgp = T.AMG_param()
     lib.orc_param_solver_init(C.byref(itp)); lib.orc_param_amg_init(C.byref(amgp))
     return itp, amgp
+
+
+def read_bsr(path):
+    """fasp_dbsr_read format (BlaIO.c:807): ROW COL NNZ / nb / storage_manner / n, IA / n, JA / n, val."""
+    tok = open(path).read().split()
+    ROW, COL, NNZ, nb, sm = (int(t) for t in tok[:5])
+    p = 5
+    n = int(tok[p]); ia = np.array(tok[p + 1:p + 1 + n], dtype=np.int32); p += 1 + n
+    n = int(tok[p]); ja = np.array(tok[p + 1:p + 1 + n], dtype=np.int32); p += 1 + n
+    n = int(tok[p]); val = np.array(tok[p + 1:p + 1 + n], dtype=np.float64)
+    assert sm == 0 and len(ia) == ROW + 1 and len(ja) == NNZ and len(val) == NNZ * nb * nb
+    return ia, ja, val, nb
+
+
+B3 = np.array([[4.0, 1.0, 0.0], [1.0, 3.0, 1.0], [0.0, 1.0, 2.0]])  # SURVEY.md section 8d
+
+
+def poisson7pt_bsr(n, block=B3):
+    """Synthetic multi-block system P7(n) (x) B: every scalar entry a_ij becomes a_ij * B."""
+    ia, ja, a, f, ue = poisson7pt(n)
+    nb = block.shape[0]
+    val = (a[:, None, None] * block[None, :, :]).reshape(-1)
+    return ia, ja, val, nb
