@@ -27,7 +27,9 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_blas_darray_norm2", "fasp_blas_darray_norminf", "fasp_blas_darray_axpy",
     "fasp_blas_darray_axpby", "fasp_smoother_dcsr_jacobi",
     "fasp_blas_dbsr_mxv", "fasp_blas_dbsr_aAxpy", "fasp_dbsr_getdiaginv", "fasp_smoother_dbsr_jacobi1",
-    "fasp_hip_time_bsr_mxv",
+    "fasp_hip_time_bsr_mxv", "fasp_solver_dbsr_krylov_amg", "fasp_hip_bsr_amg_create", "fasp_hip_bsr_amg_create_host",
+    "fasp_hip_bsr_amg_destroy", "fasp_hip_bsr_amg_num_levels", "fasp_hip_bsr_amg_get_matrix",
+    "fasp_hip_bsr_amg_get_diaginv", "fasp_hip_bsr_solve",
     "fasp_hip_set_device", "fasp_hip_device_count", "fasp_hip_available",
     "fasp_hip_amg_create", "fasp_hip_amg_create_host", "fasp_hip_amg_upload",
     "fasp_hip_amg_destroy", "fasp_hip_amg_num_levels", "fasp_hip_amg_get_matrix",
@@ -82,6 +84,18 @@ def lib():
     L.fasp_smoother_dbsr_jacobi1.argtypes = [P(T.dBSRmat), P(T.dvector), P(T.dvector), T.c_double_p]
     L.fasp_hip_time_bsr_mxv.argtypes = [P(T.dBSRmat), C.c_int]
     L.fasp_hip_time_bsr_mxv.restype = C.c_double
+    L.fasp_solver_dbsr_krylov_amg.argtypes = [P(T.dBSRmat), P(T.dvector), P(T.dvector), P(T.ITS_param),
+                                              P(T.AMG_param)]
+    L.fasp_hip_bsr_amg_create.argtypes = [P(C.c_void_p), P(T.dBSRmat), P(T.AMG_param)]
+    L.fasp_hip_bsr_amg_create_host.argtypes = [P(C.c_void_p), P(T.dBSRmat), P(T.AMG_param)]
+    L.fasp_hip_bsr_amg_destroy.argtypes = [C.c_void_p]
+    L.fasp_hip_bsr_amg_destroy.restype = None
+    L.fasp_hip_bsr_amg_num_levels.argtypes = [C.c_void_p]
+    L.fasp_hip_bsr_amg_get_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int, P(T.dBSRmat)]
+    L.fasp_hip_bsr_amg_get_diaginv.argtypes = [C.c_void_p, C.c_int]
+    L.fasp_hip_bsr_amg_get_diaginv.restype = T.c_double_p
+    L.fasp_hip_bsr_solve.argtypes = [C.c_void_p, P(T.dvector), P(T.dvector), P(T.ITS_param), T.c_double_p,
+                                     C.c_int, P(T.fasp_hip_stats)]
     L.fasp_hip_amg_create.argtypes = [P(C.c_void_p), P(T.dCSRmat), P(T.AMG_param)]
     L.fasp_hip_amg_create_host.argtypes = L.fasp_hip_amg_create.argtypes
     L.fasp_hip_amg_upload.argtypes = [C.c_void_p]
@@ -296,3 +310,73 @@ class AMG:
             self.close()
         except Exception:
             pass
+
+
+class BSRAMG:
+    """Resident block hierarchy (fasp_hip_amg_bsr, config 3).  host_only=True skips the GPU upload."""
+
+    def __init__(self, ia, ja, val, nb, amgparam, host_only=False):
+        self._A, self._keep = T.as_bsr(ia, ja, val, nb)
+        self.h = C.c_void_p()
+        fn = lib().fasp_hip_bsr_amg_create_host if host_only else lib().fasp_hip_bsr_amg_create
+        self.status = fn(C.byref(self.h), C.byref(self._A), C.byref(amgparam))
+        if self.status < 0:
+            self.h = C.c_void_p()
+            raise RuntimeError(f"fasp_hip_bsr_amg_create failed with status {self.status}")
+        self.nb = nb
+        self.n = self._A.ROW * nb
+
+    @property
+    def num_levels(self):
+        return lib().fasp_hip_bsr_amg_num_levels(self.h)
+
+    def matrix(self, level, which):
+        """which: 0 A, 1 P, 2 R -> (ROW, COL, NNZ, ia, ja, val) copies."""
+        v = T.dBSRmat()
+        if lib().fasp_hip_bsr_amg_get_matrix(self.h, level, which, C.byref(v)) < 0:
+            raise IndexError((level, which))
+        ia = np.ctypeslib.as_array(v.IA, (v.ROW + 1,)).copy()
+        ja = np.ctypeslib.as_array(v.JA, (max(v.NNZ, 1),))[:v.NNZ].copy()
+        nv = v.NNZ * v.nb * v.nb
+        val = np.ctypeslib.as_array(v.val, (max(nv, 1),))[:nv].copy()
+        return v.ROW, v.COL, v.NNZ, ia, ja, val
+
+    def diaginv(self, level):
+        p = lib().fasp_hip_bsr_amg_get_diaginv(self.h, level)
+        if not p:
+            return None
+        v = T.dBSRmat()
+        lib().fasp_hip_bsr_amg_get_matrix(self.h, level, 0, C.byref(v))
+        return np.ctypeslib.as_array(p, (v.ROW * v.nb * v.nb,)).copy()
+
+    def solve(self, b, itparam, x0=None, hist_cap=1200):
+        """Krylov solve on the resident block hierarchy -> (status, x, hist, stats)."""
+        x = np.zeros(self.n) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        bv, _b = T.as_vec(b)
+        xv, x = T.as_vec(x)
+        hist = np.zeros(hist_cap)
+        stats = T.fasp_hip_stats()
+        st = lib().fasp_hip_bsr_solve(self.h, C.byref(bv), C.byref(xv), C.byref(itparam), T.dp(hist),
+                                      hist_cap, C.byref(stats))
+        return st, x, hist[:max(min(stats.nhist, hist_cap), 0)].copy(), stats
+
+    def free(self):
+        if self.h:
+            lib().fasp_hip_bsr_amg_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def solver_dbsr_krylov_amg(ia, ja, val, nb, b, x, itparam, amgparam):
+    """Drop-in call of fasp_solver_dbsr_krylov_amg (SolBSR.c:349): x is the guess on entry, solution on exit."""
+    A, _keep = T.as_bsr(ia, ja, val, nb)
+    bv, _b = T.as_vec(b)
+    assert x.dtype == np.float64 and x.flags.c_contiguous
+    xv = T.dvector(len(x), T.dp(x))
+    return lib().fasp_solver_dbsr_krylov_amg(C.byref(A), C.byref(bv), C.byref(xv), C.byref(itparam),
+                                             C.byref(amgparam))

@@ -113,6 +113,37 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H);
 // Smoothed aggregation (PreAMGSetupSA.c:63: VMB aggregation, smoothed P and R).
 int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H);
 
+// ---- block (BSR) hierarchy of the unsmoothed-aggregation setup (config 3) ------------
+struct HostBSR {
+    int         ROW = 0, COL = 0, NNZ = 0, nb = 0;
+    Buf<int>    ia, ja;
+    Buf<double> val;  // NNZ blocks of nb*nb doubles, row-major (storage_manner 0)
+    dBSRmat     view() const
+    {
+        dBSRmat v;
+        v.ROW = ROW; v.COL = COL; v.NNZ = NNZ; v.nb = nb; v.storage_manner = 0;
+        v.val = const_cast<double*>(val.data());
+        v.IA = const_cast<int*>(ia.data());
+        v.JA = const_cast<int*>(ja.data());
+        return v;
+    }
+};
+struct HostLevelBSR {
+    HostBSR     A, P, R;
+    Buf<double> diaginv;  // inverse diagonal blocks of A (levels that are smoothed)
+    bool        has_coarse = false;
+};
+struct HostHierarchyBSR {
+    std::vector<HostLevelBSR> L;
+    double setup_seconds = 0.0;
+};
+// Unsmoothed aggregation on a block matrix (PreAMGSetupUABSR.c:55): VMB aggregation of the
+// condensed scalar matrix, identity-block prolongation, block Galerkin product.
+int host_setup_ua_bsr(const dBSRmat* A, AMG_param* param, HostHierarchyBSR& H);
+// inverse diagonal blocks (BlaSparseBSR.c:543), nb <= 3 closed forms
+int bsr_diaginv(const dBSRmat* A, double* out);
+int check_supported_bsr(const ITS_param* itparam, const AMG_param* amgparam, int nb);
+
 // Parameter screening: every AMG_param / ITS_param combination without a device
 // path returns a negative ERROR_* code here (never a silent CPU fallback).
 int check_supported(const ITS_param* itparam, const AMG_param* amgparam);

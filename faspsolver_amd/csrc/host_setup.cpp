@@ -1033,6 +1033,305 @@ int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
     return status;
 }
 
+// ===========================================================================
+// Block (BSR) unsmoothed aggregation, config 3 of BASELINE.json
+// ===========================================================================
+namespace {
+
+// fasp_blas_smat_mul (BlaSmallMat.c): c_ij = a_i0 b_0j + a_i1 b_1j + ..., left to right
+inline void smat_mul(const double* a, const double* b, double* c, int n)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = a[i * n] * b[j];
+            for (int k = 1; k < n; ++k) s = s + a[i * n + k] * b[k * n + j];
+            c[i * n + j] = s;
+        }
+}
+
+void copy_bsr(const dBSRmat* A, HostBSR& B)
+{
+    const size_t nb2 = (size_t)A->nb * A->nb;
+    B.ROW = A->ROW; B.COL = A->COL; B.NNZ = A->NNZ; B.nb = A->nb;
+    B.ia.alloc((size_t)A->ROW + 1); B.ja.alloc((size_t)A->NNZ); B.val.alloc((size_t)A->NNZ * nb2);
+    std::memcpy(B.ia.data(), A->IA, sizeof(int) * ((size_t)A->ROW + 1));
+    std::memcpy(B.ja.data(), A->JA, sizeof(int) * (size_t)A->NNZ);
+    std::memcpy(B.val.data(), A->val, sizeof(double) * (size_t)A->NNZ * nb2);
+}
+
+// condenseBSR (PreAMGAggregationBSR.inl:30-70): the (0,0) entry of every block, then
+// fasp_dcsr_compress_inplace(.., 1e-8) (BlaSparseCSR.c:1166) keeps |v| > 1e-8 and diagonals
+void condense_bsr(const HostBSR& A, HostCSR& S)
+{
+    const size_t nb2 = (size_t)A.nb * A.nb;
+    S.row = A.ROW; S.col = A.COL;
+    S.ia.alloc((size_t)A.ROW + 1);
+    S.ja.alloc((size_t)A.NNZ); S.val.alloc((size_t)A.NNZ);
+    int k = 0;
+    S.ia[0] = 0;
+    for (int i = 0; i < A.ROW; ++i) {
+        for (int j = A.ia[i]; j < A.ia[i + 1]; ++j) {
+            const double v = A.val[(size_t)j * nb2];
+            if (std::fabs(v) > 1e-8 || A.ja[j] == i) { S.ja[k] = A.ja[j]; S.val[k] = v; ++k; }
+        }
+        S.ia[i + 1] = k;
+    }
+    S.nnz = k;
+}
+
+// fasp_dbsr_trans (BlaSparseBSR.c:246): stable counting transpose, every block transposed
+void transpose_bsr(const HostBSR& A, HostBSR& AT)
+{
+    const int n = A.ROW, m = A.COL, nnz = A.NNZ, nb = A.nb, nb2 = nb * nb;
+    AT.ROW = m; AT.COL = n; AT.NNZ = nnz; AT.nb = nb;
+    AT.ia.alloc((size_t)m + 2); AT.ia.zero();
+    AT.ja.alloc((size_t)nnz); AT.val.alloc((size_t)nnz * nb2);
+    for (int j = 0; j < nnz; ++j) { const int c = A.ja[j]; if (c < m - 1) AT.ia[c + 2]++; }
+    for (int i = 2; i <= m; ++i) AT.ia[i] += AT.ia[i - 1];
+    for (int i = 0; i < n; ++i)
+        for (int p = A.ia[i]; p < A.ia[i + 1]; ++p) {
+            const int j = A.ja[p] + 1;
+            const int k = AT.ia[j];
+            AT.ja[k] = i;
+            for (int a = 0; a < nb; ++a)
+                for (int b = 0; b < nb; ++b)
+                    AT.val[(size_t)nb2 * k + a * nb + b] = A.val[(size_t)nb2 * p + b * nb + a];
+            AT.ia[j] = k + 1;
+        }
+}
+
+// fasp_blas_dbsr_rap (BlaSpmvBSR.c:5466, serial branch): the scalar product's two passes
+// (diagonal first, then columns in discovery order) with block products (R_ik A_kl) P_lj
+// formed by smat_mul and accumulated with +=.  Rows are independent: the symbolic pass
+// counts per row in parallel, the numeric pass fills each row with a private marker.
+void galerkin_rap_bsr(const HostBSR& R, const HostBSR& A, const HostBSR& P, HostBSR& B)
+{
+    const int row = R.ROW, col = P.COL, nb = A.nb, nb2 = nb * nb;
+    B.ROW = row; B.COL = col; B.nb = nb;
+    B.ia.alloc((size_t)row + 1);
+    std::vector<int> cnt((size_t)row);
+    const int ncmark = std::max(row, col);
+#pragma omp parallel
+    {
+        std::vector<int> Pm((size_t)ncmark, -1), Am((size_t)A.ROW, -1);
+#pragma omp for schedule(dynamic, 256)
+        for (int i = 0; i < row; ++i) {
+            int c = 1;
+            Pm[i] = i;  // stamp = row index
+            for (int j1 = R.ia[i]; j1 < R.ia[i + 1]; ++j1) {
+                const int i1 = R.ja[j1];
+                for (int j2 = A.ia[i1]; j2 < A.ia[i1 + 1]; ++j2) {
+                    const int i2 = A.ja[j2];
+                    if (Am[i2] != i) {
+                        Am[i2] = i;
+                        for (int j3 = P.ia[i2]; j3 < P.ia[i2 + 1]; ++j3) {
+                            const int i3 = P.ja[j3];
+                            if (Pm[i3] != i) { Pm[i3] = i; ++c; }
+                        }
+                    }
+                }
+            }
+            cnt[i] = c;
+        }
+    }
+    B.ia[0] = 0;
+    for (int i = 0; i < row; ++i) B.ia[i + 1] = B.ia[i] + cnt[i];
+    B.NNZ = B.ia[row];
+    B.ja.alloc((size_t)B.NNZ); B.val.alloc((size_t)B.NNZ * nb2);
+#pragma omp parallel
+    {
+        std::vector<int> Pm((size_t)ncmark, -1), Am((size_t)A.ROW, -1);
+        std::vector<double> tmp((size_t)2 * nb2);
+        double *t1 = tmp.data(), *t2 = tmp.data() + nb2;
+#pragma omp for schedule(dynamic, 256)
+        for (int i = 0; i < row; ++i) {
+            const int begin = B.ia[i];
+            int counter = begin;
+            Pm[i] = counter;
+            B.ja[counter] = i;
+            for (int e = 0; e < nb2; ++e) B.val[(size_t)counter * nb2 + e] = 0.0;
+            ++counter;
+            for (int j1 = R.ia[i]; j1 < R.ia[i + 1]; ++j1) {
+                const int i1 = R.ja[j1];
+                for (int j2 = A.ia[i1]; j2 < A.ia[i1 + 1]; ++j2) {
+                    smat_mul(R.val.data() + (size_t)j1 * nb2, A.val.data() + (size_t)j2 * nb2, t1, nb);
+                    const int i2 = A.ja[j2];
+                    const bool first = Am[i2] != i;
+                    Am[i2] = i;
+                    for (int j3 = P.ia[i2]; j3 < P.ia[i2 + 1]; ++j3) {
+                        const int i3 = P.ja[j3];
+                        smat_mul(t1, P.val.data() + (size_t)j3 * nb2, t2, nb);
+                        if (first && Pm[i3] < begin) {
+                            Pm[i3] = counter;
+                            std::memcpy(B.val.data() + (size_t)counter * nb2, t2, sizeof(double) * nb2);
+                            B.ja[counter] = i3;
+                            ++counter;
+                        } else {
+                            double* dst = B.val.data() + (size_t)Pm[i3] * nb2;
+                            for (int e = 0; e < nb2; ++e) dst[e] += t2[e];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int bsr_diaginv(const dBSRmat* A, double* out)
+{
+    if (!A || A->nb < 1 || A->nb > 3) return ERROR_INPUT_PAR;
+    const int nb = A->nb, nb2 = nb * nb;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < A->ROW; ++i) {
+        double* a = out + (size_t)i * nb2;
+        for (int e = 0; e < nb2; ++e) a[e] = 0.0;
+        for (int k = A->IA[i]; k < A->IA[i + 1]; ++k)
+            if (A->JA[k] == i) std::memcpy(a, A->val + (size_t)k * nb2, sizeof(double) * nb2);
+        if (nb == 1) {
+            a[0] = 1.0 / a[0];
+        } else if (nb == 2) {  // fasp_smat_inv_nc2, BlaSmallMatInv.c:33
+            const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+            const double det = a0 * a3 - a1 * a2;
+            if (std::fabs(det) < SMALLREAL) { a[0] = 1.0; a[1] = 0.0; a[2] = 0.0; a[3] = 1.0; }
+            else {
+                const double det_inv = 1.0 / det;
+                a[0] = a3 * det_inv; a[1] = -a1 * det_inv; a[2] = -a2 * det_inv; a[3] = a0 * det_inv;
+            }
+        } else {  // fasp_smat_inv_nc3, BlaSmallMatInv.c:67
+            const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8];
+            const double M0 = a4 * a8 - a5 * a7, M3 = a2 * a7 - a1 * a8, M6 = a1 * a5 - a2 * a4;
+            const double M1 = a5 * a6 - a3 * a8, M4 = a0 * a8 - a2 * a6, M7 = a2 * a3 - a0 * a5;
+            const double M2 = a3 * a7 - a4 * a6, M5 = a1 * a6 - a0 * a7, M8 = a0 * a4 - a1 * a3;
+            const double det = a0 * M0 + a3 * M3 + a6 * M6;
+            if (std::fabs(det) < SMALLREAL) {
+                a[0] = 1.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0; a[4] = 1.0; a[5] = 0.0; a[6] = 0.0; a[7] = 0.0; a[8] = 1.0;
+            } else {
+                const double det_inv = 1.0 / det;
+                a[0] = M0 * det_inv; a[1] = M3 * det_inv; a[2] = M6 * det_inv;
+                a[3] = M1 * det_inv; a[4] = M4 * det_inv; a[5] = M7 * det_inv;
+                a[6] = M2 * det_inv; a[7] = M5 * det_inv; a[8] = M8 * det_inv;
+            }
+        }
+    }
+    return FASP_SUCCESS;
+}
+
+int host_setup_ua_bsr(const dBSRmat* A, AMG_param* param, HostHierarchyBSR& H)
+{
+    const int    prtlvl   = param->print_level;
+    const short  min_cdof = (short)std::max(param->coarse_dof, 50);  // SHORT, PreAMGSetupUABSR.c:77
+    const double t0       = wall_seconds();
+    int          status   = FASP_SUCCESS;
+    const int    max_levels = std::min<int>(param->max_levels, MAX_AMG_LVL);
+
+    if (!A || !A->IA || !A->JA || !A->val || A->ROW <= 0 || A->ROW != A->COL || A->storage_manner != 0)
+        return ERROR_DATA_STRUCTURE;
+    H.L.clear();
+    H.L.reserve(MAX_AMG_LVL + 1);
+    H.L.emplace_back();
+    copy_bsr(A, H.L[0].A);
+    if (prtlvl > PRINT_NONE) std::printf("\nSetting up UA AMG (BSR) ...\n");
+
+    int lvl = 0;
+    try {
+        while (H.L[lvl].A.ROW > min_cdof && lvl < max_levels - 1) {
+            HostLevelBSR& Lv = H.L[lvl];
+            const int nb = Lv.A.nb;
+            const size_t nb2 = (size_t)nb * nb;
+            Lv.diaginv.alloc((size_t)Lv.A.ROW * nb2);
+            { dBSRmat v = Lv.A.view(); if ((status = bsr_diaginv(&v, Lv.diaginv.data())) < 0) return status; }
+            HostCSR S, N;
+            condense_bsr(Lv.A, S);
+            std::vector<int> vv;
+            int nagg = 0;
+            status = aggregation_vmb(S, vv, *param, lvl + 1, N, nagg);
+            // the reference adapts the coupling threshold to the coarsening rate (:201-205)
+            if (nagg * 4 > S.row) param->strong_coupled /= 8.0;
+            else if (nagg * 1.25 < S.row) param->strong_coupled *= 1.5;
+            if (status < 0) {
+                if (prtlvl > PRINT_MIN) std::printf("### WARNING: Forming aggregates on level-%d failed!\n", lvl);
+                status = FASP_SUCCESS;
+                break;
+            }
+            {  // form_boolean_p_bsr, PreAMGAggregationBSR.inl:141: one identity block per aggregated row
+                HostBSR& P = Lv.P;
+                P.ROW = S.row; P.COL = nagg; P.nb = nb;
+                P.ia.alloc((size_t)P.ROW + 1);
+                int j = 0;
+                for (int i = 0; i < P.ROW; ++i) { P.ia[i] = j; if (vv[i] > -1) ++j; }
+                P.ia[P.ROW] = j;
+                P.NNZ = j;
+                P.ja.alloc((size_t)j); P.val.alloc((size_t)j * nb2); P.val.zero();
+                j = 0;
+                for (int i = 0; i < P.ROW; ++i)
+                    if (vv[i] > -1) {
+                        P.ja[j] = vv[i];
+                        for (int d = 0; d < nb; ++d) P.val[(size_t)j * nb2 + d * nb + d] = 1.0;
+                        ++j;
+                    }
+            }
+            transpose_bsr(Lv.P, Lv.R);
+            H.L.emplace_back();
+            galerkin_rap_bsr(H.L[lvl].R, H.L[lvl].A, H.L[lvl].P, H.L[lvl + 1].A);
+            H.L[lvl].has_coarse = true;
+            ++lvl;
+        }
+    } catch (const std::bad_alloc&) {
+        std::printf("### ERROR: fasp_hip: host allocation failed during AMG setup\n");
+        return ERROR_ALLOC_MEM;
+    }
+    H.setup_seconds = wall_seconds() - t0;
+    if (prtlvl > PRINT_NONE)
+        std::printf("Unsmoothed aggregation (BSR) setup costs %.4f seconds, %d levels.\n", H.setup_seconds, lvl + 1);
+    return status;
+}
+
+// Parameter combinations of the block path with a device implementation
+int check_supported_bsr(const ITS_param* it, const AMG_param* amg, int nb)
+{
+    if (nb < 1 || nb > 3) {
+        std::printf("### ERROR: fasp_hip: BSR AMG needs 1 <= nb <= 3 (closed-form block inverses), got %d\n", nb);
+        return ERROR_INPUT_PAR;
+    }
+    if (amg) {
+        if (amg->AMG_type == SA_AMG) {
+            std::printf("### ERROR: fasp_hip: smoothed aggregation on BSR matrices has no device path\n");
+            return ERROR_INPUT_PAR;
+        }
+        if (amg->aggregation_type != VMB) {
+            std::printf("### ERROR: fasp_hip: BSR aggregation_type %d not supported (VMB only)\n", amg->aggregation_type);
+            return ERROR_INPUT_PAR;
+        }
+        if (amg->ILU_levels > 0 || amg->SWZ_levels > 0) {
+            std::printf("### ERROR: fasp_hip: ILU / Schwarz smoothers have no device path\n");
+            return ERROR_INPUT_PAR;
+        }
+        if (amg->smoother != SMOOTHER_JACOBI) {
+            std::printf("### ERROR: fasp_hip: BSR smoother %d has no device path (block Jacobi only)\n", amg->smoother);
+            return ERROR_AMG_SMOOTH_TYPE;
+        }
+        if (amg->coarse_scaling == 1 || amg->coarse_solver != SOLVER_DEFAULT) return ERROR_INPUT_PAR;
+        switch (amg->cycle_type) {
+            case V_CYCLE: case W_CYCLE: case VW_CYCLE: case WV_CYCLE: break;  // nu_l[l] < cycle_type rule
+            default: return ERROR_INPUT_PAR;
+        }
+        if (amg->max_levels < 1 || amg->max_levels > MAX_AMG_LVL) return ERROR_INPUT_PAR;
+    }
+    if (it) {
+        if (it->itsolver_type != SOLVER_CG && it->itsolver_type != SOLVER_VGMRES &&
+            it->itsolver_type != SOLVER_VFGMRES) {
+            std::printf("### ERROR: Unknown iterative solver type %d! [%s]\n", it->itsolver_type,
+                        "fasp_solver_dbsr_itsolver");
+            return ERROR_SOLVER_TYPE;
+        }
+        if (it->stop_type < STOP_REL_RES || it->stop_type > STOP_MOD_REL_RES) return ERROR_INPUT_PAR;
+        if (it->itsolver_type != SOLVER_CG && (it->restart < 1 || it->restart > 1000)) return ERROR_INPUT_PAR;
+    }
+    return FASP_SUCCESS;
+}
+
 }  // namespace fasp
 
 // ---------------------------------------------------------------------------

@@ -512,7 +512,10 @@ __global__ __launch_bounds__(BLOCK) void k_bsr_wstream(BsrArgs a)
         const size_t row = (size_t)br * NB + r;
         double acc = 0.0;
         if (act) {
-            if (OP == 1) acc = (a.alpha != 1.0) ? a.y[row] * (1.0 / a.alpha) : a.y[row];
+            if (OP == 1) {  // y0 taken from b when given (residual w = b - A x without a copy of b)
+                const double y0 = a.b ? a.b[row] : a.y[row];
+                acc = (a.alpha != 1.0) ? y0 * (1.0 / a.alpha) : y0;
+            }
             if (OP == 2) acc = a.b[row];
         }
         for (int lo = k0; lo < k1; lo += CAPB) {
@@ -561,6 +564,20 @@ __global__ __launch_bounds__(BLOCK) void k_bsr_wstream(BsrArgs a)
         } else if (act) {
             a.y[row] = (OP == 1 && a.alpha != 1.0) ? acc * a.alpha : acc;
         }
+    }
+}
+
+// Block-Jacobi sweep from a zero iterate: u = Dinv b (the off-diagonal sum vanishes exactly)
+__global__ __launch_bounds__(BLOCK) void k_bsr_dinv_apply(int n, int nb, const double* __restrict__ dinv,
+                                                           const double* __restrict__ b, double* __restrict__ u)
+{
+    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
+        const int br = row / nb, r = row - br * nb;
+        const double* D = dinv + (size_t)br * nb * nb + r * nb;
+        const double* bb = b + (size_t)br * nb;
+        double s = D[0] * bb[0];
+        for (int c = 1; c < nb; ++c) s = s + D[c] * bb[c];
+        u[row] = s;
     }
 }
 

@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <vector>
 
 #include "fasp_comm.h"
@@ -264,6 +266,14 @@ static int fetch_red(int slot, int nq, double* out)
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     for (int q = 0; q < nq; ++q) out[q] = g_ctx.h_red[slot + q];
     return FASP_SUCCESS;
+}
+// (x,y) left on the device in reduction slot `slot` (no host round trip)
+static int d_dot_to(int n, const double* x, const double* y, int slot, bool dist)
+{
+    const int G = vec_grid(n);
+    hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, g_ctx.stream, n, x, y, g_ctx.d_partials);
+    d_finalize(G, 1, 0u, slot, dist);
+    return 0;
 }
 static int d_dot(int n, const double* x, const double* y, double* out, bool dist = false)
 {
@@ -781,6 +791,8 @@ FINISHED:
     return iter;
 }
 
+struct KOps;
+static KOps csr_ops(fasp_hip_amg* h, int level, bool with_pc);
 // forward declarations (the coarse fallback and the preconditioner call each other's owners)
 static int precond_amg(fasp_hip_amg* h, double* r, double** z);
 static void itinfo(int ptrlvl, int stop_type, int iter, double relres, double absres, double factor);
@@ -788,6 +800,25 @@ struct PcgOut { double relres, absres, normr0; };
 struct Hist {
     double* h; int cap; int n;
     void push(double v) { if (h && n < cap) h[n] = v; ++n; }
+};
+
+// Operator bundle of the Krylov drivers: the reference has one textual copy of every Krylov
+// method per matrix format (KryPcg.c:96 / :386, KryPvgmres.c:66 / :416, ...); here the
+// drivers are written once against these callbacks.
+struct KOps {
+    int    n = 0;       // owned entries
+    size_t nvec = 0;    // vector length incl. ghosts
+    bool   dist = false;
+    const char* fmt = "CSR";
+    std::function<int(double*)> halo;                                      // refresh ghost entries of v
+    std::function<void(const double*, double*)> mxv;                       // y = A x
+    std::function<void(const double*, const double*, double*)> resid;      // r = b - A x
+    std::function<int(const double*, double*)> mxv_dot;                    // y = A x + partials of (y,x); returns #partials, < 0: unavailable
+    std::function<int(double*, double**)> pc;                              // *out = B in (empty: identity)
+    std::vector<double*>* ws = nullptr;                                    // GMRES workspace
+    size_t* ws_len = nullptr;
+    double** hh = nullptr;
+    fasp_hip_amg* stats = nullptr;                                         // event pool for the SpMV timer
 };
 
 static void d_scale(int n, double a, double* x)
@@ -807,13 +838,12 @@ static void d_scale(int n, double a, double* x)
 // `set` selects the workspace (0: level 0, 1: coarsest level); Lv is the level the operator
 // acts on (halo plan); use_pc applies the AMG preconditioner (level 0 only).
 // ---------------------------------------------------------------------------
-static int gmres_device(fasp_hip_amg* h, int set, DevLevel& Lv, const double* b, double* x, bool use_pc,
-                        int mode, double tol, double abstol, int MaxIt, int restart, int StopType,
-                        int PrtLvl, bool dist, Hist* hist, PcgOut* out)
+static int gmres_device(KOps& K, const double* b, double* x, int mode, double tol, double abstol, int MaxIt,
+                        int restart, int StopType, int PrtLvl, Hist* hist, PcgOut* out)
 {
-    const DevCSR& A = Lv.A;
-    const int n = A.row;
-    const size_t nv = (size_t)Lv.nvec;
+    const int n = K.n;
+    const size_t nv = K.nvec;
+    const bool dist = K.dist;
     const int MIN_ITER = 0;
     const double epsmac = SMALLREAL, cr_max = 0.99, cr_min = 0.174, maxdiff = tol * STAG_RATIO;
     int iter = 0, i = 0, j, k, st;
@@ -830,20 +860,21 @@ static int gmres_device(fasp_hip_amg* h, int set, DevLevel& Lv, const double* b,
 
     // workspace: p[0..Restart], w, x_best (mode 2), z[0..Restart) (mode 1)
     const size_t need = (size_t)Restart1 + 2 + (mode == 1 ? (size_t)Restart1 : 0);
-    if (h->gm_len[set] != nv) {
-        for (double* q : h->gm[set]) if (q) (void)hipFree(q);
-        h->gm[set].clear();
-        h->gm_len[set] = nv;
+    if (*K.ws_len != nv) {
+        for (double* q : *K.ws) if (q) (void)hipFree(q);
+        K.ws->clear();
+        *K.ws_len = nv;
     }
-    while (h->gm[set].size() < need) {
+    while (K.ws->size() < need) {
         double* q = nullptr;
         HIPCK(hipMalloc(&q, sizeof(double) * std::max<size_t>(nv, 1)));
         HIPCK(hipMemsetAsync(q, 0, sizeof(double) * nv, s));
-        h->gm[set].push_back(q);
+        K.ws->push_back(q);
     }
-    if (!h->gm_hh) HIPCK(hipMalloc(&h->gm_hh, sizeof(double) * 1024));
+    if (!*K.hh) HIPCK(hipMalloc(K.hh, sizeof(double) * 1024));
     if (Restart1 + 2 > 1024) return ERROR_INPUT_PAR;
-    std::vector<double*>& W = h->gm[set];
+    std::vector<double*>& W = *K.ws;
+    double* const gm_hh = *K.hh;
     double** p = W.data();
     double*  w = W[Restart1];
     double*  x_best = W[Restart1 + 1];
@@ -854,19 +885,19 @@ static int gmres_device(fasp_hip_amg* h, int set, DevLevel& Lv, const double* b,
     std::vector<double> norms((size_t)MaxIt + 2, 0.0);
 
     auto apply_pc = [&](double* in, double** outp) -> int {  // *outp = B in (pointer to the result)
-        if (use_pc) return precond_amg(h, in, outp);
+        if (K.pc) return K.pc(in, outp);
         *outp = in;
         return FASP_SUCCESS;
     };
     auto true_residual = [&](const double* xx, double* rr) -> int {  // rr = b - A xx
-        if (halo_exchange(Lv, const_cast<double*>(xx)) < 0) return ERROR_MISC;
-        d_resid(A, xx, b, rr);
+        if (K.halo(const_cast<double*>(xx)) < 0) return ERROR_MISC;
+        K.resid(xx, b, rr);
         return FASP_SUCCESS;
     };
 
     if (PrtLvl > PRINT_NONE)
-        std::printf(mode == 0 ? "\nCalling VGMRes solver (CSR) ...\n"
-                    : mode == 1 ? "\nCalling VFGMRes solver (CSR) ...\n" : "\nCalling Safe VGMRes solver (CSR) ...\n");
+        std::printf(mode == 0 ? "\nCalling VGMRes solver (%s) ...\n"
+                    : mode == 1 ? "\nCalling VFGMRes solver (%s) ...\n" : "\nCalling Safe VGMRes solver (%s) ...\n", K.fmt);
 
     if ((st = true_residual(x, p[0])) < 0) return st;
     if (mode == 1) { if (d_dot(n, b, b, red, dist) < 0) return ERROR_MISC; b_norm = std::sqrt(red[0]); }
@@ -932,18 +963,18 @@ static int gmres_device(fasp_hip_amg* h, int set, DevLevel& Lv, const double* b,
             if ((st = apply_pc(p[i - 1], &r)) < 0) return st;
             if (mode == 1 && r != z[i - 1])
                 HIPCK(hipMemcpyAsync(z[i - 1], r, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-            if (halo_exchange(Lv, r) < 0) return ERROR_MISC;
-            d_mxv(A, r, p[i]);
+            if (K.halo(r) < 0) return ERROR_MISC;
+            K.mxv(r, p[i]);
             // modified Gram-Schmidt on the device: hh_0 = (p_0, p_i); then i fused steps
             hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, s, n, p[0], p[i], g_ctx.d_partials);
-            d_finalize_to(G, 1, 0u, h->gm_hh, dist);
+            d_finalize_to(G, 1, 0u, gm_hh, dist);
             for (j = 0; j < i; j++) {
-                hipLaunchKernelGGL(k_mgs_step, dim3(G), dim3(BLOCK), 0, s, n, (const double*)(h->gm_hh + j),
+                hipLaunchKernelGGL(k_mgs_step, dim3(G), dim3(BLOCK), 0, s, n, (const double*)(gm_hh + j),
                                    (const double*)p[j], p[i], (const double*)(j + 1 < i ? p[j + 1] : nullptr),
                                    g_ctx.d_partials);
-                d_finalize_to(G, 1, 0u, h->gm_hh + j + 1, dist);
+                d_finalize_to(G, 1, 0u, gm_hh + j + 1, dist);
             }
-            HIPCK(hipMemcpyAsync(g_ctx.h_part, h->gm_hh, sizeof(double) * (i + 1), hipMemcpyDeviceToHost, s));
+            HIPCK(hipMemcpyAsync(g_ctx.h_part, gm_hh, sizeof(double) * (i + 1), hipMemcpyDeviceToHost, s));
             HIPCK(hipStreamSynchronize(s));
             for (j = 0; j < i; j++) hh[j][i - 1] = g_ctx.h_part[j];
             t = std::sqrt(g_ctx.h_part[i]);
@@ -1150,8 +1181,9 @@ ForwardSweep:
             const int m = Lc.A.row;
             const int nn = (int)((unsigned)m * (unsigned)m);
             const int maxit = std::max(250, std::min(nn, 1000));
-            st = gmres_device(h, 1, Lc, Lc.b, Lc.x, false, 2, tol, 0.0, maxit, 20, STOP_REL_RES,
-                              param.print_level - 4, false, nullptr, nullptr);
+            KOps Kc = csr_ops(h, nl - 1, false);
+            st = gmres_device(Kc, Lc.b, Lc.x, 2, tol, 0.0, maxit, 20, STOP_REL_RES, param.print_level - 4,
+                              nullptr, nullptr);
             if (st == ERROR_MISC) return st;
             if (st < 0 && param.print_level >= PRINT_MORE) {
                 std::printf("### WARNING: Coarse level solver did not converge!\n");
@@ -1214,6 +1246,28 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
     return FASP_SUCCESS;
 }
 
+// Krylov operator bundles of the CSR hierarchy: level 0 (with the AMG preconditioner) and the
+// coarsest level (no preconditioner: the SPVGMRES safety net)
+static KOps csr_ops(fasp_hip_amg* h, int level, bool with_pc)
+{
+    KOps K;
+    DevLevel* Lv = &h->L[level];
+    K.n = Lv->A.row; K.nvec = (size_t)Lv->nvec; K.fmt = "CSR";
+    K.dist = (level == 0) && h->distributed;
+    K.halo = [Lv](double* v) { return halo_exchange(*Lv, v); };
+    K.mxv = [Lv](const double* x, double* y) { d_mxv(Lv->A, x, y); };
+    K.resid = [Lv](const double* x, const double* b, double* r) { d_resid(Lv->A, x, b, r); };
+    K.mxv_dot = [Lv](const double* x, double* y) {
+        CsrArgs a{}; a.x = x; a.y = y; a.dotv = x; a.partials = g_ctx.d_partials;
+        return launch_csr<OP_MXV_DOT>(Lv->A, a);
+    };
+    if (with_pc) K.pc = [h](double* in, double** out) { return precond_amg(h, in, out); };
+    const int set = level == 0 ? 0 : 1;
+    K.ws = &h->gm[set]; K.ws_len = &h->gm_len[set]; K.hh = &h->gm_hh;
+    K.stats = h;
+    return K;
+}
+
 // ---------------------------------------------------------------------------
 // preconditioned CG (KryPcg.c:96-362) on device vectors
 // ---------------------------------------------------------------------------
@@ -1234,24 +1288,25 @@ static void itinfo(int ptrlvl, int stop_type, int iter, double relres, double ab
     }
 }
 
-static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, int MaxIt, int StopType,
+struct PcgVecs { const double* b; double *u, *p, *t, *r; };
+static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int MaxIt, int StopType,
                       int PrtLvl, Hist& hist, PcgOut& out)
 {
-    const DevCSR& A = h->L[0].A;
-    const int m = A.row;             // owned rows
-    const bool dist = h->distributed; // reductions are all-reduced over the ranks
+    const int m = K.n;         // owned rows
+    const bool dist = K.dist;  // reductions are all-reduced over the ranks
+    fasp_hip_amg* h = K.stats;
     const double maxdiff = tol * STAG_RATIO, sol_inf_tol = SMALLREAL;
     int iter = 0, stag = 1, more_step = 1;
     double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL, normr0 = BIGREAL;
     double reldiff, factor, alpha = 0.0, beta, temp1 = 0.0, temp2, red[8];
-    double *p = h->p, *r = h->r, *t = h->t, *u = h->u, *z = nullptr;
-    const double* b = h->b;
+    double *p = V.p, *r = V.r, *t = V.t, *u = V.u, *z = nullptr;
+    const double* b = V.b;
     hipStream_t s = g_ctx.stream;
     const int G = vec_grid(m);
     int st;
 
     auto apply_pc = [&]() -> int {
-        if (use_pc) return precond_amg(h, r, &z);
+        if (K.pc) return K.pc(r, &z);
         z = r;
         return FASP_SUCCESS;
     };
@@ -1278,9 +1333,9 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
         return FASP_SUCCESS;
     };
 
-    if (PrtLvl > PRINT_NONE) std::printf("\nCalling CG solver (CSR) ...\n");
+    if (PrtLvl > PRINT_NONE) std::printf("\nCalling CG solver (%s) ...\n", K.fmt);
 
-    { if (halo_exchange(h->L[0], u) < 0) return ERROR_MISC; d_resid(A, u, b, r); }  // r = b - A u
+    { if (K.halo(u) < 0) return ERROR_MISC; K.resid(u, b, r); }  // r = b - A u
     if ((st = apply_pc()) < 0) return st;
     switch (StopType) {
         case STOP_REL_RES:
@@ -1317,13 +1372,16 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
     while (iter++ < MaxIt) {
         // t = A p with the partial sums of (t,p); timed for the roofline report
         {
-            if (halo_exchange(h->L[0], p) < 0) return ERROR_MISC;
-            CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials;
-            EventPair* ep = h->ev_used < (int)h->ev.size() ? &h->ev[h->ev_used++] : nullptr;
+            if (K.halo(p) < 0) return ERROR_MISC;
+            EventPair* ep = (h && h->ev_used < (int)h->ev.size()) ? &h->ev[h->ev_used++] : nullptr;
             if (ep) (void)hipEventRecord(ep->a, s);
-            const int gdot = launch_csr<OP_MXV_DOT>(A, a);
+            int gdot = K.mxv_dot ? K.mxv_dot(p, t) : -1;
             if (ep) (void)hipEventRecord(ep->b, s);
-            d_finalize(gdot, 1, 0u, 8, dist);
+            if (gdot >= 0) d_finalize(gdot, 1, 0u, 8, dist);
+            else {  // format without a fused kernel: t = A p, then (t,p) into slot 8
+                K.mxv(p, t);
+                if (d_dot_to(m, t, p, 8, dist) < 0) return ERROR_MISC;
+            }
         }
         // alpha = temp1/(t,p) on device; u += alpha p; r -= alpha t; partial ||r||^2
         hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, (const double*)(g_ctx.d_red + 8),
@@ -1361,7 +1419,7 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
                     std::printf("### WARNING: Iteration restarted -- stagnation! [%s:%d]\n",
                                 "fasp_solver_dcsr_pcg", 232);
                 }
-                { if (halo_exchange(h->L[0], u) < 0) return ERROR_MISC; d_resid(A, u, b, r); }
+                { if (K.halo(u) < 0) return ERROR_MISC; K.resid(u, b, r); }
                 if ((st = resnorm(0.0, false)) < 0) return st;
                 if (PrtLvl >= PRINT_MORE)
                     std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
@@ -1380,7 +1438,7 @@ static int pcg_device(fasp_hip_amg* h, bool use_pc, double tol, double abstol, i
 
         if (relres < tol) {  // Check III: prevent false convergence
             const double updated_relres = relres;
-            { if (halo_exchange(h->L[0], u) < 0) return ERROR_MISC; d_resid(A, u, b, r); }
+            { if (K.halo(u) < 0) return ERROR_MISC; K.resid(u, b, r); }
             if ((st = resnorm(0.0, false)) < 0) return st;
             if (relres < tol) break;
             if (PrtLvl >= PRINT_MORE) {
@@ -1475,6 +1533,152 @@ void launch_bsr(const TmpBSR& M, BsrArgs a)
 }
 }  // namespace fasp_bsr
 using namespace fasp_bsr;
+
+// ---------------------------------------------------------------------------
+// BSR AMG hierarchy resident in HBM (config 3): unsmoothed aggregation, block-Jacobi
+// V/W cycle (PreMGCycle.c:287), GMRES on the coarsest level, Krylov drivers shared with CSR
+// ---------------------------------------------------------------------------
+struct BsrLevel {
+    std::unique_ptr<TmpBSR> A, P, R;
+    double *dinv = nullptr, *b = nullptr, *x = nullptr, *x2 = nullptr, *w = nullptr;
+    int  n = 0;  // scalar rows
+    bool x_zero = false;
+};
+struct fasp_hip_amg_bsr {
+    HostHierarchyBSR      H;
+    std::vector<BsrLevel> L;
+    AMG_param             param;
+    double *b = nullptr, *u = nullptr, *p = nullptr, *t = nullptr, *r = nullptr, *z = nullptr;
+    std::vector<double*> gm[2];
+    size_t               gm_len[2] = {0, 0};
+    double*              gm_hh = nullptr;
+    long long            coarse_iters = 0, vcycles = 0;
+};
+
+namespace fasp_bsr {
+
+static int dalloc(double** p, size_t n)
+{
+    HIPCK(hipMalloc(p, sizeof(double) * std::max<size_t>(n, 1)));
+    HIPCK(hipMemsetAsync(*p, 0, sizeof(double) * n, g_ctx.stream));
+    return 0;
+}
+
+static void bsr_mxv(const TmpBSR& M, const double* x, double* y)
+{
+    BsrArgs a{}; a.x = x; a.y = y;
+    launch_bsr<0>(M, a);
+}
+// r = b - A x with the reference's rounding: y = b; y *= -1; y += A x; y *= -1 (BlaSpmvBSR.c:548)
+static void bsr_resid(const TmpBSR& M, const double* x, const double* b, double* r)
+{
+    BsrArgs a{}; a.x = x; a.y = r; a.b = b; a.alpha = -1.0;
+    launch_bsr<1>(M, a);
+}
+static void bsr_jacobi(BsrLevel& Lv)
+{
+    const TmpBSR& M = *Lv.A;
+    if (Lv.x_zero) {
+        hipLaunchKernelGGL(k_bsr_dinv_apply, dim3(vec_grid(Lv.n)), dim3(BLOCK), 0, g_ctx.stream, Lv.n, M.nb,
+                           (const double*)Lv.dinv, (const double*)Lv.b, Lv.x);
+        Lv.x_zero = false;
+        return;
+    }
+    BsrArgs a{}; a.x = Lv.x; a.y = Lv.x2; a.b = Lv.b; a.dinv = Lv.dinv;
+    launch_bsr<2>(M, a);
+    std::swap(Lv.x, Lv.x2);
+}
+
+static KOps bsr_ops(fasp_hip_amg_bsr* h, int level, int set);
+
+// fasp_solver_mgcycle_bsr, PreMGCycle.c:287-566
+static int mgcycle_bsr(fasp_hip_amg_bsr* h, const AMG_param& param)
+{
+    const int nl = (int)h->L.size(), cycle_type = param.cycle_type, steps = param.presmooth_iter;
+    int nu_l[MAX_AMG_LVL + 1] = {0}, l = 0;
+    hipStream_t s = g_ctx.stream;
+    ++h->vcycles;
+ForwardSweep:
+    while (l < nl - 1) {
+        BsrLevel& Lv = h->L[l];
+        ++nu_l[l];
+        for (int i = 0; i < steps; ++i) bsr_jacobi(Lv);
+        if (Lv.x_zero) { HIPCK(hipMemsetAsync(Lv.x, 0, sizeof(double) * Lv.n, s)); Lv.x_zero = false; }
+        bsr_resid(*Lv.A, Lv.x, Lv.b, Lv.w);
+        bsr_mxv(*Lv.R, Lv.w, h->L[l + 1].b);
+        ++l;
+        h->L[l].x_zero = true;  // fasp_dvec_set(.., 0.0), materialised lazily
+    }
+    {   // coarsest level: fasp_solver_dbsr_pvgmres(A, b, x, NULL, tol, tol*1e-8, min(n^2,200), 25, 1, 0), :443-459
+        BsrLevel& Lc = h->L[nl - 1];
+        if (Lc.x_zero) { HIPCK(hipMemsetAsync(Lc.x, 0, sizeof(double) * Lc.n, s)); Lc.x_zero = false; }
+        const int csize = Lc.n;
+        const int cmaxit = (int)std::min<unsigned>((unsigned)csize * (unsigned)csize, 200u);
+        const double ctol = param.tol, atol = ctol * 1e-8;
+        KOps K = bsr_ops(h, nl - 1, 1);
+        PcgOut po{BIGREAL, BIGREAL, BIGREAL};
+        const int st = gmres_device(K, Lc.b, Lc.x, 0, ctol, atol, cmaxit, 25, STOP_REL_RES, 0, nullptr, &po);
+        if (st >= 0) h->coarse_iters += st;
+        else if (st != ERROR_SOLVER_MAXIT && st != ERROR_SOLVER_STAG && st != ERROR_SOLVER_SOLSTAG &&
+                 st != ERROR_SOLVER_TOLSMALL) return st;  // device failure, not a convergence verdict
+        if (st < 0 && param.print_level > PRINT_MIN) {
+            std::printf("### WARNING: Coarse level solver did not converge!\n");
+            std::printf("### WARNING: Consider to increase maxit to %d!\n", 2 * cmaxit);
+        }
+    }
+    while (l > 0) {
+        --l;
+        BsrLevel& Lv = h->L[l];
+        {   // x_l += P x_{l+1}  (fasp_blas_dbsr_aAxpy with alpha = 1)
+            BsrArgs a{}; a.x = h->L[l + 1].x; a.y = Lv.x; a.alpha = 1.0;
+            launch_bsr<1>(*Lv.P, a);
+        }
+        for (int i = 0; i < steps; ++i) bsr_jacobi(Lv);  // the reference post-smooths `steps` = presmooth_iter times (:543)
+        if (nu_l[l] < cycle_type) break;
+        nu_l[l] = 0;
+    }
+    if (l > 0) goto ForwardSweep;
+    return FASP_SUCCESS;
+}
+
+// fasp_precond_dbsr_amg, PreBSR.c:1149: z = (maxit cycles from a zero guess)(r); the AMG_param
+// handed to the cycle is re-initialised (tol stays 1e-6) apart from the copied fields
+static int precond_amg_bsr(fasp_hip_amg_bsr* h, double* r, double** z)
+{
+    AMG_param p;
+    fasp_param_amg_init(&p);
+    const AMG_param& u = h->param;
+    p.cycle_type = u.cycle_type; p.smoother = u.smoother; p.presmooth_iter = u.presmooth_iter;
+    p.postsmooth_iter = u.postsmooth_iter; p.relaxation = u.relaxation;
+    p.coarse_scaling = u.coarse_scaling; p.tentative_smooth = u.tentative_smooth;
+    BsrLevel& L0 = h->L[0];
+    double* saved_b = L0.b;
+    L0.b = r;  // level-0 rhs aliases the Krylov residual (the cycle never writes b_0)
+    L0.x_zero = true;
+    int st = FASP_SUCCESS;
+    for (int i = u.maxit; i--;)
+        if ((st = mgcycle_bsr(h, p)) < 0) break;
+    L0.b = saved_b;
+    if (L0.x_zero) { HIPCK(hipMemsetAsync(L0.x, 0, sizeof(double) * L0.n, g_ctx.stream)); L0.x_zero = false; }
+    *z = L0.x;
+    return st;
+}
+
+static KOps bsr_ops(fasp_hip_amg_bsr* h, int level, int set)
+{
+    KOps K;
+    BsrLevel* Lv = &h->L[level];
+    K.n = Lv->n; K.nvec = (size_t)Lv->n; K.fmt = "BSR"; K.dist = false;
+    K.halo = [](double*) { return 0; };
+    K.mxv = [Lv](const double* x, double* y) { bsr_mxv(*Lv->A, x, y); };
+    K.resid = [Lv](const double* x, const double* b, double* r) { bsr_resid(*Lv->A, x, b, r); };
+    if (set == 0) K.pc = [h](double* in, double** out) { return precond_amg_bsr(h, in, out); };
+    K.ws = &h->gm[set]; K.ws_len = &h->gm_len[set]; K.hh = &h->gm_hh;
+    K.stats = nullptr;
+    return K;
+}
+
+}  // namespace fasp_bsr
 
 
 // ===========================================================================
@@ -1646,13 +1850,19 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
     switch (itparam->itsolver_type) {
         case SOLVER_VGMRES:
         case SOLVER_VFGMRES:
-            st = gmres_device(h, 0, h->L[0], h->b, h->u, true, itparam->itsolver_type == SOLVER_VFGMRES ? 1 : 0,
-                              itparam->tol, itparam->abstol, itparam->maxit, (short)itparam->restart,
-                              itparam->stop_type, itparam->print_level, h->distributed, &H, &po);
-            break;
+        {
+            KOps K = csr_ops(h, 0, true);
+            st = gmres_device(K, h->b, h->u, itparam->itsolver_type == SOLVER_VFGMRES ? 1 : 0, itparam->tol,
+                              itparam->abstol, itparam->maxit, (short)itparam->restart, itparam->stop_type,
+                              itparam->print_level, &H, &po);
+        } break;
         default:
-            st = pcg_device(h, true, itparam->tol, itparam->abstol, itparam->maxit, itparam->stop_type,
+        {
+            KOps K = csr_ops(h, 0, true);
+            PcgVecs V{h->b, h->u, h->p, h->t, h->r};
+            st = pcg_device(K, V, itparam->tol, itparam->abstol, itparam->maxit, itparam->stop_type,
                             itparam->print_level, H, po);
+        }
     }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     const double t_solve = wall_seconds() - t0;
@@ -1761,6 +1971,173 @@ int fasp_solver_dcsr_krylov_amg(dCSRmat* A, dvector* b, dvector* x, ITS_param* i
     if (itparam->print_level >= PRINT_MIN)
         std::printf("AMG_Krylov method totally costs %.4f seconds.\n", wall_seconds() - t0);
     fasp_hip_amg_destroy(h);
+    return st;
+}
+
+// ---------------------------------------------------------------------------
+// BSR path: resident hierarchy + the drop-in of SolBSR.c:349
+// ---------------------------------------------------------------------------
+void fasp_hip_bsr_amg_destroy(fasp_hip_amg_bsr* h)
+{
+    if (!h) return;
+    if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+    for (auto& Lv : h->L) {
+        double* v[] = {Lv.dinv, Lv.b, Lv.x, Lv.x2, Lv.w};
+        for (double* q : v) if (q) (void)hipFree(q);
+    }
+    double* v[] = {h->b, h->u, h->p, h->t, h->r};
+    for (double* q : v) if (q) (void)hipFree(q);
+    for (int s = 0; s < 2; ++s)
+        for (double* q : h->gm[s]) if (q) (void)hipFree(q);
+    if (h->gm_hh) (void)hipFree(h->gm_hh);
+    delete h;
+}
+
+// host part only (no GPU needed): the hierarchy can be inspected, not solved with
+int fasp_hip_bsr_amg_create_host(fasp_hip_amg_bsr** out, const dBSRmat* A, AMG_param* amgparam)
+{
+    if (!out || !A || !amgparam) return ERROR_INPUT_PAR;
+    *out = nullptr;
+    int st = check_supported_bsr(nullptr, amgparam, A->nb);
+    if (st < 0) return st;
+    fasp_hip_amg_bsr* h = new fasp_hip_amg_bsr();
+    st = host_setup_ua_bsr(A, amgparam, h->H);
+    if (st < 0) { delete h; return st; }
+    h->param = *amgparam;
+    *out = h;
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_bsr_amg_create(fasp_hip_amg_bsr** out, const dBSRmat* A, AMG_param* amgparam)
+{
+    if (!out || !A || !amgparam) return ERROR_INPUT_PAR;
+    *out = nullptr;
+    int st = check_supported_bsr(nullptr, amgparam, A->nb);
+    if (st < 0) return st;
+    if ((st = ctx_init()) < 0) return st;
+    fasp_hip_amg_bsr* h = nullptr;
+    if ((st = fasp_hip_bsr_amg_create_host(&h, A, amgparam)) < 0) return st;
+    const int nl = (int)h->H.L.size();
+    h->L.resize(nl);
+    for (int l = 0; l < nl; ++l) {
+        const HostLevelBSR& HL = h->H.L[l];
+        BsrLevel& Lv = h->L[l];
+        const dBSRmat vA = HL.A.view();
+        Lv.A.reset(new TmpBSR(&vA));
+        bool ok = Lv.A->ok;
+        Lv.n = HL.A.ROW * HL.A.nb;
+        if (HL.has_coarse) {
+            const dBSRmat vP = HL.P.view(), vR = HL.R.view();
+            Lv.P.reset(new TmpBSR(&vP));
+            Lv.R.reset(new TmpBSR(&vR));
+            ok = ok && Lv.P->ok && Lv.R->ok;
+            const size_t nd = (size_t)HL.A.ROW * HL.A.nb * HL.A.nb;
+            if (hipMalloc(&Lv.dinv, sizeof(double) * std::max<size_t>(nd, 1)) != hipSuccess) ok = false;
+            else (void)hipMemcpy(Lv.dinv, HL.diaginv.data(), sizeof(double) * nd, hipMemcpyHostToDevice);
+        }
+        if (!ok || dalloc(&Lv.b, Lv.n) < 0 || dalloc(&Lv.x, Lv.n) < 0 || dalloc(&Lv.x2, Lv.n) < 0 ||
+            dalloc(&Lv.w, Lv.n) < 0) {
+            fasp_hip_bsr_amg_destroy(h);
+            return ERROR_ALLOC_MEM;
+        }
+    }
+    const size_t n0 = (size_t)h->L[0].n;
+    if (dalloc(&h->b, n0) < 0 || dalloc(&h->u, n0) < 0 || dalloc(&h->p, n0) < 0 || dalloc(&h->t, n0) < 0 ||
+        dalloc(&h->r, n0) < 0) {
+        fasp_hip_bsr_amg_destroy(h);
+        return ERROR_ALLOC_MEM;
+    }
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    *out = h;
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_bsr_amg_num_levels(const fasp_hip_amg_bsr* h) { return h ? (int)h->H.L.size() : ERROR_INPUT_PAR; }
+
+int fasp_hip_bsr_amg_get_matrix(const fasp_hip_amg_bsr* h, int level, int which, dBSRmat* view)
+{
+    if (!h || !view || level < 0 || level >= (int)h->H.L.size()) return ERROR_INPUT_PAR;
+    const HostLevelBSR& L = h->H.L[level];
+    if (which != 0 && !L.has_coarse) return ERROR_INPUT_PAR;
+    *view = which == 0 ? L.A.view() : which == 1 ? L.P.view() : L.R.view();
+    return FASP_SUCCESS;
+}
+
+const double* fasp_hip_bsr_amg_get_diaginv(const fasp_hip_amg_bsr* h, int level)
+{
+    if (!h || level < 0 || level >= (int)h->H.L.size() || !h->H.L[level].has_coarse) return nullptr;
+    return h->H.L[level].diaginv.data();
+}
+
+int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const ITS_param* itparam, double* hist,
+                       int hist_cap, fasp_hip_stats* stats)
+{
+    if (!h || !b || !x || !itparam || h->L.empty()) return ERROR_INPUT_PAR;
+    const int n = h->L[0].n;
+    if (b->row != n || x->row != n) return ERROR_MAT_SIZE;
+    int st = check_supported_bsr(itparam, &h->param, h->H.L[0].A.nb);
+    if (st < 0) return st;
+    if (itparam->tol < SMALLREAL)
+        std::printf("### WARNING: Convergence tolerance is too small! [%s:%d]\n", "ITS_CHECK", 74);
+    if (itparam->maxit <= 0)
+        std::printf("### WARNING: Max number of iterations must be POSITIVE! [%s:%d]\n", "ITS_CHECK", 78);
+    hipStream_t s = g_ctx.stream;
+    double t0 = wall_seconds();
+    HIPCK(hipMemcpyAsync(h->b, b->val, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIPCK(hipMemcpyAsync(h->u, x->val, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIPCK(hipStreamSynchronize(s));
+    double t_up = wall_seconds() - t0;
+
+    const long long ci0 = h->coarse_iters, vc0 = h->vcycles;
+    Hist   H{hist, hist_cap, 0};
+    PcgOut po{BIGREAL, BIGREAL, BIGREAL};
+    t0 = wall_seconds();
+    KOps K = bsr_ops(h, 0, 0);
+    switch (itparam->itsolver_type) {  // fasp_solver_dbsr_itsolver, SolBSR.c:55-150
+        case SOLVER_VGMRES:
+        case SOLVER_VFGMRES:
+            st = gmres_device(K, h->b, h->u, itparam->itsolver_type == SOLVER_VFGMRES ? 1 : 0, itparam->tol,
+                              itparam->abstol, itparam->maxit, (short)itparam->restart, itparam->stop_type,
+                              itparam->print_level, &H, &po);
+            break;
+        default:
+        {
+            PcgVecs V{h->b, h->u, h->p, h->t, h->r};
+            st = pcg_device(K, V, itparam->tol, itparam->abstol, itparam->maxit, itparam->stop_type,
+                            itparam->print_level, H, po);
+        }
+    }
+    HIPCK(hipStreamSynchronize(s));
+    const double t_solve = wall_seconds() - t0;
+    t0 = wall_seconds();
+    HIPCK(hipMemcpy(x->val, h->u, sizeof(double) * n, hipMemcpyDeviceToHost));
+    t_up += wall_seconds() - t0;
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->iters = st; stats->nhist = H.n; stats->relres = po.relres; stats->absres = po.absres;
+        stats->normr0 = po.normr0; stats->solve_seconds = t_solve; stats->upload_seconds = t_up;
+        stats->coarse_iters = h->coarse_iters - ci0;
+        stats->vcycles = h->vcycles - vc0;
+    }
+    if (itparam->print_level >= PRINT_SOME && st >= 0)
+        std::printf("Iterative method costs %.4f seconds.\n", t_solve);
+    return st;
+}
+
+// SolBSR.c:349: UA-AMG setup on the host, hierarchy uploaded, Krylov loop on the device
+int fasp_solver_dbsr_krylov_amg(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam, AMG_param* amgparam)
+{
+    if (!A || !b || !x || !itparam || !amgparam) return ERROR_INPUT_PAR;
+    const double t0 = wall_seconds();
+    int st = check_supported_bsr(itparam, amgparam, A->nb);
+    if (st < 0) return st;
+    fasp_hip_amg_bsr* h = nullptr;
+    st = fasp_hip_bsr_amg_create(&h, A, amgparam);
+    if (st < 0) return st;
+    st = fasp_hip_bsr_solve(h, b, x, itparam, nullptr, 0, nullptr);
+    if (itparam->print_level >= PRINT_MIN)
+        std::printf("AMG_Krylov method totally costs %.4f seconds.\n", wall_seconds() - t0);
+    fasp_hip_bsr_amg_destroy(h);
     return st;
 }
 
@@ -1895,40 +2272,9 @@ dvector fasp_dbsr_getdiaginv(const dBSRmat* A)
         std::fprintf(stderr, "### ERROR: fasp_dbsr_getdiaginv: block size %d not supported (1..3)\n", A ? A->nb : -1);
         return out;
     }
-    const int nb = A->nb, nb2 = nb * nb;
-    out.row = A->ROW * nb2;
+    out.row = A->ROW * A->nb * A->nb;
     out.val = (double*)std::calloc((size_t)std::max(out.row, 1), sizeof(double));
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < A->ROW; ++i) {
-        double* a = out.val + (size_t)i * nb2;
-        for (int k = A->IA[i]; k < A->IA[i + 1]; ++k)
-            if (A->JA[k] == i) std::memcpy(a, A->val + (size_t)k * nb2, sizeof(double) * nb2);
-        if (nb == 1) {
-            a[0] = 1.0 / a[0];
-        } else if (nb == 2) {
-            const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-            const double det = a0 * a3 - a1 * a2;
-            if (std::fabs(det) < SMALLREAL) { a[0] = 1.0; a[1] = 0.0; a[2] = 0.0; a[3] = 1.0; }
-            else {
-                const double det_inv = 1.0 / det;
-                a[0] = a3 * det_inv; a[1] = -a1 * det_inv; a[2] = -a2 * det_inv; a[3] = a0 * det_inv;
-            }
-        } else {
-            const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8];
-            const double M0 = a4 * a8 - a5 * a7, M3 = a2 * a7 - a1 * a8, M6 = a1 * a5 - a2 * a4;
-            const double M1 = a5 * a6 - a3 * a8, M4 = a0 * a8 - a2 * a6, M7 = a2 * a3 - a0 * a5;
-            const double M2 = a3 * a7 - a4 * a6, M5 = a1 * a6 - a0 * a7, M8 = a0 * a4 - a1 * a3;
-            const double det = a0 * M0 + a3 * M3 + a6 * M6;
-            if (std::fabs(det) < SMALLREAL) {
-                a[0] = 1.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0; a[4] = 1.0; a[5] = 0.0; a[6] = 0.0; a[7] = 0.0; a[8] = 1.0;
-            } else {
-                const double det_inv = 1.0 / det;
-                a[0] = M0 * det_inv; a[1] = M3 * det_inv; a[2] = M6 * det_inv;
-                a[3] = M1 * det_inv; a[4] = M4 * det_inv; a[5] = M7 * det_inv;
-                a[6] = M2 * det_inv; a[7] = M5 * det_inv; a[8] = M8 * det_inv;
-            }
-        }
-    }
+    (void)bsr_diaginv(A, out.val);
     return out;
 }
 

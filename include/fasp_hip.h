@@ -282,6 +282,25 @@ void   fasp_smoother_dbsr_jacobi1(dBSRmat* A, dvector* b, dvector* u, double* di
 /* mean milliseconds per launch of the BSR SpMV kernel on a resident copy of A (HIP events) */
 double fasp_hip_time_bsr_mxv(const dBSRmat* A, int reps);
 
+/* AMG-preconditioned Krylov solve on a block matrix -- replaces base/src/SolBSR.c:349.
+ * Unsmoothed aggregation (PreAMGSetupUABSR.c:55, VMB on the condensed matrix, identity-block
+ * prolongation, block Galerkin product) on the host, block-Jacobi V/W cycle
+ * (PreMGCycle.c:287) with GMRES(25) on the coarsest level and PCG / VGMRES / VFGMRES
+ * (KryPcg.c:386, KryPvgmres.c:416, KryPvfgmres.c:410) on the device.  Returns the iteration
+ * count or a negative ERROR_* code; unsupported parameters are refused, never run on the CPU. */
+int fasp_solver_dbsr_krylov_amg(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam,
+                                AMG_param* amgparam);
+
+/* Resident form of the block path (extension): setup + upload once, solve many times. */
+typedef struct fasp_hip_amg_bsr fasp_hip_amg_bsr;
+int  fasp_hip_bsr_amg_create(fasp_hip_amg_bsr** h, const dBSRmat* A, AMG_param* amgparam);
+int  fasp_hip_bsr_amg_create_host(fasp_hip_amg_bsr** h, const dBSRmat* A, AMG_param* amgparam); /* no GPU needed */
+void fasp_hip_bsr_amg_destroy(fasp_hip_amg_bsr* h);
+int  fasp_hip_bsr_amg_num_levels(const fasp_hip_amg_bsr* h);
+/* which: 0 = A_l, 1 = P_l, 2 = R_l; the view aliases host memory owned by the handle */
+int  fasp_hip_bsr_amg_get_matrix(const fasp_hip_amg_bsr* h, int level, int which, dBSRmat* view);
+const double* fasp_hip_bsr_amg_get_diaginv(const fasp_hip_amg_bsr* h, int level);
+
 /* ------------------------------------------------------------------------ */
 /* extensions: device binding, resident hierarchy, instrumentation          */
 /* ------------------------------------------------------------------------ */
@@ -330,6 +349,9 @@ typedef struct {
  * absolute residual norms ||r_k||_2, k = 0..iters, up to hist_cap entries. */
 int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_param* itparam,
                    double* hist, int hist_cap, fasp_hip_stats* stats);
+
+int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const ITS_param* itparam,
+                       double* hist, int hist_cap, fasp_hip_stats* stats);
 
 /* The same solve in three steps, for callers that keep b and x resident in HBM:
  * upload the right-hand side / initial guess (x == NULL: zeros), run the Krylov loop on

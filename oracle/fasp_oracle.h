@@ -139,6 +139,24 @@ void orc_amg_borrow_level(orc_amg* mgl, int l, const dCSRmat* A, const dCSRmat* 
 void orc_amg_borrow_end(orc_amg* mgl);
 void orc_amg_borrow_free(orc_amg* mgl);
 
+/* BSR path (config 3): UA-AMG on the condensed matrix + block Jacobi + Krylov.
+ * PreAMGSetupUABSR.c:55, PreMGCycle.c:287, PreBSR.c:1149, SolBSR.c:349 */
+typedef struct {
+    dBSRmat A, P, R;
+    double* diaginv;
+    dvector b, x, w;
+} orc_bsr_level;
+typedef struct {
+    int           num_levels;
+    orc_bsr_level L[ORC_MAX_LVL];
+} orc_amg_bsr;
+int  orc_amg_setup_ua_bsr(orc_amg_bsr* mgl, const dBSRmat* A, AMG_param* param);
+void orc_amg_bsr_free(orc_amg_bsr* mgl);
+void orc_mgcycle_bsr(orc_amg_bsr* mgl, const AMG_param* param);
+int  orc_solver_dbsr_krylov_amg(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam,
+                                AMG_param* amgparam, int* num_levels, double* final_relres);
+int  orc_sizeof_amg_bsr(void);
+
 int orc_sizeof_amg(void);
 
 #ifdef __cplusplus

@@ -174,3 +174,26 @@ int ref_coarse_spvgmres(dCSRmat* A, dvector* b, dvector* x, double ctol, int max
 {
     return fasp_solver_dcsr_spvgmres(A, b, x, NULL, ctol, maxit, (SHORT)restart, 1, 0);
 }
+
+/* ---- BSR path ------------------------------------------------------------ */
+#include "fasp_block.h"
+void* ref_bsr_setup_ua(dBSRmat* A, AMG_param* param)
+{
+    AMG_data_bsr* mgl = fasp_amg_data_bsr_create(param->max_levels);
+    mgl[0].A = fasp_dbsr_create(A->ROW, A->COL, A->NNZ, A->nb, A->storage_manner);
+    mgl[0].b = fasp_dvec_create(mgl[0].A.ROW * mgl[0].A.nb);
+    mgl[0].x = fasp_dvec_create(mgl[0].A.COL * mgl[0].A.nb);
+    fasp_dbsr_cp(A, &(mgl[0].A));
+    if (fasp_amg_setup_ua_bsr(mgl, param) < 0) return NULL;
+    return mgl;
+}
+int ref_bsr_num_levels(void* h) { return ((AMG_data_bsr*)h)[0].num_levels; }
+int ref_bsr_get_matrix(void* h, int l, int which, dBSRmat* view)
+{
+    AMG_data_bsr* mgl = (AMG_data_bsr*)h;
+    *view = which == 0 ? mgl[l].A : which == 1 ? mgl[l].P : mgl[l].R;
+    return 0;
+}
+double* ref_bsr_get_diaginv(void* h, int l) { return ((AMG_data_bsr*)h)[l].diaginv.val; }
+void ref_bsr_free(void* h, AMG_param* param) { fasp_amg_data_bsr_free((AMG_data_bsr*)h, param); }
+int ref_sizeof_bsr(void) { return (int)sizeof(dBSRmat); }

@@ -227,3 +227,93 @@ def poisson7pt_bsr(n, block=B3):
     nb = block.shape[0]
     val = (a[:, None, None] * block[None, :, :]).reshape(-1)
     return ia, ja, val, nb
+
+
+# --- BSR AMG (config 3) helpers ----------------------------------------------------------
+class BsrLvl(C.Structure):
+    """struct orc_bsr_level of oracle/fasp_oracle.h."""
+    _fields_ = [("A", T.dBSRmat), ("P", T.dBSRmat), ("R", T.dBSRmat), ("diaginv", T.c_double_p),
+                ("b", T.dvector), ("x", T.dvector), ("w", T.dvector)]
+
+
+def bsr_arrays(M):
+    ia = np.ctypeslib.as_array(M.IA, (M.ROW + 1,)).copy()
+    ja = np.ctypeslib.as_array(M.JA, (max(M.NNZ, 1),))[:M.NNZ].copy()
+    nv = M.NNZ * M.nb * M.nb
+    v = np.ctypeslib.as_array(M.val, (max(nv, 1),))[:nv].copy()
+    return ia, ja, v
+
+
+def bsr_protos():
+    o = oracle()
+    o.orc_amg_setup_ua_bsr.argtypes = [C.c_void_p, C.POINTER(T.dBSRmat), C.POINTER(T.AMG_param)]
+    o.orc_solver_dbsr_krylov_amg.argtypes = [
+        C.POINTER(T.dBSRmat), C.POINTER(T.dvector), C.POINTER(T.dvector), C.POINTER(T.ITS_param),
+        C.POINTER(T.AMG_param), T.c_int_p, T.c_double_p]
+    R = ref()
+    if R is not None:
+        R.ref_bsr_setup_ua.restype = C.c_void_p
+        R.ref_bsr_setup_ua.argtypes = [C.POINTER(T.dBSRmat), C.POINTER(T.AMG_param)]
+        R.ref_bsr_num_levels.argtypes = [C.c_void_p]
+        R.ref_bsr_get_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(T.dBSRmat)]
+        R.ref_bsr_get_diaginv.argtypes = [C.c_void_p, C.c_int]
+        R.ref_bsr_get_diaginv.restype = T.c_double_p
+        R.ref_bsr_free.argtypes = [C.c_void_p]
+        R.fasp_solver_dbsr_krylov_amg.argtypes = [
+            C.POINTER(T.dBSRmat), C.POINTER(T.dvector), C.POINTER(T.dvector),
+            C.POINTER(T.ITS_param), C.POINTER(T.AMG_param)]
+    return o, R
+
+
+def bsr_params(solver=5, cycle=1):
+    """Config 3 of BASELINE.json: UA-AMG (VMB), block Jacobi, VGMRES(30), tol 1e-8."""
+    itp, amgp = default_params()
+    amgp.AMG_type = T.UA_AMG; amgp.aggregation_type = 2; amgp.smoother = T.SMOOTHER_JACOBI
+    amgp.cycle_type = cycle
+    itp.tol = 1e-8; itp.itsolver_type = solver; itp.restart = 30
+    return itp, amgp
+
+
+def orc_bsr_solve(ia, ja, val, nb, f, itp, amgp):
+    o, _ = bsr_protos()
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    n = A.ROW * nb
+    x = np.zeros(n); bv, fk = T.as_vec(f); xv = T.dvector(n, T.dp(x))
+    nl = C.c_int(0); rr = C.c_double(0)
+    st = o.orc_solver_dbsr_krylov_amg(C.byref(A), C.byref(bv), C.byref(xv), C.byref(itp),
+                                      C.byref(amgp), C.byref(nl), C.byref(rr))
+    return st, x, nl.value, rr.value
+
+
+def ref_bsr_solve(ia, ja, val, nb, f, itp, amgp):
+    _, R = bsr_protos()
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    n = A.ROW * nb
+    x = np.zeros(n); bv, fk = T.as_vec(f); xv = T.dvector(n, T.dp(x))
+    st = R.fasp_solver_dbsr_krylov_amg(C.byref(A), C.byref(bv), C.byref(xv), C.byref(itp),
+                                       C.byref(amgp))
+    return st, x
+
+
+class OrcBSR:
+    """UA-BSR hierarchy built by the oracle: list of (A, P, R, diaginv) numpy tuples per level."""
+
+    def __init__(self, ia, ja, val, nb, amgp):
+        o, _ = bsr_protos()
+        A, keep = T.as_bsr(ia, ja, val, nb)
+        buf = C.create_string_buffer(o.orc_sizeof_amg_bsr())
+        self.status = o.orc_amg_setup_ua_bsr(buf, C.byref(A), C.byref(amgp))
+        self.num_levels = C.cast(buf, T.c_int_p)[0]
+        self.levels = []
+        for l in range(self.num_levels):
+            L = BsrLvl.from_address(C.addressof(buf) + 8 + l * C.sizeof(BsrLvl))
+            last = l == self.num_levels - 1
+            d = None
+            if L.diaginv:
+                d = np.ctypeslib.as_array(L.diaginv, (L.A.ROW * nb * nb,)).copy()
+            self.levels.append(dict(
+                A=(L.A.ROW, L.A.COL, L.A.NNZ) + bsr_arrays(L.A),
+                P=None if last else (L.P.ROW, L.P.COL, L.P.NNZ) + bsr_arrays(L.P),
+                R=None if last else (L.R.ROW, L.R.COL, L.R.NNZ) + bsr_arrays(L.R),
+                diaginv=d))
+        self._buf = buf  # hierarchy memory is leaked with the buffer (test process only)

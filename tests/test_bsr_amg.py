@@ -1,0 +1,180 @@
+"""Block (BSR) AMG-Krylov path, config 3 of BASELINE.json (SolBSR.c:349).
+
+CPU: oracle vs the compiled reference (hierarchies, inverse diagonal blocks, solutions, all
+bit-exact) and the product's host setup vs the oracle.  GPU: the device path vs the oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import faspsolver_amd as fa
+from faspsolver_amd import _types as T
+
+from _libs import (DATA, OrcBSR, bsr_arrays, bsr_params, bsr_protos, have_ref, orc_bsr_solve,
+                   poisson7pt_bsr, read_bsr, read_vec, ref_bsr_solve)
+
+needs_ref = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+
+
+def spe01():
+    ia, ja, val, nb = read_bsr(DATA + "/bsrmat_SPE01.dat")
+    return ia, ja, val, nb, read_vec(DATA + "/rhs_SPE01.dat")
+
+
+def synthetic(n, seed=1):
+    ia, ja, val, nb = poisson7pt_bsr(n)
+    f = np.random.default_rng(seed).standard_normal((len(ia) - 1) * nb)
+    return ia, ja, val, nb, f
+
+
+def ref_hierarchy(ia, ja, val, nb, amgp):
+    _, R = bsr_protos()
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    h = R.ref_bsr_setup_ua(C.byref(A), C.byref(amgp))
+    nl = R.ref_bsr_num_levels(h)
+    levels = []
+    for l in range(nl):
+        d = {}
+        for which, nm in ((0, "A"), (1, "P"), (2, "R")):
+            if which and l == nl - 1:
+                d[nm] = None
+                continue
+            v = T.dBSRmat()
+            R.ref_bsr_get_matrix(h, l, which, C.byref(v))
+            d[nm] = (v.ROW, v.COL, v.NNZ) + bsr_arrays(v)
+        d["diaginv"] = None
+        if l < nl - 1:
+            d["diaginv"] = np.ctypeslib.as_array(R.ref_bsr_get_diaginv(h, l), (d["A"][0] * nb * nb,)).copy()
+        levels.append(d)
+    R.ref_bsr_free(h)
+    return levels
+
+
+def same_matrix(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return a[:3] == b[:3] and all(np.array_equal(x, y) for x, y in zip(a[3:], b[3:]))
+
+
+CASES = [("spe01", spe01), ("p8", lambda: synthetic(8)), ("p12", lambda: synthetic(12)),
+         ("p16", lambda: synthetic(16))]
+
+
+@needs_ref
+@pytest.mark.parametrize("name,make", CASES)
+def test_oracle_hierarchy_equals_reference(name, make):
+    ia, ja, val, nb, f = make()
+    _, p1 = bsr_params(); _, p2 = bsr_params()
+    H = OrcBSR(ia, ja, val, nb, p1)
+    ref_levels = ref_hierarchy(ia, ja, val, nb, p2)
+    assert H.num_levels == len(ref_levels)
+    assert bytes(p1) == bytes(p2)  # strong_coupled adapted identically
+    for lo, lr in zip(H.levels, ref_levels):
+        for nm in ("A", "P", "R"):
+            assert same_matrix(lo[nm], lr[nm]), nm
+        if lr["diaginv"] is not None:
+            assert np.array_equal(lo["diaginv"], lr["diaginv"])
+
+
+@needs_ref
+@pytest.mark.parametrize("solver,cycle", [(5, 1), (1, 1), (6, 2)])
+@pytest.mark.parametrize("n", [8, 12])
+def test_oracle_solve_equals_reference(n, solver, cycle):
+    ia, ja, val, nb, f = synthetic(n)
+    i1, a1 = bsr_params(solver, cycle); i2, a2 = bsr_params(solver, cycle)
+    s1, x1, nl, rr = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    s2, x2 = ref_bsr_solve(ia, ja, val, nb, f, i2, a2)
+    assert s1 == s2 and s1 > 0
+    assert np.array_equal(x1, x2)
+    assert rr < 1e-8
+
+
+@needs_ref
+def test_oracle_spe01_one_level_equals_reference():
+    """SPE01 (shipped, 1000 block rows, nb = 3) stays a single level: every preconditioner
+    application is the coarse GMRES(25); both sides hit MaxIt the same way."""
+    ia, ja, val, nb, f = spe01()
+    i1, a1 = bsr_params(); i2, a2 = bsr_params()
+    i1.maxit = i2.maxit = 12
+    s1, x1, nl, rr = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    s2, x2 = ref_bsr_solve(ia, ja, val, nb, f, i2, a2)
+    assert nl == 1 and s1 == s2
+    assert np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("name,make", CASES)
+def test_product_host_setup_equals_oracle(name, make):
+    """libfasp_hip's host UA-BSR setup (no GPU needed) is bit-identical to the oracle's."""
+    ia, ja, val, nb, f = make()
+    _, p1 = bsr_params(); _, p2 = bsr_params()
+    H = OrcBSR(ia, ja, val, nb, p1)
+    G = fa.BSRAMG(ia, ja, val, nb, p2, host_only=True)
+    assert G.num_levels == H.num_levels
+    assert bytes(p1) == bytes(p2)
+    for l, lo in enumerate(H.levels):
+        last = l == H.num_levels - 1
+        assert same_matrix(lo["A"], G.matrix(l, 0))
+        if not last:
+            assert same_matrix(lo["P"], G.matrix(l, 1))
+            assert same_matrix(lo["R"], G.matrix(l, 2))
+            assert np.array_equal(lo["diaginv"], G.diaginv(l))
+    G.free()
+
+
+def test_bsr_unsupported_parameters_are_refused():
+    ia, ja, val, nb, f = synthetic(6)
+    itp, amgp = bsr_params()
+    amgp.smoother = T.SMOOTHER_GS
+    x = np.zeros(len(f))
+    assert fa.solver_dbsr_krylov_amg(ia, ja, val, nb, f, x, itp, amgp) == T.ERROR_AMG_SMOOTH_TYPE
+    itp, amgp = bsr_params()
+    amgp.AMG_type = T.SA_AMG
+    assert fa.solver_dbsr_krylov_amg(ia, ja, val, nb, f, x, itp, amgp) < 0
+    itp, amgp = bsr_params()
+    itp.itsolver_type = 2  # BiCGstab
+    assert fa.solver_dbsr_krylov_amg(ia, ja, val, nb, f, x, itp, amgp) == T.ERROR_SOLVER_TYPE
+
+
+# ------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,cycle", [(5, 1), (1, 1), (6, 2)])
+@pytest.mark.parametrize("n", [8, 16, 24])
+def test_gpu_bsr_solve_matches_oracle(n, solver, cycle):
+    ia, ja, val, nb, f = synthetic(n)
+    i1, a1 = bsr_params(solver, cycle); i2, a2 = bsr_params(solver, cycle)
+    s1, x1, nl, rr1 = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    G = fa.BSRAMG(ia, ja, val, nb, a2)
+    s2, x2, hist, stats = G.solve(f, i2)
+    assert G.num_levels == nl
+    assert s2 == s1, (s1, s2)
+    # tolerance: 1e-10 relative on the solution (north_star), residual agreement 1e-6 relative
+    assert np.abs(x1 - x2).max() <= 1e-10 * np.abs(x1).max()
+    assert abs(stats.relres - rr1) <= 1e-6 * rr1 + 1e-15
+    G.free()
+
+
+@pytest.mark.gpu
+def test_gpu_bsr_dropin_entry_point():
+    ia, ja, val, nb, f = synthetic(12)
+    i1, a1 = bsr_params(); i2, a2 = bsr_params()
+    s1, x1, nl, rr1 = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    x2 = np.zeros(len(f))
+    s2 = fa.solver_dbsr_krylov_amg(ia, ja, val, nb, f, x2, i2, a2)
+    assert s2 == s1
+    assert np.abs(x1 - x2).max() <= 1e-10 * np.abs(x1).max()
+    assert bytes(a1) == bytes(a2)  # the setup's in-place parameter updates match
+
+
+@pytest.mark.gpu
+def test_gpu_bsr_spe01_one_level():
+    ia, ja, val, nb, f = spe01()
+    i1, a1 = bsr_params(); i2, a2 = bsr_params()
+    i1.maxit = i2.maxit = 12
+    s1, x1, nl, rr1 = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    G = fa.BSRAMG(ia, ja, val, nb, a2)
+    s2, x2, hist, stats = G.solve(f, i2)
+    assert G.num_levels == 1 and s1 == s2
+    # ill-conditioned single-level case: inner GMRES runs 200 iterations per application
+    assert np.abs(x1 - x2).max() <= 1e-6 * np.abs(x1).max()
+    G.free()
