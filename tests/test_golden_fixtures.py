@@ -172,3 +172,125 @@ def test_midsize_summaries(n, fa):
     lv = [[H.matrix(l, 0)[0], len(H.matrix(l, 0)[4])] for l in range(H.num_levels)]
     assert lv == z[f"n{n}_levels"].tolist()
     H.close()
+
+
+# --- F7: smoothed aggregation + GMRES family (config-5 shape, small) -----------------------
+def _c5(i, a):
+    i.tol = 1e-8; i.itsolver_type = 6; i.restart = 30
+    a.AMG_type = T.SA_AMG; a.smoother = T.SMOOTHER_JACOBI; a.cycle_type = T.W_CYCLE
+
+
+def _c5v(i, a):
+    _c5(i, a); i.itsolver_type = 5; a.cycle_type = T.V_CYCLE
+
+
+def test_sa_product_host_hierarchy_vs_golden(fa):
+    z = np.load(os.path.join(G, "sa_p7_12.npz"))
+    ia, ja, a, f, ue = poisson7pt(12)
+    itp, amgp = default_params(); _c5(itp, amgp)
+    H = fa.AMG(ia, ja, a, amgp, host_only=True)
+    _check_hierarchy(z, H.matrix, H.num_levels)
+    H.close()
+
+
+@pytest.mark.parametrize("name,mod", [("vfgmres_W", _c5), ("vgmres_V", _c5v)])
+def test_sa_gmres_oracle_vs_golden(name, mod):
+    z = np.load(os.path.join(G, "sa_p7_12.npz"))
+    ia, ja, a, f, ue = poisson7pt(12)
+    itp, amgp = default_params(); mod(itp, amgp)
+    st, x, hist, rr = orc_solve(ia, ja, a, f, itp, amgp)
+    assert st == int(z[f"solve_{name}_iters"])
+    assert np.array_equal(x, z[f"solve_{name}_x"])
+
+
+# --- F6: block (BSR) path --------------------------------------------------------------------
+def test_bsr_oracle_kernels_vs_golden():
+    from _libs import read_bsr
+    z = np.load(os.path.join(G, "bsr.npz"))
+    ia, ja, val, nb = read_bsr(DATA + "/bsrmat_SPE01.dat")
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    O = oracle()
+    O.orc_bsr_mxv.argtypes = [C.POINTER(T.dBSRmat), T.c_double_p, T.c_double_p]
+    O.orc_bsr_getdiaginv.restype = T.c_double_p
+    O.orc_bsr_getdiaginv.argtypes = [C.POINTER(T.dBSRmat)]
+    x = z["spe01_x"].copy(); y = np.zeros(A.ROW * nb)
+    O.orc_bsr_mxv(C.byref(A), T.dp(x), T.dp(y))
+    assert np.array_equal(y, z["spe01_mxv"])
+    d = np.ctypeslib.as_array(O.orc_bsr_getdiaginv(C.byref(A)), (A.ROW * nb * nb,))
+    assert np.array_equal(d, z["spe01_diaginv"])
+
+
+def _check_bsr_hierarchy(z, nl, get, diaginv):
+    assert nl == int(z["p8_num_levels"])
+    for l in range(nl):
+        for which, nm in ((0, "A"), (1, "P"), (2, "R")):
+            if which and l == nl - 1:
+                continue
+            ROW, COL, NNZ, ia, ja, val = get(l, which)
+            assert [ROW, COL, NNZ] == list(z[f"p8_L{l}_{nm}_shape"])
+            assert np.array_equal(ia, z[f"p8_L{l}_{nm}_ia"]) and np.array_equal(ja, z[f"p8_L{l}_{nm}_ja"])
+            assert np.array_equal(val, z[f"p8_L{l}_{nm}_val"])
+        if l < nl - 1:
+            assert np.array_equal(diaginv(l), z[f"p8_L{l}_diaginv"])
+
+
+def test_bsr_hierarchies_vs_golden(fa):
+    from _libs import OrcBSR, bsr_params, poisson7pt_bsr
+    z = np.load(os.path.join(G, "bsr.npz"))
+    ia, ja, val, nb = poisson7pt_bsr(8)
+    _, p1 = bsr_params(); _, p2 = bsr_params()
+    H = OrcBSR(ia, ja, val, nb, p1)
+    _check_bsr_hierarchy(z, H.num_levels, lambda l, w: H.levels[l]["APR"[w]], lambda l: H.levels[l]["diaginv"])
+    Gp = fa.BSRAMG(ia, ja, val, nb, p2, host_only=True)
+    _check_bsr_hierarchy(z, Gp.num_levels, Gp.matrix, Gp.diaginv)
+    assert p1.strong_coupled == p2.strong_coupled == float(z["p8_strong_coupled_after"])
+    Gp.free()
+
+
+@pytest.mark.parametrize("name,solver,cycle", [("vgmres_V", 5, 1), ("pcg_V", 1, 1), ("vfgmres_W", 6, 2)])
+def test_bsr_oracle_solves_vs_golden(name, solver, cycle):
+    from _libs import bsr_params, orc_bsr_solve, poisson7pt_bsr
+    z = np.load(os.path.join(G, "bsr.npz"))
+    ia, ja, val, nb = poisson7pt_bsr(8)
+    itp, amgp = bsr_params(solver, cycle)
+    st, x, nl, rr = orc_bsr_solve(ia, ja, val, nb, z["p8_f"], itp, amgp)
+    assert st == int(z[f"p8_{name}_iters"])
+    assert np.array_equal(x, z[f"p8_{name}_x"])
+
+
+def test_bsr_oracle_spe01_vs_golden():
+    from _libs import bsr_params, orc_bsr_solve, read_bsr
+    z = np.load(os.path.join(G, "bsr.npz"))
+    ia, ja, val, nb = read_bsr(DATA + "/bsrmat_SPE01.dat"); f = read_vec(DATA + "/rhs_SPE01.dat")
+    itp, amgp = bsr_params(); itp.maxit = 12
+    st, x, nl, rr = orc_bsr_solve(ia, ja, val, nb, f, itp, amgp)
+    assert st == int(z["spe01_status_maxit12"]) and nl == 1
+    assert np.array_equal(x, z["spe01_x_maxit12"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,solver,cycle", [("vgmres_V", 5, 1), ("pcg_V", 1, 1), ("vfgmres_W", 6, 2)])
+def test_gpu_bsr_solves_vs_golden(fa, name, solver, cycle):
+    """The device block path against the REFERENCE's committed outputs (no oracle in between)."""
+    from _libs import bsr_params, poisson7pt_bsr
+    z = np.load(os.path.join(G, "bsr.npz"))
+    ia, ja, val, nb = poisson7pt_bsr(8)
+    itp, amgp = bsr_params(solver, cycle)
+    x = np.zeros(len(z["p8_f"]))
+    st = fa.solver_dbsr_krylov_amg(ia, ja, val, nb, z["p8_f"], x, itp, amgp)
+    assert st == int(z[f"p8_{name}_iters"])
+    xr = z[f"p8_{name}_x"]
+    assert np.abs(x - xr).max() <= 1e-10 * np.abs(xr).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mod", [("vfgmres_W", _c5), ("vgmres_V", _c5v)])
+def test_gpu_sa_gmres_vs_golden(fa, name, mod):
+    z = np.load(os.path.join(G, "sa_p7_12.npz"))
+    ia, ja, a, f, ue = poisson7pt(12)
+    itp, amgp = default_params(); mod(itp, amgp)
+    x = np.zeros(len(f))
+    st = fa.solver_dcsr_krylov_amg(ia, ja, a, f, x, itp, amgp)
+    assert st == int(z[f"solve_{name}_iters"])
+    xr = z[f"solve_{name}_x"]
+    assert np.abs(x - xr).max() <= 1e-10 * np.abs(xr).max()

@@ -46,8 +46,9 @@ def hierarchy(ia, ja, a, amgp):
             i2, j2, v2 = T.csr_arrays(v)
             out[f"L{l}_{nm}_shape"] = np.array([v.row, v.col, v.nnz])
             out[f"L{l}_{nm}_ia"] = i2; out[f"L{l}_{nm}_ja"] = j2; out[f"L{l}_{nm}_val"] = v2
-        if l < nl - 1:
-            out[f"L{l}_cfmark"] = np.ctypeslib.as_array(R.ref_amg_get_cfmark(h, l), (out[f"L{l}_A_shape"][0],)).copy()
+        cf = R.ref_amg_get_cfmark(h, l) if l < nl - 1 else None
+        if cf:  # aggregation hierarchies carry no C/F marker
+            out[f"L{l}_cfmark"] = np.ctypeslib.as_array(cf, (out[f"L{l}_A_shape"][0],)).copy()
     return h, out
 
 
@@ -152,6 +153,67 @@ def main():
         st, xs, hist = solve(ia, ja, a, f, MODS["jacobi_V"])
         summ[f"n{n}_iters"] = np.array(st); summ[f"n{n}_hist"] = hist
     np.savez_compressed(os.path.join(OUT, "p7_summaries.npz"), **summ)
+
+    # F7: config-5 shape at small size: SA hierarchy + VFGMRES(30)/W and VGMRES/V on P7(12)
+    ia, ja, a, f, ue = ref_p7(12)
+    sa = {}
+    def c5(i, a_):
+        i.tol = 1e-8; i.itsolver_type = 6; i.restart = 30
+        a_.AMG_type = T.SA_AMG; a_.smoother = T.SMOOTHER_JACOBI; a_.cycle_type = T.W_CYCLE
+    def c5v(i, a_):
+        c5(i, a_); i.itsolver_type = 5; a_.cycle_type = T.V_CYCLE
+    itp, amgp = ref_params(); c5(itp, amgp)
+    h, hier = hierarchy(ia, ja, a, amgp)
+    R.ref_amg_free(h, C.byref(amgp))
+    sa.update({k: v for k, v in hier.items() if "cfmark" not in k})
+    for nm, mod in (("vfgmres_W", c5), ("vgmres_V", c5v)):
+        st, xs, hist = solve(ia, ja, a, f, mod)
+        sa[f"solve_{nm}_iters"] = np.array(st); sa[f"solve_{nm}_hist"] = hist; sa[f"solve_{nm}_x"] = xs
+    np.savez_compressed(os.path.join(OUT, "sa_p7_12.npz"), **sa)
+
+    # F6: block path.  SPE01 (shipped): SpMV, inverse diagonal blocks, the non-converging
+    # one-level VGMRES run; synthetic P7(8) (x) B3: hierarchy + three solves
+    from _libs import bsr_arrays, bsr_params, bsr_protos, poisson7pt_bsr, read_bsr, ref_bsr_solve
+    bsr_protos()
+    bs = {}
+    ia, ja, val, nb = read_bsr(DATA + "/bsrmat_SPE01.dat"); f = read_vec(DATA + "/rhs_SPE01.dat")
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    x = np.random.default_rng(7).standard_normal(A.COL * nb); y = np.zeros(A.ROW * nb)
+    R.fasp_blas_dbsr_mxv.argtypes = [C.POINTER(T.dBSRmat), T.c_double_p, T.c_double_p]
+    R.fasp_blas_dbsr_mxv(C.byref(A), T.dp(x), T.dp(y))
+    bs["spe01_x"] = x; bs["spe01_mxv"] = y
+    R.fasp_dbsr_getdiaginv.restype = T.dvector; R.fasp_dbsr_getdiaginv.argtypes = [C.POINTER(T.dBSRmat)]
+    d = R.fasp_dbsr_getdiaginv(C.byref(A))
+    bs["spe01_diaginv"] = np.ctypeslib.as_array(d.val, (d.row,)).copy()
+    itp, amgp = bsr_params(); itp.maxit = 12
+    st, xs = ref_bsr_solve(ia, ja, val, nb, f, itp, amgp)
+    bs["spe01_status_maxit12"] = np.array(st); bs["spe01_x_maxit12"] = xs
+    n = 8
+    ia, ja, val, nb = poisson7pt_bsr(n)
+    f = np.random.default_rng(1).standard_normal((len(ia) - 1) * nb)
+    bs["p8_f"] = f
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    _, amgp = bsr_params()
+    hb = R.ref_bsr_setup_ua(C.byref(A), C.byref(amgp))
+    nl = R.ref_bsr_num_levels(hb)
+    bs["p8_num_levels"] = np.array(nl); bs["p8_strong_coupled_after"] = np.array(amgp.strong_coupled)
+    for l in range(nl):
+        for which, nm in ((0, "A"), (1, "P"), (2, "R")):
+            if which and l == nl - 1:
+                continue
+            v = T.dBSRmat(); R.ref_bsr_get_matrix(hb, l, which, C.byref(v))
+            i2, j2, v2 = bsr_arrays(v)
+            bs[f"p8_L{l}_{nm}_shape"] = np.array([v.ROW, v.COL, v.NNZ])
+            bs[f"p8_L{l}_{nm}_ia"] = i2; bs[f"p8_L{l}_{nm}_ja"] = j2; bs[f"p8_L{l}_{nm}_val"] = v2
+        if l < nl - 1:
+            bs[f"p8_L{l}_diaginv"] = np.ctypeslib.as_array(
+                R.ref_bsr_get_diaginv(hb, l), (int(bs[f"p8_L{l}_A_shape"][0]) * nb * nb,)).copy()
+    R.ref_bsr_free(hb)
+    for nm, (solver, cycle) in (("vgmres_V", (5, 1)), ("pcg_V", (1, 1)), ("vfgmres_W", (6, 2))):
+        itp, amgp = bsr_params(solver, cycle)
+        st, xs = ref_bsr_solve(ia, ja, val, nb, f, itp, amgp)
+        bs[f"p8_{nm}_iters"] = np.array(st); bs[f"p8_{nm}_x"] = xs
+    np.savez_compressed(os.path.join(OUT, "bsr.npz"), **bs)
     for fn in sorted(os.listdir(OUT)):
         p = os.path.join(OUT, fn)
         if os.path.isfile(p):
