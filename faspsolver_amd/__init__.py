@@ -27,6 +27,8 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_blas_darray_norm2", "fasp_blas_darray_norminf", "fasp_blas_darray_axpy",
     "fasp_blas_darray_axpby", "fasp_smoother_dcsr_jacobi",
     "fasp_blas_dbsr_mxv", "fasp_blas_dbsr_aAxpy", "fasp_dbsr_getdiaginv", "fasp_smoother_dbsr_jacobi1",
+    "fasp_solver_amg", "fasp_hip_amg_solve", "fasp_solver_dcsr_pcg", "fasp_solver_dcsr_pvgmres",
+    "fasp_solver_dcsr_pvfgmres", "fasp_hip_precond_setup", "fasp_hip_precond_fct", "fasp_hip_precond_free",
     "fasp_hip_time_bsr_mxv", "fasp_solver_dbsr_krylov_amg", "fasp_hip_bsr_amg_create", "fasp_hip_bsr_amg_create_host",
     "fasp_hip_bsr_amg_destroy", "fasp_hip_bsr_amg_num_levels", "fasp_hip_bsr_amg_get_matrix",
     "fasp_hip_bsr_amg_get_diaginv", "fasp_hip_bsr_solve",
@@ -84,6 +86,20 @@ def lib():
     L.fasp_smoother_dbsr_jacobi1.argtypes = [P(T.dBSRmat), P(T.dvector), P(T.dvector), T.c_double_p]
     L.fasp_hip_time_bsr_mxv.argtypes = [P(T.dBSRmat), C.c_int]
     L.fasp_hip_time_bsr_mxv.restype = C.c_double
+    L.fasp_solver_dcsr_pcg.argtypes = [P(T.dCSRmat), P(T.dvector), P(T.dvector), P(T.precond), C.c_double,
+                                       C.c_double, C.c_int, C.c_short, C.c_short]
+    L.fasp_solver_dcsr_pvgmres.argtypes = [P(T.dCSRmat), P(T.dvector), P(T.dvector), P(T.precond), C.c_double,
+                                           C.c_double, C.c_int, C.c_short, C.c_short, C.c_short]
+    L.fasp_solver_dcsr_pvfgmres.argtypes = L.fasp_solver_dcsr_pvgmres.argtypes
+    L.fasp_hip_precond_setup.argtypes = [P(T.dCSRmat), P(T.AMG_param)]
+    L.fasp_hip_precond_setup.restype = P(T.precond)
+    L.fasp_hip_precond_free.argtypes = [P(T.precond)]
+    L.fasp_hip_precond_free.restype = None
+    L.fasp_hip_precond_fct.argtypes = [T.c_double_p, T.c_double_p, C.c_void_p]
+    L.fasp_hip_precond_fct.restype = None
+    L.fasp_solver_amg.argtypes = [P(T.dCSRmat), P(T.dvector), P(T.dvector), P(T.AMG_param)]
+    L.fasp_hip_amg_solve.argtypes = [C.c_void_p, P(T.dvector), P(T.dvector), P(T.AMG_param), T.c_double_p,
+                                     C.c_int, P(T.fasp_hip_stats)]
     L.fasp_solver_dbsr_krylov_amg.argtypes = [P(T.dBSRmat), P(T.dvector), P(T.dvector), P(T.ITS_param),
                                               P(T.AMG_param)]
     L.fasp_hip_bsr_amg_create.argtypes = [P(C.c_void_p), P(T.dBSRmat), P(T.AMG_param)]
@@ -236,6 +252,18 @@ class AMG:
                                   T.dp(hist), hist_cap, C.byref(stats))
         return st, x, hist[:max(stats.nhist, 0)].copy(), stats
 
+    def amg_solve(self, b, amgparam=None, x0=None, hist_cap=600):
+        """Multigrid cycles as a stand-alone solver (fasp_amg_solve) -> (status, x, hist, stats)."""
+        x = np.zeros(self.n) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        bv, _b = T.as_vec(b)
+        xv, x = T.as_vec(x)
+        hist = np.zeros(hist_cap)
+        stats = T.fasp_hip_stats()
+        st = lib().fasp_hip_amg_solve(self.h, C.byref(bv), C.byref(xv),
+                                      C.byref(amgparam) if amgparam is not None else None,
+                                      T.dp(hist), hist_cap, C.byref(stats))
+        return st, x, hist[:max(min(stats.nhist, hist_cap), 0)].copy(), stats
+
     def set_rhs(self, b):
         bv, _b = T.as_vec(b)
         st = lib().fasp_hip_set_rhs(self.h, C.byref(bv))
@@ -380,3 +408,12 @@ def solver_dbsr_krylov_amg(ia, ja, val, nb, b, x, itparam, amgparam):
     xv = T.dvector(len(x), T.dp(x))
     return lib().fasp_solver_dbsr_krylov_amg(C.byref(A), C.byref(bv), C.byref(xv), C.byref(itparam),
                                              C.byref(amgparam))
+
+
+def solver_amg(ia, ja, a, b, x, amgparam):
+    """Drop-in call of fasp_solver_amg (SolAMG.c:49): x is the guess on entry, solution on exit."""
+    A, _keep = T.as_csr(ia, ja, a)
+    bv, _b = T.as_vec(b)
+    assert x.dtype == np.float64 and x.flags.c_contiguous
+    xv = T.dvector(len(x), T.dp(x))
+    return lib().fasp_solver_amg(C.byref(A), C.byref(bv), C.byref(xv), C.byref(amgparam))

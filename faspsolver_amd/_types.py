@@ -143,3 +143,11 @@ def dp(x):
 
 def ip(x):
     return x.ctypes.data_as(c_int_p)
+
+
+PRECOND_FCT = C.CFUNCTYPE(None, c_double_p, c_double_p, C.c_void_p)
+
+
+class precond(C.Structure):
+    """fasp.h:1095-1103: preconditioner data + action z = B r."""
+    _fields_ = [("data", C.c_void_p), ("fct", PRECOND_FCT)]

@@ -1246,6 +1246,50 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
     return FASP_SUCCESS;
 }
 
+// fasp_amg_solve (PreMGSolve.c:49): multigrid cycles as a stand-alone iteration on the resident
+// vectors h->b, h->u.  The cycle receives the caller's AMG_param (coarse tolerance tol * 1e-4).
+static int amg_solve_device(fasp_hip_amg* h, const AMG_param& param, Hist& hist, PcgOut& out)
+{
+    DevLevel& D0 = h->L[0];
+    const int m = D0.A.row, MaxIt = param.maxit, prtlvl = param.print_level;
+    const bool dist = h->distributed;
+    const double tol = param.tol;
+    hipStream_t s = g_ctx.stream;
+    double red[2], relres1 = 1.0, absres0, absres = 0.0;
+    int iter = 0, st;
+    if (d_dot(m, h->b, h->b, red, dist) < 0) return ERROR_MISC;
+    const double sumb = std::sqrt(red[0]);
+    absres0 = sumb;
+    D0.b = h->b;
+    HIPCK(hipMemcpyAsync(D0.x, h->u, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    D0.x_zero = false;
+    itinfo(prtlvl, STOP_REL_RES, iter, relres1, sumb, 0.0);
+    hist.push(sumb);
+    if (sumb <= SMALLREAL) HIPCK(hipMemsetAsync(D0.x, 0, sizeof(double) * m, s));
+    while ((iter++ < MaxIt) & (sumb > SMALLREAL)) {
+        if ((st = mgcycle(h, param)) < 0) return st;
+        materialise_zero(D0);
+        if (halo_exchange(D0, D0.x) < 0) return ERROR_MISC;
+        d_resid(D0.A, D0.x, D0.b, D0.w);
+        if (d_dot(m, D0.w, D0.w, red, dist) < 0) return ERROR_MISC;
+        absres = std::sqrt(red[0]);
+        relres1 = absres / std::max(SMALLREAL, sumb);
+        const double factor = absres / absres0;
+        absres0 = absres;
+        itinfo(prtlvl, STOP_REL_RES, iter, relres1, absres, factor);
+        hist.push(absres);
+        if (relres1 < tol) break;
+    }
+    HIPCK(hipMemcpyAsync(h->u, D0.x, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    HIPCK(hipStreamSynchronize(s));
+    if (prtlvl > PRINT_NONE) {
+        if (iter > MaxIt) std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, relres1);
+        else if (iter >= 0) std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, relres1);
+    }
+    out.relres = relres1; out.absres = absres; out.normr0 = sumb;
+    return iter > MaxIt ? ERROR_SOLVER_MAXIT : iter;
+}
+
 // Krylov operator bundles of the CSR hierarchy: level 0 (with the AMG preconditioner) and the
 // coarsest level (no preconditioner: the SPVGMRES safety net)
 static KOps csr_ops(fasp_hip_amg* h, int level, bool with_pc)
@@ -1903,6 +1947,57 @@ int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_para
     return st;
 }
 
+// AMG as a stand-alone solver on a resident hierarchy (PreMGSolve.c:49); param == NULL: the
+// parameters the hierarchy was built with
+int fasp_hip_amg_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const AMG_param* param, double* hist,
+                       int hist_cap, fasp_hip_stats* stats)
+{
+    if (!h || !b || !x || h->L.empty()) return ERROR_INPUT_PAR;
+    const AMG_param& p = param ? *param : h->param;
+    int st = check_supported(nullptr, &p);
+    if (st < 0) return st;
+    double t0 = wall_seconds();
+    if ((st = fasp_hip_set_rhs(h, b)) < 0) return st;
+    if ((st = fasp_hip_set_guess(h, x)) < 0) return st;
+    double t_up = wall_seconds() - t0;
+    h->ev_used = 0;
+    const long long ci0 = h->coarse_iters, vc0 = h->vcycles;
+    Hist   H{hist, hist_cap, 0};
+    PcgOut po{BIGREAL, BIGREAL, BIGREAL};
+    t0 = wall_seconds();
+    st = amg_solve_device(h, p, H, po);
+    const double t_solve = wall_seconds() - t0;
+    t0 = wall_seconds();
+    const int st2 = fasp_hip_get_solution(h, x);
+    if (st2 < 0) return st2;
+    t_up += wall_seconds() - t0;
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->iters = st; stats->nhist = H.n; stats->relres = po.relres; stats->absres = po.absres;
+        stats->normr0 = po.normr0; stats->solve_seconds = t_solve; stats->upload_seconds = t_up;
+        stats->coarse_iters = h->coarse_iters - ci0;
+        stats->vcycles = h->vcycles - vc0;
+    }
+    if (p.print_level > PRINT_NONE) std::printf("AMG solve costs %.4f seconds.\n", t_solve);
+    return st;
+}
+
+// SolAMG.c:49.  A failed setup returns its error code (the reference would fall back to an
+// unpreconditioned CPU GMRES there; this library has no CPU solve path).
+int fasp_solver_amg(dCSRmat* A, dvector* b, dvector* x, AMG_param* param)
+{
+    if (!A || !b || !x || !param) return ERROR_INPUT_PAR;
+    const double t0 = wall_seconds();
+    int st = check_supported(nullptr, param);
+    if (st < 0) return st;
+    fasp_hip_amg* h = nullptr;
+    if ((st = fasp_hip_amg_create(&h, A, param)) < 0) return st;
+    st = fasp_hip_amg_solve(h, b, x, param, nullptr, 0, nullptr);
+    if (param->print_level > PRINT_NONE) std::printf("AMG totally costs %.4f seconds.\n", wall_seconds() - t0);
+    fasp_hip_amg_destroy(h);
+    return st;
+}
+
 int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z)
 {
     if (!h || !r || !z || h->L.empty()) return ERROR_INPUT_PAR;
@@ -2180,6 +2275,131 @@ struct TmpVec {
     std::exit(ERROR_MISC);
 }
 }  // namespace
+
+// ---------------------------------------------------------------------------
+// plug-in level of the reference: the Krylov methods with a caller
+// supplied `precond` (fasp.h:1095), and the AMG preconditioner as such a plug-in
+// ---------------------------------------------------------------------------
+// PreCSR.c:416 signature: z = B r, host vectors; data is the fasp_hip_amg* of fasp_hip_precond_setup
+void fasp_hip_precond_fct(double* r, double* z, void* data)
+{
+    fasp_hip_amg* h = static_cast<fasp_hip_amg*>(data);
+    if (fasp_hip_precond_amg(h, r, z) < 0) {
+        std::fprintf(stderr, "### ERROR: fasp_hip_precond_fct: device preconditioner failed\n");
+        std::exit(ERROR_MISC);
+    }
+}
+
+// PreCSR.c:46 for PREC_AMG: hierarchy built and uploaded once, handed out as a `precond`
+precond* fasp_hip_precond_setup(dCSRmat* A, AMG_param* amgparam)
+{
+    fasp_hip_amg* h = nullptr;
+    if (fasp_hip_amg_create(&h, A, amgparam) < 0) return nullptr;
+    precond* pc = static_cast<precond*>(std::calloc(1, sizeof(precond)));
+    pc->data = h;
+    pc->fct = fasp_hip_precond_fct;
+    return pc;
+}
+
+void fasp_hip_precond_free(precond* pc)
+{
+    if (!pc) return;
+    if (pc->fct == fasp_hip_precond_fct) fasp_hip_amg_destroy(static_cast<fasp_hip_amg*>(pc->data));
+    std::free(pc);
+}
+
+namespace {
+bool same_host_matrix(const HostCSR& M, const dCSRmat* A)
+{
+    return M.row == A->row && M.col == A->col && M.nnz == A->nnz &&
+           std::memcmp(M.ia.data(), A->IA, sizeof(int) * ((size_t)A->row + 1)) == 0 &&
+           std::memcmp(M.ja.data(), A->JA, sizeof(int) * (size_t)A->nnz) == 0 &&
+           std::memcmp(M.val.data(), A->val, sizeof(double) * (size_t)A->nnz) == 0;
+}
+
+// which: 0 PCG, 1 VGMRES, 2 VFGMRES
+int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u, precond* pc, double tol,
+                  double abstol, int MaxIt, short restart, short StopType, short PrtLvl)
+{
+    if (ctx_init() < 0) die_no_device(fn);
+    if (!A || !b || !u || A->row != A->col || b->row != A->row || u->row != A->row) return ERROR_INPUT_PAR;
+    if (comm_size() > 1) return ERROR_INPUT_PAR;  // plug-in level: one GPU
+    const int n = b->row;
+    fasp_hip_amg* h = (pc && pc->fct == fasp_hip_precond_fct) ? static_cast<fasp_hip_amg*>(pc->data) : nullptr;
+    if (h && (h->L.empty() || h->L[0].A.row != n)) return ERROR_INPUT_PAR;
+    std::unique_ptr<TmpCSR> own;
+    const DevCSR* dA = nullptr;
+    if (h && same_host_matrix(h->H.L[0].A, A)) dA = &h->L[0].A;  // the resident level-0 operator is A itself
+    else {
+        own.reset(new TmpCSR(A));
+        if (!own->ok) return ERROR_ALLOC_MEM;
+        dA = &own->D;
+    }
+    TmpVec db(b->val, n), du(u->val, n), dp(nullptr, n), dt(nullptr, n), dr(nullptr, n), dz(nullptr, n);
+    if (!db.d || !du.d || !dp.d || !dt.d || !dr.d || !dz.d) return ERROR_ALLOC_MEM;
+    std::vector<double> hr, hz;
+    std::vector<double*> ws;
+    size_t ws_len = 0;
+    double* hh = nullptr;
+    KOps K;
+    K.n = n; K.nvec = (size_t)n; K.fmt = "CSR"; K.dist = false;
+    K.halo = [](double*) { return 0; };
+    K.mxv = [dA](const double* x, double* y) { d_mxv(*dA, x, y); };
+    K.resid = [dA](const double* x, const double* bb, double* r) { d_resid(*dA, x, bb, r); };
+    K.mxv_dot = [dA](const double* x, double* y) {
+        CsrArgs a{}; a.x = x; a.y = y; a.dotv = x; a.partials = g_ctx.d_partials;
+        return launch_csr<OP_MXV_DOT>(*dA, a);
+    };
+    if (h) {
+        K.pc = [h](double* in, double** out) { return precond_amg(h, in, out); };  // stays in HBM
+    } else if (pc && pc->fct) {
+        // foreign preconditioner: a host function; the residual is staged through host memory
+        hr.resize((size_t)n); hz.resize((size_t)n);
+        K.pc = [&, pc](double* in, double** out) {
+            HIPCK(hipMemcpyAsync(hr.data(), in, sizeof(double) * n, hipMemcpyDeviceToHost, g_ctx.stream));
+            HIPCK(hipStreamSynchronize(g_ctx.stream));
+            pc->fct(hr.data(), hz.data(), pc->data);
+            HIPCK(hipMemcpyAsync(dz.d, hz.data(), sizeof(double) * n, hipMemcpyHostToDevice, g_ctx.stream));
+            *out = dz.d;
+            return 0;
+        };
+    }
+    K.ws = &ws; K.ws_len = &ws_len; K.hh = &hh;
+    K.stats = nullptr;
+    Hist   H{nullptr, 0, 0};
+    PcgOut po{BIGREAL, BIGREAL, BIGREAL};
+    int st;
+    if (which == 0) {
+        PcgVecs V{db.d, du.d, dp.d, dt.d, dr.d};
+        st = pcg_device(K, V, tol, abstol, MaxIt, StopType, PrtLvl, H, po);
+    } else {
+        st = gmres_device(K, db.d, du.d, which == 2 ? 1 : 0, tol, abstol, MaxIt, restart, StopType, PrtLvl, &H, &po);
+    }
+    du.get(u->val);
+    for (double* q : ws) if (q) (void)hipFree(q);
+    if (hh) (void)hipFree(hh);
+    return st;
+}
+}  // namespace
+
+// KryPcg.c:96
+int fasp_solver_dcsr_pcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                         const int MaxIt, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin(__func__, 0, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+// KryPvgmres.c:66
+int fasp_solver_dcsr_pvgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                             const int MaxIt, const short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin(__func__, 1, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+// KryPvfgmres.c:67
+int fasp_solver_dcsr_pvfgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                              const int MaxIt, const short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin(__func__, 2, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
 
 void fasp_blas_dcsr_mxv(const dCSRmat* A, const double* x, double* y)
 {

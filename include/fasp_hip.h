@@ -363,6 +363,36 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
 int fasp_hip_get_solution(fasp_hip_amg* h, dvector* x);
 int fasp_hip_device_synchronize(void);
 
+/* AMG as a stand-alone solver -- replaces base/src/SolAMG.c:49 (+ PreMGSolve.c:49): setup,
+ * then multigrid cycles until ||b - A x|| / ||b|| < param->tol or param->maxit cycles.
+ * Returns the cycle count or a negative ERROR_* code (a failed setup returns its code; the
+ * reference's CPU GMRES fallback does not exist here). */
+int fasp_solver_amg(dCSRmat* A, dvector* b, dvector* x, AMG_param* param);
+/* the same iteration on a resident hierarchy; param == NULL: the parameters of the setup */
+int fasp_hip_amg_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const AMG_param* param,
+                       double* hist, int hist_cap, fasp_hip_stats* stats);
+
+/* ---- plug-in level (fasp.h:1095-1103): Krylov methods with a caller-supplied preconditioner ---- */
+/* KryPcg.c:96, KryPvgmres.c:66, KryPvfgmres.c:67 -- same arguments, return values and
+ * safeguards; SpMV, BLAS-1 and orthogonalisation run on the device.  pc == NULL: no
+ * preconditioner.  pc->fct == fasp_hip_precond_fct: the whole iteration stays in HBM.
+ * Any other pc->fct is called as a host function on host copies of r and z (one PCIe round
+ * trip per application) -- e.g. a reference preconditioner (ILU, Schwarz) kept on the CPU. */
+int fasp_solver_dcsr_pcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
+                         const double abstol, const int MaxIt, const short StopType, const short PrtLvl);
+int fasp_solver_dcsr_pvgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
+                             const double abstol, const int MaxIt, const short restart,
+                             const short StopType, const short PrtLvl);
+int fasp_solver_dcsr_pvfgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
+                              const double abstol, const int MaxIt, const short restart,
+                              const short StopType, const short PrtLvl);
+/* The AMG preconditioner as a `precond` -- the role of fasp_precond_setup(PREC_AMG, ..)
+ * (PreCSR.c:46) + fasp_precond_amg (PreCSR.c:416).  The returned object can be handed to the
+ * functions above or to the REFERENCE's own CPU Krylov methods (they only call pc->fct). */
+precond* fasp_hip_precond_setup(dCSRmat* A, AMG_param* amgparam);
+void     fasp_hip_precond_fct(double* r, double* z, void* data);
+void     fasp_hip_precond_free(precond* pc);
+
 /* One application of the AMG preconditioner z = B r (PreCSR.c:416) on the
  * resident hierarchy; host vectors in/out. */
 int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z);

@@ -125,6 +125,11 @@ int orc_solver_dcsr_krylov_amg(dCSRmat* A, dvector* b, dvector* x, ITS_param* it
 
 /* Solve with an already built hierarchy (used by bench.py's cpu_baseline leg so
  * the setup is not paid twice). */
+int orc_krylov_dcsr(int which, dCSRmat* A, dvector* b, dvector* x, void (*fct)(double*, double*, void*),
+                    void* data, double tol, double abstol, int MaxIt, int restart, int StopType, int PrtLvl,
+                    double* final_relres);
+int orc_solver_amg(dCSRmat* A, dvector* b, dvector* x, AMG_param* param, double* hist, int hist_cap,
+                   int* nhist, double* final_relres);
 int orc_solve_with_hierarchy(orc_amg* mgl, const dCSRmat* A, const dvector* b, dvector* x,
                              const ITS_param* itparam, const AMG_param* amgparam,
                              double* hist, int hist_cap, int* nhist, double* final_relres);
