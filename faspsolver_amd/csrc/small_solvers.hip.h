@@ -1,0 +1,437 @@
+// small_solvers.hip.h -- coarsest-level solvers as ONE workgroup, ONE launch.
+//
+// The coarsest level of an aggregation hierarchy is tiny (config 5: 89 rows / 5.6 k nonzeros,
+// config 3: 185 block rows), and the reference solves it iteratively to 1e-10 / 1e-6: hundreds
+// of Krylov iterations per cycle, thousands per solve.  Driven from the host, every iteration
+// costs launches plus one synchronisation (30-100 us) for a few microseconds of arithmetic.
+// Here the whole solver -- control flow included -- runs inside one 1024-thread workgroup: every
+// thread evaluates the scalar recurrences redundantly from block reductions that all threads
+// sum in the same fixed order, so branches are uniform without any flag traffic; vectors live
+// in global memory (L1/L2 resident at these sizes) and are made visible between phases by
+// the workgroup barrier.
+//
+//   k_spcg_small   fasp_solver_dcsr_spcg   KrySPcg.c:60   (unpreconditioned safe CG, CSR)
+//   k_gmres_small  fasp_solver_d{csr,bsr}_pvgmres  KryPvgmres.c:66/:416  (no preconditioner,
+//                  STOP_REL_RES, variable restart)
+//
+// Both restate the same branches as the host-driven versions in solver.hip (coarse_spcg,
+// gmres_device); those remain for coarsest levels too large for one CU (e.g. P7(256): 4 971
+// rows, 6.4 M nonzeros).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace fasp {
+
+constexpr int SMALL_BLOCK = 1024;
+constexpr int SMALL_WAVES = SMALL_BLOCK / 64;
+constexpr int SMALL_MAX_RESTART = 32;
+
+// result record written by thread 0
+struct SmallOut {
+    int    status;  // iterations (>= 0) or ERROR_* (< 0)
+    int    iters;   // iterations performed (also when status < 0)
+    double relres, absres;
+};
+
+// Sum (or max, per bit of maxmask) of NQ per-thread values over the workgroup.  Every thread
+// ends with the same result, summed in the same order: wave shuffle tree, then the 16 wave
+// partials left to right.
+template <int NQ>
+__device__ __forceinline__ void blk_reduce(double (&v)[NQ], double* sh, unsigned maxmask = 0u)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double x = v[q];
+        const bool mx = (maxmask >> q) & 1u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double y = __shfl_down(x, o);
+            x = mx ? fmax(x, y) : x + y;
+        }
+        if (lane == 0) sh[w * NQ + q] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const bool mx = (maxmask >> q) & 1u;
+        double x = sh[q];
+        for (int k = 1; k < SMALL_WAVES; ++k) {
+            const double y = sh[k * NQ + q];
+            x = mx ? fmax(x, y) : x + y;
+        }
+        v[q] = x;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double blk_dot(int n, const double* x, const double* y, double* sh)
+{
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += SMALL_BLOCK) v[0] += x[i] * y[i];
+    blk_reduce<1>(v, sh);
+    return v[0];
+}
+
+// ---- operators ---------------------------------------------------------------------------
+// CSR: 16 lanes per row, strided partial sums, xor butterfly (every lane of the group ends with
+// the same sum).  f(row, rowsum) runs on the group's first lane.
+struct SmallCSR {
+    int           m;
+    const int*    ia;
+    const int*    ja;
+    const double* val;
+    __device__ __forceinline__ int rows() const { return m; }
+    template <class F>
+    __device__ __forceinline__ void for_rows(const double* x, F&& f) const
+    {
+        const int sl = threadIdx.x & 15;
+        for (int row = threadIdx.x >> 4; row < m; row += SMALL_BLOCK / 16) {
+            double s = 0.0;
+            for (int k = ia[row] + sl, ke = ia[row + 1]; k < ke; k += 16) s += val[k] * x[ja[k]];
+            s += __shfl_xor(s, 8);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 1);
+            if (sl == 0) f(row, s, 0.0);
+        }
+    }
+};
+
+// BSR: one thread per scalar row (block row br, component r); every block contributes
+// (A_r0 x_0 + A_r1 x_1 + ...), inner sum first, blocks in storage order -- the arithmetic of
+// k_bsr_wstream / fasp_blas_smat_ypAx.  `start` seeds the accumulator (0, or -b for residuals).
+struct SmallBSR {
+    int           ROW, nb;
+    const int*    ia;
+    const int*    ja;
+    const double* val;
+    __device__ __forceinline__ int rows() const { return ROW * nb; }
+    template <class F>
+    __device__ __forceinline__ void for_rows(const double* x, F&& f, const double* seed = nullptr) const
+    {
+        const int nb2 = nb * nb;
+        for (int row = threadIdx.x; row < ROW * nb; row += SMALL_BLOCK) {
+            const int br = row / nb, r = row - br * nb;
+            double acc = seed ? -seed[row] : 0.0;
+            for (int k = ia[br], ke = ia[br + 1]; k < ke; ++k) {
+                const double* A = val + (size_t)k * nb2 + r * nb;
+                const double* xb = x + (size_t)ja[k] * nb;
+                double s = A[0] * xb[0];
+                for (int c = 1; c < nb; ++c) s = s + A[c] * xb[c];
+                acc += s;
+            }
+            f(row, acc, 1.0);
+        }
+    }
+};
+
+// y = A x
+template <class OP>
+__device__ __forceinline__ void small_mxv(const OP& A, const double* x, double* y)
+{
+    A.for_rows(x, [&](int row, double s, double) { y[row] = s; });
+    __syncthreads();
+}
+// r = b - A x with the reference's rounding (CSR: b_i - t_i, BlaSpmvCSR.c:557; BSR: -((-b_i) + t), :548)
+__device__ __forceinline__ void small_resid(const SmallCSR& A, const double* x, const double* b, double* r)
+{
+    A.for_rows(x, [&](int row, double s, double) { r[row] = b[row] - s; });
+    __syncthreads();
+}
+__device__ __forceinline__ void small_resid(const SmallBSR& A, const double* x, const double* b, double* r)
+{
+    A.for_rows(x, [&](int row, double acc, double) { r[row] = -acc; }, b);
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// Safe-net CG, no preconditioner (KrySPcg.c:60-365; z = r throughout)
+// ---------------------------------------------------------------------------
+struct SpcgArgs {
+    SmallCSR      A;
+    const double* b;
+    double *u, *p, *r, *t, *u_best;
+    double   tol;
+    int      MaxIt;
+    int      x_zero;  // the iterate is zero on entry (skips the first matrix pass)
+    SmallOut* out;
+};
+
+__global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_small(SpcgArgs a)
+{
+    __shared__ double sh[SMALL_WAVES * 5];
+    const SmallCSR A = a.A;
+    const int m = A.m, tid = threadIdx.x;
+    const double tol = a.tol, maxdiff = tol * 1e-4 /* STAG_RATIO */, sol_inf_tol = 1e-20;
+    const double BIG = 1e+20, SMALL = 1e-20, SMALL2 = 1e-40;
+    const int MaxIt = a.MaxIt, MAX_STAG = 20, MAX_RESTART = 20;
+    int iter = 0, stag = 1, more_step = 1, iter_best = 0;
+    double absres0 = BIG, absres = BIG, relres = BIG, normu, normr0 = BIG;
+    double reldiff, alpha = 0.0, beta, temp1, temp2, absres_best = BIG;
+    double *u = a.u, *p = a.p, *r = a.r, *t = a.t, *u_best = a.u_best;
+    const double* b = a.b;
+    double red[5];
+
+    for (int i = tid; i < m; i += SMALL_BLOCK) u_best[i] = 0.0;
+    if (a.x_zero) {
+        for (int i = tid; i < m; i += SMALL_BLOCK) { r[i] = b[i]; u[i] = 0.0; }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        small_resid(A, u, b, r);
+    }
+    temp1 = blk_dot(m, r, r, sh);
+    absres0 = sqrt(temp1);
+    normr0 = fmax(SMALL, absres0);
+    relres = absres0 / normr0;
+    if (relres < tol) goto FINISHED;
+    for (int i = tid; i < m; i += SMALL_BLOCK) p[i] = r[i];
+    __syncthreads();
+
+    while (iter++ < MaxIt) {
+        // t = A p and (t, p)
+        {
+            double v[1] = {0.0};
+            A.for_rows(p, [&](int row, double s, double) { t[row] = s; v[0] += s * p[row]; });
+            blk_reduce<1>(v, sh);
+            temp2 = v[0];
+        }
+        if (fabs(temp2) > SMALL2) alpha = temp1 / temp2;
+        else goto RESTORE_BESTSOL;
+        // u += alpha p; r -= alpha t; ||r||^2, ||u||^2, ||p||^2, max|u|, #NaN(u)
+        red[0] = red[1] = red[2] = red[3] = red[4] = 0.0;
+        for (int i = tid; i < m; i += SMALL_BLOCK) {
+            const double pi = p[i];
+            const double ui = u[i] + alpha * pi;
+            const double ri = r[i] - alpha * t[i];
+            u[i] = ui; r[i] = ri;
+            red[0] += ri * ri; red[1] += ui * ui; red[2] += pi * pi;
+            red[3] = fmax(red[3], fabs(ui));
+            red[4] += (ui != ui) ? 1.0 : 0.0;
+        }
+        blk_reduce<5>(red, sh, 1u << 3);
+        absres = sqrt(red[0]);
+        relres = absres / normr0;
+        if (red[4] > 0.0) {  // fasp_dvec_isnan(u), :185
+            absres = BIG;
+            goto RESTORE_BESTSOL;
+        }
+        if (absres < absres_best - maxdiff) {
+            absres_best = absres;
+            iter_best = iter;
+            for (int i = tid; i < m; i += SMALL_BLOCK) u_best[i] = u[i];
+        }
+        if (red[3] <= sol_inf_tol) {  // Check I
+            iter = -43;               // ERROR_SOLVER_SOLSTAG
+            break;
+        }
+        normu = sqrt(red[1]);
+        reldiff = fabs(alpha) * sqrt(red[2]) / normu;
+        if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {  // Check II
+            __syncthreads();
+            small_resid(A, u, b, r);
+            red[0] = blk_dot(m, r, r, sh);
+            absres = sqrt(red[0]);
+            relres = absres / normr0;
+            if (relres < tol) break;
+            if (stag >= MAX_STAG) { iter = -42; break; }  // ERROR_SOLVER_STAG
+            for (int i = tid; i < m; i += SMALL_BLOCK) p[i] = 0.0;
+            ++stag;
+        }
+        if (relres < tol) {  // Check III: true residual
+            __syncthreads();
+            small_resid(A, u, b, r);
+            red[0] = blk_dot(m, r, r, sh);
+            absres = sqrt(red[0]);
+            relres = absres / normr0;
+            if (relres < tol) break;
+            if (more_step >= MAX_RESTART) { iter = -44; break; }  // ERROR_SOLVER_TOLSMALL
+            for (int i = tid; i < m; i += SMALL_BLOCK) p[i] = 0.0;
+            ++more_step;
+        }
+        absres0 = absres;
+        temp2 = red[0];  // (z, r) with z = r
+        beta = temp2 / temp1;
+        temp1 = temp2;
+        for (int i = tid; i < m; i += SMALL_BLOCK) p[i] = 1.0 * r[i] + beta * p[i];  // fasp_blas_darray_axpby
+        __syncthreads();
+    }
+
+RESTORE_BESTSOL:
+    __syncthreads();
+    if (iter != iter_best) {
+        small_resid(A, u_best, b, r);
+        absres_best = sqrt(blk_dot(m, r, r, sh));
+        if (absres > absres_best + maxdiff || absres != absres) {
+            for (int i = tid; i < m; i += SMALL_BLOCK) u[i] = u_best[i];
+            relres = absres_best / normr0;
+        }
+    }
+FINISHED:
+    if (tid == 0) {
+        a.out->iters = iter > 0 ? (iter > MaxIt ? MaxIt : iter) : 0;
+        a.out->status = iter > MaxIt ? -48 : iter;  // ERROR_SOLVER_MAXIT
+        a.out->relres = relres;
+        a.out->absres = absres;
+    }
+    (void)absres0;
+}
+
+// ---------------------------------------------------------------------------
+// Variable-restart GMRES without preconditioner, STOP_REL_RES (KryPvgmres.c:66 / :416)
+// ---------------------------------------------------------------------------
+template <class OP>
+struct GmresArgs {
+    OP            A;
+    const double* b;
+    double*       x;
+    double*       ws;  // (restart + 2) vectors of length n: p[0..restart], w
+    double        tol, abstol;
+    int           MaxIt, restart;
+    SmallOut*     out;
+};
+
+template <class OP>
+__global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
+{
+    constexpr int R = SMALL_MAX_RESTART;
+    __shared__ double sh[SMALL_WAVES];
+    __shared__ double hh[(R + 1) * R];  // hh[j][k] -> hh[j * R + k]
+    __shared__ double rs[R + 2], c[R + 1], sn[R + 1];
+    __shared__ double sc_rnorm;         // |rs[i]| published by thread 0
+    const OP A = a.A;
+    const int n = A.rows(), tid = threadIdx.x;
+    const double tol = a.tol, abstol = a.abstol, epsmac = 1e-20, cr_max = 0.99, cr_min = 0.174;
+    const int MaxIt = a.MaxIt, restart_max = a.restart, restart_min = 3, d = 3;
+    int iter = 0, i = 0, Restart = a.restart;
+    double r_norm, r_norm_old = 0.0, absres0, absres = 1e+20, relres, cr = 1.0, t;
+    const double* b = a.b;
+    double* x = a.x;
+    auto P = [&](int k) { return a.ws + (size_t)k * n; };
+    double* w = a.ws + (size_t)(a.restart + 1) * n;
+
+    small_resid(A, x, b, P(0));
+    r_norm = sqrt(blk_dot(n, P(0), P(0), sh));
+    absres0 = fmax(1e-20, r_norm);
+    relres = r_norm / absres0;
+    if (relres < tol || absres0 < abstol) goto FINISHED;
+
+    while (iter < MaxIt) {
+        r_norm_old = r_norm;
+        if (tid == 0) rs[0] = r_norm;
+        {
+            const double s = 1.0 / r_norm;
+            double* p0 = P(0);
+            for (int e = tid; e < n; e += SMALL_BLOCK) p0[e] *= s;
+        }
+        if (cr > cr_max || iter == 0) Restart = restart_max;
+        else if (cr < cr_min) { /* keep */ }
+        else { if (Restart - d > restart_min) Restart -= d; else Restart = restart_max; }
+        __syncthreads();
+
+        i = 0;
+        while (i < Restart && iter < MaxIt) {
+            i++; iter++;
+            double* pi = P(i);
+            small_mxv(A, P(i - 1), pi);
+            // modified Gram-Schmidt: a thread updates only its own elements between the dots
+            for (int j = 0; j < i; ++j) {
+                const double* pj = P(j);
+                const double h = blk_dot(n, pj, pi, sh);
+                if (tid == 0) hh[j * R + (i - 1)] = h;
+                for (int e = tid; e < n; e += SMALL_BLOCK) pi[e] += -h * pj[e];
+            }
+            t = sqrt(blk_dot(n, pi, pi, sh));
+            if (t != 0.0) {
+                const double s = 1.0 / t;
+                for (int e = tid; e < n; e += SMALL_BLOCK) pi[e] *= s;
+            }
+            if (tid == 0) {  // Givens rotations on the new Hessenberg column
+                hh[i * R + (i - 1)] = t;
+                for (int j = 1; j < i; ++j) {
+                    const double tt = hh[(j - 1) * R + (i - 1)];
+                    hh[(j - 1) * R + (i - 1)] = sn[j - 1] * hh[j * R + (i - 1)] + c[j - 1] * tt;
+                    hh[j * R + (i - 1)] = -sn[j - 1] * tt + c[j - 1] * hh[j * R + (i - 1)];
+                }
+                double g = hh[i * R + (i - 1)] * hh[i * R + (i - 1)];
+                g += hh[(i - 1) * R + (i - 1)] * hh[(i - 1) * R + (i - 1)];
+                double gamma = sqrt(g);
+                if (gamma == 0.0) gamma = epsmac;
+                c[i - 1] = hh[(i - 1) * R + (i - 1)] / gamma;
+                sn[i - 1] = hh[i * R + (i - 1)] / gamma;
+                rs[i] = -sn[i - 1] * rs[i - 1];
+                rs[i - 1] = c[i - 1] * rs[i - 1];
+                hh[(i - 1) * R + (i - 1)] = sn[i - 1] * hh[i * R + (i - 1)] + c[i - 1] * hh[(i - 1) * R + (i - 1)];
+                sc_rnorm = fabs(rs[i]);
+            }
+            __syncthreads();
+            absres = r_norm = sc_rnorm;
+            relres = absres / absres0;
+            if (relres < tol) break;
+        }
+
+        if (tid == 0) {  // back substitution
+            rs[i - 1] = rs[i - 1] / hh[(i - 1) * R + (i - 1)];
+            for (int k = i - 2; k >= 0; k--) {
+                double tt = 0.0;
+                for (int j = k + 1; j < i; j++) tt -= hh[k * R + j] * rs[j];
+                tt += rs[k];
+                rs[k] = tt / hh[k * R + k];
+            }
+        }
+        __syncthreads();
+        // w = rs[i-1] p[i-1] + rs[i-2] p[i-2] + ... + rs[0] p[0];  x += w
+        for (int e = tid; e < n; e += SMALL_BLOCK) {
+            double we = P(i - 1)[e] * rs[i - 1];
+            for (int j = i - 2; j >= 0; j--) we += rs[j] * P(j)[e];
+            w[e] = we;
+            x[e] += we;
+        }
+        __syncthreads();
+
+        if (relres < tol) {  // check the true residual
+            small_resid(A, x, b, w);
+            r_norm = sqrt(blk_dot(n, w, w, sh));
+            absres = r_norm;
+            relres = absres / absres0;
+            if (relres < tol) break;
+            for (int e = tid; e < n; e += SMALL_BLOCK) P(0)[e] = w[e];
+            i = 0;
+        }
+
+        // residual vector of the restart (KryPvgmres.c:390-401)
+        if (tid == 0)
+            for (int j = i; j > 0; j--) {
+                rs[j - 1] = -sn[j - 1] * rs[j];
+                rs[j] = c[j - 1] * rs[j];
+            }
+        __syncthreads();
+        if (i) {
+            double* pi = P(i);
+            double* p0 = P(0);
+            for (int e = tid; e < n; e += SMALL_BLOCK) {
+                double v = pi[e];
+                v = v + (rs[i] - 1.0) * v;
+                for (int j = i - 1; j > 0; j--) v += rs[j] * P(j)[e];
+                pi[e] = v;
+                double q = p0[e];
+                q = q + (rs[0] - 1.0) * q;
+                p0[e] = q + v;
+            }
+        }
+        __syncthreads();
+        cr = r_norm / r_norm_old;
+    }
+
+FINISHED:
+    if (tid == 0) {
+        a.out->iters = iter;
+        a.out->status = iter >= MaxIt ? -48 : iter;
+        a.out->relres = relres;
+        a.out->absres = absres;
+    }
+}
+
+}  // namespace fasp

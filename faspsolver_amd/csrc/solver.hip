@@ -29,6 +29,7 @@
 #include "fasp_comm.h"
 #include "fasp_internal.h"
 #include "kernels.hip.h"
+#include "small_solvers.hip.h"
 
 namespace fasp {
 
@@ -668,12 +669,44 @@ static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order
 // PreMGUtil.inl:47 with StopType = STOP_REL_RES, maxit = MAX(250, MIN(n*n, 1000))).
 // One host synchronisation per iteration: alpha is formed on the device.
 // ---------------------------------------------------------------------------
+// Coarsest levels that fit one CU's caches are solved by the single-workgroup kernels of
+// small_solvers.hip.h (one launch, one synchronisation per solve instead of per iteration).
+static bool small_coarse_ok(long long rows, long long stored_values)
+{
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = std::getenv("FASP_HIP_SMALL_COARSE");
+        enabled = (e && std::atoi(e) == 0) ? 0 : 1;
+    }
+    return enabled && rows <= 4096 && stored_values <= 131072;
+}
+static SmallOut* small_out_dev() { return reinterpret_cast<SmallOut*>(g_ctx.d_partials2); }
+static int small_out_fetch(SmallOut& o)
+{
+    HIPCK(hipMemcpyAsync(g_ctx.h_part, g_ctx.d_partials2, sizeof(SmallOut), hipMemcpyDeviceToHost, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    std::memcpy(&o, g_ctx.h_part, sizeof(SmallOut));
+    return 0;
+}
+
 static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
 {
     const DevCSR& A = D.A;
     const int m = A.row;
     const int nn = (int)((unsigned)m * (unsigned)m);
     const int MaxIt = std::max(250, std::min(nn, 1000));
+    if (small_coarse_ok(m, A.nnz)) {
+        SpcgArgs a{};
+        a.A = SmallCSR{m, A.ia, A.ja, A.val};
+        a.b = D.b; a.u = D.x; a.p = h->cp; a.r = h->cr; a.t = h->ct; a.u_best = h->cbest;
+        a.tol = tol; a.MaxIt = MaxIt; a.x_zero = D.x_zero ? 1 : 0; a.out = small_out_dev();
+        hipLaunchKernelGGL(k_spcg_small, dim3(1), dim3(SMALL_BLOCK), 0, g_ctx.stream, a);
+        D.x_zero = false;
+        SmallOut o;
+        if (small_out_fetch(o) < 0) return ERROR_MISC;
+        h->coarse_iters += o.iters;
+        return o.status;
+    }
     const double maxdiff = tol * STAG_RATIO, sol_inf_tol = SMALLREAL;
     int iter = 0, stag = 1, more_step = 1, iter_best = 0;
     double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL, normr0 = BIGREAL;
@@ -1596,6 +1629,7 @@ struct fasp_hip_amg_bsr {
     std::vector<double*> gm[2];
     size_t               gm_len[2] = {0, 0};
     double*              gm_hh = nullptr;
+    double*              small_ws = nullptr;  // workspace of the single-workgroup coarse GMRES
     long long            coarse_iters = 0, vcycles = 0;
 };
 
@@ -1659,12 +1693,27 @@ ForwardSweep:
         const int csize = Lc.n;
         const int cmaxit = (int)std::min<unsigned>((unsigned)csize * (unsigned)csize, 200u);
         const double ctol = param.tol, atol = ctol * 1e-8;
-        KOps K = bsr_ops(h, nl - 1, 1);
-        PcgOut po{BIGREAL, BIGREAL, BIGREAL};
-        const int st = gmres_device(K, Lc.b, Lc.x, 0, ctol, atol, cmaxit, 25, STOP_REL_RES, 0, nullptr, &po);
-        if (st >= 0) h->coarse_iters += st;
-        else if (st != ERROR_SOLVER_MAXIT && st != ERROR_SOLVER_STAG && st != ERROR_SOLVER_SOLSTAG &&
-                 st != ERROR_SOLVER_TOLSMALL) return st;  // device failure, not a convergence verdict
+        int st;
+        const TmpBSR& Ac = *Lc.A;
+        if (small_coarse_ok(csize, (long long)Ac.NNZ * Ac.nb * Ac.nb)) {
+            if (!h->small_ws) HIPCK(hipMalloc(&h->small_ws, sizeof(double) * (size_t)(25 + 2) * std::max(csize, 1)));
+            GmresArgs<SmallBSR> a{};
+            a.A = SmallBSR{Ac.ROW, Ac.nb, Ac.ia, Ac.ja, Ac.val};
+            a.b = Lc.b; a.x = Lc.x; a.ws = h->small_ws; a.tol = ctol; a.abstol = atol;
+            a.MaxIt = cmaxit; a.restart = 25; a.out = small_out_dev();
+            hipLaunchKernelGGL(k_gmres_small<SmallBSR>, dim3(1), dim3(SMALL_BLOCK), 0, s, a);
+            SmallOut o;
+            if (small_out_fetch(o) < 0) return ERROR_MISC;
+            st = o.status;
+            h->coarse_iters += o.iters;
+        } else {
+            KOps K = bsr_ops(h, nl - 1, 1);
+            PcgOut po{BIGREAL, BIGREAL, BIGREAL};
+            st = gmres_device(K, Lc.b, Lc.x, 0, ctol, atol, cmaxit, 25, STOP_REL_RES, 0, nullptr, &po);
+            if (st >= 0) h->coarse_iters += st;
+        }
+        if (st < 0 && st != ERROR_SOLVER_MAXIT && st != ERROR_SOLVER_STAG && st != ERROR_SOLVER_SOLSTAG &&
+            st != ERROR_SOLVER_TOLSMALL) return st;  // device failure, not a convergence verdict
         if (st < 0 && param.print_level > PRINT_MIN) {
             std::printf("### WARNING: Coarse level solver did not converge!\n");
             std::printf("### WARNING: Consider to increase maxit to %d!\n", 2 * cmaxit);
@@ -2085,6 +2134,7 @@ void fasp_hip_bsr_amg_destroy(fasp_hip_amg_bsr* h)
     for (int s = 0; s < 2; ++s)
         for (double* q : h->gm[s]) if (q) (void)hipFree(q);
     if (h->gm_hh) (void)hipFree(h->gm_hh);
+    if (h->small_ws) (void)hipFree(h->small_ws);
     delete h;
 }
 
