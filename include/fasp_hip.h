@@ -286,7 +286,7 @@ double fasp_hip_time_bsr_mxv(const dBSRmat* A, int reps);
  * Unsmoothed aggregation (PreAMGSetupUABSR.c:55, VMB on the condensed matrix, identity-block
  * prolongation, block Galerkin product) on the host, block-Jacobi V/W cycle
  * (PreMGCycle.c:287) with GMRES(25) on the coarsest level and PCG / VGMRES / VFGMRES
- * (KryPcg.c:386, KryPvgmres.c:416, KryPvfgmres.c:410) on the device.  Returns the iteration
+ * (KryPcg.c:386, KryPvgmres.c:416, KryPvfgmres.c:386) on the device.  Returns the iteration
  * count or a negative ERROR_* code; unsupported parameters are refused, never run on the CPU. */
 int fasp_solver_dbsr_krylov_amg(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam,
                                 AMG_param* amgparam);
