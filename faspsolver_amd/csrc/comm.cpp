@@ -349,6 +349,46 @@ int fasp_hip_comm_finalize(void)
     return FASP_SUCCESS;
 }
 
+// One-rank exercise of every RCCL entry point the transport uses (symbol loading, unique id,
+// communicator, grouped all-reduce with mixed ops, broadcast, send/recv to self): what can be
+// checked of the production transport on a box with a single GPU.
+int fasp_hip_comm_selftest(void)
+{
+    if (load_rccl() < 0) return ERROR_MISC;
+    ncclUniqueId id;
+    NCK(g_rccl.GetUniqueId(&id));
+    ncclComm_t c = nullptr;
+    NCK(g_rccl.CommInitRank(&c, 1, id, 0));
+    hipStream_t s = nullptr;
+    HCK(hipStreamCreate(&s));
+    double h[8] = {1.5, -2.0, 3.25, 7.0, 0.5, 6.0, 0.0, 0.0}, out[8] = {0};
+    double* d = nullptr;
+    HCK(hipMalloc((void**)&d, sizeof(double) * 16));
+    HCK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
+    NCK(g_rccl.GroupStart());
+    NCK(g_rccl.AllReduce(d, d, 3, ncclDouble, ncclSum, c, s));
+    NCK(g_rccl.AllReduce(d + 3, d + 3, 1, ncclDouble, ncclMax, c, s));
+    NCK(g_rccl.GroupEnd());
+    NCK(g_rccl.GroupStart());
+    NCK(g_rccl.Broadcast(d + 4, d + 8, 2, ncclDouble, 0, c, s));
+    NCK(g_rccl.GroupEnd());
+    NCK(g_rccl.GroupStart());
+    NCK(g_rccl.Recv(d + 10, 2, ncclDouble, 0, c, s));
+    NCK(g_rccl.Send(d + 4, 2, ncclDouble, 0, c, s));
+    NCK(g_rccl.GroupEnd());
+    HCK(hipStreamSynchronize(s));
+    double all[16];
+    HCK(hipMemcpy(all, d, sizeof(all), hipMemcpyDeviceToHost));
+    (void)out;
+    int bad = 0;
+    for (int i = 0; i < 4; ++i) bad += all[i] != h[i];
+    bad += all[8] != 0.5 || all[9] != 6.0 || all[10] != 0.5 || all[11] != 6.0;
+    NCK(g_rccl.CommDestroy(c));
+    (void)hipStreamDestroy(s);
+    (void)hipFree(d);
+    return bad ? ERROR_MISC : FASP_SUCCESS;
+}
+
 int fasp_hip_comm_rank(void) { return g_rank; }
 int fasp_hip_comm_size(void) { return g_size; }
 

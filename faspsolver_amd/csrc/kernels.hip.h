@@ -55,6 +55,20 @@ struct CsrArgs {
     int           tiles_per_xcd;
     int           xcd_map;  // G > 0: an XCD works on runs of G consecutive tiles; 0: plain grid-stride
     int           nt;       // 1: non-temporal loads of JA / val
+    // dictionary-coded matrices (k_csr_dict8): one byte per entry selects (column offset, value)
+    const unsigned char* code;
+    const int*    rowbase;  // column base of each row (nullptr: the row index itself)
+    const int*    doff;     // 256 column offsets
+    const double* dval;     // 256 values
+    // row-pattern-coded matrices (k_csr_rowpat): two bytes per ROW select its whole entry list
+    const unsigned short* pat;  // pattern id of every row
+    const int*    pstart;   // start of every pattern in poff / pval (lists padded to multiples of 8 entries)
+    const int*    plen;     // true length of every pattern
+    const int*    poff;     // column offsets (relative to the row base) of every pattern, in storage order
+    const double* pval;     // values (padding: offset 0, value 0)
+    int           npat, npent;
+    int           ncol;     // length of x (buffer-load range check)
+    int           dbg;      // development: > 0 limits the gathers per 8-entry group (timing experiments only)
 };
 
 __device__ __forceinline__ int ld_ja(const CsrArgs& a, int k)
@@ -71,12 +85,18 @@ __device__ __forceinline__ double ld_val(const CsrArgs& a, int k)
 // entries, then hit the same XCD-private L2.  xcd_map = G (0: identity, plain grid-stride).
 __device__ __forceinline__ int tile_vmax(const CsrArgs& a)
 {
+    if (a.xcd_map < 0) return 8 * a.tiles_per_xcd;  // slab mode
     if (a.xcd_map <= 0) return a.ntiles;
     const int span = 8 * a.xcd_map;
     return (a.ntiles + span - 1) / span * span;
 }
 __device__ __forceinline__ int tile_of(const CsrArgs& a, int v)
 {
+    // xcd_map < 0: every XCD sweeps ONE contiguous eighth of the rows in order (its blocks take
+    // consecutive tiles), so an x entry gathered by rows far apart in index but close in the
+    // sweep (the +-nx*ny neighbours of a 3-D stencil) is fetched once per XCD and then hit in
+    // that XCD's L2.  Pays when x dominates the traffic (compressed matrices).
+    if (a.xcd_map < 0) return (v & 7) * a.tiles_per_xcd + (v >> 3);
     if (a.xcd_map <= 0) return v;
     const int G = a.xcd_map;
     const int xcd = v & 7, q = v >> 3;
@@ -90,6 +110,14 @@ __device__ __forceinline__ double subwave_sum(double v)
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1) v += __shfl_down(v, off, W);
     return v;
+}
+
+// orders a wavefront's own LDS writes before its later LDS reads (no workgroup barrier)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // Deterministic block reduction: wave shuffle tree, then the 4 wave results are added
@@ -364,18 +392,288 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(CsrArgs a, int R)
 }
 
 // ---------------------------------------------------------------------------
+// Dictionary-coded CSR ("value indexing" + "delta units", Kourtis / Goumas / Koziris 2008):
+// when a matrix holds at most 256 distinct (column - row base, value) pairs -- every level of
+// a stencil problem that the coarsening keeps regular: P7(n) level 0 has 14 pairs, level 1 has
+// 138 -- an entry is stored as ONE byte instead of 12 (int32 column + f64 value).  The
+// dictionary holds the exact doubles, so this is lossless: row sums are formed left to right
+// from the same values as the plain kernels and are bit-identical to them.  One lane per row:
+// the k-th entries of 64 consecutive rows of a stencil matrix gather 64 consecutive x entries
+// (coalesced), the dictionary sits in LDS (mostly broadcast reads).  Traffic per row drops from
+// 12 nnz/row + 4 + 16 to nnz/row + 4 + 16 bytes.
+// ---------------------------------------------------------------------------
+//
+// Row-pattern coding goes one step further (k_csr_rowpat below): when whole ROWS repeat -- the
+// (offset, value) list of a row is one of at most 65 536 distinct lists, as for every interior
+// / face / edge / corner row of a stencil (P7(n): 27 lists on level 0, 102 on level 1) -- a
+// row is stored as ONE 16-bit pattern id; no row pointer, no per-entry code at all: 2 bytes of
+// matrix per row instead of 12 nnz/row + 4.
+//
+// Schedule: a wavefront owns 64 consecutive rows per step.  Its code bytes form one contiguous
+// span, fetched with 16-byte loads into registers ONE STEP AHEAD (together with the row
+// pointers of the step after that), parked in the wave's LDS slab, and read back per entry;
+// so the only memory latency exposed per step is that of the x gathers (U in flight per lane).
+// No workgroup barrier inside the loop.
+template <int OP, int U>
+__global__ __launch_bounds__(BLOCK) void k_csr_dict8(CsrArgs a)
+{
+    constexpr int CAP = 2048;  // code bytes staged per wave and step
+    __shared__ double s_val[256];
+    __shared__ int    s_off[256];
+    __shared__ uint4  s_code[4][CAP / 16];
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s_val[threadIdx.x] = a.dval[threadIdx.x];
+    s_off[threadIdx.x] = a.doff[threadIdx.x];
+    __syncthreads();
+    uint4* slab = s_code[wave];
+    const unsigned char* lds = reinterpret_cast<const unsigned char*>(slab);
+    const int vmax = tile_vmax(a);
+    const int G = gridDim.x;
+    double dotacc = 0.0;
+
+    // next step of this wave: first row r0 (-1: none) and row count, wave-uniform
+    auto advance = [&](int& v, int& r0, int& nr) {
+        for (;;) {
+            r0 = -1; nr = 0;
+            if (v >= vmax) return;
+            const int t = tile_of(a, v);
+            v += G;
+            if (t >= a.ntiles) continue;
+            const int rr = t * BLOCK + wave * 64;
+            if (rr >= a.nrow) continue;
+            r0 = rr; nr = min(64, a.nrow - rr);
+            return;
+        }
+    };
+    auto stage = [&](int k0, int k1, int& s0, uint4& q0, uint4& q1) {
+        s0 = k0 & ~15;
+        if (k1 - s0 > CAP) return;  // oversized span: entries are read from global memory instead
+        const uint4* src = reinterpret_cast<const uint4*>(a.code + s0);
+        const int nseg = (k1 - s0 + 15) >> 4;
+        if (lane < nseg) q0 = src[lane];
+        if (lane + 64 < nseg) q1 = src[lane + 64];
+    };
+
+    int v = blockIdx.x;
+    int r0A, nrA, r0B, nrB, kbA = 0, keA = 0, kbB = 0, keB = 0;
+    advance(v, r0A, nrA);
+    if (r0A >= 0 && lane < nrA) { kbA = a.ia[r0A + lane]; keA = a.ia[r0A + lane + 1]; }
+    advance(v, r0B, nrB);
+    if (r0B >= 0 && lane < nrB) { kbB = a.ia[r0B + lane]; keB = a.ia[r0B + lane + 1]; }
+    int k0A = 0, k1A = 0, s0A = 0;
+    uint4 qA0 = make_uint4(0, 0, 0, 0), qA1 = make_uint4(0, 0, 0, 0);
+    if (r0A >= 0) {
+        k0A = __shfl(kbA, 0); k1A = __shfl(keA, nrA - 1);
+        stage(k0A, k1A, s0A, qA0, qA1);
+    }
+
+    while (r0A >= 0) {
+        const bool staged = (k1A - s0A) <= CAP;
+        if (staged) { slab[lane] = qA0; slab[lane + 64] = qA1; }
+        wave_lds_sync();
+        // look ahead: row pointers of step C, code span of step B
+        int r0C, nrC, kbC = 0, keC = 0;
+        advance(v, r0C, nrC);
+        if (r0C >= 0 && lane < nrC) { kbC = a.ia[r0C + lane]; keC = a.ia[r0C + lane + 1]; }
+        int k0B = 0, k1B = 0, s0B = 0;
+        uint4 qB0 = make_uint4(0, 0, 0, 0), qB1 = make_uint4(0, 0, 0, 0);
+        if (r0B >= 0) {
+            k0B = __shfl(kbB, 0); k1B = __shfl(keB, nrB - 1);
+            stage(k0B, k1B, s0B, qB0, qB1);
+        }
+
+        if (lane < nrA) {
+            const int r = r0A + lane;
+            const int base = a.rowbase ? a.rowbase[r] : r;
+            double acc = (OP == OP_JACOBI || OP == OP_L1DIAG) ? a.b[r] : 0.0;
+            for (int k = kbA; k < keA; k += U) {
+                unsigned c[U];
+                double   xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    c[u] = (k + u < keA) ? (staged ? (unsigned)lds[k + u - s0A] : (unsigned)a.code[k + u]) : 0u;
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = (k + u < keA) ? a.x[base + s_off[c[u]]] : 0.0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (k + u < keA) {
+                        const double pr = s_val[c[u]] * xv[u];
+                        if (OP == OP_JACOBI) { if (base + s_off[c[u]] != r) acc -= pr; }
+                        else if (OP == OP_L1DIAG) acc -= pr;
+                        else acc += pr;
+                    }
+                }
+            }
+            const double s = acc;
+            if (OP == OP_MXV) a.y[r] = s;
+            else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
+            else if (OP == OP_ADD) a.y[r] += s;
+            else if (OP == OP_SUB) a.y[r] -= s;
+            else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
+            else if (OP == OP_JACOBI) {
+                const double d = a.diag[r], xi = a.x[r];
+                a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * s / d : xi;
+            } else if (OP == OP_L1DIAG) {
+                const double d = a.diag[r], xi = a.x[r];
+                a.y[r] = (fabs(d) > 1e-20) ? xi + s / d : xi;
+            } else if (OP == OP_MXV_DOT) {
+                a.y[r] = s;
+                dotacc += s * a.dotv[r];
+            }
+        }
+        wave_lds_sync();
+        r0A = r0B; nrA = nrB; kbA = kbB; keA = keB; k0A = k0B; k1A = k1B; s0A = s0B; qA0 = qB0; qA1 = qB1;
+        r0B = r0C; nrB = nrC; kbB = kbC; keB = keC;
+    }
+    if (OP == OP_MXV_DOT) {
+        const double tot = block_sum(dotacc, red);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    }
+}
+
+// Row-pattern-coded CSR: lane = row; the pattern table (entry lists of all distinct rows) sits
+// in LDS when it is small (LDS_TAB), otherwise in global memory (L1/L2 resident); interior
+// rows share one pattern, so table reads are broadcasts and the k-th gathers of 64 consecutive
+// rows are coalesced.  The pattern id of the next step is fetched one step ahead.  Row sums
+// are formed left to right from the exact stored values: bit-identical to the plain kernels.
+// The loop body is branch-free: pattern lists are padded to multiples of 8 entries (offset 0,
+// value 0), x is gathered with buffer loads (32-bit offsets, hardware range check), padding
+// entries are dropped by a select on the accumulate, rows beyond the matrix are clamped and
+// only their store is predicated.  RPL rows per lane and step (rows r, r + 256, ...).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, unsigned byte_off)
+{
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(double, v);
+}
+
+template <int OP, bool LDS_TAB, int RPL>
+__global__ __launch_bounds__(BLOCK) void k_csr_rowpat(CsrArgs a)
+{
+    constexpr int U = 8;
+    constexpr int MAXP = 512, MAXE = 2048;
+    __shared__ int    s_start[LDS_TAB ? MAXP : 1];
+    __shared__ int    s_len[LDS_TAB ? MAXP : 1];
+    __shared__ int    s_off[LDS_TAB ? MAXE : 1];
+    __shared__ double s_val[LDS_TAB ? MAXE : 1];
+    __shared__ double red[4];
+    if (LDS_TAB) {
+        for (int i = threadIdx.x; i < a.npat; i += BLOCK) { s_start[i] = a.pstart[i]; s_len[i] = a.plen[i]; }
+        for (int i = threadIdx.x; i < a.npent; i += BLOCK) { s_off[i] = a.poff[i]; s_val[i] = a.pval[i]; }
+        __syncthreads();
+    }
+    const int*    pstart = LDS_TAB ? s_start : a.pstart;
+    const int*    plen   = LDS_TAB ? s_len : a.plen;
+    const int*    poff   = LDS_TAB ? s_off : a.poff;
+    const double* pval   = LDS_TAB ? s_val : a.pval;
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.x), 0, (int)((unsigned)a.ncol * 8u), 0x00020000);
+    const int vmax = tile_vmax(a);  // tiles of BLOCK * RPL rows
+    const int G = gridDim.x;
+    const int last = a.nrow - 1;
+    double dotacc = 0.0;
+
+    auto advance = [&](int& v) -> int {  // first row of the next tile of this block, -1: none
+        for (;;) {
+            if (v >= vmax) return -1;
+            const int t = tile_of(a, v);
+            v += G;
+            if (t < a.ntiles) return t * (BLOCK * RPL);
+        }
+    };
+    int      v = blockIdx.x;
+    int      rA[RPL], cbA[RPL];
+    unsigned pidA[RPL];
+    int      r0A = advance(v);
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+        rA[q] = max(r0A, 0) + q * BLOCK + (int)threadIdx.x;
+        const int rc = min(rA[q], last);
+        pidA[q] = a.pat[rc];
+        cbA[q] = a.rowbase ? a.rowbase[rc] : rc;
+    }
+    while (r0A >= 0) {
+        const int r0B = advance(v);
+        int      rB[RPL], cbB[RPL];
+        unsigned pidB[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            rB[q] = max(r0B, 0) + q * BLOCK + (int)threadIdx.x;
+            const int rc = min(rB[q], last);
+            pidB[q] = a.pat[rc];
+            cbB[q] = a.rowbase ? a.rowbase[rc] : rc;
+        }
+        int    ps[RPL], len[RPL], self[RPL];
+        double acc[RPL], dg[RPL], xi[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            const int rc = min(rA[q], last);
+            ps[q] = pstart[pidA[q]]; len[q] = plen[pidA[q]];
+            self[q] = rc - cbA[q];
+            acc[q] = dg[q] = xi[q] = 0.0;
+            if (OP == OP_JACOBI || OP == OP_L1DIAG) { acc[q] = a.b[rc]; dg[q] = a.diag[rc]; xi[q] = a.x[rc]; }
+        }
+        int kmax = len[0];
+#pragma unroll
+        for (int q = 1; q < RPL; ++q) kmax = max(kmax, len[q]);
+        for (int k = 0; k < kmax; k += U) {
+            int    off[RPL][U];
+            double xv[RPL][U];
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                for (int u = 0; u < U; ++u) off[q][u] = (k < len[q]) ? poff[ps[q] + k + u] : 0;
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    xv[q][u] = (a.dbg > 0 && u >= a.dbg) ? 1.0 : buf_load_f64(xr, (unsigned)(cbA[q] + off[q][u]) * 8u);
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double pr = ((k < len[q]) ? pval[ps[q] + k + u] : 0.0) * xv[q][u];
+                    bool use = k + u < len[q];
+                    if (OP == OP_JACOBI) use = use && off[q][u] != self[q];
+                    const double nxt = (OP == OP_JACOBI || OP == OP_L1DIAG) ? acc[q] - pr : acc[q] + pr;
+                    acc[q] = use ? nxt : acc[q];
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            if (rA[q] > last) continue;
+            const int    r = rA[q];
+            const double s = acc[q];
+            if (OP == OP_MXV) a.y[r] = s;
+            else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
+            else if (OP == OP_ADD) a.y[r] += s;
+            else if (OP == OP_SUB) a.y[r] -= s;
+            else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
+            else if (OP == OP_JACOBI) a.y[r] = (fabs(dg[q]) > 1e-20) ? (1 - a.omega) * xi[q] + a.omega * s / dg[q] : xi[q];
+            else if (OP == OP_L1DIAG) a.y[r] = (fabs(dg[q]) > 1e-20) ? xi[q] + s / dg[q] : xi[q];
+            else if (OP == OP_MXV_DOT) {
+                a.y[r] = s;
+                dotacc += s * a.dotv[r];
+            }
+        }
+        r0A = r0B;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) { rA[q] = rB[q]; pidA[q] = pidB[q]; cbA[q] = cbB[q]; }
+    }
+    if (OP == OP_MXV_DOT) {
+        const double tot = block_sum(dotacc, red);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Wavefront-level stream kernel: the same two phases as k_csr_stream, but every
 // wavefront owns its own tile of RW consecutive rows and its own LDS slab, so there is
 // no workgroup barrier anywhere: a wave's LDS traffic is ordered by the hardware, the
 // four waves of a block run fully decoupled and each keeps 8 (JA, val) pairs + 8 x
 // gathers in flight per lane.  Row sums are again the reference's left-to-right sums.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 template <int OP, int RW, int CAPW>
 __global__ __launch_bounds__(BLOCK) void k_csr_wstream(CsrArgs a)

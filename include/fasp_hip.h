@@ -439,6 +439,8 @@ int fasp_hip_dist_plan(fasp_hip_amg* h, int rank, int nranks, int min_rows);
 int fasp_hip_dist_level_info(const fasp_hip_amg* h, int level, int* info);
 int fasp_hip_dist_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view);
 int fasp_hip_dist_get_list(const fasp_hip_amg* h, int level, int which, ivector* view);
+/* one-rank exercise of every RCCL call the transport makes (0 = all results correct) */
+int  fasp_hip_comm_selftest(void);
 int fasp_hip_comm_rank(void);
 int fasp_hip_comm_size(void);
 

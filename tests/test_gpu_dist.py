@@ -66,3 +66,10 @@ def test_distributed_solve_matches_oracle(gpu, world, n, min_rows, cycle):
     # every rank saw bit-identical scalars
     for r in res[1:]:
         assert np.array_equal(r[3], res[0][3])
+
+
+@pytest.mark.gpu
+def test_rccl_entry_points_single_rank():
+    """Every RCCL call of the production transport, on a one-rank communicator (one GPU here)."""
+    import faspsolver_amd as fa
+    assert fa.lib().fasp_hip_comm_selftest() == 0

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export OMP_NUM_THREADS=${OMP_NUM_THREADS:-32}
+timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "^###\|^$" | tail -12 | tee gpurun_out/t_all.log
+timeout 600 python bench.py --steps 5 --warmup 2 2> gpurun_out/bench.err | tee gpurun_out/bench.json
+tail -5 gpurun_out/bench.err
