@@ -111,7 +111,8 @@ def main(args, rank, world, local_rank):
             "max_abs_error_vs_exact": err,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": B.PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved / B.PEAK_HBM_GBS, "traffic": None,
-                         "kernel": "k_csr_wstream<OP_MXV_DOT,64,512> (level-0 local t = A p, rank 0)",
+                         "kernel": "level-0 local t = A p on rank 0, kernel family %d "
+                                   "(2 wave-stream CSR, 4 byte-dictionary coded, 5 row-pattern coded)" % H.kernel_info(0, 0)[0],
                          "bytes_per_launch": Bl, "ms_per_launch": kernel_ms},
         }
         print(json.dumps(out), flush=True)

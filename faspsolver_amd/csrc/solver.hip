@@ -2169,6 +2169,23 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
 
 int fasp_hip_amg_num_levels(const fasp_hip_amg* h) { return h ? (int)h->H.L.size() : ERROR_INPUT_PAR; }
 
+// which kernel family serves operator `which` (0 A, 1 P, 2 R) of a level, and how many bytes of
+// matrix data one pass of it reads (row pointers / indices / values, or their coded form)
+int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* kind, double* matrix_bytes)
+{
+    if (!h || level < 0 || level >= (int)h->L.size() || which < 0 || which > 2) return ERROR_INPUT_PAR;
+    const DevLevel& D = h->L[level];
+    const DevCSR& M = which == 0 ? D.A : which == 1 ? D.P : D.R;
+    if (!M.ia) return ERROR_INPUT_PAR;
+    int k = M.kind;
+    double bytes = 12.0 * M.nnz + 4.0 * (M.row + 1.0);
+    if (M.code && g_tune.compress) { k = 4; bytes = 1.0 * M.nnz + 4.0 * (M.row + 1.0) + (M.rowbase ? 4.0 * M.row : 0.0); }
+    if (M.pat && g_tune.compress) { k = 5; bytes = 2.0 * M.row + (M.rowbase ? 4.0 * M.row : 0.0) + 12.0 * M.npent; }
+    if (kind) *kind = k;
+    if (matrix_bytes) *matrix_bytes = bytes;
+    return FASP_SUCCESS;
+}
+
 int fasp_hip_amg_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view)
 {
     if (!h || !view || level < 0 || level >= (int)h->H.L.size()) return ERROR_INPUT_PAR;

@@ -326,6 +326,9 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h);
 
 /* Hierarchy inspection (parity tests compare these with the oracle). */
 int fasp_hip_amg_num_levels(const fasp_hip_amg* h);
+/* kernel family of operator `which` (0 A, 1 P, 2 R) on a level -- 0: sub-wavefront per row, 2: wave-level
+ * stream, 4: byte-dictionary coded, 5: row-pattern coded -- and the matrix bytes one pass of it reads */
+int  fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* kind, double* matrix_bytes);
 /* which: 0 = A_l, 1 = P_l, 2 = R_l.  Returns host views owned by the handle. */
 int fasp_hip_amg_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view);
 int fasp_hip_amg_get_cfmark(const fasp_hip_amg* h, int level, ivector* view);
