@@ -69,6 +69,7 @@ struct CsrArgs {
     int           npat, npent;
     int           ncol;     // length of x (buffer-load range check)
     int           dbg;      // development: > 0 limits the gathers per 8-entry group (timing experiments only)
+    const int*    stop;     // != nullptr: the launch returns at once when *stop != 0 (queued-ahead iterations)
 };
 
 __device__ __forceinline__ int ld_ja(const CsrArgs& a, int k)
@@ -157,6 +158,7 @@ __device__ __forceinline__ double block_max(double v, double* lds)
 template <int L, int OP>
 __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
 {
+    if (a.stop && *a.stop) return;
     constexpr int RPB = BLOCK / L;
     const int sl   = threadIdx.x & (L - 1);
     const int rloc = threadIdx.x / L;
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(CsrArgs a, int R)
 template <int OP, int U>
 __global__ __launch_bounds__(BLOCK) void k_csr_dict8(CsrArgs a)
 {
+    if (a.stop && *a.stop) return;
     constexpr int CAP = 2048;  // code bytes staged per wave and step
     __shared__ double s_val[256];
     __shared__ int    s_off[256];
@@ -551,6 +554,7 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, unsign
 template <int OP, bool LDS_TAB, int RPL>
 __global__ __launch_bounds__(BLOCK) void k_csr_rowpat(CsrArgs a)
 {
+    if (a.stop && *a.stop) return;
     constexpr int U = 8;
     constexpr int MAXP = 512, MAXE = 2048;
     __shared__ int    s_start[LDS_TAB ? MAXP : 1];
@@ -678,6 +682,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat(CsrArgs a)
 template <int OP, int RW, int CAPW>
 __global__ __launch_bounds__(BLOCK) void k_csr_wstream(CsrArgs a)
 {
+    if (a.stop && *a.stop) return;
     // Jacobi skips the diagonal entry by its storage index (a.dpos), so no column staging
     __shared__ double prod_all[4 * CAPW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -280,6 +280,88 @@ FINISHED:
 }
 
 // ---------------------------------------------------------------------------
+// Safe CG on a coarsest level too large for k_spcg_small (P7(256): 4 971 rows, 6.4 M nonzeros):
+// the SpMV stays a full-chip kernel, everything between two SpMVs is ONE one-block launch that
+// keeps the iteration state on the device -- (t,p) from the SpMV's per-block partials, alpha,
+// u += alpha p, r -= alpha t, the five norms, the best-iterate copy, the reference's exit and
+// restart TESTS, beta and p = r + beta p (KrySPcg.c:160-330).  The host queues a batch of
+// iterations without waiting; when a test fires the step kernel raises `stop`, the queued
+// launches behind it return at once, and the host runs that branch of the reference (true
+// residual, restart, ...) from the recorded scalars and resumes.  One synchronisation per batch
+// instead of one per iteration.
+// ---------------------------------------------------------------------------
+enum SpcgStop : int { SPCG_RUN = 0, SPCG_CONV = 1, SPCG_STAG = 2, SPCG_NAN = 3, SPCG_DIV0 = 4, SPCG_SOLSTAG = 5, SPCG_MAXIT = 6 };
+struct SpcgState {
+    double temp1, temp1_prev, absres_best, normr0, tol, maxdiff;  // inputs carried from step to step
+    double tp, rr, uu, pp, maxu, nan, alpha, absres, relres;  // scalars of the latest step
+    int    iter, iter_best, stag, MaxIt, stop, pad;
+};
+struct SpcgStepArgs {
+    int           m;
+    SpcgState*    st;
+    const double* tp_partials;  // per-block partials of (t,p) from the fused SpMV
+    int           ntp;
+    const double* t;
+    double *p, *u, *r, *u_best;
+};
+
+__global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_step(SpcgStepArgs a)
+{
+    __shared__ double sh[SMALL_WAVES * 5];
+    SpcgState& S = *a.st;
+    if (S.stop != SPCG_RUN) return;
+    const int tid = threadIdx.x, m = a.m;
+    const double temp1 = S.temp1, absres_best = S.absres_best, normr0 = S.normr0, tol = S.tol, maxdiff = S.maxdiff;
+    const int it = S.iter + 1, stag = S.stag, MaxIt = S.MaxIt;
+    __syncthreads();  // every thread has read the state before thread 0 rewrites it
+    double v1[1] = {0.0};
+    for (int i = tid; i < a.ntp; i += SMALL_BLOCK) v1[0] += a.tp_partials[i];
+    blk_reduce<1>(v1, sh);
+    const double tp = v1[0];
+    if (!(fabs(tp) > 1e-40)) {  // KrySPcg.c:172-177: breakdown, nothing is updated
+        if (tid == 0) { S.tp = tp; S.iter = it; S.stop = SPCG_DIV0; }
+        return;
+    }
+    const double alpha = temp1 / tp;
+    double red[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < m; i += SMALL_BLOCK) {
+        const double pi = a.p[i];
+        const double ui = a.u[i] + alpha * pi;
+        const double ri = a.r[i] - alpha * a.t[i];
+        a.u[i] = ui; a.r[i] = ri;
+        red[0] += ri * ri; red[1] += ui * ui; red[2] += pi * pi;
+        red[3] = fmax(red[3], fabs(ui));
+        red[4] += (ui != ui) ? 1.0 : 0.0;
+    }
+    blk_reduce<5>(red, sh, 1u << 3);
+    const double absres = sqrt(red[0]), relres = absres / normr0;
+    int    stop = SPCG_RUN, iter_best = S.iter_best;
+    double best = absres_best;
+    if (red[4] > 0.0) stop = SPCG_NAN;
+    else {
+        if (absres < absres_best - maxdiff) {
+            best = absres; iter_best = it;
+            for (int i = tid; i < m; i += SMALL_BLOCK) a.u_best[i] = a.u[i];
+        }
+        const double reldiff = fabs(alpha) * sqrt(red[2]) / sqrt(red[1]);
+        if (red[3] <= 1e-20) stop = SPCG_SOLSTAG;                        // Check I
+        else if ((stag <= 20) & (reldiff < maxdiff)) stop = SPCG_STAG;   // Check II fires: host recomputes r
+        else if (relres < tol) stop = SPCG_CONV;                         // Check III fires: host checks the true residual
+        const double beta = red[0] / temp1;
+        for (int i = tid; i < m; i += SMALL_BLOCK) a.p[i] = 1.0 * a.r[i] + beta * a.p[i];
+        if (stop == SPCG_RUN && it >= MaxIt) stop = SPCG_MAXIT;
+    }
+    if (tid == 0) {
+        S.tp = tp; S.rr = red[0]; S.uu = red[1]; S.pp = red[2]; S.maxu = red[3]; S.nan = red[4];
+        S.alpha = alpha; S.absres = absres; S.relres = relres;
+        S.absres_best = best; S.iter_best = iter_best; S.iter = it;
+        S.temp1_prev = temp1;
+        S.temp1 = red[0];  // (z,r) of the next step, z = r
+        S.stop = stop;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Variable-restart GMRES without preconditioner, STOP_REL_RES (KryPvgmres.c:66 / :416)
 // ---------------------------------------------------------------------------
 template <class OP>

@@ -437,7 +437,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, dbg = 0; };
+struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, dbg = 0, spcg_batch = 8; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -656,6 +656,7 @@ struct fasp_hip_amg {
     std::vector<double*> gm[2];
     size_t               gm_len[2] = {0, 0};
     double*              gm_hh = nullptr;  // device Hessenberg column
+    SpcgState*           spcg_state = nullptr;  // device-resident state of the batched coarse CG
     // instrumentation
     std::vector<EventPair> ev;
     int                    ev_used = 0;
@@ -1015,13 +1016,12 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         h->coarse_iters += o.iters;
         return o.status;
     }
-    const double maxdiff = tol * STAG_RATIO, sol_inf_tol = SMALLREAL;
+    const double maxdiff = tol * STAG_RATIO;
     int iter = 0, stag = 1, more_step = 1, iter_best = 0;
     double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL, normr0 = BIGREAL;
     double reldiff, factor, alpha = 0.0, beta, temp1, temp2, absres_best = BIGREAL;
     double *p = h->cp, *r = h->cr, *t = h->ct, *u_best = h->cbest, *u = D.x;
     const double* b = D.b;
-    const int G = vec_grid(m);
     double red[8];
     hipStream_t s = g_ctx.stream;
     (void)prtlvl;
@@ -1045,75 +1045,72 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
     HIPCK(hipMemcpyAsync(p, r, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
     temp1 = red[0];
 
-    while (iter++ < MaxIt) {
-        // t = A p fused with the partial sums of (t,p); the consumer sums the partials itself
-        // (the coarsest level is never distributed, so no all-reduce sits in between)
-        int gdot;
-        {
-            CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials;
-            gdot = launch_csr<OP_MXV_DOT>(A, a);
+    {
+        // Device-resident iteration state; the host queues `batch` iterations (SpMV + step kernel
+        // each) without waiting and synchronises once per batch.  When one of the reference's
+        // tests fires, k_spcg_step raises `stop`, the launches queued behind it return at once,
+        // and the branch is replayed here from the recorded scalars (KrySPcg.c:172-330).
+        const int batch = std::max(1, std::min(g_tune.spcg_batch, 64));
+        if (!h->spcg_state) HIPCK(hipMalloc(&h->spcg_state, sizeof(SpcgState)));
+        SpcgState S{};
+        S.temp1 = temp1; S.temp1_prev = temp1; S.absres_best = absres_best; S.normr0 = normr0; S.tol = tol;
+        S.maxdiff = maxdiff; S.iter = 0; S.iter_best = 0; S.stag = stag; S.MaxIt = MaxIt; S.stop = SPCG_RUN;
+        HIPCK(hipMemcpyAsync(h->spcg_state, &S, sizeof(S), hipMemcpyHostToDevice, s));
+        for (;;) {
+            for (int q = 0; q < batch; ++q) {
+                CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials; a.stop = &h->spcg_state->stop;
+                SpcgStepArgs sa{};
+                sa.m = m; sa.st = h->spcg_state; sa.t = t; sa.p = p; sa.u = u; sa.r = r; sa.u_best = u_best;
+                sa.ntp = launch_csr<OP_MXV_DOT>(A, a);
+                sa.tp_partials = g_ctx.d_partials;
+                hipLaunchKernelGGL(k_spcg_step, dim3(1), dim3(SMALL_BLOCK), 0, s, sa);
+            }
+            HIPCK(hipMemcpyAsync(g_ctx.h_part, h->spcg_state, sizeof(SpcgState), hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            std::memcpy(&S, g_ctx.h_part, sizeof(S));
+            iter = S.iter; absres_best = S.absres_best; iter_best = S.iter_best;
+            if (S.stop == SPCG_RUN) continue;
+            // a test fired in iteration S.iter: finish that iteration as the reference does
+            temp2 = S.tp; temp1 = S.temp1_prev;
+            red[0] = S.rr; red[1] = S.uu; red[2] = S.pp; red[3] = S.maxu; red[4] = S.nan;
+            if (S.stop == SPCG_DIV0) goto RESTORE_BESTSOL;
+            alpha = S.alpha; absres = S.absres; relres = S.relres;
+            factor = absres / absres0; (void)factor; (void)alpha;
+            if (S.stop == SPCG_NAN) { absres = BIGREAL; goto RESTORE_BESTSOL; }
+            if (S.stop == SPCG_SOLSTAG) { iter = ERROR_SOLVER_SOLSTAG; break; }  // Check I
+            if (S.stop == SPCG_MAXIT) { iter = MaxIt + 1; break; }
+            normu = std::sqrt(red[1]);
+            reldiff = std::fabs(S.alpha) * std::sqrt(red[2]) / normu;
+            if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {  // Check II
+                d_resid(A, u, b, r);
+                if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+                absres = std::sqrt(red[0]);
+                relres = absres / normr0;
+                if (relres < tol) break;
+                if (stag >= MAX_STAG) { iter = ERROR_SOLVER_STAG; break; }
+                HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
+                ++stag;
+            }
+            if (relres < tol) {  // Check III: true residual
+                d_resid(A, u, b, r);
+                if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+                absres = std::sqrt(red[0]);
+                relres = absres / normr0;
+                if (relres < tol) break;
+                if (more_step >= MAX_RESTART) { iter = ERROR_SOLVER_TOLSMALL; break; }
+                HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
+                ++more_step;
+            }
+            // every branch that gets here restarted: p was zeroed, so p = z + beta p = r
+            absres0 = absres;
+            temp2 = red[0];
+            beta = temp2 / temp1;
+            temp1 = temp2;
+            d_axpby(m, 1.0, r, beta, p);
+            S.temp1 = temp1; S.temp1_prev = temp1; S.stag = stag; S.stop = SPCG_RUN;
+            HIPCK(hipMemcpyAsync(h->spcg_state, &S, sizeof(S), hipMemcpyHostToDevice, s));
+            HIPCK(hipStreamSynchronize(s));  // S lives on this stack frame
         }
-        // alpha on device; u += alpha p; r -= alpha t; norms of r, u, p; max|u|; NaN count.
-        // The G x 5 block partials and (t,p) travel to the host in one copy and are summed
-        // there in block order.
-        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, (const double*)nullptr,
-                           g_ctx.d_partials, gdot, p, t, u, r, g_ctx.d_partials2, 1, g_ctx.d_partials2 + 5 * G);
-        HIPCK(hipMemcpyAsync(g_ctx.h_part, g_ctx.d_partials2, sizeof(double) * (5 * G + 1), hipMemcpyDeviceToHost, s));
-        HIPCK(hipStreamSynchronize(s));
-        for (int q = 0; q < 5; ++q) {
-            double v = 0.0;
-            if (q == 3) { for (int i = 0; i < G; ++i) v = std::max(v, g_ctx.h_part[q * G + i]); }
-            else { for (int i = 0; i < G; ++i) v += g_ctx.h_part[q * G + i]; }
-            red[q] = v;
-        }
-        temp2 = g_ctx.h_part[5 * G];
-        if (std::fabs(temp2) > SMALLREAL2) alpha = temp1 / temp2;
-        else goto RESTORE_BESTSOL;
-
-        absres = std::sqrt(red[0]);
-        relres = absres / normr0;
-        factor = absres / absres0;
-        (void)factor;
-        if (red[4] > 0.0) {  // fasp_dvec_isnan(u), KrySPcg.c:185
-            absres = BIGREAL;
-            goto RESTORE_BESTSOL;
-        }
-        if (absres < absres_best - maxdiff) {
-            absres_best = absres;
-            iter_best   = iter;
-            HIPCK(hipMemcpyAsync(u_best, u, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
-        }
-        if (red[3] <= sol_inf_tol) {  // Check I
-            iter = ERROR_SOLVER_SOLSTAG;
-            break;
-        }
-        normu   = std::sqrt(red[1]);
-        reldiff = std::fabs(alpha) * std::sqrt(red[2]) / normu;
-        if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {  // Check II
-            d_resid(A, u, b, r);
-            if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
-            absres = std::sqrt(red[0]);
-            relres = absres / normr0;
-            if (relres < tol) break;
-            if (stag >= MAX_STAG) { iter = ERROR_SOLVER_STAG; break; }
-            HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
-            ++stag;
-        }
-        if (relres < tol) {  // Check III: true residual
-            d_resid(A, u, b, r);
-            if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
-            absres = std::sqrt(red[0]);
-            relres = absres / normr0;
-            if (relres < tol) break;
-            if (more_step >= MAX_RESTART) { iter = ERROR_SOLVER_TOLSMALL; break; }
-            HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
-            ++more_step;
-        }
-        absres0 = absres;
-        temp2   = red[0];  // (z,r) with z = r
-        beta    = temp2 / temp1;
-        temp1   = temp2;
-        d_axpby(m, 1.0, r, beta, p);  // p = z + beta p
     }
 
 RESTORE_BESTSOL:
@@ -2164,6 +2161,7 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
         for (double* q : h->gm[s])
             if (q) (void)hipFree(q);
     if (h->gm_hh) (void)hipFree(h->gm_hh);
+    if (h->spcg_state) (void)hipFree(h->spcg_state);
     delete h;
 }
 
@@ -2946,6 +2944,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "lds_tab")) g_tune.lds_tab = value;
     else if (!std::strcmp(key, "xcd_pat")) g_tune.xcd_pat = value;
     else if (!std::strcmp(key, "dbg")) g_tune.dbg = value;
+    else if (!std::strcmp(key, "spcg_batch")) g_tune.spcg_batch = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;
     else if (!std::strcmp(key, "wcap")) g_tune.wcap = value;
