@@ -37,7 +37,7 @@ struct SmallOut {
 // Sum (or max, per bit of maxmask) of NQ per-thread values over the workgroup.  Every thread
 // ends with the same result, summed in the same order: wave shuffle tree, then the 16 wave
 // partials left to right.
-template <int NQ>
+template <int NQ, int NW = SMALL_WAVES>
 __device__ __forceinline__ void blk_reduce(double (&v)[NQ], double* sh, unsigned maxmask = 0u)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -57,7 +57,7 @@ __device__ __forceinline__ void blk_reduce(double (&v)[NQ], double* sh, unsigned
     for (int q = 0; q < NQ; ++q) {
         const bool mx = (maxmask >> q) & 1u;
         double x = sh[q];
-        for (int k = 1; k < SMALL_WAVES; ++k) {
+        for (int k = 1; k < NW; ++k) {
             const double y = sh[k * NQ + q];
             x = mx ? fmax(x, y) : x + y;
         }
@@ -357,6 +357,84 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_step(SpcgStepArgs a)
         S.absres_best = best; S.iter_best = iter_best; S.iter = it;
         S.temp1_prev = temp1;
         S.temp1 = red[0];  // (z,r) of the next step, z = r
+        S.stop = stop;
+    }
+}
+
+// The same step with the vectors held in registers (m <= 512 * E): all loads of a step are issued
+// together, so the kernel is one memory round trip plus two block reductions long.
+template <int E>
+__global__ __launch_bounds__(512) void k_spcg_step_reg(SpcgStepArgs a)
+{
+    constexpr int NT = 512, NW = NT / 64;
+    __shared__ double sh[NW * 5];
+    SpcgState& S = *a.st;
+    if (S.stop != SPCG_RUN) return;
+    const int tid = threadIdx.x, m = a.m;
+    const double temp1 = S.temp1, absres_best = S.absres_best, normr0 = S.normr0, tol = S.tol, maxdiff = S.maxdiff;
+    const int it = S.iter + 1, stag = S.stag, MaxIt = S.MaxIt;
+    double pi[E], ti[E], ui[E], ri[E];
+    double v1[1] = {0.0};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = min(tid + e * NT, m - 1);
+        pi[e] = a.p[i]; ti[e] = a.t[i]; ui[e] = a.u[i]; ri[e] = a.r[i];
+    }
+    for (int i = tid; i < a.ntp; i += NT) v1[0] += a.tp_partials[i];
+    __syncthreads();  // every thread has read the state before thread 0 rewrites it
+    blk_reduce<1, NW>(v1, sh);
+    const double tp = v1[0];
+    if (!(fabs(tp) > 1e-40)) {
+        if (tid == 0) { S.tp = tp; S.iter = it; S.stop = SPCG_DIV0; }
+        return;
+    }
+    const double alpha = temp1 / tp;
+    double red[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (tid + e * NT < m) {
+            ui[e] = ui[e] + alpha * pi[e];
+            ri[e] = ri[e] - alpha * ti[e];
+            red[0] += ri[e] * ri[e]; red[1] += ui[e] * ui[e]; red[2] += pi[e] * pi[e];
+            red[3] = fmax(red[3], fabs(ui[e]));
+            red[4] += (ui[e] != ui[e]) ? 1.0 : 0.0;
+        }
+    }
+    blk_reduce<5, NW>(red, sh, 1u << 3);
+    const double absres = sqrt(red[0]), relres = absres / normr0;
+    int    stop = SPCG_RUN, iter_best = S.iter_best;
+    double best = absres_best;
+    const bool nan = red[4] > 0.0;
+    bool better = false;
+    double beta = 0.0;
+    if (nan) stop = SPCG_NAN;
+    else {
+        better = absres < absres_best - maxdiff;
+        if (better) { best = absres; iter_best = it; }
+        const double reldiff = fabs(alpha) * sqrt(red[2]) / sqrt(red[1]);
+        if (red[3] <= 1e-20) stop = SPCG_SOLSTAG;
+        else if ((stag <= 20) & (reldiff < maxdiff)) stop = SPCG_STAG;
+        else if (relres < tol) stop = SPCG_CONV;
+        beta = red[0] / temp1;
+        if (stop == SPCG_RUN && it >= MaxIt) stop = SPCG_MAXIT;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + e * NT;
+        if (i < m) {
+            a.u[i] = ui[e]; a.r[i] = ri[e];
+            if (!nan) {
+                if (better) a.u_best[i] = ui[e];
+                a.p[i] = 1.0 * ri[e] + beta * pi[e];
+            }
+        }
+    }
+    if (tid == 0) {
+        S.tp = tp; S.rr = red[0]; S.uu = red[1]; S.pp = red[2]; S.maxu = red[3]; S.nan = red[4];
+        S.alpha = alpha; S.absres = absres; S.relres = relres;
+        S.absres_best = best; S.iter_best = iter_best; S.iter = it;
+        S.temp1_prev = temp1;
+        S.temp1 = red[0];
         S.stop = stop;
     }
 }

@@ -1063,7 +1063,9 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
                 sa.m = m; sa.st = h->spcg_state; sa.t = t; sa.p = p; sa.u = u; sa.r = r; sa.u_best = u_best;
                 sa.ntp = launch_csr<OP_MXV_DOT>(A, a);
                 sa.tp_partials = g_ctx.d_partials;
-                hipLaunchKernelGGL(k_spcg_step, dim3(1), dim3(SMALL_BLOCK), 0, s, sa);
+                if (m <= 512 * 4) hipLaunchKernelGGL(k_spcg_step_reg<4>, dim3(1), dim3(512), 0, s, sa);
+                else if (m <= 512 * 10) hipLaunchKernelGGL(k_spcg_step_reg<10>, dim3(1), dim3(512), 0, s, sa);
+                else hipLaunchKernelGGL(k_spcg_step, dim3(1), dim3(SMALL_BLOCK), 0, s, sa);
             }
             HIPCK(hipMemcpyAsync(g_ctx.h_part, h->spcg_state, sizeof(SpcgState), hipMemcpyDeviceToHost, s));
             HIPCK(hipStreamSynchronize(s));
