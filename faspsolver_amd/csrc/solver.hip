@@ -2167,6 +2167,55 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
     delete h;
 }
 
+// Host-only check of the lossless matrix coding (no GPU needed): codes A the way upload_csr would,
+// decodes it again and compares with A bit for bit.  *kind_out = 5 (row patterns), 4 (byte
+// dictionary) or 0 (stays plain CSR).  Returns 0 when the round trip is exact.
+int fasp_hip_coding_selftest(const dCSRmat* A, int* kind_out)
+{
+    if (!A || !kind_out) return ERROR_INPUT_PAR;
+    HostCSR M;
+    M.row = A->row; M.col = A->col; M.nnz = A->nnz;
+    M.ia.alloc((size_t)A->row + 1); M.ja.alloc((size_t)std::max(A->nnz, 1)); M.val.alloc((size_t)std::max(A->nnz, 1));
+    std::memcpy(M.ia.data(), A->IA, sizeof(int) * ((size_t)A->row + 1));
+    std::memcpy(M.ja.data(), A->JA, sizeof(int) * (size_t)A->nnz);
+    std::memcpy(M.val.data(), A->val, sizeof(double) * (size_t)A->nnz);
+    const bool square = M.row == M.col;
+    *kind_out = 0;
+    if (!(M.nnz >= 4096 && (double)M.nnz <= 48.0 * M.row)) return FASP_SUCCESS;
+    auto bits = [](double v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; };
+    {
+        Buf<unsigned short> pat; Buf<int> rb;
+        std::vector<int> pstart, plen, poff; std::vector<double> pval;
+        if (build_rowpat(M, pat, pstart, plen, poff, pval, rb)) {
+            *kind_out = 5;
+            for (int r = 0; r < M.row; ++r) {
+                const int id = pat[r], base = square ? r : rb[r];
+                if (plen[id] != M.ia[r + 1] - M.ia[r]) return ERROR_MISC;
+                for (int j = 0; j < plen[id]; ++j) {
+                    const int k = M.ia[r] + j;
+                    if (base + poff[pstart[id] + j] != M.ja[k] || bits(pval[pstart[id] + j]) != bits(M.val[k])) return ERROR_MISC;
+                }
+                for (int j = plen[id]; j < (plen[id] + 7) / 8 * 8; ++j)  // padding: offset 0, value +0.0
+                    if (poff[pstart[id] + j] != 0 || bits(pval[pstart[id] + j]) != 0ull) return ERROR_MISC;
+            }
+            return FASP_SUCCESS;
+        }
+    }
+    {
+        std::vector<int> doff; std::vector<double> dval;
+        Buf<unsigned char> code; Buf<int> rb;
+        if (build_dict8(M, doff, dval, code, rb)) {
+            *kind_out = 4;
+            for (int r = 0; r < M.row; ++r) {
+                const int base = square ? r : rb[r];
+                for (int k = M.ia[r]; k < M.ia[r + 1]; ++k)
+                    if (base + doff[code[k]] != M.ja[k] || bits(dval[code[k]]) != bits(M.val[k])) return ERROR_MISC;
+            }
+        }
+    }
+    return FASP_SUCCESS;
+}
+
 int fasp_hip_amg_num_levels(const fasp_hip_amg* h) { return h ? (int)h->H.L.size() : ERROR_INPUT_PAR; }
 
 // which kernel family serves operator `which` (0 A, 1 P, 2 R) of a level, and how many bytes of

@@ -326,6 +326,9 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h);
 
 /* Hierarchy inspection (parity tests compare these with the oracle). */
 int fasp_hip_amg_num_levels(const fasp_hip_amg* h);
+/* host-only round-trip check of the lossless matrix coding applied at upload:
+ * *kind = 5 row-pattern coded, 4 byte-dictionary coded, 0 stays plain CSR; returns 0 if exact */
+int  fasp_hip_coding_selftest(const dCSRmat* A, int* kind);
 /* kernel family of operator `which` (0 A, 1 P, 2 R) on a level -- 0: sub-wavefront per row, 2: wave-level
  * stream, 4: byte-dictionary coded, 5: row-pattern coded -- and the matrix bytes one pass of it reads */
 int  fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* kind, double* matrix_bytes);
