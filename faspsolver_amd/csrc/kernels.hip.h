@@ -184,7 +184,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
                 const double v1 = ld_val(a, k + L);
                 const double v2 = ld_val(a, k + 2 * L);
                 const double v3 = ld_val(a, k + 3 * L);
-                const double x0 = a.x[c0], x1 = a.x[c1], x2 = a.x[c2], x3 = a.x[c3];
+                double x0, x1, x2, x3;
+                if (a.dbg == 99) { x0 = x1 = x2 = x3 = 1.0; }                                 // timing experiment: no gathers
+                else if (a.dbg == 98) { x0 = a.x[r]; x1 = x0; x2 = x0; x3 = x0; }            // one coalesced-ish load
+                else { x0 = a.x[c0]; x1 = a.x[c1]; x2 = a.x[c2]; x3 = a.x[c3]; }
                 if (OP == OP_JACOBI) {
                     if (c0 != r) s += v0 * x0;
                     if (c1 != r) s += v1 * x1;

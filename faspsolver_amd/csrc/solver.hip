@@ -113,6 +113,7 @@ struct DevCSR {
     double* val = nullptr;
     int*    dpos = nullptr;  // storage index of the last diagonal entry per row (-1: none); A matrices only
     bool    dup_diag = false;  // some row stores its diagonal more than once
+    bool    sorted = false;    // device copy has every row sorted by column (long-row operators)
     int     lanes = 8;       // vector kernel: lanes cooperating on one row
     int     kind = 0;        // 0 vector, 1 block-level stream, 2 wave-level stream
     int     tile_rows = 256; // block stream kernel: rows per block tile
@@ -392,9 +393,35 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
     HIPCK(hipMalloc(&D.ja, sizeof(int) * std::max<size_t>(H.nnz, 1)));
     HIPCK(hipMalloc(&D.val, sizeof(double) * std::max<size_t>(H.nnz, 1)));
     HIPCK(hipMemcpyAsync(D.ia, H.ia.data(), sizeof(int) * ((size_t)H.row + 1), hipMemcpyHostToDevice, g_ctx.stream));
+    pick_kernel(D);
+    static const bool sort_long = !(std::getenv("FASP_HIP_SORT_LONG_ROWS") && std::atoi(std::getenv("FASP_HIP_SORT_LONG_ROWS")) == 0);
+    if (D.kind == 0 && sort_long && H.nnz > 0) {
+        // Long-row operators (sub-wavefront kernel: lane-strided partial sums + shuffle tree, i.e. already
+        // not the storage order) are bound by the x gathers -- one L1 tag lookup per distinct cache line,
+        // up to 64 per wavefront load when a row's columns come in discovery order.  The DEVICE copy keeps
+        // every row's entries sorted by column, so neighbouring lanes gather neighbouring entries.
+        Buf<int> sj((size_t)H.nnz);
+        Buf<double> sv((size_t)H.nnz);
+#pragma omp parallel
+        {
+            std::vector<std::pair<int, double>> tmp;
+#pragma omp for schedule(dynamic, 64)
+            for (int i = 0; i < H.row; ++i) {
+                const int kb = H.ia[i], ke = H.ia[i + 1];
+                tmp.resize((size_t)(ke - kb));
+                for (int k = kb; k < ke; ++k) tmp[(size_t)(k - kb)] = {H.ja[k], H.val[k]};
+                std::stable_sort(tmp.begin(), tmp.end(),
+                                 [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+                for (int k = kb; k < ke; ++k) { sj[k] = tmp[(size_t)(k - kb)].first; sv[k] = tmp[(size_t)(k - kb)].second; }
+            }
+        }
+        HIPCK(hipMemcpy(D.ja, sj.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(D.val, sv.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice));
+        D.sorted = true;
+        return FASP_SUCCESS;
+    }
     HIPCK(hipMemcpyAsync(D.ja, H.ja.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
     HIPCK(hipMemcpyAsync(D.val, H.val.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
-    pick_kernel(D);
     // (long rows keep the sub-wavefront kernel: the coded kernels are one-lane-per-row designs)
     if (compress_enabled() && H.nnz >= 4096 && (double)H.nnz <= 48.0 * H.row) {
         Buf<unsigned short> pat; Buf<int> prb;
@@ -483,6 +510,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
     if (OP == OP_JACOBI && M.kind != 0 && M.kind < 4 && (M.dup_diag || !M.dpos)) M.kind = 0;  // needs the c != r test
     a.xcd_map = g_tune.xcd;
     a.nt = g_tune.nt;
+    a.dbg = g_tune.dbg;
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
     const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : M.kind == 3 ? 1 : BLOCK / M.lanes;
     a.ntiles = (M.row + rpb - 1) / rpb;
@@ -706,8 +734,10 @@ static int upload_diag(const HostCSR& A, DevLevel& D)
         if (hits > 1) ++ndup;
     }
     D.A.dup_diag = ndup > 0;
-    HIPCK(hipMalloc(&D.A.dpos, sizeof(int) * std::max(n, 1)));
-    HIPCK(hipMemcpy(D.A.dpos, dp.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    if (!D.A.sorted) {  // (storage indices of the host order: meaningless for a re-sorted device copy)
+        HIPCK(hipMalloc(&D.A.dpos, sizeof(int) * std::max(n, 1)));
+        HIPCK(hipMemcpy(D.A.dpos, dp.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    }
     if (alloc_vec(&D.diag, n) < 0 || alloc_vec(&D.l1, n) < 0) return ERROR_ALLOC_MEM;
     HIPCK(hipMemcpy(D.diag, d.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(D.l1, s.data(), sizeof(double) * n, hipMemcpyHostToDevice));
