@@ -394,34 +394,11 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
     HIPCK(hipMalloc(&D.val, sizeof(double) * std::max<size_t>(H.nnz, 1)));
     HIPCK(hipMemcpyAsync(D.ia, H.ia.data(), sizeof(int) * ((size_t)H.row + 1), hipMemcpyHostToDevice, g_ctx.stream));
     pick_kernel(D);
-    static const bool sort_long = !(std::getenv("FASP_HIP_SORT_LONG_ROWS") && std::atoi(std::getenv("FASP_HIP_SORT_LONG_ROWS")) == 0);
-    if (D.kind == 0 && sort_long && H.nnz > 0) {
-        // Long-row operators (sub-wavefront kernel: lane-strided partial sums + shuffle tree, i.e. already
-        // not the storage order) are bound by the x gathers -- one L1 tag lookup per distinct cache line,
-        // up to 64 per wavefront load when a row's columns come in discovery order.  The DEVICE copy keeps
-        // every row's entries sorted by column, so neighbouring lanes gather neighbouring entries.
-        Buf<int> sj((size_t)H.nnz);
-        Buf<double> sv((size_t)H.nnz);
-#pragma omp parallel
-        {
-            std::vector<std::pair<int, double>> tmp;
-#pragma omp for schedule(dynamic, 64)
-            for (int i = 0; i < H.row; ++i) {
-                const int kb = H.ia[i], ke = H.ia[i + 1];
-                tmp.resize((size_t)(ke - kb));
-                for (int k = kb; k < ke; ++k) tmp[(size_t)(k - kb)] = {H.ja[k], H.val[k]};
-                std::stable_sort(tmp.begin(), tmp.end(),
-                                 [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
-                for (int k = kb; k < ke; ++k) { sj[k] = tmp[(size_t)(k - kb)].first; sv[k] = tmp[(size_t)(k - kb)].second; }
-            }
-        }
-        HIPCK(hipMemcpy(D.ja, sj.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice));
-        HIPCK(hipMemcpy(D.val, sv.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice));
-        D.sorted = true;
-        return FASP_SUCCESS;
-    }
-    HIPCK(hipMemcpyAsync(D.ja, H.ja.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
-    HIPCK(hipMemcpyAsync(D.val, H.val.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
+    auto upload_plain = [&]() -> int {
+        HIPCK(hipMemcpyAsync(D.ja, H.ja.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
+        HIPCK(hipMemcpyAsync(D.val, H.val.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
+        return 0;
+    };
     // (long rows keep the sub-wavefront kernel: the coded kernels are one-lane-per-row designs)
     if (compress_enabled() && H.nnz >= 4096 && (double)H.nnz <= 48.0 * H.row) {
         Buf<unsigned short> pat; Buf<int> prb;
@@ -443,7 +420,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
                 HIPCK(hipMalloc(&D.rowbase, sizeof(int) * (size_t)H.row));
                 HIPCK(hipMemcpy(D.rowbase, prb.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
             }
-            return FASP_SUCCESS;
+            return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
         }
         std::vector<int> doff; std::vector<double> dval;
         Buf<unsigned char> code; Buf<int> rowbase;
@@ -458,9 +435,50 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
                 HIPCK(hipMalloc(&D.rowbase, sizeof(int) * (size_t)H.row));
                 HIPCK(hipMemcpy(D.rowbase, rowbase.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
             }
+            return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
         }
     }
-    return FASP_SUCCESS;
+    // not coded: plain CSR, rows re-sorted by column where the gathers dominate
+    static const bool sort_long = !(std::getenv("FASP_HIP_SORT_LONG_ROWS") && std::atoi(std::getenv("FASP_HIP_SORT_LONG_ROWS")) == 0);
+    static const int  sort_stream = std::getenv("FASP_HIP_SORT_STREAM") ? std::atoi(std::getenv("FASP_HIP_SORT_STREAM")) : 0;
+    const double avg_len = H.row > 0 ? (double)H.nnz / H.row : 0.0;
+    const bool do_sort = sort_long && H.nnz > 0 && (D.kind == 0 || (D.kind == 2 && sort_stream > 0 && avg_len >= sort_stream));
+    if (do_sort) {
+        // Operators whose time goes into the x gathers -- one L1 tag lookup per distinct cache line, up to 64
+        // per wavefront load when a row's columns come in discovery order: the DEVICE copy keeps every row's
+        // entries sorted by column, so neighbouring lanes gather neighbouring entries.  (The sub-wavefront
+        // kernel sums lane-strided partials + a shuffle tree, i.e. it never followed the storage order.)
+        Buf<int> sj((size_t)H.nnz);
+        Buf<double> sv((size_t)H.nnz);
+        std::vector<int> dp;
+        const bool square = H.row == H.col;
+        if (square) dp.assign((size_t)H.row, -1);
+#pragma omp parallel
+        {
+            std::vector<std::pair<int, double>> tmp;
+#pragma omp for schedule(dynamic, 64)
+            for (int i = 0; i < H.row; ++i) {
+                const int kb = H.ia[i], ke = H.ia[i + 1];
+                tmp.resize((size_t)(ke - kb));
+                for (int k = kb; k < ke; ++k) tmp[(size_t)(k - kb)] = {H.ja[k], H.val[k]};
+                std::stable_sort(tmp.begin(), tmp.end(),
+                                 [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+                for (int k = kb; k < ke; ++k) {
+                    sj[k] = tmp[(size_t)(k - kb)].first; sv[k] = tmp[(size_t)(k - kb)].second;
+                    if (square && sj[k] == i) dp[(size_t)i] = k;  // last diagonal hit (stable sort keeps their order)
+                }
+            }
+        }
+        HIPCK(hipMemcpy(D.ja, sj.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(D.val, sv.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice));
+        if (square && D.kind == 2) {
+            HIPCK(hipMalloc(&D.dpos, sizeof(int) * (size_t)std::max(H.row, 1)));
+            HIPCK(hipMemcpy(D.dpos, dp.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
+        }
+        D.sorted = true;
+        return FASP_SUCCESS;
+    }
+    return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
