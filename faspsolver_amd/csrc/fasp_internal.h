@@ -112,6 +112,8 @@ int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, 
 int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H);
 // Smoothed aggregation (PreAMGSetupSA.c:63: VMB aggregation, smoothed P and R).
 int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H);
+// Unsmoothed aggregation (PreAMGSetupUA.c:55: VMB aggregation, boolean P, rap_agg).
+int host_setup_ua(const dCSRmat* A, AMG_param* param, HostHierarchy& H);
 
 // ---- block (BSR) hierarchy of the unsmoothed-aggregation setup (config 3) ------------
 struct HostBSR {

@@ -837,9 +837,13 @@ void print_complexity(const HostHierarchy& H, int prtlvl)
 int check_supported(const ITS_param* it, const AMG_param* amg)
 {
     if (amg) {
-        if (amg->AMG_type != CLASSIC_AMG && amg->AMG_type != SA_AMG) {
-            std::printf("### ERROR: fasp_hip: AMG_type %d has no device path yet (classical RS and SA only)\n",
-                        amg->AMG_type);
+        if (amg->AMG_type != CLASSIC_AMG && amg->AMG_type != SA_AMG && amg->AMG_type != UA_AMG) {
+            std::printf("### ERROR: fasp_hip: unknown AMG_type %d\n", amg->AMG_type);
+            return ERROR_INPUT_PAR;
+        }
+        if (amg->AMG_type != CLASSIC_AMG && amg->aggregation_type != VMB) {
+            std::printf("### ERROR: fasp_hip: aggregation_type %d has no host setup here (VMB only; the reference's "
+                        "default for aggregation AMG is pairwise matching)\n", amg->aggregation_type);
             return ERROR_INPUT_PAR;
         }
         if (amg->AMG_type == SA_AMG && amg->smooth_restriction != 1) {
@@ -1029,6 +1033,80 @@ int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
     if (prtlvl > PRINT_NONE) {
         print_complexity(H, prtlvl);
         std::printf("Smoothed aggregation setup costs %.4f seconds.\n", H.setup_seconds);
+    }
+    return status;
+}
+
+// Unsmoothed aggregation on a scalar matrix (PreAMGSetupUA.c:55, VMB aggregation): tentative
+// (boolean) prolongation, R = P^T and the Galerkin product with unit entries -- for which the
+// general product equals fasp_blas_dcsr_rap_agg (BlaSpmvCSR.c:1276) bit for bit.
+int host_setup_ua(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
+{
+    const int    prtlvl   = param->print_level;
+    const short  min_cdof = (short)std::max(param->coarse_dof, 50);
+    const double t0       = wall_seconds();
+    int          status   = FASP_SUCCESS;
+    const int    max_levels = param->max_levels;
+
+    if (!A || !A->IA || !A->JA || !A->val || A->row <= 0 || A->row != A->col) return ERROR_DATA_STRUCTURE;
+    H.L.clear();
+    H.L.reserve(MAX_AMG_LVL + 1);
+    H.L.emplace_back();
+    copy_csr(A, H.L[0].A);
+    if (prtlvl > PRINT_NONE) std::printf("\nSetting up UA AMG ...\n");
+
+    int lvl = 0;
+    try {
+        while (H.L[lvl].A.row > min_cdof && lvl < max_levels - 1) {
+            HostLevel& Lv = H.L[lvl];
+            HostCSR N;
+            std::vector<int> vv;
+            int nagg = 0;
+            status = aggregation_vmb(Lv.A, vv, *param, lvl + 1, N, nagg);
+            if (nagg * 4.0 > Lv.A.row) param->strong_coupled /= 2.0;  // :235-238
+            else if (nagg * 1.25 < Lv.A.row) param->strong_coupled *= 2.0;
+            if (status < 0) {  // Check 1
+                if (prtlvl > PRINT_MIN) std::printf("### WARNING: Stop coarsening on level %d!\n", lvl);
+                status = FASP_SUCCESS;
+                break;
+            }
+            {   // form_tentative_p (PreAMGAggregationCSR.inl:40) with the constant near-kernel vector
+                HostCSR& P = Lv.P;
+                const int row = Lv.A.row;
+                P.row = row; P.col = nagg;
+                P.ia.alloc((size_t)row + 1);
+                int j = 0;
+                for (int i = 0; i < row; ++i) { P.ia[i] = j; if (vv[i] > UNPT) ++j; }
+                P.ia[row] = j;
+                P.nnz = j;
+                P.ja.alloc((size_t)std::max(j, 1)); P.val.alloc((size_t)std::max(j, 1));
+                j = 0;
+                for (int i = 0; i < row; ++i)
+                    if (vv[i] > UNPT) { P.ja[j] = vv[i]; P.val[j] = 1.0; ++j; }
+            }
+            if (Lv.P.col < MIN_CDOF) { Lv.P = HostCSR(); break; }  // Check 2
+            if (Lv.P.row > Lv.P.col * 20.0) {                      // Check 3 (MAX_CRATE)
+                if (prtlvl > PRINT_MIN) {
+                    std::printf("### WARNING: Coarsening might be too aggressive!\n");
+                    std::printf("### WARNING: Fine level = %d, coarse level = %d. Discard!\n", Lv.P.row, Lv.P.col);
+                }
+                Lv.P = HostCSR();
+                break;
+            }
+            transpose_csr(Lv.P, Lv.R);
+            H.L.emplace_back();
+            galerkin_rap(H.L[lvl].R, H.L[lvl].A, H.L[lvl].P, H.L[lvl + 1].A);
+            H.L[lvl].has_coarse = true;
+            ++lvl;
+        }
+    } catch (const std::bad_alloc&) {
+        std::printf("### ERROR: fasp_hip: host allocation failed during AMG setup\n");
+        return ERROR_ALLOC_MEM;
+    }
+    H.setup_seconds = wall_seconds() - t0;
+    if (prtlvl > PRINT_NONE) {
+        print_complexity(H, prtlvl);
+        std::printf("Unsmoothed aggregation setup costs %.4f seconds.\n", H.setup_seconds);
     }
     return status;
 }

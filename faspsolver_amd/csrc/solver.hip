@@ -2165,8 +2165,9 @@ int fasp_hip_amg_create_host(fasp_hip_amg** out, const dCSRmat* A, AMG_param* am
     int st = check_supported(nullptr, amgparam);
     if (st < 0) return st;
     fasp_hip_amg* h = new fasp_hip_amg();
-    st = (amgparam->AMG_type == SA_AMG) ? host_setup_sa(A, amgparam, h->H)  // SolCSR.c:509-521
-                                        : host_setup_rs(A, amgparam, h->H);
+    st = (amgparam->AMG_type == SA_AMG)   ? host_setup_sa(A, amgparam, h->H)  // SolCSR.c:509-521
+         : (amgparam->AMG_type == UA_AMG) ? host_setup_ua(A, amgparam, h->H)
+                                          : host_setup_rs(A, amgparam, h->H);
     if (st < 0) { delete h; return st; }
     h->param = *amgparam;
     *out = h;

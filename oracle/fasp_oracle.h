@@ -93,6 +93,7 @@ void orc_dcsr_rap(const dCSRmat* R, const dCSRmat* A, const dCSRmat* P,
  * A is deep-copied into mgl->L[0].A.  Returns FASP_SUCCESS or an ERROR_* code. */
 int  orc_amg_setup_rs(orc_amg* mgl, const dCSRmat* A, AMG_param* param);
 /* smoothed aggregation: PreAMGSetupSA.c:63 (smoothed P, smoothed R; VMB aggregation) */
+int orc_amg_setup_ua(orc_amg* mgl, const dCSRmat* A, AMG_param* param);
 int  orc_amg_setup_sa(orc_amg* mgl, const dCSRmat* A, AMG_param* param);
 void orc_amg_free(orc_amg* mgl);
 

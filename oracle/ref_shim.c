@@ -81,7 +81,8 @@ void* ref_amg_setup_rs(dCSRmat* A, AMG_param* param)
     fasp_dcsr_cp(A, &mgl[0].A);
     mgl[0].b = fasp_dvec_create(A->col);
     mgl[0].x = fasp_dvec_create(A->col);
-    if ((param->AMG_type == SA_AMG ? fasp_amg_setup_sa(mgl, param) : fasp_amg_setup_rs(mgl, param)) < 0) return NULL;
+    if ((param->AMG_type == SA_AMG ? fasp_amg_setup_sa(mgl, param)
+         : param->AMG_type == UA_AMG ? fasp_amg_setup_ua(mgl, param) : fasp_amg_setup_rs(mgl, param)) < 0) return NULL;
     return mgl;
 }
 int ref_amg_num_levels(void* h) { return ((AMG_data*)h)[0].num_levels; }
@@ -134,7 +135,8 @@ int ref_krylov_amg_hist(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam,
     fasp_dcsr_cp(A, &mgl[0].A);
     mgl[0].b = fasp_dvec_create(n);
     mgl[0].x = fasp_dvec_create(n);
-    status = (amgparam->AMG_type == SA_AMG) ? fasp_amg_setup_sa(mgl, amgparam) : fasp_amg_setup_rs(mgl, amgparam);
+    status = (amgparam->AMG_type == SA_AMG) ? fasp_amg_setup_sa(mgl, amgparam)
+             : (amgparam->AMG_type == UA_AMG) ? fasp_amg_setup_ua(mgl, amgparam) : fasp_amg_setup_rs(mgl, amgparam);
     if (status < 0) goto FINISHED;
 
     precond_data pcdata;
