@@ -841,7 +841,7 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             std::printf("### ERROR: fasp_hip: unknown AMG_type %d\n", amg->AMG_type);
             return ERROR_INPUT_PAR;
         }
-        if (amg->AMG_type != CLASSIC_AMG && amg->aggregation_type != VMB) {
+        if (amg->AMG_type == UA_AMG && amg->aggregation_type != VMB) {  // (the SA setup always aggregates by VMB, PreAMGSetupSA.c:330)
             std::printf("### ERROR: fasp_hip: aggregation_type %d has no host setup here (VMB only; the reference's "
                         "default for aggregation AMG is pairwise matching)\n", amg->aggregation_type);
             return ERROR_INPUT_PAR;
