@@ -68,7 +68,6 @@ struct CsrArgs {
     const double* pval;     // values (padding: offset 0, value 0)
     int           npat, npent;
     int           ncol;     // length of x (buffer-load range check)
-    int           dbg;      // development: > 0 limits the gathers per 8-entry group (timing experiments only)
     const int*    stop;     // != nullptr: the launch returns at once when *stop != 0 (queued-ahead iterations)
 };
 
@@ -184,10 +183,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
                 const double v1 = ld_val(a, k + L);
                 const double v2 = ld_val(a, k + 2 * L);
                 const double v3 = ld_val(a, k + 3 * L);
-                double x0, x1, x2, x3;
-                if (a.dbg == 99) { x0 = x1 = x2 = x3 = 1.0; }                                 // timing experiment: no gathers
-                else if (a.dbg == 98) { x0 = a.x[r]; x1 = x0; x2 = x0; x3 = x0; }            // one coalesced-ish load
-                else { x0 = a.x[c0]; x1 = a.x[c1]; x2 = a.x[c2]; x3 = a.x[c3]; }
+                const double x0 = a.x[c0], x1 = a.x[c1], x2 = a.x[c2], x3 = a.x[c3];
                 if (OP == OP_JACOBI) {
                     if (c0 != r) s += v0 * x0;
                     if (c1 != r) s += v1 * x1;
@@ -634,8 +630,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat(CsrArgs a)
 #pragma unroll
             for (int q = 0; q < RPL; ++q)
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    xv[q][u] = (a.dbg > 0 && u >= a.dbg) ? 1.0 : buf_load_f64(xr, (unsigned)(cbA[q] + off[q][u]) * 8u);
+                for (int u = 0; u < U; ++u) xv[q][u] = buf_load_f64(xr, (unsigned)(cbA[q] + off[q][u]) * 8u);
 #pragma unroll
             for (int q = 0; q < RPL; ++q)
 #pragma unroll

@@ -482,7 +482,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, dbg = 0, spcg_batch = 8; };
+struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 8; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -528,7 +528,6 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
     if (OP == OP_JACOBI && M.kind != 0 && M.kind < 4 && (M.dup_diag || !M.dpos)) M.kind = 0;  // needs the c != r test
     a.xcd_map = g_tune.xcd;
     a.nt = g_tune.nt;
-    a.dbg = g_tune.dbg;
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
     const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : M.kind == 3 ? 1 : BLOCK / M.lanes;
     a.ntiles = (M.row + rpb - 1) / rpb;
@@ -539,7 +538,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
         const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
         const bool lds = M.npat <= 512 && M.npent <= 2048 && g_tune.lds_tab != 0;
         const int rpl = g_tune.rpl > 0 ? g_tune.rpl : 1;
-        a.plen = M.plen; a.ncol = M.col; a.dbg = g_tune.dbg;
+        a.plen = M.plen; a.ncol = M.col;
         if (g_tune.xcd_pat != 0) a.xcd_map = g_tune.xcd_pat;
         a.ntiles = (M.row + BLOCK * rpl - 1) / (BLOCK * rpl);
         a.tiles_per_xcd = (a.ntiles + 7) / 8;
@@ -3043,7 +3042,6 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "rpl")) g_tune.rpl = value;
     else if (!std::strcmp(key, "lds_tab")) g_tune.lds_tab = value;
     else if (!std::strcmp(key, "xcd_pat")) g_tune.xcd_pat = value;
-    else if (!std::strcmp(key, "dbg")) g_tune.dbg = value;
     else if (!std::strcmp(key, "spcg_batch")) g_tune.spcg_batch = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;
