@@ -157,9 +157,16 @@ struct DevCSR {
 static void pick_kernel(DevCSR& M)
 {
     const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
-    M.kind = avg <= 48.0 ? 2 : 0;  // (kind 3, one workgroup per row, measured slower than L = 64: profiles/)
+    static const double stream_max = std::getenv("FASP_HIP_STREAM_MAX") ? std::atof(std::getenv("FASP_HIP_STREAM_MAX")) : 48.0;
+    M.kind = avg <= stream_max ? 2 : 0;  // (kind 3, one workgroup per row, measured slower than L = 64: profiles/)
     M.lanes = avg < 128.0 ? 16 : avg < 300.0 ? 32 : 64;
-    if (avg < 48.0) M.lanes = avg < 6.0 ? 4 : 8;  // only used when kind is forced to 0
+    if (avg < 48.0) M.lanes = avg < 3.0 ? 2 : avg < 6.0 ? 4 : avg < 24.0 ? 8 : 16;  // short rows on the sub-wavefront kernel
+    // Small transfer operators (fewer 256-row tiles than the chip has block slots): the stream kernel's
+    // long per-tile chain is pure latency there; the sub-wavefront kernel spreads the rows over 8-32x
+    // more blocks (level-3 restriction of P7(256): 25 -> 10 us).  Square operators keep the stream
+    // kernel (its row sums follow the reference's order).
+    static const int small_rows = std::getenv("FASP_HIP_SMALL_XFER_ROWS") ? std::atoi(std::getenv("FASP_HIP_SMALL_XFER_ROWS")) : 256 * 1024;
+    if (M.kind == 2 && M.row != M.col && M.row < small_rows) M.kind = 0;
     int R = 256;
     while (R < STREAM_MAXR && R * 2 * avg <= 3072.0) R <<= 1;
     M.tile_rows = R;
@@ -420,6 +427,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
                 HIPCK(hipMalloc(&D.rowbase, sizeof(int) * (size_t)H.row));
                 HIPCK(hipMemcpy(D.rowbase, prb.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
             }
+            D.kind = 2;  // plain-CSR twin of a coded operator: the stream kernel (same row-sum order; used by the A/B tests)
             return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
         }
         std::vector<int> doff; std::vector<double> dval;
@@ -435,6 +443,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
                 HIPCK(hipMalloc(&D.rowbase, sizeof(int) * (size_t)H.row));
                 HIPCK(hipMemcpy(D.rowbase, rowbase.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
             }
+            D.kind = 2;
             return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
         }
     }
