@@ -20,6 +20,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1518,6 +1519,178 @@ FINISHED:
 }
 
 // ---------------------------------------------------------------------------
+// BiCGstab (KryPbcgs.c:62 / :400: the formulation of MATLAB's bicgstab with half steps,
+// stagnation counters and the minimal-residual iterate) on device vectors
+// ---------------------------------------------------------------------------
+static int bicgstab_device(KOps& K, const double* b, double* x, double tol, int MaxIt, int PrtLvl, Hist* hist,
+                           PcgOut* out)
+{
+    const int m = K.n;
+    const size_t nv = K.nvec;
+    const bool dist = K.dist;
+    hipStream_t s = g_ctx.stream;
+    if (*K.ws_len != nv) {
+        for (double* q : *K.ws) if (q) (void)hipFree(q);
+        K.ws->clear();
+        *K.ws_len = nv;
+    }
+    while (K.ws->size() < 9) {
+        double* q = nullptr;
+        HIPCK(hipMalloc(&q, sizeof(double) * std::max<size_t>(nv, 1)));
+        HIPCK(hipMemsetAsync(q, 0, sizeof(double) * nv, s));
+        K.ws->push_back(q);
+    }
+    std::vector<double*>& W = *K.ws;
+    double *r = W[0], *rt = W[1], *p = W[2], *v = W[3], *xhalf = W[4], *sv = W[5], *t = W[6], *xmin = W[7], *tmp = W[8];
+    double *ph = nullptr, *sh = nullptr;  // preconditioned vectors (may alias the preconditioner's output)
+    double red[8];
+    auto cp = [&](double* dst, const double* src) -> int {
+        HIPCK(hipMemcpyAsync(dst, src, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+        return 0;
+    };
+    auto nrm2 = [&](const double* y, double& val) -> int {
+        if (d_dot(m, y, y, red, dist) < 0) return ERROR_MISC;
+        val = std::sqrt(red[0]);
+        return 0;
+    };
+    auto dot = [&](const double* y, const double* z, double& val) -> int {
+        if (d_dot(m, y, z, red, dist) < 0) return ERROR_MISC;
+        val = red[0];
+        return 0;
+    };
+    auto resid = [&](double* xx, double* rr) -> int {  // rr = b - A xx
+        if (K.halo(xx) < 0) return ERROR_MISC;
+        K.resid(xx, b, rr);
+        return 0;
+    };
+    auto apply_pc = [&](double* in, double** outp) -> int {
+        if (K.pc) return K.pc(in, outp);
+        *outp = in;
+        return FASP_SUCCESS;
+    };
+    double n2b, tolb, relres = BIGREAL, absres0 = BIGREAL, absres = BIGREAL;
+    double alpha, beta, omega, rho, rho1, rtv, tt, st_, normr, normr_act, normph, normx, imin, norm_sh, norm_xhalf, normrmin = 0.0;
+    int iter = 0, stag = 1, moresteps = 1, maxmsteps = 1, flag = 1, maxstagsteps = 3, st;
+    (void)stag; (void)moresteps; (void)maxmsteps;
+
+    if (PrtLvl > PRINT_NONE) std::printf("\nCalling BiCGstab solver (%s) ...\n", K.fmt);
+    if (nrm2(b, n2b) < 0) return ERROR_MISC;
+    if (cp(xmin, x) < 0) return ERROR_MISC;
+    imin = 0;
+    tolb = n2b * tol;
+    if (resid(x, r) < 0) return ERROR_MISC;
+    if (nrm2(r, normr) < 0) return ERROR_MISC;
+    normr_act = normr;
+    relres = normr / n2b;
+    if (hist) hist->push(normr);
+    if (normr <= tolb) { flag = 0; iter = 0; goto FINISHED; }
+    itinfo(PrtLvl, STOP_REL_RES, iter, relres, n2b, 0.0);
+    if (cp(rt, r) < 0) return ERROR_MISC;
+    normrmin = normr;
+    rho = 1.0; omega = 1.0; stag = 0; alpha = 0.0;
+    moresteps = 0; maxmsteps = 10;
+
+    for (iter = 1; iter <= MaxIt; iter++) {
+        rho1 = rho;
+        if (dot(rt, r, rho) < 0) return ERROR_MISC;
+        if ((rho == 0.0) || (std::fabs(rho) >= DBL_MAX)) { flag = 4; goto FINISHED; }
+        if (iter == 1) { if (cp(p, r) < 0) return ERROR_MISC; }
+        else {
+            beta = (rho / rho1) * (alpha / omega);
+            if ((beta == 0) || (std::fabs(beta) > DBL_MAX)) { flag = 4; goto FINISHED; }
+            d_axpy(m, -omega, v, p);
+            d_axpby(m, 1.0, r, beta, p);
+        }
+        if ((st = apply_pc(p, &ph)) < 0) return st;
+        if (K.halo(ph) < 0) return ERROR_MISC;
+        K.mxv(ph, v);
+        if (dot(rt, v, rtv) < 0) return ERROR_MISC;
+        if ((rtv == 0.0) || (std::fabs(rtv) > DBL_MAX)) { flag = 4; goto FINISHED; }
+        alpha = rho / rtv;
+        if (std::fabs(alpha) > DBL_MAX) {
+            flag = 4;
+            std::printf("### WARNING: Divided by zero! [%s:%d]\n", "fasp_solver_dcsr_pbcgs", 178);
+            goto FINISHED;
+        }
+        if (nrm2(x, normx) < 0 || nrm2(ph, normph) < 0) return ERROR_MISC;
+        if (std::fabs(alpha) * normph < DBL_EPSILON * normx) stag = stag + 1; else stag = 0;
+        if (cp(xhalf, x) < 0) return ERROR_MISC;
+        d_axpy(m, alpha, ph, xhalf);   // xhalf = alpha ph + x
+        if (cp(sv, r) < 0) return ERROR_MISC;
+        d_axpy(m, -alpha, v, sv);      // s = -alpha v + r
+        if (nrm2(sv, normr) < 0) return ERROR_MISC;
+        normr_act = normr;
+        absres = normr_act;
+        itinfo(PrtLvl, STOP_REL_RES, iter, normr_act / n2b, absres, absres / absres0);
+        if (hist) hist->push(absres);
+        if ((normr <= tolb) || (stag >= maxstagsteps) || moresteps) {
+            if (resid(xhalf, sv) < 0) return ERROR_MISC;
+            if (nrm2(sv, normr_act) < 0) return ERROR_MISC;
+            if (normr_act <= tolb) {
+                if (cp(x, xhalf) < 0) return ERROR_MISC;
+                flag = 0; imin = iter - 0.5;
+                goto FINISHED;
+            } else {
+                if ((stag >= maxstagsteps) && (moresteps == 0)) stag = 0;
+                moresteps = moresteps + 1;
+                if (moresteps >= maxmsteps) { flag = 3; if (cp(x, xhalf) < 0) return ERROR_MISC; goto FINISHED; }
+            }
+        }
+        if (stag >= maxstagsteps) { flag = 3; goto FINISHED; }
+        if (normr_act < normrmin) {
+            normrmin = normr_act;
+            if (cp(xmin, xhalf) < 0) return ERROR_MISC;
+            imin = iter - 0.5;
+        }
+        if ((st = apply_pc(sv, &sh)) < 0) return st;
+        if (K.halo(sh) < 0) return ERROR_MISC;
+        K.mxv(sh, t);
+        if (dot(t, t, tt) < 0) return ERROR_MISC;
+        if ((tt == 0) || (tt >= DBL_MAX)) { flag = 4; goto FINISHED; }
+        if (dot(sv, t, st_) < 0) return ERROR_MISC;
+        omega = st_ / tt;
+        if (std::fabs(omega) > DBL_MAX) { flag = 4; goto FINISHED; }
+        if (nrm2(sh, norm_sh) < 0 || nrm2(xhalf, norm_xhalf) < 0) return ERROR_MISC;
+        if (std::fabs(omega) * norm_sh < DBL_EPSILON * norm_xhalf) stag = stag + 1; else stag = 0;
+        if (cp(x, xhalf) < 0) return ERROR_MISC;
+        d_axpy(m, omega, sh, x);       // x = omega sh + xhalf
+        if (cp(r, sv) < 0) return ERROR_MISC;
+        d_axpy(m, -omega, t, r);       // r = -omega t + s
+        if (nrm2(r, normr) < 0) return ERROR_MISC;
+        normr_act = normr;
+        if ((normr <= tolb) || (stag >= maxstagsteps) || moresteps) {
+            if (resid(x, r) < 0) return ERROR_MISC;
+            if (nrm2(r, normr_act) < 0) return ERROR_MISC;
+            if (normr_act <= tolb) { flag = 0; goto FINISHED; }
+            else {
+                if ((stag >= maxstagsteps) && (moresteps == 0)) stag = 0;
+                moresteps = moresteps + 1;
+                if (moresteps >= maxmsteps) { flag = 3; goto FINISHED; }
+            }
+        }
+        if (normr_act < normrmin) { normrmin = normr_act; if (cp(xmin, x) < 0) return ERROR_MISC; imin = iter; }
+        if (stag >= maxstagsteps) { flag = 3; goto FINISHED; }
+        if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+        absres0 = absres;
+    }
+FINISHED:
+    if (flag == 0) relres = normr_act / n2b;
+    else {
+        if (resid(xmin, tmp) < 0) return ERROR_MISC;
+        if (nrm2(tmp, normr) < 0) return ERROR_MISC;
+        if (normr <= normr_act) { if (cp(x, xmin) < 0) return ERROR_MISC; iter = (int)imin; relres = normr / n2b; }
+        else relres = normr_act / n2b;
+    }
+    if (PrtLvl > PRINT_NONE) {
+        if (iter > MaxIt) std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, relres);
+        else if (iter >= 0) std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, relres);
+    }
+    if (out) { out->relres = relres; out->absres = relres * n2b; out->normr0 = n2b; }
+    HIPCK(hipStreamSynchronize(s));
+    return iter > MaxIt ? ERROR_SOLVER_MAXIT : iter;
+}
+
+// ---------------------------------------------------------------------------
 // one multigrid cycle on the resident hierarchy (PreMGCycle.c:48-274)
 // ---------------------------------------------------------------------------
 static int mgcycle(fasp_hip_amg* h, const AMG_param& param)
@@ -2372,6 +2545,11 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
     // SolCSR.c:530-551: the AMG preconditioner is always installed on this path;
     // SolCSR.c:84-130: dispatch on itsolver_type (restart is narrowed to SHORT, :62)
     switch (itparam->itsolver_type) {
+        case SOLVER_BiCGstab:
+        {
+            KOps K = csr_ops(h, 0, true);
+            st = bicgstab_device(K, h->b, h->u, itparam->tol, itparam->maxit, itparam->print_level, &H, &po);
+        } break;
         case SOLVER_VGMRES:
         case SOLVER_VFGMRES:
         {
@@ -2670,6 +2848,9 @@ int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const 
     t0 = wall_seconds();
     KOps K = bsr_ops(h, 0, 0);
     switch (itparam->itsolver_type) {  // fasp_solver_dbsr_itsolver, SolBSR.c:55-150
+        case SOLVER_BiCGstab:
+            st = bicgstab_device(K, h->b, h->u, itparam->tol, itparam->maxit, itparam->print_level, &H, &po);
+            break;
         case SOLVER_VGMRES:
         case SOLVER_VFGMRES:
             st = gmres_device(K, h->b, h->u, itparam->itsolver_type == SOLVER_VFGMRES ? 1 : 0, itparam->tol,
@@ -2798,7 +2979,7 @@ bool same_host_matrix(const HostCSR& M, const dCSRmat* A)
            std::memcmp(M.val.data(), A->val, sizeof(double) * (size_t)A->nnz) == 0;
 }
 
-// which: 0 PCG, 1 VGMRES, 2 VFGMRES
+// which: 0 PCG, 1 VGMRES, 2 VFGMRES, 3 BiCGstab
 int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u, precond* pc, double tol,
                   double abstol, int MaxIt, short restart, short StopType, short PrtLvl)
 {
@@ -2853,6 +3034,8 @@ int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u,
     if (which == 0) {
         PcgVecs V{db.d, du.d, dp.d, dt.d, dr.d};
         st = pcg_device(K, V, tol, abstol, MaxIt, StopType, PrtLvl, H, po);
+    } else if (which == 3) {
+        st = bicgstab_device(K, db.d, du.d, tol, MaxIt, PrtLvl, &H, &po);
     } else {
         st = gmres_device(K, db.d, du.d, which == 2 ? 1 : 0, tol, abstol, MaxIt, restart, StopType, PrtLvl, &H, &po);
     }
@@ -2874,6 +3057,12 @@ int fasp_solver_dcsr_pvgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, co
                              const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
     return krylov_plugin(__func__, 1, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+// KryPbcgs.c:62
+int fasp_solver_dcsr_pbcgs(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                           const int MaxIt, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin(__func__, 3, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 // KryPvfgmres.c:67
 int fasp_solver_dcsr_pvfgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,

@@ -101,6 +101,28 @@ def unsymmetric_vfgmres_precres():
 
 
 @case
+def bicgstab_poisson():
+    ia, ja, a, f, ue = poisson7pt(16)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 2
+    return ia, ja, a, f, None, mod
+
+
+@case
+def bicgstab_unsymmetric_tight():
+    ia, ja, a = tridiag(3000, lower=-1.3, diag=2.4, upper=-0.9)
+    f = np.sin(np.arange(3000) * 0.01)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 2; i.tol = 1e-13; i.maxit = 50
+    return ia, ja, a, f, None, mod
+
+
+@case
+def bicgstab_maxit():
+    ia, ja, a, f, ue = poisson7pt(16)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 2; i.maxit = 2
+    return ia, ja, a, f, None, mod
+
+
+@case
 def modrelres_stop():
     ia, ja, a, f, ue = poisson7pt(12)
     def mod(i, p): _jac(i, p); i.stop_type = 3
