@@ -889,7 +889,7 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
         if (amg->max_levels < 1 || amg->max_levels > MAX_AMG_LVL) return ERROR_INPUT_PAR;
     }
     if (it) {
-        if (it->itsolver_type != SOLVER_CG && it->itsolver_type != SOLVER_BiCGstab &&
+        if (it->itsolver_type != SOLVER_CG && it->itsolver_type != SOLVER_BiCGstab && it->itsolver_type != SOLVER_GMRES &&
             it->itsolver_type != SOLVER_VGMRES && it->itsolver_type != SOLVER_VFGMRES) {
             std::printf("### ERROR: Unknown iterative solver type %d! [%s]\n", it->itsolver_type,
                         "fasp_solver_dcsr_itsolver");
@@ -900,7 +900,7 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             return ERROR_SOLVER_PRECTYPE;
         }
         if (it->stop_type < STOP_REL_RES || it->stop_type > STOP_MOD_REL_RES) return ERROR_INPUT_PAR;
-        if ((it->itsolver_type == SOLVER_VGMRES || it->itsolver_type == SOLVER_VFGMRES) &&
+        if ((it->itsolver_type == SOLVER_GMRES || it->itsolver_type == SOLVER_VGMRES || it->itsolver_type == SOLVER_VFGMRES) &&
             (it->restart < 1 || it->restart > 1000)) return ERROR_INPUT_PAR;
     }
     return FASP_SUCCESS;
@@ -1399,14 +1399,14 @@ int check_supported_bsr(const ITS_param* it, const AMG_param* amg, int nb)
         if (amg->max_levels < 1 || amg->max_levels > MAX_AMG_LVL) return ERROR_INPUT_PAR;
     }
     if (it) {
-        if (it->itsolver_type != SOLVER_CG && it->itsolver_type != SOLVER_BiCGstab &&
+        if (it->itsolver_type != SOLVER_CG && it->itsolver_type != SOLVER_BiCGstab && it->itsolver_type != SOLVER_GMRES &&
             it->itsolver_type != SOLVER_VGMRES && it->itsolver_type != SOLVER_VFGMRES) {
             std::printf("### ERROR: Unknown iterative solver type %d! [%s]\n", it->itsolver_type,
                         "fasp_solver_dbsr_itsolver");
             return ERROR_SOLVER_TYPE;
         }
         if (it->stop_type < STOP_REL_RES || it->stop_type > STOP_MOD_REL_RES) return ERROR_INPUT_PAR;
-        if ((it->itsolver_type == SOLVER_VGMRES || it->itsolver_type == SOLVER_VFGMRES) &&
+        if ((it->itsolver_type == SOLVER_GMRES || it->itsolver_type == SOLVER_VGMRES || it->itsolver_type == SOLVER_VFGMRES) &&
             (it->restart < 1 || it->restart > 1000)) return ERROR_INPUT_PAR;
     }
     return FASP_SUCCESS;

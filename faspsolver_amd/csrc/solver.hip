@@ -1235,9 +1235,11 @@ static void d_scale(int n, double a, double* x)
 // `set` selects the workspace (0: level 0, 1: coarsest level); Lv is the level the operator
 // acts on (halo plan); use_pc applies the AMG preconditioner (level 0 only).
 // ---------------------------------------------------------------------------
-static int gmres_device(KOps& K, const double* b, double* x, int mode, double tol, double abstol, int MaxIt,
+static int gmres_device(KOps& K, const double* b, double* x, int mode_in, double tol, double abstol, int MaxIt,
                         int restart, int StopType, int PrtLvl, Hist* hist, PcgOut* out)
 {
+    const bool fixed = mode_in == 3;       // mode 3: fixed restart, fasp_solver_d*_pgmres (KryPgmres.c:66) ...
+    const int  mode = fixed ? 0 : mode_in; // ... the text of mode 0 with four differences
     const int n = K.n;
     const size_t nv = K.nvec;
     const bool dist = K.dist;
@@ -1248,8 +1250,8 @@ static int gmres_device(KOps& K, const double* b, double* x, int mode, double to
     double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL;
     double b_norm = 0.0, den_norm = 0.0, epsilon = 0.0, cr = 1.0, r_norm_old = 0.0;
     const int d = 3, restart_max = restart, restart_min = 3;
-    int Restart = restart;
-    const int Restart1 = Restart + 1;
+    int Restart = fixed ? std::min(restart, MaxIt) : restart;
+    const int Restart1 = restart + 1;
     int iter_best = 0;
     double absres_best = BIGREAL;
     hipStream_t s = g_ctx.stream;
@@ -1293,7 +1295,7 @@ static int gmres_device(KOps& K, const double* b, double* x, int mode, double to
     };
 
     if (PrtLvl > PRINT_NONE)
-        std::printf(mode == 0 ? "\nCalling VGMRes solver (%s) ...\n"
+        std::printf(fixed ? "\nCalling GMRes solver (%s) ...\n" : mode == 0 ? "\nCalling VGMRes solver (%s) ...\n"
                     : mode == 1 ? "\nCalling VFGMRes solver (%s) ...\n" : "\nCalling Safe VGMRes solver (%s) ...\n", K.fmt);
 
     if ((st = true_residual(x, p[0])) < 0) return st;
@@ -1343,14 +1345,16 @@ static int gmres_device(KOps& K, const double* b, double* x, int mode, double to
         norms[0] = relres;
     }
 
-    while (iter < MaxIt) {
+    while (iter < MaxIt && (!fixed || relres > tol)) {
         rs[0] = r_norm_old = r_norm;
         if (mode == 1 && r_norm == 0.0) { if (out) { out->relres = 0.0; out->absres = 0.0; out->normr0 = den_norm; } return iter; }
         if (mode != 1) d_scale(n, 1.0 / r_norm, p[0]);
 
-        if (cr > cr_max || iter == 0) Restart = restart_max;
-        else if (cr < cr_min) { /* keep */ }
-        else { if (Restart - d > restart_min) Restart -= d; else Restart = restart_max; }
+        if (!fixed) {
+            if (cr > cr_max || iter == 0) Restart = restart_max;
+            else if (cr < cr_min) { /* keep */ }
+            else { if (Restart - d > restart_min) Restart -= d; else Restart = restart_max; }
+        }
 
         if (mode == 1) d_scale(n, 1.0 / r_norm, p[0]);
 
@@ -1376,7 +1380,7 @@ static int gmres_device(KOps& K, const double* b, double* x, int mode, double to
             for (j = 0; j < i; j++) hh[j][i - 1] = g_ctx.h_part[j];
             t = std::sqrt(g_ctx.h_part[i]);
             hh[i][i - 1] = t;
-            if (t != 0.0) d_scale(n, 1.0 / t, p[i]);
+            if (fixed ? (std::fabs(t) > SMALLREAL) : (t != 0.0)) d_scale(n, 1.0 / t, p[i]);
             for (j = 1; j < i; ++j) {
                 t = hh[j - 1][i - 1];
                 hh[j - 1][i - 1] = sn[j - 1] * hh[j][i - 1] + c[j - 1] * t;
@@ -1385,7 +1389,8 @@ static int gmres_device(KOps& K, const double* b, double* x, int mode, double to
             t = hh[i][i - 1] * hh[i][i - 1];
             t += hh[i - 1][i - 1] * hh[i - 1][i - 1];
             gamma = std::sqrt(t);
-            if (gamma == 0.0) gamma = epsmac;
+            if (fixed) gamma = std::max(gamma, SMALLREAL);
+            else if (gamma == 0.0) gamma = epsmac;
             c[i - 1] = hh[i - 1][i - 1] / gamma;
             sn[i - 1] = hh[i][i - 1] / gamma;
             rs[i] = -sn[i - 1] * rs[i - 1];
@@ -2550,11 +2555,12 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
             KOps K = csr_ops(h, 0, true);
             st = bicgstab_device(K, h->b, h->u, itparam->tol, itparam->maxit, itparam->print_level, &H, &po);
         } break;
+        case SOLVER_GMRES:
         case SOLVER_VGMRES:
         case SOLVER_VFGMRES:
         {
             KOps K = csr_ops(h, 0, true);
-            st = gmres_device(K, h->b, h->u, itparam->itsolver_type == SOLVER_VFGMRES ? 1 : 0, itparam->tol,
+            st = gmres_device(K, h->b, h->u, itparam->itsolver_type == SOLVER_VFGMRES ? 1 : itparam->itsolver_type == SOLVER_GMRES ? 3 : 0, itparam->tol,
                               itparam->abstol, itparam->maxit, (short)itparam->restart, itparam->stop_type,
                               itparam->print_level, &H, &po);
         } break;
@@ -2851,9 +2857,10 @@ int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const 
         case SOLVER_BiCGstab:
             st = bicgstab_device(K, h->b, h->u, itparam->tol, itparam->maxit, itparam->print_level, &H, &po);
             break;
+        case SOLVER_GMRES:
         case SOLVER_VGMRES:
         case SOLVER_VFGMRES:
-            st = gmres_device(K, h->b, h->u, itparam->itsolver_type == SOLVER_VFGMRES ? 1 : 0, itparam->tol,
+            st = gmres_device(K, h->b, h->u, itparam->itsolver_type == SOLVER_VFGMRES ? 1 : itparam->itsolver_type == SOLVER_GMRES ? 3 : 0, itparam->tol,
                               itparam->abstol, itparam->maxit, (short)itparam->restart, itparam->stop_type,
                               itparam->print_level, &H, &po);
             break;
@@ -2979,7 +2986,7 @@ bool same_host_matrix(const HostCSR& M, const dCSRmat* A)
            std::memcmp(M.val.data(), A->val, sizeof(double) * (size_t)A->nnz) == 0;
 }
 
-// which: 0 PCG, 1 VGMRES, 2 VFGMRES, 3 BiCGstab
+// which: 0 PCG, 1 VGMRES, 2 VFGMRES, 3 BiCGstab, 4 GMRES (fixed restart)
 int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u, precond* pc, double tol,
                   double abstol, int MaxIt, short restart, short StopType, short PrtLvl)
 {
@@ -3037,7 +3044,7 @@ int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u,
     } else if (which == 3) {
         st = bicgstab_device(K, db.d, du.d, tol, MaxIt, PrtLvl, &H, &po);
     } else {
-        st = gmres_device(K, db.d, du.d, which == 2 ? 1 : 0, tol, abstol, MaxIt, restart, StopType, PrtLvl, &H, &po);
+        st = gmres_device(K, db.d, du.d, which == 2 ? 1 : which == 4 ? 3 : 0, tol, abstol, MaxIt, restart, StopType, PrtLvl, &H, &po);
     }
     du.get(u->val);
     for (double* q : ws) if (q) (void)hipFree(q);
@@ -3051,6 +3058,12 @@ int fasp_solver_dcsr_pcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const 
                          const int MaxIt, const short StopType, const short PrtLvl)
 {
     return krylov_plugin(__func__, 0, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+// KryPgmres.c:66
+int fasp_solver_dcsr_pgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                            const int MaxIt, const short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin(__func__, 4, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 // KryPvgmres.c:66
 int fasp_solver_dcsr_pvgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,

@@ -70,6 +70,7 @@ extern "C" {
 #define SOLVER_DEFAULT 0
 #define SOLVER_CG      1
 #define SOLVER_BiCGstab 2
+#define SOLVER_GMRES   4
 #define SOLVER_VGMRES  5
 #define SOLVER_VFGMRES 6
 
@@ -389,6 +390,9 @@ int fasp_solver_dcsr_pcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const 
                          const double abstol, const int MaxIt, const short StopType, const short PrtLvl);
 int fasp_solver_dcsr_pbcgs(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
                            const double abstol, const int MaxIt, const short StopType, const short PrtLvl); /* KryPbcgs.c:62 */
+int fasp_solver_dcsr_pgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
+                            const double abstol, const int MaxIt, const short restart,
+                            const short StopType, const short PrtLvl);                    /* KryPgmres.c:66 */
 int fasp_solver_dcsr_pvgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
                              const double abstol, const int MaxIt, const short restart,
                              const short StopType, const short PrtLvl);

@@ -78,7 +78,7 @@ def test_oracle_hierarchy_equals_reference(name, make):
 
 
 @needs_ref
-@pytest.mark.parametrize("solver,cycle", [(5, 1), (1, 1), (6, 2), (2, 1)])
+@pytest.mark.parametrize("solver,cycle", [(5, 1), (1, 1), (6, 2), (2, 1), (4, 1)])
 @pytest.mark.parametrize("n", [8, 12])
 def test_oracle_solve_equals_reference(n, solver, cycle):
     ia, ja, val, nb, f = synthetic(n)
@@ -138,7 +138,7 @@ def test_bsr_unsupported_parameters_are_refused():
 
 # ------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("solver,cycle", [(5, 1), (1, 1), (6, 2), (2, 1)])
+@pytest.mark.parametrize("solver,cycle", [(5, 1), (1, 1), (6, 2), (2, 1), (4, 1)])
 @pytest.mark.parametrize("n", [8, 16, 24])
 def test_gpu_bsr_solve_matches_oracle(n, solver, cycle):
     ia, ja, val, nb, f = synthetic(n)

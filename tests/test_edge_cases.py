@@ -123,6 +123,21 @@ def bicgstab_maxit():
 
 
 @case
+def gmres_fixed_restart_small():
+    ia, ja, a, f, ue = poisson7pt(16)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 4; i.restart = 3
+    return ia, ja, a, f, None, mod
+
+
+@case
+def gmres_fixed_unsymmetric_precres():
+    ia, ja, a = tridiag(3000, lower=-1.3, diag=2.4, upper=-0.9)
+    f = np.cos(np.arange(3000) * 0.02)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 4; i.restart = 6; i.stop_type = 2; i.tol = 1e-12; i.maxit = 80
+    return ia, ja, a, f, None, mod
+
+
+@case
 def modrelres_stop():
     ia, ja, a, f, ue = poisson7pt(12)
     def mod(i, p): _jac(i, p); i.stop_type = 3

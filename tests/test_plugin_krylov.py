@@ -40,7 +40,7 @@ def orc_krylov(which, ia, ja, a, f, fct=None, tol=1e-8, maxit=500, restart=30, s
 
 def ref_krylov(which, ia, ja, a, f, pc=None, tol=1e-8, maxit=500, restart=30, stop=1):
     R = ref()
-    fn = [R.fasp_solver_dcsr_pcg, R.fasp_solver_dcsr_pvgmres, R.fasp_solver_dcsr_pvfgmres, R.fasp_solver_dcsr_pbcgs][which]
+    fn = [R.fasp_solver_dcsr_pcg, R.fasp_solver_dcsr_pvgmres, R.fasp_solver_dcsr_pvfgmres, R.fasp_solver_dcsr_pbcgs, R.fasp_solver_dcsr_pgmres][which]
     fn.argtypes = KARGS + ([C.c_short, C.c_short] if which in (0, 3) else [C.c_short, C.c_short, C.c_short])
     A, keep = T.as_csr(ia, ja, a)
     x = np.zeros(len(f)); bv, fk = T.as_vec(f); xv = T.dvector(len(f), T.dp(x))
@@ -51,7 +51,7 @@ def ref_krylov(which, ia, ja, a, f, pc=None, tol=1e-8, maxit=500, restart=30, st
 
 def gpu_krylov(which, ia, ja, a, f, pc=None, tol=1e-8, maxit=500, restart=30, stop=1):
     L = fa.lib()
-    fn = [L.fasp_solver_dcsr_pcg, L.fasp_solver_dcsr_pvgmres, L.fasp_solver_dcsr_pvfgmres, L.fasp_solver_dcsr_pbcgs][which]
+    fn = [L.fasp_solver_dcsr_pcg, L.fasp_solver_dcsr_pvgmres, L.fasp_solver_dcsr_pvfgmres, L.fasp_solver_dcsr_pbcgs, L.fasp_solver_dcsr_pgmres][which]
     A, keep = T.as_csr(ia, ja, a)
     x = np.zeros(len(f)); bv, fk = T.as_vec(f); xv = T.dvector(len(f), T.dp(x))
     args = (C.byref(A), C.byref(bv), C.byref(xv), pc, tol, 1e-18, maxit)
@@ -60,7 +60,7 @@ def gpu_krylov(which, ia, ja, a, f, pc=None, tol=1e-8, maxit=500, restart=30, st
 
 
 @needs_ref
-@pytest.mark.parametrize("which", [0, 1, 2, 3])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("with_pc", [False, True])
 def test_oracle_plugin_krylov_equals_reference(which, with_pc):
     ia, ja, a, f, ue = poisson7pt(10)
@@ -73,7 +73,7 @@ def test_oracle_plugin_krylov_equals_reference(which, with_pc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", [0, 1, 2, 3])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("with_pc", [False, True])
 def test_gpu_plugin_krylov_matches_oracle(which, with_pc):
     ia, ja, a, f, ue = poisson7pt(16)
@@ -90,7 +90,7 @@ def _jac(itp, amgp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,solver", [(0, 1), (1, 5), (2, 6), (3, 2)])
+@pytest.mark.parametrize("which,solver", [(0, 1), (1, 5), (2, 6), (3, 2), (4, 4)])
 def test_gpu_amg_as_precond_equals_dropin(which, solver):
     """fasp_precond_setup + fasp_solver_dcsr_pcg (tutorial/main/poisson-pcg.c:81,91) is the same
     computation as fasp_solver_dcsr_krylov_amg."""
