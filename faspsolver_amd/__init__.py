@@ -27,7 +27,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_blas_darray_norm2", "fasp_blas_darray_norminf", "fasp_blas_darray_axpy",
     "fasp_blas_darray_axpby", "fasp_smoother_dcsr_jacobi",
     "fasp_blas_dbsr_mxv", "fasp_blas_dbsr_aAxpy", "fasp_dbsr_getdiaginv", "fasp_smoother_dbsr_jacobi1",
-    "fasp_hip_comm_selftest", "fasp_hip_amg_kernel_info", "fasp_hip_coding_selftest", "fasp_solver_amg", "fasp_hip_amg_solve", "fasp_solver_dcsr_pcg", "fasp_solver_dcsr_pbcgs", "fasp_solver_dcsr_pgmres", "fasp_solver_dcsr_pvgmres",
+    "fasp_hip_param_input", "fasp_fwrapper_dcsr_krylov_amg_", "fasp_hip_comm_selftest", "fasp_hip_amg_kernel_info", "fasp_hip_coding_selftest", "fasp_solver_amg", "fasp_hip_amg_solve", "fasp_solver_dcsr_pcg", "fasp_solver_dcsr_pbcgs", "fasp_solver_dcsr_pgmres", "fasp_solver_dcsr_pvgmres",
     "fasp_solver_dcsr_pvfgmres", "fasp_hip_precond_setup", "fasp_hip_precond_fct", "fasp_hip_precond_free",
     "fasp_hip_time_bsr_mxv", "fasp_solver_dbsr_krylov_amg", "fasp_hip_bsr_amg_create", "fasp_hip_bsr_amg_create_host",
     "fasp_hip_bsr_amg_destroy", "fasp_hip_bsr_amg_num_levels", "fasp_hip_bsr_amg_get_matrix",
@@ -99,6 +99,10 @@ def lib():
     L.fasp_hip_precond_free.restype = None
     L.fasp_hip_precond_fct.argtypes = [T.c_double_p, T.c_double_p, C.c_void_p]
     L.fasp_hip_precond_fct.restype = None
+    L.fasp_hip_param_input.argtypes = [C.c_char_p, P(T.ITS_param), P(T.AMG_param)]
+    L.fasp_fwrapper_dcsr_krylov_amg_.argtypes = [P(C.c_int), P(C.c_int), T.c_int_p, T.c_int_p, T.c_double_p,
+                                                 T.c_double_p, T.c_double_p, P(C.c_double), P(C.c_int), P(C.c_int)]
+    L.fasp_fwrapper_dcsr_krylov_amg_.restype = None
     L.fasp_hip_coding_selftest.argtypes = [P(T.dCSRmat), P(C.c_int)]
     L.fasp_hip_amg_kernel_info.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_int), P(C.c_double)]
     L.fasp_solver_amg.argtypes = [P(T.dCSRmat), P(T.dvector), P(T.dvector), P(T.AMG_param)]

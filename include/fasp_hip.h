@@ -284,6 +284,15 @@ void   fasp_smoother_dbsr_jacobi1(dBSRmat* A, dvector* b, dvector* u, double* di
 /* mean milliseconds per launch of the BSR SpMV kernel on a resident copy of A (HIP events) */
 double fasp_hip_time_bsr_mxv(const dBSRmat* A, int reps);
 
+/* ini front-end: fasp_param_input (AuxInput.c:86) + fasp_param_init (AuxParam.c:34) for the two parameter
+ * structs of this path -- same keywords, value formats, defaults and range check as the reference's
+ * ini files (test/ini/, .dat).  fname == NULL: defaults.  Returns 0, ERROR_OPEN_FILE (-10) or
+ * ERROR_INPUT_PAR; pure host code. */
+int  fasp_hip_param_input(const char* fname, ITS_param* itsparam, AMG_param* amgparam);
+/* Fortran-style wrapper, SolWrapper.c:261: parameters from "ini/amg.dat" in the working directory */
+void fasp_fwrapper_dcsr_krylov_amg_(int* n, int* nnz, int* ia, int* ja, double* a, double* b, double* u,
+                                    double* tol, int* maxit, int* ptrlvl);
+
 /* AMG-preconditioned Krylov solve on a block matrix -- replaces base/src/SolBSR.c:349.
  * Unsmoothed aggregation (PreAMGSetupUABSR.c:55, VMB on the condensed matrix, identity-block
  * prolongation, block Galerkin product) on the host, block-Jacobi V/W cycle

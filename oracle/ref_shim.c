@@ -199,3 +199,14 @@ int ref_bsr_get_matrix(void* h, int l, int which, dBSRmat* view)
 double* ref_bsr_get_diaginv(void* h, int l) { return ((AMG_data_bsr*)h)[l].diaginv.val; }
 void ref_bsr_free(void* h, AMG_param* param) { fasp_amg_data_bsr_free((AMG_data_bsr*)h, param); }
 int ref_sizeof_bsr(void) { return (int)sizeof(dBSRmat); }
+
+
+/* fasp_param_input + fasp_param_init on an ini file (AuxInput.c:86, AuxParam.c:34) */
+void ref_param_from_file(const char* fname, ITS_param* itsparam, AMG_param* amgparam)
+{
+    input_param in;
+    ILU_param   ilu;
+    memset(&in, 0, sizeof(in));  /* (the reference leaves AMG_polynomial_degree unset) */
+    fasp_param_input(fname, &in);
+    fasp_param_init(&in, itsparam, amgparam, &ilu, NULL);
+}

@@ -1,0 +1,97 @@
+"""ini front-end (fasp_hip_param_input = fasp_param_input + fasp_param_init, AuxInput.c:86 / AuxParam.c:34)
+against the reference on the reference's own ini files (data fixtures under tests/golden/data/ini), and the
+Fortran-style wrapper (SolWrapper.c:261)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import faspsolver_amd as fa
+from faspsolver_amd import _types as T
+
+from _libs import DATA, ROOT, default_params, have_ref, orc_solve, poisson7pt, ref
+
+INI = sorted(glob.glob(os.path.join(DATA, "ini", "*.dat")))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def parse(fname):
+    itp, amgp = T.ITS_param(), T.AMG_param()
+    st = fa.lib().fasp_hip_param_input(fname.encode() if fname else None, C.byref(itp), C.byref(amgp))
+    return st, itp, amgp
+
+
+def masked(amgp):
+    """AMG_param bytes without polynomial_degree (unset by the reference's input defaults) and padding."""
+    b = bytearray(bytes(amgp))
+    o = T.AMG_param.polynomial_degree.offset
+    b[o:o + 2] = b"\0\0"
+    return bytes(b)
+
+
+FIELDS_AMG = [f for f, _ in T.AMG_param._fields_ if f not in ("polynomial_degree", "amli_coef")]
+FIELDS_ITS = [f for f, _ in T.ITS_param._fields_]
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("fname", INI, ids=[os.path.basename(f) for f in INI])
+def test_parser_matches_reference(fname):
+    R = ref()
+    R.ref_param_from_file.argtypes = [C.c_char_p, C.POINTER(T.ITS_param), C.POINTER(T.AMG_param)]
+    i2, a2 = T.ITS_param(), T.AMG_param()
+    R.ref_param_from_file(fname.encode(), C.byref(i2), C.byref(a2))
+    st, i1, a1 = parse(fname)
+    assert st == 0
+    for f in FIELDS_ITS:
+        assert getattr(i1, f) == getattr(i2, f), f
+    for f in FIELDS_AMG:
+        assert getattr(a1, f) == getattr(a2, f), f
+
+
+@pytest.mark.parametrize("fname", INI, ids=[os.path.basename(f) for f in INI])
+def test_parser_matches_golden(fname):
+    z = np.load(os.path.join(G, "ini_params.npz"))
+    key = os.path.basename(fname)
+    st, i1, a1 = parse(fname)
+    assert st == 0
+    assert bytes(i1) == z[key + "_its"].tobytes()
+    assert masked(a1) == z[key + "_amg"].tobytes()
+
+
+def test_defaults_errors_and_unknown_keys(tmp_path):
+    st, itp, amgp = parse(None)
+    assert st == 0 and itp.itsolver_type == T.SOLVER_CG and itp.restart == 25 and itp.maxit == 500
+    assert amgp.smoother == T.SMOOTHER_GS and amgp.aggregation_type == 1 and amgp.strong_coupled == 0.25
+    assert parse(str(tmp_path / "missing.dat"))[0] == -10           # ERROR_OPEN_FILE
+    bad = tmp_path / "bad.dat"
+    bad.write_text("AMG_type = XX\n")
+    assert parse(str(bad))[0] == T.ERROR_INPUT_PAR
+    bad.write_text("stop_type = 7\n")
+    assert parse(str(bad))[0] == T.ERROR_INPUT_PAR                   # fasp_param_check
+    ok = tmp_path / "ok.dat"
+    ok.write_text("% comment\n[section]\nno_such_key = 3\nAMG_smoother = JACOBI % trailing text\n"
+                  "AMG_relaxation = 0.6667\nAMG_cycle_type = w\nAMG_coarse_scaling = On\nsolver_type = 6\n")
+    st, itp, amgp = parse(str(ok))
+    assert st == 0 and amgp.smoother == T.SMOOTHER_JACOBI and amgp.relaxation == 0.6667
+    assert amgp.cycle_type == T.W_CYCLE and amgp.coarse_scaling == 1 and itp.itsolver_type == 6
+
+
+@pytest.mark.gpu
+def test_fortran_wrapper(tmp_path, monkeypatch):
+    """CALL FASP_FWRAPPER_DCSR_KRYLOV_AMG: parameters from ini/amg.dat of the working directory."""
+    (tmp_path / "ini").mkdir()
+    (tmp_path / "ini" / "amg.dat").write_text(
+        "solver_type = 1\nprecond_type = 2\nAMG_type = C\nAMG_smoother = JACOBI\nAMG_relaxation = 0.6667\n"
+        "AMG_cycle_type = V\nstop_type = 1\n")
+    monkeypatch.chdir(tmp_path)
+    ia, ja, a, f, ue = poisson7pt(16)
+    itp, amgp = default_params(); itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
+    s1, x1, h1, rr = orc_solve(ia, ja, a, f, itp, amgp)
+    n = C.c_int(len(f)); nnz = C.c_int(len(a)); tol = C.c_double(1e-8); maxit = C.c_int(500); prt = C.c_int(0)
+    u = np.zeros(len(f)); ia2 = ia.copy(); ja2 = ja.copy(); a2 = a.copy(); f2 = f.copy()
+    fa.lib().fasp_fwrapper_dcsr_krylov_amg_(C.byref(n), C.byref(nnz), ia2.ctypes.data_as(T.c_int_p),
+                                            ja2.ctypes.data_as(T.c_int_p), T.dp(a2), T.dp(f2), T.dp(u),
+                                            C.byref(tol), C.byref(maxit), C.byref(prt))
+    assert np.abs(u - x1).max() <= 1e-10 * np.abs(x1).max()

@@ -214,6 +214,20 @@ def main():
         st, xs = ref_bsr_solve(ia, ja, val, nb, f, itp, amgp)
         bs[f"p8_{nm}_iters"] = np.array(st); bs[f"p8_{nm}_x"] = xs
     np.savez_compressed(os.path.join(OUT, "bsr.npz"), **bs)
+    # F8b: parameter structs the reference builds from its own ini files (test/ini/*.dat, copied as data
+    # fixtures to tests/golden/data/ini); AMG_param.polynomial_degree is masked: the reference's input
+    # defaults leave it unset (AuxParam.c:100)
+    import glob
+    R.ref_param_from_file.argtypes = [C.c_char_p, C.POINTER(T.ITS_param), C.POINTER(T.AMG_param)]
+    ini = {}
+    for fn in sorted(glob.glob(os.path.join(DATA, "ini", "*.dat"))):
+        itp, amgp = T.ITS_param(), T.AMG_param()
+        R.ref_param_from_file(fn.encode(), C.byref(itp), C.byref(amgp))
+        b = bytearray(bytes(amgp)); o = T.AMG_param.polynomial_degree.offset; b[o:o + 2] = b"\0\0"
+        ini[os.path.basename(fn) + "_its"] = np.frombuffer(bytes(itp), np.uint8)
+        ini[os.path.basename(fn) + "_amg"] = np.frombuffer(bytes(b), np.uint8)
+    np.savez(os.path.join(OUT, "ini_params.npz"), **ini)
+
     for fn in sorted(os.listdir(OUT)):
         p = os.path.join(OUT, fn)
         if os.path.isfile(p):
