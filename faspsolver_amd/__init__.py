@@ -27,7 +27,8 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_blas_darray_norm2", "fasp_blas_darray_norminf", "fasp_blas_darray_axpy",
     "fasp_blas_darray_axpby", "fasp_smoother_dcsr_jacobi",
     "fasp_blas_dbsr_mxv", "fasp_blas_dbsr_aAxpy", "fasp_dbsr_getdiaginv", "fasp_smoother_dbsr_jacobi1",
-    "fasp_hip_param_input", "fasp_fwrapper_dcsr_krylov_amg_", "fasp_hip_comm_selftest", "fasp_hip_amg_kernel_info", "fasp_hip_coding_selftest", "fasp_solver_amg", "fasp_hip_amg_solve", "fasp_solver_dcsr_pcg", "fasp_solver_dcsr_pbcgs", "fasp_solver_dcsr_pgmres", "fasp_solver_dcsr_pvgmres",
+    "fasp_hip_param_input", "fasp_fwrapper_dcsr_krylov_amg_", "fasp_dcsrvec_read2", "fasp_dvec_read",
+    "fasp_dbsr_read", "fasp_hip_free_bsr", "fasp_hip_comm_selftest", "fasp_hip_amg_kernel_info", "fasp_hip_coding_selftest", "fasp_solver_amg", "fasp_hip_amg_solve", "fasp_solver_dcsr_pcg", "fasp_solver_dcsr_pbcgs", "fasp_solver_dcsr_pgmres", "fasp_solver_dcsr_pvgmres",
     "fasp_solver_dcsr_pvfgmres", "fasp_hip_precond_setup", "fasp_hip_precond_fct", "fasp_hip_precond_free",
     "fasp_hip_time_bsr_mxv", "fasp_solver_dbsr_krylov_amg", "fasp_hip_bsr_amg_create", "fasp_hip_bsr_amg_create_host",
     "fasp_hip_bsr_amg_destroy", "fasp_hip_bsr_amg_num_levels", "fasp_hip_bsr_amg_get_matrix",
@@ -99,6 +100,11 @@ def lib():
     L.fasp_hip_precond_free.restype = None
     L.fasp_hip_precond_fct.argtypes = [T.c_double_p, T.c_double_p, C.c_void_p]
     L.fasp_hip_precond_fct.restype = None
+    L.fasp_dcsrvec_read2.argtypes = [C.c_char_p, C.c_char_p, P(T.dCSRmat), P(T.dvector)]
+    L.fasp_dvec_read.argtypes = [C.c_char_p, P(T.dvector)]
+    L.fasp_dbsr_read.argtypes = [C.c_char_p, P(T.dBSRmat)]
+    L.fasp_hip_free_bsr.argtypes = [P(T.dBSRmat)]
+    L.fasp_hip_free_bsr.restype = None
     L.fasp_hip_param_input.argtypes = [C.c_char_p, P(T.ITS_param), P(T.AMG_param)]
     L.fasp_fwrapper_dcsr_krylov_amg_.argtypes = [P(C.c_int), P(C.c_int), T.c_int_p, T.c_int_p, T.c_double_p,
                                                  T.c_double_p, T.c_double_p, P(C.c_double), P(C.c_int), P(C.c_int)]

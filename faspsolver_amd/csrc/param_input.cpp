@@ -7,7 +7,9 @@
 // The reference parses with one hand-written strcmp block per keyword; here the same keywords,
 // value formats (fscanf %d / %lf / %s tokens, " = " with spaces, '%' '[' '|' comment lines, the
 // rest of a line ignored after the value) and the same range check are table-driven.  Pure host code.
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "fasp_internal.h"
@@ -309,6 +311,138 @@ int fasp_hip_param_input(const char* fname, ITS_param* itsparam, AMG_param* amgp
         if (!itsparam) p->maxit = p->maxit > 50 ? p->maxit : 50;  // AuxParam.c:63-65
     }
     return FASP_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// Readers of the reference's ASCII formats (BlaIO.c:164, :807, :938; data/ files of the reference).
+// They return an error code where the reference prints and exits (fasp_chkerr).  Arrays are
+// calloc'ed; release them with fasp_hip_free_system / free().
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int ERROR_WRONG_FILE = -11;  // fasp_const.h:23
+struct File {
+    FILE* fp;
+    explicit File(const char* name) : fp(std::fopen(name, "r")) {}
+    ~File() { if (fp) std::fclose(fp); }
+};
+// comment lines (% ! /) at the head of a data file, BlaIOUtil.inl:27
+int skip_comments(FILE* fp)
+{
+    for (;;) {
+        char buffer[500];
+        const long loc = std::ftell(fp);
+        if (fscanf(fp, "%499s", buffer) != 1) return ERROR_WRONG_FILE;
+        if (buffer[0] == '%' || buffer[0] == '!' || buffer[0] == '/') { skip_line(fp); continue; }
+        std::fseek(fp, loc, SEEK_SET);
+        return FASP_SUCCESS;
+    }
+}
+}  // namespace
+
+// BlaIO.c:164: matrix file "n / IA(n+1) / JA(nnz) / val(nnz)" with 1-based indices, rhs file "n / values"
+int fasp_dcsrvec_read2(const char* filemat, const char* filerhs, dCSRmat* A, dvector* b)
+{
+    if (!filemat || !filerhs || !A || !b) return ERROR_INPUT_PAR;
+    File fm(filemat);
+    if (!fm.fp) return ERROR_OPEN_FILE;
+    std::printf("%s: reading file %s ...\n", __func__, filemat);
+    int n, tmp;
+    if (skip_comments(fm.fp) < 0 || fscanf(fm.fp, "%d", &n) != 1 || n <= 0) return ERROR_WRONG_FILE;
+    A->row = A->col = n;
+    A->IA = static_cast<int*>(std::calloc((size_t)n + 1, sizeof(int)));
+    A->JA = nullptr; A->val = nullptr; b->val = nullptr;
+    auto fail = [&](int code) {
+        std::free(A->IA); std::free(A->JA); std::free(A->val); std::free(b->val);
+        A->IA = A->JA = nullptr; A->val = nullptr; b->val = nullptr;
+        return code;
+    };
+    for (int i = 0; i <= n; ++i) {
+        if (fscanf(fm.fp, "%d", &tmp) != 1) return fail(ERROR_WRONG_FILE);
+        A->IA[i] = tmp - 1;
+    }
+    const int nz = A->IA[n];
+    if (nz < 0) return fail(ERROR_WRONG_FILE);
+    A->nnz = nz;
+    A->JA = static_cast<int*>(std::calloc((size_t)std::max(nz, 1), sizeof(int)));
+    A->val = static_cast<double*>(std::calloc((size_t)std::max(nz, 1), sizeof(double)));
+    for (int i = 0; i < nz; ++i) {
+        if (fscanf(fm.fp, "%d", &tmp) != 1) return fail(ERROR_WRONG_FILE);
+        A->JA[i] = tmp - 1;
+    }
+    for (int i = 0; i < nz; ++i)
+        if (fscanf(fm.fp, "%le", &A->val[i]) != 1) return fail(ERROR_WRONG_FILE);
+    File fr(filerhs);
+    if (!fr.fp) return fail(ERROR_OPEN_FILE);
+    std::printf("%s: reading file %s ...\n", __func__, filerhs);
+    int nr;
+    if (fscanf(fr.fp, "%d", &nr) != 1) return fail(ERROR_WRONG_FILE);
+    if (nr != n) {
+        std::printf("### WARNING: rhs size = %d, matrix size = %d!\n", nr, n);
+        return fail(ERROR_MAT_SIZE);
+    }
+    b->row = n;
+    b->val = static_cast<double*>(std::calloc((size_t)n, sizeof(double)));
+    for (int i = 0; i < n; ++i)
+        if (fscanf(fr.fp, "%le", &b->val[i]) != 1) return fail(ERROR_WRONG_FILE);
+    return FASP_SUCCESS;
+}
+
+// BlaIO.c:938: "n / values"
+int fasp_dvec_read(const char* filename, dvector* b)
+{
+    if (!filename || !b) return ERROR_INPUT_PAR;
+    File f(filename);
+    if (!f.fp) return ERROR_OPEN_FILE;
+    std::printf("%s: reading file %s ...\n", __func__, filename);
+    int n;
+    if (skip_comments(f.fp) < 0 || fscanf(f.fp, "%d", &n) != 1 || n < 0) return ERROR_WRONG_FILE;
+    b->row = n;
+    b->val = static_cast<double*>(std::calloc((size_t)std::max(n, 1), sizeof(double)));
+    for (int i = 0; i < n; ++i) {
+        if (fscanf(f.fp, "%le", &b->val[i]) != 1) { std::free(b->val); b->val = nullptr; return ERROR_WRONG_FILE; }
+        if (b->val[i] > fasp::BIGREAL) {
+            std::printf("### ERROR: Wrong value = %lf!\n", b->val[i]);
+            std::free(b->val); b->val = nullptr;
+            return ERROR_INPUT_PAR;
+        }
+    }
+    return FASP_SUCCESS;
+}
+
+// BlaIO.c:807: "ROW COL NNZ / nb / storage_manner / n IA.. / n JA.. / n val.." with 0-based indices
+int fasp_dbsr_read(const char* filename, dBSRmat* A)
+{
+    if (!filename || !A) return ERROR_INPUT_PAR;
+    File f(filename);
+    if (!f.fp) return ERROR_OPEN_FILE;
+    std::printf("%s: reading file %s ...\n", __func__, filename);
+    int ROW, COL, NNZ, nb, sm, n;
+    if (skip_comments(f.fp) < 0 || fscanf(f.fp, "%d %d %d", &ROW, &COL, &NNZ) != 3 || fscanf(f.fp, "%d", &nb) != 1 ||
+        fscanf(f.fp, "%d", &sm) != 1 || ROW <= 0 || COL <= 0 || NNZ < 0 || nb <= 0)
+        return ERROR_WRONG_FILE;
+    A->ROW = ROW; A->COL = COL; A->NNZ = NNZ; A->nb = nb; A->storage_manner = sm;
+    A->IA = static_cast<int*>(std::calloc((size_t)ROW + 1, sizeof(int)));
+    A->JA = static_cast<int*>(std::calloc((size_t)std::max(NNZ, 1), sizeof(int)));
+    A->val = static_cast<double*>(std::calloc((size_t)std::max(NNZ, 1) * nb * nb, sizeof(double)));
+    auto fail = [&]() {
+        std::free(A->IA); std::free(A->JA); std::free(A->val);
+        A->IA = A->JA = nullptr; A->val = nullptr;
+        return ERROR_WRONG_FILE;
+    };
+    if (fscanf(f.fp, "%d", &n) != 1 || n != ROW + 1) return fail();
+    for (int i = 0; i < n; ++i) if (fscanf(f.fp, "%d", &A->IA[i]) != 1) return fail();
+    if (fscanf(f.fp, "%d", &n) != 1 || n != NNZ) return fail();
+    for (int i = 0; i < n; ++i) if (fscanf(f.fp, "%d", &A->JA[i]) != 1) return fail();
+    if (fscanf(f.fp, "%d", &n) != 1 || (long long)n != (long long)NNZ * nb * nb) return fail();
+    for (int i = 0; i < n; ++i) if (fscanf(f.fp, "%le", &A->val[i]) != 1) return fail();
+    return FASP_SUCCESS;
+}
+
+void fasp_hip_free_bsr(dBSRmat* A)
+{
+    if (!A) return;
+    std::free(A->IA); std::free(A->JA); std::free(A->val);
+    A->IA = A->JA = nullptr; A->val = nullptr;
 }
 
 // SolWrapper.c:261 -- Fortran callers: CALL FASP_FWRAPPER_DCSR_KRYLOV_AMG(n, nnz, ia, ja, a, b, u, tol, maxit, prtlvl).

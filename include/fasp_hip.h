@@ -289,6 +289,13 @@ double fasp_hip_time_bsr_mxv(const dBSRmat* A, int reps);
  * ini files (test/ini/, .dat).  fname == NULL: defaults.  Returns 0, ERROR_OPEN_FILE (-10) or
  * ERROR_INPUT_PAR; pure host code. */
 int  fasp_hip_param_input(const char* fname, ITS_param* itsparam, AMG_param* amgparam);
+/* Readers of the reference's ASCII data formats (base/src/BlaIO.c:164, :938, :807).  Same formats and
+ * messages; an error code is returned where the reference exits.  Arrays are malloc-family
+ * allocations: release with fasp_hip_free_system / fasp_hip_free_bsr / free(). */
+int  fasp_dcsrvec_read2(const char* filemat, const char* filerhs, dCSRmat* A, dvector* b);
+int  fasp_dvec_read(const char* filename, dvector* b);
+int  fasp_dbsr_read(const char* filename, dBSRmat* A);
+void fasp_hip_free_bsr(dBSRmat* A);
 /* Fortran-style wrapper, SolWrapper.c:261: parameters from "ini/amg.dat" in the working directory */
 void fasp_fwrapper_dcsr_krylov_amg_(int* n, int* nnz, int* ia, int* ja, double* a, double* b, double* u,
                                     double* tol, int* maxit, int* ptrlvl);

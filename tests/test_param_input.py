@@ -95,3 +95,32 @@ def test_fortran_wrapper(tmp_path, monkeypatch):
                                             ja2.ctypes.data_as(T.c_int_p), T.dp(a2), T.dp(f2), T.dp(u),
                                             C.byref(tol), C.byref(maxit), C.byref(prt))
     assert np.abs(u - x1).max() <= 1e-10 * np.abs(x1).max()
+
+
+def test_file_readers_on_shipped_data(tmp_path):
+    """fasp_dcsrvec_read2 / fasp_dvec_read / fasp_dbsr_read (BlaIO.c:164/:938/:807) on the reference's data files."""
+    from _libs import read_csr, read_vec, read_bsr
+    L = fa.lib()
+    A = T.dCSRmat(); b = T.dvector()
+    assert L.fasp_dcsrvec_read2((DATA + "/csrmat_FE.dat").encode(), (DATA + "/rhs_FE.dat").encode(), C.byref(A), C.byref(b)) == 0
+    ia, ja, a = read_csr(DATA + "/csrmat_FE.dat"); f = read_vec(DATA + "/rhs_FE.dat")
+    i2, j2, a2 = T.csr_arrays(A)
+    assert (A.row, A.col, A.nnz) == (len(ia) - 1, len(ia) - 1, len(a))
+    assert np.array_equal(i2, ia) and np.array_equal(j2, ja) and np.array_equal(a2, a)
+    assert np.array_equal(np.ctypeslib.as_array(b.val, (b.row,)), f)
+    L.fasp_hip_free_system(C.byref(A), C.byref(b), None)
+    v = T.dvector()
+    assert L.fasp_dvec_read((DATA + "/rhs_SPE01.dat").encode(), C.byref(v)) == 0
+    assert np.array_equal(np.ctypeslib.as_array(v.val, (v.row,)), read_vec(DATA + "/rhs_SPE01.dat"))
+    B = T.dBSRmat()
+    assert L.fasp_dbsr_read((DATA + "/bsrmat_SPE01.dat").encode(), C.byref(B)) == 0
+    bi, bj, bv, nb = read_bsr(DATA + "/bsrmat_SPE01.dat")
+    assert (B.ROW, B.NNZ, B.nb) == (len(bi) - 1, len(bj), nb)
+    assert np.array_equal(np.ctypeslib.as_array(B.IA, (B.ROW + 1,)), bi)
+    assert np.array_equal(np.ctypeslib.as_array(B.JA, (B.NNZ,)), bj)
+    assert np.array_equal(np.ctypeslib.as_array(B.val, (B.NNZ * nb * nb,)), bv)
+    L.fasp_hip_free_bsr(C.byref(B))
+    # errors instead of exits
+    assert L.fasp_dvec_read(str(tmp_path / "none.dat").encode(), C.byref(v)) == -10
+    bad = tmp_path / "bad.dat"; bad.write_text("3\n1 2\n")
+    assert L.fasp_dcsrvec_read2(str(bad).encode(), str(bad).encode(), C.byref(A), C.byref(b)) == -11
