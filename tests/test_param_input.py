@@ -124,3 +124,22 @@ def test_file_readers_on_shipped_data(tmp_path):
     assert L.fasp_dvec_read(str(tmp_path / "none.dat").encode(), C.byref(v)) == -10
     bad = tmp_path / "bad.dat"; bad.write_text("3\n1 2\n")
     assert L.fasp_dcsrvec_read2(str(bad).encode(), str(bad).encode(), C.byref(A), C.byref(b)) == -11
+
+
+@pytest.mark.gpu
+def test_c_driver_from_files(tmp_path):
+    """examples/solve_from_files.c: ini file + data files -> fasp_solver_dcsr_krylov_amg, plain C against the header."""
+    import subprocess
+    exe = tmp_path / "solve"
+    lib = os.path.join(ROOT, "faspsolver_amd")
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "solve_from_files.c"),
+                    "-o", str(exe), "-L", lib, "-lfasp_hip", f"-Wl,-rpath,{lib}", "-lm"], check=True)
+    r = subprocess.run([str(exe), os.path.join(ROOT, "examples", "amg_jacobi.dat"), DATA + "/csrmat_FE.dat",
+                        DATA + "/rhs_FE.dat"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("status")][0]
+    its = int(line.split("=")[1].split(",")[0]); rel = float(line.split("=")[-1])
+    ia, ja, a = __import__("_libs").read_csr(DATA + "/csrmat_FE.dat"); f = __import__("_libs").read_vec(DATA + "/rhs_FE.dat")
+    itp, amgp = default_params(); itp.tol = 1e-8; itp.maxit = 100; amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
+    s1, x1, h1, rr = orc_solve(ia, ja, a, f, itp, amgp)
+    assert its == s1 and rel < 1e-8
