@@ -233,9 +233,15 @@ def main():
                      "launches_timed": int(stats.spmv_launches) * args.steps,
                      "moved_bytes_per_launch": moved, "moved_GBps": moved_gbs,
                      "frac_of_peak_on_moved_bytes": moved_gbs / PEAK_HBM_GBS,
+                     "traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+                     "frac_of_peak_on_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
                      "note": ("achieved/frac use SURVEY 8(d)'s plain-CSR algorithmic bytes; the matrix is "
                               "stored losslessly coded, so frac > 1 means fewer bytes than plain CSR were "
-                              "moved, not that the HBM peak was exceeded") if kind >= 4 else None},
+                              "moved, not that the HBM peak was exceeded.  moved = compulsory bytes of the "
+                              "coded layout (pattern ids + x once + y once); traffic = memory-side bytes "
+                              "from the PMC pass (x is re-fetched by rows one grid plane away).  With the "
+                              "coding switched off (FASP_HIP_COMPRESS=0) the plain-CSR kernel of the same "
+                              "operator reaches 0.59-0.63 of peak (profiles/)") if kind >= 4 else None},
     }
     if not args.no_cpu_baseline:
         try:
