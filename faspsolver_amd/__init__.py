@@ -27,6 +27,8 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_blas_darray_norm2", "fasp_blas_darray_norminf", "fasp_blas_darray_axpy",
     "fasp_blas_darray_axpby", "fasp_smoother_dcsr_jacobi",
     "fasp_blas_dbsr_mxv", "fasp_blas_dbsr_aAxpy", "fasp_dbsr_getdiaginv", "fasp_smoother_dbsr_jacobi1",
+    "fasp_solver_dbsr_pcg", "fasp_solver_dbsr_pbcgs", "fasp_solver_dbsr_pgmres", "fasp_solver_dbsr_pvgmres",
+    "fasp_solver_dbsr_pvfgmres", "fasp_hip_bsr_precond_setup", "fasp_hip_bsr_precond_fct", "fasp_hip_bsr_precond_free",
     "fasp_hip_param_input", "fasp_fwrapper_dcsr_krylov_amg_", "fasp_dcsrvec_read2", "fasp_dvec_read",
     "fasp_dbsr_read", "fasp_hip_free_bsr", "fasp_hip_comm_selftest", "fasp_hip_amg_kernel_info", "fasp_hip_coding_selftest", "fasp_solver_amg", "fasp_hip_amg_solve", "fasp_solver_dcsr_pcg", "fasp_solver_dcsr_pbcgs", "fasp_solver_dcsr_pgmres", "fasp_solver_dcsr_pvgmres",
     "fasp_solver_dcsr_pvfgmres", "fasp_hip_precond_setup", "fasp_hip_precond_fct", "fasp_hip_precond_free",
@@ -100,6 +102,19 @@ def lib():
     L.fasp_hip_precond_free.restype = None
     L.fasp_hip_precond_fct.argtypes = [T.c_double_p, T.c_double_p, C.c_void_p]
     L.fasp_hip_precond_fct.restype = None
+    L.fasp_solver_dbsr_pcg.argtypes = [P(T.dBSRmat), P(T.dvector), P(T.dvector), P(T.precond), C.c_double,
+                                       C.c_double, C.c_int, C.c_short, C.c_short]
+    L.fasp_solver_dbsr_pbcgs.argtypes = L.fasp_solver_dbsr_pcg.argtypes
+    L.fasp_solver_dbsr_pvgmres.argtypes = [P(T.dBSRmat), P(T.dvector), P(T.dvector), P(T.precond), C.c_double,
+                                           C.c_double, C.c_int, C.c_short, C.c_short, C.c_short]
+    L.fasp_solver_dbsr_pgmres.argtypes = L.fasp_solver_dbsr_pvgmres.argtypes
+    L.fasp_solver_dbsr_pvfgmres.argtypes = L.fasp_solver_dbsr_pvgmres.argtypes
+    L.fasp_hip_bsr_precond_setup.argtypes = [P(T.dBSRmat), P(T.AMG_param)]
+    L.fasp_hip_bsr_precond_setup.restype = P(T.precond)
+    L.fasp_hip_bsr_precond_free.argtypes = [P(T.precond)]
+    L.fasp_hip_bsr_precond_free.restype = None
+    L.fasp_hip_bsr_precond_fct.argtypes = [T.c_double_p, T.c_double_p, C.c_void_p]
+    L.fasp_hip_bsr_precond_fct.restype = None
     L.fasp_dcsrvec_read2.argtypes = [C.c_char_p, C.c_char_p, P(T.dCSRmat), P(T.dvector)]
     L.fasp_dvec_read.argtypes = [C.c_char_p, P(T.dvector)]
     L.fasp_dbsr_read.argtypes = [C.c_char_p, P(T.dBSRmat)]

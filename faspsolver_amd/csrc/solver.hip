@@ -3084,6 +3084,118 @@ int fasp_solver_dcsr_pvfgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, c
     return krylov_plugin(__func__, 2, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 
+// ---- the same plug-in level for block matrices ---------------------------------
+// z = B r with the resident block hierarchy (PreBSR.c:1149 signature); data = fasp_hip_amg_bsr*
+void fasp_hip_bsr_precond_fct(double* r, double* z, void* data)
+{
+    fasp_hip_amg_bsr* h = static_cast<fasp_hip_amg_bsr*>(data);
+    if (!h || h->L.empty() || ctx_init() < 0) die_bsr(__func__);
+    const int n = h->L[0].n;
+    TmpVec dr(r, (size_t)n);
+    double* dz = nullptr;
+    if (!dr.d || precond_amg_bsr(h, dr.d, &dz) < 0) die_bsr(__func__);
+    (void)hipStreamSynchronize(g_ctx.stream);
+    (void)hipMemcpy(z, dz, sizeof(double) * n, hipMemcpyDeviceToHost);
+}
+
+precond* fasp_hip_bsr_precond_setup(dBSRmat* A, AMG_param* amgparam)
+{
+    fasp_hip_amg_bsr* h = nullptr;
+    if (fasp_hip_bsr_amg_create(&h, A, amgparam) < 0) return nullptr;
+    precond* pc = static_cast<precond*>(std::calloc(1, sizeof(precond)));
+    pc->data = h;
+    pc->fct = fasp_hip_bsr_precond_fct;
+    return pc;
+}
+
+void fasp_hip_bsr_precond_free(precond* pc)
+{
+    if (!pc) return;
+    if (pc->fct == fasp_hip_bsr_precond_fct) fasp_hip_bsr_amg_destroy(static_cast<fasp_hip_amg_bsr*>(pc->data));
+    std::free(pc);
+}
+
+namespace {
+int krylov_plugin_bsr(const char* fn, int which, dBSRmat* A, dvector* b, dvector* u, precond* pc, double tol,
+                      double abstol, int MaxIt, short restart, short StopType, short PrtLvl)
+{
+    if (!A || !b || !u || A->ROW != A->COL || b->row != A->ROW * A->nb || u->row != b->row) return ERROR_INPUT_PAR;
+    TmpBSR M(A);
+    if (!M.ok) die_bsr(fn);
+    const int n = b->row;
+    fasp_hip_amg_bsr* h = (pc && pc->fct == fasp_hip_bsr_precond_fct) ? static_cast<fasp_hip_amg_bsr*>(pc->data) : nullptr;
+    if (h && (h->L.empty() || h->L[0].n != n)) return ERROR_INPUT_PAR;
+    TmpVec db(b->val, n), du(u->val, n), dp(nullptr, n), dt(nullptr, n), dr(nullptr, n), dz(nullptr, n);
+    if (!db.d || !du.d || !dp.d || !dt.d || !dr.d || !dz.d) return ERROR_ALLOC_MEM;
+    std::vector<double> hr, hz;
+    std::vector<double*> ws;
+    size_t ws_len = 0;
+    double* hh = nullptr;
+    KOps K;
+    K.n = n; K.nvec = (size_t)n; K.fmt = "BSR"; K.dist = false;
+    K.halo = [](double*) { return 0; };
+    const TmpBSR* Mp = &M;
+    K.mxv = [Mp](const double* x, double* y) { bsr_mxv(*Mp, x, y); };
+    K.resid = [Mp](const double* x, const double* bb, double* r) { bsr_resid(*Mp, x, bb, r); };
+    if (h) {
+        K.pc = [h](double* in, double** out) { return precond_amg_bsr(h, in, out); };
+    } else if (pc && pc->fct) {
+        hr.resize((size_t)n); hz.resize((size_t)n);
+        K.pc = [&, pc](double* in, double** out) {
+            HIPCK(hipMemcpyAsync(hr.data(), in, sizeof(double) * n, hipMemcpyDeviceToHost, g_ctx.stream));
+            HIPCK(hipStreamSynchronize(g_ctx.stream));
+            pc->fct(hr.data(), hz.data(), pc->data);
+            HIPCK(hipMemcpyAsync(dz.d, hz.data(), sizeof(double) * n, hipMemcpyHostToDevice, g_ctx.stream));
+            *out = dz.d;
+            return 0;
+        };
+    }
+    K.ws = &ws; K.ws_len = &ws_len; K.hh = &hh;
+    Hist   H{nullptr, 0, 0};
+    PcgOut po{BIGREAL, BIGREAL, BIGREAL};
+    int st;
+    if (which == 0) {
+        PcgVecs V{db.d, du.d, dp.d, dt.d, dr.d};
+        st = pcg_device(K, V, tol, abstol, MaxIt, StopType, PrtLvl, H, po);
+    } else if (which == 3) {
+        st = bicgstab_device(K, db.d, du.d, tol, MaxIt, PrtLvl, &H, &po);
+    } else {
+        st = gmres_device(K, db.d, du.d, which == 2 ? 1 : which == 4 ? 3 : 0, tol, abstol, MaxIt, restart, StopType, PrtLvl, &H, &po);
+    }
+    du.get(u->val);
+    for (double* q : ws) if (q) (void)hipFree(q);
+    if (hh) (void)hipFree(hh);
+    return st;
+}
+}  // namespace
+
+// KryPcg.c:386, KryPbcgs.c:400, KryPgmres.c:357, KryPvgmres.c:416, KryPvfgmres.c:386
+int fasp_solver_dbsr_pcg(dBSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                         const int MaxIt, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin_bsr(__func__, 0, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+int fasp_solver_dbsr_pbcgs(dBSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                           const int MaxIt, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin_bsr(__func__, 3, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+int fasp_solver_dbsr_pgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                            const int MaxIt, const short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin_bsr(__func__, 4, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+int fasp_solver_dbsr_pvgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                             const int MaxIt, const short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin_bsr(__func__, 1, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+int fasp_solver_dbsr_pvfgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                              const int MaxIt, const short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin_bsr(__func__, 2, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+
 void fasp_blas_dcsr_mxv(const dCSRmat* A, const double* x, double* y)
 {
     TmpCSR M(A);

@@ -422,6 +422,25 @@ precond* fasp_hip_precond_setup(dCSRmat* A, AMG_param* amgparam);
 void     fasp_hip_precond_fct(double* r, double* z, void* data);
 void     fasp_hip_precond_free(precond* pc);
 
+/* The same plug-in level for block matrices (KryPcg.c:386, KryPbcgs.c:400, KryPgmres.c:357,
+ * KryPvgmres.c:416, KryPvfgmres.c:386; PreBSR.c:1149 for the preconditioner action). */
+int fasp_solver_dbsr_pcg(dBSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
+                         const double abstol, const int MaxIt, const short StopType, const short PrtLvl);
+int fasp_solver_dbsr_pbcgs(dBSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
+                           const double abstol, const int MaxIt, const short StopType, const short PrtLvl);
+int fasp_solver_dbsr_pgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
+                            const double abstol, const int MaxIt, const short restart,
+                            const short StopType, const short PrtLvl);
+int fasp_solver_dbsr_pvgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
+                             const double abstol, const int MaxIt, const short restart,
+                             const short StopType, const short PrtLvl);
+int fasp_solver_dbsr_pvfgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
+                              const double abstol, const int MaxIt, const short restart,
+                              const short StopType, const short PrtLvl);
+precond* fasp_hip_bsr_precond_setup(dBSRmat* A, AMG_param* amgparam);
+void     fasp_hip_bsr_precond_fct(double* r, double* z, void* data);
+void     fasp_hip_bsr_precond_free(precond* pc);
+
 /* One application of the AMG preconditioner z = B r (PreCSR.c:416) on the
  * resident hierarchy; host vectors in/out. */
 int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z);

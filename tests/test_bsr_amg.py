@@ -194,3 +194,61 @@ def test_gpu_bsr_spe01_one_level():
     print("SPE01 true relres oracle %.6e gpu %.6e" % (r1, r2))
     assert 0.5 * r1 <= r2 <= 2.0 * r1
     G.free()
+
+
+# ---- plug-in level for block matrices (fasp_solver_dbsr_pcg / _pbcgs / _pgmres / _pvgmres / _pvfgmres) ----
+def _bsr_plugin(lib_, which, ia, ja, val, nb, f, pc, tol=1e-8, maxit=500, restart=30):
+    names = ["fasp_solver_dbsr_pcg", "fasp_solver_dbsr_pvgmres", "fasp_solver_dbsr_pvfgmres", "fasp_solver_dbsr_pbcgs",
+             "fasp_solver_dbsr_pgmres"]
+    fn = getattr(lib_, names[which])
+    base = [C.POINTER(T.dBSRmat), C.POINTER(T.dvector), C.POINTER(T.dvector), C.c_void_p, C.c_double, C.c_double, C.c_int]
+    fn.argtypes = base + ([C.c_short, C.c_short] if which in (0, 3) else [C.c_short, C.c_short, C.c_short])
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    x = np.zeros(len(f)); bv, fk = T.as_vec(f); xv = T.dvector(len(f), T.dp(x))
+    args = (C.byref(A), C.byref(bv), C.byref(xv), pc, tol, 1e-18, maxit)
+    st = fn(*args, 1, 0) if which in (0, 3) else fn(*args, restart, 1, 0)
+    return st, x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,solver", [(0, 1), (1, 5), (2, 6), (3, 2), (4, 4)])
+def test_gpu_bsr_plugin_with_device_amg_equals_dropin(which, solver):
+    ia, ja, val, nb, f = synthetic(12)
+    itp, amgp = bsr_params(solver)
+    x1 = np.zeros(len(f))
+    s1 = fa.solver_dbsr_krylov_amg(ia, ja, val, nb, f, x1, itp, amgp)
+    _, amgp2 = bsr_params(solver)
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    pc = fa.lib().fasp_hip_bsr_precond_setup(C.byref(A), C.byref(amgp2))
+    assert pc
+    s2, x2 = _bsr_plugin(fa.lib(), which, ia, ja, val, nb, f, C.cast(pc, C.c_void_p))
+    fa.lib().fasp_hip_bsr_precond_free(pc)
+    assert s1 == s2 and s1 > 0
+    assert np.array_equal(x1, x2)
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("which", [0, 1, 3])
+def test_gpu_bsr_plugin_host_callback_matches_reference(which):
+    """A caller-supplied precond (block-diagonal scaling as a host function) through the device Krylov
+    methods, against the REFERENCE's own fasp_solver_dbsr_* with the same callback."""
+    from _libs import ref
+    ia, ja, val, nb, f = synthetic(10)
+    nrow = len(ia) - 1
+    dinv = np.zeros((nrow, nb, nb))
+    for i in range(nrow):
+        for k in range(ia[i], ia[i + 1]):
+            if ja[k] == i:
+                dinv[i] = np.linalg.inv(val[k * nb * nb:(k + 1) * nb * nb].reshape(nb, nb))
+
+    def fct(r, z, data):
+        rv = np.ctypeslib.as_array(r, (nrow * nb,)).reshape(nrow, nb)
+        zv = np.ctypeslib.as_array(z, (nrow * nb,)).reshape(nrow, nb)
+        zv[:] = np.einsum("ijk,ik->ij", dinv, rv)
+    cb = T.PRECOND_FCT(fct)
+    pcs = T.precond(None, cb)
+    s1, x1 = _bsr_plugin(ref(), which, ia, ja, val, nb, f, C.cast(C.pointer(pcs), C.c_void_p))
+    s2, x2 = _bsr_plugin(fa.lib(), which, ia, ja, val, nb, f, C.cast(C.pointer(pcs), C.c_void_p))
+    assert s1 == s2 and s1 > 0
+    assert np.abs(x1 - x2).max() <= 1e-9 * np.abs(x1).max()
