@@ -4,7 +4,7 @@
 // config 3: 185 block rows), and the reference solves it iteratively to 1e-10 / 1e-6: hundreds
 // of Krylov iterations per cycle, thousands per solve.  Driven from the host, every iteration
 // costs launches plus one synchronisation (30-100 us) for a few microseconds of arithmetic.
-// Here the whole solver -- control flow included -- runs inside one 1024-thread workgroup: every
+// Here the whole solver -- control flow included -- runs inside one 512-thread workgroup: every
 // thread evaluates the scalar recurrences redundantly from block reductions that all threads
 // sum in the same fixed order, so branches are uniform without any flag traffic; vectors live
 // in global memory (L1/L2 resident at these sizes) and are made visible between phases by
@@ -23,7 +23,7 @@
 
 namespace fasp {
 
-constexpr int SMALL_BLOCK = 1024;
+constexpr int SMALL_BLOCK = 512;
 constexpr int SMALL_WAVES = SMALL_BLOCK / 64;
 constexpr int SMALL_MAX_RESTART = 32;
 
@@ -115,7 +115,33 @@ struct SmallBSR {
         for (int row = threadIdx.x; row < ROW * nb; row += SMALL_BLOCK) {
             const int br = row / nb, r = row - br * nb;
             double acc = seed ? -seed[row] : 0.0;
-            for (int k = ia[br], ke = ia[br + 1]; k < ke; ++k) {
+            int k = ia[br];
+            const int ke = ia[br + 1];
+            if (nb == 3) {  // four blocks' loads in flight (the common block size; same arithmetic order)
+                for (; k + 3 < ke; k += 4) {
+                    int    j[4];
+                    double av[4][3], xv[4][3];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        j[q] = ja[k + q];
+                        const double* A = val + (size_t)(k + q) * 9 + r * 3;
+                        av[q][0] = A[0]; av[q][1] = A[1]; av[q][2] = A[2];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double* xb = x + (size_t)j[q] * 3;
+                        xv[q][0] = xb[0]; xv[q][1] = xb[1]; xv[q][2] = xb[2];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        double s = av[q][0] * xv[q][0];
+                        s = s + av[q][1] * xv[q][1];
+                        s = s + av[q][2] * xv[q][2];
+                        acc += s;
+                    }
+                }
+            }
+            for (; k < ke; ++k) {
                 const double* A = val + (size_t)k * nb2 + r * nb;
                 const double* xb = x + (size_t)ja[k] * nb;
                 double s = A[0] * xb[0];
@@ -156,21 +182,36 @@ struct SpcgArgs {
     double   tol;
     int      MaxIt;
     int      x_zero;  // the iterate is zero on entry (skips the first matrix pass)
+    int      nnz;
     SmallOut* out;
 };
 
+// LV: the five work vectors live in dynamic LDS (5 m doubles); LM: so does the matrix (copied once):
+// every iteration then runs out of LDS, global memory is touched at entry (b, u) and exit (u) only.
+template <bool LV, bool LM>
 __global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_small(SpcgArgs a)
 {
     __shared__ double sh[SMALL_WAVES * 5];
-    const SmallCSR A = a.A;
+    extern __shared__ double dyn[];
+    SmallCSR A = a.A;
     const int m = A.m, tid = threadIdx.x;
+    if (LM) {  // layout: [5 m doubles | val (nnz doubles) | ja (nnz ints) | ia (m + 1 ints)]
+        const int nnz = a.nnz;
+        double* lval = dyn + 5 * (size_t)m;
+        int*    lja  = reinterpret_cast<int*>(lval + nnz);
+        int*    lia  = lja + nnz;
+        for (int i = tid; i < nnz; i += SMALL_BLOCK) { lval[i] = a.A.val[i]; lja[i] = a.A.ja[i]; }
+        for (int i = tid; i <= m; i += SMALL_BLOCK) lia[i] = a.A.ia[i];
+        A.val = lval; A.ja = lja; A.ia = lia;
+    }
     const double tol = a.tol, maxdiff = tol * 1e-4 /* STAG_RATIO */, sol_inf_tol = 1e-20;
     const double BIG = 1e+20, SMALL = 1e-20, SMALL2 = 1e-40;
     const int MaxIt = a.MaxIt, MAX_STAG = 20, MAX_RESTART = 20;
     int iter = 0, stag = 1, more_step = 1, iter_best = 0;
     double absres0 = BIG, absres = BIG, relres = BIG, normu, normr0 = BIG;
     double reldiff, alpha = 0.0, beta, temp1, temp2, absres_best = BIG;
-    double *u = a.u, *p = a.p, *r = a.r, *t = a.t, *u_best = a.u_best;
+    double *u = LV ? dyn : a.u, *p = LV ? dyn + m : a.p, *r = LV ? dyn + 2 * (size_t)m : a.r,
+           *t = LV ? dyn + 3 * (size_t)m : a.t, *u_best = LV ? dyn + 4 * (size_t)m : a.u_best;
     const double* b = a.b;
     double red[5];
 
@@ -179,6 +220,7 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_small(SpcgArgs a)
         for (int i = tid; i < m; i += SMALL_BLOCK) { r[i] = b[i]; u[i] = 0.0; }
         __syncthreads();
     } else {
+        if (LV) for (int i = tid; i < m; i += SMALL_BLOCK) u[i] = a.u[i];
         __syncthreads();
         small_resid(A, u, b, r);
     }
@@ -270,6 +312,10 @@ RESTORE_BESTSOL:
         }
     }
 FINISHED:
+    if (LV) {
+        __syncthreads();
+        for (int i = tid; i < m; i += SMALL_BLOCK) a.u[i] = u[i];
+    }
     if (tid == 0) {
         a.out->iters = iter > 0 ? (iter > MaxIt ? MaxIt : iter) : 0;
         a.out->status = iter > MaxIt ? -48 : iter;  // ERROR_SOLVER_MAXIT
@@ -453,10 +499,12 @@ struct GmresArgs {
     SmallOut*     out;
 };
 
-template <class OP>
+// LV: the Krylov basis p[0..restart] and w live in dynamic LDS ((restart + 2) n doubles) instead of a.ws
+template <class OP, bool LV>
 __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
 {
     constexpr int R = SMALL_MAX_RESTART;
+    extern __shared__ double dyn[];
     __shared__ double sh[SMALL_WAVES];
     __shared__ double hh[(R + 1) * R];  // hh[j][k] -> hh[j * R + k]
     __shared__ double rs[R + 2], c[R + 1], sn[R + 1];
@@ -469,8 +517,9 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
     double r_norm, r_norm_old = 0.0, absres0, absres = 1e+20, relres, cr = 1.0, t;
     const double* b = a.b;
     double* x = a.x;
-    auto P = [&](int k) { return a.ws + (size_t)k * n; };
-    double* w = a.ws + (size_t)(a.restart + 1) * n;
+    double* const basis = LV ? dyn : a.ws;
+    auto P = [&](int k) { return basis + (size_t)k * n; };
+    double* w = basis + (size_t)(a.restart + 1) * n;
 
     small_resid(A, x, b, P(0));
     r_norm = sqrt(blk_dot(n, P(0), P(0), sh));

@@ -492,7 +492,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 8; };
+struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 8, small_lds = 1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -1065,8 +1065,22 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         SpcgArgs a{};
         a.A = SmallCSR{m, A.ia, A.ja, A.val};
         a.b = D.b; a.u = D.x; a.p = h->cp; a.r = h->cr; a.t = h->ct; a.u_best = h->cbest;
-        a.tol = tol; a.MaxIt = MaxIt; a.x_zero = D.x_zero ? 1 : 0; a.out = small_out_dev();
-        hipLaunchKernelGGL(k_spcg_small, dim3(1), dim3(SMALL_BLOCK), 0, g_ctx.stream, a);
+        a.tol = tol; a.MaxIt = MaxIt; a.x_zero = D.x_zero ? 1 : 0; a.out = small_out_dev(); a.nnz = A.nnz;
+        // everything in LDS when it fits: vectors 5 m doubles, matrix 12 nnz + 4 (m + 1) bytes
+        const size_t lds_v = sizeof(double) * 5 * (size_t)m;
+        const size_t lds_m = 12 * (size_t)A.nnz + 4 * ((size_t)m + 1);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)k_spcg_small<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_spcg_small<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr = true;
+        }
+        if (g_tune.small_lds && lds_v + lds_m <= 148 * 1024)
+            hipLaunchKernelGGL((k_spcg_small<true, true>), dim3(1), dim3(SMALL_BLOCK), lds_v + lds_m, g_ctx.stream, a);
+        else if (g_tune.small_lds && lds_v <= 148 * 1024)
+            hipLaunchKernelGGL((k_spcg_small<true, false>), dim3(1), dim3(SMALL_BLOCK), lds_v, g_ctx.stream, a);
+        else
+            hipLaunchKernelGGL((k_spcg_small<false, false>), dim3(1), dim3(SMALL_BLOCK), 0, g_ctx.stream, a);
         D.x_zero = false;
         SmallOut o;
         if (small_out_fetch(o) < 0) return ERROR_MISC;
@@ -2242,7 +2256,16 @@ ForwardSweep:
             a.A = SmallBSR{Ac.ROW, Ac.nb, Ac.ia, Ac.ja, Ac.val};
             a.b = Lc.b; a.x = Lc.x; a.ws = h->small_ws; a.tol = ctol; a.abstol = atol;
             a.MaxIt = cmaxit; a.restart = 25; a.out = small_out_dev();
-            hipLaunchKernelGGL(k_gmres_small<SmallBSR>, dim3(1), dim3(SMALL_BLOCK), 0, s, a);
+            const size_t lds = sizeof(double) * (size_t)(25 + 2) * (size_t)csize;
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void*)k_gmres_small<SmallBSR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                attr = true;
+            }
+            if (g_tune.small_lds && lds <= 140 * 1024)
+                hipLaunchKernelGGL((k_gmres_small<SmallBSR, true>), dim3(1), dim3(SMALL_BLOCK), lds, s, a);
+            else
+                hipLaunchKernelGGL((k_gmres_small<SmallBSR, false>), dim3(1), dim3(SMALL_BLOCK), 0, s, a);
             SmallOut o;
             if (small_out_fetch(o) < 0) return ERROR_MISC;
             st = o.status;
@@ -3366,6 +3389,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "lds_tab")) g_tune.lds_tab = value;
     else if (!std::strcmp(key, "xcd_pat")) g_tune.xcd_pat = value;
     else if (!std::strcmp(key, "spcg_batch")) g_tune.spcg_batch = value;
+    else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;
     else if (!std::strcmp(key, "wcap")) g_tune.wcap = value;
