@@ -1085,6 +1085,7 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         SmallOut o;
         if (small_out_fetch(o) < 0) return ERROR_MISC;
         h->coarse_iters += o.iters;
+        if (std::getenv("FASP_HIP_DEBUG_COARSE")) std::printf("[coarse small] status %d iters %d relres %.6e\n", o.status, o.iters, o.relres);
         return o.status;
     }
     const double maxdiff = tol * STAG_RATIO;
@@ -1126,6 +1127,7 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         SpcgState S{};
         S.temp1 = temp1; S.temp1_prev = temp1; S.absres_best = absres_best; S.normr0 = normr0; S.tol = tol;
         S.maxdiff = maxdiff; S.iter = 0; S.iter_best = 0; S.stag = stag; S.MaxIt = MaxIt; S.stop = SPCG_RUN;
+        S.absres = absres; S.relres = relres; S.alpha = 0.0;  // values before the first iteration
         HIPCK(hipMemcpyAsync(h->spcg_state, &S, sizeof(S), hipMemcpyHostToDevice, s));
         for (;;) {
             for (int q = 0; q < batch; ++q) {
@@ -1146,8 +1148,10 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
             // a test fired in iteration S.iter: finish that iteration as the reference does
             temp2 = S.tp; temp1 = S.temp1_prev;
             red[0] = S.rr; red[1] = S.uu; red[2] = S.pp; red[3] = S.maxu; red[4] = S.nan;
-            if (S.stop == SPCG_DIV0) goto RESTORE_BESTSOL;
+            // (on a breakdown the step kernel leaves absres / relres of the PREVIOUS iteration in the state,
+            // which is what the reference's variables hold when it jumps to RESTORE_BESTSOL, KrySPcg.c:176)
             alpha = S.alpha; absres = S.absres; relres = S.relres;
+            if (S.stop == SPCG_DIV0) goto RESTORE_BESTSOL;
             factor = absres / absres0; (void)factor; (void)alpha;
             if (S.stop == SPCG_NAN) { absres = BIGREAL; goto RESTORE_BESTSOL; }
             if (S.stop == SPCG_SOLSTAG) { iter = ERROR_SOLVER_SOLSTAG; break; }  // Check I
@@ -1197,6 +1201,7 @@ RESTORE_BESTSOL:
         }
     }
 FINISHED:
+    if (std::getenv("FASP_HIP_DEBUG_COARSE")) std::printf("[coarse batched] iter %d relres %.6e absres %.6e best %d\n", iter, relres, absres, iter_best);
     if (iter > 0) h->coarse_iters += iter;
     if (iter > MaxIt) return ERROR_SOLVER_MAXIT;
     return iter;

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from _libs import (DATA, OrcAMG, T, default_params, oracle, orc_solve, poisson7pt, read_csr,
+from _libs import (DATA, ROOT, OrcAMG, T, default_params, oracle, orc_solve, poisson7pt, read_csr,
                    read_vec, read_vecind)
 
 pytestmark = pytest.mark.gpu
@@ -326,3 +326,33 @@ def test_linearity_and_roundtrip_midsize(gpu):
     r = b.copy()
     oracle().orc_aAxpy(-1.0, C.byref(A), T.dp(x), T.dp(r))
     assert np.linalg.norm(r) / np.linalg.norm(b) < 1e-8
+
+
+def test_host_batched_coarse_path_matches_oracle(gpu):
+    """Small coarsest levels are normally solved by the single-workgroup kernels; FASP_HIP_SMALL_COARSE=0 sends them
+    through the batched full-chip path (device-resident state, queued iterations) that large coarsest levels use.
+    Same scenarios, same verdicts -- including the breakdown / safety-net branches of the coarse safe CG."""
+    import subprocess, sys, os
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import faspsolver_amd as fa
+from faspsolver_amd import _types as T
+from _libs import default_params, orc_solve, poisson7pt
+def jac(i, p): i.tol = 1e-8; p.smoother = T.SMOOTHER_JACOBI; p.relaxation = 0.6667
+def modrel(i, p): jac(i, p); i.stop_type = T.STOP_MOD_REL_RES
+def wcyc(i, p): jac(i, p); p.cycle_type = T.W_CYCLE
+def scal(i, p): jac(i, p); p.coarse_scaling = 1
+for n, mod in ((10, modrel), (16, jac), (12, wcyc), (20, scal)):
+    ia, ja, a, f, ue = poisson7pt(n)
+    i1, a1 = default_params(); mod(i1, a1); i2, a2 = default_params(); mod(i2, a2)
+    s1, x1, h1, rr = orc_solve(ia, ja, a, f, i1, a1)
+    x2 = np.zeros(len(f))
+    s2 = fa.solver_dcsr_krylov_amg(ia, ja, a, f, x2, i2, a2)
+    assert s1 == s2, (n, mod.__name__, s1, s2)
+    assert np.abs(x1 - x2).max() <= 1e-8 * np.abs(x1).max(), (n, mod.__name__)
+print("OK")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, FASP_HIP_SMALL_COARSE="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
