@@ -343,7 +343,8 @@ def jac(i, p): i.tol = 1e-8; p.smoother = T.SMOOTHER_JACOBI; p.relaxation = 0.66
 def modrel(i, p): jac(i, p); i.stop_type = T.STOP_MOD_REL_RES
 def wcyc(i, p): jac(i, p); p.cycle_type = T.W_CYCLE
 def scal(i, p): jac(i, p); p.coarse_scaling = 1
-for n, mod in ((10, modrel), (16, jac), (12, wcyc), (20, scal)):
+def two(i, p): jac(i, p); p.max_levels = 2   # coarsest = level 1: thousands of rows (loop version of the step kernel)
+for n, mod in ((10, modrel), (16, jac), (12, wcyc), (20, scal), (24, two), (30, two)):
     ia, ja, a, f, ue = poisson7pt(n)
     i1, a1 = default_params(); mod(i1, a1); i2, a2 = default_params(); mod(i2, a2)
     s1, x1, h1, rr = orc_solve(ia, ja, a, f, i1, a1)
