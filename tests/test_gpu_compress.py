@@ -84,6 +84,27 @@ def test_coded_levels_present_and_rows_per_lane_variants():
 
 
 @pytest.mark.gpu
+def test_pattern_table_in_global_memory_variant():
+    """Pattern tables too large for LDS stay in global memory (LDS_TAB = false); forced here with
+    fasp_hip_tune("lds_tab", 0) and compared bit for bit with the plain kernels; also 2 rows per lane."""
+    ia, ja, a, f, ue = poisson7pt(28)
+    itp, amgp = _params()
+    H = fa.AMG(ia, ja, a, amgp)
+    L = fa.lib()
+    r = np.random.default_rng(3).standard_normal(len(f))
+    L.fasp_hip_tune(b"compress", 0); z_plain = H.precond(r)
+    L.fasp_hip_tune(b"compress", 1)
+    out = {}
+    for lds, rpl in ((1, 1), (0, 1), (0, 2), (1, 2)):
+        L.fasp_hip_tune(b"lds_tab", lds); L.fasp_hip_tune(b"rpl", rpl)
+        out[(lds, rpl)] = H.precond(r)
+    L.fasp_hip_tune(b"lds_tab", 1); L.fasp_hip_tune(b"rpl", -1)
+    for k, z in out.items():
+        assert np.array_equal(z, z_plain), k
+    H.close()
+
+
+@pytest.mark.gpu
 def test_dict8_fallback_bit_identical():
     """FASP_HIP_ROWPAT=0 leaves the per-entry byte coding (k_csr_dict8) as the coded path."""
     code = r'''
