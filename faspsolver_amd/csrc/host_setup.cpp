@@ -930,9 +930,19 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
         while (H.L[lvl].A.row > min_cdof && lvl < max_lvls - 1) {
             HostLevel& Lv = H.L[lvl];
             Pattern    S;
+            static const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
+            double tp = wall_seconds();
+            auto lap = [&](const char* what) {
+                if (!timing) return;
+                const double now = wall_seconds();
+                std::printf("  [setup level %d] %-12s %8.3f s\n", lvl, what, now - tp);
+                tp = now;
+            };
             status = strength_compressed(Lv.A, *param, S);
+            lap("strength");
             int col = -1;
             if (status >= 0) col = cfsplitting_cls(S, vertices.data());
+            lap("C/F split");
             if (status < 0 || col <= 0) {  // Check 1, PreAMGSetupRS.c:162-173
                 if (prtlvl > PRINT_MIN) {
                     std::printf("### WARNING: Could not find any C-variables!\n");
@@ -942,6 +952,7 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
                 break;
             }
             col = clean_ff_couplings(S, vertices.data(), Lv.A.row, col);
+            lap("FF clean-up");
             if (col < MIN_CDOF) break;  // Check 2, :176-181
             if (Lv.A.row > col * 10.0) {  // Check 3, :184-195
                 if (prtlvl > PRINT_MIN) {
@@ -955,9 +966,12 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
             std::memcpy(Lv.cfmark.data(), vertices.data(), (size_t)Lv.A.row * sizeof(int));
 
             build_interp_dir(Lv.A, S, vertices.data(), *param, Lv.P);  // :209
+            lap("interpolation");
             transpose_csr(Lv.P, Lv.R);                                 // :212
+            lap("transpose");
             H.L.emplace_back();
             galerkin_rap(H.L[lvl].R, H.L[lvl].A, H.L[lvl].P, H.L[lvl + 1].A);  // :213
+            lap("RAP");
             H.L[lvl].has_coarse = true;
             ++lvl;
             const HostCSR& Ac = H.L[lvl].A;
