@@ -31,6 +31,7 @@ PRINT_NONE, PRINT_MIN, PRINT_SOME, PRINT_MORE, PRINT_MOST, PRINT_ALL = 0, 1, 2, 
 SOLVER_DEFAULT, SOLVER_CG, SOLVER_VGMRES, SOLVER_VFGMRES = 0, 1, 5, 6
 SOLVER_BiCGstab = 2
 SOLVER_GMRES = 4
+SOLVER_MinRes, SOLVER_GCG, SOLVER_GCR = 3, 7, 8
 STOP_REL_RES, STOP_REL_PRECRES, STOP_MOD_REL_RES = 1, 2, 3
 PREC_NULL, PREC_DIAG, PREC_AMG, PREC_FMG = 0, 1, 2, 3
 CLASSIC_AMG, SA_AMG, UA_AMG = 1, 2, 3

@@ -158,7 +158,16 @@ int cfsplitting_cls(const Pattern& S, int* vec)
     const int row = S.row;
     int       col = 0, num_left = 0;
     Pattern   ST;
+    static const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
+    double tp = wall_seconds();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const double now = wall_seconds();
+        std::printf("      [C/F] %-12s %8.3f s\n", what, now - tp);
+        tp = now;
+    };
     transpose_pattern(S, ST);
+    lap("S^T");
 
     std::vector<int> lambda(row);
     int              maxdeg = 0;
@@ -194,6 +203,7 @@ int cfsplitting_cls(const Pattern& S, int* vec)
         }
     }
 
+    lap("fill");
     while (num_left > 0) {  // :651-717
         const int maxnode = B.top();
         const int maxmeas = lambda[maxnode];
@@ -240,6 +250,7 @@ int cfsplitting_cls(const Pattern& S, int* vec)
         }
     }
 
+    lap("first pass");
     // C1 criterion, :719-763
     std::vector<int>& graph_array = lambda;
     std::fill(graph_array.begin(), graph_array.end(), -1);
@@ -273,6 +284,7 @@ int cfsplitting_cls(const Pattern& S, int* vec)
             }
         }
     }
+    lap("C1 pass");
     return col;
 }
 
@@ -890,7 +902,8 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
     }
     if (it) {
         if (it->itsolver_type != SOLVER_CG && it->itsolver_type != SOLVER_BiCGstab && it->itsolver_type != SOLVER_GMRES &&
-            it->itsolver_type != SOLVER_VGMRES && it->itsolver_type != SOLVER_VFGMRES) {
+            it->itsolver_type != SOLVER_VGMRES && it->itsolver_type != SOLVER_VFGMRES &&
+            it->itsolver_type != SOLVER_MinRes && it->itsolver_type != SOLVER_GCG && it->itsolver_type != SOLVER_GCR) {
             std::printf("### ERROR: Unknown iterative solver type %d! [%s]\n", it->itsolver_type,
                         "fasp_solver_dcsr_itsolver");
             return ERROR_SOLVER_TYPE;
@@ -900,7 +913,8 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             return ERROR_SOLVER_PRECTYPE;
         }
         if (it->stop_type < STOP_REL_RES || it->stop_type > STOP_MOD_REL_RES) return ERROR_INPUT_PAR;
-        if ((it->itsolver_type == SOLVER_GMRES || it->itsolver_type == SOLVER_VGMRES || it->itsolver_type == SOLVER_VFGMRES) &&
+        if ((it->itsolver_type == SOLVER_GMRES || it->itsolver_type == SOLVER_VGMRES || it->itsolver_type == SOLVER_VFGMRES ||
+             it->itsolver_type == SOLVER_GCR) &&
             (it->restart < 1 || it->restart > 1000)) return ERROR_INPUT_PAR;
     }
     return FASP_SUCCESS;

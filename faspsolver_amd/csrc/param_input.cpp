@@ -438,6 +438,107 @@ int fasp_dbsr_read(const char* filename, dBSRmat* A)
     return FASP_SUCCESS;
 }
 
+namespace {
+// The coordinate-format readers of BlaIO.c share one body: "m n nnz" then nnz triples "i j value";
+// they differ in the index base and in whether the file holds one triangle of a symmetric matrix.
+// Conversion = fasp_format_dcoo_dcsr (BlaFormat.c:36): stable counting sort by row, so every row
+// keeps the file's order of its entries.
+int read_coo(const char* fn, const char* filename, dCSRmat* A, int base, bool sym)
+{
+    if (!filename || !A) return ERROR_INPUT_PAR;
+    File f(filename);
+    if (!f.fp) return ERROR_OPEN_FILE;
+    std::printf("%s: reading file %s ...\n", fn, filename);
+    int m, n, nnz;
+    if (skip_comments(f.fp) < 0 || fscanf(f.fp, "%d %d %d", &m, &n, &nnz) != 3 || m <= 0 || n <= 0 || nnz < 0)
+        return ERROR_WRONG_FILE;
+    if (sym) nnz = 2 * (nnz - m) + m;  // BlaIO.c:645: a full diagonal is assumed
+    if (nnz < 0) return ERROR_WRONG_FILE;
+    std::vector<int> ri((size_t)nnz + 1), ci((size_t)nnz + 1);
+    std::vector<double> v((size_t)nnz + 1);
+    int k = 0;
+    while (k < nnz) {
+        int i, j; double value;
+        if (fscanf(f.fp, "%d %d %le", &i, &j, &value) != 3) return ERROR_WRONG_FILE;
+        i -= base; j -= base;
+        if (i < 0 || i >= m || j < 0 || j >= n) return ERROR_WRONG_FILE;
+        ri[k] = i; ci[k] = j; v[k] = value; ++k;
+        if (sym && i != j) {
+            if (k >= nnz) return ERROR_WRONG_FILE;  // more off-diagonal entries than the header promises
+            ri[k] = j; ci[k] = i; v[k] = value; ++k;
+        }
+    }
+    A->row = m; A->col = n; A->nnz = nnz;
+    A->IA = static_cast<int*>(std::calloc((size_t)m + 1, sizeof(int)));
+    A->JA = static_cast<int*>(std::calloc((size_t)std::max(nnz, 1), sizeof(int)));
+    A->val = static_cast<double*>(std::calloc((size_t)std::max(nnz, 1), sizeof(double)));
+    std::vector<int> ind((size_t)m + 1, 0);
+    for (int q = 0; q < nnz; ++q) ind[ri[q] + 1]++;
+    for (int i = 1; i <= m; ++i) { A->IA[i] = A->IA[i - 1] + ind[i]; ind[i] = A->IA[i]; }
+    for (int q = 0; q < nnz; ++q) {
+        const int pos = ind[ri[q]]++;
+        A->JA[pos] = ci[q]; A->val[pos] = v[q];
+    }
+    return FASP_SUCCESS;
+}
+}  // namespace
+
+int fasp_dcoo_read(const char* filename, dCSRmat* A) { return read_coo(__func__, filename, A, 0, false); }        // BlaIO.c:332
+int fasp_dcoo_read1(const char* filename, dCSRmat* A) { return read_coo(__func__, filename, A, 1, false); }       // BlaIO.c:384
+int fasp_dcoo_shift_read(const char* filename, dCSRmat* A) { return read_coo(__func__, filename, A, 1, false); }  // BlaIO.c:514
+int fasp_dmtx_read(const char* filename, dCSRmat* A) { return read_coo(__func__, filename, A, 1, false); }        // BlaIO.c:567
+int fasp_dmtxsym_read(const char* filename, dCSRmat* A) { return read_coo(__func__, filename, A, 1, true); }      // BlaIO.c:624
+
+// BlaIO.c:1388: "n / values" with 15 digits
+int fasp_dvec_write(const char* filename, dvector* vec)
+{
+    if (!filename || !vec) return ERROR_INPUT_PAR;
+    FILE* fp = std::fopen(filename, "w");
+    if (!fp) return ERROR_OPEN_FILE;
+    std::printf("%s: writing to file %s ...\n", __func__, filename);
+    std::fprintf(fp, "%d\n", vec->row);
+    for (int i = 0; i < vec->row; ++i) std::fprintf(fp, "%0.15e\n", vec->val[i]);
+    std::fclose(fp);
+    return FASP_SUCCESS;
+}
+
+// BlaIO.c:1623: comment line with the sizes, then 1-based triples (what fasp_dcoo_read1 reads back)
+int fasp_dcsr_write_coo(const char* filename, const dCSRmat* A)
+{
+    if (!filename || !A) return ERROR_INPUT_PAR;
+    FILE* fp = std::fopen(filename, "w");
+    if (!fp) return ERROR_OPEN_FILE;
+    std::printf("%s: writing to file %s ...\n", __func__, filename);
+    std::fprintf(fp, "%% dimension of the matrix and nonzeros %d  %d  %d\n", A->row, A->col, A->nnz);
+    for (int i = 0; i < A->row; i++)
+        for (int j = A->IA[i]; j < A->IA[i + 1]; j++)
+            std::fprintf(fp, "%d %d %+.15E\n", i + 1, A->JA[j] + 1, A->val[j]);
+    std::fclose(fp);
+    return FASP_SUCCESS;
+}
+
+// BlaIO.c:1145: the two-file format fasp_dcsrvec_read2 reads
+int fasp_dcsrvec_write2(const char* filemat, const char* filerhs, dCSRmat* A, dvector* b)
+{
+    if (!filemat || !filerhs || !A || !b) return ERROR_INPUT_PAR;
+    const int m = A->row, nnz = A->nnz;
+    FILE* fp = std::fopen(filemat, "w");
+    if (!fp) return ERROR_OPEN_FILE;
+    std::printf("%s: writing to file %s ...\n", __func__, filemat);
+    std::fprintf(fp, "%d\n", m);
+    for (int i = 0; i < m + 1; ++i) std::fprintf(fp, "%d\n", A->IA[i] + 1);
+    for (int i = 0; i < nnz; ++i) std::fprintf(fp, "%d\n", A->JA[i] + 1);
+    for (int i = 0; i < nnz; ++i) std::fprintf(fp, "%le\n", A->val[i]);
+    std::fclose(fp);
+    fp = std::fopen(filerhs, "w");
+    if (!fp) return ERROR_OPEN_FILE;
+    std::printf("%s: writing to file %s ...\n", __func__, filerhs);
+    std::fprintf(fp, "%d\n", b->row);
+    for (int i = 0; i < b->row; ++i) std::fprintf(fp, "%le\n", b->val[i]);
+    std::fclose(fp);
+    return FASP_SUCCESS;
+}
+
 void fasp_hip_free_bsr(dBSRmat* A)
 {
     if (!A) return;
@@ -465,6 +566,45 @@ void fasp_fwrapper_dcsr_krylov_amg_(int* n, int* nnz, int* ia, int* ja, double* 
     dvector rhs{*n, b}, sol{*n, u};
     const int ret = fasp_solver_dcsr_krylov_amg(&mat, &rhs, &sol, &itsparam, &amgparam);
     if (ret < 0) std::printf("### WARNING: fasp_solver_dcsr_krylov_amg returned %d\n", ret);
+}
+
+// SolWrapper.c:136 -- AMG as the solver, parameters from fasp_param_amg_init
+void fasp_fwrapper_dcsr_amg_(int* n, int* nnz, int* ia, int* ja, double* a, double* b, double* u, double* tol, int* maxit,
+                             int* ptrlvl)
+{
+    AMG_param amgparam;
+    fasp_param_amg_init(&amgparam);
+    amgparam.tol = *tol;
+    amgparam.print_level = (short)*ptrlvl;
+    amgparam.maxit = *maxit;
+    dCSRmat mat;
+    mat.row = *n; mat.col = *n; mat.nnz = *nnz; mat.IA = ia; mat.JA = ja; mat.val = a;
+    dvector rhs{*n, b}, sol{*n, u};
+    const int ret = fasp_solver_amg(&mat, &rhs, &sol, &amgparam);
+    if (ret < 0) std::printf("### WARNING: fasp_solver_amg returned %d\n", ret);
+}
+
+// SolWrapper.c:397 -- block matrices: UA-AMG + VFGMRES.  The reference leaves storage_manner
+// uninitialised here; its kernels only know the row-major layout 0, which is what is set.
+void fasp_fwrapper_dbsr_krylov_amg_(int* n, int* nnz, int* nb, int* ia, int* ja, double* a, double* b, double* u,
+                                    double* tol, int* maxit, int* ptrlvl)
+{
+    AMG_param amgparam;
+    ITS_param itsparam;
+    fasp_param_amg_init(&amgparam);
+    amgparam.AMG_type = UA_AMG;
+    amgparam.print_level = (short)*ptrlvl;
+    fasp_param_solver_init(&itsparam);
+    itsparam.tol = *tol;
+    itsparam.print_level = (short)*ptrlvl;
+    itsparam.maxit = *maxit;
+    itsparam.itsolver_type = SOLVER_VFGMRES;
+    dBSRmat mat;
+    mat.ROW = *n; mat.COL = *n; mat.NNZ = *nnz; mat.nb = *nb; mat.storage_manner = 0;
+    mat.IA = ia; mat.JA = ja; mat.val = a;
+    dvector rhs{*n * *nb, b}, sol{*n * *nb, u};
+    const int ret = fasp_solver_dbsr_krylov_amg(&mat, &rhs, &sol, &itsparam, &amgparam);
+    if (ret < 0) std::printf("### WARNING: fasp_solver_dbsr_krylov_amg returned %d\n", ret);
 }
 
 }  // extern "C"

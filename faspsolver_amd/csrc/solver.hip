@@ -1720,6 +1720,362 @@ FINISHED:
 }
 
 // ---------------------------------------------------------------------------
+// The remaining `itsolver_type`s of fasp_solver_dcsr_itsolver (SolCSR.c:56): MinRes, GCG, GCR.
+// Host control flow as in the reference, vectors and every operation on the device; these
+// are completeness modes (one host round trip per scalar), the tuned drivers are CG and GMRES.
+// ---------------------------------------------------------------------------
+struct KVecOps {
+    KOps& K;
+    const int m;
+    const size_t nv;
+    hipStream_t s;
+    double red[8];
+    explicit KVecOps(KOps& K_) : K(K_), m(K_.n), nv(K_.nvec), s(g_ctx.stream) {}
+    int ensure(size_t count)
+    {
+        if (*K.ws_len != nv) {
+            for (double* q : *K.ws) if (q) (void)hipFree(q);
+            K.ws->clear();
+            *K.ws_len = nv;
+        }
+        while (K.ws->size() < count) {
+            double* q = nullptr;
+            HIPCK(hipMalloc(&q, sizeof(double) * std::max<size_t>(nv, 1)));
+            HIPCK(hipMemsetAsync(q, 0, sizeof(double) * nv, s));
+            K.ws->push_back(q);
+        }
+        return 0;
+    }
+    double* vec(size_t i) { return (*K.ws)[i]; }
+    int cp(double* dst, const double* src)
+    {
+        if (dst != src) HIPCK(hipMemcpyAsync(dst, src, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    int zero(double* dst) { HIPCK(hipMemsetAsync(dst, 0, sizeof(double) * m, s)); return 0; }
+    int dot(const double* y, const double* z, double& val)
+    {
+        if (d_dot(m, y, z, red, K.dist) < 0) return ERROR_MISC;
+        val = red[0];
+        return 0;
+    }
+    int nrm2(const double* y, double& val)
+    {
+        if (d_dot(m, y, y, red, K.dist) < 0) return ERROR_MISC;
+        val = std::sqrt(red[0]);
+        return 0;
+    }
+    int mxv(double* x, double* y)  // y = A x (x's ghost entries refreshed first)
+    {
+        if (K.halo(x) < 0) return ERROR_MISC;
+        K.mxv(x, y);
+        return 0;
+    }
+    int resid(double* x, const double* b, double* r)  // r = b - A x
+    {
+        if (K.halo(x) < 0) return ERROR_MISC;
+        K.resid(x, b, r);
+        return 0;
+    }
+    int pc(double* in, double* dst)  // dst = B in (the preconditioner's own output buffer is copied out)
+    {
+        double* o = in;
+        if (K.pc) { const int st = K.pc(in, &o); if (st < 0) return st; }
+        return cp(dst, o);
+    }
+};
+#define KCK(expr) do { const int st__ = (expr); if (st__ < 0) return st__; } while (0)
+
+// fasp_solver_dcsr_pminres, KryPminres.c:61-448
+static int minres_device(KOps& K, const double* b, double* u, double tol, double abstol, int MaxIt, int StopType,
+                         int PrtLvl, Hist* hist, PcgOut* out)
+{
+    KVecOps V(K);
+    const int m = V.m;
+    const double maxdiff = tol * STAG_RATIO, sol_inf_tol = SMALLREAL;
+    int iter = 0, stag = 1, more_step = 1;
+    double absres0 = BIGREAL, absres = BIGREAL, normr0 = BIGREAL, relres = BIGREAL;
+    double normu2 = BIGREAL, normuu, normp, factor, alpha, alpha0, alpha1, temp2, red[8];
+    KCK(V.ensure(11));
+    double *p0 = V.vec(0), *p1 = V.vec(1), *p2 = V.vec(2), *z0 = V.vec(3), *z1 = V.vec(4), *t0 = V.vec(5),
+           *t1 = V.vec(6), *t = V.vec(7), *tp = V.vec(8), *tz = V.vec(9), *r = V.vec(10);
+    auto resnorm = [&]() -> int {  // :228-247 and its two copies
+        switch (StopType) {
+            case STOP_REL_RES:
+                KCK(V.dot(r, r, temp2)); absres = std::sqrt(temp2); relres = absres / normr0; break;
+            case STOP_REL_PRECRES:
+                KCK(V.pc(r, t)); KCK(V.dot(r, t, temp2)); temp2 = std::fabs(temp2);
+                absres = std::sqrt(temp2); relres = absres / normr0; break;
+            case STOP_MOD_REL_RES:
+                KCK(V.dot(r, r, temp2)); absres = std::sqrt(temp2); relres = absres / normu2; break;
+        }
+        return 0;
+    };
+    auto restart = [&]() -> int {  // :331-368 == :409-446
+        KCK(V.zero(p0));
+        KCK(V.pc(r, p1));
+        KCK(V.mxv(p1, tp));
+        KCK(V.pc(tp, tz));
+        KCK(V.dot(tz, tp, normp));
+        normp = std::sqrt(normp);
+        KCK(V.cp(t, p1));
+        KCK(V.zero(t0)); KCK(V.zero(z0)); KCK(V.zero(t1)); KCK(V.zero(z1)); KCK(V.zero(p1));
+        d_axpy(m, 1 / normp, t, p1);
+        d_axpy(m, 1 / normp, tp, t1);
+        d_axpy(m, 1 / normp, tz, z1);
+        return 0;
+    };
+    if (PrtLvl > PRINT_NONE) std::printf("\nCalling MinRes solver (%s) ...\n", K.fmt);
+    KCK(V.zero(p0));
+    KCK(V.resid(u, b, r));
+    KCK(V.pc(r, p1));
+    switch (StopType) {
+        case STOP_REL_RES:
+            KCK(V.nrm2(r, absres0)); normr0 = std::max(SMALLREAL, absres0); relres = absres0 / normr0; break;
+        case STOP_REL_PRECRES:
+            KCK(V.dot(r, p1, temp2)); absres0 = std::sqrt(temp2);
+            normr0 = std::max(SMALLREAL, absres0); relres = absres0 / normr0; break;
+        case STOP_MOD_REL_RES:
+            KCK(V.nrm2(r, absres0)); KCK(V.nrm2(u, normu2)); normu2 = std::max(SMALLREAL, normu2);
+            relres = absres0 / normu2; break;
+        default:
+            std::printf("### ERROR: Unknown stopping type! [%s]\n", "fasp_solver_dcsr_pminres");
+            goto FINISHED;
+    }
+    if (hist) hist->push(absres0);
+    if (relres < tol || absres0 < abstol) goto FINISHED;
+    itinfo(PrtLvl, StopType, iter, relres, absres0, 0.0);
+    KCK(V.mxv(p1, tp));
+    KCK(V.pc(tp, tz));
+    KCK(V.dot(tz, tp, normp));
+    normp = std::sqrt(std::fabs(normp));
+    KCK(V.cp(t, p1));
+    KCK(V.zero(p1));
+    d_axpy(m, 1 / normp, t, p1);
+    KCK(V.zero(t0)); KCK(V.zero(z0)); KCK(V.zero(t1)); KCK(V.zero(z1));
+    d_axpy(m, 1.0 / normp, tp, t1);
+    d_axpy(m, 1.0 / normp, tz, z1);
+
+    while (iter++ < MaxIt) {
+        KCK(V.dot(r, z1, alpha));
+        d_axpy(m, alpha, p1, u);
+        d_axpy(m, -alpha, t1, r);
+        KCK(V.mxv(z1, t));
+        KCK(V.dot(z1, t, alpha1));
+        KCK(V.mxv(z0, t));
+        KCK(V.dot(z1, t, alpha0));
+        KCK(V.cp(p2, z1));
+        d_axpy(m, -alpha1, p1, p2);
+        d_axpy(m, -alpha0, p0, p2);
+        KCK(V.mxv(p2, tp));
+        KCK(V.pc(tp, tz));
+        KCK(V.dot(tz, tp, normp));
+        normp = std::sqrt(std::fabs(normp));
+        KCK(V.cp(t, p2));
+        KCK(V.zero(p2));
+        d_axpy(m, 1 / normp, t, p2);
+        KCK(V.cp(p0, p1)); KCK(V.cp(p1, p2)); KCK(V.cp(t0, t1)); KCK(V.cp(z0, z1));
+        KCK(V.zero(t1)); KCK(V.zero(z1));
+        d_axpy(m, 1 / normp, tp, t1);
+        d_axpy(m, 1 / normp, tz, z1);
+        if (d_norms(m, u, red, K.dist) < 0) return ERROR_MISC;  // ||u||^2, max|u|
+        normu2 = std::sqrt(red[0]);
+        KCK(resnorm());
+        factor = absres / absres0;
+        itinfo(PrtLvl, StopType, iter, relres, absres, factor);
+        if (hist) hist->push(absres);
+
+        if (factor > 0.9) {  // Check I, II (:256-373)
+            if (red[1] <= sol_inf_tol) {
+                if (PrtLvl > PRINT_MIN)
+                    std::printf("### WARNING: Iteration stopped -- solution almost zero! [%s:%d]\n", "fasp_solver_dcsr_pminres", 262);
+                iter = ERROR_SOLVER_SOLSTAG;
+                break;
+            }
+            KCK(V.nrm2(p1, normuu));
+            normuu = std::fabs(alpha) * (normuu / normu2);
+            if (normuu < maxdiff) {
+                if (stag < MAX_STAG && PrtLvl >= PRINT_MORE) {
+                    std::printf("||u-u'|| = %.10e and the comp. rel. res. = %.10e.\n", normuu, relres);
+                    std::printf("### WARNING: Iteration restarted -- stagnation! [%s:%d]\n", "fasp_solver_dcsr_pminres", 276);
+                }
+                KCK(V.resid(u, b, r));
+                KCK(resnorm());
+                if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+                if (relres < tol) break;
+                if (stag >= MAX_STAG) {
+                    if (PrtLvl > PRINT_MIN)
+                        std::printf("### WARNING: Iteration stopped -- staggnation! [%s:%d]\n", "fasp_solver_dcsr_pminres", 318);
+                    iter = ERROR_SOLVER_STAG;
+                    break;
+                }
+                ++stag;
+                KCK(restart());
+            }
+        }
+
+        if (relres < tol) {  // Check III (:376-447)
+            if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The computed relative residual = %.10e!\n", relres);
+            KCK(V.resid(u, b, r));
+            KCK(resnorm());
+            if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+            if (relres < tol) break;
+            if (more_step >= MAX_RESTART) {
+                if (PrtLvl > PRINT_MIN)
+                    std::printf("### WARNING: The tolerence might be too small! [%s:%d]\n", "fasp_solver_dcsr_pminres", 412);
+                iter = ERROR_SOLVER_TOLSMALL;
+                break;
+            }
+            ++more_step;
+            KCK(restart());
+        }
+        absres0 = absres;
+    }
+FINISHED:
+    if (PrtLvl > PRINT_NONE) {
+        if (iter > MaxIt) std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, relres);
+        else if (iter >= 0) std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, relres);
+    }
+    if (out) { out->relres = relres; out->absres = absres; out->normr0 = normr0; }
+    HIPCK(hipStreamSynchronize(V.s));
+    return iter > MaxIt ? ERROR_SOLVER_MAXIT : iter;
+}
+
+// fasp_solver_dcsr_pgcg, KryPgcg.c:60-195.  The reference allocates all MaxIt search directions
+// up front; here a direction is allocated when its iteration is reached.
+static int gcg_device(KOps& K, const double* b, double* u, double tol, double abstol, int MaxIt, int StopType,
+                      int PrtLvl, Hist* hist, PcgOut* out)
+{
+    KVecOps V(K);
+    const int m = V.m;
+    int iter = 0, i;
+    double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normb = BIGREAL, alpha, factor, num, den, beta;
+    KCK(V.ensure(4));
+    double *r = V.vec(0), *Br = V.vec(1), *Ap = V.vec(2);
+    auto P = [&](int k) { return V.vec(3 + (size_t)k); };
+    auto vmv = [&](double* x, const double* y, double& val) -> int {  // y^T A x, BlaSpmvCSR.c:839
+        KCK(V.mxv(x, Ap));
+        return V.dot(y, Ap, val);
+    };
+    auto step = [&](double* p) -> int {  // alpha = (r,p)/(p,Ap); u += alpha p; r -= alpha A p
+        KCK(V.dot(r, p, num));
+        KCK(vmv(p, p, den));
+        alpha = num / den;
+        d_axpy(m, alpha, p, u);
+        d_axpy(m, -1.0 * alpha, Ap, r);  // Ap still holds A p
+        KCK(V.nrm2(r, absres));
+        factor = absres / absres0;
+        relres = absres / normb;
+        itinfo(PrtLvl, StopType, iter, relres, absres, factor);
+        if (hist) hist->push(absres);
+        return 0;
+    };
+    if (PrtLvl > PRINT_NONE) std::printf("\nCalling GCG solver (%s) ...\n", K.fmt);
+    KCK(V.nrm2(b, normb));
+    KCK(V.resid(u, b, r));
+    KCK(V.pc(r, P(0)));
+    KCK(step(P(0)));
+    absres0 = absres;
+    for (iter = 1; iter < MaxIt; iter++) {
+        KCK(V.ensure(4 + (size_t)iter));
+        r = V.vec(0); Br = V.vec(1); Ap = V.vec(2);
+        double* pi = P(iter);
+        KCK(V.pc(r, Br));
+        KCK(V.cp(pi, Br));
+        for (i = 0; i < iter; i++) {
+            KCK(vmv(Br, P(i), num));
+            KCK(vmv(P(i), P(i), den));
+            beta = (-1.0) * (num / den);
+            d_axpy(m, beta, P(i), pi);
+        }
+        KCK(step(pi));
+        if (relres < tol || absres < abstol) break;
+        absres0 = absres;
+    }
+    if (PrtLvl > PRINT_NONE) {
+        if (iter > MaxIt) std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, relres);
+        else if (iter >= 0) std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, relres);
+    }
+    if (out) { out->relres = relres; out->absres = absres; out->normr0 = normb; }
+    HIPCK(hipStreamSynchronize(V.s));
+    return iter > MaxIt ? ERROR_SOLVER_MAXIT : iter;
+}
+
+// fasp_solver_dcsr_pgcr, KryPgcr.c:55-425 (+ dense_aAtxpby :450)
+static int gcr_device(KOps& K, const double* b, double* x, double tol, double abstol, int MaxIt, int restart_in,
+                      int StopType, int PrtLvl, Hist* hist, PcgOut* out)
+{
+    KVecOps V(K);
+    const int n = V.m;
+    int iter = 0, i, j, k, rst = -1;
+    double gamma, alpha, beta, checktol, absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, prev;
+    const int Restart = std::min(restart_in, MaxIt);
+    (void)abstol;
+    KCK(V.ensure(1 + 2 * (size_t)std::max(Restart, 0)));
+    double* r = V.vec(0);
+    auto Z = [&](int q) { return V.vec(1 + (size_t)q); };
+    auto Cv = [&](int q) { return V.vec(1 + (size_t)Restart + (size_t)q); };
+    std::vector<double> alp((size_t)std::max(Restart, 1)), tmpx((size_t)std::max(Restart, 1));
+    std::vector<std::vector<double>> h((size_t)std::max(Restart, 1), std::vector<double>((size_t)std::max(Restart, 1), 0.0));
+    if (PrtLvl > PRINT_NONE) std::printf("\nCalling GCR solver (%s) ...\n", K.fmt);
+    KCK(V.resid(x, b, r));
+    KCK(V.dot(r, r, absres));
+    absres0 = std::max(SMALLREAL, absres);
+    relres = absres / absres0;
+    itinfo(PrtLvl, StopType, 0, relres, std::sqrt(absres0), 0.0);
+    if (hist) hist->push(std::sqrt(absres));
+    prev = relres;
+    checktol = std::max(tol * tol * absres0, absres * 1.0e-4);
+    while (iter < MaxIt && std::sqrt(relres) > tol) {
+        i = -1;
+        rst++;
+        while (i < Restart - 1 && iter < MaxIt) {
+            i++;
+            iter++;
+            KCK(V.pc(r, Z(i)));
+            KCK(V.mxv(Z(i), Cv(i)));
+            for (j = 0; j < i; j++) {  // modified Gram-Schmidt
+                KCK(V.dot(Cv(j), Cv(i), gamma));
+                h[i][j] = gamma / h[j][j];
+                d_axpy(n, -h[i][j], Cv(j), Cv(i));
+            }
+            KCK(V.dot(Cv(i), Cv(i), gamma));
+            h[i][i] = gamma;
+            KCK(V.dot(Cv(i), r, alpha));
+            beta = alpha / gamma;
+            alp[i] = beta;
+            d_axpy(n, -beta, Cv(i), r);
+            absres = absres - alpha * alpha / gamma;
+            if (absres < checktol) {
+                KCK(V.dot(r, r, absres));
+                checktol = std::max(tol * tol * absres0, absres * 1.0e-4);
+            }
+            relres = absres / absres0;
+            itinfo(PrtLvl, StopType, iter, std::sqrt(relres), std::sqrt(absres), std::sqrt(relres / prev));
+            if (hist) hist->push(std::sqrt(absres));
+            prev = relres;
+            if (std::sqrt(relres) < tol) break;
+        }
+        for (k = i; k >= 0; k--) {
+            tmpx[k] = alp[k];
+            for (j = 0; j < k; ++j) alp[j] -= h[k][j] * tmpx[k];
+        }
+        // dense_aAtxpby(n, i+1, z, 1.0, tmpx, rst == 0 ? 0.0 : 1.0, x): columns scaled in place,
+        // summed into column 0 one after the other, x = 1.0 z_0 + beta x (the first cycle overwrites x)
+        for (k = 0; k < i + 1; k++) d_scale(n, tmpx[k], Z(k));
+        for (j = 1; j < i + 1; j++) d_axpy(n, 1.0, Z(j), Z(0));
+        d_axpby(n, 1.0, Z(0), rst == 0 ? 0.0 : 1.0, x);
+    }
+    if (PrtLvl > PRINT_NONE) {
+        if (iter > MaxIt) std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, std::sqrt(relres));
+        else if (iter >= 0) std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, std::sqrt(relres));
+    }
+    if (out) { out->relres = std::sqrt(relres); out->absres = std::sqrt(absres); out->normr0 = std::sqrt(absres0); }
+    HIPCK(hipStreamSynchronize(V.s));
+    return iter >= MaxIt ? ERROR_SOLVER_MAXIT : iter;
+}
+
+// ---------------------------------------------------------------------------
 // one multigrid cycle on the resident hierarchy (PreMGCycle.c:48-274)
 // ---------------------------------------------------------------------------
 static int mgcycle(fasp_hip_amg* h, const AMG_param& param)
@@ -2597,6 +2953,24 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
                               itparam->abstol, itparam->maxit, (short)itparam->restart, itparam->stop_type,
                               itparam->print_level, &H, &po);
         } break;
+        case SOLVER_MinRes:
+        {
+            KOps K = csr_ops(h, 0, true);
+            st = minres_device(K, h->b, h->u, itparam->tol, itparam->abstol, itparam->maxit, itparam->stop_type,
+                               itparam->print_level, &H, &po);
+        } break;
+        case SOLVER_GCG:
+        {
+            KOps K = csr_ops(h, 0, true);
+            st = gcg_device(K, h->b, h->u, itparam->tol, itparam->abstol, itparam->maxit, itparam->stop_type,
+                            itparam->print_level, &H, &po);
+        } break;
+        case SOLVER_GCR:
+        {
+            KOps K = csr_ops(h, 0, true);
+            st = gcr_device(K, h->b, h->u, itparam->tol, itparam->abstol, itparam->maxit, (short)itparam->restart,
+                            itparam->stop_type, itparam->print_level, &H, &po);
+        } break;
         default:
         {
             KOps K = csr_ops(h, 0, true);
@@ -3024,7 +3398,7 @@ bool same_host_matrix(const HostCSR& M, const dCSRmat* A)
            std::memcmp(M.val.data(), A->val, sizeof(double) * (size_t)A->nnz) == 0;
 }
 
-// which: 0 PCG, 1 VGMRES, 2 VFGMRES, 3 BiCGstab, 4 GMRES (fixed restart)
+// which: 0 PCG, 1 VGMRES, 2 VFGMRES, 3 BiCGstab, 4 GMRES (fixed restart), 5 MinRes, 6 GCG, 7 GCR
 int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u, precond* pc, double tol,
                   double abstol, int MaxIt, short restart, short StopType, short PrtLvl)
 {
@@ -3081,6 +3455,12 @@ int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u,
         st = pcg_device(K, V, tol, abstol, MaxIt, StopType, PrtLvl, H, po);
     } else if (which == 3) {
         st = bicgstab_device(K, db.d, du.d, tol, MaxIt, PrtLvl, &H, &po);
+    } else if (which == 5) {
+        st = minres_device(K, db.d, du.d, tol, abstol, MaxIt, StopType, PrtLvl, &H, &po);
+    } else if (which == 6) {
+        st = gcg_device(K, db.d, du.d, tol, abstol, MaxIt, StopType, PrtLvl, &H, &po);
+    } else if (which == 7) {
+        st = gcr_device(K, db.d, du.d, tol, abstol, MaxIt, restart, StopType, PrtLvl, &H, &po);
     } else {
         st = gmres_device(K, db.d, du.d, which == 2 ? 1 : which == 4 ? 3 : 0, tol, abstol, MaxIt, restart, StopType, PrtLvl, &H, &po);
     }
@@ -3114,6 +3494,24 @@ int fasp_solver_dcsr_pbcgs(dCSRmat* A, dvector* b, dvector* u, precond* pc, cons
                            const int MaxIt, const short StopType, const short PrtLvl)
 {
     return krylov_plugin(__func__, 3, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+// KryPminres.c:61
+int fasp_solver_dcsr_pminres(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                             const int MaxIt, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin(__func__, 5, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+// KryPgcg.c:60
+int fasp_solver_dcsr_pgcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                          const int MaxIt, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin(__func__, 6, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+// KryPgcr.c:55
+int fasp_solver_dcsr_pgcr(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                          const int MaxIt, const short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_plugin(__func__, 7, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 // KryPvfgmres.c:67
 int fasp_solver_dcsr_pvfgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,

@@ -70,9 +70,12 @@ extern "C" {
 #define SOLVER_DEFAULT 0
 #define SOLVER_CG      1
 #define SOLVER_BiCGstab 2
+#define SOLVER_MinRes  3
 #define SOLVER_GMRES   4
 #define SOLVER_VGMRES  5
 #define SOLVER_VFGMRES 6
+#define SOLVER_GCG     7
+#define SOLVER_GCR     8
 
 #define STOP_REL_RES     1
 #define STOP_REL_PRECRES 2
@@ -295,10 +298,25 @@ int  fasp_hip_param_input(const char* fname, ITS_param* itsparam, AMG_param* amg
 int  fasp_dcsrvec_read2(const char* filemat, const char* filerhs, dCSRmat* A, dvector* b);
 int  fasp_dvec_read(const char* filename, dvector* b);
 int  fasp_dbsr_read(const char* filename, dBSRmat* A);
+/* coordinate formats (BlaIO.c:332 0-based, :384 / :514 / :567 1-based, :624 one triangle of a
+ * symmetric MatrixMarket file) and the writers that pair with the readers (:1388, :1623, :1145) */
+int  fasp_dcoo_read(const char* filename, dCSRmat* A);
+int  fasp_dcoo_read1(const char* filename, dCSRmat* A);
+int  fasp_dcoo_shift_read(const char* filename, dCSRmat* A);
+int  fasp_dmtx_read(const char* filename, dCSRmat* A);
+int  fasp_dmtxsym_read(const char* filename, dCSRmat* A);
+int  fasp_dvec_write(const char* filename, dvector* vec);
+int  fasp_dcsr_write_coo(const char* filename, const dCSRmat* A);
+int  fasp_dcsrvec_write2(const char* filemat, const char* filerhs, dCSRmat* A, dvector* b);
 void fasp_hip_free_bsr(dBSRmat* A);
 /* Fortran-style wrapper, SolWrapper.c:261: parameters from "ini/amg.dat" in the working directory */
 void fasp_fwrapper_dcsr_krylov_amg_(int* n, int* nnz, int* ia, int* ja, double* a, double* b, double* u,
                                     double* tol, int* maxit, int* ptrlvl);
+/* SolWrapper.c:136 (AMG as the solver) and :397 (block matrix: UA-AMG + VFGMRES) */
+void fasp_fwrapper_dcsr_amg_(int* n, int* nnz, int* ia, int* ja, double* a, double* b, double* u,
+                             double* tol, int* maxit, int* ptrlvl);
+void fasp_fwrapper_dbsr_krylov_amg_(int* n, int* nnz, int* nb, int* ia, int* ja, double* a, double* b,
+                                    double* u, double* tol, int* maxit, int* ptrlvl);
 
 /* AMG-preconditioned Krylov solve on a block matrix -- replaces base/src/SolBSR.c:349.
  * Unsmoothed aggregation (PreAMGSetupUABSR.c:55, VMB on the condensed matrix, identity-block
@@ -406,6 +424,13 @@ int fasp_solver_dcsr_pcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const 
                          const double abstol, const int MaxIt, const short StopType, const short PrtLvl);
 int fasp_solver_dcsr_pbcgs(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
                            const double abstol, const int MaxIt, const short StopType, const short PrtLvl); /* KryPbcgs.c:62 */
+int fasp_solver_dcsr_pminres(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
+                             const double abstol, const int MaxIt, const short StopType, const short PrtLvl); /* KryPminres.c:61 */
+int fasp_solver_dcsr_pgcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
+                          const double abstol, const int MaxIt, const short StopType, const short PrtLvl);    /* KryPgcg.c:60 */
+int fasp_solver_dcsr_pgcr(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
+                          const double abstol, const int MaxIt, const short restart,
+                          const short StopType, const short PrtLvl);                      /* KryPgcr.c:55 */
 int fasp_solver_dcsr_pgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
                             const double abstol, const int MaxIt, const short restart,
                             const short StopType, const short PrtLvl);                    /* KryPgmres.c:66 */

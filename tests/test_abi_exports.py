@@ -67,7 +67,7 @@ def test_unsupported_parameters_are_refused_before_any_work(fa):
     cases.append((it, am, T.ERROR_INPUT_PAR))
     it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.ILU_levels = 1
     cases.append((it, am, T.ERROR_INPUT_PAR))
-    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; it.itsolver_type = 3
+    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; it.itsolver_type = 13  # SOLVER_SMinRes
     cases.append((it, am, T.ERROR_SOLVER_TYPE))
     it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.interpolation_type = T.INTERP_STD
     cases.append((it, am, T.ERROR_AMG_INTERP_TYPE))

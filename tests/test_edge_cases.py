@@ -120,6 +120,49 @@ def bicgstab_poisson():
 
 
 @case
+def minres_poisson():
+    ia, ja, a, f, ue = poisson7pt(16)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 3
+    return ia, ja, a, np.cos(np.arange(len(f)) * 0.37), None, mod
+
+
+@case
+def minres_precres_guess():
+    ia, ja, a, f, ue = poisson7pt(12)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 3; i.stop_type = 2
+    return ia, ja, a, np.cos(np.arange(len(f)) * 0.37), np.sin(np.arange(len(f)) * 0.11), mod
+
+
+@case
+def gcg_poisson():
+    ia, ja, a, f, ue = poisson7pt(16)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 7
+    return ia, ja, a, np.cos(np.arange(len(f)) * 0.37), None, mod
+
+
+@case
+def gcg_maxit():
+    ia, ja, a, f, ue = poisson7pt(12)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 7; i.maxit = 3
+    return ia, ja, a, np.cos(np.arange(len(f)) * 0.37), None, mod
+
+
+@case
+def gcr_poisson_restart3():
+    ia, ja, a, f, ue = poisson7pt(16)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 8; i.restart = 3
+    return ia, ja, a, np.cos(np.arange(len(f)) * 0.37), None, mod
+
+
+@case
+def gcr_unsymmetric():
+    ia, ja, a = tridiag(3000, lower=-1.3, diag=2.4, upper=-0.9)
+    f = np.sin(np.arange(3000) * 0.01)
+    def mod(i, p): _jac(i, p); i.itsolver_type = 8; i.restart = 20
+    return ia, ja, a, f, None, mod
+
+
+@case
 def bicgstab_unsymmetric_tight():
     ia, ja, a = tridiag(3000, lower=-1.3, diag=2.4, upper=-0.9)
     f = np.sin(np.arange(3000) * 0.01)

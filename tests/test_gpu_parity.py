@@ -304,7 +304,7 @@ def test_unsupported_is_refused(gpu):
     x = np.zeros(len(f))
     assert gpu.solver_dcsr_krylov_amg(ia, ja, a, f, x, itp, amgp) == T.ERROR_AMG_SMOOTH_TYPE
     assert np.all(x == 0.0)
-    itp, amgp = default_params(); _jac(itp, amgp); itp.itsolver_type = 3  # MinRes: not on the path
+    itp, amgp = default_params(); _jac(itp, amgp); itp.itsolver_type = 13  # SOLVER_SMinRes: not dispatched by fasp_solver_dcsr_itsolver either
     assert gpu.solver_dcsr_krylov_amg(ia, ja, a, f, x, itp, amgp) == T.ERROR_SOLVER_TYPE
 
 
