@@ -853,9 +853,9 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             std::printf("### ERROR: fasp_hip: unknown AMG_type %d\n", amg->AMG_type);
             return ERROR_INPUT_PAR;
         }
-        if (amg->AMG_type == UA_AMG && amg->aggregation_type != VMB) {  // (the SA setup always aggregates by VMB, PreAMGSetupSA.c:330)
-            std::printf("### ERROR: fasp_hip: aggregation_type %d has no host setup here (VMB only; the reference's "
-                        "default for aggregation AMG is pairwise matching)\n", amg->aggregation_type);
+        if (amg->AMG_type == UA_AMG && amg->aggregation_type != VMB && amg->aggregation_type != PAIRWISE) {  // (the SA setup always aggregates by VMB, PreAMGSetupSA.c:330)
+            std::printf("### ERROR: fasp_hip: aggregation_type %d has no host setup here (VMB and symmetric pairwise "
+                        "matching only)\n", amg->aggregation_type);
             return ERROR_INPUT_PAR;
         }
         if (amg->AMG_type == SA_AMG && amg->smooth_restriction != 1) {
@@ -1069,6 +1069,135 @@ int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 // Unsmoothed aggregation on a scalar matrix (PreAMGSetupUA.c:55, VMB aggregation): tentative
 // (boolean) prolongation, R = P^T and the Galerkin product with unit entries -- for which the
 // general product equals fasp_blas_dcsr_rap_agg (BlaSpmvCSR.c:1276) bit for bit.
+namespace {
+constexpr int G0PT = -5;                 // fasp_const.h:231
+constexpr int ERROR_AMG_COARSEING = -33; // fasp_const.h:38
+
+// boolean prolongation of an aggregation (form_tentative_p / form_boolean_p with unit values)
+void boolean_p(const int* vv, int row, int nagg, HostCSR& P)
+{
+    P.row = row; P.col = nagg;
+    P.ia.alloc((size_t)row + 1);
+    int j = 0;
+    for (int i = 0; i < row; ++i) { P.ia[i] = j; if (vv[i] > UNPT) ++j; }
+    P.ia[row] = j;
+    P.nnz = j;
+    P.ja.alloc((size_t)std::max(j, 1)); P.val.alloc((size_t)std::max(j, 1));
+    j = 0;
+    for (int i = 0; i < row; ++i)
+        if (vv[i] > UNPT) { P.ja[j] = vv[i]; P.val[j] = 1.0; ++j; }
+}
+
+// fasp_dcsr_diagpref (BlaSparseCSR.c:680): the diagonal entry changes places with the row's first entry
+int diagpref(HostCSR& A)
+{
+    for (int i = 0; i < A.row; ++i) {
+        const int b = A.ia[i], e = A.ia[i + 1];
+        if (b < e && A.ja[b] == i) continue;
+        int j = b + 1;
+        for (; j < e; ++j)
+            if (A.ja[j] == i) { std::swap(A.ja[b], A.ja[j]); std::swap(A.val[b], A.val[j]); break; }
+        if (j >= e) { std::printf("### ERROR: Diagonal entry %d is zero!\n", i); return ERROR_MISC; }
+    }
+    return FASP_SUCCESS;
+}
+
+// One pass of pairwise matching (form_pairwise, PreAMGAggregationUA.inl:170) on a matrix whose rows
+// start with the diagonal.  Sequential by definition: a vertex can only take an UNmatched neighbour.
+void form_pairwise(const HostCSR& A, int pair, double k_tg, int* vertices, int& num_agg)
+{
+    const int row = A.row;
+    const int *AIA = A.ia.data(), *AJA = A.ja.data();
+    const double* Aval = A.val.data();
+    if (pair == 1) {  // Step 1: strongly diagonally dominant rows stay out (G0)
+        for (int i = 0; i < row; ++i) {
+            double sum = 0.0;
+            for (int j = AIA[i] + 1; j < AIA[i + 1]; ++j) sum += std::fabs(Aval[j]);
+            vertices[i] = (Aval[AIA[i]] >= ((k_tg + 1.) / (k_tg - 1.)) * sum) ? G0PT : UNPT;
+        }
+    } else {
+        std::fill(vertices, vertices + row, (int)UNPT);
+    }
+    std::vector<double> s((size_t)std::max(row, 1), 0.0);  // Step 2: minus the off-diagonal row sums
+    for (int i = 0; i < row; ++i) {
+        if (vertices[i] == G0PT) continue;
+        double si = 0.0;
+        for (int j = AIA[i] + 1; j < AIA[i + 1]; ++j) si -= Aval[j];
+        s[i] = si;
+    }
+    num_agg = 0;
+    int index = 0;
+    for (int i = 0; i < row; ++i) {  // Step 3
+        if (vertices[i] != UNPT) continue;
+        double min_mu = BIGREAL;
+        const int row_start = AIA[i], row_end = AIA[i + 1];
+        const double aii = Aval[row_start];
+        for (int j = row_start + 1; j < row_end; ++j) {
+            const int col = AJA[j];
+            if (vertices[col] != UNPT) continue;
+            const double aij = Aval[j], ajj = Aval[AIA[col]];
+            double temp1 = aii + s[i] + 2 * aij;
+            double temp2 = ajj + s[col] + 2 * aij;
+            temp2 = 1.0 / temp1 + 1.0 / temp2;
+            const double temp3 = std::max(std::fabs(aii - s[i]), SMALLREAL);
+            double temp4 = std::max(std::fabs(ajj - s[col]), SMALLREAL);
+            temp4 = -aij + 1. / (1.0 / temp3 + 1.0 / temp4);
+            if (std::fabs(temp4) < SMALLREAL) temp4 = (temp4 > 0) ? SMALLREAL : -SMALLREAL;
+            const double mu = (-aij + 1.0 / temp2) / temp4;
+            if (min_mu > mu) { min_mu = mu; index = col; }
+        }
+        vertices[i] = num_agg;
+        if (min_mu <= k_tg) vertices[index] = num_agg;
+        num_agg += 1;
+    }
+}
+
+// aggregation_symmpair (PreAMGAggregationUA.inl:363): pair_number matching passes, each on the
+// Galerkin matrix of the previous one, then the aggregate indices composed.  Literal, including the
+// exit that returns the count of a pass it does not compose.
+int aggregation_symmpair(const HostCSR& A0, AMG_param& param, std::vector<int>& vv, int& nagg_out)
+{
+    const int pair_number = param.pair_number;
+    double quality_bound = param.quality_bound;
+    int num_agg = 0, dopass = 0, lvl = 0, bandwidth = 0;
+    for (int i = 0; i < A0.row; ++i) bandwidth = std::max(bandwidth, A0.ia[i + 1] - A0.ia[i]);
+    if (bandwidth > 5.0) param.quality_bound = quality_bound = 1.0 * bandwidth;
+    std::vector<HostCSR> Amid((size_t)std::max(pair_number, 1) + 1);
+    std::vector<std::vector<int>> vert((size_t)std::max(pair_number, 1) + 1);
+    const HostCSR* ptrA = &A0;
+    for (int i = 1; i <= pair_number; ++i) {
+        vert[lvl].assign((size_t)std::max(ptrA->row, 1), 0);
+        form_pairwise(*ptrA, i, quality_bound, vert[lvl].data(), num_agg);
+        if (i == 1 && num_agg < MIN_CDOF) {
+            int domin = 0;
+            for (int k = 0; k < ptrA->row; ++k) if (vert[lvl][k] == G0PT) ++domin;
+            const double isorate = (double)num_agg / domin;
+            if (isorate < 0.1) return ERROR_AMG_COARSEING;
+        }
+        if (i < pair_number) {
+            HostCSR P, R;
+            boolean_p(vert[lvl].data(), ptrA->row, num_agg, P);
+            if (P.col < MIN_CDOF) break;
+            transpose_csr(P, R);
+            galerkin_rap(R, *ptrA, P, Amid[lvl + 1]);
+            ptrA = &Amid[lvl + 1];
+        }
+        ++lvl; ++dopass;
+    }
+    vv = vert[0];
+    if (dopass > 1) {
+        for (int i = 0; i < A0.row; ++i) {
+            int aggindex = vv[i];
+            if (aggindex < 0) continue;
+            for (int j = 1; j < dopass; ++j) aggindex = vert[j][aggindex];
+            vv[i] = aggindex;
+        }
+    }
+    nagg_out = num_agg;
+    return FASP_SUCCESS;
+}
+}  // namespace
+
 int host_setup_ua(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 {
     const int    prtlvl   = param->print_level;
@@ -1083,6 +1212,10 @@ int host_setup_ua(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
     H.L.emplace_back();
     copy_csr(A, H.L[0].A);
     if (prtlvl > PRINT_NONE) std::printf("\nSetting up UA AMG ...\n");
+    if (param->aggregation_type == PAIRWISE) {  // PreAMGSetupUA.c:177-180: matching needs the diagonal first
+        param->pair_number = std::min<int>(param->pair_number, max_levels);
+        if (diagpref(H.L[0].A) < 0) return ERROR_MISC;
+    }
 
     int lvl = 0;
     try {
@@ -1091,9 +1224,13 @@ int host_setup_ua(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
             HostCSR N;
             std::vector<int> vv;
             int nagg = 0;
-            status = aggregation_vmb(Lv.A, vv, *param, lvl + 1, N, nagg);
-            if (nagg * 4.0 > Lv.A.row) param->strong_coupled /= 2.0;  // :235-238
-            else if (nagg * 1.25 < Lv.A.row) param->strong_coupled *= 2.0;
+            if (param->aggregation_type == VMB) {
+                status = aggregation_vmb(Lv.A, vv, *param, lvl + 1, N, nagg);
+                if (nagg * 4.0 > Lv.A.row) param->strong_coupled /= 2.0;  // :235-238
+                else if (nagg * 1.25 < Lv.A.row) param->strong_coupled *= 2.0;
+            } else {
+                status = aggregation_symmpair(Lv.A, *param, vv, nagg);    // :262
+            }
             if (status < 0) {  // Check 1
                 if (prtlvl > PRINT_MIN) std::printf("### WARNING: Stop coarsening on level %d!\n", lvl);
                 status = FASP_SUCCESS;
@@ -1340,6 +1477,7 @@ int host_setup_ua_bsr(const dBSRmat* A, AMG_param* param, HostHierarchyBSR& H)
     H.L.emplace_back();
     copy_bsr(A, H.L[0].A);
     if (prtlvl > PRINT_NONE) std::printf("\nSetting up UA AMG (BSR) ...\n");
+    if (param->aggregation_type == PAIRWISE) param->pair_number = std::min<int>(param->pair_number, max_levels);  // :163
 
     int lvl = 0;
     try {
@@ -1353,10 +1491,14 @@ int host_setup_ua_bsr(const dBSRmat* A, AMG_param* param, HostHierarchyBSR& H)
             condense_bsr(Lv.A, S);
             std::vector<int> vv;
             int nagg = 0;
-            status = aggregation_vmb(S, vv, *param, lvl + 1, N, nagg);
-            // the reference adapts the coupling threshold to the coarsening rate (:201-205)
-            if (nagg * 4 > S.row) param->strong_coupled /= 8.0;
-            else if (nagg * 1.25 < S.row) param->strong_coupled *= 1.5;
+            if (param->aggregation_type == VMB) {
+                status = aggregation_vmb(S, vv, *param, lvl + 1, N, nagg);
+                // the reference adapts the coupling threshold to the coarsening rate (:201-205)
+                if (nagg * 4 > S.row) param->strong_coupled /= 8.0;
+                else if (nagg * 1.25 < S.row) param->strong_coupled *= 1.5;
+            } else {  // :218-222: symmetric pairwise matching on the condensed matrix, taken as it is
+                status = aggregation_symmpair(S, *param, vv, nagg);
+            }
             if (status < 0) {
                 if (prtlvl > PRINT_MIN) std::printf("### WARNING: Forming aggregates on level-%d failed!\n", lvl);
                 status = FASP_SUCCESS;
@@ -1407,8 +1549,8 @@ int check_supported_bsr(const ITS_param* it, const AMG_param* amg, int nb)
             std::printf("### ERROR: fasp_hip: smoothed aggregation on BSR matrices has no device path\n");
             return ERROR_INPUT_PAR;
         }
-        if (amg->aggregation_type != VMB) {
-            std::printf("### ERROR: fasp_hip: BSR aggregation_type %d not supported (VMB only)\n", amg->aggregation_type);
+        if (amg->aggregation_type != VMB && amg->aggregation_type != PAIRWISE) {
+            std::printf("### ERROR: fasp_hip: BSR aggregation_type %d not supported (VMB and symmetric pairwise matching only)\n", amg->aggregation_type);
             return ERROR_INPUT_PAR;
         }
         if (amg->ILU_levels > 0 || amg->SWZ_levels > 0) {

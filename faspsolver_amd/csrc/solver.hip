@@ -131,8 +131,11 @@ struct DevCSR {
     int*    poff = nullptr;
     double* pval = nullptr;
     int     npat = 0, npent = 0;
+    unsigned short* ja16 = nullptr;  // JA as 16-bit values (long-row operators with <= 65536 columns)
     void    release()
     {
+        if (ja16) (void)hipFree(ja16);
+        ja16 = nullptr;
         if (ia) (void)hipFree(ia);
         if (ja) (void)hipFree(ja);
         if (val) (void)hipFree(val);
@@ -399,6 +402,20 @@ static bool build_rowpat(const HostCSR& M, Buf<unsigned short>& pat, std::vector
     return !collision;
 }
 
+// 16-bit copy of the column indices (in the order of the device copy) for the operators the
+// sub-wavefront kernel serves: their time is the (JA, val) stream, 12 -> 10 bytes per entry.
+static int upload_ja16(DevCSR& D, const int* ja_dev_order)
+{
+    static const bool on = !(std::getenv("FASP_HIP_JA16") && std::atoi(std::getenv("FASP_HIP_JA16")) == 0);
+    if (!on || D.kind != 0 || D.col > 65536 || D.nnz < 4096) return FASP_SUCCESS;
+    Buf<unsigned short> j16((size_t)D.nnz);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < D.nnz; ++k) j16[k] = (unsigned short)ja_dev_order[k];
+    HIPCK(hipMalloc(&D.ja16, sizeof(unsigned short) * (size_t)D.nnz));
+    HIPCK(hipMemcpy(D.ja16, j16.data(), sizeof(unsigned short) * (size_t)D.nnz, hipMemcpyHostToDevice));
+    return FASP_SUCCESS;
+}
+
 static int upload_csr(const HostCSR& H, DevCSR& D)
 {
     D.row = H.row; D.col = H.col; D.nnz = H.nnz;
@@ -491,13 +508,14 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
             HIPCK(hipMemcpy(D.dpos, dp.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
         }
         D.sorted = true;
-        return FASP_SUCCESS;
+        return upload_ja16(D, sj.data());
     }
-    return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
+    if (upload_plain() < 0) return ERROR_ALLOC_MEM;
+    return upload_ja16(D, H.ja.data());
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 8, small_lds = 1; };
+struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 8, small_lds = 1, ja16 = 1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -544,6 +562,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
     a.xcd_map = g_tune.xcd;
     a.nt = g_tune.nt;
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
+    a.ja16 = g_tune.ja16 ? M.ja16 : nullptr;
     const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : M.kind == 3 ? 1 : BLOCK / M.lanes;
     a.ntiles = (M.row + rpb - 1) / rpb;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
@@ -3803,6 +3822,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "xcd_pat")) g_tune.xcd_pat = value;
     else if (!std::strcmp(key, "spcg_batch")) g_tune.spcg_batch = value;
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
+    else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;
     else if (!std::strcmp(key, "wcap")) g_tune.wcap = value;

@@ -265,10 +265,11 @@ def bsr_protos():
     return o, R
 
 
-def bsr_params(solver=5, cycle=1):
-    """Config 3 of BASELINE.json: UA-AMG (VMB), block Jacobi, VGMRES(30), tol 1e-8."""
+def bsr_params(solver=5, cycle=1, agg=2):
+    """Config 3 of BASELINE.json: UA-AMG (agg 2 = VMB; 1 = the reference's default, symmetric
+    pairwise matching), block Jacobi, VGMRES(30), tol 1e-8."""
     itp, amgp = default_params()
-    amgp.AMG_type = T.UA_AMG; amgp.aggregation_type = 2; amgp.smoother = T.SMOOTHER_JACOBI
+    amgp.AMG_type = T.UA_AMG; amgp.aggregation_type = agg; amgp.smoother = T.SMOOTHER_JACOBI
     amgp.cycle_type = cycle
     itp.tol = 1e-8; itp.itsolver_type = solver; itp.restart = 30
     return itp, amgp

@@ -62,10 +62,11 @@ CASES = [("spe01", spe01), ("p8", lambda: synthetic(8)), ("p12", lambda: synthet
 
 
 @needs_ref
+@pytest.mark.parametrize("agg", [2, 1], ids=["vmb", "pairwise"])
 @pytest.mark.parametrize("name,make", CASES)
-def test_oracle_hierarchy_equals_reference(name, make):
+def test_oracle_hierarchy_equals_reference(name, make, agg):
     ia, ja, val, nb, f = make()
-    _, p1 = bsr_params(); _, p2 = bsr_params()
+    _, p1 = bsr_params(agg=agg); _, p2 = bsr_params(agg=agg)
     H = OrcBSR(ia, ja, val, nb, p1)
     ref_levels = ref_hierarchy(ia, ja, val, nb, p2)
     assert H.num_levels == len(ref_levels)
@@ -78,11 +79,12 @@ def test_oracle_hierarchy_equals_reference(name, make):
 
 
 @needs_ref
+@pytest.mark.parametrize("agg", [2, 1], ids=["vmb", "pairwise"])
 @pytest.mark.parametrize("solver,cycle", [(5, 1), (1, 1), (6, 2), (2, 1), (4, 1)])
 @pytest.mark.parametrize("n", [8, 12])
-def test_oracle_solve_equals_reference(n, solver, cycle):
+def test_oracle_solve_equals_reference(n, solver, cycle, agg):
     ia, ja, val, nb, f = synthetic(n)
-    i1, a1 = bsr_params(solver, cycle); i2, a2 = bsr_params(solver, cycle)
+    i1, a1 = bsr_params(solver, cycle, agg); i2, a2 = bsr_params(solver, cycle, agg)
     s1, x1, nl, rr = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
     s2, x2 = ref_bsr_solve(ia, ja, val, nb, f, i2, a2)
     assert s1 == s2 and s1 > 0
@@ -103,11 +105,12 @@ def test_oracle_spe01_one_level_equals_reference():
     assert np.array_equal(x1, x2)
 
 
+@pytest.mark.parametrize("agg", [2, 1], ids=["vmb", "pairwise"])
 @pytest.mark.parametrize("name,make", CASES)
-def test_product_host_setup_equals_oracle(name, make):
+def test_product_host_setup_equals_oracle(name, make, agg):
     """libfasp_hip's host UA-BSR setup (no GPU needed) is bit-identical to the oracle's."""
     ia, ja, val, nb, f = make()
-    _, p1 = bsr_params(); _, p2 = bsr_params()
+    _, p1 = bsr_params(agg=agg); _, p2 = bsr_params(agg=agg)
     H = OrcBSR(ia, ja, val, nb, p1)
     G = fa.BSRAMG(ia, ja, val, nb, p2, host_only=True)
     assert G.num_levels == H.num_levels
@@ -132,17 +135,18 @@ def test_bsr_unsupported_parameters_are_refused():
     amgp.AMG_type = T.SA_AMG
     assert fa.solver_dbsr_krylov_amg(ia, ja, val, nb, f, x, itp, amgp) < 0
     itp, amgp = bsr_params()
-    itp.itsolver_type = 3  # MinRes: not on the path
+    itp.itsolver_type = 3  # MinRes: the reference has no block version either (SolBSR.c:90-130)
     assert fa.solver_dbsr_krylov_amg(ia, ja, val, nb, f, x, itp, amgp) == T.ERROR_SOLVER_TYPE
 
 
 # ------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
+@pytest.mark.parametrize("agg", [2, 1], ids=["vmb", "pairwise"])
 @pytest.mark.parametrize("solver,cycle", [(5, 1), (1, 1), (6, 2), (2, 1), (4, 1)])
 @pytest.mark.parametrize("n", [8, 16, 24])
-def test_gpu_bsr_solve_matches_oracle(n, solver, cycle):
+def test_gpu_bsr_solve_matches_oracle(n, solver, cycle, agg):
     ia, ja, val, nb, f = synthetic(n)
-    i1, a1 = bsr_params(solver, cycle); i2, a2 = bsr_params(solver, cycle)
+    i1, a1 = bsr_params(solver, cycle, agg); i2, a2 = bsr_params(solver, cycle, agg)
     s1, x1, nl, rr1 = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
     G = fa.BSRAMG(ia, ja, val, nb, a2)
     s2, x2, hist, stats = G.solve(f, i2)

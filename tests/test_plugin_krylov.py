@@ -158,7 +158,9 @@ def test_gpu_amg_as_precond_equals_dropin(which, solver):
     s2, x2 = gpu_krylov(which, ia, ja, a, f, pc)
     fa.lib().fasp_hip_precond_free(pc)
     assert s1 == s2 and s1 > 0
-    assert np.array_equal(x1, x2)
+    # same computation up to the row-sum order of the deep levels: the resident handle keeps their rows
+    # sorted by column, the one-shot drop-in call skips that re-sorting
+    assert np.abs(x1 - x2).max() <= 1e-12 * np.abs(x1).max()
 
 
 @pytest.mark.gpu

@@ -1,4 +1,5 @@
-"""Unsmoothed-aggregation AMG on scalar matrices (PreAMGSetupUA.c:55, VMB aggregation):
+"""Unsmoothed-aggregation AMG on scalar matrices (PreAMGSetupUA.c:55; VMB aggregation and the reference's
+default, symmetric pairwise matching with 1-3 passes, PreAMGAggregationUA.inl:363):
 hierarchies bit-identical between product host setup, oracle and the compiled reference; solves on the device."""
 import ctypes as C
 
@@ -13,8 +14,20 @@ from _libs import DATA, OrcAMG, default_params, have_ref, oracle, orc_solve, poi
 needs_ref = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
 
 
-def ua(p):
+def ua_vmb(p):
     p.AMG_type = T.UA_AMG; p.aggregation_type = 2; p.smoother = T.SMOOTHER_JACOBI; p.relaxation = 0.6667
+
+
+def ua_pair(p):   # fasp_param_amg_init's aggregation_type (PAIRWISE), pair_number 2, quality_bound 10
+    p.AMG_type = T.UA_AMG; p.smoother = T.SMOOTHER_JACOBI; p.relaxation = 0.6667
+
+
+def ua_pair1(p): ua_pair(p); p.pair_number = 1
+def ua_pair3(p): ua_pair(p); p.pair_number = 3; p.quality_bound = 8.0
+
+
+UAS = [ua_vmb, ua_pair, ua_pair1, ua_pair3]
+UA_IDS = ["vmb", "pairwise", "pairwise1", "pairwise3"]
 
 
 def mats():
@@ -42,8 +55,9 @@ def orc_hierarchy(ia, ja, a, p):
     return H
 
 
+@pytest.mark.parametrize("ua", UAS, ids=UA_IDS)
 @pytest.mark.parametrize("name", list(MATS))
-def test_ua_hierarchy_product_equals_oracle(name):
+def test_ua_hierarchy_product_equals_oracle(name, ua):
     ia, ja, a, f = MATS[name]
     _, p1 = default_params(); ua(p1); _, p2 = default_params(); ua(p2)
     H = orc_hierarchy(ia, ja, a, p1)
@@ -63,8 +77,9 @@ def test_ua_hierarchy_product_equals_oracle(name):
 
 
 @needs_ref
+@pytest.mark.parametrize("ua", UAS, ids=UA_IDS)
 @pytest.mark.parametrize("name", list(MATS))
-def test_ua_hierarchy_oracle_equals_reference(name):
+def test_ua_hierarchy_oracle_equals_reference(name, ua):
     ia, ja, a, f = MATS[name]
     R = ref()
     _, p1 = default_params(); ua(p1); _, p2 = default_params(); ua(p2)
@@ -90,8 +105,9 @@ def _vfg_w(i, p): i.tol = 1e-8; i.itsolver_type = 6; i.restart = 30; p.cycle_typ
 
 @needs_ref
 @pytest.mark.parametrize("mod", [_pcg, _vfg_w], ids=["pcg_V", "vfgmres_W"])
+@pytest.mark.parametrize("ua", UAS, ids=UA_IDS)
 @pytest.mark.parametrize("name", list(MATS))
-def test_ua_solves_oracle_equals_reference(name, mod):
+def test_ua_solves_oracle_equals_reference(name, mod, ua):
     ia, ja, a, f = MATS[name]
     i1, a1 = default_params(); ua(a1); mod(i1, a1)
     i2, a2 = default_params(); ua(a2); mod(i2, a2)
@@ -101,17 +117,18 @@ def test_ua_solves_oracle_equals_reference(name, mod):
     assert np.array_equal(x1, x2)
 
 
-def test_ua_pairwise_default_is_refused():
+def test_ua_unsymmetric_pairwise_is_refused():
     ia, ja, a, f = MATS["p7_10"]
-    itp, amgp = default_params(); amgp.AMG_type = T.UA_AMG; amgp.smoother = T.SMOOTHER_JACOBI
+    itp, amgp = default_params(); amgp.AMG_type = T.UA_AMG; amgp.smoother = T.SMOOTHER_JACOBI; amgp.aggregation_type = 3  # NPAIR
     x = np.zeros(len(f))
     assert fa.solver_dcsr_krylov_amg(ia, ja, a, f, x, itp, amgp) == T.ERROR_INPUT_PAR
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mod", [_pcg, _vfg_w], ids=["pcg_V", "vfgmres_W"])
+@pytest.mark.parametrize("ua", UAS, ids=UA_IDS)
 @pytest.mark.parametrize("n", [16, 32])
-def test_gpu_ua_solve_matches_oracle(n, mod):
+def test_gpu_ua_solve_matches_oracle(n, mod, ua):
     ia, ja, a, f, ue = poisson7pt(n)
     i1, a1 = default_params(); ua(a1); mod(i1, a1)
     i2, a2 = default_params(); ua(a2); mod(i2, a2)
