@@ -885,9 +885,14 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
         }
         switch (amg->smoother) {
             case SMOOTHER_JACOBI: case SMOOTHER_L1DIAG:  // order independent: bandwidth-bound kernels
+            case SMOOTHER_POLY:                           // SpMVs + elementwise steps (ItrSmootherCSRpoly.c:67)
             case SMOOTHER_GS: case SMOOTHER_SGS: case SMOOTHER_SOR: case SMOOTHER_SSOR:
             case SMOOTHER_GSOR: case SMOOTHER_SGSOR:     // sequential sweeps: level-scheduled
                 break;
+            case SMOOTHER_JACOBIF:                        // Jacobi on the F points: needs the C/F marker
+                if (amg->AMG_type == CLASSIC_AMG) break;
+                std::printf("### ERROR: fasp_hip: the F-point Jacobi smoother needs a classical (C/F) hierarchy\n");
+                return ERROR_AMG_SMOOTH_TYPE;
             default:
                 std::printf("### ERROR: fasp_hip: smoother %d has no device path\n", amg->smoother);
                 return ERROR_AMG_SMOOTH_TYPE;

@@ -69,8 +69,19 @@ struct CsrArgs {
     int           npat, npent;
     int           ncol;     // length of x (buffer-load range check)
     const int*    stop;     // != nullptr: the launch returns at once when *stop != 0 (queued-ahead iterations)
+    const int*    mark;     // OP_L1DIAG only, != nullptr: C/F marker, the sweep is Jacobi on the F points (0) with weight omega
     const unsigned short* ja16;  // != nullptr: the column indices once more as 16-bit values (operators with <= 65536 columns)
 };
+
+// Epilogue of OP_L1DIAG, t = b_i - sum_j a_ij x_j accumulated from b_i entry by entry: the L1
+// smoother x_i + t / sum_j |a_ij| (ItrSmootherCSR.c:1509), or -- with a C/F marker -- Jacobi on the
+// F points only, x_i + w t / a_ii there and x_i elsewhere (fasp_smoother_dcsr_jacobi_ff, :34-74;
+// no guard on the diagonal in the reference).
+__device__ __forceinline__ double l1_or_jacobi_f(const CsrArgs& a, int r, double t, double d, double xi)
+{
+    if (a.mark) return a.mark[r] == 0 ? xi + a.omega * t / d : xi;
+    return (fabs(d) > 1e-20) ? xi + t / d : xi;
+}
 
 // Column index of entry k.  Long-row operators with at most 65536 columns carry a 16-bit copy of JA:
 // 10 instead of 12 bytes per entry on the levels where the matrix stream is all there is.
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
                 } else if (OP == OP_L1DIAG) {
                     const double d = a.diag[r], xi = a.x[r];
                     const double tt = a.b[r] - s;
-                    a.y[r] = (fabs(d) > 1e-20) ? xi + tt / d : xi;
+                    a.y[r] = l1_or_jacobi_f(a, r, tt, d, xi);
                 } else if (OP == OP_MXV_DOT) {
                     a.y[r] = s;
                     acc += s * a.dotv[r];
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_blockrow(CsrArgs a)
             } else if (OP == OP_L1DIAG) {
                 const double d = a.diag[r], xi = a.x[r];
                 const double tt = a.b[r] - s;
-                a.y[r] = (fabs(d) > 1e-20) ? xi + tt / d : xi;
+                a.y[r] = l1_or_jacobi_f(a, r, tt, d, xi);
             } else if (OP == OP_MXV_DOT) {
                 a.y[r] = s;
                 acc += s * a.dotv[r];
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(CsrArgs a, int R)
                     a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * s / d : xi;
                 } else if (OP == OP_L1DIAG) {
                     const double d = a.diag[r], xi = a.x[r];  // s == t_i of the reference
-                    a.y[r] = (fabs(d) > 1e-20) ? xi + s / d : xi;
+                    a.y[r] = l1_or_jacobi_f(a, r, s, d, xi);
                 } else if (OP == OP_MXV_DOT) {
                     a.y[r] = s;
                     dotacc += s * a.dotv[r];
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_dict8(CsrArgs a)
                 a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * s / d : xi;
             } else if (OP == OP_L1DIAG) {
                 const double d = a.diag[r], xi = a.x[r];
-                a.y[r] = (fabs(d) > 1e-20) ? xi + s / d : xi;
+                a.y[r] = l1_or_jacobi_f(a, r, s, d, xi);
             } else if (OP == OP_MXV_DOT) {
                 a.y[r] = s;
                 dotacc += s * a.dotv[r];
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat(CsrArgs a)
             else if (OP == OP_SUB) a.y[r] -= s;
             else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
             else if (OP == OP_JACOBI) a.y[r] = (fabs(dg[q]) > 1e-20) ? (1 - a.omega) * xi[q] + a.omega * s / dg[q] : xi[q];
-            else if (OP == OP_L1DIAG) a.y[r] = (fabs(dg[q]) > 1e-20) ? xi[q] + s / dg[q] : xi[q];
+            else if (OP == OP_L1DIAG) a.y[r] = l1_or_jacobi_f(a, r, s, dg[q], xi[q]);
             else if (OP == OP_MXV_DOT) {
                 a.y[r] = s;
                 dotacc += s * a.dotv[r];
@@ -759,7 +770,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream(CsrArgs a)
                 a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * s / d : xi;
             } else if (OP == OP_L1DIAG) {
                 const double d = a.diag[r], xi = a.x[r];
-                a.y[r] = (fabs(d) > 1e-20) ? xi + s / d : xi;
+                a.y[r] = l1_or_jacobi_f(a, r, s, d, xi);
             } else if (OP == OP_MXV_DOT) {
                 a.y[r] = s;
                 dotacc += s * a.dotv[r];
@@ -937,6 +948,40 @@ __global__ __launch_bounds__(BLOCK) void k_seq_level(const int* __restrict__ ord
 struct Vec2 { double x, y; };
 
 // y += a*x   (a == +-1 round identically to the reference's y += x / y -= x branches)
+// ---------------------------------------------------------------------------
+// polynomial smoother (ItrSmootherCSRpoly.c:551 Rr): the elementwise steps between its SpMVs
+// ---------------------------------------------------------------------------
+// rbar = Dinv r
+__global__ __launch_bounds__(BLOCK) void k_poly_scale(int n, const double* __restrict__ dinv, const double* __restrict__ r,
+                                                       double* __restrict__ rbar)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) rbar[i] = dinv[i] * r[i];
+}
+// v1 = Dinv v1; v0 = k1 rbar; v1 = k2 rbar - k3 v1
+__global__ __launch_bounds__(BLOCK) void k_poly_start(int n, double k1, double k2, double k3, const double* __restrict__ dinv,
+                                                       const double* __restrict__ rbar, double* __restrict__ v0,
+                                                       double* __restrict__ v1)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double w = dinv[i] * v1[i];
+        v0[i] = k1 * rbar[i];
+        v1[i] = k2 * rbar[i] - k3 * w;
+    }
+}
+// rbar = (r - A v1) Dinv (rbar holds A v1 on entry); vnew = v1 + k5 (v1 - v0) + k4 rbar; v0 = v1; v1 = vnew
+__global__ __launch_bounds__(BLOCK) void k_poly_step(int n, double k4, double k5, const double* __restrict__ dinv,
+                                                      const double* __restrict__ r, double* __restrict__ rbar,
+                                                      double* __restrict__ v0, double* __restrict__ v1,
+                                                      double* __restrict__ vnew)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double rb = (r[i] - rbar[i]) * dinv[i];
+        const double a1 = v1[i];
+        const double nw = a1 + k5 * (a1 - v0[i]) + k4 * rb;
+        rbar[i] = rb; vnew[i] = nw; v0[i] = a1; v1[i] = nw;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_axpy(int n, double a, const double* __restrict__ x,
                                                  double* __restrict__ y)
 {

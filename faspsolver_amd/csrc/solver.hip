@@ -713,6 +713,11 @@ struct DevLevel {
     // 1 descending, 2 ascending C rows, 3 ascending F rows, 4 descending from row n-2
     struct Sched { bool built = false; int* d_order = nullptr; std::vector<int> ptr; };
     Sched   sched[5];
+    // polynomial smoother (built on first use): 1 / first diagonal hit, the coefficients k[1..5] of
+    // ItrSmootherCSRpoly.c:101-109, work vectors r, rbar, v0, v1, vnew
+    struct Poly { bool built = false; double* dinv = nullptr; double k[6] = {0, 0, 0, 0, 0, 0}; double* w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
+    Poly    poly;
+    int*    d_mark = nullptr;  // C/F marker on the device (Jacobi-F smoother), built on first use
 };
 
 struct EventPair { hipEvent_t a, b; };
@@ -757,6 +762,9 @@ static void free_level(DevLevel& D)
     if (D.d_send_idx) (void)hipFree(D.d_send_idx);
     if (D.d_sendbuf) (void)hipFree(D.d_sendbuf);
     for (auto& sc : D.sched) if (sc.d_order) (void)hipFree(sc.d_order);
+    if (D.poly.dinv) (void)hipFree(D.poly.dinv);
+    for (double* q : D.poly.w) if (q) (void)hipFree(q);
+    if (D.d_mark) (void)hipFree(D.d_mark);
     D = DevLevel();
 }
 
@@ -832,7 +840,7 @@ static int upload_hierarchy(fasp_hip_amg* h)
     if (const char* e = std::getenv("FASP_HIP_DIST_MIN_ROWS")) min_rows = std::atoi(e);
     // sequential (Gauss-Seidel / SOR) sweeps couple all rows of a level: such hierarchies
     // are not row-partitioned, every rank keeps (and computes) all levels
-    if (h->param.smoother != SMOOTHER_JACOBI && h->param.smoother != SMOOTHER_L1DIAG) min_rows = 2147483647;
+    if (h->param.smoother != SMOOTHER_JACOBI && h->param.smoother != SMOOTHER_L1DIAG && h->param.smoother != SMOOTHER_POLY) min_rows = 2147483647;
     {
         const int st = build_dist_plan(h->H, comm_rank(), comm_size(), min_rows, h->dist);
         if (st < 0) return st;
@@ -983,10 +991,97 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
 // Smoother dispatch of PreMGSmoother.inl:49 (pre) / :155 (post).  Jacobi and L1-diag are
 // order independent, so their pre (ascending) and post (descending) sweeps coincide; the
 // Gauss-Seidel / SOR family runs as level-scheduled sequential sweeps.
-static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order, int nsweeps, double relax)
+// fasp_smoother_dcsr_poly (ItrSmootherCSRpoly.c:67): per sweep r = b - A u, then the recurrence of
+// Rr (:551) -- ndeg SpMVs and elementwise steps -- and u += correction.  Order independent, so the
+// level may be row-partitioned (every SpMV input gets its halo).  Dinv and the coefficients depend
+// on the matrix only: formed once per level on the host exactly as the reference does per call.
+static int poly_smooth(fasp_hip_amg* h, int level, int ndeg, int nsweeps)
 {
     DevLevel& D = h->L[level];
     const int n = D.A.row;
+    DevLevel::Poly& Q = D.poly;
+    hipStream_t s = g_ctx.stream;
+    if (!Q.built) {
+        // every rank holds the whole host hierarchy: local row i is global row r0 + i, and the
+        // norm (a maximum over ALL rows of the level) needs no exchange
+        const HostCSR& A = h->H.L[level].A;
+        const int r0 = D.replicated ? 0 : D.row0;
+        std::vector<double> dinv((size_t)std::max(n, 1));
+        double norm = 0.0;
+        for (int gi = 0; gi < A.row; ++gi) {  // Diaginv :392 (first hit) and DinvAnorminf :428
+            int j = A.ia[gi];
+            for (; j < A.ia[gi + 1]; ++j) if (A.ja[j] == gi) break;
+            const double di = 1.0 / A.val[j];
+            if (gi >= r0 && gi < r0 + n) dinv[(size_t)(gi - r0)] = di;
+            double temp = 0.0;
+            for (int q = A.ia[gi]; q < A.ia[gi + 1]; ++q) temp += std::fabs(A.val[q]);
+            temp *= di;
+            norm = std::max(norm, temp);
+        }
+        double mu0 = norm;
+        mu0 = 1.0 / mu0;
+        const double mu1 = 4.0 * mu0, smu0 = std::sqrt(mu0), smu1 = std::sqrt(mu1);
+        Q.k[1] = (mu0 + mu1) / 2.0;
+        Q.k[2] = (smu0 + smu1) * (smu0 + smu1) / 2.0;
+        Q.k[3] = mu0 * mu1;
+        Q.k[4] = 2.0 * Q.k[3] / Q.k[2];
+        Q.k[5] = (mu1 - 2.0 * smu0 * smu1 + mu0) / (mu1 + 2.0 * smu0 * smu1 + mu0);
+        HIPCK(hipMalloc(&Q.dinv, sizeof(double) * std::max(n, 1)));
+        HIPCK(hipMemcpy(Q.dinv, dinv.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        for (double*& q : Q.w) {
+            if (alloc_vec(&q, (size_t)D.nvec) < 0) return ERROR_ALLOC_MEM;
+        }
+        Q.built = true;
+    }
+    double *r = Q.w[0], *rbar = Q.w[1], *v0 = Q.w[2], *v1 = Q.w[3], *vnew = Q.w[4];
+    const int G = vec_grid(n);
+    for (int it = 0; it < nsweeps; ++it) {
+        if (D.x_zero) {  // u == 0: r = b exactly, no matrix pass
+            HIPCK(hipMemcpyAsync(r, D.b, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            materialise_zero(D);
+        } else {
+            if (halo_exchange(D, D.x) < 0) return ERROR_MISC;
+            d_resid(D.A, D.x, D.b, r);
+        }
+        hipLaunchKernelGGL(k_poly_scale, dim3(G), dim3(BLOCK), 0, s, n, Q.dinv, r, rbar);
+        if (halo_exchange(D, rbar) < 0) return ERROR_MISC;
+        d_mxv(D.A, rbar, v1);
+        hipLaunchKernelGGL(k_poly_start, dim3(G), dim3(BLOCK), 0, s, n, Q.k[1], Q.k[2], Q.k[3], Q.dinv, rbar, v0, v1);
+        if (ndeg <= 1) HIPCK(hipMemsetAsync(vnew, 0, sizeof(double) * n, s));  // the reference's correction stays zero
+        for (int j = 1; j < ndeg; ++j) {
+            if (halo_exchange(D, v1) < 0) return ERROR_MISC;
+            d_mxv(D.A, v1, rbar);
+            hipLaunchKernelGGL(k_poly_step, dim3(G), dim3(BLOCK), 0, s, n, Q.k[4], Q.k[5], Q.dinv, r, rbar, v0, v1, vnew);
+        }
+        d_axpy(n, 1.0, vnew, D.x);
+    }
+    return FASP_SUCCESS;
+}
+
+static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order, int nsweeps, double relax, int ndeg)
+{
+    DevLevel& D = h->L[level];
+    const int n = D.A.row;
+    if (smoother == SMOOTHER_POLY) return poly_smooth(h, level, ndeg, nsweeps);
+    if (smoother == SMOOTHER_JACOBIF) {  // fasp_smoother_dcsr_jacobi_ff, ItrSmootherCSR.c:34
+        const Buf<int>& cf = h->H.L[level].cfmark;
+        if (!D.replicated || cf.n != (size_t)n) {
+            std::printf("### ERROR: fasp_hip: Jacobi-F needs the C/F marker of a classical hierarchy (one GPU)\n");
+            return ERROR_AMG_SMOOTH_TYPE;
+        }
+        if (!D.d_mark) {
+            HIPCK(hipMalloc(&D.d_mark, sizeof(int) * std::max(n, 1)));
+            HIPCK(hipMemcpy(D.d_mark, cf.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+        }
+        materialise_zero(D);
+        for (int s = 0; s < nsweeps; ++s) {
+            CsrArgs a{};
+            a.x = D.x; a.y = D.xo; a.b = D.b; a.omega = relax; a.diag = D.diag; a.mark = D.d_mark;
+            launch_csr<OP_L1DIAG>(D.A, a);
+            std::swap(D.x, D.xo);
+        }
+        return FASP_SUCCESS;
+    }
     if (smoother == SMOOTHER_JACOBI || smoother == SMOOTHER_L1DIAG) {
         for (int s = 0; s < nsweeps; ++s) {
             if (D.x_zero) {
@@ -2117,7 +2212,7 @@ ForwardSweep:
     while (l < nl - 1) {
         DevLevel& D = h->L[l];
         num_lvl[l]++;
-        if ((st0 = smooth(h, l, false, smoother, param.smooth_order, param.presmooth_iter, relax)) < 0) return st0;
+        if ((st0 = smooth(h, l, false, smoother, param.smooth_order, param.presmooth_iter, relax, param.polynomial_degree)) < 0) return st0;
         // w = b - A x ; b_{l+1} = R w
         if (D.x_zero) {
             HIPCK(hipMemcpyAsync(D.w, D.b, sizeof(double) * D.A.row, hipMemcpyDeviceToDevice, g_ctx.stream));
@@ -2185,7 +2280,7 @@ ForwardSweep:
             alpha = std::min(red[0] / red[1], 1.0);
         }
         d_aAxpy(alpha, D.P, C.x, D.x);  // x_l += alpha P x_{l+1}
-        if ((st0 = smooth(h, l, true, smoother, param.smooth_order, param.postsmooth_iter, relax)) < 0) return st0;
+        if ((st0 = smooth(h, l, true, smoother, param.smooth_order, param.postsmooth_iter, relax, param.polynomial_degree)) < 0) return st0;
         if (num_lvl[l] < ncycles[l]) break;
         else num_lvl[l] = 0;
     }

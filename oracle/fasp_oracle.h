@@ -83,6 +83,10 @@ void orc_smoother_sor(double* u, int i_1, int i_n, int s, const dCSRmat* A,
                       const double* b, int L, double w);                       /* :932 */
 void orc_smoother_l1diag(double* u, int i_1, int i_n, int s, const dCSRmat* A,
                          const double* b, int L);                              /* :1509 */
+void orc_smoother_jacobi_ff(double* x, const dCSRmat* A, const double* b, int nsweeps,
+                            const int* ordering, double relax);                /* :34 */
+void orc_smoother_poly(const dCSRmat* A, const double* b, double* u, int n, int ndeg,
+                       int L);                                                 /* ItrSmootherCSRpoly.c:67 */
 
 /* sparse utilities used by the setup */
 void orc_dcsr_trans(const dCSRmat* A, dCSRmat* AT);                            /* BlaSparseCSR.c:952 */

@@ -145,9 +145,31 @@ def _jac_cs(itp, amgp):
     _jac(itp, amgp); amgp.coarse_scaling = 1
 
 
+def _poly3(itp, amgp):
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_POLY
+
+
+def _poly5w(itp, amgp):
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_POLY; amgp.polynomial_degree = 5; amgp.cycle_type = T.W_CYCLE
+    amgp.presmooth_iter = 2
+
+
+def _poly1(itp, amgp):   # degree 1: the reference's correction stays zero, the solve stagnates the same way
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_POLY; amgp.polynomial_degree = 1; itp.maxit = 30
+
+
+def _jacf(itp, amgp):    # Jacobi on the F points only (ItrSmootherCSR.c:34); stagnates for n >= 20 in the reference too
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_JACOBIF; amgp.relaxation = 0.8
+
+
+def _jacf23(itp, amgp):
+    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_JACOBIF; amgp.presmooth_iter = 2; amgp.postsmooth_iter = 3
+
+
 @pytest.mark.parametrize("n", [8, 16, 32, 48])
-@pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22, _jac_cs],
-                         ids=["jacobi-V", "jacobi-W", "l1diag-V", "jacobi-V22", "jacobi-V-coarse-scaling"])
+@pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22, _jac_cs, _poly3, _poly5w, _poly1, _jacf, _jacf23],
+                         ids=["jacobi-V", "jacobi-W", "l1diag-V", "jacobi-V22", "jacobi-V-coarse-scaling",
+                              "poly3-V", "poly5-W", "poly1-V", "jacobiF-V", "jacobiF-V23"])
 def test_pcg_history_poisson(gpu, n, mod):
     if n == 48 and mod is not _jac:
         pytest.skip("largest size only for the headline configuration")
@@ -300,7 +322,7 @@ def test_regression_defaults_fe(gpu):
 
 def test_unsupported_is_refused(gpu):
     ia, ja, a, f, ue = poisson7pt(6)
-    itp, amgp = default_params(); amgp.smoother = 9  # SMOOTHER_POLY: not on the path
+    itp, amgp = default_params(); amgp.smoother = 4  # SMOOTHER_CG: not on the path
     x = np.zeros(len(f))
     assert gpu.solver_dcsr_krylov_amg(ia, ja, a, f, x, itp, amgp) == T.ERROR_AMG_SMOOTH_TYPE
     assert np.all(x == 0.0)

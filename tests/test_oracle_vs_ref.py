@@ -41,11 +41,16 @@ def _mods():
     def vg4(i, a): jac(i, a); i.itsolver_type = T.SOLVER_VGMRES; i.restart = 4
     def vfg(i, a): jac(i, a); i.itsolver_type = T.SOLVER_VFGMRES; i.restart = 30
     def vfg5w(i, a): jac(i, a); i.itsolver_type = T.SOLVER_VFGMRES; i.restart = 5; a.cycle_type = T.W_CYCLE
+    def poly3(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_POLY
+    def poly5w(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_POLY; a.polynomial_degree = 5; a.cycle_type = T.W_CYCLE; a.presmooth_iter = 2
+    def poly1(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_POLY; a.polynomial_degree = 1; i.maxit = 30   # degree 1: the correction stays zero
+    def jacf(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_JACOBIF; a.relaxation = 0.8
+    def jacf2(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_JACOBIF; a.relaxation = 1.0; a.presmooth_iter = 2; a.postsmooth_iter = 3
     def vgpre(i, a): vg(i, a); i.stop_type = T.STOP_REL_PRECRES
     def vfgmod(i, a): vfg(i, a); i.stop_type = T.STOP_MOD_REL_RES
     return dict(jac=jac, jacw=jacw, vw=vw, l1=l1, gscf=gscf, gsn=gsn, sor=sor, ssor=ssor, sgs=sgs,
                 theta=theta, precres=precres, modres=modres, gsor=gsor, sgsor=sgsor, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
-                vgpre=vgpre, vfgmod=vfgmod)
+                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2)
 
 
 @pytest.mark.parametrize("name", list(_mods().keys()))
@@ -58,7 +63,7 @@ def test_histories_bit_exact(R, n, name):
     s2, x2, h2 = ref_solve(ia, ja, a, f, i2, a2)
     assert s1 == s2
     assert np.array_equal(x1, x2)
-    if name in ("jac", "jacw", "vw", "l1", "gscf", "gsn", "sor", "ssor", "sgs", "theta", "gsor", "sgsor"):
+    if name in ("jac", "jacw", "vw", "l1", "gscf", "gsn", "sor", "ssor", "sgs", "theta", "gsor", "sgsor", "poly3", "poly5w"):
         # PCG with STOP_REL_RES: the recorded preconditioner inputs are exactly the residuals
         assert np.array_equal(np.concatenate([h1[:-2], h1[-1:]]), h2)
 
