@@ -2190,6 +2190,249 @@ static int gcr_device(KOps& K, const double* b, double* x, double tol, double ab
 }
 
 // ---------------------------------------------------------------------------
+// Matrix-free family (SolMatFree.c): the reference keeps older texts of CG and of the GMRES
+// variants for the mxv_matfree interface; they are restated separately (oracle: pcg_mf_core,
+// gmres_mf_core).  BiCGstab and GCG perform the arithmetic of their CSR texts.
+// ---------------------------------------------------------------------------
+// fasp_solver_pcg, KryPcg.c:1260-1540
+static int pcg_mf_device(KOps& K, const double* b, double* u, double tol, double abstol, int MaxIt, int StopType,
+                         int PrtLvl, PcgOut* out)
+{
+    KVecOps V(K);
+    const int m = V.m;
+    const double maxdiff = tol * STAG_RATIO, sol_inf_tol = SMALLREAL;
+    int iter = 0, stag = 1, more_step = 1;
+    double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL, normr0 = BIGREAL;
+    double reldiff, factor, alpha, beta, temp1 = 0.0, temp2, red[8], pp;
+    KCK(V.ensure(4));
+    double *p = V.vec(0), *z = V.vec(1), *r = V.vec(2), *t = V.vec(3);
+    auto rel_from = [&]() -> int {  // relres per stop type from the current r (absres is ||r||_2 throughout)
+        switch (StopType) {
+            case STOP_REL_PRECRES:
+                KCK(V.pc(r, z)); KCK(V.dot(z, r, temp2));
+                relres = std::sqrt(std::fabs(temp2)) / normr0; break;
+            case STOP_MOD_REL_RES: relres = absres / normu; break;
+            default: relres = absres / normr0; break;
+        }
+        return 0;
+    };
+    if (PrtLvl > PRINT_NONE) std::printf("\nCalling CG solver (MatFree) ...\n");
+    KCK(V.resid(u, b, r));
+    KCK(V.pc(r, z));
+    switch (StopType) {
+        case STOP_REL_PRECRES:
+            KCK(V.dot(r, z, temp2)); absres0 = std::sqrt(temp2); normr0 = std::max(SMALLREAL, absres0); relres = absres0 / normr0; break;
+        case STOP_MOD_REL_RES:
+            KCK(V.nrm2(r, absres0)); KCK(V.nrm2(u, normu)); normu = std::max(SMALLREAL, normu); relres = absres0 / normu; break;
+        default:
+            KCK(V.nrm2(r, absres0)); normr0 = std::max(SMALLREAL, absres0); relres = absres0 / normr0; break;
+    }
+    if (relres < tol || absres0 < abstol) goto FINISHED;
+    KCK(V.cp(p, z));
+    KCK(V.dot(z, r, temp1));
+    while (iter++ < MaxIt) {
+        KCK(V.mxv(p, t));
+        KCK(V.dot(t, p, temp2));
+        alpha = temp1 / temp2;
+        d_axpy(m, alpha, p, u);
+        d_axpy(m, -alpha, t, r);
+        KCK(V.nrm2(r, absres));
+        factor = absres / absres0;
+        KCK(rel_from());
+        itinfo(PrtLvl, StopType, iter, relres, absres, factor);
+        if (d_norms(m, u, red, K.dist) < 0) return ERROR_MISC;
+        if (red[1] <= sol_inf_tol) {
+            if (PrtLvl > PRINT_MIN) std::printf("### WARNING: Iteration stopped -- solution almost zero! [%s:%d]\n", "fasp_solver_pcg", 1390);
+            iter = ERROR_SOLVER_SOLSTAG;
+            break;
+        }
+        normu = std::sqrt(red[0]);
+        KCK(V.nrm2(p, pp));
+        reldiff = std::fabs(alpha) * pp / normu;
+        if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {
+            if (PrtLvl >= PRINT_MORE) {
+                std::printf("||u-u'|| = %.10e and the comp. rel. res. = %.10e.\n", reldiff, relres);
+                std::printf("### WARNING: Iteration restarted -- stagnation! [%s:%d]\n", "fasp_solver_pcg", 1404);
+            }
+            KCK(V.resid(u, b, r));
+            KCK(V.nrm2(r, absres));
+            KCK(rel_from());
+            if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+            if (relres < tol) break;
+            if (stag >= MAX_STAG) {
+                if (PrtLvl > PRINT_MIN) std::printf("### WARNING: Iteration stopped -- staggnation! [%s:%d]\n", "fasp_solver_pcg", 1437);
+                iter = ERROR_SOLVER_STAG;
+                break;
+            }
+            KCK(V.zero(p));
+            ++stag;
+        }
+        if (relres < tol) {
+            if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The computed relative residual = %.10e!\n", relres);
+            KCK(V.resid(u, b, r));
+            if (StopType != STOP_REL_PRECRES) KCK(V.nrm2(r, absres));
+            KCK(rel_from());
+            if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+            if (relres < tol) break;
+            if (more_step >= MAX_RESTART) {
+                if (PrtLvl > PRINT_MIN) std::printf("### WARNING: The tolerence might be too small! [%s:%d]\n", "fasp_solver_pcg", 1487);
+                iter = ERROR_SOLVER_TOLSMALL;
+                break;
+            }
+            KCK(V.zero(p));
+            ++more_step;
+        }
+        absres0 = absres;
+        if (StopType != STOP_REL_PRECRES) KCK(V.pc(r, z));
+        KCK(V.dot(z, r, temp2));
+        beta = temp2 / temp1;
+        temp1 = temp2;
+        d_axpby(m, 1.0, z, beta, p);
+    }
+FINISHED:
+    if (PrtLvl > PRINT_NONE) {
+        if (iter > MaxIt) std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, relres);
+        else if (iter >= 0) std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, relres);
+    }
+    if (out) { out->relres = relres; out->absres = absres; out->normr0 = normr0; }
+    HIPCK(hipStreamSynchronize(V.s));
+    return iter > MaxIt ? ERROR_SOLVER_MAXIT : iter;
+}
+
+// fasp_solver_pgmres / _pvgmres / _pvfgmres for mxv_matfree (KryPgmres.c:1309, KryPvgmres.c:1468,
+// KryPvfgmres.c:1026): one text with two switches; stops on ||r|| <= tol ||b||, StopType ignored.
+static int gmres_mf_device(KOps& K, bool variable, bool flexible, const double* b, double* x, double tol, int MaxIt,
+                           int restart, int StopType, int PrtLvl, PcgOut* out)
+{
+    KVecOps V(K);
+    const int n = V.m, min_iter = 0;
+    const double cr_max = 0.99, cr_min = 0.174, epsmac = SMALLREAL;
+    int iter = 0, i, j, k;
+    double r_norm, b_norm, den_norm, epsilon, gamma, t, cr = 1.0, r_norm_old = 0.0, prev;
+    const int d = 3, restart_max = restart, restart_min = 3;
+    int Restart = restart;
+    const int Restart1 = restart + 1;
+    if (restart < 1) return ERROR_INPUT_PAR;
+    KCK(V.ensure(2 + (size_t)Restart1 * (flexible ? 2 : 1)));
+    double *r = V.vec(0), *w = V.vec(1);
+    auto P = [&](int q) { return V.vec(2 + (size_t)q); };
+    auto Z = [&](int q) { return V.vec(2 + (size_t)Restart1 + (size_t)q); };
+    std::vector<double> rs((size_t)Restart1 + 1), c((size_t)Restart1), sn((size_t)Restart1);
+    std::vector<std::vector<double>> hh((size_t)Restart1, std::vector<double>((size_t)restart + 1, 0.0));
+    if (PrtLvl > PRINT_NONE)
+        std::printf(flexible ? "\nCalling VFGMRes solver (MatFree) ...\n" : variable ? "\nCalling VGMRes solver (MatFree) ...\n"
+                                                                                    : "\nCalling GMRes solver (MatFree) ...\n");
+    KCK(V.resid(x, b, P(0)));
+    KCK(V.nrm2(b, b_norm));
+    KCK(V.nrm2(P(0), r_norm));
+    prev = r_norm;
+    if (PrtLvl >= PRINT_SOME) {
+        std::printf("L2 norm of %s = %.10e.\n", "right-hand side", b_norm);
+        std::printf("L2 norm of %s = %.10e.\n", "residual", r_norm);
+    }
+    den_norm = (b_norm > 0.0) ? b_norm : r_norm;
+    epsilon = tol * den_norm;
+    while (iter < MaxIt) {
+        rs[0] = r_norm;
+        r_norm_old = r_norm;
+        if (r_norm == 0.0) {
+            if (out) { out->relres = 0.0; out->absres = 0.0; out->normr0 = den_norm; }
+            HIPCK(hipStreamSynchronize(V.s));
+            return iter;
+        }
+        if (variable) {
+            if (cr > cr_max || iter == 0) Restart = restart_max;
+            else if (cr < cr_min) { /* keep */ }
+            else { if (Restart - d > restart_min) Restart -= d; else Restart = restart_max; }
+        }
+        if (r_norm <= epsilon && iter >= min_iter) {
+            KCK(V.resid(x, b, r));
+            KCK(V.nrm2(r, r_norm));
+            if (r_norm <= epsilon) break;
+            if (PrtLvl >= PRINT_SOME) std::printf("### WARNING: False convergence! [%s:%d]\n", "fasp_solver_pvgmres", 1620);
+        }
+        d_scale(n, 1.0 / r_norm, P(0));
+        i = 0;
+        while (i < Restart && iter < MaxIt) {
+            i++; iter++;
+            if (flexible) { KCK(V.pc(P(i - 1), Z(i - 1))); KCK(V.mxv(Z(i - 1), P(i))); }
+            else          { KCK(V.pc(P(i - 1), r));        KCK(V.mxv(r, P(i))); }
+            for (j = 0; j < i; j++) {  // modified Gram-Schmidt
+                KCK(V.dot(P(j), P(i), hh[j][i - 1]));
+                d_axpy(n, -hh[j][i - 1], P(j), P(i));
+            }
+            KCK(V.nrm2(P(i), t));
+            hh[i][i - 1] = t;
+            if (t != 0.0) d_scale(n, 1.0 / t, P(i));
+            for (j = 1; j < i; ++j) {
+                t = hh[j - 1][i - 1];
+                hh[j - 1][i - 1] = sn[j - 1] * hh[j][i - 1] + c[j - 1] * t;
+                hh[j][i - 1] = -sn[j - 1] * t + c[j - 1] * hh[j][i - 1];
+            }
+            t = hh[i][i - 1] * hh[i][i - 1];
+            t += hh[i - 1][i - 1] * hh[i - 1][i - 1];
+            gamma = std::sqrt(t);
+            if (gamma == 0.0) gamma = epsmac;
+            c[i - 1] = hh[i - 1][i - 1] / gamma;
+            sn[i - 1] = hh[i][i - 1] / gamma;
+            rs[i] = -sn[i - 1] * rs[i - 1];
+            rs[i - 1] = c[i - 1] * rs[i - 1];
+            hh[i - 1][i - 1] = sn[i - 1] * hh[i][i - 1] + c[i - 1] * hh[i - 1][i - 1];
+            r_norm = std::fabs(rs[i]);
+            if (b_norm > 0) itinfo(PrtLvl, StopType, iter, r_norm / b_norm, r_norm, r_norm / prev);
+            else itinfo(PrtLvl, StopType, iter, r_norm, r_norm, r_norm / prev);
+            prev = r_norm;
+            if (r_norm <= epsilon && iter >= min_iter) break;
+        }
+        rs[i - 1] = rs[i - 1] / hh[i - 1][i - 1];
+        for (k = i - 2; k >= 0; k--) {
+            t = 0.0;
+            for (j = k + 1; j < i; j++) t -= hh[k][j] * rs[j];
+            t += rs[k];
+            rs[k] = t / hh[k][k];
+        }
+        if (flexible) {
+            KCK(V.cp(r, Z(i - 1)));
+            d_scale(n, rs[i - 1], r);
+            for (j = i - 2; j >= 0; j--) d_axpy(n, rs[j], Z(j), r);
+        } else {
+            KCK(V.cp(w, P(i - 1)));
+            d_scale(n, rs[i - 1], w);
+            for (j = i - 2; j >= 0; j--) d_axpy(n, rs[j], P(j), w);
+            KCK(V.pc(w, r));
+        }
+        d_axpy(n, 1.0, r, x);
+        if (r_norm <= epsilon && iter >= min_iter) {
+            KCK(V.resid(x, b, r));
+            KCK(V.nrm2(r, r_norm));
+            if (r_norm <= epsilon) break;
+            if (PrtLvl >= PRINT_SOME) std::printf("### WARNING: False convergence! [%s:%d]\n", "fasp_solver_pvgmres", 1757);
+            KCK(V.cp(P(0), r));
+            i = 0;
+        }
+        for (j = i; j > 0; j--) {
+            rs[j - 1] = -sn[j - 1] * rs[j];
+            rs[j] = c[j - 1] * rs[j];
+        }
+        // p[i] += (rs[i] - 1) p[i] is evaluated elementwise as y + a y (BlaArray.c:90), not as a scaling
+        if (i) hipLaunchKernelGGL(k_axpy_self, dim3(vec_grid(n)), dim3(BLOCK), 0, V.s, n, rs[i] - 1.0, P(i));
+        for (j = i - 1; j > 0; j--) d_axpy(n, rs[j], P(j), P(i));
+        if (i) {
+            hipLaunchKernelGGL(k_axpy_self, dim3(vec_grid(n)), dim3(BLOCK), 0, V.s, n, rs[0] - 1.0, P(0));
+            d_axpy(n, 1.0, P(i), P(0));
+        }
+        if (variable) cr = r_norm / r_norm_old;
+    }
+    if (PrtLvl > PRINT_NONE) {
+        if (iter > MaxIt) std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, r_norm);
+        else if (iter >= 0) std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, r_norm);
+    }
+    if (out) { out->relres = r_norm / den_norm; out->absres = r_norm; out->normr0 = den_norm; }
+    HIPCK(hipStreamSynchronize(V.s));
+    return iter >= MaxIt ? ERROR_SOLVER_MAXIT : iter;
+}
+
+// ---------------------------------------------------------------------------
 // one multigrid cycle on the resident hierarchy (PreMGCycle.c:48-274)
 // ---------------------------------------------------------------------------
 static int mgcycle(fasp_hip_amg* h, const AMG_param& param)
@@ -3744,6 +3987,201 @@ int fasp_solver_dbsr_pvfgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, c
                               const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
     return krylov_plugin_bsr(__func__, 2, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+
+// ---------------------------------------------------------------------------
+// Matrix-free interface of the reference (fasp.h:1109 mxv_matfree, SolMatFree.c): Krylov methods
+// that see the operator only as y = A x.  An operator installed by fasp_solver_matfree_init
+// (MAT_CSR / MAT_BSR) is recognised by its function pointer: the matrix is uploaded once and the
+// whole iteration stays in HBM.  Any other mf->fct is a host callback: its vectors are staged
+// through host memory once per application (as for foreign preconditioners).
+// ---------------------------------------------------------------------------
+void fasp_hip_mxv_csr(const void* A, const double* x, double* y)  // SolMatFree.c: fasp_blas_mxv_csr
+{
+    fasp_blas_dcsr_mxv(static_cast<const dCSRmat*>(A), x, y);
+}
+void fasp_hip_mxv_bsr(const void* A, const double* x, double* y)  // SolMatFree.c: fasp_blas_mxv_bsr
+{
+    fasp_blas_dbsr_mxv(static_cast<const dBSRmat*>(A), x, y);
+}
+
+// SolMatFree.c:201
+void fasp_solver_matfree_init(int matrix_format, mxv_matfree* mf, void* A)
+{
+    switch (matrix_format) {
+        case MAT_CSR: mf->fct = fasp_hip_mxv_csr; break;
+        case MAT_BSR: mf->fct = fasp_hip_mxv_bsr; break;
+        default:  // the reference also knows STR / BLC / CSRL: formats this library does not have
+            std::printf("### ERROR: Unknown matrix format %d!\n", matrix_format);
+            std::exit(ERROR_DATA_STRUCTURE);
+    }
+    mf->data = A;
+}
+
+namespace {
+// which: 0 CG, 1 VGMRES, 2 VFGMRES, 3 BiCGstab, 4 GMRES, 6 GCG
+int krylov_matfree(const char* fn, int which, mxv_matfree* mf, dvector* b, dvector* u, precond* pc, double tol,
+                   double abstol, int MaxIt, short restart, short StopType, short PrtLvl)
+{
+    if (ctx_init() < 0) die_no_device(fn);
+    if (!mf || !mf->fct || !b || !u || b->row != u->row || b->row <= 0) return ERROR_INPUT_PAR;
+    if (comm_size() > 1) return ERROR_INPUT_PAR;
+    const int n = b->row;
+    std::unique_ptr<TmpCSR> csr;
+    std::unique_ptr<fasp_bsr::TmpBSR> bsr;
+    KOps K;
+    K.n = n; K.nvec = (size_t)n; K.fmt = "MatFree"; K.dist = false;
+    K.halo = [](double*) { return 0; };
+    TmpVec db(b->val, n), du(u->val, n), dz(nullptr, n), dy(nullptr, n);
+    if (!db.d || !du.d || !dz.d || !dy.d) return ERROR_ALLOC_MEM;
+    std::vector<double> hx, hy, hr, hz;
+    if (mf->fct == fasp_hip_mxv_csr) {
+        const dCSRmat* A = static_cast<const dCSRmat*>(mf->data);
+        if (!A || A->row != n || A->col != n) return ERROR_INPUT_PAR;
+        csr.reset(new TmpCSR(A));
+        if (!csr->ok) return ERROR_ALLOC_MEM;
+        const DevCSR* dA = &csr->D;
+        K.mxv = [dA](const double* x, double* y) { d_mxv(*dA, x, y); };
+        K.resid = [dA](const double* x, const double* bb, double* r) { d_resid(*dA, x, bb, r); };
+    } else if (mf->fct == fasp_hip_mxv_bsr) {
+        const dBSRmat* A = static_cast<const dBSRmat*>(mf->data);
+        if (!A || A->ROW * A->nb != n || A->ROW != A->COL) return ERROR_INPUT_PAR;
+        bsr.reset(new fasp_bsr::TmpBSR(A));
+        if (!bsr->ok) return ERROR_ALLOC_MEM;
+        const fasp_bsr::TmpBSR* Mp = bsr.get();
+        K.mxv = [Mp](const double* x, double* y) { fasp_bsr::bsr_mxv(*Mp, x, y); };
+        K.resid = [Mp](const double* x, const double* bb, double* r) { fasp_bsr::bsr_resid(*Mp, x, bb, r); };
+    } else {
+        hx.resize((size_t)n); hy.resize((size_t)n);
+        auto host_mxv = [&, mf](const double* x, double* y) {
+            (void)hipMemcpyAsync(hx.data(), x, sizeof(double) * n, hipMemcpyDeviceToHost, g_ctx.stream);
+            (void)hipStreamSynchronize(g_ctx.stream);
+            mf->fct(mf->data, hx.data(), hy.data());
+            (void)hipMemcpyAsync(y, hy.data(), sizeof(double) * n, hipMemcpyHostToDevice, g_ctx.stream);
+            (void)hipStreamSynchronize(g_ctx.stream);  // hy is reused by the next application
+        };
+        K.mxv = host_mxv;
+        K.resid = [&, host_mxv](const double* x, const double* bb, double* r) {  // r = 1.0 b + (-1.0) A x
+            host_mxv(x, dy.d);
+            (void)hipMemcpyAsync(r, dy.d, sizeof(double) * n, hipMemcpyDeviceToDevice, g_ctx.stream);
+            d_axpby(n, 1.0, bb, -1.0, r);
+        };
+    }
+    fasp_hip_amg* h = (pc && pc->fct == fasp_hip_precond_fct) ? static_cast<fasp_hip_amg*>(pc->data) : nullptr;
+    if (h && (h->L.empty() || h->L[0].A.row != n)) return ERROR_INPUT_PAR;
+    if (h) {
+        K.pc = [h](double* in, double** out) { return precond_amg(h, in, out); };
+    } else if (pc && pc->fct) {
+        hr.resize((size_t)n); hz.resize((size_t)n);
+        K.pc = [&, pc](double* in, double** out) {
+            HIPCK(hipMemcpyAsync(hr.data(), in, sizeof(double) * n, hipMemcpyDeviceToHost, g_ctx.stream));
+            HIPCK(hipStreamSynchronize(g_ctx.stream));
+            pc->fct(hr.data(), hz.data(), pc->data);
+            HIPCK(hipMemcpyAsync(dz.d, hz.data(), sizeof(double) * n, hipMemcpyHostToDevice, g_ctx.stream));
+            *out = dz.d;
+            return 0;
+        };
+    }
+    std::vector<double*> ws;
+    size_t ws_len = 0;
+    double* hh = nullptr;
+    K.ws = &ws; K.ws_len = &ws_len; K.hh = &hh;
+    K.stats = nullptr;
+    Hist   H{nullptr, 0, 0};
+    PcgOut po{BIGREAL, BIGREAL, BIGREAL};
+    int st;
+    switch (which) {
+        case 0: st = pcg_mf_device(K, db.d, du.d, tol, abstol, MaxIt, StopType, PrtLvl, &po); break;
+        case 1: st = gmres_mf_device(K, true, false, db.d, du.d, tol, MaxIt, restart, StopType, PrtLvl, &po); break;
+        case 2: st = gmres_mf_device(K, true, true, db.d, du.d, tol, MaxIt, restart, StopType, PrtLvl, &po); break;
+        case 3: st = bicgstab_device(K, db.d, du.d, tol, MaxIt, PrtLvl, &H, &po); break;
+        case 4: st = gmres_mf_device(K, false, false, db.d, du.d, tol, MaxIt, restart, StopType, PrtLvl, &po); break;
+        case 6: st = gcg_device(K, db.d, du.d, tol, abstol, MaxIt, StopType, PrtLvl, &H, &po); break;
+        default: st = ERROR_SOLVER_TYPE;
+    }
+    du.get(u->val);
+    for (double* q : ws) if (q) (void)hipFree(q);
+    if (hh) (void)hipFree(hh);
+    return st;
+}
+}  // namespace
+
+// KryPcg.c:1260, KryPbcgs.c:1349, KryPgcg.c:213, KryPgmres.c:1309, KryPvgmres.c:1468, KryPvfgmres.c:1026
+int fasp_solver_pcg(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                    const int MaxIt, const short StopType, const short PrtLvl)
+{
+    return krylov_matfree(__func__, 0, mf, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+int fasp_solver_pbcgs(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                      const int MaxIt, const short StopType, const short PrtLvl)
+{
+    return krylov_matfree(__func__, 3, mf, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+int fasp_solver_pgcg(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                     const int MaxIt, const short StopType, const short PrtLvl)
+{
+    return krylov_matfree(__func__, 6, mf, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
+}
+int fasp_solver_pgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                       const int MaxIt, const short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_matfree(__func__, 4, mf, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+int fasp_solver_pvgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                        const int MaxIt, short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_matfree(__func__, 1, mf, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+int fasp_solver_pvfgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                         const int MaxIt, const short restart, const short StopType, const short PrtLvl)
+{
+    return krylov_matfree(__func__, 2, mf, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+// KryPminres.c:1283.  Refused: the restart branches of the reference's matrix-free MinRes call
+// pc->fct exactly when pc == NULL (:1485, :1563) and skip the preconditioner otherwise.
+int fasp_solver_pminres(mxv_matfree*, dvector*, dvector*, precond*, const double, const double, const int, const short,
+                        const short)
+{
+    std::printf("### ERROR: fasp_hip: fasp_solver_pminres (matrix-free MinRes) is not provided; "
+                "fasp_solver_dcsr_pminres is\n");
+    return ERROR_SOLVER_TYPE;
+}
+
+// SolMatFree.c:58: dispatch on itsolver_type
+int fasp_solver_itsolver(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, ITS_param* itparam)
+{
+    if (!itparam) return ERROR_INPUT_PAR;
+    const short prtlvl = itparam->print_level, stop_type = itparam->stop_type;
+    const int restart = itparam->restart, MaxIt = itparam->maxit;
+    const double tol = itparam->tol, abstol = itparam->abstol;
+    const double t0 = wall_seconds();
+    int iter = ERROR_SOLVER_TYPE;
+    if (tol < SMALLREAL) std::printf("### WARNING: Convergence tolerance is too small! [%s:%d]\n", "ITS_CHECK", 74);
+    if (MaxIt <= 0) std::printf("### WARNING: Max number of iterations must be POSITIVE! [%s:%d]\n", "ITS_CHECK", 78);
+    switch (itparam->itsolver_type) {
+        case SOLVER_CG: iter = fasp_solver_pcg(mf, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        case SOLVER_BiCGstab: iter = fasp_solver_pbcgs(mf, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        case SOLVER_MinRes: iter = fasp_solver_pminres(mf, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        case SOLVER_GMRES: iter = fasp_solver_pgmres(mf, b, x, pc, tol, abstol, MaxIt, (short)restart, stop_type, prtlvl); break;
+        case SOLVER_VGMRES: iter = fasp_solver_pvgmres(mf, b, x, pc, tol, abstol, MaxIt, (short)restart, stop_type, prtlvl); break;
+        case SOLVER_VFGMRES: iter = fasp_solver_pvfgmres(mf, b, x, pc, tol, abstol, MaxIt, (short)restart, stop_type, prtlvl); break;
+        case SOLVER_GCG: iter = fasp_solver_pgcg(mf, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        default:
+            std::printf("### ERROR: Unknown iterative solver type %d! [%s]\n", itparam->itsolver_type, __func__);
+            return ERROR_SOLVER_TYPE;
+    }
+    if ((prtlvl >= PRINT_SOME) && (iter >= 0)) std::printf("Iterative method costs %.4f seconds.\n", wall_seconds() - t0);
+    return iter;
+}
+
+// SolMatFree.c:157: Krylov method without preconditioner
+int fasp_solver_krylov(mxv_matfree* mf, dvector* b, dvector* x, ITS_param* itparam)
+{
+    if (!itparam) return ERROR_INPUT_PAR;
+    const double t0 = wall_seconds();
+    const int status = fasp_solver_itsolver(mf, b, x, nullptr, itparam);
+    if (itparam->print_level >= PRINT_MIN) std::printf("Krylov method totally costs %.4f seconds.\n", wall_seconds() - t0);
+    return status;
 }
 
 void fasp_blas_dcsr_mxv(const dCSRmat* A, const double* x, double* y)

@@ -238,6 +238,15 @@ typedef struct {
     void (*fct)(double*, double*, void*);
 } precond;
 
+/* fasp.h:1109  matrix-free operator: y = A x through a function pointer */
+typedef struct {
+    void* data;
+    void (*fct)(const void*, const double*, double*);
+} mxv_matfree;
+#define MAT_FREE 0
+#define MAT_CSR  1
+#define MAT_BSR  2
+
 /* ------------------------------------------------------------------------ */
 /* reference entry points kept by this library                              */
 /* ------------------------------------------------------------------------ */
@@ -424,6 +433,32 @@ int fasp_solver_dcsr_pcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const 
                          const double abstol, const int MaxIt, const short StopType, const short PrtLvl);
 int fasp_solver_dcsr_pbcgs(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
                            const double abstol, const int MaxIt, const short StopType, const short PrtLvl); /* KryPbcgs.c:62 */
+/* Matrix-free interface (SolMatFree.c:58/:157/:201; KryPcg.c:1260, KryPbcgs.c:1349, KryPgcg.c:213,
+ * KryPgmres.c:1309, KryPvgmres.c:1468, KryPvfgmres.c:1026 -- the reference keeps older texts of CG and
+ * GMRES for this interface; they are what runs here).  fasp_solver_matfree_init(MAT_CSR | MAT_BSR)
+ * installs fasp_hip_mxv_csr / _bsr: such an operator is uploaded once and the iteration stays in HBM.
+ * Any other mf->fct is called as a host function on host copies (one PCIe round trip per product).
+ * fasp_solver_pminres returns ERROR_SOLVER_TYPE (see solver.hip). */
+void fasp_hip_mxv_csr(const void* A, const double* x, double* y);
+void fasp_hip_mxv_bsr(const void* A, const double* x, double* y);
+void fasp_solver_matfree_init(int matrix_format, mxv_matfree* mf, void* A);
+int  fasp_solver_pcg(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                     const int MaxIt, const short StopType, const short PrtLvl);
+int  fasp_solver_pbcgs(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                       const int MaxIt, const short StopType, const short PrtLvl);
+int  fasp_solver_pgcg(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                      const int MaxIt, const short StopType, const short PrtLvl);
+int  fasp_solver_pminres(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                         const int MaxIt, const short StopType, const short PrtLvl);
+int  fasp_solver_pgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                        const int MaxIt, const short restart, const short StopType, const short PrtLvl);
+int  fasp_solver_pvgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                         const int MaxIt, short restart, const short StopType, const short PrtLvl);
+int  fasp_solver_pvfgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
+                          const int MaxIt, const short restart, const short StopType, const short PrtLvl);
+int  fasp_solver_itsolver(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, ITS_param* itparam);
+int  fasp_solver_krylov(mxv_matfree* mf, dvector* b, dvector* x, ITS_param* itparam);
+
 int fasp_solver_dcsr_pminres(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
                              const double abstol, const int MaxIt, const short StopType, const short PrtLvl); /* KryPminres.c:61 */
 int fasp_solver_dcsr_pgcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,

@@ -133,6 +133,10 @@ int orc_solver_dcsr_krylov_amg(dCSRmat* A, dvector* b, dvector* x, ITS_param* it
 int orc_krylov_dcsr(int which, dCSRmat* A, dvector* b, dvector* x, void (*fct)(double*, double*, void*),
                     void* data, double tol, double abstol, int MaxIt, int restart, int StopType, int PrtLvl,
                     double* final_relres);
+/* matrix-free family on a CSR operator (KryPcg.c:1260, KryPvgmres.c:1468, KryPvfgmres.c:1026, KryPbcgs.c:1349,
+ * KryPgmres.c:1309, KryPgcg.c:213): which = 0 CG, 1 VGMRES, 2 VFGMRES, 3 BiCGstab, 4 GMRES, 6 GCG */
+int orc_krylov_mf(int which, dCSRmat* A, dvector* b, dvector* x, void (*fct)(double*, double*, void*), void* data,
+                  double tol, double abstol, int MaxIt, int restart, int StopType, int PrtLvl, double* final_relres);
 int orc_solver_amg(dCSRmat* A, dvector* b, dvector* x, AMG_param* param, double* hist, int hist_cap,
                    int* nhist, double* final_relres);
 int orc_solve_with_hierarchy(orc_amg* mgl, const dCSRmat* A, const dvector* b, dvector* x,
