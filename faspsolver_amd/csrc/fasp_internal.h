@@ -102,6 +102,18 @@ struct DistPlan {
     int                    first_replicated = 0;  // levels >= this are replicated
     std::vector<DistLevel> L;
 };
+// Team size of the host-side OpenMP loops.  A process that does not set OMP_NUM_THREADS would start
+// one thread per hardware thread (hundreds on a GPU node) in every parallel region, and libgomp rebuilds
+// its pool whenever consecutive regions differ in size: measured 0.1 s PER REGION on the MI355X host,
+// 28 s of setup instead of 11 s at 256^3.  The memory-bound setup loops saturate well below 32 threads.
+// HostThreads pins the calling thread's nthreads ICV for the duration of a host phase and restores it.
+int host_threads();  // min(omp_get_max_threads(), FASP_HIP_HOST_THREADS or 32)
+struct HostThreads {
+    int saved;
+    HostThreads();
+    ~HostThreads();
+};
+extern int g_parallel_min_nnz;  // host setup: threshold of the parallel (result-identical) transposes; fasp_hip_tune("host_parallel_min", n)
 // Levels with fewer than min_rows rows are replicated.  Pure host code.
 int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, DistPlan& D);
 

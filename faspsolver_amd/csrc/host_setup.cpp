@@ -30,6 +30,20 @@
 
 namespace fasp {
 
+int host_threads()
+{
+    static const int cap = [] {
+        const char* e = std::getenv("FASP_HIP_HOST_THREADS");
+        const int v = e ? std::atoi(e) : 32;
+        return v > 0 ? v : 32;
+    }();
+    return std::max(1, std::min(omp_get_max_threads(), cap));
+}
+HostThreads::HostThreads() : saved(omp_get_max_threads()) { omp_set_num_threads(std::min(saved, host_threads())); }
+HostThreads::~HostThreads() { omp_set_num_threads(saved); }
+
+int g_parallel_min_nnz = 1 << 20;  // below this many entries the order-preserving host loops stay serial
+
 double wall_seconds()
 {
     using namespace std::chrono;
@@ -102,6 +116,88 @@ int strength_compressed(const HostCSR& A, const AMG_param& param, Pattern& S)
     return (S.nnz <= 0) ? ERROR_UNKNOWN : FASP_SUCCESS;
 }
 
+// Stable counting transpose in parallel: the result is the one of the reference's serial loops
+// (BlaSparseCSR.c:875 / :952 -- row j of the transpose lists its sources in increasing i), obtained
+// as a two-level radix pass.  Threads own contiguous row chunks of A and drop their entries into
+// buckets of 2^shift destination rows (chunks ascend in i, so a bucket fills in increasing i);
+// then every bucket is counting-sorted by destination row on its own.  ia_t has m + 1 entries.
+template <bool HASVAL>
+void transpose_stable(int n, int m, int nnz, const int* ia, const int* ja, const double* val, int* ia_t, int* ja_t,
+                      double* val_t)
+{
+    const int T = omp_get_max_threads();
+    if (T <= 1 || nnz < g_parallel_min_nnz) {  // small: the serial text
+        std::vector<int> cur((size_t)m + 2, 0);
+        for (int j = 0; j < nnz; ++j) cur[(size_t)ja[j] + 2]++;
+        for (int i = 2; i <= m + 1; ++i) cur[i] += cur[i - 1];
+        for (int i = 0; i < n; ++i)
+            for (int p = ia[i]; p < ia[i + 1]; ++p) {
+                const int k = cur[(size_t)ja[p] + 1]++;
+                ja_t[k] = i;
+                if (HASVAL) val_t[k] = val[p];
+            }
+        ia_t[0] = 0;
+        for (int j = 0; j < m; ++j) ia_t[j + 1] = cur[(size_t)j + 1];
+        return;
+    }
+    int shift = 0;
+    while (((m - 1) >> shift) >= 4096) ++shift;   // at most 4096 buckets
+    shift = std::max(shift, 12);                  // at least 4096 rows per bucket
+    const int B = ((m - 1) >> shift) + 1;
+    std::vector<int> rstart((size_t)T + 1);       // row chunks balanced by entries
+    for (int t = 0; t <= T; ++t) {
+        const long long target = (long long)nnz * t / T;
+        rstart[t] = (int)(std::lower_bound(ia, ia + n + 1, (int)target) - ia);
+    }
+    rstart[0] = 0; rstart[T] = n;
+    for (int t = 1; t <= T; ++t) rstart[t] = std::max(rstart[t], rstart[t - 1]);
+    std::vector<long long> cnt((size_t)T * B, 0);
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        long long* c = cnt.data() + (size_t)t * B;
+        for (int p = ia[rstart[t]]; p < ia[rstart[t + 1]]; ++p) c[ja[p] >> shift]++;
+    }
+    std::vector<long long> bstart((size_t)B + 1, 0);
+    for (int b = 0; b < B; ++b) {
+        long long run = bstart[b];
+        for (int t = 0; t < T; ++t) { const long long c = cnt[(size_t)t * B + b]; cnt[(size_t)t * B + b] = run; run += c; }
+        bstart[b + 1] = run;
+    }
+    Buf<int> tcol((size_t)nnz), trow((size_t)nnz);
+    Buf<double> tval(HASVAL ? (size_t)nnz : 1);
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        long long* off = cnt.data() + (size_t)t * B;
+        for (int i = rstart[t]; i < rstart[t + 1]; ++i)
+            for (int p = ia[i]; p < ia[i + 1]; ++p) {
+                const int col = ja[p];
+                const long long k = off[col >> shift]++;
+                tcol[(size_t)k] = col; trow[(size_t)k] = i;
+                if (HASVAL) tval[(size_t)k] = val[p];
+            }
+    }
+#pragma omp parallel num_threads(T)
+    {
+        std::vector<int> cur((size_t)(1 << shift) + 1);
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; ++b) {
+            const int c0 = b << shift, c1 = std::min(m, (b + 1) << shift), w = c1 - c0;
+            std::fill(cur.begin(), cur.begin() + w + 1, 0);
+            for (long long k = bstart[b]; k < bstart[b + 1]; ++k) cur[(size_t)(tcol[(size_t)k] - c0) + 1]++;
+            int run = (int)bstart[b];
+            for (int j = 0; j < w; ++j) { const int c = cur[(size_t)j + 1]; ia_t[c0 + j] = run; cur[j] = run; run += c; }
+            for (long long k = bstart[b]; k < bstart[b + 1]; ++k) {
+                const int pos = cur[(size_t)(tcol[(size_t)k] - c0)]++;
+                ja_t[pos] = trow[(size_t)k];
+                if (HASVAL) val_t[pos] = tval[(size_t)k];
+            }
+        }
+    }
+    ia_t[m] = nnz;
+}
+
 // stable counting transpose of a pattern (BlaSparseCSR.c:875-936): row j of the
 // transpose lists its sources in increasing i.
 void transpose_pattern(const Pattern& A, Pattern& AT)
@@ -109,41 +205,37 @@ void transpose_pattern(const Pattern& A, Pattern& AT)
     const int n = A.row, m = A.col, nnz = A.nnz;
     AT.row = m; AT.col = n; AT.nnz = nnz;
     AT.ia.alloc((size_t)m + 2);
-    AT.ja.alloc((size_t)nnz);
-    int* ia = AT.ia.data();
-    std::memset(ia, 0, ((size_t)m + 2) * sizeof(int));
-    for (int j = 0; j < nnz; ++j) ia[A.ja[j] + 2]++;
-    for (int i = 2; i <= m + 1; ++i) ia[i] += ia[i - 1];
-    for (int i = 0; i < n; ++i)
-        for (int p = A.ia[i]; p < A.ia[i + 1]; ++p) {
-            const int j = A.ja[p] + 1;
-            AT.ja[ia[j]++] = i;
-        }
+    AT.ja.alloc((size_t)std::max(nnz, 1));
+    transpose_stable<false>(n, m, nnz, A.ia.data(), A.ja.data(), nullptr, AT.ia.data(), AT.ja.data(), nullptr);
 }
 
 // ---------------------------------------------------------------------------
 // bucket lists by measure: one FIFO per measure value, append at the tail
 // (enter_list, PreAMGUtil.inl:264-271), the splitting takes the head of the highest
 // non-empty list (PreAMGCoarsenRS.c:654).  Arrays instead of heap nodes: O(1) updates.
+// The splitting is a sequential greedy pass that hops between vertices; list links, measure
+// and marker of a vertex share one 16-byte record, so a hop costs one cache line, not four.
 // ---------------------------------------------------------------------------
+struct CfNode { int next, prev, lambda, vec; };
 struct Buckets {
-    std::vector<int> head, tail, next, prev;
+    std::vector<int> head, tail;
+    CfNode*          nd;
     int              cur_max = 0;
-    Buckets(int nvert, int cap) : head(cap + 1, -1), tail(cap + 1, -1), next(nvert), prev(nvert) {}
+    Buckets(CfNode* nodes, int cap) : head(cap + 1, -1), tail(cap + 1, -1), nd(nodes) {}
     void enter(int m, int v)
     {
         if (m >= (int)head.size()) { head.resize(2 * m + 2, -1); tail.resize(2 * m + 2, -1); }
-        next[v] = -1;
-        prev[v] = tail[m];
-        if (tail[m] >= 0) next[tail[m]] = v; else head[m] = v;
+        nd[v].next = -1;
+        nd[v].prev = tail[m];
+        if (tail[m] >= 0) nd[tail[m]].next = v; else head[m] = v;
         tail[m] = v;
         if (m > cur_max) cur_max = m;
     }
     void remove(int m, int v)
     {
-        const int p = prev[v], n = next[v];
-        if (p >= 0) next[p] = n; else head[m] = n;
-        if (n >= 0) prev[n] = p; else tail[m] = p;
+        const int p = nd[v].prev, n = nd[v].next;
+        if (p >= 0) nd[p].next = n; else head[m] = n;
+        if (n >= 0) nd[n].prev = p; else tail[m] = p;
     }
     int top()
     {
@@ -169,35 +261,38 @@ int cfsplitting_cls(const Pattern& S, int* vec)
     transpose_pattern(S, ST);
     lap("S^T");
 
-    std::vector<int> lambda(row);
-    int              maxdeg = 0;
+    Buf<CfNode> nodes((size_t)std::max(row, 1));
+    CfNode* nd = nodes.data();
+    int maxdeg = 0;
+#pragma omp parallel for schedule(static) reduction(max : maxdeg) reduction(+ : num_left)
     for (int i = 0; i < row; ++i) {
-        lambda[i] = ST.ia[i + 1] - ST.ia[i];
-        maxdeg    = std::max(maxdeg, lambda[i]);
+        CfNode x;
+        x.next = x.prev = -1;
+        x.lambda = ST.ia[i + 1] - ST.ia[i];
+        maxdeg = std::max(maxdeg, x.lambda);
+        if (S.ia[i + 1] == S.ia[i]) { x.vec = ISPT; x.lambda = 0; }
+        else { x.vec = UNPT; ++num_left; }
+        nd[i] = x;
     }
-    for (int i = 0; i < row; ++i) {
-        if (S.ia[i + 1] == S.ia[i]) { vec[i] = ISPT; lambda[i] = 0; }
-        else { vec[i] = UNPT; ++num_left; }
-    }
-    Buckets B(row, 2 * maxdeg + 2);
+    Buckets B(nd, 2 * maxdeg + 2);
 
     for (int i = 0; i < row; ++i) {  // :614-648
-        if (vec[i] == ISPT) continue;
-        const int measure = lambda[i];
+        if (nd[i].vec == ISPT) continue;
+        const int measure = nd[i].lambda;
         if (measure > 0) {
             B.enter(measure, i);
         } else {
             if (measure < 0) std::printf("### WARNING: Negative lambda[%d]!\n", i);
-            vec[i] = FGPT;
+            nd[i].vec = FGPT;
             --num_left;
             for (int k = S.ia[i]; k < S.ia[i + 1]; ++k) {
                 const int j = S.ja[k];
-                if (vec[j] == ISPT) continue;
+                if (nd[j].vec == ISPT) continue;
                 if (j < i) {
-                    if (lambda[j] > 0) B.remove(lambda[j], j);
-                    B.enter(++lambda[j], j);
+                    if (nd[j].lambda > 0) B.remove(nd[j].lambda, j);
+                    B.enter(++nd[j].lambda, j);
                 } else {
-                    ++lambda[j];
+                    ++nd[j].lambda;
                 }
             }
         }
@@ -206,44 +301,44 @@ int cfsplitting_cls(const Pattern& S, int* vec)
     lap("fill");
     while (num_left > 0) {  // :651-717
         const int maxnode = B.top();
-        const int maxmeas = lambda[maxnode];
+        const int maxmeas = nd[maxnode].lambda;
         if (maxmeas == 0) std::printf("### WARNING: Head of the list has measure 0!\n");
-        vec[maxnode]    = CGPT;
-        lambda[maxnode] = 0;
+        nd[maxnode].vec    = CGPT;
+        nd[maxnode].lambda = 0;
         --num_left;
         B.remove(maxmeas, maxnode);
         ++col;
 
         for (int i = ST.ia[maxnode]; i < ST.ia[maxnode + 1]; ++i) {
             const int j = ST.ja[i];
-            if (vec[j] != UNPT) continue;
-            vec[j] = FGPT;
-            B.remove(lambda[j], j);
+            if (nd[j].vec != UNPT) continue;
+            nd[j].vec = FGPT;
+            B.remove(nd[j].lambda, j);
             --num_left;
             for (int l = S.ia[j]; l < S.ia[j + 1]; ++l) {
                 const int k = S.ja[l];
-                if (vec[k] == UNPT) {
-                    B.remove(lambda[k], k);
-                    B.enter(++lambda[k], k);
+                if (nd[k].vec == UNPT) {
+                    B.remove(nd[k].lambda, k);
+                    B.enter(++nd[k].lambda, k);
                 }
             }
         }
         for (int i = S.ia[maxnode]; i < S.ia[maxnode + 1]; ++i) {
             const int j = S.ja[i];
-            if (vec[j] != UNPT) continue;
-            int measure = lambda[j];
+            if (nd[j].vec != UNPT) continue;
+            int measure = nd[j].lambda;
             B.remove(measure, j);
-            lambda[j] = --measure;
+            nd[j].lambda = --measure;
             if (measure > 0) {
                 B.enter(measure, j);
             } else {
-                vec[j] = FGPT;
+                nd[j].vec = FGPT;
                 --num_left;
                 for (int l = S.ia[j]; l < S.ia[j + 1]; ++l) {
                     const int k = S.ja[l];
-                    if (vec[k] == UNPT) {
-                        B.remove(lambda[k], k);
-                        B.enter(++lambda[k], k);
+                    if (nd[k].vec == UNPT) {
+                        B.remove(nd[k].lambda, k);
+                        B.enter(++nd[k].lambda, k);
                     }
                 }
             }
@@ -251,16 +346,16 @@ int cfsplitting_cls(const Pattern& S, int* vec)
     }
 
     lap("first pass");
-    // C1 criterion, :719-763
-    std::vector<int>& graph_array = lambda;
-    std::fill(graph_array.begin(), graph_array.end(), -1);
+    // C1 criterion, :719-763 (graph_array re-uses the measure field)
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) { vec[i] = nd[i].vec; nd[i].lambda = -1; }
     int jkeep = 0;
     for (int i = 0; i < row; ++i) {
         if (vec[i] != FGPT) continue;
         const int e = S.ia[i + 1];
         for (int ji = S.ia[i]; ji < e; ++ji) {
             const int j = S.ja[ji];
-            if (vec[j] == CGPT) graph_array[j] = i;
+            if (vec[j] == CGPT) nd[j].lambda = i;
         }
         int cnt = 0;
         for (int ji = S.ia[i]; ji < e; ++ji) {
@@ -268,12 +363,12 @@ int cfsplitting_cls(const Pattern& S, int* vec)
             if (vec[j] != FGPT) continue;
             bool set_empty = true;
             for (int jj = S.ia[j]; jj < S.ia[j + 1]; ++jj)
-                if (graph_array[S.ja[jj]] == i) { set_empty = false; break; }
+                if (nd[S.ja[jj]].lambda == i) { set_empty = false; break; }
             if (set_empty) {
                 if (cnt == 0) {
                     vec[j] = CGPT;
                     ++col;
-                    graph_array[j] = i;
+                    nd[j].lambda = i;
                     jkeep = j;
                     cnt = 1;
                 } else {
@@ -527,22 +622,10 @@ void transpose_csr(const HostCSR& A, HostCSR& AT)
 {
     const int n = A.row, m = A.col, nnz = A.nnz;
     AT.row = m; AT.col = n; AT.nnz = nnz;
-    Buf<int> cur((size_t)m + 2);
-    std::memset(cur.data(), 0, ((size_t)m + 2) * sizeof(int));
-    for (int j = 0; j < nnz; ++j) cur[A.ja[j] + 2]++;
-    for (int i = 2; i <= m + 1; ++i) cur[i] += cur[i - 1];
     AT.ia.alloc((size_t)m + 1);
-    AT.ja.alloc((size_t)nnz);
-    AT.val.alloc((size_t)nnz);
-    for (int i = 0; i < n; ++i)
-        for (int p = A.ia[i]; p < A.ia[i + 1]; ++p) {
-            const int k = cur[A.ja[p] + 1]++;
-            AT.ja[k]  = i;
-            AT.val[k] = A.val[p];
-        }
-    // after the fill, cur[j+1] == end of row j == start of row j+1
-    AT.ia[0] = 0;
-    for (int j = 0; j < m; ++j) AT.ia[j + 1] = cur[j + 1];
+    AT.ja.alloc((size_t)std::max(nnz, 1));
+    AT.val.alloc((size_t)std::max(nnz, 1));
+    transpose_stable<true>(n, m, nnz, A.ia.data(), A.ja.data(), A.val.data(), AT.ia.data(), AT.ja.data(), AT.val.data());
 }
 
 // Galerkin product RAP (BlaSpmvCSR.c:1114-1142 symbolic, :1204-1244 numeric).  Every
@@ -563,9 +646,15 @@ void galerkin_rap(const HostCSR& R, const HostCSR& A, const HostCSR& P, HostCSR&
 
     Buf<int> cia((size_t)nc + 1);
     cia[0] = 0;
+    int*    Cj = nullptr;
+    double* Cv = nullptr;
+    bool    overflow = false;
+    // One parallel region for the symbolic and the numeric pass: the per-thread marker arrays
+    // ((nc + nf) ints each) are touched once; the numeric pass stamps with -2 - ic, values the
+    // symbolic pass (stamps ic >= 0, initial -1) never wrote.
 #pragma omp parallel num_threads(nthreads)
     {
-        std::vector<int> pstamp(nc, -1), astamp(nf, -1);
+        std::vector<int> pstamp(nc, -1), ppos(nc, 0), astamp(nf, -1);
 #pragma omp for schedule(dynamic, 256)
         for (int ic = 0; ic < nc; ++ic) {
             int cnt = 1;
@@ -585,56 +674,61 @@ void galerkin_rap(const HostCSR& R, const HostCSR& A, const HostCSR& P, HostCSR&
             }
             cia[ic + 1] = cnt;
         }
-    }
-    long long total = 0;
-    for (int ic = 0; ic < nc; ++ic) { total += cia[ic + 1]; }
-    if (total > 2147483647LL) throw std::bad_alloc();  // INT is 32-bit in the ABI
-    for (int ic = 0; ic < nc; ++ic) cia[ic + 1] += cia[ic];
-    const int cnnz = cia[nc];
-    C.row = nc; C.col = nc; C.nnz = cnnz;
-    C.ja.alloc((size_t)cnnz);
-    C.val.alloc((size_t)cnnz);
-    int*    Cj = C.ja.data();
-    double* Cv = C.val.data();
-#pragma omp parallel num_threads(nthreads)
-    {
-        std::vector<int> pstamp(nc, -1), ppos(nc, 0), astamp(nf, -1);
+#pragma omp single
+        {
+            long long total = 0;
+            for (int ic = 0; ic < nc; ++ic) total += cia[ic + 1];
+            if (total > 2147483647LL) overflow = true;  // INT is 32-bit in the ABI
+            else {
+                for (int ic = 0; ic < nc; ++ic) cia[ic + 1] += cia[ic];
+                const int cnnz = cia[nc];
+                C.row = nc; C.col = nc; C.nnz = cnnz;
+                C.ja.alloc((size_t)cnnz);
+                C.val.alloc((size_t)cnnz);
+                Cj = C.ja.data();
+                Cv = C.val.data();
+            }
+        }  // implicit barrier
+        if (!overflow) {
 #pragma omp for schedule(dynamic, 256)
-        for (int ic = 0; ic < nc; ++ic) {
-            int pos = cia[ic];
-            pstamp[ic] = ic;
-            ppos[ic]   = pos;
-            Cj[pos]    = ic;
-            Cv[pos]    = 0.0;
-            ++pos;
-            for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; ++j1) {
-                const double r_entry = Rv[j1];
-                const int    i1 = Rj[j1];
-                for (int j2 = Ai[i1]; j2 < Ai[i1 + 1]; ++j2) {
-                    const double ra = r_entry * Av[j2];
-                    const int    i2 = Aj[j2];
-                    if (astamp[i2] != ic) {
-                        astamp[i2] = ic;
-                        for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) {
-                            const double rap = ra * Pv[j3];
-                            const int    i3 = Pj[j3];
-                            if (pstamp[i3] != ic) {
-                                pstamp[i3] = ic;
-                                ppos[i3]   = pos;
-                                Cv[pos]    = rap;
-                                Cj[pos]    = i3;
-                                ++pos;
-                            } else {
-                                Cv[ppos[i3]] += rap;
+            for (int ic = 0; ic < nc; ++ic) {
+                const int stamp = -2 - ic;
+                int pos = cia[ic];
+                pstamp[ic] = stamp;
+                ppos[ic]   = pos;
+                Cj[pos]    = ic;
+                Cv[pos]    = 0.0;
+                ++pos;
+                for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; ++j1) {
+                    const double r_entry = Rv[j1];
+                    const int    i1 = Rj[j1];
+                    for (int j2 = Ai[i1]; j2 < Ai[i1 + 1]; ++j2) {
+                        const double ra = r_entry * Av[j2];
+                        const int    i2 = Aj[j2];
+                        if (astamp[i2] != stamp) {
+                            astamp[i2] = stamp;
+                            for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) {
+                                const double rap = ra * Pv[j3];
+                                const int    i3 = Pj[j3];
+                                if (pstamp[i3] != stamp) {
+                                    pstamp[i3] = stamp;
+                                    ppos[i3]   = pos;
+                                    Cv[pos]    = rap;
+                                    Cj[pos]    = i3;
+                                    ++pos;
+                                } else {
+                                    Cv[ppos[i3]] += rap;
+                                }
                             }
+                        } else {
+                            for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) Cv[ppos[Pj[j3]]] += ra * Pv[j3];
                         }
-                    } else {
-                        for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) Cv[ppos[Pj[j3]]] += ra * Pv[j3];
                     }
                 }
             }
         }
     }
+    if (overflow) throw std::bad_alloc();
     C.ia = std::move(cia);
 }
 
@@ -927,6 +1021,7 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
 
 int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 {
+    HostThreads team;  // bounded, constant team size for every parallel loop below
     const int    prtlvl   = param->print_level;
     const int    min_cdof = std::max(param->coarse_dof, MIN_CDOF);
     const double t0       = wall_seconds();
@@ -1016,6 +1111,7 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 
 int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 {
+    HostThreads team;  // bounded, constant team size for every parallel loop below
     const int    prtlvl   = param->print_level;
     const short  min_cdof = (short)std::max(param->coarse_dof, 50);  // SHORT in the reference (:260)
     const double t0       = wall_seconds();
@@ -1205,6 +1301,7 @@ int aggregation_symmpair(const HostCSR& A0, AMG_param& param, std::vector<int>& 
 
 int host_setup_ua(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 {
+    HostThreads team;  // bounded, constant team size for every parallel loop below
     const int    prtlvl   = param->print_level;
     const short  min_cdof = (short)std::max(param->coarse_dof, 50);
     const double t0       = wall_seconds();
@@ -1469,6 +1566,7 @@ int bsr_diaginv(const dBSRmat* A, double* out)
 
 int host_setup_ua_bsr(const dBSRmat* A, AMG_param* param, HostHierarchyBSR& H)
 {
+    HostThreads team;  // bounded, constant team size for every parallel loop below
     const int    prtlvl   = param->print_level;
     const short  min_cdof = (short)std::max(param->coarse_dof, 50);  // SHORT, PreAMGSetupUABSR.c:77
     const double t0       = wall_seconds();

@@ -833,6 +833,7 @@ static int halo_exchange(DevLevel& D, double* v)
 
 static int upload_hierarchy(fasp_hip_amg* h)
 {
+    HostThreads team;  // matrix coding / re-sorting / partition loops
     const double t0 = wall_seconds();
     const int nl = (int)h->H.L.size();
     h->L.resize(nl);
@@ -4356,6 +4357,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "spcg_batch")) g_tune.spcg_batch = value;
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
     else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;
+    else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;
     else if (!std::strcmp(key, "wcap")) g_tune.wcap = value;
