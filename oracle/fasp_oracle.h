@@ -69,6 +69,8 @@ void    orc_bsr_mxv(const dBSRmat* A, const double* x, double* y);
 void    orc_bsr_aAxpy(double alpha, const dBSRmat* A, const double* x, double* y);
 double* orc_bsr_getdiaginv(const dBSRmat* A);
 void    orc_bsr_jacobi1(const dBSRmat* A, const double* b, double* u, const double* diaginv);
+/* ItrSmootherBSR.c:552 / :683 (block Gauss-Seidel) and :1115 / :1234 (block SOR), ascending or descending */
+void    orc_bsr_gs_sor(const dBSRmat* A, const double* b, double* u, const double* diaginv, int descend, int sor, double weight);
 void    orc_free(void* p);
 
 /* smoothers: ItrSmootherCSR.c */
