@@ -1660,9 +1660,13 @@ int check_supported_bsr(const ITS_param* it, const AMG_param* amg, int nb)
             std::printf("### ERROR: fasp_hip: ILU / Schwarz smoothers have no device path\n");
             return ERROR_INPUT_PAR;
         }
-        if (amg->smoother != SMOOTHER_JACOBI) {
-            std::printf("### ERROR: fasp_hip: BSR smoother %d has no device path (block Jacobi only)\n", amg->smoother);
-            return ERROR_AMG_SMOOTH_TYPE;
+        switch (amg->smoother) {  // the five smoothers of fasp_solver_mgcycle_bsr (PreMGCycle.c:327-365)
+            case SMOOTHER_JACOBI:                                                      // bandwidth-bound kernel
+            case SMOOTHER_GS: case SMOOTHER_SGS: case SMOOTHER_SOR: case SMOOTHER_SSOR:  // level-scheduled sweeps
+                break;
+            default:
+                std::printf("### ERROR: fasp_hip: BSR smoother %d has no device path\n", amg->smoother);
+                return ERROR_AMG_SMOOTH_TYPE;
         }
         if (amg->coarse_scaling == 1 || amg->coarse_solver != SOLVER_DEFAULT) return ERROR_INPUT_PAR;
         switch (amg->cycle_type) {

@@ -941,6 +941,73 @@ __global__ __launch_bounds__(BLOCK) void k_seq_level(const int* __restrict__ ord
 }
 
 // ---------------------------------------------------------------------------
+// Block rows of ONE dependency level of a sequential block sweep (fasp_smoother_dbsr_gs_ascend /
+// _descend, ItrSmootherBSR.c:552 / :683; _sor_ascend / _descend, :1115 / :1234): one thread per block
+// row, blocks in storage order, b_tmp -= (A_r0 u_0 + A_r1 u_1 + ...) per block (fasp_blas_smat_ymAx),
+// then u_i = Dinv_i b_tmp (fasp_blas_smat_mxv) or the SOR update in the operation order of
+// fasp_blas_smat_aAxpby (BlaSmallMat.c:1140).  A parity mode, not a bandwidth kernel.
+// ---------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(BLOCK) void k_bsr_seq_level(const int* __restrict__ order, int lo, int hi,
+                                                          const int* __restrict__ ia, const int* __restrict__ ja,
+                                                          const double* __restrict__ val, const double* __restrict__ b,
+                                                          const double* __restrict__ dinv, double* u, int sor, double w)
+{
+    constexpr int NB2 = NB * NB;
+    for (int idx = lo + blockIdx.x * BLOCK + threadIdx.x; idx < hi; idx += gridDim.x * BLOCK) {
+        const int i = order[idx];
+        double bt[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) bt[r] = b[(size_t)i * NB + r];
+        for (int k = ia[i]; k < ia[i + 1]; ++k) {
+            const int j = ja[k];
+            if (j == i) continue;
+            const double* A = val + (size_t)k * NB2;
+            double x[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) x[c] = u[(size_t)j * NB + c];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                double s = A[r * NB] * x[0];
+#pragma unroll
+                for (int c = 1; c < NB; ++c) s = s + A[r * NB + c] * x[c];
+                bt[r] -= s;
+            }
+        }
+        const double* D = dinv + (size_t)i * NB2;
+        double* y = u + (size_t)i * NB;
+        if (!sor) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                double s = D[r * NB] * bt[0];
+#pragma unroll
+                for (int c = 1; c < NB; ++c) s = s + D[r * NB + c] * bt[c];
+                y[r] = s;
+            }
+        } else if (NB == 1) {
+            y[0] = (1.0 - w) * y[0] + w * (bt[0] * D[0]);   // ItrSmootherBSR.c:1166
+        } else {
+            const double omw = 1.0 - w;
+            if (w == 0) {
+#pragma unroll
+                for (int r = 0; r < NB; ++r) y[r] *= omw;
+            } else {
+                const double tmp = omw / w;
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    double yr = y[r];
+                    if (tmp != 1.0) yr *= tmp;
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) yr += D[r * NB + c] * bt[c];
+                    if (w != 1.0) yr *= w;
+                    y[r] = yr;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // BLAS-1.  n is a double count; vectors come from hipMalloc (256-B aligned) so the
 // double2 path is always aligned; the odd tail element is handled by thread 0 of the
 // last block.  Partials layout: partials[q * gridDim.x + blockIdx.x].

@@ -2899,6 +2899,7 @@ struct BsrLevel {
     double *dinv = nullptr, *b = nullptr, *x = nullptr, *x2 = nullptr, *w = nullptr;
     int  n = 0;  // scalar rows
     bool x_zero = false;
+    DevLevel::Sched sched[2];  // level schedules of the sequential block sweeps: 0 ascending, 1 descending
 };
 struct fasp_hip_amg_bsr {
     HostHierarchyBSR      H;
@@ -2946,6 +2947,69 @@ static void bsr_jacobi(BsrLevel& Lv)
     std::swap(Lv.x, Lv.x2);
 }
 
+// One sequential block sweep (Gauss-Seidel or SOR, ascending or descending) as level-scheduled launches:
+// the rows of a dependency level are mutually uncoupled, so the result is the sequential sweep.
+static int bsr_seq_sweep(fasp_hip_amg_bsr* h, int level, bool descend, bool sor, double w)
+{
+    BsrLevel& Lv = h->L[level];
+    DevLevel::Sched& S = Lv.sched[descend ? 1 : 0];
+    const TmpBSR& M = *Lv.A;
+    if (!S.built) {
+        const HostBSR& A = h->H.L[level].A;
+        HostCSR pat;  // block pattern only (build_schedule does not read values)
+        pat.row = A.ROW; pat.col = A.COL; pat.nnz = A.NNZ;
+        pat.ia.alloc((size_t)A.ROW + 1); pat.ja.alloc((size_t)std::max(A.NNZ, 1));
+        std::memcpy(pat.ia.data(), A.ia.data(), sizeof(int) * ((size_t)A.ROW + 1));
+        std::memcpy(pat.ja.data(), A.ja.data(), sizeof(int) * (size_t)A.NNZ);
+        std::vector<int> seq((size_t)A.ROW);
+        for (int i = 0; i < A.ROW; ++i) seq[(size_t)i] = descend ? A.ROW - 1 - i : i;
+        const int st = build_schedule(pat, seq, S);
+        if (st < 0) return st;
+    }
+    if (Lv.x_zero) { HIPCK(hipMemsetAsync(Lv.x, 0, sizeof(double) * Lv.n, g_ctx.stream)); Lv.x_zero = false; }
+    const int nlev = (int)S.ptr.size() - 1;
+    for (int l = 0; l < nlev; ++l) {
+        const int lo = S.ptr[l], hi = S.ptr[l + 1];
+        const int grid = std::max(1, std::min(MAXGRID, (hi - lo + BLOCK - 1) / BLOCK));
+#define BSEQ_LAUNCH(NBV) hipLaunchKernelGGL((k_bsr_seq_level<NBV>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, \
+        (const int*)S.d_order, lo, hi, (const int*)M.ia, (const int*)M.ja, (const double*)M.val, (const double*)Lv.b, \
+        (const double*)Lv.dinv, Lv.x, sor ? 1 : 0, w)
+        switch (M.nb) {
+            case 1: BSEQ_LAUNCH(1); break;
+            case 2: BSEQ_LAUNCH(2); break;
+            case 3: BSEQ_LAUNCH(3); break;
+            default: return ERROR_INPUT_PAR;  // inverse diagonal blocks exist for nb <= 3 only
+        }
+#undef BSEQ_LAUNCH
+    }
+    return FASP_SUCCESS;
+}
+
+// smoother dispatch of fasp_solver_mgcycle_bsr, PreMGCycle.c:327-365 (pre) and :513-549 (post)
+static int bsr_smooth(fasp_hip_amg_bsr* h, int level, bool post, int smoother, int steps, double relax)
+{
+    BsrLevel& Lv = h->L[level];
+    int st = FASP_SUCCESS;
+    if (steps <= 0) return st;
+    switch (smoother) {
+        case SMOOTHER_JACOBI: for (int i = 0; i < steps; ++i) bsr_jacobi(Lv); break;
+        case SMOOTHER_GS: for (int i = 0; i < steps && st >= 0; ++i) st = bsr_seq_sweep(h, level, post, false, 0.0); break;
+        case SMOOTHER_SGS:
+            for (int i = 0; i < steps && st >= 0; ++i) {
+                st = bsr_seq_sweep(h, level, false, false, 0.0);
+                if (st >= 0) st = bsr_seq_sweep(h, level, true, false, 0.0);
+            }
+            break;
+        case SMOOTHER_SOR: for (int i = 0; i < steps && st >= 0; ++i) st = bsr_seq_sweep(h, level, post, true, relax); break;
+        case SMOOTHER_SSOR:  // `steps` ascending sweeps, then ONE descending sweep -- before and after the coarse correction
+            for (int i = 0; i < steps && st >= 0; ++i) st = bsr_seq_sweep(h, level, false, true, relax);
+            if (st >= 0) st = bsr_seq_sweep(h, level, true, true, relax);
+            break;
+        default: return ERROR_AMG_SMOOTH_TYPE;
+    }
+    return st;
+}
+
 static KOps bsr_ops(fasp_hip_amg_bsr* h, int level, int set);
 
 // fasp_solver_mgcycle_bsr, PreMGCycle.c:287-566
@@ -2959,7 +3023,7 @@ ForwardSweep:
     while (l < nl - 1) {
         BsrLevel& Lv = h->L[l];
         ++nu_l[l];
-        for (int i = 0; i < steps; ++i) bsr_jacobi(Lv);
+        { const int st = bsr_smooth(h, l, false, param.smoother, steps, param.relaxation); if (st < 0) return st; }
         if (Lv.x_zero) { HIPCK(hipMemsetAsync(Lv.x, 0, sizeof(double) * Lv.n, s)); Lv.x_zero = false; }
         bsr_resid(*Lv.A, Lv.x, Lv.b, Lv.w);
         bsr_mxv(*Lv.R, Lv.w, h->L[l + 1].b);
@@ -3014,7 +3078,8 @@ ForwardSweep:
             BsrArgs a{}; a.x = h->L[l + 1].x; a.y = Lv.x; a.alpha = 1.0;
             launch_bsr<1>(*Lv.P, a);
         }
-        for (int i = 0; i < steps; ++i) bsr_jacobi(Lv);  // the reference post-smooths `steps` = presmooth_iter times (:543)
+        // the reference post-smooths `steps` = presmooth_iter times (:543)
+        { const int st = bsr_smooth(h, l, true, param.smoother, steps, param.relaxation); if (st < 0) return st; }
         if (nu_l[l] < cycle_type) break;
         nu_l[l] = 0;
     }
@@ -3513,6 +3578,7 @@ void fasp_hip_bsr_amg_destroy(fasp_hip_amg_bsr* h)
     for (auto& Lv : h->L) {
         double* v[] = {Lv.dinv, Lv.b, Lv.x, Lv.x2, Lv.w};
         for (double* q : v) if (q) (void)hipFree(q);
+        for (auto& sc : Lv.sched) if (sc.d_order) (void)hipFree(sc.d_order);
     }
     double* v[] = {h->b, h->u, h->p, h->t, h->r};
     for (double* q : v) if (q) (void)hipFree(q);

@@ -128,7 +128,7 @@ def test_product_host_setup_equals_oracle(name, make, agg):
 def test_bsr_unsupported_parameters_are_refused():
     ia, ja, val, nb, f = synthetic(6)
     itp, amgp = bsr_params()
-    amgp.smoother = T.SMOOTHER_GS
+    amgp.smoother = T.SMOOTHER_L1DIAG   # not among the five smoothers of fasp_solver_mgcycle_bsr
     x = np.zeros(len(f))
     assert fa.solver_dbsr_krylov_amg(ia, ja, val, nb, f, x, itp, amgp) == T.ERROR_AMG_SMOOTH_TYPE
     itp, amgp = bsr_params()
@@ -157,6 +157,61 @@ def test_gpu_bsr_solve_matches_oracle(n, solver, cycle, agg):
     assert np.abs(x1 - x2).max() <= 1e-10 * np.abs(x1).max()
     assert abs(stats.relres - rr1) <= 1e-10
     G.free()
+
+
+def _smoother(amgp, sm):
+    amgp.smoother = sm
+    amgp.relaxation = 1.1 if sm in (T.SMOOTHER_SOR, T.SMOOTHER_SSOR) else 1.0
+
+
+@needs_ref
+@pytest.mark.parametrize("agg", [2, 1], ids=["vmb", "pairwise"])
+@pytest.mark.parametrize("sm", [2, 3, 5, 6], ids=["GS", "SGS", "SOR", "SSOR"])
+@pytest.mark.parametrize("solver,cycle,n", [(5, 1, 8), (1, 1, 12), (6, 2, 12)])
+def test_oracle_block_gs_sor_equals_reference(solver, cycle, n, sm, agg):
+    """Block Gauss-Seidel / SGS / SOR / SSOR cycles (ItrSmootherBSR.c:552-1350, dispatch PreMGCycle.c:327-365 and
+    :513-549 -- GS is the default smoother of fasp_param_amg_init): bit for bit."""
+    ia, ja, val, nb, f = synthetic(n)
+    i1, a1 = bsr_params(solver, cycle, agg); i2, a2 = bsr_params(solver, cycle, agg)
+    _smoother(a1, sm); _smoother(a2, sm)
+    s1, x1, nl, rr = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    s2, x2 = ref_bsr_solve(ia, ja, val, nb, f, i2, a2)
+    assert s1 == s2 and s1 > 0
+    assert np.array_equal(x1, x2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agg", [2, 1], ids=["vmb", "pairwise"])
+@pytest.mark.parametrize("sm", [2, 3, 5, 6], ids=["GS", "SGS", "SOR", "SSOR"])
+@pytest.mark.parametrize("solver,cycle,n", [(5, 1, 8), (1, 1, 16), (6, 2, 16)])
+def test_gpu_block_gs_sor_matches_oracle(solver, cycle, n, sm, agg):
+    ia, ja, val, nb, f = synthetic(n)
+    i1, a1 = bsr_params(solver, cycle, agg); i2, a2 = bsr_params(solver, cycle, agg)
+    _smoother(a1, sm); _smoother(a2, sm)
+    s1, x1, nl, rr1 = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    G = fa.BSRAMG(ia, ja, val, nb, a2)
+    s2, x2, hist, stats = G.solve(f, i2)
+    assert G.num_levels == nl and s2 == s1, (s1, s2)
+    assert np.abs(x1 - x2).max() <= 1e-10 * np.abs(x1).max()
+    assert abs(stats.relres - rr1) <= 1e-10
+    G.free()
+
+
+@pytest.mark.gpu
+def test_gpu_fortran_block_wrapper_defaults():
+    """CALL FASP_FWRAPPER_DBSR_KRYLOV_AMG (SolWrapper.c:397): UA-AMG with pairwise aggregation, block
+    Gauss-Seidel, VFGMRES -- fasp_param_amg_init's defaults, none of them refused."""
+    ia, ja, val, nb, f = synthetic(12)
+    itp, amgp = bsr_params(6, 1, 1); amgp.smoother = T.SMOOTHER_GS; amgp.relaxation = 1.0
+    itp.restart = 25; itp.maxit = 200   # fasp_param_solver_init: restart 25
+    s1, x1, nl, rr = orc_bsr_solve(ia, ja, val, nb, f, itp, amgp)
+    n = C.c_int(len(ia) - 1); nnz = C.c_int(len(ja)); cnb = C.c_int(nb); tol = C.c_double(1e-8)
+    maxit = C.c_int(200); prt = C.c_int(0)
+    u = np.zeros(len(f)); ia2 = ia.copy(); ja2 = ja.copy(); v2 = val.copy(); f2 = f.copy()
+    fa.lib().fasp_fwrapper_dbsr_krylov_amg_(C.byref(n), C.byref(nnz), C.byref(cnb), ia2.ctypes.data_as(T.c_int_p),
+                                            ja2.ctypes.data_as(T.c_int_p), T.dp(v2), T.dp(f2), T.dp(u),
+                                            C.byref(tol), C.byref(maxit), C.byref(prt))
+    assert s1 > 0 and np.abs(u - x1).max() <= 1e-10 * np.abs(x1).max()
 
 
 @pytest.mark.gpu
