@@ -432,6 +432,9 @@ int clean_ff_couplings(const Pattern& S, int* vec, int row, int col)
 // interpolation: pattern (PreAMGCoarsenRS.c:1891-1985), direct interpolation weights
 // (PreAMGInterp.c:411-487), coarse numbering (:491-517), truncation (:127-228)
 // ---------------------------------------------------------------------------
+void finish_interp(int row, const int* vec, const Buf<int>& pia, const Buf<int>& pja, const Buf<double>& pval,
+                   double eps_tr, HostCSR& P);
+
 void build_interp_dir(const HostCSR& A, const Pattern& S, const int* vec, const AMG_param& param,
                       HostCSR& P)
 {
@@ -554,6 +557,14 @@ void build_interp_dir(const HostCSR& A, const Pattern& S, const int* vec, const 
         for (int i = 0; i < row; ++i) weights_row(i, aii, use_mark ? mark.data() : nullptr);
     }
 
+    finish_interp(row, vec, pia, pja, pval, eps_tr, P);
+}
+
+// coarse numbering (PreAMGInterp.c:491-517) and truncation (:127-228) of an interpolation given in
+// fine-column indices
+void finish_interp(int row, const int* vec, const Buf<int>& pia, const Buf<int>& pja, const Buf<double>& pval,
+                   double eps_tr, HostCSR& P)
+{
     // coarse numbering: C points in increasing fine index (:491-493)
     std::vector<int> cindex(row, 0);
     int              ncoarse = 0;
@@ -615,6 +626,111 @@ void build_interp_dir(const HostCSR& A, const Pattern& S, const int* vec, const 
             }
         }
     }
+}
+
+// Standard interpolation: pattern (form_P_pattern_std, PreAMGCoarsenRS.c:2006: strong C neighbours and the
+// strong C neighbours of strong F neighbours, in discovery order) and weights (interp_STD,
+// PreAMGInterp.c:547-745, RS_C1 ON).  The reference works with row-sized scratch arrays (visited, rindi,
+// rindk, Ahat) that carry nothing from one row to the next; here every row uses short local lists and
+// linear searches instead, so rows run in parallel and every value is formed by the same operations in
+// the same order.
+void build_interp_std(const HostCSR& A, const Pattern& S, const int* vec, const AMG_param& param, HostCSR& P)
+{
+    const int row = A.row;
+    const int *ia = A.ia.data(), *ja = A.ja.data();
+    const double* av = A.val.data();
+    auto pattern_row = [&](int i, std::vector<int>& cols) {
+        cols.clear();
+        if (vec[i] == FGPT) {
+            auto add = [&](int h) {
+                for (int c : cols) if (c == h) return;
+                cols.push_back(h);
+            };
+            for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) {
+                const int k = S.ja[j];
+                if (vec[k] == CGPT) add(k);
+                else if (vec[k] == FGPT && k != i)
+                    for (int l = S.ia[k]; l < S.ia[k + 1]; ++l) { const int h = S.ja[l]; if (vec[h] == CGPT) add(h); }
+            }
+        } else if (vec[i] == CGPT) {
+            cols.push_back(i);
+        }
+    };
+    Buf<int> pia((size_t)row + 1);
+    pia[0] = 0;
+#pragma omp parallel
+    {
+        std::vector<int> cols;
+#pragma omp for schedule(static)
+        for (int i = 0; i < row; ++i) { pattern_row(i, cols); pia[i + 1] = (int)cols.size(); }
+    }
+    for (int i = 0; i < row; ++i) pia[i + 1] += pia[i];
+    const int   pnnz = pia[row];
+    Buf<int>    pja((size_t)std::max(pnnz, 1));
+    Buf<double> pval((size_t)std::max(pnnz, 1));
+
+    // Step 0 (:588-613): diagonal (last hit), sums over strong C couplings / all off-diagonals / non-isolated ones
+    std::vector<double> csum((size_t)row), psum((size_t)row), nsum((size_t)row), diag((size_t)row);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        double cs = 0.0, ps = 0.0, ns = 0.0, dg = 0.0;
+        for (int j = ia[i]; j < ia[i + 1]; ++j) {
+            const int k = ja[j];
+            bool strongC = false;  // cindex[k] == i: k is a C point in the strength row of i
+            if (vec[k] == CGPT)
+                for (int q = S.ia[i]; q < S.ia[i + 1]; ++q) if (S.ja[q] == k) { strongC = true; break; }
+            if (strongC) cs += av[j];
+            if (k == i) dg = av[j];
+            else { ns += av[j]; if (vec[k] != ISPT) ps += av[j]; }
+        }
+        csum[i] = cs; psum[i] = ps; nsum[i] = ns; diag[i] = dg;
+    }
+    auto entry = [&](int r, int c) -> double {  // A(r, c) as the reference's reverse index finds it: the LAST stored hit
+        double v = 0.0;
+        for (int m = ia[r]; m < ia[r + 1]; ++m) if (ja[m] == c) v = av[m];
+        return v;
+    };
+#pragma omp parallel
+    {
+        std::vector<int> cols;
+        std::vector<double> ah;
+#pragma omp for schedule(dynamic, 512)
+        for (int i = 0; i < row; ++i) {
+            pattern_row(i, cols);
+            const int o = pia[i];
+            for (size_t c = 0; c < cols.size(); ++c) pja[o + (int)c] = cols[c];
+            if (vec[i] == CGPT) { pval[o] = 1.0; continue; }
+            if (vec[i] != FGPT) continue;
+            ah.assign(cols.size(), 0.0);
+            auto slot = [&](int h) -> double* {
+                for (size_t c = 0; c < cols.size(); ++c) if (cols[c] == h) return &ah[c];
+                return nullptr;  // not in the pattern: the reference's scratch entry is never read
+            };
+            double alN = psum[i], alP = csum[i], ahat_i = diag[i];
+            for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) {
+                const int    k = S.ja[j];
+                const double aik = entry(i, k);
+                if (vec[k] == CGPT) { if (double* q = slot(k)) *q += aik; }
+                else if (vec[k] == FGPT) {
+                    const double akk = diag[k], factor = aik / akk;
+                    double aki = 0.0;
+                    for (int m = ia[k]; m < ia[k + 1]; ++m)
+                        if (ja[m] == i) { aki = av[m]; ahat_i -= factor * aki; }
+                    for (int m = S.ia[k]; m < S.ia[k + 1]; ++m) {
+                        const int l = S.ja[m];
+                        if (vec[l] == CGPT) { const double akl = entry(k, l); if (double* q = slot(l)) *q -= factor * akl; }
+                    }
+                    alN -= factor * (nsum[k] - aki + akk);
+                    alP -= factor * csum[k];
+                }
+            }
+            if (!cols.empty()) {
+                const double alpha = alN / alP;
+                for (size_t c = 0; c < cols.size(); ++c) pval[o + (int)c] = -alpha * ah[c] / ahat_i;
+            }
+        }
+    }
+    finish_interp(row, vec, pia, pja, pval, param.truncation_threshold, P);
 }
 
 // stable counting transpose with values (BlaSparseCSR.c:952-1018)
@@ -961,8 +1077,8 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
                         amg->coarsening_type);
             return ERROR_AMG_COARSE_TYPE;
         }
-        if (amg->AMG_type == CLASSIC_AMG && amg->interpolation_type != INTERP_DIR) {
-            std::printf("### ERROR: fasp_hip: interpolation_type %d not supported (INTERP_DIR only)\n",
+        if (amg->AMG_type == CLASSIC_AMG && amg->interpolation_type != INTERP_DIR && amg->interpolation_type != INTERP_STD) {
+            std::printf("### ERROR: fasp_hip: interpolation_type %d not supported (INTERP_DIR and INTERP_STD only)\n",
                         amg->interpolation_type);
             return ERROR_AMG_INTERP_TYPE;
         }
@@ -1065,7 +1181,8 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
                 status = FASP_SUCCESS;
                 break;
             }
-            col = clean_ff_couplings(S, vertices.data(), Lv.A.row, col);
+            const bool std_interp = param->interpolation_type == INTERP_STD;  // no F-F clean-up (PreAMGCoarsenRS.c:152)
+            if (!std_interp) col = clean_ff_couplings(S, vertices.data(), Lv.A.row, col);
             lap("FF clean-up");
             if (col < MIN_CDOF) break;  // Check 2, :176-181
             if (Lv.A.row > col * 10.0) {  // Check 3, :184-195
@@ -1079,7 +1196,8 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
             Lv.cfmark.alloc((size_t)Lv.A.row);  // :201-206
             std::memcpy(Lv.cfmark.data(), vertices.data(), (size_t)Lv.A.row * sizeof(int));
 
-            build_interp_dir(Lv.A, S, vertices.data(), *param, Lv.P);  // :209
+            if (std_interp) build_interp_std(Lv.A, S, vertices.data(), *param, Lv.P);
+            else build_interp_dir(Lv.A, S, vertices.data(), *param, Lv.P);  // :209
             lap("interpolation");
             transpose_csr(Lv.P, Lv.R);                                 // :212
             lap("transpose");

@@ -69,7 +69,7 @@ def test_unsupported_parameters_are_refused_before_any_work(fa):
     cases.append((it, am, T.ERROR_INPUT_PAR))
     it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; it.itsolver_type = 13  # SOLVER_SMinRes
     cases.append((it, am, T.ERROR_SOLVER_TYPE))
-    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.interpolation_type = T.INTERP_STD
+    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.interpolation_type = 3   # INTERP_ENG
     cases.append((it, am, T.ERROR_AMG_INTERP_TYPE))
     for it, am, code in cases:
         assert fa.solver_dcsr_krylov_amg(ia, ja, a, f, x, it, am) == code

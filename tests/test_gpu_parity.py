@@ -162,14 +162,18 @@ def _jacf(itp, amgp):    # Jacobi on the F points only (ItrSmootherCSR.c:34); st
     itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_JACOBIF; amgp.relaxation = 0.8
 
 
+def _stdint(itp, amgp):   # standard interpolation (PreAMGInterp.c:547): a host-setup variant, same device path
+    _jac(itp, amgp); amgp.interpolation_type = 2
+
+
 def _jacf23(itp, amgp):
     itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_JACOBIF; amgp.presmooth_iter = 2; amgp.postsmooth_iter = 3
 
 
 @pytest.mark.parametrize("n", [8, 16, 32, 48])
-@pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22, _jac_cs, _poly3, _poly5w, _poly1, _jacf, _jacf23],
+@pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22, _jac_cs, _poly3, _poly5w, _poly1, _jacf, _jacf23, _stdint],
                          ids=["jacobi-V", "jacobi-W", "l1diag-V", "jacobi-V22", "jacobi-V-coarse-scaling",
-                              "poly3-V", "poly5-W", "poly1-V", "jacobiF-V", "jacobiF-V23"])
+                              "poly3-V", "poly5-W", "poly1-V", "jacobiF-V", "jacobiF-V23", "jacobi-V-std-interp"])
 def test_pcg_history_poisson(gpu, n, mod):
     if n == 48 and mod is not _jac:
         pytest.skip("largest size only for the headline configuration")

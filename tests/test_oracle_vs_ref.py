@@ -46,11 +46,13 @@ def _mods():
     def poly1(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_POLY; a.polynomial_degree = 1; i.maxit = 30   # degree 1: the correction stays zero
     def jacf(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_JACOBIF; a.relaxation = 0.8
     def jacf2(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_JACOBIF; a.relaxation = 1.0; a.presmooth_iter = 2; a.postsmooth_iter = 3
+    def stdint(i, a): jac(i, a); a.interpolation_type = 2
+    def stdint_w(i, a): i.tol = 1e-8; a.interpolation_type = 2; a.cycle_type = T.W_CYCLE; a.truncation_threshold = 0.4
     def vgpre(i, a): vg(i, a); i.stop_type = T.STOP_REL_PRECRES
     def vfgmod(i, a): vfg(i, a); i.stop_type = T.STOP_MOD_REL_RES
     return dict(jac=jac, jacw=jacw, vw=vw, l1=l1, gscf=gscf, gsn=gsn, sor=sor, ssor=ssor, sgs=sgs,
                 theta=theta, precres=precres, modres=modres, gsor=gsor, sgsor=sgsor, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
-                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2)
+                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w)
 
 
 @pytest.mark.parametrize("name", list(_mods().keys()))
@@ -68,12 +70,21 @@ def test_histories_bit_exact(R, n, name):
         assert np.array_equal(np.concatenate([h1[:-2], h1[-1:]]), h2)
 
 
-@pytest.mark.parametrize("n", [9, 28])
-def test_hierarchy_bit_exact_oracle_and_product(R, fa, n):
-    ia, ja, a, f, ue = poisson7pt(n)
-    i1, a1 = default_params(); a1.smoother = T.SMOOTHER_JACOBI
-    i2, a2 = default_params(); a2.smoother = T.SMOOTHER_JACOBI
-    a3 = fa.param_amg_init(); a3.smoother = T.SMOOTHER_JACOBI
+def _matrix(name):
+    if name == "fe":
+        from _libs import DATA, read_csr
+        return read_csr(DATA + "/csrmat_FE.dat")
+    return poisson7pt(int(name))[:3]
+
+
+@pytest.mark.parametrize("interp", [1, 2], ids=["direct", "standard"])
+@pytest.mark.parametrize("name", ["9", "28", "fe"])
+def test_hierarchy_bit_exact_oracle_and_product(R, fa, name, interp):
+    """Direct (PreAMGInterp.c:302) and standard (:547, pattern PreAMGCoarsenRS.c:2006) interpolation."""
+    ia, ja, a = _matrix(name)
+    i1, a1 = default_params(); a1.smoother = T.SMOOTHER_JACOBI; a1.interpolation_type = interp
+    i2, a2 = default_params(); a2.smoother = T.SMOOTHER_JACOBI; a2.interpolation_type = interp
+    a3 = fa.param_amg_init(); a3.smoother = T.SMOOTHER_JACOBI; a3.interpolation_type = interp
     A, keep = T.as_csr(ia, ja, a)
     O = OrcAMG(A, a1)
     hr = R.ref_amg_setup_rs(C.byref(A), C.byref(a2))
