@@ -883,6 +883,16 @@ __global__ __launch_bounds__(BLOCK) void k_bsr_wstream(BsrArgs a)
     }
 }
 
+// fasp_precond_diag (PreCSR.c:172): z = r, then z_i /= d_i where |d_i| > SMALLREAL
+__global__ __launch_bounds__(BLOCK) void k_diag_precond(int n, const double* __restrict__ d, const double* __restrict__ r,
+                                                         double* __restrict__ z)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double di = d[i], ri = r[i];
+        z[i] = (fabs(di) > 1e-20) ? ri / di : ri;
+    }
+}
+
 // Block-Jacobi sweep from a zero iterate: u = Dinv b (the off-diagonal sum vanishes exactly)
 __global__ __launch_bounds__(BLOCK) void k_bsr_dinv_apply(int n, int nb, const double* __restrict__ dinv,
                                                            const double* __restrict__ b, double* __restrict__ u)

@@ -3855,8 +3855,20 @@ int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u,
         CsrArgs a{}; a.x = x; a.y = y; a.dotv = x; a.partials = g_ctx.d_partials;
         return launch_csr<OP_MXV_DOT>(*dA, a);
     };
+    std::unique_ptr<TmpVec> ddiag;
     if (h) {
         K.pc = [h](double* in, double** out) { return precond_amg(h, in, out); };  // stays in HBM
+    } else if (pc && pc->fct == fasp_precond_diag && pc->data && static_cast<dvector*>(pc->data)->row == n) {
+        // the reference's diagonal preconditioner: recognised by its function pointer, applied on the device
+        ddiag.reset(new TmpVec(static_cast<dvector*>(pc->data)->val, n));
+        if (!ddiag->d) return ERROR_ALLOC_MEM;
+        const double* dd = ddiag->d;
+        double* zz = dz.d;
+        K.pc = [dd, zz, n](double* in, double** out) {
+            hipLaunchKernelGGL(k_diag_precond, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, dd, (const double*)in, zz);
+            *out = zz;
+            return 0;
+        };
     } else if (pc && pc->fct) {
         // foreign preconditioner: a host function; the residual is staged through host memory
         hr.resize((size_t)n); hz.resize((size_t)n);
@@ -3997,8 +4009,22 @@ int krylov_plugin_bsr(const char* fn, int which, dBSRmat* A, dvector* b, dvector
     const TmpBSR* Mp = &M;
     K.mxv = [Mp](const double* x, double* y) { bsr_mxv(*Mp, x, y); };
     K.resid = [Mp](const double* x, const double* bb, double* r) { bsr_resid(*Mp, x, bb, r); };
+    std::unique_ptr<TmpVec> ddiag;
     if (h) {
         K.pc = [h](double* in, double** out) { return precond_amg_bsr(h, in, out); };
+    } else if (pc && pc->fct == fasp_precond_dbsr_diag && pc->data &&
+               static_cast<precond_diag_bsr*>(pc->data)->diag.row == A->ROW * A->nb * A->nb) {
+        // block-diagonal preconditioner of the reference (PreBSR.c:49): z_i = Dinv_i r_i on the device
+        ddiag.reset(new TmpVec(static_cast<precond_diag_bsr*>(pc->data)->diag.val, (size_t)A->ROW * A->nb * A->nb));
+        if (!ddiag->d) return ERROR_ALLOC_MEM;
+        const double* dd = ddiag->d;
+        double* zz = dz.d;
+        const int nb = A->nb;
+        K.pc = [dd, zz, n, nb](double* in, double** out) {
+            hipLaunchKernelGGL(k_bsr_dinv_apply, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, nb, dd, (const double*)in, zz);
+            *out = zz;
+            return 0;
+        };
     } else if (pc && pc->fct) {
         hr.resize((size_t)n); hz.resize((size_t)n);
         K.pc = [&, pc](double* in, double** out) {
@@ -4054,6 +4080,134 @@ int fasp_solver_dbsr_pvfgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, c
                               const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
     return krylov_plugin_bsr(__func__, 2, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
+}
+
+// ---------------------------------------------------------------------------
+// The other solver-level entry points of SolCSR.c / SolBSR.c: dispatch on itsolver_type with a caller's
+// preconditioner, no preconditioner, or the (block-)diagonal one.
+// ---------------------------------------------------------------------------
+void fasp_precond_diag(double* r, double* z, void* data)  // PreCSR.c:172 (host arrays)
+{
+    const dvector* diag = static_cast<const dvector*>(data);
+    std::memcpy(z, r, sizeof(double) * (size_t)diag->row);
+    for (int i = 0; i < diag->row; ++i)
+        if (std::fabs(diag->val[i]) > SMALLREAL) z[i] /= diag->val[i];
+}
+void fasp_precond_dbsr_diag(double* r, double* z, void* data)  // PreBSR.c:49 (host arrays): z_i = Dinv_i r_i
+{
+    const precond_diag_bsr* d = static_cast<const precond_diag_bsr*>(data);
+    const int nb = d->nb, nb2 = nb * nb, m = d->diag.row / nb2;
+    for (int i = 0; i < m; ++i)
+        for (int rr = 0; rr < nb; ++rr) {
+            const double* D = d->diag.val + (size_t)i * nb2 + rr * nb;
+            double s = D[0] * r[(size_t)i * nb];
+            for (int c = 1; c < nb; ++c) s = s + D[c] * r[(size_t)i * nb + c];
+            z[(size_t)i * nb + rr] = s;
+        }
+}
+
+// SolCSR.c:56
+int fasp_solver_dcsr_itsolver(dCSRmat* A, dvector* b, dvector* x, precond* pc, ITS_param* itparam)
+{
+    if (!itparam) return ERROR_INPUT_PAR;
+    const short prtlvl = itparam->print_level, stop_type = itparam->stop_type, restart = (short)itparam->restart;
+    const int MaxIt = itparam->maxit;
+    const double tol = itparam->tol, abstol = itparam->abstol, t0 = wall_seconds();
+    int iter;
+    if (tol < SMALLREAL) std::printf("### WARNING: Convergence tolerance is too small! [%s:%d]\n", "ITS_CHECK", 74);
+    if (MaxIt <= 0) std::printf("### WARNING: Max number of iterations must be POSITIVE! [%s:%d]\n", "ITS_CHECK", 78);
+    switch (itparam->itsolver_type) {
+        case SOLVER_CG: iter = fasp_solver_dcsr_pcg(A, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        case SOLVER_BiCGstab: iter = fasp_solver_dcsr_pbcgs(A, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        case SOLVER_MinRes: iter = fasp_solver_dcsr_pminres(A, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        case SOLVER_GMRES: iter = fasp_solver_dcsr_pgmres(A, b, x, pc, tol, abstol, MaxIt, restart, stop_type, prtlvl); break;
+        case SOLVER_VGMRES: iter = fasp_solver_dcsr_pvgmres(A, b, x, pc, tol, abstol, MaxIt, restart, stop_type, prtlvl); break;
+        case SOLVER_VFGMRES: iter = fasp_solver_dcsr_pvfgmres(A, b, x, pc, tol, abstol, MaxIt, restart, stop_type, prtlvl); break;
+        case SOLVER_GCG: iter = fasp_solver_dcsr_pgcg(A, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        case SOLVER_GCR: iter = fasp_solver_dcsr_pgcr(A, b, x, pc, tol, abstol, MaxIt, restart, stop_type, prtlvl); break;
+        default:
+            std::printf("### ERROR: Unknown iterative solver type %d! [%s]\n", itparam->itsolver_type, __func__);
+            return ERROR_SOLVER_TYPE;
+    }
+    if ((prtlvl >= PRINT_SOME) && (iter >= 0)) std::printf("Iterative method costs %.4f seconds.\n", wall_seconds() - t0);
+    return iter;
+}
+// SolCSR.c:245
+int fasp_solver_dcsr_krylov(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam)
+{
+    if (!itparam) return ERROR_INPUT_PAR;
+    const double t0 = wall_seconds();
+    const int status = fasp_solver_dcsr_itsolver(A, b, x, nullptr, itparam);
+    if (itparam->print_level >= PRINT_MIN) std::printf("Krylov method totally costs %.4f seconds.\n", wall_seconds() - t0);
+    return status;
+}
+// SolCSR.c:333: diagonal preconditioner from fasp_dcsr_getdiag(0, A, ..) -- the FIRST diagonal hit of each row
+int fasp_solver_dcsr_krylov_diag(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam)
+{
+    if (!A || !itparam || !A->IA || !A->JA || !A->val) return ERROR_INPUT_PAR;
+    const double t0 = wall_seconds();
+    const int n = std::min(A->row, A->col);
+    std::vector<double> dv((size_t)std::max(n, 1), 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int k = A->IA[i]; k < A->IA[i + 1]; ++k)
+            if (A->JA[k] == i) { dv[(size_t)i] = A->val[k]; break; }
+    dvector diag{n, dv.data()};
+    precond pc{&diag, fasp_precond_diag};
+    const int status = fasp_solver_dcsr_itsolver(A, b, x, &pc, itparam);
+    if (itparam->print_level >= PRINT_MIN) std::printf("Diag_Krylov method totally costs %.4f seconds.\n", wall_seconds() - t0);
+    return status;
+}
+// SolBSR.c:64
+int fasp_solver_dbsr_itsolver(dBSRmat* A, dvector* b, dvector* x, precond* pc, ITS_param* itparam)
+{
+    if (!itparam) return ERROR_INPUT_PAR;
+    const short prtlvl = itparam->print_level, stop_type = itparam->stop_type, restart = (short)itparam->restart;
+    const int MaxIt = itparam->maxit;
+    const double tol = itparam->tol, abstol = itparam->abstol, t0 = wall_seconds();
+    int iter;
+    if (tol < SMALLREAL) std::printf("### WARNING: Convergence tolerance is too small! [%s:%d]\n", "ITS_CHECK", 74);
+    if (MaxIt <= 0) std::printf("### WARNING: Max number of iterations must be POSITIVE! [%s:%d]\n", "ITS_CHECK", 78);
+    switch (itparam->itsolver_type) {
+        case SOLVER_CG: iter = fasp_solver_dbsr_pcg(A, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        case SOLVER_BiCGstab: iter = fasp_solver_dbsr_pbcgs(A, b, x, pc, tol, abstol, MaxIt, stop_type, prtlvl); break;
+        case SOLVER_GMRES: iter = fasp_solver_dbsr_pgmres(A, b, x, pc, tol, abstol, MaxIt, restart, stop_type, prtlvl); break;
+        case SOLVER_VGMRES: iter = fasp_solver_dbsr_pvgmres(A, b, x, pc, tol, abstol, MaxIt, restart, stop_type, prtlvl); break;
+        case SOLVER_VFGMRES: iter = fasp_solver_dbsr_pvfgmres(A, b, x, pc, tol, abstol, MaxIt, restart, stop_type, prtlvl); break;
+        default:
+            std::printf("### ERROR: Unknown iterative solver type %d! [%s]\n", itparam->itsolver_type, __func__);
+            return ERROR_SOLVER_TYPE;
+    }
+    if ((prtlvl >= PRINT_SOME) && (iter >= 0)) std::printf("Iterative method costs %.4f seconds.\n", wall_seconds() - t0);
+    return iter;
+}
+// SolBSR.c:145
+int fasp_solver_dbsr_krylov(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam)
+{
+    if (!itparam) return ERROR_INPUT_PAR;
+    const double t0 = wall_seconds();
+    const int status = fasp_solver_dbsr_itsolver(A, b, x, nullptr, itparam);
+    if (itparam->print_level >= PRINT_MIN) std::printf("Krylov method totally costs %.4f seconds.\n", wall_seconds() - t0);
+    return status;
+}
+// SolBSR.c:186: block-diagonal preconditioner, inverse blocks by fasp_smat_inv (nb <= 3 here)
+int fasp_solver_dbsr_krylov_diag(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam)
+{
+    if (!A || !itparam || !A->IA || !A->JA || !A->val) return ERROR_INPUT_PAR;
+    if (A->nb < 1 || A->nb > 3) {
+        std::printf("### ERROR: fasp_hip: block-diagonal preconditioner needs 1 <= nb <= 3, got %d\n", A->nb);
+        return ERROR_INPUT_PAR;
+    }
+    const double t0 = wall_seconds();
+    const int nb2 = A->nb * A->nb;
+    std::vector<double> dv((size_t)std::max(A->ROW, 1) * nb2, 0.0);
+    const int st = bsr_diaginv(A, dv.data());
+    if (st < 0) return st;
+    precond_diag_bsr diag;
+    diag.nb = A->nb; diag.diag.row = A->ROW * nb2; diag.diag.val = dv.data();
+    precond pc{&diag, fasp_precond_dbsr_diag};
+    const int status = fasp_solver_dbsr_itsolver(A, b, x, &pc, itparam);
+    if (itparam->print_level > PRINT_NONE) std::printf("Diag_Krylov method totally costs %.4f seconds.\n", wall_seconds() - t0);
+    return status;
 }
 
 // ---------------------------------------------------------------------------

@@ -238,6 +238,12 @@ typedef struct {
     void (*fct)(double*, double*, void*);
 } precond;
 
+/* fasp_block.h:255  data of the block-diagonal preconditioner */
+typedef struct {
+    int     nb;
+    dvector diag;   /* ROW inverse diagonal blocks of nb*nb doubles */
+} precond_diag_bsr;
+
 /* fasp.h:1109  matrix-free operator: y = A x through a function pointer */
 typedef struct {
     void* data;
@@ -433,6 +439,19 @@ int fasp_solver_dcsr_pcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const 
                          const double abstol, const int MaxIt, const short StopType, const short PrtLvl);
 int fasp_solver_dcsr_pbcgs(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol,
                            const double abstol, const int MaxIt, const short StopType, const short PrtLvl); /* KryPbcgs.c:62 */
+/* Solver-level entry points next to the AMG drop-in (SolCSR.c:56/:245/:333, SolBSR.c:64/:145/:186): dispatch on
+ * itsolver_type with a caller's preconditioner, without one, or with the (block-)diagonal one.  fasp_precond_diag
+ * (PreCSR.c:172) and fasp_precond_dbsr_diag (PreBSR.c:49) are host functions usable anywhere a `precond` is; handed
+ * to this library's Krylov methods they are recognised by their address and applied on the device. */
+void fasp_precond_diag(double* r, double* z, void* data);        /* data: dvector* of diagonal entries */
+void fasp_precond_dbsr_diag(double* r, double* z, void* data);   /* data: precond_diag_bsr* */
+int  fasp_solver_dcsr_itsolver(dCSRmat* A, dvector* b, dvector* x, precond* pc, ITS_param* itparam);
+int  fasp_solver_dcsr_krylov(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam);
+int  fasp_solver_dcsr_krylov_diag(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam);
+int  fasp_solver_dbsr_itsolver(dBSRmat* A, dvector* b, dvector* x, precond* pc, ITS_param* itparam);
+int  fasp_solver_dbsr_krylov(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam);
+int  fasp_solver_dbsr_krylov_diag(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam);
+
 /* Matrix-free interface (SolMatFree.c:58/:157/:201; KryPcg.c:1260, KryPbcgs.c:1349, KryPgcg.c:213,
  * KryPgmres.c:1309, KryPvgmres.c:1468, KryPvfgmres.c:1026 -- the reference keeps older texts of CG and
  * GMRES for this interface; they are what runs here).  fasp_solver_matfree_init(MAT_CSR | MAT_BSR)
