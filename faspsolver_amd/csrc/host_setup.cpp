@@ -1088,8 +1088,11 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
         }
         switch (amg->cycle_type) {
             case V_CYCLE: case W_CYCLE: case VW_CYCLE: case WV_CYCLE: break;
+            case AMLI_CYCLE:
+                if (amg->amli_degree >= 0 && amg->amli_degree <= 30) break;
+                return ERROR_INPUT_PAR;
             default:
-                std::printf("### ERROR: fasp_hip: cycle_type %d has no device path (V/W/VW/WV only)\n",
+                std::printf("### ERROR: fasp_hip: cycle_type %d has no device path (V/W/VW/WV/AMLI only)\n",
                             amg->cycle_type);
                 return ERROR_INPUT_PAR;
         }

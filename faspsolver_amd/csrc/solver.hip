@@ -718,6 +718,7 @@ struct DevLevel {
     struct Poly { bool built = false; double* dinv = nullptr; double k[6] = {0, 0, 0, 0, 0, 0}; double* w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
     Poly    poly;
     int*    d_mark = nullptr;  // C/F marker on the device (Jacobi-F smoother), built on first use
+    double* w2 = nullptr;      // AMLI cycle: the coarse residual r1 of the level above, built on first use
 };
 
 struct EventPair { hipEvent_t a, b; };
@@ -741,6 +742,7 @@ struct fasp_hip_amg {
     size_t               gm_len[2] = {0, 0};
     double*              gm_hh = nullptr;  // device Hessenberg column
     SpcgState*           spcg_state = nullptr;  // device-resident state of the batched coarse CG
+    std::vector<double>  amli_coef;             // AMLI polynomial coefficients (amli_degree + 1), formed on first use
     // instrumentation
     std::vector<EventPair> ev;
     int                    ev_used = 0;
@@ -765,6 +767,7 @@ static void free_level(DevLevel& D)
     if (D.poly.dinv) (void)hipFree(D.poly.dinv);
     for (double* q : D.poly.w) if (q) (void)hipFree(q);
     if (D.d_mark) (void)hipFree(D.d_mark);
+    if (D.w2) (void)hipFree(D.w2);
     D = DevLevel();
 }
 
@@ -842,6 +845,7 @@ static int upload_hierarchy(fasp_hip_amg* h)
     // sequential (Gauss-Seidel / SOR) sweeps couple all rows of a level: such hierarchies
     // are not row-partitioned, every rank keeps (and computes) all levels
     if (h->param.smoother != SMOOTHER_JACOBI && h->param.smoother != SMOOTHER_L1DIAG && h->param.smoother != SMOOTHER_POLY) min_rows = 2147483647;
+    if (h->param.cycle_type == AMLI_CYCLE) min_rows = 2147483647;  // the recursive AMLI cycle runs on whole levels
     {
         const int st = build_dist_plan(h->H, comm_rank(), comm_size(), min_rows, h->dist);
         if (st < 0) return st;
@@ -2436,9 +2440,112 @@ static int gmres_mf_device(KOps& K, bool variable, bool flexible, const double* 
 // ---------------------------------------------------------------------------
 // one multigrid cycle on the resident hierarchy (PreMGCycle.c:48-274)
 // ---------------------------------------------------------------------------
+// fasp_coarse_itsolver (PreMGUtil.inl:37): safe CG on the coarsest level, SPVGMRES as the safety net
+static int coarse_solve(fasp_hip_amg* h, const AMG_param& param, double tol)
+{
+    const int nl = (int)h->L.size();
+    DevLevel& Lc = h->L[nl - 1];
+    int st = coarse_spcg(h, Lc, tol, param.print_level);
+    if (st == ERROR_MISC) return st;  // device failure, not a solver verdict
+    if (st < 0) {
+        // safety net of PreMGUtil.inl:50-52: fasp_solver_dcsr_spvgmres(A, b, x, NULL, ctol, maxit, 20, 1, ..)
+        const int m = Lc.A.row;
+        const int nn = (int)((unsigned)m * (unsigned)m);
+        const int maxit = std::max(250, std::min(nn, 1000));
+        KOps Kc = csr_ops(h, nl - 1, false);
+        st = gmres_device(Kc, Lc.b, Lc.x, 2, tol, 0.0, maxit, 20, STOP_REL_RES, param.print_level - 4,
+                          nullptr, nullptr);
+        if (st == ERROR_MISC) return st;
+        if (st < 0 && param.print_level >= PRINT_MORE) {
+            std::printf("### WARNING: Coarse level solver did not converge!\n");
+            std::printf("### WARNING: Consider to increase maxit to %d!\n", 2 * maxit);
+        }
+    }
+    return FASP_SUCCESS;
+}
+
+// fasp_amg_amli_coef (PreMGRecurAMLI.c:791): coefficients of the degree-`degree` polynomial that
+// approximates 1/t on [lambda_min, lambda_max]
+static void amli_coef(double lambda_max, double lambda_min, int degree, double* coef)
+{
+    const double mu0 = 1.0 / lambda_max, mu1 = 1.0 / lambda_min;
+    const double c = (std::sqrt(mu0) + std::sqrt(mu1)) * (std::sqrt(mu0) + std::sqrt(mu1));
+    const double a = (4 * mu0 * mu1) / (c);
+    const double kappa = lambda_max / lambda_min;
+    const double delta = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
+    const double b = delta * delta;
+    if (degree == 0) coef[0] = 0.5 * (mu0 + mu1);
+    else if (degree == 1) { coef[0] = 0.5 * c; coef[1] = -1.0 * mu0 * mu1; }
+    else if (degree > 1) {
+        std::vector<double> work((size_t)2 * degree - 1, 0.0);
+        double *coef_k = work.data(), *coef_km1 = work.data() + degree;
+        amli_coef(lambda_max, lambda_min, degree - 1, coef_k);
+        amli_coef(lambda_max, lambda_min, degree - 2, coef_km1);
+        coef[0] = a - b * coef_km1[0] + (1 + b) * coef_k[0];
+        for (int i = 1; i < degree - 1; i++) coef[i] = -b * coef_km1[i] + (1 + b) * coef_k[i] - a * coef_k[i - 1];
+        coef[degree - 1] = (1 + b) * coef_k[degree - 1] - a * coef_k[degree - 2];
+        coef[degree] = -a * coef_k[degree - 1];
+    }
+}
+
+// fasp_solver_amli (PreMGRecurAMLI.c:58): the coarse-grid correction of every level is a polynomial of
+// degree amli_degree in the recursively preconditioned coarse operator (coefficients for the interval
+// [0.5, 2], PreAMGSetupRS.c:93-97).  One GPU (AMLI hierarchies are not row-partitioned).
+static int amli_cycle(fasp_hip_amg* h, const AMG_param& param, int l)
+{
+    const int nl = (int)h->L.size(), degree = param.amli_degree;
+    hipStream_t s = g_ctx.stream;
+    DevLevel& D = h->L[l];
+    int st;
+    if (l >= nl - 1) return coarse_solve(h, param, param.tol * 1e-4);
+    DevLevel& C = h->L[l + 1];
+    const int m0 = D.A.row, m1 = C.A.row;
+    const double* coef = h->amli_coef.data();
+    if (!C.w2) { if (alloc_vec(&C.w2, (size_t)C.nvec) < 0) return ERROR_ALLOC_MEM; }
+    double* r1 = C.w2;
+    if ((st = smooth(h, l, false, param.smoother, param.smooth_order, param.presmooth_iter, param.relaxation, param.polynomial_degree)) < 0) return st;
+    if (D.x_zero) HIPCK(hipMemcpyAsync(D.w, D.b, sizeof(double) * m0, hipMemcpyDeviceToDevice, s));
+    else d_resid(D.A, D.x, D.b, D.w);
+    d_mxv(D.R, D.w, C.b);
+    HIPCK(hipMemcpyAsync(r1, C.b, sizeof(double) * m1, hipMemcpyDeviceToDevice, s));
+    for (int i = 1; i <= degree; i++) {
+        C.x_zero = true;
+        if ((st = amli_cycle(h, param, l + 1)) < 0) return st;
+        materialise_zero(C);
+        d_mxv(C.A, C.x, C.b);                                           // b1 = A1 e1
+        d_axpy(m1, coef[degree - i] / coef[degree], r1, C.b);           // b1 += (q_{degree-i} / q_degree) r1
+    }
+    C.x_zero = true;
+    if ((st = amli_cycle(h, param, l + 1)) < 0) return st;
+    materialise_zero(C);
+    d_scale(m1, coef[degree], C.x);
+    double alpha = 1.0;
+    if (param.coarse_scaling == 1) {  // alpha = (e1, r1) / (A1 e1, e1), capped at 1; C.w is free scratch here
+        double red[2];
+        CsrArgs a{}; a.x = C.x; a.y = C.w; a.dotv = C.x; a.partials = g_ctx.d_partials;
+        const int gdot = launch_csr<OP_MXV_DOT>(C.A, a);
+        d_finalize(gdot, 1, 0u, 1, false);
+        if (fetch_red(1, 1, red + 1) < 0) return ERROR_MISC;
+        if (d_dot(m1, C.x, r1, red, false) < 0) return ERROR_MISC;
+        alpha = std::min(red[0] / red[1], 1.0);
+    }
+    materialise_zero(D);
+    d_aAxpy(alpha, D.P, C.x, D.x);
+    return smooth(h, l, true, param.smoother, param.smooth_order, param.postsmooth_iter, param.relaxation, param.polynomial_degree);
+}
+
 static int mgcycle(fasp_hip_amg* h, const AMG_param& param)
 {
     const int nl = (int)h->L.size();
+    if (param.cycle_type == AMLI_CYCLE) {  // fasp_precond_amli (PreCSR.c:482) / fasp_amg_solve_amli (PreMGSolve.c:142)
+        if (h->distributed || param.amli_degree < 0 || param.amli_degree > 30) return ERROR_INPUT_PAR;
+        if ((int)h->amli_coef.size() != param.amli_degree + 1) {
+            h->amli_coef.assign((size_t)param.amli_degree + 1, 0.0);
+            amli_coef(2.0, 0.5, param.amli_degree, h->amli_coef.data());
+        }
+        h->vcycles++;
+        return amli_cycle(h, param, 0);
+    }
     const int smoother = param.smoother, cycle_type = param.cycle_type;
     const double relax = param.relaxation;
     const double tol = param.tol * 1e-4;
@@ -2484,25 +2591,7 @@ ForwardSweep:
         h->L[l].x_zero = true;  // fasp_dvec_set(x_{l}, 0): materialised lazily
     }
 
-    {
-        DevLevel& Lc = h->L[nl - 1];
-        int st = coarse_spcg(h, Lc, tol, param.print_level);
-        if (st == ERROR_MISC) return st;  // device failure, not a solver verdict
-        if (st < 0) {
-            // safety net of PreMGUtil.inl:50-52: fasp_solver_dcsr_spvgmres(A, b, x, NULL, ctol, maxit, 20, 1, ..)
-            const int m = Lc.A.row;
-            const int nn = (int)((unsigned)m * (unsigned)m);
-            const int maxit = std::max(250, std::min(nn, 1000));
-            KOps Kc = csr_ops(h, nl - 1, false);
-            st = gmres_device(Kc, Lc.b, Lc.x, 2, tol, 0.0, maxit, 20, STOP_REL_RES, param.print_level - 4,
-                              nullptr, nullptr);
-            if (st == ERROR_MISC) return st;
-            if (st < 0 && param.print_level >= PRINT_MORE) {
-                std::printf("### WARNING: Coarse level solver did not converge!\n");
-                std::printf("### WARNING: Consider to increase maxit to %d!\n", 2 * maxit);
-            }
-        }
-    }
+    if ((st0 = coarse_solve(h, param, tol)) < 0) return st0;
 
     while (l > 0) {
         --l;
@@ -2546,6 +2635,7 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
     p.postsmooth_iter = u.postsmooth_iter; p.relaxation = u.relaxation;
     p.polynomial_degree = u.polynomial_degree; p.coarse_solver = u.coarse_solver;
     p.coarse_scaling = u.coarse_scaling; p.tentative_smooth = u.tentative_smooth;
+    p.amli_degree = u.amli_degree; p.nl_amli_krylov_type = u.nl_amli_krylov_type;
     DevLevel& D0 = h->L[0];
     D0.b = r;
     D0.x_zero = true;

@@ -36,6 +36,8 @@ typedef struct {
     /* counters (not in the reference; instrumentation for tests) */
     long long coarse_iters;
     long long cycles;
+    /* AMLI polynomial coefficients (PreAMGSetupRS.c:93-97; the reference hangs them on AMG_param) */
+    double amli_coef[32];
 } orc_amg;
 
 /* threads used by the row-parallel loops (1 = exact serial order everywhere,

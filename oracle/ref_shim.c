@@ -118,7 +118,11 @@ static void hist_pc_fct(double* r, double* z, void* data)
     hist_pc* h = (hist_pc*)data;
     if (h->hist && h->n < h->cap) h->hist[h->n] = fasp_blas_darray_norm2(h->m, r);
     h->n++;
-    fasp_precond_amg(r, z, h->pcdata);
+    switch (h->pcdata->cycle_type) {   /* SolCSR.c:540-549 */
+        case AMLI_CYCLE: fasp_precond_amli(r, z, h->pcdata); break;
+        case NL_AMLI_CYCLE: fasp_precond_namli(r, z, h->pcdata); break;
+        default: fasp_precond_amg(r, z, h->pcdata);
+    }
 }
 
 /* Mirrors SolCSR.c:476-569 step by step, only swapping pc.fct for the recording

@@ -166,14 +166,28 @@ def _stdint(itp, amgp):   # standard interpolation (PreAMGInterp.c:547): a host-
     _jac(itp, amgp); amgp.interpolation_type = 2
 
 
+def _amli1(itp, amgp):    # AMLI cycle (PreMGRecurAMLI.c:58), polynomial degree 1 / 2 with coarse scaling / 3 with GS
+    _jac(itp, amgp); amgp.cycle_type = T.AMLI_CYCLE; amgp.amli_degree = 1
+
+
+def _amli2cs(itp, amgp):
+    _jac(itp, amgp); amgp.cycle_type = T.AMLI_CYCLE; amgp.amli_degree = 2; amgp.coarse_scaling = 1
+
+
+def _amli3gs(itp, amgp):
+    itp.tol = 1e-8; amgp.cycle_type = T.AMLI_CYCLE; amgp.amli_degree = 3
+
+
 def _jacf23(itp, amgp):
     itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_JACOBIF; amgp.presmooth_iter = 2; amgp.postsmooth_iter = 3
 
 
 @pytest.mark.parametrize("n", [8, 16, 32, 48])
-@pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22, _jac_cs, _poly3, _poly5w, _poly1, _jacf, _jacf23, _stdint],
+@pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22, _jac_cs, _poly3, _poly5w, _poly1, _jacf, _jacf23, _stdint,
+                                 _amli1, _amli2cs, _amli3gs],
                          ids=["jacobi-V", "jacobi-W", "l1diag-V", "jacobi-V22", "jacobi-V-coarse-scaling",
-                              "poly3-V", "poly5-W", "poly1-V", "jacobiF-V", "jacobiF-V23", "jacobi-V-std-interp"])
+                              "poly3-V", "poly5-W", "poly1-V", "jacobiF-V", "jacobiF-V23", "jacobi-V-std-interp",
+                              "jacobi-AMLI1", "jacobi-AMLI2-coarse-scaling", "gs-AMLI3"])
 def test_pcg_history_poisson(gpu, n, mod):
     if n == 48 and mod is not _jac:
         pytest.skip("largest size only for the headline configuration")

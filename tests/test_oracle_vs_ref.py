@@ -48,11 +48,16 @@ def _mods():
     def jacf2(i, a): i.tol = 1e-8; a.smoother = T.SMOOTHER_JACOBIF; a.relaxation = 1.0; a.presmooth_iter = 2; a.postsmooth_iter = 3
     def stdint(i, a): jac(i, a); a.interpolation_type = 2
     def stdint_w(i, a): i.tol = 1e-8; a.interpolation_type = 2; a.cycle_type = T.W_CYCLE; a.truncation_threshold = 0.4
+    def amli1(i, a): jac(i, a); a.cycle_type = T.AMLI_CYCLE; a.amli_degree = 1
+    def amli2gs(i, a): i.tol = 1e-8; a.cycle_type = T.AMLI_CYCLE; a.amli_degree = 2
+    def amli2cs(i, a): jac(i, a); a.cycle_type = T.AMLI_CYCLE; a.amli_degree = 2; a.coarse_scaling = 1
+    def amli0(i, a): jac(i, a); a.cycle_type = T.AMLI_CYCLE; a.amli_degree = 0
+    def amli3vg(i, a): vg(i, a); a.cycle_type = T.AMLI_CYCLE; a.amli_degree = 3
     def vgpre(i, a): vg(i, a); i.stop_type = T.STOP_REL_PRECRES
     def vfgmod(i, a): vfg(i, a); i.stop_type = T.STOP_MOD_REL_RES
     return dict(jac=jac, jacw=jacw, vw=vw, l1=l1, gscf=gscf, gsn=gsn, sor=sor, ssor=ssor, sgs=sgs,
                 theta=theta, precres=precres, modres=modres, gsor=gsor, sgsor=sgsor, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
-                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w)
+                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w, amli1=amli1, amli2gs=amli2gs, amli2cs=amli2cs, amli0=amli0, amli3vg=amli3vg)
 
 
 @pytest.mark.parametrize("name", list(_mods().keys()))
