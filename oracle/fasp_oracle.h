@@ -38,6 +38,9 @@ typedef struct {
     long long cycles;
     /* AMLI polynomial coefficients (PreAMGSetupRS.c:93-97; the reference hangs them on AMG_param) */
     double amli_coef[32];
+    /* AMG_data.cycle_type of every level (PreAMGSetupRS.c:325, PreAMGSetupUA.c:380-401): read by the
+     * nonlinear AMLI cycle, which drops to a V-cycle where it is <= 1 */
+    int level_cycle_type[ORC_MAX_LVL];
 } orc_amg;
 
 /* threads used by the row-parallel loops (1 = exact serial order everywhere,
