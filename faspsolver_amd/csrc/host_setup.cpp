@@ -1091,8 +1091,9 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             case AMLI_CYCLE:
                 if (amg->amli_degree >= 0 && amg->amli_degree <= 30) break;
                 return ERROR_INPUT_PAR;
+            case NL_AMLI_CYCLE: break;
             default:
-                std::printf("### ERROR: fasp_hip: cycle_type %d has no device path (V/W/VW/WV/AMLI only)\n",
+                std::printf("### ERROR: fasp_hip: cycle_type %d has no device path\n",
                             amg->cycle_type);
                 return ERROR_INPUT_PAR;
         }

@@ -719,6 +719,7 @@ struct DevLevel {
     Poly    poly;
     int*    d_mark = nullptr;  // C/F marker on the device (Jacobi-F smoother), built on first use
     double* w2 = nullptr;      // AMLI cycle: the coarse residual r1 of the level above, built on first use
+    double* kw[4] = {nullptr, nullptr, nullptr, nullptr};  // K-cycle work vectors r, x1, v1, v2 of this level
 };
 
 struct EventPair { hipEvent_t a, b; };
@@ -743,6 +744,7 @@ struct fasp_hip_amg {
     double*              gm_hh = nullptr;  // device Hessenberg column
     SpcgState*           spcg_state = nullptr;  // device-resident state of the batched coarse CG
     std::vector<double>  amli_coef;             // AMLI polynomial coefficients (amli_degree + 1), formed on first use
+    std::vector<int>     level_cycle_type;      // AMG_data.cycle_type per level as the setup leaves it (K-cycle)
     // instrumentation
     std::vector<EventPair> ev;
     int                    ev_used = 0;
@@ -768,6 +770,7 @@ static void free_level(DevLevel& D)
     for (double* q : D.poly.w) if (q) (void)hipFree(q);
     if (D.d_mark) (void)hipFree(D.d_mark);
     if (D.w2) (void)hipFree(D.w2);
+    for (double* q : D.kw) if (q) (void)hipFree(q);
     D = DevLevel();
 }
 
@@ -845,7 +848,25 @@ static int upload_hierarchy(fasp_hip_amg* h)
     // sequential (Gauss-Seidel / SOR) sweeps couple all rows of a level: such hierarchies
     // are not row-partitioned, every rank keeps (and computes) all levels
     if (h->param.smoother != SMOOTHER_JACOBI && h->param.smoother != SMOOTHER_L1DIAG && h->param.smoother != SMOOTHER_POLY) min_rows = 2147483647;
-    if (h->param.cycle_type == AMLI_CYCLE) min_rows = 2147483647;  // the recursive AMLI cycle runs on whole levels
+    if (h->param.cycle_type == AMLI_CYCLE || h->param.cycle_type == NL_AMLI_CYCLE) min_rows = 2147483647;  // the recursive cycles run on whole levels
+    {   // AMG_data.cycle_type of every level: the setup's cycle type for levels >= 1 (PreAMGSetupRS.c:325,
+        // PreAMGSetupSA.c:495); the UA setup derives it from the operator complexity (PreAMGSetupUA.c:390-401)
+        h->level_cycle_type.assign((size_t)nl, h->param.cycle_type);
+        h->level_cycle_type[0] = 0;
+        if (h->param.AMG_type == UA_AMG) {
+            const double cplxmax = 3.0, xsi = 0.6, eta = xsi / ((1 - xsi) * (cplxmax - 1));
+            int icum = 1;
+            h->level_cycle_type[0] = 1;
+            h->level_cycle_type[(size_t)nl - 1] = 0;
+            for (int lvl = 1; lvl < nl - 1; ++lvl) {
+                const double fracratio = (double)h->H.L[lvl].A.nnz / h->H.L[0].A.nnz;
+                int ct = (int)(std::pow(xsi, (double)lvl) / (eta * fracratio * icum));
+                ct = std::max(1, std::min(2, ct));
+                h->level_cycle_type[(size_t)lvl] = ct;
+                icum = icum * ct;
+            }
+        }
+    }
     {
         const int st = build_dist_plan(h->H, comm_rank(), comm_size(), min_rows, h->dist);
         if (st < 0) return st;
@@ -2534,9 +2555,128 @@ static int amli_cycle(fasp_hip_amg* h, const AMG_param& param, int l)
     return smooth(h, l, true, param.smoother, param.smooth_order, param.postsmooth_iter, param.relaxation, param.polynomial_degree);
 }
 
+// Nonlinear AMLI / K-cycle (fasp_solver_namli, PreMGRecurAMLI.c:291; Kcycle_dcsr_pgcg / _pgcr,
+// PreMGRecurAMLI.inl:36 / :139; fasp_precond_namli, PreCSR.c:524): the coarse problem of a level whose
+// AMG_data.cycle_type is > 1 is solved by at most two steps of a Krylov method preconditioned by the
+// same cycle one level down.  `base` = the level the reference's shifted pointer &mgl[l+1] points at.
+static int namli_cycle(fasp_hip_amg* h, const AMG_param& param, int base, int num_levels);
+
+static int namli_precond(fasp_hip_amg* h, const AMG_param& user, int base, int num_levels, const double* r, double* z)
+{
+    AMG_param p;  // fasp_param_amg_init + fasp_param_prec_to_amg (AuxParam.c:816): tol is not carried over
+    fasp_param_amg_init(&p);
+    p.AMG_type = user.AMG_type; p.print_level = user.print_level; p.cycle_type = user.cycle_type;
+    p.smoother = user.smoother; p.smooth_order = user.smooth_order; p.presmooth_iter = user.presmooth_iter;
+    p.postsmooth_iter = user.postsmooth_iter; p.relaxation = user.relaxation;
+    p.polynomial_degree = user.polynomial_degree; p.coarse_solver = user.coarse_solver;
+    p.coarse_scaling = user.coarse_scaling; p.amli_degree = user.amli_degree;
+    p.nl_amli_krylov_type = user.nl_amli_krylov_type; p.tentative_smooth = user.tentative_smooth;
+    DevLevel& L = h->L[base];
+    const int m = L.A.row;
+    HIPCK(hipMemcpyAsync(L.b, r, sizeof(double) * m, hipMemcpyDeviceToDevice, g_ctx.stream));
+    L.x_zero = true;
+    const int st = namli_cycle(h, p, base, num_levels);
+    if (st < 0) return st;
+    materialise_zero(L);
+    HIPCK(hipMemcpyAsync(z, L.x, sizeof(double) * m, hipMemcpyDeviceToDevice, g_ctx.stream));
+    return FASP_SUCCESS;
+}
+
+// at most two steps of GCG (gcr == false) or GCR on level `base` (matrix L.A, right-hand side L.b), result in x
+static int kcycle(fasp_hip_amg* h, const AMG_param& param, bool gcr, int base, int num_levels, double* x)
+{
+    DevLevel& L = h->L[base];
+    const int m = L.A.row;
+    hipStream_t s = g_ctx.stream;
+    for (double*& q : L.kw) if (!q) { if (alloc_vec(&q, (size_t)L.nvec) < 0) return ERROR_ALLOC_MEM; }
+    double *r = L.kw[0], *x1 = L.kw[1], *v1 = L.kw[2], *v2 = L.kw[3];
+    double red[2], normb, absres, relres, alpha1, alpha2, gamma, rho1, rho2;
+    auto dot = [&](const double* a, const double* b, double& v) -> int {
+        if (d_dot(m, a, b, red, false) < 0) return ERROR_MISC;
+        v = red[0];
+        return 0;
+    };
+    int st;
+    if ((st = dot(L.b, L.b, normb)) < 0) return st;
+    normb = std::sqrt(normb);
+    HIPCK(hipMemcpyAsync(r, L.b, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    if ((st = namli_precond(h, param, base, num_levels, r, x)) < 0) return st;
+    d_mxv(L.A, x, v1);
+    if (!gcr) {
+        if ((st = dot(x, v1, rho1)) < 0 || (st = dot(x, r, alpha1)) < 0) return st;
+        const double beta1 = alpha1 / rho1;
+        d_axpy(m, -beta1, v1, r);
+        if ((st = dot(r, r, absres)) < 0) return st;
+        relres = std::sqrt(absres) / normb;
+        if (relres < 0.2) { d_scale(m, beta1, x); return FASP_SUCCESS; }
+        if ((st = namli_precond(h, param, base, num_levels, r, x1)) < 0) return st;
+        d_mxv(L.A, x1, v2);
+        if ((st = dot(x1, v1, gamma)) < 0 || (st = dot(x1, r, alpha2)) < 0 || (st = dot(x1, v2, rho2)) < 0) return st;
+        const double beta2 = rho2 - gamma * gamma / rho1;
+        if (std::fabs(beta2) < SMALLREAL) return FASP_SUCCESS;
+        const double beta3 = (alpha1 - gamma * alpha2 / beta2) / rho1, beta4 = alpha2 / beta2;
+        d_scale(m, beta3, x);
+        d_axpy(m, beta4, x1, x);
+    } else {
+        double beta;
+        if ((st = dot(v1, v1, rho1)) < 0 || (st = dot(v1, r, alpha1)) < 0) return st;
+        const double alpha = alpha1 / rho1;
+        d_axpy(m, -alpha, v1, r);
+        if ((st = dot(r, r, absres)) < 0) return st;
+        relres = std::sqrt(absres) / normb;
+        if (relres < 0.2) { d_scale(m, alpha, x); return FASP_SUCCESS; }
+        if ((st = namli_precond(h, param, base, num_levels, r, x1)) < 0) return st;
+        d_mxv(L.A, x1, v2);
+        if ((st = dot(v1, v2, gamma)) < 0 || (st = dot(v2, v2, beta)) < 0 || (st = dot(r, v2, alpha2)) < 0) return st;
+        rho2 = beta - gamma * gamma / rho1;
+        const double alpha3 = alpha1 / rho1 - gamma * alpha2 / (rho1 * rho2), alpha4 = alpha2 / rho2;
+        d_scale(m, alpha3, x);
+        d_axpy(m, alpha4, x1, x);
+    }
+    return FASP_SUCCESS;
+}
+
+static int namli_cycle(fasp_hip_amg* h, const AMG_param& param, int base, int num_levels)
+{
+    hipStream_t s = g_ctx.stream;
+    DevLevel& D = h->L[base];
+    int st;
+    if (num_levels <= 1) {  // coarsest level of this sub-hierarchy == coarsest level of the hierarchy
+        if (base != (int)h->L.size() - 1) return ERROR_INPUT_PAR;
+        return coarse_solve(h, param, param.tol * 1e-4);
+    }
+    DevLevel& C = h->L[base + 1];
+    const int m0 = D.A.row, m1 = C.A.row;
+    if ((st = smooth(h, base, false, param.smoother, param.smooth_order, param.presmooth_iter, param.relaxation, param.polynomial_degree)) < 0) return st;
+    if (D.x_zero) HIPCK(hipMemcpyAsync(D.w, D.b, sizeof(double) * m0, hipMemcpyDeviceToDevice, s));
+    else d_resid(D.A, D.x, D.b, D.w);
+    d_mxv(D.R, D.w, C.b);
+    const int ct = (base + 1 < (int)h->level_cycle_type.size()) ? h->level_cycle_type[(size_t)base + 1] : 1;
+    if (ct <= 1) {  // a V-cycle is enforced on this level
+        C.x_zero = true;
+        if ((st = namli_cycle(h, param, base + 1, num_levels - 1)) < 0) return st;
+        materialise_zero(C);
+    } else {
+        if (!C.w2) { if (alloc_vec(&C.w2, (size_t)C.nvec) < 0) return ERROR_ALLOC_MEM; }
+        double* uH = C.w2;
+        HIPCK(hipMemsetAsync(uH, 0, sizeof(double) * m1, s));
+        if ((st = kcycle(h, param, param.nl_amli_krylov_type != SOLVER_GCG, base + 1, num_levels - 1, uH)) < 0) return st;
+        HIPCK(hipMemcpyAsync(C.x, uH, sizeof(double) * m1, hipMemcpyDeviceToDevice, s));
+        C.x_zero = false;
+    }
+    materialise_zero(D);
+    d_aAxpy(1.0, D.P, C.x, D.x);
+    return smooth(h, base, true, param.smoother, param.smooth_order, param.postsmooth_iter, param.relaxation, param.polynomial_degree);
+}
+
 static int mgcycle(fasp_hip_amg* h, const AMG_param& param)
 {
     const int nl = (int)h->L.size();
+    if (param.cycle_type == NL_AMLI_CYCLE) {  // fasp_precond_namli (PreCSR.c:524) / fasp_amg_solve_namli (PreMGSolve.c:230)
+        if (h->distributed) return ERROR_INPUT_PAR;
+        h->vcycles++;
+        return namli_cycle(h, param, 0, nl);
+    }
     if (param.cycle_type == AMLI_CYCLE) {  // fasp_precond_amli (PreCSR.c:482) / fasp_amg_solve_amli (PreMGSolve.c:142)
         if (h->distributed || param.amli_degree < 0 || param.amli_degree > 30) return ERROR_INPUT_PAR;
         if ((int)h->amli_coef.size() != param.amli_degree + 1) {

@@ -63,7 +63,7 @@ def test_unsupported_parameters_are_refused_before_any_work(fa):
     cases.append((it, am, T.ERROR_AMG_SMOOTH_TYPE))
     it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.AMG_type = T.UA_AMG; am.aggregation_type = 3  # NPAIR: unfinished in the reference
     cases.append((it, am, T.ERROR_INPUT_PAR))
-    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.cycle_type = T.NL_AMLI_CYCLE
+    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.cycle_type = 7   # not a cycle type of the reference
     cases.append((it, am, T.ERROR_INPUT_PAR))
     it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.ILU_levels = 1
     cases.append((it, am, T.ERROR_INPUT_PAR))

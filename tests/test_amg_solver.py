@@ -46,11 +46,12 @@ def dflt(p): p.tol = 1e-8; p.maxit = 100
 def wcyc(p): jac(p); p.cycle_type = T.W_CYCLE
 def sa(p): jac(p); p.AMG_type = T.SA_AMG
 def amli(p): jac(p); p.cycle_type = T.AMLI_CYCLE; p.amli_degree = 2   # fasp_amg_solve_amli, PreMGSolve.c:142
+def namli(p): jac(p); p.cycle_type = T.NL_AMLI_CYCLE   # fasp_amg_solve_namli, PreMGSolve.c:230
 def few(p): jac(p); p.maxit = 3
 def sor(p): p.smoother = T.SMOOTHER_SOR; p.relaxation = 1.1; p.tol = 1e-8; p.maxit = 100
 
 
-MODS = {"jacobi": jac, "default_gscf": dflt, "W": wcyc, "sa": sa, "maxit3": few, "sor": sor, "amli2": amli}
+MODS = {"jacobi": jac, "default_gscf": dflt, "W": wcyc, "sa": sa, "maxit3": few, "sor": sor, "amli2": amli, "namli": namli}
 
 
 def params(mod):
