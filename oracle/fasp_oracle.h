@@ -110,6 +110,8 @@ void orc_amg_free(orc_amg* mgl);
 
 /* one multigrid cycle: PreMGCycle.c:48 */
 void orc_mgcycle(orc_amg* mgl, const AMG_param* param);
+/* one full-multigrid cycle: PreMGCycleFull.c:47 */
+void orc_fmgcycle(orc_amg* mgl, const AMG_param* param);
 /* z = B r with the parameter hand-over of PreCSR.c:416 (tol is NOT forwarded) */
 void orc_precond_amg(orc_amg* mgl, const AMG_param* amgparam, const double* r, double* z);
 

@@ -111,6 +111,7 @@ typedef struct {
     precond_data* pcdata;
     double*       hist;
     int           cap, n, m;
+    int           fmg;
 } hist_pc;
 
 static void hist_pc_fct(double* r, double* z, void* data)
@@ -118,6 +119,7 @@ static void hist_pc_fct(double* r, double* z, void* data)
     hist_pc* h = (hist_pc*)data;
     if (h->hist && h->n < h->cap) h->hist[h->n] = fasp_blas_darray_norm2(h->m, r);
     h->n++;
+    if (h->fmg) { fasp_precond_famg(r, z, h->pcdata); return; }   /* SolCSR.c:537 */
     switch (h->pcdata->cycle_type) {   /* SolCSR.c:540-549 */
         case AMLI_CYCLE: fasp_precond_amli(r, z, h->pcdata); break;
         case NL_AMLI_CYCLE: fasp_precond_namli(r, z, h->pcdata); break;
@@ -148,7 +150,7 @@ int ref_krylov_amg_hist(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam,
     pcdata.max_levels = mgl[0].num_levels;
     pcdata.mgl_data   = mgl;
 
-    hist_pc hp = {&pcdata, hist, cap, 0, m};
+    hist_pc hp = {&pcdata, hist, cap, 0, m, itparam->precond_type == PREC_FMG};
     precond pc;
     pc.data = &hp;
     pc.fct  = hist_pc_fct;
