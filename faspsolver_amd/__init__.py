@@ -30,7 +30,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_solver_dbsr_pcg", "fasp_solver_dbsr_pbcgs", "fasp_solver_dbsr_pgmres", "fasp_solver_dbsr_pvgmres",
     "fasp_solver_dbsr_pvfgmres", "fasp_hip_bsr_precond_setup", "fasp_hip_bsr_precond_fct", "fasp_hip_bsr_precond_free",
     "fasp_hip_param_input", "fasp_fwrapper_dcsr_krylov_amg_", "fasp_dcsrvec_read2", "fasp_dvec_read",
-    "fasp_dbsr_read", "fasp_dcoo_read", "fasp_dcoo_read1", "fasp_dcoo_shift_read", "fasp_dmtx_read", "fasp_dmtxsym_read", "fasp_dvec_write", "fasp_dcsr_write_coo", "fasp_dcsrvec_write2", "fasp_fwrapper_dcsr_amg_", "fasp_fwrapper_dbsr_krylov_amg_", "fasp_hip_free_bsr", "fasp_hip_comm_selftest", "fasp_hip_amg_kernel_info", "fasp_hip_coding_selftest", "fasp_solver_amg", "fasp_hip_amg_solve", "fasp_precond_diag", "fasp_precond_dbsr_diag", "fasp_solver_dcsr_itsolver", "fasp_solver_dcsr_krylov", "fasp_solver_dcsr_krylov_diag", "fasp_solver_dbsr_itsolver", "fasp_solver_dbsr_krylov", "fasp_solver_dbsr_krylov_diag", "fasp_hip_mxv_csr", "fasp_hip_mxv_bsr", "fasp_solver_matfree_init", "fasp_solver_pcg", "fasp_solver_pbcgs", "fasp_solver_pgcg", "fasp_solver_pminres", "fasp_solver_pgmres", "fasp_solver_pvgmres", "fasp_solver_pvfgmres", "fasp_solver_itsolver", "fasp_solver_krylov", "fasp_solver_dcsr_pcg", "fasp_solver_dcsr_pminres", "fasp_solver_dcsr_pgcg", "fasp_solver_dcsr_pgcr", "fasp_solver_dcsr_pbcgs", "fasp_solver_dcsr_pgmres", "fasp_solver_dcsr_pvgmres",
+    "fasp_dbsr_read", "fasp_dcoo_read", "fasp_dcoo_read1", "fasp_dcoo_shift_read", "fasp_dmtx_read", "fasp_dmtxsym_read", "fasp_dvec_write", "fasp_dcsr_write_coo", "fasp_dcsrvec_write2", "fasp_fwrapper_dcsr_amg_", "fasp_fwrapper_dbsr_krylov_amg_", "fasp_hip_free_bsr", "fasp_hip_comm_selftest", "fasp_hip_amg_kernel_info", "fasp_hip_coding_selftest", "fasp_solver_amg", "fasp_solver_famg", "fasp_hip_amg_solve", "fasp_precond_diag", "fasp_precond_dbsr_diag", "fasp_solver_dcsr_itsolver", "fasp_solver_dcsr_krylov", "fasp_solver_dcsr_krylov_diag", "fasp_solver_dbsr_itsolver", "fasp_solver_dbsr_krylov", "fasp_solver_dbsr_krylov_diag", "fasp_hip_mxv_csr", "fasp_hip_mxv_bsr", "fasp_solver_matfree_init", "fasp_solver_pcg", "fasp_solver_pbcgs", "fasp_solver_pgcg", "fasp_solver_pminres", "fasp_solver_pgmres", "fasp_solver_pvgmres", "fasp_solver_pvfgmres", "fasp_solver_itsolver", "fasp_solver_krylov", "fasp_solver_dcsr_pcg", "fasp_solver_dcsr_pminres", "fasp_solver_dcsr_pgcg", "fasp_solver_dcsr_pgcr", "fasp_solver_dcsr_pbcgs", "fasp_solver_dcsr_pgmres", "fasp_solver_dcsr_pvgmres",
     "fasp_solver_dcsr_pvfgmres", "fasp_hip_precond_setup", "fasp_hip_precond_fct", "fasp_hip_precond_free",
     "fasp_hip_time_bsr_mxv", "fasp_solver_dbsr_krylov_amg", "fasp_hip_bsr_amg_create", "fasp_hip_bsr_amg_create_host",
     "fasp_hip_bsr_amg_destroy", "fasp_hip_bsr_amg_num_levels", "fasp_hip_bsr_amg_get_matrix",

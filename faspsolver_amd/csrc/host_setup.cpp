@@ -1127,10 +1127,6 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
                         "fasp_solver_dcsr_itsolver");
             return ERROR_SOLVER_TYPE;
         }
-        if (it->precond_type == PREC_FMG) {
-            std::printf("### ERROR: fasp_hip: full-multigrid preconditioner has no device path\n");
-            return ERROR_SOLVER_PRECTYPE;
-        }
         if (it->stop_type < STOP_REL_RES || it->stop_type > STOP_MOD_REL_RES) return ERROR_INPUT_PAR;
         if ((it->itsolver_type == SOLVER_GMRES || it->itsolver_type == SOLVER_VGMRES || it->itsolver_type == SOLVER_VFGMRES ||
              it->itsolver_type == SOLVER_GCR) &&

@@ -745,6 +745,7 @@ struct fasp_hip_amg {
     SpcgState*           spcg_state = nullptr;  // device-resident state of the batched coarse CG
     std::vector<double>  amli_coef;             // AMLI polynomial coefficients (amli_degree + 1), formed on first use
     std::vector<int>     level_cycle_type;      // AMG_data.cycle_type per level as the setup leaves it (K-cycle)
+    bool                 use_fmg = false;       // the preconditioner is one full-multigrid cycle (precond_type == PREC_FMG)
     // instrumentation
     std::vector<EventPair> ev;
     int                    ev_used = 0;
@@ -2669,6 +2670,77 @@ static int namli_cycle(fasp_hip_amg* h, const AMG_param& param, int base, int nu
     return smooth(h, base, true, param.smoother, param.smooth_order, param.postsmooth_iter, param.relaxation, param.polynomial_degree);
 }
 
+// fasp_solver_fmgcycle (PreMGCycleFull.c:47): the right-hand side is restricted to every level, the
+// coarsest system solved, then level by level the solution is interpolated and improved by up to 3
+// V-cycles from that level.  As in the reference the iterate of an intermediate level is not reset
+// before the interpolated correction is added: it keeps what the previous call left there.  One GPU.
+static int fmg_cycle(fasp_hip_amg* h, const AMG_param& param)
+{
+    const int nl = (int)h->L.size(), maxit = 3;
+    const double tol = param.tol * 1e-4;
+    hipStream_t s = g_ctx.stream;
+    int st, l;
+    if (h->distributed) return ERROR_INPUT_PAR;
+    h->vcycles++;
+    for (l = 0; l < nl - 1; ++l) d_mxv(h->L[l].R, h->L[l].b, h->L[l + 1].b);
+    h->L[l].x_zero = true;
+    if (nl == 1) return coarse_solve(h, param, tol);
+    auto scaled_prolongation = [&](int lf) -> int {  // x_lf += alpha P x_{lf+1}
+        DevLevel& D = h->L[lf];
+        DevLevel& C = h->L[lf + 1];
+        double alpha = 1.0;
+        materialise_zero(C);
+        if (param.coarse_scaling == 1) {
+            double red[2];
+            CsrArgs a{}; a.x = C.x; a.y = C.w; a.dotv = C.x; a.partials = g_ctx.d_partials;
+            const int gdot = launch_csr<OP_MXV_DOT>(C.A, a);
+            d_finalize(gdot, 1, 0u, 1, false);
+            if (fetch_red(1, 1, red + 1) < 0) return ERROR_MISC;
+            if (d_dot(C.A.row, C.x, C.b, red, false) < 0) return ERROR_MISC;
+            alpha = std::min(red[0] / red[1], 1.0);
+        }
+        materialise_zero(D);
+        d_aAxpy(alpha, D.P, C.x, D.x);
+        return FASP_SUCCESS;
+    };
+    for (int i = 1; i < nl; ++i) {
+        if ((st = coarse_solve(h, param, tol)) < 0) return st;
+        --l;
+        if ((st = scaled_prolongation(l)) < 0) return st;
+        int num_cycle = 0;
+        double relerr = BIGREAL, red[2];
+        while (relerr > param.tol && num_cycle < maxit) {
+            ++num_cycle;
+            {
+                DevLevel& D = h->L[l];
+                d_resid(D.A, D.x, D.b, D.w);
+                double nw, nb;
+                if (d_dot(D.A.row, D.w, D.w, red, false) < 0) return ERROR_MISC;
+                nw = std::sqrt(red[0]);
+                if (d_dot(D.A.row, D.b, D.b, red, false) < 0) return ERROR_MISC;
+                nb = std::sqrt(red[0]);
+                relerr = nw / nb;
+            }
+            for (int lvl = 0; lvl < i; ++lvl) {
+                DevLevel& D = h->L[l];
+                if ((st = smooth(h, l, false, param.smoother, param.smooth_order, param.presmooth_iter, param.relaxation, param.polynomial_degree)) < 0) return st;
+                if (D.x_zero) HIPCK(hipMemcpyAsync(D.w, D.b, sizeof(double) * D.A.row, hipMemcpyDeviceToDevice, s));
+                else d_resid(D.A, D.x, D.b, D.w);
+                d_mxv(D.R, D.w, h->L[l + 1].b);
+                ++l;
+                h->L[l].x_zero = true;
+            }
+            if ((st = coarse_solve(h, param, tol)) < 0) return st;
+            for (int lvl = 0; lvl < i; ++lvl) {
+                --l;
+                if ((st = scaled_prolongation(l)) < 0) return st;
+                if ((st = smooth(h, l, true, param.smoother, param.smooth_order, param.postsmooth_iter, param.relaxation, param.polynomial_degree)) < 0) return st;
+            }
+        }
+    }
+    return FASP_SUCCESS;
+}
+
 static int mgcycle(fasp_hip_amg* h, const AMG_param& param)
 {
     const int nl = (int)h->L.size();
@@ -2780,7 +2852,7 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
     D0.b = r;
     D0.x_zero = true;
     for (int i = u.maxit; i--;) {
-        const int st = mgcycle(h, p);
+        const int st = h->use_fmg ? fmg_cycle(h, p) : mgcycle(h, p);  // fasp_precond_famg (PreCSR.c:560) / fasp_precond_amg
         if (st < 0) return st;
     }
     materialise_zero(D0);
@@ -3585,6 +3657,7 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
         std::printf("### WARNING: Max number of iterations must be POSITIVE! [%s:%d]\n", "ITS_CHECK", 78);
 
     h->ev_used = 0;
+    h->use_fmg = itparam->precond_type == PREC_FMG;   // SolCSR.c:537-538
     const long long ci0 = h->coarse_iters, vc0 = h->vcycles;
     Hist   H{hist, hist_cap, 0};
     PcgOut po{BIGREAL, BIGREAL, BIGREAL};
@@ -3721,6 +3794,45 @@ int fasp_solver_amg(dCSRmat* A, dvector* b, dvector* x, AMG_param* param)
     if (st < 0) return st;
     st = fasp_hip_amg_solve(h, b, x, param, nullptr, 0, nullptr);
     if (param->print_level > PRINT_NONE) std::printf("AMG totally costs %.4f seconds.\n", wall_seconds() - t0);
+    fasp_hip_amg_destroy(h);
+    return st;
+}
+
+// SolFAMG.c:41 -> fasp_famg_solve (PreMGSolve.c:300): ONE full-multigrid cycle as the solver; x is the
+// initial guess of the finest level and receives the result.  void in the reference; the status is an extension.
+int fasp_solver_famg(const dCSRmat* A, const dvector* b, dvector* x, AMG_param* param)
+{
+    if (!A || !b || !x || !param) return ERROR_INPUT_PAR;
+    const double t0 = wall_seconds();
+    int st = check_supported(nullptr, param);
+    if (st < 0) return st;
+    fasp_hip_amg* h = nullptr;
+    g_oneshot_upload = std::getenv("FASP_HIP_ONESHOT_CODING") == nullptr;
+    st = fasp_hip_amg_create(&h, A, param);
+    g_oneshot_upload = false;
+    if (st < 0) return st;
+    if ((st = fasp_hip_set_rhs(h, b)) >= 0 && (st = fasp_hip_set_guess(h, x)) >= 0) {
+        DevLevel& D0 = h->L[0];
+        const int m = D0.A.row;
+        double red[2];
+        D0.b = h->b;
+        (void)hipMemcpyAsync(D0.x, h->u, sizeof(double) * m, hipMemcpyDeviceToDevice, g_ctx.stream);
+        D0.x_zero = false;
+        st = d_dot(m, h->b, h->b, red, false) < 0 ? ERROR_MISC : FASP_SUCCESS;
+        const double sumb = std::sqrt(red[0]);
+        if (st >= 0 && sumb <= SMALLREAL) (void)hipMemsetAsync(D0.x, 0, sizeof(double) * m, g_ctx.stream);
+        if (st >= 0) st = fmg_cycle(h, *param);
+        if (st >= 0) {
+            d_resid(D0.A, D0.x, D0.b, D0.w);
+            if (d_dot(m, D0.w, D0.w, red, false) < 0) st = ERROR_MISC;
+            else if (param->print_level > PRINT_NONE)
+                std::printf("FMG finishes with relative residual %e.\n", std::sqrt(red[0]) / std::max(SMALLREAL, sumb));
+            (void)hipMemcpyAsync(h->u, D0.x, sizeof(double) * m, hipMemcpyDeviceToDevice, g_ctx.stream);
+            const int st2 = fasp_hip_get_solution(h, x);
+            if (st2 < 0) st = st2;
+        }
+    }
+    if (param->print_level > PRINT_NONE) std::printf("FAMG totally costs %.4f seconds.\n", wall_seconds() - t0);
     fasp_hip_amg_destroy(h);
     return st;
 }

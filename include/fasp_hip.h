@@ -425,6 +425,10 @@ int fasp_hip_device_synchronize(void);
  * Returns the cycle count or a negative ERROR_* code (a failed setup returns its code; the
  * reference's CPU GMRES fallback does not exist here). */
 int fasp_solver_amg(dCSRmat* A, dvector* b, dvector* x, AMG_param* param);
+/* One full-multigrid cycle as the solver -- replaces base/src/SolFAMG.c:41 (void there; the status is an
+ * extension).  x: initial guess in, result out.  itparam->precond_type = PREC_FMG selects the same cycle as
+ * the preconditioner of fasp_solver_dcsr_krylov_amg (SolCSR.c:537). */
+int fasp_solver_famg(const dCSRmat* A, const dvector* b, dvector* x, AMG_param* param);
 /* the same iteration on a resident hierarchy; param == NULL: the parameters of the setup */
 int fasp_hip_amg_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const AMG_param* param,
                        double* hist, int hist_cap, fasp_hip_stats* stats);

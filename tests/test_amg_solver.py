@@ -138,3 +138,34 @@ def test_gpu_amg_solver_tutorial_case():
     for i in range(len(ia) - 1):
         r[i] -= np.dot(a[ia[i]:ia[i + 1]], x[ja[ia[i]:ia[i + 1]]])
     assert "%.5e" % (np.linalg.norm(r) / np.linalg.norm(f)) == "8.82079e-07"
+
+
+def _famg(lib_, ia, ja, a, f, p, x0=None):
+    A, keep = T.as_csr(ia, ja, a)
+    x = np.zeros(len(f)) if x0 is None else x0.copy()
+    bv, fk = T.as_vec(f); xv = T.dvector(len(f), T.dp(x))
+    fn = lib_.fasp_solver_famg
+    fn.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(T.dvector), C.POINTER(T.dvector), C.POINTER(T.AMG_param)]
+    fn(C.byref(A), C.byref(bv), C.byref(xv), C.byref(p))
+    return x
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("n", [12, 24])
+def test_gpu_famg_solver_matches_reference(n):
+    """fasp_solver_famg (SolFAMG.c:41): one full-multigrid cycle from a non-zero guess, against the compiled reference."""
+    import faspsolver_amd as fa
+    from _libs import ref
+    ia, ja, a, f, ue = poisson7pt(n)
+    x0 = np.cos(np.arange(len(f)) * 0.05) * 1e-3
+    x1 = _famg(ref(), ia, ja, a, f, params(jac), x0)
+    x2 = _famg(fa.lib(), ia, ja, a, f, params(jac), x0)
+    assert np.abs(x1 - x2).max() <= 1e-10 * np.abs(x1).max()
+    A, keep = T.as_csr(ia, ja, a)
+    assert np.linalg.norm(f - _matvec(ia, ja, a, x2)) <= 0.2 * np.linalg.norm(f)   # one cycle: a solver step, not a solve
+
+
+def _matvec(ia, ja, a, x):
+    import scipy.sparse as sp
+    return sp.csr_matrix((a, ja, ia), shape=(len(x), len(x))) @ x

@@ -190,17 +190,25 @@ def _namli_ua(itp, amgp):
     _jac(itp, amgp); amgp.cycle_type = T.NL_AMLI_CYCLE; amgp.AMG_type = T.UA_AMG
 
 
+def _fmg(itp, amgp):   # full multigrid as the preconditioner (PreMGCycleFull.c:47, SolCSR.c:537)
+    _jac(itp, amgp); itp.precond_type = T.PREC_FMG
+
+
+def _fmg_gs_cs(itp, amgp):
+    itp.tol = 1e-8; itp.precond_type = T.PREC_FMG; amgp.coarse_scaling = 1
+
+
 def _jacf23(itp, amgp):
     itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_JACOBIF; amgp.presmooth_iter = 2; amgp.postsmooth_iter = 3
 
 
 @pytest.mark.parametrize("n", [8, 16, 32, 48])
 @pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22, _jac_cs, _poly3, _poly5w, _poly1, _jacf, _jacf23, _stdint,
-                                 _amli1, _amli2cs, _amli3gs, _namli_gcg, _namli_gcr_gs, _namli_ua],
+                                 _amli1, _amli2cs, _amli3gs, _namli_gcg, _namli_gcr_gs, _namli_ua, _fmg, _fmg_gs_cs],
                          ids=["jacobi-V", "jacobi-W", "l1diag-V", "jacobi-V22", "jacobi-V-coarse-scaling",
                               "poly3-V", "poly5-W", "poly1-V", "jacobiF-V", "jacobiF-V23", "jacobi-V-std-interp",
                               "jacobi-AMLI1", "jacobi-AMLI2-coarse-scaling", "gs-AMLI3",
-                              "jacobi-Kcycle-GCG", "gs-Kcycle-GCR", "jacobi-Kcycle-UA-pairwise"])
+                              "jacobi-Kcycle-GCG", "gs-Kcycle-GCR", "jacobi-Kcycle-UA-pairwise", "jacobi-FMG", "gs-FMG-coarse-scaling"])
 def test_pcg_history_poisson(gpu, n, mod):
     if n == 48 and mod is not _jac:
         pytest.skip("largest size only for the headline configuration")

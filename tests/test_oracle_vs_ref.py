@@ -57,11 +57,14 @@ def _mods():
     def namli_gcr_gs(i, a): i.tol = 1e-8; a.cycle_type = T.NL_AMLI_CYCLE; a.nl_amli_krylov_type = 8
     def namli_ua(i, a): jac(i, a); a.cycle_type = T.NL_AMLI_CYCLE; a.AMG_type = T.UA_AMG   # pairwise aggregation + K-cycle: Notay's method
     def namli_sa_vfg(i, a): vfg(i, a); a.cycle_type = T.NL_AMLI_CYCLE; a.AMG_type = T.SA_AMG
+    def fmg(i, a): jac(i, a); i.precond_type = T.PREC_FMG
+    def fmg_gs_cs(i, a): i.tol = 1e-8; i.precond_type = T.PREC_FMG; a.coarse_scaling = 1
+    def fmg_sa_vfg(i, a): vfg(i, a); i.precond_type = T.PREC_FMG; a.AMG_type = T.SA_AMG
     def vgpre(i, a): vg(i, a); i.stop_type = T.STOP_REL_PRECRES
     def vfgmod(i, a): vfg(i, a); i.stop_type = T.STOP_MOD_REL_RES
     return dict(jac=jac, jacw=jacw, vw=vw, l1=l1, gscf=gscf, gsn=gsn, sor=sor, ssor=ssor, sgs=sgs,
                 theta=theta, precres=precres, modres=modres, gsor=gsor, sgsor=sgsor, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
-                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w, amli1=amli1, amli2gs=amli2gs, amli2cs=amli2cs, amli0=amli0, amli3vg=amli3vg, namli_gcg=namli_gcg, namli_gcr_gs=namli_gcr_gs, namli_ua=namli_ua, namli_sa_vfg=namli_sa_vfg)
+                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w, amli1=amli1, amli2gs=amli2gs, amli2cs=amli2cs, amli0=amli0, amli3vg=amli3vg, namli_gcg=namli_gcg, namli_gcr_gs=namli_gcr_gs, namli_ua=namli_ua, namli_sa_vfg=namli_sa_vfg, fmg=fmg, fmg_gs_cs=fmg_gs_cs, fmg_sa_vfg=fmg_sa_vfg)
 
 
 @pytest.mark.parametrize("name", list(_mods().keys()))
