@@ -1103,9 +1103,12 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             case SMOOTHER_GS: case SMOOTHER_SGS: case SMOOTHER_SOR: case SMOOTHER_SSOR:
             case SMOOTHER_GSOR: case SMOOTHER_SGSOR:     // sequential sweeps: level-scheduled
                 break;
+            case SMOOTHER_CG:                             // `nsweeps` steps of CG on the level's system
+                break;
+            case SMOOTHER_GSF:                            // Gauss-Seidel on the F points: needs the C/F marker
             case SMOOTHER_JACOBIF:                        // Jacobi on the F points: needs the C/F marker
                 if (amg->AMG_type == CLASSIC_AMG) break;
-                std::printf("### ERROR: fasp_hip: the F-point Jacobi smoother needs a classical (C/F) hierarchy\n");
+                std::printf("### ERROR: fasp_hip: the F-point smoothers need a classical (C/F) hierarchy\n");
                 return ERROR_AMG_SMOOTH_TYPE;
             default:
                 std::printf("### ERROR: fasp_hip: smoother %d has no device path\n", amg->smoother);

@@ -1022,6 +1022,8 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
 // Rr (:551) -- ndeg SpMVs and elementwise steps -- and u += correction.  Order independent, so the
 // level may be row-partitioned (every SpMV input gets its halo).  Dinv and the coefficients depend
 // on the matrix only: formed once per level on the host exactly as the reference does per call.
+static int cg_smooth(fasp_hip_amg* h, int level, int nsweeps);  // defined after the Krylov drivers
+
 static int poly_smooth(fasp_hip_amg* h, int level, int ndeg, int nsweeps)
 {
     DevLevel& D = h->L[level];
@@ -1131,7 +1133,16 @@ static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order
         return FASP_SUCCESS;
     }
     if (!D.replicated) return ERROR_AMG_SMOOTH_TYPE;  // sequential sweeps are not distributed
+    if (smoother == SMOOTHER_CG) return cg_smooth(h, level, nsweeps);
     const bool has_cf = h->H.L[level].cfmark.n == (size_t)n;
+    if (smoother == SMOOTHER_GSF) {  // fasp_smoother_dcsr_gs_ff (ItrSmootherCSR.c:700): GS over the non-C rows, ascending, before and after
+        if (!has_cf) {
+            std::printf("### ERROR: fasp_hip: the F-point Gauss-Seidel smoother needs the C/F marker of a classical hierarchy\n");
+            return ERROR_AMG_SMOOTH_TYPE;
+        }
+        for (int sw = 0; sw < nsweeps; ++sw) { const int st = seq_sweep(h, level, 3, 1, 0.0); if (st < 0) return st; }
+        return FASP_SUCCESS;
+    }
     auto rep = [&](int kind, int form, double w) -> int {  // nsweeps repetitions, as the `while (L--)` loops
         for (int s = 0; s < nsweeps; ++s) { const int st = seq_sweep(h, level, kind, form, w); if (st < 0) return st; }
         return FASP_SUCCESS;
@@ -3136,6 +3147,23 @@ FINISHED:
     HIPCK(hipStreamSynchronize(s));
     if (iter > MaxIt) return ERROR_SOLVER_MAXIT;
     return iter;
+}
+
+// CG as a smoother: fasp_solver_dcsr_pcg(A, b, x, NULL, 1e-3, 1e-15, nsweeps, STOP_REL_RES, PRINT_NONE),
+// PreMGSmoother.inl:116 / :222 -- `nsweeps` CG steps on the level's system; its return code (normally
+// "MaxIt reached") is ignored there too
+static int cg_smooth(fasp_hip_amg* h, int level, int nsweeps)
+{
+    DevLevel& D = h->L[level];
+    for (int q = 0; q < 3; ++q) if (!D.kw[q]) { if (alloc_vec(&D.kw[q], (size_t)D.nvec) < 0) return ERROR_ALLOC_MEM; }
+    materialise_zero(D);
+    KOps K = csr_ops(h, level, false);
+    K.stats = nullptr;
+    PcgVecs V{D.b, D.x, D.kw[0], D.kw[1], D.kw[2]};
+    Hist H{nullptr, 0, 0};
+    PcgOut po{BIGREAL, BIGREAL, BIGREAL};
+    const int st = pcg_device(K, V, 1e-3, 1e-15, nsweeps, STOP_REL_RES, PRINT_NONE, H, po);
+    return (st == ERROR_MISC || st == ERROR_ALLOC_MEM) ? st : FASP_SUCCESS;
 }
 
 }  // namespace fasp

@@ -90,6 +90,7 @@ void orc_smoother_sor(double* u, int i_1, int i_n, int s, const dCSRmat* A,
                       const double* b, int L, double w);                       /* :932 */
 void orc_smoother_l1diag(double* u, int i_1, int i_n, int s, const dCSRmat* A,
                          const double* b, int L);                              /* :1509 */
+void orc_smoother_gs_ff(double* u, const dCSRmat* A, const double* b, int L, const int* mark); /* GS on the non-C rows */
 void orc_smoother_jacobi_ff(double* x, const dCSRmat* A, const double* b, int nsweeps,
                             const int* ordering, double relax);                /* :34 */
 void orc_smoother_poly(const dCSRmat* A, const double* b, double* u, int n, int ndeg,

@@ -59,7 +59,7 @@ def test_unsupported_parameters_are_refused_before_any_work(fa):
     ia, ja, a, f, ue = poisson7pt(5)
     x = np.zeros(len(f))
     cases = []
-    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = 4   # SMOOTHER_CG: not on the path
+    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = 21   # SMOOTHER_BLKOIL: an application-specific smoother
     cases.append((it, am, T.ERROR_AMG_SMOOTH_TYPE))
     it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.AMG_type = T.UA_AMG; am.aggregation_type = 3  # NPAIR: unfinished in the reference
     cases.append((it, am, T.ERROR_INPUT_PAR))

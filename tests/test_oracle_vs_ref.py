@@ -60,11 +60,14 @@ def _mods():
     def fmg(i, a): jac(i, a); i.precond_type = T.PREC_FMG
     def fmg_gs_cs(i, a): i.tol = 1e-8; i.precond_type = T.PREC_FMG; a.coarse_scaling = 1
     def fmg_sa_vfg(i, a): vfg(i, a); i.precond_type = T.PREC_FMG; a.AMG_type = T.SA_AMG
+    def gsf2w(i, a): i.tol = 1e-8; a.smoother = 12; a.presmooth_iter = 2; a.postsmooth_iter = 2; a.cycle_type = T.W_CYCLE   # SMOOTHER_GSF
+    def cgsm1(i, a): vfg(i, a); a.smoother = 4          # SMOOTHER_CG: a nonlinear preconditioner, hence flexible GMRES
+    def cgsm3(i, a): vfg(i, a); a.smoother = 4; a.presmooth_iter = 3; a.postsmooth_iter = 3
     def vgpre(i, a): vg(i, a); i.stop_type = T.STOP_REL_PRECRES
     def vfgmod(i, a): vfg(i, a); i.stop_type = T.STOP_MOD_REL_RES
     return dict(jac=jac, jacw=jacw, vw=vw, l1=l1, gscf=gscf, gsn=gsn, sor=sor, ssor=ssor, sgs=sgs,
                 theta=theta, precres=precres, modres=modres, gsor=gsor, sgsor=sgsor, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
-                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w, amli1=amli1, amli2gs=amli2gs, amli2cs=amli2cs, amli0=amli0, amli3vg=amli3vg, namli_gcg=namli_gcg, namli_gcr_gs=namli_gcr_gs, namli_ua=namli_ua, namli_sa_vfg=namli_sa_vfg, fmg=fmg, fmg_gs_cs=fmg_gs_cs, fmg_sa_vfg=fmg_sa_vfg)
+                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w, amli1=amli1, amli2gs=amli2gs, amli2cs=amli2cs, amli0=amli0, amli3vg=amli3vg, namli_gcg=namli_gcg, namli_gcr_gs=namli_gcr_gs, namli_ua=namli_ua, namli_sa_vfg=namli_sa_vfg, fmg=fmg, fmg_gs_cs=fmg_gs_cs, fmg_sa_vfg=fmg_sa_vfg, gsf2w=gsf2w, cgsm1=cgsm1, cgsm3=cgsm3)
 
 
 @pytest.mark.parametrize("name", list(_mods().keys()))
