@@ -117,9 +117,10 @@ def _cmp_solve(gpu, ia, ja, a, f, mod, rtol_hist=1e-8):
     s, x, h, stats = H.solve(f, itp2)
     H.close()
     assert s == s_ref, (s, s_ref)
-    assert len(h) == len(h_ref)
-    # entries at the rounding floor (||r_k|| ~ 1e-15 ||r_0||) carry no digits: absolute floor
-    assert np.allclose(h, h_ref, rtol=rtol_hist, atol=1e-12 * h_ref[0]), np.max(np.abs(h - h_ref) / h_ref)
+    if len(h_ref):   # the oracle records the residual history of CG only
+        assert len(h) == len(h_ref)
+        # entries at the rounding floor (||r_k|| ~ 1e-15 ||r_0||) carry no digits: absolute floor
+        assert np.allclose(h, h_ref, rtol=rtol_hist, atol=1e-12 * h_ref[0]), np.max(np.abs(h - h_ref) / h_ref)
     assert abs(stats.relres - rr_ref) <= 1e-10
     assert np.max(np.abs(x - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
     return stats
