@@ -1,0 +1,180 @@
+// coarse_cg.hip.h -- coarsest level: safe CG (single-workgroup kernel or batched device-resident iteration).
+// Part of the single translation unit solver.hip (included there, in this order; not a stand-alone header).
+
+// ---------------------------------------------------------------------------
+// coarsest level: safe-net CG without preconditioner (KrySPcg.c:60, called from
+// PreMGUtil.inl:47 with StopType = STOP_REL_RES, maxit = MAX(250, MIN(n*n, 1000))).
+// One host synchronisation per iteration: alpha is formed on the device.
+// ---------------------------------------------------------------------------
+// Coarsest levels that fit one CU's caches are solved by the single-workgroup kernels of
+// small_solvers.hip.h (one launch, one synchronisation per solve instead of per iteration).
+static bool small_coarse_ok(long long rows, long long stored_values)
+{
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = std::getenv("FASP_HIP_SMALL_COARSE");
+        enabled = (e && std::atoi(e) == 0) ? 0 : 1;
+    }
+    return enabled && rows <= 4096 && stored_values <= 131072;
+}
+static SmallOut* small_out_dev() { return reinterpret_cast<SmallOut*>(g_ctx.d_partials2); }
+static int small_out_fetch(SmallOut& o)
+{
+    HIPCK(hipMemcpyAsync(g_ctx.h_part, g_ctx.d_partials2, sizeof(SmallOut), hipMemcpyDeviceToHost, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    std::memcpy(&o, g_ctx.h_part, sizeof(SmallOut));
+    return 0;
+}
+
+static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
+{
+    const DevCSR& A = D.A;
+    const int m = A.row;
+    const int nn = (int)((unsigned)m * (unsigned)m);
+    const int MaxIt = std::max(250, std::min(nn, 1000));
+    if (small_coarse_ok(m, A.nnz)) {
+        SpcgArgs a{};
+        a.A = SmallCSR{m, A.ia, A.ja, A.val};
+        a.b = D.b; a.u = D.x; a.p = h->cp; a.r = h->cr; a.t = h->ct; a.u_best = h->cbest;
+        a.tol = tol; a.MaxIt = MaxIt; a.x_zero = D.x_zero ? 1 : 0; a.out = small_out_dev(); a.nnz = A.nnz;
+        // everything in LDS when it fits: vectors 5 m doubles, matrix 12 nnz + 4 (m + 1) bytes
+        const size_t lds_v = sizeof(double) * 5 * (size_t)m;
+        const size_t lds_m = 12 * (size_t)A.nnz + 4 * ((size_t)m + 1);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)k_spcg_small<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_spcg_small<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr = true;
+        }
+        if (g_tune.small_lds && lds_v + lds_m <= 148 * 1024)
+            hipLaunchKernelGGL((k_spcg_small<true, true>), dim3(1), dim3(SMALL_BLOCK), lds_v + lds_m, g_ctx.stream, a);
+        else if (g_tune.small_lds && lds_v <= 148 * 1024)
+            hipLaunchKernelGGL((k_spcg_small<true, false>), dim3(1), dim3(SMALL_BLOCK), lds_v, g_ctx.stream, a);
+        else
+            hipLaunchKernelGGL((k_spcg_small<false, false>), dim3(1), dim3(SMALL_BLOCK), 0, g_ctx.stream, a);
+        D.x_zero = false;
+        SmallOut o;
+        if (small_out_fetch(o) < 0) return ERROR_MISC;
+        h->coarse_iters += o.iters;
+        if (std::getenv("FASP_HIP_DEBUG_COARSE")) std::printf("[coarse small] status %d iters %d relres %.6e\n", o.status, o.iters, o.relres);
+        return o.status;
+    }
+    const double maxdiff = tol * STAG_RATIO;
+    int iter = 0, stag = 1, more_step = 1, iter_best = 0;
+    double absres0 = BIGREAL, absres = BIGREAL, relres = BIGREAL, normu = BIGREAL, normr0 = BIGREAL;
+    double reldiff, factor, alpha = 0.0, beta, temp1, temp2, absres_best = BIGREAL;
+    double *p = h->cp, *r = h->cr, *t = h->ct, *u_best = h->cbest, *u = D.x;
+    const double* b = D.b;
+    double red[8];
+    hipStream_t s = g_ctx.stream;
+    (void)prtlvl;
+
+    // u_best starts as zeros (calloc'ed work array, KrySPcg.c:88)
+    HIPCK(hipMemsetAsync(u_best, 0, sizeof(double) * m, s));
+
+    // r = b - A u  (u == 0 on entry from the cycle: r = b, no matrix pass)
+    if (D.x_zero) {
+        HIPCK(hipMemcpyAsync(r, b, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+        HIPCK(hipMemsetAsync(u, 0, sizeof(double) * m, s));
+        D.x_zero = false;
+    } else {
+        d_resid(A, u, b, r);
+    }
+    if (d_dot(m, r, r, red) < 0) return ERROR_MISC;  // z = r: (r,r) serves both ||r|| and (z,r)
+    absres0 = std::sqrt(red[0]);
+    normr0  = std::max(SMALLREAL, absres0);
+    relres  = absres0 / normr0;
+    if (relres < tol) goto FINISHED;
+    HIPCK(hipMemcpyAsync(p, r, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    temp1 = red[0];
+
+    {
+        // Device-resident iteration state; the host queues `batch` iterations (SpMV + step kernel
+        // each) without waiting and synchronises once per batch.  When one of the reference's
+        // tests fires, k_spcg_step raises `stop`, the launches queued behind it return at once,
+        // and the branch is replayed here from the recorded scalars (KrySPcg.c:172-330).
+        const int batch = std::max(1, std::min(g_tune.spcg_batch, 64));
+        if (!h->spcg_state) HIPCK(hipMalloc(&h->spcg_state, sizeof(SpcgState)));
+        SpcgState S{};
+        S.temp1 = temp1; S.temp1_prev = temp1; S.absres_best = absres_best; S.normr0 = normr0; S.tol = tol;
+        S.maxdiff = maxdiff; S.iter = 0; S.iter_best = 0; S.stag = stag; S.MaxIt = MaxIt; S.stop = SPCG_RUN;
+        S.absres = absres; S.relres = relres; S.alpha = 0.0;  // values before the first iteration
+        HIPCK(hipMemcpyAsync(h->spcg_state, &S, sizeof(S), hipMemcpyHostToDevice, s));
+        for (;;) {
+            for (int q = 0; q < batch; ++q) {
+                CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials; a.stop = &h->spcg_state->stop;
+                SpcgStepArgs sa{};
+                sa.m = m; sa.st = h->spcg_state; sa.t = t; sa.p = p; sa.u = u; sa.r = r; sa.u_best = u_best;
+                sa.ntp = launch_csr<OP_MXV_DOT>(A, a);
+                sa.tp_partials = g_ctx.d_partials;
+                if (m <= 512 * 4) hipLaunchKernelGGL(k_spcg_step_reg<4>, dim3(1), dim3(512), 0, s, sa);
+                else if (m <= 512 * 10) hipLaunchKernelGGL(k_spcg_step_reg<10>, dim3(1), dim3(512), 0, s, sa);
+                else hipLaunchKernelGGL(k_spcg_step, dim3(1), dim3(SMALL_BLOCK), 0, s, sa);
+            }
+            HIPCK(hipMemcpyAsync(g_ctx.h_part, h->spcg_state, sizeof(SpcgState), hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            std::memcpy(&S, g_ctx.h_part, sizeof(S));
+            iter = S.iter; absres_best = S.absres_best; iter_best = S.iter_best;
+            if (S.stop == SPCG_RUN) continue;
+            // a test fired in iteration S.iter: finish that iteration as the reference does
+            temp2 = S.tp; temp1 = S.temp1_prev;
+            red[0] = S.rr; red[1] = S.uu; red[2] = S.pp; red[3] = S.maxu; red[4] = S.nan;
+            // (on a breakdown the step kernel leaves absres / relres of the PREVIOUS iteration in the state,
+            // which is what the reference's variables hold when it jumps to RESTORE_BESTSOL, KrySPcg.c:176)
+            alpha = S.alpha; absres = S.absres; relres = S.relres;
+            if (S.stop == SPCG_DIV0) goto RESTORE_BESTSOL;
+            factor = absres / absres0; (void)factor; (void)alpha;
+            if (S.stop == SPCG_NAN) { absres = BIGREAL; goto RESTORE_BESTSOL; }
+            if (S.stop == SPCG_SOLSTAG) { iter = ERROR_SOLVER_SOLSTAG; break; }  // Check I
+            if (S.stop == SPCG_MAXIT) { iter = MaxIt + 1; break; }
+            normu = std::sqrt(red[1]);
+            reldiff = std::fabs(S.alpha) * std::sqrt(red[2]) / normu;
+            if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {  // Check II
+                d_resid(A, u, b, r);
+                if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+                absres = std::sqrt(red[0]);
+                relres = absres / normr0;
+                if (relres < tol) break;
+                if (stag >= MAX_STAG) { iter = ERROR_SOLVER_STAG; break; }
+                HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
+                ++stag;
+            }
+            if (relres < tol) {  // Check III: true residual
+                d_resid(A, u, b, r);
+                if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+                absres = std::sqrt(red[0]);
+                relres = absres / normr0;
+                if (relres < tol) break;
+                if (more_step >= MAX_RESTART) { iter = ERROR_SOLVER_TOLSMALL; break; }
+                HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
+                ++more_step;
+            }
+            // every branch that gets here restarted: p was zeroed, so p = z + beta p = r
+            absres0 = absres;
+            temp2 = red[0];
+            beta = temp2 / temp1;
+            temp1 = temp2;
+            d_axpby(m, 1.0, r, beta, p);
+            S.temp1 = temp1; S.temp1_prev = temp1; S.stag = stag; S.stop = SPCG_RUN;
+            HIPCK(hipMemcpyAsync(h->spcg_state, &S, sizeof(S), hipMemcpyHostToDevice, s));
+            HIPCK(hipStreamSynchronize(s));  // S lives on this stack frame
+        }
+    }
+
+RESTORE_BESTSOL:
+    if (iter != iter_best) {
+        d_resid(A, u_best, b, r);
+        if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+        absres_best = std::sqrt(red[0]);
+        if (absres > absres_best + maxdiff || std::isnan(absres)) {
+            HIPCK(hipMemcpyAsync(u, u_best, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+            relres = absres_best / normr0;
+        }
+    }
+FINISHED:
+    if (std::getenv("FASP_HIP_DEBUG_COARSE")) std::printf("[coarse batched] iter %d relres %.6e absres %.6e best %d\n", iter, relres, absres, iter_best);
+    if (iter > 0) h->coarse_iters += iter;
+    if (iter > MaxIt) return ERROR_SOLVER_MAXIT;
+    return iter;
+}
+

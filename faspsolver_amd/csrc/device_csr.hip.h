@@ -1,0 +1,586 @@
+// device_csr.hip.h -- device matrices: CSR in HBM, lossless coding at upload, kernel selection and launch, BLAS-1 wrappers.
+// Part of the single translation unit solver.hip (included there, in this order; not a stand-alone header).
+
+// ---------------------------------------------------------------------------
+// device matrices
+// ---------------------------------------------------------------------------
+struct DevCSR {
+    int     row = 0, col = 0, nnz = 0;
+    int*    ia  = nullptr;
+    int*    ja  = nullptr;
+    double* val = nullptr;
+    int*    dpos = nullptr;  // storage index of the last diagonal entry per row (-1: none); A matrices only
+    bool    dup_diag = false;  // some row stores its diagonal more than once
+    bool    sorted = false;    // device copy has every row sorted by column (long-row operators)
+    int     lanes = 8;       // vector kernel: lanes cooperating on one row
+    int     kind = 0;        // 0 vector, 1 block-level stream, 2 wave-level stream
+    int     tile_rows = 256; // block stream kernel: rows per block tile
+    int     wrows = 64, wcap = 512;  // wave stream kernel: rows per wave tile, LDS products per wave
+    // dictionary coding (k_csr_dict8): present when the matrix has <= 256 distinct (offset, value) pairs
+    unsigned char* code = nullptr;
+    int*    rowbase = nullptr;  // nullptr: column offsets are relative to the row index
+    int*    doff = nullptr;
+    double* dval = nullptr;
+    // row-pattern coding (k_csr_rowpat): present when the matrix has <= 65536 distinct rows
+    unsigned short* pat = nullptr;
+    int*    pstart = nullptr;
+    int*    plen = nullptr;
+    int*    poff = nullptr;
+    double* pval = nullptr;
+    int     npat = 0, npent = 0;
+    unsigned short* ja16 = nullptr;  // JA as 16-bit values (long-row operators with <= 65536 columns)
+    void    release()
+    {
+        if (ja16) (void)hipFree(ja16);
+        ja16 = nullptr;
+        if (ia) (void)hipFree(ia);
+        if (ja) (void)hipFree(ja);
+        if (val) (void)hipFree(val);
+        if (dpos) (void)hipFree(dpos);
+        if (code) (void)hipFree(code);
+        if (rowbase) (void)hipFree(rowbase);
+        if (doff) (void)hipFree(doff);
+        if (dval) (void)hipFree(dval);
+        if (pat) (void)hipFree(pat);
+        if (pstart) (void)hipFree(pstart);
+        if (plen) (void)hipFree(plen);
+        if (poff) (void)hipFree(poff);
+        if (pval) (void)hipFree(pval);
+        pat = nullptr; pstart = plen = poff = nullptr; pval = nullptr;
+        ia = ja = dpos = rowbase = doff = nullptr; val = dval = nullptr; code = nullptr;
+    }
+};
+
+// Kernel family per matrix, from its mean row length (measured on MI355X, P7(256)
+// hierarchy, profiles/r01_kernel_sweep.md):
+//   <= 48 nnz/row : wave-level stream kernel, 64 rows / 512 products per wave
+//   longer rows   : sub-wavefront-per-row vector kernel with ~avg/4 lanes per row
+static void pick_kernel(DevCSR& M)
+{
+    const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
+    static const double stream_max = std::getenv("FASP_HIP_STREAM_MAX") ? std::atof(std::getenv("FASP_HIP_STREAM_MAX")) : 48.0;
+    M.kind = avg <= stream_max ? 2 : 0;  // (kind 3, one workgroup per row, measured slower than L = 64: profiles/)
+    M.lanes = avg < 128.0 ? 16 : avg < 300.0 ? 32 : 64;
+    if (avg < 48.0) M.lanes = avg < 3.0 ? 2 : avg < 6.0 ? 4 : avg < 24.0 ? 8 : 16;  // short rows on the sub-wavefront kernel
+    // Small transfer operators (fewer 256-row tiles than the chip has block slots): the stream kernel's
+    // long per-tile chain is pure latency there; the sub-wavefront kernel spreads the rows over 8-32x
+    // more blocks (level-3 restriction of P7(256): 25 -> 10 us).  Square operators keep the stream
+    // kernel (its row sums follow the reference's order).
+    static const int small_rows = std::getenv("FASP_HIP_SMALL_XFER_ROWS") ? std::atoi(std::getenv("FASP_HIP_SMALL_XFER_ROWS")) : 256 * 1024;
+    if (M.kind == 2 && M.row != M.col && M.row < small_rows) M.kind = 0;
+    int R = 256;
+    while (R < STREAM_MAXR && R * 2 * avg <= 3072.0) R <<= 1;
+    M.tile_rows = R;
+    M.wrows = 64;
+    M.wcap  = 512;
+}
+
+// Lossless dictionary coding of a matrix with <= 256 distinct (column - base, value) pairs
+// (kernels.hip.h, k_csr_dict8).  base = row index for square matrices, first stored column of
+// the row otherwise.  Returns false (nothing allocated) when the matrix has more pairs.
+// One-shot callers (fasp_solver_dcsr_krylov_amg / fasp_solver_amg: one solve per setup) skip the
+// hashing / re-sorting of the device copies: at 256^3 it costs 3.7 s of host time and saves 0.04 s per solve.
+// Resident handles (fasp_hip_amg_create + many fasp_hip_solve) keep it.
+static bool g_oneshot_upload = false;
+static bool compress_enabled()
+{
+    if (g_oneshot_upload) return false;
+    static int en = -1;
+    if (en < 0) { const char* e = std::getenv("FASP_HIP_COMPRESS"); en = (e && std::atoi(e) == 0) ? 0 : 1; }
+    return en != 0;
+}
+struct PairKey { int off; unsigned long long bits; };
+static inline unsigned pair_hash(int off, unsigned long long bits)
+{
+    unsigned long long h = bits * 0x9E3779B97F4A7C15ull + (unsigned long long)(unsigned)off * 0xC2B2AE3D27D4EB4Full;
+    return (unsigned)(h >> 40);
+}
+static bool build_dict8(const HostCSR& M, std::vector<int>& doff, std::vector<double>& dval,
+                        Buf<unsigned char>& code, Buf<int>& rowbase)
+{
+    const bool square = M.row == M.col;
+    const int n = M.row;
+    if (n <= 0 || M.nnz <= 0) return false;
+    constexpr int SLOTS = 1024;
+    struct Table {
+        int      cnt = 0;
+        int      slot_id[SLOTS];
+        PairKey  keys[257];
+        Table() { for (int& s : slot_id) s = -1; }
+        // returns the id of the pair, inserting it; -1 when the table is full
+        int find_or_add(int off, unsigned long long bits, bool add)
+        {
+            unsigned h = pair_hash(off, bits) & (SLOTS - 1);
+            for (;;) {
+                const int id = slot_id[h];
+                if (id < 0) {
+                    if (!add || cnt >= 257) return -1;
+                    keys[cnt] = PairKey{off, bits};
+                    slot_id[h] = cnt;
+                    return cnt++;
+                }
+                if (keys[id].off == off && keys[id].bits == bits) return id;
+                h = (h + 1) & (SLOTS - 1);
+            }
+        }
+    };
+    auto base_of = [&](int r) { return square ? r : (M.ia[r] < M.ia[r + 1] ? M.ja[M.ia[r]] : 0); };
+    auto bits_of = [](double v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; };
+    // pass 1: distinct pairs (every thread scans its share, bails out beyond 256)
+    const int nt = omp_get_max_threads();
+    std::vector<Table> local((size_t)nt);
+    bool fail = false;
+#pragma omp parallel num_threads(nt)
+    {
+        Table& T = local[(size_t)omp_get_thread_num()];
+#pragma omp for schedule(static)
+        for (int r = 0; r < n; ++r) {
+            if (fail || T.cnt > 256) continue;
+            const int base = base_of(r);
+            for (int k = M.ia[r]; k < M.ia[r + 1]; ++k)
+                if (T.find_or_add(M.ja[k] - base, bits_of(M.val[k]), true) < 0 || T.cnt > 256) { fail = true; break; }
+        }
+    }
+    if (fail) return false;
+    std::vector<PairKey> all;
+    for (const Table& T : local) all.insert(all.end(), T.keys, T.keys + T.cnt);
+    std::sort(all.begin(), all.end(), [](const PairKey& x, const PairKey& y) {
+        return x.off != y.off ? x.off < y.off : x.bits < y.bits; });
+    all.erase(std::unique(all.begin(), all.end(), [](const PairKey& x, const PairKey& y) {
+        return x.off == y.off && x.bits == y.bits; }), all.end());
+    if (all.size() > 256) return false;
+    doff.assign(256, 0); dval.assign(256, 0.0);
+    Table G;
+    for (size_t i = 0; i < all.size(); ++i) {
+        G.find_or_add(all[i].off, all[i].bits, true);  // ids in sorted order: deterministic
+        doff[i] = all[i].off;
+        std::memcpy(&dval[i], &all[i].bits, 8);
+    }
+    // pass 2: codes
+    code.alloc((size_t)M.nnz);
+    if (!square) rowbase.alloc((size_t)n);
+#pragma omp parallel
+    {
+        Table T = G;
+#pragma omp for schedule(static)
+        for (int r = 0; r < n; ++r) {
+            const int base = base_of(r);
+            if (!square) rowbase[r] = base;
+            for (int k = M.ia[r]; k < M.ia[r + 1]; ++k)
+                code[k] = (unsigned char)T.find_or_add(M.ja[k] - base, bits_of(M.val[k]), false);
+        }
+    }
+    return true;
+}
+
+// Row-pattern coding (kernels.hip.h, k_csr_rowpat): every row is replaced by the id of its
+// (column - base, value) list when the matrix has at most 65 536 distinct lists with at most
+// 1 M entries in total.  Lossless; ids are numbered by first occurrence, so the coding is
+// deterministic.  Returns false when the matrix does not qualify (or on a hash collision).
+static bool build_rowpat(const HostCSR& M, Buf<unsigned short>& pat, std::vector<int>& pstart, std::vector<int>& plen,
+                         std::vector<int>& poff, std::vector<double>& pval, Buf<int>& rowbase)
+{
+    const bool square = M.row == M.col;
+    const int n = M.row;
+    if (n <= 0 || M.nnz <= 0) return false;
+    constexpr int MAXPAT = 65536, MAXENT = 1 << 20;
+    auto base_of = [&](int r) { return square ? r : (M.ia[r] < M.ia[r + 1] ? M.ja[M.ia[r]] : 0); };
+    auto bits_of = [](double v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; };
+    auto row_hash = [&](int r) {
+        unsigned long long h = 0x9FB21C651E98DF25ull * (unsigned long long)(M.ia[r + 1] - M.ia[r] + 1);
+        const int base = base_of(r);
+        for (int k = M.ia[r]; k < M.ia[r + 1]; ++k) {
+            h ^= (unsigned long long)(unsigned)(M.ja[k] - base) * 0x9E3779B97F4A7C15ull + bits_of(M.val[k]) * 0xC2B2AE3D27D4EB4Full;
+            h = (h << 23 | h >> 41) * 0xD6E8FEB86659FD93ull;
+        }
+        return h ? h : 1ull;
+    };
+    auto same_row = [&](int r, int q) {  // identical (offset, value) lists
+        const int len = M.ia[r + 1] - M.ia[r];
+        if (len != M.ia[q + 1] - M.ia[q]) return false;
+        const int br = base_of(r), bq = base_of(q);
+        for (int j = 0; j < len; ++j) {
+            if (M.ja[M.ia[r] + j] - br != M.ja[M.ia[q] + j] - bq) return false;
+            if (bits_of(M.val[M.ia[r] + j]) != bits_of(M.val[M.ia[q] + j])) return false;
+        }
+        return true;
+    };
+    // pass 1: hash of every row; per-thread sets of (hash -> first row), bounded
+    Buf<unsigned long long> rh((size_t)n);
+    const int nt = omp_get_max_threads();
+    constexpr int SLOTS = 1 << 18;  // open addressing, <= 25 % load
+    struct Set {
+        std::vector<unsigned long long> key;
+        std::vector<int> first;
+        int cnt = 0;
+        Set() : key(SLOTS, 0ull), first(SLOTS, -1) {}
+        bool add(unsigned long long h, int r)
+        {
+            unsigned s = (unsigned)(h >> 20) & (SLOTS - 1);
+            for (;;) {
+                if (key[s] == 0ull) { key[s] = h; first[s] = r; ++cnt; return true; }
+                if (key[s] == h) { if (r < first[s]) first[s] = r; return true; }
+                s = (s + 1) & (SLOTS - 1);
+            }
+        }
+        int find(unsigned long long h) const
+        {
+            unsigned s = (unsigned)(h >> 20) & (SLOTS - 1);
+            for (;;) {
+                if (key[s] == 0ull) return -1;
+                if (key[s] == h) return first[s];
+                s = (s + 1) & (SLOTS - 1);
+            }
+        }
+    };
+    std::vector<Set*> local((size_t)nt, nullptr);
+    bool fail = false;
+#pragma omp parallel num_threads(nt)
+    {
+        Set* S = new Set();
+        local[(size_t)omp_get_thread_num()] = S;
+#pragma omp for schedule(static)
+        for (int r = 0; r < n; ++r) {
+            const unsigned long long h = row_hash(r);
+            rh[r] = h;
+            if (fail) continue;
+            S->add(h, r);
+            if (S->cnt > MAXPAT) fail = true;
+        }
+    }
+    Set* Gs = nullptr;
+    std::vector<std::pair<int, unsigned long long>> reps;  // (first row, hash)
+    if (!fail) {
+        Gs = new Set();
+        for (Set* S : local)
+            if (S)
+                for (int s = 0; s < SLOTS && !fail; ++s)
+                    if (S->key[s]) { Gs->add(S->key[s], S->first[s]); if (Gs->cnt > MAXPAT) fail = true; }
+    }
+    for (Set* S : local) delete S;
+    if (fail) { delete Gs; return false; }
+    for (int s = 0; s < SLOTS; ++s)
+        if (Gs->key[s]) reps.emplace_back(Gs->first[s], Gs->key[s]);
+    std::sort(reps.begin(), reps.end());
+    long long tot = 0;
+    for (auto& q : reps) tot += (M.ia[q.first + 1] - M.ia[q.first] + 7) / 8 * 8;
+    // worth it only when rows really repeat: >= 8 rows per pattern and a table << the matrix
+    if (tot > MAXENT || (long long)reps.size() * 8 > n || tot * 4 > M.nnz) { delete Gs; return false; }
+    // pattern table; the set now maps hash -> pattern id
+    pstart.assign(reps.size(), 0); plen.assign(reps.size(), 0);
+    poff.clear(); pval.clear();
+    for (size_t i = 0; i < reps.size(); ++i) {  // lists padded to multiples of 8 entries with (offset 0, value 0)
+        const int r = reps[i].first, base = base_of(r);
+        pstart[i] = (int)poff.size();
+        plen[i] = M.ia[r + 1] - M.ia[r];
+        for (int k = M.ia[r]; k < M.ia[r + 1]; ++k) { poff.push_back(M.ja[k] - base); pval.push_back(M.val[k]); }
+        while (poff.size() % 8) { poff.push_back(0); pval.push_back(0.0); }
+    }
+    for (int s = 0; s < SLOTS; ++s) Gs->first[s] = -1;
+    {
+        Set& S = *Gs;
+        for (size_t i = 0; i < reps.size(); ++i) {
+            unsigned s = (unsigned)(reps[i].second >> 20) & (SLOTS - 1);
+            while (S.key[s] != reps[i].second) s = (s + 1) & (SLOTS - 1);
+            S.first[s] = (int)i;
+        }
+    }
+    pat.alloc((size_t)n);
+    if (!square) rowbase.alloc((size_t)n);
+    bool collision = false;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < n; ++r) {
+        const int id = Gs->find(rh[r]);
+        if (id < 0 || !same_row(r, reps[(size_t)id].first)) { collision = true; continue; }
+        pat[r] = (unsigned short)id;
+        if (!square) rowbase[r] = base_of(r);
+    }
+    delete Gs;
+    return !collision;
+}
+
+// 16-bit copy of the column indices (in the order of the device copy) for the operators the
+// sub-wavefront kernel serves: their time is the (JA, val) stream, 12 -> 10 bytes per entry.
+static int upload_ja16(DevCSR& D, const int* ja_dev_order)
+{
+    static const bool on = !(std::getenv("FASP_HIP_JA16") && std::atoi(std::getenv("FASP_HIP_JA16")) == 0);
+    if (!on || D.kind != 0 || D.col > 65536 || D.nnz < 4096) return FASP_SUCCESS;
+    Buf<unsigned short> j16((size_t)D.nnz);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < D.nnz; ++k) j16[k] = (unsigned short)ja_dev_order[k];
+    HIPCK(hipMalloc(&D.ja16, sizeof(unsigned short) * (size_t)D.nnz));
+    HIPCK(hipMemcpy(D.ja16, j16.data(), sizeof(unsigned short) * (size_t)D.nnz, hipMemcpyHostToDevice));
+    return FASP_SUCCESS;
+}
+
+static int upload_csr(const HostCSR& H, DevCSR& D)
+{
+    D.row = H.row; D.col = H.col; D.nnz = H.nnz;
+    HIPCK(hipMalloc(&D.ia, sizeof(int) * ((size_t)H.row + 1)));
+    HIPCK(hipMalloc(&D.ja, sizeof(int) * std::max<size_t>(H.nnz, 1)));
+    HIPCK(hipMalloc(&D.val, sizeof(double) * std::max<size_t>(H.nnz, 1)));
+    HIPCK(hipMemcpyAsync(D.ia, H.ia.data(), sizeof(int) * ((size_t)H.row + 1), hipMemcpyHostToDevice, g_ctx.stream));
+    pick_kernel(D);
+    auto upload_plain = [&]() -> int {
+        HIPCK(hipMemcpyAsync(D.ja, H.ja.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
+        HIPCK(hipMemcpyAsync(D.val, H.val.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream));
+        return 0;
+    };
+    // (long rows keep the sub-wavefront kernel: the coded kernels are one-lane-per-row designs)
+    if (compress_enabled() && H.nnz >= 4096 && (double)H.nnz <= 48.0 * H.row) {
+        Buf<unsigned short> pat; Buf<int> prb;
+        std::vector<int> pstart, plen, poff; std::vector<double> pval;
+        static const bool rowpat_on = !(std::getenv("FASP_HIP_ROWPAT") && std::atoi(std::getenv("FASP_HIP_ROWPAT")) == 0);
+        if (rowpat_on && build_rowpat(H, pat, pstart, plen, poff, pval, prb)) {
+            D.npat = (int)pstart.size(); D.npent = (int)poff.size();
+            HIPCK(hipMalloc(&D.pat, sizeof(unsigned short) * (size_t)H.row));
+            HIPCK(hipMalloc(&D.pstart, sizeof(int) * pstart.size()));
+            HIPCK(hipMalloc(&D.plen, sizeof(int) * plen.size()));
+            HIPCK(hipMemcpy(D.plen, plen.data(), sizeof(int) * plen.size(), hipMemcpyHostToDevice));
+            HIPCK(hipMalloc(&D.poff, sizeof(int) * std::max<size_t>(poff.size(), 1)));
+            HIPCK(hipMalloc(&D.pval, sizeof(double) * std::max<size_t>(pval.size(), 1)));
+            HIPCK(hipMemcpy(D.pat, pat.data(), sizeof(unsigned short) * (size_t)H.row, hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(D.pstart, pstart.data(), sizeof(int) * pstart.size(), hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(D.poff, poff.data(), sizeof(int) * poff.size(), hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(D.pval, pval.data(), sizeof(double) * pval.size(), hipMemcpyHostToDevice));
+            if (prb.n) {
+                HIPCK(hipMalloc(&D.rowbase, sizeof(int) * (size_t)H.row));
+                HIPCK(hipMemcpy(D.rowbase, prb.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
+            }
+            D.kind = 2;  // plain-CSR twin of a coded operator: the stream kernel (same row-sum order; used by the A/B tests)
+            return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
+        }
+        std::vector<int> doff; std::vector<double> dval;
+        Buf<unsigned char> code; Buf<int> rowbase;
+        if (build_dict8(H, doff, dval, code, rowbase)) {
+            HIPCK(hipMalloc(&D.code, (size_t)H.nnz + 256));  // + slack: spans are fetched in 16-byte units
+            HIPCK(hipMalloc(&D.doff, sizeof(int) * 256));
+            HIPCK(hipMalloc(&D.dval, sizeof(double) * 256));
+            HIPCK(hipMemcpy(D.code, code.data(), (size_t)H.nnz, hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(D.doff, doff.data(), sizeof(int) * 256, hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(D.dval, dval.data(), sizeof(double) * 256, hipMemcpyHostToDevice));
+            if (rowbase.n) {
+                HIPCK(hipMalloc(&D.rowbase, sizeof(int) * (size_t)H.row));
+                HIPCK(hipMemcpy(D.rowbase, rowbase.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
+            }
+            D.kind = 2;
+            return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
+        }
+    }
+    // not coded: plain CSR, rows re-sorted by column where the gathers dominate
+    static const bool sort_long = !(std::getenv("FASP_HIP_SORT_LONG_ROWS") && std::atoi(std::getenv("FASP_HIP_SORT_LONG_ROWS")) == 0);
+    static const int  sort_stream = std::getenv("FASP_HIP_SORT_STREAM") ? std::atoi(std::getenv("FASP_HIP_SORT_STREAM")) : 0;
+    const double avg_len = H.row > 0 ? (double)H.nnz / H.row : 0.0;
+    const bool do_sort = sort_long && !g_oneshot_upload && H.nnz > 0 && (D.kind == 0 || (D.kind == 2 && sort_stream > 0 && avg_len >= sort_stream));
+    if (do_sort) {
+        // Operators whose time goes into the x gathers -- one L1 tag lookup per distinct cache line, up to 64
+        // per wavefront load when a row's columns come in discovery order: the DEVICE copy keeps every row's
+        // entries sorted by column, so neighbouring lanes gather neighbouring entries.  (The sub-wavefront
+        // kernel sums lane-strided partials + a shuffle tree, i.e. it never followed the storage order.)
+        Buf<int> sj((size_t)H.nnz);
+        Buf<double> sv((size_t)H.nnz);
+        std::vector<int> dp;
+        const bool square = H.row == H.col;
+        if (square) dp.assign((size_t)H.row, -1);
+#pragma omp parallel
+        {
+            std::vector<std::pair<int, double>> tmp;
+#pragma omp for schedule(dynamic, 64)
+            for (int i = 0; i < H.row; ++i) {
+                const int kb = H.ia[i], ke = H.ia[i + 1];
+                tmp.resize((size_t)(ke - kb));
+                for (int k = kb; k < ke; ++k) tmp[(size_t)(k - kb)] = {H.ja[k], H.val[k]};
+                std::stable_sort(tmp.begin(), tmp.end(),
+                                 [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+                for (int k = kb; k < ke; ++k) {
+                    sj[k] = tmp[(size_t)(k - kb)].first; sv[k] = tmp[(size_t)(k - kb)].second;
+                    if (square && sj[k] == i) dp[(size_t)i] = k;  // last diagonal hit (stable sort keeps their order)
+                }
+            }
+        }
+        HIPCK(hipMemcpy(D.ja, sj.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(D.val, sv.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice));
+        if (square && D.kind == 2) {
+            HIPCK(hipMalloc(&D.dpos, sizeof(int) * (size_t)std::max(H.row, 1)));
+            HIPCK(hipMemcpy(D.dpos, dp.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
+        }
+        D.sorted = true;
+        return upload_ja16(D, sj.data());
+    }
+    if (upload_plain() < 0) return ERROR_ALLOC_MEM;
+    return upload_ja16(D, H.ja.data());
+}
+
+// development knobs (fasp_hip_tune): -1 = automatic
+struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 8, small_lds = 1, ja16 = 1; };
+static Tuning g_tune;
+
+// Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
+// limits), from the occupancy API, cached per instantiation.  The persistent grids
+// below are sized to exactly this residency: a grid larger than what is resident
+// serialises into two rounds (measured: +35 % time), a smaller one leaves CUs idle.
+template <class K>
+static int resident_blocks_per_cu(K kernel)
+{
+    static int cached = -1;
+    if (cached < 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+        cached = std::min(nb, 8);
+    }
+    return cached;
+}
+
+template <class K>
+static int launch_persistent(K kernel, int ntiles, CsrArgs& a)
+{
+    int cap = resident_blocks_per_cu(kernel) * g_ctx.num_cu;
+    if (g_tune.maxgrid > 0) cap = g_tune.maxgrid;
+    cap = std::min(cap, MAXGRID);
+    int grid = std::min(cap, ntiles);
+    grid = std::max(8, (grid + 7) / 8 * 8);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, a);
+    return grid;
+}
+
+// Launches the row kernel of family M.kind for operation OP; returns the grid size
+// (= number of per-block partials written by OP_MXV_DOT).
+template <int OP>
+static int launch_csr(const DevCSR& M0, CsrArgs a)
+{
+    DevCSR M = M0;  // shallow copy: tuning overrides
+    if (M.code && g_tune.compress) M.kind = 4;  // dictionary-coded copy present: one byte per entry
+    if (M.pat && g_tune.compress) M.kind = 5;   // row-pattern-coded copy present: two bytes per row
+    if (g_tune.kind >= 0 && !(g_tune.kind == 4 && !M.code) && !(g_tune.kind == 5 && !M.pat)) M.kind = g_tune.kind;
+    if (g_tune.lanes > 0) M.lanes = g_tune.lanes;
+    if (g_tune.wrows > 0) M.wrows = g_tune.wrows;
+    if (g_tune.wcap > 0) M.wcap = g_tune.wcap;
+    if (OP == OP_JACOBI && M.kind != 0 && M.kind < 4 && (M.dup_diag || !M.dpos)) M.kind = 0;  // needs the c != r test
+    a.xcd_map = g_tune.xcd;
+    a.nt = g_tune.nt;
+    a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
+    a.ja16 = g_tune.ja16 ? M.ja16 : nullptr;
+    const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : M.kind == 3 ? 1 : BLOCK / M.lanes;
+    a.ntiles = (M.row + rpb - 1) / rpb;
+    a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    if (M.kind == 5) {
+        a.pat = M.pat; a.pstart = M.pstart; a.poff = M.poff; a.pval = M.pval; a.rowbase = M.rowbase;
+        a.npat = M.npat; a.npent = M.npent;
+        const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
+        const bool lds = M.npat <= 512 && M.npent <= 2048 && g_tune.lds_tab != 0;
+        const int rpl = g_tune.rpl > 0 ? g_tune.rpl : 1;
+        a.plen = M.plen; a.ncol = M.col;
+        if (g_tune.xcd_pat != 0) a.xcd_map = g_tune.xcd_pat;
+        a.ntiles = (M.row + BLOCK * rpl - 1) / (BLOCK * rpl);
+        a.tiles_per_xcd = (a.ntiles + 7) / 8;
+        (void)avg;
+        if (lds) {
+            if (rpl == 1) return launch_persistent(k_csr_rowpat<OP, true, 1>, a.ntiles, a);
+            return launch_persistent(k_csr_rowpat<OP, true, 2>, a.ntiles, a);
+        }
+        if (rpl == 1) return launch_persistent(k_csr_rowpat<OP, false, 1>, a.ntiles, a);
+        return launch_persistent(k_csr_rowpat<OP, false, 2>, a.ntiles, a);
+    }
+    if (M.kind == 4) {
+        a.code = M.code; a.rowbase = M.rowbase; a.doff = M.doff; a.dval = M.dval;
+        const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
+        if (avg <= 8.5) return launch_persistent(k_csr_dict8<OP, 8>, a.ntiles, a);
+        if (avg <= 20.0) return launch_persistent(k_csr_dict8<OP, 16>, a.ntiles, a);
+        return launch_persistent(k_csr_dict8<OP, 24>, a.ntiles, a);
+    }
+    if (M.kind == 2) {
+        if (M.wrows == 64 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 64, 512>, a.ntiles, a);
+        if (M.wrows == 64) return launch_persistent(k_csr_wstream<OP, 64, 1024>, a.ntiles, a);
+        if (M.wrows == 32 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 32, 512>, a.ntiles, a);
+        return launch_persistent(k_csr_wstream<OP, 32, 1024>, a.ntiles, a);
+    }
+    if (M.kind == 3) return launch_persistent(k_csr_blockrow<OP>, M.row, a);
+    if (M.kind == 1) {
+        int cap = g_tune.maxgrid > 0 ? g_tune.maxgrid : 4 * g_ctx.num_cu;
+        int grid = std::max(8, (std::min(std::min(cap, MAXGRID), a.ntiles) + 7) / 8 * 8);
+        hipLaunchKernelGGL((k_csr_stream<OP>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, a, M.tile_rows);
+        return grid;
+    }
+    switch (M.lanes) {
+        case 2:  return launch_persistent(k_csr_rows<2, OP>, a.ntiles, a);
+        case 4:  return launch_persistent(k_csr_rows<4, OP>, a.ntiles, a);
+        case 8:  return launch_persistent(k_csr_rows<8, OP>, a.ntiles, a);
+        case 16: return launch_persistent(k_csr_rows<16, OP>, a.ntiles, a);
+        case 32: return launch_persistent(k_csr_rows<32, OP>, a.ntiles, a);
+        default: return launch_persistent(k_csr_rows<64, OP>, a.ntiles, a);
+    }
+}
+
+// y = A x
+static void d_mxv(const DevCSR& A, const double* x, double* y)
+{
+    CsrArgs a{}; a.x = x; a.y = y;
+    launch_csr<OP_MXV>(A, a);
+}
+// y = b - A x
+static void d_resid(const DevCSR& A, const double* x, const double* b, double* y)
+{
+    CsrArgs a{}; a.x = x; a.y = y; a.b = b;
+    launch_csr<OP_RESID>(A, a);
+}
+// y += alpha A x  (three rounding-distinct paths of BlaSpmvCSR.c:494)
+static void d_aAxpy(double alpha, const DevCSR& A, const double* x, double* y)
+{
+    CsrArgs a{}; a.x = x; a.y = y; a.alpha = alpha;
+    if (alpha == 1.0) launch_csr<OP_ADD>(A, a);
+    else if (alpha == -1.0) launch_csr<OP_SUB>(A, a);
+    else launch_csr<OP_AXPY>(A, a);
+}
+
+// --- reductions ----------------------------------------------------------------
+// local partials -> d_red[slot .. slot+nq) -> (all-reduce over ranks) .  Host copy on demand.
+static void d_finalize_to(int G, int nq, unsigned maxmask, double* out, bool dist)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, g_ctx.stream, g_ctx.d_partials, G, nq,
+                       maxmask, out);
+    if (dist && comm_size() > 1) comm_allreduce(out, nq, maxmask, g_ctx.stream);
+}
+static void d_finalize(int G, int nq, unsigned maxmask, int slot, bool dist)
+{
+    d_finalize_to(G, nq, maxmask, g_ctx.d_red + slot, dist);
+}
+static int fetch_red(int slot, int nq, double* out)
+{
+    HIPCK(hipMemcpyAsync(g_ctx.h_red + slot, g_ctx.d_red + slot, sizeof(double) * nq,
+                         hipMemcpyDeviceToHost, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    for (int q = 0; q < nq; ++q) out[q] = g_ctx.h_red[slot + q];
+    return FASP_SUCCESS;
+}
+// (x,y) left on the device in reduction slot `slot` (no host round trip)
+static int d_dot_to(int n, const double* x, const double* y, int slot, bool dist)
+{
+    const int G = vec_grid(n);
+    hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, g_ctx.stream, n, x, y, g_ctx.d_partials);
+    d_finalize(G, 1, 0u, slot, dist);
+    return 0;
+}
+static int d_dot(int n, const double* x, const double* y, double* out, bool dist = false)
+{
+    const int G = vec_grid(n);
+    hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, g_ctx.stream, n, x, y, g_ctx.d_partials);
+    d_finalize(G, 1, 0u, 0, dist);
+    return fetch_red(0, 1, out);
+}
+// out[0] = sum x^2, out[1] = max |x|
+static int d_norms(int n, const double* x, double* out, bool dist = false)
+{
+    const int G = vec_grid(n);
+    hipLaunchKernelGGL(k_norms, dim3(G), dim3(BLOCK), 0, g_ctx.stream, n, x, g_ctx.d_partials);
+    d_finalize(G, 2, 0x2u, 0, dist);
+    return fetch_red(0, 2, out);
+}
+static void d_axpy(int n, double a, const double* x, double* y)
+{
+    hipLaunchKernelGGL(k_axpy, dim3(vec_grid(n / 2 + 1)), dim3(BLOCK), 0, g_ctx.stream, n, a, x, y);
+}
+static void d_axpby(int n, double a, const double* x, double b, double* y)
+{
+    hipLaunchKernelGGL(k_axpby, dim3(vec_grid(n / 2 + 1)), dim3(BLOCK), 0, g_ctx.stream, n, a, x, b, y);
+}
+

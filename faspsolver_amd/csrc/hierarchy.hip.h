@@ -1,0 +1,234 @@
+// hierarchy.hip.h -- the resident hierarchy: per-level device data, halo exchange, upload.
+// Part of the single translation unit solver.hip (included there, in this order; not a stand-alone header).
+
+// ---------------------------------------------------------------------------
+// resident hierarchy
+// ---------------------------------------------------------------------------
+struct DevLevel {
+    DevCSR  A, P, R;
+    double* diag = nullptr;  // last diagonal hit per row (Jacobi: ItrSmootherCSR.c:160)
+    double* l1   = nullptr;  // sum_j |a_ij| (L1-diag: ItrSmootherCSR.c:1566)
+    double *b = nullptr, *xa = nullptr, *xb = nullptr, *w = nullptr;
+    double* x  = nullptr;    // current iterate: xa or xb
+    double* xo = nullptr;    // the other buffer
+    bool    x_zero = true;   // x is (conceptually) all zeros and not materialised
+    bool    owns_b = true;
+    // distribution (single GPU: nloc == nvec == rows, no halo)
+    bool    replicated = true;   // whole level on every rank, computed redundantly
+    int     nloc = 0;            // owned entries of this level's vectors
+    int     nvec = 0;            // vector length incl. ghost entries [nloc, nvec)
+    int     row0 = 0;            // global index of the first owned row
+    int     nglobal = 0;
+    std::vector<int> send_off, recv_off;  // nranks+1 each
+    int*    d_send_idx = nullptr;
+    double* d_sendbuf  = nullptr;
+    bool    has_halo() const { return !replicated && nvec > nloc; }
+    // level schedules of the sequential sweeps (built on first use): kind 0 ascending,
+    // 1 descending, 2 ascending C rows, 3 ascending F rows, 4 descending from row n-2
+    struct Sched { bool built = false; int* d_order = nullptr; std::vector<int> ptr; };
+    Sched   sched[5];
+    // polynomial smoother (built on first use): 1 / first diagonal hit, the coefficients k[1..5] of
+    // ItrSmootherCSRpoly.c:101-109, work vectors r, rbar, v0, v1, vnew
+    struct Poly { bool built = false; double* dinv = nullptr; double k[6] = {0, 0, 0, 0, 0, 0}; double* w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
+    Poly    poly;
+    int*    d_mark = nullptr;  // C/F marker on the device (Jacobi-F smoother), built on first use
+    double* w2 = nullptr;      // AMLI cycle: the coarse residual r1 of the level above, built on first use
+    double* kw[4] = {nullptr, nullptr, nullptr, nullptr};  // K-cycle work vectors r, x1, v1, v2 of this level
+};
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace fasp
+
+using namespace fasp;
+
+struct fasp_hip_amg {
+    HostHierarchy         H;
+    DistPlan              dist;        // row partition (nranks == 1: trivial)
+    bool                  distributed = false;  // level 0 is row-partitioned over the ranks
+    std::vector<DevLevel> L;
+    AMG_param             param;  // copy of the user's parameters after setup
+    // Krylov work vectors on level 0
+    double *b = nullptr, *u = nullptr, *p = nullptr, *t = nullptr, *r = nullptr;
+    // coarse-level SPCG work vectors
+    double *cp = nullptr, *cr = nullptr, *ct = nullptr, *cbest = nullptr;
+    // GMRES basis vectors (allocated on first use): level-0 set and coarse-level set
+    std::vector<double*> gm[2];
+    size_t               gm_len[2] = {0, 0};
+    double*              gm_hh = nullptr;  // device Hessenberg column
+    SpcgState*           spcg_state = nullptr;  // device-resident state of the batched coarse CG
+    std::vector<double>  amli_coef;             // AMLI polynomial coefficients (amli_degree + 1), formed on first use
+    std::vector<int>     level_cycle_type;      // AMG_data.cycle_type per level as the setup leaves it (K-cycle)
+    bool                 use_fmg = false;       // the preconditioner is one full-multigrid cycle (precond_type == PREC_FMG)
+    // instrumentation
+    std::vector<EventPair> ev;
+    int                    ev_used = 0;
+    long long              coarse_iters = 0, vcycles = 0;
+    double                 upload_seconds = 0.0;
+};
+
+namespace fasp {
+
+static void free_level(DevLevel& D)
+{
+    D.A.release(); D.P.release(); D.R.release();
+    if (D.diag) (void)hipFree(D.diag);
+    if (D.l1) (void)hipFree(D.l1);
+    if (D.b && D.owns_b) (void)hipFree(D.b);
+    if (D.xa) (void)hipFree(D.xa);
+    if (D.xb) (void)hipFree(D.xb);
+    if (D.w) (void)hipFree(D.w);
+    if (D.d_send_idx) (void)hipFree(D.d_send_idx);
+    if (D.d_sendbuf) (void)hipFree(D.d_sendbuf);
+    for (auto& sc : D.sched) if (sc.d_order) (void)hipFree(sc.d_order);
+    if (D.poly.dinv) (void)hipFree(D.poly.dinv);
+    for (double* q : D.poly.w) if (q) (void)hipFree(q);
+    if (D.d_mark) (void)hipFree(D.d_mark);
+    if (D.w2) (void)hipFree(D.w2);
+    for (double* q : D.kw) if (q) (void)hipFree(q);
+    D = DevLevel();
+}
+
+static int alloc_vec(double** p, size_t n)
+{
+    HIPCK(hipMalloc(p, sizeof(double) * std::max<size_t>(n, 1)));
+    return FASP_SUCCESS;
+}
+
+// diag / l1 are derived on the host in the reference's order (one pass, setup time)
+static int upload_diag(const HostCSR& A, DevLevel& D)
+{
+    const int n = A.row;
+    std::vector<double> d(n, 0.0), s(n, 0.0);
+    std::vector<int>    dp(n, -1);
+    int                 ndup = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ndup)
+    for (int i = 0; i < n; ++i) {
+        double di = 0.0, si = 0.0;
+        int    hits = 0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            if (A.ja[k] == i) { di = A.val[k]; dp[i] = k; ++hits; }
+            si += (A.val[k] >= 0.0) ? A.val[k] : -A.val[k];
+        }
+        d[i] = di; s[i] = si;
+        if (hits > 1) ++ndup;
+    }
+    D.A.dup_diag = ndup > 0;
+    if (!D.A.sorted) {  // (storage indices of the host order: meaningless for a re-sorted device copy)
+        HIPCK(hipMalloc(&D.A.dpos, sizeof(int) * std::max(n, 1)));
+        HIPCK(hipMemcpy(D.A.dpos, dp.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    }
+    if (alloc_vec(&D.diag, n) < 0 || alloc_vec(&D.l1, n) < 0) return ERROR_ALLOC_MEM;
+    HIPCK(hipMemcpy(D.diag, d.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(D.l1, s.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    return FASP_SUCCESS;
+}
+
+// gather v[idx[i]] into a contiguous send buffer
+__global__ __launch_bounds__(BLOCK) void k_pack(int n, const int* __restrict__ idx,
+                                                 const double* __restrict__ v, double* __restrict__ out)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) out[i] = v[idx[i]];
+}
+
+// Refresh the ghost entries [nloc, nvec) of a level-l vector from their owners: pack the
+// entries the peers need, one grouped RCCL send/recv, receive straight into the ghost
+// slots (ghosts are sorted by owner, so every peer's block is contiguous).
+static int halo_exchange(DevLevel& D, double* v)
+{
+    if (!D.has_halo() && (D.send_off.empty() || D.send_off.back() == 0)) return FASP_SUCCESS;
+    const int P = comm_size(), me = comm_rank();
+    const int nsend = D.send_off.back();
+    if (nsend > 0)
+        hipLaunchKernelGGL(k_pack, dim3(vec_grid(nsend)), dim3(BLOCK), 0, g_ctx.stream, nsend, D.d_send_idx, v,
+                           D.d_sendbuf);
+    std::vector<CommXfer> sends, recvs;
+    for (int q = 0; q < P; ++q) {
+        if (q == me) continue;
+        const int ns = D.send_off[q + 1] - D.send_off[q], nr = D.recv_off[q + 1] - D.recv_off[q];
+        if (ns > 0) sends.push_back({q, D.d_sendbuf + D.send_off[q], (size_t)ns});
+        if (nr > 0) recvs.push_back({q, v + D.nloc + D.recv_off[q], (size_t)nr});
+    }
+    return comm_exchange(sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size(), g_ctx.stream);
+}
+
+static int upload_hierarchy(fasp_hip_amg* h)
+{
+    HostThreads team;  // matrix coding / re-sorting / partition loops
+    const double t0 = wall_seconds();
+    const int nl = (int)h->H.L.size();
+    h->L.resize(nl);
+    int min_rows = 200000;
+    if (const char* e = std::getenv("FASP_HIP_DIST_MIN_ROWS")) min_rows = std::atoi(e);
+    // sequential (Gauss-Seidel / SOR) sweeps couple all rows of a level: such hierarchies
+    // are not row-partitioned, every rank keeps (and computes) all levels
+    if (h->param.smoother != SMOOTHER_JACOBI && h->param.smoother != SMOOTHER_L1DIAG && h->param.smoother != SMOOTHER_POLY) min_rows = 2147483647;
+    if (h->param.cycle_type == AMLI_CYCLE || h->param.cycle_type == NL_AMLI_CYCLE) min_rows = 2147483647;  // the recursive cycles run on whole levels
+    {   // AMG_data.cycle_type of every level: the setup's cycle type for levels >= 1 (PreAMGSetupRS.c:325,
+        // PreAMGSetupSA.c:495); the UA setup derives it from the operator complexity (PreAMGSetupUA.c:390-401)
+        h->level_cycle_type.assign((size_t)nl, h->param.cycle_type);
+        h->level_cycle_type[0] = 0;
+        if (h->param.AMG_type == UA_AMG) {
+            const double cplxmax = 3.0, xsi = 0.6, eta = xsi / ((1 - xsi) * (cplxmax - 1));
+            int icum = 1;
+            h->level_cycle_type[0] = 1;
+            h->level_cycle_type[(size_t)nl - 1] = 0;
+            for (int lvl = 1; lvl < nl - 1; ++lvl) {
+                const double fracratio = (double)h->H.L[lvl].A.nnz / h->H.L[0].A.nnz;
+                int ct = (int)(std::pow(xsi, (double)lvl) / (eta * fracratio * icum));
+                ct = std::max(1, std::min(2, ct));
+                h->level_cycle_type[(size_t)lvl] = ct;
+                icum = icum * ct;
+            }
+        }
+    }
+    {
+        const int st = build_dist_plan(h->H, comm_rank(), comm_size(), min_rows, h->dist);
+        if (st < 0) return st;
+    }
+    h->distributed = !h->dist.L[0].replicated;
+    for (int l = 0; l < nl; ++l) {
+        const HostLevel& HL = h->H.L[l];
+        const DistLevel& DL = h->dist.L[l];
+        DevLevel& D = h->L[l];
+        D.replicated = DL.replicated;
+        D.nloc = DL.nloc; D.row0 = DL.row0; D.nglobal = DL.nglobal;
+        D.nvec = DL.replicated ? DL.nglobal : DL.nloc + (int)DL.ghosts.size();
+        const HostCSR& A = DL.replicated ? HL.A : DL.A;
+        if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;
+        if (HL.has_coarse) {
+            if (upload_csr(DL.replicated ? HL.P : DL.P, D.P) < 0) return ERROR_ALLOC_MEM;
+            if (upload_csr(DL.replicated ? HL.R : DL.R, D.R) < 0) return ERROR_ALLOC_MEM;
+        }
+        HIPCK(hipStreamSynchronize(g_ctx.stream));
+        if (upload_diag(A, D) < 0) return ERROR_ALLOC_MEM;
+        const size_t n = D.nvec;
+        if (l > 0) { if (alloc_vec(&D.b, n) < 0) return ERROR_ALLOC_MEM; }
+        else D.owns_b = false;  // level-0 rhs aliases the Krylov residual (PreCSR.c:429 copy elided)
+        if (alloc_vec(&D.xa, n) < 0 || alloc_vec(&D.xb, n) < 0 || alloc_vec(&D.w, n) < 0) return ERROR_ALLOC_MEM;
+        D.x = D.xa; D.xo = D.xb; D.x_zero = true;
+        if (!DL.replicated) {
+            D.send_off = DL.send_off; D.recv_off = DL.recv_off;
+            const size_t ns = DL.send_idx.size();
+            HIPCK(hipMalloc(&D.d_send_idx, sizeof(int) * std::max<size_t>(ns, 1)));
+            HIPCK(hipMalloc(&D.d_sendbuf, sizeof(double) * std::max<size_t>(ns, 1)));
+            if (ns) HIPCK(hipMemcpy(D.d_send_idx, DL.send_idx.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
+        }
+    }
+    const size_t m = h->L[0].nvec;
+    if (alloc_vec(&h->b, m) < 0 || alloc_vec(&h->u, m) < 0 || alloc_vec(&h->p, m) < 0 ||
+        alloc_vec(&h->t, m) < 0 || alloc_vec(&h->r, m) < 0) return ERROR_ALLOC_MEM;
+    HIPCK(hipMemsetAsync(h->u, 0, sizeof(double) * m, g_ctx.stream));
+    HIPCK(hipMemsetAsync(h->p, 0, sizeof(double) * m, g_ctx.stream));
+    const size_t mc = h->L[nl - 1].nvec;
+    if (alloc_vec(&h->cp, mc) < 0 || alloc_vec(&h->cr, mc) < 0 || alloc_vec(&h->ct, mc) < 0 ||
+        alloc_vec(&h->cbest, mc) < 0) return ERROR_ALLOC_MEM;
+    h->ev.resize(64);
+    for (auto& e : h->ev) { HIPCK(hipEventCreate(&e.a)); HIPCK(hipEventCreate(&e.b)); }
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    // the local copies of the partitioned operators are only needed for the upload
+    for (auto& DL : h->dist.L) { DL.A = HostCSR(); DL.P = HostCSR(); DL.R = HostCSR(); }
+    h->upload_seconds = wall_seconds() - t0;
+    return FASP_SUCCESS;
+}
+

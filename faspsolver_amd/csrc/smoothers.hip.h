@@ -1,0 +1,272 @@
+// smoothers.hip.h -- smoothers on a resident level: Jacobi / L1 / polynomial kernels, level-scheduled sequential sweeps.
+// Part of the single translation unit solver.hip (included there, in this order; not a stand-alone header).
+
+// ---------------------------------------------------------------------------
+// smoothers on the resident level (PreMGSmoother.inl:49 / :155).  Jacobi and L1-diag
+// are order independent, so pre (ascending) and post (descending) sweeps coincide.
+// ---------------------------------------------------------------------------
+static void materialise_zero(DevLevel& D)
+{
+    if (D.x_zero) {
+        (void)hipMemsetAsync(D.x, 0, sizeof(double) * D.nvec, g_ctx.stream);
+        D.x_zero = false;
+    }
+}
+
+// Level schedule of one sequential sweep over the rows `seq` (in sweep order) of the host
+// matrix A: level(i) = 1 + max level of the rows coupled to i (pattern of A and of A^T) that
+// come earlier in the sweep.  Rows outside the sweep are not updated and impose nothing.
+static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLevel::Sched& S)
+{
+    const int n = A.row;
+    std::vector<int> pos(n, -1), lev(n, 0);
+    for (int q = 0; q < (int)seq.size(); ++q) pos[seq[q]] = q;
+    // transpose pattern for the anti-dependencies of structurally unsymmetric matrices
+    std::vector<int> tia(n + 2, 0), tja(A.nnz);
+    for (int k = 0; k < A.nnz; ++k) if (A.ja[k] < n) tia[A.ja[k] + 2]++;
+    for (int i = 2; i <= n + 1; ++i) tia[i] += tia[i - 1];
+    for (int i = 0; i < n; ++i)
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
+            if (A.ja[k] < n) tja[tia[A.ja[k] + 1]++] = i;
+    int nlev = 0;
+    for (int q = 0; q < (int)seq.size(); ++q) {
+        const int i = seq[q];
+        int l = 0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            const int j = A.ja[k];
+            if (j != i && j < n && pos[j] >= 0 && pos[j] < q) l = std::max(l, lev[j]);
+        }
+        for (int k = tia[i]; k < tia[i + 1]; ++k) {
+            const int j = tja[k];
+            if (j != i && pos[j] >= 0 && pos[j] < q) l = std::max(l, lev[j]);
+        }
+        lev[i] = l + 1;
+        nlev = std::max(nlev, l + 1);
+    }
+    S.ptr.assign(nlev + 1, 0);
+    for (int i : seq) S.ptr[lev[i]]++;
+    for (int l = 0; l < nlev; ++l) S.ptr[l + 1] += S.ptr[l];
+    std::vector<int> cur(S.ptr.begin(), S.ptr.end() - 1), order(seq.size());
+    for (int i : seq) order[cur[lev[i] - 1]++] = i;
+    HIPCK(hipMalloc(&S.d_order, sizeof(int) * std::max<size_t>(order.size(), 1)));
+    if (!order.empty()) HIPCK(hipMemcpy(S.d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
+    S.built = true;
+    return FASP_SUCCESS;
+}
+
+// one sequential sweep of schedule `kind` with update formula `form` (see k_seq_level)
+static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
+{
+    DevLevel& D = h->L[level];
+    DevLevel::Sched& S = D.sched[kind];
+    if (!S.built) {
+        const HostCSR& A = h->H.L[level].A;
+        const int n = A.row;
+        std::vector<int> seq;
+        seq.reserve(n);
+        const int* cf = h->H.L[level].cfmark.n ? h->H.L[level].cfmark.data() : nullptr;
+        switch (kind) {
+            case 0: for (int i = 0; i < n; ++i) seq.push_back(i); break;
+            case 1: for (int i = n - 1; i >= 0; --i) seq.push_back(i); break;
+            case 2: for (int i = 0; i < n; ++i) if (cf && cf[i] == 1) seq.push_back(i); break;
+            case 3: for (int i = 0; i < n; ++i) if (!cf || cf[i] != 1) seq.push_back(i); break;
+            default: for (int i = n - 2; i >= 0; --i) seq.push_back(i); break;
+        }
+        const int st = build_schedule(A, seq, S);
+        if (st < 0) return st;
+    }
+    materialise_zero(D);
+    const int L = D.A.lanes;
+    const int nlev = (int)S.ptr.size() - 1;
+    for (int l = 0; l < nlev; ++l) {
+        const int lo = S.ptr[l], hi = S.ptr[l + 1];
+        const int rpb = BLOCK / L;
+        const int grid = std::max(1, std::min(MAXGRID, (hi - lo + rpb - 1) / rpb));
+#define SEQ_LAUNCH(LL) hipLaunchKernelGGL((k_seq_level<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, \
+        (const int*)S.d_order, lo, hi, (const int*)D.A.ia, (const int*)D.A.ja, (const double*)D.A.val,    \
+        (const double*)D.b, (const double*)D.diag, D.x, form, w)
+        switch (L) {
+            case 2: SEQ_LAUNCH(2); break;
+            case 4: SEQ_LAUNCH(4); break;
+            case 8: SEQ_LAUNCH(8); break;
+            case 16: SEQ_LAUNCH(16); break;
+            case 32: SEQ_LAUNCH(32); break;
+            default: SEQ_LAUNCH(64); break;
+        }
+#undef SEQ_LAUNCH
+    }
+    return FASP_SUCCESS;
+}
+
+// Smoother dispatch of PreMGSmoother.inl:49 (pre) / :155 (post).  Jacobi and L1-diag are
+// order independent, so their pre (ascending) and post (descending) sweeps coincide; the
+// Gauss-Seidel / SOR family runs as level-scheduled sequential sweeps.
+// fasp_smoother_dcsr_poly (ItrSmootherCSRpoly.c:67): per sweep r = b - A u, then the recurrence of
+// Rr (:551) -- ndeg SpMVs and elementwise steps -- and u += correction.  Order independent, so the
+// level may be row-partitioned (every SpMV input gets its halo).  Dinv and the coefficients depend
+// on the matrix only: formed once per level on the host exactly as the reference does per call.
+static int cg_smooth(fasp_hip_amg* h, int level, int nsweeps);  // defined after the Krylov drivers
+
+static int poly_smooth(fasp_hip_amg* h, int level, int ndeg, int nsweeps)
+{
+    DevLevel& D = h->L[level];
+    const int n = D.A.row;
+    DevLevel::Poly& Q = D.poly;
+    hipStream_t s = g_ctx.stream;
+    if (!Q.built) {
+        // every rank holds the whole host hierarchy: local row i is global row r0 + i, and the
+        // norm (a maximum over ALL rows of the level) needs no exchange
+        const HostCSR& A = h->H.L[level].A;
+        const int r0 = D.replicated ? 0 : D.row0;
+        std::vector<double> dinv((size_t)std::max(n, 1));
+        double norm = 0.0;
+        for (int gi = 0; gi < A.row; ++gi) {  // Diaginv :392 (first hit) and DinvAnorminf :428
+            int j = A.ia[gi];
+            for (; j < A.ia[gi + 1]; ++j) if (A.ja[j] == gi) break;
+            const double di = 1.0 / A.val[j];
+            if (gi >= r0 && gi < r0 + n) dinv[(size_t)(gi - r0)] = di;
+            double temp = 0.0;
+            for (int q = A.ia[gi]; q < A.ia[gi + 1]; ++q) temp += std::fabs(A.val[q]);
+            temp *= di;
+            norm = std::max(norm, temp);
+        }
+        double mu0 = norm;
+        mu0 = 1.0 / mu0;
+        const double mu1 = 4.0 * mu0, smu0 = std::sqrt(mu0), smu1 = std::sqrt(mu1);
+        Q.k[1] = (mu0 + mu1) / 2.0;
+        Q.k[2] = (smu0 + smu1) * (smu0 + smu1) / 2.0;
+        Q.k[3] = mu0 * mu1;
+        Q.k[4] = 2.0 * Q.k[3] / Q.k[2];
+        Q.k[5] = (mu1 - 2.0 * smu0 * smu1 + mu0) / (mu1 + 2.0 * smu0 * smu1 + mu0);
+        HIPCK(hipMalloc(&Q.dinv, sizeof(double) * std::max(n, 1)));
+        HIPCK(hipMemcpy(Q.dinv, dinv.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        for (double*& q : Q.w) {
+            if (alloc_vec(&q, (size_t)D.nvec) < 0) return ERROR_ALLOC_MEM;
+        }
+        Q.built = true;
+    }
+    double *r = Q.w[0], *rbar = Q.w[1], *v0 = Q.w[2], *v1 = Q.w[3], *vnew = Q.w[4];
+    const int G = vec_grid(n);
+    for (int it = 0; it < nsweeps; ++it) {
+        if (D.x_zero) {  // u == 0: r = b exactly, no matrix pass
+            HIPCK(hipMemcpyAsync(r, D.b, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            materialise_zero(D);
+        } else {
+            if (halo_exchange(D, D.x) < 0) return ERROR_MISC;
+            d_resid(D.A, D.x, D.b, r);
+        }
+        hipLaunchKernelGGL(k_poly_scale, dim3(G), dim3(BLOCK), 0, s, n, Q.dinv, r, rbar);
+        if (halo_exchange(D, rbar) < 0) return ERROR_MISC;
+        d_mxv(D.A, rbar, v1);
+        hipLaunchKernelGGL(k_poly_start, dim3(G), dim3(BLOCK), 0, s, n, Q.k[1], Q.k[2], Q.k[3], Q.dinv, rbar, v0, v1);
+        if (ndeg <= 1) HIPCK(hipMemsetAsync(vnew, 0, sizeof(double) * n, s));  // the reference's correction stays zero
+        for (int j = 1; j < ndeg; ++j) {
+            if (halo_exchange(D, v1) < 0) return ERROR_MISC;
+            d_mxv(D.A, v1, rbar);
+            hipLaunchKernelGGL(k_poly_step, dim3(G), dim3(BLOCK), 0, s, n, Q.k[4], Q.k[5], Q.dinv, r, rbar, v0, v1, vnew);
+        }
+        d_axpy(n, 1.0, vnew, D.x);
+    }
+    return FASP_SUCCESS;
+}
+
+static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order, int nsweeps, double relax, int ndeg)
+{
+    DevLevel& D = h->L[level];
+    const int n = D.A.row;
+    if (smoother == SMOOTHER_POLY) return poly_smooth(h, level, ndeg, nsweeps);
+    if (smoother == SMOOTHER_JACOBIF) {  // fasp_smoother_dcsr_jacobi_ff, ItrSmootherCSR.c:34
+        const Buf<int>& cf = h->H.L[level].cfmark;
+        if (!D.replicated || cf.n != (size_t)n) {
+            std::printf("### ERROR: fasp_hip: Jacobi-F needs the C/F marker of a classical hierarchy (one GPU)\n");
+            return ERROR_AMG_SMOOTH_TYPE;
+        }
+        if (!D.d_mark) {
+            HIPCK(hipMalloc(&D.d_mark, sizeof(int) * std::max(n, 1)));
+            HIPCK(hipMemcpy(D.d_mark, cf.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+        }
+        materialise_zero(D);
+        for (int s = 0; s < nsweeps; ++s) {
+            CsrArgs a{};
+            a.x = D.x; a.y = D.xo; a.b = D.b; a.omega = relax; a.diag = D.diag; a.mark = D.d_mark;
+            launch_csr<OP_L1DIAG>(D.A, a);
+            std::swap(D.x, D.xo);
+        }
+        return FASP_SUCCESS;
+    }
+    if (smoother == SMOOTHER_JACOBI || smoother == SMOOTHER_L1DIAG) {
+        for (int s = 0; s < nsweeps; ++s) {
+            if (D.x_zero) {
+                // zero initial guess: t_i = b_i exactly, no matrix pass
+                if (smoother == SMOOTHER_JACOBI)
+                    hipLaunchKernelGGL(k_jacobi_zero, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, relax,
+                                       D.b, D.diag, D.x);
+                else
+                    hipLaunchKernelGGL(k_l1_zero, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, D.b, D.l1, D.x);
+                D.x_zero = false;
+                continue;
+            }
+            if (halo_exchange(D, D.x) < 0) return ERROR_MISC;
+            CsrArgs a{};
+            a.x = D.x; a.y = D.xo; a.b = D.b; a.omega = relax;
+            if (smoother == SMOOTHER_JACOBI) { a.diag = D.diag; launch_csr<OP_JACOBI>(D.A, a); }
+            else { a.diag = D.l1; launch_csr<OP_L1DIAG>(D.A, a); }
+            std::swap(D.x, D.xo);
+        }
+        return FASP_SUCCESS;
+    }
+    if (!D.replicated) return ERROR_AMG_SMOOTH_TYPE;  // sequential sweeps are not distributed
+    if (smoother == SMOOTHER_CG) return cg_smooth(h, level, nsweeps);
+    const bool has_cf = h->H.L[level].cfmark.n == (size_t)n;
+    if (smoother == SMOOTHER_GSF) {  // fasp_smoother_dcsr_gs_ff (ItrSmootherCSR.c:700): GS over the non-C rows, ascending, before and after
+        if (!has_cf) {
+            std::printf("### ERROR: fasp_hip: the F-point Gauss-Seidel smoother needs the C/F marker of a classical hierarchy\n");
+            return ERROR_AMG_SMOOTH_TYPE;
+        }
+        for (int sw = 0; sw < nsweeps; ++sw) { const int st = seq_sweep(h, level, 3, 1, 0.0); if (st < 0) return st; }
+        return FASP_SUCCESS;
+    }
+    auto rep = [&](int kind, int form, double w) -> int {  // nsweeps repetitions, as the `while (L--)` loops
+        for (int s = 0; s < nsweeps; ++s) { const int st = seq_sweep(h, level, kind, form, w); if (st < 0) return st; }
+        return FASP_SUCCESS;
+    };
+    int st = FASP_SUCCESS;
+    switch (smoother) {
+        case SMOOTHER_GS:
+            if (order == NO_ORDER || !has_cf) st = rep(post ? 1 : 0, 0, 0.0);
+            else if (order == CF_ORDER) {  // fasp_smoother_dcsr_gs_cf: pre C then F, post F then C
+                for (int s = 0; s < nsweeps && st >= 0; ++s) {
+                    st = seq_sweep(h, level, post ? 3 : 2, 1, 0.0);
+                    if (st >= 0) st = seq_sweep(h, level, post ? 2 : 3, 1, 0.0);
+                }
+            }
+            break;
+        case SMOOTHER_SGS:
+            for (int s = 0; s < nsweeps && st >= 0; ++s) {
+                st = seq_sweep(h, level, 0, 1, 0.0);
+                if (st >= 0) st = seq_sweep(h, level, 4, 1, 0.0);
+            }
+            break;
+        case SMOOTHER_SOR: st = rep(post ? 1 : 0, 2, relax); break;
+        case SMOOTHER_SSOR:
+            st = rep(0, 2, relax);
+            if (st >= 0) st = rep(1, 2, relax);
+            break;
+        case SMOOTHER_GSOR:
+            if (!post) { st = rep(0, 0, 0.0); if (st >= 0) st = rep(1, 2, relax); }
+            else       { st = rep(0, 2, relax); if (st >= 0) st = rep(1, 0, 0.0); }
+            break;
+        case SMOOTHER_SGSOR:
+            if (!post) {
+                st = rep(0, 0, 0.0); if (st >= 0) st = rep(1, 0, 0.0);
+                if (st >= 0) st = rep(0, 2, relax); if (st >= 0) st = rep(1, 2, relax);
+            } else {
+                st = rep(0, 2, relax); if (st >= 0) st = rep(1, 2, relax);
+                if (st >= 0) st = rep(0, 0, 0.0); if (st >= 0) st = rep(1, 0, 0.0);
+            }
+            break;
+        default: return ERROR_AMG_SMOOTH_TYPE;
+    }
+    return st;
+}
+
