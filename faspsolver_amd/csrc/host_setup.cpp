@@ -66,7 +66,35 @@ struct Pattern {  // integer CSR (iCSRmat without values)
 // diagonal is never strong; if row_sum < (2 - max_row_sum)*|a_ii| the whole row is weak;
 // otherwise j is weak when -a_ij <= row_scl.  a_ii = first diagonal hit, 0 if absent.
 // The compressed S keeps the surviving columns in storage order.
-int strength_compressed(const HostCSR& A, const AMG_param& param, Pattern& S)
+// `strong` (one flag per stored entry of A) is the uncompressed strength pattern the reference keeps in
+// iCSRmat S before compress_S; the RSP splitting needs it once more after the first pass.
+void compress_strength(const HostCSR& A, const Buf<unsigned char>& strong, Pattern& S)
+{
+    const int row = A.row;
+    const int *ia = A.ia.data(), *ja = A.ja.data();
+    Buf<int> cnt((size_t)row + 1);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        int c = 0;
+        for (int j = ia[i]; j < ia[i + 1]; ++j) c += strong[j] ? 1 : 0;
+        cnt[i] = c;
+    }
+    S.row = row; S.col = A.col;
+    S.ia.alloc((size_t)row + 1);
+    int acc = 0;
+    for (int i = 0; i < row; ++i) { S.ia[i] = acc; acc += cnt[i]; }
+    S.ia[row] = acc;
+    S.nnz = acc;
+    S.ja.alloc((size_t)std::max(acc, 1));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        int o = S.ia[i];
+        for (int j = ia[i]; j < ia[i + 1]; ++j)
+            if (strong[j]) S.ja[o++] = ja[j];
+    }
+}
+
+int strength_compressed(const HostCSR& A, const AMG_param& param, Pattern& S, Buf<unsigned char>* keep = nullptr)
 {
     const int    row = A.row;
     const double max_row_sum = param.max_row_sum, eps = param.strong_threshold;
@@ -74,7 +102,8 @@ int strength_compressed(const HostCSR& A, const AMG_param& param, Pattern& S)
     const double* aj = A.val.data();
     const int nd = std::min(A.row, A.col);
 
-    Buf<unsigned char> strong((size_t)A.nnz);
+    const bool rsp = param.coarsening_type == COARSE_RSP;
+    Buf<unsigned char> strong((size_t)std::max(A.nnz, 1));
     Buf<int>           cnt((size_t)row + 1);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < row; ++i) {
@@ -94,26 +123,42 @@ int strength_compressed(const HostCSR& A, const AMG_param& param, Pattern& S)
             bool s = true;
             if (ja[j] == i && !diag_removed) { s = false; diag_removed = true; }  // first diagonal hit only (:350-355)
             if (all_weak) s = false;
-            else if (-aj[j] <= row_scl) s = false;
+            else if (rsp ? (dabs(aj[j]) <= row_scl) : (-aj[j] <= row_scl)) s = false;  // :368-379: RSP keeps positive couplings too
             strong[j] = s;
             c += s;
         }
         cnt[i] = c;
     }
-    S.row = row; S.col = A.col;
-    S.ia.alloc((size_t)row + 1);
-    int acc = 0;
-    for (int i = 0; i < row; ++i) { S.ia[i] = acc; acc += cnt[i]; }
-    S.ia[row] = acc;
-    S.nnz = acc;
-    S.ja.alloc((size_t)acc);
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < row; ++i) {
-        int o = S.ia[i];
-        for (int j = ia[i]; j < ia[i + 1]; ++j)
-            if (strong[j]) S.ja[o++] = ja[j];
+    compress_strength(A, strong, S);
+    const int status = (S.nnz <= 0) ? ERROR_UNKNOWN : FASP_SUCCESS;
+    if (keep) *keep = std::move(strong);
+    return status;
+}
+
+// rem_positive_ff (PreAMGCoarsenRS.c:444): strong positive F-F couplings come back into the uncompressed
+// pattern and the largest of each F row becomes a C point.  Sequential: vec changes as the rows go by.
+void rem_positive_ff(const HostCSR& A, Buf<unsigned char>& strong, int* vec)
+{
+    const int *ia = A.ia.data(), *ja = A.ja.data();
+    const double* av = A.val.data();
+    for (int i = 0; i < A.row; ++i) {
+        if (vec[i] != FGPT) continue;
+        double row_scl = 0.0;
+        for (int ji = ia[i]; ji < ia[i + 1]; ++ji)
+            if (ja[ji] != i) row_scl = std::max(row_scl, dabs(av[ji]));
+        row_scl *= 0.75;
+        int max_index = -1;
+        double max_entry = 0.0;
+        for (int ji = ia[i]; ji < ia[i + 1]; ++ji) {
+            const int j = ja[ji];
+            if (j == i || vec[j] != FGPT) continue;
+            if (av[ji] > row_scl) {
+                strong[ji] = 1;
+                if (av[ji] > max_entry) { max_entry = av[ji]; max_index = j; }
+            }
+        }
+        if (max_index != -1) vec[max_index] = CGPT;
     }
-    return (S.nnz <= 0) ? ERROR_UNKNOWN : FASP_SUCCESS;
 }
 
 // Stable counting transpose in parallel: the result is the one of the reference's serial loops
@@ -245,7 +290,8 @@ struct Buckets {
 };
 
 // C/F splitting, first pass + C1 second pass (PreAMGCoarsenRS.c:507-785, RS_C1 ON)
-int cfsplitting_cls(const Pattern& S, int* vec)
+// a_rowlen != nullptr selects cfsplitting_clsp (:806): "isolated" = a matrix row of at most one entry, no C1 pass
+int cfsplitting_cls(const Pattern& S, int* vec, const int* a_ia = nullptr)
 {
     const int row = S.row;
     int       col = 0, num_left = 0;
@@ -270,7 +316,8 @@ int cfsplitting_cls(const Pattern& S, int* vec)
         x.next = x.prev = -1;
         x.lambda = ST.ia[i + 1] - ST.ia[i];
         maxdeg = std::max(maxdeg, x.lambda);
-        if (S.ia[i + 1] == S.ia[i]) { x.vec = ISPT; x.lambda = 0; }
+        const bool isolated = a_ia ? ((a_ia[i + 1] - a_ia[i]) <= 1) : (S.ia[i + 1] == S.ia[i]);
+        if (isolated) { x.vec = ISPT; x.lambda = 0; }
         else { x.vec = UNPT; ++num_left; }
         nd[i] = x;
     }
@@ -350,7 +397,7 @@ int cfsplitting_cls(const Pattern& S, int* vec)
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < row; ++i) { vec[i] = nd[i].vec; nd[i].lambda = -1; }
     int jkeep = 0;
-    for (int i = 0; i < row; ++i) {
+    for (int i = 0; i < (a_ia ? 0 : row); ++i) {
         if (vec[i] != FGPT) continue;
         const int e = S.ia[i + 1];
         for (int ji = S.ia[i]; ji < e; ++ji) {
@@ -1072,8 +1119,8 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             std::printf("### ERROR: fasp_hip: SA with unsmoothed restriction has no device path\n");
             return ERROR_INPUT_PAR;
         }
-        if (amg->AMG_type == CLASSIC_AMG && amg->coarsening_type != COARSE_RS) {
-            std::printf("### ERROR: fasp_hip: coarsening_type %d not supported (COARSE_RS only)\n",
+        if (amg->AMG_type == CLASSIC_AMG && amg->coarsening_type != COARSE_RS && amg->coarsening_type != COARSE_RSP) {
+            std::printf("### ERROR: fasp_hip: coarsening_type %d not supported (COARSE_RS and COARSE_RSP only)\n",
                         amg->coarsening_type);
             return ERROR_AMG_COARSE_TYPE;
         }
@@ -1171,10 +1218,18 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
                 std::printf("  [setup level %d] %-12s %8.3f s\n", lvl, what, now - tp);
                 tp = now;
             };
-            status = strength_compressed(Lv.A, *param, S);
+            const bool rsp = param->coarsening_type == COARSE_RSP;
+            Buf<unsigned char> strong;
+            status = strength_compressed(Lv.A, *param, S, rsp ? &strong : nullptr);
             lap("strength");
             int col = -1;
-            if (status >= 0) col = cfsplitting_cls(S, vertices.data());
+            if (status >= 0) col = cfsplitting_cls(S, vertices.data(), rsp ? Lv.A.ia.data() : nullptr);
+            if (status >= 0 && rsp) {  // :1020-1036: positive F-F couplings, then the pattern is compressed again
+                rem_positive_ff(Lv.A, strong, vertices.data());
+                Pattern S2;
+                compress_strength(Lv.A, strong, S2);
+                if (S2.nnz > 0) S = std::move(S2);
+            }
             lap("C/F split");
             if (status < 0 || col <= 0) {  // Check 1, PreAMGSetupRS.c:162-173
                 if (prtlvl > PRINT_MIN) {
@@ -1196,6 +1251,10 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
                 }
                 break;
             }
+            // :198-199: the reference falls back to the classical splitting once coarsening slows down
+            // (and after the aggressive levels; aggressive_level is 0 unless COARSE_AC is requested)
+            if (col * 1.5 > Lv.A.row) param->coarsening_type = COARSE_RS;   // (P.col there = the splitting's C count)
+            if (lvl == param->aggressive_level) param->coarsening_type = COARSE_RS;
             Lv.cfmark.alloc((size_t)Lv.A.row);  // :201-206
             std::memcpy(Lv.cfmark.data(), vertices.data(), (size_t)Lv.A.row * sizeof(int));
 

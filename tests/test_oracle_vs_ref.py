@@ -89,17 +89,27 @@ def _matrix(name):
     if name == "fe":
         from _libs import DATA, read_csr
         return read_csr(DATA + "/csrmat_FE.dat")
+    if name.startswith("pos"):   # P7 with 15 % of the couplings made positive: exercises rem_positive_ff
+        ia, ja, a = poisson7pt(int(name[3:]))[:3]
+        a = a.copy()
+        rng = np.random.default_rng(2)
+        off = ja != np.repeat(np.arange(len(ia) - 1), np.diff(ia))
+        flip = off & (rng.random(len(a)) < 0.15)
+        a[flip] = np.abs(a[flip]) * 0.9
+        return ia, ja, a
     return poisson7pt(int(name))[:3]
 
 
+@pytest.mark.parametrize("coarsening", [1, 2], ids=["RS", "RSP"])
 @pytest.mark.parametrize("interp", [1, 2], ids=["direct", "standard"])
-@pytest.mark.parametrize("name", ["9", "28", "fe"])
-def test_hierarchy_bit_exact_oracle_and_product(R, fa, name, interp):
-    """Direct (PreAMGInterp.c:302) and standard (:547, pattern PreAMGCoarsenRS.c:2006) interpolation."""
+@pytest.mark.parametrize("name", ["9", "28", "fe", "pos16"])
+def test_hierarchy_bit_exact_oracle_and_product(R, fa, name, interp, coarsening):
+    """Direct (PreAMGInterp.c:302) and standard (:547, pattern PreAMGCoarsenRS.c:2006) interpolation; classical
+    splitting (cfsplitting_cls) and the variant that keeps positive couplings (COARSE_RSP, cfsplitting_clsp :806)."""
     ia, ja, a = _matrix(name)
-    i1, a1 = default_params(); a1.smoother = T.SMOOTHER_JACOBI; a1.interpolation_type = interp
-    i2, a2 = default_params(); a2.smoother = T.SMOOTHER_JACOBI; a2.interpolation_type = interp
-    a3 = fa.param_amg_init(); a3.smoother = T.SMOOTHER_JACOBI; a3.interpolation_type = interp
+    i1, a1 = default_params(); a1.smoother = T.SMOOTHER_JACOBI; a1.interpolation_type = interp; a1.coarsening_type = coarsening
+    i2, a2 = default_params(); a2.smoother = T.SMOOTHER_JACOBI; a2.interpolation_type = interp; a2.coarsening_type = coarsening
+    a3 = fa.param_amg_init(); a3.smoother = T.SMOOTHER_JACOBI; a3.interpolation_type = interp; a3.coarsening_type = coarsening
     A, keep = T.as_csr(ia, ja, a)
     O = OrcAMG(A, a1)
     hr = R.ref_amg_setup_rs(C.byref(A), C.byref(a2))
