@@ -430,6 +430,180 @@ int cfsplitting_cls(const Pattern& S, int* vec, const int* a_ia = nullptr)
     return col;
 }
 
+// Couplings between the temporary C points for aggressive coarsening (strong_couplings_agg1 / _agg2,
+// PreAMGCoarsenRS.c:1065 / :1243): path 1 = a strong path of length <= 2, path 2 = a direct coupling or at
+// least two paths of length 2.  The reference's marks are per source point (ci / ci+1 / -ci-1), so rows are
+// independent: count and fill run in parallel with a private mark array, column order as in the reference.
+static void couplings_between_c(const Pattern& S, const int* vec, bool two_paths, std::vector<int>& cp_index,
+                                Pattern& Sh)
+{
+    const int row = S.row;
+    std::vector<int> cp_rindex((size_t)std::max(row, 1));
+    cp_index.clear();
+    for (int i = 0; i < row; ++i)
+        if (vec[i] == CGPT) { cp_rindex[i] = (int)cp_index.size(); cp_index.push_back(i); }
+    const int num_c = (int)cp_index.size();
+    Sh.row = Sh.col = num_c;
+    Sh.ia.alloc((size_t)num_c + 2);
+    Sh.ia[0] = 0;
+
+    // visit the couplings of C point ci in the reference's order; emit(c) is called once per coupled C point
+    auto walk = [&](int ci, int* visited, auto&& emit) {
+        const int i = cp_index[ci], hit = two_paths ? ci + 1 : ci;
+        for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) {
+            const int fj = S.ja[j];
+            if (vec[fj] == CGPT && fj != i) {
+                const int cj = cp_rindex[fj];
+                if (visited[cj] != hit) { visited[cj] = hit; emit(cj); }
+            } else if (vec[fj] == FGPT) {
+                for (int k = S.ia[fj]; k < S.ia[fj + 1]; ++k) {
+                    const int ck = S.ja[k];
+                    if (vec[ck] != CGPT || ck == i) continue;
+                    const int cck = cp_rindex[ck];
+                    if (!two_paths) {
+                        if (visited[cck] != hit) { visited[cck] = hit; emit(cck); }
+                    } else if (visited[cck] == hit) {
+                    } else if (visited[cck] == -hit) {  // second path
+                        visited[cck] = hit;
+                        emit(cck);
+                    } else {
+                        visited[cck] = -hit;
+                    }
+                }
+            }
+        }
+    };
+    const int init = two_paths ? 0 : -1;
+#pragma omp parallel
+    {
+        std::vector<int> visited((size_t)std::max(num_c, 1), init);
+#pragma omp for schedule(static)
+        for (int ci = 0; ci < num_c; ++ci) {
+            int count = 0;
+            walk(ci, visited.data(), [&](int) { ++count; });
+            Sh.ia[ci + 1] = count;
+        }
+    }
+    for (int ci = 0; ci < num_c; ++ci) Sh.ia[ci + 1] += Sh.ia[ci];
+    Sh.nnz = Sh.ia[num_c];
+    Sh.ja.alloc((size_t)std::max(Sh.nnz, 1));
+#pragma omp parallel
+    {
+        // the fill pass starts from fresh marks like the reference's (:1168 / :1353); a row's marks from the
+        // counting pass would otherwise suppress its own entries
+        std::vector<int> visited((size_t)std::max(num_c, 1), init);
+#pragma omp for schedule(static)
+        for (int ci = 0; ci < num_c; ++ci) {
+            int o = Sh.ia[ci];
+            walk(ci, visited.data(), [&](int c) { Sh.ja[o++] = c; });
+        }
+    }
+}
+
+// Aggressive coarsening (cfsplitting_agg, PreAMGCoarsenRS.c:1435-1684): the classical splitting, then a
+// second greedy pass over its C points with the couplings above (real C points 3, fake ones 4 in the
+// reference; :1543/:1557/:1589), then F points without a C point within distance two become C points.
+int cfsplitting_agg(const Pattern& S, int* vec, int aggressive_path)
+{
+    enum { REAL_C = 3, FAKE_C = 4 };
+    const int row = S.row;
+    int col = 0, num_left = 0;
+    cfsplitting_cls(S, vec);
+
+    std::vector<int> cp_index;
+    Pattern Sh, ShT;
+    couplings_between_c(S, vec, aggressive_path >= 2, cp_index, Sh);
+    transpose_pattern(Sh, ShT);
+    const int num_c = Sh.row;
+
+    Buf<CfNode> nodes((size_t)std::max(num_c, 1));
+    CfNode* nd = nodes.data();
+    int maxdeg = 0;
+    for (int ci = 0; ci < num_c; ++ci) {
+        nd[ci].next = nd[ci].prev = -1;
+        nd[ci].lambda = ShT.ia[ci + 1] - ShT.ia[ci];
+        nd[ci].vec = CGPT;
+        maxdeg = std::max(maxdeg, nd[ci].lambda);
+    }
+    Buckets B(nd, 2 * maxdeg + 2);
+
+    for (int ci = 0; ci < num_c; ++ci) {  // :1492-1532 (num_left counts the listed points here)
+        if (nd[ci].lambda > 0) {
+            B.enter(nd[ci].lambda, ci);
+            ++num_left;
+        } else {
+            nd[ci].vec = FGPT;
+            for (int k = Sh.ia[ci]; k < Sh.ia[ci + 1]; ++k) {
+                const int cj = Sh.ja[k];
+                if (cj < ci) {  // (a point already set to F is listed again, as in the reference)
+                    if (nd[cj].lambda > 0) { B.remove(nd[cj].lambda, cj); --num_left; }
+                    B.enter(++nd[cj].lambda, cj);
+                    ++num_left;
+                } else {
+                    ++nd[cj].lambda;
+                }
+            }
+        }
+    }
+
+    auto bump_neighbours = [&](int cj) {
+        for (int l = Sh.ia[cj]; l < Sh.ia[cj + 1]; ++l) {
+            const int ck = Sh.ja[l];
+            if (nd[ck].vec == CGPT) {
+                B.remove(nd[ck].lambda, ck);
+                B.enter(++nd[ck].lambda, ck);
+            }
+        }
+    };
+    while (num_left > 0) {  // :1535-1604
+        const int maxnode = B.top();
+        const int maxmeas = nd[maxnode].lambda;
+        if (maxmeas == 0) std::printf("### WARNING: Head of the list has measure 0!\n");
+        nd[maxnode].vec = REAL_C;
+        --num_left;
+        B.remove(maxmeas, maxnode);
+        nd[maxnode].lambda = 0;
+        ++col;
+        for (int i = ShT.ia[maxnode]; i < ShT.ia[maxnode + 1]; ++i) {
+            const int cj = ShT.ja[i];
+            if (nd[cj].vec != CGPT) continue;
+            nd[cj].vec = FAKE_C;
+            B.remove(nd[cj].lambda, cj);
+            --num_left;
+            bump_neighbours(cj);
+        }
+        for (int i = Sh.ia[maxnode]; i < Sh.ia[maxnode + 1]; ++i) {
+            const int cj = Sh.ja[i];
+            if (nd[cj].vec != CGPT) continue;
+            int measure = nd[cj].lambda;
+            B.remove(measure, cj);
+            nd[cj].lambda = --measure;
+            if (measure > 0) {
+                B.enter(measure, cj);
+            } else {
+                nd[cj].vec = FAKE_C;
+                --num_left;
+                bump_neighbours(cj);
+            }
+        }
+    }
+    for (int ci = 0; ci < num_c; ++ci) vec[cp_index[ci]] = (nd[ci].vec == REAL_C) ? CGPT : FGPT;  // :1611-1620
+
+    for (int i = 0; i < row; ++i) {  // :1628-1660; sequential: a promoted point serves the rows after it
+        if (vec[i] != FGPT) continue;
+        bool has_c = false;
+        for (int j = S.ia[i]; j < S.ia[i + 1] && !has_c; ++j) {
+            const int k = S.ja[j];
+            if (vec[k] == CGPT) has_c = true;
+            else if (vec[k] == FGPT)
+                for (int l = S.ia[k]; l < S.ia[k + 1]; ++l)
+                    if (vec[S.ja[l]] == CGPT) { has_c = true; break; }
+        }
+        if (!has_c) { vec[i] = CGPT; ++col; }
+    }
+    return col;
+}
+
 // F-F couplings without a common C point (PreAMGCoarsenRS.c:1709-1781), with the
 // reference's "tentatively promote j, re-check i" roll-back (:1762-1769).
 int clean_ff_couplings(const Pattern& S, int* vec, int row, int col)
@@ -482,8 +656,32 @@ int clean_ff_couplings(const Pattern& S, int* vec, int row, int col)
 void finish_interp(int row, const int* vec, const Buf<int>& pia, const Buf<int>& pja, const Buf<double>& pval,
                    double eps_tr, HostCSR& P);
 
+// one row of the standard-interpolation pattern (form_P_pattern_std, PreAMGCoarsenRS.c:2006): strong C
+// neighbours and the strong C neighbours of strong F neighbours, in discovery order
+static inline void std_pattern_row(const Pattern& S, const int* vec, int i, std::vector<int>& cols)
+{
+    cols.clear();
+    if (vec[i] == FGPT) {
+        auto add = [&](int h) {
+            for (int c : cols) if (c == h) return;
+            cols.push_back(h);
+        };
+        for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) {
+            const int k = S.ja[j];
+            if (vec[k] == CGPT) add(k);
+            else if (vec[k] == FGPT && k != i)
+                for (int l = S.ia[k]; l < S.ia[k + 1]; ++l) { const int h = S.ja[l]; if (vec[h] == CGPT) add(h); }
+        }
+    } else if (vec[i] == CGPT) {
+        cols.push_back(i);
+    }
+}
+
+// std_pattern: direct-interpolation WEIGHTS on the standard pattern -- what the reference computes on the level
+// where aggressive coarsening ends (the pattern is formed while coarsening_type is still COARSE_AC,
+// PreAMGCoarsenRS.c:96, the weights after it was switched back, PreAMGSetupRS.c:198-199 / PreAMGInterp.c:68-71)
 void build_interp_dir(const HostCSR& A, const Pattern& S, const int* vec, const AMG_param& param,
-                      HostCSR& P)
+                      HostCSR& P, bool std_pattern = false)
 {
     const int row = A.row;
     const int *ia = A.ia.data(), *ja = A.ja.data();
@@ -493,24 +691,37 @@ void build_interp_dir(const HostCSR& A, const Pattern& S, const int* vec, const 
     // pattern of the untruncated P, in fine-column indices
     Buf<int> pia((size_t)row + 1);
     pia[0] = 0;
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < row; ++i) {
-        int c = 0;
-        if (vec[i] == FGPT) {
-            for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) c += (vec[S.ja[j]] == CGPT);
-        } else if (vec[i] == CGPT) {
-            c = 1;
+#pragma omp parallel
+    {
+        std::vector<int> cols;
+#pragma omp for schedule(static)
+        for (int i = 0; i < row; ++i) {
+            int c = 0;
+            if (std_pattern) {
+                std_pattern_row(S, vec, i, cols);
+                c = (int)cols.size();
+            } else if (vec[i] == FGPT) {
+                for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) c += (vec[S.ja[j]] == CGPT);
+            } else if (vec[i] == CGPT) {
+                c = 1;
+            }
+            pia[i + 1] = c;
         }
-        pia[i + 1] = c;
     }
     for (int i = 0; i < row; ++i) pia[i + 1] += pia[i];
     const int   pnnz = pia[row];
-    Buf<int>    pja((size_t)pnnz);
-    Buf<double> pval((size_t)pnnz);
-#pragma omp parallel for schedule(static)
+    Buf<int>    pja((size_t)std::max(pnnz, 1));
+    Buf<double> pval((size_t)std::max(pnnz, 1));
+#pragma omp parallel
+    {
+    std::vector<int> cols;
+#pragma omp for schedule(static)
     for (int i = 0; i < row; ++i) {
         int o = pia[i];
-        if (vec[i] == FGPT) {
+        if (std_pattern) {
+            std_pattern_row(S, vec, i, cols);
+            for (int c : cols) pja[o++] = c;
+        } else if (vec[i] == FGPT) {
             for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) {
                 const int k = S.ja[j];
                 if (vec[k] == CGPT) pja[o++] = k;
@@ -518,6 +729,7 @@ void build_interp_dir(const HostCSR& A, const Pattern& S, const int* vec, const 
         } else if (vec[i] == CGPT) {
             pja[o++] = i;
         }
+    }
     }
 
     // The reference keeps `aii` in a function-scope variable (PreAMGInterp.c:314): a row
@@ -576,8 +788,11 @@ void build_interp_dir(const HostCSR& A, const Pattern& S, const int* vec, const 
                 int       l = b;
                 for (; l < e; ++l)
                     if (ja[l] == k) break;
-                if (av[l] > 0) pval[j] = -beta * av[l] / aii;
-                else pval[j] = -alpha * av[l] / aii;
+                // (standard pattern only) a column absent from the row: the reference reads the entry just past
+                // the row (:481-486) = the next row's first entry; past the array's end that is undefined there, 0 here
+                const double ail = (l < A.nnz) ? av[l] : 0.0;
+                if (ail > 0) pval[j] = -beta * ail / aii;
+                else pval[j] = -alpha * ail / aii;
             }
         } else if (vec[i] == CGPT) {
             pval[pia[i]] = 1.0;
@@ -686,23 +901,7 @@ void build_interp_std(const HostCSR& A, const Pattern& S, const int* vec, const 
     const int row = A.row;
     const int *ia = A.ia.data(), *ja = A.ja.data();
     const double* av = A.val.data();
-    auto pattern_row = [&](int i, std::vector<int>& cols) {
-        cols.clear();
-        if (vec[i] == FGPT) {
-            auto add = [&](int h) {
-                for (int c : cols) if (c == h) return;
-                cols.push_back(h);
-            };
-            for (int j = S.ia[i]; j < S.ia[i + 1]; ++j) {
-                const int k = S.ja[j];
-                if (vec[k] == CGPT) add(k);
-                else if (vec[k] == FGPT && k != i)
-                    for (int l = S.ia[k]; l < S.ia[k + 1]; ++l) { const int h = S.ja[l]; if (vec[h] == CGPT) add(h); }
-            }
-        } else if (vec[i] == CGPT) {
-            cols.push_back(i);
-        }
-    };
+    auto pattern_row = [&](int i, std::vector<int>& cols) { std_pattern_row(S, vec, i, cols); };
     Buf<int> pia((size_t)row + 1);
     pia[0] = 0;
 #pragma omp parallel
@@ -1119,8 +1318,9 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             std::printf("### ERROR: fasp_hip: SA with unsmoothed restriction has no device path\n");
             return ERROR_INPUT_PAR;
         }
-        if (amg->AMG_type == CLASSIC_AMG && amg->coarsening_type != COARSE_RS && amg->coarsening_type != COARSE_RSP) {
-            std::printf("### ERROR: fasp_hip: coarsening_type %d not supported (COARSE_RS and COARSE_RSP only)\n",
+        if (amg->AMG_type == CLASSIC_AMG && amg->coarsening_type != COARSE_RS && amg->coarsening_type != COARSE_RSP &&
+            amg->coarsening_type != COARSE_AC) {
+            std::printf("### ERROR: fasp_hip: coarsening_type %d not supported (COARSE_RS, COARSE_RSP and COARSE_AC only)\n",
                         amg->coarsening_type);
             return ERROR_AMG_COARSE_TYPE;
         }
@@ -1203,6 +1403,7 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 
     if (prtlvl > PRINT_NONE) std::printf("\nSetting up Classical AMG ...\n");
     param->tentative_smooth = 1.0;  // PreAMGSetupRS.c:83
+    if (param->coarsening_type == COARSE_AC) param->aggressive_level = std::max<int>(param->aggressive_level, 1);  // :88-89
 
     std::vector<int> vertices(A->row);
     int lvl = 0;
@@ -1223,7 +1424,10 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
             status = strength_compressed(Lv.A, *param, S, rsp ? &strong : nullptr);
             lap("strength");
             int col = -1;
-            if (status >= 0) col = cfsplitting_cls(S, vertices.data(), rsp ? Lv.A.ia.data() : nullptr);
+            const bool agg = param->coarsening_type == COARSE_AC;
+            if (status >= 0)
+                col = agg ? cfsplitting_agg(S, vertices.data(), param->aggressive_path)
+                          : cfsplitting_cls(S, vertices.data(), rsp ? Lv.A.ia.data() : nullptr);
             if (status >= 0 && rsp) {  // :1020-1036: positive F-F couplings, then the pattern is compressed again
                 rem_positive_ff(Lv.A, strong, vertices.data());
                 Pattern S2;
@@ -1239,8 +1443,9 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
                 status = FASP_SUCCESS;
                 break;
             }
-            const bool std_interp = param->interpolation_type == INTERP_STD;  // no F-F clean-up (PreAMGCoarsenRS.c:152)
-            if (!std_interp) col = clean_ff_couplings(S, vertices.data(), Lv.A.row, col);
+            // the standard pattern (no F-F clean-up, PreAMGCoarsenRS.c:152) is forced for aggressive coarsening (:96)
+            const bool std_pattern = agg || param->interpolation_type == INTERP_STD;
+            if (!std_pattern) col = clean_ff_couplings(S, vertices.data(), Lv.A.row, col);
             lap("FF clean-up");
             if (col < MIN_CDOF) break;  // Check 2, :176-181
             if (Lv.A.row > col * 10.0) {  // Check 3, :184-195
@@ -1258,8 +1463,11 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
             Lv.cfmark.alloc((size_t)Lv.A.row);  // :201-206
             std::memcpy(Lv.cfmark.data(), vertices.data(), (size_t)Lv.A.row * sizeof(int));
 
-            if (std_interp) build_interp_std(Lv.A, S, vertices.data(), *param, Lv.P);
-            else build_interp_dir(Lv.A, S, vertices.data(), *param, Lv.P);  // :209
+            // PreAMGInterp.c:68-71 looks at coarsening_type AFTER the switch above: on the level where aggressive
+            // coarsening ends, the user's interpolation fills the standard pattern
+            if (param->interpolation_type == INTERP_STD || param->coarsening_type == COARSE_AC)
+                build_interp_std(Lv.A, S, vertices.data(), *param, Lv.P);
+            else build_interp_dir(Lv.A, S, vertices.data(), *param, Lv.P, std_pattern);  // :209
             lap("interpolation");
             transpose_csr(Lv.P, Lv.R);                                 // :212
             lap("transpose");

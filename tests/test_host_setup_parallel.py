@@ -11,11 +11,13 @@ from faspsolver_amd import _types as T
 def _build(ia, ja, a, kind, minnz):
     fa.lib().fasp_hip_tune(b"host_parallel_min", minnz)
     amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
-    amgp.AMG_type = {"rs": T.CLASSIC_AMG, "sa": T.SA_AMG, "ua": T.UA_AMG}[kind]
+    amgp.AMG_type = {"rs": T.CLASSIC_AMG, "ac": T.CLASSIC_AMG, "sa": T.SA_AMG, "ua": T.UA_AMG}[kind]
+    if kind == "ac":   # aggressive coarsening, two-path couplings between the C points
+        amgp.coarsening_type = T.COARSE_AC; amgp.aggressive_path = 2
     return fa.AMG(ia, ja, a, amgp, host_only=True)
 
 
-@pytest.mark.parametrize("kind,n", [("rs", 24), ("rs", 33), ("sa", 24), ("ua", 20)])
+@pytest.mark.parametrize("kind,n", [("rs", 24), ("rs", 33), ("ac", 33), ("sa", 24), ("ua", 20)])
 def test_parallel_transposes_reproduce_the_serial_hierarchy(kind, n):
     ia, ja, a, f, ue = fa.poisson7pt(n)
     try:

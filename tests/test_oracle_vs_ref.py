@@ -63,11 +63,14 @@ def _mods():
     def gsf2w(i, a): i.tol = 1e-8; a.smoother = 12; a.presmooth_iter = 2; a.postsmooth_iter = 2; a.cycle_type = T.W_CYCLE   # SMOOTHER_GSF
     def cgsm1(i, a): vfg(i, a); a.smoother = 4          # SMOOTHER_CG: a nonlinear preconditioner, hence flexible GMRES
     def cgsm3(i, a): vfg(i, a); a.smoother = 4; a.presmooth_iter = 3; a.postsmooth_iter = 3
+    def ac2(i, a): jac(i, a); a.coarsening_type = T.COARSE_AC; a.aggressive_path = 2
+    def ac2_std_w(i, a): vfg(i, a); a.coarsening_type = T.COARSE_AC; a.aggressive_path = 2; a.interpolation_type = 2; a.cycle_type = T.W_CYCLE; a.aggressive_level = 2
+    def ac1(i, a): jac(i, a); a.coarsening_type = T.COARSE_AC
     def vgpre(i, a): vg(i, a); i.stop_type = T.STOP_REL_PRECRES
     def vfgmod(i, a): vfg(i, a); i.stop_type = T.STOP_MOD_REL_RES
     return dict(jac=jac, jacw=jacw, vw=vw, l1=l1, gscf=gscf, gsn=gsn, sor=sor, ssor=ssor, sgs=sgs,
                 theta=theta, precres=precres, modres=modres, gsor=gsor, sgsor=sgsor, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
-                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w, amli1=amli1, amli2gs=amli2gs, amli2cs=amli2cs, amli0=amli0, amli3vg=amli3vg, namli_gcg=namli_gcg, namli_gcr_gs=namli_gcr_gs, namli_ua=namli_ua, namli_sa_vfg=namli_sa_vfg, fmg=fmg, fmg_gs_cs=fmg_gs_cs, fmg_sa_vfg=fmg_sa_vfg, gsf2w=gsf2w, cgsm1=cgsm1, cgsm3=cgsm3)
+                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w, amli1=amli1, amli2gs=amli2gs, amli2cs=amli2cs, amli0=amli0, amli3vg=amli3vg, namli_gcg=namli_gcg, namli_gcr_gs=namli_gcr_gs, namli_ua=namli_ua, namli_sa_vfg=namli_sa_vfg, fmg=fmg, fmg_gs_cs=fmg_gs_cs, fmg_sa_vfg=fmg_sa_vfg, gsf2w=gsf2w, cgsm1=cgsm1, cgsm3=cgsm3, ac2=ac2, ac2_std_w=ac2_std_w, ac1=ac1)
 
 
 @pytest.mark.parametrize("name", list(_mods().keys()))
@@ -128,6 +131,41 @@ def test_hierarchy_bit_exact_oracle_and_product(R, fa, name, interp, coarsening)
                 assert np.array_equal(x, y) and np.array_equal(x, z)
     R.ref_amg_free(hr, C.byref(a2)); O.free(); P.close()
     assert bytes(a1) == bytes(a2) == bytes(a3)  # the same mutations of AMG_param
+
+
+@pytest.mark.parametrize("alvl", [0, 2], ids=["lvl-default", "lvl2"])
+@pytest.mark.parametrize("path", [1, 2], ids=["path1", "path2"])
+@pytest.mark.parametrize("interp", [1, 2], ids=["direct", "standard"])
+@pytest.mark.parametrize("name", ["9", "24", "fe", "pos16"])
+def test_aggressive_coarsening_hierarchy_bit_exact(R, fa, name, interp, path, alvl):
+    """COARSE_AC (cfsplitting_agg, PreAMGCoarsenRS.c:1435, couplings between C points :1065 / :1243): standard
+    interpolation is forced while it is active; on the level where it ends the reference fills the standard
+    pattern with the user's interpolation (PreAMGInterp.c:68-71 after PreAMGSetupRS.c:198-199) -- the `direct`
+    cases cover that."""
+    ia, ja, a = _matrix(name)
+    def prm(x):
+        x.smoother = T.SMOOTHER_JACOBI; x.interpolation_type = interp; x.coarsening_type = T.COARSE_AC
+        x.aggressive_path = path; x.aggressive_level = alvl
+        return x
+    a1 = prm(default_params()[1]); a2 = prm(default_params()[1]); a3 = prm(fa.param_amg_init())
+    A, keep = T.as_csr(ia, ja, a)
+    O = OrcAMG(A, a1)
+    hr = R.ref_amg_setup_rs(C.byref(A), C.byref(a2))
+    P = fa.AMG(ia, ja, a, a3, host_only=True)
+    nl = R.ref_amg_num_levels(hr)
+    assert O.num_levels == nl == P.num_levels
+    for l in range(nl):
+        for which, nm in ((0, "A"), (1, "P"), (2, "R")):
+            if which and l == nl - 1:
+                continue
+            v = T.dCSRmat(); R.ref_amg_get_matrix(hr, l, which, C.byref(v))
+            ref_arr = T.csr_arrays(v)
+            mine = T.csr_arrays(getattr(O.level(l), nm))
+            prod = P.matrix(l, which)[2:]
+            for x, y, z in zip(ref_arr, mine, prod):
+                assert np.array_equal(x, y) and np.array_equal(x, z)
+    R.ref_amg_free(hr, C.byref(a2)); O.free(); P.close()
+    assert bytes(a1) == bytes(a2) == bytes(a3)
 
 
 def test_coarse_spvgmres_bit_exact(R):
