@@ -93,15 +93,41 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         // each) without waiting and synchronises once per batch.  When one of the reference's
         // tests fires, k_spcg_step raises `stop`, the launches queued behind it return at once,
         // and the branch is replayed here from the recorded scalars (KrySPcg.c:172-330).
-        const int batch = std::max(1, std::min(g_tune.spcg_batch, 64));
+        const int batch = std::max(1, std::min(g_tune.spcg_batch > 0 ? g_tune.spcg_batch : 8, 64));
         if (!h->spcg_state) HIPCK(hipMalloc(&h->spcg_state, sizeof(SpcgState)));
         SpcgState S{};
         S.temp1 = temp1; S.temp1_prev = temp1; S.absres_best = absres_best; S.normr0 = normr0; S.tol = tol;
         S.maxdiff = maxdiff; S.iter = 0; S.iter_best = 0; S.stag = stag; S.MaxIt = MaxIt; S.stop = SPCG_RUN;
         S.absres = absres; S.relres = relres; S.alpha = 0.0;  // values before the first iteration
         HIPCK(hipMemcpyAsync(h->spcg_state, &S, sizeof(S), hipMemcpyHostToDevice, s));
+        // one launch per iteration (k_spcg_fused) when p fits the LDS of a CU and the level is stored as plain CSR
+        const bool fused = g_tune.spcg_fused && m <= 512 * 16 && A.val && A.ja && !A.code && !A.pat;
+        double *R[2] = {r, nullptr}, *P[2] = {p, nullptr}, *T[2] = {t, nullptr};
+        SpcgBc* bc = nullptr;
+        int  cur = 0;        // parity of the buffers that hold r and p
+        bool first = true;   // next launch starts a batch sequence: SpMV only
+        if (fused) {
+            if (!h->spcg_fused_buf) HIPCK(hipMalloc(&h->spcg_fused_buf, sizeof(double) * (3 * (size_t)m + 4)));
+            R[1] = h->spcg_fused_buf; P[1] = R[1] + m; T[1] = P[1] + m;
+            bc = reinterpret_cast<SpcgBc*>(T[1] + m);
+        }
         for (;;) {
-            for (int q = 0; q < batch; ++q) {
+            for (int q = 0; q < batch && fused; ++q) {
+                SpcgFusedArgs fa{};
+                fa.m = m; fa.first = first ? 1 : 0; fa.in = cur; fa.st = h->spcg_state; fa.bc = bc;
+                fa.ia = A.ia; fa.ja = A.ja; fa.ja16 = A.ja16; fa.val = A.val;
+                for (int k = 0; k < 2; ++k) { fa.r[k] = R[k]; fa.p[k] = P[k]; fa.t[k] = T[k]; }
+                fa.u = u; fa.u_best = u_best;
+                // two 512-thread blocks per CU are resident (126 VGPRs): one wave of blocks, block 0 included
+                const int cap = g_tune.spcg_grid > 0 ? g_tune.spcg_grid : 2 * g_ctx.num_cu - 1;
+                const dim3 grid(1 + std::max(1, std::min((m + 7) / 8, cap)));
+                const size_t lds = sizeof(double) * (size_t)m;
+                if (m <= 512 * 4) hipLaunchKernelGGL(k_spcg_fused<4>, grid, dim3(512), lds, s, fa);
+                else if (m <= 512 * 10) hipLaunchKernelGGL(k_spcg_fused<10>, grid, dim3(512), lds, s, fa);
+                else hipLaunchKernelGGL(k_spcg_fused<16>, grid, dim3(512), lds, s, fa);
+                cur ^= 1; first = false;
+            }
+            for (int q = 0; q < batch && !fused; ++q) {
                 CsrArgs a{}; a.x = p; a.y = t; a.dotv = p; a.partials = g_ctx.d_partials; a.stop = &h->spcg_state->stop;
                 SpcgStepArgs sa{};
                 sa.m = m; sa.st = h->spcg_state; sa.t = t; sa.p = p; sa.u = u; sa.r = r; sa.u_best = u_best;
@@ -116,6 +142,7 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
             std::memcpy(&S, g_ctx.h_part, sizeof(S));
             iter = S.iter; absres_best = S.absres_best; iter_best = S.iter_best;
             if (S.stop == SPCG_RUN) continue;
+            if (fused) { cur = S.pad; r = R[cur]; p = P[cur]; first = true; }  // where the last finished step left r and p
             // a test fired in iteration S.iter: finish that iteration as the reference does
             temp2 = S.tp; temp1 = S.temp1_prev;
             red[0] = S.rr; red[1] = S.uu; red[2] = S.pp; red[3] = S.maxu; red[4] = S.nan;

@@ -211,10 +211,25 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
                     s += v3 * x3;
                 }
             }
-            for (; k < ke; k += L) {
-                const int    c = ld_ja(a, k);
-                const double v = ld_val(a, k);
-                if (OP != OP_JACOBI || c != r) s += v * a.x[c];
+            if (k < ke) {
+                // the last one to three strides in ONE round trip instead of one each: indices clamped into
+                // the row, padded values replaced by 0 (same adds in the same order, then + 0)
+                const int    kl = ke - 1;
+                const int    k1 = min(k + L, kl), k2 = min(k + 2 * L, kl);
+                const int    c0 = ld_ja(a, k), c1 = ld_ja(a, k1), c2 = ld_ja(a, k2);
+                const double v0 = ld_val(a, k);
+                const double w1 = ld_val(a, k1), w2 = ld_val(a, k2);
+                const double v1 = (k + L < ke) ? w1 : 0.0, v2 = (k + 2 * L < ke) ? w2 : 0.0;
+                const double x0 = a.x[c0], x1 = a.x[c1], x2 = a.x[c2];
+                if (OP == OP_JACOBI) {
+                    if (c0 != r) s += v0 * x0;
+                    if (c1 != r) s += v1 * x1;
+                    if (c2 != r) s += v2 * x2;
+                } else {
+                    s += v0 * x0;
+                    s += v1 * x1;
+                    s += v2 * x2;
+                }
             }
             s = subwave_sum<L>(s);
             if (sl == 0) {

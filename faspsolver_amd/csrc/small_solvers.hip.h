@@ -486,6 +486,172 @@ __global__ __launch_bounds__(512) void k_spcg_step_reg(SpcgStepArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// The batched safe CG with ONE launch per iteration (coarsest levels whose vectors fit the LDS of a CU).
+// Every block repeats the step of k_spcg_step_reg on its own (same loads, same reduction order, hence the
+// same alpha, residual and beta in every block, bit for bit), leaves p_new in its LDS and multiplies ITS rows
+// of A with it, gathering from LDS instead of through the vector cache; block 0 does no rows: it carries
+// the part of the step nobody else needs (u, the norms of u and p, the best iterate, the exit tests) and
+// publishes r_new, p_new and the two scalars the next launch needs.  r, p, t and that broadcast record
+// are double-buffered by launch parity, so within a launch nothing that is read is also written.
+// (t,p) is formed from the finished vector t in the next launch's prologue: no per-block partials.
+// ---------------------------------------------------------------------------
+struct SpcgBc { double temp1; int stop, pad; };
+struct SpcgFusedArgs {
+    int        m, first, in;  // in: parity of the buffers holding r, p, t and the broadcast record on entry
+    SpcgState* st;            // touched by block 0 only
+    SpcgBc*    bc;            // [2]
+    const int* ia; const int* ja; const unsigned short* ja16; const double* val;
+    double *r[2], *p[2], *t[2];
+    double *u, *u_best;
+};
+
+// One lane's share of a row sum, x gathered from LDS.  The row is consumed in chunks of 8 wave-strides whose
+// 16 loads are all issued before the first use; the last chunk is padded (index clamped into the row, value
+// replaced by 0), so a row of n entries costs ceil(n / 512) memory round trips, not one per leftover stride.
+template <class IDX>
+__device__ __forceinline__ double fused_row_sum(const IDX* __restrict__ ja, const double* __restrict__ val,
+                                                const double* sp, int k, int ke)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (; k - (int)(threadIdx.x & 63) < ke; k += 8 * 64) {   // (uniform trip count over the wave)
+        int c[8]; double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int kk = k + q * 64, kc = min(kk, ke - 1);
+            c[q] = (int)__builtin_nontemporal_load(ja + kc);
+            const double x = __builtin_nontemporal_load(val + kc);
+            v[q] = kk < ke ? x : 0.0;
+        }
+        s0 += v[0] * sp[c[0]]; s1 += v[1] * sp[c[1]]; s2 += v[2] * sp[c[2]]; s3 += v[3] * sp[c[3]];
+        s0 += v[4] * sp[c[4]]; s1 += v[5] * sp[c[5]]; s2 += v[6] * sp[c[6]]; s3 += v[7] * sp[c[7]];
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+template <int E>
+__global__ __launch_bounds__(512) void k_spcg_fused(SpcgFusedArgs a)
+{
+    constexpr int NT = 512, NW = NT / 64;
+    extern __shared__ double sp[];  // p_new, m doubles
+    __shared__ double sh[NW * 4];
+    const int tid = threadIdx.x, m = a.m, in = a.in, out = in ^ 1;
+    const bool lead = blockIdx.x == 0;
+    if (a.first) {
+        // first launch of a batch: no step, p = the host's p; block 0 moves r, p and the scalars to the other parity
+        for (int i = tid; i < m; i += NT) {
+            const double pi = a.p[in][i];
+            sp[i] = pi;
+            if (lead) { a.p[out][i] = pi; a.r[out][i] = a.r[in][i]; }
+        }
+        if (lead && tid == 0) { a.bc[out].temp1 = a.st->temp1; a.bc[out].stop = SPCG_RUN; a.st->pad = out; }
+    } else {
+        const SpcgBc bc = a.bc[in];
+        if (bc.stop != SPCG_RUN) {
+            if (lead && tid == 0) a.bc[out] = bc;  // hand the verdict on to the launches queued behind
+            return;
+        }
+        const double temp1 = bc.temp1;
+        const double *rp = a.r[in], *pp = a.p[in], *tp_ = a.t[in];
+        double pi[E], ti[E], ri[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = min(tid + e * NT, m - 1);
+            pi[e] = pp[i]; ti[e] = tp_[i]; ri[e] = rp[i];
+        }
+        double v1[1] = {0.0};
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (tid + e * NT < m) v1[0] += ti[e] * pi[e];
+        blk_reduce<1, NW>(v1, sh);
+        const double tp = v1[0];
+        SpcgState& S = *a.st;
+        if (!(fabs(tp) > 1e-40)) {  // KrySPcg.c:172-177: breakdown, nothing is updated
+            if (lead && tid == 0) {
+                S.tp = tp; S.iter = S.iter + 1; S.stop = SPCG_DIV0;
+                a.bc[out].temp1 = temp1; a.bc[out].stop = SPCG_DIV0;
+            }
+            return;
+        }
+        const double alpha = temp1 / tp;
+        v1[0] = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (tid + e * NT < m) {
+                ri[e] = ri[e] - alpha * ti[e];
+                v1[0] += ri[e] * ri[e];
+            }
+        }
+        blk_reduce<1, NW>(v1, sh);
+        const double rr = v1[0], beta = rr / temp1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = tid + e * NT;
+            if (i < m) sp[i] = 1.0 * ri[e] + beta * pi[e];
+        }
+        if (lead) {
+            const double absres_best = S.absres_best, normr0 = S.normr0, tol = S.tol, maxdiff = S.maxdiff;
+            const int it = S.iter + 1, stag = S.stag, MaxIt = S.MaxIt;
+            int iter_best = S.iter_best;
+            double red[4] = {0.0, 0.0, 0.0, 0.0};  // (u,u), (p,p), max |u|, NaN count
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = tid + e * NT;
+                if (i < m) {
+                    const double ui = a.u[i] + alpha * pi[e];
+                    a.u[i] = ui;
+                    a.r[out][i] = ri[e];
+                    a.p[out][i] = sp[i];
+                    red[0] += ui * ui; red[1] += pi[e] * pi[e];
+                    red[2] = fmax(red[2], fabs(ui));
+                    red[3] += (ui != ui) ? 1.0 : 0.0;
+                }
+            }
+            blk_reduce<4, NW>(red, sh, 1u << 2);  // (also orders the reads of S above before thread 0 rewrites it)
+            const double absres = sqrt(rr), relres = absres / normr0;
+            int    stop = SPCG_RUN;
+            double best = absres_best;
+            if (red[3] > 0.0) stop = SPCG_NAN;
+            else {
+                if (absres < absres_best - maxdiff) {
+                    best = absres; iter_best = it;
+                    for (int i = tid; i < m; i += NT) a.u_best[i] = a.u[i];  // own stores of this thread
+                }
+                const double reldiff = fabs(alpha) * sqrt(red[1]) / sqrt(red[0]);
+                if (red[2] <= 1e-20) stop = SPCG_SOLSTAG;                        // Check I
+                else if ((stag <= 20) & (reldiff < maxdiff)) stop = SPCG_STAG;   // Check II: host recomputes r
+                else if (relres < tol) stop = SPCG_CONV;                         // Check III: host checks the true residual
+                if (stop == SPCG_RUN && it >= MaxIt) stop = SPCG_MAXIT;
+            }
+            if (tid == 0) {
+                S.tp = tp; S.rr = rr; S.uu = red[0]; S.pp = red[1]; S.maxu = red[2]; S.nan = red[3];
+                S.alpha = alpha; S.absres = absres; S.relres = relres;
+                S.absres_best = best; S.iter_best = iter_best; S.iter = it;
+                S.temp1_prev = temp1;
+                S.temp1 = rr;
+                S.stop = stop;
+                S.pad = out;  // parity of the buffers that now hold r and p
+                a.bc[out].temp1 = rr; a.bc[out].stop = stop;
+            }
+            return;
+        }
+    }
+    if (lead) return;
+    __syncthreads();
+    // t_out = A p_new on the rows of this block: one wave per row, rows dealt round-robin over all waves
+    const int lane = tid & 63;
+    const int nwaves = ((int)gridDim.x - 1) * NW;
+    double* t_out = a.t[out];
+    for (int row = ((int)blockIdx.x - 1) * NW + (tid >> 6); row < m; row += nwaves) {
+        const int kb = a.ia[row], ke = a.ia[row + 1];
+        double s = 0.0;
+        if (ke > kb) s = a.ja16 ? fused_row_sum(a.ja16, a.val, sp, kb + lane, ke) : fused_row_sum(a.ja, a.val, sp, kb + lane, ke);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) t_out[row] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Variable-restart GMRES without preconditioner, STOP_REL_RES (KryPvgmres.c:66 / :416)
 // ---------------------------------------------------------------------------
 template <class OP>

@@ -206,6 +206,7 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
             if (q) (void)hipFree(q);
     if (h->gm_hh) (void)hipFree(h->gm_hh);
     if (h->spcg_state) (void)hipFree(h->spcg_state);
+    if (h->spcg_fused_buf) (void)hipFree(h->spcg_fused_buf);
     delete h;
 }
 
@@ -1610,6 +1611,8 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "lds_tab")) g_tune.lds_tab = value;
     else if (!std::strcmp(key, "xcd_pat")) g_tune.xcd_pat = value;
     else if (!std::strcmp(key, "spcg_batch")) g_tune.spcg_batch = value;
+    else if (!std::strcmp(key, "spcg_fused")) g_tune.spcg_fused = value;
+    else if (!std::strcmp(key, "spcg_grid")) g_tune.spcg_grid = value;
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
     else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;

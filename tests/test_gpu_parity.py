@@ -427,14 +427,16 @@ def modrel(i, p): jac(i, p); i.stop_type = T.STOP_MOD_REL_RES
 def wcyc(i, p): jac(i, p); p.cycle_type = T.W_CYCLE
 def scal(i, p): jac(i, p); p.coarse_scaling = 1
 def two(i, p): jac(i, p); p.max_levels = 2   # coarsest = level 1: thousands of rows (loop version of the step kernel)
-for n, mod in ((10, modrel), (16, jac), (12, wcyc), (20, scal), (24, two), (30, two)):
+# spcg_fused 1: one launch per iteration (k_spcg_fused; coarsest levels of at most 8192 rows); 0: SpMV + step kernel
+for fused, n, mod in [(fz, n, mod) for fz in (1, 0) for n, mod in ((10, modrel), (16, jac), (12, wcyc), (20, scal), (24, two), (30, two))]:
+    fa.lib().fasp_hip_tune(b"spcg_fused", fused)
     ia, ja, a, f, ue = poisson7pt(n)
     i1, a1 = default_params(); mod(i1, a1); i2, a2 = default_params(); mod(i2, a2)
     s1, x1, h1, rr = orc_solve(ia, ja, a, f, i1, a1)
     x2 = np.zeros(len(f))
     s2 = fa.solver_dcsr_krylov_amg(ia, ja, a, f, x2, i2, a2)
-    assert s1 == s2, (n, mod.__name__, s1, s2)
-    assert np.abs(x1 - x2).max() <= 1e-8 * np.abs(x1).max(), (n, mod.__name__)
+    assert s1 == s2, (fused, n, mod.__name__, s1, s2)
+    assert np.abs(x1 - x2).max() <= 1e-8 * np.abs(x1).max(), (fused, n, mod.__name__)
 print("OK")
 ''' % (ROOT, ROOT)
     env = dict(os.environ, FASP_HIP_SMALL_COARSE="0")
