@@ -69,6 +69,19 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
     hipStream_t s = g_ctx.stream;
     (void)prtlvl;
 
+    // one launch per iteration (k_spcg_fused) when p fits the LDS of a CU and the level is stored as plain CSR
+    const bool fused = g_tune.spcg_fused && m <= 512 * 16 && A.val && A.ja && !A.code && !A.pat;
+    if (!h->spcg_state) HIPCK(hipMalloc(&h->spcg_state, sizeof(SpcgState)));
+    if (fused) {  // the start of the solve on the device too: no host round trip before the first batch
+        if (!D.x_zero) d_resid(A, u, b, r);
+        SpcgInitArgs ia{};
+        ia.m = m; ia.x_zero = D.x_zero ? 1 : 0; ia.MaxIt = MaxIt; ia.tol = tol; ia.maxdiff = maxdiff;
+        ia.b = b; ia.u = u; ia.r = r; ia.p = p; ia.u_best = u_best; ia.st = h->spcg_state;
+        hipLaunchKernelGGL(k_spcg_init, dim3(1), dim3(512), 0, s, ia);
+        D.x_zero = false;
+        goto ITERATE;
+    }
+
     // u_best starts as zeros (calloc'ed work array, KrySPcg.c:88)
     HIPCK(hipMemsetAsync(u_best, 0, sizeof(double) * m, s));
 
@@ -88,20 +101,24 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
     HIPCK(hipMemcpyAsync(p, r, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
     temp1 = red[0];
 
+ITERATE:
     {
         // Device-resident iteration state; the host queues `batch` iterations (SpMV + step kernel
         // each) without waiting and synchronises once per batch.  When one of the reference's
         // tests fires, k_spcg_step raises `stop`, the launches queued behind it return at once,
         // and the branch is replayed here from the recorded scalars (KrySPcg.c:172-330).
-        const int batch = std::max(1, std::min(g_tune.spcg_batch > 0 ? g_tune.spcg_batch : 8, 64));
-        if (!h->spcg_state) HIPCK(hipMalloc(&h->spcg_state, sizeof(SpcgState)));
+        // the first batch is sized by the previous solve on this level (the count hardly moves from cycle to
+        // cycle): normally one synchronisation per solve; 1 + iterations launches, the first one has no step
+        int batch = std::max(1, std::min(g_tune.spcg_batch > 0 ? g_tune.spcg_batch : 8, 64));
+        const int batch_next = batch;
+        if (fused && h->spcg_last_iters > 0) batch = std::max(4, std::min(h->spcg_last_iters + 1, 96));
         SpcgState S{};
-        S.temp1 = temp1; S.temp1_prev = temp1; S.absres_best = absres_best; S.normr0 = normr0; S.tol = tol;
-        S.maxdiff = maxdiff; S.iter = 0; S.iter_best = 0; S.stag = stag; S.MaxIt = MaxIt; S.stop = SPCG_RUN;
-        S.absres = absres; S.relres = relres; S.alpha = 0.0;  // values before the first iteration
-        HIPCK(hipMemcpyAsync(h->spcg_state, &S, sizeof(S), hipMemcpyHostToDevice, s));
-        // one launch per iteration (k_spcg_fused) when p fits the LDS of a CU and the level is stored as plain CSR
-        const bool fused = g_tune.spcg_fused && m <= 512 * 16 && A.val && A.ja && !A.code && !A.pat;
+        if (!fused) {
+            S.temp1 = temp1; S.temp1_prev = temp1; S.absres_best = absres_best; S.normr0 = normr0; S.tol = tol;
+            S.maxdiff = maxdiff; S.iter = 0; S.iter_best = 0; S.stag = stag; S.MaxIt = MaxIt; S.stop = SPCG_RUN;
+            S.absres = absres; S.relres = relres; S.alpha = 0.0;  // values before the first iteration
+            HIPCK(hipMemcpyAsync(h->spcg_state, &S, sizeof(S), hipMemcpyHostToDevice, s));
+        }
         double *R[2] = {r, nullptr}, *P[2] = {p, nullptr}, *T[2] = {t, nullptr};
         SpcgBc* bc = nullptr;
         int  cur = 0;        // parity of the buffers that hold r and p
@@ -141,6 +158,11 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
             HIPCK(hipStreamSynchronize(s));
             std::memcpy(&S, g_ctx.h_part, sizeof(S));
             iter = S.iter; absres_best = S.absres_best; iter_best = S.iter_best;
+            batch = batch_next;
+            if (fused) {
+                normr0 = S.normr0;
+                if (S.stop == SPCG_ZERO_RHS) { relres = S.relres; goto FINISHED; }  // KrySPcg.c:135
+            }
             if (S.stop == SPCG_RUN) continue;
             if (fused) { cur = S.pad; r = R[cur]; p = P[cur]; first = true; }  // where the last finished step left r and p
             // a test fired in iteration S.iter: finish that iteration as the reference does
@@ -200,7 +222,7 @@ RESTORE_BESTSOL:
     }
 FINISHED:
     if (std::getenv("FASP_HIP_DEBUG_COARSE")) std::printf("[coarse batched] iter %d relres %.6e absres %.6e best %d\n", iter, relres, absres, iter_best);
-    if (iter > 0) h->coarse_iters += iter;
+    if (iter > 0) { h->coarse_iters += iter; h->spcg_last_iters = iter; }
     if (iter > MaxIt) return ERROR_SOLVER_MAXIT;
     return iter;
 }

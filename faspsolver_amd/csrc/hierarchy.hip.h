@@ -57,6 +57,7 @@ struct fasp_hip_amg {
     size_t               gm_len[2] = {0, 0};
     double*              gm_hh = nullptr;  // device Hessenberg column
     double*              spcg_fused_buf = nullptr;  // second parity of r, p, t and the broadcast record (k_spcg_fused)
+    int                  spcg_last_iters = 0;   // iterations of the previous coarse solve: sizes the first batch of the next one
     SpcgState*           spcg_state = nullptr;  // device-resident state of the batched coarse CG
     std::vector<double>  amli_coef;             // AMLI polynomial coefficients (amli_degree + 1), formed on first use
     std::vector<int>     level_cycle_type;      // AMG_data.cycle_type per level as the setup leaves it (K-cycle)

@@ -336,7 +336,7 @@ FINISHED:
 // residual, restart, ...) from the recorded scalars and resumes.  One synchronisation per batch
 // instead of one per iteration.
 // ---------------------------------------------------------------------------
-enum SpcgStop : int { SPCG_RUN = 0, SPCG_CONV = 1, SPCG_STAG = 2, SPCG_NAN = 3, SPCG_DIV0 = 4, SPCG_SOLSTAG = 5, SPCG_MAXIT = 6 };
+enum SpcgStop : int { SPCG_RUN = 0, SPCG_CONV = 1, SPCG_STAG = 2, SPCG_NAN = 3, SPCG_DIV0 = 4, SPCG_SOLSTAG = 5, SPCG_MAXIT = 6, SPCG_ZERO_RHS = 7 };
 struct SpcgState {
     double temp1, temp1_prev, absres_best, normr0, tol, maxdiff;  // inputs carried from step to step
     double tp, rr, uu, pp, maxu, nan, alpha, absres, relres;  // scalars of the latest step
@@ -528,6 +528,40 @@ __device__ __forceinline__ double fused_row_sum(const IDX* __restrict__ ja, cons
     return (s0 + s1) + (s2 + s3);
 }
 
+// Start of a coarse solve without a host round trip (KrySPcg.c:88-135): r = b (u = 0 on entry from the cycle; otherwise
+// the caller has put b - A u into r), u_best = 0, p = r, and the iteration state from (r,r).
+struct SpcgInitArgs {
+    int m, x_zero, MaxIt;
+    double tol, maxdiff;
+    const double* b;
+    double *u, *r, *p, *u_best;
+    SpcgState* st;
+};
+__global__ __launch_bounds__(512) void k_spcg_init(SpcgInitArgs a)
+{
+    constexpr int NT = 512, NW = NT / 64;
+    __shared__ double sh[NW];
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < a.m; i += NT) {
+        double ri;
+        if (a.x_zero) { ri = a.b[i]; a.r[i] = ri; a.u[i] = 0.0; }
+        else ri = a.r[i];
+        a.p[i] = ri;
+        a.u_best[i] = 0.0;
+        v[0] += ri * ri;
+    }
+    blk_reduce<1, NW>(v, sh);
+    if (threadIdx.x == 0) {
+        const double absres0 = sqrt(v[0]), normr0 = fmax(1e-20, absres0);  // SMALLREAL
+        SpcgState S{};
+        S.temp1 = v[0]; S.temp1_prev = v[0]; S.absres_best = 1e+20; S.normr0 = normr0; S.tol = a.tol; S.maxdiff = a.maxdiff;
+        S.absres = 1e+20; S.relres = absres0 / normr0; S.rr = v[0];
+        S.iter = 0; S.iter_best = 0; S.stag = 1; S.MaxIt = a.MaxIt; S.pad = 0;
+        S.stop = (S.relres < a.tol) ? SPCG_ZERO_RHS : SPCG_RUN;
+        *a.st = S;
+    }
+}
+
 template <int E>
 __global__ __launch_bounds__(512) void k_spcg_fused(SpcgFusedArgs a)
 {
@@ -543,7 +577,8 @@ __global__ __launch_bounds__(512) void k_spcg_fused(SpcgFusedArgs a)
             sp[i] = pi;
             if (lead) { a.p[out][i] = pi; a.r[out][i] = a.r[in][i]; }
         }
-        if (lead && tid == 0) { a.bc[out].temp1 = a.st->temp1; a.bc[out].stop = SPCG_RUN; a.st->pad = out; }
+        // (a zero right-hand side: k_spcg_init has raised the stop already; this product is then idle work)
+        if (lead && tid == 0) { a.bc[out].temp1 = a.st->temp1; a.bc[out].stop = a.st->stop; a.st->pad = out; }
     } else {
         const SpcgBc bc = a.bc[in];
         if (bc.stop != SPCG_RUN) {
