@@ -1324,8 +1324,9 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
                         amg->coarsening_type);
             return ERROR_AMG_COARSE_TYPE;
         }
-        if (amg->AMG_type == CLASSIC_AMG && amg->interpolation_type != INTERP_DIR && amg->interpolation_type != INTERP_STD) {
-            std::printf("### ERROR: fasp_hip: interpolation_type %d not supported (INTERP_DIR and INTERP_STD only)\n",
+        if (amg->AMG_type == CLASSIC_AMG && amg->interpolation_type != INTERP_DIR && amg->interpolation_type != INTERP_STD &&
+            amg->interpolation_type != INTERP_EXT) {
+            std::printf("### ERROR: fasp_hip: interpolation_type %d not supported (INTERP_DIR, INTERP_STD and INTERP_EXT only)\n",
                         amg->interpolation_type);
             return ERROR_AMG_INTERP_TYPE;
         }
@@ -1444,7 +1445,9 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
                 break;
             }
             // the standard pattern (no F-F clean-up, PreAMGCoarsenRS.c:152) is forced for aggressive coarsening (:96)
-            const bool std_pattern = agg || param->interpolation_type == INTERP_STD;
+            // (INTERP_EXT is the same pattern and, in the reference, the same text as interp_STD: PreAMGInterp.c:760 vs :547)
+            const bool std_like = param->interpolation_type == INTERP_STD || param->interpolation_type == INTERP_EXT;
+            const bool std_pattern = agg || std_like;
             if (!std_pattern) col = clean_ff_couplings(S, vertices.data(), Lv.A.row, col);
             lap("FF clean-up");
             if (col < MIN_CDOF) break;  // Check 2, :176-181
@@ -1465,7 +1468,7 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 
             // PreAMGInterp.c:68-71 looks at coarsening_type AFTER the switch above: on the level where aggressive
             // coarsening ends, the user's interpolation fills the standard pattern
-            if (param->interpolation_type == INTERP_STD || param->coarsening_type == COARSE_AC)
+            if (std_like || param->coarsening_type == COARSE_AC)
                 build_interp_std(Lv.A, S, vertices.data(), *param, Lv.P);
             else build_interp_dir(Lv.A, S, vertices.data(), *param, Lv.P, std_pattern);  // :209
             lap("interpolation");

@@ -104,7 +104,7 @@ def _matrix(name):
 
 
 @pytest.mark.parametrize("coarsening", [1, 2], ids=["RS", "RSP"])
-@pytest.mark.parametrize("interp", [1, 2], ids=["direct", "standard"])
+@pytest.mark.parametrize("interp", [1, 2, 6], ids=["direct", "standard", "extended"])
 @pytest.mark.parametrize("name", ["9", "28", "fe", "pos16"])
 def test_hierarchy_bit_exact_oracle_and_product(R, fa, name, interp, coarsening):
     """Direct (PreAMGInterp.c:302) and standard (:547, pattern PreAMGCoarsenRS.c:2006) interpolation; classical
