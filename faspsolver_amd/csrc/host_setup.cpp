@@ -604,6 +604,31 @@ int cfsplitting_agg(const Pattern& S, int* vec, int aggressive_path)
     return col;
 }
 
+// COARSE_MIS (PreAMGCoarsenRS.c:120-128): greedy maximal independent set of the strength graph (cfsplitting_mis,
+// :2127) in the order of ordering1 (:2179): natural order, the first vertex of highest degree swapped to the front.
+int cfsplitting_mis(const Pattern& S, int* vec)
+{
+    const int n = S.row;
+    int col = 0, maxind = 0, maxdeg = 0;
+    for (int i = 0; i < n; ++i) {
+        const int degree = S.ia[i + 1] - S.ia[i];
+        if (degree > maxdeg) { maxind = i; maxdeg = degree; }
+    }
+    std::fill(vec, vec + n, (int)UNPT);
+    for (int i = 0; i < n; ++i) {
+        const int ind = (i == 0) ? maxind : (i == maxind ? 0 : i);
+        if (vec[ind] != UNPT) continue;
+        bool c_neighbour = false;
+        for (int j = S.ia[ind]; j < S.ia[ind + 1]; ++j)
+            if (vec[S.ja[j]] == CGPT) { c_neighbour = true; break; }
+        if (c_neighbour) { vec[ind] = FGPT; continue; }
+        vec[ind] = CGPT;
+        ++col;
+        for (int j = S.ia[ind]; j < S.ia[ind + 1]; ++j) vec[S.ja[j]] = FGPT;
+    }
+    return col;
+}
+
 // F-F couplings without a common C point (PreAMGCoarsenRS.c:1709-1781), with the
 // reference's "tentatively promote j, re-check i" roll-back (:1762-1769).
 int clean_ff_couplings(const Pattern& S, int* vec, int row, int col)
@@ -1319,8 +1344,8 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             return ERROR_INPUT_PAR;
         }
         if (amg->AMG_type == CLASSIC_AMG && amg->coarsening_type != COARSE_RS && amg->coarsening_type != COARSE_RSP &&
-            amg->coarsening_type != COARSE_AC) {
-            std::printf("### ERROR: fasp_hip: coarsening_type %d not supported (COARSE_RS, COARSE_RSP and COARSE_AC only)\n",
+            amg->coarsening_type != COARSE_AC && amg->coarsening_type != COARSE_MIS) {
+            std::printf("### ERROR: fasp_hip: coarsening_type %d not supported (COARSE_RS, COARSE_RSP, COARSE_AC and COARSE_MIS only)\n",
                         amg->coarsening_type);
             return ERROR_AMG_COARSE_TYPE;
         }
@@ -1426,7 +1451,10 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
             lap("strength");
             int col = -1;
             const bool agg = param->coarsening_type == COARSE_AC;
-            if (status >= 0)
+            if (param->coarsening_type == COARSE_MIS) {  // (the reference ignores an empty strength pattern here: every vertex is a C point then)
+                col = cfsplitting_mis(S, vertices.data());
+                status = FASP_SUCCESS;
+            } else if (status >= 0)
                 col = agg ? cfsplitting_agg(S, vertices.data(), param->aggressive_path)
                           : cfsplitting_cls(S, vertices.data(), rsp ? Lv.A.ia.data() : nullptr);
             if (status >= 0 && rsp) {  // :1020-1036: positive F-F couplings, then the pattern is compressed again
