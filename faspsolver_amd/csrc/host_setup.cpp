@@ -1004,6 +1004,77 @@ void build_interp_std(const HostCSR& A, const Pattern& S, const int* vec, const 
     finish_interp(row, vec, pia, pja, pval, param.truncation_threshold, P);
 }
 
+// Reduction-based AMG (INTERP_RDC).  rdc_theta: the diagonal-dominance measure of the F rows, min over rows
+// (form_P_pattern_rdc, PreAMGCoarsenRS.c:1796-1850: the diagonal itself counts in the F-row sum), and what the
+// reference derives from it (:167-202): theta raised to 0.5 + 1e-5 if needed, the weight of the F-point Jacobi smoother.
+void rdc_theta(const HostCSR& A, const int* vec, AMG_param& param)
+{
+    const int row = A.row;
+    double th = 1.0;
+#pragma omp parallel for schedule(static) reduction(min : th)
+    for (int i = 0; i < row; ++i) {
+        if (vec[i] == CGPT) continue;
+        double sum = 0.0;
+        int    diagptr = -1;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            const int j = A.ja[k];
+            if (vec[j] != CGPT) sum += dabs(A.val[k]);
+            if (j == i) diagptr = k;
+        }
+        if (diagptr > -1) th = std::min(th, dabs(A.val[diagptr]) / sum);
+    }
+    param.theta = th;
+    if (param.theta <= 0.5) {
+        if (param.print_level > PRINT_MIN)
+            std::printf("### WARNING: theta = %e <= 0.5, use %e instead \n", param.theta, 0.5 + 1e-5);
+        param.theta = 0.5 + 1e-5;
+    }
+    if (param.theta >= 0.0) {
+        const double t = param.theta, eps = (2 - 2 * t) / (2 * t - 1), sigma = 2 / (2 + eps);
+        if (param.smoother == SMOOTHER_JACOBIF) param.relaxation = sigma / (2 - 1 / t);
+    }
+}
+
+// P = [-(alpha D_FF)^{-1} A_FC; I], alpha = 2 - 1/theta (interp_RDC, PreAMGInterp.c:240-280); no truncation
+void build_interp_rdc(const HostCSR& A, const int* vec, const AMG_param& param, HostCSR& P)
+{
+    const int    row = A.row;
+    const double alpha = 2.0 - 1.0 / param.theta;
+    std::vector<int> cindex((size_t)row, 0);
+    int ncoarse = 0;
+    for (int i = 0; i < row; ++i)
+        if (vec[i] == CGPT) cindex[i] = ncoarse++;
+    P.row = row; P.col = ncoarse;
+    P.ia.alloc((size_t)row + 1);
+    P.ia[0] = 0;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        int c = 1;
+        if (vec[i] != CGPT) {
+            c = 0;
+            for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) c += (vec[A.ja[k]] == CGPT);
+        }
+        P.ia[i + 1] = c;
+    }
+    for (int i = 0; i < row; ++i) P.ia[i + 1] += P.ia[i];
+    P.nnz = P.ia[row];
+    P.ja.alloc((size_t)std::max(P.nnz, 1));
+    P.val.alloc((size_t)std::max(P.nnz, 1));
+    // (a row without a diagonal entry inherits the previous row's position in the reference: rows then depend on
+    // each other, which a matrix that reaches this point does not have -- theta would be undefined there)
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < row; ++i) {
+        int o = P.ia[i];
+        if (vec[i] == CGPT) { P.ja[o] = cindex[i]; P.val[o] = 1.0; continue; }
+        int idiag = A.ia[i];
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
+            if (A.ja[k] == i) { idiag = k; break; }
+        const double Dii = alpha * A.val[idiag];
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
+            if (vec[A.ja[k]] == CGPT) { P.ja[o] = cindex[A.ja[k]]; P.val[o++] = -A.val[k] / Dii; }
+    }
+}
+
 // stable counting transpose with values (BlaSparseCSR.c:952-1018)
 void transpose_csr(const HostCSR& A, HostCSR& AT)
 {
@@ -1350,8 +1421,10 @@ int check_supported(const ITS_param* it, const AMG_param* amg)
             return ERROR_AMG_COARSE_TYPE;
         }
         if (amg->AMG_type == CLASSIC_AMG && amg->interpolation_type != INTERP_DIR && amg->interpolation_type != INTERP_STD &&
-            amg->interpolation_type != INTERP_EXT) {
-            std::printf("### ERROR: fasp_hip: interpolation_type %d not supported (INTERP_DIR, INTERP_STD and INTERP_EXT only)\n",
+            amg->interpolation_type != INTERP_EXT && !(amg->interpolation_type == INTERP_RDC && amg->coarsening_type != COARSE_AC)) {
+            // (INTERP_RDC with aggressive coarsening: on the level where COARSE_AC ends the reference fills the standard
+            // pattern with interp_RDC's entry stream of a different length -- undefined there, refused here)
+            std::printf("### ERROR: fasp_hip: interpolation_type %d not supported (INTERP_DIR, INTERP_STD, INTERP_EXT, INTERP_RDC w/o COARSE_AC)\n",
                         amg->interpolation_type);
             return ERROR_AMG_INTERP_TYPE;
         }
@@ -1476,7 +1549,9 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
             // (INTERP_EXT is the same pattern and, in the reference, the same text as interp_STD: PreAMGInterp.c:760 vs :547)
             const bool std_like = param->interpolation_type == INTERP_STD || param->interpolation_type == INTERP_EXT;
             const bool std_pattern = agg || std_like;
-            if (!std_pattern) col = clean_ff_couplings(S, vertices.data(), Lv.A.row, col);
+            const bool rdc = !agg && param->interpolation_type == INTERP_RDC;
+            if (rdc) rdc_theta(Lv.A, vertices.data(), *param);  // :157-202, before the checks below as in the reference
+            else if (!std_pattern) col = clean_ff_couplings(S, vertices.data(), Lv.A.row, col);
             lap("FF clean-up");
             if (col < MIN_CDOF) break;  // Check 2, :176-181
             if (Lv.A.row > col * 10.0) {  // Check 3, :184-195
@@ -1496,7 +1571,8 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 
             // PreAMGInterp.c:68-71 looks at coarsening_type AFTER the switch above: on the level where aggressive
             // coarsening ends, the user's interpolation fills the standard pattern
-            if (std_like || param->coarsening_type == COARSE_AC)
+            if (rdc) build_interp_rdc(Lv.A, vertices.data(), *param, Lv.P);
+            else if (std_like || param->coarsening_type == COARSE_AC)
                 build_interp_std(Lv.A, S, vertices.data(), *param, Lv.P);
             else build_interp_dir(Lv.A, S, vertices.data(), *param, Lv.P, std_pattern);  // :209
             lap("interpolation");

@@ -223,18 +223,22 @@ def _mis_ext(itp, amgp):  # maximal-independent-set splitting (cfsplitting_mis, 
     _jac(itp, amgp); amgp.coarsening_type = T.COARSE_MIS; amgp.interpolation_type = T.INTERP_EXT
 
 
+def _rdc_jacf(itp, amgp):  # reduction-based AMG (interp_RDC, PreAMGInterp.c:240): the setup derives the F-Jacobi weight from theta
+    itp.tol = 1e-8; amgp.interpolation_type = T.INTERP_RDC; amgp.smoother = T.SMOOTHER_JACOBIF
+
+
 def _jacf23(itp, amgp):
     itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_JACOBIF; amgp.presmooth_iter = 2; amgp.postsmooth_iter = 3
 
 
 @pytest.mark.parametrize("n", [8, 16, 32, 48])
 @pytest.mark.parametrize("mod", [_jac, _jac_w, _l1, _jac22, _jac_cs, _poly3, _poly5w, _poly1, _jacf, _jacf23, _stdint,
-                                 _amli1, _amli2cs, _amli3gs, _namli_gcg, _namli_gcr_gs, _namli_ua, _fmg, _fmg_gs_cs, _gsf2w, _cgsm, _rsp, _ac2, _ac1w, _mis_ext],
+                                 _amli1, _amli2cs, _amli3gs, _namli_gcg, _namli_gcr_gs, _namli_ua, _fmg, _fmg_gs_cs, _gsf2w, _cgsm, _rsp, _ac2, _ac1w, _mis_ext, _rdc_jacf],
                          ids=["jacobi-V", "jacobi-W", "l1diag-V", "jacobi-V22", "jacobi-V-coarse-scaling",
                               "poly3-V", "poly5-W", "poly1-V", "jacobiF-V", "jacobiF-V23", "jacobi-V-std-interp",
                               "jacobi-AMLI1", "jacobi-AMLI2-coarse-scaling", "gs-AMLI3",
                               "jacobi-Kcycle-GCG", "gs-Kcycle-GCR", "jacobi-Kcycle-UA-pairwise", "jacobi-FMG", "gs-FMG-coarse-scaling", "gsF-W22", "cg-smoother-V33", "jacobi-V-RSP-std",
-                              "jacobi-V-aggressive2", "jacobi-W-aggressive1-std", "jacobi-V-MIS-ext"])
+                              "jacobi-V-aggressive2", "jacobi-W-aggressive1-std", "jacobi-V-MIS-ext", "jacobiF-V-reduction"])
 def test_pcg_history_poisson(gpu, n, mod):
     if n == 48 and mod is not _jac:
         pytest.skip("largest size only for the headline configuration")

@@ -67,12 +67,14 @@ def _mods():
     def ac2_std_w(i, a): vfg(i, a); a.coarsening_type = T.COARSE_AC; a.aggressive_path = 2; a.interpolation_type = 2; a.cycle_type = T.W_CYCLE; a.aggressive_level = 2
     def ac1(i, a): jac(i, a); a.coarsening_type = T.COARSE_AC
     def mis(i, a): jac(i, a); a.coarsening_type = T.COARSE_MIS
+    def rdc_jacf(i, a): i.tol = 1e-8; a.interpolation_type = T.INTERP_RDC; a.smoother = T.SMOOTHER_JACOBIF   # reduction-based AMG: the setup sets the F-Jacobi weight
+    def rdc_gs_w(i, a): i.tol = 1e-8; a.interpolation_type = T.INTERP_RDC; a.cycle_type = T.W_CYCLE
     def mis_ext_w(i, a): jac(i, a); a.coarsening_type = T.COARSE_MIS; a.interpolation_type = T.INTERP_EXT; a.cycle_type = T.W_CYCLE
     def vgpre(i, a): vg(i, a); i.stop_type = T.STOP_REL_PRECRES
     def vfgmod(i, a): vfg(i, a); i.stop_type = T.STOP_MOD_REL_RES
     return dict(jac=jac, jacw=jacw, vw=vw, l1=l1, gscf=gscf, gsn=gsn, sor=sor, ssor=ssor, sgs=sgs,
                 theta=theta, precres=precres, modres=modres, gsor=gsor, sgsor=sgsor, vg=vg, vg4=vg4, vfg=vfg, vfg5w=vfg5w,
-                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w, amli1=amli1, amli2gs=amli2gs, amli2cs=amli2cs, amli0=amli0, amli3vg=amli3vg, namli_gcg=namli_gcg, namli_gcr_gs=namli_gcr_gs, namli_ua=namli_ua, namli_sa_vfg=namli_sa_vfg, fmg=fmg, fmg_gs_cs=fmg_gs_cs, fmg_sa_vfg=fmg_sa_vfg, gsf2w=gsf2w, cgsm1=cgsm1, cgsm3=cgsm3, ac2=ac2, ac2_std_w=ac2_std_w, ac1=ac1, mis=mis, mis_ext_w=mis_ext_w)
+                vgpre=vgpre, vfgmod=vfgmod, poly3=poly3, poly5w=poly5w, poly1=poly1, jacf=jacf, jacf2=jacf2, stdint=stdint, stdint_w=stdint_w, amli1=amli1, amli2gs=amli2gs, amli2cs=amli2cs, amli0=amli0, amli3vg=amli3vg, namli_gcg=namli_gcg, namli_gcr_gs=namli_gcr_gs, namli_ua=namli_ua, namli_sa_vfg=namli_sa_vfg, fmg=fmg, fmg_gs_cs=fmg_gs_cs, fmg_sa_vfg=fmg_sa_vfg, gsf2w=gsf2w, cgsm1=cgsm1, cgsm3=cgsm3, ac2=ac2, ac2_std_w=ac2_std_w, ac1=ac1, mis=mis, mis_ext_w=mis_ext_w, rdc_jacf=rdc_jacf, rdc_gs_w=rdc_gs_w)
 
 
 @pytest.mark.parametrize("name", list(_mods().keys()))
@@ -106,7 +108,7 @@ def _matrix(name):
 
 
 @pytest.mark.parametrize("coarsening", [1, 2, 5], ids=["RS", "RSP", "MIS"])
-@pytest.mark.parametrize("interp", [1, 2, 6], ids=["direct", "standard", "extended"])
+@pytest.mark.parametrize("interp", [1, 2, 6, 4], ids=["direct", "standard", "extended", "reduction"])
 @pytest.mark.parametrize("name", ["9", "28", "fe", "pos16"])
 def test_hierarchy_bit_exact_oracle_and_product(R, fa, name, interp, coarsening):
     """Direct (PreAMGInterp.c:302) and standard (:547, pattern PreAMGCoarsenRS.c:2006) interpolation; classical
