@@ -70,7 +70,8 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
     (void)prtlvl;
 
     // one launch per iteration (k_spcg_fused) when p fits the LDS of a CU and the level is stored as plain CSR
-    const bool fused = g_tune.spcg_fused && m <= 512 * 16 && A.val && A.ja && !A.code && !A.pat;
+    // (p in LDS: 8 m bytes of dynamic LDS next to the reduction scratch, within the 64 KB a kernel gets without opting in)
+    const bool fused = g_tune.spcg_fused && m <= 8000 && A.val && A.ja && !A.code && !A.pat;
     if (!h->spcg_state) HIPCK(hipMalloc(&h->spcg_state, sizeof(SpcgState)));
     if (fused) {  // the start of the solve on the device too: no host round trip before the first batch
         if (!D.x_zero) d_resid(A, u, b, r);

@@ -71,6 +71,11 @@ def test_unsupported_parameters_are_refused_before_any_work(fa):
     cases.append((it, am, T.ERROR_SOLVER_TYPE))
     it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.interpolation_type = 3   # INTERP_ENG
     cases.append((it, am, T.ERROR_AMG_INTERP_TYPE))
+    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI
+    am.interpolation_type = T.INTERP_RDC; am.coarsening_type = T.COARSE_AC   # undefined in the reference
+    cases.append((it, am, T.ERROR_AMG_INTERP_TYPE))
+    it, am = fa.param_solver_init(), fa.param_amg_init(); am.smoother = T.SMOOTHER_JACOBI; am.coarsening_type = T.COARSE_CR
+    cases.append((it, am, T.ERROR_AMG_COARSE_TYPE))
     for it, am, code in cases:
         assert fa.solver_dcsr_krylov_amg(ia, ja, a, f, x, it, am) == code
         assert np.all(x == 0.0)
