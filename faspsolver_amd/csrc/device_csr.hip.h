@@ -474,12 +474,16 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
         a.ntiles = (M.row + BLOCK * rpl - 1) / (BLOCK * rpl);
         a.tiles_per_xcd = (a.ntiles + 7) / 8;
         (void)avg;
-        if (lds) {
-            if (rpl == 1) return launch_persistent(k_csr_rowpat<OP, true, 1>, a.ntiles, a);
-            return launch_persistent(k_csr_rowpat<OP, true, 2>, a.ntiles, a);
+        if (lds && M.npat <= 64 && M.npent <= 512 && g_tune.lds_tab != 3) {  // small table: more resident blocks
+            if (rpl == 1) return launch_persistent(k_csr_rowpat<OP, 2, 1>, a.ntiles, a);
+            return launch_persistent(k_csr_rowpat<OP, 2, 2>, a.ntiles, a);
         }
-        if (rpl == 1) return launch_persistent(k_csr_rowpat<OP, false, 1>, a.ntiles, a);
-        return launch_persistent(k_csr_rowpat<OP, false, 2>, a.ntiles, a);
+        if (lds) {
+            if (rpl == 1) return launch_persistent(k_csr_rowpat<OP, 1, 1>, a.ntiles, a);
+            return launch_persistent(k_csr_rowpat<OP, 1, 2>, a.ntiles, a);
+        }
+        if (rpl == 1) return launch_persistent(k_csr_rowpat<OP, 0, 1>, a.ntiles, a);
+        return launch_persistent(k_csr_rowpat<OP, 0, 2>, a.ntiles, a);
     }
     if (M.kind == 4) {
         a.code = M.code; a.rowbase = M.rowbase; a.doff = M.doff; a.dval = M.dval;

@@ -580,12 +580,14 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, unsign
     return __builtin_bit_cast(double, v);
 }
 
-template <int OP, bool LDS_TAB, int RPL>
+// LDS_TAB: 0 table in global memory; 1 in LDS, up to 512 patterns / 2048 entries (28 KB: five blocks per CU);
+// 2 in LDS, up to 64 patterns / 512 entries (6.5 KB: the register file bounds the occupancy, not the LDS)
+template <int OP, int LDS_TAB, int RPL>
 __global__ __launch_bounds__(BLOCK) void k_csr_rowpat(CsrArgs a)
 {
     if (a.stop && *a.stop) return;
     constexpr int U = 8;
-    constexpr int MAXP = 512, MAXE = 2048;
+    constexpr int MAXP = LDS_TAB == 2 ? 64 : 512, MAXE = LDS_TAB == 2 ? 512 : 2048;
     __shared__ int    s_start[LDS_TAB ? MAXP : 1];
     __shared__ int    s_len[LDS_TAB ? MAXP : 1];
     __shared__ int    s_off[LDS_TAB ? MAXE : 1];
