@@ -29,8 +29,12 @@ struct DevCSR {
     double* pval = nullptr;
     int     npat = 0, npent = 0;
     unsigned short* ja16 = nullptr;  // JA as 16-bit values (long-row operators with <= 65536 columns)
+    int*    xrows = nullptr;         // k_csr_rowpat4: rows outside their wave's uniform pattern (square coded operators)
+    int     nxrows = -1;             // -1: no list (k_csr_rowpat4 not applicable)
     void    release()
     {
+        if (xrows) (void)hipFree(xrows);
+        xrows = nullptr; nxrows = -1;
         if (ja16) (void)hipFree(ja16);
         ja16 = nullptr;
         if (ia) (void)hipFree(ia);
@@ -333,7 +337,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
         static const bool rowpat_on = !(std::getenv("FASP_HIP_ROWPAT") && std::atoi(std::getenv("FASP_HIP_ROWPAT")) == 0);
         if (rowpat_on && build_rowpat(H, pat, pstart, plen, poff, pval, prb)) {
             D.npat = (int)pstart.size(); D.npent = (int)poff.size();
-            HIPCK(hipMalloc(&D.pat, sizeof(unsigned short) * (size_t)H.row));
+            HIPCK(hipMalloc(&D.pat, sizeof(unsigned short) * ((size_t)H.row + 2)));  // + pad: the pair kernels load two ids at once
             HIPCK(hipMalloc(&D.pstart, sizeof(int) * pstart.size()));
             HIPCK(hipMalloc(&D.plen, sizeof(int) * plen.size()));
             HIPCK(hipMemcpy(D.plen, plen.data(), sizeof(int) * plen.size(), hipMemcpyHostToDevice));
@@ -346,6 +350,23 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
             if (prb.n) {
                 HIPCK(hipMalloc(&D.rowbase, sizeof(int) * (size_t)H.row));
                 HIPCK(hipMemcpy(D.rowbase, prb.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
+            } else {
+                // k_csr_rowpat4 (kernels2.hip.h): the sweep computes the row pairs (2i, 2i+1) whose two rows have the
+                // pattern of row 128 w + 64 of their wave tile w; every other row goes on this list.
+                const int nr = H.row, npair = (nr + 1) / 2;
+                std::vector<int> xr;
+                for (int w0 = 0; w0 < nr; w0 += 128) {
+                    const unsigned dom = pat[(size_t)2 * std::min((w0 + 64) / 2, npair - 1)];
+                    for (int r = w0; r < std::min(w0 + 128, nr); r += 2) {
+                        const bool vb = r + 1 < nr;
+                        if (!(vb && pat[r] == dom && pat[r + 1] == dom)) { xr.push_back(r); if (vb) xr.push_back(r + 1); }
+                    }
+                }
+                if ((long long)xr.size() * 4 <= nr) {  // worth it when most rows are swept
+                    D.nxrows = (int)xr.size();
+                    HIPCK(hipMalloc(&D.xrows, sizeof(int) * std::max<size_t>(xr.size(), 1)));
+                    HIPCK(hipMemcpy(D.xrows, xr.data(), sizeof(int) * xr.size(), hipMemcpyHostToDevice));
+                }
             }
             D.kind = 2;  // plain-CSR twin of a coded operator: the stream kernel (same row-sum order; used by the A/B tests)
             return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
@@ -412,7 +433,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0; };
+struct Tuning { int gen2 = 1, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -432,9 +453,9 @@ static int resident_blocks_per_cu(K kernel)
 }
 
 template <class K>
-static int launch_persistent(K kernel, int ntiles, CsrArgs& a)
+static int launch_persistent(K kernel, int ntiles, CsrArgs& a, int blocks_per_cu = 0)
 {
-    int cap = resident_blocks_per_cu(kernel) * g_ctx.num_cu;
+    int cap = (blocks_per_cu > 0 ? std::min(blocks_per_cu, resident_blocks_per_cu(kernel)) : resident_blocks_per_cu(kernel)) * g_ctx.num_cu;
     if (g_tune.maxgrid > 0) cap = g_tune.maxgrid;
     cap = std::min(cap, MAXGRID);
     int grid = std::min(cap, ntiles);
@@ -455,7 +476,8 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
     if (g_tune.lanes > 0) M.lanes = g_tune.lanes;
     if (g_tune.wrows > 0) M.wrows = g_tune.wrows;
     if (g_tune.wcap > 0) M.wcap = g_tune.wcap;
-    if (OP == OP_JACOBI && M.kind != 0 && M.kind < 4 && (M.dup_diag || !M.dpos)) M.kind = 0;  // needs the c != r test
+    const bool lstream_ok = g_tune.gen2 && M.kind == 2 && M.wrows == 64 && M.wcap == 512 && (double)M.nnz <= 7.6 * M.row;  // tests c != r itself
+    if (OP == OP_JACOBI && M.kind != 0 && M.kind < 4 && (M.dup_diag || !M.dpos) && !lstream_ok) M.kind = 0;  // needs the c != r test
     a.xcd_map = g_tune.xcd;
     a.nt = g_tune.nt;
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
@@ -463,6 +485,16 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
     const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : M.kind == 3 ? 1 : BLOCK / M.lanes;
     a.ntiles = (M.row + rpb - 1) / rpb;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    if (M.kind == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase && g_tune.rpl <= 0) {
+        // square row-pattern-coded operator: scalar-pattern sweep + exception list (kernels2.hip.h)
+        a.pat = M.pat; a.pstart = M.pstart; a.plen = M.plen; a.poff = M.poff; a.pval = M.pval;
+        a.npat = M.npat; a.npent = M.npent; a.ncol = M.col; a.rowbase = nullptr;
+        a.xrows = M.xrows; a.nxrows = M.nxrows;
+        a.ntiles = (M.row + 2 * BLOCK - 1) / (2 * BLOCK);
+        a.tiles_per_xcd = (a.ntiles + 7) / 8;
+        a.xcd_map = a.ntiles >= 8 * 64 ? -1 : 16;  // slabs: x is fetched once per XCD (PMC: 0.18 GB instead of 0.45 GB per level-0 pass)
+        return launch_persistent(k_csr_rowpat4<OP>, a.ntiles, a, 5);
+    }
     if (M.kind == 5) {
         a.pat = M.pat; a.pstart = M.pstart; a.poff = M.poff; a.pval = M.pval; a.rowbase = M.rowbase;
         a.npat = M.npat; a.npent = M.npent;
@@ -491,6 +523,10 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
         if (avg <= 8.5) return launch_persistent(k_csr_dict8<OP, 8>, a.ntiles, a);
         if (avg <= 20.0) return launch_persistent(k_csr_dict8<OP, 16>, a.ntiles, a);
         return launch_persistent(k_csr_dict8<OP, 24>, a.ntiles, a);
+    }
+    if (M.kind == 2 && g_tune.gen2 && M.wrows == 64 && M.wcap == 512 && (double)M.nnz <= 7.6 * M.row) {
+        // short rows (64 rows fit the 512-entry slab with room for ragged tiles): 16-byte staged stream, lane = row
+        return launch_persistent(k_csr_lstream<OP, 512>, a.ntiles, a, 4);
     }
     if (M.kind == 2) {
         if (M.wrows == 64 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 64, 512>, a.ntiles, a);

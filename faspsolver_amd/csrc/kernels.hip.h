@@ -71,6 +71,8 @@ struct CsrArgs {
     const int*    stop;     // != nullptr: the launch returns at once when *stop != 0 (queued-ahead iterations)
     const int*    mark;     // OP_L1DIAG only, != nullptr: C/F marker, the sweep is Jacobi on the F points (0) with weight omega
     const unsigned short* ja16;  // != nullptr: the column indices once more as 16-bit values (operators with <= 65536 columns)
+    const int*    xrows;    // k_csr_rowpat4: rows outside their wave's uniform pattern, computed lane = row after the sweep
+    int           nxrows;
 };
 
 // Epilogue of OP_L1DIAG, t = b_i - sum_j a_ij x_j accumulated from b_i entry by entry: the L1
@@ -115,7 +117,9 @@ __device__ __forceinline__ int tile_of(const CsrArgs& a, int v)
     if (a.xcd_map <= 0) return v;
     const int G = a.xcd_map;
     const int xcd = v & 7, q = v >> 3;
-    const int chunk = q / G, within = q - chunk * G;
+    int chunk, within;
+    if ((G & (G - 1)) == 0) { const int sh = __ffs(G) - 1; chunk = q >> sh; within = q & (G - 1); }  // no integer division
+    else { chunk = q / G; within = q - chunk * G; }
     return (chunk * 8 + xcd) * G + within;
 }
 

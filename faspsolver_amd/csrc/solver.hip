@@ -32,6 +32,7 @@
 #include "fasp_comm.h"
 #include "fasp_internal.h"
 #include "kernels.hip.h"
+#include "kernels2.hip.h"
 #include "small_solvers.hip.h"
 
 namespace fasp {
@@ -1604,6 +1605,7 @@ int fasp_hip_tune(const char* key, int value)
     if (!key) return ERROR_INPUT_PAR;
     if (!std::strcmp(key, "maxgrid")) g_tune.maxgrid = value;
     else if (!std::strcmp(key, "xcd")) g_tune.xcd = value;
+    else if (!std::strcmp(key, "gen2")) g_tune.gen2 = value;
     else if (!std::strcmp(key, "nt")) g_tune.nt = value;
     else if (!std::strcmp(key, "kind")) g_tune.kind = value;
     else if (!std::strcmp(key, "compress")) g_tune.compress = value;
