@@ -11,21 +11,35 @@ Krylov solve (all PCG iterations, every V-cycle, the coarse-level safe CG) on th
 resident hierarchy, with b and x already in HBM.  The host-side AMG setup and the
 upload happen once, before the warm-up, and are reported separately.
 
-value   = DOF / s = (rows x K) / (time of K solves), whole job (all ranks)
-roofline: the level-0 SpMV kernel (t = A p fused with the (t,p) partial sums), algorithmic
-          bytes 12 nnz + 4 (m+1) + 8 m + 8 m per launch / mean launch time measured with
-          HIP events on the launch stream inside the timed solves.
-cpu_baseline: the oracle (oracle/liboracle.so, a plain-C restatement of the reference's
-          serial algorithm, OpenMP row loops) on the node's host cores, same problem,
-          same hierarchy, bounded number of PCG iterations scaled to the full solve.
+value    = DOF / s = (rows x K) / (time of K solves), whole job (all ranks)
+roofline = the level-0 SpMV kernel the solve runs (t = A p fused with the (t,p) partial
+           sums): bytes that kernel HAS TO MOVE per launch (its stored matrix form + x once
+           + y once) / mean launch time measured with HIP events on the launch stream inside
+           the timed solves; frac = that / 8 TB/s, never above 1.  traffic = memory-side bytes
+           per launch from the rocprofv3 PMC passes of this same command (tools/profile.sh ->
+           profiles/r02_rocprof/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate passes).
+roofline_plain_csr = the same operator through the plain-CSR kernel (lossless coding switched
+           off for these launches): SURVEY 8(d)'s algorithmic bytes 12 nnz + 4 (m+1) + 8 m + 8 m
+           are exactly what this kernel moves.  This is north_star's "SpMV >= 60 % of the HBM roofline".
+ceilings = measured 16-byte-per-lane read / copy / triad rates of this device (1 GiB buffers).
+variable_coefficient = a second full solve: -div(kappa grad u) with a smooth kappa of contrast 9 on
+           the same grid; no two rows repeat, so every level runs the plain-CSR kernels.
+cpu_baseline = the oracle (oracle/liboracle.so, a plain-C restatement of the reference's
+           serial algorithm with OpenMP row loops) on the node's host cores, same problem, same
+           hierarchy, a bounded number of PCG iterations scaled to the full solve; once on all
+           cores and once on one thread.
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; the matrix is
-row-partitioned, halos and dot products go over RCCL (faspsolver_amd/csrc/dist.hip).
+N > 1: `python bench.py --gpus N` starts `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` as a child (unless the driver already did: WORLD_SIZE set); the matrix is
+row-partitioned, halos and dot products go over RCCL (faspsolver_amd/csrc/comm.cpp,
+dist_plan.cpp; bench_dist.py).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,6 +59,15 @@ import faspsolver_amd as fa  # noqa: E402
 from faspsolver_amd import _types as T  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_rocprof", "traffic.json")
+
+# kernel family codes of fasp_hip_amg_kernel_info -> (rocprofv3 kernel name of the OP_MXV_DOT instantiation, description)
+KERNELS = {0: ("k_csr_rows", "k_csr_rows<L, OP_MXV_DOT> (sub-wavefront per row, plain CSR)"),
+           2: ("k_csr_wstream<7, 64, 512>", "k_csr_wstream<OP_MXV_DOT,64,512> (wave-level stream, plain CSR)"),
+           4: ("k_csr_dict8<7", "k_csr_dict8<OP_MXV_DOT> (one byte per entry: (column offset, value) dictionary)"),
+           5: ("k_csr_rowpat<7", "k_csr_rowpat<OP_MXV_DOT> (one 16-bit row-pattern id per row)"),
+           6: ("k_csr_rowpat4<7>", "k_csr_rowpat4<OP_MXV_DOT> (16-bit row-pattern ids, scalar-pattern sweep + exception list)"),
+           7: ("k_csr_lstream<7, 512>", "k_csr_lstream<OP_MXV_DOT,512> (16-byte staged stream, lane = row, plain CSR)")}
 
 
 def log(*a):
@@ -66,17 +89,28 @@ def workload_params():
     return itp, amgp
 
 
-def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s, threads):
     """Time the oracle on the host cores on a bounded sample of the same solve."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _libs
     O = _libs.oracle()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    threads = max(1, min(cores, int(os.environ.get("BENCH_CPU_THREADS", "64"))))
     O.orc_set_threads(threads)
     nl = H.num_levels
     buf = C.create_string_buffer(O.orc_sizeof_amg())
@@ -117,6 +151,12 @@ def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s):
         sample = f"full solve, {stk} PCG iterations"
         t_full = tk
         its_cpu = stk
+    elif k == 1:
+        tk, hk = t1, h1
+        t_full = tk * (iters_gpu + 1.0) / 2.0
+        sample = (f"1 of {iters_gpu} PCG iterations of the same solve ({tk:.2f} s), scaled by ({iters_gpu}+1)/2")
+        its_cpu = None
+        rrk = None
     else:
         tk, stk, hk, rrk = run(k)
         # k iterations contain k+1 preconditioner applies; the full solve iters+1
@@ -129,7 +169,49 @@ def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s):
     hist_dev = float(np.max(np.abs(hk[:ncmp] - hist_gpu[:ncmp]) / hk[:ncmp])) if ncmp > 0 else None
     O.orc_amg_borrow_free(buf)
     return {"value": len(f) / t_full, "unit": "DOF/s", "cores": threads, "kind": "port",
-            "sample": sample, "seconds_full_solve_est": t_full}, its_cpu, rrk, hist_dev
+            "sample": sample, "seconds_full_solve_est": t_full, "cpu_model": cpu_model(),
+            "host_cores_visible": host_cores()}, its_cpu, rrk, hist_dev
+
+
+def pmc_traffic(kernel_name):
+    """bytes per launch of a kernel from the committed PMC summary of this command (None if absent)."""
+    try:
+        tj = json.load(open(TRAFFIC_JSON))
+        for name, rec in tj.get("kernels", {}).items():
+            if name.startswith(kernel_name):
+                return float(rec["bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
+def roofline_entry(kind, moved_bytes, kernel_ms, launches, note=None):
+    name, desc = KERNELS.get(kind, (str(kind), str(kind)))
+    achieved = moved_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = pmc_traffic(name)
+    out = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+           "kernel": "level-0 t = A p fused with (t,p): " + desc,
+           "bytes_per_launch": moved_bytes, "ms_per_launch": kernel_ms, "launches_timed": launches,
+           "traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic and kernel_ms > 0 else None,
+           "traffic_over_bytes": (traffic / moved_bytes) if traffic else None}
+    if note:
+        out["note"] = note
+    return out
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the ranks as a child job (never re-exec this process)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--n", str(args.n)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    log("bench.py: launching", " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -139,11 +221,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", "256")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variable", action="store_true", help="skip the variable-coefficient second solve")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # before anything touches the GPU in this process
     if world != args.gpus and world > 1:
         log(f"WORLD_SIZE {world} != --gpus {args.gpus}; using WORLD_SIZE")
     if world > 1:
@@ -175,17 +260,20 @@ def main():
     def sync():
         L.fasp_hip_device_synchronize()
 
-    stats = None
-    for _ in range(args.warmup):
-        st, hist, stats = H.solve_resident(itp)
-    sync()
-    t0 = time.perf_counter()
-    spmv_ms = []
-    for _ in range(args.steps):
-        st, hist, stats = H.solve_resident(itp)
-        spmv_ms.append(stats.spmv_ms)
-    sync()
-    elapsed = time.perf_counter() - t0
+    def timed_solves(Hx, warmup, steps):
+        st = hist = stats = None
+        for _ in range(warmup):
+            st, hist, stats = Hx.solve_resident(itp)
+        sync()
+        t0 = time.perf_counter()
+        sp = []
+        for _ in range(steps):
+            st, hist, stats = Hx.solve_resident(itp)
+            sp.append(stats.spmv_ms)
+        sync()
+        return time.perf_counter() - t0, st, hist, stats, float(np.mean(sp))
+
+    elapsed, st, hist, stats, kernel_ms = timed_solves(H, args.warmup, args.steps)
     ms_per_step = 1e3 * elapsed / args.steps
     value = m * args.steps / elapsed
     x = H.get_solution()
@@ -193,46 +281,45 @@ def main():
         f"coarse its {stats.coarse_iters}, max|x-u_exact| {np.max(np.abs(x-ue)):.3e}")
 
     B = spmv_bytes(m, m, nnz)
-    kernel_ms = float(np.mean(spmv_ms))
-    achieved = B / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    # The algorithmic bytes above are SURVEY 8(d)'s plain-CSR figure.  When level 0 qualifies for the
-    # lossless row-pattern / byte-dictionary coding (kernels.hip.h) the kernel reads far fewer matrix
-    # bytes; the bytes it actually has to move (coded matrix + x once + y once) are reported beside it.
     kind, matrix_bytes = H.kernel_info(0, 0)
-    KERNELS = {0: "k_csr_rows<L,OP_MXV_DOT> (sub-wavefront per row)",
-               2: "k_csr_wstream<OP_MXV_DOT,64,512> (wave-level stream, plain CSR)",
-               4: "k_csr_dict8<OP_MXV_DOT> (one byte per entry: (column offset, value) dictionary)",
-               5: "k_csr_rowpat<OP_MXV_DOT> (one 16-bit row-pattern id per row)"}
-    moved = matrix_bytes + 8.0 * m + 8.0 * m
-    moved_gbs = moved / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_rocprof", "traffic.json")
-    if os.path.exists(tfile):  # PMC pass of the same command (tools/profile.sh), bytes per launch
-        try:
-            tj = json.load(open(tfile))
-            if tj.get("kernel_kind") == kind:
-                traffic = tj.get("bytes_per_launch")
-        except Exception:
-            traffic = None
+    moved = matrix_bytes + 8.0 * m + 8.0 * m   # stored matrix form + x once + y once (the dotted vector is x)
+    coded = kind in (4, 5, 6)
+    roof = roofline_entry(kind, moved, kernel_ms, int(stats.spmv_launches) * args.steps,
+                          note=("the operator is stored losslessly coded (2 bytes per row + a 27-entry pattern table): "
+                                "bytes_per_launch is what this kernel has to move, not SURVEY 8(d)'s plain-CSR figure "
+                                f"({B} B); the plain-CSR kernel of the same operator is timed in the same run: "
+                                "roofline_plain_csr") if coded else None)
+    roof["plain_csr_algorithmic_bytes"] = B
 
-    # The same operator through the plain-CSR kernel (coding switched off for these launches only): the
-    # figure north_star's "SpMV >= 60 % of the HBM roofline" refers to, measured live with HIP events.
+    # The same operator through the plain-CSR kernel (coding switched off for these launches only)
     plain = None
-    if kind >= 4:
+    if coded:
         try:
             L.fasp_hip_tune(b"compress", 0)
+            pkind, _pb = H.kernel_info(0, 0)
             ms_plain = float(H.time_kernel(5, 0, 20))   # level-0 t = A p fused with (t,p), 20 launches
             L.fasp_hip_tune(b"compress", 1)
-            gbs = B / (ms_plain * 1e-3) / 1e9
-            plain = {"kernel": KERNELS[2], "bytes_per_launch": B, "ms_per_launch": ms_plain, "launches_timed": 20,
-                     "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
-            log(f"plain-CSR level-0 SpMV: {ms_plain*1e3:.1f} us = {gbs:.0f} GB/s = {gbs/PEAK_HBM_GBS:.3f} of peak")
+            plain = roofline_entry(pkind, float(B), ms_plain, 20)
+            log(f"plain-CSR level-0 SpMV: {ms_plain*1e3:.1f} us = {plain['achieved']:.0f} GB/s = {plain['frac']:.3f} of peak")
         except Exception as e:
             L.fasp_hip_tune(b"compress", 1)
             log(f"plain-CSR timing failed: {e!r}")
+    else:
+        plain = dict(roof)
+
+    ceilings = None
+    try:
+        out3 = (C.c_double * 3)()
+        if L.fasp_hip_measure_ceilings(out3, C.c_size_t(1 << 30), 5) == 0:
+            ceilings = {"unit": "GB/s", "read": out3[0], "copy": out3[1], "triad": out3[2],
+                        "buffer_bytes": 1 << 30,
+                        "note": "16 bytes per lane, 1024-block grid, HIP events; roofline fractions use the nominal 8000 GB/s"}
+            log(f"device ceilings: read {out3[0]:.0f}, copy {out3[1]:.0f}, triad {out3[2]:.0f} GB/s")
+    except Exception as e:
+        log(f"ceiling measurement failed: {e!r}")
 
     out = {
-        "metric": "AMG-PCG solve DOF/s (3D 7-pt Poisson 256^3, classical AMG V(1,1) w-Jacobi + PCG, rtol 1e-8)",
+        "metric": f"AMG-PCG solve DOF/s (3D 7-pt Poisson {n}^3, classical AMG V(1,1) w-Jacobi + PCG, rtol 1e-8)",
         "value": value, "unit": "DOF/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -242,35 +329,48 @@ def main():
                    "rows": m, "nnz": nnz, "levels": H.num_levels, "parallelism": "1 GPU"},
         "iterations": int(st), "relres": stats.relres,
         "setup_seconds": t_setup,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
-                     "kernel": "level-0 t = A p fused with (t,p): " + KERNELS.get(kind, str(kind)),
-                     "bytes_per_launch": B, "ms_per_launch": kernel_ms,
-                     "launches_timed": int(stats.spmv_launches) * args.steps,
-                     "moved_bytes_per_launch": moved, "moved_GBps": moved_gbs,
-                     "frac_of_peak_on_moved_bytes": moved_gbs / PEAK_HBM_GBS,
-                     "traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-                     "frac_of_peak_on_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
-                     "note": ("achieved/frac use SURVEY 8(d)'s plain-CSR algorithmic bytes; the matrix is "
-                              "stored losslessly coded, so frac > 1 means fewer bytes than plain CSR were "
-                              "moved, not that the HBM peak was exceeded.  moved = compulsory bytes of the "
-                              "coded layout (pattern ids + x once + y once); traffic = memory-side bytes "
-                              "from the PMC pass (x is re-fetched by rows one grid plane away).  With the "
-                              "coding switched off (FASP_HIP_COMPRESS=0) the plain-CSR kernel of the same "
-                              "operator is timed in the same run: roofline_plain_csr") if kind >= 4 else None},
+        "roofline": roof,
         "roofline_plain_csr": plain,
+        "ceilings": ceilings,
     }
     if not args.no_cpu_baseline:
         try:
+            allc = max(1, min(host_cores(), int(os.environ.get("BENCH_CPU_THREADS", "64"))))
             cb, its_cpu, rr_cpu, hist_dev = cpu_baseline(H, ia, ja, a, f, int(st), hist,
-                                                         float(os.environ.get("BENCH_CPU_BUDGET_S", "20")))
+                                                         float(os.environ.get("BENCH_CPU_BUDGET_S", "15")), allc)
             out["cpu_baseline"] = cb
             out["parity"] = {"iters_gpu": int(st), "iters_cpu": its_cpu, "relres_gpu": stats.relres,
                              "relres_cpu": rr_cpu, "max_rel_dev_residual_history": hist_dev}
+            cb1, _i, _r, _h = cpu_baseline(H, ia, ja, a, f, int(st), hist, 0.0, 1)
+            out["cpu_baseline_1thread"] = cb1
         except Exception as e:  # the baseline is a report, never a reason to lose the line
             log(f"cpu_baseline failed: {e!r}")
-            out["cpu_baseline"] = None
+            out.setdefault("cpu_baseline", None)
     H.close()
+
+    if not args.no_variable:
+        # Variable coefficients: -div(kappa grad u) on the same grid.  No two rows repeat, so no lossless
+        # coding applies and every level runs the plain-CSR kernels (what an application matrix sees).
+        try:
+            _ia, _ja, a2, f2 = fa.poisson7pt_var(n, (ia, ja, a, f, ue))
+            t0 = time.perf_counter()
+            H2 = fa.AMG(ia, ja, a2, amgp)
+            ts2 = time.perf_counter() - t0
+            H2.set_rhs(f2)
+            el2, st2, hist2, stats2, kms2 = timed_solves(H2, 1, 3)
+            k2, mb2 = H2.kernel_info(0, 0)
+            out["variable_coefficient"] = {
+                "workload": f"-div(kappa grad u) on the grid of P7({n}), kappa = 1 + 0.8 sin(2 pi x) sin(2 pi y) sin(2 pi z) "
+                            "(contrast 9, no repeated rows); same solver parameters; 3 timed solves",
+                "value": m * 3 / el2, "unit": "DOF/s", "ms_per_step": 1e3 * el2 / 3, "iterations": int(st2),
+                "relres": stats2.relres, "setup_seconds": ts2, "levels": H2.num_levels,
+                "roofline": roofline_entry(k2, mb2 + 16.0 * m, kms2, int(stats2.spmv_launches) * 3)}
+            log(f"variable-coefficient solve: {st2} iterations, {1e3*el2/3:.2f} ms/solve, level-0 kernel family {k2}, "
+                f"SpMV {kms2*1e3:.1f} us")
+            H2.close()
+        except Exception as e:
+            log(f"variable-coefficient solve failed: {e!r}")
+            out["variable_coefficient"] = None
     print(json.dumps(out), flush=True)
 
 

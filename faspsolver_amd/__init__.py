@@ -41,7 +41,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_amg_get_cfmark", "fasp_hip_solve", "fasp_hip_set_rhs", "fasp_hip_set_guess",
     "fasp_hip_solve_resident", "fasp_hip_get_solution", "fasp_hip_device_synchronize",
     "fasp_hip_precond_amg",
-    "fasp_hip_poisson7pt", "fasp_hip_aniso27pt", "fasp_hip_free_system", "fasp_hip_time_kernel",
+    "fasp_hip_poisson7pt", "fasp_hip_aniso27pt", "fasp_hip_free_system", "fasp_hip_time_kernel", "fasp_hip_measure_ceilings",
     "fasp_hip_tune", "fasp_hip_comm_unique_id", "fasp_hip_comm_init", "fasp_hip_comm_finalize",
     "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version", "fasp_hip_comm_init_shm",
     "fasp_hip_dist_plan", "fasp_hip_dist_level_info", "fasp_hip_dist_get_matrix",
@@ -165,6 +165,7 @@ def lib():
     L.fasp_hip_aniso27pt.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, P(T.dCSRmat), P(T.dvector)]
     L.fasp_hip_free_system.argtypes = [P(T.dCSRmat), P(T.dvector), P(T.dvector)]
     L.fasp_hip_free_system.restype = None
+    L.fasp_hip_measure_ceilings.argtypes = [P(C.c_double), C.c_size_t, C.c_int]
     L.fasp_hip_time_kernel.restype = C.c_double
     L.fasp_hip_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.fasp_hip_tune.argtypes = [C.c_char_p, C.c_int]
@@ -211,6 +212,30 @@ def poisson7pt(nx, ny=None, nz=None):
     ue = np.ctypeslib.as_array(u.val, (u.row,)).copy()
     lib().fasp_hip_free_system(C.byref(A), C.byref(b), C.byref(u))
     return ia, ja, a, f, ue
+
+
+def poisson7pt_var(n, p7=None):
+    """Variable-coefficient twin of P7(n): -div(kappa grad u) = f on the same grid and sparsity pattern,
+    kappa = 1 + 0.8 sin(2 pi x) sin(2 pi y) sin(2 pi z) (contrast 9), face coefficients = mean of the two
+    node values, Dirichlet boundary.  No two rows repeat, so no lossless matrix coding applies: the
+    plain-CSR kernels serve every level.  Entry order = P7's (diagonal first).  -> (ia, ja, a, f)"""
+    ia, ja, a, f, _ue = p7 if p7 is not None else poisson7pt(n)
+    m = len(f)
+    h = 1.0 / (n + 1)
+    idx = np.arange(m, dtype=np.int64)
+    xi = (idx % n + 1) * h
+    yi = ((idx // n) % n + 1) * h
+    zi = (idx // (n * n) + 1) * h
+    kap = 1.0 + 0.8 * np.sin(2 * np.pi * xi) * np.sin(2 * np.pi * yi) * np.sin(2 * np.pi * zi)
+    del xi, yi, zi
+    cnt = np.diff(ia)
+    rows = np.repeat(idx, cnt)
+    off = ja != rows
+    a2 = np.where(off, a * 0.5 * (kap[rows] + kap[ja]), 0.0)          # -kappa_face / h^2
+    rowsum = np.bincount(rows, weights=a2, minlength=m)                # sum of the off-diagonals (negative)
+    diag = -rowsum + (7 - cnt) * kap / (h * h)                         # + the faces that touch the boundary
+    a2[ia[:-1]] = diag                                                 # P7 stores the diagonal first
+    return ia, ja, a2, f.copy()
 
 
 def aniso27pt(n, kx=1.0, ky=1.0, kz=0.01):

@@ -274,6 +274,9 @@ int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* k
     double bytes = 12.0 * M.nnz + 4.0 * (M.row + 1.0);
     if (M.code && g_tune.compress) { k = 4; bytes = 1.0 * M.nnz + 4.0 * (M.row + 1.0) + (M.rowbase ? 4.0 * M.row : 0.0); }
     if (M.pat && g_tune.compress) { k = 5; bytes = 2.0 * M.row + (M.rowbase ? 4.0 * M.row : 0.0) + 12.0 * M.npent; }
+    // second-generation kernels (kernels2.hip.h), same selection as launch_csr: 6 = k_csr_rowpat4, 7 = k_csr_lstream
+    if (k == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase) { k = 6; bytes += 4.0 * M.nxrows; }
+    if (k == 2 && g_tune.gen2 && M.wrows == 64 && M.wcap == 512 && (double)M.nnz <= 7.6 * M.row) k = 7;
     if (kind) *kind = k;
     if (matrix_bytes) *matrix_bytes = bytes;
     return FASP_SUCCESS;
@@ -1622,6 +1625,41 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;
     else if (!std::strcmp(key, "wcap")) g_tune.wcap = value;
     else return ERROR_INPUT_PAR;
+    return FASP_SUCCESS;
+}
+
+// Measured device ceilings beside the roofline: a 16-byte-per-lane read, copy and triad over buffers of
+// `bytes` each (use >= 512 MiB: beyond the 256 MiB Infinity Cache).  out[0..2] = GB/s of read, copy (read + write
+// counted), triad (two reads + one write counted).  Returns 0 or a negative error code.
+int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps)
+{
+    if (!out || bytes < (1u << 20) || reps <= 0) return ERROR_INPUT_PAR;
+    if (ctx_init() != FASP_SUCCESS) return ERROR_MISC;
+    f64x2_t *p = nullptr, *q = nullptr, *r = nullptr;
+    HIPCK(hipMalloc(&p, bytes)); HIPCK(hipMalloc(&q, bytes)); HIPCK(hipMalloc(&r, bytes));
+    HIPCK(hipMemsetAsync(p, 0, bytes, g_ctx.stream)); HIPCK(hipMemsetAsync(q, 0, bytes, g_ctx.stream));
+    HIPCK(hipMemsetAsync(r, 0, bytes, g_ctx.stream));
+    const size_t n16 = bytes / 16;
+    hipEvent_t e0, e1;
+    HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+    const int grid = 4 * g_ctx.num_cu;
+    for (int which = 0; which < 3; ++which) {
+        auto run = [&]() {
+            if (which == 0) hipLaunchKernelGGL(k_read16, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, n16, p, (double*)q);
+            else if (which == 1) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, n16, p, q);
+            else hipLaunchKernelGGL(k_triad16, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, n16, 0.5, p, q, r);
+        };
+        run(); run();
+        HIPCK(hipEventRecord(e0, g_ctx.stream));
+        for (int i = 0; i < reps; ++i) run();
+        HIPCK(hipEventRecord(e1, g_ctx.stream));
+        HIPCK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCK(hipEventElapsedTime(&ms, e0, e1));
+        out[which] = (double)(which + 1) * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(p); (void)hipFree(q); (void)hipFree(r);
     return FASP_SUCCESS;
 }
 

@@ -1,16 +1,20 @@
-# rocprofv3 profiles of the bench command (run on the GPU box via gpurun)
+# rocprofv3 profiles of the bench command (run on the GPU box via gpurun): kernel trace + stats, then the
+# two PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, nothing but --kernel-trace beside them).
+# usage: bash tools/profile.sh [round-tag]      -> gpurun_out/prof_<tag>/{kernel_stats.csv,summary.md,traffic.json}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export OMP_NUM_THREADS=${OMP_NUM_THREADS:-32}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1
-find $OUT -name "*.csv" | head -20
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variable"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
 python3 tools/summarize_prof.py $OUT > $OUT/summary.md 2>&1
-cat $OUT/summary.md | head -70
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
+head -60 $OUT/summary.md
 # keep the merged-back payload small
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
+find $OUT -name "*.db" -delete
