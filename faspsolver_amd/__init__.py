@@ -42,6 +42,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_solve_resident", "fasp_hip_get_solution", "fasp_hip_device_synchronize",
     "fasp_hip_precond_amg",
     "fasp_hip_poisson7pt", "fasp_hip_aniso27pt", "fasp_hip_free_system", "fasp_hip_time_kernel", "fasp_hip_measure_ceilings",
+    "fasp_precond_setup", "fasp_precond_amg", "fasp_precond_famg", "fasp_precond_amli", "fasp_precond_namli", "fasp_amg_data_create", "fasp_amg_data_free", "fasp_param_amg_to_prec", "fasp_param_prec_to_amg", "fasp_mem_free", "fasp_mem_calloc", "fasp_dvec_alloc", "fasp_dvec_set", "fasp_dvec_free", "fasp_dvec_create", "fasp_dcsr_create", "fasp_dcsr_free", "fasp_smoother_dcsr_gs", "fasp_smoother_dcsr_sor", "fasp_smoother_dcsr_L1diag",
     "fasp_hip_tune", "fasp_hip_comm_unique_id", "fasp_hip_comm_init", "fasp_hip_comm_finalize",
     "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version", "fasp_hip_comm_init_shm",
     "fasp_hip_dist_plan", "fasp_hip_dist_level_info", "fasp_hip_dist_get_matrix",

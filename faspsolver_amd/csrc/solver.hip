@@ -846,6 +846,8 @@ precond* fasp_hip_precond_setup(dCSRmat* A, AMG_param* amgparam)
     return pc;
 }
 
+#include "precond_api.hip.h"
+
 void fasp_hip_precond_free(precond* pc)
 {
     if (!pc) return;
@@ -870,7 +872,7 @@ int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u,
     if (!A || !b || !u || A->row != A->col || b->row != A->row || u->row != A->row) return ERROR_INPUT_PAR;
     if (comm_size() > 1) return ERROR_INPUT_PAR;  // plug-in level: one GPU
     const int n = b->row;
-    fasp_hip_amg* h = (pc && pc->fct == fasp_hip_precond_fct) ? static_cast<fasp_hip_amg*>(pc->data) : nullptr;
+    fasp_hip_amg* h = (pc && pc->fct == fasp_hip_precond_fct) ? static_cast<fasp_hip_amg*>(pc->data) : amg_handle_of_precond(pc);
     if (h && (h->L.empty() || h->L[0].A.row != n)) return ERROR_INPUT_PAR;
     std::unique_ptr<TmpCSR> own;
     const DevCSR* dA = nullptr;

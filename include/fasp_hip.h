@@ -34,6 +34,7 @@
 #ifndef FASP_HIP_H
 #define FASP_HIP_H
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -237,6 +238,88 @@ typedef struct {
     void* data;
     void (*fct)(double*, double*, void*);
 } precond;
+
+/* ---- reference-layout data of the AMG preconditioner (fasp.h:596-981, serial build without UMFPACK / MUMPS /
+ * PARDISO / MULTI_COLOR_ORDER).  Field order and types are the reference's, so code compiled against fasp.h and
+ * code compiled against this header agree on every offset (sizes pinned in tests/golden/abi.npz:
+ * AMG_data 1104 bytes, precond_data 152 bytes).  ILU / Schwarz / direct-solver members are carried for layout
+ * only: those smoothers and coarse solvers are out of scope here and stay zero. ---- */
+typedef struct {            /* fasp.h:404  ILU_param */
+    short  print_level;
+    short  ILU_type;
+    int    ILU_lfil;
+    double ILU_droptol;
+    double ILU_relax;
+    double ILU_permtol;
+} ILU_param;
+struct SWZ_param_;          /* fasp.h:430: only ever a pointer here */
+typedef struct { int job; } Mumps_data;            /* fasp.h:596 */
+typedef struct { void* pt[64]; } Pardiso_data;     /* fasp.h:623 */
+typedef struct {            /* fasp.h:651  ILU_data */
+    dCSRmat* A;
+    int      type, row, col, nzlu;
+    int*     ijlu;
+    double*  luval;
+    int      nb, nwork;
+    double*  work;
+    int*     iperm;
+    int      ncolors;
+    int     *ic, *icmap, *uptr;
+    int      nlevL, nlevU;
+    int     *ilevL, *ilevU, *jlevL, *jlevU;
+} ILU_data;
+typedef struct {            /* fasp.h:724  SWZ_data */
+    dCSRmat  A;
+    int      nblk;
+    int     *iblock, *jblock;
+    double*  rhsloc;
+    dvector  rhsloc1, xloc1;
+    double  *au, *al;
+    int      SWZ_type, blk_solver, memt;
+    int*     mask;
+    int      maxbs;
+    int*     maxa;
+    dCSRmat* blk_data;
+    Mumps_data*        mumps;
+    struct SWZ_param_* swzparam;
+} SWZ_data;
+typedef struct {            /* fasp.h:804  AMG_data: one per level, mgl[0 .. num_levels) */
+    short        max_levels;
+    short        num_levels;
+    dCSRmat      A, R, P;          /* host copies of this level's operators (this library: views of its own hierarchy) */
+    dvector      b, x;             /* host vectors of this level (scratch of the reference's cycle; unused by the device cycle) */
+    void*        Numeric;
+    Pardiso_data pdata;
+    ivector      cfmark;
+    int          ILU_levels;
+    ILU_data     LU;
+    int          near_kernel_dim;
+    double**     near_kernel_basis;
+    int          SWZ_levels;
+    SWZ_data     Schwarz;
+    dvector      w;
+    Mumps_data   mumps;
+    int          cycle_type;
+    int         *ic, *icmap;
+    int          colors;
+    double       weight;
+} AMG_data;
+typedef struct {            /* fasp.h:894  precond_data */
+    short     AMG_type, print_level;
+    int       maxit;
+    short     max_levels;
+    double    tol;
+    short     cycle_type, smoother, smooth_order, presmooth_iter, postsmooth_iter;
+    double    relaxation;
+    short     polynomial_degree, coarsening_type, coarse_solver, coarse_scaling, amli_degree, nl_amli_krylov_type;
+    double    tentative_smooth;
+    double*   amli_coef;
+    AMG_data* mgl_data;
+    ILU_data* LU;
+    dCSRmat  *A, *A_nk, *P_nk, *R_nk;
+    dvector   r;
+    double*   w;
+} precond_data;
 
 /* fasp_block.h:255  data of the block-diagonal preconditioner */
 typedef struct {
@@ -498,6 +581,43 @@ int fasp_solver_dcsr_pvgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, co
 int fasp_solver_dcsr_pvfgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol,
                               const double abstol, const int MaxIt, const short restart,
                               const short StopType, const short PrtLvl);
+/* ---- the reference's own preconditioner objects (relink-only callers: tutorial/main/poisson-pcg.c:81,91) ----
+ * fasp_precond_setup (PreCSR.c:46): PREC_AMG / PREC_FMG build the hierarchy on the host, upload it, and hand out
+ * precond{data = precond_data*, fct = fasp_precond_amg | _amli | _namli | _famg}; mgl_data[l].A / P / R / cfmark show
+ * the host hierarchy (read-only views owned by the library), b / x / w are allocated as the reference's setup
+ * leaves them.  PREC_DIAG gives fasp_precond_diag on a copy of the diagonal, PREC_NULL returns NULL; PREC_ILU /
+ * PREC_SCHWARZ are out of scope: message + exit, as fasp_chkerr does.
+ * fasp_precond_amg (PreCSR.c:416): z = B r for host vectors r, z -- pcdata->maxit cycles from a zero guess, cycle /
+ * smoother parameters re-read from pcdata at every call (fasp_param_prec_to_amg).  Handed to this library's Krylov
+ * methods these functions are recognised by their address and the whole iteration stays in HBM.
+ * fasp_amg_data_create / _free (PreDataInit.c:64 / :101): a hierarchy obtained from fasp_precond_setup is released
+ * together with its device copy; an AMG_data the caller filled itself is freed field by field like the reference. */
+AMG_data* fasp_amg_data_create(short max_levels);
+void      fasp_amg_data_free(AMG_data* mgl, AMG_param* param);
+precond*  fasp_precond_setup(const short precond_type, AMG_param* amgparam, ILU_param* iluparam, dCSRmat* A);
+void      fasp_precond_amg(double* r, double* z, void* data);
+void      fasp_precond_famg(double* r, double* z, void* data);    /* PreCSR.c:450 */
+void      fasp_precond_amli(double* r, double* z, void* data);    /* PreCSR.c:484 */
+void      fasp_precond_namli(double* r, double* z, void* data);   /* PreCSR.c:518 */
+void      fasp_param_amg_to_prec(precond_data* pcdata, const AMG_param* amgparam);   /* AuxParam.c:782 */
+void      fasp_param_prec_to_amg(AMG_param* amgparam, const precond_data* pcdata);   /* AuxParam.c:816 */
+/* the small host utilities such callers use around the solver (AuxMemory.c:152, AuxVector.c:105/:222/:145,
+ * BlaSparseCSR.c:184/:34) */
+void    fasp_mem_free(void* mem);
+void*   fasp_mem_calloc(const unsigned int size, const unsigned int type);
+void    fasp_dvec_alloc(const int m, dvector* u);
+void    fasp_dvec_set(int n, dvector* x, const double val);
+void    fasp_dvec_free(dvector* u);
+dvector fasp_dvec_create(const int m);
+dCSRmat fasp_dcsr_create(const int m, const int n, const int nnz);
+void    fasp_dcsr_free(dCSRmat* A);
+/* stand-alone sweeps of the other hot-path smoothers (ItrSmootherCSR.c:251 / :932 / :1509), host vectors in and
+ * out, the sweep itself on the device by level scheduling (same result as the sequential sweep) */
+void fasp_smoother_dcsr_gs(dvector* u, const int i_1, const int i_n, const int s, dCSRmat* A, dvector* b, int L);
+void fasp_smoother_dcsr_sor(dvector* u, const int i_1, const int i_n, const int s, dCSRmat* A, dvector* b, int L,
+                            const double w);
+void fasp_smoother_dcsr_L1diag(dvector* u, const int i_1, const int i_n, const int s, dCSRmat* A, dvector* b, int L);
+
 /* The AMG preconditioner as a `precond` -- the role of fasp_precond_setup(PREC_AMG, ..)
  * (PreCSR.c:46) + fasp_precond_amg (PreCSR.c:416).  The returned object can be handed to the
  * functions above or to the REFERENCE's own CPU Krylov methods (they only call pc->fct). */

@@ -33,6 +33,74 @@ int ref_sizeof(int which)
         default: return -1;
     }
 }
+/* every field of AMG_data / precond_data, in declaration order (fasp.h:804-888, :894-981) */
+int ref_offsetof_amgdata(int which)
+{
+    switch (which) {
+        case 0: return (int)offsetof(AMG_data, max_levels);
+        case 1: return (int)offsetof(AMG_data, num_levels);
+        case 2: return (int)offsetof(AMG_data, A);
+        case 3: return (int)offsetof(AMG_data, R);
+        case 4: return (int)offsetof(AMG_data, P);
+        case 5: return (int)offsetof(AMG_data, b);
+        case 6: return (int)offsetof(AMG_data, x);
+        case 7: return (int)offsetof(AMG_data, Numeric);
+        case 8: return (int)offsetof(AMG_data, pdata);
+        case 9: return (int)offsetof(AMG_data, cfmark);
+        case 10: return (int)offsetof(AMG_data, ILU_levels);
+        case 11: return (int)offsetof(AMG_data, LU);
+        case 12: return (int)offsetof(AMG_data, near_kernel_dim);
+        case 13: return (int)offsetof(AMG_data, near_kernel_basis);
+        case 14: return (int)offsetof(AMG_data, SWZ_levels);
+        case 15: return (int)offsetof(AMG_data, Schwarz);
+        case 16: return (int)offsetof(AMG_data, w);
+        case 17: return (int)offsetof(AMG_data, mumps);
+        case 18: return (int)offsetof(AMG_data, cycle_type);
+        case 19: return (int)offsetof(AMG_data, ic);
+        case 20: return (int)offsetof(AMG_data, icmap);
+        case 21: return (int)offsetof(AMG_data, colors);
+        case 22: return (int)offsetof(AMG_data, weight);
+        case 23: return (int)sizeof(AMG_data);
+        case 24: return (int)sizeof(ILU_data);
+        case 25: return (int)sizeof(SWZ_data);
+        case 26: return (int)sizeof(ILU_param);
+        default: return -1;
+    }
+}
+int ref_offsetof_precdata(int which)
+{
+    switch (which) {
+        case 0: return (int)offsetof(precond_data, AMG_type);
+        case 1: return (int)offsetof(precond_data, print_level);
+        case 2: return (int)offsetof(precond_data, maxit);
+        case 3: return (int)offsetof(precond_data, max_levels);
+        case 4: return (int)offsetof(precond_data, tol);
+        case 5: return (int)offsetof(precond_data, cycle_type);
+        case 6: return (int)offsetof(precond_data, smoother);
+        case 7: return (int)offsetof(precond_data, smooth_order);
+        case 8: return (int)offsetof(precond_data, presmooth_iter);
+        case 9: return (int)offsetof(precond_data, postsmooth_iter);
+        case 10: return (int)offsetof(precond_data, relaxation);
+        case 11: return (int)offsetof(precond_data, polynomial_degree);
+        case 12: return (int)offsetof(precond_data, coarsening_type);
+        case 13: return (int)offsetof(precond_data, coarse_solver);
+        case 14: return (int)offsetof(precond_data, coarse_scaling);
+        case 15: return (int)offsetof(precond_data, amli_degree);
+        case 16: return (int)offsetof(precond_data, nl_amli_krylov_type);
+        case 17: return (int)offsetof(precond_data, tentative_smooth);
+        case 18: return (int)offsetof(precond_data, amli_coef);
+        case 19: return (int)offsetof(precond_data, mgl_data);
+        case 20: return (int)offsetof(precond_data, LU);
+        case 21: return (int)offsetof(precond_data, A);
+        case 22: return (int)offsetof(precond_data, A_nk);
+        case 23: return (int)offsetof(precond_data, P_nk);
+        case 24: return (int)offsetof(precond_data, R_nk);
+        case 25: return (int)offsetof(precond_data, r);
+        case 26: return (int)offsetof(precond_data, w);
+        case 27: return (int)sizeof(precond_data);
+        default: return -1;
+    }
+}
 int ref_offsetof_amgparam(int which)
 {
     switch (which) {

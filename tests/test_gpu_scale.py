@@ -1,0 +1,141 @@
+"""Parity at scale (fixture F5): the HIP path through the C-ABI at 64^3, 128^3 and
+256^3 against numbers the REFERENCE produced -- tests/golden/p7_scale.npz, written by
+tools/gen_golden_f5.py from the compiled reference (64^3, 128^3, the variable-coefficient twin at 48^3 and
+96^3) and from BASELINE.md section 2 (256^3: 14 iterations, relres 6.3426837114e-09).
+
+Bars (north_star): equal iteration counts; |relres_gpu - relres_ref| <= 1e-10; level sizes equal; the
+residual history to rtol 1e-8; the solution to 1e-9 of its maximum.  Plus the kernel A/B identities at
+sizes where the full-chip kernel variants (16-bit ids, slab schedule, exception lists, 16-byte staged
+streams) are the ones that run.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import faspsolver_amd as fa
+from faspsolver_amd import _types as T
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RELRES_TOL = 1e-10   # north_star: final residual within 1e-10 of the reference's
+HIST_RTOL = 1e-8
+X_TOL = 1e-9
+
+
+def _same_history(hist, ref_hist):
+    """The device history ends with two entries for the last iteration (recurrence residual, then the true residual
+    b - A x the reference prints); the reference's log keeps the true one.  Entries agree to HIST_RTOL; the last one --
+    a difference of O(1) vectors -- to 1e-10 of the initial residual (north_star's bar)."""
+    h = np.concatenate([hist[:-2], hist[-1:]])
+    return (len(h) == len(ref_hist) and np.allclose(h[:-1], ref_hist[:-1], rtol=HIST_RTOL, atol=0.0)
+            and abs(h[-1] - ref_hist[-1]) <= RELRES_TOL * ref_hist[0])
+
+
+def _params():
+    itp = fa.param_solver_init(); itp.tol = 1e-8; itp.maxit = 500; itp.print_level = 0
+    amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
+    return itp, amgp
+
+
+def _levels(H):
+    out = []
+    for l in range(H.num_levels):
+        r, c, ia, ja, v = H.matrix(l, 0)
+        out.append([r, len(v)])
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 128])
+def test_p7_matches_reference_at_scale(gpu, n):
+    z = np.load(os.path.join(G, "p7_scale.npz"))
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _params()
+    H = fa.AMG(ia, ja, a, amgp)
+    assert _levels(H) == z[f"n{n}_levels"].tolist()
+    st, x, hist, stats = H.solve(f, itp)
+    ref_hist = z[f"n{n}_hist"]
+    assert st == int(z[f"n{n}_iters"])
+    assert abs(stats.relres - float(z[f"n{n}_relres"])) <= RELRES_TOL
+    assert _same_history(hist, ref_hist)
+    step = max(1, len(x) // 4096)
+    xs = z[f"n{n}_xsample"]
+    assert np.abs(x[::step] - xs).max() <= X_TOL * np.abs(xs).max()
+    s, mx, n2 = z[f"n{n}_xsum"]
+    assert abs(np.abs(x).max() - mx) <= X_TOL * mx and abs(np.sqrt((x * x).sum()) - n2) <= X_TOL * n2
+    H.close()
+
+
+@pytest.mark.gpu
+def test_p7_256_headline_iterations_and_residual(gpu):
+    """The benchmark configuration itself: 14 iterations and relres 6.3426837114e-09,
+    the reference's ten level sizes, and the plain-CSR kernels reproducing the coded ones on the same hierarchy."""
+    z = np.load(os.path.join(G, "p7_scale.npz"))
+    n = 256
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _params()
+    H = fa.AMG(ia, ja, a, amgp)
+    assert _levels(H) == z["n256_levels"].tolist()
+    H.set_rhs(f)
+    st, hist, stats = H.solve_resident(itp)
+    assert st == int(z["n256_iters"])
+    assert abs(stats.relres - float(z["n256_relres"])) <= RELRES_TOL
+    x = H.get_solution()
+    assert np.abs(x - ue).max() < 2e-5   # second-order discretisation error of the generator's exact solution
+    kinds = [H.kernel_info(l, 0)[0] for l in range(H.num_levels)]
+    assert kinds[0] == 6 and kinds[1] == 6   # scalar-pattern sweep on the two coded levels
+    L = fa.lib()
+    L.fasp_hip_tune(b"compress", 0)
+    try:
+        assert H.kernel_info(0, 0)[0] == 7   # 16-byte staged stream on the plain level-0 operator
+        st0, hist0, stats0 = H.solve_resident(itp)
+    finally:
+        L.fasp_hip_tune(b"compress", 1)
+    assert st0 == st and abs(stats0.relres - stats.relres) <= 1e-13
+    assert np.allclose(hist0[:-1], hist[:-1], rtol=1e-9, atol=0.0) and abs(hist0[-1] - hist[-1]) <= RELRES_TOL * hist[0]
+    H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [48, 96])
+def test_variable_coefficient_matches_reference(gpu, n):
+    """-div(kappa grad u), kappa of contrast 9: no row repeats, every level on the plain-CSR kernels."""
+    z = np.load(os.path.join(G, "p7_scale.npz"))
+    ia, ja, a, f = fa.poisson7pt_var(n)
+    itp, amgp = _params()
+    H = fa.AMG(ia, ja, a, amgp)
+    assert _levels(H) == z[f"var{n}_levels"].tolist()
+    assert H.kernel_info(0, 0)[0] in (2, 7)   # nothing to code
+    st, x, hist, stats = H.solve(f, itp)
+    assert st == int(z[f"var{n}_iters"])
+    assert abs(stats.relres - float(z[f"var{n}_relres"])) <= RELRES_TOL
+    assert _same_history(hist, z[f"var{n}_hist"])
+    step = max(1, len(x) // 4096)
+    xs = z[f"var{n}_xsample"]
+    assert np.abs(x[::step] - xs).max() <= X_TOL * np.abs(xs).max()
+    H.close()
+
+
+@pytest.mark.gpu
+def test_coded_vs_plain_and_gen1_vs_gen2_bit_identity_128(gpu):
+    """One multigrid cycle (every operator, every epilogue, no fused dots) at 128^3 through four kernel sets:
+    coded / plain x second-generation / round-1 kernels.  All row sums are the reference's left-to-right sums
+    of the exact stored values, so the four results agree BIT FOR BIT."""
+    n = 128
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _params()
+    H = fa.AMG(ia, ja, a, amgp)
+    L = fa.lib()
+    r = np.random.default_rng(5).standard_normal(len(f))
+    out = {}
+    try:
+        for comp in (1, 0):
+            for gen2 in (1, 0):
+                L.fasp_hip_tune(b"compress", comp); L.fasp_hip_tune(b"gen2", gen2)
+                out[(comp, gen2)] = H.precond(r)
+    finally:
+        L.fasp_hip_tune(b"compress", 1); L.fasp_hip_tune(b"gen2", 1)
+    base = out[(1, 1)]
+    for k, v in out.items():
+        assert np.array_equal(v, base), k
+    H.close()
