@@ -205,11 +205,12 @@ def spawn_ranks(args):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
-           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--n", str(args.n)]
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     log("bench.py: launching", " ".join(cmd))
     env = dict(os.environ)
+    env["BENCH_N"] = str(args.n)   # (torch.distributed.run's parser trips over a script option called --n)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
 

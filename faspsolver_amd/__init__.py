@@ -41,7 +41,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_amg_get_cfmark", "fasp_hip_solve", "fasp_hip_set_rhs", "fasp_hip_set_guess",
     "fasp_hip_solve_resident", "fasp_hip_get_solution", "fasp_hip_device_synchronize",
     "fasp_hip_precond_amg",
-    "fasp_hip_poisson7pt", "fasp_hip_aniso27pt", "fasp_hip_free_system", "fasp_hip_time_kernel", "fasp_hip_measure_ceilings",
+    "fasp_hip_poisson7pt", "fasp_hip_aniso27pt", "fasp_hip_free_system", "fasp_hip_time_kernel", "fasp_hip_measure_ceilings", "fasp_hip_amg_publish", "fasp_hip_amg_attach", "fasp_hip_amg_unpublish",
     "fasp_precond_setup", "fasp_precond_amg", "fasp_precond_famg", "fasp_precond_amli", "fasp_precond_namli", "fasp_amg_data_create", "fasp_amg_data_free", "fasp_param_amg_to_prec", "fasp_param_prec_to_amg", "fasp_mem_free", "fasp_mem_calloc", "fasp_dvec_alloc", "fasp_dvec_set", "fasp_dvec_free", "fasp_dvec_create", "fasp_dcsr_create", "fasp_dcsr_free", "fasp_smoother_dcsr_gs", "fasp_smoother_dcsr_sor", "fasp_smoother_dcsr_L1diag",
     "fasp_hip_tune", "fasp_hip_comm_unique_id", "fasp_hip_comm_init", "fasp_hip_comm_finalize",
     "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version", "fasp_hip_comm_init_shm",
@@ -167,6 +167,9 @@ def lib():
     L.fasp_hip_free_system.argtypes = [P(T.dCSRmat), P(T.dvector), P(T.dvector)]
     L.fasp_hip_free_system.restype = None
     L.fasp_hip_measure_ceilings.argtypes = [P(C.c_double), C.c_size_t, C.c_int]
+    L.fasp_hip_amg_publish.argtypes = [C.c_void_p, C.c_char_p]
+    L.fasp_hip_amg_attach.argtypes = [P(C.c_void_p), C.c_char_p]
+    L.fasp_hip_amg_unpublish.argtypes = [C.c_char_p]
     L.fasp_hip_time_kernel.restype = C.c_double
     L.fasp_hip_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.fasp_hip_tune.argtypes = [C.c_char_p, C.c_int]
@@ -274,6 +277,30 @@ class AMG:
             self.h = C.c_void_p()
             raise RuntimeError(f"fasp_hip_amg_create failed with status {self.status}")
         self.n = self._A.row
+
+    @classmethod
+    def attach(cls, name):
+        """Host-only handle on a hierarchy another process of this node published (fasp_hip_amg_attach)."""
+        self = cls.__new__(cls)
+        self._A = None; self._keep = None
+        self.h = C.c_void_p()
+        self.status = lib().fasp_hip_amg_attach(C.byref(self.h), name.encode())
+        if self.status < 0:
+            self.h = C.c_void_p()
+            raise RuntimeError(f"fasp_hip_amg_attach({name}) failed with status {self.status}")
+        v = T.dCSRmat()
+        lib().fasp_hip_amg_get_matrix(self.h, 0, 0, C.byref(v))
+        self.n = v.row
+        return self
+
+    def publish(self, name):
+        st = lib().fasp_hip_amg_publish(self.h, name.encode())
+        if st < 0:
+            raise RuntimeError(f"fasp_hip_amg_publish({name}) failed with status {st}")
+
+    @staticmethod
+    def unpublish(name):
+        lib().fasp_hip_amg_unpublish(name.encode())
 
     @property
     def num_levels(self):

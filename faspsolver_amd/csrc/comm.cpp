@@ -22,6 +22,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -109,6 +110,7 @@ constexpr size_t SHM_BOX_BYTES = 64u << 20;  // mailbox per rank
 struct ShmHeader {
     std::atomic<int> arrive;
     std::atomic<int> generation;
+    std::atomic<int> error;   // set by any rank that fails inside a collective; every rank sees it after the barrier
     int              nranks;
 };
 struct ShmBoxHeader {
@@ -126,7 +128,16 @@ ShmBoxHeader* box_hdr(int r) { return reinterpret_cast<ShmBoxHeader*>(shm_box(r)
 double*       box_data(int r) { return reinterpret_cast<double*>(shm_box(r) + sizeof(ShmBoxHeader)); }
 constexpr size_t box_cap() { return (SHM_BOX_BYTES - sizeof(ShmBoxHeader)) / sizeof(double); }
 
-void shm_barrier()
+// Every rank enters every barrier of every collective (a failing rank raises the error flag FIRST and still
+// arrives), so no rank is ever left spinning on a peer that returned early; the wait itself is bounded.
+bool g_comm_failed = false;   // sticky: a collective failed on this rank or on a peer
+int  shm_timeout_s()
+{
+    static int t = -1;
+    if (t < 0) { const char* e = std::getenv("FASP_HIP_SHM_TIMEOUT_S"); t = e ? std::atoi(e) : 300; if (t <= 0) t = 300; }
+    return t;
+}
+int shm_barrier()
 {
     ShmHeader* h = shm_hdr();
     const int gen = h->generation.load(std::memory_order_acquire);
@@ -134,33 +145,52 @@ void shm_barrier()
         h->arrive.store(0, std::memory_order_relaxed);
         h->generation.store(gen + 1, std::memory_order_release);
     } else {
-        while (h->generation.load(std::memory_order_acquire) == gen) usleep(20);
+        const auto t0 = std::chrono::steady_clock::now();
+        long long polls = 0;
+        while (h->generation.load(std::memory_order_acquire) == gen) {
+            usleep(20);
+            if ((++polls & 1023) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (double)shm_timeout_s()) {
+                std::fprintf(stderr, "### ERROR: fasp_hip: rank %d waited %d s at a shared-memory barrier: a peer is gone\n",
+                             g_rank, shm_timeout_s());
+                h->error.store(1, std::memory_order_release);
+                g_comm_failed = true;
+                return ERROR_MISC;
+            }
+        }
     }
+    if (h->error.load(std::memory_order_acquire)) { g_comm_failed = true; return ERROR_MISC; }
+    return FASP_SUCCESS;
 }
+void shm_raise_error() { shm_hdr()->error.store(1, std::memory_order_release); g_comm_failed = true; }
 
 }  // namespace
 
-int comm_rank() { return g_rank; }
-int comm_size() { return g_size; }
+int  comm_rank() { return g_rank; }
+int  comm_size() { return g_size; }
+bool comm_failed() { return g_comm_failed; }
+void comm_mark_failed() { g_comm_failed = true; }
 
 int comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream)
 {
     if (g_size <= 1) return FASP_SUCCESS;
     if (g_backend == SHM) {
-        HCK(hipMemcpyAsync(g_stage, dbuf, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
-        HCK(hipStreamSynchronize(stream));
-        std::memcpy(box_data(g_rank), g_stage, sizeof(double) * n);
-        shm_barrier();
+        bool ok = n >= 0 && (size_t)n <= box_cap();
+        if (ok) ok = hipMemcpyAsync(g_stage, dbuf, sizeof(double) * n, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                     hipStreamSynchronize(stream) == hipSuccess;
+        if (ok) std::memcpy(box_data(g_rank), g_stage, sizeof(double) * n);
+        else shm_raise_error();
+        if (shm_barrier() < 0) { (void)shm_barrier(); return ERROR_MISC; }
         for (int i = 0; i < n; ++i) {
             const bool mx = (maxmask >> i) & 1u;
-            double v = mx ? 0.0 : 0.0;
-            for (int r = 0; r < g_size; ++r) {  // rank order: identical result on every rank
+            double v = box_data(0)[i];  // seeded with rank 0's value: a true maximum also for negative entries, like ncclMax
+            for (int r = 1; r < g_size; ++r) {  // rank order: identical result on every rank
                 const double x = box_data(r)[i];
                 v = mx ? (x > v ? x : v) : v + x;
             }
             g_stage[i] = v;
         }
-        shm_barrier();
+        if (shm_barrier() < 0) return ERROR_MISC;
         HCK(hipMemcpyAsync(dbuf, g_stage, sizeof(double) * n, hipMemcpyHostToDevice, stream));
         HCK(hipStreamSynchronize(stream));
         return FASP_SUCCESS;
@@ -184,34 +214,39 @@ int comm_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int n
     if (g_backend == SHM) {
         ShmBoxHeader* bh = box_hdr(g_rank);
         size_t off = 0;
+        bool   ok = true;
         for (int q = 0; q < g_size; ++q) { bh->off[q] = 0; bh->cnt[q] = 0; }
-        for (int i = 0; i < nsend; ++i) {
+        for (int i = 0; i < nsend && ok; ++i) {
             if (off + sends[i].count > box_cap()) {
                 std::fprintf(stderr, "### ERROR: fasp_hip: shm mailbox too small\n");
-                return ERROR_MISC;
+                ok = false;
+                break;
             }
-            HCK(hipMemcpyAsync(g_stage + off, sends[i].buf, sizeof(double) * sends[i].count, hipMemcpyDeviceToHost, stream));
+            ok = hipMemcpyAsync(g_stage + off, sends[i].buf, sizeof(double) * sends[i].count, hipMemcpyDeviceToHost, stream) == hipSuccess;
             bh->off[sends[i].peer] = (long long)off;
             bh->cnt[sends[i].peer] = (long long)sends[i].count;
             off += sends[i].count;
         }
-        HCK(hipStreamSynchronize(stream));
-        std::memcpy(box_data(g_rank), g_stage, sizeof(double) * off);
-        shm_barrier();
+        if (ok) ok = hipStreamSynchronize(stream) == hipSuccess;
+        if (ok) std::memcpy(box_data(g_rank), g_stage, sizeof(double) * off);
+        else shm_raise_error();
+        if (shm_barrier() < 0) { (void)shm_barrier(); return ERROR_MISC; }  // still arrive at the second barrier
         size_t roff = 0;
-        for (int i = 0; i < nrecv; ++i) {
+        for (int i = 0; i < nrecv && ok; ++i) {
             const ShmBoxHeader* ph = box_hdr(recvs[i].peer);
             if ((size_t)ph->cnt[g_rank] != recvs[i].count) {
                 std::fprintf(stderr, "### ERROR: fasp_hip: halo size mismatch: rank %d expects %zu from %d, offered %lld\n",
                              g_rank, recvs[i].count, recvs[i].peer, ph->cnt[g_rank]);
-                return ERROR_MISC;
+                ok = false;
+                break;
             }
             std::memcpy(g_stage + roff, box_data(recvs[i].peer) + ph->off[g_rank], sizeof(double) * recvs[i].count);
-            HCK(hipMemcpyAsync(recvs[i].buf, g_stage + roff, sizeof(double) * recvs[i].count, hipMemcpyHostToDevice, stream));
+            ok = hipMemcpyAsync(recvs[i].buf, g_stage + roff, sizeof(double) * recvs[i].count, hipMemcpyHostToDevice, stream) == hipSuccess;
             roff += recvs[i].count;
         }
-        HCK(hipStreamSynchronize(stream));
-        shm_barrier();
+        if (ok) ok = hipStreamSynchronize(stream) == hipSuccess;
+        if (!ok) shm_raise_error();
+        if (shm_barrier() < 0) return ERROR_MISC;
         return FASP_SUCCESS;
     }
     NCK(g_rccl.GroupStart());
@@ -232,19 +267,21 @@ int comm_allgatherv(const double* sendbuf, int sendcount, double* recvbuf, const
         return FASP_SUCCESS;
     }
     if (g_backend == SHM) {
-        if ((size_t)sendcount > box_cap()) return ERROR_MISC;
-        HCK(hipMemcpyAsync(g_stage, sendbuf, sizeof(double) * sendcount, hipMemcpyDeviceToHost, stream));
-        HCK(hipStreamSynchronize(stream));
-        std::memcpy(box_data(g_rank), g_stage, sizeof(double) * sendcount);
-        shm_barrier();
-        for (int r = 0; r < g_size; ++r) {
+        bool ok = (size_t)sendcount <= box_cap();
+        if (ok) ok = hipMemcpyAsync(g_stage, sendbuf, sizeof(double) * sendcount, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                     hipStreamSynchronize(stream) == hipSuccess;
+        if (ok) std::memcpy(box_data(g_rank), g_stage, sizeof(double) * sendcount);
+        else shm_raise_error();
+        if (shm_barrier() < 0) { (void)shm_barrier(); return ERROR_MISC; }
+        for (int r = 0; r < g_size && ok; ++r) {
             if (r == g_rank || counts[r] == 0) continue;
-            HCK(hipMemcpy(recvbuf + displs[r], box_data(r), sizeof(double) * counts[r], hipMemcpyHostToDevice));
+            ok = hipMemcpy(recvbuf + displs[r], box_data(r), sizeof(double) * counts[r], hipMemcpyHostToDevice) == hipSuccess;
         }
-        if (recvbuf + displs[g_rank] != sendbuf)
-            HCK(hipMemcpyAsync(recvbuf + displs[g_rank], sendbuf, sizeof(double) * sendcount, hipMemcpyDeviceToDevice, stream));
-        HCK(hipStreamSynchronize(stream));
-        shm_barrier();
+        if (ok && recvbuf + displs[g_rank] != sendbuf)
+            ok = hipMemcpyAsync(recvbuf + displs[g_rank], sendbuf, sizeof(double) * sendcount, hipMemcpyDeviceToDevice, stream) == hipSuccess;
+        if (ok) ok = hipStreamSynchronize(stream) == hipSuccess;
+        if (!ok) shm_raise_error();
+        if (shm_barrier() < 0) return ERROR_MISC;
         return FASP_SUCCESS;
     }
     // all-gather with per-rank counts as a group of broadcasts
@@ -286,6 +323,7 @@ int fasp_hip_comm_init(int rank, int nranks, const char* id_bytes)
     g_rank = rank;
     g_size = nranks;
     g_backend = RCCL;
+    g_comm_failed = false;
     return FASP_SUCCESS;
 }
 
@@ -316,6 +354,7 @@ int fasp_hip_comm_init_shm(int rank, int nranks, const char* name)
     if (rank == 0) {
         new (&shm_hdr()->arrive) std::atomic<int>(0);
         new (&shm_hdr()->generation) std::atomic<int>(0);
+        new (&shm_hdr()->error) std::atomic<int>(0);
         shm_hdr()->nranks = nranks;
         std::atomic_thread_fence(std::memory_order_seq_cst);
         reinterpret_cast<std::atomic<int>*>(g_shm_base + 2048)->store(0x5A5A, std::memory_order_release);
@@ -326,8 +365,8 @@ int fasp_hip_comm_init_shm(int rank, int nranks, const char* name)
     g_rank = rank;
     g_size = nranks;
     g_backend = SHM;
-    shm_barrier();
-    return FASP_SUCCESS;
+    g_comm_failed = false;
+    return shm_barrier();
 }
 
 int fasp_hip_comm_finalize(void)
@@ -337,7 +376,7 @@ int fasp_hip_comm_finalize(void)
         g_comm = nullptr;
     }
     if (g_backend == SHM && g_shm_base) {
-        shm_barrier();
+        (void)shm_barrier();
         munmap(g_shm_base, g_shm_bytes);
         g_shm_base = nullptr;
         if (g_rank == 0) shm_unlink(g_shm_name.c_str());

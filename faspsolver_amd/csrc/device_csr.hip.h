@@ -578,7 +578,7 @@ static void d_finalize_to(int G, int nq, unsigned maxmask, double* out, bool dis
 {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, g_ctx.stream, g_ctx.d_partials, G, nq,
                        maxmask, out);
-    if (dist && comm_size() > 1) comm_allreduce(out, nq, maxmask, g_ctx.stream);
+    if (dist && comm_size() > 1 && comm_allreduce(out, nq, maxmask, g_ctx.stream) < 0) comm_mark_failed();  // seen by fetch_red
 }
 static void d_finalize(int G, int nq, unsigned maxmask, int slot, bool dist)
 {
@@ -590,6 +590,10 @@ static int fetch_red(int slot, int nq, double* out)
                          hipMemcpyDeviceToHost, g_ctx.stream));
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     for (int q = 0; q < nq; ++q) out[q] = g_ctx.h_red[slot + q];
+    if (comm_failed()) {  // an all-reduce or halo exchange failed: the scalars are local, unreduced values
+        std::fprintf(stderr, "### ERROR: fasp_hip: rank %d: a collective failed; the iteration is abandoned\n", comm_rank());
+        return ERROR_MISC;
+    }
     return FASP_SUCCESS;
 }
 // (x,y) left on the device in reduction slot `slot` (no host round trip)

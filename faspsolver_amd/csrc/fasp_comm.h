@@ -8,6 +8,8 @@ namespace fasp {
 
 int  comm_rank();
 int  comm_size();
+bool comm_failed();       // sticky: a collective failed on this rank or (SHM transport) on a peer
+void comm_mark_failed();
 // sum-reduce (and max-reduce the entries whose bit is set in maxmask) n doubles in
 // place across all ranks, on `stream`.  No-op when comm_size() == 1.
 int  comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream);

@@ -28,29 +28,34 @@ template <class T>
 struct Buf {
     T*     p = nullptr;
     size_t n = 0;
+    bool   own = true;   // false: a view of memory owned elsewhere (a hierarchy mapped from shared memory)
     Buf() = default;
     explicit Buf(size_t n_) { alloc(n_); }
     Buf(const Buf&)            = delete;
     Buf& operator=(const Buf&) = delete;
-    Buf(Buf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    Buf(Buf&& o) noexcept : p(o.p), n(o.n), own(o.own) { o.p = nullptr; o.n = 0; o.own = true; }
     Buf& operator=(Buf&& o) noexcept
     {
-        if (this != &o) { std::free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; own = o.own; o.p = nullptr; o.n = 0; o.own = true; }
         return *this;
     }
-    ~Buf() { std::free(p); }
+    ~Buf() { release(); }
+    void release() { if (own) std::free(p); p = nullptr; n = 0; own = true; }
     void alloc(size_t n_)
     {
-        std::free(p);
+        release();
         n = n_;
         p = static_cast<T*>(std::malloc((n_ ? n_ : 1) * sizeof(T)));
         if (!p) throw std::bad_alloc();
     }
+    void view(T* q, size_t n_) { release(); p = q; n = n_; own = false; }
     void zero() { std::memset(p, 0, n * sizeof(T)); }
     void shrink(size_t n_)
     {
-        T* q = static_cast<T*>(std::realloc(p, (n_ ? n_ : 1) * sizeof(T)));
-        if (q) p = q;
+        if (own) {
+            T* q = static_cast<T*>(std::realloc(p, (n_ ? n_ : 1) * sizeof(T)));
+            if (q) p = q;
+        }
         n = n_;
     }
     T&       operator[](size_t i) { return p[i]; }

@@ -138,7 +138,10 @@ __global__ __launch_bounds__(BLOCK) void k_pack(int n, const int* __restrict__ i
 // slots (ghosts are sorted by owner, so every peer's block is contiguous).
 static int halo_exchange(DevLevel& D, double* v)
 {
-    if (!D.has_halo() && (D.send_off.empty() || D.send_off.back() == 0)) return FASP_SUCCESS;
+    // Every rank of a distributed level enters the exchange, also with nothing to send or receive: whether a level
+    // is distributed is known to all ranks alike, whether THIS rank has halo traffic is not (a rank that
+    // skipped the collective left its peers in the transport's barriers).
+    if (D.replicated || comm_size() <= 1 || D.send_off.empty()) return FASP_SUCCESS;
     const int P = comm_size(), me = comm_rank();
     const int nsend = D.send_off.back();
     if (nsend > 0)
@@ -151,7 +154,9 @@ static int halo_exchange(DevLevel& D, double* v)
         if (ns > 0) sends.push_back({q, D.d_sendbuf + D.send_off[q], (size_t)ns});
         if (nr > 0) recvs.push_back({q, v + D.nloc + D.recv_off[q], (size_t)nr});
     }
-    return comm_exchange(sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size(), g_ctx.stream);
+    const int st = comm_exchange(sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size(), g_ctx.stream);
+    if (st < 0) comm_mark_failed();
+    return st;
 }
 
 static int upload_hierarchy(fasp_hip_amg* h)

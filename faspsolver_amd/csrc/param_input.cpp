@@ -17,7 +17,6 @@
 namespace {
 
 constexpr int STRLEN = 256;  // fasp.h:77
-constexpr int ERROR_OPEN_FILE = -10;  // fasp_const.h:22
 
 // the members of the reference's input_param (fasp.h:1123-1190) that feed ITS_param / AMG_param
 struct InParam {
@@ -319,7 +318,6 @@ int fasp_hip_param_input(const char* fname, ITS_param* itsparam, AMG_param* amgp
 // calloc'ed; release them with fasp_hip_free_system / free().
 // ---------------------------------------------------------------------------
 namespace {
-constexpr int ERROR_WRONG_FILE = -11;  // fasp_const.h:23
 struct File {
     FILE* fp;
     explicit File(const char* name) : fp(std::fopen(name, "r")) {}

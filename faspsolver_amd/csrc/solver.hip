@@ -17,7 +17,11 @@
 // computes returns ERROR_MISC after printing why.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
 #include <omp.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -27,6 +31,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "fasp_comm.h"
@@ -76,9 +81,20 @@ static int ctx_init()
                              "no CPU fallback.\n", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
         return ERROR_MISC;
     }
-    int dev = g_requested_device >= 0 ? g_requested_device : 0;
-    if (const char* lr = std::getenv("FASP_HIP_DEVICE")) dev = std::atoi(lr);
-    if (dev >= ndev) dev = dev % ndev;
+    // an explicit fasp_hip_set_device() wins over the environment; FASP_HIP_DEVICE only fills in when nothing was asked for
+    int dev = 0;
+    if (g_requested_device >= 0) dev = g_requested_device;
+    else if (const char* lr = std::getenv("FASP_HIP_DEVICE")) dev = std::atoi(lr);
+    if (dev < 0 || dev >= ndev) {
+        // several ranks on one device is the validation set-up only (shared-memory transport): it must be asked for
+        const char* wrap = std::getenv("FASP_HIP_ALLOW_DEVICE_WRAP");
+        if (wrap && std::atoi(wrap) != 0 && dev >= 0) dev = dev % ndev;
+        else {
+            std::fprintf(stderr, "### ERROR: fasp_hip: device %d requested, %d visible (one process per GPU; "
+                                 "FASP_HIP_ALLOW_DEVICE_WRAP=1 shares devices for the shared-memory validation transport)\n", dev, ndev);
+            return ERROR_INPUT_PAR;
+        }
+    }
     HIPCK(hipSetDevice(dev));
     hipDeviceProp_t prop;
     HIPCK(hipGetDeviceProperties(&prop, dev));
@@ -168,6 +184,114 @@ int fasp_hip_amg_create_host(fasp_hip_amg** out, const dCSRmat* A, AMG_param* am
     return FASP_SUCCESS;
 }
 
+// ---- one host setup per node (SURVEY.md section 8e "Setup"): the rank that ran it publishes the host hierarchy
+// in a POSIX shared-memory segment, the other ranks of the node map it read-only and take their rows from it.
+namespace {
+struct ShmHierHeader {
+    unsigned long long magic;       // 'FASPHIER'
+    unsigned long long total_bytes;
+    int                nl;
+    AMG_param          param;       // as the setup left it
+    struct Lvl { int has_coarse; int dims[3][3]; unsigned long long off[3][3]; unsigned long long cf_off; unsigned long long cf_n; } lvl[MAX_AMG_LVL];
+};
+constexpr unsigned long long HIER_MAGIC = 0x5245494850534146ull;
+inline unsigned long long align64(unsigned long long x) { return (x + 63ull) & ~63ull; }
+struct ShmMapping { void* base; size_t bytes; };
+std::vector<std::pair<fasp_hip_amg*, ShmMapping>> g_attached;  // unmapped when the handle is destroyed
+}  // namespace
+
+int fasp_hip_amg_publish(const fasp_hip_amg* h, const char* name)
+{
+    if (!h || !name || h->H.L.empty() || (int)h->H.L.size() > MAX_AMG_LVL) return ERROR_INPUT_PAR;
+    const int nl = (int)h->H.L.size();
+    ShmHierHeader hd;
+    std::memset(&hd, 0, sizeof(hd));
+    hd.magic = HIER_MAGIC; hd.nl = nl; hd.param = h->param;
+    unsigned long long off = align64(sizeof(ShmHierHeader));
+    for (int l = 0; l < nl; ++l) {
+        const HostLevel& L = h->H.L[l];
+        hd.lvl[l].has_coarse = L.has_coarse ? 1 : 0;
+        const HostCSR* M[3] = {&L.A, &L.P, &L.R};
+        for (int w = 0; w < 3; ++w) {
+            if (w > 0 && !L.has_coarse) continue;
+            hd.lvl[l].dims[w][0] = M[w]->row; hd.lvl[l].dims[w][1] = M[w]->col; hd.lvl[l].dims[w][2] = M[w]->nnz;
+            hd.lvl[l].off[w][0] = off; off = align64(off + 4ull * ((unsigned long long)M[w]->row + 1));
+            hd.lvl[l].off[w][1] = off; off = align64(off + 4ull * (unsigned long long)M[w]->nnz);
+            hd.lvl[l].off[w][2] = off; off = align64(off + 8ull * (unsigned long long)M[w]->nnz);
+        }
+        hd.lvl[l].cf_n = L.cfmark.n;
+        hd.lvl[l].cf_off = off; off = align64(off + 4ull * L.cfmark.n);
+    }
+    hd.total_bytes = off;
+    const std::string nm = std::string("/") + name;
+    shm_unlink(nm.c_str());
+    const int fd = shm_open(nm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)off) != 0) { std::perror("fasp_hip_amg_publish"); if (fd >= 0) close(fd); return ERROR_MISC; }
+    char* base = (char*)mmap(nullptr, (size_t)off, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) { std::perror("fasp_hip_amg_publish mmap"); return ERROR_ALLOC_MEM; }
+    for (int l = 0; l < nl; ++l) {
+        const HostLevel& L = h->H.L[l];
+        const HostCSR* M[3] = {&L.A, &L.P, &L.R};
+        for (int w = 0; w < 3; ++w) {
+            if (w > 0 && !L.has_coarse) continue;
+            std::memcpy(base + hd.lvl[l].off[w][0], M[w]->ia.data(), 4 * ((size_t)M[w]->row + 1));
+            std::memcpy(base + hd.lvl[l].off[w][1], M[w]->ja.data(), 4 * (size_t)M[w]->nnz);
+            std::memcpy(base + hd.lvl[l].off[w][2], M[w]->val.data(), 8 * (size_t)M[w]->nnz);
+        }
+        if (L.cfmark.n) std::memcpy(base + hd.lvl[l].cf_off, L.cfmark.data(), 4 * L.cfmark.n);
+    }
+    std::memcpy(base, &hd, sizeof(hd));  // header last: a reader that sees the magic sees everything
+    munmap(base, (size_t)off);
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_amg_unpublish(const char* name)
+{
+    if (!name) return ERROR_INPUT_PAR;
+    shm_unlink((std::string("/") + name).c_str());
+    return FASP_SUCCESS;
+}
+
+int fasp_hip_amg_attach(fasp_hip_amg** out, const char* name)
+{
+    if (!out || !name) return ERROR_INPUT_PAR;
+    *out = nullptr;
+    const std::string nm = std::string("/") + name;
+    const int fd = shm_open(nm.c_str(), O_RDONLY, 0600);
+    if (fd < 0) { std::fprintf(stderr, "### ERROR: fasp_hip_amg_attach: no segment %s\n", nm.c_str()); return ERROR_OPEN_FILE; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof(ShmHierHeader)) { close(fd); return ERROR_WRONG_FILE; }
+    char* base = (char*)mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_SHARED, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) return ERROR_ALLOC_MEM;
+    const ShmHierHeader* hd = reinterpret_cast<const ShmHierHeader*>(base);
+    if (hd->magic != HIER_MAGIC || hd->total_bytes > (unsigned long long)sb.st_size || hd->nl <= 0 || hd->nl > MAX_AMG_LVL) {
+        munmap(base, (size_t)sb.st_size);
+        return ERROR_WRONG_FILE;
+    }
+    fasp_hip_amg* h = new fasp_hip_amg();
+    h->param = hd->param;
+    h->param.amli_coef = nullptr;  // a pointer of the publishing process; formed again on first use
+    h->H.L.resize((size_t)hd->nl);
+    for (int l = 0; l < hd->nl; ++l) {
+        HostLevel& L = h->H.L[(size_t)l];
+        L.has_coarse = hd->lvl[l].has_coarse != 0;
+        HostCSR* M[3] = {&L.A, &L.P, &L.R};
+        for (int w = 0; w < 3; ++w) {
+            if (w > 0 && !L.has_coarse) continue;
+            M[w]->row = hd->lvl[l].dims[w][0]; M[w]->col = hd->lvl[l].dims[w][1]; M[w]->nnz = hd->lvl[l].dims[w][2];
+            M[w]->ia.view(reinterpret_cast<int*>(base + hd->lvl[l].off[w][0]), (size_t)M[w]->row + 1);
+            M[w]->ja.view(reinterpret_cast<int*>(base + hd->lvl[l].off[w][1]), (size_t)M[w]->nnz);
+            M[w]->val.view(reinterpret_cast<double*>(base + hd->lvl[l].off[w][2]), (size_t)M[w]->nnz);
+        }
+        if (hd->lvl[l].cf_n) L.cfmark.view(reinterpret_cast<int*>(base + hd->lvl[l].cf_off), (size_t)hd->lvl[l].cf_n);
+    }
+    g_attached.push_back({h, ShmMapping{base, (size_t)sb.st_size}});
+    *out = h;
+    return FASP_SUCCESS;
+}
+
 int fasp_hip_amg_upload(fasp_hip_amg* h)
 {
     if (!h) return ERROR_INPUT_PAR;
@@ -208,7 +332,11 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
     if (h->gm_hh) (void)hipFree(h->gm_hh);
     if (h->spcg_state) (void)hipFree(h->spcg_state);
     if (h->spcg_fused_buf) (void)hipFree(h->spcg_fused_buf);
-    delete h;
+    ShmMapping map{nullptr, 0};
+    for (size_t q = 0; q < g_attached.size(); ++q)
+        if (g_attached[q].first == h) { map = g_attached[q].second; g_attached.erase(g_attached.begin() + (long)q); break; }
+    delete h;                                     // views release nothing
+    if (map.base) munmap(map.base, map.bytes);    // ... and the mapping goes after them
 }
 
 // Host-only check of the lossless matrix coding (no GPU needed): codes A the way upload_csr would,

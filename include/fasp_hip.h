@@ -43,6 +43,8 @@ extern "C" {
 /* constants (values of base/include/fasp_const.h)                          */
 /* ------------------------------------------------------------------------ */
 #define FASP_SUCCESS            0
+#define ERROR_OPEN_FILE       (-10)
+#define ERROR_WRONG_FILE      (-11)
 #define ERROR_INPUT_PAR       (-13)
 #define ERROR_MAT_SIZE        (-15)
 #define ERROR_MISC            (-19)
@@ -456,6 +458,14 @@ int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgpara
  * can be inspected with the getters below) and the upload to the bound GPU. */
 int fasp_hip_amg_create_host(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgparam);
 int fasp_hip_amg_upload(fasp_hip_amg* h);
+/* One host setup per node: the process that ran fasp_hip_amg_create_host publishes the host
+ * hierarchy (and the parameters as the setup left them) in the POSIX shared-memory segment /<name>; the other ranks
+ * of the node attach to it -- a host-only handle whose arrays are read-only views of the segment -- and call
+ * fasp_hip_amg_upload, which extracts and uploads the rows they own.  unpublish removes the name once every rank has
+ * attached (the mapping of an attached handle lives until fasp_hip_amg_destroy). */
+int fasp_hip_amg_publish(const fasp_hip_amg* h, const char* name);
+int fasp_hip_amg_attach(fasp_hip_amg** out, const char* name);
+int fasp_hip_amg_unpublish(const char* name);
 void fasp_hip_amg_destroy(fasp_hip_amg* h);
 
 /* Hierarchy inspection (parity tests compare these with the oracle). */

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, min_rows, q):
+def _worker(rank, world, port, n, min_rows, q, shared=False):
     try:
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
         import ctypes as C
@@ -34,7 +34,20 @@ def _worker(rank, world, port, n, min_rows, q):
         O = _libs.oracle()
         ia, ja, a, f, ue = fa.poisson7pt(n)
         amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
-        H = fa.AMG(ia, ja, a, amgp, host_only=True)
+        if shared:
+            # one host setup per node: rank 0 builds and publishes, the others map the segment (fasp_hip_amg_publish / _attach)
+            seg = f"fasp_cpu_test_{port}"
+            if rank == 0:
+                H = fa.AMG(ia, ja, a, amgp, host_only=True)
+                H.publish(seg)
+            dist.barrier()
+            if rank != 0:
+                H = fa.AMG.attach(seg)
+            dist.barrier()
+            if rank == 0:
+                fa.AMG.unpublish(seg)
+        else:
+            H = fa.AMG(ia, ja, a, amgp, host_only=True)
         H.dist_plan(rank, world, min_rows)
         nl = H.num_levels
         info = [H.dist_info(l) for l in range(nl)]
@@ -126,18 +139,22 @@ def _worker(rank, world, port, n, min_rows, q):
         q.put((rank, "fail", traceback.format_exc(), 0))
 
 
-@pytest.mark.parametrize("n,min_rows", [(12, 150), (16, 300)])
-def test_two_rank_partition_and_operators(n, min_rows):
+@pytest.mark.parametrize("n,min_rows,shared", [(12, 150, False), (16, 300, False), (16, 300, True)])
+def test_two_rank_partition_and_operators(n, min_rows, shared):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, min_rows, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, min_rows, q, shared)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
-    for p in procs:
-        p.join(30)
+    try:
+        res = [q.get(timeout=240) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.terminate()
     for r in res:
         assert r[1] == "ok", r[2]
     assert all(r[2] >= 3 for r in res)

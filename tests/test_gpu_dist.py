@@ -13,33 +13,71 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, name, n, min_rows, cycle, q):
+def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="shm", idfile=None):
     try:
         os.environ["FASP_HIP_DIST_MIN_ROWS"] = str(min_rows)
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
         import faspsolver_amd as fa
         from faspsolver_amd import _types as T
         L = fa.lib()
-        assert L.fasp_hip_set_device(0) == 0
-        assert L.fasp_hip_comm_init_shm(rank, world, name.encode()) == 0
+        import time
+        if transport == "rccl":   # the production transport: one device per rank, unique id through a file
+            import ctypes as C
+            assert L.fasp_hip_set_device(rank) == 0
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                assert L.fasp_hip_comm_unique_id(buf) == 0
+                with open(idfile + ".tmp", "wb") as fh:
+                    fh.write(buf.raw)
+                os.replace(idfile + ".tmp", idfile)
+            t0 = time.time()
+            while not os.path.exists(idfile):
+                assert time.time() - t0 < 120, "no unique id from rank 0"
+                time.sleep(0.05)
+            ids = open(idfile, "rb").read()
+            assert L.fasp_hip_comm_init(rank, world, ids) == 0
+        else:
+            assert L.fasp_hip_set_device(0) == 0
+            assert L.fasp_hip_comm_init_shm(rank, world, name.encode()) == 0
         ia, ja, a, f, ue = fa.poisson7pt(n)
         itp = fa.param_solver_init(); itp.tol = 1e-8
         amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
         amgp.cycle_type = cycle
-        H = fa.AMG(ia, ja, a, amgp)
+        if shared:   # one host setup: rank 0 publishes, the others attach
+            seg = name + "_hier"
+            flag = "/dev/shm/" + seg + ".ready"
+            if rank == 0:
+                H = fa.AMG(ia, ja, a, amgp, host_only=True)
+                H.publish(seg)
+                open(flag, "w").close()
+            else:
+                t0 = time.time()
+                while not os.path.exists(flag):
+                    assert time.time() - t0 < 120, "rank 0 never published"
+                    time.sleep(0.02)
+                H = fa.AMG.attach(seg)
+            H.upload()
+        else:
+            H = fa.AMG(ia, ja, a, amgp)
         info = H.dist_info(0)
         st, x, hist, stats = H.solve(f, itp)
         H.close()
         L.fasp_hip_comm_finalize()
+        if shared and rank == 0:
+            fa.AMG.unpublish(name + "_hier")
+            try:
+                os.remove("/dev/shm/" + name + "_hier.ready")
+            except OSError:
+                pass
         q.put((rank, "ok", st, hist, x[info["row0"]:info["row0"] + info["nloc"]], info))
     except Exception:  # pragma: no cover
         import traceback
         q.put((rank, "fail", traceback.format_exc(), None, None, None))
 
 
-@pytest.mark.parametrize("world,n,min_rows,cycle", [(2, 24, 500, 1), (3, 24, 2000, 1), (2, 20, 300, 2), (4, 32, 3000, 1)])
-def test_distributed_solve_matches_oracle(gpu, world, n, min_rows, cycle):
+def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm"):
     import multiprocessing as mp
+    import tempfile
     from _libs import T, default_params, orc_solve, poisson7pt
     ia, ja, a, f, ue = poisson7pt(n)
     itp, amgp = default_params()
@@ -47,13 +85,22 @@ def test_distributed_solve_matches_oracle(gpu, world, n, min_rows, cycle):
     s_ref, x_ref, h_ref, rr = orc_solve(ia, ja, a, f, itp, amgp)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    name = f"fasp_test_{os.getpid()}_{world}_{n}"
-    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q)) for r in range(world)]
+    name = f"fasp_test_{os.getpid()}_{world}_{n}_{int(shared)}"
+    idfile = os.path.join(tempfile.gettempdir(), name + ".ncclid")
+    if os.path.exists(idfile):
+        os.remove(idfile)
+    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q, shared, transport, idfile)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(60)
+    try:
+        res = [q.get(timeout=600) for _ in procs]
+    finally:   # a failed rank must not leave its peers (or this test) waiting
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.terminate()
+        if os.path.exists(idfile):
+            os.remove(idfile)
     for r in res:
         assert r[1] == "ok", r[2]
     for rank, _, st, hist, xloc, info in res:
@@ -66,6 +113,23 @@ def test_distributed_solve_matches_oracle(gpu, world, n, min_rows, cycle):
     # every rank saw bit-identical scalars
     for r in res[1:]:
         assert np.array_equal(r[3], res[0][3])
+
+
+@pytest.mark.parametrize("world,n,min_rows,cycle,shared", [(2, 24, 500, 1, False), (3, 24, 2000, 1, False), (2, 20, 300, 2, False),
+                                                           (4, 32, 3000, 1, False), (3, 24, 2000, 1, True)])
+def test_distributed_solve_matches_oracle(gpu, world, n, min_rows, cycle, shared):
+    _run_ranks(world, n, min_rows, cycle, shared)
+
+
+def test_rccl_transport_with_all_visible_gpus(gpu):
+    """The production transport with real peers: world = number of visible GPUs (skipped on a one-GPU box, where the
+    shared-memory transport above drives the same partition / halo / replicated-level code).  Halo ncclSend / ncclRecv,
+    the all-gather at the replicated boundary and the scalar all-reduces against the oracle."""
+    import faspsolver_amd as fa
+    ndev = fa.lib().fasp_hip_device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} GPU visible: RCCL with peers needs at least two")
+    _run_ranks(min(ndev, 8), 40, 4000, 1, shared=True, transport="rccl")
 
 
 @pytest.mark.gpu
