@@ -26,6 +26,88 @@ static int small_out_fetch(SmallOut& o)
     return 0;
 }
 
+// k_spcg_persist (small_solvers.hip.h): deal the rows of the coarsest matrix to the waves of the chip -- whole rows,
+// longest first, always to the least loaded wave -- and lay their entries out slot by slot (64 lanes x NE slots per
+// wave) for the registers.  Returns false (and remembers it) when the level does not fit the scheme.
+static bool g_persist_disabled = false;
+static bool build_persist_plan(fasp_hip_amg* h, int level)
+{
+    auto& P = h->persist;
+    if (P.tried) return P.ok;
+    P.tried = true;
+    const HostCSR& A = h->H.L[(size_t)level].A;
+    const int m = A.row;
+    const int nblocks = g_ctx.num_cu, nw = (nblocks - 1) * 8;   // 512-thread blocks, block 0 owns no rows
+    if (m < 1 || m > 6144 || m != A.col || nw < 8 || A.nnz <= 0) return false;
+    std::vector<int> order((size_t)m), slots((size_t)m);
+    for (int i = 0; i < m; ++i) { order[(size_t)i] = i; slots[(size_t)i] = (A.ia[i + 1] - A.ia[i] + 63) / 64; }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return slots[(size_t)x] > slots[(size_t)y]; });
+    std::vector<int> load((size_t)nw, 0), cnt((size_t)nw, 0), wrow((size_t)nw * 8, -1), wend((size_t)nw * 8, 0);
+    // least-loaded wave first: a binary heap of (load, wave)
+    std::vector<std::pair<int, int>> heap;
+    for (int w = 0; w < nw; ++w) heap.emplace_back(0, w);
+    auto cmp = [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x > y; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    for (int i : order) {
+        if (slots[(size_t)i] == 0) continue;   // empty row: t_i = 0 is written by nobody -> not representable here
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        std::pair<int, int> top = heap.back();
+        const int w = top.second;
+        if (cnt[(size_t)w] >= 8) return false;
+        load[(size_t)w] += slots[(size_t)i];
+        wrow[(size_t)w * 8 + cnt[(size_t)w]] = i;
+        wend[(size_t)w * 8 + cnt[(size_t)w]] = load[(size_t)w];
+        cnt[(size_t)w]++;
+        heap.back() = std::make_pair(load[(size_t)w], w);
+        std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+    for (int i = 0; i < m; ++i) if (slots[(size_t)i] == 0) return false;
+    const int maxload = *std::max_element(load.begin(), load.end());
+    const int NE = maxload <= 32 ? 32 : maxload <= 48 ? 48 : maxload <= 56 ? 56 : maxload <= 64 ? 64 : 0;   // doubles per lane that stay in the 256 registers of a lane
+    if (!NE) return false;
+    const size_t tot = (size_t)nw * NE * 64;
+    Buf<double> vals(tot);
+    Buf<unsigned short> cols(tot);
+    std::memset(vals.data(), 0, tot * sizeof(double));
+    std::memset(cols.data(), 0, tot * sizeof(unsigned short));
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int w = 0; w < nw; ++w) {
+        int base = 0;
+        for (int j = 0; j < cnt[(size_t)w]; ++j) {
+            const int row = wrow[(size_t)w * 8 + j];
+            const int kb = A.ia[row], len = A.ia[row + 1] - kb;
+            for (int e = 0; e < len; ++e) {
+                const size_t at = ((size_t)w * NE + base + e / 64) * 64 + (size_t)(e % 64);
+                vals[at] = A.val[kb + e];
+                cols[at] = (unsigned short)(A.ja[kb + e] * 8);   // byte offset into p's LDS image (m <= 6144: < 65536)
+            }
+            base = wend[(size_t)w * 8 + j];
+        }
+    }
+    bool ok = hipMalloc(&P.vals, tot * sizeof(double)) == hipSuccess && hipMalloc(&P.cols, tot * sizeof(unsigned short)) == hipSuccess &&
+              hipMalloc(&P.wrow, sizeof(int) * (size_t)nw * 8) == hipSuccess && hipMalloc(&P.wend, sizeof(int) * (size_t)nw * 8) == hipSuccess &&
+              hipMalloc(&P.t2, sizeof(double) * 2 * (size_t)m) == hipSuccess && hipMalloc(&P.sync, 1024) == hipSuccess;
+    if (ok) ok = hipMemcpy(P.vals, vals.data(), tot * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(P.cols, cols.data(), tot * sizeof(unsigned short), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(P.wrow, wrow.data(), sizeof(int) * (size_t)nw * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(P.wend, wend.data(), sizeof(int) * (size_t)nw * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) return false;
+    P.NE = NE; P.nblocks = nblocks; P.ok = true;
+    return true;
+}
+
+template <int NE>
+static int launch_spcg_persist(const SpcgPersistArgs& pa, size_t lds)
+{
+    static bool attr = false;
+    if (!attr) {
+        HIPCK(hipFuncSetAttribute((const void*)k_spcg_persist<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_spcg_persist<NE>, dim3(pa.nblocks), dim3(512), lds, g_ctx.stream, pa);
+    return FASP_SUCCESS;
+}
+
 static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
 {
     const DevCSR& A = D.A;
@@ -72,6 +154,10 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
     // one launch per iteration (k_spcg_fused) when p fits the LDS of a CU and the level is stored as plain CSR
     // (p in LDS: 8 m bytes of dynamic LDS next to the reduction scratch, within the 64 KB a kernel gets without opting in)
     const bool fused = g_tune.spcg_fused && m <= 8000 && A.val && A.ja && !A.code && !A.pat;
+    // one launch per coarse SOLVE with the matrix resident in the register files (k_spcg_persist): needs the chip to
+    // itself (every block resident at once) -- not when several validation ranks share a device
+    const bool persist = fused && g_tune.spcg_persist && !g_persist_disabled && !comm_shares_devices() &&
+                         (size_t)m * 24 <= 150 * 1024 && build_persist_plan(h, (int)(&D - &h->L[0]));
     if (!h->spcg_state) HIPCK(hipMalloc(&h->spcg_state, sizeof(SpcgState)));
     if (fused) {  // the start of the solve on the device too: no host round trip before the first batch
         if (!D.x_zero) d_resid(A, u, b, r);
@@ -130,7 +216,24 @@ ITERATE:
             bc = reinterpret_cast<SpcgBc*>(T[1] + m);
         }
         for (;;) {
-            for (int q = 0; q < batch && fused; ++q) {
+            if (persist) {
+                const auto& PP = h->persist;
+                SpcgPersistArgs pa{};
+                pa.m = m; pa.max_steps = MaxIt + 2; pa.nblocks = PP.nblocks; pa.st = h->spcg_state;
+                pa.r = r; pa.p = p; pa.u = u; pa.u_best = u_best; pa.t2 = PP.t2; pa.sync = PP.sync;
+                pa.vals = PP.vals; pa.cols = PP.cols; pa.wrow = PP.wrow; pa.wend = PP.wend;
+                HIPCK(hipMemsetAsync(PP.sync, 0, 1024, s));
+                // p, r, t in every block; a fourth vector (u, used by block 0) when the CU's 160 KiB allow it
+                pa.u_lds = (sizeof(double) * 4 * (size_t)m + 1024 <= 160 * 1024) ? 1 : 0;
+                const size_t lds = sizeof(double) * (pa.u_lds ? 4 : 3) * (size_t)m;
+                int lst;
+                if (PP.NE == 32) lst = launch_spcg_persist<32>(pa, lds);
+                else if (PP.NE == 48) lst = launch_spcg_persist<48>(pa, lds);
+                else if (PP.NE == 56) lst = launch_spcg_persist<56>(pa, lds);
+                else lst = launch_spcg_persist<64>(pa, lds);
+                if (lst < 0) return lst;
+            }
+            for (int q = 0; q < batch && fused && !persist; ++q) {
                 SpcgFusedArgs fa{};
                 fa.m = m; fa.first = first ? 1 : 0; fa.in = cur; fa.st = h->spcg_state; fa.bc = bc;
                 fa.ia = A.ia; fa.ja = A.ja; fa.ja16 = A.ja16; fa.val = A.val;
@@ -164,8 +267,25 @@ ITERATE:
                 normr0 = S.normr0;
                 if (S.stop == SPCG_ZERO_RHS) { relres = S.relres; goto FINISHED; }  // KrySPcg.c:135
             }
+#ifdef SPCG_PERSIST_STAMPS
+            if (persist) {
+                unsigned dbg[64];
+                (void)hipMemcpy(dbg, h->persist.sync, sizeof(dbg), hipMemcpyDeviceToHost);
+                std::printf("[persist stamps, 10 ns ticks, %d steps] lead:", S.iter);
+                for (int q = 0; q < 8; ++q) std::printf(" %u", dbg[32 + q]);
+                std::printf(" | block 1:");
+                for (int q = 0; q < 8; ++q) std::printf(" %u", dbg[40 + q]);
+                std::printf("   (spmv meet read step(tail) pass1-2 pass3 reduce4 -)\n");
+            }
+#endif
+            if (S.stop == SPCG_HANG) {
+                std::fprintf(stderr, "### ERROR: fasp_hip: the persistent coarse CG kernel timed out at its grid meeting (a block was not "
+                                     "resident: is another process using this GPU?); FASP_HIP_TUNE spcg_persist=0 selects the per-iteration kernels\n");
+                g_persist_disabled = true;
+                return ERROR_MISC;
+            }
             if (S.stop == SPCG_RUN) continue;
-            if (fused) { cur = S.pad; r = R[cur]; p = P[cur]; first = true; }  // where the last finished step left r and p
+            if (fused && !persist) { cur = S.pad; r = R[cur]; p = P[cur]; first = true; }  // where the last finished step left r and p
             // a test fired in iteration S.iter: finish that iteration as the reference does
             temp2 = S.tp; temp1 = S.temp1_prev;
             red[0] = S.rr; red[1] = S.uu; red[2] = S.pp; red[3] = S.maxu; red[4] = S.nan;

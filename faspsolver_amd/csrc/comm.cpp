@@ -169,6 +169,7 @@ void shm_raise_error() { shm_hdr()->error.store(1, std::memory_order_release); g
 int  comm_rank() { return g_rank; }
 int  comm_size() { return g_size; }
 bool comm_failed() { return g_comm_failed; }
+bool comm_shares_devices() { return g_backend == SHM; }
 void comm_mark_failed() { g_comm_failed = true; }
 
 int comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream)

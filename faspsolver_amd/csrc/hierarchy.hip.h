@@ -59,6 +59,9 @@ struct fasp_hip_amg {
     double*              spcg_fused_buf = nullptr;  // second parity of r, p, t and the broadcast record (k_spcg_fused)
     int                  spcg_last_iters = 0;   // iterations of the previous coarse solve: sizes the first batch of the next one
     SpcgState*           spcg_state = nullptr;  // device-resident state of the batched coarse CG
+    // k_spcg_persist: the coarsest matrix dealt to the waves of the chip (built on first use; tried == true afterwards)
+    struct Persist { bool tried = false, ok = false; int NE = 0, nblocks = 0; double* vals = nullptr; unsigned short* cols = nullptr;
+                     int *wrow = nullptr, *wend = nullptr; double* t2 = nullptr; unsigned* sync = nullptr; } persist;
     std::vector<double>  amli_coef;             // AMLI polynomial coefficients (amli_degree + 1), formed on first use
     std::vector<int>     level_cycle_type;      // AMG_data.cycle_type per level as the setup leaves it (K-cycle)
     bool                 use_fmg = false;       // the preconditioner is one full-multigrid cycle (precond_type == PREC_FMG)

@@ -844,4 +844,360 @@ FINISHED:
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_spcg_persist<NE>: the safe CG of a coarsest level too large for one CU (P7(256): 4 971 rows, 6.4 M
+// entries = 64 MB) as ONE launch per coarse solve, the matrix resident ON CHIP for all its iterations.
+//
+//   * The chip's register files hold the matrix: wave w of block b >= 1 owns up to 4 whole rows (assigned on the
+//     host, longest-processing-time first: 56 slots of 64 entries against an ideal of 50 on P7(256)) and keeps
+//     their values (NE doubles per lane) and LDS byte offsets of their columns (NE 16-bit values per lane) in
+//     VGPRs from the first iteration to the last.  64 MB are read once per solve instead of once per iteration.
+//   * Every block keeps r and p in its LDS and repeats the scalar recurrence on its own (same loads, same
+//     reduction order -> bit-identical alpha, beta, ||r|| in every block: k_spcg_fused's scheme); p is gathered
+//     from LDS by the row sums.
+//   * Per iteration ONE exchange: the waves publish t = A p (40 KB, write-through stores), the blocks meet at an
+//     arrival counter and read t back through L2 (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores,
+//     drained; one lane per workgroup adds to the counter behind the workgroup barrier; relaxed sc1 poll; sc1
+//     loads).  t and the stop word are double-buffered by iteration parity, so nothing read in an iteration is
+//     written in it.
+//   * Block 0 owns no rows; it carries what nobody else needs (u, its norms, the best iterate, the reference's
+//     exit tests, KrySPcg.c:147-199) and raises the stop word; the others see it after the next meeting.
+//   The host queues nothing: it reads the state once per solve and replays a fired test exactly as for
+//   k_spcg_fused (coarse_cg.hip.h).  Every spin is bounded (SPCG_HANG + error word).
+// ---------------------------------------------------------------------------
+constexpr int SPCG_HANG = 8;
+
+// Sum over the 64 lanes of a wavefront by data-parallel-primitive moves (no LDS crossbar round trips): inclusive
+// row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast 15 and 31 across them; the total ends in lane 63.  Fixed order.
+__device__ __forceinline__ double dpp_mov_f64(double x, const int ctrl, const int row_mask)
+{
+    const long long b = __double_as_longlong(x);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    switch (ctrl) {   // the control word must be a compile-time constant
+        case 0x111: lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
+        case 0x112: lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
+        case 0x114: lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
+        case 0x118: lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
+        case 0x142: lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, true); break;
+        default:    lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, true); break;
+    }
+    (void)row_mask;
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double x)
+{
+    x += dpp_mov_f64(x, 0x111, 0xf);
+    x += dpp_mov_f64(x, 0x112, 0xf);
+    x += dpp_mov_f64(x, 0x114, 0xf);
+    x += dpp_mov_f64(x, 0x118, 0xf);
+    x += dpp_mov_f64(x, 0x142, 0xa);   // lanes of rows 1 and 3 take lane 15 / 47 (rows not in the mask add 0)
+    x += dpp_mov_f64(x, 0x143, 0xc);   // lanes of rows 2 and 3 take lane 31
+    return x;
+}
+
+struct SpcgPersistArgs {
+    int        m, max_steps, nblocks;
+    int        u_lds;                  // the launch carries a fourth LDS vector: block 0 keeps u on chip
+    SpcgState* st;
+    double    *r, *p, *u, *u_best;     // r, p: in / out (block 0 writes them back at the end)
+    double*    t2;                     // [2][m] published products
+    unsigned*  sync;                   // [0] arrival counter, [1..2] stop word by parity, [3] error word; zeroed before the launch
+    const double*         vals;        // [(nblocks-1)*8][NE][64]
+    const unsigned short* cols;        // same shape: column * 8 (byte offset into p's LDS image)
+    const int*            wrow;        // [(nblocks-1)*8][8] rows of the wave (-1: none)
+    const int*            wend;        // [(nblocks-1)*8][8] end slot (exclusive) of each of them
+};
+
+// blk_reduce with the wave stage on data-parallel-primitive moves instead of LDS-crossbar shuffles (a dozen dependent
+// ds_bpermute round trips per quantity are microseconds when a kernel runs one or two waves per SIMD)
+__device__ __forceinline__ double wave_max_to_lane63(double x)
+{
+    x = fmax(x, dpp_mov_f64(x, 0x111, 0xf));   // (rows shifted in are 0: the quantities reduced this way are >= 0)
+    x = fmax(x, dpp_mov_f64(x, 0x112, 0xf));
+    x = fmax(x, dpp_mov_f64(x, 0x114, 0xf));
+    x = fmax(x, dpp_mov_f64(x, 0x118, 0xf));
+    x = fmax(x, dpp_mov_f64(x, 0x142, 0xa));
+    x = fmax(x, dpp_mov_f64(x, 0x143, 0xc));
+    return x;
+}
+// workgroup barrier that orders LDS traffic only: global stores in flight (the published products, the best iterate)
+// stay in flight across it -- __syncthreads() would wait for every one of them to be acknowledged
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <int NQ, int NW>
+__device__ __forceinline__ void blk_reduce_dpp(double (&v)[NQ], double* sh, unsigned maxmask = 0u)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const bool mx = (maxmask >> q) & 1u;
+        const double x = mx ? wave_max_to_lane63(v[q]) : wave_sum_to_lane63(v[q]);
+        if (lane == 63) sh[w * NQ + q] = x;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const bool mx = (maxmask >> q) & 1u;
+        double x = sh[q];
+        for (int k = 1; k < NW; ++k) {
+            const double y = sh[k * NQ + q];
+            x = mx ? fmax(x, y) : x + y;
+        }
+        v[q] = x;
+    }
+    lds_barrier();
+}
+
+__device__ __forceinline__ bool absres_improves(double rr, double best, double maxdiff) { return sqrt(rr) < best - maxdiff; }
+
+template <int NE>
+__global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
+{
+    constexpr int NT = 512, NW = 8, E = 12, EQ = 6, CH = 6;  // m <= E * NT = 6144; two waves per SIMD: 256 registers per lane
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    __shared__ double sh[NW * 4];
+    __shared__ int    s_flag;
+    typedef __attribute__((address_space(1))) unsigned           gu32;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    const int tid = threadIdx.x, lane = tid & 63, m = a.m;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool lead = blockIdx.x == 0;
+    double* sp = dyn;        // p
+    double* sr = dyn + m;    // r
+    double* st = dyn + 2 * m;  // t of this iteration, read back from the published copy
+    double* su = dyn + 3 * m;  // block 0, a.u_lds: the iterate itself (written back once, at the end)
+    gu32* g_cnt = (gu32*)(a.sync);
+    gu32* g_stop = (gu32*)(a.sync + 1);
+    gu32* g_err = (gu32*)(a.sync + 3);
+    SpcgState& S = *a.st;
+    if (S.stop != SPCG_RUN) return;   // (written before this launch: every block reads the same value)
+
+    // ---- the wave's slice of the matrix -> registers ----
+    double   v[NE];
+    unsigned cpk[NE / 2];
+    int      my_rows = 0, endsv = 0, rowsv = -1;   // lane j < 8 holds end slot / row id of the wave's j-th row
+    if (!lead) {
+        const int gw = ((int)blockIdx.x - 1) * NW + wave;
+        const double* pv = a.vals + ((size_t)gw * NE) * 64 + lane;
+        const unsigned short* pc = a.cols + ((size_t)gw * NE) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) v[k] = __builtin_nontemporal_load(pv + (size_t)k * 64);
+#pragma unroll
+        for (int k = 0; k < NE / 2; ++k)
+            cpk[k] = (unsigned)__builtin_nontemporal_load(pc + (size_t)(2 * k) * 64) |
+                     ((unsigned)__builtin_nontemporal_load(pc + (size_t)(2 * k + 1) * 64) << 16);
+        if (lane < 8) { endsv = a.wend[gw * 8 + lane]; rowsv = a.wrow[gw * 8 + lane]; }
+        my_rows = __popcll(__ballot(lane < 8 && rowsv >= 0));
+    }
+    for (int i = tid; i < m; i += NT) { sp[i] = a.p[i]; sr[i] = a.r[i]; }
+    const bool u_lds = a.u_lds != 0;
+    if (lead && u_lds) for (int i = tid; i < m; i += NT) su[i] = a.u[i];
+    double temp1 = S.temp1;
+    const double absres_best0 = S.absres_best, normr0 = S.normr0, tol = S.tol, maxdiff = S.maxdiff;
+    const int    it0 = S.iter, stag = S.stag, MaxIt = S.MaxIt;
+    double best = absres_best0;
+    int    iter_best = S.iter_best;
+    // scalars of the latest finished step (block 0, thread 0 writes them out at the end)
+    double o_tp = S.tp, o_rr = S.rr, o_uu = S.uu, o_pp = S.pp, o_maxu = S.maxu, o_nan = S.nan, o_alpha = S.alpha,
+           o_absres = S.absres, o_relres = S.relres, o_temp1_prev = S.temp1_prev;
+    int steps_done = 0, my_stop = SPCG_RUN;
+    __syncthreads();
+#ifdef SPCG_PERSIST_STAMPS
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memrealtime();
+#define STAMP(q) do { const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tk[q] += tn_ - tl; tl = tn_; } while (0)
+#else
+#define STAMP(q) do { } while (0)
+#endif
+
+    for (int step = 0; step < a.max_steps; ++step) {
+        const int par = step & 1;
+        double* tpub = a.t2 + (size_t)par * m;
+        // ---- t = A p on the rows of this wave, p from LDS, matrix from registers ----
+        if (!lead && my_rows > 0 && my_stop == SPCG_RUN) {
+            double acc = 0.0;
+            int    j = 0;
+            int    next_end = __builtin_amdgcn_readlane(endsv, 0);
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const unsigned off = (k & 1) ? (cpk[k >> 1] >> 16) : (cpk[k >> 1] & 0xffffu);
+                const double x = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sp) + off);
+                acc += v[k] * x;
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // eight gathers in flight, not NE of them: the registers hold the matrix
+                if (k + 1 == next_end) {   // wave-uniform: the row is complete
+                    const double ssum = wave_sum_to_lane63(acc);
+                    const int row = __builtin_amdgcn_readlane(rowsv, j);
+                    if (lane == 63)
+                        __hip_atomic_store((gu64*)(tpub + row), (unsigned long long)__double_as_longlong(ssum), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    acc = 0.0;
+                    ++j;
+                    next_end = (j < 8) ? __builtin_amdgcn_readlane(endsv, j & 7) : -1;
+                    if (j >= my_rows) next_end = -1;
+                }
+            }
+        }
+        // ---- meet: every storing wave drains its stores, the block's barrier, one lane adds, one lane polls ----
+        STAMP(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            // arrival in two stages: the blocks b, b + 8, ... (one XCD under round-robin placement -- for speed only) add to
+            // their shard; the last of a shard adds to the top counter, which every block polls
+            const unsigned shard = blockIdx.x & 7u;
+            const unsigned in_shard = ((unsigned)a.nblocks - shard + 7u) >> 3;
+            gu32* g_sh = (gu32*)(a.sync + 16 + 16 * shard);
+            if (__hip_atomic_fetch_add(g_sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard * (unsigned)(step + 1))
+                __hip_atomic_fetch_add(g_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)min(a.nblocks, 8) * (unsigned)(step + 1);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int ok = 1;
+            while (__hip_atomic_load(g_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz: a block is not resident
+                    __hip_atomic_store(g_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+            if (__hip_atomic_load(g_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+            int flag = ok ? 0 : -1;
+            if (ok && step > 0) flag = (int)__hip_atomic_load(g_stop + ((step - 1) & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_flag = flag;
+        }
+        __syncthreads();
+        STAMP(1);
+        const int flag = s_flag;
+        if (flag != 0) { if (flag < 0) my_stop = SPCG_HANG; break; }   // the previous step raised a stop (or a hang): uniform over the grid
+        if (my_stop != SPCG_RUN) break;                                // (block 0 after its own verdict: it only had to arrive)
+        // ---- read t back (write-through stores of other CUs: sc1 loads, never the L1) ----
+        // (t, p and r live in LDS and are re-read pass by pass: the registers belong to the matrix)
+        {
+            typedef unsigned int tu32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc(tpub, 0, (int)((unsigned)m * 8u), 0x00020000);
+#pragma unroll 1
+            for (int e0 = 0; e0 < EQ; e0 += 6) {   // six 16-byte loads in flight per thread
+                tu32x4 q[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(tr, (tid + (e0 + e) * NT) * 16, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const int i = 2 * (tid + (e0 + e) * NT);
+                    if (i + 1 < m) *reinterpret_cast<tu32x4*>(st + i) = q[e];
+                    else if (i < m) st[i] = __longlong_as_double((long long)(((unsigned long long)q[e].y << 32) | q[e].x));
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(2);
+        // the vector passes run in chunks of 8 entries per thread: 8 LDS reads in flight, few registers (they hold the matrix)
+        double v1[1] = {0.0};
+#pragma unroll 1
+        for (int e0 = 0; e0 < E; e0 += CH) {
+            double tv[CH], pv[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) { const int i = min(tid + (e0 + e) * NT, m - 1); tv[e] = st[i]; pv[e] = sp[i]; }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) if (tid + (e0 + e) * NT < m) v1[0] += tv[e] * pv[e];
+        }
+        blk_reduce_dpp<1, NW>(v1, sh);
+        const double tp = v1[0];
+        if (!(fabs(tp) > 1e-40)) {   // KrySPcg.c:172-177: breakdown, nothing is updated; every block takes this exit
+            o_tp = tp; steps_done = step + 1; my_stop = SPCG_DIV0;
+            break;
+        }
+        const double alpha = temp1 / tp;
+        v1[0] = 0.0;
+#pragma unroll 1
+        for (int e0 = 0; e0 < E; e0 += CH) {
+            double tv[CH], rv[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) { const int i = min(tid + (e0 + e) * NT, m - 1); tv[e] = st[i]; rv[e] = sr[i]; }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int i = tid + (e0 + e) * NT;
+                if (i < m) {
+                    const double rn = rv[e] - alpha * tv[e];
+                    sr[i] = rn;   // own entries of this thread in every pass
+                    v1[0] += rn * rn;
+                }
+            }
+        }
+        blk_reduce_dpp<1, NW>(v1, sh);
+        const double rr = v1[0], beta = rr / temp1;
+        double red[4] = {0.0, 0.0, 0.0, 0.0};  // block 0: (u,u), (p,p), max |u|, NaN count
+        STAMP(4);
+        const bool keep_best = lead && absres_improves(rr, best, maxdiff);   // KrySPcg.c:189-193, decided from rr alone
+#pragma unroll 1
+        for (int e0 = 0; e0 < E; e0 += CH) {
+            double rv[CH], pv[CH], uv[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int i = min(tid + (e0 + e) * NT, m - 1);
+                rv[e] = sr[i]; pv[e] = sp[i];
+                uv[e] = lead ? (u_lds ? su[i] : a.u[i]) : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int i = tid + (e0 + e) * NT;
+                if (i < m) {
+                    sp[i] = 1.0 * rv[e] + beta * pv[e];
+                    if (lead) {
+                        const double ui = uv[e] + alpha * pv[e];
+                        if (u_lds) su[i] = ui; else a.u[i] = ui;
+                        if (keep_best) a.u_best[i] = ui;
+                        red[0] += ui * ui; red[1] += pv[e] * pv[e];
+                        red[2] = fmax(red[2], fabs(ui));
+                        red[3] += (ui != ui) ? 1.0 : 0.0;
+                    }
+                }
+            }
+        }
+        STAMP(5);
+        if (lead) {
+            const int it = it0 + step + 1;
+            blk_reduce_dpp<4, NW>(red, sh, 1u << 2);
+            STAMP(6);
+            const double absres = sqrt(rr), relres = absres / normr0;
+            int stop = SPCG_RUN;
+            if (red[3] > 0.0) stop = SPCG_NAN;
+            else {
+                if (absres < best - maxdiff) { best = absres; iter_best = it; }   // (the copy into u_best went out above)
+                const double reldiff = fabs(alpha) * sqrt(red[1]) / sqrt(red[0]);
+                if (red[2] <= 1e-20) stop = SPCG_SOLSTAG;                        // Check I
+                else if ((stag <= 20) & (reldiff < maxdiff)) stop = SPCG_STAG;   // Check II: host recomputes r
+                else if (relres < tol) stop = SPCG_CONV;                         // Check III: host checks the true residual
+                if (stop == SPCG_RUN && it >= MaxIt) stop = SPCG_MAXIT;
+            }
+            o_tp = tp; o_rr = rr; o_uu = red[0]; o_pp = red[1]; o_maxu = red[2]; o_nan = red[3];
+            o_alpha = alpha; o_absres = absres; o_relres = relres; o_temp1_prev = temp1;
+            my_stop = stop;
+            if (tid == 0) __hip_atomic_store(g_stop + par, (unsigned)stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        temp1 = rr;
+        steps_done = step + 1;
+        lds_barrier();   // p, r complete in LDS before the next product gathers from them
+        STAMP(3);
+    }
+#ifdef SPCG_PERSIST_STAMPS
+    if (tid == 0 && blockIdx.x < 2)
+        for (int q = 0; q < 8; ++q) a.sync[32 + blockIdx.x * 8 + q] = (unsigned)tk[q];
+#endif
+#undef STAMP
+
+    if (lead) {
+        // r and p as the last finished step left them (a breakdown updates nothing: the LDS images are the old ones)
+        for (int i = tid; i < m; i += NT) { a.r[i] = sr[i]; a.p[i] = sp[i]; if (u_lds) a.u[i] = su[i]; }
+        if (tid == 0) {
+            S.tp = o_tp; S.rr = o_rr; S.uu = o_uu; S.pp = o_pp; S.maxu = o_maxu; S.nan = o_nan;
+            S.alpha = o_alpha; S.absres = o_absres; S.relres = o_relres;
+            S.absres_best = best; S.iter_best = iter_best; S.iter = it0 + steps_done;
+            S.temp1_prev = o_temp1_prev;
+            S.temp1 = (my_stop == SPCG_DIV0) ? S.temp1 : temp1;
+            S.stop = my_stop;
+        }
+    }
+}
+
 }  // namespace fasp

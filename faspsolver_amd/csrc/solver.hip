@@ -332,6 +332,11 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
     if (h->gm_hh) (void)hipFree(h->gm_hh);
     if (h->spcg_state) (void)hipFree(h->spcg_state);
     if (h->spcg_fused_buf) (void)hipFree(h->spcg_fused_buf);
+    {
+        auto& P = h->persist;
+        void* q[] = {P.vals, P.cols, P.wrow, P.wend, P.t2, P.sync};
+        for (void* x : q) if (x) (void)hipFree(x);
+    }
     ShmMapping map{nullptr, 0};
     for (size_t q = 0; q < g_attached.size(); ++q)
         if (g_attached[q].first == h) { map = g_attached[q].second; g_attached.erase(g_attached.begin() + (long)q); break; }
@@ -1747,6 +1752,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "xcd_pat")) g_tune.xcd_pat = value;
     else if (!std::strcmp(key, "spcg_batch")) g_tune.spcg_batch = value;
     else if (!std::strcmp(key, "spcg_fused")) g_tune.spcg_fused = value;
+    else if (!std::strcmp(key, "spcg_persist")) g_tune.spcg_persist = value;
     else if (!std::strcmp(key, "spcg_grid")) g_tune.spcg_grid = value;
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
     else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;

@@ -436,8 +436,10 @@ def wcyc(i, p): jac(i, p); p.cycle_type = T.W_CYCLE
 def scal(i, p): jac(i, p); p.coarse_scaling = 1
 def two(i, p): jac(i, p); p.max_levels = 2   # coarsest = level 1: thousands of rows (loop version of the step kernel)
 # spcg_fused 1: one launch per iteration (k_spcg_fused; coarsest levels of at most 8192 rows); 0: SpMV + step kernel
-for fused, n, mod in [(fz, n, mod) for fz in (1, 0) for n, mod in ((10, modrel), (16, jac), (12, wcyc), (20, scal), (24, two), (30, two))]:
-    fa.lib().fasp_hip_tune(b"spcg_fused", fused)
+# spcg_persist 1 (with spcg_fused 1): ONE launch per coarse solve, matrix resident in the register files (k_spcg_persist)
+for fused, n, mod in [(fz, n, mod) for fz in (2, 1, 0) for n, mod in ((10, modrel), (16, jac), (12, wcyc), (20, scal), (24, two), (30, two))]:
+    fa.lib().fasp_hip_tune(b"spcg_fused", 1 if fused else 0)
+    fa.lib().fasp_hip_tune(b"spcg_persist", 1 if fused == 2 else 0)
     ia, ja, a, f, ue = poisson7pt(n)
     i1, a1 = default_params(); mod(i1, a1); i2, a2 = default_params(); mod(i2, a2)
     s1, x1, h1, rr = orc_solve(ia, ja, a, f, i1, a1)
