@@ -25,7 +25,7 @@ struct DevLevel {
     bool    has_halo() const { return !replicated && nvec > nloc; }
     // level schedules of the sequential sweeps (built on first use): kind 0 ascending,
     // 1 descending, 2 ascending C rows, 3 ascending F rows, 4 descending from row n-2
-    struct Sched { bool built = false; int* d_order = nullptr; std::vector<int> ptr; };
+    struct Sched { bool built = false; int* d_order = nullptr; int* d_ptr = nullptr; std::vector<int> ptr; };
     Sched   sched[5];
     // polynomial smoother (built on first use): 1 / first diagonal hit, the coefficients k[1..5] of
     // ItrSmootherCSRpoly.c:101-109, work vectors r, rbar, v0, v1, vnew
@@ -85,7 +85,7 @@ static void free_level(DevLevel& D)
     if (D.w) (void)hipFree(D.w);
     if (D.d_send_idx) (void)hipFree(D.d_send_idx);
     if (D.d_sendbuf) (void)hipFree(D.d_sendbuf);
-    for (auto& sc : D.sched) if (sc.d_order) (void)hipFree(sc.d_order);
+    for (auto& sc : D.sched) { if (sc.d_order) (void)hipFree(sc.d_order); if (sc.d_ptr) (void)hipFree(sc.d_ptr); }
     if (D.poly.dinv) (void)hipFree(D.poly.dinv);
     for (double* q : D.poly.w) if (q) (void)hipFree(q);
     if (D.d_mark) (void)hipFree(D.d_mark);

@@ -739,6 +739,102 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// k_seq_sweep<L>: a whole sequential sweep (Gauss-Seidel / SOR family, ItrSmootherCSR.c:251-1040) in ONE launch.
+// The host's level schedule (smoothers.hip.h: rows grouped by the level of the sweep's dependency DAG) is walked by
+// a resident grid: all blocks update the rows of DAG level l -- mutually uncoupled, so the result IS the sequential
+// sweep -- meet at a sharded arrival counter, and go on to level l + 1.  P7(256): 766 launches of k_seq_level per
+// sweep become one launch with 766 meetings of ~2.5 us.
+// u changes under the kernel's feet and per-CU L1s are never refreshed by other CUs' stores: every load of u is a
+// write-through-coherent (sc1) load and every store of u an sc1 store, drained before the block arrives
+// (MI355X_MICROARCH.md, inter-workgroup visibility, sc1-loads form).  Spins are bounded; *err != 0 afterwards
+// means a block was not resident.
+//   form 0  u_i = t * (1/a_ii)      form 1  u_i = t / a_ii      form 2  u_i = w (t / a_ii) + (1-w) u_i
+// ---------------------------------------------------------------------------
+struct SeqSweepArgs {
+    const int*    order;    // rows in schedule order
+    const int*    lptr;     // nlev + 1 offsets into order
+    int           nlev;
+    const int*    ia;
+    const int*    ja;
+    const double* val;
+    const double* b;
+    const double* diag;
+    double*       u;
+    int           form;
+    double        w;
+    unsigned*     sync;     // [0] top counter, [3] error word, [16 + 16 s] shard counters; zeroed before the launch
+};
+
+template <int L>
+__global__ __launch_bounds__(BLOCK) void k_seq_sweep(SeqSweepArgs a)
+{
+    typedef __attribute__((address_space(1))) unsigned           gu32;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    constexpr int RPB = BLOCK / L;
+    __shared__ int s_ok;
+    const int sl = threadIdx.x & (L - 1);
+    const int rloc = threadIdx.x / L;
+    const int nb = (int)gridDim.x;
+    gu32* g_cnt = (gu32*)a.sync;
+    gu32* g_err = (gu32*)(a.sync + 3);
+    const unsigned shard = blockIdx.x & 7u;
+    const unsigned in_shard = ((unsigned)nb - shard + 7u) >> 3;
+    gu32* g_sh = (gu32*)(a.sync + 16 + 16 * shard);
+    const unsigned nshard = (unsigned)min(nb, 8);
+    auto ld_u = [&](int c) -> double {
+        return __longlong_as_double((long long)__hip_atomic_load((gu64*)(a.u + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    for (int l = 0; l < a.nlev; ++l) {
+        const int lo = a.lptr[l], hi = a.lptr[l + 1];
+        for (int idx = lo + blockIdx.x * RPB + rloc; idx < hi; idx += nb * RPB) {
+            const int r = a.order[idx];
+            const int kb = a.ia[r], ke = a.ia[r + 1];
+            double s = 0.0;
+            for (int k = kb + sl; k < ke; k += L) {
+                const int c = a.ja[k];
+                if (c != r) s += a.val[k] * ld_u(c);
+            }
+            s = subwave_sum<L>(s);
+            if (sl == 0) {
+                const double d = a.diag[r];
+                const double t = a.b[r] - s;
+                if (fabs(d) > 1e-20) {
+                    double un;
+                    if (a.form == 0) un = t * (1.0 / d);
+                    else if (a.form == 1) un = t / d;
+                    else un = a.w * (t / d) + (1 - a.w) * ld_u(r);
+                    __hip_atomic_store((gu64*)(a.u + r), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (l + 1 == a.nlev) break;
+        // meet: every storing wave drains, the block's barrier, one lane arrives (two-stage counter) and polls
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (__hip_atomic_fetch_add(g_sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard * (unsigned)(l + 1))
+                __hip_atomic_fetch_add(g_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = nshard * (unsigned)(l + 1);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int ok = 1;
+            while (__hip_atomic_load(g_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s at 100 MHz
+                    __hip_atomic_store(g_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+            if (__hip_atomic_load(g_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) return;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Device copy / triad ceilings (bench.py reports them beside the roofline): 16 bytes per lane, grid-stride
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_copy16(size_t n16, const f64x2_t* __restrict__ src, f64x2_t* __restrict__ dst)

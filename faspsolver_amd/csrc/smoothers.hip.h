@@ -54,6 +54,22 @@ static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLeve
     return FASP_SUCCESS;
 }
 
+// error word of the persistent sweep kernel: read back where the solve synchronises anyway
+static unsigned* g_seq_sync = nullptr;
+static unsigned* g_seq_herr = nullptr;
+static int seq_persist_check()
+{
+    if (!g_seq_sync) return FASP_SUCCESS;
+    HIPCK(hipMemcpyAsync(g_seq_herr, g_seq_sync + 3, sizeof(unsigned), hipMemcpyDeviceToHost, g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    if (*g_seq_herr) {
+        std::fprintf(stderr, "### ERROR: fasp_hip: the persistent sweep kernel timed out at a grid meeting (a block was not resident); "
+                             "fasp_hip_tune(\"seq_persist\", 0) selects one launch per dependency level\n");
+        return ERROR_MISC;
+    }
+    return FASP_SUCCESS;
+}
+
 // one sequential sweep of schedule `kind` with update formula `form` (see k_seq_level)
 static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
 {
@@ -78,6 +94,44 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     materialise_zero(D);
     const int L = D.A.lanes;
     const int nlev = (int)S.ptr.size() - 1;
+    // Optional (fasp_hip_tune("seq_persist", 1)): one launch per sweep (k_seq_sweep), the dependency levels separated by
+    // grid meetings instead of kernel boundaries.  MEASURED SLOWER than one launch per level (P7(128), GS-CF defaults:
+    // 922 ms against 852 ms per solve; profiles/r02_gs_persistent_sweep.txt): a meeting costs what a launch boundary
+    // costs (~3 us: drained write-through stores + arrival + poll), and the time of a sweep is the DEPTH of the
+    // dependency DAG on the dense coarse levels (thousands of levels of one to three rows), not the launch count.
+    // Needs every block resident at once, so never when validation ranks share the device.
+    static bool seq_persist_disabled = false;
+    if (g_tune.seq_persist && !seq_persist_disabled && !comm_shares_devices() && nlev >= 4) {
+        if (!S.d_ptr) {
+            HIPCK(hipMalloc(&S.d_ptr, sizeof(int) * (size_t)(nlev + 1)));
+            HIPCK(hipMemcpy(S.d_ptr, S.ptr.data(), sizeof(int) * (size_t)(nlev + 1), hipMemcpyHostToDevice));
+        }
+        static unsigned* d_sync = nullptr;
+        static unsigned* h_err = nullptr;
+        if (!d_sync) { HIPCK(hipMalloc(&d_sync, 1024)); HIPCK(hipHostMalloc((void**)&h_err, 64, hipHostMallocDefault)); }
+        HIPCK(hipMemsetAsync(d_sync, 0, 1024, g_ctx.stream));
+        SeqSweepArgs sa{};
+        sa.order = S.d_order; sa.lptr = S.d_ptr; sa.nlev = nlev; sa.ia = D.A.ia; sa.ja = D.A.ja; sa.val = D.A.val;
+        sa.b = D.b; sa.diag = D.diag; sa.u = D.x; sa.form = form; sa.w = w; sa.sync = d_sync;
+        // two 256-thread blocks per CU: far below any residency limit of this small kernel, enough waves to hide the gathers
+        int widest = 0;
+        for (int l = 0; l < nlev; ++l) widest = std::max(widest, S.ptr[l + 1] - S.ptr[l]);
+        const int rpb = BLOCK / L;
+        const int grid = std::max(8, std::min(2 * g_ctx.num_cu, (widest + rpb - 1) / rpb));
+#define SEQP_LAUNCH(LL) hipLaunchKernelGGL((k_seq_sweep<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, sa)
+        switch (L) {
+            case 2: SEQP_LAUNCH(2); break;
+            case 4: SEQP_LAUNCH(4); break;
+            case 8: SEQP_LAUNCH(8); break;
+            case 16: SEQP_LAUNCH(16); break;
+            case 32: SEQP_LAUNCH(32); break;
+            default: SEQP_LAUNCH(64); break;
+        }
+#undef SEQP_LAUNCH
+        // the error word is checked lazily (no synchronisation per sweep): once per solve by seq_persist_check()
+        g_seq_sync = d_sync; g_seq_herr = h_err;
+        return FASP_SUCCESS;
+    }
     for (int l = 0; l < nlev; ++l) {
         const int lo = S.ptr[l], hi = S.ptr[l + 1];
         const int rpb = BLOCK / L;

@@ -537,6 +537,7 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
         }
     }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
+    if (seq_persist_check() < 0) return ERROR_MISC;   // a persistent sweep kernel that gave up at a grid meeting
     const double t_solve = wall_seconds() - t0;
 
     if (stats) {
@@ -679,7 +680,7 @@ int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z)
     if (st < 0) return st;
     HIPCK(hipMemcpyAsync(z, dz, sizeof(double) * m, hipMemcpyDeviceToHost, g_ctx.stream));
     HIPCK(hipStreamSynchronize(g_ctx.stream));
-    return FASP_SUCCESS;
+    return seq_persist_check();
 }
 
 // ---- row-partition inspection (host only; used by the CPU-side distributed tests) ----
@@ -1753,6 +1754,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "spcg_batch")) g_tune.spcg_batch = value;
     else if (!std::strcmp(key, "spcg_fused")) g_tune.spcg_fused = value;
     else if (!std::strcmp(key, "spcg_persist")) g_tune.spcg_persist = value;
+    else if (!std::strcmp(key, "seq_persist")) g_tune.seq_persist = value;
     else if (!std::strcmp(key, "spcg_grid")) g_tune.spcg_grid = value;
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
     else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;
