@@ -433,7 +433,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 1, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0; };
+struct Tuning { int gen2 = 2, ws2_bpc = 0, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -528,6 +528,8 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
         // short rows (64 rows fit the 512-entry slab with room for ragged tiles): 16-byte staged stream, lane = row
         return launch_persistent(k_csr_lstream<OP, 512>, a.ntiles, a, 4);
     }
+    if (M.kind == 2 && g_tune.gen2 >= 2 && M.wrows == 64 && M.wcap == 512 && (OP != OP_JACOBI || (M.dpos && !M.dup_diag)))
+        return launch_persistent(k_csr_wstream2<OP>, a.ntiles, a, g_tune.ws2_bpc);   // rows of any length: staged, prefetched stream
     if (M.kind == 2) {
         if (M.wrows == 64 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 64, 512>, a.ntiles, a);
         if (M.wrows == 64) return launch_persistent(k_csr_wstream<OP, 64, 1024>, a.ntiles, a);

@@ -223,6 +223,154 @@ __global__ __launch_bounds__(BLOCK) void k_csr_lstream(CsrArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// k_csr_wstream2<OP>: plain CSR with rows of any length up to ~48 on average (levels 1-2, R, P of an unstructured
+// hierarchy) -- k_csr_wstream's two phases (lane = entry products into LDS, then lane = row sums in storage order: the
+// reference's left-to-right row sums, bit-identical) fed like k_csr_lstream: JA / val of the NEXT 512-entry chunk are
+// in flight as 16-byte loads while the current one is multiplied and summed, and nothing in the loop waits for a
+// store or drains the vector-memory counter (k_csr_wstream's workgroup-scope fences did both).
+// ---------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
+{
+    if (a.stop && *a.stop) return;
+    constexpr int CAP = 512, NJ = 2, NV = 4;
+    __shared__ __attribute__((aligned(16))) double sv_all[4 * CAP];   // values, then (in place) products
+    __shared__ __attribute__((aligned(16))) int    sj_all[4 * CAP];
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* sv = sv_all + wave * CAP;
+    int*    sj = sj_all + wave * CAP;
+    const int vmax = tile_vmax(a);
+    const int G = gridDim.x;
+    double dotacc = 0.0;
+
+    auto advance = [&](int& v, int& r0, int& nr) {
+        for (;;) {
+            r0 = -1; nr = 0;
+            if (v >= vmax) return;
+            const int t = tile_of(a, v);
+            v += G;
+            if (t >= a.ntiles) continue;
+            const int rr = t * BLOCK + wave * 64;
+            if (rr >= a.nrow) continue;
+            r0 = rr; nr = min(64, a.nrow - rr);
+            return;
+        }
+    };
+    auto load_ia = [&](int r0, int nr, int& kb, int& ke) {
+        kb = ke = 0;
+        if (r0 >= 0 && lane < nr) { kb = a.ia[r0 + lane]; ke = a.ia[r0 + lane + 1]; }
+    };
+    i32x4_t qj[NJ];
+    f64x2_t qv[NV];
+    // chunk [lo, hi) staged from the 4-aligned entry s = lo & ~3: slab index of entry k is k - s
+    auto stage_load = [&](int s, int hi) {
+        const int n = hi - s;
+        const i32x4_t* pj = reinterpret_cast<const i32x4_t*>(a.ja + s);
+        const f64x2_t* pv = reinterpret_cast<const f64x2_t*>(a.val + s);
+#pragma unroll
+        for (int q = 0; q < NJ; ++q)
+            if ((lane + 64 * q) * 4 < n) qj[q] = __builtin_nontemporal_load(pj + lane + 64 * q);
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+            if ((lane + 64 * q) * 2 < n) qv[q] = __builtin_nontemporal_load(pv + lane + 64 * q);
+    };
+    auto stage_store = [&](int s, int hi) {
+        const int n = hi - s;
+#pragma unroll
+        for (int q = 0; q < NJ; ++q)
+            if ((lane + 64 * q) * 4 < n) reinterpret_cast<i32x4_t*>(sj)[lane + 64 * q] = qj[q];
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+            if ((lane + 64 * q) * 2 < n) reinterpret_cast<f64x2_t*>(sv)[lane + 64 * q] = qv[q];
+    };
+    // chunks of a tile: [k0, k1) cut at lo_c = k0 + c * (CAP - 4): with s = lo & ~3 every chunk fits the slab
+    constexpr int STEP = CAP - 4;
+
+    int v = blockIdx.x;
+    int r0A, nrA, kbA, keA, r0B, nrB, kbB, keB;
+    advance(v, r0A, nrA);
+    load_ia(r0A, nrA, kbA, keA);
+    advance(v, r0B, nrB);
+    load_ia(r0B, nrB, kbB, keB);
+    int k0 = 0, k1 = 0, lo = 0, hi = 0;
+    if (r0A >= 0) {
+        k0 = __builtin_amdgcn_readlane(kbA, 0); k1 = __builtin_amdgcn_readlane(keA, nrA - 1);
+        lo = k0; hi = min(lo + STEP, k1);
+        stage_load(lo & ~3, hi);
+        stage_store(lo & ~3, hi);
+    }
+    wave_order();
+    while (r0A >= 0) {
+        const int r = r0A + lane;
+        double acc = ((OP == OP_JACOBI || OP == OP_L1DIAG) && lane < nrA) ? a.b[r] : 0.0;
+        const int dk = (OP == OP_JACOBI && lane < nrA) ? a.dpos[r] : -1;
+        for (;;) {   // chunks of tile A; the slab holds [lo & ~3, hi)
+            const int s = lo & ~3;
+            // phase 1: lane = entry -- columns and values from the slab, x gathered, products back in place
+            int    c[8];
+            double w[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = lane + 64 * u;
+                const bool ok = s + e < hi;
+                c[u] = ok ? sj[e] : 0;
+                w[u] = ok ? sv[e] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
+            // look ahead: the next chunk of this tile, or the first chunk of tile B (and the row pointers of tile C)
+            const bool last = hi >= k1;
+            int nlo, nhi, nk0 = 0, nk1 = 0;
+            int r0C = -1, nrC = 0, kbC = 0, keC = 0;
+            if (!last) { nlo = hi; nhi = min(nlo + STEP, k1); }
+            else {
+                if (r0B >= 0) { nk0 = __builtin_amdgcn_readlane(kbB, 0); nk1 = __builtin_amdgcn_readlane(keB, nrB - 1); }
+                nlo = nk0; nhi = min(nlo + STEP, nk1);
+                advance(v, r0C, nrC);
+                load_ia(r0C, nrC, kbC, keC);
+            }
+            if (!last || r0B >= 0) stage_load(nlo & ~3, nhi);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = lane + 64 * u;
+                if (s + e < hi) sv[e] = w[u] * xv[u];
+            }
+            wave_order();
+            // phase 2: lane = row, storage order
+            if (lane < nrA) {
+                const int pb = max(kbA, lo), pe = min(keA, hi);
+                if (OP == OP_JACOBI) {
+                    for (int k = pb; k < pe; ++k)
+                        if (k != dk) acc -= sv[k - s];
+                } else if (OP == OP_L1DIAG) {
+                    for (int k = pb; k < pe; ++k) acc -= sv[k - s];
+                } else {
+                    for (int k = pb; k < pe; ++k) acc += sv[k - s];
+                }
+            }
+            wave_order();
+            if (last) {
+                if (lane < nrA) row_epilogue<OP>(a, r, acc, dotacc);
+                if (r0B >= 0) stage_store(nlo & ~3, nhi);
+                wave_order();
+                r0A = r0B; nrA = nrB; kbA = kbB; keA = keB;
+                r0B = r0C; nrB = nrC; kbB = kbC; keB = keC;
+                k0 = nk0; k1 = nk1; lo = nlo; hi = nhi;
+                break;
+            }
+            stage_store(nlo & ~3, nhi);
+            wave_order();
+            lo = nlo; hi = nhi;
+        }
+    }
+    if (OP == OP_MXV_DOT) {
+        const double tot = block_sum(dotacc, red);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_csr_rowpat2<OP, LDS_TAB>: row-pattern-coded SQUARE matrix (column base = row index), a lane owns rows
 // 2i and 2i+1 of its wave's 128-row tile.  Pattern lists are padded to multiples of 8 entries (offset 0,
 // value 0); x goes through buffer loads (hardware range check: the second half of a 16-byte load at

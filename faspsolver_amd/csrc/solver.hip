@@ -407,9 +407,10 @@ int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* k
     double bytes = 12.0 * M.nnz + 4.0 * (M.row + 1.0);
     if (M.code && g_tune.compress) { k = 4; bytes = 1.0 * M.nnz + 4.0 * (M.row + 1.0) + (M.rowbase ? 4.0 * M.row : 0.0); }
     if (M.pat && g_tune.compress) { k = 5; bytes = 2.0 * M.row + (M.rowbase ? 4.0 * M.row : 0.0) + 12.0 * M.npent; }
-    // second-generation kernels (kernels2.hip.h), same selection as launch_csr: 6 = k_csr_rowpat4, 7 = k_csr_lstream
+    // second-generation kernels (kernels2.hip.h), same selection as launch_csr: 6 = k_csr_rowpat4, 7 = k_csr_lstream, 8 = k_csr_wstream2
     if (k == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase) { k = 6; bytes += 4.0 * M.nxrows; }
     if (k == 2 && g_tune.gen2 && M.wrows == 64 && M.wcap == 512 && (double)M.nnz <= 7.6 * M.row) k = 7;
+    else if (k == 2 && g_tune.gen2 >= 2 && M.wrows == 64 && M.wcap == 512) k = 8;   // k_csr_wstream2
     if (kind) *kind = k;
     if (matrix_bytes) *matrix_bytes = bytes;
     return FASP_SUCCESS;
@@ -1745,6 +1746,7 @@ int fasp_hip_tune(const char* key, int value)
     if (!std::strcmp(key, "maxgrid")) g_tune.maxgrid = value;
     else if (!std::strcmp(key, "xcd")) g_tune.xcd = value;
     else if (!std::strcmp(key, "gen2")) g_tune.gen2 = value;
+    else if (!std::strcmp(key, "ws2_bpc")) g_tune.ws2_bpc = value;
     else if (!std::strcmp(key, "nt")) g_tune.nt = value;
     else if (!std::strcmp(key, "kind")) g_tune.kind = value;
     else if (!std::strcmp(key, "compress")) g_tune.compress = value;

@@ -105,7 +105,7 @@ def test_variable_coefficient_matches_reference(gpu, n):
     itp, amgp = _params()
     H = fa.AMG(ia, ja, a, amgp)
     assert _levels(H) == z[f"var{n}_levels"].tolist()
-    assert H.kernel_info(0, 0)[0] in (2, 7)   # nothing to code
+    assert H.kernel_info(0, 0)[0] in (2, 7, 8)   # nothing to code
     st, x, hist, stats = H.solve(f, itp)
     assert st == int(z[f"var{n}_iters"])
     assert abs(stats.relres - float(z[f"var{n}_relres"])) <= RELRES_TOL
@@ -118,8 +118,8 @@ def test_variable_coefficient_matches_reference(gpu, n):
 
 @pytest.mark.gpu
 def test_coded_vs_plain_and_gen1_vs_gen2_bit_identity_128(gpu):
-    """One multigrid cycle (every operator, every epilogue, no fused dots) at 128^3 through four kernel sets:
-    coded / plain x second-generation / round-1 kernels.  All row sums are the reference's left-to-right sums
+    """One multigrid cycle (every operator, every epilogue, no fused dots) at 128^3 through six kernel sets:
+    coded / plain x the three kernel generations.  All row sums are the reference's left-to-right sums
     of the exact stored values, so the four results agree BIT FOR BIT."""
     n = 128
     ia, ja, a, f, ue = fa.poisson7pt(n)
@@ -130,12 +130,12 @@ def test_coded_vs_plain_and_gen1_vs_gen2_bit_identity_128(gpu):
     out = {}
     try:
         for comp in (1, 0):
-            for gen2 in (1, 0):
+            for gen2 in (2, 1, 0):   # 2: + k_csr_wstream2 on the mid levels; 1: k_csr_lstream / k_csr_rowpat4 only; 0: round-1 kernels
                 L.fasp_hip_tune(b"compress", comp); L.fasp_hip_tune(b"gen2", gen2)
                 out[(comp, gen2)] = H.precond(r)
     finally:
-        L.fasp_hip_tune(b"compress", 1); L.fasp_hip_tune(b"gen2", 1)
-    base = out[(1, 1)]
+        L.fasp_hip_tune(b"compress", 1); L.fasp_hip_tune(b"gen2", 2)
+    base = out[(1, 2)]
     for k, v in out.items():
         assert np.array_equal(v, base), k
     H.close()
