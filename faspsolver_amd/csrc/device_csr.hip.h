@@ -187,7 +187,8 @@ static bool build_rowpat(const HostCSR& M, Buf<unsigned short>& pat, std::vector
     const bool square = M.row == M.col;
     const int n = M.row;
     if (n <= 0 || M.nnz <= 0) return false;
-    constexpr int MAXPAT = 65536, MAXENT = 1 << 20;
+    if ((long long)M.col >= (1ll << 28)) return false;   // the coded kernels form byte offsets of x in 32 bits
+    constexpr int MAXPAT = 65535, MAXENT = 1 << 20;   // (id 0xffff is the pad of the pair kernels)
     auto base_of = [&](int r) { return square ? r : (M.ia[r] < M.ia[r + 1] ? M.ja[M.ia[r]] : 0); };
     auto bits_of = [](double v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; };
     auto row_hash = [&](int r) {
@@ -343,13 +344,31 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
             HIPCK(hipMemcpy(D.plen, plen.data(), sizeof(int) * plen.size(), hipMemcpyHostToDevice));
             HIPCK(hipMalloc(&D.poff, sizeof(int) * std::max<size_t>(poff.size(), 1)));
             HIPCK(hipMalloc(&D.pval, sizeof(double) * std::max<size_t>(pval.size(), 1)));
+            HIPCK(hipMemset(D.pat + H.row, 0xff, sizeof(unsigned short) * 2));   // pad = 0xffff: never a pattern id (MAXPAT 65535)
             HIPCK(hipMemcpy(D.pat, pat.data(), sizeof(unsigned short) * (size_t)H.row, hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(D.pstart, pstart.data(), sizeof(int) * pstart.size(), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(D.poff, poff.data(), sizeof(int) * poff.size(), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(D.pval, pval.data(), sizeof(double) * pval.size(), hipMemcpyHostToDevice));
             if (prb.n) {
-                HIPCK(hipMalloc(&D.rowbase, sizeof(int) * (size_t)H.row));
+                HIPCK(hipMalloc(&D.rowbase, sizeof(int) * ((size_t)H.row + 2)));   // + pad: the pair kernel loads two bases at once
                 HIPCK(hipMemcpy(D.rowbase, prb.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
+                // k_csr_rowpat5 (kernels2.hip.h): the sweep computes the row pairs whose two patterns are those of the pair
+                // (128 w + 64, 128 w + 65) of their wave tile w; every other row goes on this list.
+                const int nr = H.row, npair = (nr + 1) / 2;
+                std::vector<int> xr;
+                for (int w0 = 0; w0 < nr; w0 += 128) {
+                    const int    pm = std::min((w0 + 64) / 2, npair - 1);
+                    const unsigned domA = pat[(size_t)2 * pm], domB = (2 * pm + 1 < nr) ? pat[(size_t)2 * pm + 1] : 0xffffu;   // (the device copy is padded with 0xffff)
+                    for (int r = w0; r < std::min(w0 + 128, nr); r += 2) {
+                        const bool vb = r + 1 < nr;
+                        if (!(vb && pat[r] == domA && pat[r + 1] == domB)) { xr.push_back(r); if (vb) xr.push_back(r + 1); }
+                    }
+                }
+                if ((long long)xr.size() * 4 <= nr) {
+                    D.nxrows = (int)xr.size();
+                    HIPCK(hipMalloc(&D.xrows, sizeof(int) * std::max<size_t>(xr.size(), 1)));
+                    HIPCK(hipMemcpy(D.xrows, xr.data(), sizeof(int) * xr.size(), hipMemcpyHostToDevice));
+                }
             } else {
                 // k_csr_rowpat4 (kernels2.hip.h): the sweep computes the row pairs (2i, 2i+1) whose two rows have the
                 // pattern of row 128 w + 64 of their wave tile w; every other row goes on this list.
@@ -464,6 +483,14 @@ static int launch_persistent(K kernel, int ntiles, CsrArgs& a, int blocks_per_cu
     return grid;
 }
 
+// (the transfer-operator kernel has no smoother instantiations)
+template <int OP>
+static int launch_rowpat5(CsrArgs& a)
+{
+    if constexpr (OP == OP_JACOBI || OP == OP_L1DIAG) { (void)a; return 0; }
+    else return launch_persistent(k_csr_rowpat5<OP>, a.ntiles, a, 5);
+}
+
 // Launches the row kernel of family M.kind for operation OP; returns the grid size
 // (= number of per-block partials written by OP_MXV_DOT).
 template <int OP>
@@ -494,6 +521,19 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
         a.tiles_per_xcd = (a.ntiles + 7) / 8;
         a.xcd_map = a.ntiles >= 8 * 64 ? -1 : 16;  // slabs: x is fetched once per XCD (PMC: 0.18 GB instead of 0.45 GB per level-0 pass)
         return launch_persistent(k_csr_rowpat4<OP>, a.ntiles, a, 5);
+    }
+    // (measured on P7(256) level 0: prolongation, 1-6 entries per row, 140 -> 131 us; restriction, 7-13 entries per row,
+    // 68 -> 80 us: the sweep pays for short lists only)
+    if (M.kind == 5 && g_tune.gen2 >= 2 && M.nxrows >= 0 && M.rowbase && g_tune.rpl <= 0 && OP != OP_JACOBI && OP != OP_L1DIAG &&
+        (double)M.nnz <= 4.5 * M.row) {
+        // rectangular row-pattern-coded operator (R, P of the coded levels): pair-of-patterns sweep + exception list
+        a.pat = M.pat; a.pstart = M.pstart; a.plen = M.plen; a.poff = M.poff; a.pval = M.pval;
+        a.npat = M.npat; a.npent = M.npent; a.ncol = M.col; a.rowbase = M.rowbase;
+        a.xrows = M.xrows; a.nxrows = M.nxrows;
+        a.ntiles = (M.row + 2 * BLOCK - 1) / (2 * BLOCK);
+        a.tiles_per_xcd = (a.ntiles + 7) / 8;
+        a.xcd_map = a.ntiles >= 8 * 64 ? -1 : 16;
+        return launch_rowpat5<OP>(a);
     }
     if (M.kind == 5) {
         a.pat = M.pat; a.pstart = M.pstart; a.poff = M.poff; a.pval = M.pval; a.rowbase = M.rowbase;

@@ -887,6 +887,162 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// k_csr_rowpat5<OP>: k_csr_rowpat4 for row-pattern-coded RECTANGULAR operators (the restriction and prolongation of
+// the coded levels: every row has its own column base, a.rowbase).  A lane again owns rows 2i and 2i+1; the PAIR of
+// patterns of the wave's middle lane is treated as wave-uniform -- the rows of a transfer operator alternate between
+// two patterns (C point: one entry; F point: its C neighbours), in one order along a grid line and the other along the
+// next -- both lists through the scalar cache.  x is gathered with 8-byte buffer loads (the two rows have unrelated
+// bases), y / the dotted vector move as 16-byte accesses, the store is deferred behind the next step's loads, pairs with
+// other patterns are left to the list pass (a.xrows, built at upload with the same rule).  OPs: MXV, ADD, SUB, AXPY,
+// RESID, MXV_DOT (no smoother runs on a rectangular operator).
+// ---------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
+{
+    if (a.stop && *a.stop) return;
+    static_assert(OP != OP_JACOBI && OP != OP_L1DIAG, "transfer operators are not smoothed");
+    __shared__ double red[4];
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.x), 0, (int)((unsigned)a.ncol * 8u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr =
+        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)(a.nrow & ~1) * 8u), 0x00020000);
+    typedef const __attribute__((address_space(4))) int    cint_t;
+    typedef const __attribute__((address_space(4))) double cdbl_t;
+    cint_t* cpstart = (cint_t*)(a.pstart);
+    cint_t* cplen   = (cint_t*)(a.plen);
+    cint_t* cpoff   = (cint_t*)(a.poff);
+    cdbl_t* cpval   = (cdbl_t*)(a.pval);
+    const int vmax = tile_vmax(a);  // tiles of 2 * BLOCK rows
+    const int G = gridDim.x;
+    const int last = a.nrow - 1;
+    const unsigned* pat2 = reinterpret_cast<const unsigned*>(a.pat);
+    const int npair = (a.nrow + 1) >> 1;
+    double dotacc = 0.0;
+
+    auto advance = [&](int& v) -> int {
+        for (;;) {
+            if (v >= vmax) return -1;
+            const int t = tile_of(a, v);
+            v += G;
+            if (t < a.ntiles) return t * (2 * BLOCK);
+        }
+    };
+    auto pair_of = [&](int r0) -> int { return min((max(r0, 0) >> 1) + (int)threadIdx.x, npair - 1); };
+    int      v = blockIdx.x;
+    int      r0A = advance(v);
+    unsigned pp = pat2[pair_of(r0A)];
+    f64x2_t  pend_out = {0.0, 0.0};
+    unsigned pend_off = 0xfffffff0u;
+    auto flush = [&]() {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pend_out), yr, (int)pend_off, 0, 0);
+        pend_off = 0xfffffff0u;
+    };
+    // the two wave-uniform lists over per-lane bases, chunk by chunk in lockstep: 16 gathers in flight per lane
+    auto sweep_lists = [&](int psA, int lenA, unsigned baseA8, double& accA, int psB, int lenB, unsigned baseB8, double& accB) {
+        const int lmax = max(lenA, lenB);
+        for (int k = 0; k < lmax; k += 8) {
+            const bool doA = k < lenA, doB = k < lenB;   // wave-uniform
+            int    ofA[8], ofB[8];
+            double xa[8], xb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { ofA[u] = doA ? cpoff[psA + k + u] : 0; ofB[u] = doB ? cpoff[psB + k + u] : 0; }
+            if (doA) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xa[u] = buf_load_f64(xr, baseA8 + (unsigned)(ofA[u] * 8));
+            }
+            if (doB) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xb[u] = buf_load_f64(xr, baseB8 + (unsigned)(ofB[u] * 8));
+            }
+            if (k == 0) flush();  // the previous step's result leaves behind this step's first loads
+            auto chunk = [&](int ps, int len, const double (&xv)[8], double& acc) {
+                double w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = cpval[ps + k + u];
+                auto entry = [&](int u) { acc += w[u] * xv[u]; };
+                switch (min(len - k, 8)) {  // padding entries contribute nothing, not even a signed zero
+                    case 8: entry(0); entry(1); entry(2); entry(3); entry(4); entry(5); entry(6); entry(7); break;
+                    case 7: entry(0); entry(1); entry(2); entry(3); entry(4); entry(5); entry(6); break;
+                    case 6: entry(0); entry(1); entry(2); entry(3); entry(4); entry(5); break;
+                    case 5: entry(0); entry(1); entry(2); entry(3); entry(4); break;
+                    case 4: entry(0); entry(1); entry(2); entry(3); break;
+                    case 3: entry(0); entry(1); entry(2); break;
+                    case 2: entry(0); entry(1); break;
+                    default: entry(0); break;
+                }
+            };
+            if (doA) chunk(psA, lenA, xa, accA);
+            if (doB) chunk(psB, lenB, xb, accB);
+        }
+        if (lmax == 0) flush();
+    };
+    while (r0A >= 0) {
+        const int      r0B = advance(v);
+        const unsigned ppB = pat2[pair_of(r0B)];
+        const int  ra = r0A + 2 * (int)threadIdx.x;
+        const bool vb = ra + 1 <= last;
+        const unsigned pidA = pp & 0xffffu, pidB = pp >> 16;
+        const unsigned domA = (unsigned)__builtin_amdgcn_readlane((int)pidA, 32);
+        unsigned       domB = (unsigned)__builtin_amdgcn_readlane((int)pidB, 32);
+        // (odd row count: the partner of the last row is the 0xffff pad, not a pattern -- no pair of that wave tile is swept)
+        const bool     domok = domB < (unsigned)a.npat;
+        if (!domok) domB = 0;
+        const bool     mine = vb && domok && pidA == domA && pidB == domB;  // everything else is on the list
+        const int      rs = mine ? ra : 0;  // lanes that store nothing work on the first rows: always valid
+        const int      psA = cpstart[domA], lenA = cplen[domA], psB = cpstart[domB], lenB = cplen[domB];
+        // the two column bases in one 8-byte load
+        const int2 cb = *reinterpret_cast<const int2*>(a.rowbase + rs);
+        f64x2_t aux = {0.0, 0.0};
+        if (OP == OP_RESID) aux = *reinterpret_cast<const f64x2_t*>(a.b + rs);
+        else if (OP == OP_MXV_DOT) aux = *reinterpret_cast<const f64x2_t*>(a.dotv + rs);
+        else if (OP == OP_ADD || OP == OP_SUB || OP == OP_AXPY) aux = *reinterpret_cast<const f64x2_t*>(a.y + rs);
+        double accA = 0.0, accB = 0.0;
+        sweep_lists(psA, lenA, (unsigned)cb.x * 8u, accA, psB, lenB, (unsigned)cb.y * 8u, accB);
+        f64x2_t out = {0.0, 0.0};
+        if (OP == OP_MXV) { out.x = accA; out.y = accB; }
+        else if (OP == OP_RESID) { out.x = aux.x - accA; out.y = aux.y - accB; }
+        else if (OP == OP_ADD) { out.x = aux.x + accA; out.y = aux.y + accB; }
+        else if (OP == OP_SUB) { out.x = aux.x - accA; out.y = aux.y - accB; }
+        else if (OP == OP_AXPY) { out.x = aux.x + accA * a.alpha; out.y = aux.y + accB * a.alpha; }
+        else {  // OP_MXV_DOT
+            out.x = accA; out.y = accB;
+            if (mine) { dotacc += accA * aux.x; dotacc += accB * aux.y; }
+        }
+        if (mine) { pend_out = out; pend_off = (unsigned)ra * 8u; }
+        r0A = r0B;
+        pp = ppB;
+    }
+    flush();
+
+    // rows outside their wave's pattern pair: lane = row, own list, 8 gathers in flight
+    for (int i = blockIdx.x * BLOCK + (int)threadIdx.x; i < a.nxrows; i += G * BLOCK) {
+        const int      r = a.xrows[i];
+        const unsigned pid = a.pat[r];
+        const int      ps = a.pstart[pid], len = a.plen[pid];
+        const unsigned base = (unsigned)a.rowbase[r] * 8u;
+        double acc = 0.0;
+        for (int k = 0; k < len; k += 8) {
+            int    of[8];
+            double xk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) of[u] = a.poff[ps + k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xk[u] = buf_load_f64(xr, base + (unsigned)(of[u] * 8));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double pr = a.pval[ps + k + u] * xk[u];
+                acc = (k + u < len) ? acc + pr : acc;
+            }
+        }
+        row_epilogue<OP>(a, r, acc, dotacc);
+    }
+    if (OP == OP_MXV_DOT) {
+        const double tot = block_sum(dotacc, red);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_seq_sweep<L>: a whole sequential sweep (Gauss-Seidel / SOR family, ItrSmootherCSR.c:251-1040) in ONE launch.
 // The host's level schedule (smoothers.hip.h: rows grouped by the level of the sweep's dependency DAG) is walked by
 // a resident grid: all blocks update the rows of DAG level l -- mutually uncoupled, so the result IS the sequential

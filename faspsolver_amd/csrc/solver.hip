@@ -409,6 +409,7 @@ int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* k
     if (M.pat && g_tune.compress) { k = 5; bytes = 2.0 * M.row + (M.rowbase ? 4.0 * M.row : 0.0) + 12.0 * M.npent; }
     // second-generation kernels (kernels2.hip.h), same selection as launch_csr: 6 = k_csr_rowpat4, 7 = k_csr_lstream, 8 = k_csr_wstream2
     if (k == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase) { k = 6; bytes += 4.0 * M.nxrows; }
+    else if (k == 5 && g_tune.gen2 >= 2 && M.nxrows >= 0 && M.rowbase && (double)M.nnz <= 4.5 * M.row) { k = 9; bytes += 4.0 * M.nxrows; }   // k_csr_rowpat5
     if (k == 2 && g_tune.gen2 && M.wrows == 64 && M.wcap == 512 && (double)M.nnz <= 7.6 * M.row) k = 7;
     else if (k == 2 && g_tune.gen2 >= 2 && M.wrows == 64 && M.wcap == 512) k = 8;   // k_csr_wstream2
     if (kind) *kind = k;
