@@ -212,13 +212,19 @@ static bool build_rowpat(const HostCSR& M, Buf<unsigned short>& pat, std::vector
     };
     // pass 1: hash of every row; per-thread sets of (hash -> first row), bounded
     Buf<unsigned long long> rh((size_t)n);
-    const int nt = omp_get_max_threads();
-    constexpr int SLOTS = 1 << 18;  // open addressing, <= 25 % load
+    // worth it only when rows really repeat (>= 8 rows per pattern, below): the sets are sized for that bound, and a
+    // small operator is hashed by a small team (a 3 MB set per thread of a 32-thread team costs more than the hashing)
+    const int maxpat = std::min<long long>(MAXPAT, n / 8);
+    if (maxpat < 1) return false;
+    const int nt = std::max(1, std::min(omp_get_max_threads(), n / 32768));
+    int slots_pow = 1024;
+    while (slots_pow < 4 * (maxpat + 1)) slots_pow *= 2;   // open addressing, <= 25 % load
+    const int SLOTS = slots_pow;
     struct Set {
         std::vector<unsigned long long> key;
         std::vector<int> first;
-        int cnt = 0;
-        Set() : key(SLOTS, 0ull), first(SLOTS, -1) {}
+        int cnt = 0, SLOTS;
+        explicit Set(int slots) : key((size_t)slots, 0ull), first((size_t)slots, -1), SLOTS(slots) {}
         bool add(unsigned long long h, int r)
         {
             unsigned s = (unsigned)(h >> 20) & (SLOTS - 1);
@@ -242,7 +248,7 @@ static bool build_rowpat(const HostCSR& M, Buf<unsigned short>& pat, std::vector
     bool fail = false;
 #pragma omp parallel num_threads(nt)
     {
-        Set* S = new Set();
+        Set* S = new Set(SLOTS);
         local[(size_t)omp_get_thread_num()] = S;
 #pragma omp for schedule(static)
         for (int r = 0; r < n; ++r) {
@@ -250,17 +256,17 @@ static bool build_rowpat(const HostCSR& M, Buf<unsigned short>& pat, std::vector
             rh[r] = h;
             if (fail) continue;
             S->add(h, r);
-            if (S->cnt > MAXPAT) fail = true;
+            if (S->cnt > maxpat) fail = true;
         }
     }
     Set* Gs = nullptr;
     std::vector<std::pair<int, unsigned long long>> reps;  // (first row, hash)
     if (!fail) {
-        Gs = new Set();
+        Gs = new Set(SLOTS);
         for (Set* S : local)
             if (S)
                 for (int s = 0; s < SLOTS && !fail; ++s)
-                    if (S->key[s]) { Gs->add(S->key[s], S->first[s]); if (Gs->cnt > MAXPAT) fail = true; }
+                    if (S->key[s]) { Gs->add(S->key[s], S->first[s]); if (Gs->cnt > maxpat) fail = true; }
     }
     for (Set* S : local) delete S;
     if (fail) { delete Gs; return false; }
@@ -293,7 +299,7 @@ static bool build_rowpat(const HostCSR& M, Buf<unsigned short>& pat, std::vector
     pat.alloc((size_t)n);
     if (!square) rowbase.alloc((size_t)n);
     bool collision = false;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nt)
     for (int r = 0; r < n; ++r) {
         const int id = Gs->find(rh[r]);
         if (id < 0 || !same_row(r, reps[(size_t)id].first)) { collision = true; continue; }
@@ -316,6 +322,72 @@ static int upload_ja16(DevCSR& D, const int* ja_dev_order)
     HIPCK(hipMalloc(&D.ja16, sizeof(unsigned short) * (size_t)D.nnz));
     HIPCK(hipMemcpy(D.ja16, j16.data(), sizeof(unsigned short) * (size_t)D.nnz, hipMemcpyHostToDevice));
     return FASP_SUCCESS;
+}
+
+static int g_device_sort = 1;   // fasp_hip_tune("device_sort", 0): per-row sort of the device copies on the host (A/B tests)
+// Stable sort of every row's entries by column ON THE DEVICE: one workgroup per row, bitonic network in LDS over the
+// keys (column << 32 | position in the row) -- keys are distinct, so the result is THE stable order, the same the host
+// std::stable_sort of the fallback below produces.  P7(256): levels 2-9 carry 15-19 M entries each in rows of 64-3100;
+// sorting them on the host cost 0.2-0.5 s per level (2.9 s of the 4.4 s upload), here < 5 ms.
+constexpr int SORT_BLK = 256, SORT_MAXLEN = 16384;   // 16384 keys = 128 KB of LDS
+__global__ __launch_bounds__(SORT_BLK) void k_sort_rows(int nrow, const int* __restrict__ ia, const int* __restrict__ ja_in,
+                                                        const double* __restrict__ val_in, int* __restrict__ ja_out,
+                                                        double* __restrict__ val_out, unsigned short* __restrict__ ja16)
+{
+    extern __shared__ unsigned long long sort_keys[];
+    const int tid = threadIdx.x;
+    for (int r = blockIdx.x; r < nrow; r += gridDim.x) {
+        const int kb = ia[r], len = ia[r + 1] - kb;
+        int P = 1;
+        while (P < len) P <<= 1;
+        for (int i = tid; i < P; i += SORT_BLK)
+            sort_keys[i] = i < len ? ((unsigned long long)(unsigned)ja_in[kb + i] << 32) | (unsigned)i : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < P / 2; t += SORT_BLK) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const unsigned long long a = sort_keys[i], b = sort_keys[l];
+                    if ((a > b) == ((i & k) == 0)) { sort_keys[i] = b; sort_keys[l] = a; }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < len; i += SORT_BLK) {
+            const unsigned long long key = sort_keys[i];
+            const int col = (int)(key >> 32);
+            ja_out[kb + i] = col;
+            val_out[kb + i] = val_in[kb + (int)(unsigned)key];
+            if (ja16) ja16[kb + i] = (unsigned short)col;
+        }
+        __syncthreads();
+    }
+}
+
+static int upload_sorted_on_device(const HostCSR& H, DevCSR& D, int maxlen)
+{
+    static const bool ja16_on = !(std::getenv("FASP_HIP_JA16") && std::atoi(std::getenv("FASP_HIP_JA16")) == 0);
+    int* tj = nullptr; double* tv = nullptr;
+    HIPCK(hipMalloc(&tj, sizeof(int) * (size_t)H.nnz));
+    if (hipMalloc(&tv, sizeof(double) * (size_t)H.nnz) != hipSuccess) { (void)hipFree(tj); return ERROR_ALLOC_MEM; }
+    int st = FASP_SUCCESS;
+    if (hipMemcpyAsync(tj, H.ja.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream) != hipSuccess ||
+        hipMemcpyAsync(tv, H.val.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream) != hipSuccess) st = ERROR_ALLOC_MEM;
+    const bool want16 = ja16_on && D.kind == 0 && D.col <= 65536 && D.nnz >= 4096;   // as upload_ja16
+    if (st >= 0 && want16 && hipMalloc(&D.ja16, sizeof(unsigned short) * (size_t)D.nnz) != hipSuccess) st = ERROR_ALLOC_MEM;
+    if (st >= 0) {
+        int P = 64;
+        while (P < maxlen) P <<= 1;
+        const size_t lds = sizeof(unsigned long long) * (size_t)P;
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) st = ERROR_MISC;
+        if (st >= 0) {
+            const int grid = std::min(H.row, 256 * 64);
+            hipLaunchKernelGGL(k_sort_rows, dim3(grid), dim3(SORT_BLK), lds, g_ctx.stream, H.row, D.ia, tj, tv, D.ja, D.val, D.ja16);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_ctx.stream) != hipSuccess) st = ERROR_MISC;
+        }
+    }
+    (void)hipFree(tj); (void)hipFree(tv);
+    if (st >= 0) D.sorted = true;
+    return st;
 }
 
 static int upload_csr(const HostCSR& H, DevCSR& D)
@@ -412,6 +484,24 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
     static const int  sort_stream = std::getenv("FASP_HIP_SORT_STREAM") ? std::atoi(std::getenv("FASP_HIP_SORT_STREAM")) : 0;
     const double avg_len = H.row > 0 ? (double)H.nnz / H.row : 0.0;
     const bool do_sort = sort_long && !g_oneshot_upload && H.nnz > 0 && (D.kind == 0 || (D.kind == 2 && sort_stream > 0 && avg_len >= sort_stream));
+    static const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
+    double tp = wall_seconds();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const double now = wall_seconds();
+        std::printf("        [upload_csr %d x %d, %d nnz] %-10s %8.3f s\n", H.row, H.col, H.nnz, what, now - tp);
+        tp = now;
+    };
+    if (do_sort && D.kind == 0) {   // (kind 2 wants the diagonal positions of the sorted copy: host path below)
+        int maxlen = 0;
+#pragma omp parallel for schedule(static) reduction(max : maxlen)
+        for (int i = 0; i < H.row; ++i) maxlen = std::max(maxlen, H.ia[i + 1] - H.ia[i]);
+        if (g_device_sort && maxlen <= SORT_MAXLEN) {
+            const int st = upload_sorted_on_device(H, D, maxlen);
+            lap("device sort");
+            return st;
+        }
+    }
     if (do_sort) {
         // Operators whose time goes into the x gathers -- one L1 tag lookup per distinct cache line, up to 64
         // per wavefront load when a row's columns come in discovery order: the DEVICE copy keeps every row's
@@ -438,8 +528,10 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
                 }
             }
         }
+        lap("row sort");
         HIPCK(hipMemcpy(D.ja, sj.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice));
         HIPCK(hipMemcpy(D.val, sv.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice));
+        lap("memcpy");
         if (square && D.kind == 2) {
             HIPCK(hipMalloc(&D.dpos, sizeof(int) * (size_t)std::max(H.row, 1)));
             HIPCK(hipMemcpy(D.dpos, dp.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));

@@ -162,12 +162,58 @@ static int halo_exchange(DevLevel& D, double* v)
     return st;
 }
 
+// One level to the device.  DL == nullptr: single rank, the level is whole (the overlapped upload of
+// fasp_hip_amg_create runs this from a second thread while the host setup builds the next levels).
+static int upload_level(fasp_hip_amg* h, int l, const DistLevel* DLp)
+{
+    const HostLevel& HL = h->H.L[l];
+    DevLevel& D = h->L[l];
+    const bool rep = !DLp || DLp->replicated;
+    D.replicated = rep;
+    D.nloc = rep ? HL.A.row : DLp->nloc; D.row0 = rep ? 0 : DLp->row0; D.nglobal = HL.A.row;
+    D.nvec = rep ? HL.A.row : DLp->nloc + (int)DLp->ghosts.size();
+    const HostCSR& A = rep ? HL.A : DLp->A;
+    static const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
+    double tp = wall_seconds();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const double now = wall_seconds();
+        std::printf("    [upload level %d] %-10s %8.3f s\n", l, what, now - tp);
+        tp = now;
+    };
+    if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;
+    lap("A");
+    if (HL.has_coarse) {
+        if (upload_csr(rep ? HL.P : DLp->P, D.P) < 0) return ERROR_ALLOC_MEM;
+        lap("P");
+        if (upload_csr(rep ? HL.R : DLp->R, D.R) < 0) return ERROR_ALLOC_MEM;
+        lap("R");
+    }
+    HIPCK(hipStreamSynchronize(g_ctx.stream));
+    lap("sync");
+    if (upload_diag(A, D) < 0) return ERROR_ALLOC_MEM;
+    lap("diag");
+    const size_t n = D.nvec;
+    if (l > 0) { if (alloc_vec(&D.b, n) < 0) return ERROR_ALLOC_MEM; }
+    else D.owns_b = false;  // level-0 rhs aliases the Krylov residual (PreCSR.c:429 copy elided)
+    if (alloc_vec(&D.xa, n) < 0 || alloc_vec(&D.xb, n) < 0 || alloc_vec(&D.w, n) < 0) return ERROR_ALLOC_MEM;
+    D.x = D.xa; D.xo = D.xb; D.x_zero = true;
+    if (!rep) {
+        D.send_off = DLp->send_off; D.recv_off = DLp->recv_off;
+        const size_t ns = DLp->send_idx.size();
+        HIPCK(hipMalloc(&D.d_send_idx, sizeof(int) * std::max<size_t>(ns, 1)));
+        HIPCK(hipMalloc(&D.d_sendbuf, sizeof(double) * std::max<size_t>(ns, 1)));
+        if (ns) HIPCK(hipMemcpy(D.d_send_idx, DLp->send_idx.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
+    }
+    return FASP_SUCCESS;
+}
+
 static int upload_hierarchy(fasp_hip_amg* h)
 {
     HostThreads team;  // matrix coding / re-sorting / partition loops
     const double t0 = wall_seconds();
     const int nl = (int)h->H.L.size();
-    h->L.resize(nl);
+    h->L.resize(nl);   // (never grows here when levels were uploaded ahead: the vector was reserved for MAX_AMG_LVL + 1)
     int min_rows = 200000;
     if (const char* e = std::getenv("FASP_HIP_DIST_MIN_ROWS")) min_rows = std::atoi(e);
     // sequential (Gauss-Seidel / SOR) sweeps couple all rows of a level: such hierarchies
@@ -198,32 +244,9 @@ static int upload_hierarchy(fasp_hip_amg* h)
     }
     h->distributed = !h->dist.L[0].replicated;
     for (int l = 0; l < nl; ++l) {
-        const HostLevel& HL = h->H.L[l];
-        const DistLevel& DL = h->dist.L[l];
-        DevLevel& D = h->L[l];
-        D.replicated = DL.replicated;
-        D.nloc = DL.nloc; D.row0 = DL.row0; D.nglobal = DL.nglobal;
-        D.nvec = DL.replicated ? DL.nglobal : DL.nloc + (int)DL.ghosts.size();
-        const HostCSR& A = DL.replicated ? HL.A : DL.A;
-        if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;
-        if (HL.has_coarse) {
-            if (upload_csr(DL.replicated ? HL.P : DL.P, D.P) < 0) return ERROR_ALLOC_MEM;
-            if (upload_csr(DL.replicated ? HL.R : DL.R, D.R) < 0) return ERROR_ALLOC_MEM;
-        }
-        HIPCK(hipStreamSynchronize(g_ctx.stream));
-        if (upload_diag(A, D) < 0) return ERROR_ALLOC_MEM;
-        const size_t n = D.nvec;
-        if (l > 0) { if (alloc_vec(&D.b, n) < 0) return ERROR_ALLOC_MEM; }
-        else D.owns_b = false;  // level-0 rhs aliases the Krylov residual (PreCSR.c:429 copy elided)
-        if (alloc_vec(&D.xa, n) < 0 || alloc_vec(&D.xb, n) < 0 || alloc_vec(&D.w, n) < 0) return ERROR_ALLOC_MEM;
-        D.x = D.xa; D.xo = D.xb; D.x_zero = true;
-        if (!DL.replicated) {
-            D.send_off = DL.send_off; D.recv_off = DL.recv_off;
-            const size_t ns = DL.send_idx.size();
-            HIPCK(hipMalloc(&D.d_send_idx, sizeof(int) * std::max<size_t>(ns, 1)));
-            HIPCK(hipMalloc(&D.d_sendbuf, sizeof(double) * std::max<size_t>(ns, 1)));
-            if (ns) HIPCK(hipMemcpy(D.d_send_idx, DL.send_idx.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
-        }
+        if (h->L[l].A.ia) continue;   // uploaded already, while the host setup was still running (single rank: replicated)
+        const int st = upload_level(h, l, &h->dist.L[l]);
+        if (st < 0) return st;
     }
     const size_t m = h->L[0].nvec;
     if (alloc_vec(&h->b, m) < 0 || alloc_vec(&h->u, m) < 0 || alloc_vec(&h->p, m) < 0 ||

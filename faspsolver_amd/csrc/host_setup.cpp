@@ -1582,6 +1582,7 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
             galerkin_rap(H.L[lvl].R, H.L[lvl].A, H.L[lvl].P, H.L[lvl + 1].A);  // :213
             lap("RAP");
             H.L[lvl].has_coarse = true;
+            if (g_on_level_ready) g_on_level_ready(lvl, g_on_level_ready_ctx);   // A, P, R, cfmark of this level are final
             ++lvl;
             const HostCSR& Ac = H.L[lvl].A;
             if (Ac.nnz / Ac.row > Ac.col * 0.2) {  // Check 4, :261 (integer division)
@@ -1603,6 +1604,9 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
     }
     return status;
 }
+
+void (*g_on_level_ready)(int level, void* ctx) = nullptr;
+void* g_on_level_ready_ctx = nullptr;
 
 int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
 {

@@ -30,8 +30,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fasp_comm.h"
@@ -301,6 +304,47 @@ int fasp_hip_amg_upload(fasp_hip_amg* h)
     return upload_hierarchy(h);
 }
 
+namespace {
+// Overlapped upload (single rank, classical setup): a second thread sends level l to the device -- matrix coding,
+// re-sorting and all -- while the host setup builds level l + 1.  256^3: the 3.5-4 s of coding + upload disappear
+// behind the 10 s of host setup.
+struct AheadUpload {
+    fasp_hip_amg*           h = nullptr;
+    std::mutex              mu;
+    std::condition_variable cv;
+    std::vector<int>        ready;
+    bool                    done = false;
+    int                     status = FASP_SUCCESS;
+    std::thread             th;
+    static void on_ready(int level, void* ctx)
+    {
+        AheadUpload* self = static_cast<AheadUpload*>(ctx);
+        { std::lock_guard<std::mutex> lk(self->mu); self->ready.push_back(level); }
+        self->cv.notify_one();
+    }
+    void run()
+    {
+        (void)hipSetDevice(g_ctx.device);
+        HostThreads team;
+        double t_first = -1.0;
+        for (;;) {
+            int l = -1;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !ready.empty() || done; });
+                if (ready.empty()) return;
+                l = ready.front(); ready.erase(ready.begin());
+            }
+            if (t_first < 0) t_first = wall_seconds();
+            const double t0 = wall_seconds();
+            if (status >= 0) { const int st = upload_level(h, l, nullptr); if (st < 0) status = st; }
+            if (std::getenv("FASP_HIP_SETUP_TIMING"))
+                std::printf("  [upload ahead] level %d: %.3f s (started %.3f s after the first)\n", l, wall_seconds() - t0, t0 - t_first);
+        }
+    }
+};
+}  // namespace
+
 int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgparam)
 {
     if (!out || !A || !amgparam) return ERROR_INPUT_PAR;
@@ -309,9 +353,43 @@ int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgpara
     if (st < 0) return st;
     if ((st = ctx_init()) < 0) return st;  // fail before the (long) host setup when there is no GPU
     fasp_hip_amg* h = nullptr;
-    st = fasp_hip_amg_create_host(&h, A, amgparam);
-    if (st < 0) return st;
+    static const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
+    double tp = wall_seconds();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const double now = wall_seconds();
+        std::printf("  [create] %-28s %8.3f s\n", what, now - tp);
+        tp = now;
+    };
+    static const bool ahead_on = !(std::getenv("FASP_HIP_UPLOAD_AHEAD") && std::atoi(std::getenv("FASP_HIP_UPLOAD_AHEAD")) == 0);
+    const bool ahead = ahead_on && comm_size() == 1 && amgparam->AMG_type != SA_AMG && amgparam->AMG_type != UA_AMG &&
+                       A->nnz >= 1000000;   // worth a thread from a few hundred thousand rows on
+    if (ahead) {
+        h = new fasp_hip_amg();
+        h->param = *amgparam;                    // (compress_enabled() etc. read globals only)
+        h->L.resize(MAX_AMG_LVL + 1);            // no reallocation while the second thread fills levels
+        AheadUpload up;
+        up.h = h;
+        up.th = std::thread([&up] { up.run(); });
+        g_on_level_ready = &AheadUpload::on_ready; g_on_level_ready_ctx = &up;
+        st = host_setup_rs(A, amgparam, h->H);
+        g_on_level_ready = nullptr; g_on_level_ready_ctx = nullptr;
+        lap("host setup");
+        if (st >= 0) AheadUpload::on_ready((int)h->H.L.size() - 1, &up);   // the coarsest level
+        { std::lock_guard<std::mutex> lk(up.mu); up.done = true; }
+        up.cv.notify_one();
+        up.th.join();
+        lap("wait for the level uploads");
+        if (st >= 0) st = up.status;
+        if (st < 0) { h->L.resize(h->H.L.size()); fasp_hip_amg_destroy(h); return st; }
+        h->param = *amgparam;
+    } else {
+        st = fasp_hip_amg_create_host(&h, A, amgparam);
+        if (st < 0) return st;
+        lap("host setup");
+    }
     st = upload_hierarchy(h);
+    lap("upload_hierarchy");
     if (st < 0) { fasp_hip_amg_destroy(h); return st; }
     *out = h;
     return FASP_SUCCESS;
@@ -1761,6 +1839,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "spcg_grid")) g_tune.spcg_grid = value;
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
     else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;
+    else if (!std::strcmp(key, "device_sort")) g_device_sort = value;
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;

@@ -139,3 +139,28 @@ def test_coded_vs_plain_and_gen1_vs_gen2_bit_identity_128(gpu):
     for k, v in out.items():
         assert np.array_equal(v, base), k
     H.close()
+
+
+@pytest.mark.gpu
+def test_device_row_sort_equals_host_row_sort(gpu):
+    """The long-row levels keep a device copy with every row stable-sorted by column.  The sort runs on the GPU
+    (k_sort_rows, bitonic over (column, position) keys); the host std::stable_sort it replaced is still there
+    behind fasp_hip_tune("device_sort", 0).  Same order -> the same lane-strided sums -> identical bits.
+    The ahead-of-time upload thread (setups from a million nonzeros on) is exercised by the 96^3 build."""
+    n = 96
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _params()
+    L = fa.lib()
+    r = np.random.default_rng(6).standard_normal(len(f))
+    out = []
+    try:
+        for dev in (1, 0):
+            L.fasp_hip_tune(b"device_sort", dev)
+            H = fa.AMG(ia, ja, a, amgp)
+            kinds = [H.kernel_info(l, 0)[0] for l in range(H.num_levels)]
+            assert 0 in kinds    # there are sub-wavefront (long-row) levels to sort
+            out.append(H.precond(r))
+            H.close()
+    finally:
+        L.fasp_hip_tune(b"device_sort", 1)
+    assert np.array_equal(out[0], out[1])
