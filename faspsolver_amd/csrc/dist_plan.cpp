@@ -11,6 +11,11 @@
 //    [nloc, nloc + nghost) for the halo ("ghost") entries, ghosts sorted by global index and
 //    therefore grouped by owner.  One ghost set per level's vector space (the union over
 //    the operators that read it: A_l, R_l, P_{l-1}) -> one halo plan per level.
+//  * Aggregation hierarchies (SA / UA) carry no C/F marker: every level is cut into equal contiguous row blocks
+//    of its own.  The VMB aggregates are numbered in discovery order, i.e. essentially by their first member
+//    (PreAMGAggregation.inl:455-486), so a rank's coarse block still sits under its fine block and the halos of
+//    P and R stay near the block ends -- but nothing below depends on that: ghost sets and send lists come from
+//    the actual columns of the rows a rank owns.
 //  * Levels with fewer than `min_rows` rows are REPLICATED: every rank holds the whole
 //    level and computes it redundantly; the rhs of the first replicated level is assembled
 //    with one all-gather.  Small dense coarse levels would otherwise need all-to-all halos
@@ -92,12 +97,16 @@ int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, 
     D.L.resize(nl);
 
     // ownership ranges of every level (classical AMG: coarse rows follow their C points;
-    // aggregation hierarchies carry no C/F marker -> they are not partitioned, only replicated)
-    bool can_partition = true;
+    // aggregation hierarchies: equal blocks per level)
+    const bool can_partition = true;
+    bool has_cf = true;
     for (int l = 0; l + 1 < nl; ++l)
-        if (H.L[l].cfmark.n != (size_t)H.L[l].A.row) can_partition = false;
+        if (H.L[l].cfmark.n != (size_t)H.L[l].A.row) has_cf = false;
     for (int l = 0; l < nl; ++l) D.L[l].start.assign(nranks + 1, 0);
-    if (can_partition) {
+    if (!has_cf) {
+        for (int l = 0; l < nl; ++l)
+            for (int r = 0; r <= nranks; ++r) D.L[l].start[r] = (int)((long long)H.L[l].A.row * r / nranks);
+    } else {
         const int n0 = H.L[0].A.row;
         for (int r = 0; r <= nranks; ++r) D.L[0].start[r] = (int)((long long)n0 * r / nranks);
         for (int l = 0; l + 1 < nl; ++l) {

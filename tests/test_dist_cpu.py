@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, min_rows, q, shared=False):
+def _worker(rank, world, port, n, min_rows, q, shared=False, amg_type=1):
     try:
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
         import ctypes as C
@@ -34,6 +34,7 @@ def _worker(rank, world, port, n, min_rows, q, shared=False):
         O = _libs.oracle()
         ia, ja, a, f, ue = fa.poisson7pt(n)
         amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
+        amgp.AMG_type = amg_type   # 1 classical (coarse rows follow their C points), 2 SA / 3 UA (equal blocks per level)
         if shared:
             # one host setup per node: rank 0 builds and publishes, the others map the segment (fasp_hip_amg_publish / _attach)
             seg = f"fasp_cpu_test_{port}"
@@ -139,13 +140,14 @@ def _worker(rank, world, port, n, min_rows, q, shared=False):
         q.put((rank, "fail", traceback.format_exc(), 0))
 
 
-@pytest.mark.parametrize("n,min_rows,shared", [(12, 150, False), (16, 300, False), (16, 300, True)])
-def test_two_rank_partition_and_operators(n, min_rows, shared):
+@pytest.mark.parametrize("n,min_rows,shared,amg_type", [(12, 150, False, 1), (16, 300, False, 1), (16, 300, True, 1),
+                                                        (16, 100, False, 2), (16, 100, False, 3)])
+def test_two_rank_partition_and_operators(n, min_rows, shared, amg_type):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, min_rows, q, shared)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, min_rows, q, shared, amg_type)) for r in range(2)]
     for p in procs:
         p.start()
     try:
