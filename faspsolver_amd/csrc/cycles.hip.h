@@ -322,23 +322,25 @@ ForwardSweep:
         if (D.x_zero) {
             HIPCK(hipMemcpyAsync(D.w, D.b, sizeof(double) * D.A.row, hipMemcpyDeviceToDevice, g_ctx.stream));
         } else {
-            if (halo_exchange(D, D.x) < 0) return ERROR_MISC;
-            d_resid(D.A, D.x, D.b, D.w);
+            CsrArgs a{}; a.x = D.x; a.y = D.w; a.b = D.b;
+            if (dist_launch<OP_RESID>(D, D.A, a) < 0) return ERROR_MISC;   // halo of x beside the interior rows
         }
-        if (halo_exchange(D, D.w) < 0) return ERROR_MISC;
         {
             DevLevel& C = h->L[l + 1];
+            CsrArgs ra{}; ra.x = D.w;
             if (!D.replicated && C.replicated) {
                 // first replicated level: every rank restricts onto the coarse rows it owns,
                 // one all-gather assembles the whole right-hand side on every rank
                 const std::vector<int>& cs = h->dist.L[l + 1].start;
                 std::vector<int> counts(comm_size());
                 for (int q = 0; q < comm_size(); ++q) counts[q] = cs[q + 1] - cs[q];
-                d_mxv(D.R, D.w, C.b + cs[comm_rank()]);
+                ra.y = C.b + cs[comm_rank()];
+                if (dist_launch<OP_MXV>(D, D.R, ra) < 0) return ERROR_MISC;
                 if (comm_allgatherv(C.b + cs[comm_rank()], counts[comm_rank()], C.b, counts.data(), cs.data(),
                                     g_ctx.stream) < 0) return ERROR_MISC;
             } else {
-                d_mxv(D.R, D.w, C.b);
+                ra.y = C.b;
+                if (dist_launch<OP_MXV>(D, D.R, ra) < 0) return ERROR_MISC;
             }
         }
         ++l;
@@ -352,9 +354,9 @@ ForwardSweep:
         DevLevel& D = h->L[l];
         materialise_zero(D);
         DevLevel& C = h->L[l + 1];
-        if (halo_exchange(C, C.x) < 0) return ERROR_MISC;
         double alpha = 1.0;
         if (param.coarse_scaling == 1) {
+            if (halo_exchange(C, C.x) < 0) return ERROR_MISC;
             // PreMGCycle.c:210-216: alpha = (x_c, b_c) / (A_c x_c, x_c), capped at 1
             // (fasp_blas_dcsr_vmv, BlaSpmvCSR.c:839); C.w is free scratch on the way up
             const bool cdist = !C.replicated && comm_size() > 1;
@@ -366,7 +368,11 @@ ForwardSweep:
             if (d_dot(C.A.row, C.x, C.b, red, cdist) < 0) return ERROR_MISC;
             alpha = std::min(red[0] / red[1], 1.0);
         }
-        d_aAxpy(alpha, D.P, C.x, D.x);  // x_l += alpha P x_{l+1}
+        if (param.coarse_scaling == 1) d_aAxpy(alpha, D.P, C.x, D.x);  // x_l += alpha P x_{l+1}  (ghosts of x_{l+1} are there)
+        else {   // alpha == 1: the halo of x_{l+1} travels beside the interior rows of P
+            CsrArgs pa{}; pa.x = C.x; pa.y = D.x; pa.alpha = 1.0;
+            if (dist_launch<OP_ADD>(C, D.P, pa) < 0) return ERROR_MISC;
+        }
         if ((st0 = smooth(h, l, true, smoother, param.smooth_order, param.postsmooth_iter, relax, param.polynomial_degree)) < 0) return st0;
         if (num_lvl[l] < ncycles[l]) break;
         else num_lvl[l] = 0;
@@ -425,8 +431,7 @@ static int amg_solve_device(fasp_hip_amg* h, const AMG_param& param, Hist& hist,
     while ((iter++ < MaxIt) & (sumb > SMALLREAL)) {
         if ((st = mgcycle(h, param)) < 0) return st;
         materialise_zero(D0);
-        if (halo_exchange(D0, D0.x) < 0) return ERROR_MISC;
-        d_resid(D0.A, D0.x, D0.b, D0.w);
+        { CsrArgs a{}; a.x = D0.x; a.y = D0.w; a.b = D0.b; if (dist_launch<OP_RESID>(D0, D0.A, a) < 0) return ERROR_MISC; }
         if (d_dot(m, D0.w, D0.w, red, dist) < 0) return ERROR_MISC;
         absres = std::sqrt(red[0]);
         relres1 = absres / std::max(SMALLREAL, sumb);
@@ -454,12 +459,31 @@ static KOps csr_ops(fasp_hip_amg* h, int level, bool with_pc)
     DevLevel* Lv = &h->L[level];
     K.n = Lv->A.row; K.nvec = (size_t)Lv->nvec; K.fmt = "CSR";
     K.dist = (level == 0) && h->distributed;
-    K.halo = [Lv](double* v) { return halo_exchange(*Lv, v); };
-    K.mxv = [Lv](const double* x, double* y) { d_mxv(Lv->A, x, y); };
-    K.resid = [Lv](const double* x, const double* b, double* r) { d_resid(Lv->A, x, b, r); };
-    K.mxv_dot = [Lv](const double* x, double* y) {
+    // The Krylov texts call halo(v) right before the operator that reads v.  Here halo() only notes the vector; the
+    // operator that follows does the exchange beside its interior rows (dist_launch).  An operator that finds a
+    // different vector pending exchanges that one first, the plain way.
+    K.halo = [Lv](double* v) { Lv->halo_pending = v; return 0; };
+    auto run = [Lv](auto op_tag, CsrArgs a) {
+        constexpr int OP = decltype(op_tag)::value;
+        double* pend = Lv->halo_pending;
+        Lv->halo_pending = nullptr;
+        if (pend && pend != a.x) { if (halo_exchange(*Lv, pend) < 0) return -1; pend = nullptr; }
+        if (pend) return dist_launch<OP>(*Lv, Lv->A, a);
+        return launch_csr<OP>(Lv->A, a);
+    };
+    K.mxv = [run](const double* x, double* y) {
+        CsrArgs a{}; a.x = x; a.y = y;
+        if (run(std::integral_constant<int, OP_MXV>(), a) < 0) comm_mark_failed();
+    };
+    K.resid = [run](const double* x, const double* b, double* r) {
+        CsrArgs a{}; a.x = x; a.y = r; a.b = b;
+        if (run(std::integral_constant<int, OP_RESID>(), a) < 0) comm_mark_failed();
+    };
+    K.mxv_dot = [run](const double* x, double* y) {
         CsrArgs a{}; a.x = x; a.y = y; a.dotv = x; a.partials = g_ctx.d_partials;
-        return launch_csr<OP_MXV_DOT>(Lv->A, a);
+        const int G = run(std::integral_constant<int, OP_MXV_DOT>(), a);
+        if (G < 0) comm_mark_failed();
+        return std::max(G, 8);
     };
     if (with_pc) K.pc = [h](double* in, double** out) { return precond_amg(h, in, out); };
     const int set = level == 0 ? 0 : 1;

@@ -31,6 +31,9 @@ struct DevCSR {
     unsigned short* ja16 = nullptr;  // JA as 16-bit values (long-row operators with <= 65536 columns)
     int*    xrows = nullptr;         // k_csr_rowpat4: rows outside their wave's uniform pattern (square coded operators)
     int     nxrows = -1;             // -1: no list (k_csr_rowpat4 not applicable)
+    // local operator of a row-partitioned level: the rows [win_lo, win_hi) read no ghost column (multiples of WIN_ALIGN
+    // or the row count; win_hi < 0: no such window worth a split launch) -- they run while the halo is in flight
+    int     win_lo = 0, win_hi = -1;
     void    release()
     {
         if (xrows) (void)hipFree(xrows);
@@ -544,7 +547,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 0, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0; };
+struct Tuning { int gen2 = 2, ws2_bpc = 0, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -585,10 +588,33 @@ static int launch_rowpat5(CsrArgs& a)
 
 // Launches the row kernel of family M.kind for operation OP; returns the grid size
 // (= number of per-block partials written by OP_MXV_DOT).
+// Row window of a launch: rows [lo, hi) (lo a multiple of WIN_ALIGN, which every kernel's tile size divides),
+// per-block partials written from slot goff on.  hi < 0: the whole operator.
+constexpr int WIN_ALIGN = 1024;
+struct RowWin { int lo = 0, hi = -1, goff = 0; };
+
 template <int OP>
-static int launch_csr(const DevCSR& M0, CsrArgs a)
+static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
 {
+    if (win.hi < 0 && g_tune.split_rows > 0 && M0.row >= 4 * WIN_ALIGN) {
+        // test mode (fasp_hip_tune("split_rows", k)): every operator in three row windows, as dist_launch issues them
+        const int lo = std::min(g_tune.split_rows, M0.row / 4) / WIN_ALIGN * WIN_ALIGN, hi = (M0.row - lo) / WIN_ALIGN * WIN_ALIGN;
+        RowWin w; w.lo = lo; w.hi = hi; w.goff = 0;
+        int G = launch_csr<OP>(M0, a, w);
+        w.lo = 0; w.hi = lo; w.goff = G;
+        G += launch_csr<OP>(M0, a, w);
+        w.lo = hi; w.hi = M0.row; w.goff = G;
+        return G + launch_csr<OP>(M0, a, w);
+    }
     DevCSR M = M0;  // shallow copy: tuning overrides
+    const int w_lo = win.hi >= 0 ? win.lo : 0, w_hi = win.hi >= 0 ? std::min(win.hi, M0.row) : M0.row;
+    if (w_hi <= w_lo && win.hi >= 0) return 0;
+    if (a.partials) a.partials += win.goff;
+    auto set_tiles = [&](int rpb) {
+        a.nrow = w_hi; a.row_lo = w_lo; a.tile0 = w_lo / rpb;
+        a.ntiles = (w_hi - w_lo + rpb - 1) / rpb;
+        a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    };
     if (M.code && g_tune.compress) M.kind = 4;  // dictionary-coded copy present: one byte per entry
     if (M.pat && g_tune.compress) M.kind = 5;   // row-pattern-coded copy present: two bytes per row
     if (g_tune.kind >= 0 && !(g_tune.kind == 4 && !M.code) && !(g_tune.kind == 5 && !M.pat)) M.kind = g_tune.kind;
@@ -602,15 +628,13 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
     a.ja16 = g_tune.ja16 ? M.ja16 : nullptr;
     const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : M.kind == 3 ? 1 : BLOCK / M.lanes;
-    a.ntiles = (M.row + rpb - 1) / rpb;
-    a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    set_tiles(rpb);
     if (M.kind == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase && g_tune.rpl <= 0) {
         // square row-pattern-coded operator: scalar-pattern sweep + exception list (kernels2.hip.h)
         a.pat = M.pat; a.pstart = M.pstart; a.plen = M.plen; a.poff = M.poff; a.pval = M.pval;
         a.npat = M.npat; a.npent = M.npent; a.ncol = M.col; a.rowbase = nullptr;
         a.xrows = M.xrows; a.nxrows = M.nxrows;
-        a.ntiles = (M.row + 2 * BLOCK - 1) / (2 * BLOCK);
-        a.tiles_per_xcd = (a.ntiles + 7) / 8;
+        set_tiles(2 * BLOCK);
         a.xcd_map = a.ntiles >= 8 * 64 ? -1 : 16;  // slabs: x is fetched once per XCD (PMC: 0.18 GB instead of 0.45 GB per level-0 pass)
         return launch_persistent(k_csr_rowpat4<OP>, a.ntiles, a, 5);
     }
@@ -622,8 +646,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
         a.pat = M.pat; a.pstart = M.pstart; a.plen = M.plen; a.poff = M.poff; a.pval = M.pval;
         a.npat = M.npat; a.npent = M.npent; a.ncol = M.col; a.rowbase = M.rowbase;
         a.xrows = M.xrows; a.nxrows = M.nxrows;
-        a.ntiles = (M.row + 2 * BLOCK - 1) / (2 * BLOCK);
-        a.tiles_per_xcd = (a.ntiles + 7) / 8;
+        set_tiles(2 * BLOCK);
         a.xcd_map = a.ntiles >= 8 * 64 ? -1 : 16;
         return launch_rowpat5<OP>(a);
     }
@@ -635,8 +658,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
         const int rpl = g_tune.rpl > 0 ? g_tune.rpl : 1;
         a.plen = M.plen; a.ncol = M.col;
         if (g_tune.xcd_pat != 0) a.xcd_map = g_tune.xcd_pat;
-        a.ntiles = (M.row + BLOCK * rpl - 1) / (BLOCK * rpl);
-        a.tiles_per_xcd = (a.ntiles + 7) / 8;
+        set_tiles(BLOCK * rpl);
         (void)avg;
         if (lds && M.npat <= 64 && M.npent <= 512 && g_tune.lds_tab != 3) {  // small table: more resident blocks
             if (rpl == 1) return launch_persistent(k_csr_rowpat<OP, 2, 1>, a.ntiles, a);
@@ -668,7 +690,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a)
         if (M.wrows == 32 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 32, 512>, a.ntiles, a);
         return launch_persistent(k_csr_wstream<OP, 32, 1024>, a.ntiles, a);
     }
-    if (M.kind == 3) return launch_persistent(k_csr_blockrow<OP>, M.row, a);
+    if (M.kind == 3) return launch_persistent(k_csr_blockrow<OP>, w_hi - w_lo, a);
     if (M.kind == 1) {
         int cap = g_tune.maxgrid > 0 ? g_tune.maxgrid : 4 * g_ctx.num_cu;
         int grid = std::max(8, (std::min(std::min(cap, MAXGRID), a.ntiles) + 7) / 8 * 8);

@@ -12,6 +12,7 @@ struct DevLevel {
     double* x  = nullptr;    // current iterate: xa or xb
     double* xo = nullptr;    // the other buffer
     bool    x_zero = true;   // x is (conceptually) all zeros and not materialised
+    double* halo_pending = nullptr;  // Krylov operator bundle: vector whose halo the next operator exchanges (cycles.hip.h, csr_ops)
     bool    owns_b = true;
     // distribution (single GPU: nloc == nvec == rows, no halo)
     bool    replicated = true;   // whole level on every rank, computed redundantly
@@ -139,8 +140,9 @@ __global__ __launch_bounds__(BLOCK) void k_pack(int n, const int* __restrict__ i
 // Refresh the ghost entries [nloc, nvec) of a level-l vector from their owners: pack the
 // entries the peers need, one grouped RCCL send/recv, receive straight into the ghost
 // slots (ghosts are sorted by owner, so every peer's block is contiguous).
-static int halo_exchange(DevLevel& D, double* v)
+static int halo_exchange(DevLevel& D, double* v, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = g_ctx.stream;
     // Every rank of a distributed level enters the exchange, also with nothing to send or receive: whether a level
     // is distributed is known to all ranks alike, whether THIS rank has halo traffic is not (a rank that
     // skipped the collective left its peers in the transport's barriers).
@@ -148,7 +150,7 @@ static int halo_exchange(DevLevel& D, double* v)
     const int P = comm_size(), me = comm_rank();
     const int nsend = D.send_off.back();
     if (nsend > 0)
-        hipLaunchKernelGGL(k_pack, dim3(vec_grid(nsend)), dim3(BLOCK), 0, g_ctx.stream, nsend, D.d_send_idx, v,
+        hipLaunchKernelGGL(k_pack, dim3(vec_grid(nsend)), dim3(BLOCK), 0, stream, nsend, D.d_send_idx, v,
                            D.d_sendbuf);
     std::vector<CommXfer> sends, recvs;
     for (int q = 0; q < P; ++q) {
@@ -157,9 +159,65 @@ static int halo_exchange(DevLevel& D, double* v)
         if (ns > 0) sends.push_back({q, D.d_sendbuf + D.send_off[q], (size_t)ns});
         if (nr > 0) recvs.push_back({q, v + D.nloc + D.recv_off[q], (size_t)nr});
     }
-    const int st = comm_exchange(sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size(), g_ctx.stream);
+    const int st = comm_exchange(sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size(), stream);
     if (st < 0) comm_mark_failed();
     return st;
+}
+
+// ---- halo exchange overlapped with the interior rows ------------------------------------------------------------
+// y = OP(M, x) on a row-partitioned level V (the level x lives on):  the exchange of x's ghost entries runs on its own
+// stream while the compute stream works on the rows [win_lo, win_hi) of M that read no ghost column; the boundary
+// rows (the two ends of the block: with a 1-D partition of a grid in natural ordering, one plane each) follow when
+// the ghosts have arrived.  Three launches of the same kernel through its row window: the arithmetic of every row is
+// what the single launch does, only the partition of the fused dot product into per-block partials changes.
+static int g_halo_overlap = 1;   // fasp_hip_tune("halo_overlap", 0): exchange, then one launch (the round-1 sequence)
+
+// interior window of a local operator: nown = number of owned columns (ghosts are numbered from nown on)
+static void find_row_window(const HostCSR& M, int nown, DevCSR& D)
+{
+    D.win_lo = 0; D.win_hi = -1;
+    const int n = M.row;
+    if (n < 4 * WIN_ALIGN) return;
+    const int half = n / 2;
+    int last_lo = -1, first_hi = n;   // last ghost-reading row of the first half, first one of the second half
+#pragma omp parallel for schedule(static) reduction(max : last_lo) reduction(min : first_hi)
+    for (int i = 0; i < n; ++i) {
+        bool g = false;
+        for (int k = M.ia[i]; k < M.ia[i + 1] && !g; ++k) g = M.ja[k] >= nown;
+        if (!g) continue;
+        if (i < half) last_lo = std::max(last_lo, i);
+        else first_hi = std::min(first_hi, i);
+    }
+    const int lo = (last_lo + 1 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+    const int hi = first_hi == n ? n : first_hi / WIN_ALIGN * WIN_ALIGN;
+    if (hi - lo < n / 2) return;   // ghost readers all over the block: nothing to overlap
+    D.win_lo = lo; D.win_hi = hi;
+}
+
+template <int OP>
+static int dist_launch(DevLevel& V, const DevCSR& M, CsrArgs a)
+{
+    double* v = const_cast<double*>(a.x);
+    if (V.replicated || comm_size() <= 1 || V.send_off.empty()) return launch_csr<OP>(M, a);
+    if (!g_halo_overlap || M.win_hi < 0) {
+        if (halo_exchange(V, v) < 0) return -1;
+        return launch_csr<OP>(M, a);
+    }
+    // the exchange waits for whatever produced x, then runs beside the interior rows
+    if (hipEventRecord(g_ctx.ev_ready, g_ctx.stream) != hipSuccess ||
+        hipStreamWaitEvent(g_ctx.comm_stream, g_ctx.ev_ready, 0) != hipSuccess) return -1;
+    RowWin w;
+    w.lo = M.win_lo; w.hi = M.win_hi; w.goff = 0;
+    int G = launch_csr<OP>(M, a, w);
+    // (the transport may block the host -- the shared-memory one does: the interior launch is queued before it)
+    if (halo_exchange(V, v, g_ctx.comm_stream) < 0) return -1;
+    if (hipEventRecord(g_ctx.ev_halo, g_ctx.comm_stream) != hipSuccess ||
+        hipStreamWaitEvent(g_ctx.stream, g_ctx.ev_halo, 0) != hipSuccess) return -1;
+    w.lo = 0; w.hi = M.win_lo; w.goff = G;
+    G += launch_csr<OP>(M, a, w);
+    w.lo = M.win_hi; w.hi = M.row; w.goff = G;
+    G += launch_csr<OP>(M, a, w);
+    return G;
 }
 
 // One level to the device.  DL == nullptr: single rank, the level is whole (the overlapped upload of
@@ -188,6 +246,14 @@ static int upload_level(fasp_hip_amg* h, int l, const DistLevel* DLp)
         lap("P");
         if (upload_csr(rep ? HL.R : DLp->R, D.R) < 0) return ERROR_ALLOC_MEM;
         lap("R");
+    }
+    if (!rep) {   // interior windows (dist_launch): A and R read this level's vectors, P the next level's
+        find_row_window(A, DLp->nloc, D.A);
+        if (HL.has_coarse) {
+            find_row_window(DLp->R, DLp->nloc, D.R);
+            const DistLevel& DC = h->dist.L[l + 1];
+            if (!DC.replicated) find_row_window(DLp->P, DC.nloc, D.P);
+        }
     }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     lap("sync");

@@ -73,6 +73,9 @@ struct CsrArgs {
     const unsigned short* ja16;  // != nullptr: the column indices once more as 16-bit values (operators with <= 65536 columns)
     const int*    xrows;    // k_csr_rowpat4: rows outside their wave's uniform pattern, computed lane = row after the sweep
     int           nxrows;
+    // row window of a launch (distributed levels: interior rows while the halo is in flight, boundary rows after it):
+    // the launch covers the tiles tile0 .. tile0 + ntiles of the kernel's own tile size, i.e. the rows [row_lo, nrow)
+    int           tile0, row_lo;
 };
 
 // Epilogue of OP_L1DIAG, t = b_i - sum_j a_ij x_j accumulated from b_i entry by entry: the L1
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
     for (int v = blockIdx.x; v < vmax; v += gridDim.x) {
         const int t = tile_of(a, v);
         if (t >= a.ntiles) continue;
-        const int r = t * RPB + rloc;
+        const int r = (t + a.tile0) * RPB + rloc;
         if (r < a.nrow) {
             const int kb = a.ia[r], ke = a.ia[r + 1];
             double s = 0.0;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_blockrow(CsrArgs a)
 {
     __shared__ double lds[4];
     double acc = 0.0;
-    for (int r = blockIdx.x; r < a.nrow; r += gridDim.x) {
+    for (int r = a.row_lo + blockIdx.x; r < a.nrow; r += gridDim.x) {
         const int kb = a.ia[r], ke = a.ia[r + 1];
         double s = 0.0;
         for (int base = kb + threadIdx.x; base < ke; base += 8 * BLOCK) {
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(CsrArgs a, int R)
     for (int v = blockIdx.x; v < vmax; v += gridDim.x) {
         const int t = tile_of(a, v);
         if (t >= a.ntiles) continue;
-        const int r0 = t * R;
+        const int r0 = (t + a.tile0) * R;
         const int nr = min(R, a.nrow - r0);
         for (int i = tid; i <= nr; i += BLOCK) rowptr[i] = a.ia[r0 + i];
         __syncthreads();
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_dict8(CsrArgs a)
             const int t = tile_of(a, v);
             v += G;
             if (t >= a.ntiles) continue;
-            const int rr = t * BLOCK + wave * 64;
+            const int rr = (t + a.tile0) * BLOCK + wave * 64;
             if (rr >= a.nrow) continue;
             r0 = rr; nr = min(64, a.nrow - rr);
             return;
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat(CsrArgs a)
             if (v >= vmax) return -1;
             const int t = tile_of(a, v);
             v += G;
-            if (t < a.ntiles) return t * (BLOCK * RPL);
+            if (t < a.ntiles) return (t + a.tile0) * (BLOCK * RPL);
         }
     };
     int      v = blockIdx.x;
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream(CsrArgs a)
     for (int v = blockIdx.x; v < vmax; v += gridDim.x) {
         const int t = tile_of(a, v);
         if (t >= a.ntiles) continue;
-        const int r0 = (t * 4 + wave) * RW;
+        const int r0 = ((t + a.tile0) * 4 + wave) * RW;
         if (r0 >= a.nrow) continue;  // wave-uniform
         const int nr = min(RW, a.nrow - r0);
         int kb = 0, ke = 0;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_lstream(CsrArgs a)
             const int t = tile_of(a, v);
             v += G;
             if (t >= a.ntiles) continue;
-            const int rr = t * BLOCK + wave * 64;
+            const int rr = (t + a.tile0) * BLOCK + wave * 64;
             if (rr >= a.nrow) continue;
             r0 = rr; nr = min(64, a.nrow - rr);
             return;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
             const int t = tile_of(a, v);
             v += G;
             if (t >= a.ntiles) continue;
-            const int rr = t * BLOCK + wave * 64;
+            const int rr = (t + a.tile0) * BLOCK + wave * 64;
             if (rr >= a.nrow) continue;
             r0 = rr; nr = min(64, a.nrow - rr);
             return;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat2(CsrArgs a)
             if (v >= vmax) return -1;
             const int t = tile_of(a, v);
             v += G;
-            if (t < a.ntiles) return t * (2 * BLOCK);
+            if (t < a.ntiles) return (t + a.tile0) * (2 * BLOCK);
         }
     };
     int v = blockIdx.x;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat3(CsrArgs a)
             if (v >= vmax) return -1;
             const int t = tile_of(a, v);
             v += G;
-            if (t < a.ntiles) return t * (2 * BLOCK);
+            if (t < a.ntiles) return (t + a.tile0) * (2 * BLOCK);
         }
     };
     auto ld_pp = [&](int r0) -> unsigned { return pat2[min((max(r0, 0) >> 1) + (int)threadIdx.x, npair - 1)]; };
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
             if (v >= vmax) return -1;
             const int t = tile_of(a, v);
             v += G;
-            if (t < a.ntiles) return t * (2 * BLOCK);
+            if (t < a.ntiles) return (t + a.tile0) * (2 * BLOCK);
         }
     };
     auto ld_pp = [&](int r0) -> unsigned { return pat2[min((max(r0, 0) >> 1) + (int)threadIdx.x, npair - 1)]; };
@@ -846,6 +846,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
     // rows outside their wave's pattern: lane = row, own list, 8 gathers in flight
     for (int i = blockIdx.x * BLOCK + (int)threadIdx.x; i < a.nxrows; i += G * BLOCK) {
         const int      r = a.xrows[i];
+        if (r < a.row_lo || r >= a.nrow) continue;   // (windowed launch)
         const unsigned pid = a.pat[r];
         const int      ps = a.pstart[pid], len = a.plen[pid];
         const unsigned base = (unsigned)r * 8u;
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
             if (v >= vmax) return -1;
             const int t = tile_of(a, v);
             v += G;
-            if (t < a.ntiles) return t * (2 * BLOCK);
+            if (t < a.ntiles) return (t + a.tile0) * (2 * BLOCK);
         }
     };
     auto pair_of = [&](int r0) -> int { return min((max(r0, 0) >> 1) + (int)threadIdx.x, npair - 1); };
@@ -1017,6 +1018,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
     // rows outside their wave's pattern pair: lane = row, own list, 8 gathers in flight
     for (int i = blockIdx.x * BLOCK + (int)threadIdx.x; i < a.nxrows; i += G * BLOCK) {
         const int      r = a.xrows[i];
+        if (r < a.row_lo || r >= a.nrow) continue;   // (windowed launch)
         const unsigned pid = a.pat[r];
         const int      ps = a.pstart[pid], len = a.plen[pid];
         const unsigned base = (unsigned)a.rowbase[r] * 8u;

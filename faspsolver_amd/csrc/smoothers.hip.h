@@ -260,11 +260,12 @@ static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order
                 D.x_zero = false;
                 continue;
             }
-            if (halo_exchange(D, D.x) < 0) return ERROR_MISC;
             CsrArgs a{};
             a.x = D.x; a.y = D.xo; a.b = D.b; a.omega = relax;
-            if (smoother == SMOOTHER_JACOBI) { a.diag = D.diag; launch_csr<OP_JACOBI>(D.A, a); }
-            else { a.diag = D.l1; launch_csr<OP_L1DIAG>(D.A, a); }
+            int st;   // (row-partitioned level: the halo of x travels beside the interior rows)
+            if (smoother == SMOOTHER_JACOBI) { a.diag = D.diag; st = dist_launch<OP_JACOBI>(D, D.A, a); }
+            else { a.diag = D.l1; st = dist_launch<OP_L1DIAG>(D, D.A, a); }
+            if (st < 0) return ERROR_MISC;
             std::swap(D.x, D.xo);
         }
         return FASP_SUCCESS;

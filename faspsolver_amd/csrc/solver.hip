@@ -62,6 +62,8 @@ struct Ctx {
     bool        ready  = false;
     int         device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;   // halo exchanges that overlap the interior rows (hierarchy.hip.h, dist_launch)
+    hipEvent_t  ev_ready = nullptr, ev_halo = nullptr;
     double*     d_partials = nullptr;  // 8 quantities x MAXGRID
     double*     d_partials2 = nullptr; // second set (consumer kernels that read the first)
     double*     h_part     = nullptr;  // pinned mirror of d_partials2
@@ -107,6 +109,9 @@ static int ctx_init()
     g_ctx.num_cu = prop.multiProcessorCount;
     g_ctx.device = dev;
     HIPCK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    HIPCK(hipStreamCreateWithFlags(&g_ctx.comm_stream, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&g_ctx.ev_ready, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&g_ctx.ev_halo, hipEventDisableTiming));
     HIPCK(hipMalloc(&g_ctx.d_partials, sizeof(double) * 8 * MAXGRID));
     HIPCK(hipMalloc(&g_ctx.d_partials2, sizeof(double) * (8 * MAXGRID + 8)));
     HIPCK(hipHostMalloc(&g_ctx.h_part, sizeof(double) * (8 * MAXGRID + 8), hipHostMallocDefault));
@@ -1840,6 +1845,8 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
     else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;
     else if (!std::strcmp(key, "device_sort")) g_device_sort = value;
+    else if (!std::strcmp(key, "halo_overlap")) g_halo_overlap = value;
+    else if (!std::strcmp(key, "split_rows")) g_tune.split_rows = value;
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;

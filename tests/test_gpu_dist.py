@@ -116,7 +116,7 @@ def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_typ
 
 
 @pytest.mark.parametrize("world,n,min_rows,cycle,shared", [(2, 24, 500, 1, False), (3, 24, 2000, 1, False), (2, 20, 300, 2, False),
-                                                           (4, 32, 3000, 1, False), (3, 24, 2000, 1, True)])
+                                                           (4, 32, 3000, 1, False), (3, 24, 2000, 1, True), (2, 48, 3000, 1, True)])
 def test_distributed_solve_matches_oracle(gpu, world, n, min_rows, cycle, shared):
     _run_ranks(world, n, min_rows, cycle, shared)
 

@@ -164,3 +164,34 @@ def test_device_row_sort_equals_host_row_sort(gpu):
     finally:
         L.fasp_hip_tune(b"device_sort", 1)
     assert np.array_equal(out[0], out[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var", [False, True])
+def test_row_window_launches_are_bit_identical(gpu, var):
+    """A row-partitioned level runs every operator as three launches of the same kernel -- interior rows while the
+    halo is in flight, then the two boundary windows (hierarchy.hip.h, dist_launch).  fasp_hip_tune("split_rows", k)
+    issues every operator of a single-GPU hierarchy that way: each row is computed exactly as in the single launch, so
+    one V-cycle agrees bit for bit (coded kernels, their exception lists, the plain stream kernels, the sub-wavefront
+    kernel), and a PCG solve -- whose fused (t, p) partials are now cut differently -- agrees to rounding."""
+    n = 96
+    if var:
+        ia, ja, a, f = fa.poisson7pt_var(n)
+    else:
+        ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _params()
+    H = fa.AMG(ia, ja, a, amgp)
+    L = fa.lib()
+    r = np.random.default_rng(7).standard_normal(len(f))
+    try:
+        base = H.precond(r)
+        st0, x0, h0, s0 = H.solve(f, itp)
+        for k in (1024, 5000, 300000):
+            L.fasp_hip_tune(b"split_rows", k)
+            assert np.array_equal(H.precond(r), base), k
+        st1, x1, h1, s1 = H.solve(f, itp)
+    finally:
+        L.fasp_hip_tune(b"split_rows", 0)
+    assert st1 == st0 and abs(s1.relres - s0.relres) <= 1e-6 * s0.relres   # (rounding of the re-cut dot partials, carried through the iteration)
+    assert np.abs(x1 - x0).max() <= 1e-10 * np.abs(x0).max()
+    H.close()
