@@ -542,12 +542,36 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
         D.sorted = true;
         return upload_ja16(D, sj.data());
     }
+#ifdef FASP_LAB_DEBUG
+    if (std::getenv("FASP_HIP_EXPT_CHUNKSORT") && D.kind == 2) {   // timing experiment only: results are WRONG
+        Buf<int> sj((size_t)H.nnz); Buf<double> sv((size_t)H.nnz);
+        const int ntile = (H.row + 63) / 64;
+#pragma omp parallel
+        {
+            std::vector<std::pair<int, double>> tmp;
+#pragma omp for schedule(dynamic, 16)
+            for (int t = 0; t < ntile; ++t) {
+                const int k0 = H.ia[t * 64], k1 = H.ia[std::min(H.row, t * 64 + 64)];
+                for (int lo = k0; lo < k1; lo += 508) {
+                    const int hi = std::min(lo + 508, k1);
+                    tmp.resize((size_t)(hi - lo));
+                    for (int k = lo; k < hi; ++k) tmp[(size_t)(k - lo)] = {H.ja[k], H.val[k]};
+                    std::sort(tmp.begin(), tmp.end());
+                    for (int k = lo; k < hi; ++k) { sj[k] = tmp[(size_t)(k - lo)].first; sv[k] = tmp[(size_t)(k - lo)].second; }
+                }
+            }
+        }
+        HIPCK(hipMemcpy(D.ja, sj.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(D.val, sv.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice));
+        return FASP_SUCCESS;
+    }
+#endif
     if (upload_plain() < 0) return ERROR_ALLOC_MEM;
     return upload_ja16(D, H.ja.data());
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 0, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -557,13 +581,17 @@ static Tuning g_tune;
 template <class K>
 static int resident_blocks_per_cu(K kernel)
 {
-    static int cached = -1;
-    if (cached < 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
-        cached = std::min(nb, 8);
-    }
-    return cached;
+    // keyed by the kernel's ADDRESS: K is only the signature, which all CsrArgs kernels share (round 1 cached one
+    // value per signature -- whatever kernel ran first decided the grid of all the others)
+    static std::vector<std::pair<const void*, int>> cache;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    for (const auto& e : cache)
+        if (e.first == key) return e.second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+    nb = std::min(nb, 8);
+    cache.emplace_back(key, nb);
+    return nb;
 }
 
 template <class K>

@@ -26,7 +26,7 @@ struct DevLevel {
     bool    has_halo() const { return !replicated && nvec > nloc; }
     // level schedules of the sequential sweeps (built on first use): kind 0 ascending,
     // 1 descending, 2 ascending C rows, 3 ascending F rows, 4 descending from row n-2
-    struct Sched { bool built = false; int* d_order = nullptr; int* d_ptr = nullptr; std::vector<int> ptr; };
+    struct Sched { bool built = false, multicolor = false; int* d_order = nullptr; int* d_ptr = nullptr; std::vector<int> ptr; };
     Sched   sched[5];
     // polynomial smoother (built on first use): 1 / first diagonal hit, the coefficients k[1..5] of
     // ItrSmootherCSRpoly.c:101-109, work vectors r, rbar, v0, v1, vnew

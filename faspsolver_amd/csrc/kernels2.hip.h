@@ -263,26 +263,25 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
     };
     i32x4_t qj[NJ];
     f64x2_t qv[NV];
-    // chunk [lo, hi) staged from the 4-aligned entry s = lo & ~3: slab index of entry k is k - s
+    // chunk [lo, hi) staged from the 4-aligned entry s = lo & ~3: slab index of entry k is k - s.  Buffer loads with
+    // the range set to the chunk (a scalar descriptor per chunk): no lane is branched around, entries at or beyond hi
+    // come back as 0 (column 0, value 0.0) without being fetched, and the whole slab is written every time.
     auto stage_load = [&](int s, int hi) {
-        const int n = hi - s;
-        const i32x4_t* pj = reinterpret_cast<const i32x4_t*>(a.ja + s);
-        const f64x2_t* pv = reinterpret_cast<const f64x2_t*>(a.val + s);
+        const int n4 = (hi - s + 3) & ~3;
+        const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(a.ja + s), 0, n4 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.val + s), 0, n4 * 8, 0x00020000);
 #pragma unroll
         for (int q = 0; q < NJ; ++q)
-            if ((lane + 64 * q) * 4 < n) qj[q] = __builtin_nontemporal_load(pj + lane + 64 * q);
+            qj[q] = __builtin_bit_cast(i32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rj, (lane + 64 * q) * 16, 0, 2));
 #pragma unroll
         for (int q = 0; q < NV; ++q)
-            if ((lane + 64 * q) * 2 < n) qv[q] = __builtin_nontemporal_load(pv + lane + 64 * q);
+            qv[q] = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(rv, (lane + 64 * q) * 16, 0, 2));
     };
-    auto stage_store = [&](int s, int hi) {
-        const int n = hi - s;
+    auto stage_store = [&]() {
 #pragma unroll
-        for (int q = 0; q < NJ; ++q)
-            if ((lane + 64 * q) * 4 < n) reinterpret_cast<i32x4_t*>(sj)[lane + 64 * q] = qj[q];
+        for (int q = 0; q < NJ; ++q) reinterpret_cast<i32x4_t*>(sj)[lane + 64 * q] = qj[q];
 #pragma unroll
-        for (int q = 0; q < NV; ++q)
-            if ((lane + 64 * q) * 2 < n) reinterpret_cast<f64x2_t*>(sv)[lane + 64 * q] = qv[q];
+        for (int q = 0; q < NV; ++q) reinterpret_cast<f64x2_t*>(sv)[lane + 64 * q] = qv[q];
     };
     // chunks of a tile: [k0, k1) cut at lo_c = k0 + c * (CAP - 4): with s = lo & ~3 every chunk fits the slab
     constexpr int STEP = CAP - 4;
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
         k0 = __builtin_amdgcn_readlane(kbA, 0); k1 = __builtin_amdgcn_readlane(keA, nrA - 1);
         lo = k0; hi = min(lo + STEP, k1);
         stage_load(lo & ~3, hi);
-        stage_store(lo & ~3, hi);
+        stage_store();
     }
     wave_order();
     while (r0A >= 0) {
@@ -310,13 +309,15 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
             // phase 1: lane = entry -- columns and values from the slab, x gathered, products back in place
             int    c[8];
             double w[8], xv[8];
+            // (every slab entry is readable; the up to three entries between hi and the end of the last 16-byte group
+            // belong to the next rows -- or, at the very end of the arrays, to nobody: their columns are not used)
+            int cs[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = lane + 64 * u;
-                const bool ok = s + e < hi;
-                c[u] = ok ? sj[e] : 0;
-                w[u] = ok ? sv[e] : 0.0;
-            }
+            for (int u = 0; u < 8; ++u) cs[u] = sj[lane + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = sv[lane + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = (s + lane + 64 * u < hi) ? cs[u] : 0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
             // look ahead: the next chunk of this tile, or the first chunk of tile B (and the row pointers of tile C)
@@ -332,34 +333,36 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
             }
             if (!last || r0B >= 0) stage_load(nlo & ~3, nhi);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = lane + 64 * u;
-                if (s + e < hi) sv[e] = w[u] * xv[u];
-            }
+            for (int u = 0; u < 8; ++u) sv[lane + 64 * u] = w[u] * xv[u];   // (beyond the chunk: 0.0 * x[0], never summed)
             wave_order();
             // phase 2: lane = row, storage order
+            // Eight products per LDS round trip (the adds stay one after the other, in storage order); the last,
+            // partial batch reads clamped slots and keeps the sum where the slot is past the row's end.
             if (lane < nrA) {
                 const int pb = max(kbA, lo), pe = min(keA, hi);
-                if (OP == OP_JACOBI) {
-                    for (int k = pb; k < pe; ++k)
-                        if (k != dk) acc -= sv[k - s];
-                } else if (OP == OP_L1DIAG) {
-                    for (int k = pb; k < pe; ++k) acc -= sv[k - s];
-                } else {
-                    for (int k = pb; k < pe; ++k) acc += sv[k - s];
+                for (int k = pb; k < pe; k += 8) {
+                    double p[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) p[u] = sv[min(k + u, pe - 1) - s];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double t = (OP == OP_JACOBI || OP == OP_L1DIAG) ? acc - p[u] : acc + p[u];
+                        const bool take = (k + u < pe) && !(OP == OP_JACOBI && k + u == dk);
+                        acc = take ? t : acc;
+                    }
                 }
             }
             wave_order();
             if (last) {
                 if (lane < nrA) row_epilogue<OP>(a, r, acc, dotacc);
-                if (r0B >= 0) stage_store(nlo & ~3, nhi);
+                if (r0B >= 0) stage_store();
                 wave_order();
                 r0A = r0B; nrA = nrB; kbA = kbB; keA = keB;
                 r0B = r0C; nrB = nrC; kbB = kbC; keB = keC;
                 k0 = nk0; k1 = nk1; lo = nlo; hi = nhi;
                 break;
             }
-            stage_store(nlo & ~3, nhi);
+            stage_store();
             wave_order();
             lo = nlo; hi = nhi;
         }
@@ -1137,6 +1140,98 @@ __global__ __launch_bounds__(BLOCK) void k_seq_sweep(SeqSweepArgs a)
         }
         __syncthreads();
         if (!s_ok) return;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_seq_block<L>: a whole sequential sweep in ONE workgroup of 1024 threads -- for the schedules whose classes
+// (dependency levels, or colours) hold a handful of rows each: the deep, dense levels, where a sweep is thousands
+// of classes of one to three rows and one launch per class costs ~4 us of launch latency for ~1 us of work.  Here a
+// class costs one workgroup barrier plus ONE memory round trip: the rows of the next class, their row pointers and
+// their first 4 L entries are fetched (they do not depend on u) before the barrier that ends the current class, so
+// after it only the gathers of u remain.  u travels through the L2 (agent-scope relaxed atomics: a wave must see what
+// a wave of another SIMD stored in the class before).  Arithmetic per row exactly as k_seq_level: lane-strided partial
+// sums in k order, sub-wavefront tree, the same three update forms -- the two kernels are interchangeable bit for bit.
+// ---------------------------------------------------------------------------
+constexpr int SEQ_BLOCK = 1024;
+template <int L>
+__global__ __launch_bounds__(SEQ_BLOCK) void k_seq_block(SeqSweepArgs a)
+{
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    constexpr int RPB = SEQ_BLOCK / L, PF = 4;
+    const int sl = threadIdx.x & (L - 1);
+    const int rloc = threadIdx.x / L;
+    auto ld_u = [&](int c) -> double {
+        return __longlong_as_double((long long)__hip_atomic_load((gu64*)(a.u + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    auto finish = [&](int r, double s) {
+        s = subwave_sum<L>(s);
+        if (sl == 0) {
+            const double d = a.diag[r];
+            const double t = a.b[r] - s;
+            if (fabs(d) > 1e-20) {
+                double un;
+                if (a.form == 0) un = t * (1.0 / d);
+                else if (a.form == 1) un = t / d;
+                else un = a.w * (t / d) + (1 - a.w) * ld_u(r);
+                __hip_atomic_store((gu64*)(a.u + r), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    int    rn = -1, kbn = 0, ken = 0, cn[PF];
+    double vn[PF];
+    auto prefetch = [&](int lo, int hi) {
+        rn = -1;
+        const int idx = lo + rloc;
+        if (idx < hi) {
+            rn = a.order[idx];
+            kbn = a.ia[rn]; ken = a.ia[rn + 1];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int k = kbn + sl + q * L;
+                const bool ok = k < ken;
+                cn[q] = ok ? a.ja[k] : rn;       // (a masked slot looks like the diagonal: skipped below)
+                vn[q] = ok ? a.val[k] : 0.0;
+            }
+        }
+    };
+    int lo = a.lptr[0], hi = a.lptr[1];
+    prefetch(lo, hi);
+    for (int l = 0; l < a.nlev; ++l) {
+        const int r = rn, ke = ken, k1 = kbn + sl + PF * L;
+        int    c[PF];
+        double v[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) { c[q] = cn[q]; v[q] = vn[q]; }
+        int nlo = hi, nhi = hi;
+        if (l + 1 < a.nlev) { nhi = a.lptr[l + 2]; prefetch(nlo, nhi); }
+        if (r >= 0) {
+            double s = 0.0, uq[PF];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) uq[q] = ld_u(c[q]);
+#pragma unroll
+            for (int q = 0; q < PF; ++q)
+                if (c[q] != r) s += v[q] * uq[q];
+            for (int k = k1; k < ke; k += L) {
+                const int cc = a.ja[k];
+                if (cc != r) s += a.val[k] * ld_u(cc);
+            }
+            finish(r, s);
+        }
+        for (int idx = lo + RPB + rloc; idx < hi; idx += RPB) {   // classes wider than one round
+            const int rr = a.order[idx];
+            const int kb = a.ia[rr], kend = a.ia[rr + 1];
+            double s = 0.0;
+            for (int k = kb + sl; k < kend; k += L) {
+                const int cc = a.ja[k];
+                if (cc != rr) s += a.val[k] * ld_u(cc);
+            }
+            finish(rr, s);
+        }
+        lo = nlo; hi = nhi;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 }
 

@@ -16,7 +16,13 @@ static void materialise_zero(DevLevel& D)
 // Level schedule of one sequential sweep over the rows `seq` (in sweep order) of the host
 // matrix A: level(i) = 1 + max level of the rows coupled to i (pattern of A and of A^T) that
 // come earlier in the sweep.  Rows outside the sweep are not updated and impose nothing.
-static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLevel::Sched& S)
+//
+// multicolor == true (fasp_hip_tune("gs_multicolor", 1); NOT the reference's iteration, see seq_sweep): the "levels"
+// are the colour classes of a greedy colouring of the swept rows (ascending row order, smallest colour no coupled row
+// has), visited in ascending colour order by an ascending sweep and in descending colour order by a descending one.
+// Rows of one colour are not coupled, so a class is one launch whatever its size: 2 launches per sweep on the 7-point
+// level 0 instead of 3n - 2 dependency levels.
+static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLevel::Sched& S, bool multicolor = false)
 {
     const int n = A.row;
     std::vector<int> pos(n, -1), lev(n, 0);
@@ -29,7 +35,23 @@ static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLeve
         for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
             if (A.ja[k] < n) tja[tia[A.ja[k] + 1]++] = i;
     int nlev = 0;
-    for (int q = 0; q < (int)seq.size(); ++q) {
+    if (multicolor) {
+        std::vector<int> rows(seq);
+        std::sort(rows.begin(), rows.end());
+        std::vector<int> color(n, -1), mark(rows.size() + 2, -1);
+        for (int i : rows) {
+            auto see = [&](int j) { if (j != i && j < n && color[j] >= 0) mark[color[j]] = i; };
+            for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) see(A.ja[k]);
+            for (int k = tia[i]; k < tia[i + 1]; ++k) see(tja[k]);
+            int c = 0;
+            while (mark[c] == i) ++c;
+            color[i] = c;
+            nlev = std::max(nlev, c + 1);
+        }
+        const bool descending = seq.size() > 1 && seq.front() > seq.back();
+        for (int i : rows) lev[i] = descending ? nlev - color[i] : color[i] + 1;
+    }
+    for (int q = 0; !multicolor && q < (int)seq.size(); ++q) {
         const int i = seq[q];
         int l = 0;
         for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
@@ -48,9 +70,12 @@ static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLeve
     for (int l = 0; l < nlev; ++l) S.ptr[l + 1] += S.ptr[l];
     std::vector<int> cur(S.ptr.begin(), S.ptr.end() - 1), order(seq.size());
     for (int i : seq) order[cur[lev[i] - 1]++] = i;
+    if (S.d_order) { (void)hipFree(S.d_order); S.d_order = nullptr; }
+    if (S.d_ptr) { (void)hipFree(S.d_ptr); S.d_ptr = nullptr; }
     HIPCK(hipMalloc(&S.d_order, sizeof(int) * std::max<size_t>(order.size(), 1)));
     if (!order.empty()) HIPCK(hipMemcpy(S.d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
     S.built = true;
+    S.multicolor = multicolor;
     return FASP_SUCCESS;
 }
 
@@ -75,7 +100,12 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
 {
     DevLevel& D = h->L[level];
     DevLevel::Sched& S = D.sched[kind];
-    if (!S.built) {
+    // Multicolour mode -- a FLAGGED NON-PARITY mode for speed: the sweep visits the rows colour by colour instead of
+    // in the reference's index order, which is a different (equally convergent, deterministic) Gauss-Seidel / SOR
+    // iteration; iteration counts and residuals then differ from the reference's.  The default is the level-scheduled
+    // sweep, which reproduces the reference's sequential sweep exactly.
+    const bool multicolor = g_tune.gs_multicolor != 0;
+    if (!S.built || S.multicolor != multicolor) {
         const HostCSR& A = h->H.L[level].A;
         const int n = A.row;
         std::vector<int> seq;
@@ -88,7 +118,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
             case 3: for (int i = 0; i < n; ++i) if (!cf || cf[i] != 1) seq.push_back(i); break;
             default: for (int i = n - 2; i >= 0; --i) seq.push_back(i); break;
         }
-        const int st = build_schedule(A, seq, S);
+        const int st = build_schedule(A, seq, S, multicolor);
         if (st < 0) return st;
     }
     materialise_zero(D);
@@ -100,6 +130,28 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     // costs (~3 us: drained write-through stores + arrival + poll), and the time of a sweep is the DEPTH of the
     // dependency DAG on the dense coarse levels (thousands of levels of one to three rows), not the launch count.
     // Needs every block resident at once, so never when validation ranks share the device.
+    // Schedules of many small classes (the deep, dense levels -- in either mode): the whole sweep in one workgroup
+    // (k_seq_block, kernels2.hip.h), a barrier and one memory round trip per class instead of a launch.
+    if (g_tune.seq_block && nlev >= 8 && (long long)S.ptr[nlev] <= (long long)nlev * (2 * SEQ_BLOCK / L)) {
+        if (!S.d_ptr) {
+            HIPCK(hipMalloc(&S.d_ptr, sizeof(int) * (size_t)(nlev + 1)));
+            HIPCK(hipMemcpy(S.d_ptr, S.ptr.data(), sizeof(int) * (size_t)(nlev + 1), hipMemcpyHostToDevice));
+        }
+        SeqSweepArgs sa{};
+        sa.order = S.d_order; sa.lptr = S.d_ptr; sa.nlev = nlev; sa.ia = D.A.ia; sa.ja = D.A.ja; sa.val = D.A.val;
+        sa.b = D.b; sa.diag = D.diag; sa.u = D.x; sa.form = form; sa.w = w; sa.sync = nullptr;
+#define SEQB_LAUNCH(LL) hipLaunchKernelGGL((k_seq_block<LL>), dim3(1), dim3(SEQ_BLOCK), 0, g_ctx.stream, sa)
+        switch (L) {
+            case 2: SEQB_LAUNCH(2); break;
+            case 4: SEQB_LAUNCH(4); break;
+            case 8: SEQB_LAUNCH(8); break;
+            case 16: SEQB_LAUNCH(16); break;
+            case 32: SEQB_LAUNCH(32); break;
+            default: SEQB_LAUNCH(64); break;
+        }
+#undef SEQB_LAUNCH
+        return FASP_SUCCESS;
+    }
     static bool seq_persist_disabled = false;
     if (g_tune.seq_persist && !seq_persist_disabled && !comm_shares_devices() && nlev >= 4) {
         if (!S.d_ptr) {

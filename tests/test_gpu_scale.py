@@ -195,3 +195,63 @@ def test_row_window_launches_are_bit_identical(gpu, var):
     assert st1 == st0 and abs(s1.relres - s0.relres) <= 1e-6 * s0.relres   # (rounding of the re-cut dot partials, carried through the iteration)
     assert np.abs(x1 - x0).max() <= 1e-10 * np.abs(x0).max()
     H.close()
+
+
+def _gs_params(smoother, order, w=1.0):
+    itp = fa.param_solver_init(); itp.tol = 1e-8
+    amgp = fa.param_amg_init()
+    amgp.smoother = smoother; amgp.smooth_order = order; amgp.relaxation = w
+    return itp, amgp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("smoother,order,w", [(T.SMOOTHER_GS, 1, 1.0), (T.SMOOTHER_GS, 0, 1.0), (T.SMOOTHER_SOR, 0, 1.1)],
+                         ids=["GS-CF", "GS-natural", "SOR-natural"])
+def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
+    """The level-scheduled sweep (the reference's sequential Gauss-Seidel / SOR sweep, dependency level by dependency
+    level) runs the deep, dense levels in one workgroup (k_seq_block: a barrier per dependency level) and the others as
+    one launch per level (k_seq_level).  Same schedule, same row arithmetic: identical bits."""
+    n = 40
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _gs_params(smoother, order, w)
+    H = fa.AMG(ia, ja, a, amgp)
+    L = fa.lib()
+    r = np.random.default_rng(11).standard_normal(len(f))
+    try:
+        out = []
+        for sb in (1, 0):
+            L.fasp_hip_tune(b"seq_block", sb)
+            out.append(H.precond(r))
+    finally:
+        L.fasp_hip_tune(b"seq_block", 1)
+    assert np.array_equal(out[0], out[1])
+    H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("smoother,order,w", [(T.SMOOTHER_GS, 1, 1.0), (T.SMOOTHER_SOR, 0, 1.1)], ids=["GS-CF", "SOR-natural"])
+def test_multicolour_sweep_mode_converges_and_is_deterministic(gpu, smoother, order, w):
+    """fasp_hip_tune("gs_multicolor", 1) -- the FLAGGED NON-PARITY mode: rows are relaxed colour by colour (greedy
+    colouring) instead of in index order.  A different Gauss-Seidel / SOR iteration: it must converge to the same
+    solution in about as many PCG iterations as the reference's sweep (not in exactly as many), reproducibly, and
+    the default mode must be untouched by having used it."""
+    n = 48
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _gs_params(smoother, order, w)
+    H = fa.AMG(ia, ja, a, amgp)
+    L = fa.lib()
+    try:
+        st0, x0, h0, s0 = H.solve(f, itp)
+        L.fasp_hip_tune(b"gs_multicolor", 1)
+        st1, x1, h1, s1 = H.solve(f, itp)
+        st2, x2, h2, s2 = H.solve(f, itp)
+        L.fasp_hip_tune(b"gs_multicolor", 0)
+        st3, x3, h3, s3 = H.solve(f, itp)
+    finally:
+        L.fasp_hip_tune(b"gs_multicolor", 0)
+    assert st0 > 0 and st1 > 0 and abs(st1 - st0) <= 3
+    assert s1.relres <= 1e-8
+    assert np.abs(x1 - x0).max() <= 1e-6 * np.abs(x0).max()      # same solution, to the solver tolerance
+    assert st2 == st1 and np.array_equal(x1, x2)                 # reproducible
+    assert st3 == st0 and np.array_equal(x3, x0)                 # parity mode unchanged afterwards
+    H.close()
