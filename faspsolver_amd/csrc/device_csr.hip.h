@@ -67,7 +67,11 @@ static void pick_kernel(DevCSR& M)
     const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
     static const double stream_max = std::getenv("FASP_HIP_STREAM_MAX") ? std::atof(std::getenv("FASP_HIP_STREAM_MAX")) : 48.0;
     M.kind = avg <= stream_max ? 2 : 0;  // (kind 3, one workgroup per row, measured slower than L = 64: profiles/)
-    M.lanes = avg < 128.0 ? 16 : avg < 300.0 ? 32 : 64;
+    // lanes per row of the sub-wavefront kernel, measured on the levels of P7(256) (profiles/r02_lanes_per_row.txt):
+    // 16 lanes up to ~300 entries per row, 32 up to ~1000, 64 beyond -- and never so few that rows x lanes leaves
+    // the 2048 x 256 threads of the persistent grid unfilled (the last levels: few, very long rows)
+    M.lanes = avg < 300.0 ? 16 : avg < 1000.0 ? 32 : 64;
+    while (M.lanes < 64 && (double)M.row * M.lanes < 0.75 * MAXGRID * BLOCK) M.lanes *= 2;
     if (avg < 48.0) M.lanes = avg < 3.0 ? 2 : avg < 6.0 ? 4 : avg < 24.0 ? 8 : 16;  // short rows on the sub-wavefront kernel
     // Small transfer operators (fewer 256-row tiles than the chip has block slots): the stream kernel's
     // long per-tile chain is pure latency there; the sub-wavefront kernel spreads the rows over 8-32x
