@@ -399,10 +399,14 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
     DevLevel& D0 = h->L[0];
     D0.b = r;
     D0.x_zero = true;
+    const bool ask_zr = h->want_zr && u.cycle_type != AMLI_CYCLE && u.cycle_type != NL_AMLI_CYCLE;   // (set by the PCG operator bundle for this apply only; V / W cycles end with the level-0 sweep)
+    h->zr_G = 0;
     for (int i = u.maxit; i--;) {
+        h->want_zr = ask_zr && i == 0 && !h->use_fmg;   // the last sweep of the last cycle leaves the (z, r) partials
         const int st = h->use_fmg ? fmg_cycle(h, p) : mgcycle(h, p);  // fasp_precond_famg (PreCSR.c:560) / fasp_precond_amg
-        if (st < 0) return st;
+        if (st < 0) { h->want_zr = false; return st; }
     }
+    h->want_zr = false;
     materialise_zero(D0);
     *z = D0.x;
     return FASP_SUCCESS;
@@ -485,7 +489,18 @@ static KOps csr_ops(fasp_hip_amg* h, int level, bool with_pc)
         if (G < 0) comm_mark_failed();
         return std::max(G, 8);
     };
-    if (with_pc) K.pc = [h](double* in, double** out) { return precond_amg(h, in, out); };
+    if (with_pc) {
+        K.pc = [h](double* in, double** out) { return precond_amg(h, in, out); };
+        // PCG: the same apply, asking for the partials of (z, r); returns their number (0: take the dot product yourself)
+        K.pc_zr = [h](double* in, double** out, int* G) {
+            h->want_zr = true;
+            const int st = precond_amg(h, in, out);
+            h->want_zr = false;
+            *G = st < 0 ? 0 : h->zr_G;
+            h->zr_G = 0;
+            return st;
+        };
+    }
     const int set = level == 0 ? 0 : 1;
     K.ws = &h->gm[set]; K.ws_len = &h->gm_len[set]; K.hh = &h->gm_hh;
     K.stats = h;

@@ -575,7 +575,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1, fuse_zr = 1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -624,6 +624,9 @@ static int launch_rowpat5(CsrArgs& a)
 // per-block partials written from slot goff on.  hi < 0: the whole operator.
 constexpr int WIN_ALIGN = 1024;
 struct RowWin { int lo = 0, hi = -1, goff = 0; };
+// OP_JACOBI with a.partials set asks for the partials of (x_new, b) on the way out (the (z, r) of PCG from the last
+// sweep of level 0).  Only the kernels of the fast paths do it; a launch that did sets this flag.
+static bool g_jacobi_dot_done = false;
 
 template <int OP>
 static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
@@ -668,6 +671,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         a.xrows = M.xrows; a.nxrows = M.nxrows;
         set_tiles(2 * BLOCK);
         a.xcd_map = a.ntiles >= 8 * 64 ? -1 : 16;  // slabs: x is fetched once per XCD (PMC: 0.18 GB instead of 0.45 GB per level-0 pass)
+        if (OP == OP_JACOBI && a.partials) g_jacobi_dot_done = true;
         return launch_persistent(k_csr_rowpat4<OP>, a.ntiles, a, 5);
     }
     // (measured on P7(256) level 0: prolongation, 1-6 entries per row, 140 -> 131 us; restriction, 7-13 entries per row,
@@ -712,10 +716,14 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
     }
     if (M.kind == 2 && g_tune.gen2 && M.wrows == 64 && M.wcap == 512 && (double)M.nnz <= 7.6 * M.row) {
         // short rows (64 rows fit the 512-entry slab with room for ragged tiles): 16-byte staged stream, lane = row
+        if (OP == OP_JACOBI && a.partials) g_jacobi_dot_done = true;
         return launch_persistent(k_csr_lstream<OP, 512>, a.ntiles, a, 4);
     }
     if (M.kind == 2 && g_tune.gen2 >= 2 && M.wrows == 64 && M.wcap == 512 && (OP != OP_JACOBI || (M.dpos && !M.dup_diag)))
+    {
+        if (OP == OP_JACOBI && a.partials) g_jacobi_dot_done = true;
         return launch_persistent(k_csr_wstream2<OP>, a.ntiles, a, g_tune.ws2_bpc);   // rows of any length: staged, prefetched stream
+    }
     if (M.kind == 2) {
         if (M.wrows == 64 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 64, 512>, a.ntiles, a);
         if (M.wrows == 64) return launch_persistent(k_csr_wstream<OP, 64, 1024>, a.ntiles, a);

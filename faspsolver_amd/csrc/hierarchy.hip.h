@@ -49,6 +49,10 @@ struct fasp_hip_amg {
     bool                  distributed = false;  // level 0 is row-partitioned over the ranks
     std::vector<DevLevel> L;
     AMG_param             param;  // copy of the user's parameters after setup
+    // PCG asks the preconditioner for the partials of (z, r) (fused into the last Jacobi sweep of level 0): want_zr is
+    // set around the last cycle of an apply, zr_G = number of partials waiting in g_ctx.d_partials (0: not produced)
+    bool                  want_zr = false;
+    int                   zr_G = 0;
     // Krylov work vectors on level 0
     double *b = nullptr, *u = nullptr, *p = nullptr, *t = nullptr, *r = nullptr;
     // coarse-level SPCG work vectors

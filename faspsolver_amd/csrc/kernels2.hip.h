@@ -46,7 +46,9 @@ __device__ __forceinline__ void row_epilogue(const CsrArgs& a, int r, double s, 
     else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
     else if (OP == OP_JACOBI) {
         const double d = a.diag[r], xi = a.x[r];
-        a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * s / d : xi;
+        const double xn = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * s / d : xi;
+        a.y[r] = xn;
+        if (a.partials) dotacc += xn * a.b[r];   // last sweep of level 0 under PCG: (z, r) on the way out
     } else if (OP == OP_L1DIAG) {
         const double d = a.diag[r], xi = a.x[r];
         a.y[r] = l1_or_jacobi_f(a, r, s, d, xi);
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_lstream(CsrArgs a)
         r0A = r0B; nrA = nrB; kbA = kbB; keA = keB; s0A = s0B; k1A = k1B;
         r0B = r0C; nrB = nrC; kbB = kbC; keB = keC;
     }
-    if (OP == OP_MXV_DOT) {
+    if (OP == OP_MXV_DOT || (OP == OP_JACOBI && a.partials)) {
         const double tot = block_sum(dotacc, red);
         if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
     }
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
             lo = nlo; hi = nhi;
         }
     }
-    if (OP == OP_MXV_DOT) {
+    if (OP == OP_MXV_DOT || (OP == OP_JACOBI && a.partials)) {
         const double tot = block_sum(dotacc, red);
         if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
     }
@@ -832,6 +834,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
             }
             out.x = (fabs(dg) > 1e-20) ? (1 - a.omega) * xiA + a.omega * accA / dg : xiA;
             out.y = (fabs(dg) > 1e-20) ? (1 - a.omega) * xiB + a.omega * accB / dg : xiB;
+            if (a.partials && mine) { dotacc += out.x * bb.x; dotacc += out.y * bb.y; }   // (z, r) of the last level-0 sweep
         } else if (OP == OP_L1DIAG) {
             const f64x2_t xi = *reinterpret_cast<const f64x2_t*>(a.x + rs);
             out.x = l1_or_jacobi_f(a, rs, accA, aux.x, xi.x);
@@ -877,14 +880,16 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
         }
         if (OP == OP_JACOBI) {
             if (!hasd) xi = a.x[r];
-            a.y[r] = (fabs(dgr) > 1e-20) ? (1 - a.omega) * xi + a.omega * acc / dgr : xi;
+            const double xn = (fabs(dgr) > 1e-20) ? (1 - a.omega) * xi + a.omega * acc / dgr : xi;
+            a.y[r] = xn;
+            if (a.partials) dotacc += xn * a.b[r];
         } else if (OP == OP_L1DIAG) {
             a.y[r] = l1_or_jacobi_f(a, r, acc, a.diag[r], a.x[r]);
         } else {
             row_epilogue<OP>(a, r, acc, dotacc);
         }
     }
-    if (OP == OP_MXV_DOT) {
+    if (OP == OP_MXV_DOT || (OP == OP_JACOBI && a.partials)) {
         const double tot = block_sum(dotacc, red);
         if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
     }

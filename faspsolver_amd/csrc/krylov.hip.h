@@ -25,6 +25,7 @@ struct KOps {
     std::function<void(const double*, const double*, double*)> resid;      // r = b - A x
     std::function<int(const double*, double*)> mxv_dot;                    // y = A x + partials of (y,x); returns #partials, < 0: unavailable
     std::function<int(double*, double**)> pc;                              // *out = B in (empty: identity)
+    std::function<int(double*, double**, int*)> pc_zr;                     // pc + partials of (out, in) in g_ctx.d_partials (count in *G, 0: none)
     std::vector<double*>* ws = nullptr;                                    // GMRES workspace
     size_t* ws_len = nullptr;
     double** hh = nullptr;

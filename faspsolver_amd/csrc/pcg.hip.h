@@ -190,9 +190,15 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
         }
 
         absres0 = absres;
-        if (StopType != STOP_REL_PRECRES)
-            if ((st = apply_pc()) < 0) return st;
-        if (d_dot(m, z, r, red, dist) < 0) return ERROR_MISC;
+        int zr_G = 0;   // partials of (z, r) left behind by the preconditioner's last sweep (0: none)
+        if (StopType != STOP_REL_PRECRES) {
+            if (K.pc_zr) { if ((st = K.pc_zr(r, &z, &zr_G)) < 0) return st; }
+            else if ((st = apply_pc()) < 0) return st;
+        }
+        if (zr_G > 0) {
+            d_finalize(zr_G, 1, 0u, 0, dist);
+            if (fetch_red(0, 1, red) < 0) return ERROR_MISC;
+        } else if (d_dot(m, z, r, red, dist) < 0) return ERROR_MISC;
         temp2 = red[0];
         beta  = temp2 / temp1;
         temp1 = temp2;

@@ -315,7 +315,12 @@ static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order
             CsrArgs a{};
             a.x = D.x; a.y = D.xo; a.b = D.b; a.omega = relax;
             int st;   // (row-partitioned level: the halo of x travels beside the interior rows)
-            if (smoother == SMOOTHER_JACOBI) { a.diag = D.diag; st = dist_launch<OP_JACOBI>(D, D.A, a); }
+            const bool ask_zr = smoother == SMOOTHER_JACOBI && post && level == 0 && s == nsweeps - 1 && h->want_zr && g_tune.fuse_zr;
+            if (ask_zr) { a.partials = g_ctx.d_partials; g_jacobi_dot_done = false; }
+            if (smoother == SMOOTHER_JACOBI) {
+                a.diag = D.diag; st = dist_launch<OP_JACOBI>(D, D.A, a);
+                if (ask_zr && g_jacobi_dot_done && st > 0) h->zr_G = st;
+            }
             else { a.diag = D.l1; st = dist_launch<OP_L1DIAG>(D, D.A, a); }
             if (st < 0) return ERROR_MISC;
             std::swap(D.x, D.xo);

@@ -255,3 +255,31 @@ def test_multicolour_sweep_mode_converges_and_is_deterministic(gpu, smoother, or
     assert st2 == st1 and np.array_equal(x1, x2)                 # reproducible
     assert st3 == st0 and np.array_equal(x3, x0)                 # parity mode unchanged afterwards
     H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var", [False, True])
+def test_fused_zr_product_matches_separate_dot(gpu, var):
+    """PCG takes (z, r) from the partial sums the last Jacobi sweep of level 0 leaves behind (x_new . b, row by row as
+    the sweep writes x_new) instead of a separate pass over z and r.  Same products, another grouping of the partial
+    sums: iteration counts equal, residuals equal to rounding.  fasp_hip_tune("fuse_zr", 0) is the separate pass."""
+    n = 64
+    if var:
+        ia, ja, a, f = fa.poisson7pt_var(n)
+    else:
+        ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _params()
+    H = fa.AMG(ia, ja, a, amgp)
+    L = fa.lib()
+    try:
+        out = []
+        for fz in (1, 0):
+            L.fasp_hip_tune(b"fuse_zr", fz)
+            out.append(H.solve(f, itp))
+    finally:
+        L.fasp_hip_tune(b"fuse_zr", 1)
+    (st1, x1, h1, s1), (st0, x0, h0, s0) = out
+    assert st1 == st0 and len(h1) == len(h0)
+    assert np.allclose(h1, h0, rtol=1e-9, atol=1e-13 * h0[0])
+    assert np.abs(x1 - x0).max() <= 1e-11 * np.abs(x0).max()
+    H.close()
