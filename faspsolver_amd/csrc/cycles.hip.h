@@ -325,9 +325,17 @@ ForwardSweep:
             CsrArgs a{}; a.x = D.x; a.y = D.w; a.b = D.b;
             if (dist_launch<OP_RESID>(D, D.A, a) < 0) return ERROR_MISC;   // halo of x beside the interior rows
         }
+        bool fused_presmooth = false;
         {
             DevLevel& C = h->L[l + 1];
             CsrArgs ra{}; ra.x = D.w;
+            // the restriction also writes the first pre-smoothing sweep of the next level (Jacobi from a zero guess:
+            // x = (w b) / d, k_jacobi_zero's expression) when that level is smoothed and both levels are laid out alike
+            if (g_tune.fuse_presmooth && smoother == SMOOTHER_JACOBI && param.presmooth_iter >= 1 && l + 1 < nl - 1 &&
+                D.replicated == C.replicated) {
+                ra.zx = C.x; ra.zdiag = C.diag; ra.zomega = relax;
+                fused_presmooth = true;
+            }
             if (!D.replicated && C.replicated) {
                 // first replicated level: every rank restricts onto the coarse rows it owns,
                 // one all-gather assembles the whole right-hand side on every rank
@@ -345,6 +353,7 @@ ForwardSweep:
         }
         ++l;
         h->L[l].x_zero = true;  // fasp_dvec_set(x_{l}, 0): materialised lazily
+        h->L[l].presmoothed = fused_presmooth;
     }
 
     if ((st0 = coarse_solve(h, param, tol)) < 0) return st0;
@@ -399,6 +408,8 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
     DevLevel& D0 = h->L[0];
     D0.b = r;
     D0.x_zero = true;
+    D0.presmoothed = h->pre_marked && !h->use_fmg;   // (the CG update wrote x = (w r) / d of this r: csr_ops, pcg.hip.h)
+    h->pre_marked = false;
     const bool ask_zr = h->want_zr && u.cycle_type != AMLI_CYCLE && u.cycle_type != NL_AMLI_CYCLE;   // (set by the PCG operator bundle for this apply only; V / W cycles end with the level-0 sweep)
     h->zr_G = 0;
     for (int i = u.maxit; i--;) {
@@ -492,6 +503,13 @@ static KOps csr_ops(fasp_hip_amg* h, int level, bool with_pc)
     if (with_pc) {
         K.pc = [h](double* in, double** out) { return precond_amg(h, in, out); };
         // PCG: the same apply, asking for the partials of (z, r); returns their number (0: take the dot product yourself)
+        const AMG_param& ap = h->param;
+        if (g_tune.fuse_presmooth && ap.smoother == SMOOTHER_JACOBI && ap.presmooth_iter >= 1 && ap.maxit >= 1 && !h->use_fmg &&
+            ap.cycle_type != AMLI_CYCLE && ap.cycle_type != NL_AMLI_CYCLE && h->L.size() > 1) {
+            K.pre_x = [Lv]() { return Lv->x; };
+            K.pre_diag = Lv->diag; K.pre_omega = ap.relaxation;
+            K.mark_presmoothed = [h]() { h->pre_marked = true; };
+        }
         K.pc_zr = [h](double* in, double** out, int* G) {
             h->want_zr = true;
             const int st = precond_amg(h, in, out);

@@ -12,6 +12,7 @@ struct DevLevel {
     double* x  = nullptr;    // current iterate: xa or xb
     double* xo = nullptr;    // the other buffer
     bool    x_zero = true;   // x is (conceptually) all zeros and not materialised
+    bool    presmoothed = false;  // x already holds the first Jacobi sweep from zero (written by the kernel that produced b)
     double* halo_pending = nullptr;  // Krylov operator bundle: vector whose halo the next operator exchanges (cycles.hip.h, csr_ops)
     bool    owns_b = true;
     // distribution (single GPU: nloc == nvec == rows, no halo)
@@ -52,6 +53,7 @@ struct fasp_hip_amg {
     // PCG asks the preconditioner for the partials of (z, r) (fused into the last Jacobi sweep of level 0): want_zr is
     // set around the last cycle of an apply, zr_G = number of partials waiting in g_ctx.d_partials (0: not produced)
     bool                  want_zr = false;
+    bool                  pre_marked = false;   // the next precond_amg finds level 0's first Jacobi sweep written (K.mark_presmoothed)
     int                   zr_G = 0;
     // Krylov work vectors on level 0
     double *b = nullptr, *u = nullptr, *p = nullptr, *t = nullptr, *r = nullptr;

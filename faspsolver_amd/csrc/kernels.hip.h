@@ -76,7 +76,21 @@ struct CsrArgs {
     // row window of a launch (distributed levels: interior rows while the halo is in flight, boundary rows after it):
     // the launch covers the tiles tile0 .. tile0 + ntiles of the kernel's own tile size, i.e. the rows [row_lo, nrow)
     int           tile0, row_lo;
+    // OP_MXV only, zx != nullptr: the result is the right-hand side of a level whose first smoothing step is a Jacobi
+    // sweep from a zero guess -- the kernel writes that sweep's result too, zx_i = (w y_i) / zdiag_i (k_jacobi_zero's
+    // expression), saving the pass that would read y again
+    double*       zx;
+    const double* zdiag;
+    double        zomega;
 };
+
+__device__ __forceinline__ void zx_store(const CsrArgs& a, int r, double s)
+{
+    if (a.zx) {
+        const double di = a.zdiag[r];
+        a.zx[r] = (fabs(di) > 1e-20) ? (1 - a.zomega) * 0.0 + a.zomega * s / di : 0.0;
+    }
+}
 
 // Epilogue of OP_L1DIAG, t = b_i - sum_j a_ij x_j accumulated from b_i entry by entry: the L1
 // smoother x_i + t / sum_j |a_ij| (ItrSmootherCSR.c:1509), or -- with a C/F marker -- Jacobi on the
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
             }
             s = subwave_sum<L>(s);
             if (sl == 0) {
-                if (OP == OP_MXV) a.y[r] = s;
+                if (OP == OP_MXV) { a.y[r] = s; zx_store(a, r, s); }
                 else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
                 else if (OP == OP_ADD) a.y[r] += s;
                 else if (OP == OP_SUB) a.y[r] -= s;
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_blockrow(CsrArgs a)
         }
         s = block_sum(s, lds);
         if (threadIdx.x == 0) {
-            if (OP == OP_MXV) a.y[r] = s;
+            if (OP == OP_MXV) { a.y[r] = s; zx_store(a, r, s); }
             else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
             else if (OP == OP_ADD) a.y[r] += s;
             else if (OP == OP_SUB) a.y[r] -= s;
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(CsrArgs a, int R)
             if (i < nr) {
                 const int    r = r0 + i;
                 const double s = acc[q];
-                if (OP == OP_MXV) a.y[r] = s;
+                if (OP == OP_MXV) { a.y[r] = s; zx_store(a, r, s); }
                 else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
                 else if (OP == OP_ADD) a.y[r] += s;
                 else if (OP == OP_SUB) a.y[r] -= s;
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_dict8(CsrArgs a)
                 }
             }
             const double s = acc;
-            if (OP == OP_MXV) a.y[r] = s;
+            if (OP == OP_MXV) { a.y[r] = s; zx_store(a, r, s); }
             else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
             else if (OP == OP_ADD) a.y[r] += s;
             else if (OP == OP_SUB) a.y[r] -= s;
@@ -686,7 +700,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat(CsrArgs a)
             if (rA[q] > last) continue;
             const int    r = rA[q];
             const double s = acc[q];
-            if (OP == OP_MXV) a.y[r] = s;
+            if (OP == OP_MXV) { a.y[r] = s; zx_store(a, r, s); }
             else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
             else if (OP == OP_ADD) a.y[r] += s;
             else if (OP == OP_SUB) a.y[r] -= s;
@@ -784,7 +798,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream(CsrArgs a)
 
         if (lane < nr) {
             const double s = acc;
-            if (OP == OP_MXV) a.y[r] = s;
+            if (OP == OP_MXV) { a.y[r] = s; zx_store(a, r, s); }
             else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
             else if (OP == OP_ADD) a.y[r] += s;
             else if (OP == OP_SUB) a.y[r] -= s;
@@ -1169,8 +1183,12 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const 
                                                       const double* __restrict__ t,
                                                       double* __restrict__ u, double* __restrict__ r,
                                                       double* __restrict__ partials, int full_norms,
-                                                      double* __restrict__ temp2_out)
+                                                      double* __restrict__ temp2_out,
+                                                      double* __restrict__ zx = nullptr,
+                                                      const double* __restrict__ zdiag = nullptr, double zomega = 0.0)
 {
+    // zx != nullptr: r is about to be the right-hand side of a preconditioner whose first step is a Jacobi sweep
+    // from zero -- written here, zx_i = (w r_i) / zdiag_i (k_jacobi_zero's expression), instead of re-reading r
     __shared__ double lds[5][4];
     __shared__ double bcast;
     double temp2;
@@ -1195,6 +1213,10 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const 
             const double ri = r[i] + (-alpha) * t[i];
             u[i] = ui;
             r[i] = ri;
+            if (zx) {
+                const double di = zdiag[i];
+                zx[i] = (fabs(di) > 1e-20) ? (1 - zomega) * 0.0 + zomega * ri / di : 0.0;
+            }
             q[0] += ri * ri;
             if (full_norms) {
                 q[1] += ui * ui;

@@ -39,7 +39,7 @@ __device__ __forceinline__ void wave_order()
 template <int OP>
 __device__ __forceinline__ void row_epilogue(const CsrArgs& a, int r, double s, double& dotacc)
 {
-    if (OP == OP_MXV) { if (a.nt & 2) __builtin_nontemporal_store(s, a.y + r); else a.y[r] = s; }
+    if (OP == OP_MXV) { if (a.nt & 2) __builtin_nontemporal_store(s, a.y + r); else a.y[r] = s; zx_store(a, r, s); }
     else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
     else if (OP == OP_ADD) a.y[r] += s;
     else if (OP == OP_SUB) a.y[r] -= s;
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
         }
         if (dlen == 0) flush();
         f64x2_t out = {0.0, 0.0};
-        if (OP == OP_MXV) { out.x = accA; out.y = accB; }
+        if (OP == OP_MXV) { out.x = accA; out.y = accB; if (mine) { zx_store(a, ra, accA); zx_store(a, ra + 1, accB); } }
         else if (OP == OP_RESID) { out.x = bb.x - accA; out.y = bb.y - accB; }
         else if (OP == OP_ADD) { out.x = aux.x + accA; out.y = aux.y + accB; }
         else if (OP == OP_SUB) { out.x = aux.x - accA; out.y = aux.y - accB; }
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
         double accA = 0.0, accB = 0.0;
         sweep_lists(psA, lenA, (unsigned)cb.x * 8u, accA, psB, lenB, (unsigned)cb.y * 8u, accB);
         f64x2_t out = {0.0, 0.0};
-        if (OP == OP_MXV) { out.x = accA; out.y = accB; }
+        if (OP == OP_MXV) { out.x = accA; out.y = accB; if (mine) { zx_store(a, ra, accA); zx_store(a, ra + 1, accB); } }
         else if (OP == OP_RESID) { out.x = aux.x - accA; out.y = aux.y - accB; }
         else if (OP == OP_ADD) { out.x = aux.x + accA; out.y = aux.y + accB; }
         else if (OP == OP_SUB) { out.x = aux.x - accA; out.y = aux.y - accB; }

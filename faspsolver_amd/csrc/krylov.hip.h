@@ -25,6 +25,12 @@ struct KOps {
     std::function<void(const double*, const double*, double*)> resid;      // r = b - A x
     std::function<int(const double*, double*)> mxv_dot;                    // y = A x + partials of (y,x); returns #partials, < 0: unavailable
     std::function<int(double*, double**)> pc;                              // *out = B in (empty: identity)
+    // PCG: the update kernel may write the preconditioner's first Jacobi sweep of r (pre_x() = where, pre_diag, pre_omega);
+    // mark_presmoothed() tells the preconditioner that its next apply finds that sweep done
+    std::function<double*()> pre_x;
+    const double* pre_diag = nullptr;
+    double pre_omega = 0.0;
+    std::function<void()> mark_presmoothed;
     std::function<int(double*, double**, int*)> pc_zr;                     // pc + partials of (out, in) in g_ctx.d_partials (count in *G, 0: none)
     std::vector<double*>* ws = nullptr;                                    // GMRES workspace
     size_t* ws_len = nullptr;

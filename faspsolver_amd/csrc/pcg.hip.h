@@ -117,8 +117,12 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
             }
         }
         // alpha = temp1/(t,p) on device; u += alpha p; r -= alpha t; partial ||r||^2
+        // (+ the preconditioner's first Jacobi sweep of the new r, when it has one: K.pre_x)
+        double* const pre_x = (K.pre_x && StopType != STOP_REL_PRECRES) ? K.pre_x() : nullptr;
         hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, (const double*)(g_ctx.d_red + 8),
-                           (const double*)nullptr, 0, p, t, u, r, g_ctx.d_partials, 0, (double*)nullptr);
+                           (const double*)nullptr, 0, p, t, u, r, g_ctx.d_partials, 0, (double*)nullptr,
+                           pre_x, K.pre_diag, K.pre_omega);
+        bool r_is_updates = pre_x != nullptr;   // false again as soon as r is recomputed from u
         d_finalize(G, 1, 0u, 0, dist);
         HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * 9, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
@@ -153,6 +157,7 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
                                 "fasp_solver_dcsr_pcg", 232);
                 }
                 { if (K.halo(u) < 0) return ERROR_MISC; K.resid(u, b, r); }
+                r_is_updates = false;
                 if ((st = resnorm(0.0, false)) < 0) return st;
                 if (PrtLvl >= PRINT_MORE)
                     std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
@@ -172,6 +177,7 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
         if (relres < tol) {  // Check III: prevent false convergence
             const double updated_relres = relres;
             { if (K.halo(u) < 0) return ERROR_MISC; K.resid(u, b, r); }
+            r_is_updates = false;
             if ((st = resnorm(0.0, false)) < 0) return st;
             if (relres < tol) break;
             if (PrtLvl >= PRINT_MORE) {
@@ -192,6 +198,7 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
         absres0 = absres;
         int zr_G = 0;   // partials of (z, r) left behind by the preconditioner's last sweep (0: none)
         if (StopType != STOP_REL_PRECRES) {
+            if (r_is_updates && K.mark_presmoothed) K.mark_presmoothed();
             if (K.pc_zr) { if ((st = K.pc_zr(r, &z, &zr_G)) < 0) return st; }
             else if ((st = apply_pc()) < 0) return st;
         }

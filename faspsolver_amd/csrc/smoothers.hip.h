@@ -302,6 +302,10 @@ static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order
     }
     if (smoother == SMOOTHER_JACOBI || smoother == SMOOTHER_L1DIAG) {
         for (int s = 0; s < nsweeps; ++s) {
+            if (D.x_zero && D.presmoothed && smoother == SMOOTHER_JACOBI) {   // this sweep was written with the rhs
+                D.presmoothed = false; D.x_zero = false;
+                continue;
+            }
             if (D.x_zero) {
                 // zero initial guess: t_i = b_i exactly, no matrix pass
                 if (smoother == SMOOTHER_JACOBI)

@@ -1850,6 +1850,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "gs_multicolor")) g_tune.gs_multicolor = value;
     else if (!std::strcmp(key, "seq_block")) g_tune.seq_block = value;
     else if (!std::strcmp(key, "fuse_zr")) g_tune.fuse_zr = value;
+    else if (!std::strcmp(key, "fuse_presmooth")) g_tune.fuse_presmooth = value;
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;

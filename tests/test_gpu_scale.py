@@ -283,3 +283,33 @@ def test_fused_zr_product_matches_separate_dot(gpu, var):
     assert np.allclose(h1, h0, rtol=1e-9, atol=1e-13 * h0[0])
     assert np.abs(x1 - x0).max() <= 1e-11 * np.abs(x0).max()
     H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var,cycle", [(False, 1), (True, 1), (False, 2)])
+def test_fused_first_jacobi_sweep_is_bit_identical(gpu, var, cycle):
+    """The first pre-smoothing sweep of a level (Jacobi from a zero guess, x = (w b) / d) is written by the kernel that
+    produces b -- the restriction of the level above, on level 0 the CG update that produces r -- with the expression
+    of the stand-alone kernel.  fasp_hip_tune("fuse_presmooth", 0) runs the stand-alone kernel: same bits, in a
+    V-cycle apply, a W-cycle apply and a whole PCG solve."""
+    n = 64
+    if var:
+        ia, ja, a, f = fa.poisson7pt_var(n)
+    else:
+        ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _params()
+    amgp.cycle_type = cycle
+    H = fa.AMG(ia, ja, a, amgp)
+    L = fa.lib()
+    r = np.random.default_rng(13).standard_normal(len(f))
+    try:
+        out = []
+        for fp in (1, 0):
+            L.fasp_hip_tune(b"fuse_presmooth", fp)
+            out.append((H.precond(r), H.solve(f, itp)))
+    finally:
+        L.fasp_hip_tune(b"fuse_presmooth", 1)
+    (z1, (st1, x1, h1, s1)), (z0, (st0, x0, h0, s0)) = out
+    assert np.array_equal(z1, z0)
+    assert st1 == st0 and np.array_equal(h1, h0) and np.array_equal(x1, x0)
+    H.close()
