@@ -678,8 +678,20 @@ double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps);
  * triad over buffers of `bytes` each (>= 512 MiB: beyond the Infinity Cache) */
 int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
 
-/* Development knob: override kernel selection / launch geometry at run time
- * (keys: maxgrid, xcd, nt, kind, lanes, wrows, wcap; value -1 = automatic). */
+/* Run-time switches (A/B tests, profiling, and ONE behavioural mode):
+ *   kernel selection / launch geometry: maxgrid, xcd, nt, kind, lanes, wrows, wcap (-1 = automatic), gen2 (0 round-1
+ *     kernels, 1, 2 = default), compress (lossless matrix coding on/off), ja16, ws2_bpc, rpl, lds_tab, xcd_pat;
+ *   coarse solve: spcg_persist, spcg_fused, spcg_batch, spcg_grid, small_lds;
+ *   upload: device_sort (per-row sorts of the long-row levels on the device, default 1);
+ *   fusions: fuse_zr ((z, r) of PCG from the last level-0 Jacobi sweep), fuse_presmooth (first Jacobi sweep written with
+ *     its right-hand side) -- both default 1, results identical (fuse_presmooth: bit for bit; fuse_zr: to rounding);
+ *   sequential sweeps: seq_block (one-workgroup sweeps on the deep levels, default 1, same bits), seq_persist (0);
+ *     gs_multicolor = 1 selects the MULTICOLOUR Gauss-Seidel / SOR sweep -- NOT the reference's iteration (rows are
+ *     relaxed colour by colour instead of in index order; faster, converges alike, other iteration counts). Default 0:
+ *     the reference's sequential sweep, reproduced exactly;
+ *   multi-GPU: halo_overlap (exchange beside the interior rows, default 1), split_rows (test mode: every operator in
+ *     three row windows).
+ * Unknown keys return ERROR_INPUT_PAR. */
 int fasp_hip_tune(const char* key, int value);
 
 /* Multi-GPU (1-D row partition, RCCL over xGMI).  The unique id is produced on

@@ -13,7 +13,7 @@ for cfg in "$@"; do
   tag=$(echo "$cfg" | tr ' <>,' '____')
   g=0
   for grp in "${CTRS[@]}"; do
-    timeout 90 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/${tag}_g$g -- tools/lab/lab $N $WHAT 3 $1 $2 $3 1 > $OUT/${tag}_g$g.log 2>&1
+    timeout -s KILL 90 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/${tag}_g$g -- tools/lab/lab $N $WHAT 3 $1 $2 $3 1 > $OUT/${tag}_g$g.log 2>&1
     g=$((g+1))
   done
 done
