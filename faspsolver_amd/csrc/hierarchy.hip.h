@@ -27,7 +27,11 @@ struct DevLevel {
     bool    has_halo() const { return !replicated && nvec > nloc; }
     // level schedules of the sequential sweeps (built on first use): kind 0 ascending,
     // 1 descending, 2 ascending C rows, 3 ascending F rows, 4 descending from row n-2
-    struct Sched { bool built = false, multicolor = false; int* d_order = nullptr; int* d_ptr = nullptr; std::vector<int> ptr; };
+    struct Sched {
+        bool built = false, multicolor = false; int* d_order = nullptr; int* d_ptr = nullptr; std::vector<int> ptr;
+        // the sweep's launches as a replayable graph, valid for these vectors / this update form
+        hipGraphExec_t graph_exec = nullptr; const double* g_b = nullptr; const double* g_x = nullptr; int g_form = -1, g_L = 0; double g_w = 0.0;
+    };
     Sched   sched[5];
     // polynomial smoother (built on first use): 1 / first diagonal hit, the coefficients k[1..5] of
     // ItrSmootherCSRpoly.c:101-109, work vectors r, rbar, v0, v1, vnew
@@ -92,7 +96,7 @@ static void free_level(DevLevel& D)
     if (D.w) (void)hipFree(D.w);
     if (D.d_send_idx) (void)hipFree(D.d_send_idx);
     if (D.d_sendbuf) (void)hipFree(D.d_sendbuf);
-    for (auto& sc : D.sched) { if (sc.d_order) (void)hipFree(sc.d_order); if (sc.d_ptr) (void)hipFree(sc.d_ptr); }
+    for (auto& sc : D.sched) { if (sc.graph_exec) (void)hipGraphExecDestroy(sc.graph_exec); if (sc.d_order) (void)hipFree(sc.d_order); if (sc.d_ptr) (void)hipFree(sc.d_ptr); }
     if (D.poly.dinv) (void)hipFree(D.poly.dinv);
     for (double* q : D.poly.w) if (q) (void)hipFree(q);
     if (D.d_mark) (void)hipFree(D.d_mark);

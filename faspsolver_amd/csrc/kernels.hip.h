@@ -956,6 +956,36 @@ __global__ __launch_bounds__(BLOCK) void k_bsr_dinv_apply(int n, int nb, const d
 //   form 2  u_i = w (t / a_ii) + (1-w) u_i     _sor :981-993
 // with t = b_i - sum_{j != i} a_ij u_j.
 // ---------------------------------------------------------------------------
+// Off-diagonal part of one row of a sequential sweep, entries k, k + L, k + 2L, ... of the calling lane, added in that
+// order: four (JA, val) pairs and four gathers of u in flight per round trip (rows of the deep levels hold hundreds
+// to thousands of entries; one entry per round trip made a dependency level of three such rows cost 15-20 us), the
+// last one to three strides in one more round trip with clamped indices.  ldu(c) reads u_c.
+template <int L, class LDU>
+__device__ __forceinline__ double seq_row_sum(const int* __restrict__ ja, const double* __restrict__ val, int k, int ke,
+                                              int r, LDU ldu, double s = 0.0)
+{
+    for (; k + 3 * L < ke; k += 4 * L) {
+        const int    c0 = ja[k], c1 = ja[k + L], c2 = ja[k + 2 * L], c3 = ja[k + 3 * L];
+        const double v0 = val[k], v1 = val[k + L], v2 = val[k + 2 * L], v3 = val[k + 3 * L];
+        const double u0 = ldu(c0), u1 = ldu(c1), u2 = ldu(c2), u3 = ldu(c3);
+        if (c0 != r) s += v0 * u0;
+        if (c1 != r) s += v1 * u1;
+        if (c2 != r) s += v2 * u2;
+        if (c3 != r) s += v3 * u3;
+    }
+    if (k < ke) {
+        const int    kl = ke - 1;
+        const int    k1 = min(k + L, kl), k2 = min(k + 2 * L, kl);
+        const int    c0 = ja[k], c1 = ja[k1], c2 = ja[k2];
+        const double v0 = val[k], v1 = val[k1], v2 = val[k2];
+        const double u0 = ldu(c0), u1 = ldu(c1), u2 = ldu(c2);
+        if (c0 != r) s += v0 * u0;
+        if (k + L < ke && c1 != r) s += v1 * u1;
+        if (k + 2 * L < ke && c2 != r) s += v2 * u2;
+    }
+    return s;
+}
+
 template <int L>
 __global__ __launch_bounds__(BLOCK) void k_seq_level(const int* __restrict__ order, int lo, int hi,
                                                       const int* __restrict__ ia, const int* __restrict__ ja,
@@ -970,11 +1000,7 @@ __global__ __launch_bounds__(BLOCK) void k_seq_level(const int* __restrict__ ord
     for (int idx = lo + blockIdx.x * RPB + rloc; idx < hi; idx += gridDim.x * RPB) {
         const int r = order[idx];
         const int kb = ia[r], ke = ia[r + 1];
-        double s = 0.0;
-        for (int k = kb + sl; k < ke; k += L) {
-            const int c = ja[k];
-            if (c != r) s += val[k] * u[c];
-        }
+        double s = seq_row_sum<L>(ja, val, kb + sl, ke, r, [&](int c) { return u[c]; });
         s = subwave_sum<L>(s);
         if (sl == 0) {
             const double d = diag[r];

@@ -1103,11 +1103,7 @@ __global__ __launch_bounds__(BLOCK) void k_seq_sweep(SeqSweepArgs a)
         for (int idx = lo + blockIdx.x * RPB + rloc; idx < hi; idx += nb * RPB) {
             const int r = a.order[idx];
             const int kb = a.ia[r], ke = a.ia[r + 1];
-            double s = 0.0;
-            for (int k = kb + sl; k < ke; k += L) {
-                const int c = a.ja[k];
-                if (c != r) s += a.val[k] * ld_u(c);
-            }
+            double s = seq_row_sum<L>(a.ja, a.val, kb + sl, ke, r, ld_u);
             s = subwave_sum<L>(s);
             if (sl == 0) {
                 const double d = a.diag[r];
@@ -1153,20 +1149,28 @@ __global__ __launch_bounds__(BLOCK) void k_seq_sweep(SeqSweepArgs a)
 // (dependency levels, or colours) hold a handful of rows each: the deep, dense levels, where a sweep is thousands
 // of classes of one to three rows and one launch per class costs ~4 us of launch latency for ~1 us of work.  Here a
 // class costs one workgroup barrier plus ONE memory round trip: the rows of the next class, their row pointers and
-// their first 4 L entries are fetched (they do not depend on u) before the barrier that ends the current class, so
+// their first 8 L entries are fetched (they do not depend on u) before the barrier that ends the current class, so
 // after it only the gathers of u remain.  u travels through the L2 (agent-scope relaxed atomics: a wave must see what
 // a wave of another SIMD stored in the class before).  Arithmetic per row exactly as k_seq_level: lane-strided partial
 // sums in k order, sub-wavefront tree, the same three update forms -- the two kernels are interchangeable bit for bit.
 // ---------------------------------------------------------------------------
+// ULDS: the level's u fits the workgroup's LDS (n * 8 bytes of dynamic LDS, n <= ~19 000): it is loaded once, gathered and
+// updated there -- a class then costs an LDS round trip instead of one through the L2 -- and written back at the end.
 constexpr int SEQ_BLOCK = 1024;
-template <int L>
-__global__ __launch_bounds__(SEQ_BLOCK) void k_seq_block(SeqSweepArgs a)
+template <int L, bool ULDS>
+__global__ __launch_bounds__(SEQ_BLOCK) void k_seq_block(SeqSweepArgs a, int n)
 {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
-    constexpr int RPB = SEQ_BLOCK / L, PF = 4;
+    extern __shared__ __attribute__((aligned(16))) double u_lds[];
+    constexpr int RPB = SEQ_BLOCK / L, PF = 8;
     const int sl = threadIdx.x & (L - 1);
     const int rloc = threadIdx.x / L;
+    if (ULDS) {
+        for (int i = threadIdx.x; i < n; i += SEQ_BLOCK) u_lds[i] = a.u[i];
+        __syncthreads();
+    }
     auto ld_u = [&](int c) -> double {
+        if (ULDS) return u_lds[c];
         return __longlong_as_double((long long)__hip_atomic_load((gu64*)(a.u + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     };
     auto finish = [&](int r, double s) {
@@ -1179,8 +1183,9 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_seq_block(SeqSweepArgs a)
                 if (a.form == 0) un = t * (1.0 / d);
                 else if (a.form == 1) un = t / d;
                 else un = a.w * (t / d) + (1 - a.w) * ld_u(r);
-                __hip_atomic_store((gu64*)(a.u + r), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                if (ULDS) u_lds[r] = un;
+                else __hip_atomic_store((gu64*)(a.u + r), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
@@ -1218,26 +1223,20 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_seq_block(SeqSweepArgs a)
 #pragma unroll
             for (int q = 0; q < PF; ++q)
                 if (c[q] != r) s += v[q] * uq[q];
-            for (int k = k1; k < ke; k += L) {
-                const int cc = a.ja[k];
-                if (cc != r) s += a.val[k] * ld_u(cc);
-            }
+            s = seq_row_sum<L>(a.ja, a.val, k1, ke, r, ld_u, s);
             finish(r, s);
         }
         for (int idx = lo + RPB + rloc; idx < hi; idx += RPB) {   // classes wider than one round
             const int rr = a.order[idx];
             const int kb = a.ia[rr], kend = a.ia[rr + 1];
-            double s = 0.0;
-            for (int k = kb + sl; k < kend; k += L) {
-                const int cc = a.ja[k];
-                if (cc != rr) s += a.val[k] * ld_u(cc);
-            }
-            finish(rr, s);
+            finish(rr, seq_row_sum<L>(a.ja, a.val, kb + sl, kend, rr, ld_u));
         }
         lo = nlo; hi = nhi;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!ULDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (ULDS)
+        for (int i = threadIdx.x; i < n; i += SEQ_BLOCK) a.u[i] = u_lds[i];
 }
 
 // ---------------------------------------------------------------------------

@@ -70,6 +70,7 @@ static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLeve
     for (int l = 0; l < nlev; ++l) S.ptr[l + 1] += S.ptr[l];
     std::vector<int> cur(S.ptr.begin(), S.ptr.end() - 1), order(seq.size());
     for (int i : seq) order[cur[lev[i] - 1]++] = i;
+    if (S.graph_exec) { (void)hipGraphExecDestroy(S.graph_exec); S.graph_exec = nullptr; }
     if (S.d_order) { (void)hipFree(S.d_order); S.d_order = nullptr; }
     if (S.d_ptr) { (void)hipFree(S.d_ptr); S.d_ptr = nullptr; }
     HIPCK(hipMalloc(&S.d_order, sizeof(int) * std::max<size_t>(order.size(), 1)));
@@ -120,9 +121,15 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
         }
         const int st = build_schedule(A, seq, S, multicolor);
         if (st < 0) return st;
+        if (std::getenv("FASP_HIP_SETUP_TIMING"))
+            std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind,
+                        multicolor ? "colours" : "dependency levels", (int)seq.size(), (int)S.ptr.size() - 1);
     }
     materialise_zero(D);
-    const int L = D.A.lanes;
+    // lanes per row: a class of a sequential sweep holds few rows (on the deep levels one to a few dozen), so a long row
+    // gets a whole wavefront whatever the SpMV kernel of the level uses (fasp_hip_tune("seq_lanes", L) overrides)
+    const double avg_len = D.A.row > 0 ? (double)D.A.nnz / D.A.row : 0.0;
+    const int L = g_tune.seq_lanes > 0 ? g_tune.seq_lanes : (avg_len >= 96.0 ? 64 : D.A.lanes);
     const int nlev = (int)S.ptr.size() - 1;
     // Optional (fasp_hip_tune("seq_persist", 1)): one launch per sweep (k_seq_sweep), the dependency levels separated by
     // grid meetings instead of kernel boundaries.  MEASURED SLOWER than one launch per level (P7(128), GS-CF defaults:
@@ -132,7 +139,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     // Needs every block resident at once, so never when validation ranks share the device.
     // Schedules of many small classes (the deep, dense levels -- in either mode): the whole sweep in one workgroup
     // (k_seq_block, kernels2.hip.h), a barrier and one memory round trip per class instead of a launch.
-    if (g_tune.seq_block && nlev >= 8 && (long long)S.ptr[nlev] <= (long long)nlev * (2 * SEQ_BLOCK / L)) {
+    if (g_tune.seq_block && !multicolor && nlev >= 8 && (long long)S.ptr[nlev] <= (long long)nlev * (2 * SEQ_BLOCK / L)) {
         if (!S.d_ptr) {
             HIPCK(hipMalloc(&S.d_ptr, sizeof(int) * (size_t)(nlev + 1)));
             HIPCK(hipMemcpy(S.d_ptr, S.ptr.data(), sizeof(int) * (size_t)(nlev + 1), hipMemcpyHostToDevice));
@@ -140,7 +147,19 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
         SeqSweepArgs sa{};
         sa.order = S.d_order; sa.lptr = S.d_ptr; sa.nlev = nlev; sa.ia = D.A.ia; sa.ja = D.A.ja; sa.val = D.A.val;
         sa.b = D.b; sa.diag = D.diag; sa.u = D.x; sa.form = form; sa.w = w; sa.sync = nullptr;
-#define SEQB_LAUNCH(LL) hipLaunchKernelGGL((k_seq_block<LL>), dim3(1), dim3(SEQ_BLOCK), 0, g_ctx.stream, sa)
+        const int   nrow = D.A.row;
+        const bool  ulds = g_tune.seq_ulds && (size_t)nrow * 8 <= 150 * 1024;   // u of the level in the workgroup's LDS
+        const size_t dyn = ulds ? (size_t)nrow * 8 : 0;
+#define SEQB_LAUNCH(LL)                                                                                                     \
+        if (ulds) {                                                                                                         \
+            static bool attr_set = false;                                                                                   \
+            if (!attr_set) {                                                                                                \
+                HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_block<LL, true>),                             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));                         \
+                attr_set = true;                                                                                            \
+            }                                                                                                               \
+            hipLaunchKernelGGL((k_seq_block<LL, true>), dim3(1), dim3(SEQ_BLOCK), dyn, g_ctx.stream, sa, nrow);             \
+        } else hipLaunchKernelGGL((k_seq_block<LL, false>), dim3(1), dim3(SEQ_BLOCK), 0, g_ctx.stream, sa, nrow)
         switch (L) {
             case 2: SEQB_LAUNCH(2); break;
             case 4: SEQB_LAUNCH(4); break;
@@ -184,6 +203,17 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
         g_seq_sync = d_sync; g_seq_herr = h_err;
         return FASP_SUCCESS;
     }
+    // One launch per class.  Optional (fasp_hip_tune("seq_graph", 1)): the sweep's launches captured once as a HIP graph per
+    // (schedule, vectors, update form) and replayed.  MEASURED: no gain (P7(128) GS, 348 ms with and without) -- the
+    // ~4.4 us per class are the GPU's dispatch of a dependent kernel, not host launch overhead -- so it is off by default.
+    const bool use_graph = g_tune.seq_graph && nlev >= 16 && !comm_shares_devices();
+    if (use_graph && S.graph_exec && S.g_b == D.b && S.g_x == D.x && S.g_form == form && S.g_w == w && S.g_L == L)
+        return hipGraphLaunch(S.graph_exec, g_ctx.stream) == hipSuccess ? FASP_SUCCESS : ERROR_MISC;
+    bool capturing = false;
+    if (use_graph) {
+        if (S.graph_exec) { (void)hipGraphExecDestroy(S.graph_exec); S.graph_exec = nullptr; }
+        capturing = hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    }
     for (int l = 0; l < nlev; ++l) {
         const int lo = S.ptr[l], hi = S.ptr[l + 1];
         const int rpb = BLOCK / L;
@@ -200,6 +230,15 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
             default: SEQ_LAUNCH(64); break;
         }
 #undef SEQ_LAUNCH
+    }
+    if (capturing) {
+        hipGraph_t g = nullptr;
+        if (hipStreamEndCapture(g_ctx.stream, &g) != hipSuccess || !g) return ERROR_MISC;
+        const hipError_t e = hipGraphInstantiate(&S.graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { S.graph_exec = nullptr; return ERROR_MISC; }
+        S.g_b = D.b; S.g_x = D.x; S.g_form = form; S.g_w = w; S.g_L = L;
+        return hipGraphLaunch(S.graph_exec, g_ctx.stream) == hipSuccess ? FASP_SUCCESS : ERROR_MISC;
     }
     return FASP_SUCCESS;
 }

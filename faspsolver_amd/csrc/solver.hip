@@ -1851,6 +1851,9 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_block")) g_tune.seq_block = value;
     else if (!std::strcmp(key, "fuse_zr")) g_tune.fuse_zr = value;
     else if (!std::strcmp(key, "fuse_presmooth")) g_tune.fuse_presmooth = value;
+    else if (!std::strcmp(key, "seq_lanes")) g_tune.seq_lanes = value;
+    else if (!std::strcmp(key, "seq_ulds")) g_tune.seq_ulds = value;
+    else if (!std::strcmp(key, "seq_graph")) g_tune.seq_graph = value;
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;
