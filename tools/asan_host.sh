@@ -23,8 +23,8 @@ fa.LIB_PATH = "$OUT/libfasp_hip.so"
 import pytest
 # tests that call the compiled REFERENCE are left out: it is not built with the sanitizer runtime
 sys.exit(pytest.main(["tests/test_host_setup_parallel.py", "tests/test_ua_amg.py", "tests/test_bsr_amg.py", "tests/test_sa_amg.py",
-                      "tests/test_param_input.py", "tests/test_golden_fixtures.py", "tests/test_matrix_coding.py",
-                      "-q", "-m", "not gpu", "-k", "not reference", "-p", "no:cacheprovider"]))
+                      "tests/test_param_input.py", "tests/test_golden_fixtures.py", "tests/test_matrix_coding.py", "tests/test_dist_cpu.py",
+                      "-q", "-m", "not gpu", "-k", "not reference and not two_rank", "-p", "no:cacheprovider"]))
 PY
 cd $ROOT
 LD_PRELOAD="$GCCLIB/libasan.so $GCCLIB/libubsan.so" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 OMP_NUM_THREADS=4 \
