@@ -34,23 +34,59 @@ struct SmallOut {
     double relres, absres;
 };
 
+// Sum over the 64 lanes of a wavefront by data-parallel-primitive moves (no LDS crossbar round trips): inclusive
+// row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast 15 and 31 across them; the total ends in lane 63.  Fixed order.
+__device__ __forceinline__ double dpp_mov_f64(double x, const int ctrl, const int row_mask)
+{
+    const long long b = __double_as_longlong(x);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    switch (ctrl) {   // the control word must be a compile-time constant
+        case 0x111: lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
+        case 0x112: lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
+        case 0x114: lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
+        case 0x118: lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
+        case 0x142: lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, true); break;
+        default:    lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, true); break;
+    }
+    (void)row_mask;
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double x)
+{
+    x += dpp_mov_f64(x, 0x111, 0xf);
+    x += dpp_mov_f64(x, 0x112, 0xf);
+    x += dpp_mov_f64(x, 0x114, 0xf);
+    x += dpp_mov_f64(x, 0x118, 0xf);
+    x += dpp_mov_f64(x, 0x142, 0xa);   // lanes of rows 1 and 3 take lane 15 / 47 (rows not in the mask add 0)
+    x += dpp_mov_f64(x, 0x143, 0xc);   // lanes of rows 2 and 3 take lane 31
+    return x;
+}
+
+__device__ __forceinline__ double wave_max_to_lane63(double x)
+{
+    x = fmax(x, dpp_mov_f64(x, 0x111, 0xf));   // (rows shifted in are 0: the quantities reduced this way are >= 0)
+    x = fmax(x, dpp_mov_f64(x, 0x112, 0xf));
+    x = fmax(x, dpp_mov_f64(x, 0x114, 0xf));
+    x = fmax(x, dpp_mov_f64(x, 0x118, 0xf));
+    x = fmax(x, dpp_mov_f64(x, 0x142, 0xa));
+    x = fmax(x, dpp_mov_f64(x, 0x143, 0xc));
+    return x;
+}
 // Sum (or max, per bit of maxmask) of NQ per-thread values over the workgroup.  Every thread
-// ends with the same result, summed in the same order: wave shuffle tree, then the 16 wave
-// partials left to right.
+// ends with the same result, summed in the same order: the wave's fixed DPP pattern, then the wave
+// partials left to right.  (max: for quantities >= 0 only -- lanes shifted in contribute 0.)
 template <int NQ, int NW = SMALL_WAVES>
 __device__ __forceinline__ void blk_reduce(double (&v)[NQ], double* sh, unsigned maxmask = 0u)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        double x = v[q];
+        // wave stage on data-parallel-primitive moves: a dozen dependent ds_bpermute round trips per quantity (the
+        // shuffle tree this replaces) were most of an iteration of the single-workgroup solvers -- config 5's
+        // 124 000 coarse CG iterations ran at 4.8 us each
         const bool mx = (maxmask >> q) & 1u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double y = __shfl_down(x, o);
-            x = mx ? fmax(x, y) : x + y;
-        }
-        if (lane == 0) sh[w * NQ + q] = x;
+        const double x = mx ? wave_max_to_lane63(v[q]) : wave_sum_to_lane63(v[q]);
+        if (lane == 63) sh[w * NQ + q] = x;
     }
     __syncthreads();
 #pragma unroll
@@ -867,34 +903,6 @@ FINISHED:
 // ---------------------------------------------------------------------------
 constexpr int SPCG_HANG = 8;
 
-// Sum over the 64 lanes of a wavefront by data-parallel-primitive moves (no LDS crossbar round trips): inclusive
-// row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast 15 and 31 across them; the total ends in lane 63.  Fixed order.
-__device__ __forceinline__ double dpp_mov_f64(double x, const int ctrl, const int row_mask)
-{
-    const long long b = __double_as_longlong(x);
-    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    switch (ctrl) {   // the control word must be a compile-time constant
-        case 0x111: lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
-        case 0x112: lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
-        case 0x114: lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
-        case 0x118: lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
-        case 0x142: lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, true); break;
-        default:    lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, true); break;
-    }
-    (void)row_mask;
-    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
-}
-__device__ __forceinline__ double wave_sum_to_lane63(double x)
-{
-    x += dpp_mov_f64(x, 0x111, 0xf);
-    x += dpp_mov_f64(x, 0x112, 0xf);
-    x += dpp_mov_f64(x, 0x114, 0xf);
-    x += dpp_mov_f64(x, 0x118, 0xf);
-    x += dpp_mov_f64(x, 0x142, 0xa);   // lanes of rows 1 and 3 take lane 15 / 47 (rows not in the mask add 0)
-    x += dpp_mov_f64(x, 0x143, 0xc);   // lanes of rows 2 and 3 take lane 31
-    return x;
-}
-
 struct SpcgPersistArgs {
     int        m, max_steps, nblocks;
     int        u_lds;                  // the launch carries a fourth LDS vector: block 0 keeps u on chip
@@ -908,24 +916,13 @@ struct SpcgPersistArgs {
     const int*            wend;        // [(nblocks-1)*8][8] end slot (exclusive) of each of them
 };
 
-// blk_reduce with the wave stage on data-parallel-primitive moves instead of LDS-crossbar shuffles (a dozen dependent
-// ds_bpermute round trips per quantity are microseconds when a kernel runs one or two waves per SIMD)
-__device__ __forceinline__ double wave_max_to_lane63(double x)
-{
-    x = fmax(x, dpp_mov_f64(x, 0x111, 0xf));   // (rows shifted in are 0: the quantities reduced this way are >= 0)
-    x = fmax(x, dpp_mov_f64(x, 0x112, 0xf));
-    x = fmax(x, dpp_mov_f64(x, 0x114, 0xf));
-    x = fmax(x, dpp_mov_f64(x, 0x118, 0xf));
-    x = fmax(x, dpp_mov_f64(x, 0x142, 0xa));
-    x = fmax(x, dpp_mov_f64(x, 0x143, 0xc));
-    return x;
-}
 // workgroup barrier that orders LDS traffic only: global stores in flight (the published products, the best iterate)
 // stay in flight across it -- __syncthreads() would wait for every one of them to be acknowledged
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// blk_reduce with LDS-only barriers (global stores in flight stay in flight)
 template <int NQ, int NW>
 __device__ __forceinline__ void blk_reduce_dpp(double (&v)[NQ], double* sh, unsigned maxmask = 0u)
 {
