@@ -125,7 +125,15 @@ struct SmallCSR {
         const int sl = threadIdx.x & 15;
         for (int row = threadIdx.x >> 4; row < m; row += SMALL_BLOCK / 16) {
             double s = 0.0;
-            for (int k = ia[row] + sl, ke = ia[row + 1]; k < ke; k += 16) s += val[k] * x[ja[k]];
+            int k = ia[row] + sl;
+            const int ke = ia[row + 1];
+            for (; k + 48 < ke; k += 64) {   // four entries per round trip (LDS or L2), added in the old order
+                const int    c0 = ja[k], c1 = ja[k + 16], c2 = ja[k + 32], c3 = ja[k + 48];
+                const double v0 = val[k], v1 = val[k + 16], v2 = val[k + 32], v3 = val[k + 48];
+                const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+                s += v0 * x0; s += v1 * x1; s += v2 * x2; s += v3 * x3;
+            }
+            for (; k < ke; k += 16) s += val[k] * x[ja[k]];
             s += __shfl_xor(s, 8);
             s += __shfl_xor(s, 4);
             s += __shfl_xor(s, 2);
