@@ -68,7 +68,9 @@ KERNELS = {0: ("k_csr_rows", "k_csr_rows<L, OP_MXV_DOT> (sub-wavefront per row, 
            5: ("k_csr_rowpat<7", "k_csr_rowpat<OP_MXV_DOT> (one 16-bit row-pattern id per row)"),
            6: ("k_csr_rowpat4<7>", "k_csr_rowpat4<OP_MXV_DOT> (16-bit row-pattern ids, scalar-pattern sweep + exception list)"),
            7: ("k_csr_lstream<7, 512>", "k_csr_lstream<OP_MXV_DOT,512> (16-byte staged stream, lane = row, plain CSR)"),
-           8: ("k_csr_wstream2<7>", "k_csr_wstream2<OP_MXV_DOT> (16-byte staged, prefetched wave stream, plain CSR)")}
+           8: ("k_csr_wstream2<7>", "k_csr_wstream2<OP_MXV_DOT> (16-byte staged, prefetched wave stream, plain CSR)"),
+           9: ("k_csr_rowpat5<7>", "k_csr_rowpat5<OP_MXV_DOT> (16-bit row-pattern ids, pair-of-patterns sweep, rectangular)"),
+           10: ("k_csr_xtile<7>", "k_csr_xtile<OP_MXV_DOT> (tile's distinct x entries in LDS, 16-bit column positions; lossless)")}
 
 
 def log(*a):

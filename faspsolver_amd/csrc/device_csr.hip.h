@@ -34,8 +34,17 @@ struct DevCSR {
     // local operator of a row-partitioned level: the rows [win_lo, win_hi) read no ghost column (multiples of WIN_ALIGN
     // or the row count; win_hi < 0: no such window worth a split launch) -- they run while the halo is in flight
     int     win_lo = 0, win_hi = -1;
+    // k_csr_xtile: distinct columns per 64-row wave tile + 16-bit positions per entry (nullptr: not built)
+    unsigned short* lja16 = nullptr;
+    int*    tptr = nullptr;
+    int*    tcols = nullptr;
+    long long ntcols = 0;            // entries of tcols
     void    release()
     {
+        if (lja16) (void)hipFree(lja16);
+        if (tptr) (void)hipFree(tptr);
+        if (tcols) (void)hipFree(tcols);
+        lja16 = nullptr; tptr = nullptr; tcols = nullptr;
         if (xrows) (void)hipFree(xrows);
         xrows = nullptr; nxrows = -1;
         if (ja16) (void)hipFree(ja16);
@@ -397,6 +406,65 @@ static int upload_sorted_on_device(const HostCSR& H, DevCSR& D, int maxlen)
     return st;
 }
 
+// k_csr_xtile's structures (kernels2.hip.h): per wave tile of 64 rows the sorted list of the distinct columns of its
+// entries, per entry the position of its column in that list.  Refused (nothing built) when a tile has more than
+// XT_XCAP distinct columns or the lists would not pay for themselves.
+static int build_xtile(const HostCSR& H, DevCSR& D)
+{
+    static const bool on = !(std::getenv("FASP_HIP_XTILE") && std::atoi(std::getenv("FASP_HIP_XTILE")) == 0);
+    if (!on || H.row < 4096 || H.nnz < 16 * H.row) return FASP_SUCCESS;   // short rows: k_csr_lstream's territory
+    const int ntile = (H.row + 63) / 64;
+    std::vector<int> cnt((size_t)ntile + 1, 0);
+    Buf<unsigned short> l16((size_t)H.nnz);
+    std::vector<std::vector<int>> lists((size_t)ntile);
+    bool too_fat = false;
+#pragma omp parallel
+    {
+        std::vector<int> cols;
+#pragma omp for schedule(dynamic, 64)
+        for (int t = 0; t < ntile; ++t) {
+            if (too_fat) continue;
+            const int k0 = H.ia[t * 64], k1 = H.ia[std::min(H.row, t * 64 + 64)];
+            cols.assign(H.ja.data() + k0, H.ja.data() + k1);
+            std::sort(cols.begin(), cols.end());
+            cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+            if ((int)cols.size() > XT_XCAP) { too_fat = true; continue; }
+            for (int k = k0; k < k1; ++k)
+                l16[k] = (unsigned short)(std::lower_bound(cols.begin(), cols.end(), H.ja[k]) - cols.begin());
+            cnt[(size_t)t + 1] = (int)cols.size();
+            lists[(size_t)t] = cols;
+        }
+    }
+    static const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
+    if (too_fat) {
+        if (timing) std::printf("        [xtile %d x %d, %d nnz] a tile has more than %d distinct columns: not built\n", H.row, H.col, H.nnz, XT_XCAP);
+        return FASP_SUCCESS;
+    }
+    int fattest = 0;
+    for (int t = 0; t < ntile; ++t) { fattest = std::max(fattest, cnt[(size_t)t + 1]); cnt[(size_t)t + 1] += cnt[(size_t)t]; }
+    const long long total = cnt[(size_t)ntile];
+    if (timing) std::printf("        [xtile %d x %d, %d nnz] %lld distinct columns in %d tiles (%.1f entries per distinct column, fattest tile %d)\n",
+                            H.row, H.col, H.nnz, total, ntile, (double)H.nnz / std::max<long long>(total, 1), fattest);
+    // worth it when the rows of a tile share their columns: >= 2.5 entries per distinct column (then 10 + 4 / 2.5 = 11.6
+    // bytes per entry against 12, and 2.5 x fewer gathers).  AMG coarse levels in C-point order share little (P7(256):
+    // 1.5 on level 1, > 1024 distinct columns per tile on level 2): they keep k_csr_wstream2 until their rows are
+    // re-ordered in bricks.  FASP_HIP_XTILE_MIN_SHARE overrides (tests).
+    double min_share = 2.5;
+    if (const char* e = std::getenv("FASP_HIP_XTILE_MIN_SHARE")) min_share = std::atof(e);
+    if ((double)total * min_share > (double)H.nnz) return FASP_SUCCESS;
+    std::vector<int> flat((size_t)std::max<long long>(total, 1));
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < ntile; ++t) std::copy(lists[(size_t)t].begin(), lists[(size_t)t].end(), flat.begin() + cnt[(size_t)t]);
+    HIPCK(hipMalloc(&D.lja16, sizeof(unsigned short) * ((size_t)H.nnz + 8)));
+    HIPCK(hipMalloc(&D.tptr, sizeof(int) * ((size_t)ntile + 1)));
+    HIPCK(hipMalloc(&D.tcols, sizeof(int) * flat.size()));
+    HIPCK(hipMemcpy(D.lja16, l16.data(), sizeof(unsigned short) * (size_t)H.nnz, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(D.tptr, cnt.data(), sizeof(int) * ((size_t)ntile + 1), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(D.tcols, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice));
+    D.ntcols = total;
+    return FASP_SUCCESS;
+}
+
 static int upload_csr(const HostCSR& H, DevCSR& D)
 {
     D.row = H.row; D.col = H.col; D.nnz = H.nnz;
@@ -571,11 +639,12 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
     }
 #endif
     if (upload_plain() < 0) return ERROR_ALLOC_MEM;
+    if (D.kind == 2 && !g_oneshot_upload && build_xtile(H, D) < 0) return ERROR_ALLOC_MEM;
     return upload_ja16(D, H.ja.data());
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, seq_ulds = 1, seq_graph = 0; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, seq_ulds = 1, seq_graph = 0, xtile = 1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -718,6 +787,13 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         // short rows (64 rows fit the 512-entry slab with room for ragged tiles): 16-byte staged stream, lane = row
         if (OP == OP_JACOBI && a.partials) g_jacobi_dot_done = true;
         return launch_persistent(k_csr_lstream<OP, 512>, a.ntiles, a, 4);
+    }
+    if (M.kind == 2 && g_tune.gen2 >= 2 && g_tune.xtile && M.lja16 && M.wrows == 64 && M.wcap == 512 && (OP != OP_JACOBI || (M.dpos && !M.dup_diag)))
+    {
+        // mid levels (20-60 nonzeros per row): the tile's distinct x entries staged in LDS, 16-bit column positions
+        a.lja16 = M.lja16; a.tptr = M.tptr; a.tcols = M.tcols;
+        if (OP == OP_JACOBI && a.partials) g_jacobi_dot_done = true;
+        return launch_persistent(k_csr_xtile<OP>, a.ntiles, a, 3);
     }
     if (M.kind == 2 && g_tune.gen2 >= 2 && M.wrows == 64 && M.wcap == 512 && (OP != OP_JACOBI || (M.dpos && !M.dup_diag)))
     {

@@ -82,6 +82,11 @@ struct CsrArgs {
     double*       zx;
     const double* zdiag;
     double        zomega;
+    // k_csr_xtile: per 64-row wave tile the sorted list of its distinct columns (tcols[tptr[t] .. tptr[t+1])) and, per
+    // entry, the 16-bit position of its column in that list
+    const unsigned short* lja16;
+    const int*    tptr;
+    const int*    tcols;
 };
 
 __device__ __forceinline__ void zx_store(const CsrArgs& a, int r, double s)

@@ -376,6 +376,168 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// k_csr_xtile<OP>: k_csr_wstream2 with the operand staged per tile.  The levels this serves (20-60 nonzeros per row,
+// x of tens of MB) were bound by the x gathers: ~30 distinct cache lines per 64-lane gather, every one an L1 miss,
+// 2-3 GB of L2 -> L1 line traffic per pass beside 0.6 GB of matrix stream -- whatever the occupancy, the grid or the
+// order of the entries.  But the 64 rows of a wave tile share their columns: ~2 240 entries
+// touch only 300-600 DISTINCT columns.  At upload every tile gets the sorted list of its distinct columns and every
+// entry the 16-bit position of its column in that list (device_csr.hip.h, build_xtile); the kernel gathers each
+// distinct x entry ONCE per tile into the wave's LDS (a handful of well-clustered gathers) and the chunk loop --
+// 16-byte staged loads of the 16-bit indices and the values, products, left-to-right row sums -- never leaves the
+// LDS.  Bytes per entry 8 + 2 (+ ~0.7 for the lists) instead of 12; the arithmetic and its order are k_csr_wstream2's
+// (bit-identical results).  XCAP distinct columns per tile at most (the builder refuses matrices with a fatter tile).
+// ---------------------------------------------------------------------------
+constexpr int XT_XCAP = 1024;
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void k_csr_xtile(CsrArgs a)
+{
+    if (a.stop && *a.stop) return;
+    constexpr int CAP = 512, NV = 4, XR = XT_XCAP / 64;
+    __shared__ __attribute__((aligned(16))) double         sv_all[4 * CAP];      // values, then (in place) products
+    __shared__ __attribute__((aligned(16))) unsigned short sj_all[4 * CAP];      // local column positions
+    __shared__ __attribute__((aligned(16))) double         xl_all[4 * XT_XCAP];  // the tile's distinct x entries
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double*         sv = sv_all + wave * CAP;
+    unsigned short* sj = sj_all + wave * CAP;
+    double*         xl = xl_all + wave * XT_XCAP;
+    const int vmax = tile_vmax(a);
+    const int G = gridDim.x;
+    double dotacc = 0.0;
+
+    auto advance = [&](int& v, int& r0, int& nr) {
+        for (;;) {
+            r0 = -1; nr = 0;
+            if (v >= vmax) return;
+            const int t = tile_of(a, v);
+            v += G;
+            if (t >= a.ntiles) continue;
+            const int rr = (t + a.tile0) * BLOCK + wave * 64;
+            if (rr >= a.nrow) continue;
+            r0 = rr; nr = min(64, a.nrow - rr);
+            return;
+        }
+    };
+    auto load_ia = [&](int r0, int nr, int& kb, int& ke) {
+        kb = ke = 0;
+        if (r0 >= 0 && lane < nr) { kb = a.ia[r0 + lane]; ke = a.ia[r0 + lane + 1]; }
+    };
+    u32x4_t qj;
+    f64x2_t qv[NV];
+    // chunk [lo, hi) staged from the 8-aligned entry s = lo & ~7 (16 bytes of 16-bit positions): slab index of entry k is k - s
+    auto stage_load = [&](int s, int hi) {
+        const int n8 = (hi - s + 7) & ~7;
+        const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.lja16 + s), 0, n8 * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.val + s), 0, n8 * 8, 0x00020000);
+        qj = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16, 0, 2);
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+            qv[q] = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(rv, (lane + 64 * q) * 16, 0, 2));
+    };
+    auto stage_store = [&]() {
+        reinterpret_cast<u32x4_t*>(sj)[lane] = qj;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) reinterpret_cast<f64x2_t*>(sv)[lane + 64 * q] = qv[q];
+    };
+    // the distinct x entries of wave tile r0 / 64 into the wave's LDS (positions at or beyond the list read column 0)
+    auto stage_x = [&](int r0) {
+        const int t = r0 >> 6;
+        const int p0 = a.tptr[t], n = a.tptr[t + 1] - p0;
+        int    col[XR];
+        double xv[XR];
+#pragma unroll
+        for (int q = 0; q < XR; ++q) col[q] = (lane + 64 * q < n) ? a.tcols[p0 + lane + 64 * q] : -1;
+#pragma unroll
+        for (int q = 0; q < XR; ++q) xv[q] = (col[q] >= 0) ? a.x[col[q]] : 0.0;
+#pragma unroll
+        for (int q = 0; q < XR; ++q)
+            if (64 * q < n) xl[lane + 64 * q] = xv[q];     // wave-uniform skip of the rounds beyond the list
+    };
+    constexpr int STEP = CAP - 8;
+
+    int v = blockIdx.x;
+    int r0A, nrA, kbA, keA, r0B, nrB, kbB, keB;
+    advance(v, r0A, nrA);
+    load_ia(r0A, nrA, kbA, keA);
+    advance(v, r0B, nrB);
+    load_ia(r0B, nrB, kbB, keB);
+    int k0 = 0, k1 = 0, lo = 0, hi = 0;
+    if (r0A >= 0) {
+        k0 = __builtin_amdgcn_readlane(kbA, 0); k1 = __builtin_amdgcn_readlane(keA, nrA - 1);
+        lo = k0; hi = min(lo + STEP, k1);
+        stage_load(lo & ~7, hi);
+        stage_x(r0A);
+        stage_store();
+    }
+    wave_order();
+    while (r0A >= 0) {
+        const int r = r0A + lane;
+        double acc = ((OP == OP_JACOBI || OP == OP_L1DIAG) && lane < nrA) ? a.b[r] : 0.0;
+        const int dk = (OP == OP_JACOBI && lane < nrA) ? a.dpos[r] : -1;
+        for (;;) {   // chunks of tile A; the slab holds [lo & ~7, hi)
+            const int s = lo & ~7;
+            // look ahead first: the next chunk of this tile, or the first chunk of tile B (and the row pointers of tile C)
+            const bool last = hi >= k1;
+            int nlo, nhi, nk0 = 0, nk1 = 0;
+            int r0C = -1, nrC = 0, kbC = 0, keC = 0;
+            if (!last) { nlo = hi; nhi = min(nlo + STEP, k1); }
+            else {
+                if (r0B >= 0) { nk0 = __builtin_amdgcn_readlane(kbB, 0); nk1 = __builtin_amdgcn_readlane(keB, nrB - 1); }
+                nlo = nk0; nhi = min(nlo + STEP, nk1);
+                advance(v, r0C, nrC);
+                load_ia(r0C, nrC, kbC, keC);
+            }
+            if (!last || r0B >= 0) stage_load(nlo & ~7, nhi);
+            // phase 1: lane = entry -- positions and values from the slab, x from the tile's LDS image, products in place
+            // (slab entries beyond the chunk hold position 0 / value 0.0, or the next rows' entries: never summed)
+            int    c[8];
+            double w[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = sj[lane + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = sv[lane + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = xl[(s + lane + 64 * u < hi) ? c[u] : 0];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[lane + 64 * u] = w[u] * xv[u];
+            wave_order();
+            // phase 2: lane = row, storage order, eight products per LDS round trip
+            if (lane < nrA) {
+                const int pb = max(kbA, lo), pe = min(keA, hi);
+                for (int k = pb; k < pe; k += 8) {
+                    double p[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) p[u] = sv[min(k + u, pe - 1) - s];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double t = (OP == OP_JACOBI || OP == OP_L1DIAG) ? acc - p[u] : acc + p[u];
+                        const bool take = (k + u < pe) && !(OP == OP_JACOBI && k + u == dk);
+                        acc = take ? t : acc;
+                    }
+                }
+            }
+            wave_order();
+            if (last) {
+                if (lane < nrA) row_epilogue<OP>(a, r, acc, dotacc);
+                if (r0B >= 0) { stage_x(r0B); stage_store(); }
+                wave_order();
+                r0A = r0B; nrA = nrB; kbA = kbB; keA = keB;
+                r0B = r0C; nrB = nrC; kbB = kbC; keB = keC;
+                k0 = nk0; k1 = nk1; lo = nlo; hi = nhi;
+                break;
+            }
+            stage_store();
+            wave_order();
+            lo = nlo; hi = nhi;
+        }
+    }
+    if (OP == OP_MXV_DOT || (OP == OP_JACOBI && a.partials)) {
+        const double tot = block_sum(dotacc, red);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_csr_rowpat2<OP, LDS_TAB>: row-pattern-coded SQUARE matrix (column base = row index), a lane owns rows
 // 2i and 2i+1 of its wave's 128-row tile.  Pattern lists are padded to multiples of 8 entries (offset 0,
 // value 0); x goes through buffer loads (hardware range check: the second half of a 16-byte load at

@@ -490,10 +490,14 @@ int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* k
     double bytes = 12.0 * M.nnz + 4.0 * (M.row + 1.0);
     if (M.code && g_tune.compress) { k = 4; bytes = 1.0 * M.nnz + 4.0 * (M.row + 1.0) + (M.rowbase ? 4.0 * M.row : 0.0); }
     if (M.pat && g_tune.compress) { k = 5; bytes = 2.0 * M.row + (M.rowbase ? 4.0 * M.row : 0.0) + 12.0 * M.npent; }
-    // second-generation kernels (kernels2.hip.h), same selection as launch_csr: 6 = k_csr_rowpat4, 7 = k_csr_lstream, 8 = k_csr_wstream2
+    // second-generation kernels (kernels2.hip.h), same selection as launch_csr: 6 = k_csr_rowpat4, 7 = k_csr_lstream, 8 = k_csr_wstream2, 9 = k_csr_rowpat5, 10 = k_csr_xtile
     if (k == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase) { k = 6; bytes += 4.0 * M.nxrows; }
     else if (k == 5 && g_tune.gen2 >= 2 && M.nxrows >= 0 && M.rowbase && (double)M.nnz <= 4.5 * M.row) { k = 9; bytes += 4.0 * M.nxrows; }   // k_csr_rowpat5
     if (k == 2 && g_tune.gen2 && M.wrows == 64 && M.wcap == 512 && (double)M.nnz <= 7.6 * M.row) k = 7;
+    else if (k == 2 && g_tune.gen2 >= 2 && g_tune.xtile && M.lja16 && M.wrows == 64 && M.wcap == 512) {   // k_csr_xtile
+        k = 10;
+        bytes = 10.0 * M.nnz + 4.0 * (M.row + 1.0) + 4.0 * M.ntcols + 4.0 * ((M.row + 63) / 64 + 1.0);   // values + 16-bit positions + the tiles' column lists
+    }
     else if (k == 2 && g_tune.gen2 >= 2 && M.wrows == 64 && M.wcap == 512) k = 8;   // k_csr_wstream2
     if (kind) *kind = k;
     if (matrix_bytes) *matrix_bytes = bytes;
@@ -1854,6 +1858,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_lanes")) g_tune.seq_lanes = value;
     else if (!std::strcmp(key, "seq_ulds")) g_tune.seq_ulds = value;
     else if (!std::strcmp(key, "seq_graph")) g_tune.seq_graph = value;
+    else if (!std::strcmp(key, "xtile")) g_tune.xtile = value;
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;

@@ -105,7 +105,7 @@ def test_variable_coefficient_matches_reference(gpu, n):
     itp, amgp = _params()
     H = fa.AMG(ia, ja, a, amgp)
     assert _levels(H) == z[f"var{n}_levels"].tolist()
-    assert H.kernel_info(0, 0)[0] in (2, 7, 8)   # nothing to code
+    assert H.kernel_info(0, 0)[0] in (2, 7, 8, 10)   # nothing to code
     st, x, hist, stats = H.solve(f, itp)
     assert st == int(z[f"var{n}_iters"])
     assert abs(stats.relres - float(z[f"var{n}_relres"])) <= RELRES_TOL
@@ -130,11 +130,14 @@ def test_coded_vs_plain_and_gen1_vs_gen2_bit_identity_128(gpu):
     out = {}
     try:
         for comp in (1, 0):
-            for gen2 in (2, 1, 0):   # 2: + k_csr_wstream2 on the mid levels; 1: k_csr_lstream / k_csr_rowpat4 only; 0: round-1 kernels
+            for gen2 in (2, 1, 0):   # 2: + k_csr_xtile / k_csr_wstream2 on the mid levels; 1: k_csr_lstream / k_csr_rowpat4 only; 0: round-1 kernels
                 L.fasp_hip_tune(b"compress", comp); L.fasp_hip_tune(b"gen2", gen2)
                 out[(comp, gen2)] = H.precond(r)
+            L.fasp_hip_tune(b"gen2", 2); L.fasp_hip_tune(b"xtile", 0)   # the same mid levels through k_csr_wstream2
+            out[(comp, "wstream2")] = H.precond(r)
+            L.fasp_hip_tune(b"xtile", 1)
     finally:
-        L.fasp_hip_tune(b"compress", 1); L.fasp_hip_tune(b"gen2", 2)
+        L.fasp_hip_tune(b"compress", 1); L.fasp_hip_tune(b"gen2", 2); L.fasp_hip_tune(b"xtile", 1)
     base = out[(1, 2)]
     for k, v in out.items():
         assert np.array_equal(v, base), k
@@ -310,6 +313,45 @@ def test_fused_first_jacobi_sweep_is_bit_identical(gpu, var, cycle):
     finally:
         L.fasp_hip_tune(b"fuse_presmooth", 1)
     (z1, (st1, x1, h1, s1)), (z0, (st0, x0, h0, s0)) = out
+    assert np.array_equal(z1, z0)
+    assert st1 == st0 and np.array_equal(h1, h0) and np.array_equal(x1, x0)
+    H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var", [False, True])
+def test_xtile_kernel_is_bit_identical_to_wstream2(gpu, var):
+    """k_csr_xtile stages the distinct x entries of a 64-row tile in LDS and reads 16-bit column positions; it is built
+    only for operators whose tiles share their columns (>= 2.5 entries per distinct column).  The coarse levels of this
+    hierarchy share less, so the threshold is lowered for the test: the levels that then run it must give the bits
+    k_csr_wstream2 gives (same products, same left-to-right sums)."""
+    n = 64
+    if var:
+        ia, ja, a, f = fa.poisson7pt_var(n)
+    else:
+        ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _params()
+    L = fa.lib()
+    old = os.environ.get("FASP_HIP_XTILE_MIN_SHARE")
+    os.environ["FASP_HIP_XTILE_MIN_SHARE"] = "1.0"
+    try:
+        H = fa.AMG(ia, ja, a, amgp)
+    finally:
+        if old is None:
+            del os.environ["FASP_HIP_XTILE_MIN_SHARE"]
+        else:
+            os.environ["FASP_HIP_XTILE_MIN_SHARE"] = old
+    kinds = [H.kernel_info(l, w)[0] for l in range(H.num_levels - 1) for w in (0, 1, 2)]
+    assert 10 in kinds, kinds          # some operator really runs k_csr_xtile
+    r = np.random.default_rng(17).standard_normal(len(f))
+    try:
+        z1 = H.precond(r)
+        st1, x1, h1, s1 = H.solve(f, itp)
+        L.fasp_hip_tune(b"xtile", 0)
+        z0 = H.precond(r)
+        st0, x0, h0, s0 = H.solve(f, itp)
+    finally:
+        L.fasp_hip_tune(b"xtile", 1)
     assert np.array_equal(z1, z0)
     assert st1 == st0 and np.array_equal(h1, h0) and np.array_equal(x1, x0)
     H.close()
