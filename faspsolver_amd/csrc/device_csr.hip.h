@@ -414,6 +414,27 @@ static int build_xtile(const HostCSR& H, DevCSR& D)
     static const bool on = !(std::getenv("FASP_HIP_XTILE") && std::atoi(std::getenv("FASP_HIP_XTILE")) == 0);
     if (!on || H.row < 4096 || H.nnz < 16 * H.row) return FASP_SUCCESS;   // short rows: k_csr_lstream's territory
     const int ntile = (H.row + 63) / 64;
+    double min_share = 2.5;
+    if (const char* e = std::getenv("FASP_HIP_XTILE_MIN_SHARE")) min_share = std::atof(e);
+    {   // a sample of the tiles first (every 61st): most operators are decided here, for a percent of the work
+        long long ent = 0, dist = 0;
+        bool fat = false;
+        std::vector<int> cols;
+        for (int t = 0; t < ntile; t += 61) {
+            const int k0 = H.ia[t * 64], k1 = H.ia[std::min(H.row, t * 64 + 64)];
+            cols.assign(H.ja.data() + k0, H.ja.data() + k1);
+            std::sort(cols.begin(), cols.end());
+            cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+            ent += k1 - k0; dist += (long long)cols.size();
+            if ((int)cols.size() > XT_XCAP) fat = true;
+        }
+        if (fat || (double)dist * min_share > 1.1 * (double)ent) {
+            if (std::getenv("FASP_HIP_SETUP_TIMING"))
+                std::printf("        [xtile %d x %d, %d nnz] sample: %.1f entries per distinct column%s: not built\n", H.row, H.col, H.nnz,
+                            (double)ent / std::max<long long>(dist, 1), fat ? ", a tile beyond the LDS list" : "");
+            return FASP_SUCCESS;
+        }
+    }
     std::vector<int> cnt((size_t)ntile + 1, 0);
     Buf<unsigned short> l16((size_t)H.nnz);
     std::vector<std::vector<int>> lists((size_t)ntile);
@@ -449,8 +470,6 @@ static int build_xtile(const HostCSR& H, DevCSR& D)
     // bytes per entry against 12, and 2.5 x fewer gathers).  AMG coarse levels in C-point order share little (P7(256):
     // 1.5 on level 1, > 1024 distinct columns per tile on level 2): they keep k_csr_wstream2 until their rows are
     // re-ordered in bricks.  FASP_HIP_XTILE_MIN_SHARE overrides (tests).
-    double min_share = 2.5;
-    if (const char* e = std::getenv("FASP_HIP_XTILE_MIN_SHARE")) min_share = std::atof(e);
     if ((double)total * min_share > (double)H.nnz) return FASP_SUCCESS;
     std::vector<int> flat((size_t)std::max<long long>(total, 1));
 #pragma omp parallel for schedule(static)
