@@ -342,7 +342,12 @@ struct AheadUpload {
             }
             if (t_first < 0) t_first = wall_seconds();
             const double t0 = wall_seconds();
-            if (status >= 0) { const int st = upload_level(h, l, nullptr); if (st < 0) status = st; }
+            if (status >= 0) {
+                int st;
+                try { st = upload_level(h, l, nullptr); }
+                catch (const std::bad_alloc&) { st = ERROR_ALLOC_MEM; }   // (a host buffer of the coding passes: never out of this thread)
+                if (st < 0) status = st;
+            }
             if (std::getenv("FASP_HIP_SETUP_TIMING"))
                 std::printf("  [upload ahead] level %d: %.3f s (started %.3f s after the first)\n", l, wall_seconds() - t0, t0 - t_first);
         }

@@ -5,7 +5,10 @@ import faspsolver_amd as fa
 from faspsolver_amd import _types as T
 n = int(sys.argv[1]); key = sys.argv[2].encode(); vals = [int(v) for v in sys.argv[3:]]
 L = fa.lib()
-ia, ja, a, f, ue = fa.poisson7pt(n)
+if os.environ.get("VAR"):
+    ia, ja, a, f = fa.poisson7pt_var(n)   # variable coefficients: every level on the plain-CSR kernels
+else:
+    ia, ja, a, f, ue = fa.poisson7pt(n)
 amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
 H = fa.AMG(ia, ja, a, amgp)
 itp = fa.param_solver_init(); itp.tol = 1e-8
