@@ -306,7 +306,8 @@ int fasp_hip_amg_upload(fasp_hip_amg* h)
     if (!h->L.empty()) return FASP_SUCCESS;
     int st = ctx_init();
     if (st < 0) return st;
-    return upload_hierarchy(h);
+    try { return upload_hierarchy(h); }
+    catch (const std::bad_alloc&) { std::printf("### ERROR: fasp_hip: host allocation failed during the upload\n"); return ERROR_ALLOC_MEM; }
 }
 
 namespace {
@@ -398,7 +399,8 @@ int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgpara
         if (st < 0) return st;
         lap("host setup");
     }
-    st = upload_hierarchy(h);
+    try { st = upload_hierarchy(h); }
+    catch (const std::bad_alloc&) { std::printf("### ERROR: fasp_hip: host allocation failed during the upload\n"); st = ERROR_ALLOC_MEM; }
     lap("upload_hierarchy");
     if (st < 0) { fasp_hip_amg_destroy(h); return st; }
     *out = h;
