@@ -355,3 +355,24 @@ def test_xtile_kernel_is_bit_identical_to_wstream2(gpu, var):
     assert np.array_equal(z1, z0)
     assert st1 == st0 and np.array_equal(h1, h0) and np.array_equal(x1, x0)
     H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,smoother,order,w", [("gscf", T.SMOOTHER_GS, 1, 1.0), ("gsnat", T.SMOOTHER_GS, 0, 1.0), ("sor11", T.SMOOTHER_SOR, 0, 1.1)])
+def test_sequential_smoothers_match_reference_64(gpu, tag, smoother, order, w):
+    """The parity mode of the sequential smoothers at 64^3 against the REFERENCE's own run (tests/golden/p7_sweeps.npz,
+    tools/gen_golden_sweeps.py): Gauss-Seidel in C/F order (the reference's defaults), in natural order, SOR(1.1).
+    At this size the deep levels run as one-workgroup sweeps with u in LDS, the upper ones as one launch per
+    dependency level: equal iteration counts, residual histories to 1e-8, |relres - ref| <= 1e-10."""
+    z = np.load(os.path.join(G, "p7_sweeps.npz"))
+    ia, ja, a, f, ue = fa.poisson7pt(64)
+    itp, amgp = _gs_params(smoother, order, w)
+    H = fa.AMG(ia, ja, a, amgp)
+    st, x, hist, stats = H.solve(f, itp)
+    assert st == int(z[f"{tag}_iters"])
+    assert abs(stats.relres - float(z[f"{tag}_relres"])) <= RELRES_TOL
+    assert _same_history(hist, z[f"{tag}_hist"])
+    step = max(1, len(x) // 4096)
+    xs = z[f"{tag}_xsample"]
+    assert np.abs(x[::step] - xs).max() <= X_TOL * np.abs(xs).max()
+    H.close()

@@ -1,0 +1,40 @@
+"""Sequential-smoother fixtures at scale: tests/golden/p7_sweeps.npz from the REFERENCE ITSELF (oracle/_ref/libfasp_ref.so).
+Run in the build container only; the fixture is data (iteration counts, residual histories, solution samples).
+
+    python tools/gen_golden_sweeps.py
+
+P7(64) with the reference's default smoother (Gauss-Seidel, C/F order), Gauss-Seidel in natural order and SOR(1.1):
+the sizes at which the device runs its deep levels as one-workgroup sweeps with u in LDS (k_seq_block).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_golden as G  # noqa: E402  (reference bindings; importing does not regenerate anything)
+
+T = G.T
+MODS = {
+    "gscf": lambda i, a: (setattr(i, "tol", 1e-8),),
+    "gsnat": lambda i, a: (setattr(i, "tol", 1e-8), setattr(a, "smooth_order", 0)),
+    "sor11": lambda i, a: (setattr(i, "tol", 1e-8), setattr(a, "smoother", T.SMOOTHER_SOR), setattr(a, "relaxation", 1.1),
+                           setattr(a, "smooth_order", 0)),
+}
+
+if __name__ == "__main__":
+    out = {}
+    n = 64
+    ia, ja, a, f, ue = G.ref_p7(n)
+    for tag, mod in MODS.items():
+        st, xs, hist = G.solve(ia, ja, a, f, mod)
+        out[f"{tag}_iters"] = np.array(st)
+        out[f"{tag}_hist"] = hist
+        out[f"{tag}_relres"] = np.array(hist[-1] / hist[0])
+        step = max(1, len(xs) // 4096)
+        out[f"{tag}_xsample"] = xs[::step].copy()
+        print(tag, "iters", st, "relres %.10e" % (hist[-1] / hist[0]), flush=True)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "p7_sweeps.npz"), **out)
+    print("wrote tests/golden/p7_sweeps.npz")
