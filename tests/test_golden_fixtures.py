@@ -174,6 +174,23 @@ def test_midsize_summaries(n, fa):
     H.close()
 
 
+@pytest.mark.parametrize("tag", ["gscf", "gsnat", "sor11"])
+def test_oracle_sweeps_bit_exact_64(tag):
+    """The oracle's sequential smoothers at 64^3 against the reference's own run (tests/golden/p7_sweeps.npz,
+    tools/gen_golden_sweeps.py): Gauss-Seidel in C/F order (the reference's defaults), in natural order, SOR(1.1) --
+    bit for bit, as at the small sizes.  (The device parity test of the same fixture: tests/test_gpu_scale.py.)"""
+    z = np.load(os.path.join(G, "p7_sweeps.npz"))
+    ia, ja, a, f, ue = poisson7pt(64)
+    itp, amgp = default_params(); itp.tol = 1e-8
+    if tag == "gsnat": amgp.smooth_order = 0
+    if tag == "sor11": amgp.smoother = T.SMOOTHER_SOR; amgp.relaxation = 1.1; amgp.smooth_order = 0
+    st, x, hist, rr = orc_solve(ia, ja, a, f, itp, amgp)
+    assert st == int(z[f"{tag}_iters"])
+    assert np.array_equal(np.concatenate([hist[:-2], hist[-1:]]), z[f"{tag}_hist"])
+    step = max(1, len(x) // 4096)
+    assert np.array_equal(x[::step], z[f"{tag}_xsample"])
+
+
 # --- F7: smoothed aggregation + GMRES family (config-5 shape, small) -----------------------
 def _c5(i, a):
     i.tol = 1e-8; i.itsolver_type = 6; i.restart = 30
