@@ -663,7 +663,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, seq_ulds = 1, seq_graph = 0, xtile = 1; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, seq_ulds = 1, seq_graph = 0, xtile = 1, rp5_max = 45; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -765,7 +765,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
     // (measured on P7(256) level 0: prolongation, 1-6 entries per row, 140 -> 131 us; restriction, 7-13 entries per row,
     // 68 -> 80 us: the sweep pays for short lists only)
     if (M.kind == 5 && g_tune.gen2 >= 2 && M.nxrows >= 0 && M.rowbase && g_tune.rpl <= 0 && OP != OP_JACOBI && OP != OP_L1DIAG &&
-        (double)M.nnz <= 4.5 * M.row) {
+        (double)M.nnz <= 0.1 * g_tune.rp5_max * M.row) {
         // rectangular row-pattern-coded operator (R, P of the coded levels): pair-of-patterns sweep + exception list
         a.pat = M.pat; a.pstart = M.pstart; a.plen = M.plen; a.poff = M.poff; a.pval = M.pval;
         a.npat = M.npat; a.npent = M.npent; a.ncol = M.col; a.rowbase = M.rowbase;

@@ -499,7 +499,7 @@ int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* k
     if (M.pat && g_tune.compress) { k = 5; bytes = 2.0 * M.row + (M.rowbase ? 4.0 * M.row : 0.0) + 12.0 * M.npent; }
     // second-generation kernels (kernels2.hip.h), same selection as launch_csr: 6 = k_csr_rowpat4, 7 = k_csr_lstream, 8 = k_csr_wstream2, 9 = k_csr_rowpat5, 10 = k_csr_xtile
     if (k == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase) { k = 6; bytes += 4.0 * M.nxrows; }
-    else if (k == 5 && g_tune.gen2 >= 2 && M.nxrows >= 0 && M.rowbase && (double)M.nnz <= 4.5 * M.row) { k = 9; bytes += 4.0 * M.nxrows; }   // k_csr_rowpat5
+    else if (k == 5 && g_tune.gen2 >= 2 && M.nxrows >= 0 && M.rowbase && (double)M.nnz <= 0.1 * g_tune.rp5_max * M.row) { k = 9; bytes += 4.0 * M.nxrows; }   // k_csr_rowpat5
     if (k == 2 && g_tune.gen2 && M.wrows == 64 && M.wcap == 512 && (double)M.nnz <= 7.6 * M.row) k = 7;
     else if (k == 2 && g_tune.gen2 >= 2 && g_tune.xtile && M.lja16 && M.wrows == 64 && M.wcap == 512) {   // k_csr_xtile
         k = 10;
@@ -1866,6 +1866,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_ulds")) g_tune.seq_ulds = value;
     else if (!std::strcmp(key, "seq_graph")) g_tune.seq_graph = value;
     else if (!std::strcmp(key, "xtile")) g_tune.xtile = value;
+    else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;

@@ -15,5 +15,6 @@ H = fa.AMG(ia, ja, a, amgp)
 for v in vals:
     L.fasp_hip_tune(key, v)
     t = [min(H.time_kernel(k, lev, 20) for _ in range(2)) * 1e3 for k in (0, 2, 5)]
-    print(f"level {lev} kind {H.kernel_info(lev, 0)[0]} {key.decode()} = {v:5d}: mxv {t[0]:7.1f} us  jacobi {t[1]:7.1f} us  mxv+dot {t[2]:7.1f} us", flush=True)
+    tr = [min(H.time_kernel(k, lev, 20) for _ in range(2)) * 1e3 for k in (6, 7)] if lev < H.num_levels - 1 else [0, 0]
+    print(f"level {lev} kind {H.kernel_info(lev, 0)[0]} {key.decode()} = {v:5d}: mxv {t[0]:7.1f} us  jacobi {t[1]:7.1f} us  mxv+dot {t[2]:7.1f} us | R mxv {tr[0]:7.1f} us (kind {H.kernel_info(lev, 2)[0] if lev < H.num_levels - 1 else -1})  P aAxpy {tr[1]:7.1f} us (kind {H.kernel_info(lev, 1)[0] if lev < H.num_levels - 1 else -1})", flush=True)
 H.close()
