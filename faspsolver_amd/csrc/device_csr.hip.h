@@ -633,30 +633,6 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
         D.sorted = true;
         return upload_ja16(D, sj.data());
     }
-#ifdef FASP_LAB_DEBUG
-    if (std::getenv("FASP_HIP_EXPT_CHUNKSORT") && D.kind == 2) {   // timing experiment only: results are WRONG
-        Buf<int> sj((size_t)H.nnz); Buf<double> sv((size_t)H.nnz);
-        const int ntile = (H.row + 63) / 64;
-#pragma omp parallel
-        {
-            std::vector<std::pair<int, double>> tmp;
-#pragma omp for schedule(dynamic, 16)
-            for (int t = 0; t < ntile; ++t) {
-                const int k0 = H.ia[t * 64], k1 = H.ia[std::min(H.row, t * 64 + 64)];
-                for (int lo = k0; lo < k1; lo += 508) {
-                    const int hi = std::min(lo + 508, k1);
-                    tmp.resize((size_t)(hi - lo));
-                    for (int k = lo; k < hi; ++k) tmp[(size_t)(k - lo)] = {H.ja[k], H.val[k]};
-                    std::sort(tmp.begin(), tmp.end());
-                    for (int k = lo; k < hi; ++k) { sj[k] = tmp[(size_t)(k - lo)].first; sv[k] = tmp[(size_t)(k - lo)].second; }
-                }
-            }
-        }
-        HIPCK(hipMemcpy(D.ja, sj.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice));
-        HIPCK(hipMemcpy(D.val, sv.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice));
-        return FASP_SUCCESS;
-    }
-#endif
     if (upload_plain() < 0) return ERROR_ALLOC_MEM;
     if (D.kind == 2 && !g_oneshot_upload && build_xtile(H, D) < 0) return ERROR_ALLOC_MEM;
     return upload_ja16(D, H.ja.data());
