@@ -76,6 +76,35 @@ def test_empty_rows_and_ragged(gpu):
     assert np.allclose(y1, y2, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("avg", [3, 20])
+def test_long_rows_inside_short_row_matrices(gpu, avg):
+    """Matrices whose AVERAGE row selects a stream kernel (k_csr_lstream below 7.6 entries per row, k_csr_wstream2 above)
+    but which hold rows far longer than a wave tile's 512-entry slab: the oversized-tile path of the first, rows spanning
+    several chunks in the second; empty rows in between."""
+    rng = np.random.default_rng(100 + avg)
+    n = m = 5000
+    lens = rng.poisson(avg, n)
+    lens[[7, 64, 65, 4000, 4999]] = [1500, 600, 513, 2500, 700]
+    lens[[8, 9, 66, 4001]] = 0
+    ia = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ja = np.concatenate([rng.choice(m, size=l, replace=False) for l in lens]).astype(np.int32)
+    a = rng.standard_normal(len(ja))
+    x = rng.standard_normal(m)
+    A, keep = T.as_csr(ia, ja, a, ncol=m)
+    y_ref = np.zeros(n); y = np.full(n, 7.0)
+    oracle().orc_mxv(C.byref(A), T.dp(x), T.dp(y_ref))
+    gpu.lib().fasp_blas_dcsr_mxv(C.byref(A), T.dp(x), T.dp(y))
+    rowabs = np.array([np.sum(np.abs(a[ia[i]:ia[i + 1]] * x[ja[ia[i]:ia[i + 1]]])) for i in range(n)])
+    assert np.all(y[lens == 0] == 0.0)
+    assert np.all(np.abs(y - y_ref) <= 1e-13 * np.maximum(rowabs, 1e-300) + 1e-300)
+    for alpha in (1.0, -1.0, 0.7):
+        y0 = rng.standard_normal(n)
+        y1 = y0.copy(); y2 = y0.copy()
+        oracle().orc_aAxpy(alpha, C.byref(A), T.dp(x), T.dp(y1))
+        gpu.lib().fasp_blas_dcsr_aAxpy(alpha, C.byref(A), T.dp(x), T.dp(y2))
+        assert np.all(np.abs(y1 - y2) <= 1e-13 * (rowabs + np.abs(y0)) + 1e-300)
+
+
 @pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 100003])
 def test_blas1(gpu, n):
     rng = np.random.default_rng(n)
