@@ -170,8 +170,9 @@ def test_device_row_sort_equals_host_row_sort(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("var", [False, True])
-def test_row_window_launches_are_bit_identical(gpu, var):
+@pytest.mark.parametrize("var,smoother", [(False, T.SMOOTHER_JACOBI), (True, T.SMOOTHER_JACOBI), (False, T.SMOOTHER_L1DIAG), (True, T.SMOOTHER_L1DIAG)],
+                         ids=["const-jacobi", "var-jacobi", "const-l1", "var-l1"])
+def test_row_window_launches_are_bit_identical(gpu, var, smoother):
     """A row-partitioned level runs every operator as three launches of the same kernel -- interior rows while the
     halo is in flight, then the two boundary windows (hierarchy.hip.h, dist_launch).  fasp_hip_tune("split_rows", k)
     issues every operator of a single-GPU hierarchy that way: each row is computed exactly as in the single launch, so
@@ -183,6 +184,7 @@ def test_row_window_launches_are_bit_identical(gpu, var):
     else:
         ia, ja, a, f, ue = fa.poisson7pt(n)
     itp, amgp = _params()
+    amgp.smoother = smoother
     H = fa.AMG(ia, ja, a, amgp)
     L = fa.lib()
     r = np.random.default_rng(7).standard_normal(len(f))
