@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="shm", idfile=None, amg_type=1):
+def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="shm", idfile=None, amg_type=1, smoother=1):
     try:
         os.environ["FASP_HIP_DIST_MIN_ROWS"] = str(min_rows)
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -41,7 +41,7 @@ def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="s
             assert L.fasp_hip_comm_init_shm(rank, world, name.encode()) == 0
         ia, ja, a, f, ue = fa.poisson7pt(n)
         itp = fa.param_solver_init(); itp.tol = 1e-8
-        amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
+        amgp = fa.param_amg_init(); amgp.smoother = smoother; amgp.relaxation = 0.6667
         amgp.cycle_type = cycle; amgp.AMG_type = amg_type
         if shared:   # one host setup: rank 0 publishes, the others attach
             seg = name + "_hier"
@@ -75,13 +75,13 @@ def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="s
         q.put((rank, "fail", traceback.format_exc(), None, None, None))
 
 
-def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_type=1):
+def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_type=1, smoother=1):
     import multiprocessing as mp
     import tempfile
     from _libs import T, default_params, orc_solve, poisson7pt
     ia, ja, a, f, ue = poisson7pt(n)
     itp, amgp = default_params()
-    itp.tol = 1e-8; amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667; amgp.cycle_type = cycle; amgp.AMG_type = amg_type
+    itp.tol = 1e-8; amgp.smoother = smoother; amgp.relaxation = 0.6667; amgp.cycle_type = cycle; amgp.AMG_type = amg_type
     s_ref, x_ref, h_ref, rr = orc_solve(ia, ja, a, f, itp, amgp)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -89,7 +89,7 @@ def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_typ
     idfile = os.path.join(tempfile.gettempdir(), name + ".ncclid")
     if os.path.exists(idfile):
         os.remove(idfile)
-    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q, shared, transport, idfile, amg_type)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q, shared, transport, idfile, amg_type, smoother)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -125,6 +125,12 @@ def test_distributed_solve_matches_oracle(gpu, world, n, min_rows, cycle, shared
 def test_distributed_aggregation_hierarchies_match_oracle(gpu, world, n, min_rows, amg_type):
     """SA (2) and UA (3) hierarchies carry no C/F marker: every level is cut into equal row blocks (dist_plan.cpp)."""
     _run_ranks(world, n, min_rows, 1, amg_type=amg_type)
+
+
+def test_distributed_l1_smoother_matches_oracle(gpu):
+    """The L1-diagonal smoother on row-partitioned levels (its sweep, too, runs interior rows beside the halo exchange)."""
+    from _libs import T
+    _run_ranks(2, 32, 500, 1, smoother=T.SMOOTHER_L1DIAG)
 
 
 def test_rccl_transport_with_all_visible_gpus(gpu):
