@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="shm", idfile=None, amg_type=1, smoother=1):
+def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="shm", idfile=None, amg_type=1, smoother=1, itsolver=1):
     try:
         os.environ["FASP_HIP_DIST_MIN_ROWS"] = str(min_rows)
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -40,7 +40,7 @@ def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="s
             assert L.fasp_hip_set_device(0) == 0
             assert L.fasp_hip_comm_init_shm(rank, world, name.encode()) == 0
         ia, ja, a, f, ue = fa.poisson7pt(n)
-        itp = fa.param_solver_init(); itp.tol = 1e-8
+        itp = fa.param_solver_init(); itp.tol = 1e-8; itp.itsolver_type = itsolver
         amgp = fa.param_amg_init(); amgp.smoother = smoother; amgp.relaxation = 0.6667
         amgp.cycle_type = cycle; amgp.AMG_type = amg_type
         if shared:   # one host setup: rank 0 publishes, the others attach
@@ -75,13 +75,13 @@ def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="s
         q.put((rank, "fail", traceback.format_exc(), None, None, None))
 
 
-def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_type=1, smoother=1):
+def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_type=1, smoother=1, itsolver=1):
     import multiprocessing as mp
     import tempfile
     from _libs import T, default_params, orc_solve, poisson7pt
     ia, ja, a, f, ue = poisson7pt(n)
     itp, amgp = default_params()
-    itp.tol = 1e-8; amgp.smoother = smoother; amgp.relaxation = 0.6667; amgp.cycle_type = cycle; amgp.AMG_type = amg_type
+    itp.tol = 1e-8; itp.itsolver_type = itsolver; amgp.smoother = smoother; amgp.relaxation = 0.6667; amgp.cycle_type = cycle; amgp.AMG_type = amg_type
     s_ref, x_ref, h_ref, rr = orc_solve(ia, ja, a, f, itp, amgp)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -89,7 +89,7 @@ def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_typ
     idfile = os.path.join(tempfile.gettempdir(), name + ".ncclid")
     if os.path.exists(idfile):
         os.remove(idfile)
-    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q, shared, transport, idfile, amg_type, smoother)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q, shared, transport, idfile, amg_type, smoother, itsolver)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -106,8 +106,9 @@ def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_typ
     for rank, _, st, hist, xloc, info in res:
         assert info["replicated"] == 0 and info["first_replicated"] >= 1   # level 0 really is partitioned
         assert st == s_ref
-        assert len(hist) == len(h_ref)
-        assert np.allclose(hist, h_ref, rtol=1e-8, atol=1e-12 * h_ref[0])
+        if len(h_ref):   # (the oracle records the residual history of CG only)
+            assert len(hist) == len(h_ref)
+            assert np.allclose(hist, h_ref, rtol=1e-8, atol=1e-12 * h_ref[0])
         ref_loc = x_ref[info["row0"]:info["row0"] + info["nloc"]]
         assert np.max(np.abs(xloc - ref_loc)) <= 1e-8 * np.max(np.abs(x_ref))
     # every rank saw bit-identical scalars
@@ -131,6 +132,13 @@ def test_distributed_l1_smoother_matches_oracle(gpu):
     """The L1-diagonal smoother on row-partitioned levels (its sweep, too, runs interior rows beside the halo exchange)."""
     from _libs import T
     _run_ranks(2, 32, 500, 1, smoother=T.SMOOTHER_L1DIAG)
+
+
+@pytest.mark.parametrize("itsolver", [2, 4, 5, 6], ids=["BiCGstab", "GMRES", "VGMRES", "VFGMRES"])
+def test_distributed_other_krylov_methods_match_oracle(gpu, itsolver):
+    """The other Krylov drivers on a row-partitioned level 0: they call halo(v) and then the operator, and the operator
+    bundle turns that pair into one overlapped application (cycles.hip.h, csr_ops)."""
+    _run_ranks(2, 24, 500, 1, itsolver=itsolver)
 
 
 def test_rccl_transport_with_all_visible_gpus(gpu):
