@@ -686,7 +686,7 @@ static int launch_rowpat5(CsrArgs& a)
 // (= number of per-block partials written by OP_MXV_DOT).
 // Row window of a launch: rows [lo, hi) (lo a multiple of WIN_ALIGN, which every kernel's tile size divides),
 // per-block partials written from slot goff on.  hi < 0: the whole operator.
-constexpr int WIN_ALIGN = 1024;
+constexpr int WIN_ALIGN = DIST_WIN_ALIGN;
 struct RowWin { int lo = 0, hi = -1, goff = 0; };
 // OP_JACOBI with a.partials set asks for the partials of (x_new, b) on the way out (the (z, r) of PCG from the last
 // sweep of level 0).  Only the kernels of the fast paths do it; a launch that did sets this flag.

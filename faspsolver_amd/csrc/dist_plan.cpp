@@ -87,6 +87,27 @@ void extract_rows(const HostCSR& M, int r0, int r1, int c0, int c1, const std::v
 
 }  // namespace
 
+void find_row_window(const HostCSR& M, int nown, int align, int win[2])
+{
+    win[0] = 0; win[1] = -1;
+    const int n = M.row;
+    if (n < 4 * align) return;
+    const int half = n / 2;
+    int last_lo = -1, first_hi = n;   // last ghost-reading row of the first half, first one of the second half
+#pragma omp parallel for schedule(static) reduction(max : last_lo) reduction(min : first_hi)
+    for (int i = 0; i < n; ++i) {
+        bool g = false;
+        for (int k = M.ia[i]; k < M.ia[i + 1] && !g; ++k) g = M.ja[k] >= nown;
+        if (!g) continue;
+        if (i < half) last_lo = std::max(last_lo, i);
+        else first_hi = std::min(first_hi, i);
+    }
+    const int lo = (last_lo + 1 + align - 1) / align * align;
+    const int hi = first_hi == n ? n : first_hi / align * align;
+    if (hi - lo < n / 2) return;   // ghost readers all over the block: nothing to overlap
+    win[0] = lo; win[1] = hi;
+}
+
 int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, DistPlan& D)
 {
     const int nl = (int)H.L.size();
@@ -203,7 +224,10 @@ int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, 
             // P_l: fine rows I own; operand lives on level l+1
             if (DC.replicated) extract_rows(HL.P, r0, r1, 0, DC.nglobal, nullptr, DC.nglobal, DL.P);
             else extract_rows(HL.P, r0, r1, cr0, cr1, &DC.ghosts, (cr1 - cr0) + (int)DC.ghosts.size(), DL.P);
+            find_row_window(DL.R, DL.nloc, DIST_WIN_ALIGN, DL.winR);          // R reads this level's vectors
+            if (!DC.replicated) find_row_window(DL.P, cr1 - cr0, DIST_WIN_ALIGN, DL.winP);   // P reads the next level's
         }
+        find_row_window(DL.A, DL.nloc, DIST_WIN_ALIGN, DL.winA);
     }
     return FASP_SUCCESS;
 }

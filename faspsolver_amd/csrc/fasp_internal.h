@@ -91,6 +91,7 @@ struct HostHierarchy {
 };
 
 // ---- 1-D row partition over the GPUs of a node (dist_plan.cpp) ----------------------
+constexpr int DIST_WIN_ALIGN = 1024;   // row windows start at multiples of this (every kernel's tile size divides it)
 struct DistLevel {
     bool             replicated = true;  // every rank holds (and computes) the whole level
     int              nglobal = 0;        // rows of the level
@@ -101,7 +102,13 @@ struct DistLevel {
     std::vector<int> send_off;           // nranks+1 offsets into send_idx
     std::vector<int> send_idx;           // local ids (0..nloc) to send, grouped by destination rank
     HostCSR          A, P, R;            // local rows, local column numbering (distributed levels only)
+    // interior windows of the local operators: rows [win[0], win[1]) read no ghost column (win[1] < 0: none worth a
+    // split launch) -- they run while the halo exchange is in flight (hierarchy.hip.h, dist_launch)
+    int              winA[2] = {0, -1}, winP[2] = {0, -1}, winR[2] = {0, -1};
 };
+// Rows of M that read no column >= nown, as the largest window [lo, hi) around the middle of the block with lo and hi
+// multiples of `align` (or the row count); hi = -1 when fewer than half of the rows qualify.
+void find_row_window(const HostCSR& M, int nown, int align, int win[2]);
 struct DistPlan {
     int                    rank = 0, nranks = 1;
     int                    first_replicated = 0;  // levels >= this are replicated

@@ -182,28 +182,6 @@ static int halo_exchange(DevLevel& D, double* v, hipStream_t stream = nullptr)
 // what the single launch does, only the partition of the fused dot product into per-block partials changes.
 static int g_halo_overlap = 1;   // fasp_hip_tune("halo_overlap", 0): exchange, then one launch (the round-1 sequence)
 
-// interior window of a local operator: nown = number of owned columns (ghosts are numbered from nown on)
-static void find_row_window(const HostCSR& M, int nown, DevCSR& D)
-{
-    D.win_lo = 0; D.win_hi = -1;
-    const int n = M.row;
-    if (n < 4 * WIN_ALIGN) return;
-    const int half = n / 2;
-    int last_lo = -1, first_hi = n;   // last ghost-reading row of the first half, first one of the second half
-#pragma omp parallel for schedule(static) reduction(max : last_lo) reduction(min : first_hi)
-    for (int i = 0; i < n; ++i) {
-        bool g = false;
-        for (int k = M.ia[i]; k < M.ia[i + 1] && !g; ++k) g = M.ja[k] >= nown;
-        if (!g) continue;
-        if (i < half) last_lo = std::max(last_lo, i);
-        else first_hi = std::min(first_hi, i);
-    }
-    const int lo = (last_lo + 1 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
-    const int hi = first_hi == n ? n : first_hi / WIN_ALIGN * WIN_ALIGN;
-    if (hi - lo < n / 2) return;   // ghost readers all over the block: nothing to overlap
-    D.win_lo = lo; D.win_hi = hi;
-}
-
 template <int OP>
 static int dist_launch(DevLevel& V, const DevCSR& M, CsrArgs a)
 {
@@ -257,12 +235,11 @@ static int upload_level(fasp_hip_amg* h, int l, const DistLevel* DLp)
         if (upload_csr(rep ? HL.R : DLp->R, D.R) < 0) return ERROR_ALLOC_MEM;
         lap("R");
     }
-    if (!rep) {   // interior windows (dist_launch): A and R read this level's vectors, P the next level's
-        find_row_window(A, DLp->nloc, D.A);
+    if (!rep) {   // interior windows (dist_launch), found with the partition (dist_plan.cpp)
+        D.A.win_lo = DLp->winA[0]; D.A.win_hi = DLp->winA[1];
         if (HL.has_coarse) {
-            find_row_window(DLp->R, DLp->nloc, D.R);
-            const DistLevel& DC = h->dist.L[l + 1];
-            if (!DC.replicated) find_row_window(DLp->P, DC.nloc, D.P);
+            D.R.win_lo = DLp->winR[0]; D.R.win_hi = DLp->winR[1];
+            D.P.win_lo = DLp->winP[0]; D.P.win_hi = DLp->winP[1];
         }
     }
     HIPCK(hipStreamSynchronize(g_ctx.stream));

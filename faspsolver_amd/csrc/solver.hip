@@ -811,6 +811,12 @@ int fasp_hip_dist_get_list(const fasp_hip_amg* h, int level, int which, ivector*
 {
     if (!h || !view || level < 0 || level >= (int)h->dist.L.size()) return ERROR_INPUT_PAR;
     const DistLevel& D = h->dist.L[level];
+    if (which >= 5 && which <= 7) {   // interior window [lo, hi) of the local A (5), P (6), R (7); hi < 0: none
+        const int* w = which == 5 ? D.winA : which == 6 ? D.winP : D.winR;
+        view->row = 2;
+        view->val = const_cast<int*>(w);
+        return FASP_SUCCESS;
+    }
     const std::vector<int>* v = which == 0 ? &D.ghosts : which == 1 ? &D.recv_off : which == 2 ? &D.send_off
                               : which == 3 ? &D.send_idx : which == 4 ? &D.start : nullptr;
     if (!v) return ERROR_INPUT_PAR;

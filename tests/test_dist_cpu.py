@@ -206,3 +206,44 @@ def test_three_rank_plan_consistency():
                 assert np.array_equal(want, have), (l, r, q)
     for H in Hs:
         H.close()
+
+
+@pytest.mark.parametrize("n,P", [(24, 2), (32, 3)])
+def test_interior_row_windows_read_no_ghost(n, P):
+    """The halo exchange of a row-partitioned level runs beside the rows that read no ghost entry (hierarchy.hip.h,
+    dist_launch); the windows come with the partition (dist_plan.cpp, find_row_window).  For every rank and operator:
+    no row inside the window reads a column beyond the owned ones, the window starts at a multiple of 1 024 rows, ends
+    at one or at the last row, and holds at least half of the rows."""
+    sys.path.insert(0, ROOT)
+    import faspsolver_amd as fa
+    from faspsolver_amd import _types as T
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    seen = 0
+    for r in range(P):
+        amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI
+        H = fa.AMG(ia, ja, a, amgp, host_only=True)
+        H.dist_plan(r, P, 400)
+        first_rep = H.dist_info(0)["first_replicated"]
+        for l in range(first_rep):
+            I = H.dist_info(l)
+            for which, lst in ((0, 5), (1, 6), (2, 7)):          # A, P, R
+                if which != 0 and l == H.num_levels - 1:
+                    continue
+                w = H.dist_list(l, lst)
+                if w[1] < 0:
+                    continue
+                rows, cols, mi, mj, mv = H.dist_matrix(l, which)
+                nown = I["nloc"] if which != 1 else H.dist_info(l + 1)["nloc"]    # A, R read level l; P reads level l + 1
+                if which == 1 and H.dist_info(l + 1)["replicated"]:
+                    continue
+                lo, hi = int(w[0]), int(w[1])
+                assert lo % 1024 == 0 and (hi % 1024 == 0 or hi == rows) and hi - lo >= rows // 2
+                assert not np.any(mj[mi[lo]:mi[hi]] >= nown)
+                # and the window is not needlessly small: the 1 024 rows in front of it / behind it do read ghosts
+                if lo > 0:
+                    assert np.any(mj[mi[max(lo - 1024, 0)]:mi[lo]] >= nown)
+                if hi < rows:
+                    assert np.any(mj[mi[hi]:mi[min(hi + 1024, rows)]] >= nown)
+                seen += 1
+        H.close()
+    assert seen >= P      # level 0 at least has a window on every rank
