@@ -59,7 +59,10 @@ import faspsolver_amd as fa  # noqa: E402
 from faspsolver_amd import _types as T  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_rocprof", "traffic.json")
+# PMC traffic summaries of THIS command, one per workload (tools/profile.sh <tag> <workload> -> tools/summarize_prof.py);
+# a figure is attached to a roofline entry only when kernel name, workload and grid size all match the run
+TRAFFIC_JSONS = {"constant": os.path.join("profiles", "r03_rocprof", "traffic.json"),
+                 "variable": os.path.join("profiles", "r03_rocprof_var", "traffic.json")}
 
 # kernel family codes of fasp_hip_amg_kernel_info -> (rocprofv3 kernel name of the OP_MXV_DOT instantiation, description)
 KERNELS = {0: ("k_csr_rows", "k_csr_rows<L, OP_MXV_DOT> (sub-wavefront per row, plain CSR)"),
@@ -114,6 +117,11 @@ def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s, threads):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _libs
     O = _libs.oracle()
+    O.orc_get_threads.restype = C.c_int
+    # the oracle and libfasp_hip share one OpenMP runtime: orc_set_threads() moves the calling thread's nthreads ICV,
+    # which the host AMG setup reads afterwards (round 2's variable-coefficient setup ran on ONE thread behind the
+    # one-thread baseline: 24.7 s instead of 10 s) -- restored on the way out
+    omp_before = int(os.environ.get("OMP_NUM_THREADS", "0")) or host_cores()
     O.orc_set_threads(threads)
     nl = H.num_levels
     buf = C.create_string_buffer(O.orc_sizeof_amg())
@@ -171,31 +179,41 @@ def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s, threads):
     ncmp = min(len(hk) - 1, len(hist_gpu) - 1)
     hist_dev = float(np.max(np.abs(hk[:ncmp] - hist_gpu[:ncmp]) / hk[:ncmp])) if ncmp > 0 else None
     O.orc_amg_borrow_free(buf)
+    O.orc_set_threads(omp_before)
     return {"value": len(f) / t_full, "unit": "DOF/s", "cores": threads, "kind": "port",
             "sample": sample, "seconds_full_solve_est": t_full, "cpu_model": cpu_model(),
             "host_cores_visible": host_cores()}, its_cpu, rrk, hist_dev
 
 
-def pmc_traffic(kernel_name):
-    """bytes per launch of a kernel from the committed PMC summary of this command (None if absent)."""
+def pmc_traffic(kernel_name, workload, n):
+    """(bytes per launch, source file) of a kernel from the committed PMC summary of this command for THIS workload
+    and grid size; (None, None) when there is no pass of exactly this kernel instantiation on this workload."""
+    rel = TRAFFIC_JSONS.get(workload)
+    if rel is None:
+        return None, None
     try:
-        tj = json.load(open(TRAFFIC_JSON))
-        for name, rec in tj.get("kernels", {}).items():
-            if name.startswith(kernel_name):
-                return float(rec["bytes_per_launch"])
+        tj = json.load(open(os.path.join(ROOT, rel)))
+        if tj.get("workload") != workload or int(tj.get("n", -1)) != int(n):
+            return None, None
+        rec = tj.get("kernels", {}).get(kernel_name)   # exact instantiation name, e.g. "k_csr_lstream<7, 512>"
+        if rec is not None:
+            return float(rec["bytes_per_launch"]), rel
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def roofline_entry(kind, moved_bytes, kernel_ms, launches, note=None):
+def roofline_entry(kind, moved_bytes, kernel_ms, launches, note=None, workload=None, n=None, lanes=None):
     name, desc = KERNELS.get(kind, (str(kind), str(kind)))
+    if kind == 0 and lanes:
+        name = f"k_csr_rows<{lanes}, 7>"
     achieved = moved_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = pmc_traffic(name)
+    traffic, traffic_source = pmc_traffic(name, workload, n) if workload else (None, None)
     out = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
            "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
            "kernel": "level-0 t = A p fused with (t,p): " + desc,
            "bytes_per_launch": moved_bytes, "ms_per_launch": kernel_ms, "launches_timed": launches,
+           "traffic_source": traffic_source,
            "traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic and kernel_ms > 0 else None,
            "traffic_over_bytes": (traffic / moved_bytes) if traffic else None}
     if note:
@@ -218,6 +236,34 @@ def spawn_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def variable_leg(n, system, itp, amgp, timed_solves):
+    """Variable coefficients: -div(kappa grad u) on the same grid.  No two rows repeat, so no lossless coding applies
+    and every level runs the plain-CSR kernels (what an application matrix sees)."""
+    ia, ja, a, f, ue = system
+    m = len(f)
+    try:
+        _ia, _ja, a2, f2 = fa.poisson7pt_var(n, (ia, ja, a, f, ue))
+        t0 = time.perf_counter()
+        H2 = fa.AMG(ia, ja, a2, amgp)
+        ts2 = time.perf_counter() - t0
+        H2.set_rhs(f2)
+        el2, st2, hist2, stats2, kms2 = timed_solves(H2, 1, 3)
+        k2, mb2 = H2.kernel_info(0, 0)
+        res = {
+            "workload": f"-div(kappa grad u) on the grid of P7({n}), kappa = 1 + 0.8 sin(2 pi x) sin(2 pi y) sin(2 pi z) "
+                        "(contrast 9, no repeated rows); same solver parameters; 3 timed solves",
+            "value": m * 3 / el2, "unit": "DOF/s", "ms_per_step": 1e3 * el2 / 3, "iterations": int(st2),
+            "relres": stats2.relres, "setup_seconds": ts2, "levels": H2.num_levels,
+            "roofline": roofline_entry(k2, mb2 + 16.0 * m, kms2, int(stats2.spmv_launches) * 3, workload="variable", n=n)}
+        log(f"variable-coefficient solve: {st2} iterations, {1e3*el2/3:.2f} ms/solve, setup {ts2:.1f} s, level-0 kernel family {k2}, "
+            f"SpMV {kms2*1e3:.1f} us")
+        H2.close()
+        return res
+    except Exception as e:
+        log(f"variable-coefficient solve failed: {e!r}")
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +272,8 @@ def main():
     ap.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", "256")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variable", action="store_true", help="skip the variable-coefficient second solve")
+    ap.add_argument("--only-variable", action="store_true",
+                    help="profiling runs: only the variable-coefficient solve (tools/profile.sh <tag> variable)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -255,11 +303,6 @@ def main():
     log(f"P7({n}): {m} rows, {nnz} nnz, generated in {time.perf_counter()-t0:.2f} s")
 
     itp, amgp = workload_params()
-    t0 = time.perf_counter()
-    H = fa.AMG(ia, ja, a, amgp)
-    t_setup = time.perf_counter() - t0
-    H.set_rhs(f)
-    log(f"AMG setup + upload: {t_setup:.2f} s, {H.num_levels} levels")
 
     def sync():
         L.fasp_hip_device_synchronize()
@@ -277,6 +320,16 @@ def main():
         sync()
         return time.perf_counter() - t0, st, hist, stats, float(np.mean(sp))
 
+    if args.only_variable:   # the profiled command of profiles/r03_rocprof_var (tools/profile.sh <tag> variable)
+        print(json.dumps({"variable_coefficient": variable_leg(n, (ia, ja, a, f, ue), itp, amgp, timed_solves)}), flush=True)
+        return
+
+    t0 = time.perf_counter()
+    H = fa.AMG(ia, ja, a, amgp)
+    t_setup = time.perf_counter() - t0
+    H.set_rhs(f)
+    log(f"AMG setup + upload: {t_setup:.2f} s, {H.num_levels} levels")
+
     elapsed, st, hist, stats, kernel_ms = timed_solves(H, args.warmup, args.steps)
     ms_per_step = 1e3 * elapsed / args.steps
     value = m * args.steps / elapsed
@@ -288,7 +341,7 @@ def main():
     kind, matrix_bytes = H.kernel_info(0, 0)
     moved = matrix_bytes + 8.0 * m + 8.0 * m   # stored matrix form + x once + y once (the dotted vector is x)
     coded = kind in (4, 5, 6)
-    roof = roofline_entry(kind, moved, kernel_ms, int(stats.spmv_launches) * args.steps,
+    roof = roofline_entry(kind, moved, kernel_ms, int(stats.spmv_launches) * args.steps, workload="constant", n=n,
                           note=("the operator is stored losslessly coded (2 bytes per row + a 27-entry pattern table): "
                                 "bytes_per_launch is what this kernel has to move, not SURVEY 8(d)'s plain-CSR figure "
                                 f"({B} B); the plain-CSR kernel of the same operator is timed in the same run: "
@@ -303,7 +356,7 @@ def main():
             pkind, _pb = H.kernel_info(0, 0)
             ms_plain = float(H.time_kernel(5, 0, 20))   # level-0 t = A p fused with (t,p), 20 launches
             L.fasp_hip_tune(b"compress", 1)
-            plain = roofline_entry(pkind, float(B), ms_plain, 20)
+            plain = roofline_entry(pkind, float(B), ms_plain, 20, workload="constant", n=n)
             log(f"plain-CSR level-0 SpMV: {ms_plain*1e3:.1f} us = {plain['achieved']:.0f} GB/s = {plain['frac']:.3f} of peak")
         except Exception as e:
             L.fasp_hip_tune(b"compress", 1)
@@ -353,28 +406,7 @@ def main():
     H.close()
 
     if not args.no_variable:
-        # Variable coefficients: -div(kappa grad u) on the same grid.  No two rows repeat, so no lossless
-        # coding applies and every level runs the plain-CSR kernels (what an application matrix sees).
-        try:
-            _ia, _ja, a2, f2 = fa.poisson7pt_var(n, (ia, ja, a, f, ue))
-            t0 = time.perf_counter()
-            H2 = fa.AMG(ia, ja, a2, amgp)
-            ts2 = time.perf_counter() - t0
-            H2.set_rhs(f2)
-            el2, st2, hist2, stats2, kms2 = timed_solves(H2, 1, 3)
-            k2, mb2 = H2.kernel_info(0, 0)
-            out["variable_coefficient"] = {
-                "workload": f"-div(kappa grad u) on the grid of P7({n}), kappa = 1 + 0.8 sin(2 pi x) sin(2 pi y) sin(2 pi z) "
-                            "(contrast 9, no repeated rows); same solver parameters; 3 timed solves",
-                "value": m * 3 / el2, "unit": "DOF/s", "ms_per_step": 1e3 * el2 / 3, "iterations": int(st2),
-                "relres": stats2.relres, "setup_seconds": ts2, "levels": H2.num_levels,
-                "roofline": roofline_entry(k2, mb2 + 16.0 * m, kms2, int(stats2.spmv_launches) * 3)}
-            log(f"variable-coefficient solve: {st2} iterations, {1e3*el2/3:.2f} ms/solve, level-0 kernel family {k2}, "
-                f"SpMV {kms2*1e3:.1f} us")
-            H2.close()
-        except Exception as e:
-            log(f"variable-coefficient solve failed: {e!r}")
-            out["variable_coefficient"] = None
+        out["variable_coefficient"] = variable_leg(n, (ia, ja, a, f, ue), itp, amgp, timed_solves)
     print(json.dumps(out), flush=True)
 
 

@@ -120,7 +120,7 @@ def main(args, rank, world, local_rank):
         moved = matrix_bytes + 8.0 * (nloc + info0["nghost"]) + 8.0 * nloc
         roof = B.roofline_entry(kind, moved, kernel_ms, int(stats.spmv_launches) * args.steps)
         roof["kernel"] = "rank 0, " + roof["kernel"]
-        roof["traffic"] = None; roof["traffic_GBps"] = None; roof["traffic_over_bytes"] = None  # PMC passes are single-GPU
+        # (traffic stays null: the PMC passes are single-GPU runs of the whole operator)
         out = {
             "metric": f"AMG-PCG solve DOF/s (3D 7-pt Poisson {n}^3, classical AMG V(1,1) w-Jacobi + PCG, rtol 1e-8)",
             "value": m * args.steps / elapsed, "unit": "DOF/s", "n_gpus": world, "steps": args.steps,
@@ -134,6 +134,19 @@ def main(args, rank, world, local_rank):
             "max_abs_error_vs_exact": err,
             "roofline": roof,
         }
+        if not args.no_cpu_baseline:
+            # the same routine as the single-GPU line: the oracle on this node's host cores, on rank 0 only, on a bounded
+            # sample of the same solve (rank 0 holds the global host hierarchy it published)
+            try:
+                allc = max(1, min(B.host_cores(), int(os.environ.get("BENCH_CPU_THREADS", "64"))))
+                cb, its_cpu, rr_cpu, hist_dev = B.cpu_baseline(H, ia, ja, a, f, int(st), hist,
+                                                               float(os.environ.get("BENCH_CPU_BUDGET_S", "15")), allc)
+                out["cpu_baseline"] = cb
+                out["parity"] = {"iters_gpu": int(st), "iters_cpu": its_cpu, "relres_gpu": stats.relres,
+                                 "relres_cpu": rr_cpu, "max_rel_dev_residual_history": hist_dev}
+            except Exception as e:
+                B.log(f"cpu_baseline failed: {e!r}")
+                out.setdefault("cpu_baseline", None)
         print(json.dumps(out), flush=True)
     H.close()
     L.fasp_hip_comm_finalize()

@@ -47,6 +47,8 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_comm_rank", "fasp_hip_comm_size", "fasp_hip_version", "fasp_hip_comm_init_shm",
     "fasp_hip_dist_plan", "fasp_hip_dist_level_info", "fasp_hip_dist_get_matrix",
     "fasp_hip_dist_get_list",
+    "fasp_blas_dcsr_vmv", "fasp_blas_dcsr_mxv_agg", "fasp_blas_dcsr_aAxpy_agg", "fasp_blas_darray_ax",
+    "fasp_blas_darray_axpyz", "fasp_blas_darray_norm1", "fasp_darray_cp", "fasp_darray_set", "fasp_dvec_isnan",
 ]
 
 
@@ -81,6 +83,18 @@ def lib():
     L.fasp_blas_darray_axpy.argtypes = [C.c_int, C.c_double, T.c_double_p, T.c_double_p]
     L.fasp_blas_darray_axpby.argtypes = [C.c_int, C.c_double, T.c_double_p, C.c_double,
                                          T.c_double_p]
+    L.fasp_blas_dcsr_vmv.restype = C.c_double
+    L.fasp_blas_dcsr_vmv.argtypes = [P(T.dCSRmat), T.c_double_p, T.c_double_p]
+    L.fasp_blas_dcsr_mxv_agg.argtypes = [P(T.dCSRmat), T.c_double_p, T.c_double_p]
+    L.fasp_blas_dcsr_aAxpy_agg.argtypes = [C.c_double, P(T.dCSRmat), T.c_double_p, T.c_double_p]
+    L.fasp_blas_darray_ax.argtypes = [C.c_int, C.c_double, T.c_double_p]
+    L.fasp_blas_darray_axpyz.argtypes = [C.c_int, C.c_double, T.c_double_p, T.c_double_p, T.c_double_p]
+    L.fasp_blas_darray_norm1.restype = C.c_double
+    L.fasp_blas_darray_norm1.argtypes = [C.c_int, T.c_double_p]
+    L.fasp_darray_cp.argtypes = [C.c_int, T.c_double_p, T.c_double_p]
+    L.fasp_darray_set.argtypes = [C.c_int, T.c_double_p, C.c_double]
+    L.fasp_dvec_isnan.restype = C.c_short
+    L.fasp_dvec_isnan.argtypes = [P(T.dvector)]
     L.fasp_smoother_dcsr_jacobi.argtypes = [P(T.dvector), C.c_int, C.c_int, C.c_int,
                                             P(T.dCSRmat), P(T.dvector), C.c_int, C.c_double]
     L.fasp_blas_dbsr_mxv.argtypes = [P(T.dBSRmat), T.c_double_p, T.c_double_p]

@@ -1306,6 +1306,32 @@ __global__ __launch_bounds__(BLOCK) void k_scale(int n, double a, double* __rest
 {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) x[i] *= a;
 }
+// x = v  (fasp_darray_set, AuxArray.c:41)
+__global__ __launch_bounds__(BLOCK) void k_set(int n, double v, double* __restrict__ x)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) x[i] = v;
+}
+// z = a*x + y  (fasp_blas_darray_axpyz, BlaArray.c:403; z may alias x or y)
+__global__ __launch_bounds__(BLOCK) void k_axpyz(int n, double a, const double* x, const double* y, double* z)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) z[i] = a * x[i] + y[i];
+}
+// q0 = sum |x_i| (fasp_blas_darray_norm1, BlaArray.c:663), q1 = number of NaN entries (fasp_dvec_isnan, AuxVector.c:39)
+__global__ __launch_bounds__(BLOCK) void k_norm1_nan(int n, const double* __restrict__ x, double* __restrict__ partials)
+{
+    __shared__ double lds[4];
+    double s = 0.0, nn = 0.0;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const double v = x[i];
+        s += fabs(v);
+        nn += (v != v) ? 1.0 : 0.0;
+    }
+    const int G = gridDim.x;
+    double v = block_sum(s, lds);
+    if (threadIdx.x == 0) partials[0 * G + blockIdx.x] = v;
+    v = block_sum(nn, lds);
+    if (threadIdx.x == 0) partials[1 * G + blockIdx.x] = v;
+}
 // y += a*y  (fasp_blas_darray_axpy called with x == y, KryPvgmres.c:395,398)
 __global__ __launch_bounds__(BLOCK) void k_axpy_self(int n, double a, double* __restrict__ y)
 {

@@ -1744,6 +1744,92 @@ void fasp_blas_darray_axpby(const int n, const double a, const double* x, const 
     dy.get(y);
 }
 
+// ---- the remaining names of SURVEY.md section 8 rows a10-a12 as stand-alone entries over the solve's own kernels ----
+// alpha = y' A x (BlaSpmvCSR.c:839): the fused SpMV + dot epilogue the coarse-scaling step of the cycle uses
+double fasp_blas_dcsr_vmv(const dCSRmat* A, const double* x, const double* y)
+{
+    TmpCSR M(A);
+    if (!M.ok) die_no_device(__func__);
+    TmpVec dx(x, A->col), dy(y, A->row), dt(nullptr, A->row);
+    CsrArgs a{}; a.x = dx.d; a.y = dt.d; a.dotv = dy.d; a.partials = g_ctx.d_partials;
+    const int G = launch_csr<OP_MXV_DOT>(M.D, a);
+    d_finalize(G, 1, 0u, 0, false);
+    double out = 0.0;
+    (void)fetch_red(0, 1, &out);
+    return out;
+}
+namespace {
+// the matrix of the *_agg kernels: the caller's pattern with unit entries (the reference never reads val there, and
+// 1.0 * x = x exactly, so the general kernels ARE the aggregation kernels: same sums, same order)
+struct TmpUnitCSR {
+    dCSRmat view;
+    std::vector<double> ones;
+    explicit TmpUnitCSR(const dCSRmat* A) : view(*A), ones((size_t)std::max(A->nnz, 1), 1.0) { view.val = ones.data(); }
+};
+}  // namespace
+void fasp_blas_dcsr_mxv_agg(const dCSRmat* A, const double* x, double* y)  // BlaSpmvCSR.c:438
+{
+    TmpUnitCSR U(A);
+    fasp_blas_dcsr_mxv(&U.view, x, y);
+}
+void fasp_blas_dcsr_aAxpy_agg(const double alpha, const dCSRmat* A, const double* x, double* y)  // BlaSpmvCSR.c:727
+{
+    TmpUnitCSR U(A);
+    fasp_blas_dcsr_aAxpy(alpha, &U.view, x, y);
+}
+void fasp_blas_darray_ax(const int n, const double a, double* x)  // BlaArray.c:43
+{
+    if (a == 1.0) return;
+    if (ctx_init() < 0) die_no_device(__func__);
+    TmpVec dx(x, n);
+    hipLaunchKernelGGL(k_scale, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, a, dx.d);
+    dx.get(x);
+}
+void fasp_blas_darray_axpyz(const int n, const double a, const double* x, const double* y, double* z)  // BlaArray.c:403
+{
+    if (ctx_init() < 0) die_no_device(__func__);
+    TmpVec dx(x, n), dy(y, n), dz(nullptr, n);
+    hipLaunchKernelGGL(k_axpyz, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, a, dx.d, dy.d, dz.d);
+    dz.get(z);
+}
+namespace {
+int norm1_nan(const char* fn, int n, const double* x, double out[2])
+{
+    if (ctx_init() < 0) die_no_device(fn);
+    TmpVec dx(x, n);
+    const int G = vec_grid(n);
+    hipLaunchKernelGGL(k_norm1_nan, dim3(G), dim3(BLOCK), 0, g_ctx.stream, n, dx.d, g_ctx.d_partials);
+    d_finalize(G, 2, 0u, 0, false);
+    return fetch_red(0, 2, out);
+}
+}  // namespace
+double fasp_blas_darray_norm1(const int n, const double* x)  // BlaArray.c:663
+{
+    double out[2] = {0, 0};
+    (void)norm1_nan(__func__, n, x, out);
+    return out[0];
+}
+short fasp_dvec_isnan(const dvector* u)  // AuxVector.c:39
+{
+    double out[2] = {0, 0};
+    (void)norm1_nan(__func__, u->row, u->val, out);
+    return out[1] > 0.0 ? 1 : 0;
+}
+void fasp_darray_cp(const int n, const double* x, double* y)  // AuxArray.c:210: through HBM (upload, device copy, download)
+{
+    if (ctx_init() < 0) die_no_device(__func__);
+    TmpVec dx(x, n), dy(nullptr, n);
+    (void)hipMemcpyAsync(dy.d, dx.d, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, g_ctx.stream);
+    dy.get(y);
+}
+void fasp_darray_set(const int n, double* x, const double val)  // AuxArray.c:41
+{
+    if (ctx_init() < 0) die_no_device(__func__);
+    TmpVec dx(nullptr, n);
+    hipLaunchKernelGGL(k_set, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, val, dx.d);
+    dx.get(x);
+}
+
 void fasp_blas_dbsr_mxv(const dBSRmat* A, const double* x, double* y)
 {
     TmpBSR M(A);

@@ -373,6 +373,18 @@ double fasp_blas_darray_norminf(const int n, const double* x);                  
 void   fasp_blas_darray_axpy(const int n, const double a, const double* x, double* y); /* BlaArray.c:90 */
 void   fasp_blas_darray_axpby(const int n, const double a, const double* x,
                               const double b, double* y);                             /* BlaArray.c:620 */
+/* the remaining kernel-level names of the path, host arrays in and out */
+double fasp_blas_dcsr_vmv(const dCSRmat* A, const double* x, const double* y);           /* BlaSpmvCSR.c:839  y' A x */
+void   fasp_blas_dcsr_mxv_agg(const dCSRmat* A, const double* x, double* y);             /* BlaSpmvCSR.c:438  unit entries, val unread */
+void   fasp_blas_dcsr_aAxpy_agg(const double alpha, const dCSRmat* A, const double* x,
+                                double* y);                                              /* BlaSpmvCSR.c:727 */
+void   fasp_blas_darray_ax(const int n, const double a, double* x);                      /* BlaArray.c:43 */
+void   fasp_blas_darray_axpyz(const int n, const double a, const double* x,
+                              const double* y, double* z);                               /* BlaArray.c:403 */
+double fasp_blas_darray_norm1(const int n, const double* x);                             /* BlaArray.c:663 */
+void   fasp_darray_cp(const int n, const double* x, double* y);                          /* AuxArray.c:210 */
+void   fasp_darray_set(const int n, double* x, const double val);                        /* AuxArray.c:41 */
+short  fasp_dvec_isnan(const dvector* u);                                                /* AuxVector.c:39 */
 void   fasp_smoother_dcsr_jacobi(dvector* u, const int i_1, const int i_n, const int s,
                                  dCSRmat* A, dvector* b, int L, const double w);      /* ItrSmootherCSR.c:98 */
 

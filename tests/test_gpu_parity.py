@@ -481,3 +481,62 @@ print("OK")
     env = dict(os.environ, FASP_HIP_SMALL_COARSE="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# --- stand-alone entries of the remaining a10-a12 names ---------------------------------------
+@pytest.mark.parametrize("n,m,avg", [(1, 1, 1), (300, 300, 3), (1000, 777, 7), (4097, 4097, 19), (700, 700, 700)])
+def test_vmv_and_agg_kernels(gpu, n, m, avg):
+    """fasp_blas_dcsr_vmv (BlaSpmvCSR.c:839), _mxv_agg (:438), _aAxpy_agg (:727) against the oracle's restatements.
+    The *_agg entries never read A->val (handed over as NULL here, as the reference's aggregation matrices may)."""
+    ia, ja, a = _rand_csr(n, m, avg, seed=3 * n + avg)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(m); yv = rng.standard_normal(n)
+    A, keep = T.as_csr(ia, ja, a, ncol=m)
+    L = gpu.lib(); O = oracle()
+    O.orc_vmv.restype = C.c_double
+    O.orc_vmv.argtypes = [C.POINTER(T.dCSRmat), T.c_double_p, T.c_double_p]
+    v_ref = O.orc_vmv(C.byref(A), T.dp(x), T.dp(yv))
+    v = L.fasp_blas_dcsr_vmv(C.byref(A), T.dp(x), T.dp(yv))
+    bound = sum(abs(yv[i]) * np.sum(np.abs(a[ia[i]:ia[i + 1]] * x[ja[ia[i]:ia[i + 1]]])) for i in range(n))
+    assert abs(v - v_ref) <= 1e-13 * max(bound, 1e-300)
+    U = T.dCSRmat(); U.row = A.row; U.col = A.col; U.nnz = A.nnz; U.IA = A.IA; U.JA = A.JA; U.val = None
+    O.orc_mxv_agg.argtypes = [C.POINTER(T.dCSRmat), T.c_double_p, T.c_double_p]
+    O.orc_aAxpy_agg.argtypes = [C.c_double, C.POINTER(T.dCSRmat), T.c_double_p, T.c_double_p]
+    rowabs = np.array([np.sum(np.abs(x[ja[ia[i]:ia[i + 1]]])) for i in range(n)])
+    y1 = np.zeros(n); y2 = np.ones(n)
+    O.orc_mxv_agg(C.byref(U), T.dp(x), T.dp(y1)); L.fasp_blas_dcsr_mxv_agg(C.byref(U), T.dp(x), T.dp(y2))
+    assert np.all(np.abs(y1 - y2) <= 1e-13 * rowabs + 1e-300)
+    for alpha in (1.0, -1.0, 0.7):
+        y0 = rng.standard_normal(n); y1 = y0.copy(); y2 = y0.copy()
+        O.orc_aAxpy_agg(alpha, C.byref(U), T.dp(x), T.dp(y1)); L.fasp_blas_dcsr_aAxpy_agg(alpha, C.byref(U), T.dp(x), T.dp(y2))
+        assert np.all(np.abs(y1 - y2) <= 1e-13 * (rowabs + np.abs(y0)) + 1e-300)
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 257, 100003])
+def test_array_entries(gpu, n):
+    """fasp_blas_darray_ax / _axpyz / _norm1 (BlaArray.c:43/403/663), fasp_darray_cp / _set (AuxArray.c:210/41),
+    fasp_dvec_isnan (AuxVector.c:39): elementwise results bit-exact, the norm to a few ulp of its value."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n); y = rng.standard_normal(n)
+    L = gpu.lib(); O = oracle()
+    O.orc_array_ax.argtypes = [C.c_int, C.c_double, T.c_double_p]
+    O.orc_axpyz.argtypes = [C.c_int, C.c_double, T.c_double_p, T.c_double_p, T.c_double_p]
+    O.orc_norm1.restype = C.c_double; O.orc_norm1.argtypes = [C.c_int, T.c_double_p]
+    for a in (1.0, -0.3, 1e300):
+        x1 = x.copy(); x2 = x.copy()
+        O.orc_array_ax(n, a, T.dp(x1)); L.fasp_blas_darray_ax(n, a, T.dp(x2))
+        assert np.array_equal(x1, x2)
+    z1 = np.zeros(n); z2 = np.ones(n)
+    O.orc_axpyz(n, 0.37, T.dp(x), T.dp(y), T.dp(z1)); L.fasp_blas_darray_axpyz(n, 0.37, T.dp(x), T.dp(y), T.dp(z2))
+    assert np.array_equal(z1, z2)
+    assert abs(L.fasp_blas_darray_norm1(n, T.dp(x)) - O.orc_norm1(n, T.dp(x))) <= 1e-13 * np.sum(np.abs(x))
+    c = np.zeros(n); L.fasp_darray_cp(n, T.dp(x), T.dp(c))
+    assert np.array_equal(c, x)
+    for v in (0.0, -2.5):
+        s = rng.standard_normal(n); L.fasp_darray_set(n, T.dp(s), v)
+        assert np.array_equal(s, np.full(n, v))
+    u = T.dvector(n, T.dp(x))
+    assert L.fasp_dvec_isnan(C.byref(u)) == 0
+    xn = x.copy(); xn[n // 2] = np.nan
+    u = T.dvector(n, T.dp(xn))
+    assert L.fasp_dvec_isnan(C.byref(u)) == 1

@@ -210,3 +210,46 @@ def test_coarse_spcg_bit_exact(R):
     s2 = R.ref_coarse_spcg(C.byref(Ac), C.byref(bv), C.byref(xv2), 1e-10)
     assert s1 == s2 and np.array_equal(x1, x2)
     O.free()
+
+
+def test_standalone_blas_restatements_equal_reference(R):
+    """orc_vmv / _mxv_agg / _aAxpy_agg / _array_ax / _axpyz / _norm1 against the compiled reference's functions of
+    SURVEY.md section 8 rows a10-a12, bit for bit (serial build: the same left-to-right loops)."""
+    O = oracle()
+    rng = np.random.default_rng(11)
+    n, m = 500, 431
+    ia = [0]; ja = []
+    for i in range(n):
+        cols = rng.choice(m, size=int(rng.integers(0, 12)), replace=False)
+        ja.extend(cols.tolist()); ia.append(len(ja))
+    ia = np.array(ia, np.int32); ja = np.array(ja, np.int32); a = rng.standard_normal(len(ja))
+    A, keep = T.as_csr(ia, ja, a, ncol=m)
+    x = rng.standard_normal(m); yv = rng.standard_normal(n)
+    P = C.POINTER
+    for lib, pre in ((O, "orc_"), (R, "fasp_blas_dcsr_")):
+        getattr(lib, pre + "vmv").restype = C.c_double
+        getattr(lib, pre + "vmv").argtypes = [P(T.dCSRmat), T.c_double_p, T.c_double_p]
+        getattr(lib, pre + "mxv_agg").argtypes = [P(T.dCSRmat), T.c_double_p, T.c_double_p]
+        getattr(lib, pre + "aAxpy_agg").argtypes = [C.c_double, P(T.dCSRmat), T.c_double_p, T.c_double_p]
+    assert O.orc_vmv(C.byref(A), T.dp(x), T.dp(yv)) == R.fasp_blas_dcsr_vmv(C.byref(A), T.dp(x), T.dp(yv))
+    y1 = np.zeros(n); y2 = np.ones(n)
+    O.orc_mxv_agg(C.byref(A), T.dp(x), T.dp(y1)); R.fasp_blas_dcsr_mxv_agg(C.byref(A), T.dp(x), T.dp(y2))
+    assert np.array_equal(y1, y2)
+    for alpha in (1.0, -1.0, 0.7):
+        y1 = yv.copy(); y2 = yv.copy()
+        O.orc_aAxpy_agg(alpha, C.byref(A), T.dp(x), T.dp(y1)); R.fasp_blas_dcsr_aAxpy_agg(alpha, C.byref(A), T.dp(x), T.dp(y2))
+        assert np.array_equal(y1, y2)
+    O.orc_array_ax.argtypes = [C.c_int, C.c_double, T.c_double_p]; R.fasp_blas_darray_ax.argtypes = O.orc_array_ax.argtypes
+    O.orc_axpyz.argtypes = [C.c_int, C.c_double, T.c_double_p, T.c_double_p, T.c_double_p]
+    R.fasp_blas_darray_axpyz.argtypes = O.orc_axpyz.argtypes
+    O.orc_norm1.restype = C.c_double; O.orc_norm1.argtypes = [C.c_int, T.c_double_p]
+    R.fasp_blas_darray_norm1.restype = C.c_double; R.fasp_blas_darray_norm1.argtypes = O.orc_norm1.argtypes
+    for s in (1.0, -0.3):
+        x1 = x.copy(); x2 = x.copy()
+        O.orc_array_ax(m, s, T.dp(x1)); R.fasp_blas_darray_ax(m, s, T.dp(x2))
+        assert np.array_equal(x1, x2)
+    xs = x[:n].copy() if m >= n else np.resize(x, n)
+    z1 = np.zeros(n); z2 = np.ones(n)
+    O.orc_axpyz(n, 0.37, T.dp(xs), T.dp(yv), T.dp(z1)); R.fasp_blas_darray_axpyz(n, 0.37, T.dp(xs), T.dp(yv), T.dp(z2))
+    assert np.array_equal(z1, z2)
+    assert O.orc_norm1(m, T.dp(x)) == R.fasp_blas_darray_norm1(m, T.dp(x))

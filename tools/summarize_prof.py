@@ -3,6 +3,9 @@ kernel trace, and per-kernel FETCH_SIZE / WRITE_SIZE per launch from the two PMC
 import csv, glob, os, sys, collections
 
 root = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else "constant"
+command = sys.argv[3] if len(sys.argv) > 3 else "bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variable"
+N = int(os.environ.get("BENCH_N", "256"))
 
 def find(sub, pat):
     g = glob.glob(os.path.join(root, sub, "**", pat), recursive=True)
@@ -29,7 +32,7 @@ def pmc(sub, counter):
 fetch = pmc("pmc_fetch", "FETCH_SIZE")
 write = pmc("pmc_write", "WRITE_SIZE")
 tot = sum(sum(v) for v in dur.values())
-print("# rocprofv3 summary (bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variable, P7(256))\n")
+print(f"# rocprofv3 summary (python3 {command}; workload: {workload} coefficients, n = {N})\n")
 print("| kernel | launches | mean us | total ms | % | FETCH_SIZE KB/launch (raw) | WRITE_SIZE KB/launch |")
 print("|---|---|---|---|---|---|---|")
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
@@ -54,7 +57,7 @@ for k, v in dur.items():
     kernels[k] = {"bytes_per_launch": (2.0 * sum(top) / len(top) + sum(topw) / len(topw)) * 1024.0,
                   "fetch_KB_raw": sum(top) / len(top), "write_KB": sum(topw) / len(topw),
                   "mean_us_largest_half": sum(topd) / len(topd), "launches": len(v)}
-json.dump({"command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variable (P7(256))",
+json.dump({"command": "python3 " + command, "workload": workload, "n": N,
            "note": "HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes); level-0 launches",
            "kernels": kernels}, open(os.path.join(root, "traffic.json"), "w"), indent=1)
 print("\n## traffic per launch (level-0 launches)\n")
