@@ -69,7 +69,7 @@ KERNELS = {0: ("k_csr_rows", "k_csr_rows<L, OP_MXV_DOT> (sub-wavefront per row, 
            2: ("k_csr_wstream<7, 64, 512>", "k_csr_wstream<OP_MXV_DOT,64,512> (wave-level stream, plain CSR)"),
            4: ("k_csr_dict8<7", "k_csr_dict8<OP_MXV_DOT> (one byte per entry: (column offset, value) dictionary)"),
            5: ("k_csr_rowpat<7", "k_csr_rowpat<OP_MXV_DOT> (one 16-bit row-pattern id per row)"),
-           6: ("k_csr_rowpat4<7>", "k_csr_rowpat4<OP_MXV_DOT> (16-bit row-pattern ids, scalar-pattern sweep + exception list)"),
+           6: ("k_csr_rowpat4<7>", "k_csr_rowpat4<OP_MXV_DOT> (16-bit row-pattern ids, scalar-pattern sweep, rows off the wave's pattern through an in-sweep LDS queue)"),
            7: ("k_csr_lstream<7, 512>", "k_csr_lstream<OP_MXV_DOT,512> (16-byte staged stream, lane = row, plain CSR)"),
            8: ("k_csr_wstream2<7>", "k_csr_wstream2<OP_MXV_DOT> (16-byte staged, prefetched wave stream, plain CSR)"),
            9: ("k_csr_rowpat5<7>", "k_csr_rowpat5<OP_MXV_DOT> (16-bit row-pattern ids, pair-of-patterns sweep, rectangular)"),

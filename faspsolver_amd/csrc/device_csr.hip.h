@@ -29,8 +29,7 @@ struct DevCSR {
     double* pval = nullptr;
     int     npat = 0, npent = 0;
     unsigned short* ja16 = nullptr;  // JA as 16-bit values (long-row operators with <= 65536 columns)
-    int*    xrows = nullptr;         // k_csr_rowpat4: rows outside their wave's uniform pattern (square coded operators)
-    int     nxrows = -1;             // -1: no list (k_csr_rowpat4 not applicable)
+    int     nxrows = -1;             // k_csr_rowpat4 / 5: rows outside their wave's uniform pattern(s); -1: the pair sweep does not apply
     // local operator of a row-partitioned level: the rows [win_lo, win_hi) read no ghost column (multiples of WIN_ALIGN
     // or the row count; win_hi < 0: no such window worth a split launch) -- they run while the halo is in flight
     int     win_lo = 0, win_hi = -1;
@@ -45,8 +44,7 @@ struct DevCSR {
         if (tptr) (void)hipFree(tptr);
         if (tcols) (void)hipFree(tcols);
         lja16 = nullptr; tptr = nullptr; tcols = nullptr;
-        if (xrows) (void)hipFree(xrows);
-        xrows = nullptr; nxrows = -1;
+        nxrows = -1;
         if (ja16) (void)hipFree(ja16);
         ja16 = nullptr;
         if (ia) (void)hipFree(ia);
@@ -521,37 +519,31 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
                 // k_csr_rowpat5 (kernels2.hip.h): the sweep computes the row pairs whose two patterns are those of the pair
                 // (128 w + 64, 128 w + 65) of their wave tile w; every other row goes on this list.
                 const int nr = H.row, npair = (nr + 1) / 2;
-                std::vector<int> xr;
+                long long nx = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nx)
                 for (int w0 = 0; w0 < nr; w0 += 128) {
                     const int    pm = std::min((w0 + 64) / 2, npair - 1);
                     const unsigned domA = pat[(size_t)2 * pm], domB = (2 * pm + 1 < nr) ? pat[(size_t)2 * pm + 1] : 0xffffu;   // (the device copy is padded with 0xffff)
                     for (int r = w0; r < std::min(w0 + 128, nr); r += 2) {
                         const bool vb = r + 1 < nr;
-                        if (!(vb && pat[r] == domA && pat[r + 1] == domB)) { xr.push_back(r); if (vb) xr.push_back(r + 1); }
+                        if (!(vb && pat[r] == domA && pat[r + 1] == domB)) nx += vb ? 2 : 1;
                     }
                 }
-                if ((long long)xr.size() * 4 <= nr) {
-                    D.nxrows = (int)xr.size();
-                    HIPCK(hipMalloc(&D.xrows, sizeof(int) * std::max<size_t>(xr.size(), 1)));
-                    HIPCK(hipMemcpy(D.xrows, xr.data(), sizeof(int) * xr.size(), hipMemcpyHostToDevice));
-                }
+                if (nx * 4 <= nr) D.nxrows = (int)nx;   // worth it when most rows are swept (the others go through the wave's queue)
             } else {
                 // k_csr_rowpat4 (kernels2.hip.h): the sweep computes the row pairs (2i, 2i+1) whose two rows have the
                 // pattern of row 128 w + 64 of their wave tile w; every other row goes on this list.
                 const int nr = H.row, npair = (nr + 1) / 2;
-                std::vector<int> xr;
+                long long nx = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nx)
                 for (int w0 = 0; w0 < nr; w0 += 128) {
                     const unsigned dom = pat[(size_t)2 * std::min((w0 + 64) / 2, npair - 1)];
                     for (int r = w0; r < std::min(w0 + 128, nr); r += 2) {
                         const bool vb = r + 1 < nr;
-                        if (!(vb && pat[r] == dom && pat[r + 1] == dom)) { xr.push_back(r); if (vb) xr.push_back(r + 1); }
+                        if (!(vb && pat[r] == dom && pat[r + 1] == dom)) nx += vb ? 2 : 1;
                     }
                 }
-                if ((long long)xr.size() * 4 <= nr) {  // worth it when most rows are swept
-                    D.nxrows = (int)xr.size();
-                    HIPCK(hipMalloc(&D.xrows, sizeof(int) * std::max<size_t>(xr.size(), 1)));
-                    HIPCK(hipMemcpy(D.xrows, xr.data(), sizeof(int) * xr.size(), hipMemcpyHostToDevice));
-                }
+                if (nx * 4 <= nr) D.nxrows = (int)nx;  // worth it when most rows are swept
             }
             D.kind = 2;  // plain-CSR twin of a coded operator: the stream kernel (same row-sum order; used by the A/B tests)
             return upload_plain() < 0 ? ERROR_ALLOC_MEM : FASP_SUCCESS;
@@ -639,7 +631,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, seq_ulds = 1, seq_graph = 0, xtile = 1, rp5_max = 45; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, seq_ulds = 1, seq_graph = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -729,23 +721,21 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
     const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : M.kind == 3 ? 1 : BLOCK / M.lanes;
     set_tiles(rpb);
     if (M.kind == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase && g_tune.rpl <= 0) {
-        // square row-pattern-coded operator: scalar-pattern sweep + exception list (kernels2.hip.h)
+        // square row-pattern-coded operator: scalar-pattern sweep, other rows through the wave's LDS queue (kernels2.hip.h)
         a.pat = M.pat; a.pstart = M.pstart; a.plen = M.plen; a.poff = M.poff; a.pval = M.pval;
         a.npat = M.npat; a.npent = M.npent; a.ncol = M.col; a.rowbase = nullptr;
-        a.xrows = M.xrows; a.nxrows = M.nxrows;
         set_tiles(2 * BLOCK);
-        a.xcd_map = a.ntiles >= 8 * 64 ? -1 : 16;  // slabs: x is fetched once per XCD (PMC: 0.18 GB instead of 0.45 GB per level-0 pass)
+        a.xcd_map = a.ntiles >= 8 * 64 ? g_tune.rp_xcd : 16;  // slabs: x is fetched once per XCD (PMC: 0.18 GB instead of 0.45 GB per level-0 pass)
         if (OP == OP_JACOBI && a.partials) g_jacobi_dot_done = true;
-        return launch_persistent(k_csr_rowpat4<OP>, a.ntiles, a, 5);
+        return launch_persistent(k_csr_rowpat4<OP>, a.ntiles, a, g_tune.rp_bpc);
     }
     // (measured on P7(256) level 0: prolongation, 1-6 entries per row, 140 -> 131 us; restriction, 7-13 entries per row,
     // 68 -> 80 us: the sweep pays for short lists only)
     if (M.kind == 5 && g_tune.gen2 >= 2 && M.nxrows >= 0 && M.rowbase && g_tune.rpl <= 0 && OP != OP_JACOBI && OP != OP_L1DIAG &&
         (double)M.nnz <= 0.1 * g_tune.rp5_max * M.row) {
-        // rectangular row-pattern-coded operator (R, P of the coded levels): pair-of-patterns sweep + exception list
+        // rectangular row-pattern-coded operator (R, P of the coded levels): pair-of-patterns sweep + LDS queue
         a.pat = M.pat; a.pstart = M.pstart; a.plen = M.plen; a.poff = M.poff; a.pval = M.pval;
         a.npat = M.npat; a.npent = M.npent; a.ncol = M.col; a.rowbase = M.rowbase;
-        a.xrows = M.xrows; a.nxrows = M.nxrows;
         set_tiles(2 * BLOCK);
         a.xcd_map = a.ntiles >= 8 * 64 ? -1 : 16;
         return launch_rowpat5<OP>(a);

@@ -71,8 +71,6 @@ struct CsrArgs {
     const int*    stop;     // != nullptr: the launch returns at once when *stop != 0 (queued-ahead iterations)
     const int*    mark;     // OP_L1DIAG only, != nullptr: C/F marker, the sweep is Jacobi on the F points (0) with weight omega
     const unsigned short* ja16;  // != nullptr: the column indices once more as 16-bit values (operators with <= 65536 columns)
-    const int*    xrows;    // k_csr_rowpat4: rows outside their wave's uniform pattern, computed lane = row after the sweep
-    int           nxrows;
     // row window of a launch (distributed levels: interior rows while the halo is in flight, boundary rows after it):
     // the launch covers the tiles tile0 .. tile0 + ntiles of the kernel's own tile size, i.e. the rows [row_lo, nrow)
     int           tile0, row_lo;

@@ -887,16 +887,23 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat3(CsrArgs a)
 // ---------------------------------------------------------------------------
 // k_csr_rowpat4<OP>: k_csr_rowpat3 without its divergent tail.  The sweep computes every row pair
 // whose two rows have the pattern of their wave's middle row (row 128 w + 64 of wave tile w) and stores
-// nothing for the others; those rows -- a list the host builds at upload with the same rule (domain
-// boundaries: 2-3 % of the rows of a 3-D stencil) -- are then computed lane = row, 8 gathers in flight, by
-// all blocks together (grid-stride over the list).  Pattern table read through the scalar cache in the
-// sweep, through the vector cache in the list pass.
+// nothing for the others; those rows (domain boundaries: 2-3 % of the rows of a 3-D stencil) are parked in
+// the wave's LDS queue and computed lane = row, 8 gathers in flight, 64 at a time by the wave that met
+// them -- while the x planes they read are still in this XCD's L2.  (Round 2 computed them from a list built
+// at upload, in a pass behind the sweep: its scattered 64-byte fetches were 0.2 GB of the 0.56 GB a level-0
+// pass of P7(256) moved.  Same time, less traffic: profiles/r03_coded_kernel_experiments.txt.)  Pattern table
+// read through the scalar cache in the sweep, through the vector cache for the queued rows.
 // ---------------------------------------------------------------------------
+constexpr int RP_QCAP = 192;   // per-wave queue of deferred rows: < 64 left over + at most 128 pushed by one step
 template <int OP>
 __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
 {
     if (a.stop && *a.stop) return;
     __shared__ double red[4];
+    __shared__ int xq[4 * RP_QCAP];
+    int* const myq = xq + (threadIdx.x >> 6) * RP_QCAP;
+    int        qn = 0;   // wave-uniform
+    const int  lane = threadIdx.x & 63;
     constexpr bool NEG = (OP == OP_JACOBI || OP == OP_L1DIAG);
     const __amdgpu_buffer_rsrc_t xr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.x), 0, (int)((unsigned)a.ncol * 8u), 0x00020000);
@@ -925,6 +932,50 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
     };
     auto ld_pp = [&](int r0) -> unsigned { return pat2[min((max(r0, 0) >> 1) + (int)threadIdx.x, npair - 1)]; };
 
+    // a row outside its wave's pattern: lane = row, its own list through the vector cache, 8 gathers in flight
+    auto one_row = [&](int r) {
+        const unsigned pid = a.pat[r];
+        const int      ps = a.pstart[pid], len = a.plen[pid];
+        const unsigned base = (unsigned)r * 8u;
+        double acc = NEG ? a.b[r] : 0.0, xi = 0.0, dgr = 0.0;
+        bool   hasd = false;
+        for (int k = 0; k < len; k += 8) {
+            int    of[8];
+            double xk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) of[u] = a.poff[ps + k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xk[u] = buf_load_f64(xr, base + (unsigned)(of[u] * 8));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double w = a.pval[ps + k + u];
+                const double pr = w * xk[u];
+                bool use = k + u < len;
+                if (OP == OP_JACOBI) {
+                    if (use && of[u] == 0) { xi = xk[u]; dgr = w; hasd = true; }
+                    use = use && of[u] != 0;
+                }
+                const double nxt = NEG ? acc - pr : acc + pr;
+                acc = use ? nxt : acc;
+            }
+        }
+        if (OP == OP_JACOBI) {
+            if (!hasd) xi = a.x[r];
+            const double xn = (fabs(dgr) > 1e-20) ? (1 - a.omega) * xi + a.omega * acc / dgr : xi;
+            a.y[r] = xn;
+            if (a.partials) dotacc += xn * a.b[r];
+        } else if (OP == OP_L1DIAG) {
+            a.y[r] = l1_or_jacobi_f(a, r, acc, a.diag[r], a.x[r]);
+        } else {
+            row_epilogue<OP>(a, r, acc, dotacc);
+        }
+    };
+    auto drain = [&](int n) {
+        wave_order();
+        const int r = lane < n ? myq[qn - n + lane] : -1;
+        if (r >= 0) one_row(r);
+        qn -= n;
+    };
     int      v = blockIdx.x;
     int      r0A = advance(v);
     unsigned pp = ld_pp(r0A);
@@ -1006,51 +1057,22 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
             if (mine) { dotacc += accA * aux.x; dotacc += accB * aux.y; }
         }
         if (mine) { pend_out = out; pend_off = (unsigned)ra * 8u; }
+        {   // pairs that are not the wave's pattern: queued, computed 64 rows at a time by this wave
+            const bool ex = ra <= last && !mine;
+            const unsigned long long exm = __ballot(ex);
+            if (exm) {
+                const int pos = qn + 2 * __popcll(exm & ((1ull << lane) - 1ull));
+                if (ex) { myq[pos] = ra; myq[pos + 1] = (ra + 1 <= last) ? ra + 1 : -1; }
+                qn += 2 * __popcll(exm);
+                while (qn >= 64) drain(64);
+            }
+        }
         r0A = r0B;
         pp = ppB;
     }
     flush();
 
-    // rows outside their wave's pattern: lane = row, own list, 8 gathers in flight
-    for (int i = blockIdx.x * BLOCK + (int)threadIdx.x; i < a.nxrows; i += G * BLOCK) {
-        const int      r = a.xrows[i];
-        if (r < a.row_lo || r >= a.nrow) continue;   // (windowed launch)
-        const unsigned pid = a.pat[r];
-        const int      ps = a.pstart[pid], len = a.plen[pid];
-        const unsigned base = (unsigned)r * 8u;
-        double acc = NEG ? a.b[r] : 0.0, xi = 0.0, dgr = 0.0;
-        bool   hasd = false;
-        for (int k = 0; k < len; k += 8) {
-            int    of[8];
-            double xk[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) of[u] = a.poff[ps + k + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xk[u] = buf_load_f64(xr, base + (unsigned)(of[u] * 8));
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const double w = a.pval[ps + k + u];
-                const double pr = w * xk[u];
-                bool use = k + u < len;
-                if (OP == OP_JACOBI) {
-                    if (use && of[u] == 0) { xi = xk[u]; dgr = w; hasd = true; }
-                    use = use && of[u] != 0;
-                }
-                const double nxt = NEG ? acc - pr : acc + pr;
-                acc = use ? nxt : acc;
-            }
-        }
-        if (OP == OP_JACOBI) {
-            if (!hasd) xi = a.x[r];
-            const double xn = (fabs(dgr) > 1e-20) ? (1 - a.omega) * xi + a.omega * acc / dgr : xi;
-            a.y[r] = xn;
-            if (a.partials) dotacc += xn * a.b[r];
-        } else if (OP == OP_L1DIAG) {
-            a.y[r] = l1_or_jacobi_f(a, r, acc, a.diag[r], a.x[r]);
-        } else {
-            row_epilogue<OP>(a, r, acc, dotacc);
-        }
-    }
+    if (qn > 0) drain(qn);
     if (OP == OP_MXV_DOT || (OP == OP_JACOBI && a.partials)) {
         const double tot = block_sum(dotacc, red);
         if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
@@ -1064,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
 // two patterns (C point: one entry; F point: its C neighbours), in one order along a grid line and the other along the
 // next -- both lists through the scalar cache.  x is gathered with 8-byte buffer loads (the two rows have unrelated
 // bases), y / the dotted vector move as 16-byte accesses, the store is deferred behind the next step's loads, pairs with
-// other patterns are left to the list pass (a.xrows, built at upload with the same rule).  OPs: MXV, ADD, SUB, AXPY,
+// other patterns go through the wave's LDS queue (k_csr_rowpat4).  OPs: MXV, ADD, SUB, AXPY,
 // RESID, MXV_DOT (no smoother runs on a rectangular operator).
 // ---------------------------------------------------------------------------
 template <int OP>
@@ -1073,6 +1095,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
     if (a.stop && *a.stop) return;
     static_assert(OP != OP_JACOBI && OP != OP_L1DIAG, "transfer operators are not smoothed");
     __shared__ double red[4];
+    __shared__ int xq[4 * RP_QCAP];
+    int* const myq = xq + (threadIdx.x >> 6) * RP_QCAP;
+    int        qn = 0;   // wave-uniform
+    const int  lane = threadIdx.x & 63;
     const __amdgpu_buffer_rsrc_t xr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.x), 0, (int)((unsigned)a.ncol * 8u), 0x00020000);
     const __amdgpu_buffer_rsrc_t yr =
@@ -1099,6 +1125,33 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
         }
     };
     auto pair_of = [&](int r0) -> int { return min((max(r0, 0) >> 1) + (int)threadIdx.x, npair - 1); };
+    // a row outside its wave's pattern pair: lane = row, its own list through the vector cache, 8 gathers in flight
+    auto one_row = [&](int r) {
+        const unsigned pid = a.pat[r];
+        const int      ps = a.pstart[pid], len = a.plen[pid];
+        const unsigned base = (unsigned)a.rowbase[r] * 8u;
+        double acc = 0.0;
+        for (int k = 0; k < len; k += 8) {
+            int    of[8];
+            double xk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) of[u] = a.poff[ps + k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xk[u] = buf_load_f64(xr, base + (unsigned)(of[u] * 8));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double pr = a.pval[ps + k + u] * xk[u];
+                acc = (k + u < len) ? acc + pr : acc;
+            }
+        }
+        row_epilogue<OP>(a, r, acc, dotacc);
+    };
+    auto drain = [&](int n) {   // (k_csr_rowpat4: the deferred rows of the sweep, 64 at a time, by the wave that met them)
+        wave_order();
+        const int r = lane < n ? myq[qn - n + lane] : -1;
+        if (r >= 0) one_row(r);
+        qn -= n;
+    };
     int      v = blockIdx.x;
     int      r0A = advance(v);
     unsigned pp = pat2[pair_of(r0A)];
@@ -1180,34 +1233,22 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
             if (mine) { dotacc += accA * aux.x; dotacc += accB * aux.y; }
         }
         if (mine) { pend_out = out; pend_off = (unsigned)ra * 8u; }
+        {   // pairs that are not the wave's pattern: queued, computed 64 rows at a time by this wave
+            const bool ex = ra <= last && !mine;
+            const unsigned long long exm = __ballot(ex);
+            if (exm) {
+                const int pos = qn + 2 * __popcll(exm & ((1ull << lane) - 1ull));
+                if (ex) { myq[pos] = ra; myq[pos + 1] = (ra + 1 <= last) ? ra + 1 : -1; }
+                qn += 2 * __popcll(exm);
+                while (qn >= 64) drain(64);
+            }
+        }
         r0A = r0B;
         pp = ppB;
     }
     flush();
 
-    // rows outside their wave's pattern pair: lane = row, own list, 8 gathers in flight
-    for (int i = blockIdx.x * BLOCK + (int)threadIdx.x; i < a.nxrows; i += G * BLOCK) {
-        const int      r = a.xrows[i];
-        if (r < a.row_lo || r >= a.nrow) continue;   // (windowed launch)
-        const unsigned pid = a.pat[r];
-        const int      ps = a.pstart[pid], len = a.plen[pid];
-        const unsigned base = (unsigned)a.rowbase[r] * 8u;
-        double acc = 0.0;
-        for (int k = 0; k < len; k += 8) {
-            int    of[8];
-            double xk[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) of[u] = a.poff[ps + k + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xk[u] = buf_load_f64(xr, base + (unsigned)(of[u] * 8));
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const double pr = a.pval[ps + k + u] * xk[u];
-                acc = (k + u < len) ? acc + pr : acc;
-            }
-        }
-        row_epilogue<OP>(a, r, acc, dotacc);
-    }
+    if (qn > 0) drain(qn);
     if (OP == OP_MXV_DOT) {
         const double tot = block_sum(dotacc, red);
         if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;

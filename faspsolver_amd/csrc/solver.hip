@@ -118,6 +118,20 @@ static int ctx_init()
     HIPCK(hipMalloc(&g_ctx.d_red, sizeof(double) * RED_SLOTS));
     HIPCK(hipHostMalloc(&g_ctx.h_red, sizeof(double) * RED_SLOTS, hipHostMallocDefault));
     g_ctx.ready = true;
+    // development knobs from the environment: FASP_HIP_TUNE="key=value,key=value" (the keys of fasp_hip_tune)
+    if (const char* tv = std::getenv("FASP_HIP_TUNE")) {
+        std::string all(tv);
+        size_t p0 = 0;
+        while (p0 < all.size()) {
+            size_t p1 = all.find(',', p0);
+            if (p1 == std::string::npos) p1 = all.size();
+            const std::string kv = all.substr(p0, p1 - p0);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos && fasp_hip_tune(kv.substr(0, eq).c_str(), std::atoi(kv.c_str() + eq + 1)) < 0)
+                std::fprintf(stderr, "### WARNING: fasp_hip: FASP_HIP_TUNE: unknown key in '%s'\n", kv.c_str());
+            p0 = p1 + 1;
+        }
+    }
     return FASP_SUCCESS;
 }
 
@@ -498,8 +512,8 @@ int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* k
     if (M.code && g_tune.compress) { k = 4; bytes = 1.0 * M.nnz + 4.0 * (M.row + 1.0) + (M.rowbase ? 4.0 * M.row : 0.0); }
     if (M.pat && g_tune.compress) { k = 5; bytes = 2.0 * M.row + (M.rowbase ? 4.0 * M.row : 0.0) + 12.0 * M.npent; }
     // second-generation kernels (kernels2.hip.h), same selection as launch_csr: 6 = k_csr_rowpat4, 7 = k_csr_lstream, 8 = k_csr_wstream2, 9 = k_csr_rowpat5, 10 = k_csr_xtile
-    if (k == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase) { k = 6; bytes += 4.0 * M.nxrows; }
-    else if (k == 5 && g_tune.gen2 >= 2 && M.nxrows >= 0 && M.rowbase && (double)M.nnz <= 0.1 * g_tune.rp5_max * M.row) { k = 9; bytes += 4.0 * M.nxrows; }   // k_csr_rowpat5
+    if (k == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase) k = 6;
+    else if (k == 5 && g_tune.gen2 >= 2 && M.nxrows >= 0 && M.rowbase && (double)M.nnz <= 0.1 * g_tune.rp5_max * M.row) k = 9;   // k_csr_rowpat5
     if (k == 2 && g_tune.gen2 && M.wrows == 64 && M.wcap == 512 && (double)M.nnz <= 7.6 * M.row) k = 7;
     else if (k == 2 && g_tune.gen2 >= 2 && g_tune.xtile && M.lja16 && M.wrows == 64 && M.wcap == 512) {   // k_csr_xtile
         k = 10;
@@ -1959,6 +1973,8 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_graph")) g_tune.seq_graph = value;
     else if (!std::strcmp(key, "xtile")) g_tune.xtile = value;
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
+    else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;
+    else if (!std::strcmp(key, "rp_xcd")) g_tune.rp_xcd = value;
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;
@@ -2035,6 +2051,58 @@ double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps)
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return (double)ms / reps;
+}
+
+
+// Development / test entry: one operator through the resident upload path (lossless coding, kernel selection as for a
+// hierarchy level) timed with HIP events on the launch stream.  op: 0 y = A x, 1 y -= A x, 2 Jacobi sweep, 5 y = A x
+// fused with (y, x).  Returns milliseconds per launch (< 0: error); *kind_out = kernel family as fasp_hip_amg_kernel_info.
+double fasp_hip_time_matrix(const dCSRmat* A, int op, int reps, int* kind_out)
+{
+    if (!A || reps <= 0 || ctx_init() < 0) return -1.0;
+    HostCSR M;
+    M.row = A->row; M.col = A->col; M.nnz = A->nnz;
+    M.ia.view(A->IA, (size_t)A->row + 1); M.ja.view(A->JA, (size_t)std::max(A->nnz, 1)); M.val.view(A->val, (size_t)std::max(A->nnz, 1));
+    DevCSR D;
+    {
+        HostThreads team;
+        if (upload_csr(M, D) < 0) { D.release(); return -1.0; }
+    }
+    const int n = A->row, nc = A->col;
+    double *x = nullptr, *y = nullptr, *w = nullptr, *dg = nullptr;
+    if (hipMalloc(&x, 8 * (size_t)std::max(nc, n)) != hipSuccess || hipMalloc(&y, 8 * (size_t)n) != hipSuccess ||
+        hipMalloc(&w, 8 * (size_t)n) != hipSuccess || hipMalloc(&dg, 8 * (size_t)n) != hipSuccess) { D.release(); return -1.0; }
+    (void)hipMemsetAsync(x, 0, 8 * (size_t)std::max(nc, n), g_ctx.stream);
+    (void)hipMemsetAsync(y, 0, 8 * (size_t)n, g_ctx.stream);
+    (void)hipMemsetAsync(w, 0, 8 * (size_t)n, g_ctx.stream);
+    hipLaunchKernelGGL(k_set, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, 1.0, dg);
+    auto run = [&]() {
+        switch (op) {
+            case 0: d_mxv(D, x, y); break;
+            case 1: d_aAxpy(-1.0, D, x, y); break;
+            case 2: { CsrArgs a{}; a.x = x; a.y = y; a.b = w; a.diag = dg; a.omega = 0.6667; launch_csr<OP_JACOBI>(D, a); } break;
+            default: { CsrArgs a{}; a.x = x; a.y = y; a.dotv = x; a.partials = g_ctx.d_partials; launch_csr<OP_MXV_DOT>(D, a); } break;
+        }
+    };
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    run(); run();
+    (void)hipEventRecord(e0, g_ctx.stream);
+    for (int i = 0; i < reps; ++i) run();
+    (void)hipEventRecord(e1, g_ctx.stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (kind_out) {
+        int k = D.kind;
+        if (D.code && g_tune.compress) k = 4;
+        if (D.pat && g_tune.compress) k = (D.nxrows >= 0 && g_tune.gen2) ? (D.rowbase ? 9 : 6) : 5;
+        *kind_out = k;
+    }
+    (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(dg);
+    D.release();
     return (double)ms / reps;
 }
 

@@ -110,7 +110,7 @@ static void run_variant(Case& C, const char* name, K kernel, int op, int rows_pe
     a.nt = g_nt; a.xcd_map = xcd;
     a.pat = M.pat; a.pstart = M.pstart; a.plen = M.plen; a.poff = M.poff; a.pval = M.pval; a.npat = M.npat; a.npent = M.npent;
     a.rowbase = M.rowbase;
-    a.xrows = g_xrows; a.nxrows = g_nxrows;
+
     a.ntiles = (M.row + rows_per_tile - 1) / rows_per_tile;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     const int save = g_tune.maxgrid;
