@@ -86,11 +86,12 @@ static bool build_persist_plan(fasp_hip_amg* h, int level)
     }
     bool ok = hipMalloc(&P.vals, tot * sizeof(double)) == hipSuccess && hipMalloc(&P.cols, tot * sizeof(unsigned short)) == hipSuccess &&
               hipMalloc(&P.wrow, sizeof(int) * (size_t)nw * 8) == hipSuccess && hipMalloc(&P.wend, sizeof(int) * (size_t)nw * 8) == hipSuccess &&
-              hipMalloc(&P.t2, sizeof(double) * 2 * (size_t)m) == hipSuccess && hipMalloc(&P.sync, 1024) == hipSuccess;
+              hipMalloc(&P.t2, sizeof(double) * 4 * (size_t)m) == hipSuccess && hipMalloc(&P.sync, 1024) == hipSuccess;   // t2: [2][m] 16-byte records
     if (ok) ok = hipMemcpy(P.vals, vals.data(), tot * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(P.cols, cols.data(), tot * sizeof(unsigned short), hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(P.wrow, wrow.data(), sizeof(int) * (size_t)nw * 8, hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(P.wend, wend.data(), sizeof(int) * (size_t)nw * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok = hipMemset(P.t2, 0, sizeof(double) * 4 * (size_t)m) == hipSuccess;   // epoch 0 is never waited for
     if (!ok) return false;
     P.NE = NE; P.nblocks = nblocks; P.ok = true;
     return true;
@@ -104,7 +105,8 @@ static int launch_spcg_persist(const SpcgPersistArgs& pa, size_t lds)
         HIPCK(hipFuncSetAttribute((const void*)k_spcg_persist<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(k_spcg_persist<NE>, dim3(pa.nblocks), dim3(512), lds, g_ctx.stream, pa);
+    // (fasp_hip_tune("spcg_test_hang", 1): one block short -- the others time out, the solve falls back; tests only)
+    hipLaunchKernelGGL(k_spcg_persist<NE>, dim3(pa.nblocks - (g_tune.spcg_test_hang ? 1 : 0)), dim3(512), lds, g_ctx.stream, pa);
     return FASP_SUCCESS;
 }
 
@@ -156,8 +158,8 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
     const bool fused = g_tune.spcg_fused && m <= 8000 && A.val && A.ja && !A.code && !A.pat;
     // one launch per coarse SOLVE with the matrix resident in the register files (k_spcg_persist): needs the chip to
     // itself (every block resident at once) -- not when several validation ranks share a device
-    const bool persist = fused && g_tune.spcg_persist && !g_persist_disabled && !comm_shares_devices() &&
-                         (size_t)m * 24 <= 150 * 1024 && build_persist_plan(h, (int)(&D - &h->L[0]));
+    bool persist = fused && g_tune.spcg_persist && !g_persist_disabled && !comm_shares_devices() &&
+                   (size_t)m * 24 <= 150 * 1024 && build_persist_plan(h, (int)(&D - &h->L[0]));
     if (!h->spcg_state) HIPCK(hipMalloc(&h->spcg_state, sizeof(SpcgState)));
     if (fused) {  // the start of the solve on the device too: no host round trip before the first batch
         if (!D.x_zero) d_resid(A, u, b, r);
@@ -217,8 +219,13 @@ ITERATE:
         }
         for (;;) {
             if (persist) {
-                const auto& PP = h->persist;
+                auto& PP = h->persist;
+                // epochs of this launch: (launch number) << 11 | iteration + 1 (max_steps <= 1002 < 2048); on wrap-around the
+                // records are cleared, so an old record can never carry a current epoch
+                PP.launches = (PP.launches + 1u) & 0x1fffffu;
+                if (PP.launches == 0u) { HIPCK(hipMemsetAsync(PP.t2, 0, sizeof(double) * 4 * (size_t)m, s)); PP.launches = 1u; }
                 SpcgPersistArgs pa{};
+                pa.epoch0 = PP.launches << 11;
                 pa.m = m; pa.max_steps = MaxIt + 2; pa.nblocks = PP.nblocks; pa.st = h->spcg_state;
                 pa.r = r; pa.p = p; pa.u = u; pa.u_best = u_best; pa.t2 = PP.t2; pa.sync = PP.sync;
                 pa.vals = PP.vals; pa.cols = PP.cols; pa.wrow = PP.wrow; pa.wend = PP.wend;
@@ -259,8 +266,15 @@ ITERATE:
                 else hipLaunchKernelGGL(k_spcg_step, dim3(1), dim3(SMALL_BLOCK), 0, s, sa);
             }
             HIPCK(hipMemcpyAsync(g_ctx.h_part, h->spcg_state, sizeof(SpcgState), hipMemcpyDeviceToHost, s));
+            static_assert(sizeof(SpcgState) % 8 == 0 && sizeof(SpcgState) + 16 <= sizeof(double) * 64, "the error word travels behind the state");
+            if (persist) HIPCK(hipMemcpyAsync(reinterpret_cast<char*>(g_ctx.h_part) + sizeof(SpcgState), h->persist.sync, 16, hipMemcpyDeviceToHost, s));
             HIPCK(hipStreamSynchronize(s));
             std::memcpy(&S, g_ctx.h_part, sizeof(S));
+            if (persist) {   // a block that gave up waiting raised the error word -- also when block 0 itself never ran
+                unsigned ew[4];
+                std::memcpy(ew, reinterpret_cast<char*>(g_ctx.h_part) + sizeof(SpcgState), 16);
+                if (ew[3] != 0u && S.stop == SPCG_RUN) S.stop = SPCG_HANG;
+            }
             iter = S.iter; absres_best = S.absres_best; iter_best = S.iter_best;
             batch = batch_next;
             if (fused) {
@@ -279,10 +293,18 @@ ITERATE:
             }
 #endif
             if (S.stop == SPCG_HANG) {
-                std::fprintf(stderr, "### ERROR: fasp_hip: the persistent coarse CG kernel timed out at its grid meeting (a block was not "
-                                     "resident: is another process using this GPU?); FASP_HIP_TUNE spcg_persist=0 selects the per-iteration kernels\n");
+                // A block of the persistent kernel was not resident (another process on this GPU, a concurrently resident
+                // kernel): a benign condition, not a failed solve.  r, p, u and the scalars are those of the last finished
+                // iteration -- this coarse solve goes on through the per-iteration kernels, and so do all later ones.
+                std::fprintf(stderr, "### WARNING: fasp_hip: the persistent coarse CG kernel timed out waiting for a block that was not "
+                                     "resident (is another process using this GPU?); continuing with the per-iteration kernels\n");
                 g_persist_disabled = true;
-                return ERROR_MISC;
+                persist = false;
+                S.stop = SPCG_RUN;
+                HIPCK(hipMemcpyAsync(h->spcg_state, &S, sizeof(S), hipMemcpyHostToDevice, s));
+                HIPCK(hipStreamSynchronize(s));  // S lives on this stack frame
+                cur = 0; first = true;
+                continue;
             }
             if (S.stop == SPCG_RUN) continue;
             if (fused && !persist) { cur = S.pad; r = R[cur]; p = P[cur]; first = true; }  // where the last finished step left r and p

@@ -72,7 +72,7 @@ struct fasp_hip_amg {
     SpcgState*           spcg_state = nullptr;  // device-resident state of the batched coarse CG
     // k_spcg_persist: the coarsest matrix dealt to the waves of the chip (built on first use; tried == true afterwards)
     struct Persist { bool tried = false, ok = false; int NE = 0, nblocks = 0; double* vals = nullptr; unsigned short* cols = nullptr;
-                     int *wrow = nullptr, *wend = nullptr; double* t2 = nullptr; unsigned* sync = nullptr; } persist;
+                     int *wrow = nullptr, *wend = nullptr; double* t2 = nullptr; unsigned* sync = nullptr; unsigned launches = 0; } persist;
     std::vector<double>  amli_coef;             // AMLI polynomial coefficients (amli_degree + 1), formed on first use
     std::vector<int>     level_cycle_type;      // AMG_data.cycle_type per level as the setup leaves it (K-cycle)
     bool                 use_fmg = false;       // the preconditioner is one full-multigrid cycle (precond_type == PREC_FMG)

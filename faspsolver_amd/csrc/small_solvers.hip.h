@@ -899,13 +899,17 @@ FINISHED:
 //   * Every block keeps r and p in its LDS and repeats the scalar recurrence on its own (same loads, same
 //     reduction order -> bit-identical alpha, beta, ||r|| in every block: k_spcg_fused's scheme); p is gathered
 //     from LDS by the row sums.
-//   * Per iteration ONE exchange: the waves publish t = A p (40 KB, write-through stores), the blocks meet at an
-//     arrival counter and read t back through L2 (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores,
-//     drained; one lane per workgroup adds to the counter behind the workgroup barrier; relaxed sc1 poll; sc1
-//     loads).  t and the stop word are double-buffered by iteration parity, so nothing read in an iteration is
-//     written in it.
+//   * Per iteration ONE exchange and no meeting (round 3): a finished row leaves as a self-validating 16-byte record
+//     {low word, epoch, high word, epoch} -- two 8-byte units, each atomic on its own, written with ONE write-through
+//     (sc1) store and nothing behind it: no drain of the stores, no arrival counter, no block barrier before the
+//     read.  Every block polls the m records with 16-byte sc1 loads until all carry this iteration's epoch; the
+//     epoch is unique over launches and iterations, the records are double-buffered by iteration parity (a block can
+//     run at most one iteration ahead of the slowest: it needs everybody's products to get further), so a stale
+//     record is never taken for a fresh one.  Round 2's meeting (stores drained, shard counter, top counter, poll:
+//     four L2 round trips, 3.9 of 12 us per iteration) is gone; what remains is store -> L2 -> load.
 //   * Block 0 owns no rows; it carries what nobody else needs (u, its norms, the best iterate, the reference's
-//     exit tests, KrySPcg.c:147-199) and raises the stop word; the others see it after the next meeting.
+//     exit tests, KrySPcg.c:147-199) and publishes its verdict as one more record, which every block polls with the
+//     products of the next iteration -- that also keeps the grid within one iteration of block 0.
 //   The host queues nothing: it reads the state once per solve and replays a fired test exactly as for
 //   k_spcg_fused (coarse_cg.hip.h).  Every spin is bounded (SPCG_HANG + error word).
 // ---------------------------------------------------------------------------
@@ -916,8 +920,9 @@ struct SpcgPersistArgs {
     int        u_lds;                  // the launch carries a fourth LDS vector: block 0 keeps u on chip
     SpcgState* st;
     double    *r, *p, *u, *u_best;     // r, p: in / out (block 0 writes them back at the end)
-    double*    t2;                     // [2][m] published products
-    unsigned*  sync;                   // [0] arrival counter, [1..2] stop word by parity, [3] error word; zeroed before the launch
+    double*    t2;                     // [2][m] published products as 16-byte records {lo, epoch, hi, epoch}
+    unsigned*  sync;                   // [3] error word, [8..11] block 0's verdict records {stop, epoch} by parity; zeroed before the launch
+    unsigned   epoch0;                 // epoch of iteration s of this launch: epoch0 + s + 1 (unique over launches)
     const double*         vals;        // [(nblocks-1)*8][NE][64]
     const unsigned short* cols;        // same shape: column * 8 (byte offset into p's LDS image)
     const int*            wrow;        // [(nblocks-1)*8][8] rows of the wave (-1: none)
@@ -960,7 +965,7 @@ __device__ __forceinline__ bool absres_improves(double rr, double best, double m
 template <int NE>
 __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
 {
-    constexpr int NT = 512, NW = 8, E = 12, EQ = 6, CH = 6;  // m <= E * NT = 6144; two waves per SIMD: 256 registers per lane
+    constexpr int NT = 512, NW = 8, E = 12, CH = 6;  // m <= E * NT = 6144; two waves per SIMD: 256 registers per lane
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ double sh[NW * 4];
     __shared__ int    s_flag;
@@ -973,9 +978,10 @@ __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
     double* sr = dyn + m;    // r
     double* st = dyn + 2 * m;  // t of this iteration, read back from the published copy
     double* su = dyn + 3 * m;  // block 0, a.u_lds: the iterate itself (written back once, at the end)
-    gu32* g_cnt = (gu32*)(a.sync);
-    gu32* g_stop = (gu32*)(a.sync + 1);
     gu32* g_err = (gu32*)(a.sync + 3);
+    gu64* g_verdict = (gu64*)(a.sync + 8);   // [parity]: {stop, epoch} of block 0
+    __shared__ int s_hang;
+    typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
     SpcgState& S = *a.st;
     if (S.stop != SPCG_RUN) return;   // (written before this launch: every block reads the same value)
 
@@ -1008,6 +1014,11 @@ __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
     double o_tp = S.tp, o_rr = S.rr, o_uu = S.uu, o_pp = S.pp, o_maxu = S.maxu, o_nan = S.nan, o_alpha = S.alpha,
            o_absres = S.absres, o_relres = S.relres, o_temp1_prev = S.temp1_prev;
     int steps_done = 0, my_stop = SPCG_RUN;
+    if (tid == 0) {
+        s_hang = 0;
+        if (lead)   // nothing to stop before the first iteration
+            __hip_atomic_store(g_verdict, ((unsigned long long)(a.epoch0 + 1u) << 32) | (unsigned)SPCG_RUN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
 #ifdef SPCG_PERSIST_STAMPS
     unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memrealtime();
@@ -1018,7 +1029,9 @@ __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
 
     for (int step = 0; step < a.max_steps; ++step) {
         const int par = step & 1;
-        double* tpub = a.t2 + (size_t)par * m;
+        const unsigned ep = a.epoch0 + (unsigned)step + 1u;
+        const __amdgpu_buffer_rsrc_t tr =
+            __builtin_amdgcn_make_buffer_rsrc(a.t2 + (size_t)par * 2 * m, 0, (int)((unsigned)m * 16u), 0x00020000);
         // ---- t = A p on the rows of this wave, p from LDS, matrix from registers ----
         if (!lead && my_rows > 0 && my_stop == SPCG_RUN) {
             double acc = 0.0;
@@ -1033,9 +1046,11 @@ __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
                 if (k + 1 == next_end) {   // wave-uniform: the row is complete
                     const double ssum = wave_sum_to_lane63(acc);
                     const int row = __builtin_amdgcn_readlane(rowsv, j);
-                    if (lane == 63)
-                        __hip_atomic_store((gu64*)(tpub + row), (unsigned long long)__double_as_longlong(ssum), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 63) {   // one write-through 16-byte store: {lo, epoch, hi, epoch}
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(ssum);
+                        const pu32x4 rec = {(unsigned)bits, ep, (unsigned)(bits >> 32), ep};
+                        __builtin_amdgcn_raw_buffer_store_b128(rec, tr, row * 16, 0, 16 /* sc1 */);
+                    }
                     acc = 0.0;
                     ++j;
                     next_end = (j < 8) ? __builtin_amdgcn_readlane(endsv, j & 7) : -1;
@@ -1043,58 +1058,52 @@ __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
                 }
             }
         }
-        // ---- meet: every storing wave drains its stores, the block's barrier, one lane adds, one lane polls ----
-        STAMP(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            // arrival in two stages: the blocks b, b + 8, ... (one XCD under round-robin placement -- for speed only) add to
-            // their shard; the last of a shard adds to the top counter, which every block polls
-            const unsigned shard = blockIdx.x & 7u;
-            const unsigned in_shard = ((unsigned)a.nblocks - shard + 7u) >> 3;
-            gu32* g_sh = (gu32*)(a.sync + 16 + 16 * shard);
-            if (__hip_atomic_fetch_add(g_sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard * (unsigned)(step + 1))
-                __hip_atomic_fetch_add(g_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned want = (unsigned)min(a.nblocks, 8) * (unsigned)(step + 1);
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            int ok = 1;
-            while (__hip_atomic_load(g_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(2);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz: a block is not resident
-                    __hip_atomic_store(g_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-            }
-            if (__hip_atomic_load(g_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
-            int flag = ok ? 0 : -1;
-            if (ok && step > 0) flag = (int)__hip_atomic_load(g_stop + ((step - 1) & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_flag = flag;
-        }
-        __syncthreads();
-        STAMP(1);
-        const int flag = s_flag;
-        if (flag != 0) { if (flag < 0) my_stop = SPCG_HANG; break; }   // the previous step raised a stop (or a hang): uniform over the grid
-        if (my_stop != SPCG_RUN) break;                                // (block 0 after its own verdict: it only had to arrive)
-        // ---- read t back (write-through stores of other CUs: sc1 loads, never the L1) ----
+        // ---- the exchange: poll the m records of this iteration (sc1 loads: never the L1) and block 0's verdict ----
         // (t, p and r live in LDS and are re-read pass by pass: the registers belong to the matrix)
+        STAMP(0);
         {
-            typedef unsigned int tu32x4 __attribute__((ext_vector_type(4)));
-            const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc(tpub, 0, (int)((unsigned)m * 8u), 0x00020000);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool hung = false;
 #pragma unroll 1
-            for (int e0 = 0; e0 < EQ; e0 += 6) {   // six 16-byte loads in flight per thread
-                tu32x4 q[6];
+            for (int e0 = 0; e0 < E && !hung; e0 += 6) {   // six records in flight per thread (more spill: the registers hold the matrix)
+                unsigned pend = 0u;
 #pragma unroll
-                for (int e = 0; e < 6; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(tr, (tid + (e0 + e) * NT) * 16, 0, 16 /* sc1 */);
+                for (int e = 0; e < 6; ++e) if (tid + (e0 + e) * NT < m) pend |= 1u << e;
+                while (pend) {
+                    pu32x4 q[6];
 #pragma unroll
-                for (int e = 0; e < 6; ++e) {
-                    const int i = 2 * (tid + (e0 + e) * NT);
-                    if (i + 1 < m) *reinterpret_cast<tu32x4*>(st + i) = q[e];
-                    else if (i < m) st[i] = __longlong_as_double((long long)(((unsigned long long)q[e].y << 32) | q[e].x));
+                    for (int e = 0; e < 6; ++e)
+                        q[e] = __builtin_amdgcn_raw_buffer_load_b128(tr, ((pend >> e) & 1u) ? (tid + (e0 + e) * NT) * 16 : (int)0xfffffff0u, 0, 16 /* sc1 */);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        if (((pend >> e) & 1u) && q[e].y == ep && q[e].w == ep) {
+                            st[tid + (e0 + e) * NT] = __longlong_as_double((long long)(((unsigned long long)q[e].z << 32) | q[e].x));
+                            pend &= ~(1u << e);
+                        }
+                    if (pend && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { hung = true; break; }   // 2 s at 100 MHz: a block is not resident
                 }
             }
+            if (tid == 0 && !hung) {
+                int flag = -1;
+                for (;;) {
+                    const unsigned long long vr = __hip_atomic_load(g_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(vr >> 32) == ep) { flag = (int)(unsigned)vr; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { hung = true; break; }
+                }
+                s_flag = flag;
+            }
+            if (hung) {
+                s_hang = 1;
+                __hip_atomic_store(g_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(1);
+        if (s_hang) { my_stop = SPCG_HANG; break; }
+        const int flag = s_flag;
+        if (flag != SPCG_RUN) break;                  // the previous iteration raised a stop: uniform over the grid
+        if (my_stop != SPCG_RUN) break;
         STAMP(2);
         // the vector passes run in chunks of 8 entries per thread: 8 LDS reads in flight, few registers (they hold the matrix)
         double v1[1] = {0.0};
@@ -1178,7 +1187,9 @@ __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
             o_tp = tp; o_rr = rr; o_uu = red[0]; o_pp = red[1]; o_maxu = red[2]; o_nan = red[3];
             o_alpha = alpha; o_absres = absres; o_relres = relres; o_temp1_prev = temp1;
             my_stop = stop;
-            if (tid == 0) __hip_atomic_store(g_stop + par, (unsigned)stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0)   // the verdict every block polls with the products of the next iteration
+                __hip_atomic_store(g_verdict + (par ^ 1), ((unsigned long long)(ep + 1u) << 32) | (unsigned)stop, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
         temp1 = rr;
         steps_done = step + 1;

@@ -1956,7 +1956,8 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "xcd_pat")) g_tune.xcd_pat = value;
     else if (!std::strcmp(key, "spcg_batch")) g_tune.spcg_batch = value;
     else if (!std::strcmp(key, "spcg_fused")) g_tune.spcg_fused = value;
-    else if (!std::strcmp(key, "spcg_persist")) g_tune.spcg_persist = value;
+    else if (!std::strcmp(key, "spcg_persist")) { g_tune.spcg_persist = value; if (value) g_persist_disabled = false; }
+    else if (!std::strcmp(key, "spcg_test_hang")) g_tune.spcg_test_hang = value;
     else if (!std::strcmp(key, "seq_persist")) g_tune.seq_persist = value;
     else if (!std::strcmp(key, "spcg_grid")) g_tune.spcg_grid = value;
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
