@@ -415,8 +415,7 @@ static int build_xtile(const HostCSR& H, DevCSR& D)
     double min_share = 2.5;
     if (const char* e = std::getenv("FASP_HIP_XTILE_MIN_SHARE")) min_share = std::atof(e);
     {   // a sample of the tiles first (every 61st): most operators are decided here, for a percent of the work
-        long long ent = 0, dist = 0;
-        bool fat = false;
+        long long ent = 0, dist = 0, nfat = 0, nsamp = 0;
         std::vector<int> cols;
         for (int t = 0; t < ntile; t += 61) {
             const int k0 = H.ia[t * 64], k1 = H.ia[std::min(H.row, t * 64 + 64)];
@@ -424,8 +423,10 @@ static int build_xtile(const HostCSR& H, DevCSR& D)
             std::sort(cols.begin(), cols.end());
             cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
             ent += k1 - k0; dist += (long long)cols.size();
-            if ((int)cols.size() > XT_XCAP) fat = true;
+            ++nsamp;
+            if ((int)cols.size() > XT_XCAP) ++nfat;
         }
+        const bool fat = nfat * 20 > nsamp;   // more than 5 % of the tiles beyond the LDS list
         if (fat || (double)dist * min_share > 1.1 * (double)ent) {
             if (std::getenv("FASP_HIP_SETUP_TIMING"))
                 std::printf("        [xtile %d x %d, %d nnz] sample: %.1f entries per distinct column%s: not built\n", H.row, H.col, H.nnz,
@@ -436,18 +437,21 @@ static int build_xtile(const HostCSR& H, DevCSR& D)
     std::vector<int> cnt((size_t)ntile + 1, 0);
     Buf<unsigned short> l16((size_t)H.nnz);
     std::vector<std::vector<int>> lists((size_t)ntile);
-    bool too_fat = false;
+    long long nfat_all = 0;
 #pragma omp parallel
     {
         std::vector<int> cols;
-#pragma omp for schedule(dynamic, 64)
+#pragma omp for schedule(dynamic, 64) reduction(+ : nfat_all)
         for (int t = 0; t < ntile; ++t) {
-            if (too_fat) continue;
             const int k0 = H.ia[t * 64], k1 = H.ia[std::min(H.row, t * 64 + 64)];
             cols.assign(H.ja.data() + k0, H.ja.data() + k1);
             std::sort(cols.begin(), cols.end());
             cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-            if ((int)cols.size() > XT_XCAP) { too_fat = true; continue; }
+            if ((int)cols.size() > XT_XCAP) {   // no list: the kernel gathers this tile's operands from global memory
+                for (int k = k0; k < k1; ++k) l16[k] = 0;
+                ++nfat_all;
+                continue;
+            }
             for (int k = k0; k < k1; ++k)
                 l16[k] = (unsigned short)(std::lower_bound(cols.begin(), cols.end(), H.ja[k]) - cols.begin());
             cnt[(size_t)t + 1] = (int)cols.size();
@@ -455,15 +459,15 @@ static int build_xtile(const HostCSR& H, DevCSR& D)
         }
     }
     static const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
-    if (too_fat) {
-        if (timing) std::printf("        [xtile %d x %d, %d nnz] a tile has more than %d distinct columns: not built\n", H.row, H.col, H.nnz, XT_XCAP);
+    if (nfat_all * 20 > ntile) {
+        if (timing) std::printf("        [xtile %d x %d, %d nnz] %lld of %d tiles have more than %d distinct columns: not built\n", H.row, H.col, H.nnz, nfat_all, ntile, XT_XCAP);
         return FASP_SUCCESS;
     }
     int fattest = 0;
     for (int t = 0; t < ntile; ++t) { fattest = std::max(fattest, cnt[(size_t)t + 1]); cnt[(size_t)t + 1] += cnt[(size_t)t]; }
     const long long total = cnt[(size_t)ntile];
-    if (timing) std::printf("        [xtile %d x %d, %d nnz] %lld distinct columns in %d tiles (%.1f entries per distinct column, fattest tile %d)\n",
-                            H.row, H.col, H.nnz, total, ntile, (double)H.nnz / std::max<long long>(total, 1), fattest);
+    if (timing) std::printf("        [xtile %d x %d, %d nnz] %lld distinct columns in %d tiles (%.1f entries per distinct column, fattest listed tile %d, %lld tiles without a list)\n",
+                            H.row, H.col, H.nnz, total, ntile, (double)H.nnz / std::max<long long>(total, 1), fattest, nfat_all);
     // worth it when the rows of a tile share their columns: >= 2.5 entries per distinct column (then 10 + 4 / 2.5 = 11.6
     // bytes per entry against 12, and 2.5 x fewer gathers).  AMG coarse levels in C-point order share little (P7(256):
     // 1.5 on level 1, > 1024 distinct columns per tile on level 2): they keep k_csr_wstream2 until their rows are

@@ -385,7 +385,8 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
 // distinct x entry ONCE per tile into the wave's LDS (a handful of well-clustered gathers) and the chunk loop --
 // 16-byte staged loads of the 16-bit indices and the values, products, left-to-right row sums -- never leaves the
 // LDS.  Bytes per entry 8 + 2 (+ ~0.7 for the lists) instead of 12; the arithmetic and its order are k_csr_wstream2's
-// (bit-identical results).  XCAP distinct columns per tile at most (the builder refuses matrices with a fatter tile).
+// (bit-identical results).  A tile with more than XCAP distinct columns has no list: its operands are gathered from
+// global memory (the builder accepts a few such tiles -- the seams of a clustered numbering).
 // ---------------------------------------------------------------------------
 constexpr int XT_XCAP = 1024;
 template <int OP>
@@ -440,9 +441,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_xtile(CsrArgs a)
         for (int q = 0; q < NV; ++q) reinterpret_cast<f64x2_t*>(sv)[lane + 64 * q] = qv[q];
     };
     // the distinct x entries of wave tile r0 / 64 into the wave's LDS (positions at or beyond the list read column 0)
-    auto stage_x = [&](int r0) {
+    auto stage_x = [&](int r0) -> int {
         const int t = r0 >> 6;
         const int p0 = a.tptr[t], n = a.tptr[t + 1] - p0;
+        if (n == 0) return 0;   // a fat tile (more than XT_XCAP distinct columns: no list) -- its operands come from global memory
         int    col[XR];
         double xv[XR];
 #pragma unroll
@@ -452,6 +454,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_xtile(CsrArgs a)
 #pragma unroll
         for (int q = 0; q < XR; ++q)
             if (64 * q < n) xl[lane + 64 * q] = xv[q];     // wave-uniform skip of the rounds beyond the list
+        return n;
     };
     constexpr int STEP = CAP - 8;
 
@@ -462,11 +465,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_xtile(CsrArgs a)
     advance(v, r0B, nrB);
     load_ia(r0B, nrB, kbB, keB);
     int k0 = 0, k1 = 0, lo = 0, hi = 0;
+    int nxA = 0;   // distinct columns of tile A in the wave's LDS image (0: fat tile, gather from global memory)
     if (r0A >= 0) {
         k0 = __builtin_amdgcn_readlane(kbA, 0); k1 = __builtin_amdgcn_readlane(keA, nrA - 1);
         lo = k0; hi = min(lo + STEP, k1);
         stage_load(lo & ~7, hi);
-        stage_x(r0A);
+        nxA = stage_x(r0A);
         stage_store();
     }
     wave_order();
@@ -496,8 +500,13 @@ __global__ __launch_bounds__(BLOCK) void k_csr_xtile(CsrArgs a)
             for (int u = 0; u < 8; ++u) c[u] = sj[lane + 64 * u];
 #pragma unroll
             for (int u = 0; u < 8; ++u) w[u] = sv[lane + 64 * u];
+            if (nxA > 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = xl[(s + lane + 64 * u < hi) ? c[u] : 0];
+                for (int u = 0; u < 8; ++u) xv[u] = xl[(s + lane + 64 * u < hi) ? c[u] : 0];
+            } else {   // wave-uniform, rare: a tile without an LDS image
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int k = s + lane + 64 * u; xv[u] = (k >= lo && k < hi) ? a.x[a.ja[k]] : 0.0; }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) sv[lane + 64 * u] = w[u] * xv[u];
             wave_order();
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_xtile(CsrArgs a)
             wave_order();
             if (last) {
                 if (lane < nrA) row_epilogue<OP>(a, r, acc, dotacc);
-                if (r0B >= 0) { stage_x(r0B); stage_store(); }
+                if (r0B >= 0) { nxA = stage_x(r0B); stage_store(); }
                 wave_order();
                 r0A = r0B; nrA = nrB; kbA = kbB; keA = keB;
                 r0B = r0C; nrB = nrC; kbB = kbC; keB = keC;

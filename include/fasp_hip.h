@@ -688,6 +688,8 @@ void fasp_hip_free_system(dCSRmat* A, dvector* b, dvector* u);
 double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps);
 /* development / test entry: one operator through the resident upload path (coding + kernel selection), ms per launch */
 double fasp_hip_time_matrix(const dCSRmat* A, int op, int reps, int* kind_out);
+/* development / test entry: brick-like cluster order of a square matrix from its graph (order[k] = old index at new position k) */
+int    fasp_hip_cluster_order(const dCSRmat* A, int chunk, int* order);
 /* measured device ceilings reported beside the roofline: out[0..2] = GB/s of a 16-byte-per-lane read, copy and
  * triad over buffers of `bytes` each (>= 512 MiB: beyond the Infinity Cache) */
 int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
