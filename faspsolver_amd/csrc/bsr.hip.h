@@ -141,7 +141,11 @@ static int bsr_seq_sweep(fasp_hip_amg_bsr* h, int level, bool descend, bool sor,
             case 1: BSEQ_LAUNCH(1); break;
             case 2: BSEQ_LAUNCH(2); break;
             case 3: BSEQ_LAUNCH(3); break;
-            default: return ERROR_INPUT_PAR;  // inverse diagonal blocks exist for nb <= 3 only
+            case 4: BSEQ_LAUNCH(4); break;
+            case 5: BSEQ_LAUNCH(5); break;
+            case 6: BSEQ_LAUNCH(6); break;
+            case 7: BSEQ_LAUNCH(7); break;
+            default: return ERROR_INPUT_PAR;
         }
 #undef BSEQ_LAUNCH
     }

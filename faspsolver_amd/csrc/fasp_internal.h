@@ -172,7 +172,7 @@ struct HostHierarchyBSR {
 // Unsmoothed aggregation on a block matrix (PreAMGSetupUABSR.c:55): VMB aggregation of the
 // condensed scalar matrix, identity-block prolongation, block Galerkin product.
 int host_setup_ua_bsr(const dBSRmat* A, AMG_param* param, HostHierarchyBSR& H);
-// inverse diagonal blocks (BlaSparseBSR.c:543), nb <= 3 closed forms
+// inverse diagonal blocks (BlaSparseBSR.c:543 -> fasp_smat_inv): closed forms for nb = 2, 3, 4, pivoting Gauss-Jordan for 5..7
 int bsr_diaginv(const dBSRmat* A, double* out);
 int check_supported_bsr(const ITS_param* itparam, const AMG_param* amgparam, int nb);
 

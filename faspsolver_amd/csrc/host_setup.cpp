@@ -2024,9 +2024,75 @@ void galerkin_rap_bsr(const HostBSR& R, const HostBSR& A, const HostBSR& P, Host
 
 }  // namespace
 
+namespace {
+// fasp_smat_inv_nc4 (BlaSmallMatInv.c:111): adjugate over determinant.  Cofactor m is the sum of three products of the
+// listed entries minus three more, accumulated left to right -- the reference's grouping, so the inverse is bit-identical.
+const unsigned char kCof4[16][6][3] = {
+    {{5,10,15},{6,11,13},{7,9,14},{5,11,14},{6,9,15},{7,10,13}}, {{1,11,14},{2,9,15},{3,10,13},{1,10,15},{2,11,13},{3,9,14}},
+    {{1,6,15},{2,7,13},{3,5,14},{1,7,14},{2,5,15},{3,6,13}},     {{1,7,10},{2,5,11},{3,6,9},{1,6,11},{2,7,9},{3,5,10}},
+    {{4,11,14},{6,8,15},{7,10,12},{4,10,15},{6,11,12},{7,8,14}}, {{0,10,15},{2,11,12},{3,8,14},{0,11,14},{2,8,15},{3,10,12}},
+    {{0,7,14},{2,4,15},{3,6,12},{0,6,15},{2,7,12},{3,4,14}},     {{0,6,11},{2,7,8},{3,4,10},{0,7,10},{2,4,11},{3,6,8}},
+    {{4,9,15},{5,11,12},{7,8,13},{4,11,13},{5,8,15},{7,9,12}},   {{0,11,13},{1,8,15},{3,9,12},{0,9,15},{1,11,12},{3,8,13}},
+    {{0,5,15},{1,7,12},{3,4,13},{0,7,13},{1,4,15},{3,5,12}},     {{0,7,9},{1,4,11},{3,5,8},{0,5,11},{1,7,8},{3,4,9}},
+    {{4,10,13},{5,8,14},{6,9,12},{4,9,14},{5,10,12},{6,8,13}},   {{0,9,14},{1,10,12},{2,8,13},{0,10,13},{1,8,14},{2,9,12}},
+    {{0,6,13},{1,4,14},{2,5,12},{0,5,14},{1,6,12},{2,4,13}},     {{0,5,10},{1,6,8},{2,4,9},{0,6,9},{1,4,10},{2,5,8}}};
+void block_inv4(double* a)
+{
+    double c[16], cof[16];
+    std::memcpy(c, a, sizeof(c));
+    for (int m = 0; m < 16; ++m) {
+        double v = 0.0;
+        for (int q = 0; q < 6; ++q) {
+            const double pr = c[kCof4[m][q][0]] * c[kCof4[m][q][1]] * c[kCof4[m][q][2]];
+            v = q == 0 ? pr : (q < 3 ? v + pr : v - pr);
+        }
+        cof[m] = v;
+    }
+    const double det = c[0] * cof[0] + c[1] * cof[4] + c[2] * cof[8] + c[3] * cof[12];
+    if (std::fabs(det) < SMALLREAL) { for (int m = 0; m < 16; ++m) a[m] = (m % 5 == 0) ? 1.0 : 0.0; return; }
+    const double det_inv = 1.0 / det;
+    for (int m = 0; m < 16; ++m) a[m] = cof[m] * det_inv;
+}
+// fasp_smat_invp_nc (BlaSmallMatInv.c:508; what fasp_smat_inv runs for n >= 5): in-place Gauss-Jordan elimination with
+// full pivoting -- pivot = the LAST entry of largest magnitude among the rows and columns not yet used, row swap onto the
+// diagonal, scaling, elimination of the column, columns unscrambled at the end.  A pivot below SMALLREAL stops it.
+int block_inv_pivot(double* a, int n)
+{
+    int prow_of[8], pcol_of[8], taken[8];
+    for (int j = 0; j < n; ++j) taken[j] = 0;
+    for (int step = 0; step < n; ++step) {
+        double big = 0.0;
+        int pr = 0, pc = 0;
+        for (int j = 0; j < n; ++j)
+            if (taken[j] != 1)
+                for (int k = 0; k < n; ++k)
+                    if (taken[k] == 0 && std::fabs(a[j * n + k]) >= big) { big = std::fabs(a[j * n + k]); pr = j; pc = k; }
+        ++taken[pc];
+        if (pr != pc)
+            for (int l = 0; l < n; ++l) std::swap(a[pr * n + l], a[pc * n + l]);
+        prow_of[step] = pr; pcol_of[step] = pc;
+        double& piv = a[pc * n + pc];
+        if (std::fabs(piv) < SMALLREAL) return ERROR_SOLVER_EXIT;
+        const double pinv = 1.0 / piv;
+        piv = 1.0;
+        for (int l = 0; l < n; ++l) a[pc * n + l] *= pinv;
+        for (int r = 0; r < n; ++r) {
+            if (r == pc) continue;
+            const double f = a[r * n + pc];
+            a[r * n + pc] = 0.0;
+            for (int l = 0; l < n; ++l) a[r * n + l] -= a[pc * n + l] * f;
+        }
+    }
+    for (int step = n - 1; step >= 0; --step)
+        if (prow_of[step] != pcol_of[step])
+            for (int k = 0; k < n; ++k) std::swap(a[k * n + prow_of[step]], a[k * n + pcol_of[step]]);
+    return FASP_SUCCESS;
+}
+}  // namespace
+
 int bsr_diaginv(const dBSRmat* A, double* out)
 {
-    if (!A || A->nb < 1 || A->nb > 3) return ERROR_INPUT_PAR;
+    if (!A || A->nb < 1 || A->nb > 7) return ERROR_INPUT_PAR;
     const int nb = A->nb, nb2 = nb * nb;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < A->ROW; ++i) {
@@ -2036,6 +2102,10 @@ int bsr_diaginv(const dBSRmat* A, double* out)
             if (A->JA[k] == i) std::memcpy(a, A->val + (size_t)k * nb2, sizeof(double) * nb2);
         if (nb == 1) {
             a[0] = 1.0 / a[0];
+        } else if (nb == 4) {
+            block_inv4(a);
+        } else if (nb > 4) {   // fasp_smat_inv's default branch (the nc5 closed form is switched off there: `case -5`)
+            (void)block_inv_pivot(a, nb);
         } else if (nb == 2) {  // fasp_smat_inv_nc2, BlaSmallMatInv.c:33
             const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
             const double det = a0 * a3 - a1 * a2;
@@ -2142,8 +2212,8 @@ int host_setup_ua_bsr(const dBSRmat* A, AMG_param* param, HostHierarchyBSR& H)
 // Parameter combinations of the block path with a device implementation
 int check_supported_bsr(const ITS_param* it, const AMG_param* amg, int nb)
 {
-    if (nb < 1 || nb > 3) {
-        std::printf("### ERROR: fasp_hip: BSR AMG needs 1 <= nb <= 3 (closed-form block inverses), got %d\n", nb);
+    if (nb < 1 || nb > 7) {
+        std::printf("### ERROR: fasp_hip: BSR AMG needs 1 <= nb <= 7 (block kernels), got %d\n", nb);
         return ERROR_INPUT_PAR;
     }
     if (amg) {

@@ -1481,12 +1481,12 @@ int fasp_solver_dbsr_krylov(dBSRmat* A, dvector* b, dvector* x, ITS_param* itpar
     if (itparam->print_level >= PRINT_MIN) std::printf("Krylov method totally costs %.4f seconds.\n", wall_seconds() - t0);
     return status;
 }
-// SolBSR.c:186: block-diagonal preconditioner, inverse blocks by fasp_smat_inv (nb <= 3 here)
+// SolBSR.c:186: block-diagonal preconditioner, inverse blocks by fasp_smat_inv
 int fasp_solver_dbsr_krylov_diag(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam)
 {
     if (!A || !itparam || !A->IA || !A->JA || !A->val) return ERROR_INPUT_PAR;
-    if (A->nb < 1 || A->nb > 3) {
-        std::printf("### ERROR: fasp_hip: block-diagonal preconditioner needs 1 <= nb <= 3, got %d\n", A->nb);
+    if (A->nb < 1 || A->nb > 7) {
+        std::printf("### ERROR: fasp_hip: block-diagonal preconditioner needs 1 <= nb <= 7, got %d\n", A->nb);
         return ERROR_INPUT_PAR;
     }
     const double t0 = wall_seconds();
@@ -1865,13 +1865,13 @@ void fasp_blas_dbsr_aAxpy(const double alpha, const dBSRmat* A, const double* x,
     dy.get(y);
 }
 
-// BlaSparseBSR.c:543 (host): diagonal blocks inverted with the reference's closed forms
-// (fasp_smat_inv_nc2 / _nc3, BlaSmallMatInv.c:33 / :67); nb == 1: reciprocals
+// BlaSparseBSR.c:543 (host): diagonal blocks inverted as fasp_smat_inv does (BlaSmallMatInv.c:603): closed forms for
+// nb = 2, 3, 4, Gauss-Jordan with full pivoting for 5..7; nb == 1: reciprocals
 dvector fasp_dbsr_getdiaginv(const dBSRmat* A)
 {
     dvector out{0, nullptr};
-    if (!A || A->nb < 1 || A->nb > 3) {
-        std::fprintf(stderr, "### ERROR: fasp_dbsr_getdiaginv: block size %d not supported (1..3)\n", A ? A->nb : -1);
+    if (!A || A->nb < 1 || A->nb > 7) {
+        std::fprintf(stderr, "### ERROR: fasp_dbsr_getdiaginv: block size %d not supported (1..7)\n", A ? A->nb : -1);
         return out;
     }
     out.row = A->ROW * A->nb * A->nb;

@@ -61,6 +61,7 @@ extern "C" {
 #define ERROR_SOLVER_TOLSMALL (-44)
 #define ERROR_SOLVER_MISC     (-46)
 #define ERROR_SOLVER_MAXIT    (-48)
+#define ERROR_SOLVER_EXIT     (-49)
 #define ERROR_UNKNOWN         (-99)
 
 #define PRINT_NONE 0

@@ -28,6 +28,18 @@ def synthetic(n, seed=1):
     return ia, ja, val, nb, f
 
 
+def block_system(n, nb, seed=7):
+    """P7(n) (x) B with a random, diagonally dominant, non-symmetric nb x nb block B: exercises the block inverses of
+    fasp_smat_inv (closed forms nb <= 4, pivoting Gauss-Jordan beyond) and every block kernel width."""
+    from _libs import poisson7pt
+    rng = np.random.default_rng(seed + nb)
+    Bk = rng.standard_normal((nb, nb)) + np.diag(nb + rng.random(nb))
+    ia, ja, a, f0, ue = poisson7pt(n)
+    val = (a[:, None, None] * Bk[None, :, :]).reshape(-1)
+    f = rng.standard_normal((len(ia) - 1) * nb)
+    return ia, ja, val, nb, f
+
+
 def ref_hierarchy(ia, ja, val, nb, amgp):
     _, R = bsr_protos()
     A, keep = T.as_bsr(ia, ja, val, nb)
@@ -76,6 +88,33 @@ def test_oracle_hierarchy_equals_reference(name, make, agg):
             assert same_matrix(lo[nm], lr[nm]), nm
         if lr["diaginv"] is not None:
             assert np.array_equal(lo["diaginv"], lr["diaginv"])
+
+
+@needs_ref
+@pytest.mark.parametrize("nb", [2, 4, 5, 6, 7])
+def test_block_sizes_oracle_and_product_equal_reference(nb):
+    """Block sizes beyond 3 (BlaSparseBSR.c:543 -> fasp_smat_inv, BlaSmallMatInv.c:603: cofactors for nb = 4, Gauss-Jordan
+    with full pivoting for nb >= 5): inverse diagonal blocks and hierarchies of the oracle AND of the product's host setup
+    bit-identical to the compiled reference; a whole block-Jacobi VGMRES solve of the oracle equal to the reference's."""
+    ia, ja, val, nb, f = block_system(10, nb)
+    _, p1 = bsr_params(); _, p2 = bsr_params(); _, p3 = bsr_params()
+    H = OrcBSR(ia, ja, val, nb, p1)
+    ref_levels = ref_hierarchy(ia, ja, val, nb, p2)
+    G = fa.BSRAMG(ia, ja, val, nb, p3, host_only=True)
+    assert H.num_levels == len(ref_levels) == G.num_levels and H.num_levels >= 2
+    for l, (lo, lr) in enumerate(zip(H.levels, ref_levels)):
+        for w, nm in enumerate(("A", "P", "R")):
+            assert same_matrix(lo[nm], lr[nm]), nm
+            if lr[nm] is not None:
+                assert same_matrix(G.matrix(l, w), lr[nm]), ("product", nm)
+        if lr["diaginv"] is not None:
+            assert np.array_equal(lo["diaginv"], lr["diaginv"])
+            assert np.array_equal(G.diaginv(l), lr["diaginv"])
+    G.free()
+    i1, a1 = bsr_params(5, 1); i2, a2 = bsr_params(5, 1)
+    s1, x1, nl, rr = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    s2, x2 = ref_bsr_solve(ia, ja, val, nb, f, i2, a2)
+    assert s1 == s2 and s1 > 0 and np.array_equal(x1, x2)
 
 
 @needs_ref
@@ -178,6 +217,23 @@ def test_oracle_block_gs_sor_equals_reference(solver, cycle, n, sm, agg):
     s2, x2 = ref_bsr_solve(ia, ja, val, nb, f, i2, a2)
     assert s1 == s2 and s1 > 0
     assert np.array_equal(x1, x2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sm", [T.SMOOTHER_JACOBI, T.SMOOTHER_GS, T.SMOOTHER_SOR], ids=["jacobi", "GS", "SOR"])
+@pytest.mark.parametrize("nb", [2, 4, 5, 6, 7])
+def test_gpu_block_sizes_match_oracle(nb, sm):
+    """Device block kernels (SpMV, block Jacobi, level-scheduled block GS / SOR, coarse GMRES) at every width up to 7."""
+    ia, ja, val, nb, f = block_system(12, nb)
+    i1, a1 = bsr_params(5, 1); i2, a2 = bsr_params(5, 1)
+    _smoother(a1, sm); _smoother(a2, sm)
+    s1, x1, nl, rr1 = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    G = fa.BSRAMG(ia, ja, val, nb, a2)
+    s2, x2, hist, stats = G.solve(f, i2)
+    assert G.num_levels == nl and s2 == s1, (s1, s2)
+    assert np.abs(x1 - x2).max() <= 1e-10 * np.abs(x1).max()
+    assert abs(stats.relres - rr1) <= 1e-10
+    G.free()
 
 
 @pytest.mark.gpu
