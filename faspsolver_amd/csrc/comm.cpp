@@ -137,6 +137,12 @@ int  shm_timeout_s()
     if (t < 0) { const char* e = std::getenv("FASP_HIP_SHM_TIMEOUT_S"); t = e ? std::atoi(e) : 300; if (t <= 0) t = 300; }
     return t;
 }
+// Returns 0, SHM_PEER_ERROR (a rank raised the error flag before this barrier released) or SHM_TIMEOUT (a peer never
+// arrived: the caller must NOT enter another barrier of this collective -- it has already counted itself in and the
+// generation it would wait for can never come).  The error word holds the generation (+ 1) in which it was raised, so
+// a barrier only reports errors raised up to its own release: a fast peer that fails in the NEXT collective does not
+// make a slow rank fail the previous one (and then skip the next).
+constexpr int SHM_PEER_ERROR = -1, SHM_TIMEOUT = -2;
 int shm_barrier()
 {
     ShmHeader* h = shm_hdr();
@@ -153,16 +159,24 @@ int shm_barrier()
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (double)shm_timeout_s()) {
                 std::fprintf(stderr, "### ERROR: fasp_hip: rank %d waited %d s at a shared-memory barrier: a peer is gone\n",
                              g_rank, shm_timeout_s());
-                h->error.store(1, std::memory_order_release);
+                int none = 0;
+                h->error.compare_exchange_strong(none, gen + 1, std::memory_order_acq_rel);
                 g_comm_failed = true;
-                return ERROR_MISC;
+                return SHM_TIMEOUT;
             }
         }
     }
-    if (h->error.load(std::memory_order_acquire)) { g_comm_failed = true; return ERROR_MISC; }
+    const int err = h->error.load(std::memory_order_acquire);
+    if (err != 0 && err <= gen + 1) { g_comm_failed = true; return SHM_PEER_ERROR; }
     return FASP_SUCCESS;
 }
-void shm_raise_error() { shm_hdr()->error.store(1, std::memory_order_release); g_comm_failed = true; }
+void shm_raise_error()   // (raised before the collective's first barrier releases: stamped with the current generation)
+{
+    ShmHeader* h = shm_hdr();
+    int none = 0;
+    h->error.compare_exchange_strong(none, h->generation.load(std::memory_order_acquire) + 1, std::memory_order_acq_rel);
+    g_comm_failed = true;
+}
 
 }  // namespace
 
@@ -181,7 +195,7 @@ int comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream)
                      hipStreamSynchronize(stream) == hipSuccess;
         if (ok) std::memcpy(box_data(g_rank), g_stage, sizeof(double) * n);
         else shm_raise_error();
-        if (shm_barrier() < 0) { (void)shm_barrier(); return ERROR_MISC; }
+        { const int bs = shm_barrier(); if (bs < 0) { if (bs != SHM_TIMEOUT) (void)shm_barrier(); return ERROR_MISC; } }   // a peer's error: still arrive at the second barrier
         for (int i = 0; i < n; ++i) {
             const bool mx = (maxmask >> i) & 1u;
             double v = box_data(0)[i];  // seeded with rank 0's value: a true maximum also for negative entries, like ncclMax
@@ -231,7 +245,7 @@ int comm_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int n
         if (ok) ok = hipStreamSynchronize(stream) == hipSuccess;
         if (ok) std::memcpy(box_data(g_rank), g_stage, sizeof(double) * off);
         else shm_raise_error();
-        if (shm_barrier() < 0) { (void)shm_barrier(); return ERROR_MISC; }  // still arrive at the second barrier
+        { const int bs = shm_barrier(); if (bs < 0) { if (bs != SHM_TIMEOUT) (void)shm_barrier(); return ERROR_MISC; } }   // a peer's error: still arrive at the second barrier
         size_t roff = 0;
         for (int i = 0; i < nrecv && ok; ++i) {
             const ShmBoxHeader* ph = box_hdr(recvs[i].peer);

@@ -706,6 +706,13 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
     if (w_hi <= w_lo && win.hi >= 0) return 0;
     if (a.partials) a.partials += win.goff;
     auto set_tiles = [&](int rpb) {
+        // a row window starts at a multiple of WIN_ALIGN; a kernel whose tile size does not divide it (only reachable through
+        // fasp_hip_tune: block-stream tiles beyond 1024 rows, k_csr_rowpat with 8 rows per lane) would compute rows outside
+        // the window a second time -- refuse loudly instead
+        if (win.hi >= 0 && rpb > 0 && (w_lo % rpb) != 0) {
+            std::fprintf(stderr, "### ERROR: fasp_hip: row window at %d with a kernel tile of %d rows (a tuning knob broke the window alignment)\n", w_lo, rpb);
+            std::abort();
+        }
         a.nrow = w_hi; a.row_lo = w_lo; a.tile0 = w_lo / rpb;
         a.ntiles = (w_hi - w_lo + rpb - 1) / rpb;
         a.tiles_per_xcd = (a.ntiles + 7) / 8;

@@ -191,21 +191,35 @@ static int dist_launch(DevLevel& V, const DevCSR& M, CsrArgs a)
         if (halo_exchange(V, v) < 0) return -1;
         return launch_csr<OP>(M, a);
     }
-    // the exchange waits for whatever produced x, then runs beside the interior rows
-    if (hipEventRecord(g_ctx.ev_ready, g_ctx.stream) != hipSuccess ||
-        hipStreamWaitEvent(g_ctx.comm_stream, g_ctx.ev_ready, 0) != hipSuccess) return -1;
+    // the exchange waits for whatever produced x, then runs beside the interior rows.  A local HIP failure never makes this
+    // rank skip the exchange its peers enter (they would wait for it: the shared-memory transport until its timeout, RCCL
+    // for ever): the failure is recorded -- the next fetch_red turns it into ERROR_MISC on every rank -- and the sequence
+    // goes on in exchange-then-launch order.
+    bool local_ok = hipEventRecord(g_ctx.ev_ready, g_ctx.stream) == hipSuccess &&
+                    hipStreamWaitEvent(g_ctx.comm_stream, g_ctx.ev_ready, 0) == hipSuccess;
+    if (!local_ok) {
+        comm_mark_failed();
+        (void)hipStreamSynchronize(g_ctx.stream);
+        (void)halo_exchange(V, v);
+        (void)launch_csr<OP>(M, a);
+        return -1;
+    }
     RowWin w;
     w.lo = M.win_lo; w.hi = M.win_hi; w.goff = 0;
     int G = launch_csr<OP>(M, a, w);
     // (the transport may block the host -- the shared-memory one does: the interior launch is queued before it)
-    if (halo_exchange(V, v, g_ctx.comm_stream) < 0) return -1;
+    const int hst = halo_exchange(V, v, g_ctx.comm_stream);
     if (hipEventRecord(g_ctx.ev_halo, g_ctx.comm_stream) != hipSuccess ||
-        hipStreamWaitEvent(g_ctx.stream, g_ctx.ev_halo, 0) != hipSuccess) return -1;
+        hipStreamWaitEvent(g_ctx.stream, g_ctx.ev_halo, 0) != hipSuccess) {
+        comm_mark_failed();
+        (void)hipStreamSynchronize(g_ctx.comm_stream);   // the compute stream could not be ordered behind the halo: wait here
+        local_ok = false;
+    }
     w.lo = 0; w.hi = M.win_lo; w.goff = G;
     G += launch_csr<OP>(M, a, w);
     w.lo = M.win_hi; w.hi = M.row; w.goff = G;
     G += launch_csr<OP>(M, a, w);
-    return G;
+    return (hst < 0 || !local_ok) ? -1 : G;
 }
 
 // One level to the device.  DL == nullptr: single rank, the level is whole (the overlapped upload of
