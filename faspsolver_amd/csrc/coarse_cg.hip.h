@@ -130,7 +130,16 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
             (void)hipFuncSetAttribute((const void*)k_spcg_small<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             attr = true;
         }
-        if (g_tune.small_lds && lds_v + lds_m <= 148 * 1024)
+        // at most 128 rows: one wavefront, vectors in registers, the matrix dense in LDS (small_solvers.hip.h, k_spcg_wave)
+        int LD = m; while (LD % 32 != 1) ++LD;     // row stride in doubles: conflict-free lane = row reads
+        const size_t lds_w = sizeof(double) * (128 * (size_t)LD + 128);
+        const bool one_wave = g_tune.small_onewave && m <= 128 && lds_w <= 148 * 1024;
+        if (one_wave) {
+            static bool attr_w = false;
+            if (!attr_w) { (void)hipFuncSetAttribute((const void*)k_spcg_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_w = true; }
+            hipLaunchKernelGGL(k_spcg_wave, dim3(1), dim3(64), lds_w, g_ctx.stream, a, LD);
+        }
+        else if (g_tune.small_lds && lds_v + lds_m <= 148 * 1024)
             hipLaunchKernelGGL((k_spcg_small<true, true>), dim3(1), dim3(SMALL_BLOCK), lds_v + lds_m, g_ctx.stream, a);
         else if (g_tune.small_lds && lds_v <= 148 * 1024)
             hipLaunchKernelGGL((k_spcg_small<true, false>), dim3(1), dim3(SMALL_BLOCK), lds_v, g_ctx.stream, a);

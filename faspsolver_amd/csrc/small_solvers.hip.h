@@ -102,11 +102,12 @@ __device__ __forceinline__ void blk_reduce(double (&v)[NQ], double* sh, unsigned
     __syncthreads();
 }
 
+template <int NT = SMALL_BLOCK>
 __device__ __forceinline__ double blk_dot(int n, const double* x, const double* y, double* sh)
 {
     double v[1] = {0.0};
-    for (int i = threadIdx.x; i < n; i += SMALL_BLOCK) v[0] += x[i] * y[i];
-    blk_reduce<1>(v, sh);
+    for (int i = threadIdx.x; i < n; i += NT) v[0] += x[i] * y[i];
+    blk_reduce<1, NT / 64>(v, sh);
     return v[0];
 }
 
@@ -119,11 +120,11 @@ struct SmallCSR {
     const int*    ja;
     const double* val;
     __device__ __forceinline__ int rows() const { return m; }
-    template <class F>
+    template <int NT = SMALL_BLOCK, class F>
     __device__ __forceinline__ void for_rows(const double* x, F&& f) const
     {
         const int sl = threadIdx.x & 15;
-        for (int row = threadIdx.x >> 4; row < m; row += SMALL_BLOCK / 16) {
+        for (int row = threadIdx.x >> 4; row < m; row += NT / 16) {
             double s = 0.0;
             int k = ia[row] + sl;
             const int ke = ia[row + 1];
@@ -205,9 +206,10 @@ __device__ __forceinline__ void small_mxv(const OP& A, const double* x, double* 
     __syncthreads();
 }
 // r = b - A x with the reference's rounding (CSR: b_i - t_i, BlaSpmvCSR.c:557; BSR: -((-b_i) + t), :548)
+template <int NT = SMALL_BLOCK>
 __device__ __forceinline__ void small_resid(const SmallCSR& A, const double* x, const double* b, double* r)
 {
-    A.for_rows(x, [&](int row, double s, double) { r[row] = b[row] - s; });
+    A.template for_rows<NT>(x, [&](int row, double s, double) { r[row] = b[row] - s; });
     __syncthreads();
 }
 __device__ __forceinline__ void small_resid(const SmallBSR& A, const double* x, const double* b, double* r)
@@ -232,10 +234,12 @@ struct SpcgArgs {
 
 // LV: the five work vectors live in dynamic LDS (5 m doubles); LM: so does the matrix (copied once):
 // every iteration then runs out of LDS, global memory is touched at entry (b, u) and exit (u) only.
-template <bool LV, bool LM>
-__global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_small(SpcgArgs a)
+// NT: 512 threads, or ONE wavefront for coarsest levels of a few dozen rows (config 5 of BASELINE.json: 89 rows, 124 000
+// coarse CG iterations per solve): no second wave to wait for at any barrier, lane = row products.
+template <bool LV, bool LM, int NT = SMALL_BLOCK>
+__global__ __launch_bounds__(NT) void k_spcg_small(SpcgArgs a)
 {
-    __shared__ double sh[SMALL_WAVES * 5];
+    __shared__ double sh[(NT / 64) * 5];
     extern __shared__ double dyn[];
     SmallCSR A = a.A;
     const int m = A.m, tid = threadIdx.x;
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_small(SpcgArgs a)
         double* lval = dyn + 5 * (size_t)m;
         int*    lja  = reinterpret_cast<int*>(lval + nnz);
         int*    lia  = lja + nnz;
-        for (int i = tid; i < nnz; i += SMALL_BLOCK) { lval[i] = a.A.val[i]; lja[i] = a.A.ja[i]; }
-        for (int i = tid; i <= m; i += SMALL_BLOCK) lia[i] = a.A.ia[i];
+        for (int i = tid; i < nnz; i += NT) { lval[i] = a.A.val[i]; lja[i] = a.A.ja[i]; }
+        for (int i = tid; i <= m; i += NT) lia[i] = a.A.ia[i];
         A.val = lval; A.ja = lja; A.ia = lia;
     }
     const double tol = a.tol, maxdiff = tol * 1e-4 /* STAG_RATIO */, sol_inf_tol = 1e-20;
@@ -259,36 +263,36 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_small(SpcgArgs a)
     const double* b = a.b;
     double red[5];
 
-    for (int i = tid; i < m; i += SMALL_BLOCK) u_best[i] = 0.0;
+    for (int i = tid; i < m; i += NT) u_best[i] = 0.0;
     if (a.x_zero) {
-        for (int i = tid; i < m; i += SMALL_BLOCK) { r[i] = b[i]; u[i] = 0.0; }
+        for (int i = tid; i < m; i += NT) { r[i] = b[i]; u[i] = 0.0; }
         __syncthreads();
     } else {
-        if (LV) for (int i = tid; i < m; i += SMALL_BLOCK) u[i] = a.u[i];
+        if (LV) for (int i = tid; i < m; i += NT) u[i] = a.u[i];
         __syncthreads();
-        small_resid(A, u, b, r);
+        small_resid<NT>(A, u, b, r);
     }
-    temp1 = blk_dot(m, r, r, sh);
+    temp1 = blk_dot<NT>(m, r, r, sh);
     absres0 = sqrt(temp1);
     normr0 = fmax(SMALL, absres0);
     relres = absres0 / normr0;
     if (relres < tol) goto FINISHED;
-    for (int i = tid; i < m; i += SMALL_BLOCK) p[i] = r[i];
+    for (int i = tid; i < m; i += NT) p[i] = r[i];
     __syncthreads();
 
     while (iter++ < MaxIt) {
         // t = A p and (t, p)
         {
             double v[1] = {0.0};
-            A.for_rows(p, [&](int row, double s, double) { t[row] = s; v[0] += s * p[row]; });
-            blk_reduce<1>(v, sh);
+            A.template for_rows<NT>(p, [&](int row, double s, double) { t[row] = s; v[0] += s * p[row]; });
+            blk_reduce<1, NT / 64>(v, sh);
             temp2 = v[0];
         }
         if (fabs(temp2) > SMALL2) alpha = temp1 / temp2;
         else goto RESTORE_BESTSOL;
         // u += alpha p; r -= alpha t; ||r||^2, ||u||^2, ||p||^2, max|u|, #NaN(u)
         red[0] = red[1] = red[2] = red[3] = red[4] = 0.0;
-        for (int i = tid; i < m; i += SMALL_BLOCK) {
+        for (int i = tid; i < m; i += NT) {
             const double pi = p[i];
             const double ui = u[i] + alpha * pi;
             const double ri = r[i] - alpha * t[i];
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_small(SpcgArgs a)
             red[3] = fmax(red[3], fabs(ui));
             red[4] += (ui != ui) ? 1.0 : 0.0;
         }
-        blk_reduce<5>(red, sh, 1u << 3);
+        blk_reduce<5, NT / 64>(red, sh, 1u << 3);
         absres = sqrt(red[0]);
         relres = absres / normr0;
         if (red[4] > 0.0) {  // fasp_dvec_isnan(u), :185
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_small(SpcgArgs a)
         if (absres < absres_best - maxdiff) {
             absres_best = absres;
             iter_best = iter;
-            for (int i = tid; i < m; i += SMALL_BLOCK) u_best[i] = u[i];
+            for (int i = tid; i < m; i += NT) u_best[i] = u[i];
         }
         if (red[3] <= sol_inf_tol) {  // Check I
             iter = -43;               // ERROR_SOLVER_SOLSTAG
@@ -317,50 +321,214 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_spcg_small(SpcgArgs a)
         reldiff = fabs(alpha) * sqrt(red[2]) / normu;
         if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {  // Check II
             __syncthreads();
-            small_resid(A, u, b, r);
-            red[0] = blk_dot(m, r, r, sh);
+            small_resid<NT>(A, u, b, r);
+            red[0] = blk_dot<NT>(m, r, r, sh);
             absres = sqrt(red[0]);
             relres = absres / normr0;
             if (relres < tol) break;
             if (stag >= MAX_STAG) { iter = -42; break; }  // ERROR_SOLVER_STAG
-            for (int i = tid; i < m; i += SMALL_BLOCK) p[i] = 0.0;
+            for (int i = tid; i < m; i += NT) p[i] = 0.0;
             ++stag;
         }
         if (relres < tol) {  // Check III: true residual
             __syncthreads();
-            small_resid(A, u, b, r);
-            red[0] = blk_dot(m, r, r, sh);
+            small_resid<NT>(A, u, b, r);
+            red[0] = blk_dot<NT>(m, r, r, sh);
             absres = sqrt(red[0]);
             relres = absres / normr0;
             if (relres < tol) break;
             if (more_step >= MAX_RESTART) { iter = -44; break; }  // ERROR_SOLVER_TOLSMALL
-            for (int i = tid; i < m; i += SMALL_BLOCK) p[i] = 0.0;
+            for (int i = tid; i < m; i += NT) p[i] = 0.0;
             ++more_step;
         }
         absres0 = absres;
         temp2 = red[0];  // (z, r) with z = r
         beta = temp2 / temp1;
         temp1 = temp2;
-        for (int i = tid; i < m; i += SMALL_BLOCK) p[i] = 1.0 * r[i] + beta * p[i];  // fasp_blas_darray_axpby
+        for (int i = tid; i < m; i += NT) p[i] = 1.0 * r[i] + beta * p[i];  // fasp_blas_darray_axpby
         __syncthreads();
     }
 
 RESTORE_BESTSOL:
     __syncthreads();
     if (iter != iter_best) {
-        small_resid(A, u_best, b, r);
-        absres_best = sqrt(blk_dot(m, r, r, sh));
+        small_resid<NT>(A, u_best, b, r);
+        absres_best = sqrt(blk_dot<NT>(m, r, r, sh));
         if (absres > absres_best + maxdiff || absres != absres) {
-            for (int i = tid; i < m; i += SMALL_BLOCK) u[i] = u_best[i];
+            for (int i = tid; i < m; i += NT) u[i] = u_best[i];
             relres = absres_best / normr0;
         }
     }
 FINISHED:
     if (LV) {
         __syncthreads();
-        for (int i = tid; i < m; i += SMALL_BLOCK) a.u[i] = u[i];
+        for (int i = tid; i < m; i += NT) a.u[i] = u[i];
     }
     if (tid == 0) {
+        a.out->iters = iter > 0 ? (iter > MaxIt ? MaxIt : iter) : 0;
+        a.out->status = iter > MaxIt ? -48 : iter;  // ERROR_SOLVER_MAXIT
+        a.out->relres = relres;
+        a.out->absres = absres;
+    }
+    (void)absres0;
+}
+
+// ---------------------------------------------------------------------------
+// k_spcg_wave: the same safe CG (KrySPcg.c:60-365) for coarsest levels of at most 128 rows, in ONE wavefront.
+// The 512-thread kernel spends 3.7 us per iteration on a level of 89 rows (config 5 of BASELINE.json: a W-cycle over
+// five levels = 124 000 coarse iterations per solve, 84 % of it): every phase of an iteration is a chain of LDS round
+// trips and barriers that eight waves wait through together.  Here a lane owns rows i and i + 64; the iterate, the
+// residual, the direction and the product live in its registers, the matrix sits DENSE in LDS (row stride = 1 mod 32
+// doubles: conflict-free for lane = row reads), p is broadcast from LDS; the row sums of t = A p are 2 m independent
+// LDS reads per lane with no index to wait for, the reductions are data-parallel-primitive moves + readlane.  Row sums
+// are four interleaved partial sums over ascending columns (the reference: storage order): O(1e-16) apart, like every
+// reduction here.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_bcast63(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_allsum(double x) { return wave_bcast63(wave_sum_to_lane63(x)); }
+__device__ __forceinline__ double wave_allmax(double x) { return wave_bcast63(wave_max_to_lane63(x)); }
+
+__global__ __launch_bounds__(64) void k_spcg_wave(SpcgArgs a, int LD)
+{
+    extern __shared__ double dyn[];   // [128 * LD] dense matrix, [128] p
+    const SmallCSR A = a.A;
+    const int m = A.m, lane = threadIdx.x;
+    double* Ad = dyn;
+    double* pb = dyn + 128 * (size_t)LD;
+    const int r0 = lane, r1 = lane + 64;
+    const bool h0 = r0 < m, h1 = r1 < m;
+    // dense copy (rows beyond m and absent entries are zeros; a column stored twice is added up)
+    for (int i = lane; i < 128 * LD; i += 64) Ad[i] = 0.0;
+    __syncthreads();
+    for (int e = 0; e < 2; ++e) {
+        const int row = lane + 64 * e;
+        if (row < m)
+            for (int k = A.ia[row]; k < A.ia[row + 1]; ++k) Ad[row * LD + A.ja[k]] += A.val[k];
+    }
+    __syncthreads();
+    const double* A0 = Ad + (size_t)r0 * LD;
+    const double* A1 = Ad + (size_t)r1 * LD;
+    auto mxv = [&](double x0, double x1, double& y0, double& y1) {   // y = A x, x through the broadcast buffer
+        __syncthreads();
+        pb[r0] = x0; pb[r1] = x1;
+        __syncthreads();
+        // four partial sums per row (columns j = c mod 4): the additions of a row are not one chain of m dependent
+        // operations -- a lone wavefront has nobody to hide that latency behind -- and eight columns' loads are in flight
+        double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+        int j = 0;
+        for (; j + 7 < m; j += 8) {
+            double q[8], x0[8], x1[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { q[c] = pb[j + c]; x0[c] = A0[j + c]; x1[c] = A1[j + c]; }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { sa[c & 3] += x0[c] * q[c]; sb[c & 3] += x1[c] * q[c]; }
+        }
+        for (; j < m; ++j) { const double q = pb[j]; sa[j & 3] += A0[j] * q; sb[j & 3] += A1[j] * q; }
+        const double s0 = (sa[0] + sa[1]) + (sa[2] + sa[3]), s1 = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+        y0 = s0; y1 = s1;
+    };
+    const double tol = a.tol, maxdiff = tol * 1e-4 /* STAG_RATIO */, sol_inf_tol = 1e-20;
+    const double BIG = 1e+20, SMALL = 1e-20, SMALL2 = 1e-40;
+    const int MaxIt = a.MaxIt, MAX_STAG = 20, MAX_RESTART = 20;
+    int iter = 0, stag = 1, more_step = 1, iter_best = 0;
+    double absres0 = BIG, absres = BIG, relres = BIG, normu, normr0 = BIG;
+    double reldiff, alpha = 0.0, beta, temp1, temp2, absres_best = BIG;
+    const double b0 = h0 ? a.b[r0] : 0.0, b1 = h1 ? a.b[r1] : 0.0;
+    double u0 = 0.0, u1 = 0.0, p0 = 0.0, p1 = 0.0, rr0, rr1, t0 = 0.0, t1 = 0.0, ub0 = 0.0, ub1 = 0.0;
+    auto resid = [&](double x0, double x1, double& y0, double& y1) {   // b - A x (rows beyond m: 0 - 0)
+        double s0, s1;
+        mxv(x0, x1, s0, s1);
+        y0 = b0 - s0; y1 = b1 - s1;
+    };
+    if (a.x_zero) { rr0 = b0; rr1 = b1; }
+    else {
+        u0 = h0 ? a.u[r0] : 0.0; u1 = h1 ? a.u[r1] : 0.0;
+        resid(u0, u1, rr0, rr1);
+    }
+    temp1 = wave_allsum(rr0 * rr0 + rr1 * rr1);
+    absres0 = sqrt(temp1);
+    normr0 = fmax(SMALL, absres0);
+    relres = absres0 / normr0;
+    if (relres < tol) goto FINISHED;
+    p0 = rr0; p1 = rr1;
+
+    while (iter++ < MaxIt) {
+        mxv(p0, p1, t0, t1);
+        temp2 = wave_allsum(t0 * p0 + t1 * p1);
+        if (fabs(temp2) > SMALL2) alpha = temp1 / temp2;
+        else goto RESTORE_BESTSOL;
+        u0 = u0 + alpha * p0; u1 = u1 + alpha * p1;
+        rr0 = rr0 - alpha * t0; rr1 = rr1 - alpha * t1;
+        const double q_rr = wave_allsum(rr0 * rr0 + rr1 * rr1);
+        const double q_uu = wave_allsum(u0 * u0 + u1 * u1);
+        const double q_pp = wave_allsum(p0 * p0 + p1 * p1);
+        const double q_mx = wave_allmax(fmax(fabs(u0), fabs(u1)));
+        const double q_nan = wave_allsum(((u0 != u0) ? 1.0 : 0.0) + ((u1 != u1) ? 1.0 : 0.0));
+        absres = sqrt(q_rr);
+        relres = absres / normr0;
+        double red0 = q_rr;
+        if (q_nan > 0.0) {  // fasp_dvec_isnan(u), :185
+            absres = BIG;
+            goto RESTORE_BESTSOL;
+        }
+        if (absres < absres_best - maxdiff) {
+            absres_best = absres;
+            iter_best = iter;
+            ub0 = u0; ub1 = u1;
+        }
+        if (q_mx <= sol_inf_tol) {  // Check I
+            iter = -43;             // ERROR_SOLVER_SOLSTAG
+            break;
+        }
+        normu = sqrt(q_uu);
+        reldiff = fabs(alpha) * sqrt(q_pp) / normu;
+        if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {  // Check II
+            resid(u0, u1, rr0, rr1);
+            red0 = wave_allsum(rr0 * rr0 + rr1 * rr1);
+            absres = sqrt(red0);
+            relres = absres / normr0;
+            if (relres < tol) break;
+            if (stag >= MAX_STAG) { iter = -42; break; }  // ERROR_SOLVER_STAG
+            p0 = 0.0; p1 = 0.0;
+            ++stag;
+        }
+        if (relres < tol) {  // Check III: true residual
+            resid(u0, u1, rr0, rr1);
+            red0 = wave_allsum(rr0 * rr0 + rr1 * rr1);
+            absres = sqrt(red0);
+            relres = absres / normr0;
+            if (relres < tol) break;
+            if (more_step >= MAX_RESTART) { iter = -44; break; }  // ERROR_SOLVER_TOLSMALL
+            p0 = 0.0; p1 = 0.0;
+            ++more_step;
+        }
+        absres0 = absres;
+        temp2 = red0;  // (z, r) with z = r
+        beta = temp2 / temp1;
+        temp1 = temp2;
+        p0 = 1.0 * rr0 + beta * p0; p1 = 1.0 * rr1 + beta * p1;  // fasp_blas_darray_axpby
+    }
+
+RESTORE_BESTSOL:
+    if (iter != iter_best) {
+        double s0, s1;
+        resid(ub0, ub1, s0, s1);
+        absres_best = sqrt(wave_allsum(s0 * s0 + s1 * s1));
+        if (absres > absres_best + maxdiff || absres != absres) {
+            u0 = ub0; u1 = ub1;
+            relres = absres_best / normr0;
+        }
+    }
+FINISHED:
+    if (h0) a.u[r0] = u0;
+    if (h1) a.u[r1] = u1;
+    if (lane == 0) {
         a.out->iters = iter > 0 ? (iter > MaxIt ? MaxIt : iter) : 0;
         a.out->status = iter > MaxIt ? -48 : iter;  // ERROR_SOLVER_MAXIT
         a.out->relres = relres;

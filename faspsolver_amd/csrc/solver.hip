@@ -1961,6 +1961,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_persist")) g_tune.seq_persist = value;
     else if (!std::strcmp(key, "spcg_grid")) g_tune.spcg_grid = value;
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
+    else if (!std::strcmp(key, "small_onewave")) g_tune.small_onewave = value;
     else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;
     else if (!std::strcmp(key, "device_sort")) g_device_sort = value;
     else if (!std::strcmp(key, "halo_overlap")) g_halo_overlap = value;
