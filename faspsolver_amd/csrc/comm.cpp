@@ -287,7 +287,7 @@ int comm_allgatherv(const double* sendbuf, int sendcount, double* recvbuf, const
                      hipStreamSynchronize(stream) == hipSuccess;
         if (ok) std::memcpy(box_data(g_rank), g_stage, sizeof(double) * sendcount);
         else shm_raise_error();
-        if (shm_barrier() < 0) { (void)shm_barrier(); return ERROR_MISC; }
+        { const int bs = shm_barrier(); if (bs < 0) { if (bs != SHM_TIMEOUT) (void)shm_barrier(); return ERROR_MISC; } }
         for (int r = 0; r < g_size && ok; ++r) {
             if (r == g_rank || counts[r] == 0) continue;
             ok = hipMemcpy(recvbuf + displs[r], box_data(r), sizeof(double) * counts[r], hipMemcpyHostToDevice) == hipSuccess;

@@ -332,7 +332,7 @@ ForwardSweep:
             // the restriction also writes the first pre-smoothing sweep of the next level (Jacobi from a zero guess:
             // x = (w b) / d, k_jacobi_zero's expression) when that level is smoothed and both levels are laid out alike
             if (g_tune.fuse_presmooth && smoother == SMOOTHER_JACOBI && param.presmooth_iter >= 1 && l + 1 < nl - 1 &&
-                D.replicated == C.replicated) {
+                D.replicated == C.replicated && !(D.replicated && coarse_split_active(D.R))) {   // (a split restriction gathers b only)
                 ra.zx = C.x; ra.zdiag = C.diag; ra.zomega = relax;
                 fused_presmooth = true;
             }
@@ -380,7 +380,7 @@ ForwardSweep:
         if (param.coarse_scaling == 1) d_aAxpy(alpha, D.P, C.x, D.x);  // x_l += alpha P x_{l+1}  (ghosts of x_{l+1} are there)
         else {   // alpha == 1: the halo of x_{l+1} travels beside the interior rows of P
             CsrArgs pa{}; pa.x = C.x; pa.y = D.x; pa.alpha = 1.0;
-            if (dist_launch<OP_ADD>(C, D.P, pa) < 0) return ERROR_MISC;
+            if (dist_launch<OP_ADD>(C, D.P, pa, &D) < 0) return ERROR_MISC;
         }
         if ((st0 = smooth(h, l, true, smoother, param.smooth_order, param.postsmooth_iter, relax, param.polynomial_degree)) < 0) return st0;
         if (num_lvl[l] < ncycles[l]) break;

@@ -182,10 +182,41 @@ static int halo_exchange(DevLevel& D, double* v, hipStream_t stream = nullptr)
 // what the single launch does, only the partition of the fused dot product into per-block partials changes.
 static int g_halo_overlap = 1;   // fasp_hip_tune("halo_overlap", 0): exchange, then one launch (the round-1 sequence)
 
+// ---- replicated levels, "split" mode (fasp_hip_tune("coarse_mode", 1)) -----------------------------------------------
+// Levels below FASP_HIP_DIST_MIN_ROWS are replicated: every rank holds the whole level and (mode 0) computes all of it,
+// which costs no time but caps the speed-up (Amdahl).  Mode 1 keeps the vectors replicated and splits the WORK: a rank
+// applies an operator to its share of the rows only (row windows, multiples of WIN_ALIGN) and one all-gather completes
+// the result on every rank.  Per operator: 1 / P of the kernel + an all-gather of 8 m bytes -- worth it where the kernel
+// is long against the collective's latency (DESIGN.md section 4 has the per-level model); the arithmetic of a row does
+// not depend on who computes it, so the iteration is the same one.  Operators with fewer rows than
+// `g_coarse_split_min` stay redundant.
+static int g_coarse_mode = 0, g_coarse_split_min = 16384;
+static bool coarse_split_active(const DevCSR& M) { return g_coarse_mode == 1 && comm_size() > 1 && M.row >= g_coarse_split_min; }
 template <int OP>
-static int dist_launch(DevLevel& V, const DevCSR& M, CsrArgs a)
+static int rep_launch(const DevCSR& M, CsrArgs a)
+{
+    if (!coarse_split_active(M) || a.partials || a.zx) return launch_csr<OP>(M, a);
+    const int P = comm_size(), me = comm_rank();
+    const int nwin = (M.row + WIN_ALIGN - 1) / WIN_ALIGN, per = (nwin + P - 1) / P;
+    std::vector<int> counts((size_t)P), displs((size_t)P);
+    for (int q = 0; q < P; ++q) {
+        const int lo = std::min(M.row, q * per * WIN_ALIGN), hi = std::min(M.row, (q + 1) * per * WIN_ALIGN);
+        displs[(size_t)q] = lo; counts[(size_t)q] = hi - lo;
+    }
+    RowWin w; w.lo = displs[(size_t)me]; w.hi = w.lo + counts[(size_t)me]; w.goff = 0;
+    int G = 0;
+    if (w.hi > w.lo) G = launch_csr<OP>(M, a, w);
+    if (comm_allgatherv(a.y + w.lo, counts[(size_t)me], a.y, counts.data(), displs.data(), g_ctx.stream) < 0) { comm_mark_failed(); return -1; }
+    return G;
+}
+
+// (Out: the level the result lives on when it is not V -- the prolongation from a replicated level onto a distributed one
+// is that rank's own rows and must not be split)
+template <int OP>
+static int dist_launch(DevLevel& V, const DevCSR& M, CsrArgs a, const DevLevel* Out = nullptr)
 {
     double* v = const_cast<double*>(a.x);
+    if (V.replicated && (!Out || Out->replicated) && comm_size() > 1) return rep_launch<OP>(M, a);
     if (V.replicated || comm_size() <= 1 || V.send_off.empty()) return launch_csr<OP>(M, a);
     if (!g_halo_overlap || M.win_hi < 0) {
         if (halo_exchange(V, v) < 0) return -1;

@@ -1965,6 +1965,8 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;
     else if (!std::strcmp(key, "device_sort")) g_device_sort = value;
     else if (!std::strcmp(key, "halo_overlap")) g_halo_overlap = value;
+    else if (!std::strcmp(key, "coarse_mode")) g_coarse_mode = value;            // replicated levels: 0 redundant work, 1 split rows + all-gather
+    else if (!std::strcmp(key, "coarse_split_min")) g_coarse_split_min = value;
     else if (!std::strcmp(key, "split_rows")) g_tune.split_rows = value;
     else if (!std::strcmp(key, "gs_multicolor")) g_tune.gs_multicolor = value;
     else if (!std::strcmp(key, "seq_block")) g_tune.seq_block = value;

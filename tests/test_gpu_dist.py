@@ -13,9 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="shm", idfile=None, amg_type=1, smoother=1, itsolver=1):
+def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="shm", idfile=None, amg_type=1, smoother=1, itsolver=1, tune=""):
     try:
         os.environ["FASP_HIP_DIST_MIN_ROWS"] = str(min_rows)
+        if tune:
+            os.environ["FASP_HIP_TUNE"] = tune
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
         import faspsolver_amd as fa
         from faspsolver_amd import _types as T
@@ -75,7 +77,7 @@ def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="s
         q.put((rank, "fail", traceback.format_exc(), None, None, None))
 
 
-def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_type=1, smoother=1, itsolver=1):
+def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_type=1, smoother=1, itsolver=1, tune=""):
     import multiprocessing as mp
     import tempfile
     from _libs import T, default_params, orc_solve, poisson7pt
@@ -89,7 +91,7 @@ def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_typ
     idfile = os.path.join(tempfile.gettempdir(), name + ".ncclid")
     if os.path.exists(idfile):
         os.remove(idfile)
-    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q, shared, transport, idfile, amg_type, smoother, itsolver)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q, shared, transport, idfile, amg_type, smoother, itsolver, tune)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -157,3 +159,11 @@ def test_rccl_entry_points_single_rank():
     """Every RCCL call of the production transport, on a one-rank communicator (one GPU here)."""
     import faspsolver_amd as fa
     assert fa.lib().fasp_hip_comm_selftest() == 0
+
+
+@pytest.mark.parametrize("world,n,min_rows,cycle", [(2, 32, 20000, 1), (3, 40, 40000, 1), (4, 32, 20000, 2)])
+def test_replicated_levels_with_split_work_match_oracle(world, n, min_rows, cycle):
+    """fasp_hip_tune("coarse_mode", 1): the replicated levels keep their vectors on every rank but every rank applies an
+    operator to its share of the rows only, an all-gather completes the result (hierarchy.hip.h, rep_launch).  Same
+    iteration as the oracle's: iteration count, residual history, every rank's rows of the solution."""
+    _run_ranks(world, n, min_rows, cycle, tune="coarse_mode=1,coarse_split_min=1024")
