@@ -102,6 +102,35 @@ __device__ __forceinline__ void blk_reduce(double (&v)[NQ], double* sh, unsigned
     __syncthreads();
 }
 
+// blk_reduce with ONE barrier: the wave partials go to one of two alternating buffers (sh2: 2 * NW * NQ doubles, par
+// toggles per call).  A wave that runs ahead writes the other buffer; it cannot get two reductions ahead, because the
+// barrier of the next one needs every wave to have read this one's.  (The single-workgroup Krylov solvers are chains of
+// such reductions: the modified Gram-Schmidt of the coarse GMRES does a dozen per iteration.)
+template <int NQ, int NW = SMALL_WAVES>
+__device__ __forceinline__ void blk_reduce1(double (&v)[NQ], double* sh2, int& par, unsigned maxmask = 0u)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double* sh = sh2 + par * (NW * NQ);
+    par ^= 1;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const bool mx = (maxmask >> q) & 1u;
+        const double x = mx ? wave_max_to_lane63(v[q]) : wave_sum_to_lane63(v[q]);
+        if (lane == 63) sh[w * NQ + q] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const bool mx = (maxmask >> q) & 1u;
+        double x = sh[q];
+        for (int k = 1; k < NW; ++k) {
+            const double y = sh[k * NQ + q];
+            x = mx ? fmax(x, y) : x + y;
+        }
+        v[q] = x;
+    }
+}
+
 template <int NT = SMALL_BLOCK>
 __device__ __forceinline__ double blk_dot(int n, const double* x, const double* y, double* sh)
 {
@@ -919,6 +948,8 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
     constexpr int R = SMALL_MAX_RESTART;
     extern __shared__ double dyn[];
     __shared__ double sh[SMALL_WAVES];
+    __shared__ double sh2[2 * SMALL_WAVES];
+    int par = 0;
     __shared__ double hh[(R + 1) * R];  // hh[j][k] -> hh[j * R + k]
     __shared__ double rs[R + 2], c[R + 1], sn[R + 1];
     __shared__ double sc_rnorm;         // |rs[i]| published by thread 0
@@ -961,11 +992,19 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
             // modified Gram-Schmidt: a thread updates only its own elements between the dots
             for (int j = 0; j < i; ++j) {
                 const double* pj = P(j);
-                const double h = blk_dot(n, pj, pi, sh);
+                double hv[1] = {0.0};
+                for (int e = tid; e < n; e += SMALL_BLOCK) hv[0] += pj[e] * pi[e];
+                blk_reduce1<1>(hv, sh2, par);
+                const double h = hv[0];
                 if (tid == 0) hh[j * R + (i - 1)] = h;
                 for (int e = tid; e < n; e += SMALL_BLOCK) pi[e] += -h * pj[e];
             }
-            t = sqrt(blk_dot(n, pi, pi, sh));
+            {
+                double tv[1] = {0.0};
+                for (int e = tid; e < n; e += SMALL_BLOCK) tv[0] += pi[e] * pi[e];
+                blk_reduce1<1>(tv, sh2, par);
+                t = sqrt(tv[0]);
+            }
             if (t != 0.0) {
                 const double s = 1.0 / t;
                 for (int e = tid; e < n; e += SMALL_BLOCK) pi[e] *= s;
