@@ -729,7 +729,8 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
     a.nt = g_tune.nt;
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
     a.ja16 = g_tune.ja16 ? M.ja16 : nullptr;
-    const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : M.kind == 1 ? M.tile_rows : M.kind == 3 ? 1 : BLOCK / M.lanes;
+    if (M.kind == 1 || M.kind == 3) M.kind = 0;   // (block-level stream, one workgroup per row: measured slower, retired to tools/lab/)
+    const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : BLOCK / M.lanes;
     set_tiles(rpb);
     if (M.kind == 5 && g_tune.gen2 && M.nxrows >= 0 && !M.rowbase && g_tune.rpl <= 0) {
         // square row-pattern-coded operator: scalar-pattern sweep, other rows through the wave's LDS queue (kernels2.hip.h)
@@ -801,13 +802,6 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         if (M.wrows == 64) return launch_persistent(k_csr_wstream<OP, 64, 1024>, a.ntiles, a);
         if (M.wrows == 32 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 32, 512>, a.ntiles, a);
         return launch_persistent(k_csr_wstream<OP, 32, 1024>, a.ntiles, a);
-    }
-    if (M.kind == 3) return launch_persistent(k_csr_blockrow<OP>, w_hi - w_lo, a);
-    if (M.kind == 1) {
-        int cap = g_tune.maxgrid > 0 ? g_tune.maxgrid : 4 * g_ctx.num_cu;
-        int grid = std::max(8, (std::min(std::min(cap, MAXGRID), a.ntiles) + 7) / 8 * 8);
-        hipLaunchKernelGGL((k_csr_stream<OP>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, a, M.tile_rows);
-        return grid;
     }
     switch (M.lanes) {
         case 2:  return launch_persistent(k_csr_rows<2, OP>, a.ntiles, a);

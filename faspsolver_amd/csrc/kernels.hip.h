@@ -284,168 +284,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------
-// One workgroup per row: for the few, very long rows of the coarsest levels (1000+ nnz
-// per row, < 64 K rows) a wavefront per row leaves the chip under-filled and serialises 20
-// dependent load rounds; with 256 lanes per row every lane issues its whole share of the
-// row (<= 8 loads) at once and the kernel is one memory round trip deep.
-// ---------------------------------------------------------------------------
-template <int OP>
-__global__ __launch_bounds__(BLOCK) void k_csr_blockrow(CsrArgs a)
-{
-    __shared__ double lds[4];
-    double acc = 0.0;
-    for (int r = a.row_lo + blockIdx.x; r < a.nrow; r += gridDim.x) {
-        const int kb = a.ia[r], ke = a.ia[r + 1];
-        double s = 0.0;
-        for (int base = kb + threadIdx.x; base < ke; base += 8 * BLOCK) {
-            int    c[8];
-            double v[8], xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int  k = base + u * BLOCK;
-                const bool ok = k < ke;
-                c[u] = ok ? ld_ja(a, k) : 0;
-                v[u] = ok ? ld_val(a, k) : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = base + u * BLOCK;
-                if (k < ke && (OP != OP_JACOBI || c[u] != r)) s += v[u] * xv[u];
-            }
-        }
-        s = block_sum(s, lds);
-        if (threadIdx.x == 0) {
-            if (OP == OP_MXV) { a.y[r] = s; zx_store(a, r, s); }
-            else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
-            else if (OP == OP_ADD) a.y[r] += s;
-            else if (OP == OP_SUB) a.y[r] -= s;
-            else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
-            else if (OP == OP_JACOBI) {
-                const double d = a.diag[r], xi = a.x[r];
-                const double tt = a.b[r] - s;
-                a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * tt / d : xi;
-            } else if (OP == OP_L1DIAG) {
-                const double d = a.diag[r], xi = a.x[r];
-                const double tt = a.b[r] - s;
-                a.y[r] = l1_or_jacobi_f(a, r, tt, d, xi);
-            } else if (OP == OP_MXV_DOT) {
-                a.y[r] = s;
-                acc += s * a.dotv[r];
-            }
-        }
-    }
-    if (OP == OP_MXV_DOT && threadIdx.x == 0) a.partials[blockIdx.x] = acc;
-}
-
-// ---------------------------------------------------------------------------
-// CSR "stream" kernel for short rows (<= ~48 nnz/row: the fine levels, R and P, which
-// hold 3/4 of all nonzeros).  A block owns a tile of R consecutive rows (R = 256..1024):
-//   phase 1  all 256 threads sweep the tile's contiguous span of val/JA with unit-stride
-//            loads (fully coalesced whatever the row lengths), gather x through L2 and
-//            park the products val[k]*x[JA[k]] in LDS, <= CAP entries per chunk;
-//   phase 2  thread i sums the products of rows i, i+256, ... from LDS in storage order,
-//            starting from 0.0 (or from b_i for Jacobi): the same left-to-right sum as the
-//            reference's scalar loops (BlaSpmvCSR.c:414-416, ItrSmootherCSR.c:151-160), so
-//            row results are bit-identical to the reference's;
-//   epilogue consecutive threads own consecutive rows: b, diag, x, y are all coalesced.
-// ---------------------------------------------------------------------------
-constexpr int STREAM_CAP  = 4096;  // products per chunk (32 KiB of LDS)
-constexpr int STREAM_MAXR = 1024;  // rows per tile upper bound
-
-template <int OP>
-__global__ __launch_bounds__(BLOCK) void k_csr_stream(CsrArgs a, int R)
-{
-    __shared__ double prod[STREAM_CAP];
-    __shared__ int    rowptr[STREAM_MAXR + 1];
-    __shared__ int    colidx[OP == OP_JACOBI ? STREAM_CAP : 1];
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    const int vmax = tile_vmax(a);
-    double dotacc = 0.0;
-
-    for (int v = blockIdx.x; v < vmax; v += gridDim.x) {
-        const int t = tile_of(a, v);
-        if (t >= a.ntiles) continue;
-        const int r0 = (t + a.tile0) * R;
-        const int nr = min(R, a.nrow - r0);
-        for (int i = tid; i <= nr; i += BLOCK) rowptr[i] = a.ia[r0 + i];
-        __syncthreads();
-        const int k0 = rowptr[0], k1 = rowptr[nr];
-
-        double acc[STREAM_MAXR / BLOCK];
-#pragma unroll
-        for (int q = 0; q < STREAM_MAXR / BLOCK; ++q) {
-            const int i = tid + q * BLOCK;
-            acc[q] = ((OP == OP_JACOBI || OP == OP_L1DIAG) && i < nr) ? a.b[r0 + i] : 0.0;
-        }
-
-        for (int lo = k0; lo < k1; lo += STREAM_CAP) {
-            const int hi = min(lo + STREAM_CAP, k1);
-            // phase 1: coalesced sweep of the chunk
-            for (int k = lo + tid; k < hi; k += BLOCK) {
-                const int    c = ld_ja(a, k);
-                const double v = ld_val(a, k);
-                prod[k - lo] = v * a.x[c];
-                if (OP == OP_JACOBI) colidx[k - lo] = c;
-            }
-            __syncthreads();
-            // phase 2: sequential per-row sums over the part of each row inside the chunk
-#pragma unroll
-            for (int q = 0; q < STREAM_MAXR / BLOCK; ++q) {
-                const int i = tid + q * BLOCK;
-                if (i < nr) {
-                    const int kb = max(rowptr[i], lo), ke = min(rowptr[i + 1], hi);
-                    double s = acc[q];
-                    if (OP == OP_JACOBI) {
-                        const int r = r0 + i;
-                        for (int k = kb; k < ke; ++k)
-                            if (colidx[k - lo] != r) s -= prod[k - lo];
-                    } else if (OP == OP_L1DIAG) {
-                        for (int k = kb; k < ke; ++k) s -= prod[k - lo];
-                    } else {
-                        for (int k = kb; k < ke; ++k) s += prod[k - lo];
-                    }
-                    acc[q] = s;
-                }
-            }
-            __syncthreads();
-        }
-        if (k0 >= k1) __syncthreads();  // rowptr is re-staged by the next tile
-
-        // epilogue: coalesced
-#pragma unroll
-        for (int q = 0; q < STREAM_MAXR / BLOCK; ++q) {
-            const int i = tid + q * BLOCK;
-            if (i < nr) {
-                const int    r = r0 + i;
-                const double s = acc[q];
-                if (OP == OP_MXV) { a.y[r] = s; zx_store(a, r, s); }
-                else if (OP == OP_RESID) a.y[r] = a.b[r] - s;
-                else if (OP == OP_ADD) a.y[r] += s;
-                else if (OP == OP_SUB) a.y[r] -= s;
-                else if (OP == OP_AXPY) a.y[r] += s * a.alpha;
-                else if (OP == OP_JACOBI) {
-                    const double d = a.diag[r], xi = a.x[r];  // s == t_i of the reference
-                    a.y[r] = (fabs(d) > 1e-20) ? (1 - a.omega) * xi + a.omega * s / d : xi;
-                } else if (OP == OP_L1DIAG) {
-                    const double d = a.diag[r], xi = a.x[r];  // s == t_i of the reference
-                    a.y[r] = l1_or_jacobi_f(a, r, s, d, xi);
-                } else if (OP == OP_MXV_DOT) {
-                    a.y[r] = s;
-                    dotacc += s * a.dotv[r];
-                }
-            }
-        }
-    }
-    if (OP == OP_MXV_DOT) {
-        const double tot = block_sum(dotacc, red);
-        if (tid == 0) a.partials[blockIdx.x] = tot;
-    }
-}
-
+constexpr int STREAM_MAXR = 1024;  // (tile bound of the retired block-stream kernel; pick_kernel still sizes tile_rows with it)
 // ---------------------------------------------------------------------------
 // Dictionary-coded CSR ("value indexing" + "delta units", Kourtis / Goumas / Koziris 2008):
 // when a matrix holds at most 256 distinct (column - row base, value) pairs -- every level of

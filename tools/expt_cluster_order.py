@@ -24,7 +24,13 @@ def t(M):
         L.fasp_hip_tune(b"xtile", xt)
         out.append(L.fasp_hip_time_matrix(C.byref(A), 0, 20, C.byref(k)) * 1e3)
     L.fasp_hip_tune(b"xtile", 1)
-    return f"mxv with k_csr_xtile allowed {out[0]:7.1f} us, k_csr_wstream2 {out[1]:7.1f} us"
+    rows = []
+    for lanes in (4, 8, 16):
+        L.fasp_hip_tune(b"kind", 0); L.fasp_hip_tune(b"lanes", lanes)
+        rows.append(L.fasp_hip_time_matrix(C.byref(A), 0, 20, C.byref(k)) * 1e3)
+    L.fasp_hip_tune(b"kind", -1); L.fasp_hip_tune(b"lanes", -1)
+    return (f"mxv with k_csr_xtile allowed {out[0]:7.1f} us, k_csr_wstream2 {out[1]:7.1f} us, k_csr_rows<4/8/16> "
+            + "/".join(f"{v:.1f}" for v in rows))
 for lev in levels:
     r, c, mi, mj, mv = H.matrix(lev, 0)
     A = sp.csr_matrix((mv.copy(), mj.copy(), mi.copy()), shape=(r, c))

@@ -10,6 +10,7 @@
 #define FASP_LAB_DEBUG 1
 #include "../../faspsolver_amd/csrc/solver.hip"
 #include "../../faspsolver_amd/csrc/kernels2.hip.h"
+#include "retired_kernels.hip.h"
 
 #include <string>
 
