@@ -635,7 +635,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, seq_ulds = 1, seq_graph = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, spcg_test_hang = 0, small_onewave = 1; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, seq_persist = 0, split_rows = 0, gs_multicolor = 0, seq_block = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, seq_ulds = 1, seq_graph = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, spcg_test_hang = 0, small_onewave = 1, rp_stream = -1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -727,6 +727,9 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
     if (OP == OP_JACOBI && M.kind != 0 && M.kind < 4 && (M.dup_diag || !M.dpos) && !lstream_ok) M.kind = 0;  // needs the c != r test
     a.xcd_map = g_tune.xcd;
     a.nt = g_tune.nt;
+    // coded pair kernels: streaming hints on y / pattern ids / b where a vector does not fit the Infinity Cache beside the
+    // others anyway (P7(256): level 0 yes -- 0.546 -> 0.519 GB, 93 -> 88 us; level 1, 67 MB vectors, no: 63 -> 73 us with hints)
+    if (g_tune.rp_stream > 0 || (g_tune.rp_stream < 0 && (size_t)M.row * 8 > (size_t)96 << 20)) a.nt |= 4;
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
     a.ja16 = g_tune.ja16 ? M.ja16 : nullptr;
     if (M.kind == 1 || M.kind == 3) M.kind = 0;   // (block-level stream, one workgroup per row: measured slower, retired to tools/lab/)

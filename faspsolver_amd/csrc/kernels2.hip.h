@@ -572,6 +572,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
     int* const myq = xq + (threadIdx.x >> 6) * RP_QCAP;
     int        qn = 0;   // wave-uniform
     const int  lane = threadIdx.x & 63;
+    const bool stream = (a.nt & 4) != 0;   // wave-uniform: y, pattern ids and b with streaming (nt) hints
     constexpr bool NEG = (OP == OP_JACOBI || OP == OP_L1DIAG);
     const __amdgpu_buffer_rsrc_t xr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.x), 0, (int)((unsigned)a.ncol * 8u), 0x00020000);
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
             if (t < a.ntiles) return (t + a.tile0) * (2 * BLOCK);
         }
     };
-    auto ld_pp = [&](int r0) -> unsigned { return __builtin_nontemporal_load(pat2 + min((max(r0, 0) >> 1) + (int)threadIdx.x, npair - 1)); };
+    auto ld_pp = [&](int r0) -> unsigned { const unsigned* q = pat2 + min((max(r0, 0) >> 1) + (int)threadIdx.x, npair - 1); return stream ? __builtin_nontemporal_load(q) : *q; };
 
     // a row outside its wave's pattern: lane = row, its own list through the vector cache, 8 gathers in flight
     auto one_row = [&](int r) {
@@ -650,7 +651,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
     f64x2_t  pend_out = {0.0, 0.0};
     unsigned pend_off = 0xfffffff0u;
     auto flush = [&]() {  // one unconditional buffer store per step; lanes with nothing to store are out of range
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pend_out), yr, (int)pend_off, 0, 2);   // streaming (nt) store: y must not push the x planes out of the L2
+        // (streaming: y must not push the x planes out of the L2 -- only where the vectors exceed the Infinity Cache anyway)
+        if (stream) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pend_out), yr, (int)pend_off, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pend_out), yr, (int)pend_off, 0, 0);
         pend_off = 0xfffffff0u;
     };
     while (r0A >= 0) {
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
         const unsigned baseA = (unsigned)min(ra, last) * 8u;
         const int      rs = mine ? ra : 0;  // lanes that store nothing load from the first rows: always valid
         f64x2_t bb = {0.0, 0.0}, aux = {0.0, 0.0};
-        if (OP == OP_JACOBI || OP == OP_L1DIAG || OP == OP_RESID) bb = __builtin_nontemporal_load(reinterpret_cast<const f64x2_t*>(a.b + rs));   // (read once)
+        if (OP == OP_JACOBI || OP == OP_L1DIAG || OP == OP_RESID) bb = stream ? __builtin_nontemporal_load(reinterpret_cast<const f64x2_t*>(a.b + rs)) : *reinterpret_cast<const f64x2_t*>(a.b + rs);
         if (OP == OP_MXV_DOT) aux = *reinterpret_cast<const f64x2_t*>(a.dotv + rs);
         else if (OP == OP_ADD || OP == OP_SUB || OP == OP_AXPY) aux = *reinterpret_cast<const f64x2_t*>(a.y + rs);
         else if (OP == OP_L1DIAG) aux = *reinterpret_cast<const f64x2_t*>(a.diag + rs);
@@ -767,6 +770,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
     int* const myq = xq + (threadIdx.x >> 6) * RP_QCAP;
     int        qn = 0;   // wave-uniform
     const int  lane = threadIdx.x & 63;
+    const bool stream = (a.nt & 4) != 0;   // wave-uniform: y, pattern ids and b with streaming (nt) hints
     const __amdgpu_buffer_rsrc_t xr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.x), 0, (int)((unsigned)a.ncol * 8u), 0x00020000);
     const __amdgpu_buffer_rsrc_t yr =
@@ -822,11 +826,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
     };
     int      v = blockIdx.x;
     int      r0A = advance(v);
-    unsigned pp = __builtin_nontemporal_load(pat2 + pair_of(r0A));
+    unsigned pp = stream ? __builtin_nontemporal_load(pat2 + pair_of(r0A)) : pat2[pair_of(r0A)];
     f64x2_t  pend_out = {0.0, 0.0};
     unsigned pend_off = 0xfffffff0u;
     auto flush = [&]() {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pend_out), yr, (int)pend_off, 0, 2);
+        if (stream) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pend_out), yr, (int)pend_off, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pend_out), yr, (int)pend_off, 0, 0);
         pend_off = 0xfffffff0u;
     };
     // the two wave-uniform lists over per-lane bases, chunk by chunk in lockstep: 16 gathers in flight per lane
@@ -870,7 +875,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
     };
     while (r0A >= 0) {
         const int      r0B = advance(v);
-        const unsigned ppB = __builtin_nontemporal_load(pat2 + pair_of(r0B));
+        const unsigned ppB = stream ? __builtin_nontemporal_load(pat2 + pair_of(r0B)) : pat2[pair_of(r0B)];
         const int  ra = r0A + 2 * (int)threadIdx.x;
         const bool vb = ra + 1 <= last;
         const unsigned pidA = pp & 0xffffu, pidB = pp >> 16;

@@ -1978,6 +1978,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "xtile")) g_tune.xtile = value;
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
     else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;
+    else if (!std::strcmp(key, "rp_stream")) g_tune.rp_stream = value;
     else if (!std::strcmp(key, "rp_xcd")) g_tune.rp_xcd = value;
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
