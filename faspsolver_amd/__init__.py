@@ -49,7 +49,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_dist_get_list",
     "fasp_blas_dcsr_vmv", "fasp_blas_dcsr_mxv_agg", "fasp_blas_dcsr_aAxpy_agg", "fasp_blas_darray_ax",
     "fasp_blas_darray_axpyz", "fasp_blas_darray_norm1", "fasp_darray_cp", "fasp_darray_set", "fasp_dvec_isnan",
-    "fasp_hip_time_matrix", "fasp_hip_cluster_order",
+    "fasp_hip_time_matrix", "fasp_hip_cluster_order", "fasp_hip_bsr_dist_info",
 ]
 
 
@@ -497,6 +497,12 @@ class BSRAMG:
         st = lib().fasp_hip_bsr_solve(self.h, C.byref(bv), C.byref(xv), C.byref(itparam), T.dp(hist),
                                       hist_cap, C.byref(stats))
         return st, x, hist[:max(min(stats.nhist, hist_cap), 0)].copy(), stats
+
+    def dist_info(self):
+        """Row partition of level 0 (one process per GPU): owned block rows [row0, row0 + nloc)."""
+        info = (C.c_int * 6)()
+        lib().fasp_hip_bsr_dist_info(self.h, info)
+        return {"replicated": info[0], "row0": info[1], "nloc": info[2], "nghost": info[3], "first_replicated": info[4], "nb": info[5]}
 
     def free(self):
         if self.h:

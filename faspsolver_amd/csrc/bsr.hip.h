@@ -60,14 +60,23 @@ using namespace fasp_bsr;
 struct BsrLevel {
     std::unique_ptr<TmpBSR> A, P, R;
     double *dinv = nullptr, *b = nullptr, *x = nullptr, *x2 = nullptr, *w = nullptr;
-    int  n = 0;  // scalar rows
+    int  n = 0;  // scalar rows (owned)
     bool x_zero = false;
     DevLevel::Sched sched[2];  // level schedules of the sequential block sweeps: 0 ascending, 1 descending
+    // row partition (one process per GPU; single GPU: replicated, nv == n): owned block rows [row0, row0 + nloc) of
+    // nglobal, vectors of nv = (nloc + ghost blocks) * nb scalars, halo lists in SCALAR indices (a block = nb entries)
+    bool replicated = true;
+    int  nv = 0, row0 = 0, nloc = 0, nglobal = 0, nghost = 0;
+    std::vector<int> send_off, recv_off;   // nranks + 1 each, in scalars
+    int*    d_send_idx = nullptr;
+    double* d_sendbuf = nullptr;
 };
 struct fasp_hip_amg_bsr {
     HostHierarchyBSR      H;
     std::vector<BsrLevel> L;
     AMG_param             param;
+    DistPlan              dist;
+    bool                  distributed = false;   // level 0 is row-partitioned over the ranks
     double *b = nullptr, *u = nullptr, *p = nullptr, *t = nullptr, *r = nullptr, *z = nullptr;
     std::vector<double*> gm[2];
     size_t               gm_len[2] = {0, 0};
@@ -96,9 +105,11 @@ static void bsr_resid(const TmpBSR& M, const double* x, const double* b, double*
     BsrArgs a{}; a.x = x; a.y = r; a.b = b; a.alpha = -1.0;
     launch_bsr<1>(M, a);
 }
+static int bsr_halo_fwd(BsrLevel& Lv, double* v);
 static void bsr_jacobi(BsrLevel& Lv)
 {
     const TmpBSR& M = *Lv.A;
+    if (!Lv.x_zero && !Lv.replicated && bsr_halo_fwd(Lv, Lv.x) < 0) comm_mark_failed();   // the sweep reads its neighbours' old values
     if (Lv.x_zero) {
         hipLaunchKernelGGL(k_bsr_dinv_apply, dim3(vec_grid(Lv.n)), dim3(BLOCK), 0, g_ctx.stream, Lv.n, M.nb,
                            (const double*)Lv.dinv, (const double*)Lv.b, Lv.x);
@@ -158,6 +169,7 @@ static int bsr_smooth(fasp_hip_amg_bsr* h, int level, bool post, int smoother, i
     BsrLevel& Lv = h->L[level];
     int st = FASP_SUCCESS;
     if (steps <= 0) return st;
+    if (!Lv.replicated && smoother != SMOOTHER_JACOBI) return ERROR_AMG_SMOOTH_TYPE;   // block Gauss-Seidel / SOR sweeps couple all rows: whole levels only
     switch (smoother) {
         case SMOOTHER_JACOBI: for (int i = 0; i < steps; ++i) bsr_jacobi(Lv); break;
         case SMOOTHER_GS: for (int i = 0; i < steps && st >= 0; ++i) st = bsr_seq_sweep(h, level, post, false, 0.0); break;
@@ -179,6 +191,29 @@ static int bsr_smooth(fasp_hip_amg_bsr* h, int level, bool post, int smoother, i
 
 static KOps bsr_ops(fasp_hip_amg_bsr* h, int level, int set);
 
+// ghost entries of a vector of a row-partitioned block level from their owners (hierarchy.hip.h, halo_exchange: the same
+// pack + grouped send / receive, lists expanded to scalars; every rank of a distributed level enters it)
+static int bsr_halo(BsrLevel& Lv, double* v);
+static int bsr_halo_fwd(BsrLevel& Lv, double* v) { return bsr_halo(Lv, v); }
+static int bsr_halo(BsrLevel& Lv, double* v)
+{
+    if (Lv.replicated || comm_size() <= 1 || Lv.send_off.empty()) return FASP_SUCCESS;
+    const int P = comm_size(), me = comm_rank();
+    const int nsend = Lv.send_off.back();
+    if (nsend > 0)
+        hipLaunchKernelGGL(k_pack, dim3(vec_grid(nsend)), dim3(BLOCK), 0, g_ctx.stream, nsend, Lv.d_send_idx, v, Lv.d_sendbuf);
+    std::vector<CommXfer> sends, recvs;
+    for (int q = 0; q < P; ++q) {
+        if (q == me) continue;
+        const int ns = Lv.send_off[q + 1] - Lv.send_off[q], nr = Lv.recv_off[q + 1] - Lv.recv_off[q];
+        if (ns > 0) sends.push_back({q, Lv.d_sendbuf + Lv.send_off[q], (size_t)ns});
+        if (nr > 0) recvs.push_back({q, v + Lv.n + Lv.recv_off[q], (size_t)nr});
+    }
+    const int st = comm_exchange(sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size(), g_ctx.stream);
+    if (st < 0) comm_mark_failed();
+    return st;
+}
+
 // fasp_solver_mgcycle_bsr, PreMGCycle.c:287-566
 static int mgcycle_bsr(fasp_hip_amg_bsr* h, const AMG_param& param)
 {
@@ -191,14 +226,31 @@ ForwardSweep:
         BsrLevel& Lv = h->L[l];
         ++nu_l[l];
         { const int st = bsr_smooth(h, l, false, param.smoother, steps, param.relaxation); if (st < 0) return st; }
-        if (Lv.x_zero) { HIPCK(hipMemsetAsync(Lv.x, 0, sizeof(double) * Lv.n, s)); Lv.x_zero = false; }
+        if (Lv.x_zero) { HIPCK(hipMemsetAsync(Lv.x, 0, sizeof(double) * Lv.nv, s)); Lv.x_zero = false; }
+        if (bsr_halo(Lv, Lv.x) < 0) return ERROR_MISC;
         bsr_resid(*Lv.A, Lv.x, Lv.b, Lv.w);
-        bsr_mxv(*Lv.R, Lv.w, h->L[l + 1].b);
+        if (bsr_halo(Lv, Lv.w) < 0) return ERROR_MISC;       // R reads this level's residual, ghosts included
+        {
+            BsrLevel& C = h->L[l + 1];
+            if (!Lv.replicated && C.replicated) {
+                // first replicated level: every rank restricts onto the coarse block rows it owns, one all-gather
+                // assembles the whole right-hand side on every rank
+                const std::vector<int>& cs = h->dist.L[(size_t)l + 1].start;
+                const int nb = Lv.A->nb, P = comm_size(), me = comm_rank();
+                std::vector<int> counts((size_t)P), displs((size_t)P);
+                for (int q = 0; q < P; ++q) { counts[(size_t)q] = (cs[(size_t)q + 1] - cs[(size_t)q]) * nb; displs[(size_t)q] = cs[(size_t)q] * nb; }
+                bsr_mxv(*Lv.R, Lv.w, C.b + displs[(size_t)me]);
+                if (comm_allgatherv(C.b + displs[(size_t)me], counts[(size_t)me], C.b, counts.data(), displs.data(), s) < 0) return ERROR_MISC;
+            } else {
+                bsr_mxv(*Lv.R, Lv.w, C.b);
+            }
+        }
         ++l;
         h->L[l].x_zero = true;  // fasp_dvec_set(.., 0.0), materialised lazily
     }
     {   // coarsest level: fasp_solver_dbsr_pvgmres(A, b, x, NULL, tol, tol*1e-8, min(n^2,200), 25, 1, 0), :443-459
         BsrLevel& Lc = h->L[nl - 1];
+        if (!Lc.replicated) return ERROR_INPUT_PAR;   // (the plan keeps the coarsest level whole on every rank)
         if (Lc.x_zero) { HIPCK(hipMemsetAsync(Lc.x, 0, sizeof(double) * Lc.n, s)); Lc.x_zero = false; }
         const int csize = Lc.n;
         const int cmaxit = (int)std::min<unsigned>((unsigned)csize * (unsigned)csize, 200u);
@@ -241,7 +293,8 @@ ForwardSweep:
     while (l > 0) {
         --l;
         BsrLevel& Lv = h->L[l];
-        {   // x_l += P x_{l+1}  (fasp_blas_dbsr_aAxpy with alpha = 1)
+        {   // x_l += P x_{l+1}  (fasp_blas_dbsr_aAxpy with alpha = 1); a distributed coarse level: its ghosts first
+            if (bsr_halo(h->L[l + 1], h->L[l + 1].x) < 0) return ERROR_MISC;
             BsrArgs a{}; a.x = h->L[l + 1].x; a.y = Lv.x; a.alpha = 1.0;
             launch_bsr<1>(*Lv.P, a);
         }
@@ -272,7 +325,7 @@ static int precond_amg_bsr(fasp_hip_amg_bsr* h, double* r, double** z)
     for (int i = u.maxit; i--;)
         if ((st = mgcycle_bsr(h, p)) < 0) break;
     L0.b = saved_b;
-    if (L0.x_zero) { HIPCK(hipMemsetAsync(L0.x, 0, sizeof(double) * L0.n, g_ctx.stream)); L0.x_zero = false; }
+    if (L0.x_zero) { HIPCK(hipMemsetAsync(L0.x, 0, sizeof(double) * L0.nv, g_ctx.stream)); L0.x_zero = false; }
     *z = L0.x;
     return st;
 }
@@ -281,8 +334,8 @@ static KOps bsr_ops(fasp_hip_amg_bsr* h, int level, int set)
 {
     KOps K;
     BsrLevel* Lv = &h->L[level];
-    K.n = Lv->n; K.nvec = (size_t)Lv->n; K.fmt = "BSR"; K.dist = false;
-    K.halo = [](double*) { return 0; };
+    K.n = Lv->n; K.nvec = (size_t)Lv->nv; K.fmt = "BSR"; K.dist = (level == 0) && h->distributed;
+    K.halo = [Lv](double* v) { return bsr_halo(*Lv, v); };
     K.mxv = [Lv](const double* x, double* y) { bsr_mxv(*Lv->A, x, y); };
     K.resid = [Lv](const double* x, const double* b, double* r) { bsr_resid(*Lv->A, x, b, r); };
     if (set == 0) K.pc = [h](double* in, double** out) { return precond_amg_bsr(h, in, out); };

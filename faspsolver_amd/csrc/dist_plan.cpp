@@ -232,4 +232,49 @@ int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, 
     return FASP_SUCCESS;
 }
 
+// ---- block (BSR) hierarchy: the CSR planner on the block pattern ---------------------------------------------------
+int build_dist_plan_bsr(const HostHierarchyBSR& H, int rank, int nranks, int min_rows, DistPlan& D, std::vector<DistLocalBSR>& local)
+{
+    const int nl = (int)H.L.size();
+    // pattern hierarchy: a block row is a row; the "value" of an entry is its block index in the global matrix
+    HostHierarchy Hp;
+    Hp.L.resize((size_t)nl);
+    auto pattern = [](const HostBSR& B, HostCSR& C) {
+        C.row = B.ROW; C.col = B.COL; C.nnz = B.NNZ;
+        C.ia.view(const_cast<int*>(B.ia.data()), (size_t)B.ROW + 1);
+        C.ja.view(const_cast<int*>(B.ja.data()), (size_t)std::max(B.NNZ, 1));
+        C.val.alloc((size_t)std::max(B.NNZ, 1));
+#pragma omp parallel for schedule(static)
+        for (int k = 0; k < B.NNZ; ++k) C.val[k] = (double)k;
+    };
+    for (int l = 0; l < nl; ++l) {
+        pattern(H.L[(size_t)l].A, Hp.L[(size_t)l].A);
+        Hp.L[(size_t)l].has_coarse = H.L[(size_t)l].has_coarse;
+        if (H.L[(size_t)l].has_coarse) { pattern(H.L[(size_t)l].P, Hp.L[(size_t)l].P); pattern(H.L[(size_t)l].R, Hp.L[(size_t)l].R); }
+    }
+    const int st = build_dist_plan(Hp, rank, nranks, min_rows, D);
+    if (st < 0) return st;
+    local.clear();
+    local.resize((size_t)nl);
+    auto gather = [](const HostCSR& Lc, const HostBSR& G, HostBSR& out) {
+        const int nb = G.nb, nb2 = nb * nb;
+        out.ROW = Lc.row; out.COL = Lc.col; out.NNZ = Lc.nnz; out.nb = nb;
+        out.ia.alloc((size_t)Lc.row + 1); out.ja.alloc((size_t)std::max(Lc.nnz, 1)); out.val.alloc((size_t)std::max(Lc.nnz, 1) * nb2);
+        std::memcpy(out.ia.data(), Lc.ia.data(), sizeof(int) * ((size_t)Lc.row + 1));
+#pragma omp parallel for schedule(static)
+        for (int k = 0; k < Lc.nnz; ++k) {
+            out.ja[k] = Lc.ja[k];
+            std::memcpy(out.val.data() + (size_t)k * nb2, G.val.data() + (size_t)Lc.val[k] * nb2, sizeof(double) * nb2);
+        }
+    };
+    for (int l = 0; l < nl; ++l) {
+        DistLevel& DL = D.L[(size_t)l];
+        if (DL.replicated) continue;
+        gather(DL.A, H.L[(size_t)l].A, local[(size_t)l].A);
+        if (H.L[(size_t)l].has_coarse) { gather(DL.P, H.L[(size_t)l].P, local[(size_t)l].P); gather(DL.R, H.L[(size_t)l].R, local[(size_t)l].R); }
+        DL.A = HostCSR(); DL.P = HostCSR(); DL.R = HostCSR();   // the index-carrying patterns are no longer needed
+    }
+    return FASP_SUCCESS;
+}
+
 }  // namespace fasp

@@ -130,6 +130,12 @@ struct HostThreads {
 extern int g_parallel_min_nnz;  // host setup: threshold of the parallel (result-identical) transposes; fasp_hip_tune("host_parallel_min", n)
 // Levels with fewer than min_rows rows are replicated.  Pure host code.
 int build_dist_plan(const HostHierarchy& H, int rank, int nranks, int min_rows, DistPlan& D);
+// The same partition for the block (BSR) hierarchy of config 3: the plan is built on the BLOCK pattern (a block row is a
+// row, the aggregation hierarchy is cut into equal contiguous blocks), then the local block operators are gathered.
+// local[l] = {A, P, R} of the distributed levels (empty matrices on replicated levels).
+struct HostHierarchyBSR;
+struct DistLocalBSR;
+int build_dist_plan_bsr(const HostHierarchyBSR& H, int rank, int nranks, int min_rows, DistPlan& D, std::vector<DistLocalBSR>& local);
 
 // Classical (Ruge-Stuben) AMG setup, host side.  Restates PreAMGSetupRS.c:52
 // (+ PreAMGCoarsenRS.c, PreAMGInterp.c, BlaSparseCSR.c transposes, BlaSpmvCSR.c RAP)
@@ -160,6 +166,7 @@ struct HostBSR {
         return v;
     }
 };
+struct DistLocalBSR { HostBSR A, P, R; };   // local rows of a distributed block level, local block-column numbering
 struct HostLevelBSR {
     HostBSR     A, P, R;
     Buf<double> diaginv;  // inverse diagonal blocks of A (levels that are smoothed)

@@ -869,6 +869,8 @@ void fasp_hip_bsr_amg_destroy(fasp_hip_amg_bsr* h)
         double* v[] = {Lv.dinv, Lv.b, Lv.x, Lv.x2, Lv.w};
         for (double* q : v) if (q) (void)hipFree(q);
         for (auto& sc : Lv.sched) if (sc.d_order) (void)hipFree(sc.d_order);
+        if (Lv.d_send_idx) (void)hipFree(Lv.d_send_idx);
+        if (Lv.d_sendbuf) (void)hipFree(Lv.d_sendbuf);
     }
     double* v[] = {h->b, h->u, h->p, h->t, h->r};
     for (double* q : v) if (q) (void)hipFree(q);
@@ -905,29 +907,59 @@ int fasp_hip_bsr_amg_create(fasp_hip_amg_bsr** out, const dBSRmat* A, AMG_param*
     if ((st = fasp_hip_bsr_amg_create_host(&h, A, amgparam)) < 0) return st;
     const int nl = (int)h->H.L.size();
     h->L.resize(nl);
+    // one process per GPU: block rows partitioned over the ranks (dist_plan.cpp, build_dist_plan_bsr); levels below
+    // FASP_HIP_DIST_MIN_ROWS block rows -- and always the coarsest one -- are kept whole on every rank.  Block Gauss-Seidel /
+    // SOR sweeps couple all rows: such hierarchies stay whole.
+    std::vector<DistLocalBSR> local;
+    if (comm_size() > 1) {
+        int min_rows = 200000;
+        if (const char* e = std::getenv("FASP_HIP_DIST_MIN_ROWS")) min_rows = std::atoi(e);
+        if (h->param.smoother != SMOOTHER_JACOBI) min_rows = 2147483647;
+        min_rows = std::max(min_rows, h->H.L[(size_t)nl - 1].A.ROW + 1);
+        HostThreads team;
+        if ((st = build_dist_plan_bsr(h->H, comm_rank(), comm_size(), min_rows, h->dist, local)) < 0) { fasp_hip_bsr_amg_destroy(h); return st; }
+        h->distributed = !h->dist.L[0].replicated;
+    }
     for (int l = 0; l < nl; ++l) {
         const HostLevelBSR& HL = h->H.L[l];
         BsrLevel& Lv = h->L[l];
-        const dBSRmat vA = HL.A.view();
+        const int nb = HL.A.nb, nb2 = nb * nb;
+        const DistLevel* DL = (comm_size() > 1 && !h->dist.L[(size_t)l].replicated) ? &h->dist.L[(size_t)l] : nullptr;
+        Lv.replicated = DL == nullptr;
+        Lv.nglobal = HL.A.ROW;
+        Lv.row0 = DL ? DL->row0 : 0; Lv.nloc = DL ? DL->nloc : HL.A.ROW; Lv.nghost = DL ? (int)DL->ghosts.size() : 0;
+        const dBSRmat vA = DL ? local[(size_t)l].A.view() : HL.A.view();
         Lv.A.reset(new TmpBSR(&vA));
         bool ok = Lv.A->ok;
-        Lv.n = HL.A.ROW * HL.A.nb;
+        Lv.n = Lv.nloc * nb;
+        Lv.nv = (Lv.nloc + Lv.nghost) * nb;
         if (HL.has_coarse) {
-            const dBSRmat vP = HL.P.view(), vR = HL.R.view();
+            const dBSRmat vP = DL ? local[(size_t)l].P.view() : HL.P.view(), vR = DL ? local[(size_t)l].R.view() : HL.R.view();
             Lv.P.reset(new TmpBSR(&vP));
             Lv.R.reset(new TmpBSR(&vR));
             ok = ok && Lv.P->ok && Lv.R->ok;
-            const size_t nd = (size_t)HL.A.ROW * HL.A.nb * HL.A.nb;
+            const size_t nd = (size_t)Lv.nloc * nb2;
             if (hipMalloc(&Lv.dinv, sizeof(double) * std::max<size_t>(nd, 1)) != hipSuccess) ok = false;
-            else (void)hipMemcpy(Lv.dinv, HL.diaginv.data(), sizeof(double) * nd, hipMemcpyHostToDevice);
+            else (void)hipMemcpy(Lv.dinv, HL.diaginv.data() + (size_t)Lv.row0 * nb2, sizeof(double) * nd, hipMemcpyHostToDevice);
         }
-        if (!ok || dalloc(&Lv.b, Lv.n) < 0 || dalloc(&Lv.x, Lv.n) < 0 || dalloc(&Lv.x2, Lv.n) < 0 ||
-            dalloc(&Lv.w, Lv.n) < 0) {
+        if (ok && DL) {   // halo lists, expanded from blocks to scalars
+            const int P = comm_size();
+            Lv.send_off.assign((size_t)P + 1, 0); Lv.recv_off.assign((size_t)P + 1, 0);
+            for (int q = 0; q <= P; ++q) { Lv.send_off[(size_t)q] = DL->send_off[(size_t)q] * nb; Lv.recv_off[(size_t)q] = DL->recv_off[(size_t)q] * nb; }
+            std::vector<int> sidx(DL->send_idx.size() * (size_t)nb);
+            for (size_t i = 0; i < DL->send_idx.size(); ++i)
+                for (int c = 0; c < nb; ++c) sidx[i * nb + c] = DL->send_idx[i] * nb + c;
+            if (hipMalloc(&Lv.d_send_idx, sizeof(int) * std::max<size_t>(sidx.size(), 1)) != hipSuccess ||
+                hipMalloc(&Lv.d_sendbuf, sizeof(double) * std::max<size_t>(sidx.size(), 1)) != hipSuccess) ok = false;
+            else if (!sidx.empty()) (void)hipMemcpy(Lv.d_send_idx, sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice);
+        }
+        if (!ok || dalloc(&Lv.b, Lv.nv) < 0 || dalloc(&Lv.x, Lv.nv) < 0 || dalloc(&Lv.x2, Lv.nv) < 0 ||
+            dalloc(&Lv.w, Lv.nv) < 0) {
             fasp_hip_bsr_amg_destroy(h);
             return ERROR_ALLOC_MEM;
         }
     }
-    const size_t n0 = (size_t)h->L[0].n;
+    const size_t n0 = (size_t)h->L[0].nv;
     if (dalloc(&h->b, n0) < 0 || dalloc(&h->u, n0) < 0 || dalloc(&h->p, n0) < 0 || dalloc(&h->t, n0) < 0 ||
         dalloc(&h->r, n0) < 0) {
         fasp_hip_bsr_amg_destroy(h);
@@ -935,6 +967,18 @@ int fasp_hip_bsr_amg_create(fasp_hip_amg_bsr** out, const dBSRmat* A, AMG_param*
     }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     *out = h;
+    return FASP_SUCCESS;
+}
+
+// block rows of level 0 this rank owns: info[0] = 1 if the level is whole on every rank, [1] first owned block row,
+// [2] owned block rows, [3] ghost blocks, [4] first level kept whole, [5] block size
+int fasp_hip_bsr_dist_info(const fasp_hip_amg_bsr* h, int* info)
+{
+    if (!h || !info || h->L.empty()) return ERROR_INPUT_PAR;
+    const BsrLevel& L0 = h->L[0];
+    int first_rep = 0;
+    while (first_rep < (int)h->L.size() && !h->L[(size_t)first_rep].replicated) ++first_rep;
+    info[0] = L0.replicated ? 1 : 0; info[1] = L0.row0; info[2] = L0.nloc; info[3] = L0.nghost; info[4] = first_rep; info[5] = L0.A->nb;
     return FASP_SUCCESS;
 }
 
@@ -959,8 +1003,10 @@ int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const 
                        int hist_cap, fasp_hip_stats* stats)
 {
     if (!h || !b || !x || !itparam || h->L.empty()) return ERROR_INPUT_PAR;
-    const int n = h->L[0].n;
-    if (b->row != n || x->row != n) return ERROR_MAT_SIZE;
+    const int n = h->L[0].n;                                    // owned scalar rows
+    const int nglob = h->L[0].nglobal * h->H.L[0].A.nb;          // b and x are the GLOBAL vectors: a rank reads / fills its rows
+    const size_t off0 = (size_t)h->L[0].row0 * h->H.L[0].A.nb;
+    if (b->row != nglob || x->row != nglob) return ERROR_MAT_SIZE;
     int st = check_supported_bsr(itparam, &h->param, h->H.L[0].A.nb);
     if (st < 0) return st;
     if (itparam->tol < SMALLREAL)
@@ -969,8 +1015,8 @@ int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const 
         std::printf("### WARNING: Max number of iterations must be POSITIVE! [%s:%d]\n", "ITS_CHECK", 78);
     hipStream_t s = g_ctx.stream;
     double t0 = wall_seconds();
-    HIPCK(hipMemcpyAsync(h->b, b->val, sizeof(double) * n, hipMemcpyHostToDevice, s));
-    HIPCK(hipMemcpyAsync(h->u, x->val, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIPCK(hipMemcpyAsync(h->b, b->val + off0, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIPCK(hipMemcpyAsync(h->u, x->val + off0, sizeof(double) * n, hipMemcpyHostToDevice, s));
     HIPCK(hipStreamSynchronize(s));
     double t_up = wall_seconds() - t0;
 
@@ -1000,7 +1046,7 @@ int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const 
     HIPCK(hipStreamSynchronize(s));
     const double t_solve = wall_seconds() - t0;
     t0 = wall_seconds();
-    HIPCK(hipMemcpy(x->val, h->u, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(x->val + off0, h->u, sizeof(double) * n, hipMemcpyDeviceToHost));
     t_up += wall_seconds() - t0;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));

@@ -515,6 +515,10 @@ int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_para
 
 int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const ITS_param* itparam,
                        double* hist, int hist_cap, fasp_hip_stats* stats);
+/* one process per GPU (fasp_hip_comm_init before the create call): block rows of level 0 this rank owns --
+ * info[0] = 1 if level 0 is whole on every rank, [1] first owned block row, [2] owned block rows, [3] ghost blocks,
+ * [4] first level kept whole, [5] block size.  fasp_hip_bsr_solve takes the GLOBAL b and x; a rank fills its rows of x. */
+int fasp_hip_bsr_dist_info(const fasp_hip_amg_bsr* h, int* info);
 
 /* The same solve in three steps, for callers that keep b and x resident in HBM:
  * upload the right-hand side / initial guess (x == NULL: zeros), run the Krylov loop on

@@ -167,3 +167,62 @@ def test_replicated_levels_with_split_work_match_oracle(world, n, min_rows, cycl
     operator to its share of the rows only, an all-gather completes the result (hierarchy.hip.h, rep_launch).  Same
     iteration as the oracle's: iteration count, residual history, every rank's rows of the solution."""
     _run_ranks(world, n, min_rows, cycle, tune="coarse_mode=1,coarse_split_min=1024")
+
+
+# --- block (BSR) path, config 3: block rows partitioned over the ranks (dist_plan.cpp, build_dist_plan_bsr) ---------------
+def _bsr_worker(rank, world, name, n, min_rows, solver, cycle, q):
+    try:
+        os.environ["FASP_HIP_DIST_MIN_ROWS"] = str(min_rows)
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import faspsolver_amd as fa
+        import _libs
+        L = fa.lib()
+        assert L.fasp_hip_set_device(0) == 0
+        assert L.fasp_hip_comm_init_shm(rank, world, name.encode()) == 0
+        ia, ja, val, nb = _libs.poisson7pt_bsr(n)
+        f = np.random.default_rng(1).standard_normal((len(ia) - 1) * nb)
+        itp, amgp = _libs.bsr_params(solver, cycle)
+        G = fa.BSRAMG(ia, ja, val, nb, amgp)
+        info = G.dist_info()
+        st, x, hist, stats = G.solve(f, itp)
+        G.free()
+        L.fasp_hip_comm_finalize()
+        lo, hi = info["row0"] * nb, (info["row0"] + info["nloc"]) * nb
+        q.put((rank, "ok", st, stats.relres, x[lo:hi], info))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), None, None, None))
+
+
+@pytest.mark.parametrize("world,n,min_rows,solver,cycle", [(2, 16, 300, 5, 1), (3, 20, 500, 5, 1), (2, 16, 300, 1, 1), (4, 24, 800, 6, 2)])
+def test_block_rows_partitioned_match_oracle(world, n, min_rows, solver, cycle):
+    """P7(n) (x) B3, UA-AMG (VMB) + block Jacobi, Krylov methods of config 3 (VGMRES, CG, VFGMRES + W-cycle) on 2-4 ranks
+    over the shared-memory transport: iteration count, final residual and every rank's rows of the solution against the
+    oracle's single-process solve; level 0 really is partitioned."""
+    import multiprocessing as mp
+    from _libs import bsr_params, orc_bsr_solve, poisson7pt_bsr
+    ia, ja, val, nb = poisson7pt_bsr(n)
+    f = np.random.default_rng(1).standard_normal((len(ia) - 1) * nb)
+    i1, a1 = bsr_params(solver, cycle)
+    s_ref, x_ref, nl, rr_ref = orc_bsr_solve(ia, ja, val, nb, f, i1, a1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"fasp_bsr_{os.getpid()}_{world}_{n}_{solver}"
+    procs = [ctx.Process(target=_bsr_worker, args=(r, world, name, n, min_rows, solver, cycle, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=600) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.terminate()
+    for r in res:
+        assert r[1] == "ok", r[2]
+    for rank, _, st, relres, xloc, info in res:
+        assert info["replicated"] == 0 and info["first_replicated"] >= 1
+        assert st == s_ref
+        assert abs(relres - rr_ref) <= 1e-10
+        lo, hi = info["row0"] * nb, (info["row0"] + info["nloc"]) * nb
+        assert np.max(np.abs(xloc - x_ref[lo:hi])) <= 1e-8 * np.max(np.abs(x_ref))
