@@ -2088,6 +2088,7 @@ double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps)
             case 5: { CsrArgs a{}; a.x = x; a.y = y; a.dotv = x; a.partials = g_ctx.d_partials; launch_csr<OP_MXV_DOT>(D.A, a); } break;
             case 6: if (D.R.ia) d_mxv(D.R, w, h->L[level + 1].xa); break;
             case 7: if (D.P.ia) d_aAxpy(1.0, D.P, h->L[level + 1].xa, y); break;
+            case 10: case 11: case 12: case 13: (void)seq_sweep(h, level, kind - 10, 1, 1.0); break;   // GS sweep: ascending, descending, C rows, F rows
             default: break;
         }
     };
