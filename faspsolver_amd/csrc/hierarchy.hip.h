@@ -29,8 +29,18 @@ struct DevLevel {
     // 1 descending, 2 ascending C rows, 3 ascending F rows, 4 descending from row n-2
     struct Sched {
         bool built = false, multicolor = false; int* d_order = nullptr; int* d_ptr = nullptr; std::vector<int> ptr;
-        // the sweep's launches as a replayable graph, valid for these vectors / this update form
-        hipGraphExec_t graph_exec = nullptr; const double* g_b = nullptr; const double* g_x = nullptr; int g_form = -1, g_L = 0; double g_w = 0.0;
+        // split form (seq_split.hip.h): lower part in slots + tail CSR, the rest as a CSR, per-position diagonal / old value / W
+        int ns = 0, L = 1, LR = 1, reach = 0, pfmax = 1; bool nolower = false; long long ntail = 0, nslot = 0; double block_us = 0.0;
+        std::vector<int> cptr;   // split form: class -> first chunk (ptr holds the chunk descriptors)
+        int* d_sbase = nullptr; int* d_sc = nullptr; double* d_sv = nullptr; int* d_tia = nullptr; int* d_tja = nullptr; double* d_tval = nullptr;
+        int* d_ria = nullptr; int* d_rja = nullptr; double* d_rval = nullptr; double* d_rec = nullptr; double* d_dr = nullptr; int* d_tr = nullptr; double* d_W = nullptr;
+        std::vector<void*> owned;   // device arrays of the split form (d_order and d_ptr among them)
+        void release()
+        {
+            if (!owned.empty()) { for (void* q : owned) (void)hipFree(q); owned.clear(); }
+            else { if (d_order) (void)hipFree(d_order); if (d_ptr) (void)hipFree(d_ptr); }
+            d_order = nullptr; d_ptr = nullptr; built = false;
+        }
     };
     Sched   sched[5];
     // polynomial smoother (built on first use): 1 / first diagonal hit, the coefficients k[1..5] of
@@ -96,7 +106,7 @@ static void free_level(DevLevel& D)
     if (D.w) (void)hipFree(D.w);
     if (D.d_send_idx) (void)hipFree(D.d_send_idx);
     if (D.d_sendbuf) (void)hipFree(D.d_sendbuf);
-    for (auto& sc : D.sched) { if (sc.graph_exec) (void)hipGraphExecDestroy(sc.graph_exec); if (sc.d_order) (void)hipFree(sc.d_order); if (sc.d_ptr) (void)hipFree(sc.d_ptr); }
+    for (auto& sc : D.sched) sc.release();
     if (D.poly.dinv) (void)hipFree(D.poly.dinv);
     for (double* q : D.poly.w) if (q) (void)hipFree(q);
     if (D.d_mark) (void)hipFree(D.d_mark);

@@ -929,193 +929,6 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// k_seq_sweep<L>: a whole sequential sweep (Gauss-Seidel / SOR family, ItrSmootherCSR.c:251-1040) in ONE launch.
-// The host's level schedule (smoothers.hip.h: rows grouped by the level of the sweep's dependency DAG) is walked by
-// a resident grid: all blocks update the rows of DAG level l -- mutually uncoupled, so the result IS the sequential
-// sweep -- meet at a sharded arrival counter, and go on to level l + 1.  P7(256): 766 launches of k_seq_level per
-// sweep become one launch with 766 meetings of ~2.5 us.
-// u changes under the kernel's feet and per-CU L1s are never refreshed by other CUs' stores: every load of u is a
-// write-through-coherent (sc1) load and every store of u an sc1 store, drained before the block arrives
-// (MI355X_MICROARCH.md, inter-workgroup visibility, sc1-loads form).  Spins are bounded; *err != 0 afterwards
-// means a block was not resident.
-//   form 0  u_i = t * (1/a_ii)      form 1  u_i = t / a_ii      form 2  u_i = w (t / a_ii) + (1-w) u_i
-// ---------------------------------------------------------------------------
-struct SeqSweepArgs {
-    const int*    order;    // rows in schedule order
-    const int*    lptr;     // nlev + 1 offsets into order
-    int           nlev;
-    const int*    ia;
-    const int*    ja;
-    const double* val;
-    const double* b;
-    const double* diag;
-    double*       u;
-    int           form;
-    double        w;
-    unsigned*     sync;     // [0] top counter, [3] error word, [16 + 16 s] shard counters; zeroed before the launch
-};
-
-template <int L>
-__global__ __launch_bounds__(BLOCK) void k_seq_sweep(SeqSweepArgs a)
-{
-    typedef __attribute__((address_space(1))) unsigned           gu32;
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
-    constexpr int RPB = BLOCK / L;
-    __shared__ int s_ok;
-    const int sl = threadIdx.x & (L - 1);
-    const int rloc = threadIdx.x / L;
-    const int nb = (int)gridDim.x;
-    gu32* g_cnt = (gu32*)a.sync;
-    gu32* g_err = (gu32*)(a.sync + 3);
-    const unsigned shard = blockIdx.x & 7u;
-    const unsigned in_shard = ((unsigned)nb - shard + 7u) >> 3;
-    gu32* g_sh = (gu32*)(a.sync + 16 + 16 * shard);
-    const unsigned nshard = (unsigned)min(nb, 8);
-    auto ld_u = [&](int c) -> double {
-        return __longlong_as_double((long long)__hip_atomic_load((gu64*)(a.u + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    };
-    for (int l = 0; l < a.nlev; ++l) {
-        const int lo = a.lptr[l], hi = a.lptr[l + 1];
-        for (int idx = lo + blockIdx.x * RPB + rloc; idx < hi; idx += nb * RPB) {
-            const int r = a.order[idx];
-            const int kb = a.ia[r], ke = a.ia[r + 1];
-            double s = seq_row_sum<L>(a.ja, a.val, kb + sl, ke, r, ld_u);
-            s = subwave_sum<L>(s);
-            if (sl == 0) {
-                const double d = a.diag[r];
-                const double t = a.b[r] - s;
-                if (fabs(d) > 1e-20) {
-                    double un;
-                    if (a.form == 0) un = t * (1.0 / d);
-                    else if (a.form == 1) un = t / d;
-                    else un = a.w * (t / d) + (1 - a.w) * ld_u(r);
-                    __hip_atomic_store((gu64*)(a.u + r), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        if (l + 1 == a.nlev) break;
-        // meet: every storing wave drains, the block's barrier, one lane arrives (two-stage counter) and polls
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (__hip_atomic_fetch_add(g_sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard * (unsigned)(l + 1))
-                __hip_atomic_fetch_add(g_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned want = nshard * (unsigned)(l + 1);
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            int ok = 1;
-            while (__hip_atomic_load(g_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(1);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s at 100 MHz
-                    __hip_atomic_store(g_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-            }
-            if (__hip_atomic_load(g_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
-            s_ok = ok;
-        }
-        __syncthreads();
-        if (!s_ok) return;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// k_seq_block<L>: a whole sequential sweep in ONE workgroup of 1024 threads -- for the schedules whose classes
-// (dependency levels, or colours) hold a handful of rows each: the deep, dense levels, where a sweep is thousands
-// of classes of one to three rows and one launch per class costs ~4 us of launch latency for ~1 us of work.  Here a
-// class costs one workgroup barrier plus ONE memory round trip: the rows of the next class, their row pointers and
-// their first 8 L entries are fetched (they do not depend on u) before the barrier that ends the current class, so
-// after it only the gathers of u remain.  u travels through the L2 (agent-scope relaxed atomics: a wave must see what
-// a wave of another SIMD stored in the class before).  Arithmetic per row exactly as k_seq_level: lane-strided partial
-// sums in k order, sub-wavefront tree, the same three update forms -- the two kernels are interchangeable bit for bit.
-// ---------------------------------------------------------------------------
-// ULDS: the level's u fits the workgroup's LDS (n * 8 bytes of dynamic LDS, n <= ~19 000): it is loaded once, gathered and
-// updated there -- a class then costs an LDS round trip instead of one through the L2 -- and written back at the end.
-constexpr int SEQ_BLOCK = 1024;
-template <int L, bool ULDS>
-__global__ __launch_bounds__(SEQ_BLOCK) void k_seq_block(SeqSweepArgs a, int n)
-{
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
-    extern __shared__ __attribute__((aligned(16))) double u_lds[];
-    constexpr int RPB = SEQ_BLOCK / L, PF = 8;
-    const int sl = threadIdx.x & (L - 1);
-    const int rloc = threadIdx.x / L;
-    if (ULDS) {
-        for (int i = threadIdx.x; i < n; i += SEQ_BLOCK) u_lds[i] = a.u[i];
-        __syncthreads();
-    }
-    auto ld_u = [&](int c) -> double {
-        if (ULDS) return u_lds[c];
-        return __longlong_as_double((long long)__hip_atomic_load((gu64*)(a.u + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    };
-    auto finish = [&](int r, double s) {
-        s = subwave_sum<L>(s);
-        if (sl == 0) {
-            const double d = a.diag[r];
-            const double t = a.b[r] - s;
-            if (fabs(d) > 1e-20) {
-                double un;
-                if (a.form == 0) un = t * (1.0 / d);
-                else if (a.form == 1) un = t / d;
-                else un = a.w * (t / d) + (1 - a.w) * ld_u(r);
-                if (ULDS) u_lds[r] = un;
-                else __hip_atomic_store((gu64*)(a.u + r), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    };
-    int    rn = -1, kbn = 0, ken = 0, cn[PF];
-    double vn[PF];
-    auto prefetch = [&](int lo, int hi) {
-        rn = -1;
-        const int idx = lo + rloc;
-        if (idx < hi) {
-            rn = a.order[idx];
-            kbn = a.ia[rn]; ken = a.ia[rn + 1];
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int k = kbn + sl + q * L;
-                const bool ok = k < ken;
-                cn[q] = ok ? a.ja[k] : rn;       // (a masked slot looks like the diagonal: skipped below)
-                vn[q] = ok ? a.val[k] : 0.0;
-            }
-        }
-    };
-    int lo = a.lptr[0], hi = a.lptr[1];
-    prefetch(lo, hi);
-    for (int l = 0; l < a.nlev; ++l) {
-        const int r = rn, ke = ken, k1 = kbn + sl + PF * L;
-        int    c[PF];
-        double v[PF];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) { c[q] = cn[q]; v[q] = vn[q]; }
-        int nlo = hi, nhi = hi;
-        if (l + 1 < a.nlev) { nhi = a.lptr[l + 2]; prefetch(nlo, nhi); }
-        if (r >= 0) {
-            double s = 0.0, uq[PF];
-#pragma unroll
-            for (int q = 0; q < PF; ++q) uq[q] = ld_u(c[q]);
-#pragma unroll
-            for (int q = 0; q < PF; ++q)
-                if (c[q] != r) s += v[q] * uq[q];
-            s = seq_row_sum<L>(a.ja, a.val, k1, ke, r, ld_u, s);
-            finish(r, s);
-        }
-        for (int idx = lo + RPB + rloc; idx < hi; idx += RPB) {   // classes wider than one round
-            const int rr = a.order[idx];
-            const int kb = a.ia[rr], kend = a.ia[rr + 1];
-            finish(rr, seq_row_sum<L>(a.ja, a.val, kb + sl, kend, rr, ld_u));
-        }
-        lo = nlo; hi = nhi;
-        if (!ULDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    if (ULDS)
-        for (int i = threadIdx.x; i < n; i += SEQ_BLOCK) a.u[i] = u_lds[i];
-}
-
-// ---------------------------------------------------------------------------
 // Device copy / triad ceilings (bench.py reports them beside the roofline): 16 bytes per lane, grid-stride
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_copy16(size_t n16, const f64x2_t* __restrict__ src, f64x2_t* __restrict__ dst)

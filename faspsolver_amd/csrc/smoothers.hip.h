@@ -70,9 +70,7 @@ static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLeve
     for (int l = 0; l < nlev; ++l) S.ptr[l + 1] += S.ptr[l];
     std::vector<int> cur(S.ptr.begin(), S.ptr.end() - 1), order(seq.size());
     for (int i : seq) order[cur[lev[i] - 1]++] = i;
-    if (S.graph_exec) { (void)hipGraphExecDestroy(S.graph_exec); S.graph_exec = nullptr; }
-    if (S.d_order) { (void)hipFree(S.d_order); S.d_order = nullptr; }
-    if (S.d_ptr) { (void)hipFree(S.d_ptr); S.d_ptr = nullptr; }
+    S.release();
     HIPCK(hipMalloc(&S.d_order, sizeof(int) * std::max<size_t>(order.size(), 1)));
     if (!order.empty()) HIPCK(hipMemcpy(S.d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
     S.built = true;
@@ -80,31 +78,166 @@ static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLeve
     return FASP_SUCCESS;
 }
 
-// error word of the persistent sweep kernel: read back where the solve synchronises anyway
-static unsigned* g_seq_sync = nullptr;
-static unsigned* g_seq_herr = nullptr;
-static int seq_persist_check()
+// ---------------------------------------------------------------------------
+// The split form of a sequential sweep (seq_split.hip.h): class-major numbering of the swept rows by TRUE dependencies
+// only (row i after the coupled rows the sweep visits before it), the lower part in slot storage, the rest as a CSR
+// in sweep numbering.  Built once per (level, sweep kind) on first use.
+// ---------------------------------------------------------------------------
+constexpr int TRI_PF = 4;   // slot rounds the lanes-per-row choice aims at (TRI_PFMAX = 8 is what a chunk can store)
+template <class T>
+static int split_upload(DevLevel::Sched& S, T** dst, const std::vector<T>& v)
 {
-    if (!g_seq_sync) return FASP_SUCCESS;
-    HIPCK(hipMemcpyAsync(g_seq_herr, g_seq_sync + 3, sizeof(unsigned), hipMemcpyDeviceToHost, g_ctx.stream));
-    HIPCK(hipStreamSynchronize(g_ctx.stream));
-    if (*g_seq_herr) {
-        std::fprintf(stderr, "### ERROR: fasp_hip: the persistent sweep kernel timed out at a grid meeting (a block was not resident); "
-                             "fasp_hip_tune(\"seq_persist\", 0) selects one launch per dependency level\n");
-        return ERROR_MISC;
+    *dst = nullptr;
+    HIPCK(hipMalloc((void**)dst, sizeof(T) * std::max<size_t>(v.size(), 1)));
+    S.owned.push_back(*dst);
+    if (!v.empty()) HIPCK(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return FASP_SUCCESS;
+}
+static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::Sched& S)
+{
+    const int n = A.row, ns = (int)seq.size();
+    std::vector<int> pos(n, -1), lev(ns, 0);
+    for (int q = 0; q < ns; ++q) pos[seq[q]] = q;
+    int nlev = ns > 0 ? 1 : 0;
+    std::vector<int> nlow(ns, 0);
+    auto is_lower = [&](int i, int q, int j) { return j != i && j < n && pos[j] >= 0 && pos[j] < q; };
+    for (int q = 0; q < ns; ++q) {
+        const int i = seq[q];
+        int l = 0, c = 0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
+            if (is_lower(i, q, A.ja[k])) { l = std::max(l, lev[pos[A.ja[k]]]); ++c; }
+        lev[q] = l + 1; nlow[q] = c;
+        nlev = std::max(nlev, l + 1);
     }
+    std::vector<int> cls(nlev + 1, 0);
+    for (int q = 0; q < ns; ++q) cls[lev[q]]++;
+    for (int l = 0; l < nlev; ++l) cls[l + 1] += cls[l];
+    std::vector<int> cur(cls.begin(), cls.end() - 1), newpos(ns), order(ns), len(ns);
+    for (int q = 0; q < ns; ++q) { const int p = cur[lev[q] - 1]++; newpos[q] = p; order[p] = seq[q]; len[p] = nlow[q]; }
+    // lanes per row of the triangular part: TRI_PF * L slots cover the lower entries of 90 % of the rows
+    long long lower_total = 0;
+    int len90 = 0;
+    {
+        std::vector<long long> hist(258, 0);
+        for (int q = 0; q < ns; ++q) { hist[std::min(nlow[q], 257)]++; lower_total += nlow[q]; }
+        long long acc = 0;
+        for (int v = 0; v < 258; ++v) { acc += hist[v]; if (acc * 10 >= (long long)ns * 9) { len90 = v; break; } }
+    }
+    int L = 1;
+    while (L < 64 && TRI_PF * L < len90) L *= 2;
+    if (g_tune.seq_lanes > 0) { L = 1; while (L < 64 && L < g_tune.seq_lanes) L *= 2; }
+    // chunks: the classes cut into rounds of a TRI_BLOCK-thread workgroup; slots per lane = what the chunk's longest row needs
+    const int rpb = TRI_BLOCK / L;
+    std::vector<int> lo_of(1, 0);
+    S.cptr.assign(1, 0);
+    for (int l = 0; l < nlev; ++l) {
+        for (int lo = cls[l]; lo < cls[l + 1]; lo += rpb) lo_of.push_back(std::min(lo + rpb, cls[l + 1]));
+        S.cptr.push_back((int)lo_of.size() - 1);
+    }
+    const int nchunk = (int)lo_of.size() - 1;
+    if (ns > TRI_POS_MASK) return ERROR_INPUT_PAR;
+    std::vector<int> chunk_of(ns), pf_of(nchunk, 0), sbase(nchunk + 1, 0);
+    S.ptr.assign(nchunk + 1, 0);
+    long long nslot = 0;
+    int pfmax = 1;
+    double bytes_us = 0.0;   // the cost model of seq_sweep: microseconds of one workgroup's memory traffic
+    for (int c = 0; c < nchunk; ++c) {
+        int mx = 0;
+        for (int p = lo_of[c]; p < lo_of[c + 1]; ++p) { chunk_of[p] = c; mx = std::max(mx, len[p]); }
+        pf_of[c] = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));   // (at least one round: tri_fetch is branch-free)
+        pfmax = std::max(pfmax, pf_of[c]);
+        sbase[c] = (int)nslot;
+        nslot += (long long)pf_of[c] * L * (lo_of[c + 1] - lo_of[c]);
+        if (nslot > 0x0fffffffll) return ERROR_INPUT_PAR;   // (byte offsets of the slot values stay below 2^31)
+        S.ptr[c] = lo_of[c] | (pf_of[c] << 28);
+        const double bytes = (double)(lo_of[c + 1] - lo_of[c]) * L * (12.0 * pf_of[c] + 32.0);
+        bytes_us += std::max(0.7, bytes / 60e3);
+    }
+    sbase[nchunk] = (int)nslot; S.ptr[nchunk] = ns;
+    std::vector<int>    sc((size_t)nslot), tia(ns + 1, 0), ria(ns + 1, 0);
+    std::vector<double> sv((size_t)nslot, 0.0), dr(2 * (size_t)ns, 0.0);
+    std::vector<int>    tr(2 * (size_t)ns, 0);
+    for (int c = 0; c < nchunk; ++c) {
+        const int lo = lo_of[c], hi = lo_of[c + 1];
+        for (int q = 0; q < pf_of[c]; ++q)
+            for (int p = lo; p < hi; ++p)
+                for (int sl = 0; sl < L; ++sl) sc[(size_t)sbase[c] + (size_t)q * L * (hi - lo) + (size_t)(p - lo) * L + sl] = p;
+    }
+    long long ntail = 0, nrest = 0;
+    for (int q = 0; q < ns; ++q) {
+        const int i = seq[q], p = newpos[q];
+        const int t = std::max(0, nlow[q] - TRI_PFMAX * L);
+        tia[p + 1] = t; ntail += t;
+        int r = 0;
+        double dg = 0.0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            const int j = A.ja[k];
+            if (j == i) { dg = A.val[k]; continue; }   // the last diagonal hit, as the reference's loop leaves it
+            if (!is_lower(i, q, j)) ++r;
+        }
+        ria[p + 1] = r; nrest += r;
+        const bool alone = !(std::fabs(dg) > SMALLREAL);
+        dr[2 * (size_t)p] = dg; dr[2 * (size_t)p + 1] = alone ? 0.0 : 1.0 / dg;
+        tr[2 * (size_t)p] = t | (alone ? (int)0x80000000 : 0); tr[2 * (size_t)p + 1] = i;
+    }
+    for (int p = 0; p < ns; ++p) { tia[p + 1] += tia[p]; ria[p + 1] += ria[p]; }
+    std::vector<int>    tja((size_t)ntail), rja((size_t)nrest);
+    std::vector<double> tval((size_t)ntail), rval((size_t)nrest);
+    int reach = 0;   // how far back (in positions, from the end of its chunk) a row reads: the LDS ring must cover it
+    for (int q = 0; q < ns; ++q) {
+        const int i = seq[q], p = newpos[q];
+        const int ck = chunk_of[p], lo = lo_of[ck], hi = lo_of[ck + 1];
+        int e = 0;
+        size_t kt = (size_t)tia[p], kr = (size_t)ria[p];
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            const int j = A.ja[k];
+            if (j == i) continue;
+            if (is_lower(i, q, j)) {
+                const int cpos = newpos[pos[j]];
+                reach = std::max(reach, hi - cpos);
+                if (e < TRI_PFMAX * L) {
+                    const size_t at = (size_t)sbase[ck] + (size_t)(e / L) * L * (hi - lo) + (size_t)(p - lo) * L + (e % L);
+                    sc[at] = cpos; sv[at] = A.val[k];
+                } else { tja[kt] = cpos; tval[kt] = A.val[k]; ++kt; }
+                ++e;
+            } else { rja[kr] = j; rval[kr] = A.val[k]; ++kr; }
+        }
+    }
+    S.release();
+    int st = FASP_SUCCESS;
+    if ((st = split_upload(S, &S.d_order, order)) < 0) return st;
+    if ((st = split_upload(S, &S.d_ptr, S.ptr)) < 0) return st;
+    if ((st = split_upload(S, &S.d_sbase, sbase)) < 0) return st;
+    if ((st = split_upload(S, &S.d_sc, sc)) < 0) return st;
+    if ((st = split_upload(S, &S.d_sv, sv)) < 0) return st;
+    if ((st = split_upload(S, &S.d_tia, tia)) < 0) return st;
+    if ((st = split_upload(S, &S.d_tja, tja)) < 0) return st;
+    if ((st = split_upload(S, &S.d_tval, tval)) < 0) return st;
+    if ((st = split_upload(S, &S.d_ria, ria)) < 0) return st;
+    if ((st = split_upload(S, &S.d_rja, rja)) < 0) return st;
+    if ((st = split_upload(S, &S.d_rval, rval)) < 0) return st;
+    if ((st = split_upload(S, &S.d_rec, std::vector<double>(2 * (size_t)ns, 0.0))) < 0) return st;
+    if ((st = split_upload(S, &S.d_dr, dr)) < 0) return st;
+    if ((st = split_upload(S, &S.d_tr, tr)) < 0) return st;
+    if ((st = split_upload(S, &S.d_W, std::vector<double>((size_t)ns, 0.0))) < 0) return st;
+    S.ns = ns; S.L = L; S.nolower = lower_total == 0; S.ntail = ntail; S.reach = reach; S.block_us = bytes_us; S.nslot = nslot; S.pfmax = pfmax;
+    const double avg_rest = ns > 0 ? (double)nrest / ns : 0.0;
+    S.LR = 1;
+    while (S.LR < 64 && 4 * S.LR < avg_rest) S.LR *= 2;
+    S.built = true;
+    S.multicolor = false;
     return FASP_SUCCESS;
 }
 
-// one sequential sweep of schedule `kind` with update formula `form` (see k_seq_level)
+// one sequential sweep of schedule `kind` with update formula `form` (see tri_update)
 static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
 {
     DevLevel& D = h->L[level];
     DevLevel::Sched& S = D.sched[kind];
     // Multicolour mode -- a FLAGGED NON-PARITY mode for speed: the sweep visits the rows colour by colour instead of
     // in the reference's index order, which is a different (equally convergent, deterministic) Gauss-Seidel / SOR
-    // iteration; iteration counts and residuals then differ from the reference's.  The default is the level-scheduled
-    // sweep, which reproduces the reference's sequential sweep exactly.
+    // iteration; iteration counts and residuals then differ from the reference's.  The default is the split sweep
+    // (seq_split.hip.h), which reproduces the reference's sequential sweep.
     const bool multicolor = g_tune.gs_multicolor != 0;
     if (!S.built || S.multicolor != multicolor) {
         const HostCSR& A = h->H.L[level].A;
@@ -119,127 +252,129 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
             case 3: for (int i = 0; i < n; ++i) if (!cf || cf[i] != 1) seq.push_back(i); break;
             default: for (int i = n - 2; i >= 0; --i) seq.push_back(i); break;
         }
-        const int st = build_schedule(A, seq, S, multicolor);
+        const double t0 = wall_seconds();
+        const int st = multicolor ? build_schedule(A, seq, S, true) : build_split(A, seq, S);
         if (st < 0) return st;
-        if (std::getenv("FASP_HIP_SETUP_TIMING"))
-            std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind,
-                        multicolor ? "colours" : "dependency levels", (int)seq.size(), (int)S.ptr.size() - 1);
+        if (std::getenv("FASP_HIP_SETUP_TIMING")) {
+            if (multicolor) std::printf("  [sweep schedule] level %d, sweep kind %d, colours: %d rows in %d classes\n", level, kind, (int)seq.size(), (int)S.ptr.size() - 1);
+            else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes (%d chunks, reach %d), %d lanes per row, %.1f slots per row (%lld tail entries), rest pass %d lanes per row, one-workgroup estimate %.0f us, built in %.3f s\n",
+                             level, kind, S.ns, (int)S.cptr.size() - 1, (int)S.ptr.size() - 1, S.reach, S.L, S.ns ? (double)S.nslot / S.ns : 0.0, S.ntail, S.LR, S.block_us, wall_seconds() - t0);
+        }
     }
     materialise_zero(D);
-    // lanes per row: a class of a sequential sweep holds few rows (on the deep levels one to a few dozen), so a long row
-    // gets a whole wavefront whatever the SpMV kernel of the level uses (fasp_hip_tune("seq_lanes", L) overrides)
-    const double avg_len = D.A.row > 0 ? (double)D.A.nnz / D.A.row : 0.0;
-    const int L = g_tune.seq_lanes > 0 ? g_tune.seq_lanes : (avg_len >= 96.0 ? 64 : D.A.lanes);
-    const int nlev = (int)S.ptr.size() - 1;
-    // Optional (fasp_hip_tune("seq_persist", 1)): one launch per sweep (k_seq_sweep), the dependency levels separated by
-    // grid meetings instead of kernel boundaries.  MEASURED SLOWER than one launch per level (P7(128), GS-CF defaults:
-    // 922 ms against 852 ms per solve; profiles/r02_gs_persistent_sweep.txt): a meeting costs what a launch boundary
-    // costs (~3 us: drained write-through stores + arrival + poll), and the time of a sweep is the DEPTH of the
-    // dependency DAG on the dense coarse levels (thousands of levels of one to three rows), not the launch count.
-    // Needs every block resident at once, so never when validation ranks share the device.
-    // Schedules of many small classes (the deep, dense levels -- in either mode): the whole sweep in one workgroup
-    // (k_seq_block, kernels2.hip.h), a barrier and one memory round trip per class instead of a launch.
-    if (g_tune.seq_block && !multicolor && nlev >= 8 && (long long)S.ptr[nlev] <= (long long)nlev * (2 * SEQ_BLOCK / L)) {
-        if (!S.d_ptr) {
-            HIPCK(hipMalloc(&S.d_ptr, sizeof(int) * (size_t)(nlev + 1)));
-            HIPCK(hipMemcpy(S.d_ptr, S.ptr.data(), sizeof(int) * (size_t)(nlev + 1), hipMemcpyHostToDevice));
+    if (multicolor) {
+        const int nlev = (int)S.ptr.size() - 1;
+        // one launch per colour; lanes per row as the level's SpMV kernel
+        const double avg_len = D.A.row > 0 ? (double)D.A.nnz / D.A.row : 0.0;
+        const int L = g_tune.seq_lanes > 0 ? g_tune.seq_lanes : (avg_len >= 96.0 ? 64 : D.A.lanes);
+        for (int l = 0; l < nlev; ++l) {
+            const int lo = S.ptr[l], hi = S.ptr[l + 1];
+            const int rpb = BLOCK / L;
+            const int grid = std::max(1, std::min(MAXGRID, (hi - lo + rpb - 1) / rpb));
+#define SEQ_LAUNCH(LL) hipLaunchKernelGGL((k_seq_level<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, \
+            (const int*)S.d_order, lo, hi, (const int*)D.A.ia, (const int*)D.A.ja, (const double*)D.A.val,    \
+            (const double*)D.b, (const double*)D.diag, D.x, form, w)
+            switch (L) {
+                case 2: SEQ_LAUNCH(2); break;
+                case 4: SEQ_LAUNCH(4); break;
+                case 8: SEQ_LAUNCH(8); break;
+                case 16: SEQ_LAUNCH(16); break;
+                case 32: SEQ_LAUNCH(32); break;
+                default: SEQ_LAUNCH(64); break;
+            }
+#undef SEQ_LAUNCH
         }
-        SeqSweepArgs sa{};
-        sa.order = S.d_order; sa.lptr = S.d_ptr; sa.nlev = nlev; sa.ia = D.A.ia; sa.ja = D.A.ja; sa.val = D.A.val;
-        sa.b = D.b; sa.diag = D.diag; sa.u = D.x; sa.form = form; sa.w = w; sa.sync = nullptr;
-        const int   nrow = D.A.row;
-        const bool  ulds = g_tune.seq_ulds && (size_t)nrow * 8 <= 150 * 1024;   // u of the level in the workgroup's LDS
-        const size_t dyn = ulds ? (size_t)nrow * 8 : 0;
-#define SEQB_LAUNCH(LL)                                                                                                     \
-        if (ulds) {                                                                                                         \
+        return FASP_SUCCESS;
+    }
+    const int ns = S.ns;
+    if (ns == 0) return FASP_SUCCESS;
+    const int nchunk = (int)S.ptr.size() - 1, nlev = (int)S.cptr.size() - 1;
+    TriArgs ta{};
+    ta.lptr = S.d_ptr; ta.sbase = S.d_sbase; ta.nchunk = nchunk; ta.sc = S.d_sc; ta.sv = S.d_sv; ta.tia = S.d_tia; ta.tja = S.d_tja; ta.tval = S.d_tval;
+    ta.rec = S.d_rec; ta.dr = S.d_dr; ta.tr = S.d_tr; ta.nrow = D.A.row; ta.order = S.d_order; ta.W = S.d_W; ta.u = D.x; ta.form = form; ta.w = w;
+    // pass (1): everything that reads old values, all rows at once
+    {
+        const int rpb = BLOCK / S.LR;
+        const int grid = std::max(1, std::min(MAXGRID, (ns + rpb - 1) / rpb));
+#define REST_LAUNCH(LL) hipLaunchKernelGGL((k_split_rest<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, ns, (const int*)S.d_order, \
+        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)D.b, (const double*)D.x, S.d_rec)
+        switch (S.LR) {
+            case 1: REST_LAUNCH(1); break;
+            case 2: REST_LAUNCH(2); break;
+            case 4: REST_LAUNCH(4); break;
+            case 8: REST_LAUNCH(8); break;
+            case 16: REST_LAUNCH(16); break;
+            case 32: REST_LAUNCH(32); break;
+            default: REST_LAUNCH(64); break;
+        }
+#undef REST_LAUNCH
+    }
+    const int sgrid = std::max(1, std::min(MAXGRID, (ns + BLOCK - 1) / BLOCK));
+    if (S.nolower) {   // no row of the sweep reads another one's new value (the C rows / F rows of the 7-point level 0)
+        hipLaunchKernelGGL(k_split_scatter, dim3(sgrid), dim3(BLOCK), 0, g_ctx.stream, ns, ta, 1);
+        return FASP_SUCCESS;
+    }
+    // pass (2) in ONE workgroup (k_tri_block) when its chain of chunks beats one launch per class.  MEASURED on P7(128)
+    // (tools/perf_gs_levels.py): ~0.7 us per chunk with the new values in an LDS ring (more where chunks are wide: one
+    // compute unit keeps ~60 GB/s in flight), ~2.2 us per chunk when the schedule reaches further back than the ring and
+    // W goes through the L2; a launch per class costs ~3.2 us (classes of one chunk) to ~3.9 us.
+    // fasp_hip_tune("seq_block", 0) / ("seq_ulds", 0) switch the workgroup form / the ring off: same slots, same row
+    // arithmetic, same bits.
+    const int L = S.L;
+    const size_t lds_ptr = 2 * sizeof(int) * (size_t)(nchunk + 1);
+    constexpr size_t LDS_CAP = 158 * 1024;
+    int cap = 0;
+    if (g_tune.seq_ulds)
+        for (int c = 16384; c >= 1024 && !cap; c >>= 1)
+            if (S.reach <= c && (size_t)c * 8 + lds_ptr <= LDS_CAP) cap = c;
+    while (cap > 1024 && (cap >> 1) >= S.reach) cap >>= 1;   // (no larger than needed: the ring is zeroed per launch)
+    const double cost_block = cap ? S.block_us : std::max(S.block_us, 2.2 * nchunk), cost_launch = (double)nlev * 3.2 + 0.15 * (nchunk - nlev);
+    if (g_tune.seq_block && nlev >= 8 && lds_ptr <= LDS_CAP && cost_block < cost_launch) {
+        const size_t dyn = (cap ? (size_t)cap * 8 : 0) + lds_ptr;
+#define TRIB_ONE(LL, PP, WW, TT)                                                                                           \
+        {                                                                                                                   \
             static bool attr_set = false;                                                                                   \
             if (!attr_set) {                                                                                                \
-                HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_block<LL, true>),                             \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));                         \
+                HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tri_block<LL, PP, WW, TT>),                       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP));                       \
                 attr_set = true;                                                                                            \
             }                                                                                                               \
-            hipLaunchKernelGGL((k_seq_block<LL, true>), dim3(1), dim3(SEQ_BLOCK), dyn, g_ctx.stream, sa, nrow);             \
-        } else hipLaunchKernelGGL((k_seq_block<LL, false>), dim3(1), dim3(SEQ_BLOCK), 0, g_ctx.stream, sa, nrow)
-        switch (L) {
-            case 2: SEQB_LAUNCH(2); break;
-            case 4: SEQB_LAUNCH(4); break;
-            case 8: SEQB_LAUNCH(8); break;
-            case 16: SEQB_LAUNCH(16); break;
-            case 32: SEQB_LAUNCH(32); break;
-            default: SEQB_LAUNCH(64); break;
+            hipLaunchKernelGGL((k_tri_block<LL, PP, WW, TT>), dim3(1), dim3(TRI_BLOCK), dyn, g_ctx.stream, ta, ns, cap ? cap : 2); \
         }
-#undef SEQB_LAUNCH
+#define TRIB_LAUNCH(LL)                                                                                                     \
+        if (!cap) TRIB_ONE(LL, TRI_PFMAX, false, true)                                                                      \
+        else if (S.ntail) TRIB_ONE(LL, TRI_PFMAX, true, true)                                                               \
+        else if (S.pfmax > 4) TRIB_ONE(LL, TRI_PFMAX, true, false)                                                          \
+        else TRIB_ONE(LL, 4, true, false)
+        switch (L) {
+            case 1: TRIB_LAUNCH(1); break;
+            case 2: TRIB_LAUNCH(2); break;
+            case 4: TRIB_LAUNCH(4); break;
+            case 8: TRIB_LAUNCH(8); break;
+            case 16: TRIB_LAUNCH(16); break;
+            case 32: TRIB_LAUNCH(32); break;
+            default: TRIB_LAUNCH(64); break;
+        }
+#undef TRIB_LAUNCH
+#undef TRIB_ONE
         return FASP_SUCCESS;
     }
-    static bool seq_persist_disabled = false;
-    if (g_tune.seq_persist && !seq_persist_disabled && !comm_shares_devices() && nlev >= 4) {
-        if (!S.d_ptr) {
-            HIPCK(hipMalloc(&S.d_ptr, sizeof(int) * (size_t)(nlev + 1)));
-            HIPCK(hipMemcpy(S.d_ptr, S.ptr.data(), sizeof(int) * (size_t)(nlev + 1), hipMemcpyHostToDevice));
-        }
-        static unsigned* d_sync = nullptr;
-        static unsigned* h_err = nullptr;
-        if (!d_sync) { HIPCK(hipMalloc(&d_sync, 1024)); HIPCK(hipHostMalloc((void**)&h_err, 64, hipHostMallocDefault)); }
-        HIPCK(hipMemsetAsync(d_sync, 0, 1024, g_ctx.stream));
-        SeqSweepArgs sa{};
-        sa.order = S.d_order; sa.lptr = S.d_ptr; sa.nlev = nlev; sa.ia = D.A.ia; sa.ja = D.A.ja; sa.val = D.A.val;
-        sa.b = D.b; sa.diag = D.diag; sa.u = D.x; sa.form = form; sa.w = w; sa.sync = d_sync;
-        // two 256-thread blocks per CU: far below any residency limit of this small kernel, enough waves to hide the gathers
-        int widest = 0;
-        for (int l = 0; l < nlev; ++l) widest = std::max(widest, S.ptr[l + 1] - S.ptr[l]);
-        const int rpb = BLOCK / L;
-        const int grid = std::max(8, std::min(2 * g_ctx.num_cu, (widest + rpb - 1) / rpb));
-#define SEQP_LAUNCH(LL) hipLaunchKernelGGL((k_seq_sweep<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, sa)
-        switch (L) {
-            case 2: SEQP_LAUNCH(2); break;
-            case 4: SEQP_LAUNCH(4); break;
-            case 8: SEQP_LAUNCH(8); break;
-            case 16: SEQP_LAUNCH(16); break;
-            case 32: SEQP_LAUNCH(32); break;
-            default: SEQP_LAUNCH(64); break;
-        }
-#undef SEQP_LAUNCH
-        // the error word is checked lazily (no synchronisation per sweep): once per solve by seq_persist_check()
-        g_seq_sync = d_sync; g_seq_herr = h_err;
-        return FASP_SUCCESS;
-    }
-    // One launch per class.  Optional (fasp_hip_tune("seq_graph", 1)): the sweep's launches captured once as a HIP graph per
-    // (schedule, vectors, update form) and replayed.  MEASURED: no gain (P7(128) GS, 348 ms with and without) -- the
-    // ~4.4 us per class are the GPU's dispatch of a dependent kernel, not host launch overhead -- so it is off by default.
-    const bool use_graph = g_tune.seq_graph && nlev >= 16 && !comm_shares_devices();
-    if (use_graph && S.graph_exec && S.g_b == D.b && S.g_x == D.x && S.g_form == form && S.g_w == w && S.g_L == L)
-        return hipGraphLaunch(S.graph_exec, g_ctx.stream) == hipSuccess ? FASP_SUCCESS : ERROR_MISC;
-    bool capturing = false;
-    if (use_graph) {
-        if (S.graph_exec) { (void)hipGraphExecDestroy(S.graph_exec); S.graph_exec = nullptr; }
-        capturing = hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-    }
+    // wide classes: one launch per class, one workgroup per chunk
     for (int l = 0; l < nlev; ++l) {
-        const int lo = S.ptr[l], hi = S.ptr[l + 1];
-        const int rpb = BLOCK / L;
-        const int grid = std::max(1, std::min(MAXGRID, (hi - lo + rpb - 1) / rpb));
-#define SEQ_LAUNCH(LL) hipLaunchKernelGGL((k_seq_level<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, \
-        (const int*)S.d_order, lo, hi, (const int*)D.A.ia, (const int*)D.A.ja, (const double*)D.A.val,    \
-        (const double*)D.b, (const double*)D.diag, D.x, form, w)
+        const int c0 = S.cptr[l], grid = S.cptr[l + 1] - c0;
+#define TRIL_LAUNCH(LL) hipLaunchKernelGGL((k_tri_level<LL>), dim3(grid), dim3(TRI_BLOCK), 0, g_ctx.stream, ta, c0)
         switch (L) {
-            case 2: SEQ_LAUNCH(2); break;
-            case 4: SEQ_LAUNCH(4); break;
-            case 8: SEQ_LAUNCH(8); break;
-            case 16: SEQ_LAUNCH(16); break;
-            case 32: SEQ_LAUNCH(32); break;
-            default: SEQ_LAUNCH(64); break;
+            case 1: TRIL_LAUNCH(1); break;
+            case 2: TRIL_LAUNCH(2); break;
+            case 4: TRIL_LAUNCH(4); break;
+            case 8: TRIL_LAUNCH(8); break;
+            case 16: TRIL_LAUNCH(16); break;
+            case 32: TRIL_LAUNCH(32); break;
+            default: TRIL_LAUNCH(64); break;
         }
-#undef SEQ_LAUNCH
+#undef TRIL_LAUNCH
     }
-    if (capturing) {
-        hipGraph_t g = nullptr;
-        if (hipStreamEndCapture(g_ctx.stream, &g) != hipSuccess || !g) return ERROR_MISC;
-        const hipError_t e = hipGraphInstantiate(&S.graph_exec, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (e != hipSuccess) { S.graph_exec = nullptr; return ERROR_MISC; }
-        S.g_b = D.b; S.g_x = D.x; S.g_form = form; S.g_w = w; S.g_L = L;
-        return hipGraphLaunch(S.graph_exec, g_ctx.stream) == hipSuccess ? FASP_SUCCESS : ERROR_MISC;
-    }
+    hipLaunchKernelGGL(k_split_scatter, dim3(sgrid), dim3(BLOCK), 0, g_ctx.stream, ns, ta, 0);
     return FASP_SUCCESS;
 }
 

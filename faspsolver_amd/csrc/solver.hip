@@ -42,6 +42,7 @@
 #include "kernels.hip.h"
 #include "kernels2.hip.h"
 #include "small_solvers.hip.h"
+#include "seq_split.hip.h"
 
 namespace fasp {
 
@@ -647,7 +648,6 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
         }
     }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
-    if (seq_persist_check() < 0) return ERROR_MISC;   // a persistent sweep kernel that gave up at a grid meeting
     const double t_solve = wall_seconds() - t0;
 
     if (stats) {
@@ -790,7 +790,7 @@ int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z)
     if (st < 0) return st;
     HIPCK(hipMemcpyAsync(z, dz, sizeof(double) * m, hipMemcpyDeviceToHost, g_ctx.stream));
     HIPCK(hipStreamSynchronize(g_ctx.stream));
-    return seq_persist_check();
+    return FASP_SUCCESS;
 }
 
 // ---- row-partition inspection (host only; used by the CPU-side distributed tests) ----
@@ -868,7 +868,7 @@ void fasp_hip_bsr_amg_destroy(fasp_hip_amg_bsr* h)
     for (auto& Lv : h->L) {
         double* v[] = {Lv.dinv, Lv.b, Lv.x, Lv.x2, Lv.w};
         for (double* q : v) if (q) (void)hipFree(q);
-        for (auto& sc : Lv.sched) if (sc.d_order) (void)hipFree(sc.d_order);
+        for (auto& sc : Lv.sched) sc.release();
         if (Lv.d_send_idx) (void)hipFree(Lv.d_send_idx);
         if (Lv.d_sendbuf) (void)hipFree(Lv.d_sendbuf);
     }
@@ -2004,7 +2004,6 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "spcg_fused")) g_tune.spcg_fused = value;
     else if (!std::strcmp(key, "spcg_persist")) { g_tune.spcg_persist = value; if (value) g_persist_disabled = false; }
     else if (!std::strcmp(key, "spcg_test_hang")) g_tune.spcg_test_hang = value;
-    else if (!std::strcmp(key, "seq_persist")) g_tune.seq_persist = value;
     else if (!std::strcmp(key, "spcg_grid")) g_tune.spcg_grid = value;
     else if (!std::strcmp(key, "small_lds")) g_tune.small_lds = value;
     else if (!std::strcmp(key, "small_onewave")) g_tune.small_onewave = value;
@@ -2020,7 +2019,6 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "fuse_presmooth")) g_tune.fuse_presmooth = value;
     else if (!std::strcmp(key, "seq_lanes")) g_tune.seq_lanes = value;
     else if (!std::strcmp(key, "seq_ulds")) g_tune.seq_ulds = value;
-    else if (!std::strcmp(key, "seq_graph")) g_tune.seq_graph = value;
     else if (!std::strcmp(key, "xtile")) g_tune.xtile = value;
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
     else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;
@@ -2095,11 +2093,14 @@ double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps)
     (void)hipMemsetAsync(x, 0, sizeof(double) * n, g_ctx.stream);
     (void)hipMemsetAsync(y, 0, sizeof(double) * n, g_ctx.stream);
     (void)hipMemsetAsync(w, 0, sizeof(double) * n, g_ctx.stream);
+    double* const keep_b = D.b; double* const keep_x = D.x;
+    if (kind >= 10) { D.b = w; D.x = x; }   // the sweeps work on the level's own vectors: scratch ones while timing
     run(); run();
     (void)hipEventRecord(e0, g_ctx.stream);
     for (int i = 0; i < reps; ++i) run();
     (void)hipEventRecord(e1, g_ctx.stream);
     (void)hipEventSynchronize(e1);
+    D.b = keep_b; D.x = keep_x;
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

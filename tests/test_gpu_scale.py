@@ -213,9 +213,9 @@ def _gs_params(smoother, order, w=1.0):
 @pytest.mark.parametrize("smoother,order,w", [(T.SMOOTHER_GS, 1, 1.0), (T.SMOOTHER_GS, 0, 1.0), (T.SMOOTHER_SOR, 0, 1.1)],
                          ids=["GS-CF", "GS-natural", "SOR-natural"])
 def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
-    """The level-scheduled sweep (the reference's sequential Gauss-Seidel / SOR sweep, dependency level by dependency
-    level) runs the deep, dense levels in one workgroup (k_seq_block: a barrier per dependency level) and the others as
-    one launch per level (k_seq_level).  Same schedule, same row arithmetic: identical bits."""
+    """The triangular solve of a sequential sweep (seq_split.hip.h) runs in one workgroup where the dependency classes are
+    narrow (k_tri_block: a barrier per chunk, the new values in an LDS ring -- or through the L2 with the ring switched off)
+    and as one launch per class elsewhere (k_tri_level).  Same slots, same row arithmetic: identical bits."""
     n = 40
     ia, ja, a, f, ue = fa.poisson7pt(n)
     itp, amgp = _gs_params(smoother, order, w)
@@ -224,12 +224,13 @@ def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
     r = np.random.default_rng(11).standard_normal(len(f))
     try:
         out = []
-        for sb in (1, 0):
-            L.fasp_hip_tune(b"seq_block", sb)
+        for sb, ring in ((1, 1), (0, 1), (1, 0)):
+            L.fasp_hip_tune(b"seq_block", sb); L.fasp_hip_tune(b"seq_ulds", ring)
             out.append(H.precond(r))
     finally:
-        L.fasp_hip_tune(b"seq_block", 1)
+        L.fasp_hip_tune(b"seq_block", 1); L.fasp_hip_tune(b"seq_ulds", 1)
     assert np.array_equal(out[0], out[1])
+    assert np.array_equal(out[0], out[2])
     H.close()
 
 
@@ -364,8 +365,8 @@ def test_xtile_kernel_is_bit_identical_to_wstream2(gpu, var):
 def test_sequential_smoothers_match_reference_64(gpu, tag, smoother, order, w):
     """The parity mode of the sequential smoothers at 64^3 against the REFERENCE's own run (tests/golden/p7_sweeps.npz,
     tools/gen_golden_sweeps.py): Gauss-Seidel in C/F order (the reference's defaults), in natural order, SOR(1.1).
-    At this size the deep levels run as one-workgroup sweeps with u in LDS, the upper ones as one launch per
-    dependency level: equal iteration counts, residual histories to 1e-8, |relres - ref| <= 1e-10."""
+    At this size the deep levels run as one-workgroup triangular solves with the new values in an LDS ring, the upper
+    ones as one launch per dependency class: equal iteration counts, residual histories to 1e-8, |relres - ref| <= 1e-10."""
     z = np.load(os.path.join(G, "p7_sweeps.npz"))
     ia, ja, a, f, ue = fa.poisson7pt(64)
     itp, amgp = _gs_params(smoother, order, w)
