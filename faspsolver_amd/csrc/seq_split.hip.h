@@ -48,10 +48,13 @@ struct TriArgs {
     double*       W;       // the new iterate of the swept rows (variants that do not keep it in LDS)
     double*       u;       // the level's iterate (scatter target)
     int           nrow;    // rows of the level
+    int           far;     // the schedule has far entries: the one-workgroup solve also writes W
     int           form;    // 0  u_i = t * (1/a_ii)   1  u_i = t / a_ii   2  u_i = w (t / a_ii) + (1 - w) u_i
     double        w;
 };
 constexpr int TRI_POS_MASK = 0x0fffffff;
+constexpr int TRI_FAR_BIT = 0x10000000;          // tail columns: an entry the LDS ring does not reach back to (read from W in memory)
+constexpr size_t TRI_LDS_CAP = 158 * 1024;      // dynamic LDS of the one-workgroup solve
 
 // t / d from the stored reciprocal rd = RN(1 / d): q = RN(t rd), then one correction step with the exact remainder
 // (Markstein): q' = RN(q + (t - d q) rd) -- the correctly rounded quotient (the IEEE division the reference performs)
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_level(TriArgs a, int chunk0)
         const TriBufs B = tri_bufs(a);
         TriPre<TRI_PFMAX> r;
         tri_fetch<L, TRI_PFMAX>(B, r, lo, hi, pf, a.sbase[ck], rloc, sl);
-        const double un = tri_row<L, TRI_PFMAX, true>(a, r, p, sl, [&](int c) -> double { return a.W[c]; });
+        const double un = tri_row<L, TRI_PFMAX, true>(a, r, p, sl, [&](int c) -> double { return a.W[c & TRI_POS_MASK]; });
         if (sl == L - 1) a.W[p] = un;
     }
 }
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_block(TriArgs a, int nseq, in
         for (int i = threadIdx.x; i < cap; i += TRI_BLOCK) ring[i] = 0.0;   // (unused slots read their own, not yet written, position: times 0)
     __syncthreads();
     auto ldw = [&](int c) -> double {
-        if (WIN) return ring[c & mask];
-        return __longlong_as_double((long long)__hip_atomic_load((gu64*)(a.W + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (WIN && !(TAIL && (c & TRI_FAR_BIT))) return ring[c & mask];
+        return __longlong_as_double((long long)__hip_atomic_load((gu64*)(a.W + (c & TRI_POS_MASK)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     };
     struct Set { TriPre<PF> r[G]; int lo[G], hi[G]; };
     Set S0, S1;
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_block(TriArgs a, int nseq, in
                 if (WIN) {
                     ring[p & mask] = un;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, un), B.u, S.r[d].row * 8, 0, 0);
+                    if (a.far) a.W[p] = un;   // (read back, L1 bypassed, at least four drained groups of chunks later)
                 } else __hip_atomic_store((gu64*)(a.W + p), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_block(TriArgs a, int nseq, in
     // one group: its first chain (the compiler's own wait for the set lands here: everything requested a group ago has
     // arrived, nothing younger is in flight), THEN the request for the next group, then the remaining chains
     auto run_group = [&](const Set& S, Set& N, int l0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also what makes a far read safe: every store of W older than a group has landed)
         run_chunk(S, 0, l0);
         fetch_group(N, l0 + G);
 #pragma unroll

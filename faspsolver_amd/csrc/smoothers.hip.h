@@ -135,15 +135,40 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
         S.cptr.push_back((int)lo_of.size() - 1);
     }
     const int nchunk = (int)lo_of.size() - 1;
-    if (ns > TRI_POS_MASK) return ERROR_INPUT_PAR;
+    if (ns >= TRI_FAR_BIT) return ERROR_INPUT_PAR;
     std::vector<int> chunk_of(ns), pf_of(nchunk, 0), sbase(nchunk + 1, 0);
+    for (int c = 0; c < nchunk; ++c)
+        for (int p = lo_of[c]; p < lo_of[c + 1]; ++p) chunk_of[p] = c;
+    // The LDS ring the one-workgroup solve keeps the new values in covers `ringcap` positions behind the end of the chunk
+    // at work.  A lower entry further back is FAR: it goes to the row's tail, flagged, and is read from W in memory
+    // (written there dozens of chunks -- several drained memory counters -- earlier).  The ring is the largest power of
+    // two that fits beside the chunk descriptors; no far entries where it would be shorter than four groups of chunks.
+    int ringcap = 0;
+    for (int c = 16384; c >= 1024 && !ringcap; c >>= 1)
+        if ((size_t)c * 8 + 2 * sizeof(int) * (size_t)(nchunk + 1) <= TRI_LDS_CAP) ringcap = c;
+    if (ringcap < 16 * rpb) ringcap = 0;
+    auto is_far = [&](int p, int cpos) { return ringcap > 0 && lo_of[chunk_of[p] + 1] - cpos > ringcap; };
+    std::vector<int> nfar_of(ns, 0);
+    long long nfar = 0;
+    for (int q = 0; q < ns; ++q) {
+        const int i = seq[q], p = newpos[q];
+        int f = 0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
+            if (is_lower(i, q, A.ja[k]) && is_far(p, newpos[pos[A.ja[k]]])) ++f;
+        nfar_of[p] = f; nfar += f;
+    }
+    if (nfar * 50 > lower_total) {   // more than a few stragglers: not a schedule for the ring (seq_sweep then weighs the L2 form against launches)
+        ringcap = 0; nfar = 0;
+        std::fill(nfar_of.begin(), nfar_of.end(), 0);
+    }
+    for (int p = 0; p < ns; ++p) len[p] -= nfar_of[p];   // len: NEAR lower entries from here on
     S.ptr.assign(nchunk + 1, 0);
     long long nslot = 0;
     int pfmax = 1;
     double bytes_us = 0.0;   // the cost model of seq_sweep: microseconds of one workgroup's memory traffic
     for (int c = 0; c < nchunk; ++c) {
         int mx = 0;
-        for (int p = lo_of[c]; p < lo_of[c + 1]; ++p) { chunk_of[p] = c; mx = std::max(mx, len[p]); }
+        for (int p = lo_of[c]; p < lo_of[c + 1]; ++p) mx = std::max(mx, len[p]);
         pf_of[c] = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));   // (at least one round: tri_fetch is branch-free)
         pfmax = std::max(pfmax, pf_of[c]);
         sbase[c] = (int)nslot;
@@ -151,7 +176,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
         if (nslot > 0x0fffffffll) return ERROR_INPUT_PAR;   // (byte offsets of the slot values stay below 2^31)
         S.ptr[c] = lo_of[c] | (pf_of[c] << 28);
         const double bytes = (double)(lo_of[c + 1] - lo_of[c]) * L * (12.0 * pf_of[c] + 32.0);
-        bytes_us += std::max(0.7, bytes / 60e3);
+        bytes_us += std::max(0.7, bytes / 25e3);   // (measured: one compute unit sustains ~25 GB/s of such fetches)
     }
     sbase[nchunk] = (int)nslot; S.ptr[nchunk] = ns;
     std::vector<int>    sc((size_t)nslot), tia(ns + 1, 0), ria(ns + 1, 0);
@@ -166,7 +191,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     long long ntail = 0, nrest = 0;
     for (int q = 0; q < ns; ++q) {
         const int i = seq[q], p = newpos[q];
-        const int t = std::max(0, nlow[q] - TRI_PFMAX * L);
+        const int t = std::max(0, len[p] - TRI_PFMAX * L) + nfar_of[p];   // near entries beyond the slots + far entries
         tia[p + 1] = t; ntail += t;
         int r = 0;
         double dg = 0.0;
@@ -194,6 +219,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
             if (j == i) continue;
             if (is_lower(i, q, j)) {
                 const int cpos = newpos[pos[j]];
+                if (is_far(p, cpos)) { tja[kt] = cpos | TRI_FAR_BIT; tval[kt] = A.val[k]; ++kt; continue; }
                 reach = std::max(reach, hi - cpos);
                 if (e < TRI_PFMAX * L) {
                     const size_t at = (size_t)sbase[ck] + (size_t)(e / L) * L * (hi - lo) + (size_t)(p - lo) * L + (e % L);
@@ -220,7 +246,13 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     if ((st = split_upload(S, &S.d_dr, dr)) < 0) return st;
     if ((st = split_upload(S, &S.d_tr, tr)) < 0) return st;
     if ((st = split_upload(S, &S.d_W, std::vector<double>((size_t)ns, 0.0))) < 0) return st;
-    S.ns = ns; S.L = L; S.nolower = lower_total == 0; S.ntail = ntail; S.reach = reach; S.block_us = bytes_us; S.nslot = nslot; S.pfmax = pfmax;
+    S.nfar_chunks = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        bool any = false;
+        for (int p = lo_of[c]; p < lo_of[c + 1] && !any; ++p) any = nfar_of[p] > 0;
+        S.nfar_chunks += any;
+    }
+    S.ns = ns; S.L = L; S.nolower = lower_total == 0; S.ntail = ntail; S.reach = reach; S.nfar = nfar; S.ringcap = ringcap; S.block_us = bytes_us; S.nslot = nslot; S.pfmax = pfmax;
     const double avg_rest = ns > 0 ? (double)nrest / ns : 0.0;
     S.LR = 1;
     while (S.LR < 64 && 4 * S.LR < avg_rest) S.LR *= 2;
@@ -257,8 +289,8 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
         if (st < 0) return st;
         if (std::getenv("FASP_HIP_SETUP_TIMING")) {
             if (multicolor) std::printf("  [sweep schedule] level %d, sweep kind %d, colours: %d rows in %d classes\n", level, kind, (int)seq.size(), (int)S.ptr.size() - 1);
-            else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes (%d chunks, reach %d), %d lanes per row, %.1f slots per row (%lld tail entries), rest pass %d lanes per row, one-workgroup estimate %.0f us, built in %.3f s\n",
-                             level, kind, S.ns, (int)S.cptr.size() - 1, (int)S.ptr.size() - 1, S.reach, S.L, S.ns ? (double)S.nslot / S.ns : 0.0, S.ntail, S.LR, S.block_us, wall_seconds() - t0);
+            else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes (%d chunks, reach %d, %lld far entries in %d chunks), %d lanes per row, %.1f slots per row (%lld tail entries), rest pass %d lanes per row, one-workgroup estimate %.0f us, built in %.3f s\n",
+                             level, kind, S.ns, (int)S.cptr.size() - 1, (int)S.ptr.size() - 1, S.reach, S.nfar, S.nfar_chunks, S.L, S.ns ? (double)S.nslot / S.ns : 0.0, S.ntail, S.LR, S.block_us, wall_seconds() - t0);
         }
     }
     materialise_zero(D);
@@ -291,7 +323,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     const int nchunk = (int)S.ptr.size() - 1, nlev = (int)S.cptr.size() - 1;
     TriArgs ta{};
     ta.lptr = S.d_ptr; ta.sbase = S.d_sbase; ta.nchunk = nchunk; ta.sc = S.d_sc; ta.sv = S.d_sv; ta.tia = S.d_tia; ta.tja = S.d_tja; ta.tval = S.d_tval;
-    ta.rec = S.d_rec; ta.dr = S.d_dr; ta.tr = S.d_tr; ta.nrow = D.A.row; ta.order = S.d_order; ta.W = S.d_W; ta.u = D.x; ta.form = form; ta.w = w;
+    ta.rec = S.d_rec; ta.dr = S.d_dr; ta.tr = S.d_tr; ta.nrow = D.A.row; ta.order = S.d_order; ta.W = S.d_W; ta.u = D.x; ta.form = form; ta.w = w; ta.far = S.nfar > 0;
     // pass (1): everything that reads old values, all rows at once
     {
         const int rpb = BLOCK / S.LR;
@@ -316,19 +348,23 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     }
     // pass (2) in ONE workgroup (k_tri_block) when its chain of chunks beats one launch per class.  MEASURED on P7(128)
     // (tools/perf_gs_levels.py): ~0.7 us per chunk with the new values in an LDS ring (more where chunks are wide: one
-    // compute unit keeps ~60 GB/s in flight), ~2.2 us per chunk when the schedule reaches further back than the ring and
+    // compute unit sustains ~25 GB/s of these fetches), ~2.2 us per chunk when the schedule reaches further back than the ring and
     // W goes through the L2; a launch per class costs ~3.2 us (classes of one chunk) to ~3.9 us.
     // fasp_hip_tune("seq_block", 0) / ("seq_ulds", 0) switch the workgroup form / the ring off: same slots, same row
     // arithmetic, same bits.
     const int L = S.L;
     const size_t lds_ptr = 2 * sizeof(int) * (size_t)(nchunk + 1);
-    constexpr size_t LDS_CAP = 158 * 1024;
+    constexpr size_t LDS_CAP = TRI_LDS_CAP;
     int cap = 0;
-    if (g_tune.seq_ulds)
-        for (int c = 16384; c >= 1024 && !cap; c >>= 1)
-            if (S.reach <= c && (size_t)c * 8 + lds_ptr <= LDS_CAP) cap = c;
-    while (cap > 1024 && (cap >> 1) >= S.reach) cap >>= 1;   // (no larger than needed: the ring is zeroed per launch)
-    const double cost_block = cap ? S.block_us : std::max(S.block_us, 2.2 * nchunk), cost_launch = (double)nlev * 3.2 + 0.15 * (nchunk - nlev);
+    if (g_tune.seq_ulds) {
+        if (S.nfar) cap = S.ringcap;   // (the far entries were chosen against exactly this ring)
+        else {
+            for (int c = 16384; c >= 1024 && !cap; c >>= 1)
+                if (S.reach <= c && (size_t)c * 8 + lds_ptr <= LDS_CAP) cap = c;
+            while (cap > 1024 && (cap >> 1) >= S.reach) cap >>= 1;   // (no larger than needed: the ring is zeroed per launch)
+        }
+    }
+    const double cost_block = cap ? S.block_us + 1.5 * S.nfar_chunks : std::max(S.block_us, 2.2 * nchunk), cost_launch = (double)nlev * 3.2 + 0.15 * (nchunk - nlev);
     if (g_tune.seq_block && nlev >= 8 && lds_ptr <= LDS_CAP && cost_block < cost_launch) {
         const size_t dyn = (cap ? (size_t)cap * 8 : 0) + lds_ptr;
 #define TRIB_ONE(LL, PP, WW, TT)                                                                                           \

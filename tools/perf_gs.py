@@ -19,7 +19,7 @@ for name, mod in cases:
     amgp = fa.param_amg_init(); mod(amgp)
     t = time.time(); H = fa.AMG(ia, ja, a, amgp); print(f"P7({n}) {name}: setup {time.time()-t:.1f}s levels {H.num_levels}", flush=True)
     H.set_rhs(f)
-    for mc, sb in (((0, 1),) if "Jacobi" in name else ((0, 0), (0, 0), (0, 1), (0, 1), (0, 1), (1, 1), (1, 1))):
+    for mc, sb in (((0, 1), (0, 1), (0, 1)) if "Jacobi" in name else ((0, 0), (0, 0), (0, 1), (0, 1), (0, 1), (1, 1), (1, 1))):
         L.fasp_hip_tune(b"gs_multicolor", mc); L.fasp_hip_tune(b"seq_block", sb)
         st, hist, stats = H.solve_resident(itp)
         print(f"  gs_multicolor {mc} seq_block {sb}: iters {st} relres {stats.relres:.10e} solve {stats.solve_seconds*1e3:.1f} ms coarse its {stats.coarse_iters}", flush=True)
