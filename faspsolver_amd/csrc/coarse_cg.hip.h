@@ -134,7 +134,19 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         int LD = m; while (LD % 32 != 1) ++LD;     // row stride in doubles: conflict-free lane = row reads
         const size_t lds_w = sizeof(double) * (128 * (size_t)LD + 128);
         const bool one_wave = g_tune.small_onewave && m <= 128 && lds_w <= 148 * 1024;
-        if (one_wave) {
+        if (one_wave && g_tune.small_onewave >= 2) {   // the matrix in registers (four wavefronts); small_onewave 1: dense in LDS, one wavefront
+            static bool attr_r = false;
+            if (!attr_r) {
+                (void)hipFuncSetAttribute((const void*)k_spcg_reg<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_spcg_reg<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_spcg_reg<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                attr_r = true;
+            }
+            if (m <= 64) hipLaunchKernelGGL(k_spcg_reg<32>, dim3(1), dim3(SPCG_REG_NT), lds_w, g_ctx.stream, a, LD);
+            else if (m <= 96) hipLaunchKernelGGL(k_spcg_reg<48>, dim3(1), dim3(SPCG_REG_NT), lds_w, g_ctx.stream, a, LD);
+            else hipLaunchKernelGGL(k_spcg_reg<64>, dim3(1), dim3(SPCG_REG_NT), lds_w, g_ctx.stream, a, LD);
+        }
+        else if (one_wave) {
             static bool attr_w = false;
             if (!attr_w) { (void)hipFuncSetAttribute((const void*)k_spcg_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_w = true; }
             hipLaunchKernelGGL(k_spcg_wave, dim3(1), dim3(64), lds_w, g_ctx.stream, a, LD);

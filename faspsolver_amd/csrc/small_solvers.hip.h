@@ -567,6 +567,175 @@ FINISHED:
 }
 
 // ---------------------------------------------------------------------------
+// k_spcg_reg<MC>: the same safe CG for coarsest levels of at most 128 rows with the MATRIX IN REGISTERS: four
+// wavefronts, thread (row, h) = (tid / 2, tid % 2) keeps the entries of its row in the columns 2 k + h (k < MC, dense,
+// zeros where the level stores nothing) in MC register pairs for the whole solve.  An iteration of k_spcg_wave reads
+// 3 m doubles per lane from LDS (its two dense rows and the broadcast of p) -- 3 us at 89 rows, and config 5 of
+// BASELINE.json runs 124 000 of them per solve; here the product is MC multiply-adds on registers against p read as
+// 16-byte broadcasts (all lanes one address), the two halves of a row meet by one lane swap, and the price is a
+// workgroup barrier where the single wavefront had none: two around the broadcast of p, one per reduction.
+// Row sums: four interleaved partial sums per half over ascending k, then half 0 + half 1 (the reference: storage
+// order) -- O(1e-16) apart, like every reduction here.  Same exit and restart logic as k_spcg_small, line for line.
+// ---------------------------------------------------------------------------
+constexpr int SPCG_REG_NT = 256;
+__device__ __forceinline__ double pair_swap(double x)   // the value of the other lane of the pair (2 i, 2 i + 1)
+{
+    const long long b = __double_as_longlong(x);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xb1, 0xf, 0xf, true);   // quad_perm [1, 0, 3, 2]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xb1, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+template <int MC>
+__global__ __launch_bounds__(SPCG_REG_NT) void k_spcg_reg(SpcgArgs a, int LD)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn[];   // [128 * LD] dense staging of the matrix, then [2 MC + 2] p
+    __shared__ double sh2[2 * 4 * 5];
+    const SmallCSR A = a.A;
+    const int m = A.m, tid = threadIdx.x;
+    const int row = tid >> 1, h = tid & 1;
+    const bool has = row < m, mine = has && h == 0;   // `mine`: the lane that counts the row in reductions
+    int par = 0;
+    // dense staging (rows beyond m and absent entries are zeros; a column stored twice is added up), then into registers
+    for (int i = tid; i < 128 * LD; i += SPCG_REG_NT) dyn[i] = 0.0;
+    __syncthreads();
+    if (mine)
+        for (int k = A.ia[row]; k < A.ia[row + 1]; ++k) dyn[row * LD + A.ja[k]] += A.val[k];
+    __syncthreads();
+    double Ar[MC];
+#pragma unroll
+    for (int k = 0; k < MC; ++k) Ar[k] = (2 * k + h < LD) ? dyn[row * LD + 2 * k + h] : 0.0;
+    __syncthreads();
+    double* pb = dyn;   // the staging area is free now
+    for (int i = tid; i < 2 * MC + 2; i += SPCG_REG_NT) pb[i] = 0.0;
+    __syncthreads();
+    // The scalar tail of an iteration is three square roots and three divisions that every lane would work through one
+    // after the other (each a sequence of ~30 dependent instructions, ~0.1 us): lanes 0, 1, 2 take one each, side by
+    // side, and the results come back by readlane -- the same operations on the same operands, a third of the time.
+    const int lane = tid & 63;
+    auto bcast = [&](double x, int from) -> double {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, from);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), from);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    auto sqrt3 = [&](double x0, double x1, double x2, double& y0, double& y1, double& y2) {
+        const double y = sqrt(lane == 0 ? x0 : lane == 1 ? x1 : x2);
+        y0 = bcast(y, 0); y1 = bcast(y, 1); y2 = bcast(y, 2);
+    };
+    auto div3 = [&](double n0, double d0, double n1, double d1, double n2, double d2, double& y0, double& y1, double& y2) {
+        const double y = (lane == 0 ? n0 : lane == 1 ? n1 : n2) / (lane == 0 ? d0 : lane == 1 ? d1 : d2);
+        y0 = bcast(y, 0); y1 = bcast(y, 1); y2 = bcast(y, 2);
+    };
+    // (every product is followed by a reduction before the next one: its barrier also says that everybody is done
+    // reading the previous broadcast, so the broadcast needs one barrier, not two)
+    const double* pmine = pb + h;
+    auto mxv = [&](double x) -> double {   // y_row = (A x)_row, x_row given in every lane of the pair
+        if (mine) pb[row] = x;
+        __syncthreads();
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < MC; ++k) s[k & 3] += Ar[k] * pmine[2 * k];   // (even lanes one address, odd lanes the next: a two-address broadcast)
+        const double sh_ = (s[0] + s[1]) + (s[2] + s[3]);
+        const double so = pair_swap(sh_);
+        return h ? so + sh_ : sh_ + so;    // half 0 + half 1 in both lanes
+    };
+    auto allsum1 = [&](double x) -> double { double v[1] = {mine ? x : 0.0}; blk_reduce1<1, 4>(v, sh2, par); return v[0]; };
+    const double tol = a.tol, maxdiff = tol * 1e-4 /* STAG_RATIO */, sol_inf_tol = 1e-20;
+    const double BIG = 1e+20, SMALL = 1e-20, SMALL2 = 1e-40;
+    const int MaxIt = a.MaxIt, MAX_STAG = 20, MAX_RESTART = 20;
+    int iter = 0, stag = 1, more_step = 1, iter_best = 0;
+    double absres0 = BIG, absres = BIG, relres = BIG, normu, normr0 = BIG;
+    double reldiff, alpha = 0.0, beta, temp1, temp2, absres_best = BIG;
+    const double b = has ? a.b[row] : 0.0;
+    double u = 0.0, p = 0.0, r, t = 0.0, ub = 0.0;
+    if (a.x_zero) r = b;
+    else {
+        u = has ? a.u[row] : 0.0;
+        r = b - mxv(u);
+    }
+    temp1 = allsum1(r * r);
+    absres0 = sqrt(temp1);
+    normr0 = fmax(SMALL, absres0);
+    relres = absres0 / normr0;
+    if (relres < tol) goto FINISHED;
+    p = r;
+
+    while (iter++ < MaxIt) {
+        t = mxv(p);
+        temp2 = allsum1(t * p);
+        if (fabs(temp2) > SMALL2) alpha = temp1 / temp2;
+        else goto RESTORE_BESTSOL;
+        u = u + alpha * p;
+        r = r - alpha * t;
+        double q[5] = {mine ? r * r : 0.0, mine ? u * u : 0.0, mine ? p * p : 0.0, mine ? fabs(u) : 0.0, (mine && u != u) ? 1.0 : 0.0};
+        blk_reduce1<5, 4>(q, sh2, par, 1u << 3);
+        double sq_pp, fac;
+        sqrt3(q[0], q[1], q[2], absres, normu, sq_pp);      // absres = sqrt(rr), normu = sqrt(uu), sqrt(pp)
+        fac = fabs(alpha) * sq_pp;
+        div3(absres, normr0, fac, normu, q[0], temp1, relres, reldiff, beta);   // relres, reldiff, and beta = rr / temp1 for the usual path
+        double red0 = q[0];
+        if (q[4] > 0.0) {  // fasp_dvec_isnan(u), :185
+            absres = BIG;
+            goto RESTORE_BESTSOL;
+        }
+        if (absres < absres_best - maxdiff) {
+            absres_best = absres;
+            iter_best = iter;
+            ub = u;
+        }
+        if (q[3] <= sol_inf_tol) {  // Check I
+            iter = -43;             // ERROR_SOLVER_SOLSTAG
+            break;
+        }
+        if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {  // Check II
+            r = b - mxv(u);
+            red0 = allsum1(r * r);
+            absres = sqrt(red0);
+            relres = absres / normr0;
+            if (relres < tol) break;
+            if (stag >= MAX_STAG) { iter = -42; break; }  // ERROR_SOLVER_STAG
+            p = 0.0;
+            ++stag;
+        }
+        if (relres < tol) {  // Check III: true residual
+            r = b - mxv(u);
+            red0 = allsum1(r * r);
+            absres = sqrt(red0);
+            relres = absres / normr0;
+            if (relres < tol) break;
+            if (more_step >= MAX_RESTART) { iter = -44; break; }  // ERROR_SOLVER_TOLSMALL
+            p = 0.0;
+            ++more_step;
+        }
+        absres0 = absres;
+        temp2 = red0;  // (z, r) with z = r
+        if (red0 != q[0]) beta = temp2 / temp1;   // (a check recomputed the residual: not the quotient formed above)
+        temp1 = temp2;
+        p = 1.0 * r + beta * p;  // fasp_blas_darray_axpby
+    }
+
+RESTORE_BESTSOL:
+    if (iter != iter_best) {
+        const double s = b - mxv(ub);
+        absres_best = sqrt(allsum1(s * s));
+        if (absres > absres_best + maxdiff || absres != absres) {
+            u = ub;
+            relres = absres_best / normr0;
+        }
+    }
+FINISHED:
+    if (mine) a.u[row] = u;
+    if (tid == 0) {
+        a.out->iters = iter > 0 ? (iter > MaxIt ? MaxIt : iter) : 0;
+        a.out->status = iter > MaxIt ? -48 : iter;  // ERROR_SOLVER_MAXIT
+        a.out->relres = relres;
+        a.out->absres = absres;
+    }
+    (void)absres0;
+}
+
+// ---------------------------------------------------------------------------
 // Safe CG on a coarsest level too large for k_spcg_small (P7(256): 4 971 rows, 6.4 M nonzeros):
 // the SpMV stays a full-chip kernel, everything between two SpMVs is ONE one-block launch that
 // keeps the iteration state on the device -- (t,p) from the SpMV's per-block partials, alpha,
