@@ -690,7 +690,7 @@ __global__ __launch_bounds__(BLOCK) void k_bsr_wstream(BsrArgs a)
 {
     constexpr int NB2 = NB * NB;
     constexpr int RW = 64 / NB;                 // block rows per wave tile
-    constexpr int CAPB = 2048 / NB2;            // blocks per LDS chunk (<= 16 KiB per wave)
+    constexpr int CAPB = 1536 / NB2;            // blocks per LDS chunk: 12 KiB per wave, three workgroups per CU (2048: two, measured 0.49 of peak against 0.58 on P7(128) x B3; 1024 splits the tiles of 7-block rows in two: 0.40)
     __shared__ double lds_all[4 * CAPB * NB2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* lds = lds_all + wave * CAPB * NB2;
@@ -733,16 +733,31 @@ __global__ __launch_bounds__(BLOCK) void k_bsr_wstream(BsrArgs a)
             }
             wave_lds_sync();
             if (act) {
+                // four (nb <= 3: eight) blocks per round trip: their column indices first, then the entries of x they name, then the
+                // products in storage order (one block at a time -- index, then x, then the next index -- made a row of
+                // seven blocks a chain of fourteen dependent memory latencies)
                 const int pb = max(kb, lo), pe = min(ke, hi);
-                for (int k = pb; k < pe; ++k) {
-                    const int j = a.ja[k];
-                    if (OP == 2 && j == br) continue;
-                    const double* A = lds + (k - lo) * NB2 + r * NB;
-                    const double* xb = a.x + (size_t)j * NB;
-                    double s = A[0] * xb[0];
+                constexpr int U = NB <= 3 ? 8 : 4;
+                for (int k = pb; k < pe; k += U) {
+                    int    j[U];
+                    double xv[U][NB];
 #pragma unroll
-                    for (int c = 1; c < NB; ++c) s = s + A[c] * xb[c];
-                    if (OP == 2) acc -= s; else acc += s;
+                    for (int u = 0; u < U; ++u) j[u] = a.ja[min(k + u, pe - 1)];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const double* xb = a.x + (size_t)j[u] * NB;
+#pragma unroll
+                        for (int c = 0; c < NB; ++c) xv[u][c] = xb[c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (k + u >= pe || (OP == 2 && j[u] == br)) continue;
+                        const double* A = lds + (k + u - lo) * NB2 + r * NB;
+                        double s = A[0] * xv[u][0];
+#pragma unroll
+                        for (int c = 1; c < NB; ++c) s = s + A[c] * xv[u][c];
+                        if (OP == 2) acc -= s; else acc += s;
+                    }
                 }
             }
             wave_lds_sync();
