@@ -121,6 +121,7 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         a.A = SmallCSR{m, A.ia, A.ja, A.val};
         a.b = D.b; a.u = D.x; a.p = h->cp; a.r = h->cr; a.t = h->ct; a.u_best = h->cbest;
         a.tol = tol; a.MaxIt = MaxIt; a.x_zero = D.x_zero ? 1 : 0; a.out = small_out_dev(); a.nnz = A.nnz;
+        a.lazy = h->lazy_active ? h->d_lazy : nullptr;
         // everything in LDS when it fits: vectors 5 m doubles, matrix 12 nnz + 4 (m + 1) bytes
         const size_t lds_v = sizeof(double) * 5 * (size_t)m;
         const size_t lds_m = 12 * (size_t)A.nnz + 4 * ((size_t)m + 1);
@@ -158,6 +159,7 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         else
             hipLaunchKernelGGL((k_spcg_small<false, false>), dim3(1), dim3(SMALL_BLOCK), 0, g_ctx.stream, a);
         D.x_zero = false;
+        if (a.lazy) return FASP_SUCCESS;   // the verdict is read once per application of the preconditioner (precond_amg)
         SmallOut o;
         if (small_out_fetch(o) < 0) return ERROR_MISC;
         h->coarse_iters += o.iters;

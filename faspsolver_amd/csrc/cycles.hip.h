@@ -406,18 +406,46 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
     p.coarse_scaling = u.coarse_scaling; p.tentative_smooth = u.tentative_smooth;
     p.amli_degree = u.amli_degree; p.nl_amli_krylov_type = u.nl_amli_krylov_type;
     DevLevel& D0 = h->L[0];
-    D0.b = r;
-    D0.x_zero = true;
-    D0.presmoothed = h->pre_marked && !h->use_fmg;   // (the CG update wrote x = (w r) / d of this r: csr_ops, pcg.hip.h)
+    const bool pre_marked = h->pre_marked;
     h->pre_marked = false;
     const bool ask_zr = h->want_zr && u.cycle_type != AMLI_CYCLE && u.cycle_type != NL_AMLI_CYCLE;   // (set by the PCG operator bundle for this apply only; V / W cycles end with the level-0 sweep)
-    h->zr_G = 0;
-    for (int i = u.maxit; i--;) {
-        h->want_zr = ask_zr && i == 0 && !h->use_fmg;   // the last sweep of the last cycle leaves the (z, r) partials
-        const int st = h->use_fmg ? fmg_cycle(h, p) : mgcycle(h, p);  // fasp_precond_famg (PreCSR.c:560) / fasp_precond_amg
-        if (st < 0) { h->want_zr = false; return st; }
+    // Lazy coarse verdicts.  A coarsest level small enough for a one-launch solver is visited up to 2^(levels - 1) times per
+    // W-cycle, and reading every solve's verdict (has the safe CG given up? then the reference's SPVGMRES net takes over) was a
+    // host synchronisation each: 1 424 per solve of config 5.  The solvers now leave the minimum status and the iteration sum
+    // in two device words, read ONCE per application; if a solve did give up, the application is replayed from r -- which a
+    // cycle only reads -- with the verdicts read as they come, and the hierarchy stays in that mode.
+    const DevLevel& Dc = h->L.back();
+    // (not for full multigrid: its cycle carries the levels' iterates over from one application to the next, a replay would not start where the first attempt did)
+    const bool lazy = g_tune.lazy_coarse && !h->coarse_sync && !h->use_fmg && h->L.size() > 1 && small_coarse_ok(Dc.A.row, Dc.A.nnz);
+    if (lazy && !h->d_lazy) {
+        HIPCK(hipMalloc((void**)&h->d_lazy, 2 * sizeof(int)));
+        HIPCK(hipHostMalloc((void**)&h->h_lazy, 4 * sizeof(int), hipHostMallocDefault));
     }
-    h->want_zr = false;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool la = lazy && attempt == 0;
+        D0.b = r;
+        D0.x_zero = true;
+        D0.presmoothed = attempt == 0 && pre_marked && !h->use_fmg;   // (the CG update wrote x = (w r) / d of this r: csr_ops, pcg.hip.h; a replay redoes that sweep itself)
+        h->zr_G = 0;
+        if (la) {
+            h->h_lazy[2] = 0x7fffffff; h->h_lazy[3] = 0;
+            HIPCK(hipMemcpyAsync(h->d_lazy, h->h_lazy + 2, 2 * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+        }
+        h->lazy_active = la;
+        int st = FASP_SUCCESS;
+        for (int i = u.maxit; i-- && st >= 0;) {
+            h->want_zr = ask_zr && i == 0 && !h->use_fmg;   // the last sweep of the last cycle leaves the (z, r) partials
+            st = h->use_fmg ? fmg_cycle(h, p) : mgcycle(h, p);  // fasp_precond_famg (PreCSR.c:560) / fasp_precond_amg
+        }
+        h->lazy_active = false;
+        h->want_zr = false;
+        if (st < 0) return st;
+        if (!la) break;
+        HIPCK(hipMemcpyAsync(h->h_lazy, h->d_lazy, 2 * sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
+        HIPCK(hipStreamSynchronize(g_ctx.stream));
+        if (h->h_lazy[0] >= 0 && g_tune.lazy_coarse != 2) { h->coarse_iters += h->h_lazy[1]; break; }
+        h->coarse_sync = true;   // (fasp_hip_tune("lazy_coarse", 2): every first application is replayed -- tests)
+    }
     materialise_zero(D0);
     *z = D0.x;
     return FASP_SUCCESS;

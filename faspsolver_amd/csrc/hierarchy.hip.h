@@ -90,6 +90,9 @@ struct fasp_hip_amg {
     std::vector<EventPair> ev;
     int                    ev_used = 0;
     long long              coarse_iters = 0, vcycles = 0;
+    // lazy coarse verdicts (precond_amg): device words {min status, iteration sum}, their pinned host copy; coarse_sync: a coarse
+    // solve gave up once on this hierarchy -- verdicts are read per solve from then on
+    int*                   d_lazy = nullptr; int* h_lazy = nullptr; bool lazy_active = false, coarse_sync = false;
     double                 upload_seconds = 0.0;
 };
 

@@ -259,7 +259,18 @@ struct SpcgArgs {
     int      x_zero;  // the iterate is zero on entry (skips the first matrix pass)
     int      nnz;
     SmallOut* out;
+    int*     lazy;    // != nullptr: the verdict is not read per solve -- [0] takes the minimum status, [1] the sum of the iteration counts (precond_amg)
 };
+__device__ __forceinline__ void spcg_report(const SpcgArgs& a, int iter, int MaxIt, double relres, double absres)
+{
+    const int iters = iter > 0 ? (iter > MaxIt ? MaxIt : iter) : 0;
+    const int status = iter > MaxIt ? -48 : iter;  // ERROR_SOLVER_MAXIT
+    if (a.lazy) { atomicMin(a.lazy, status); atomicAdd(a.lazy + 1, iters); return; }
+    a.out->iters = iters;
+    a.out->status = status;
+    a.out->relres = relres;
+    a.out->absres = absres;
+}
 
 // LV: the five work vectors live in dynamic LDS (5 m doubles); LM: so does the matrix (copied once):
 // every iteration then runs out of LDS, global memory is touched at entry (b, u) and exit (u) only.
@@ -394,10 +405,7 @@ FINISHED:
         for (int i = tid; i < m; i += NT) a.u[i] = u[i];
     }
     if (tid == 0) {
-        a.out->iters = iter > 0 ? (iter > MaxIt ? MaxIt : iter) : 0;
-        a.out->status = iter > MaxIt ? -48 : iter;  // ERROR_SOLVER_MAXIT
-        a.out->relres = relres;
-        a.out->absres = absres;
+        spcg_report(a, iter, MaxIt, relres, absres);
     }
     (void)absres0;
 }
@@ -558,10 +566,7 @@ FINISHED:
     if (h0) a.u[r0] = u0;
     if (h1) a.u[r1] = u1;
     if (lane == 0) {
-        a.out->iters = iter > 0 ? (iter > MaxIt ? MaxIt : iter) : 0;
-        a.out->status = iter > MaxIt ? -48 : iter;  // ERROR_SOLVER_MAXIT
-        a.out->relres = relres;
-        a.out->absres = absres;
+        spcg_report(a, iter, MaxIt, relres, absres);
     }
     (void)absres0;
 }
@@ -668,8 +673,22 @@ __global__ __launch_bounds__(SPCG_REG_NT) void k_spcg_reg(SpcgArgs a, int LD)
         else goto RESTORE_BESTSOL;
         u = u + alpha * p;
         r = r - alpha * t;
-        double q[5] = {mine ? r * r : 0.0, mine ? u * u : 0.0, mine ? p * p : 0.0, mine ? fabs(u) : 0.0, (mine && u != u) ? 1.0 : 0.0};
-        blk_reduce1<5, 4>(q, sh2, par, 1u << 3);
+        // (u has a NaN exactly when (u, u) is one: squares are >= 0, so no sum of them cancels to NaN -- the fifth quantity of
+        // fasp_dvec_isnan's count is read off the second)
+        double q[5] = {mine ? r * r : 0.0, mine ? u * u : 0.0, mine ? p * p : 0.0, 1.0, 0.0};
+        {
+            double q3[3] = {q[0], q[1], q[2]};
+            blk_reduce1<3, 4>(q3, sh2, par);
+            q[0] = q3[0]; q[1] = q3[1]; q[2] = q3[2];
+            q[4] = (q3[1] != q3[1]) ? 1.0 : 0.0;
+            // Check I asks whether max |u_i| <= 1e-20.  (u, u) > 2 m 1e-40 settles it (some u_i^2 exceeds 1e-40 then, whatever the
+            // rounding of the sum); only below that -- an iterate that is zero to forty digits -- is the maximum itself formed.
+            if (!(q3[1] > 2.0 * m * 1e-40)) {
+                double qm[1] = {mine ? fabs(u) : 0.0};
+                blk_reduce1<1, 4>(qm, sh2, par, 1u);
+                q[3] = qm[0];
+            }
+        }
         double sq_pp, fac;
         sqrt3(q[0], q[1], q[2], absres, normu, sq_pp);      // absres = sqrt(rr), normu = sqrt(uu), sqrt(pp)
         fac = fabs(alpha) * sq_pp;
@@ -727,10 +746,7 @@ RESTORE_BESTSOL:
 FINISHED:
     if (mine) a.u[row] = u;
     if (tid == 0) {
-        a.out->iters = iter > 0 ? (iter > MaxIt ? MaxIt : iter) : 0;
-        a.out->status = iter > MaxIt ? -48 : iter;  // ERROR_SOLVER_MAXIT
-        a.out->relres = relres;
-        a.out->absres = absres;
+        spcg_report(a, iter, MaxIt, relres, absres);
     }
     (void)absres0;
 }

@@ -430,6 +430,8 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
     double* v[] = {h->b, h->u, h->p, h->t, h->r, h->cp, h->cr, h->ct, h->cbest};
     for (double* q : v)
         if (q) (void)hipFree(q);
+    if (h->d_lazy) (void)hipFree(h->d_lazy);
+    if (h->h_lazy) (void)hipHostFree(h->h_lazy);
     for (auto& e : h->ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int s = 0; s < 2; ++s)
         for (double* q : h->gm[s])
@@ -2019,6 +2021,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "fuse_presmooth")) g_tune.fuse_presmooth = value;
     else if (!std::strcmp(key, "seq_lanes")) g_tune.seq_lanes = value;
     else if (!std::strcmp(key, "seq_ulds")) g_tune.seq_ulds = value;
+    else if (!std::strcmp(key, "lazy_coarse")) g_tune.lazy_coarse = value;
     else if (!std::strcmp(key, "xtile")) g_tune.xtile = value;
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
     else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;

@@ -321,6 +321,36 @@ def test_coarse_fallback_spvgmres(gpu):
     assert np.max(np.abs(x - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
 
 
+def _c5_small(itp, amgp):   # config 5's parameters: SA-AMG, W-cycle, VFGMRES(30)
+    itp.tol = 1e-8; itp.itsolver_type = 6; itp.restart = 30
+    amgp.AMG_type = T.SA_AMG; amgp.cycle_type = T.W_CYCLE; amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mod", [_jac, _c5_small, _amli1, _namli_gcg, _fmg], ids=["V", "SA-W-VFGMRES", "AMLI1", "Kcycle-GCG", "FMG-not-lazy"])
+def test_lazy_coarse_verdicts_change_nothing(gpu, mod):
+    """The one-launch coarse solvers leave their verdict on the device and precond_amg reads it once per application
+    (fasp_hip_tune("lazy_coarse", 1), the default) instead of once per coarse solve (0).  2 = every first application is
+    replayed as if a coarse solve had given up: the replay path (the one a real failure takes, see
+    test_coarse_fallback_spvgmres) must reproduce the cycle bit for bit from the untouched r."""
+    ia, ja, a, f, ue = poisson7pt(14)
+    L = gpu.lib()
+    out = []
+    try:
+        for lazy in (0, 1, 2):
+            L.fasp_hip_tune(b"lazy_coarse", lazy)
+            itp, amgp = default_params(); mod(itp, amgp)
+            H = gpu.AMG(ia, ja, a, amgp)
+            s, x, h, stats = H.solve(f, itp)
+            out.append((s, x.copy(), np.array(h), stats.coarse_iters))
+            H.close()
+    finally:
+        L.fasp_hip_tune(b"lazy_coarse", 1)
+    for s, x, h, ci in out[1:]:
+        assert s == out[0][0] and ci == out[0][3]
+        assert np.array_equal(x, out[0][1]) and np.array_equal(h, out[0][2])
+
+
 def test_pcg_history_fe(gpu):
     ia, ja, a = read_csr(DATA + "/csrmat_FE.dat"); f = read_vec(DATA + "/rhs_FE.dat")
     _cmp_solve(gpu, ia, ja, a, f, _jac)
