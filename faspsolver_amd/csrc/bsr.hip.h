@@ -263,7 +263,10 @@ ForwardSweep:
             a.A = SmallBSR{Ac.ROW, Ac.nb, Ac.ia, Ac.ja, Ac.val};
             a.b = Lc.b; a.x = Lc.x; a.ws = h->small_ws; a.tol = ctol; a.abstol = atol;
             a.MaxIt = cmaxit; a.restart = 25; a.out = small_out_dev();
-            const size_t lds = sizeof(double) * (size_t)(25 + 2) * (size_t)csize;
+            size_t lds = sizeof(double) * (size_t)(25 + 2) * (size_t)csize;
+            // rows beyond the first 512 of an nb = 3 system keep their blocks in LDS behind the basis (k_gmres_small)
+            const size_t lds2 = (size_t)std::max(csize - SMALL_BLOCK, 0) * GM_CB * 28;
+            if (Ac.nb == 3 && csize <= 2 * SMALL_BLOCK && lds + lds2 <= 140 * 1024) { a.cache2 = 1; lds += lds2; }
             static bool attr = false;
             if (!attr) {
                 (void)hipFuncSetAttribute((const void*)k_gmres_small<SmallBSR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

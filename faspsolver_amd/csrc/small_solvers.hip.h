@@ -26,6 +26,7 @@ namespace fasp {
 constexpr int SMALL_BLOCK = 512;
 constexpr int SMALL_WAVES = SMALL_BLOCK / 64;
 constexpr int SMALL_MAX_RESTART = 32;
+constexpr int GM_NE = 16;   // k_gmres_small: systems of at most 64 * GM_NE rows orthogonalise in one wavefront
 
 // result record written by thread 0
 struct SmallOut {
@@ -1124,12 +1125,59 @@ struct GmresArgs {
     double        tol, abstol;
     int           MaxIt, restart;
     SmallOut*     out;
+    int           cache2;   // LV only: rows beyond the first 512 have GM_CB * 28 bytes each of LDS behind the basis (k_gmres_small: the matrix held on chip)
 };
+constexpr int GM_CB = 16;   // blocks of a row k_gmres_small holds on chip (nb = 3)
 
 // LV: the Krylov basis p[0..restart] and w live in dynamic LDS ((restart + 2) n doubles) instead of a.ws
+// Modified Gram-Schmidt of the new Krylov vector `pi` against basis vectors 0 .. i-1 (n doubles apart) in ONE wavefront:
+// NE elements per lane in registers, a dot product = NE multiply-adds per lane (four interleaved partial sums) + the
+// wavefront's DPP sum, no LDS partials, no barrier.  The coefficients go to hcol[j * ldh]; returns the norm of what is
+// left and leaves pi normalised (KryPvgmres.c:207-233).
+template <int NE>
+__device__ __forceinline__ double gm_mgs_wave(int n, int i, int lane, const double* basis, double* pi, double* hcol, int ldh)
+{
+    double wv[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) wv[k] = (lane + 64 * k < n) ? pi[lane + 64 * k] : 0.0;
+    for (int j = 0; j < i; ++j) {
+        const double* pj = basis + (size_t)j * n;
+        double pv[NE], hs[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NE; ++k) pv[k] = (lane + 64 * k < n) ? pj[lane + 64 * k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) hs[k & 3] += pv[k] * wv[k];
+        const double h = wave_allsum((hs[0] + hs[1]) + (hs[2] + hs[3]));
+        if (lane == 0) hcol[j * ldh] = h;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) wv[k] += -h * pv[k];
+    }
+    double ts[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NE; ++k) ts[k & 3] += wv[k] * wv[k];
+    const double t = sqrt(wave_allsum((ts[0] + ts[1]) + (ts[2] + ts[3])));
+    if (t != 0.0) {
+        const double s = 1.0 / t;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) wv[k] *= s;
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k)
+        if (lane + 64 * k < n) pi[lane + 64 * k] = wv[k];
+    return t;
+}
+
+#ifdef GM_TIMING
+#define GMT(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); gmt[k] += now_ - gmt_last; gmt_last = now_; } while (0)
+#else
+#define GMT(k)
+#endif
 template <class OP, bool LV>
 __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
 {
+#ifdef GM_TIMING
+    unsigned long long gmt[5] = {0, 0, 0, 0, 0}, gmt_last = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int R = SMALL_MAX_RESTART;
     extern __shared__ double dyn[];
     __shared__ double sh[SMALL_WAVES];
@@ -1150,7 +1198,107 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
     auto P = [&](int k) { return basis + (size_t)k * n; };
     double* w = basis + (size_t)(a.restart + 1) * n;
 
-    small_resid(A, x, b, P(0));
+    // nb = 3 systems of at most 1 024 rows keep the MATRIX on chip for the whole solve: a thread holds the first GM_CB
+    // blocks of its row t (its three values per block + the column) in registers, the rows t + 512 sit in LDS behind
+    // the basis.  A product then reads x (the basis vector, in LDS) and nothing else -- from memory it was two passes of
+    // four dependent round trips through the L2, 12 us of an iteration's 12.5 on config 3's coarsest level (555 rows,
+    // 5 297 iterations per solve).  Same blocks in the same order: identical bits.
+    const bool oc = LV && A.nb == 3 && n <= 2 * SMALL_BLOCK && (n <= SMALL_BLOCK || a.cache2);
+    double ca[GM_CB][3];
+    int    cj[GM_CB], cnt0 = 0, kb0 = 0, r0 = 0, cnt1 = 0, kb1 = 0, r1 = 0;
+    const int n1 = max(n - SMALL_BLOCK, 0);
+    double* c1a = dyn + (size_t)(a.restart + 2) * n;                     // [n1][GM_CB][3]
+    int*    c1j = reinterpret_cast<int*>(c1a + (size_t)n1 * GM_CB * 3);  // [n1][GM_CB]
+    if (oc) {
+        if (tid < n) {
+            const int br = tid / 3;
+            r0 = tid - br * 3; kb0 = A.ia[br]; cnt0 = A.ia[br + 1] - kb0;
+#pragma unroll
+            for (int q = 0; q < GM_CB; ++q) {
+                const int k = kb0 + min(q, max(cnt0 - 1, 0));
+                cj[q] = A.ja[k];
+                const double* B = A.val + (size_t)k * 9 + r0 * 3;
+                ca[q][0] = B[0]; ca[q][1] = B[1]; ca[q][2] = B[2];
+            }
+        }
+        if (tid < n1) {
+            const int row = tid + SMALL_BLOCK, br = row / 3;
+            r1 = row - br * 3; kb1 = A.ia[br]; cnt1 = A.ia[br + 1] - kb1;
+            for (int q = 0; q < min(cnt1, GM_CB); ++q) {
+                c1j[tid * GM_CB + q] = A.ja[kb1 + q];
+                const double* B = A.val + (size_t)(kb1 + q) * 9 + r1 * 3;
+                double* C = c1a + ((size_t)tid * GM_CB + q) * 3;
+                C[0] = B[0]; C[1] = B[1]; C[2] = B[2];
+            }
+        }
+    }
+    // y-callback f(row, acc): acc = (seed ? -seed_row : 0) + sum of the row's block products in storage order
+    auto rows_onchip = [&](const double* xin, const double* seed, auto&& f) {
+        if (tid < n) {
+            double acc = seed ? -seed[tid] : 0.0;
+#pragma unroll
+            for (int q = 0; q < GM_CB; ++q) {
+                if (q < cnt0) {
+                    const double* xb = xin + (size_t)cj[q] * 3;
+                    double sq = ca[q][0] * xb[0];
+                    sq = sq + ca[q][1] * xb[1];
+                    sq = sq + ca[q][2] * xb[2];
+                    acc += sq;
+                }
+            }
+            for (int k = kb0 + GM_CB; k < kb0 + cnt0; ++k) {   // (a row of more than GM_CB blocks: the rest from memory)
+                const double* B = A.val + (size_t)k * 9 + r0 * 3;
+                const double* xb = xin + (size_t)A.ja[k] * 3;
+                double sq = B[0] * xb[0];
+                sq = sq + B[1] * xb[1];
+                sq = sq + B[2] * xb[2];
+                acc += sq;
+            }
+            f(tid, acc);
+        }
+        if (tid < n1) {
+            const int row = tid + SMALL_BLOCK;
+            double acc = seed ? -seed[row] : 0.0;
+            const int nq = min(cnt1, GM_CB);
+            for (int q0 = 0; q0 < nq; q0 += 4) {   // four blocks' operands in flight, added in storage order
+                double sq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = min(q0 + e, nq - 1);
+                    const double* C = c1a + ((size_t)tid * GM_CB + q) * 3;
+                    const double* xb = xin + (size_t)c1j[tid * GM_CB + q] * 3;
+                    double v = C[0] * xb[0];
+                    v = v + C[1] * xb[1];
+                    v = v + C[2] * xb[2];
+                    sq[e] = v;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (q0 + e < nq) acc += sq[e];
+            }
+            for (int k = kb1 + GM_CB; k < kb1 + cnt1; ++k) {
+                const double* B = A.val + (size_t)k * 9 + r1 * 3;
+                const double* xb = xin + (size_t)A.ja[k] * 3;
+                double sq = B[0] * xb[0];
+                sq = sq + B[1] * xb[1];
+                sq = sq + B[2] * xb[2];
+                acc += sq;
+            }
+            f(row, acc);
+        }
+        __syncthreads();
+    };
+    auto g_mxv = [&](const double* xin, double* y) {
+        if (oc) rows_onchip(xin, nullptr, [&](int row, double acc) { y[row] = acc; });
+        else small_mxv(A, xin, y);
+    };
+    auto g_resid = [&](const double* xin, const double* bb, double* rr) {   // -((-b_i) + t) (BlaSpmvBSR: the reference's rounding)
+        if (oc) rows_onchip(xin, bb, [&](int row, double acc) { rr[row] = -acc; });
+        else small_resid(A, xin, bb, rr);
+    };
+    if (oc) __syncthreads();
+
+    g_resid(x, b, P(0));
     r_norm = sqrt(blk_dot(n, P(0), P(0), sh));
     absres0 = fmax(1e-20, r_norm);
     relres = r_norm / absres0;
@@ -1173,7 +1321,23 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
         while (i < Restart && iter < MaxIt) {
             i++; iter++;
             double* pi = P(i);
-            small_mxv(A, P(i - 1), pi);
+            GMT(0);
+            g_mxv(P(i - 1), pi);
+            GMT(1);
+            if (n <= 64 * GM_NE) {
+                // Modified Gram-Schmidt in ONE wavefront: the new vector in its registers (GM_NE elements per lane), a dot product
+                // = GM_NE multiply-adds per lane + a DPP sum, no LDS partials, no barrier -- the chain of i dependent
+                // (dot, update) pairs was half of an iteration when eight wavefronts met at a barrier for every one of them
+                // (config 3: 555 rows, 5 297 coarse iterations per solve).  Sums: per lane over ascending elements, then the
+                // wavefront's fixed DPP order.
+                if (tid < 64) {
+                    const int ne = (n + 63) >> 6;   // elements per lane
+                    if (ne <= 4) t = gm_mgs_wave<4>(n, i, tid, basis, pi, hh + (i - 1), R);
+                    else if (ne <= 8) t = gm_mgs_wave<8>(n, i, tid, basis, pi, hh + (i - 1), R);
+                    else if (ne <= 12) t = gm_mgs_wave<12>(n, i, tid, basis, pi, hh + (i - 1), R);
+                    else t = gm_mgs_wave<GM_NE>(n, i, tid, basis, pi, hh + (i - 1), R);
+                }
+            } else {
             // modified Gram-Schmidt: a thread updates only its own elements between the dots
             for (int j = 0; j < i; ++j) {
                 const double* pj = P(j);
@@ -1194,6 +1358,8 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
                 const double s = 1.0 / t;
                 for (int e = tid; e < n; e += SMALL_BLOCK) pi[e] *= s;
             }
+            }
+            GMT(2);
             if (tid == 0) {  // Givens rotations on the new Hessenberg column
                 hh[i * R + (i - 1)] = t;
                 for (int j = 1; j < i; ++j) {
@@ -1212,7 +1378,9 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
                 hh[(i - 1) * R + (i - 1)] = sn[i - 1] * hh[i * R + (i - 1)] + c[i - 1] * hh[(i - 1) * R + (i - 1)];
                 sc_rnorm = fabs(rs[i]);
             }
+            GMT(3);
             __syncthreads();
+            GMT(4);
             absres = r_norm = sc_rnorm;
             relres = absres / absres0;
             if (relres < tol) break;
@@ -1238,7 +1406,7 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
         __syncthreads();
 
         if (relres < tol) {  // check the true residual
-            small_resid(A, x, b, w);
+            g_resid(x, b, w);
             r_norm = sqrt(blk_dot(n, w, w, sh));
             absres = r_norm;
             relres = absres / absres0;
@@ -1272,6 +1440,9 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
     }
 
 FINISHED:
+#ifdef GM_TIMING
+    if (tid == 0 && iter > 20) printf("[gmres_small] iters %d: other %.2f spmv %.2f mgs %.2f givens %.2f barrier %.2f us per iteration\n", iter, gmt[0] * 0.01 / iter, gmt[1] * 0.01 / iter, gmt[2] * 0.01 / iter, gmt[3] * 0.01 / iter, gmt[4] * 0.01 / iter);
+#endif
     if (tid == 0) {
         a.out->iters = iter;
         a.out->status = iter >= MaxIt ? -48 : iter;
