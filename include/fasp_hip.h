@@ -702,11 +702,17 @@ int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
 /* Run-time switches (A/B tests, profiling, and ONE behavioural mode):
  *   kernel selection / launch geometry: maxgrid, xcd, nt, kind, lanes, wrows, wcap (-1 = automatic), gen2 (0 round-1
  *     kernels, 1, 2 = default), compress (lossless matrix coding on/off), ja16, ws2_bpc, rpl, lds_tab, xcd_pat;
- *   coarse solve: spcg_persist, spcg_fused, spcg_batch, spcg_grid, small_lds;
+ *   coarse solve: spcg_persist, spcg_fused, spcg_batch, spcg_grid, small_lds, small_onewave (coarsest levels of <= 128
+ *     rows: 2 = matrix in registers, four wavefronts (default), 1 = dense in LDS, one wavefront, 0 = the general kernel),
+ *     lazy_coarse (the one-launch solvers' verdicts read once per application of the preconditioner, default 1;
+ *     2 = replay every first application as if a coarse solve had given up: tests), coarse_mode / coarse_split_min
+ *     (multi-GPU: replicated levels computed in row windows + all-gather);
  *   upload: device_sort (per-row sorts of the long-row levels on the device, default 1);
  *   fusions: fuse_zr ((z, r) of PCG from the last level-0 Jacobi sweep), fuse_presmooth (first Jacobi sweep written with
  *     its right-hand side) -- both default 1, results identical (fuse_presmooth: bit for bit; fuse_zr: to rounding);
- *   sequential sweeps: seq_block (one-workgroup sweeps on the deep levels, default 1, same bits), seq_persist (0);
+ *   sequential sweeps (a parallel pass + a sparse triangular solve, csrc/seq_split.hip.h): seq_block (the triangular
+ *     solve in one workgroup where the dependency classes are narrow, default 1), seq_ulds (its new values in an LDS
+ *     ring, default 1), seq_lanes (lanes per row, 0 = from the row lengths) -- same slots, same arithmetic, same bits;
  *     gs_multicolor = 1 selects the MULTICOLOUR Gauss-Seidel / SOR sweep -- NOT the reference's iteration (rows are
  *     relaxed colour by colour instead of in index order; faster, converges alike, other iteration counts). Default 0:
  *     the reference's sequential sweep, reproduced exactly;
