@@ -20,9 +20,9 @@
 //
 // Storage of the lower part ("slots"): the rows of a dependency class are numbered consecutively (class-major) and cut
 // into CHUNKS of at most 512 / L rows (L lanes per row: one chunk is one round of a 512-thread workgroup).  A chunk
-// [lo, hi) stores pf * L slots per row (pf <= 4: what the longest row of the chunk needs), slot-major:   slot (q, lane sl)
-// of row p sits at
-//     sbase + q * L * (hi - lo) + (p - lo) * L + sl
+// [lo, hi) stores pf * L slots per row (pf <= 8 rounds: what the longest row of the chunk needs; entry e of a row is round
+// e / L of lane e % L), in packs of four rounds, a lane's four slots of a pack side by side:   slot (q, lane sl) of row p at
+//     sbase + ((q / 4) * L * (hi - lo) + (p - lo) * L + sl) * 4 + q % 4
 // so that the address of everything a chunk needs follows from its descriptor (lo | pf << 28, sbase) alone: ONE memory
 // round trip per chunk (no row pointer -> entries chain), perfectly coalesced, issued several chunks ahead of the one
 // being computed.  Unused slots hold (column p, value 0).  Rows with more than 4 L lower entries keep the excess in a
@@ -152,15 +152,19 @@ constexpr int TRI_OOR = (int)0x80000000u;   // (the resources declare 2^31 - 1 b
 template <int L, int PF>
 __device__ __forceinline__ void tri_fetch(const TriBufs& B, TriPre<PF>& r, int lo, int hi, int pf, int sb, int rloc, int sl)
 {
+    static_assert(PF % 4 == 0, "slots come in packs of four");
     const bool on = rloc < hi - lo;
     const int p = lo + rloc;
-    const int e = sb + rloc * L + sl;     // (slot index of round 0; host: nslot < 2^28)
-    const int qs = L * (hi - lo);         // wave-uniform
+    const int e = sb + (rloc * L + sl) * 4;   // first slot of this lane's pack 0 (host: nslot < 2^28)
+    const int gs = 4 * L * (hi - lo);         // slots per pack of the chunk: wave-uniform
 #pragma unroll
-    for (int q = 0; q < PF; ++q) {
-        const bool use = on && q < pf;
-        r.c[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(B.sc, use ? e * 4 : TRI_OOR, q * qs * 4, 0);
-        r.v[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(B.sv, use ? e * 8 : TRI_OOR, q * qs * 8, 0));
+    for (int g = 0; g < PF / 4; ++g) {        // four slots of a lane are contiguous: one 16-byte load of columns, two of values
+        const bool use = on && 4 * g < pf;
+        const u32x4_t cq = __builtin_amdgcn_raw_buffer_load_b128(B.sc, use ? e * 4 : TRI_OOR, g * gs * 4, 0);
+        const f64x2_t v0 = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(B.sv, use ? e * 8 : TRI_OOR, g * gs * 8, 0));
+        const f64x2_t v1 = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(B.sv, use ? e * 8 + 16 : TRI_OOR, g * gs * 8, 0));
+        r.c[4 * g] = (int)cq[0]; r.c[4 * g + 1] = (int)cq[1]; r.c[4 * g + 2] = (int)cq[2]; r.c[4 * g + 3] = (int)cq[3];
+        r.v[4 * g] = v0[0]; r.v[4 * g + 1] = v0[1]; r.v[4 * g + 2] = v1[0]; r.v[4 * g + 3] = v1[1];
     }
     const f64x2_t r0 = buf_load_f64x2(B.rec, on ? (unsigned)p * 16u : (unsigned)TRI_OOR), r1 = buf_load_f64x2(B.dr, on ? (unsigned)p * 16u : (unsigned)TRI_OOR);
     const u32x2_t r2 = __builtin_amdgcn_raw_buffer_load_b64(B.tr, on ? p * 8 : TRI_OOR, 0, 0);

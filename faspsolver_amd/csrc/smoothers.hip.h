@@ -172,10 +172,10 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
         pf_of[c] = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));   // (at least one round: tri_fetch is branch-free)
         pfmax = std::max(pfmax, pf_of[c]);
         sbase[c] = (int)nslot;
-        nslot += (long long)pf_of[c] * L * (lo_of[c + 1] - lo_of[c]);
+        nslot += (long long)((pf_of[c] + 3) & ~3) * L * (lo_of[c + 1] - lo_of[c]);   // (packs of four rounds)
         if (nslot > 0x0fffffffll) return ERROR_INPUT_PAR;   // (byte offsets of the slot values stay below 2^31)
         S.ptr[c] = lo_of[c] | (pf_of[c] << 28);
-        const double bytes = (double)(lo_of[c + 1] - lo_of[c]) * L * (12.0 * pf_of[c] + 32.0);
+        const double bytes = (double)(lo_of[c + 1] - lo_of[c]) * L * (12.0 * ((pf_of[c] + 3) & ~3) + 32.0);
         bytes_us += std::max(0.7, bytes / 25e3);   // (measured: one compute unit sustains ~25 GB/s of such fetches)
     }
     sbase[nchunk] = (int)nslot; S.ptr[nchunk] = ns;
@@ -184,9 +184,9 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     std::vector<int>    tr(2 * (size_t)ns, 0);
     for (int c = 0; c < nchunk; ++c) {
         const int lo = lo_of[c], hi = lo_of[c + 1];
-        for (int q = 0; q < pf_of[c]; ++q)
+        for (int q = 0; q < ((pf_of[c] + 3) & ~3); ++q)
             for (int p = lo; p < hi; ++p)
-                for (int sl = 0; sl < L; ++sl) sc[(size_t)sbase[c] + (size_t)q * L * (hi - lo) + (size_t)(p - lo) * L + sl] = p;
+                for (int sl = 0; sl < L; ++sl) sc[(size_t)sbase[c] + ((size_t)(q / 4) * L * (hi - lo) + (size_t)(p - lo) * L + sl) * 4 + (q % 4)] = p;
     }
     long long ntail = 0, nrest = 0;
     for (int q = 0; q < ns; ++q) {
@@ -222,7 +222,8 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
                 if (is_far(p, cpos)) { tja[kt] = cpos | TRI_FAR_BIT; tval[kt] = A.val[k]; ++kt; continue; }
                 reach = std::max(reach, hi - cpos);
                 if (e < TRI_PFMAX * L) {
-                    const size_t at = (size_t)sbase[ck] + (size_t)(e / L) * L * (hi - lo) + (size_t)(p - lo) * L + (e % L);
+                    const int    qe = e / L;   // round of this entry
+                    const size_t at = (size_t)sbase[ck] + ((size_t)(qe / 4) * L * (hi - lo) + (size_t)(p - lo) * L + (e % L)) * 4 + (qe % 4);
                     sc[at] = cpos; sv[at] = A.val[k];
                 } else { tja[kt] = cpos; tval[kt] = A.val[k]; ++kt; }
                 ++e;
