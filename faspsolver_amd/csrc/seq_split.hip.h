@@ -94,9 +94,10 @@ template <int L>
 __global__ __launch_bounds__(BLOCK) void k_split_rest(int nseq, const int* __restrict__ order, const int* __restrict__ ria,
                                                        const int* __restrict__ rja, const double* __restrict__ rval,
                                                        const double* __restrict__ b, const double* __restrict__ u,
-                                                       double* __restrict__ rec)
+                                                       double* __restrict__ rec, unsigned* __restrict__ prog)
 {
     constexpr int RPB = BLOCK / L;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *prog = 0u;   // progress word of the triangular solve that follows (tri_prefetch)
     const int sl = threadIdx.x & (L - 1);
     const int rloc = threadIdx.x / L;
     for (int p0 = blockIdx.x * RPB; p0 < nseq; p0 += gridDim.x * RPB) {   // (whole wavefronts walk the loop: the DPP moves read neighbours)
@@ -230,9 +231,46 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_level(TriArgs a, int chunk0)
 // chunk [lo, hi)), so W never travels through memory: results go to the ring and straight to u_i.
 // !WIN (a schedule that reaches further back): W goes through the L2 with agent-scope atomics (a wave must see what a
 // wave of another SIMD stored in the chunk before), a chunk costs two L2 round trips; ends with the scatter u_i <- W_p.
-template <int L, int PF, bool WIN, bool TAIL>
-__global__ __launch_bounds__(TRI_BLOCK) void k_tri_block(TriArgs a, int nseq, int cap)
+// Helper workgroups of k_tri_block (blocks 8, 16, ... of its grid: under the round-robin placement of workgroups they share
+// the solving workgroup's XCD, hence its L2): they READ what the solver is going to need -- slots and row records of the
+// chunks h, h + nhelp, ... -- a bounded distance ahead of its published progress and throw it away.  One compute unit
+// sustains ~25 GB/s of fetches from HBM (a few hundred cache lines in flight against ~2 us); from the L2 the same lines
+// in flight come back three to four times faster.  Purely a hint: if the placement is another one, or the progress word
+// is never seen, the solver reads from memory as before and the result is the same.
+__device__ __forceinline__ void tri_prefetch(const TriArgs& a, int h, int nhelp, int ahead, const unsigned* prog)
 {
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    unsigned long long sink = 0;
+    for (int c = h; c < a.nchunk; c += nhelp) {
+        if (threadIdx.x == 0) {
+            for (int spin = 0; spin < 4096; ++spin) {   // bounded: a helper that cannot see the progress just runs on
+                if ((int)__hip_atomic_load((gu32*)prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ahead >= c) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        const int lo = a.lptr[c] & TRI_POS_MASK, hi = a.lptr[c + 1] & TRI_POS_MASK;
+        const size_t s0 = (size_t)a.sbase[c], s1 = (size_t)a.sbase[c + 1];
+        const u32x4_t* v16 = reinterpret_cast<const u32x4_t*>(a.sv + s0);
+        const size_t   nv = (s1 - s0) / 2;   // 16-byte units of the values (slot counts are multiples of four)
+        for (size_t i = threadIdx.x; i < nv; i += TRI_BLOCK) { const u32x4_t q = v16[i]; sink += q[0] ^ q[3]; }
+        const u32x4_t* c16 = reinterpret_cast<const u32x4_t*>(a.sc + s0);
+        for (size_t i = threadIdx.x; i < nv / 2; i += TRI_BLOCK) { const u32x4_t q = c16[i]; sink += q[1]; }
+        for (int p = lo + (int)threadIdx.x; p < hi; p += TRI_BLOCK) {
+            sink += (unsigned long long)__double_as_longlong(a.dr[2 * (size_t)p]) ^ (unsigned long long)a.tr[2 * (size_t)p]
+                    ^ (unsigned long long)__double_as_longlong(a.rec[2 * (size_t)p]);
+        }
+    }
+    asm volatile("" ::"v"((unsigned)sink), "v"((unsigned)(sink >> 32)));   // (the loads are the point)
+}
+
+template <int L, int PF, bool WIN, bool TAIL>
+__global__ __launch_bounds__(TRI_BLOCK) void k_tri_block(TriArgs a, int nseq, int cap, int nhelp, int ahead, unsigned* prog)
+{
+    if (blockIdx.x != 0) {
+        if ((blockIdx.x & 7) == 0) tri_prefetch(a, (int)(blockIdx.x >> 3) - 1, nhelp, ahead, prog);
+        return;
+    }
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     extern __shared__ __attribute__((aligned(16))) double tri_lds[];
     constexpr int G = !WIN ? 1 : PF <= 4 ? 4 : 3;   // (!WIN drains the counter per chunk anyway)
@@ -286,6 +324,7 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_block(TriArgs a, int nseq, in
     // one group: its first chain (the compiler's own wait for the set lands here: everything requested a group ago has
     // arrived, nothing younger is in flight), THEN the request for the next group, then the remaining chains
     auto run_group = [&](const Set& S, Set& N, int l0) {
+        if (nhelp && threadIdx.x == 0) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)prog, (unsigned)l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also what makes a far read safe: every store of W older than a group has landed)
         run_chunk(S, 0, l0);
         fetch_group(N, l0 + G);

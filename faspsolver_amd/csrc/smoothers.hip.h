@@ -247,6 +247,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     if ((st = split_upload(S, &S.d_dr, dr)) < 0) return st;
     if ((st = split_upload(S, &S.d_tr, tr)) < 0) return st;
     if ((st = split_upload(S, &S.d_W, std::vector<double>((size_t)ns, 0.0))) < 0) return st;
+    if ((st = split_upload(S, &S.d_prog, std::vector<unsigned>(4, 0u))) < 0) return st;
     S.nfar_chunks = 0;
     for (int c = 0; c < nchunk; ++c) {
         bool any = false;
@@ -330,7 +331,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
         const int rpb = BLOCK / S.LR;
         const int grid = std::max(1, std::min(MAXGRID, (ns + rpb - 1) / rpb));
 #define REST_LAUNCH(LL) hipLaunchKernelGGL((k_split_rest<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, ns, (const int*)S.d_order, \
-        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)D.b, (const double*)D.x, S.d_rec)
+        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)D.b, (const double*)D.x, S.d_rec, S.d_prog)
         switch (S.LR) {
             case 1: REST_LAUNCH(1); break;
             case 2: REST_LAUNCH(2); break;
@@ -368,6 +369,10 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     const double cost_block = cap ? S.block_us + 1.5 * S.nfar_chunks : std::max(S.block_us, 2.2 * nchunk), cost_launch = (double)nlev * 3.2 + 0.15 * (nchunk - nlev);
     if (g_tune.seq_block && nlev >= 8 && lds_ptr <= LDS_CAP && cost_block < cost_launch) {
         const size_t dyn = (cap ? (size_t)cap * 8 : 0) + lds_ptr;
+        // helper workgroups that read ahead of the solver into the XCD's L2 (tri_prefetch): ~1.5 MB ahead, at least three groups of chunks
+        const int nhelp = comm_shares_devices() ? 0 : std::max(0, g_tune.seq_help);
+        const double chunk_bytes = nchunk ? (12.0 * S.nslot + 40.0 * ns) / nchunk : 1.0;
+        const int ahead = (int)std::min(4096.0, std::max(12.0, 1.5e6 / chunk_bytes));
 #define TRIB_ONE(LL, PP, WW, TT)                                                                                           \
         {                                                                                                                   \
             static bool attr_set = false;                                                                                   \
@@ -376,7 +381,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP));                       \
                 attr_set = true;                                                                                            \
             }                                                                                                               \
-            hipLaunchKernelGGL((k_tri_block<LL, PP, WW, TT>), dim3(1), dim3(TRI_BLOCK), dyn, g_ctx.stream, ta, ns, cap ? cap : 2); \
+            hipLaunchKernelGGL((k_tri_block<LL, PP, WW, TT>), dim3(1 + 8 * nhelp), dim3(TRI_BLOCK), dyn, g_ctx.stream, ta, ns, cap ? cap : 2, nhelp, ahead, S.d_prog); \
         }
 #define TRIB_LAUNCH(LL)                                                                                                     \
         if (!cap) TRIB_ONE(LL, TRI_PFMAX, false, true)                                                                      \
