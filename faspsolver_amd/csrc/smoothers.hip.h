@@ -123,8 +123,12 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
         long long acc = 0;
         for (int v = 0; v < 258; ++v) { acc += hist[v]; if (acc * 10 >= (long long)ns * 9) { len90 = v; break; } }
     }
+    // wide classes (levels 1-2 of a 3-D problem: hundreds of rows each) keep every wavefront of the solving workgroup busy, and
+    // what a chunk costs there is instructions, per LANE mostly: half the lanes with twice the rounds is less work per row.
+    // Narrow classes (a few rows: the deep levels) are a latency chain: more lanes, shorter chains.
+    const bool wide = nlev > 0 && ns / nlev >= 128;   // (measured at 128^3: classes of 190 and 1 700 rows gain 28-33 %, of 33 and 109 rows lose)
     int L = 1;
-    while (L < 64 && TRI_PF * L < len90) L *= 2;
+    while (L < 64 && (wide ? TRI_PFMAX : TRI_PF) * L < len90) L *= 2;
     if (g_tune.seq_lanes > 0) { L = 1; while (L < 64 && L < g_tune.seq_lanes) L *= 2; }
     // chunks: the classes cut into rounds of a TRI_BLOCK-thread workgroup; slots per lane = what the chunk's longest row needs
     const int rpb = TRI_BLOCK / L;
