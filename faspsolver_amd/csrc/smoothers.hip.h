@@ -95,6 +95,7 @@ static int split_upload(DevLevel::Sched& S, T** dst, const std::vector<T>& v)
 }
 static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::Sched& S)
 {
+    HostThreads host_team;   // (bounded OpenMP team for the row-parallel loops below; the dependency levels themselves are a sequential pass)
     const int n = A.row, ns = (int)seq.size();
     std::vector<int> pos(n, -1), lev(ns, 0);
     for (int q = 0; q < ns; ++q) pos[seq[q]] = q;
@@ -154,6 +155,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     auto is_far = [&](int p, int cpos) { return ringcap > 0 && lo_of[chunk_of[p] + 1] - cpos > ringcap; };
     std::vector<int> nfar_of(ns, 0);
     long long nfar = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nfar)
     for (int q = 0; q < ns; ++q) {
         const int i = seq[q], p = newpos[q];
         int f = 0;
@@ -186,6 +188,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     std::vector<int>    sc((size_t)nslot), tia(ns + 1, 0), ria(ns + 1, 0);
     std::vector<double> sv((size_t)nslot, 0.0), dr(2 * (size_t)ns, 0.0);
     std::vector<int>    tr(2 * (size_t)ns, 0);
+#pragma omp parallel for schedule(dynamic, 64)
     for (int c = 0; c < nchunk; ++c) {
         const int lo = lo_of[c], hi = lo_of[c + 1];
         for (int q = 0; q < ((pf_of[c] + 3) & ~3); ++q)
@@ -193,6 +196,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
                 for (int sl = 0; sl < L; ++sl) sc[(size_t)sbase[c] + ((size_t)(q / 4) * L * (hi - lo) + (size_t)(p - lo) * L + sl) * 4 + (q % 4)] = p;
     }
     long long ntail = 0, nrest = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ntail, nrest)
     for (int q = 0; q < ns; ++q) {
         const int i = seq[q], p = newpos[q];
         const int t = std::max(0, len[p] - TRI_PFMAX * L) + nfar_of[p];   // near entries beyond the slots + far entries
@@ -213,6 +217,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     std::vector<int>    tja((size_t)ntail), rja((size_t)nrest);
     std::vector<double> tval((size_t)ntail), rval((size_t)nrest);
     int reach = 0;   // how far back (in positions, from the end of its chunk) a row reads: the LDS ring must cover it
+#pragma omp parallel for schedule(static) reduction(max : reach)
     for (int q = 0; q < ns; ++q) {
         const int i = seq[q], p = newpos[q];
         const int ck = chunk_of[p], lo = lo_of[ck], hi = lo_of[ck + 1];
