@@ -150,7 +150,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     // two that fits beside the chunk descriptors; no far entries where it would be shorter than four groups of chunks.
     int ringcap = 0;
     for (int c = 16384; c >= 1024 && !ringcap; c >>= 1)
-        if ((size_t)c * 8 + 2 * sizeof(int) * (size_t)(nchunk + 1) <= TRI_LDS_CAP) ringcap = c;
+        if (c <= g_tune.seq_ring && (size_t)c * 8 + 2 * sizeof(int) * (size_t)(nchunk + 1) <= TRI_LDS_CAP) ringcap = c;   // (seq_ring: a smaller ring, so that tests meet far entries on small grids)
     if (ringcap < 16 * rpb) ringcap = 0;
     auto is_far = [&](int p, int cpos) { return ringcap > 0 && lo_of[chunk_of[p] + 1] - cpos > ringcap; };
     std::vector<int> nfar_of(ns, 0);
@@ -371,7 +371,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
         if (S.nfar) cap = S.ringcap;   // (the far entries were chosen against exactly this ring)
         else {
             for (int c = 16384; c >= 1024 && !cap; c >>= 1)
-                if (S.reach <= c && (size_t)c * 8 + lds_ptr <= LDS_CAP) cap = c;
+                if (c <= g_tune.seq_ring && S.reach <= c && (size_t)c * 8 + lds_ptr <= LDS_CAP) cap = c;
             while (cap > 1024 && (cap >> 1) >= S.reach) cap >>= 1;   // (no larger than needed: the ring is zeroed per launch)
         }
     }

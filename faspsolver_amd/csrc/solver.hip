@@ -2023,6 +2023,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_ulds")) g_tune.seq_ulds = value;
     else if (!std::strcmp(key, "lazy_coarse")) g_tune.lazy_coarse = value;
     else if (!std::strcmp(key, "seq_help")) g_tune.seq_help = value;
+    else if (!std::strcmp(key, "seq_ring")) g_tune.seq_ring = value;
     else if (!std::strcmp(key, "xtile")) g_tune.xtile = value;
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
     else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;

@@ -10,6 +10,7 @@ residual, checked as |relres_gpu - relres_ref| <= 1e-10).
 """
 import ctypes as C
 
+import os
 import numpy as np
 import pytest
 

@@ -191,3 +191,108 @@ def test_standalone_sequential_smoothers(gpu, which):
         L.fasp_smoother_dcsr_L1diag.restype = None
         L.fasp_smoother_dcsr_L1diag(C.byref(uv), i1, i2, s, C.byref(A), C.byref(bv), 2)
     assert np.abs(u - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["gs_fwd", "gs_bwd", "sor_fwd", "sor_bwd"])
+def test_standalone_sweeps_on_a_ragged_matrix(gpu, which):
+    """The split sweep (a parallel pass + a sparse triangular solve, csrc/seq_split.hip.h) on what a stencil never shows:
+    an unsymmetric pattern (anti-dependencies), rows far longer than the slot storage holds (tails), empty rows, rows
+    without a diagonal and with a zero diagonal (left alone, ItrSmootherCSR.c: |d| <= SMALLREAL), a diagonal stored
+    twice (the reference's loop keeps the LAST one and subtracts nothing for either)."""
+    import scipy.sparse as sp
+    L = fa.lib()
+    rng = np.random.default_rng(5)
+    n = 700
+    M = sp.random(n, n, density=0.03, random_state=7, format="lil")
+    for i in (3, 250, 699):                       # very long rows: more lower entries than 8 x 64 slots
+        M[i, :] = rng.standard_normal(n)
+    for i in range(n): M[i, i] = 30.0 + rng.random()
+    for i in (10, 11, 400): M[i, :] = 0.0         # empty rows
+    M[20, 20] = 0.0                               # stored zero diagonal
+    M = M.tocsr(); M.sort_indices()
+    M[21, 21] = 0.0; M.eliminate_zeros()          # no diagonal at all in row 21 (row 20 lost its zero too: put it back below)
+    ia = M.indptr.astype(np.int32).tolist(); ja = M.indices.astype(np.int32).tolist(); a = M.data.tolist()
+    def insert(row, col, v):                      # append an entry to a row (unsorted storage is allowed)
+        k = ia[row + 1]
+        ja.insert(k, col); a.insert(k, v)
+        for r in range(row + 1, n + 1): ia[r] += 1
+    insert(20, 20, 0.0)                           # zero diagonal, stored
+    insert(100, 100, 55.0)                        # diagonal stored twice: the last one counts
+    ia = np.array(ia, dtype=np.int32); ja = np.array(ja, dtype=np.int32); a = np.array(a)
+    f = rng.standard_normal(n); u0 = rng.standard_normal(n)
+    A, keep = T.as_csr(ia, ja, a)
+    u = u0.copy(); uv, u = T.as_vec(u); bv, _f = T.as_vec(f)
+    w = 1.1
+    s = -1 if which.endswith("bwd") else 1
+    i1, i2 = (0, n - 1) if s > 0 else (n - 1, 0)
+    ref = u0.copy()
+    order = range(n) if s > 0 else range(n - 1, -1, -1)
+    for sweep in range(2):
+        for i in order:
+            t = f[i]; d = 0.0
+            for k in range(ia[i], ia[i + 1]):
+                if ja[k] != i: t -= a[k] * ref[ja[k]]
+                else: d = a[k]
+            if abs(d) > 1e-20:
+                ref[i] = t * (1.0 / d) if which.startswith("gs") else w * (t / d) + (1 - w) * ref[i]
+    if which.startswith("gs"):
+        L.fasp_smoother_dcsr_gs.argtypes = [C.POINTER(T.dvector), C.c_int, C.c_int, C.c_int, C.POINTER(T.dCSRmat), C.POINTER(T.dvector), C.c_int]
+        L.fasp_smoother_dcsr_gs.restype = None
+        L.fasp_smoother_dcsr_gs(C.byref(uv), i1, i2, s, C.byref(A), C.byref(bv), 2)
+    else:
+        L.fasp_smoother_dcsr_sor.argtypes = [C.POINTER(T.dvector), C.c_int, C.c_int, C.c_int, C.POINTER(T.dCSRmat), C.POINTER(T.dvector), C.c_int, C.c_double]
+        L.fasp_smoother_dcsr_sor.restype = None
+        L.fasp_smoother_dcsr_sor(C.byref(uv), i1, i2, s, C.byref(A), C.byref(bv), 2, w)
+    assert np.all(np.isfinite(u))
+    assert np.abs(u - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["gs_fwd", "sor_bwd"])
+def test_standalone_sweeps_with_far_entries(gpu, which):
+    """A 5-point grid in natural order (anti-diagonal dependency classes, every row reads the class before) plus twenty
+    couplings 19 000 rows back, with the LDS ring of the one-workgroup triangular solve cut to 8 192 values
+    (fasp_hip_tune("seq_ring")): those twenty are FAR entries -- read from W in memory while everything else comes from
+    the ring (the path levels 1-2 of a 128^3 hierarchy take; FASP_HIP_SETUP_TIMING=1 prints the count)."""
+    import scipy.sparse as sp
+    L = fa.lib()
+    nx, ny = 200, 100
+    n = nx * ny
+    rng = np.random.default_rng(9)
+    I = sp.identity(nx, format="csr"); J = sp.identity(ny, format="csr")
+    Tx = sp.diags([-1.0, -1.0], [-1, 1], shape=(nx, nx)); Ty = sp.diags([-1.0, -1.0], [-1, 1], shape=(ny, ny))
+    M = (sp.kron(J, Tx) + sp.kron(Ty, I) + 4.5 * sp.identity(n)).tolil()
+    for i in rng.choice(np.arange(19500, n), size=20, replace=False):
+        M[i, i - 19000] = -0.25; M[i - 19000, i] = -0.25
+    M = M.tocsr(); M.sort_indices()
+    ia = M.indptr.astype(np.int32); ja = M.indices.astype(np.int32); a = M.data.copy()
+    f = rng.standard_normal(n); u0 = rng.standard_normal(n)
+    A, keep = T.as_csr(ia, ja, a)
+    u = u0.copy(); uv, u = T.as_vec(u); bv, _f = T.as_vec(f)
+    w = 1.1
+    s = -1 if which.endswith("bwd") else 1
+    i1, i2 = (0, n - 1) if s > 0 else (n - 1, 0)
+    ref = u0.copy()
+    order = range(n) if s > 0 else range(n - 1, -1, -1)
+    ial, jal, al = ia.tolist(), ja.tolist(), a.tolist()
+    for sweep in range(2):
+        for i in order:
+            t = f[i]; d = 0.0
+            for k in range(ial[i], ial[i + 1]):
+                if jal[k] != i: t -= al[k] * ref[jal[k]]
+                else: d = al[k]
+            ref[i] = t * (1.0 / d) if which.startswith("gs") else w * (t / d) + (1 - w) * ref[i]
+    try:
+        L.fasp_hip_tune(b"seq_ring", 8192)
+        if which.startswith("gs"):
+            L.fasp_smoother_dcsr_gs.argtypes = [C.POINTER(T.dvector), C.c_int, C.c_int, C.c_int, C.POINTER(T.dCSRmat), C.POINTER(T.dvector), C.c_int]
+            L.fasp_smoother_dcsr_gs.restype = None
+            L.fasp_smoother_dcsr_gs(C.byref(uv), i1, i2, s, C.byref(A), C.byref(bv), 2)
+        else:
+            L.fasp_smoother_dcsr_sor.argtypes = [C.POINTER(T.dvector), C.c_int, C.c_int, C.c_int, C.POINTER(T.dCSRmat), C.POINTER(T.dvector), C.c_int, C.c_double]
+            L.fasp_smoother_dcsr_sor.restype = None
+            L.fasp_smoother_dcsr_sor(C.byref(uv), i1, i2, s, C.byref(A), C.byref(bv), 2, w)
+    finally:
+        L.fasp_hip_tune(b"seq_ring", 16384)
+    assert np.abs(u - ref).max() <= 1e-12 * np.abs(ref).max()
