@@ -136,6 +136,21 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         const size_t lds_w = sizeof(double) * (128 * (size_t)LD + 128);
         const bool one_wave = g_tune.small_onewave && m <= 128 && lds_w <= 148 * 1024;
         if (one_wave && g_tune.small_onewave >= 2) {   // the matrix in registers (four wavefronts); small_onewave 1: dense in LDS, one wavefront
+            const int MC = m <= 64 ? 32 : m <= 96 ? 48 : 64;
+            if (!h->reg_img || h->reg_mc != MC) {   // the register image, once per hierarchy: thread t = (row t / 2, half t % 2), entry k = column 4 (k / 2) + 2 (t % 2) + k % 2
+                const HostCSR& Ah = h->H.L.back().A;
+                std::vector<double> img((size_t)MC * SPCG_REG_NT, 0.0);
+                for (int row = 0; row < m; ++row)
+                    for (int k = Ah.ia[row]; k < Ah.ia[row + 1]; ++k) {
+                        const int c = Ah.ja[k], hh = (c >> 1) & 1, kk = 2 * (c >> 2) + (c & 1);
+                        if (kk < MC) img[(size_t)kk * SPCG_REG_NT + 2 * row + hh] += Ah.val[k];
+                    }
+                if (h->reg_img) (void)hipFree(h->reg_img);
+                HIPCK(hipMalloc((void**)&h->reg_img, sizeof(double) * img.size()));
+                HIPCK(hipMemcpy(h->reg_img, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+                h->reg_mc = MC;
+            }
+            a.img = h->reg_img;
             static bool attr_r = false;
             if (!attr_r) {
                 (void)hipFuncSetAttribute((const void*)k_spcg_reg<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -143,9 +158,10 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
                 (void)hipFuncSetAttribute((const void*)k_spcg_reg<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
                 attr_r = true;
             }
-            if (m <= 64) hipLaunchKernelGGL(k_spcg_reg<32>, dim3(1), dim3(SPCG_REG_NT), lds_w, g_ctx.stream, a, LD);
-            else if (m <= 96) hipLaunchKernelGGL(k_spcg_reg<48>, dim3(1), dim3(SPCG_REG_NT), lds_w, g_ctx.stream, a, LD);
-            else hipLaunchKernelGGL(k_spcg_reg<64>, dim3(1), dim3(SPCG_REG_NT), lds_w, g_ctx.stream, a, LD);
+            const size_t lds_r = sizeof(double) * (2 * (size_t)MC + 4);
+            if (m <= 64) hipLaunchKernelGGL(k_spcg_reg<32>, dim3(1), dim3(SPCG_REG_NT), lds_r, g_ctx.stream, a, LD);
+            else if (m <= 96) hipLaunchKernelGGL(k_spcg_reg<48>, dim3(1), dim3(SPCG_REG_NT), lds_r, g_ctx.stream, a, LD);
+            else hipLaunchKernelGGL(k_spcg_reg<64>, dim3(1), dim3(SPCG_REG_NT), lds_r, g_ctx.stream, a, LD);
         }
         else if (one_wave) {
             static bool attr_w = false;

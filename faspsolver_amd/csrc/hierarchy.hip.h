@@ -93,6 +93,7 @@ struct fasp_hip_amg {
     // lazy coarse verdicts (precond_amg): device words {min status, iteration sum}, their pinned host copy; coarse_sync: a coarse
     // solve gave up once on this hierarchy -- verdicts are read per solve from then on
     int*                   d_lazy = nullptr; int* h_lazy = nullptr; bool lazy_active = false, coarse_sync = false;
+    double*                reg_img = nullptr; int reg_mc = 0;   // k_spcg_reg: the coarsest matrix as its threads hold it
     double                 upload_seconds = 0.0;
 };
 

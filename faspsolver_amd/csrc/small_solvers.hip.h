@@ -260,6 +260,7 @@ struct SpcgArgs {
     int      x_zero;  // the iterate is zero on entry (skips the first matrix pass)
     int      nnz;
     SmallOut* out;
+    const double* img;   // k_spcg_reg: the matrix as its threads hold it, [MC][256] (spcg_reg_image)
     int*     lazy;    // != nullptr: the verdict is not read per solve -- [0] takes the minimum status, [1] the sum of the iteration counts (precond_amg)
 };
 __device__ __forceinline__ void spcg_report(const SpcgArgs& a, int iter, int MaxIt, double relres, double absres)
@@ -574,8 +575,8 @@ FINISHED:
 
 // ---------------------------------------------------------------------------
 // k_spcg_reg<MC>: the same safe CG for coarsest levels of at most 128 rows with the MATRIX IN REGISTERS: four
-// wavefronts, thread (row, h) = (tid / 2, tid % 2) keeps the entries of its row in the columns 2 k + h (k < MC, dense,
-// zeros where the level stores nothing) in MC register pairs for the whole solve.  An iteration of k_spcg_wave reads
+// wavefronts, thread (row, h) = (tid / 2, tid % 2) keeps the entries of its row in the columns 4 (k / 2) + 2 h + k % 2 (k < MC,
+// dense, zeros where the level stores nothing) in MC register pairs for the whole solve.  An iteration of k_spcg_wave reads
 // 3 m doubles per lane from LDS (its two dense rows and the broadcast of p) -- 3 us at 89 rows, and config 5 of
 // BASELINE.json runs 124 000 of them per solve; here the product is MC multiply-adds on registers against p read as
 // 16-byte broadcasts (all lanes one address), the two halves of a row meet by one lane swap, and the price is a
@@ -592,28 +593,33 @@ __device__ __forceinline__ double pair_swap(double x)   // the value of the othe
     hi = __builtin_amdgcn_mov_dpp(hi, 0xb1, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
+#ifdef SR_TIMING
+#define SRT(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); srt[k] += now_ - srt_last; srt_last = now_; } while (0)
+#else
+#define SRT(k)
+#endif
 template <int MC>
 __global__ __launch_bounds__(SPCG_REG_NT) void k_spcg_reg(SpcgArgs a, int LD)
 {
-    extern __shared__ __attribute__((aligned(16))) double dyn[];   // [128 * LD] dense staging of the matrix, then [2 MC + 2] p
+#ifdef SR_TIMING
+    unsigned long long srt[6] = {0, 0, 0, 0, 0, 0}, srt_last = __builtin_amdgcn_s_memrealtime();
+#endif
+    extern __shared__ __attribute__((aligned(16))) double dyn[];   // [2 MC + 4] p
     __shared__ double sh2[2 * 4 * 5];
     const SmallCSR A = a.A;
     const int m = A.m, tid = threadIdx.x;
     const int row = tid >> 1, h = tid & 1;
     const bool has = row < m, mine = has && h == 0;   // `mine`: the lane that counts the row in reductions
     int par = 0;
-    // dense staging (rows beyond m and absent entries are zeros; a column stored twice is added up), then into registers
-    for (int i = tid; i < 128 * LD; i += SPCG_REG_NT) dyn[i] = 0.0;
-    __syncthreads();
-    if (mine)
-        for (int k = A.ia[row]; k < A.ia[row + 1]; ++k) dyn[row * LD + A.ja[k]] += A.val[k];
-    __syncthreads();
+    (void)LD;
+    // the thread's share of the matrix: entry k = column 4 (k / 2) + 2 h + k % 2 of its row, dense, from the image the host
+    // lays out once per hierarchy (spcg_reg_image: [MC][256]; a column stored twice is added up there in storage order) --
+    // building it here took 15-35 us of every one of config 5's 712 coarse solves per solve
     double Ar[MC];
 #pragma unroll
-    for (int k = 0; k < MC; ++k) Ar[k] = (2 * k + h < LD) ? dyn[row * LD + 2 * k + h] : 0.0;
-    __syncthreads();
-    double* pb = dyn;   // the staging area is free now
-    for (int i = tid; i < 2 * MC + 2; i += SPCG_REG_NT) pb[i] = 0.0;
+    for (int k = 0; k < MC; ++k) Ar[k] = a.img[(size_t)k * SPCG_REG_NT + tid];
+    double* pb = dyn;
+    for (int i = tid; i < 2 * MC + 4; i += SPCG_REG_NT) pb[i] = 0.0;
     __syncthreads();
     // The scalar tail of an iteration is three square roots and three divisions that every lane would work through one
     // after the other (each a sequence of ~30 dependent instructions, ~0.1 us): lanes 0, 1, 2 take one each, side by
@@ -635,13 +641,17 @@ __global__ __launch_bounds__(SPCG_REG_NT) void k_spcg_reg(SpcgArgs a, int LD)
     };
     // (every product is followed by a reduction before the next one: its barrier also says that everybody is done
     // reading the previous broadcast, so the broadcast needs one barrier, not two)
-    const double* pmine = pb + h;
+    const f64x2_t* pmine = reinterpret_cast<const f64x2_t*>(pb + 2 * h);
     auto mxv = [&](double x) -> double {   // y_row = (A x)_row, x_row given in every lane of the pair
         if (mine) pb[row] = x;
         __syncthreads();
         double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < MC; ++k) s[k & 3] += Ar[k] * pmine[2 * k];   // (even lanes one address, odd lanes the next: a two-address broadcast)
+        for (int k = 0; k < MC; k += 2) {   // two columns per 16-byte read (even lanes one address, odd lanes the next: a two-address broadcast)
+            const f64x2_t q = pmine[k];     // columns 2 k + 2 h, 2 k + 2 h + 1
+            s[k & 3] += Ar[k] * q[0];
+            s[(k + 1) & 3] += Ar[k + 1] * q[1];
+        }
         const double sh_ = (s[0] + s[1]) + (s[2] + s[3]);
         const double so = pair_swap(sh_);
         return h ? so + sh_ : sh_ + so;    // half 0 + half 1 in both lanes
@@ -667,9 +677,13 @@ __global__ __launch_bounds__(SPCG_REG_NT) void k_spcg_reg(SpcgArgs a, int LD)
     if (relres < tol) goto FINISHED;
     p = r;
 
+    SRT(0);
     while (iter++ < MaxIt) {
+        SRT(5);
         t = mxv(p);
+        SRT(1);
         temp2 = allsum1(t * p);
+        SRT(2);
         if (fabs(temp2) > SMALL2) alpha = temp1 / temp2;
         else goto RESTORE_BESTSOL;
         u = u + alpha * p;
@@ -690,10 +704,12 @@ __global__ __launch_bounds__(SPCG_REG_NT) void k_spcg_reg(SpcgArgs a, int LD)
                 q[3] = qm[0];
             }
         }
+        SRT(3);
         double sq_pp, fac;
         sqrt3(q[0], q[1], q[2], absres, normu, sq_pp);      // absres = sqrt(rr), normu = sqrt(uu), sqrt(pp)
         fac = fabs(alpha) * sq_pp;
         div3(absres, normr0, fac, normu, q[0], temp1, relres, reldiff, beta);   // relres, reldiff, and beta = rr / temp1 for the usual path
+        SRT(4);
         double red0 = q[0];
         if (q[4] > 0.0) {  // fasp_dvec_isnan(u), :185
             absres = BIG;
@@ -745,6 +761,9 @@ RESTORE_BESTSOL:
         }
     }
 FINISHED:
+#ifdef SR_TIMING
+    if (tid == 0 && iter > 50) printf("[spcg_reg] iters %d: setup %.2f us | per iteration: mxv %.3f dot %.3f update+reduce3 %.3f sqrt/div %.3f rest %.3f us\n", iter, srt[0] * 0.01, srt[1] * 0.01 / iter, srt[2] * 0.01 / iter, srt[3] * 0.01 / iter, srt[4] * 0.01 / iter, srt[5] * 0.01 / iter);
+#endif
     if (mine) a.u[row] = u;
     if (tid == 0) {
         spcg_report(a, iter, MaxIt, relres, absres);

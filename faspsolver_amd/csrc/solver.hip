@@ -431,6 +431,7 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
     for (double* q : v)
         if (q) (void)hipFree(q);
     if (h->d_lazy) (void)hipFree(h->d_lazy);
+    if (h->reg_img) (void)hipFree(h->reg_img);
     if (h->h_lazy) (void)hipHostFree(h->h_lazy);
     for (auto& e : h->ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int s = 0; s < 2; ++s)
