@@ -411,7 +411,7 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
     const bool ask_zr = h->want_zr && u.cycle_type != AMLI_CYCLE && u.cycle_type != NL_AMLI_CYCLE;   // (set by the PCG operator bundle for this apply only; V / W cycles end with the level-0 sweep)
     // Lazy coarse verdicts.  A coarsest level small enough for a one-launch solver is visited up to 2^(levels - 1) times per
     // W-cycle, and reading every solve's verdict (has the safe CG given up? then the reference's SPVGMRES net takes over) was a
-    // host synchronisation each: 1 424 per solve of config 5.  The solvers now leave the minimum status and the iteration sum
+    // host synchronisation each: 712 per solve of config 5.  The solvers now leave the minimum status and the iteration sum
     // in two device words, read ONCE per application; if a solve did give up, the application is replayed from r -- which a
     // cycle only reads -- with the verdicts read as they come, and the hierarchy stays in that mode.
     const DevLevel& Dc = h->L.back();
