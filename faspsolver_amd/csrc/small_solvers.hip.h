@@ -1544,8 +1544,10 @@ __device__ __forceinline__ void blk_reduce_dpp(double (&v)[NQ], double* sh, unsi
 
 __device__ __forceinline__ bool absres_improves(double rr, double best, double maxdiff) { return sqrt(rr) < best - maxdiff; }
 
-template <int NE>
-__global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
+// (LEAD: block 0's instantiation.  The same text, but its registers never hold a matrix: what the early verdict needs
+// extra does not add to the product loop's register pressure -- as one body it spilled there, 2.66 -> 3.5 us per product)
+template <int NE, bool LEAD>
+__device__ __forceinline__ void spcg_persist_body(const SpcgPersistArgs& a)
 {
     constexpr int NT = 512, NW = 8, E = 12, CH = 6;  // m <= E * NT = 6144; two waves per SIMD: 256 registers per lane
     extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -1555,7 +1557,7 @@ __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     const int tid = threadIdx.x, lane = tid & 63, m = a.m;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool lead = blockIdx.x == 0;
+    constexpr bool lead = LEAD;
     double* sp = dyn;        // p
     double* sr = dyn + m;    // r
     double* st = dyn + 2 * m;  // t of this iteration, read back from the published copy
@@ -1704,75 +1706,108 @@ __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
             break;
         }
         const double alpha = temp1 / tp;
-        v1[0] = 0.0;
+        // Block 0's verdict is what every other block waits for at the NEXT exchange, so block 0 forms it as early as it can:
+        // the iterate and its norms ride with the residual pass (u += alpha p needs nothing the p update produces), one
+        // three-quantity reduction, the scalar tail, the verdict out -- and only then the new direction.  With the norms in
+        // the third pass (round 2) the verdict left 8.1 us after the exchange and the others, done with their products after
+        // 5.9, waited for it: 10.4 us per iteration (stamps in coarse_cg.hip.h).
+        double red[3] = {0.0, 0.0, 0.0};   // (r,r) everywhere; block 0: + (u,u), (p,p)
 #pragma unroll 1
         for (int e0 = 0; e0 < E; e0 += CH) {
-            double tv[CH], rv[CH];
-#pragma unroll
-            for (int e = 0; e < CH; ++e) { const int i = min(tid + (e0 + e) * NT, m - 1); tv[e] = st[i]; rv[e] = sr[i]; }
-#pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                const int i = tid + (e0 + e) * NT;
-                if (i < m) {
-                    const double rn = rv[e] - alpha * tv[e];
-                    sr[i] = rn;   // own entries of this thread in every pass
-                    v1[0] += rn * rn;
-                }
-            }
-        }
-        blk_reduce_dpp<1, NW>(v1, sh);
-        const double rr = v1[0], beta = rr / temp1;
-        double red[4] = {0.0, 0.0, 0.0, 0.0};  // block 0: (u,u), (p,p), max |u|, NaN count
-        STAMP(4);
-        const bool keep_best = lead && absres_improves(rr, best, maxdiff);   // KrySPcg.c:189-193, decided from rr alone
-#pragma unroll 1
-        for (int e0 = 0; e0 < E; e0 += CH) {
-            double rv[CH], pv[CH], uv[CH];
+            double tv[CH], rv[CH], pv[CH], uv[CH];
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
                 const int i = min(tid + (e0 + e) * NT, m - 1);
-                rv[e] = sr[i]; pv[e] = sp[i];
+                tv[e] = st[i]; rv[e] = sr[i];
+                pv[e] = lead ? sp[i] : 0.0;
                 uv[e] = lead ? (u_lds ? su[i] : a.u[i]) : 0.0;
             }
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
                 const int i = tid + (e0 + e) * NT;
                 if (i < m) {
-                    sp[i] = 1.0 * rv[e] + beta * pv[e];
+                    const double rn = rv[e] - alpha * tv[e];
+                    sr[i] = rn;   // own entries of this thread in every pass
+                    red[0] += rn * rn;
                     if (lead) {
                         const double ui = uv[e] + alpha * pv[e];
                         if (u_lds) su[i] = ui; else a.u[i] = ui;
-                        if (keep_best) a.u_best[i] = ui;
-                        red[0] += ui * ui; red[1] += pv[e] * pv[e];
-                        red[2] = fmax(red[2], fabs(ui));
-                        red[3] += (ui != ui) ? 1.0 : 0.0;
+                        red[1] += ui * ui; red[2] += pv[e] * pv[e];
                     }
                 }
             }
         }
-        STAMP(5);
+        double maxu = 1.0, nan_u = 0.0;
+        if (lead) {
+            blk_reduce_dpp<3, NW>(red, sh);
+            // (u has a NaN exactly when (u,u) is one -- squares do not cancel; max |u_i| <= 1e-20 is impossible when
+            // (u,u) > 2 m 1e-40, and only below that is the maximum itself formed: Check I, KrySPcg.c:195)
+            nan_u = (red[1] != red[1]) ? 1.0 : 0.0;
+            if (!(red[1] > 2.0 * m * 1e-40)) {
+                double mx[1] = {0.0};
+                for (int i = tid; i < m; i += NT) mx[0] = fmax(mx[0], fabs(u_lds ? su[i] : a.u[i]));
+                blk_reduce_dpp<1, NW>(mx, sh, 1u);
+                maxu = mx[0];
+            }
+        } else {
+            double r1[1] = {red[0]};
+            blk_reduce_dpp<1, NW>(r1, sh);
+            red[0] = r1[0];
+        }
+        const double rr = red[0], beta = rr / temp1;
+        STAMP(4);
+        const bool keep_best = lead && absres_improves(rr, best, maxdiff);   // KrySPcg.c:189-193, decided from rr alone
         if (lead) {
             const int it = it0 + step + 1;
-            blk_reduce_dpp<4, NW>(red, sh, 1u << 2);
             STAMP(6);
-            const double absres = sqrt(rr), relres = absres / normr0;
+            // the scalar tail: three square roots side by side in lanes 0-2, then the two quotients (the same operations on the
+            // same operands as one after the other)
+            const double sq = sqrt(lane == 0 ? rr : lane == 1 ? red[1] : red[2]);
+            auto bc = [&](double x, int from) -> double {
+                const unsigned long long bb = (unsigned long long)__double_as_longlong(x);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bb, from);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bb >> 32), from);
+                return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            };
+            const double absres = bc(sq, 0), normu = bc(sq, 1), sq_pp = bc(sq, 2);
+            const double fac = fabs(alpha) * sq_pp;
+            const double qd = (lane == 0 ? absres : fac) / (lane == 0 ? normr0 : normu);
+            const double relres = bc(qd, 0), reldiff = bc(qd, 1);
             int stop = SPCG_RUN;
-            if (red[3] > 0.0) stop = SPCG_NAN;
+            if (nan_u > 0.0) stop = SPCG_NAN;
             else {
-                if (absres < best - maxdiff) { best = absres; iter_best = it; }   // (the copy into u_best went out above)
-                const double reldiff = fabs(alpha) * sqrt(red[1]) / sqrt(red[0]);
-                if (red[2] <= 1e-20) stop = SPCG_SOLSTAG;                        // Check I
+                if (absres < best - maxdiff) { best = absres; iter_best = it; }   // (the copy into u_best goes out with the next pass)
+                if (maxu <= 1e-20) stop = SPCG_SOLSTAG;                          // Check I
                 else if ((stag <= 20) & (reldiff < maxdiff)) stop = SPCG_STAG;   // Check II: host recomputes r
                 else if (relres < tol) stop = SPCG_CONV;                         // Check III: host checks the true residual
                 if (stop == SPCG_RUN && it >= MaxIt) stop = SPCG_MAXIT;
             }
-            o_tp = tp; o_rr = rr; o_uu = red[0]; o_pp = red[1]; o_maxu = red[2]; o_nan = red[3];
+            o_tp = tp; o_rr = rr; o_uu = red[1]; o_pp = red[2]; o_maxu = maxu; o_nan = nan_u;
             o_alpha = alpha; o_absres = absres; o_relres = relres; o_temp1_prev = temp1;
             my_stop = stop;
             if (tid == 0)   // the verdict every block polls with the products of the next iteration
                 __hip_atomic_store(g_verdict + (par ^ 1), ((unsigned long long)(ep + 1u) << 32) | (unsigned)stop, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
+        // the new direction (block 0: and the best iterate, if this one is it)
+#pragma unroll 1
+        for (int e0 = 0; e0 < E; e0 += CH) {
+            double rv[CH], pv[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int i = min(tid + (e0 + e) * NT, m - 1);
+                rv[e] = sr[i]; pv[e] = sp[i];
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int i = tid + (e0 + e) * NT;
+                if (i < m) {
+                    sp[i] = 1.0 * rv[e] + beta * pv[e];
+                    if (keep_best) a.u_best[i] = u_lds ? su[i] : a.u[i];
+                }
+            }
+        }
+        STAMP(5);
         temp1 = rr;
         steps_done = step + 1;
         lds_barrier();   // p, r complete in LDS before the next product gathers from them
@@ -1796,6 +1831,13 @@ __global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
             S.stop = my_stop;
         }
     }
+}
+
+template <int NE>
+__global__ __launch_bounds__(512) void k_spcg_persist(SpcgPersistArgs a)
+{
+    if (blockIdx.x == 0) spcg_persist_body<NE, true>(a);
+    else spcg_persist_body<NE, false>(a);
 }
 
 }  // namespace fasp
