@@ -1146,7 +1146,7 @@ struct GmresArgs {
     SmallOut*     out;
     int           cache2;   // LV only: rows beyond the first 512 have GM_CB * 28 bytes each of LDS behind the basis (k_gmres_small: the matrix held on chip)
 };
-constexpr int GM_CB = 16;   // blocks of a row k_gmres_small holds on chip (nb = 3)
+constexpr int GM_CB = 14;   // blocks of a row k_gmres_small holds on chip (nb = 3)
 
 // LV: the Krylov basis p[0..restart] and w live in dynamic LDS ((restart + 2) n doubles) instead of a.ws
 // Modified Gram-Schmidt of the new Krylov vector `pi` against basis vectors 0 .. i-1 (n doubles apart) in ONE wavefront:
