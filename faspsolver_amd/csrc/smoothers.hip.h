@@ -175,7 +175,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     for (int c = 0; c < nchunk; ++c) {
         int mx = 0;
         for (int p = lo_of[c]; p < lo_of[c + 1]; ++p) mx = std::max(mx, len[p]);
-        pf_of[c] = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));   // (at least one round: tri_fetch is branch-free)
+        pf_of[c] = lower_total == 0 ? 0 : std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));   // (at least one round: tri_fetch is branch-free; none at all for a sweep without lower entries: it never reaches the triangular kernels)
         pfmax = std::max(pfmax, pf_of[c]);
         sbase[c] = (int)nslot;
         nslot += (long long)((pf_of[c] + 3) & ~3) * L * (lo_of[c + 1] - lo_of[c]);   // (packs of four rounds)
