@@ -264,6 +264,69 @@ def variable_leg(n, system, itp, amgp, timed_solves):
         return None
 
 
+def other_configs_leg():
+    """The other single-GPU configurations of BASELINE.json at full size, and the reference's DEFAULT smoother: one timed solve
+    each on a resident hierarchy (second solve: the first one builds lazily what it needs).  Reported beside the headline,
+    never instead of it; iteration counts are the compiled reference's (tests/golden/configs_full.npz, p7_sweeps.npz pin
+    them in the test suite)."""
+    from faspsolver_amd import _types as T
+    res = {}
+    try:   # config 3: P7(128) (x) B3, UA-AMG (VMB) + block Jacobi + VGMRES(30)
+        ia, ja, a, f0, ue = fa.poisson7pt(128)
+        B3 = np.array([[4.0, 1.0, 0.0], [1.0, 3.0, 1.0], [0.0, 1.0, 2.0]])
+        val = (a[:, None, None] * B3[None, :, :]).reshape(-1)
+        f = np.random.default_rng(1).standard_normal((len(ia) - 1) * 3)
+        itp, amgp = fa.param_solver_init(), fa.param_amg_init()
+        amgp.AMG_type = T.UA_AMG; amgp.aggregation_type = 2; amgp.smoother = T.SMOOTHER_JACOBI; amgp.cycle_type = 1
+        itp.tol = 1e-8; itp.itsolver_type = 5; itp.restart = 30
+        t0 = time.perf_counter()
+        G = fa.BSRAMG(ia, ja, val, 3, amgp)
+        ts = time.perf_counter() - t0
+        for rep in range(2):
+            st, x, hist, stats = G.solve(f, itp)
+        res["config3"] = {"workload": "P7(128) (x) B3 (6.3 M DOF, 14.6 M blocks), UA-AMG (VMB) + block Jacobi + VGMRES(30), rtol 1e-8",
+                          "ms_per_solve": stats.solve_seconds * 1e3, "iterations": int(st), "iterations_reference": 66,
+                          "relres": stats.relres, "DOF_per_s": len(f) / stats.solve_seconds, "setup_seconds": ts}
+        G.free()
+        log(f"config 3: {st} iterations, {stats.solve_seconds*1e3:.1f} ms")
+    except Exception as e:
+        log(f"config 3 leg failed: {e!r}")
+    try:   # config 5: anisotropic 27-point operator, SA-AMG + W-cycle + VFGMRES(30)
+        ia, ja, a, f = fa.aniso27pt(123)
+        itp, amgp = fa.param_solver_init(), fa.param_amg_init()
+        itp.tol = 1e-8; itp.itsolver_type = 6; itp.restart = 30
+        amgp.AMG_type = T.SA_AMG; amgp.cycle_type = T.W_CYCLE; amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
+        t0 = time.perf_counter()
+        H = fa.AMG(ia, ja, a, amgp)
+        ts = time.perf_counter() - t0
+        H.set_rhs(f)
+        for rep in range(2):
+            st, hist, stats = H.solve_resident(itp)
+        res["config5"] = {"workload": "Q1 27-point, anisotropy (1, 1, 0.01), n = 123 (1.86 M rows, 49.4 M nnz), SA-AMG + W-cycle + VFGMRES(30), w-Jacobi, rtol 1e-8",
+                          "ms_per_solve": stats.solve_seconds * 1e3, "iterations": int(st), "iterations_reference": 89,
+                          "relres": stats.relres, "DOF_per_s": len(f) / stats.solve_seconds, "setup_seconds": ts}
+        H.close()
+        log(f"config 5: {st} iterations, {stats.solve_seconds*1e3:.1f} ms")
+    except Exception as e:
+        log(f"config 5 leg failed: {e!r}")
+    try:   # the reference's default smoother (Gauss-Seidel, C/F order) in the parity mode
+        ia, ja, a, f, ue = fa.poisson7pt(128)
+        itp, amgp = fa.param_solver_init(), fa.param_amg_init()
+        itp.tol = 1e-8
+        H = fa.AMG(ia, ja, a, amgp)
+        H.set_rhs(f)
+        for rep in range(3):
+            st, hist, stats = H.solve_resident(itp)
+        res["gs_defaults_128"] = {"workload": "P7(128), fasp_param_amg_init defaults (GS smoother in C/F order, the reference's sequential sweep) + PCG, rtol 1e-8",
+                                  "ms_per_solve": stats.solve_seconds * 1e3, "iterations": int(st), "iterations_reference": 8,
+                                  "relres": stats.relres}
+        H.close()
+        log(f"GS defaults at 128^3: {st} iterations, {stats.solve_seconds*1e3:.1f} ms")
+    except Exception as e:
+        log(f"GS-defaults leg failed: {e!r}")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +335,7 @@ def main():
     ap.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", "256")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variable", action="store_true", help="skip the variable-coefficient second solve")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other configurations (configs 3 and 5 at full size, GS defaults at 128^3)")
     ap.add_argument("--only-variable", action="store_true",
                     help="profiling runs: only the variable-coefficient solve (tools/profile.sh <tag> variable)")
     args = ap.parse_args()
@@ -407,6 +471,9 @@ def main():
 
     if not args.no_variable:
         out["variable_coefficient"] = variable_leg(n, (ia, ja, a, f, ue), itp, amgp, timed_solves)
+    if not args.no_extra and args.gpus == 1:
+        del ia, ja, a
+        out["other_configs"] = other_configs_leg()
     print(json.dumps(out), flush=True)
 
 

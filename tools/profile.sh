@@ -12,7 +12,7 @@ if [ "$WL" = "variable" ]; then
   ARGS="bench.py --only-variable"
 else
   OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-  ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variable"
+  ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variable --no-extra"
 fi
 rm -rf $OUT; mkdir -p $OUT
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
