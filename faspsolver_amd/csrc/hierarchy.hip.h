@@ -33,7 +33,7 @@ struct DevLevel {
         int ns = 0, L = 1, LR = 1, reach = 0, pfmax = 1, ringcap = 0, nfar_chunks = 0; long long nfar = 0; bool nolower = false; long long ntail = 0, nslot = 0; double block_us = 0.0;
         std::vector<int> cptr;   // split form: class -> first chunk (ptr holds the chunk descriptors)
         int* d_sbase = nullptr; int* d_sc = nullptr; double* d_sv = nullptr; int* d_tia = nullptr; int* d_tja = nullptr; double* d_tval = nullptr;
-        int* d_ria = nullptr; int* d_rja = nullptr; double* d_rval = nullptr; double* d_rec = nullptr; double* d_dr = nullptr; int* d_tr = nullptr; double* d_W = nullptr; unsigned* d_prog = nullptr;
+        int* d_ria = nullptr; int* d_rja = nullptr; double* d_rval = nullptr; double* d_rec = nullptr; double* d_dr = nullptr; int* d_tr = nullptr; double* d_W = nullptr; unsigned* d_prog = nullptr; int* d_cptr = nullptr; int* d_cdesc = nullptr; int maxw = 0;
         std::vector<void*> owned;   // device arrays of the split form (d_order and d_ptr among them)
         void release()
         {

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_rest(int nseq, const int* __res
                                                        double* __restrict__ rec, unsigned* __restrict__ prog)
 {
     constexpr int RPB = BLOCK / L;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *prog = 0u;   // progress word of the triangular solve that follows (tri_prefetch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { prog[0] = 0u; prog[4] = 0u; prog[6] = 0u; }   // progress word of the one-workgroup solve that follows (tri_prefetch); arrivals and progress of the cluster form
     const int sl = threadIdx.x & (L - 1);
     const int rloc = threadIdx.x / L;
     for (int p0 = blockIdx.x * RPB; p0 < nseq; p0 += gridDim.x * RPB) {   // (whole wavefronts walk the loop: the DPP moves read neighbours)
@@ -338,6 +338,153 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_block(TriArgs a, int nseq, in
     }
     if (!WIN)
         for (int p = threadIdx.x; p < nseq; p += TRI_BLOCK) a.u[a.order[p]] = ldw(p);
+}
+
+// ---------------------------------------------------------------------------
+// k_tri_cluster<L>: the triangular solve of a schedule with WIDE dependency classes (hundreds to thousands of rows: the upper
+// levels) in one launch of a few cooperating workgroups.  One launch per class costs 3.2-3.9 us of dispatch; a barrier
+// among 2-16 workgroups on ONE XCD -- arrival by an atomic add, release by polling, with the class's values written
+// before and read (L1 bypassed) after it -- costs 0.7 us (tools/micro/xcdbar.hip: 0.68-0.70 us for 2-8 workgroups,
+// 0.72-1.05 us when they sit on several XCDs).
+//   * grid = 8 (nb + nhelp) workgroups; those whose index is a multiple of 8 take part (one XCD under the round-robin
+//     placement of workgroups): nb solvers, then nhelp helpers that read ahead into the XCD's L2 (tri_prefetch).
+//   * class l: solver b takes chunks cptr[l] + b, + nb, ...; W lives in memory: read with L1-bypassing loads, written
+//     with plain stores (they stay in the XCD's L2) when every solver reported the same HW_REG_XCC_ID at the start,
+//     with write-through (agent-scope) stores otherwise -- correct on any placement, fastest on the usual one.
+//   * the fetch for the next class is issued after the drain of this class's stores, so it travels during the wait.
+//   * every spin is bounded; a solver that is not resident raises the error word (the host checks it, smoothers.hip.h).
+// Same slots, same row arithmetic (tri_row) as the other two forms: identical bits.
+// ---------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(TRI_BLOCK) void k_tri_cluster(TriArgs a, const int* __restrict__ cptr, const int* __restrict__ cdesc, int nlev, int nseq, int nb, int nhelp,
+                                                            int ahead, unsigned* sync /* [0] arrivals, [1] error, [2] progress, [16 + b] XCC ids */)
+{
+    typedef __attribute__((address_space(1))) unsigned           gu32;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    if (blockIdx.x & 7) return;
+    const int b = (int)(blockIdx.x >> 3);
+    if (b >= nb) { tri_prefetch(a, b - nb, nhelp, ahead, sync + 2); return; }
+    __shared__ int s_ok, s_same;
+    const int tid = threadIdx.x;
+    const int sl = tid & (L - 1);
+    const int rloc = tid / L;
+    const TriBufs B = tri_bufs(a);
+    gu32* g_cnt = (gu32*)sync;
+    gu32* g_err = (gu32*)(sync + 1);
+    unsigned round = 0;
+    auto barrier = [&]() -> bool {   // (the caller has issued everything it wants visible; returns false when the cluster is broken)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ++round;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(g_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)nb * round;
+            int ok = 1;
+            unsigned spins = 0;
+            unsigned long long t0 = 0;
+            while (__hip_atomic_load(g_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if ((++spins & 1023u) == 0u) {   // (the clock is a memory operation of its own: not in every turn of the poll)
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (!t0) t0 = now;
+                    else if (now - t0 > 200000000ull) {   // 2 s at 100 MHz: a solver is not resident
+                        __hip_atomic_store(g_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            if (__hip_atomic_load(g_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+            s_ok = ok;
+        }
+        __syncthreads();
+        return s_ok != 0;
+    };
+    // placement: do the solvers share an XCD?
+    if (tid == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        __hip_atomic_store((gu32*)(sync + 16 + b), id & 0xfu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!barrier()) return;
+    if (tid == 0) {
+        int same = 1;
+        const unsigned id0 = __hip_atomic_load((gu32*)(sync + 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 1; q < nb; ++q)
+            if (__hip_atomic_load((gu32*)(sync + 16 + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != id0) same = 0;
+        s_same = same;
+    }
+    __syncthreads();
+    const bool same_xcd = s_same != 0;
+    auto ldw = [&](int c) -> double {
+        return __longlong_as_double((long long)__hip_atomic_load((gu64*)(a.W + (c & TRI_POS_MASK)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    // cdesc[(l * nb + b) * 4 ..]: {first position | rounds << 28, end position, slot offset, -} of solver b's first chunk of class l
+    // (an empty range when the class has fewer chunks): ONE load at an address that follows from (l, b), taken a class ahead
+    // of the slots it describes -- cptr -> chunk offsets -> slots was a chain of three round trips in front of every class
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4* cd = reinterpret_cast<const i32x4*>(cdesc);
+    TriPre<TRI_PFMAX> nxt;
+    int nlo = 0, nhi = 0;
+    i32x4 dn = cd[(size_t)0 * nb + b];                       // descriptor of class 0 ...
+    auto fetch_first = [&](int l) {   // this solver's first chunk of class l, from the descriptor at hand; then the descriptor of l + 1
+        nlo = nhi = 0;
+        if (l < nlev) {
+            nlo = dn[0] & TRI_POS_MASK; nhi = dn[1];
+            if (nhi > nlo) tri_fetch<L, TRI_PFMAX>(B, nxt, nlo, nhi, (int)((unsigned)dn[0] >> 28), dn[2], rloc, sl);
+            if (l + 1 < nlev) dn = cd[(size_t)(l + 1) * nb + b];
+        }
+    };
+    auto run = [&](const TriPre<TRI_PFMAX>& r, int lo, int hi) {
+        const int p = lo + rloc;
+        if (p < hi) {
+            const double un = tri_row<L, TRI_PFMAX, true>(a, r, p, sl, ldw);
+            if (sl == L - 1) {
+                if (same_xcd) a.W[p] = un;
+                else __hip_atomic_store((gu64*)(a.W + p), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    fetch_first(0);
+    for (int l = 0; l < nlev; ++l) {
+        if (nhelp && b == 0 && tid == 0) __hip_atomic_store((gu32*)(sync + 2), (unsigned)cptr[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const TriPre<TRI_PFMAX> cur = nxt;
+        run(cur, nlo, nhi);
+        for (int c = cptr[l] + b + nb; c < cptr[l + 1]; c += nb) {   // classes of more chunks than solvers: fetched on the spot
+            TriPre<TRI_PFMAX> r;
+            const int d0 = a.lptr[c], lo = d0 & TRI_POS_MASK, hi = a.lptr[c + 1] & TRI_POS_MASK;
+            tri_fetch<L, TRI_PFMAX>(B, r, lo, hi, (int)((unsigned)d0 >> 28), a.sbase[c], rloc, sl);
+            run(r, lo, hi);
+        }
+        // drain the stores, arrive; the next class's fetch travels during the wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fetch_first(l + 1);
+        __syncthreads();
+        ++round;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(g_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)nb * round;
+            int ok = 1;
+            unsigned spins = 0;
+            unsigned long long t0 = 0;
+            while (__hip_atomic_load(g_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if ((++spins & 1023u) == 0u) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (!t0) t0 = now;
+                    else if (now - t0 > 200000000ull) {
+                        __hip_atomic_store(g_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            if (__hip_atomic_load(g_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) return;
+    }
+    // u_i <- W_p, a slice per solver (every W is final and visible: the last barrier)
+    for (int p = b * TRI_BLOCK + tid; p < nseq; p += nb * TRI_BLOCK) a.u[a.order[p]] = ldw(p);
 }
 
 }  // namespace fasp

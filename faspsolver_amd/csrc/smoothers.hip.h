@@ -78,6 +78,24 @@ static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLeve
     return FASP_SUCCESS;
 }
 
+// Error word of the cluster form of the triangular solve (a solver workgroup that was not resident: bounded spins, then this
+// word).  It is copied to pinned host memory behind every launch and looked at -- without waiting -- before the next sweep and
+// where a solve synchronises anyway: a broken cluster fails the solve loudly, and the process goes on without that form.
+static unsigned* g_seq_herr = nullptr;
+static bool seq_err_pending() { return g_seq_herr && *g_seq_herr != 0u; }
+static void seq_err_watch(const unsigned* d_err)
+{
+    if (!g_seq_herr && hipHostMalloc((void**)&g_seq_herr, 64, hipHostMallocDefault) != hipSuccess) { g_seq_herr = nullptr; return; }
+    if (*g_seq_herr == 0u) (void)hipMemcpyAsync(g_seq_herr, d_err, sizeof(unsigned), hipMemcpyDeviceToHost, g_ctx.stream);
+}
+static int seq_err_check()   // after a stream synchronisation
+{
+    if (!seq_err_pending()) return FASP_SUCCESS;
+    std::fprintf(stderr, "### ERROR: fasp_hip: a workgroup of the clustered triangular solve (sequential smoothers) was not resident; "
+                         "fasp_hip_tune(\"seq_cluster\", 0) selects one launch per dependency class\n");
+    return ERROR_MISC;
+}
+
 // ---------------------------------------------------------------------------
 // The split form of a sequential sweep (seq_split.hip.h): class-major numbering of the swept rows by TRUE dependencies
 // only (row i after the coupled rows the sweep visits before it), the lower part in slot storage, the rest as a CSR
@@ -256,7 +274,23 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     if ((st = split_upload(S, &S.d_dr, dr)) < 0) return st;
     if ((st = split_upload(S, &S.d_tr, tr)) < 0) return st;
     if ((st = split_upload(S, &S.d_W, std::vector<double>((size_t)ns, 0.0))) < 0) return st;
-    if ((st = split_upload(S, &S.d_prog, std::vector<unsigned>(4, 0u))) < 0) return st;
+    if ((st = split_upload(S, &S.d_prog, std::vector<unsigned>(64, 0u))) < 0) return st;   // [0] progress (one-workgroup form); cluster form: [4] arrivals, [5] error, [6] progress, [20 + b] XCC ids
+    if ((st = split_upload(S, &S.d_cptr, S.cptr)) < 0) return st;
+    {   // cluster form: the first chunk of every (class, solver)
+        int maxw = 0;
+        for (size_t l = 0; l + 1 < S.cptr.size(); ++l) maxw = std::max(maxw, S.cptr[l + 1] - S.cptr[l]);
+        const int cnb = std::min(16, std::max(1, maxw));
+        std::vector<int> cdesc(4 * (size_t)cnb * std::max<size_t>(S.cptr.size() - 1, 1), 0);
+        for (size_t l = 0; l + 1 < S.cptr.size(); ++l)
+            for (int b = 0; b < cnb; ++b) {
+                const int c = S.cptr[l] + b;
+                int* d = &cdesc[4 * (l * cnb + b)];
+                if (c < S.cptr[l + 1]) { d[0] = S.ptr[c]; d[1] = lo_of[c + 1]; d[2] = sbase[c]; }
+            }
+        if ((st = split_upload(S, &S.d_cdesc, cdesc)) < 0) return st;
+    }
+    S.maxw = 0;
+    for (size_t l = 0; l + 1 < S.cptr.size(); ++l) S.maxw = std::max(S.maxw, S.cptr[l + 1] - S.cptr[l]);
     S.nfar_chunks = 0;
     for (int c = 0; c < nchunk; ++c) {
         bool any = false;
@@ -376,6 +410,33 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
         }
     }
     const double cost_block = cap ? S.block_us + 1.5 * S.nfar_chunks : std::max(S.block_us, 2.2 * nchunk), cost_launch = (double)nlev * 3.2 + 0.15 * (nchunk - nlev);
+    // the cluster form (k_tri_cluster): a few workgroups on one XCD, a barrier per class instead of a launch: 2.4 us per class
+    // measured (0.7 the barrier round itself, the rest the chain through the L2 and the drained stores), 0.4 us per further
+    // chunk of a solver
+    const int  cl_nb = std::min(16, std::max(1, S.maxw));
+    const double cost_cluster = (double)nlev * 2.4 + 0.4 * std::max(0, (nchunk - nlev * cl_nb + cl_nb - 1) / cl_nb);   // (measured on P7(128): 2.4-2.5 us per class)
+    static bool cluster_disabled = false;
+    if (seq_err_pending()) { cluster_disabled = true; return ERROR_MISC; }
+    if (g_tune.seq_cluster && !cluster_disabled && !comm_shares_devices() && nlev >= 8 && cl_nb >= 2 &&
+        cost_cluster < cost_launch && (!g_tune.seq_block || cost_cluster < cost_block || lds_ptr > LDS_CAP)) {
+        const int nhelp = std::max(0, std::max(g_tune.seq_help, 8));   // (several compute units to stream what a cluster consumes)
+        const double chunk_bytes = nchunk ? (12.0 * S.nslot + 40.0 * ns) / nchunk : 1.0;
+        const int ahead = (int)std::min(4096.0, std::max(2.0 * cl_nb, 1.5e6 / chunk_bytes));
+        unsigned* sync = S.d_prog + 4;
+#define TRIC_LAUNCH(LL) hipLaunchKernelGGL((k_tri_cluster<LL>), dim3(8 * (cl_nb + nhelp)), dim3(TRI_BLOCK), 0, g_ctx.stream, ta, (const int*)S.d_cptr, (const int*)S.d_cdesc, nlev, ns, cl_nb, nhelp, ahead, sync)
+        switch (L) {
+            case 1: TRIC_LAUNCH(1); break;
+            case 2: TRIC_LAUNCH(2); break;
+            case 4: TRIC_LAUNCH(4); break;
+            case 8: TRIC_LAUNCH(8); break;
+            case 16: TRIC_LAUNCH(16); break;
+            case 32: TRIC_LAUNCH(32); break;
+            default: TRIC_LAUNCH(64); break;
+        }
+#undef TRIC_LAUNCH
+        seq_err_watch(sync + 1);
+        return FASP_SUCCESS;
+    }
     if (g_tune.seq_block && nlev >= 8 && lds_ptr <= LDS_CAP && cost_block < cost_launch) {
         const size_t dyn = (cap ? (size_t)cap * 8 : 0) + lds_ptr;
         // helper workgroups that read ahead of the solver into the XCD's L2 (tri_prefetch): ~1.5 MB ahead, at least three groups of chunks

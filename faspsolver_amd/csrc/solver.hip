@@ -651,6 +651,7 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
         }
     }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
+    if (seq_err_check() < 0) return ERROR_MISC;   // a broken cluster of the sequential smoothers (smoothers.hip.h)
     const double t_solve = wall_seconds() - t0;
 
     if (stats) {
@@ -793,7 +794,7 @@ int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z)
     if (st < 0) return st;
     HIPCK(hipMemcpyAsync(z, dz, sizeof(double) * m, hipMemcpyDeviceToHost, g_ctx.stream));
     HIPCK(hipStreamSynchronize(g_ctx.stream));
-    return FASP_SUCCESS;
+    return seq_err_check();
 }
 
 // ---- row-partition inspection (host only; used by the CPU-side distributed tests) ----
@@ -2024,6 +2025,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_ulds")) g_tune.seq_ulds = value;
     else if (!std::strcmp(key, "lazy_coarse")) g_tune.lazy_coarse = value;
     else if (!std::strcmp(key, "seq_help")) g_tune.seq_help = value;
+    else if (!std::strcmp(key, "seq_cluster")) g_tune.seq_cluster = value;
     else if (!std::strcmp(key, "seq_ring")) g_tune.seq_ring = value;
     else if (!std::strcmp(key, "xtile")) g_tune.xtile = value;
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;

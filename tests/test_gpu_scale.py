@@ -214,8 +214,9 @@ def _gs_params(smoother, order, w=1.0):
                          ids=["GS-CF", "GS-natural", "SOR-natural"])
 def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
     """The triangular solve of a sequential sweep (seq_split.hip.h) runs in one workgroup where the dependency classes are
-    narrow (k_tri_block: a barrier per chunk, the new values in an LDS ring -- or through the L2 with the ring switched off)
-    and as one launch per class elsewhere (k_tri_level).  Same slots, same row arithmetic: identical bits."""
+    narrow (k_tri_block: a barrier per chunk, the new values in an LDS ring -- or through the L2 with the ring switched off),
+    in a cluster of workgroups on one XCD where they are wide (k_tri_cluster: a barrier among the workgroups per class), or
+    as one launch per class (k_tri_level).  Same slots, same row arithmetic: identical bits."""
     n = 40
     ia, ja, a, f, ue = fa.poisson7pt(n)
     itp, amgp = _gs_params(smoother, order, w)
@@ -224,13 +225,13 @@ def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
     r = np.random.default_rng(11).standard_normal(len(f))
     try:
         out = []
-        for sb, ring in ((1, 1), (0, 1), (1, 0)):
-            L.fasp_hip_tune(b"seq_block", sb); L.fasp_hip_tune(b"seq_ulds", ring)
+        for sb, ring, cl in ((1, 1, 1), (0, 1, 0), (1, 0, 0), (0, 1, 1)):
+            L.fasp_hip_tune(b"seq_block", sb); L.fasp_hip_tune(b"seq_ulds", ring); L.fasp_hip_tune(b"seq_cluster", cl)
             out.append(H.precond(r))
     finally:
-        L.fasp_hip_tune(b"seq_block", 1); L.fasp_hip_tune(b"seq_ulds", 1)
-    assert np.array_equal(out[0], out[1])
-    assert np.array_equal(out[0], out[2])
+        L.fasp_hip_tune(b"seq_block", 1); L.fasp_hip_tune(b"seq_ulds", 1); L.fasp_hip_tune(b"seq_cluster", 1)
+    for o in out[1:]:
+        assert np.array_equal(out[0], o)
     H.close()
 
 
