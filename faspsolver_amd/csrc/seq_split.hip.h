@@ -444,11 +444,21 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_cluster(TriArgs a, const int*
             }
         }
     };
+#ifdef TC_TIMING
+    unsigned long long tct[5] = {0, 0, 0, 0, 0}, tcl = __builtin_amdgcn_s_memrealtime();
+#define TCT(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tct[k] += n_ - tcl; tcl = n_; } while (0)
+#else
+#define TCT(k)
+#endif
     fetch_first(0);
     for (int l = 0; l < nlev; ++l) {
+        TCT(4);
         if (nhelp && b == 0 && tid == 0) __hip_atomic_store((gu32*)(sync + 2), (unsigned)cptr[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const TriPre<TRI_PFMAX> cur = nxt;
+        if (nhi > nlo && rloc < nhi - nlo) { asm volatile("" :: "v"(cur.c[0]), "v"(cur.row)); }
+        TCT(0);
         run(cur, nlo, nhi);
+        TCT(1);
         for (int c = cptr[l] + b + nb; c < cptr[l + 1]; c += nb) {   // classes of more chunks than solvers: fetched on the spot
             TriPre<TRI_PFMAX> r;
             const int d0 = a.lptr[c], lo = d0 & TRI_POS_MASK, hi = a.lptr[c + 1] & TRI_POS_MASK;
@@ -457,6 +467,7 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_cluster(TriArgs a, const int*
         }
         // drain the stores, arrive; the next class's fetch travels during the wait
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TCT(2);
         fetch_first(l + 1);
         __syncthreads();
         ++round;
@@ -481,8 +492,12 @@ __global__ __launch_bounds__(TRI_BLOCK) void k_tri_cluster(TriArgs a, const int*
             s_ok = ok;
         }
         __syncthreads();
+        TCT(3);
         if (!s_ok) return;
     }
+#ifdef TC_TIMING
+    if (tid == 0 && b == 0 && nlev > 100) printf("[tri_cluster] %d classes, %d solvers: wait for slots %.2f, row chain %.2f, drain %.2f, barrier %.2f, rest %.2f us per class\n", nlev, nb, tct[0] * 0.01 / nlev, tct[1] * 0.01 / nlev, tct[2] * 0.01 / nlev, tct[3] * 0.01 / nlev, tct[4] * 0.01 / nlev);
+#endif
     // u_i <- W_p, a slice per solver (every W is final and visible: the last barrier)
     for (int p = b * TRI_BLOCK + tid; p < nseq; p += nb * TRI_BLOCK) a.u[a.order[p]] = ldw(p);
 }
