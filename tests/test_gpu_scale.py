@@ -362,14 +362,17 @@ def test_xtile_kernel_is_bit_identical_to_wstream2(gpu, var):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,fixture", [(64, "p7_sweeps.npz"), (128, "p7_sweeps_128.npz")], ids=["64", "128"])
 @pytest.mark.parametrize("tag,smoother,order,w", [("gscf", T.SMOOTHER_GS, 1, 1.0), ("gsnat", T.SMOOTHER_GS, 0, 1.0), ("sor11", T.SMOOTHER_SOR, 0, 1.1)])
-def test_sequential_smoothers_match_reference_64(gpu, tag, smoother, order, w):
-    """The parity mode of the sequential smoothers at 64^3 against the REFERENCE's own run (tests/golden/p7_sweeps.npz,
-    tools/gen_golden_sweeps.py): Gauss-Seidel in C/F order (the reference's defaults), in natural order, SOR(1.1).
-    At this size the deep levels run as one-workgroup triangular solves with the new values in an LDS ring, the upper
-    ones as one launch per dependency class: equal iteration counts, residual histories to 1e-8, |relres - ref| <= 1e-10."""
-    z = np.load(os.path.join(G, "p7_sweeps.npz"))
-    ia, ja, a, f, ue = fa.poisson7pt(64)
+def test_sequential_smoothers_match_reference_64(gpu, tag, smoother, order, w, n, fixture):
+    """The parity mode of the sequential smoothers at 64^3 and 128^3 against the REFERENCE's own runs
+    (tests/golden/p7_sweeps*.npz, tools/gen_golden_sweeps.py): Gauss-Seidel in C/F order (the reference's defaults), in
+    natural order, SOR(1.1).  At 64^3 the deep levels run as one-workgroup triangular solves with the new values in an LDS
+    ring, the upper ones as one launch per dependency class; at 128^3 levels 0-2 have the wide classes that take the cluster
+    form, far entries and the helper workgroups (csrc/seq_split.hip.h): equal iteration counts, residual histories to 1e-8,
+    |relres - ref| <= 1e-10."""
+    z = np.load(os.path.join(G, fixture))
+    ia, ja, a, f, ue = fa.poisson7pt(n)
     itp, amgp = _gs_params(smoother, order, w)
     H = fa.AMG(ia, ja, a, amgp)
     st, x, hist, stats = H.solve(f, itp)
