@@ -226,3 +226,103 @@ def test_block_rows_partitioned_match_oracle(world, n, min_rows, solver, cycle):
         assert abs(relres - rr_ref) <= 1e-10
         lo, hi = info["row0"] * nb, (info["row0"] + info["nloc"]) * nb
         assert np.max(np.abs(xloc - x_ref[lo:hi])) <= 1e-8 * np.max(np.abs(x_ref))
+
+
+# --- the partitioned path at the size of the metric (round 4) ------------------------------------------
+def _p7_256_worker(rank, world, name, q):
+    try:
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import time
+        import faspsolver_amd as fa
+        from faspsolver_amd import _types as T
+        L = fa.lib()
+        assert L.fasp_hip_set_device(0) == 0
+        assert L.fasp_hip_comm_init_shm(rank, world, name.encode()) == 0
+        n = 256
+        itp = fa.param_solver_init(); itp.tol = 1e-8; itp.maxit = 500; itp.print_level = 0
+        amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
+        seg = name + "_hier"
+        flag = "/dev/shm/" + seg + ".ready"
+        ia, ja, a, f, ue = fa.poisson7pt(n)
+        if rank == 0:   # ONE host setup: rank 0 publishes the hierarchy, the others map it (bench_dist.py's sequence)
+            H = fa.AMG(ia, ja, a, amgp, host_only=True)
+            H.publish(seg)
+            open(flag, "w").close()
+        else:
+            del ia, ja, a
+            t0 = time.time()
+            while not os.path.exists(flag):
+                assert time.time() - t0 < 600, "rank 0 never published"
+                time.sleep(0.05)
+            H = fa.AMG.attach(seg)
+        H.upload()
+        H.set_rhs(f)
+        infos = [H.dist_info(l) for l in range(H.num_levels)]
+        wins = [H.dist_list(l, 5).tolist() for l in range(H.num_levels)]
+        kinds = [H.kernel_info(l, 0)[0] for l in range(2)]
+        st, hist, stats = H.solve_resident(itp)
+        x = H.get_solution()
+        i0 = infos[0]
+        lo, hi = i0["row0"], i0["row0"] + i0["nloc"]
+        err = float(np.max(np.abs(x[lo:hi] - ue[lo:hi])))
+        step = max(1, len(x) // 4096)
+        idx = np.arange(0, len(x), step)
+        own = (idx >= lo) & (idx < hi)
+        H.close()
+        L.fasp_hip_comm_finalize()
+        if rank == 0:
+            fa.AMG.unpublish(seg)
+            try:
+                os.remove(flag)
+            except OSError:
+                pass
+        q.put((rank, "ok", st, stats.relres, np.asarray(hist), infos, wins, kinds, err, (own, x[idx[own]])))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+
+
+@pytest.mark.skipif(os.environ.get("FASP_TEST_DIST256") == "0", reason="switched off (FASP_TEST_DIST256=0)")
+def test_partitioned_p7_256_two_ranks_matches_reference(gpu):
+    """BASELINE.json's metric workload through the ROW-PARTITIONED path (config 4's code at config 2's size): P7(256) cut
+    into two z-slabs, two processes sharing the box's one GPU over the shared-memory transport, one published host
+    setup.  Bars: the reference's 14 iterations, |relres - 6.3426837114e-09| <= 1e-10 (tests/golden/p7_scale.npz, from
+    BASELINE.md section 2), residual history to 1e-8, levels 0-3 distributed, interior row windows in use on them (halo
+    beside the interior rows), the coded level-0/1 kernels in their row-window form, every rank's rows of the solution
+    against the generator's exact solution and the reference's sample."""
+    import multiprocessing as mp
+    z = np.load(os.path.join(ROOT, "tests", "golden", "p7_scale.npz"))
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"fasp_p7_256_{os.getpid()}"
+    procs = [ctx.Process(target=_p7_256_worker, args=(r, world, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=900) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.terminate()
+    for r in res:
+        assert r[1] == "ok", r[2]
+    ref_hist = z["n256_hist"] if "n256_hist" in z.files else None
+    for rank, _, st, relres, hist, infos, wins, kinds, err, (own, xs) in res:
+        assert st == int(z["n256_iters"]) == 14
+        assert abs(relres - float(z["n256_relres"])) <= 1e-10
+        assert infos[0]["nranks"] == 2 and infos[0]["first_replicated"] >= 4      # levels 0-3 are row-partitioned
+        for l in range(4):
+            assert infos[l]["replicated"] == 0 and 0 < infos[l]["nloc"] < infos[l]["nglobal"] and infos[l]["nghost"] > 0
+            assert wins[l][1] > wins[l][0] >= 0 and wins[l][1] - wins[l][0] >= infos[l]["nloc"] // 2   # interior window
+        assert infos[0]["nloc"] == 256 ** 3 // 2 and infos[0]["nghost"] == 256 ** 2
+        assert kinds == [6, 6]            # the coded scalar-pattern sweep, in row windows
+        assert err < 2e-5                 # discretisation error of the generator's exact solution
+        if "n256_xsample" in z.files:
+            ref = z["n256_xsample"][own]
+            assert np.abs(xs - ref).max() <= 1e-9 * np.abs(z["n256_xsample"]).max()
+        if ref_hist is not None:
+            h = np.concatenate([hist[:-2], hist[-1:]])
+            assert len(h) == len(ref_hist) and np.allclose(h[:-1], ref_hist[:-1], rtol=1e-8, atol=0.0)
+    assert np.array_equal(res[0][4], res[1][4])   # bit-identical replicated scalars on both ranks

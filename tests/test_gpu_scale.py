@@ -452,10 +452,17 @@ def test_config5_full_size_matches_reference(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("FASP_TEST_512") != "1", reason="opt-in (FASP_TEST_512=1): 2 minutes of host setup, 50 GB of host memory")
+@pytest.mark.skipif(os.environ.get("FASP_TEST_512") == "0", reason="switched off (FASP_TEST_512=0): 2 minutes of host setup, 50 GB of host memory")
 def test_config4_p7_512_on_one_gpu(gpu):
     """Config 4's system on ONE GPU: P7(512), 134 M DOF -- 31 iterations (the oracle's count on the same hierarchy,
-    profiles/r03_check512_single_gpu.txt), the exact solution of the generator to discretisation-free 1e-5."""
+    profiles/r03_check512_single_gpu.txt), the exact solution of the generator to discretisation-free 1e-5.
+    Runs by default (round 4); FASP_TEST_512=0 switches it off on hosts with less than ~60 GB of memory."""
+    try:
+        avail_kb = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1])
+    except Exception:
+        avail_kb = 1 << 40
+    if avail_kb < 70 * (1 << 20):
+        pytest.skip(f"P7(512) needs ~55 GB of host memory for the setup, {avail_kb >> 20} GB available")
     n = 512
     ia, ja, a, f, ue = fa.poisson7pt(n)
     itp, amgp = _params()
