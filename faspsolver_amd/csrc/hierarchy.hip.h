@@ -29,11 +29,12 @@ struct DevLevel {
     // 1 descending, 2 ascending C rows, 3 ascending F rows, 4 descending from row n-2
     struct Sched {
         bool built = false, multicolor = false; int* d_order = nullptr; int* d_ptr = nullptr; std::vector<int> ptr;
-        // split form (seq_split.hip.h): lower part in slots + tail CSR, the rest as a CSR, per-position diagonal / old value / W
-        int ns = 0, L = 1, LR = 1, reach = 0, pfmax = 1, ringcap = 0, nfar_chunks = 0; long long nfar = 0; bool nolower = false; long long ntail = 0, nslot = 0; double block_us = 0.0;
-        std::vector<int> cptr;   // split form: class -> first chunk (ptr holds the chunk descriptors)
-        int* d_sbase = nullptr; int* d_sc = nullptr; double* d_sv = nullptr; int* d_tia = nullptr; int* d_tja = nullptr; double* d_tval = nullptr;
-        int* d_ria = nullptr; int* d_rja = nullptr; double* d_rval = nullptr; double* d_rec = nullptr; double* d_dr = nullptr; int* d_tr = nullptr; double* d_W = nullptr; unsigned* d_prog = nullptr; int* d_cptr = nullptr; int* d_cdesc = nullptr; int maxw = 0;
+        // split form (seq_split.hip.h): strips / chunks / slots of the lower part, tail CSR, the rest as a CSR, per-position records and W
+        int ns = 0, L = 1, LR = 1, pfmax = 1, nstrips = 0, nchunk = 0, maxent = 0; bool nolower = false, flow_ok = false, rowlevels = false; long long ntail = 0, nghost = 0, slot_bytes = 0;
+        std::vector<int> cptr;   // split form: dependency class -> first entry of d_lchunks (k_tri_level)
+        void* d_strips = nullptr; void* d_chunks = nullptr; unsigned char* d_slots = nullptr; int* d_gpos = nullptr; int* d_cstrip = nullptr; int* d_lchunks = nullptr;
+        int* d_tia = nullptr; int* d_tja = nullptr; double* d_tval = nullptr;
+        int* d_ria = nullptr; int* d_rja = nullptr; double* d_rval = nullptr; double* d_rec = nullptr; double* d_dr = nullptr; int* d_tr = nullptr; double* d_W = nullptr; unsigned* d_prog = nullptr;
         std::vector<void*> owned;   // device arrays of the split form (d_order and d_ptr among them)
         void release()
         {

@@ -78,227 +78,288 @@ static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLeve
     return FASP_SUCCESS;
 }
 
-// Error word of the cluster form of the triangular solve (a solver workgroup that was not resident: bounded spins, then this
-// word).  It is copied to pinned host memory behind every launch and looked at -- without waiting -- before the next sweep and
-// where a solve synchronises anyway: a broken cluster fails the solve loudly, and the process goes on without that form.
+// Error word of the dataflow form of the triangular solve (a waiter that spun for two seconds: seq_split.hip.h).  It is copied
+// to pinned host memory behind every launch and looked at -- without waiting -- before the next sweep of that form and where
+// a solve synchronises anyway: the solve in which it happened fails loudly, the process goes on with one launch per
+// dependency class (k_tri_level).
 static unsigned* g_seq_herr = nullptr;
+static bool      g_flow_disabled = false;
 static bool seq_err_pending() { return g_seq_herr && *g_seq_herr != 0u; }
 static void seq_err_watch(const unsigned* d_err)
 {
-    if (!g_seq_herr && hipHostMalloc((void**)&g_seq_herr, 64, hipHostMallocDefault) != hipSuccess) { g_seq_herr = nullptr; return; }
+    if (!g_seq_herr) {
+        if (hipHostMalloc((void**)&g_seq_herr, 64, hipHostMallocDefault) != hipSuccess) { g_seq_herr = nullptr; return; }
+        std::memset(g_seq_herr, 0, 64);
+    }
     if (*g_seq_herr == 0u) (void)hipMemcpyAsync(g_seq_herr, d_err, sizeof(unsigned), hipMemcpyDeviceToHost, g_ctx.stream);
 }
-static int seq_err_check()   // after a stream synchronisation
+static int seq_err_check()   // after a stream synchronisation (or between sweeps: whatever has arrived)
 {
     if (!seq_err_pending()) return FASP_SUCCESS;
-    std::fprintf(stderr, "### ERROR: fasp_hip: a workgroup of the clustered triangular solve (sequential smoothers) was not resident; "
-                         "fasp_hip_tune(\"seq_cluster\", 0) selects one launch per dependency class\n");
+    std::fprintf(stderr, "### ERROR: fasp_hip: the dataflow triangular solve of the sequential smoothers timed out; this solve fails, "
+                         "later sweeps run as one launch per dependency class (fasp_hip_tune(\"seq_flow\", 1) re-enables the dataflow form)\n");
+    g_flow_disabled = true;
+    *g_seq_herr = 0u;   // (the device word is reset by pass (1) of the next sweep)
     return ERROR_MISC;
 }
 
 // ---------------------------------------------------------------------------
-// The split form of a sequential sweep (seq_split.hip.h): class-major numbering of the swept rows by TRUE dependencies
-// only (row i after the coupled rows the sweep visits before it), the lower part in slot storage, the rest as a CSR
-// in sweep numbering.  Built once per (level, sweep kind) on first use.
+// The split form of a sequential sweep (seq_split.hip.h), built once per (level, sweep kind) on first use: the sweep
+// sequence cut into strips, every strip's rows ordered by dependency class (TRUE dependencies only: row i after the
+// coupled rows the sweep visits before it) and cut into chunks of 64 / L rows, the lower entries in slot storage with
+// LDS indices as columns, the strip's ghost list, the rest as a CSR in position order.
 // ---------------------------------------------------------------------------
 constexpr int TRI_PF = 4;   // slot rounds the lanes-per-row choice aims at (TRI_PFMAX = 8 is what a chunk can store)
 template <class T>
-static int split_upload(DevLevel::Sched& S, T** dst, const std::vector<T>& v)
+static int split_upload(DevLevel::Sched& S, T** dst, const T* v, size_t n)
 {
     *dst = nullptr;
-    HIPCK(hipMalloc((void**)dst, sizeof(T) * std::max<size_t>(v.size(), 1)));
+    HIPCK(hipMalloc((void**)dst, sizeof(T) * std::max<size_t>(n, 1)));
     S.owned.push_back(*dst);
-    if (!v.empty()) HIPCK(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    if (n) HIPCK(hipMemcpy(*dst, v, sizeof(T) * n, hipMemcpyHostToDevice));
     return FASP_SUCCESS;
 }
+template <class T>
+static int split_upload(DevLevel::Sched& S, T** dst, const std::vector<T>& v) { return split_upload(S, dst, v.data(), v.size()); }
+
 static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::Sched& S)
 {
-    HostThreads host_team;   // (bounded OpenMP team for the row-parallel loops below; the dependency levels themselves are a sequential pass)
+    HostThreads host_team;   // (bounded OpenMP team for the row-parallel loops below; the dependency pass itself is sequential)
     const int n = A.row, ns = (int)seq.size();
-    std::vector<int> pos(n, -1), lev(ns, 0);
+    Buf<int> pos((size_t)std::max(n, 1));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) pos[i] = -1;
+#pragma omp parallel for schedule(static)
     for (int q = 0; q < ns; ++q) pos[seq[q]] = q;
+    // lanes per row from a sample-free pass over the row lengths would need the lower counts; they come out of the dependency pass
+    // below, which therefore runs first with nothing but the matrix: class (dependency level) and number of lower entries per row
+    Buf<int> lev((size_t)std::max(ns, 1)), nlow((size_t)std::max(ns, 1)), nrest((size_t)std::max(ns, 1));
     int nlev = ns > 0 ? 1 : 0;
-    std::vector<int> nlow(ns, 0);
-    auto is_lower = [&](int i, int q, int j) { return j != i && j < n && pos[j] >= 0 && pos[j] < q; };
+    long long lower_total = 0;
     for (int q = 0; q < ns; ++q) {
         const int i = seq[q];
-        int l = 0, c = 0;
-        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
-            if (is_lower(i, q, A.ja[k])) { l = std::max(l, lev[pos[A.ja[k]]]); ++c; }
-        lev[q] = l + 1; nlow[q] = c;
+        int l = 0, c = 0, dg = 0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            const int j = A.ja[k];
+            if (j == i) { ++dg; continue; }
+            if (j < n) { const int pj = pos[j]; if ((unsigned)pj < (unsigned)q) { l = std::max(l, lev[pj]); ++c; } }
+        }
+        lev[q] = l + 1; nlow[q] = c; nrest[q] = A.ia[i + 1] - A.ia[i] - c - dg;
         nlev = std::max(nlev, l + 1);
+        lower_total += c;
     }
-    std::vector<int> cls(nlev + 1, 0);
-    for (int q = 0; q < ns; ++q) cls[lev[q]]++;
-    for (int l = 0; l < nlev; ++l) cls[l + 1] += cls[l];
-    std::vector<int> cur(cls.begin(), cls.end() - 1), newpos(ns), order(ns), len(ns);
-    for (int q = 0; q < ns; ++q) { const int p = cur[lev[q] - 1]++; newpos[q] = p; order[p] = seq[q]; len[p] = nlow[q]; }
     // lanes per row of the triangular part: TRI_PF * L slots cover the lower entries of 90 % of the rows
-    long long lower_total = 0;
     int len90 = 0;
     {
         std::vector<long long> hist(258, 0);
-        for (int q = 0; q < ns; ++q) { hist[std::min(nlow[q], 257)]++; lower_total += nlow[q]; }
+        for (int q = 0; q < ns; ++q) hist[std::min(nlow[q], 257)]++;
         long long acc = 0;
         for (int v = 0; v < 258; ++v) { acc += hist[v]; if (acc * 10 >= (long long)ns * 9) { len90 = v; break; } }
     }
-    // wide classes (levels 1-2 of a 3-D problem: hundreds of rows each) keep every wavefront of the solving workgroup busy, and
-    // what a chunk costs there is instructions, per LANE mostly: half the lanes with twice the rounds is less work per row.
-    // Narrow classes (a few rows: the deep levels) are a latency chain: more lanes, shorter chains.
-    const bool wide = nlev > 0 && ns / nlev >= 128;   // (measured at 128^3: classes of 190 and 1 700 rows gain 28-33 %, of 33 and 109 rows lose)
+    // wide classes (levels 1-2 of a 3-D problem: hundreds of rows each): what a chunk costs there is instructions, per LANE
+    // mostly: half the lanes with twice the rounds is less work per row.  Narrow classes (a few rows: the deep levels) are a
+    // latency chain: more lanes, shorter chains.
+    const bool wide = nlev > 0 && ns / nlev >= 128;
     int L = 1;
     while (L < 64 && (wide ? TRI_PFMAX : TRI_PF) * L < len90) L *= 2;
     if (g_tune.seq_lanes > 0) { L = 1; while (L < 64 && L < g_tune.seq_lanes) L *= 2; }
-    // chunks: the classes cut into rounds of a TRI_BLOCK-thread workgroup; slots per lane = what the chunk's longest row needs
-    const int rpb = TRI_BLOCK / L;
-    std::vector<int> lo_of(1, 0);
-    S.cptr.assign(1, 0);
-    for (int l = 0; l < nlev; ++l) {
-        for (int lo = cls[l]; lo < cls[l + 1]; lo += rpb) lo_of.push_back(std::min(lo + rpb, cls[l + 1]));
-        S.cptr.push_back((int)lo_of.size() - 1);
-    }
-    const int nchunk = (int)lo_of.size() - 1;
-    if (ns >= TRI_FAR_BIT) return ERROR_INPUT_PAR;
-    std::vector<int> chunk_of(ns), pf_of(nchunk, 0), sbase(nchunk + 1, 0);
-    for (int c = 0; c < nchunk; ++c)
-        for (int p = lo_of[c]; p < lo_of[c + 1]; ++p) chunk_of[p] = c;
-    // The LDS ring the one-workgroup solve keeps the new values in covers `ringcap` positions behind the end of the chunk
-    // at work.  A lower entry further back is FAR: it goes to the row's tail, flagged, and is read from W in memory
-    // (written there dozens of chunks -- several drained memory counters -- earlier).  The ring is the largest power of
-    // two that fits beside the chunk descriptors; no far entries where it would be shorter than four groups of chunks.
-    int ringcap = 0;
-    for (int c = 16384; c >= 1024 && !ringcap; c >>= 1)
-        if (c <= g_tune.seq_ring && (size_t)c * 8 + 2 * sizeof(int) * (size_t)(nchunk + 1) <= TRI_LDS_CAP) ringcap = c;   // (seq_ring: a smaller ring, so that tests meet far entries on small grids)
-    if (ringcap < 16 * rpb) ringcap = 0;
-    auto is_far = [&](int p, int cpos) { return ringcap > 0 && lo_of[chunk_of[p] + 1] - cpos > ringcap; };
-    std::vector<int> nfar_of(ns, 0);
-    long long nfar = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nfar)
-    for (int q = 0; q < ns; ++q) {
-        const int i = seq[q], p = newpos[q];
-        int f = 0;
-        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
-            if (is_lower(i, q, A.ja[k]) && is_far(p, newpos[pos[A.ja[k]]])) ++f;
-        nfar_of[p] = f; nfar += f;
-    }
-    if (nfar * 50 > lower_total) {   // more than a few stragglers: not a schedule for the ring (seq_sweep then weighs the L2 form against launches)
-        ringcap = 0; nfar = 0;
-        std::fill(nfar_of.begin(), nfar_of.end(), 0);
-    }
-    for (int p = 0; p < ns; ++p) len[p] -= nfar_of[p];   // len: NEAR lower entries from here on
-    S.ptr.assign(nchunk + 1, 0);
-    long long nslot = 0;
-    int pfmax = 1;
-    double bytes_us = 0.0;   // the cost model of seq_sweep: microseconds of one workgroup's memory traffic
-    for (int c = 0; c < nchunk; ++c) {
-        int mx = 0;
-        for (int p = lo_of[c]; p < lo_of[c + 1]; ++p) mx = std::max(mx, len[p]);
-        pf_of[c] = lower_total == 0 ? 0 : std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));   // (at least one round: tri_fetch is branch-free; none at all for a sweep without lower entries: it never reaches the triangular kernels)
-        pfmax = std::max(pfmax, pf_of[c]);
-        sbase[c] = (int)nslot;
-        nslot += (long long)((pf_of[c] + 3) & ~3) * L * (lo_of[c + 1] - lo_of[c]);   // (packs of four rounds)
-        if (nslot > 0x0fffffffll) return ERROR_INPUT_PAR;   // (byte offsets of the slot values stay below 2^31)
-        S.ptr[c] = lo_of[c] | (pf_of[c] << 28);
-        const double bytes = (double)(lo_of[c + 1] - lo_of[c]) * L * (12.0 * ((pf_of[c] + 3) & ~3) + 32.0);
-        bytes_us += std::max(0.7, bytes / 25e3);   // (measured: one compute unit sustains ~25 GB/s of such fetches)
-    }
-    sbase[nchunk] = (int)nslot; S.ptr[nchunk] = ns;
-    std::vector<int>    sc((size_t)nslot), tia(ns + 1, 0), ria(ns + 1, 0);
-    std::vector<double> sv((size_t)nslot, 0.0), dr(2 * (size_t)ns, 0.0);
-    std::vector<int>    tr(2 * (size_t)ns, 0);
-#pragma omp parallel for schedule(dynamic, 64)
-    for (int c = 0; c < nchunk; ++c) {
-        const int lo = lo_of[c], hi = lo_of[c + 1];
-        for (int q = 0; q < ((pf_of[c] + 3) & ~3); ++q)
-            for (int p = lo; p < hi; ++p)
-                for (int sl = 0; sl < L; ++sl) sc[(size_t)sbase[c] + ((size_t)(q / 4) * L * (hi - lo) + (size_t)(p - lo) * L + sl) * 4 + (q % 4)] = p;
-    }
-    long long ntail = 0, nrest = 0;
-#pragma omp parallel for schedule(static) reduction(+ : ntail, nrest)
-    for (int q = 0; q < ns; ++q) {
-        const int i = seq[q], p = newpos[q];
-        const int t = std::max(0, len[p] - TRI_PFMAX * L) + nfar_of[p];   // near entries beyond the slots + far entries
-        tia[p + 1] = t; ntail += t;
-        int r = 0;
-        double dg = 0.0;
-        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
-            const int j = A.ja[k];
-            if (j == i) { dg = A.val[k]; continue; }   // the last diagonal hit, as the reference's loop leaves it
-            if (!is_lower(i, q, j)) ++r;
+    const int rpw = 64 / L;   // rows per chunk (one wavefront)
+    // ---- strips: contiguous ranges of the sweep sequence, closed when the slot bytes reach the target or the LDS is full
+    // (own rows + distinct earlier rows read + the constant).  Sequential: one more pass over the lower entries.
+    const long long target = std::max(16, g_tune.seq_strip_kb) * 1024ll;
+    std::vector<int> sq0(1, 0), sng;   // first sequence index of every strip (+ end), ghosts per strip
+    bool flow_ok = true;
+    {
+        Buf<int> gmark((size_t)std::max(ns, 1));
+#pragma omp parallel for schedule(static)
+        for (int q = 0; q < ns; ++q) gmark[q] = -1;
+        int sid = 0, rows = 0, ng = 0;
+        long long bytes = 0;
+        std::vector<int> fresh;
+        for (int q = 0; q < ns; ++q) {
+            const int i = seq[q];
+            const int q0 = sq0.back();
+            const long long rb = 40 + 16ll * L * (1 + (std::min(TRI_PFMAX, (nlow[q] + L - 1) / L) + 1) / 2) + 12ll * std::max(0, nlow[q] - TRI_PFMAX * L);
+            fresh.clear();
+            for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                const int j = A.ja[k];
+                if (j == i || j >= n) continue;
+                const int pj = pos[j];
+                if ((unsigned)pj < (unsigned)q0 && gmark[pj] != sid) { gmark[pj] = sid; fresh.push_back(pj); }
+            }
+            if (rows > 0 && (bytes + rb > target || rows + 1 + ng + (int)fresh.size() + 1 > FLOW_LDS_ENT || rows >= 0xffff)) {
+                // close the strip in front of this row; the row opens the next one: every earlier row it reads is a ghost now
+                sng.push_back(ng);
+                sq0.push_back(q);
+                ++sid; rows = 0; ng = 0; bytes = 0;
+                for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                    const int j = A.ja[k];
+                    if (j == i || j >= n) continue;
+                    const int pj = pos[j];
+                    if ((unsigned)pj < (unsigned)q && gmark[pj] != sid) { gmark[pj] = sid; ++ng; }
+                }
+            } else ng += (int)fresh.size();
+            if (1 + ng + 1 > FLOW_LDS_ENT) flow_ok = false;   // one row that reads more than the LDS holds: no dataflow form for this sweep
+            ++rows; bytes += rb;
         }
-        ria[p + 1] = r; nrest += r;
-        const bool alone = !(std::fabs(dg) > SMALLREAL);
-        dr[2 * (size_t)p] = dg; dr[2 * (size_t)p + 1] = alone ? 0.0 : 1.0 / dg;
-        tr[2 * (size_t)p] = t | (alone ? (int)0x80000000 : 0); tr[2 * (size_t)p + 1] = i;
+        if (ns > 0) { sng.push_back(ng); sq0.push_back(ns); }
     }
-    for (int p = 0; p < ns; ++p) { tia[p + 1] += tia[p]; ria[p + 1] += ria[p]; }
-    std::vector<int>    tja((size_t)ntail), rja((size_t)nrest);
-    std::vector<double> tval((size_t)ntail), rval((size_t)nrest);
-    int reach = 0;   // how far back (in positions, from the end of its chunk) a row reads: the LDS ring must cover it
-#pragma omp parallel for schedule(static) reduction(max : reach)
-    for (int q = 0; q < ns; ++q) {
-        const int i = seq[q], p = newpos[q];
-        const int ck = chunk_of[p], lo = lo_of[ck], hi = lo_of[ck + 1];
-        int e = 0;
-        size_t kt = (size_t)tia[p], kr = (size_t)ria[p];
-        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
-            const int j = A.ja[k];
-            if (j == i) continue;
-            if (is_lower(i, q, j)) {
-                const int cpos = newpos[pos[j]];
-                if (is_far(p, cpos)) { tja[kt] = cpos | TRI_FAR_BIT; tval[kt] = A.val[k]; ++kt; continue; }
-                reach = std::max(reach, hi - cpos);
-                if (e < TRI_PFMAX * L) {
-                    const int    qe = e / L;   // round of this entry
-                    const size_t at = (size_t)sbase[ck] + ((size_t)(qe / 4) * L * (hi - lo) + (size_t)(p - lo) * L + (e % L)) * 4 + (qe % 4);
-                    sc[at] = cpos; sv[at] = A.val[k];
-                } else { tja[kt] = cpos; tval[kt] = A.val[k]; ++kt; }
-                ++e;
-            } else { rja[kr] = j; rval[kr] = A.val[k]; ++kr; }
+    if (!flow_ok) { S.flow_ok = false; return 1; }   // (the caller falls back to whole-row level scheduling: build_schedule + k_seq_level)
+    const int nstrips = (int)sq0.size() - 1;
+    // ---- per strip: rows by (class, sequence), chunks; positions = strip base + local index
+    Buf<int> newpos((size_t)std::max(ns, 1)), seqof((size_t)std::max(ns, 1));   // position of sequence index q; sequence index at position p
+    std::vector<int> schunks((size_t)nstrips + 1, 0);
+    std::vector<long long> sbytes((size_t)nstrips + 1, 0);
+#pragma omp parallel
+    {
+        std::vector<int> cnt;
+#pragma omp for schedule(dynamic, 1)
+        for (int s = 0; s < nstrips; ++s) {
+            const int q0 = sq0[s], q1 = sq0[s + 1];
+            int lmin = lev[q0], lmax = lev[q0];
+            for (int q = q0; q < q1; ++q) { lmin = std::min(lmin, lev[q]); lmax = std::max(lmax, lev[q]); }
+            cnt.assign((size_t)(lmax - lmin + 2), 0);
+            for (int q = q0; q < q1; ++q) cnt[(size_t)(lev[q] - lmin + 1)]++;
+            for (size_t l = 1; l < cnt.size(); ++l) cnt[l] += cnt[l - 1];
+            for (int q = q0; q < q1; ++q) { const int p = q0 + cnt[(size_t)(lev[q] - lmin)]++; newpos[q] = p; seqof[p] = q; }
+            // chunks: runs of one class, rpw rows at most
+            int nch = 0;
+            long long by = 0;
+            for (int p = q0; p < q1;) {
+                const int l = lev[seqof[p]];
+                int e = p, mx = 0;
+                while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
+                const int pf = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));
+                by += 16ll * (e - p) * L * (1 + (pf + 1) / 2);
+                ++nch; p = e;
+            }
+            schunks[(size_t)s + 1] = nch; sbytes[(size_t)s + 1] = by;
         }
+    }
+    std::vector<int> sghost((size_t)nstrips + 1, 0);
+    for (int s = 0; s < nstrips; ++s) { schunks[(size_t)s + 1] += schunks[(size_t)s]; sbytes[(size_t)s + 1] += sbytes[(size_t)s]; sghost[(size_t)s + 1] = sghost[(size_t)s] + sng[(size_t)s]; }
+    const int nchunk = nstrips ? schunks[(size_t)nstrips] : 0;
+    const long long slot_bytes = nstrips ? sbytes[(size_t)nstrips] : 0, nghost = nstrips ? sghost[(size_t)nstrips] : 0;
+    // ---- tail and rest offsets by position
+    Buf<int> tia((size_t)ns + 1), ria((size_t)ns + 1);
+    tia[0] = 0; ria[0] = 0;
+    long long ntail = 0, nrest_total = 0;
+    for (int p = 0; p < ns; ++p) {
+        const int q = seqof[p];
+        ntail += std::max(0, nlow[q] - TRI_PFMAX * L); nrest_total += nrest[q];
+        if (ntail > 0x7fffffffll || nrest_total > 0x7fffffffll) return ERROR_INPUT_PAR;
+        tia[(size_t)p + 1] = (int)ntail; ria[(size_t)p + 1] = (int)nrest_total;
+    }
+    // ---- fill: chunk descriptors, slots, ghost lists, tails, the rest, the per-row records
+    std::vector<FlowStrip> strips((size_t)nstrips);
+    Buf<int2> chunks((size_t)std::max(nchunk, 1));
+    Buf<int> cstrip((size_t)std::max(nchunk, 1)), clev((size_t)std::max(nchunk, 1));
+    Buf<unsigned char> slots((size_t)std::max<long long>(slot_bytes, 16));
+    Buf<int> gpos((size_t)std::max<long long>(nghost, 1));
+    Buf<int> tja((size_t)std::max<long long>(ntail, 1)), rja((size_t)std::max<long long>(nrest_total, 1)), tr(2 * (size_t)std::max(ns, 1));
+    Buf<double> tval((size_t)std::max<long long>(ntail, 1)), rval((size_t)std::max<long long>(nrest_total, 1)), dr(2 * (size_t)std::max(ns, 1));
+    int pfmax = 1, maxent = 0, bad = 0;
+#pragma omp parallel reduction(max : pfmax, maxent) reduction(+ : bad)
+    {
+        // ghost index of an earlier position: open addressing, emptied per strip by a stamp
+        constexpr int HB = 1 << 16;   // (2 x FLOW_LDS_ENT rounded up: at most FLOW_LDS_ENT distinct keys)
+        std::vector<int> hkey((size_t)HB, -1), hval((size_t)HB, 0), hstamp((size_t)HB, -1);
+#pragma omp for schedule(dynamic, 1)
+        for (int s = 0; s < nstrips; ++s) {
+            const int q0 = sq0[s], q1 = sq0[s + 1];
+            FlowStrip& F = strips[(size_t)s];
+            F.slot0 = sbytes[(size_t)s]; F.row0 = q0; F.nrows = q1 - q0; F.chunk0 = schunks[(size_t)s]; F.nchunk = schunks[(size_t)s + 1] - schunks[(size_t)s];
+            F.ghost0 = sghost[(size_t)s]; F.nghost = sng[(size_t)s];
+            maxent = std::max(maxent, F.nrows + F.nghost);
+            const int zero_idx = F.nrows + F.nghost;
+            int ng = 0;
+            auto lds_index = [&](int p) -> int {   // position of a lower entry -> LDS index of this strip
+                if (p >= q0) return p - q0;
+                unsigned h = ((unsigned)p * 2654435761u) >> 16;
+                for (;; h = (h + 1) & (HB - 1)) {
+                    if (hstamp[h] != s) { hstamp[h] = s; hkey[h] = p; hval[h] = ng; gpos[(size_t)F.ghost0 + ng] = p; return F.nrows + ng++; }
+                    if (hkey[h] == p) return F.nrows + hval[h];
+                }
+            };
+            unsigned char* sb = slots.data() + F.slot0;
+            long long off = 0;
+            int ck = F.chunk0;
+            for (int p = q0; p < q1; ++ck) {
+                const int l = lev[seqof[p]];
+                int e = p, mx = 0;
+                while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
+                const int pf = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L)), nr = e - p, nl = nr * L;
+                pfmax = std::max(pfmax, pf);
+                chunks[(size_t)ck] = make_int2((p - q0) | (nr << 16) | (pf << 24), (int)(off / 16));
+                cstrip[(size_t)ck] = s; clev[(size_t)ck] = l;
+                unsigned short* cols = reinterpret_cast<unsigned short*>(sb + off);
+                double* vals = reinterpret_cast<double*>(sb + off + 16ll * nl);
+                for (int t = 0; t < nl * 8; ++t) cols[t] = (unsigned short)zero_idx;
+                for (long long t = 0; t < 2ll * nl * ((pf + 1) / 2); ++t) vals[t] = 0.0;
+                for (int pp = p; pp < e; ++pp) {
+                    const int q = seqof[pp], i = seq[q];
+                    int en = 0;
+                    size_t kt = (size_t)tia[pp], kr = (size_t)ria[pp];
+                    double dg = 0.0;
+                    for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                        const int j = A.ja[k];
+                        if (j == i) { dg = A.val[k]; continue; }   // the last diagonal hit, as the reference's loop leaves it
+                        const int pj = j < n ? pos[j] : -1;
+                        if ((unsigned)pj < (unsigned)q) {
+                            const int c = lds_index(newpos[pj]);
+                            if (en < TRI_PFMAX * L) {
+                                const int qe = en / L, lane = (pp - p) * L + en % L;   // round, lane of the chunk
+                                cols[lane * 8 + qe] = (unsigned short)c;
+                                vals[(size_t)(qe / 2) * 2 * nl + (size_t)lane * 2 + (qe & 1)] = A.val[k];
+                            } else { tja[kt] = c; tval[kt] = A.val[k]; ++kt; }
+                            ++en;
+                        } else { rja[kr] = j; rval[kr] = A.val[k]; ++kr; }
+                    }
+                    const bool alone = !(std::fabs(dg) > SMALLREAL);
+                    dr[2 * (size_t)pp] = dg; dr[2 * (size_t)pp + 1] = alone ? 0.0 : 1.0 / dg;
+                    tr[2 * (size_t)pp] = (tia[(size_t)pp + 1] - tia[pp]) | (alone ? (int)0x80000000 : 0); tr[2 * (size_t)pp + 1] = i;
+                }
+                off += 16ll * nl * (1 + (pf + 1) / 2);
+                p = e;
+            }
+            if (ng != F.nghost || off != sbytes[(size_t)s + 1] - sbytes[(size_t)s] || off > 0x7fffffffll) ++bad;
+        }
+    }
+    if (bad) { std::fprintf(stderr, "### ERROR: fasp_hip: inconsistent strip bookkeeping in the sweep schedule\n"); return ERROR_MISC; }
+    // chunks by dependency class (k_tri_level): a counting sort
+    S.cptr.assign((size_t)nlev + 1, 0);
+    for (int c = 0; c < nchunk; ++c) S.cptr[(size_t)clev[(size_t)c]]++;
+    for (int l = 0; l < nlev; ++l) S.cptr[(size_t)l + 1] += S.cptr[(size_t)l];
+    Buf<int> lchunks((size_t)std::max(nchunk, 1));
+    {
+        std::vector<int> cur(S.cptr.begin(), S.cptr.end() - 1);
+        for (int c = 0; c < nchunk; ++c) lchunks[(size_t)cur[(size_t)clev[(size_t)c] - 1]++] = c;
     }
     S.release();
     int st = FASP_SUCCESS;
-    if ((st = split_upload(S, &S.d_order, order)) < 0) return st;
-    if ((st = split_upload(S, &S.d_ptr, S.ptr)) < 0) return st;
-    if ((st = split_upload(S, &S.d_sbase, sbase)) < 0) return st;
-    if ((st = split_upload(S, &S.d_sc, sc)) < 0) return st;
-    if ((st = split_upload(S, &S.d_sv, sv)) < 0) return st;
-    if ((st = split_upload(S, &S.d_tia, tia)) < 0) return st;
-    if ((st = split_upload(S, &S.d_tja, tja)) < 0) return st;
-    if ((st = split_upload(S, &S.d_tval, tval)) < 0) return st;
-    if ((st = split_upload(S, &S.d_ria, ria)) < 0) return st;
-    if ((st = split_upload(S, &S.d_rja, rja)) < 0) return st;
-    if ((st = split_upload(S, &S.d_rval, rval)) < 0) return st;
-    if ((st = split_upload(S, &S.d_rec, std::vector<double>(2 * (size_t)ns, 0.0))) < 0) return st;
-    if ((st = split_upload(S, &S.d_dr, dr)) < 0) return st;
-    if ((st = split_upload(S, &S.d_tr, tr)) < 0) return st;
-    if ((st = split_upload(S, &S.d_W, std::vector<double>((size_t)ns, 0.0))) < 0) return st;
-    if ((st = split_upload(S, &S.d_prog, std::vector<unsigned>(64, 0u))) < 0) return st;   // [0] progress (one-workgroup form); cluster form: [4] arrivals, [5] error, [6] progress, [20 + b] XCC ids
-    if ((st = split_upload(S, &S.d_cptr, S.cptr)) < 0) return st;
-    {   // cluster form: the first chunk of every (class, solver)
-        int maxw = 0;
-        for (size_t l = 0; l + 1 < S.cptr.size(); ++l) maxw = std::max(maxw, S.cptr[l + 1] - S.cptr[l]);
-        const int cnb = std::min(16, std::max(1, maxw));
-        std::vector<int> cdesc(4 * (size_t)cnb * std::max<size_t>(S.cptr.size() - 1, 1), 0);
-        for (size_t l = 0; l + 1 < S.cptr.size(); ++l)
-            for (int b = 0; b < cnb; ++b) {
-                const int c = S.cptr[l] + b;
-                int* d = &cdesc[4 * (l * cnb + b)];
-                if (c < S.cptr[l + 1]) { d[0] = S.ptr[c]; d[1] = lo_of[c + 1]; d[2] = sbase[c]; }
-            }
-        if ((st = split_upload(S, &S.d_cdesc, cdesc)) < 0) return st;
-    }
-    S.maxw = 0;
-    for (size_t l = 0; l + 1 < S.cptr.size(); ++l) S.maxw = std::max(S.maxw, S.cptr[l + 1] - S.cptr[l]);
-    S.nfar_chunks = 0;
-    for (int c = 0; c < nchunk; ++c) {
-        bool any = false;
-        for (int p = lo_of[c]; p < lo_of[c + 1] && !any; ++p) any = nfar_of[p] > 0;
-        S.nfar_chunks += any;
-    }
-    S.ns = ns; S.L = L; S.nolower = lower_total == 0; S.ntail = ntail; S.reach = reach; S.nfar = nfar; S.ringcap = ringcap; S.block_us = bytes_us; S.nslot = nslot; S.pfmax = pfmax;
-    const double avg_rest = ns > 0 ? (double)nrest / ns : 0.0;
+    FlowStrip* d_strips = nullptr; int2* d_chunks = nullptr;
+    if ((st = split_upload(S, &d_strips, strips)) < 0) return st;
+    if ((st = split_upload(S, &d_chunks, chunks.data(), (size_t)nchunk)) < 0) return st;
+    S.d_strips = d_strips; S.d_chunks = d_chunks;
+    if ((st = split_upload(S, &S.d_slots, slots.data(), (size_t)slot_bytes)) < 0) return st;
+    if ((st = split_upload(S, &S.d_gpos, gpos.data(), (size_t)nghost)) < 0) return st;
+    if ((st = split_upload(S, &S.d_cstrip, cstrip.data(), (size_t)nchunk)) < 0) return st;
+    if ((st = split_upload(S, &S.d_lchunks, lchunks.data(), (size_t)nchunk)) < 0) return st;
+    if ((st = split_upload(S, &S.d_tia, tia.data(), (size_t)ns + 1)) < 0) return st;
+    if ((st = split_upload(S, &S.d_tja, tja.data(), (size_t)ntail)) < 0) return st;
+    if ((st = split_upload(S, &S.d_tval, tval.data(), (size_t)ntail)) < 0) return st;
+    if ((st = split_upload(S, &S.d_ria, ria.data(), (size_t)ns + 1)) < 0) return st;
+    if ((st = split_upload(S, &S.d_rja, rja.data(), (size_t)nrest_total)) < 0) return st;
+    if ((st = split_upload(S, &S.d_rval, rval.data(), (size_t)nrest_total)) < 0) return st;
+    if ((st = split_upload(S, &S.d_dr, dr.data(), 2 * (size_t)ns)) < 0) return st;
+    if ((st = split_upload(S, &S.d_tr, tr.data(), 2 * (size_t)ns)) < 0) return st;
+    HIPCK(hipMalloc((void**)&S.d_rec, sizeof(double) * 2 * (size_t)std::max(ns, 1))); S.owned.push_back(S.d_rec);
+    HIPCK(hipMalloc((void**)&S.d_W, sizeof(double) * (size_t)std::max(ns, 1))); S.owned.push_back(S.d_W);
+    HIPCK(hipMemset(S.d_W, 0, sizeof(double) * (size_t)std::max(ns, 1)));
+    if ((st = split_upload(S, &S.d_prog, std::vector<unsigned>(64, 0u))) < 0) return st;   // [0] ticket counter, [1] error word
+    S.ns = ns; S.L = L; S.nolower = lower_total == 0; S.ntail = ntail; S.pfmax = pfmax; S.nstrips = nstrips; S.nchunk = nchunk; S.maxent = maxent;
+    S.nghost = nghost; S.slot_bytes = slot_bytes; S.flow_ok = flow_ok;
+    const double avg_rest = ns > 0 ? (double)nrest_total / ns : 0.0;
     S.LR = 1;
     while (S.LR < 64 && 4 * S.LR < avg_rest) S.LR *= 2;
     S.built = true;
@@ -330,18 +391,25 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
             default: for (int i = n - 2; i >= 0; --i) seq.push_back(i); break;
         }
         const double t0 = wall_seconds();
-        const int st = multicolor ? build_schedule(A, seq, S, true) : build_split(A, seq, S);
+        int st = multicolor ? build_schedule(A, seq, S, true) : build_split(A, seq, S);
         if (st < 0) return st;
+        S.rowlevels = false;
+        if (st == 1) {   // a row of this sweep reads more earlier rows than a strip's LDS holds: whole rows, one launch per dependency level
+            if ((st = build_schedule(A, seq, S, false)) < 0) return st;
+            S.rowlevels = true;
+        }
         if (std::getenv("FASP_HIP_SETUP_TIMING")) {
-            if (multicolor) std::printf("  [sweep schedule] level %d, sweep kind %d, colours: %d rows in %d classes\n", level, kind, (int)seq.size(), (int)S.ptr.size() - 1);
-            else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes (%d chunks, reach %d, %lld far entries in %d chunks), %d lanes per row, %.1f slots per row (%lld tail entries), rest pass %d lanes per row, one-workgroup estimate %.0f us, built in %.3f s\n",
-                             level, kind, S.ns, (int)S.cptr.size() - 1, (int)S.ptr.size() - 1, S.reach, S.nfar, S.nfar_chunks, S.L, S.ns ? (double)S.nslot / S.ns : 0.0, S.ntail, S.LR, S.block_us, wall_seconds() - t0);
+            if (multicolor || S.rowlevels) std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind, multicolor ? "colours" : "whole-row dependency levels", (int)seq.size(), (int)S.ptr.size() - 1);
+            else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes, %d strips (%lld ghosts, at most %d values in LDS), %d chunks, %d lanes per row, "
+                             "%.1f slot bytes per row (%lld tail entries), rest pass %d lanes per row%s, built in %.3f s\n",
+                             level, kind, S.ns, (int)S.cptr.size() - 1, S.nstrips, S.nghost, S.maxent + 1, S.nchunk, S.L, S.ns ? (double)S.slot_bytes / S.ns : 0.0, S.ntail, S.LR,
+                             "", wall_seconds() - t0);
         }
     }
     materialise_zero(D);
-    if (multicolor) {
+    if (multicolor || S.rowlevels) {
         const int nlev = (int)S.ptr.size() - 1;
-        // one launch per colour; lanes per row as the level's SpMV kernel
+        // one launch per colour (or per dependency level of whole rows); lanes per row as the level's SpMV kernel
         const double avg_len = D.A.row > 0 ? (double)D.A.nnz / D.A.row : 0.0;
         const int L = g_tune.seq_lanes > 0 ? g_tune.seq_lanes : (avg_len >= 96.0 ? 64 : D.A.lanes);
         for (int l = 0; l < nlev; ++l) {
@@ -365,16 +433,16 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     }
     const int ns = S.ns;
     if (ns == 0) return FASP_SUCCESS;
-    const int nchunk = (int)S.ptr.size() - 1, nlev = (int)S.cptr.size() - 1;
-    TriArgs ta{};
-    ta.lptr = S.d_ptr; ta.sbase = S.d_sbase; ta.nchunk = nchunk; ta.sc = S.d_sc; ta.sv = S.d_sv; ta.tia = S.d_tia; ta.tja = S.d_tja; ta.tval = S.d_tval;
-    ta.rec = S.d_rec; ta.dr = S.d_dr; ta.tr = S.d_tr; ta.nrow = D.A.row; ta.order = S.d_order; ta.W = S.d_W; ta.u = D.x; ta.form = form; ta.w = w; ta.far = S.nfar > 0;
+    FlowArgs fa{};
+    fa.strips = (const FlowStrip*)S.d_strips; fa.chunks = (const int2*)S.d_chunks; fa.slots = S.d_slots; fa.gpos = S.d_gpos; fa.cstrip = S.d_cstrip;
+    fa.tia = S.d_tia; fa.tja = S.d_tja; fa.tval = S.d_tval; fa.rec = S.d_rec; fa.dr = S.d_dr; fa.tr = S.d_tr; fa.W = S.d_W; fa.u = D.x;
+    fa.sync = S.d_prog; fa.nstrips = S.nstrips; fa.form = form; fa.w = w;
     // pass (1): everything that reads old values, all rows at once
     {
         const int rpb = BLOCK / S.LR;
         const int grid = std::max(1, std::min(MAXGRID, (ns + rpb - 1) / rpb));
-#define REST_LAUNCH(LL) hipLaunchKernelGGL((k_split_rest<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, ns, (const int*)S.d_order, \
-        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)D.b, (const double*)D.x, S.d_rec, S.d_prog)
+#define REST_LAUNCH(LL) hipLaunchKernelGGL((k_split_rest<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, ns, (const int*)S.d_tr, \
+        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)D.b, (const double*)D.x, S.d_rec, S.d_W, S.d_prog)
         switch (S.LR) {
             case 1: REST_LAUNCH(1); break;
             case 2: REST_LAUNCH(2); break;
@@ -388,93 +456,50 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     }
     const int sgrid = std::max(1, std::min(MAXGRID, (ns + BLOCK - 1) / BLOCK));
     if (S.nolower) {   // no row of the sweep reads another one's new value (the C rows / F rows of the 7-point level 0)
-        hipLaunchKernelGGL(k_split_scatter, dim3(sgrid), dim3(BLOCK), 0, g_ctx.stream, ns, ta, 1);
+        hipLaunchKernelGGL(k_split_scatter, dim3(sgrid), dim3(BLOCK), 0, g_ctx.stream, ns, fa, 1);
         return FASP_SUCCESS;
     }
-    // pass (2) in ONE workgroup (k_tri_block) when its chain of chunks beats one launch per class.  MEASURED on P7(128)
-    // (tools/perf_gs_levels.py): ~0.7 us per chunk with the new values in an LDS ring (more where chunks are wide: one
-    // compute unit sustains ~25 GB/s of these fetches), ~2.2 us per chunk when the schedule reaches further back than the ring and
-    // W goes through the L2; a launch per class costs ~3.2 us (classes of one chunk) to ~3.9 us.
-    // fasp_hip_tune("seq_block", 0) / ("seq_ulds", 0) switch the workgroup form / the ring off: same slots, same row
-    // arithmetic, same bits.
+    // pass (2), the dataflow form: one launch, workgroups draw strips from the ticket counter (seq_split.hip.h)
     const int L = S.L;
-    const size_t lds_ptr = 2 * sizeof(int) * (size_t)(nchunk + 1);
-    constexpr size_t LDS_CAP = TRI_LDS_CAP;
-    int cap = 0;
-    if (g_tune.seq_ulds) {
-        if (S.nfar) cap = S.ringcap;   // (the far entries were chosen against exactly this ring)
-        else {
-            for (int c = 16384; c >= 1024 && !cap; c >>= 1)
-                if (c <= g_tune.seq_ring && S.reach <= c && (size_t)c * 8 + lds_ptr <= LDS_CAP) cap = c;
-            while (cap > 1024 && (cap >> 1) >= S.reach) cap >>= 1;   // (no larger than needed: the ring is zeroed per launch)
-        }
-    }
-    const double cost_block = cap ? S.block_us + 1.5 * S.nfar_chunks : std::max(S.block_us, 2.2 * nchunk), cost_launch = (double)nlev * 3.2 + 0.15 * (nchunk - nlev);
-    // the cluster form (k_tri_cluster): a few workgroups on one XCD, a barrier per class instead of a launch: 2.4 us per class
-    // measured (0.7 the barrier round itself, the rest the chain through the L2 and the drained stores), 0.4 us per further
-    // chunk of a solver
-    const int  cl_nb = std::min(16, std::max(1, S.maxw));
-    const double cost_cluster = (double)nlev * 2.4 + 0.4 * std::max(0, (nchunk - nlev * cl_nb + cl_nb - 1) / cl_nb);   // (measured on P7(128): 2.4-2.5 us per class)
-    static bool cluster_disabled = false;
-    if (seq_err_pending()) { cluster_disabled = true; return ERROR_MISC; }
-    if (g_tune.seq_cluster && !cluster_disabled && !comm_shares_devices() && nlev >= 8 && cl_nb >= 2 &&
-        cost_cluster < cost_launch && (!g_tune.seq_block || cost_cluster < cost_block || lds_ptr > LDS_CAP)) {
-        const int nhelp = std::max(0, std::max(g_tune.seq_help, 8));   // (several compute units to stream what a cluster consumes)
-        const double chunk_bytes = nchunk ? (12.0 * S.nslot + 40.0 * ns) / nchunk : 1.0;
-        const int ahead = (int)std::min(4096.0, std::max(2.0 * cl_nb, 1.5e6 / chunk_bytes));
-        unsigned* sync = S.d_prog + 4;
-#define TRIC_LAUNCH(LL) hipLaunchKernelGGL((k_tri_cluster<LL>), dim3(8 * (cl_nb + nhelp)), dim3(TRI_BLOCK), 0, g_ctx.stream, ta, (const int*)S.d_cptr, (const int*)S.d_cdesc, nlev, ns, cl_nb, nhelp, ahead, sync)
-        switch (L) {
-            case 1: TRIC_LAUNCH(1); break;
-            case 2: TRIC_LAUNCH(2); break;
-            case 4: TRIC_LAUNCH(4); break;
-            case 8: TRIC_LAUNCH(8); break;
-            case 16: TRIC_LAUNCH(16); break;
-            case 32: TRIC_LAUNCH(32); break;
-            default: TRIC_LAUNCH(64); break;
-        }
-#undef TRIC_LAUNCH
-        seq_err_watch(sync + 1);
-        return FASP_SUCCESS;
-    }
-    if (g_tune.seq_block && nlev >= 8 && lds_ptr <= LDS_CAP && cost_block < cost_launch) {
-        const size_t dyn = (cap ? (size_t)cap * 8 : 0) + lds_ptr;
-        // helper workgroups that read ahead of the solver into the XCD's L2 (tri_prefetch): ~1.5 MB ahead, at least three groups of chunks
-        const int nhelp = comm_shares_devices() ? 0 : std::max(0, g_tune.seq_help);
-        const double chunk_bytes = nchunk ? (12.0 * S.nslot + 40.0 * ns) / nchunk : 1.0;
-        const int ahead = (int)std::min(4096.0, std::max(12.0, 1.5e6 / chunk_bytes));
-#define TRIB_ONE(LL, PP, WW, TT)                                                                                           \
+    if (g_tune.seq_flow && S.flow_ok && !g_flow_disabled) {
+        if (seq_err_check() < 0) return ERROR_MISC;   // an earlier sweep's time-out that has arrived meanwhile
+        const size_t dyn = sizeof(double) * ((size_t)S.maxent + 1);
+        const int per_cu = std::max(1, std::min(2048 / FLOW_THREADS, (int)((160 * 1024 - 64) / (dyn + 16))));
+        const int grid = std::max(1, std::min(S.nstrips, per_cu * g_ctx.num_cu));
+#define FLOW_ONE(LL, PP, TT)                                                                                                \
         {                                                                                                                   \
             static bool attr_set = false;                                                                                   \
             if (!attr_set) {                                                                                                \
-                HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tri_block<LL, PP, WW, TT>),                       \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP));                       \
+                HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tri_flow<LL, PP, TT>),                            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (FLOW_LDS_ENT + 1)))); \
                 attr_set = true;                                                                                            \
             }                                                                                                               \
-            hipLaunchKernelGGL((k_tri_block<LL, PP, WW, TT>), dim3(1 + 8 * nhelp), dim3(TRI_BLOCK), dyn, g_ctx.stream, ta, ns, cap ? cap : 2, nhelp, ahead, S.d_prog); \
+            hipLaunchKernelGGL((k_tri_flow<LL, PP, TT>), dim3(grid), dim3(FLOW_THREADS), dyn, g_ctx.stream, fa);            \
         }
-#define TRIB_LAUNCH(LL)                                                                                                     \
-        if (!cap) TRIB_ONE(LL, TRI_PFMAX, false, true)                                                                      \
-        else if (S.ntail) TRIB_ONE(LL, TRI_PFMAX, true, true)                                                               \
-        else if (S.pfmax > 4) TRIB_ONE(LL, TRI_PFMAX, true, false)                                                          \
-        else TRIB_ONE(LL, 4, true, false)
+#define FLOW_LAUNCH(LL)                                                                                                     \
+        if (S.ntail) FLOW_ONE(LL, TRI_PFMAX, true)                                                                          \
+        else if (S.pfmax > 4) FLOW_ONE(LL, TRI_PFMAX, false)                                                                \
+        else FLOW_ONE(LL, 4, false)
         switch (L) {
-            case 1: TRIB_LAUNCH(1); break;
-            case 2: TRIB_LAUNCH(2); break;
-            case 4: TRIB_LAUNCH(4); break;
-            case 8: TRIB_LAUNCH(8); break;
-            case 16: TRIB_LAUNCH(16); break;
-            case 32: TRIB_LAUNCH(32); break;
-            default: TRIB_LAUNCH(64); break;
+            case 1: FLOW_LAUNCH(1); break;
+            case 2: FLOW_LAUNCH(2); break;
+            case 4: FLOW_LAUNCH(4); break;
+            case 8: FLOW_LAUNCH(8); break;
+            case 16: FLOW_LAUNCH(16); break;
+            case 32: FLOW_LAUNCH(32); break;
+            default: FLOW_LAUNCH(64); break;
         }
-#undef TRIB_LAUNCH
-#undef TRIB_ONE
+#undef FLOW_LAUNCH
+#undef FLOW_ONE
+        seq_err_watch(S.d_prog + 1);
         return FASP_SUCCESS;
     }
-    // wide classes: one launch per class, one workgroup per chunk
+    // the plain form: one launch per dependency class, one wavefront per chunk
+    const int nlev = (int)S.cptr.size() - 1;
     for (int l = 0; l < nlev; ++l) {
         const int c0 = S.cptr[l], grid = S.cptr[l + 1] - c0;
-#define TRIL_LAUNCH(LL) hipLaunchKernelGGL((k_tri_level<LL>), dim3(grid), dim3(TRI_BLOCK), 0, g_ctx.stream, ta, c0)
+        if (grid <= 0) continue;
+#define TRIL_LAUNCH(LL) hipLaunchKernelGGL((k_tri_level<LL>), dim3(grid), dim3(64), 0, g_ctx.stream, fa, (const int*)S.d_lchunks, c0)
         switch (L) {
             case 1: TRIL_LAUNCH(1); break;
             case 2: TRIL_LAUNCH(2); break;
@@ -486,7 +511,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
         }
 #undef TRIL_LAUNCH
     }
-    hipLaunchKernelGGL(k_split_scatter, dim3(sgrid), dim3(BLOCK), 0, g_ctx.stream, ns, ta, 0);
+    hipLaunchKernelGGL(k_split_scatter, dim3(sgrid), dim3(BLOCK), 0, g_ctx.stream, ns, fa, 0);
     return FASP_SUCCESS;
 }
 

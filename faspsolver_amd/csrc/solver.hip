@@ -2018,15 +2018,12 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "coarse_split_min")) g_coarse_split_min = value;
     else if (!std::strcmp(key, "split_rows")) g_tune.split_rows = value;
     else if (!std::strcmp(key, "gs_multicolor")) g_tune.gs_multicolor = value;
-    else if (!std::strcmp(key, "seq_block")) g_tune.seq_block = value;
+    else if (!std::strcmp(key, "seq_flow")) { g_tune.seq_flow = value; if (value) g_flow_disabled = false; }
+    else if (!std::strcmp(key, "seq_strip_kb")) g_tune.seq_strip_kb = value;
     else if (!std::strcmp(key, "fuse_zr")) g_tune.fuse_zr = value;
     else if (!std::strcmp(key, "fuse_presmooth")) g_tune.fuse_presmooth = value;
     else if (!std::strcmp(key, "seq_lanes")) g_tune.seq_lanes = value;
-    else if (!std::strcmp(key, "seq_ulds")) g_tune.seq_ulds = value;
     else if (!std::strcmp(key, "lazy_coarse")) g_tune.lazy_coarse = value;
-    else if (!std::strcmp(key, "seq_help")) g_tune.seq_help = value;
-    else if (!std::strcmp(key, "seq_cluster")) g_tune.seq_cluster = value;
-    else if (!std::strcmp(key, "seq_ring")) g_tune.seq_ring = value;
     else if (!std::strcmp(key, "xtile")) g_tune.xtile = value;
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
     else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;
