@@ -18,7 +18,7 @@ from . import _types as T
 from ._types import *  # noqa: F401,F403  (constants + struct mirrors)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfasp_hip.so")
+LIB_PATH = os.environ.get("FASP_HIP_LIB") or os.path.join(_HERE, "libfasp_hip.so")   # (FASP_HIP_LIB: a development build beside the product one, tools/build_variant.sh)
 _lib = None
 
 EXPORTS = [  # every symbol include/fasp_hip.h declares

@@ -28,10 +28,12 @@
 //     naturally aligned 8-byte store (arithmetic cannot produce the sentinel's bits).  Inside a strip the values live in
 //     LDS, between strips they travel through W in memory (write-through stores / L1-bypassing loads): a consumer polls
 //     the value itself.  No flags, no fences, no barriers, no drained counters.
-//   * ROLES.  Wave 0 of a workgroup imports the strip's ghosts (polls W in memory, in the order the strip needs them,
-//     into LDS), wave 1 exports finished rows (LDS -> W and u_i), the other waves compute: wave w takes the strip's
-//     chunks w, w + nw, ... (a chunk = 64 / L rows of one dependency class, L lanes per row, ordered by class), its
-//     operands are LDS indices, the slots of its NEXT chunk are in flight while it waits for the operands of this one.
+//   * ROLES.  Waves 0 and 1 of a workgroup import the strip's ghosts (they poll W in memory, in the order the strip needs
+//     them, into LDS), the other waves compute: wave w takes the strip's chunks w, w + nw, ... (a chunk = 64 / L rows of
+//     one dependency class, L lanes per row, ordered by class), its operands are LDS indices, the slots of its NEXT
+//     chunk(s) are in flight while it waits for the operands of this one; a finished row goes to LDS, to W (one
+//     write-through store, nothing waits for it) and to u_i.  A chunk first polls ONE word -- the operand the host expects
+//     last -- and only then looks at all of them: waiting waves cost the LDS one broadcast read per turn.
 //     A chunk waits only for the rows it actually reads, so a wide class is as many chunks in flight as there are waves
 //     on the chip, and a chain of narrow classes advances at an LDS round trip per row.
 // k_tri_level is the plain form of the same arithmetic (one launch per dependency class, one wavefront per chunk, W in
@@ -58,7 +60,7 @@ struct FlowStrip {     // 32 bytes
 };
 struct FlowArgs {
     const FlowStrip*     strips;
-    const int2*          chunks;   // {first local row | rows << 16 | rounds << 24, offset of the slots in 16-byte units}
+    const int4*          chunks;   // {first local row | rows << 16 | rounds << 24, offset of the slots in 16-byte units, LDS index of the operand expected last, -}
     const unsigned char* slots;
     const int*           gpos;
     const int*           cstrip;   // strip of a chunk (k_tri_level)
@@ -77,7 +79,6 @@ struct FlowArgs {
 };
 constexpr unsigned long long FLOW_SENT = 0x7FF4DEADBEEF0001ull;   // a signalling NaN: no arithmetic result carries these bits
 constexpr int FLOW_LDS_ENT = 19 * 1024;        // doubles of LDS per strip: rows + ghosts + the constant 0.0
-constexpr int FLOW_THREADS = 1024;
 constexpr int TRI_PFMAX = 8;                   // slot rounds a chunk can store; the kernels come with room for 4 (schedules that never need more) or 8
 
 // t / d from the stored reciprocal rd = RN(1 / d): q = RN(t rd), then one correction step with the exact remainder
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_scatter(int nseq, FlowArgs a, i
 
 // what a lane holds of a chunk before the chain reaches it: PF slots and the row's records
 template <int PF>
-struct FlowSet { unsigned cw[PF / 2]; double v[PF]; double t, uo, d, rd; int tn; int lo, n, pf; };
+struct FlowSet { unsigned cw[PF / 2]; double v[PF]; double t, uo, d, rd; int tn, row; int lo, n, pf, wait; };
 
 struct FlowBufs { __amdgpu_buffer_rsrc_t slots, rec, dr, tr; };
 __device__ __forceinline__ FlowBufs flow_bufs(const FlowArgs& a, const FlowStrip& S)
@@ -165,14 +166,14 @@ __device__ __forceinline__ FlowBufs flow_bufs(const FlowArgs& a, const FlowStrip
     B.tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(a.tr + 2 * (size_t)S.row0), 0, 0x7fffffff, 0x00020000);
     return B;
 }
-// Branch-free per lane: idle lanes put their offset beyond the buffers' range -- such a lane gets 0 back and causes no
-// memory access; value planes the chunk does not have are skipped wave-uniformly.
+// Branch-free, and the same number of loads whatever the chunk looks like: idle lanes, and value planes the chunk does not
+// have, put their offset beyond the buffers' range -- such a lane gets 0 back and causes no memory access.
 constexpr int FLOW_OOR = (int)0x80000000u;   // (the resources declare 2^31 - 1 bytes)
 template <int L, int PF>
-__device__ __forceinline__ void flow_fetch(const FlowBufs& B, FlowSet<PF>& r, int2 d, int lane)
+__device__ __forceinline__ void flow_fetch(const FlowBufs& B, FlowSet<PF>& r, int4 d, int lane)
 {
     static_assert(PF == 4 || PF == 8, "slots come in rounds of four or eight");
-    r.lo = d.x & 0xffff; r.n = (d.x >> 16) & 0xff; r.pf = (d.x >> 24) & 0xf;
+    r.lo = d.x & 0xffff; r.n = (d.x >> 16) & 0xff; r.pf = (d.x >> 24) & 0xf; r.wait = d.z;
     const int nl = r.n * L;
     const bool on = lane < nl;
     const int base = d.y * 16;
@@ -186,35 +187,45 @@ __device__ __forceinline__ void flow_fetch(const FlowBufs& B, FlowSet<PF>& r, in
     }
 #pragma unroll
     for (int g = 0; g < PF / 2; ++g) {
-        f64x2_t v;
-        v[0] = 0.0; v[1] = 0.0;
-        if (2 * g < r.pf) v = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(B.slots, off, (1 + g) * nl * 16, 0));
+        const f64x2_t v = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(B.slots, 2 * g < r.pf ? off : FLOW_OOR, (1 + g) * nl * 16, 0));
         r.v[2 * g] = v[0]; r.v[2 * g + 1] = v[1];
     }
     const int rloc = lane / L;
     const unsigned po = on ? (unsigned)(r.lo + rloc) * 16u : (unsigned)FLOW_OOR;
     const f64x2_t r0 = buf_load_f64x2(B.rec, po), r1 = buf_load_f64x2(B.dr, po);
-    r.tn = (int)__builtin_amdgcn_raw_buffer_load_b32(B.tr, on ? (r.lo + rloc) * 8 : FLOW_OOR, 0, 0);
+    const u32x2_t r2 = __builtin_amdgcn_raw_buffer_load_b64(B.tr, on ? (r.lo + rloc) * 8 : FLOW_OOR, 0, 0);
     r.t = r0[0]; r.uo = r0[1]; r.d = r1[0]; r.rd = r1[1];
+    r.tn = (int)r2[0]; r.row = (int)r2[1];
 }
 template <int PF>
 __device__ __forceinline__ int flow_col(const FlowSet<PF>& r, int q) { return (int)((q & 1) ? (r.cw[q >> 1] >> 16) : (r.cw[q >> 1] & 0xffffu)); }
 
-// the row arithmetic shared by both forms (identical bits): lane-strided products in slot order, then the tail, the
-// DPP tree, the update in the group's last lane.  x[q] = the operand of slot q; ldw(c) reads the operand with LDS
-// index c (tail entries).  Returns the new value (valid in lane L - 1).
-template <int L, int PF, bool TAIL, class LDW>
-__device__ __forceinline__ double flow_row(const FlowArgs& a, const FlowSet<PF>& r, const double (&x)[PF], int p, int sl, LDW ldw)
+// the row arithmetic shared by both forms (identical bits): s = the lane's tail entries, then its slot products in slot order
+// (summed left to right from 0.0); the DPP tree; the update in the group's last lane.  Returns the new value (valid in lane L - 1).
+template <int L>
+__device__ __forceinline__ double flow_row(const FlowArgs& a, double t, double uo, double d, double rd, int tn, double s)
 {
-    double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < PF; ++q) s += r.v[q] * x[q];
-    if (TAIL && (r.tn & 0x7fffffff)) {   // (memory loads inside the chain: only schedules that have such rows compile this in)
-        const int kb = a.tia[p], ke = a.tia[p + 1];
-        s = seq_row_sum<L>(a.tja, a.tval, kb + sl, ke, -1, ldw, s);
-    }
     s = group_sum_last<L>(s);
-    return tri_update(r.t - s, r.d, r.rd, r.tn < 0, a.form, a.w, r.uo);
+    if (tn < 0) {   // a row that is left alone keeps its value -- which must not be mistaken for "not there yet"
+        return (unsigned long long)__double_as_longlong(uo) == FLOW_SENT ? __longlong_as_double((long long)(FLOW_SENT | 0x0008000000000000ull)) : uo;
+    }
+    return tri_update(t - s, d, rd, false, a.form, a.w, uo);
+}
+
+// descriptors are read through the scalar cache (constant address space: nothing in a launch writes them)
+typedef const __attribute__((address_space(4))) int* flow_int_cp;
+__device__ __forceinline__ FlowStrip flow_strip(const FlowArgs& a, int s)
+{
+    const flow_int_cp q = (flow_int_cp)(unsigned long long)(a.strips + s);
+    FlowStrip S;
+    S.slot0 = (long long)(((unsigned long long)(unsigned)q[1] << 32) | (unsigned)q[0]);
+    S.row0 = q[2]; S.nrows = q[3]; S.chunk0 = q[4]; S.nchunk = q[5]; S.ghost0 = q[6]; S.nghost = q[7];
+    return S;
+}
+__device__ __forceinline__ int4 flow_chunk(const FlowArgs& a, int c)
+{
+    const flow_int_cp q = (flow_int_cp)(unsigned long long)(a.chunks + c);
+    return make_int4(q[0], q[1], q[2], q[3]);
 }
 
 // ONE dependency class per launch, one wavefront per chunk, W in memory (plain loads and stores: launches order them)
@@ -223,10 +234,10 @@ __global__ __launch_bounds__(64) void k_tri_level(FlowArgs a, const int* __restr
 {
     const int lane = threadIdx.x;
     const int ck = lchunks[c0 + blockIdx.x];
-    const FlowStrip S = a.strips[a.cstrip[ck]];
+    const FlowStrip S = flow_strip(a, __builtin_amdgcn_readfirstlane(a.cstrip[ck]));
     const FlowBufs B = flow_bufs(a, S);
     FlowSet<TRI_PFMAX> r;
-    flow_fetch<L, TRI_PFMAX>(B, r, a.chunks[ck], lane);
+    flow_fetch<L, TRI_PFMAX>(B, r, flow_chunk(a, __builtin_amdgcn_readfirstlane(ck)), lane);
     const int rloc = lane / L, sl = lane & (L - 1);
     auto ldw = [&](int c) -> double {   // LDS index -> position
         if (c < S.nrows) return a.W[S.row0 + c];
@@ -234,11 +245,12 @@ __global__ __launch_bounds__(64) void k_tri_level(FlowArgs a, const int* __restr
         return 0.0;
     };
     if (rloc < r.n) {
-        double x[TRI_PFMAX];
-#pragma unroll
-        for (int q = 0; q < TRI_PFMAX; ++q) x[q] = q < r.pf ? ldw(flow_col(r, q)) : 0.0;
         const int p = S.row0 + r.lo + rloc;
-        const double un = flow_row<L, TRI_PFMAX, true>(a, r, x, p, sl, ldw);
+        double s = 0.0;
+        if (r.tn & 0x7fffffff) { const int kb = a.tia[p], ke = a.tia[p + 1]; s = seq_row_sum<L>(a.tja, a.tval, kb + sl, ke, -1, ldw); }
+#pragma unroll
+        for (int q = 0; q < TRI_PFMAX; ++q) s += r.v[q] * (q < r.pf ? ldw(flow_col(r, q)) : 0.0);
+        const double un = flow_row<L>(a, r.t, r.uo, r.d, r.rd, r.tn, s);
         if (sl == L - 1) a.W[p] = un;
     }
 }
@@ -263,14 +275,23 @@ __device__ __forceinline__ bool flow_give_up(unsigned* sync, unsigned& spins, un
     return false;
 }
 
+// Workgroup size and register sets per compute wave: chunks of four rounds leave room for two sets in the 128 registers of a
+// 1024-thread workgroup (14 compute waves); chunks of eight rounds run in 512-thread workgroups (6 compute waves) with three
+// sets: the slots of the next TWO chunks of a wave are in flight.
+#ifndef FLOW_NT8
+#define FLOW_NT8 512
+#define FLOW_NSET8 3
+#endif
+template <int PF> struct FlowGeom { static constexpr int NT = PF <= 4 ? 1024 : FLOW_NT8, NSET = PF <= 4 ? 2 : FLOW_NSET8; };
 template <int L, int PF, bool TAIL>
-__global__ __launch_bounds__(FLOW_THREADS) void k_tri_flow(FlowArgs a)
+__global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
 {
+    constexpr int FLOW_THREADS = FlowGeom<PF>::NT, NSET = FlowGeom<PF>::NSET;
     typedef __attribute__((address_space(1))) unsigned           gu32;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     extern __shared__ __attribute__((aligned(16))) double flow_lds[];
     __shared__ int s_strip;
-    constexpr int NW = FLOW_THREADS / 64, NWC = NW - 2;
+    constexpr int NW = FLOW_THREADS / 64, NIMP = 2, NWC = NW - NIMP;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -282,14 +303,15 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_tri_flow(FlowArgs a)
         __syncthreads();
         const int s = __builtin_amdgcn_readfirstlane(s_strip);
         if (s >= a.nstrips) break;
-        const FlowStrip S = a.strips[s];
+        const FlowStrip S = flow_strip(a, s);
         const int nent = S.nrows + S.nghost;
         for (int i = tid; i < nent; i += FLOW_THREADS) flow_lds[i] = sent;
         if (tid == 0) flow_lds[nent] = 0.0;
         __syncthreads();
-        if (wave == 0) {
-            // ---- importer: the strip's ghosts, in the order the strip needs them, 256 at a time
-            for (int g0 = 0; g0 < S.nghost; g0 += 256) {
+        if (wave < NIMP) {
+            // ---- importers: the strip's ghosts, in the order the strip needs them, 256 at a time, batches dealt to the two waves in turn;
+            // a ghost goes to LDS the moment it is seen
+            for (int g0 = wave * 256; g0 < S.nghost; g0 += NIMP * 256) {
                 int gp[4];
                 unsigned pend = 0u;
 #pragma unroll
@@ -301,14 +323,13 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_tri_flow(FlowArgs a)
                 unsigned spins = 0;
                 unsigned long long t0 = 0;
                 for (;;) {
+                    unsigned long long v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = __hip_atomic_load((gu64*)(a.W + gp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if ((pend >> k) & 1u) {
-                            const unsigned long long v = __hip_atomic_load((gu64*)(a.W + gp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (v != FLOW_SENT) { lds_put(S.nrows + g0 + k * 64 + lane, __longlong_as_double((long long)v)); pend &= ~(1u << k); }
-                        }
+                        if (((pend >> k) & 1u) && v[k] != FLOW_SENT) { lds_put(S.nrows + g0 + k * 64 + lane, __longlong_as_double((long long)v[k])); pend &= ~(1u << k); }
                     if (!__builtin_amdgcn_ballot_w64(pend != 0u)) break;
-                    __builtin_amdgcn_s_sleep(2);
                     if (flow_give_up(a.sync, spins, t0)) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) if ((pend >> k) & 1u) lds_put(S.nrows + g0 + k * 64 + lane, 0.0);
@@ -316,58 +337,39 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_tri_flow(FlowArgs a)
                     }
                 }
             }
-        } else if (wave == 1) {
-            // ---- exporter: finished rows leave for W (write-through: other strips poll it) and for u_i, each as soon as it is there
-            for (int i0 = 0; i0 < S.nrows; i0 += 64) {
-                const int i = i0 + lane;
-                bool todo = i < S.nrows;
-                const int row = todo ? a.tr[2 * (size_t)(S.row0 + i) + 1] : 0;
-                unsigned spins = 0;
-                unsigned long long t0 = 0;
-                for (;;) {
-                    if (todo) {
-                        const double v = lds_get(i);
-                        if (flow_ready(v)) {
-                            __hip_atomic_store((gu64*)(a.W + S.row0 + i), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            a.u[row] = v;
-                            todo = false;
-                        }
-                    }
-                    if (!__builtin_amdgcn_ballot_w64(todo)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (flow_give_up(a.sync, spins, t0)) break;
-                }
-            }
         } else {
             // ---- compute: chunks w, w + NWC, ... of the strip; the next chunk's slots travel while this one waits for its operands
-            const int w = wave - 2;
+            const int w = wave - NIMP;
             const int rloc = lane / L, sl = lane & (L - 1);
             const FlowBufs B = flow_bufs(a, S);
             const int zero_idx = nent;
-            auto fetch = [&](FlowSet<PF>& X, int ci) {
-                if (ci < S.nchunk) flow_fetch<L, PF>(B, X, a.chunks[S.chunk0 + ci], lane);
-                else { X.n = 0; X.pf = 0; X.lo = 0; }
+#ifdef FLOW_TIMING
+            long long ft[5] = {0, 0, 0, 0, 0}, fl = clock64();
+#define FT(k) do { const long long n_ = clock64(); ft[k] += n_ - fl; fl = n_; } while (0)
+#else
+#define FT(k)
+#endif
+            auto fetch = [&](FlowSet<PF>& X, int ci) {   // (past the end: an empty chunk, every load out of range)
+                flow_fetch<L, PF>(B, X, ci < S.nchunk ? flow_chunk(a, S.chunk0 + ci) : make_int4(0, 0, zero_idx, 0), lane);
             };
             auto run = [&](const FlowSet<PF>& X) {
                 const bool on = rloc < X.n;
+                const int pl = X.lo + rloc;
                 double x[PF];
                 unsigned pend = on ? ((1u << X.pf) - 1u) : 0u;
-#pragma unroll
-                for (int q = 0; q < PF; ++q) x[q] = 0.0;
                 unsigned spins = 0;
                 unsigned long long t0 = 0;
-                for (;;) {
+                FT(4);
+                // every round of every lane once (unused ones point at the constant), back to back: most operands are old
 #pragma unroll
-                    for (int q = 0; q < PF; ++q)
-                        if ((pend >> q) & 1u) {
-                            const double y = lds_get(flow_col(X, q));
-                            if (flow_ready(y)) { x[q] = y; pend &= ~(1u << q); }
-                        }
-                    if (!__builtin_amdgcn_ballot_w64(pend != 0u)) break;
-                    if (flow_give_up(a.sync, spins, t0)) break;
+                for (int q = 0; q < PF; ++q) {
+                    x[q] = lds_get(flow_col(X, q));
+                    if (flow_ready(x[q])) pend &= ~(1u << q);
                 }
-                if (on) {
-                    auto ldw = [&](int c) -> double {   // tail entries: one operand at a time
+                // the tail (rows with more than PF * L lower entries: their OLDEST entries), one operand at a time
+                double s = 0.0;
+                if (TAIL && on && (X.tn & 0x7fffffff)) {
+                    auto ldw = [&](int c) -> double {
                         unsigned sp = 0;
                         unsigned long long tt = 0;
                         for (;;) {
@@ -376,26 +378,86 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_tri_flow(FlowArgs a)
                             if (flow_give_up(a.sync, sp, tt)) return 0.0;
                         }
                     };
-                    const int pl = X.lo + rloc;
-                    double un = flow_row<L, PF, TAIL>(a, X, x, S.row0 + pl, sl, ldw);
-                    if (sl == L - 1) {
-                        if (!flow_ready(un)) un = __longlong_as_double((long long)(FLOW_SENT | 0x0008000000000000ull));   // (cannot come out of arithmetic; an untouched u_i could carry it)
-                        lds_put(pl, un);
+                    const int p = S.row0 + pl, kb = a.tia[p], ke = a.tia[p + 1];
+                    s = seq_row_sum<L>(a.tja, a.tval, kb + sl, ke, -1, ldw);
+                }
+                FT(2);
+                // The entries of a row sit in the order of their positions, right-aligned in the chunk's rounds: what is still
+                // missing is in the LAST round(s).  The rounds that are complete are summed while the wave waits.
+                int qr = PF;   // first round somebody still waits for (wave-uniform)
+#pragma unroll
+                for (int q = PF - 1; q >= 0; --q)
+                    if (__builtin_amdgcn_ballot_w64(((pend >> q) & 1u) != 0u)) qr = q;
+#pragma unroll
+                for (int q = 0; q < PF; ++q)
+                    if (q < qr) s += X.v[q] * x[q];
+                if (qr < PF) {
+                    // round after round, oldest first: a tight loop per round somebody misses (read, compare, branch; wave-uniform
+                    // control flow: every lane reads, the lanes that miss decide).  The waits for the older rounds end while the
+                    // chain is still on its way; only the last one is part of it.
+#pragma unroll
+                    for (int q = 0; q < PF; ++q) {
+                        const bool miss = ((pend >> q) & 1u) != 0u;
+                        if (q >= qr && __builtin_amdgcn_ballot_w64(miss)) {
+                            const int c = flow_col(X, q);
+                            double y;
+                            for (;;) {
+                                y = lds_get(c);
+                                if (!__builtin_amdgcn_ballot_w64(miss && !flow_ready(y))) break;
+                                if (flow_give_up(a.sync, spins, t0)) break;
+                            }
+                            if (miss) x[q] = y;
+                        }
+                    }
+                    __builtin_amdgcn_s_setprio(3);   // from here to the store of the row's value the wave is the chain
+                    switch (qr) {   // the remaining rounds, in order
+                        case 0: s += X.v[0] * x[0]; [[fallthrough]];
+                        case 1: s += X.v[1] * x[1]; [[fallthrough]];
+                        case 2: s += X.v[2] * x[2]; [[fallthrough]];
+                        case 3: s += X.v[3] * x[3]; if (PF == 4) break; [[fallthrough]];
+                        case 4: s += X.v[PF - 4] * x[PF - 4]; [[fallthrough]];
+                        case 5: s += X.v[PF - 3] * x[PF - 3]; [[fallthrough]];
+                        case 6: s += X.v[PF - 2] * x[PF - 2]; [[fallthrough]];
+                        default: s += X.v[PF - 1] * x[PF - 1]; break;
                     }
                 }
+                FT(1);
+                if (on) {
+                    double un = flow_row<L>(a, X.t, X.uo, X.d, X.rd, X.tn, s);
+                    if (sl == L - 1) {
+                        lds_put(pl, un);
+                        __hip_atomic_store((gu64*)(a.W + S.row0 + pl), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through: other strips poll it)
+                        a.u[X.row] = un;
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                FT(3);
             };
-            (void)zero_idx;
-            FlowSet<PF> A0, A1;
-            fetch(A0, w);
-            for (int ci = w; ci < S.nchunk; ci += 2 * NWC) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the set about to be used was requested a whole chunk ago; nothing younger is in flight
-                fetch(A1, ci + NWC);
-                run(A0);
+            // A set is TOUCHED (its last load's result named in an empty asm) before the next fetch is issued: whatever wait
+            // the compiler derives for the set lands in front of the younger loads, not behind them.
+            FlowSet<PF> X0, X1, X2;
+            fetch(X0, w);
+            if (NSET == 3) fetch(X1, w + NWC);
+            for (int ci = w; ci < S.nchunk; ci += NSET * NWC) {
+                FT(4); asm volatile("" ::"v"(X0.tn)); FT(0);
+                if (NSET == 3) fetch(X2, ci + 2 * NWC); else fetch(X1, ci + NWC);
+                run(X0);
                 if (ci + NWC >= S.nchunk) break;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                fetch(A0, ci + 2 * NWC);
-                run(A1);
+                FT(4); asm volatile("" ::"v"(X1.tn)); FT(0);
+                if (NSET == 3) fetch(X0, ci + 3 * NWC); else fetch(X0, ci + 2 * NWC);
+                run(X1);
+                if (NSET == 3) {
+                    if (ci + 2 * NWC >= S.nchunk) break;
+                    FT(4); asm volatile("" ::"v"(X2.tn)); FT(0);
+                    fetch(X1, ci + 4 * NWC);
+                    run(X2);
+                }
             }
+#ifdef FLOW_TIMING
+            FT(4);
+            if (lane == 0 && a.nstrips <= 64 && S.nchunk >= 6 * NWC) printf("[flow] strip %3d wave %2d: %4d chunks; per chunk of this wave: slots %.0f, last operand %.0f, all operands %.0f, row %.0f, rest %.0f cycles\n", s, w, (S.nchunk - w + NWC - 1) / NWC,
+                                             (double)ft[0] * NWC / (S.nchunk), (double)ft[1] * NWC / S.nchunk, (double)ft[2] * NWC / S.nchunk, (double)ft[3] * NWC / S.nchunk, (double)ft[4] * NWC / S.nchunk);
+#endif
         }
         __syncthreads();   // every role is done with this strip's LDS
     }

@@ -252,7 +252,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     }
     // ---- fill: chunk descriptors, slots, ghost lists, tails, the rest, the per-row records
     std::vector<FlowStrip> strips((size_t)nstrips);
-    Buf<int2> chunks((size_t)std::max(nchunk, 1));
+    Buf<int4> chunks((size_t)std::max(nchunk, 1));
     Buf<int> cstrip((size_t)std::max(nchunk, 1)), clev((size_t)std::max(nchunk, 1));
     Buf<unsigned char> slots((size_t)std::max<long long>(slot_bytes, 16));
     Buf<int> gpos((size_t)std::max<long long>(nghost, 1));
@@ -264,6 +264,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
         // ghost index of an earlier position: open addressing, emptied per strip by a stamp
         constexpr int HB = 1 << 16;   // (2 x FLOW_LDS_ENT rounded up: at most FLOW_LDS_ENT distinct keys)
         std::vector<int> hkey((size_t)HB, -1), hval((size_t)HB, 0), hstamp((size_t)HB, -1);
+        std::vector<std::pair<int, double>> low;
 #pragma omp for schedule(dynamic, 1)
         for (int s = 0; s < nstrips; ++s) {
             const int q0 = sq0[s], q1 = sq0[s + 1];
@@ -290,7 +291,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
                 while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
                 const int pf = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L)), nr = e - p, nl = nr * L;
                 pfmax = std::max(pfmax, pf);
-                chunks[(size_t)ck] = make_int2((p - q0) | (nr << 16) | (pf << 24), (int)(off / 16));
+                int wown = -1, wghost = -1;   // the operand expected last: the chunk's highest own row, else its latest ghost
                 cstrip[(size_t)ck] = s; clev[(size_t)ck] = l;
                 unsigned short* cols = reinterpret_cast<unsigned short*>(sb + off);
                 double* vals = reinterpret_cast<double*>(sb + off + 16ll * nl);
@@ -298,27 +299,36 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
                 for (long long t = 0; t < 2ll * nl * ((pf + 1) / 2); ++t) vals[t] = 0.0;
                 for (int pp = p; pp < e; ++pp) {
                     const int q = seqof[pp], i = seq[q];
-                    int en = 0;
                     size_t kt = (size_t)tia[pp], kr = (size_t)ria[pp];
                     double dg = 0.0;
+                    low.clear();
                     for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
                         const int j = A.ja[k];
                         if (j == i) { dg = A.val[k]; continue; }   // the last diagonal hit, as the reference's loop leaves it
                         const int pj = j < n ? pos[j] : -1;
-                        if ((unsigned)pj < (unsigned)q) {
-                            const int c = lds_index(newpos[pj]);
-                            if (en < TRI_PFMAX * L) {
-                                const int qe = en / L, lane = (pp - p) * L + en % L;   // round, lane of the chunk
-                                cols[lane * 8 + qe] = (unsigned short)c;
-                                vals[(size_t)(qe / 2) * 2 * nl + (size_t)lane * 2 + (qe & 1)] = A.val[k];
-                            } else { tja[kt] = c; tval[kt] = A.val[k]; ++kt; }
-                            ++en;
-                        } else { rja[kr] = j; rval[kr] = A.val[k]; ++kr; }
+                        if ((unsigned)pj < (unsigned)q) low.emplace_back(pj, A.val[k]);
+                        else { rja[kr] = j; rval[kr] = A.val[k]; ++kr; }
+                    }
+                    // lower entries in the order of their dependency classes (= the order in which they become available): what a row
+                    // still waits for sits in its last slots (k_tri_flow sums the complete rounds while it waits)
+                    std::stable_sort(low.begin(), low.end(), [&](const std::pair<int, double>& x, const std::pair<int, double>& y) {   // by (class, sequence): the same order however the strips are cut
+                        return lev[x.first] != lev[y.first] ? lev[x.first] < lev[y.first] : x.first < y.first; });
+                    // right-aligned in the chunk's pf rounds: the row's LAST L entries fill the last round; what does not fit (the oldest) is the tail
+                    const int nlo = (int)low.size(), ntl = std::max(0, nlo - TRI_PFMAX * L), shift = pf * L - (nlo - ntl);
+                    for (int en = 0; en < nlo; ++en) {
+                        const int c = lds_index(newpos[low[(size_t)en].first]);
+                        if (c < F.nrows) wown = std::max(wown, c); else wghost = std::max(wghost, c);
+                        if (en >= ntl) {
+                            const int e2 = en - ntl + shift, qe = e2 / L, lane = (pp - p) * L + e2 % L;   // round, lane of the chunk
+                            cols[lane * 8 + qe] = (unsigned short)c;
+                            vals[(size_t)(qe / 2) * 2 * nl + (size_t)lane * 2 + (qe & 1)] = low[(size_t)en].second;
+                        } else { tja[kt] = c; tval[kt] = low[(size_t)en].second; ++kt; }
                     }
                     const bool alone = !(std::fabs(dg) > SMALLREAL);
                     dr[2 * (size_t)pp] = dg; dr[2 * (size_t)pp + 1] = alone ? 0.0 : 1.0 / dg;
                     tr[2 * (size_t)pp] = (tia[(size_t)pp + 1] - tia[pp]) | (alone ? (int)0x80000000 : 0); tr[2 * (size_t)pp + 1] = i;
                 }
+                chunks[(size_t)ck] = make_int4((p - q0) | (nr << 16) | (pf << 24), (int)(off / 16), wown >= 0 ? wown : wghost >= 0 ? wghost : zero_idx, 0);
                 off += 16ll * nl * (1 + (pf + 1) / 2);
                 p = e;
             }
@@ -337,7 +347,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     }
     S.release();
     int st = FASP_SUCCESS;
-    FlowStrip* d_strips = nullptr; int2* d_chunks = nullptr;
+    FlowStrip* d_strips = nullptr; int4* d_chunks = nullptr;
     if ((st = split_upload(S, &d_strips, strips)) < 0) return st;
     if ((st = split_upload(S, &d_chunks, chunks.data(), (size_t)nchunk)) < 0) return st;
     S.d_strips = d_strips; S.d_chunks = d_chunks;
@@ -434,7 +444,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     const int ns = S.ns;
     if (ns == 0) return FASP_SUCCESS;
     FlowArgs fa{};
-    fa.strips = (const FlowStrip*)S.d_strips; fa.chunks = (const int2*)S.d_chunks; fa.slots = S.d_slots; fa.gpos = S.d_gpos; fa.cstrip = S.d_cstrip;
+    fa.strips = (const FlowStrip*)S.d_strips; fa.chunks = (const int4*)S.d_chunks; fa.slots = S.d_slots; fa.gpos = S.d_gpos; fa.cstrip = S.d_cstrip;
     fa.tia = S.d_tia; fa.tja = S.d_tja; fa.tval = S.d_tval; fa.rec = S.d_rec; fa.dr = S.d_dr; fa.tr = S.d_tr; fa.W = S.d_W; fa.u = D.x;
     fa.sync = S.d_prog; fa.nstrips = S.nstrips; fa.form = form; fa.w = w;
     // pass (1): everything that reads old values, all rows at once
@@ -464,8 +474,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     if (g_tune.seq_flow && S.flow_ok && !g_flow_disabled) {
         if (seq_err_check() < 0) return ERROR_MISC;   // an earlier sweep's time-out that has arrived meanwhile
         const size_t dyn = sizeof(double) * ((size_t)S.maxent + 1);
-        const int per_cu = std::max(1, std::min(2048 / FLOW_THREADS, (int)((160 * 1024 - 64) / (dyn + 16))));
-        const int grid = std::max(1, std::min(S.nstrips, per_cu * g_ctx.num_cu));
+        const int by_lds = (int)((160 * 1024 - 64) / (dyn + 16));
 #define FLOW_ONE(LL, PP, TT)                                                                                                \
         {                                                                                                                   \
             static bool attr_set = false;                                                                                   \
@@ -474,7 +483,9 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (FLOW_LDS_ENT + 1)))); \
                 attr_set = true;                                                                                            \
             }                                                                                                               \
-            hipLaunchKernelGGL((k_tri_flow<LL, PP, TT>), dim3(grid), dim3(FLOW_THREADS), dyn, g_ctx.stream, fa);            \
+            const int nt = FlowGeom<PP>::NT, per_cu = std::max(1, std::min(2048 / nt, by_lds));                             \
+            const int grid = std::max(1, std::min(S.nstrips, per_cu * g_ctx.num_cu));                                       \
+            hipLaunchKernelGGL((k_tri_flow<LL, PP, TT>), dim3(grid), dim3(nt), dyn, g_ctx.stream, fa);                      \
         }
 #define FLOW_LAUNCH(LL)                                                                                                     \
         if (S.ntail) FLOW_ONE(LL, TRI_PFMAX, true)                                                                          \

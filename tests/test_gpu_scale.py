@@ -213,26 +213,29 @@ def _gs_params(smoother, order, w=1.0):
 @pytest.mark.parametrize("smoother,order,w", [(T.SMOOTHER_GS, 1, 1.0), (T.SMOOTHER_GS, 0, 1.0), (T.SMOOTHER_SOR, 0, 1.1)],
                          ids=["GS-CF", "GS-natural", "SOR-natural"])
 def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
-    """The triangular solve of a sequential sweep (seq_split.hip.h) runs in one workgroup where the dependency classes are
-    narrow (k_tri_block: a barrier per chunk, the new values in an LDS ring -- or through the L2 with the ring switched off),
-    in a cluster of workgroups on one XCD where they are wide (k_tri_cluster: a barrier among the workgroups per class), or
-    as one launch per class (k_tri_level).  Same slots, same row arithmetic: identical bits."""
+    """The triangular solve of a sequential sweep (seq_split.hip.h) runs as a dataflow over strips of the sweep sequence
+    (k_tri_flow: values in LDS inside a strip, through W in memory between strips, a value is its own flag) or as one
+    launch per dependency class (k_tri_level).  Same slots, same row arithmetic: identical bits -- with one strip per
+    level, with the strips of the default size, and with strips of 16 KB (dozens of strips per level: ghosts, importer and
+    exporter waves, the ticket counter all at work)."""
     n = 40
     ia, ja, a, f, ue = fa.poisson7pt(n)
     itp, amgp = _gs_params(smoother, order, w)
-    H = fa.AMG(ia, ja, a, amgp)
     L = fa.lib()
     r = np.random.default_rng(11).standard_normal(len(f))
+    out = []
     try:
-        out = []
-        for sb, ring, cl in ((1, 1, 1), (0, 1, 0), (1, 0, 0), (0, 1, 1)):
-            L.fasp_hip_tune(b"seq_block", sb); L.fasp_hip_tune(b"seq_ulds", ring); L.fasp_hip_tune(b"seq_cluster", cl)
+        for flow, kb in ((1, 512), (0, 512), (1, 16), (1, 1 << 20)):
+            L.fasp_hip_tune(b"seq_flow", flow); L.fasp_hip_tune(b"seq_strip_kb", kb)
+            H = fa.AMG(ia, ja, a, amgp)    # (the strips are cut when a level's schedule is built: one hierarchy per setting)
             out.append(H.precond(r))
+            out.append(H.precond(out[-1]))
+            H.close()
     finally:
-        L.fasp_hip_tune(b"seq_block", 1); L.fasp_hip_tune(b"seq_ulds", 1); L.fasp_hip_tune(b"seq_cluster", 1)
-    for o in out[1:]:
-        assert np.array_equal(out[0], o)
-    H.close()
+        L.fasp_hip_tune(b"seq_flow", 1); L.fasp_hip_tune(b"seq_strip_kb", 512)
+    assert np.all(np.isfinite(out[0]))
+    for k in range(2, len(out), 2):
+        assert np.array_equal(out[0], out[k]) and np.array_equal(out[1], out[k + 1])
 
 
 @pytest.mark.gpu

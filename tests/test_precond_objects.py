@@ -250,11 +250,11 @@ def test_standalone_sweeps_on_a_ragged_matrix(gpu, which):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["gs_fwd", "sor_bwd"])
-def test_standalone_sweeps_with_far_entries(gpu, which):
+def test_standalone_sweeps_with_distant_couplings(gpu, which):
     """A 5-point grid in natural order (anti-diagonal dependency classes, every row reads the class before) plus twenty
-    couplings 19 000 rows back, with the LDS ring of the one-workgroup triangular solve cut to 8 192 values
-    (fasp_hip_tune("seq_ring")): those twenty are FAR entries -- read from W in memory while everything else comes from
-    the ring (the path levels 1-2 of a 128^3 hierarchy take; FASP_HIP_SETUP_TIMING=1 prints the count)."""
+    couplings 19 000 rows back, with the strips of the dataflow triangular solve cut to 16 KB
+    (fasp_hip_tune("seq_strip_kb")): a few dozen strips, every one reading its predecessor's last grid line and twenty of
+    them a row far behind -- ghosts that travel through W in memory (FASP_HIP_SETUP_TIMING=1 prints the counts)."""
     import scipy.sparse as sp
     L = fa.lib()
     nx, ny = 200, 100
@@ -284,7 +284,7 @@ def test_standalone_sweeps_with_far_entries(gpu, which):
                 else: d = al[k]
             ref[i] = t * (1.0 / d) if which.startswith("gs") else w * (t / d) + (1 - w) * ref[i]
     try:
-        L.fasp_hip_tune(b"seq_ring", 8192)
+        L.fasp_hip_tune(b"seq_strip_kb", 16)
         if which.startswith("gs"):
             L.fasp_smoother_dcsr_gs.argtypes = [C.POINTER(T.dvector), C.c_int, C.c_int, C.c_int, C.POINTER(T.dCSRmat), C.POINTER(T.dvector), C.c_int]
             L.fasp_smoother_dcsr_gs.restype = None
@@ -294,5 +294,5 @@ def test_standalone_sweeps_with_far_entries(gpu, which):
             L.fasp_smoother_dcsr_sor.restype = None
             L.fasp_smoother_dcsr_sor(C.byref(uv), i1, i2, s, C.byref(A), C.byref(bv), 2, w)
     finally:
-        L.fasp_hip_tune(b"seq_ring", 16384)
+        L.fasp_hip_tune(b"seq_strip_kb", 512)
     assert np.abs(u - ref).max() <= 1e-12 * np.abs(ref).max()

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Development: a second libfasp_hip.so with extra -D flags beside the product build, for in-one-box A/B runs
+# (FASP_HIP_LIB=build/libfasp_hip_<tag>.so python tools/...).  usage: tools/build_variant.sh <tag> [-DFLAG ...]
+set -e
+cd "$(dirname "$0")/.."
+tag=$1; shift
+mkdir -p build
+make -s -C faspsolver_amd/csrc
+/opt/rocm/bin/hipcc "$@" --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fopenmp=libgomp -Wno-unused-function -Wno-unused-result \
+    -c faspsolver_amd/csrc/solver.hip -o build/solver_$tag.o
+cd faspsolver_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../../build/libfasp_hip_$tag.so host_setup.o dist_plan.o comm.o param_input.o reorder.o ../../build/solver_$tag.o \
+    -L/opt/rocm/lib -lamdhip64 -lgomp -ldl -Wl,-rpath,/opt/rocm/lib
+echo built build/libfasp_hip_$tag.so

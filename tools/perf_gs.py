@@ -1,6 +1,6 @@
 """Reference DEFAULT parameters (GS smoother with C/F ordering) and SOR on P7(n): solve time of the parity mode (the
-reference's sequential sweep as a parallel pass + a triangular solve, seq_split.hip.h; seq_block 0 = one launch per
-dependency class everywhere) and of the flagged multicolour mode (fasp_hip_tune("gs_multicolor", 1): one launch per
+reference's sequential sweep as a parallel pass + a triangular solve, seq_split.hip.h; seq_flow 0 = one launch per
+dependency class instead of the dataflow form) and of the flagged multicolour mode (fasp_hip_tune("gs_multicolor", 1): one launch per
 colour, a different iteration), next to the Jacobi-smoothed solve of the benchmark.
 Development tool: python tools/perf_gs.py [n]"""
 import os, sys, time
@@ -19,9 +19,9 @@ for name, mod in cases:
     amgp = fa.param_amg_init(); mod(amgp)
     t = time.time(); H = fa.AMG(ia, ja, a, amgp); print(f"P7({n}) {name}: setup {time.time()-t:.1f}s levels {H.num_levels}", flush=True)
     H.set_rhs(f)
-    for mc, sb in (((0, 1), (0, 1), (0, 1)) if "Jacobi" in name else ((0, 0), (0, 0), (0, 1), (0, 1), (0, 1), (1, 1), (1, 1))):
-        L.fasp_hip_tune(b"gs_multicolor", mc); L.fasp_hip_tune(b"seq_block", sb)
+    for mc, sb in (((0, 1), (0, 1), (0, 1)) if "Jacobi" in name else ((0, 1), (0, 1), (0, 1), (0, 0), (0, 0), (1, 1), (1, 1))):
+        L.fasp_hip_tune(b"gs_multicolor", mc); L.fasp_hip_tune(b"seq_flow", sb)
         st, hist, stats = H.solve_resident(itp)
-        print(f"  gs_multicolor {mc} seq_block {sb}: iters {st} relres {stats.relres:.10e} solve {stats.solve_seconds*1e3:.1f} ms coarse its {stats.coarse_iters}", flush=True)
+        print(f"  gs_multicolor {mc} seq_flow {sb}: iters {st} relres {stats.relres:.10e} solve {stats.solve_seconds*1e3:.1f} ms coarse its {stats.coarse_iters}", flush=True)
     H.close()
-L.fasp_hip_tune(b"gs_multicolor", 0); L.fasp_hip_tune(b"seq_block", 1)
+L.fasp_hip_tune(b"gs_multicolor", 0); L.fasp_hip_tune(b"seq_flow", 1)
