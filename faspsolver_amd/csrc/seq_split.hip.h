@@ -41,9 +41,11 @@
 // and the A/B partner of the bit-identity test.
 //
 // Storage of the lower part.  Per chunk of nl = rows * L lanes, at a 16-byte-aligned offset from the strip's base:
-//     nl * 16 bytes   columns: eight 16-bit LDS indices per lane (round q of lane sl = entry q * L + sl of the row)
-//     ceil(pf / 2) planes of nl * 16 bytes   values: rounds 2g, 2g + 1 of a lane side by side
-// (pf <= 8 rounds = what the longest row of the chunk needs).  Everything a chunk needs sits at addresses that follow
+//     nl * 16 bytes   columns: eight 16-bit LDS indices per lane
+//     PF / 2 - (PF - pf) / 2 planes of nl * 16 bytes   values: rounds 2g, 2g + 1 of a lane side by side, g >= (PF - pf) / 2
+// (PF = 4 or 8 rounds per schedule, pf <= PF = what the longest row of the chunk needs).  A row's lower entries are sorted by
+// dependency class and RIGHT-ALIGNED in the PF rounds of L lanes: its last L entries -- the ones it waits for -- are round
+// PF - 1, the L before them round PF - 2, ...; the leading rounds of a short row are empty.  Everything a chunk needs sits at addresses that follow
 // from its 8-byte descriptor: one memory round trip, perfectly coalesced, one chunk ahead.  Unused slots hold (index of
 // a constant 0.0, value 0).  Rows with more than 8 L lower entries keep the excess in a CSR tail (LDS indices too).
 // The per-row scalars travel as three small records: (b - rest, old u_i) from pass (1), (a_ii, 1 / a_ii) and
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_rest(int nseq, const int* __res
             const int r = tr[2 * (size_t)p + 1];
             f64x2_t o;
             o[0] = b[r] - s; o[1] = u[r];
+            if ((unsigned long long)__double_as_longlong(o[1]) == FLOW_SENT) o[1] = __longlong_as_double((long long)(FLOW_SENT | 0x0008000000000000ull));   // (an untouched u_i must not look like "not there yet")
             *reinterpret_cast<f64x2_t*>(rec + 2 * (size_t)p) = o;
             W[p] = __longlong_as_double((long long)FLOW_SENT);
         }
@@ -185,9 +188,10 @@ __device__ __forceinline__ void flow_fetch(const FlowBufs& B, FlowSet<PF>& r, in
         const u32x2_t cq = __builtin_amdgcn_raw_buffer_load_b64(B.slots, off, 0, 0);
         r.cw[0] = cq[0]; r.cw[1] = cq[1];
     }
+    const int g0 = (PF - r.pf) >> 1;   // planes in front of g0 are not stored: rounds that no row of the chunk uses
 #pragma unroll
     for (int g = 0; g < PF / 2; ++g) {
-        const f64x2_t v = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(B.slots, 2 * g < r.pf ? off : FLOW_OOR, (1 + g) * nl * 16, 0));
+        const f64x2_t v = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(B.slots, g >= g0 ? off : FLOW_OOR, (1 + g - g0) * nl * 16, 0));
         r.v[2 * g] = v[0]; r.v[2 * g + 1] = v[1];
     }
     const int rloc = lane / L;
@@ -206,10 +210,8 @@ template <int L>
 __device__ __forceinline__ double flow_row(const FlowArgs& a, double t, double uo, double d, double rd, int tn, double s)
 {
     s = group_sum_last<L>(s);
-    if (tn < 0) {   // a row that is left alone keeps its value -- which must not be mistaken for "not there yet"
-        return (unsigned long long)__double_as_longlong(uo) == FLOW_SENT ? __longlong_as_double((long long)(FLOW_SENT | 0x0008000000000000ull)) : uo;
-    }
-    return tri_update(t - s, d, rd, false, a.form, a.w, uo);
+    const double un = tri_update(t - s, d, rd, false, a.form, a.w, uo);
+    return tn < 0 ? uo : un;   // a row that is left alone keeps its value (pass (1) made sure it does not look like "not there yet")
 }
 
 // descriptors are read through the scalar cache (constant address space: nothing in a launch writes them)
@@ -229,15 +231,15 @@ __device__ __forceinline__ int4 flow_chunk(const FlowArgs& a, int c)
 }
 
 // ONE dependency class per launch, one wavefront per chunk, W in memory (plain loads and stores: launches order them)
-template <int L>
+template <int L, int PF>
 __global__ __launch_bounds__(64) void k_tri_level(FlowArgs a, const int* __restrict__ lchunks, int c0)
 {
     const int lane = threadIdx.x;
     const int ck = lchunks[c0 + blockIdx.x];
     const FlowStrip S = flow_strip(a, __builtin_amdgcn_readfirstlane(a.cstrip[ck]));
     const FlowBufs B = flow_bufs(a, S);
-    FlowSet<TRI_PFMAX> r;
-    flow_fetch<L, TRI_PFMAX>(B, r, flow_chunk(a, __builtin_amdgcn_readfirstlane(ck)), lane);
+    FlowSet<PF> r;
+    flow_fetch<L, PF>(B, r, flow_chunk(a, __builtin_amdgcn_readfirstlane(ck)), lane);
     const int rloc = lane / L, sl = lane & (L - 1);
     auto ldw = [&](int c) -> double {   // LDS index -> position
         if (c < S.nrows) return a.W[S.row0 + c];
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(64) void k_tri_level(FlowArgs a, const int* __restr
         double s = 0.0;
         if (r.tn & 0x7fffffff) { const int kb = a.tia[p], ke = a.tia[p + 1]; s = seq_row_sum<L>(a.tja, a.tval, kb + sl, ke, -1, ldw); }
 #pragma unroll
-        for (int q = 0; q < TRI_PFMAX; ++q) s += r.v[q] * (q < r.pf ? ldw(flow_col(r, q)) : 0.0);
+        for (int q = 0; q < PF; ++q) s += r.v[q] * ldw(flow_col(r, q));
         const double un = flow_row<L>(a, r.t, r.uo, r.d, r.rd, r.tn, s);
         if (sl == L - 1) a.W[p] = un;
     }
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
                 const bool on = rloc < X.n;
                 const int pl = X.lo + rloc;
                 double x[PF];
-                unsigned pend = on ? ((1u << X.pf) - 1u) : 0u;
+                unsigned pend = on ? (((1u << X.pf) - 1u) << (PF - X.pf)) : 0u;   // the chunk's rounds are the last pf of PF
                 unsigned spins = 0;
                 unsigned long long t0 = 0;
                 FT(4);
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
                     s = seq_row_sum<L>(a.tja, a.tval, kb + sl, ke, -1, ldw);
                 }
                 FT(2);
-                // The entries of a row sit in the order of their positions, right-aligned in the chunk's rounds: what is still
+                // The entries of a row sit in the order of their dependency classes, right-aligned in the PF rounds: what is still
                 // missing is in the LAST round(s).  The rounds that are complete are summed while the wave waits.
                 int qr = PF;   // first round somebody still waits for (wave-uniform)
 #pragma unroll

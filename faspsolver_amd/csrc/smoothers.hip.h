@@ -206,6 +206,11 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     }
     if (!flow_ok) { S.flow_ok = false; return 1; }   // (the caller falls back to whole-row level scheduling: build_schedule + k_seq_level)
     const int nstrips = (int)sq0.size() - 1;
+    // rounds per chunk of this schedule: four where no row needs more (then the kernels with room for four run it)
+    int nlowmax = 0;
+#pragma omp parallel for schedule(static) reduction(max : nlowmax)
+    for (int q = 0; q < ns; ++q) nlowmax = std::max(nlowmax, nlow[q]);
+    const int PFS = (nlowmax + L - 1) / L > 4 ? TRI_PFMAX : 4;
     // ---- per strip: rows by (class, sequence), chunks; positions = strip base + local index
     Buf<int> newpos((size_t)std::max(ns, 1)), seqof((size_t)std::max(ns, 1));   // position of sequence index q; sequence index at position p
     std::vector<int> schunks((size_t)nstrips + 1, 0);
@@ -230,7 +235,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
                 int e = p, mx = 0;
                 while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
                 const int pf = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));
-                by += 16ll * (e - p) * L * (1 + (pf + 1) / 2);
+                by += 16ll * (e - p) * L * (1 + PFS / 2 - (PFS - pf) / 2);
                 ++nch; p = e;
             }
             schunks[(size_t)s + 1] = nch; sbytes[(size_t)s + 1] = by;
@@ -296,7 +301,8 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
                 unsigned short* cols = reinterpret_cast<unsigned short*>(sb + off);
                 double* vals = reinterpret_cast<double*>(sb + off + 16ll * nl);
                 for (int t = 0; t < nl * 8; ++t) cols[t] = (unsigned short)zero_idx;
-                for (long long t = 0; t < 2ll * nl * ((pf + 1) / 2); ++t) vals[t] = 0.0;
+                const int g0 = (PFS - pf) / 2;   // value planes in front of g0 are not stored
+                for (long long t = 0; t < 2ll * nl * (PFS / 2 - g0); ++t) vals[t] = 0.0;
                 for (int pp = p; pp < e; ++pp) {
                     const int q = seqof[pp], i = seq[q];
                     size_t kt = (size_t)tia[pp], kr = (size_t)ria[pp];
@@ -313,15 +319,15 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
                     // still waits for sits in its last slots (k_tri_flow sums the complete rounds while it waits)
                     std::stable_sort(low.begin(), low.end(), [&](const std::pair<int, double>& x, const std::pair<int, double>& y) {   // by (class, sequence): the same order however the strips are cut
                         return lev[x.first] != lev[y.first] ? lev[x.first] < lev[y.first] : x.first < y.first; });
-                    // right-aligned in the chunk's pf rounds: the row's LAST L entries fill the last round; what does not fit (the oldest) is the tail
-                    const int nlo = (int)low.size(), ntl = std::max(0, nlo - TRI_PFMAX * L), shift = pf * L - (nlo - ntl);
+                    // right-aligned in the PFS rounds: the row's LAST L entries fill the last round; what does not fit (the oldest) is the tail
+                    const int nlo = (int)low.size(), ntl = std::max(0, nlo - TRI_PFMAX * L), shift = PFS * L - (nlo - ntl);
                     for (int en = 0; en < nlo; ++en) {
                         const int c = lds_index(newpos[low[(size_t)en].first]);
                         if (c < F.nrows) wown = std::max(wown, c); else wghost = std::max(wghost, c);
                         if (en >= ntl) {
                             const int e2 = en - ntl + shift, qe = e2 / L, lane = (pp - p) * L + e2 % L;   // round, lane of the chunk
                             cols[lane * 8 + qe] = (unsigned short)c;
-                            vals[(size_t)(qe / 2) * 2 * nl + (size_t)lane * 2 + (qe & 1)] = low[(size_t)en].second;
+                            vals[(size_t)(qe / 2 - g0) * 2 * nl + (size_t)lane * 2 + (qe & 1)] = low[(size_t)en].second;
                         } else { tja[kt] = c; tval[kt] = low[(size_t)en].second; ++kt; }
                     }
                     const bool alone = !(std::fabs(dg) > SMALLREAL);
@@ -329,7 +335,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
                     tr[2 * (size_t)pp] = (tia[(size_t)pp + 1] - tia[pp]) | (alone ? (int)0x80000000 : 0); tr[2 * (size_t)pp + 1] = i;
                 }
                 chunks[(size_t)ck] = make_int4((p - q0) | (nr << 16) | (pf << 24), (int)(off / 16), wown >= 0 ? wown : wghost >= 0 ? wghost : zero_idx, 0);
-                off += 16ll * nl * (1 + (pf + 1) / 2);
+                off += 16ll * nl * (1 + PFS / 2 - g0);
                 p = e;
             }
             if (ng != F.nghost || off != sbytes[(size_t)s + 1] - sbytes[(size_t)s] || off > 0x7fffffffll) ++bad;
@@ -367,7 +373,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     HIPCK(hipMalloc((void**)&S.d_W, sizeof(double) * (size_t)std::max(ns, 1))); S.owned.push_back(S.d_W);
     HIPCK(hipMemset(S.d_W, 0, sizeof(double) * (size_t)std::max(ns, 1)));
     if ((st = split_upload(S, &S.d_prog, std::vector<unsigned>(64, 0u))) < 0) return st;   // [0] ticket counter, [1] error word
-    S.ns = ns; S.L = L; S.nolower = lower_total == 0; S.ntail = ntail; S.pfmax = pfmax; S.nstrips = nstrips; S.nchunk = nchunk; S.maxent = maxent;
+    S.ns = ns; S.L = L; S.nolower = lower_total == 0; S.ntail = ntail; S.pfmax = PFS; (void)pfmax; S.nstrips = nstrips; S.nchunk = nchunk; S.maxent = maxent;
     S.nghost = nghost; S.slot_bytes = slot_bytes; S.flow_ok = flow_ok;
     const double avg_rest = ns > 0 ? (double)nrest_total / ns : 0.0;
     S.LR = 1;
@@ -510,7 +516,8 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     for (int l = 0; l < nlev; ++l) {
         const int c0 = S.cptr[l], grid = S.cptr[l + 1] - c0;
         if (grid <= 0) continue;
-#define TRIL_LAUNCH(LL) hipLaunchKernelGGL((k_tri_level<LL>), dim3(grid), dim3(64), 0, g_ctx.stream, fa, (const int*)S.d_lchunks, c0)
+#define TRIL_LAUNCH(LL) if (S.pfmax > 4) hipLaunchKernelGGL((k_tri_level<LL, TRI_PFMAX>), dim3(grid), dim3(64), 0, g_ctx.stream, fa, (const int*)S.d_lchunks, c0); \
+                        else hipLaunchKernelGGL((k_tri_level<LL, 4>), dim3(grid), dim3(64), 0, g_ctx.stream, fa, (const int*)S.d_lchunks, c0)
         switch (L) {
             case 1: TRIL_LAUNCH(1); break;
             case 2: TRIL_LAUNCH(2); break;
