@@ -17,13 +17,17 @@ roofline = the level-0 SpMV kernel the solve runs (t = A p fused with the (t,p) 
            + y once) / mean launch time measured with HIP events on the launch stream inside
            the timed solves; frac = that / 8 TB/s, never above 1.  traffic = memory-side bytes
            per launch from the rocprofv3 PMC passes of this same command (tools/profile.sh ->
-           profiles/r02_rocprof/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate passes).
+           profiles/r04_rocprof/traffic.json, falling back to the previous round's: 2 x FETCH_SIZE +
+           WRITE_SIZE, separate passes).
 roofline_plain_csr = the same operator through the plain-CSR kernel (lossless coding switched
            off for these launches): SURVEY 8(d)'s algorithmic bytes 12 nnz + 4 (m+1) + 8 m + 8 m
            are exactly what this kernel moves.  This is north_star's "SpMV >= 60 % of the HBM roofline".
 ceilings = measured 16-byte-per-lane read / copy / triad rates of this device (1 GiB buffers).
 variable_coefficient = a second full solve: -div(kappa grad u) with a smooth kappa of contrast 9 on
            the same grid; no two rows repeat, so every level runs the plain-CSR kernels.
+other_configs = configs 3 and 5 of BASELINE.json at full size and the reference's DEFAULT smoother (Gauss-Seidel in C/F
+           order, the reference's sequential sweep reproduced: csrc/seq_split.hip.h) at 128^3 and 256^3 -- one warm-up solve, then
+           the mean of three timed solves each, with the reference's iteration count beside the measured one.
 cpu_baseline = the oracle (oracle/liboracle.so, a plain-C restatement of the reference's
            serial algorithm with OpenMP row loops) on the node's host cores, same problem, same
            hierarchy, a bounded number of PCG iterations scaled to the full solve; once on all
@@ -264,6 +268,14 @@ def variable_leg(n, system, itp, amgp, timed_solves):
         return None
 
 
+TIMED_SOLVES = 3
+GS256_ITERS_REF = None   # filled in from tests/golden/p7_sweeps_256.npz when that fixture is present
+try:
+    GS256_ITERS_REF = int(np.load(os.path.join(ROOT, "tests", "golden", "p7_sweeps_256.npz"))["gscf_iters"])
+except Exception:
+    pass
+
+
 def other_configs_leg():
     """The other single-GPU configurations of BASELINE.json at full size, and the reference's DEFAULT smoother: one timed solve
     each on a resident hierarchy (second solve: the first one builds lazily what it needs).  Reported beside the headline,
@@ -282,13 +294,16 @@ def other_configs_leg():
         t0 = time.perf_counter()
         G = fa.BSRAMG(ia, ja, val, 3, amgp)
         ts = time.perf_counter() - t0
-        for rep in range(2):
+        secs = []
+        for rep in range(1 + TIMED_SOLVES):
             st, x, hist, stats = G.solve(f, itp)
+            secs.append(stats.solve_seconds)
+        sec = float(np.mean(secs[1:]))
         res["config3"] = {"workload": "P7(128) (x) B3 (6.3 M DOF, 14.6 M blocks), UA-AMG (VMB) + block Jacobi + VGMRES(30), rtol 1e-8",
-                          "ms_per_solve": stats.solve_seconds * 1e3, "iterations": int(st), "iterations_reference": 66,
-                          "relres": stats.relres, "DOF_per_s": len(f) / stats.solve_seconds, "setup_seconds": ts}
+                          "ms_per_solve": sec * 1e3, "timed_solves": TIMED_SOLVES, "iterations": int(st), "iterations_reference": 66,
+                          "relres": stats.relres, "DOF_per_s": len(f) / sec, "setup_seconds": ts}
         G.free()
-        log(f"config 3: {st} iterations, {stats.solve_seconds*1e3:.1f} ms")
+        log(f"config 3: {st} iterations, {sec*1e3:.1f} ms")
     except Exception as e:
         log(f"config 3 leg failed: {e!r}")
     try:   # config 5: anisotropic 27-point operator, SA-AMG + W-cycle + VFGMRES(30)
@@ -300,30 +315,41 @@ def other_configs_leg():
         H = fa.AMG(ia, ja, a, amgp)
         ts = time.perf_counter() - t0
         H.set_rhs(f)
-        for rep in range(2):
+        secs = []
+        for rep in range(1 + TIMED_SOLVES):
             st, hist, stats = H.solve_resident(itp)
+            secs.append(stats.solve_seconds)
+        sec = float(np.mean(secs[1:]))
         res["config5"] = {"workload": "Q1 27-point, anisotropy (1, 1, 0.01), n = 123 (1.86 M rows, 49.4 M nnz), SA-AMG + W-cycle + VFGMRES(30), w-Jacobi, rtol 1e-8",
-                          "ms_per_solve": stats.solve_seconds * 1e3, "iterations": int(st), "iterations_reference": 89,
-                          "relres": stats.relres, "DOF_per_s": len(f) / stats.solve_seconds, "setup_seconds": ts}
+                          "ms_per_solve": sec * 1e3, "timed_solves": TIMED_SOLVES, "iterations": int(st), "iterations_reference": 89,
+                          "relres": stats.relres, "DOF_per_s": len(f) / sec, "setup_seconds": ts}
         H.close()
-        log(f"config 5: {st} iterations, {stats.solve_seconds*1e3:.1f} ms")
+        log(f"config 5: {st} iterations, {sec*1e3:.1f} ms")
     except Exception as e:
         log(f"config 5 leg failed: {e!r}")
-    try:   # the reference's default smoother (Gauss-Seidel, C/F order) in the parity mode
-        ia, ja, a, f, ue = fa.poisson7pt(128)
-        itp, amgp = fa.param_solver_init(), fa.param_amg_init()
-        itp.tol = 1e-8
-        H = fa.AMG(ia, ja, a, amgp)
-        H.set_rhs(f)
-        for rep in range(3):
-            st, hist, stats = H.solve_resident(itp)
-        res["gs_defaults_128"] = {"workload": "P7(128), fasp_param_amg_init defaults (GS smoother in C/F order, the reference's sequential sweep) + PCG, rtol 1e-8",
-                                  "ms_per_solve": stats.solve_seconds * 1e3, "iterations": int(st), "iterations_reference": 8,
-                                  "relres": stats.relres}
-        H.close()
-        log(f"GS defaults at 128^3: {st} iterations, {stats.solve_seconds*1e3:.1f} ms")
-    except Exception as e:
-        log(f"GS-defaults leg failed: {e!r}")
+    # the reference's default smoother (Gauss-Seidel, C/F order) in the parity mode, at 128^3 and at the size of the metric;
+    # reference iteration counts: tests/golden/p7_sweeps_128.npz / p7_sweeps_256.npz (the compiled reference's own runs)
+    for n, its_ref in ((128, 8), (256, GS256_ITERS_REF)):
+        try:
+            ia, ja, a, f, ue = fa.poisson7pt(n)
+            itp, amgp = fa.param_solver_init(), fa.param_amg_init()
+            itp.tol = 1e-8
+            t0 = time.perf_counter()
+            H = fa.AMG(ia, ja, a, amgp)
+            ts = time.perf_counter() - t0
+            H.set_rhs(f)
+            secs = []
+            for rep in range(1 + TIMED_SOLVES):   # (the first solve also builds the sweep schedules of every level)
+                st, hist, stats = H.solve_resident(itp)
+                secs.append(stats.solve_seconds)
+            sec = float(np.mean(secs[1:]))
+            res[f"gs_defaults_{n}"] = {"workload": f"P7({n}), fasp_param_amg_init defaults (GS smoother in C/F order, the reference's sequential sweep) + PCG, rtol 1e-8",
+                                       "ms_per_solve": sec * 1e3, "timed_solves": TIMED_SOLVES, "first_solve_ms": secs[0] * 1e3, "iterations": int(st),
+                                       "iterations_reference": its_ref, "relres": stats.relres, "DOF_per_s": len(f) / sec, "setup_seconds": ts}
+            H.close()
+            log(f"GS defaults at {n}^3: {st} iterations, {sec*1e3:.1f} ms (first solve, with the schedules: {secs[0]*1e3:.0f} ms)")
+        except Exception as e:
+            log(f"GS-defaults leg at {n}^3 failed: {e!r}")
     return res
 
 
@@ -335,7 +361,7 @@ def main():
     ap.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", "256")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variable", action="store_true", help="skip the variable-coefficient second solve")
-    ap.add_argument("--no-extra", action="store_true", help="skip the other configurations (configs 3 and 5 at full size, GS defaults at 128^3)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other configurations (configs 3 and 5 at full size, GS defaults at 128^3 and 256^3)")
     ap.add_argument("--only-variable", action="store_true",
                     help="profiling runs: only the variable-coefficient solve (tools/profile.sh <tag> variable)")
     args = ap.parse_args()

@@ -1,0 +1,349 @@
+// seq_sched.cpp -- host side of the sequential sweeps' split form (seq_split.hip.h): strips, chunks, slots, ghost lists, tails,
+// the rest CSR and the per-row records of one (level, sweep kind), built once on first use.  Pure host code in a translation
+// unit of its own: the OpenMP loops below are compiled by g++ (the HIP translation unit is compiled by clang with
+// -fopenmp=libgomp, which parses the directives and generates NO parallel code -- measured: the fill ran on one thread).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <utility>
+#include <vector>
+
+#include "fasp_internal.h"
+#include "seq_sched.h"
+
+namespace fasp {
+
+int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H)
+{
+    HostThreads host_team;   // (bounded OpenMP team for the row-parallel loops below; the dependency pass itself is sequential)
+    const int n = A.row;
+    double tl = wall_seconds();
+    auto lap = [&](const char* what) { if (timing) { const double t = wall_seconds(); std::printf("    [sweep schedule] %-28s %.3f s\n", what, t - tl); tl = t; } };
+    Buf<int> pos((size_t)std::max(n, 1));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) pos[i] = -1;
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < ns; ++q) pos[seq[q]] = q;
+    // lanes per row from a sample-free pass over the row lengths would need the lower counts; they come out of the dependency pass
+    // below, which therefore runs first with nothing but the matrix: class (dependency level) and number of lower entries per row
+    Buf<int> lev((size_t)std::max(ns, 1)), nlow((size_t)std::max(ns, 1)), nrest((size_t)std::max(ns, 1));
+    int nlev = ns > 0 ? 1 : 0;
+    long long lower_total = 0;
+    for (int q = 0; q < ns; ++q) {
+        const int i = seq[q];
+        int l = 0, c = 0, dg = 0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            const int j = A.ja[k];
+            if (j == i) { ++dg; continue; }
+            if (j < n) { const int pj = pos[j]; if ((unsigned)pj < (unsigned)q) { l = std::max(l, lev[pj]); ++c; } }
+        }
+        lev[q] = l + 1; nlow[q] = c; nrest[q] = A.ia[i + 1] - A.ia[i] - c - dg;
+        nlev = std::max(nlev, l + 1);
+        lower_total += c;
+    }
+    lap("dependency classes");
+    // lanes per row of the triangular part: TRI_PF * L slots cover the lower entries of 90 % of the rows
+    int len90 = 0;
+    {
+        std::vector<long long> hist(258, 0);
+        for (int q = 0; q < ns; ++q) hist[std::min(nlow[q], 257)]++;
+        long long acc = 0;
+        for (int v = 0; v < 258; ++v) { acc += hist[v]; if (acc * 10 >= (long long)ns * 9) { len90 = v; break; } }
+    }
+    // wide classes (levels 1-2 of a 3-D problem: hundreds of rows each): what a chunk costs there is instructions, per LANE
+    // mostly: half the lanes with twice the rounds is less work per row.  Narrow classes (a few rows: the deep levels) are a
+    // latency chain: more lanes, shorter chains.
+    const bool wide = nlev > 0 && ns / nlev >= 128;
+    int L = 1;
+    while (L < 64 && (wide ? TRI_PFMAX : TRI_PF) * L < len90) L *= 2;
+    if (seq_lanes > 0) { L = 1; while (L < 64 && L < seq_lanes) L *= 2; }
+    const int rpw = 64 / L;   // rows per chunk (one wavefront)
+    // ---- strips: contiguous ranges of the sweep sequence, closed when the slot bytes reach the target or the LDS is full
+    // (own rows + distinct earlier rows read + the constant).  Sequential: one more pass over the lower entries.
+    const long long target = std::max(16, strip_kb) * 1024ll;
+    std::vector<int> sq0(1, 0), sng;   // first sequence index of every strip (+ end), ghosts per strip
+    bool flow_ok = true;
+    {
+        Buf<int> gmark((size_t)std::max(ns, 1));
+#pragma omp parallel for schedule(static)
+        for (int q = 0; q < ns; ++q) gmark[q] = -1;
+        int sid = 0, rows = 0, ng = 0;
+        long long bytes = 0;
+        std::vector<int> fresh;
+        for (int q = 0; q < ns; ++q) {
+            const int i = seq[q];
+            const int q0 = sq0.back();
+            const long long rb = 40 + 16ll * L * (1 + (std::min(TRI_PFMAX, (nlow[q] + L - 1) / L) + 1) / 2) + 12ll * std::max(0, nlow[q] - TRI_PFMAX * L);
+            fresh.clear();
+            for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                const int j = A.ja[k];
+                if (j == i || j >= n) continue;
+                const int pj = pos[j];
+                if ((unsigned)pj < (unsigned)q0 && gmark[pj] != sid) { gmark[pj] = sid; fresh.push_back(pj); }
+            }
+            if (rows > 0 && (bytes + rb > target || rows + 1 + ng + (int)fresh.size() + 1 > FLOW_LDS_ENT || rows >= 0xffff)) {
+                // close the strip in front of this row; the row opens the next one: every earlier row it reads is a ghost now
+                sng.push_back(ng);
+                sq0.push_back(q);
+                ++sid; rows = 0; ng = 0; bytes = 0;
+                for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                    const int j = A.ja[k];
+                    if (j == i || j >= n) continue;
+                    const int pj = pos[j];
+                    if ((unsigned)pj < (unsigned)q && gmark[pj] != sid) { gmark[pj] = sid; ++ng; }
+                }
+            } else ng += (int)fresh.size();
+            if (1 + ng + 1 > FLOW_LDS_ENT) flow_ok = false;   // one row that reads more than the LDS holds: no dataflow form for this sweep
+            ++rows; bytes += rb;
+        }
+        if (ns > 0) { sng.push_back(ng); sq0.push_back(ns); }
+    }
+    lap("strips");
+    if (!flow_ok) { H.flow_ok = false; return 1; }   // (the caller falls back to whole-row level scheduling: build_schedule + k_seq_level)
+    const int nstrips = (int)sq0.size() - 1;
+    // rounds per chunk of this schedule: four where no row needs more (then the kernels with room for four run it)
+    int nlowmax = 0;
+#pragma omp parallel for schedule(static) reduction(max : nlowmax)
+    for (int q = 0; q < ns; ++q) nlowmax = std::max(nlowmax, nlow[q]);
+    const int PFS = (nlowmax + L - 1) / L > 4 ? TRI_PFMAX : 4;
+    // ---- per strip: rows by (class, sequence), chunks; positions = strip base + local index
+    Buf<int> newpos((size_t)std::max(ns, 1)), seqof((size_t)std::max(ns, 1));   // position of sequence index q; sequence index at position p
+    std::vector<int> schunks((size_t)nstrips + 1, 0);
+    std::vector<long long> sbytes((size_t)nstrips + 1, 0);
+#pragma omp parallel
+    {
+        std::vector<int> cnt;
+#pragma omp for schedule(dynamic, 1)
+        for (int s = 0; s < nstrips; ++s) {
+            const int q0 = sq0[s], q1 = sq0[s + 1];
+            int lmin = lev[q0], lmax = lev[q0];
+            for (int q = q0; q < q1; ++q) { lmin = std::min(lmin, lev[q]); lmax = std::max(lmax, lev[q]); }
+            cnt.assign((size_t)(lmax - lmin + 2), 0);
+            for (int q = q0; q < q1; ++q) cnt[(size_t)(lev[q] - lmin + 1)]++;
+            for (size_t l = 1; l < cnt.size(); ++l) cnt[l] += cnt[l - 1];
+            for (int q = q0; q < q1; ++q) { const int p = q0 + cnt[(size_t)(lev[q] - lmin)]++; newpos[q] = p; seqof[p] = q; }
+            // chunks: runs of one class, rpw rows at most
+            int nch = 0;
+            long long by = 0;
+            for (int p = q0; p < q1;) {
+                const int l = lev[seqof[p]];
+                int e = p, mx = 0;
+                while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
+                const int pf = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));
+                by += 16ll * (e - p) * L * (1 + PFS / 2 - (PFS - pf) / 2);
+                ++nch; p = e;
+            }
+            schunks[(size_t)s + 1] = nch; sbytes[(size_t)s + 1] = by;
+        }
+    }
+    lap("order and chunks per strip");
+    std::vector<int> sghost((size_t)nstrips + 1, 0);
+    for (int s = 0; s < nstrips; ++s) { schunks[(size_t)s + 1] += schunks[(size_t)s]; sbytes[(size_t)s + 1] += sbytes[(size_t)s]; sghost[(size_t)s + 1] = sghost[(size_t)s] + sng[(size_t)s]; }
+    const int nchunk = nstrips ? schunks[(size_t)nstrips] : 0;
+    const long long slot_bytes = nstrips ? sbytes[(size_t)nstrips] : 0, nghost = nstrips ? sghost[(size_t)nstrips] : 0;
+    // ---- tail and rest offsets by position
+    H.tia.alloc((size_t)ns + 1); H.ria.alloc((size_t)ns + 1);
+    Buf<int>&tia = H.tia, &ria = H.ria;
+    tia[0] = 0; ria[0] = 0;
+    long long ntail = 0, nrest_total = 0;
+    for (int p = 0; p < ns; ++p) {
+        const int q = seqof[p];
+        ntail += std::max(0, nlow[q] - TRI_PFMAX * L); nrest_total += nrest[q];
+        if (ntail > 0x7fffffffll || nrest_total > 0x7fffffffll) return ERROR_INPUT_PAR;
+        tia[(size_t)p + 1] = (int)ntail; ria[(size_t)p + 1] = (int)nrest_total;
+    }
+    lap("offsets");
+    // ---- fill: chunk descriptors, slots, ghost lists, tails, the rest, the per-row records
+    H.strips.assign((size_t)nstrips, FlowStrip{});
+    std::vector<FlowStrip>& strips = H.strips;
+    H.chunks.alloc(4 * (size_t)std::max(nchunk, 1));
+    Buf<int>& chunks = H.chunks;
+    H.cstrip.alloc((size_t)std::max(nchunk, 1));
+    Buf<int>& cstrip = H.cstrip;
+    Buf<int> clev((size_t)std::max(nchunk, 1));
+    H.slots.alloc((size_t)std::max<long long>(slot_bytes, 16));
+    Buf<unsigned char>& slots = H.slots;
+    H.gpos.alloc((size_t)std::max<long long>(nghost, 1));
+    Buf<int>& gpos = H.gpos;
+    H.tja.alloc((size_t)std::max<long long>(ntail, 1)); H.rja.alloc((size_t)std::max<long long>(nrest_total, 1)); H.tr.alloc(2 * (size_t)std::max(ns, 1));
+    Buf<int>&tja = H.tja, &rja = H.rja, &tr = H.tr;
+    H.tval.alloc((size_t)std::max<long long>(ntail, 1)); H.rval.alloc((size_t)std::max<long long>(nrest_total, 1)); H.dr.alloc(2 * (size_t)std::max(ns, 1));
+    Buf<double>&tval = H.tval, &rval = H.rval, &dr = H.dr;
+    int pfmax = 1, maxent = 0, bad = 0;
+#pragma omp parallel reduction(max : pfmax, maxent) reduction(+ : bad)
+    {
+        // ghost index of an earlier position: open addressing, emptied per strip by a stamp
+        constexpr int HB = 1 << 16;   // (2 x FLOW_LDS_ENT rounded up: at most FLOW_LDS_ENT distinct keys)
+        std::vector<int> hkey((size_t)HB, -1), hval((size_t)HB, 0), hstamp((size_t)HB, -1);
+        std::vector<std::pair<int, double>> low;
+#pragma omp for schedule(dynamic, 1)
+        for (int s = 0; s < nstrips; ++s) {
+            const int q0 = sq0[s], q1 = sq0[s + 1];
+            FlowStrip& F = strips[(size_t)s];
+            F.slot0 = sbytes[(size_t)s]; F.row0 = q0; F.nrows = q1 - q0; F.chunk0 = schunks[(size_t)s]; F.nchunk = schunks[(size_t)s + 1] - schunks[(size_t)s];
+            F.ghost0 = sghost[(size_t)s]; F.nghost = sng[(size_t)s];
+            maxent = std::max(maxent, F.nrows + F.nghost);
+            const int zero_idx = F.nrows + F.nghost;
+            int ng = 0;
+            auto lds_index = [&](int p) -> int {   // position of a lower entry -> LDS index of this strip
+                if (p >= q0) return p - q0;
+                unsigned h = ((unsigned)p * 2654435761u) >> 16;
+                for (;; h = (h + 1) & (HB - 1)) {
+                    if (hstamp[h] != s) { hstamp[h] = s; hkey[h] = p; hval[h] = ng; gpos[(size_t)F.ghost0 + ng] = p; return F.nrows + ng++; }
+                    if (hkey[h] == p) return F.nrows + hval[h];
+                }
+            };
+            unsigned char* sb = slots.data() + F.slot0;
+            long long off = 0;
+            int ck = F.chunk0;
+            for (int p = q0; p < q1; ++ck) {
+                const int l = lev[seqof[p]];
+                int e = p, mx = 0;
+                while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
+                const int pf = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L)), nr = e - p, nl = nr * L;
+                pfmax = std::max(pfmax, pf);
+                int wown = -1, wghost = -1;   // the operand expected last: the chunk's highest own row, else its latest ghost
+                cstrip[(size_t)ck] = s; clev[(size_t)ck] = l;
+                unsigned short* cols = reinterpret_cast<unsigned short*>(sb + off);
+                double* vals = reinterpret_cast<double*>(sb + off + 16ll * nl);
+                for (int t = 0; t < nl * 8; ++t) cols[t] = (unsigned short)zero_idx;
+                const int g0 = (PFS - pf) / 2;   // value planes in front of g0 are not stored
+                for (long long t = 0; t < 2ll * nl * (PFS / 2 - g0); ++t) vals[t] = 0.0;
+                for (int pp = p; pp < e; ++pp) {
+                    const int q = seqof[pp], i = seq[q];
+                    size_t kt = (size_t)tia[pp], kr = (size_t)ria[pp];
+                    double dg = 0.0;
+                    low.clear();
+                    for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                        const int j = A.ja[k];
+                        if (j == i) { dg = A.val[k]; continue; }   // the last diagonal hit, as the reference's loop leaves it
+                        const int pj = j < n ? pos[j] : -1;
+                        if ((unsigned)pj < (unsigned)q) low.emplace_back(pj, A.val[k]);
+                        else { rja[kr] = j; rval[kr] = A.val[k]; ++kr; }
+                    }
+                    // lower entries in the order of their dependency classes (= the order in which they become available): what a row
+                    // still waits for sits in its last slots (k_tri_flow sums the complete rounds while it waits)
+                    std::stable_sort(low.begin(), low.end(), [&](const std::pair<int, double>& x, const std::pair<int, double>& y) {   // by (class, sequence): the same order however the strips are cut
+                        return lev[x.first] != lev[y.first] ? lev[x.first] < lev[y.first] : x.first < y.first; });
+                    // right-aligned in the PFS rounds: the row's LAST L entries fill the last round; what does not fit (the oldest) is the tail
+                    const int nlo = (int)low.size(), ntl = std::max(0, nlo - TRI_PFMAX * L), shift = PFS * L - (nlo - ntl);
+                    for (int en = 0; en < nlo; ++en) {
+                        const int c = lds_index(newpos[low[(size_t)en].first]);
+                        if (c < F.nrows) wown = std::max(wown, c); else wghost = std::max(wghost, c);
+                        if (en >= ntl) {
+                            const int e2 = en - ntl + shift, qe = e2 / L, lane = (pp - p) * L + e2 % L;   // round, lane of the chunk
+                            cols[lane * 8 + qe] = (unsigned short)c;
+                            vals[(size_t)(qe / 2 - g0) * 2 * nl + (size_t)lane * 2 + (qe & 1)] = low[(size_t)en].second;
+                        } else { tja[kt] = c; tval[kt] = low[(size_t)en].second; ++kt; }
+                    }
+                    const bool alone = !(std::fabs(dg) > SMALLREAL);
+                    dr[2 * (size_t)pp] = dg; dr[2 * (size_t)pp + 1] = alone ? 0.0 : 1.0 / dg;
+                    tr[2 * (size_t)pp] = (tia[(size_t)pp + 1] - tia[pp]) | (alone ? (int)0x80000000 : 0); tr[2 * (size_t)pp + 1] = i;
+                }
+                { int* cd = &chunks[4 * (size_t)ck]; cd[0] = (p - q0) | (nr << 16) | (pf << 24); cd[1] = (int)(off / 16); cd[2] = wown >= 0 ? wown : wghost >= 0 ? wghost : zero_idx; cd[3] = 0; }
+                off += 16ll * nl * (1 + PFS / 2 - g0);
+                p = e;
+            }
+            if (ng != F.nghost || off != sbytes[(size_t)s + 1] - sbytes[(size_t)s] || off > 0x7fffffffll) ++bad;
+        }
+    }
+    lap("fill");
+    if (bad) { std::fprintf(stderr, "### ERROR: fasp_hip: inconsistent strip bookkeeping in the sweep schedule\n"); return ERROR_MISC; }
+    // chunks by dependency class (k_tri_level): a counting sort
+    H.cptr.assign((size_t)nlev + 1, 0);
+    for (int c = 0; c < nchunk; ++c) H.cptr[(size_t)clev[(size_t)c]]++;
+    for (int l = 0; l < nlev; ++l) H.cptr[(size_t)l + 1] += H.cptr[(size_t)l];
+    H.lchunks.alloc((size_t)std::max(nchunk, 1));
+    Buf<int>& lchunks = H.lchunks;
+    {
+        std::vector<int> cur(H.cptr.begin(), H.cptr.end() - 1);
+        for (int c = 0; c < nchunk; ++c) lchunks[(size_t)cur[(size_t)clev[(size_t)c] - 1]++] = c;
+    }
+    lap("chunks by class");
+    H.ns = ns; H.L = L; H.nolower = lower_total == 0; H.ntail = ntail; H.pfs = PFS; (void)pfmax; H.nstrips = nstrips; H.nchunk = nchunk; H.maxent = maxent;
+    H.nghost = nghost; H.slot_bytes = slot_bytes; H.nrest = nrest_total; H.flow_ok = flow_ok;
+    const double avg_rest = ns > 0 ? (double)nrest_total / ns : 0.0;
+    H.LR = 1;
+    while (H.LR < 64 && 4 * H.LR < avg_rest) H.LR *= 2;
+    return FASP_SUCCESS;
+}
+
+}  // namespace fasp
+
+// Host-side check of a schedule (tests/test_seq_schedule.py, no GPU): build it, then walk it the way the kernels do -- strips in
+// ticket order, chunks in order, every operand through its LDS index (own row, ghost list or the constant) -- for one
+// Gauss-Seidel sweep, and compare with the plain sequential sweep over the same rows.  Returns the largest difference relative
+// to the largest entry (< 0: error).  Also checks what the kernels rely on: every operand of a chunk is produced by an earlier
+// chunk of the strip or by an earlier strip; slots of unused rounds point at the constant.
+extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* seq, int ns, int strip_kb, int lanes)
+{
+    using namespace fasp;
+    if (!Av || !seq || ns < 0) return -1.0;
+    HostCSR A;
+    A.row = Av->row; A.col = Av->col; A.nnz = Av->nnz;
+    A.ia.view(Av->IA, (size_t)Av->row + 1); A.ja.view(Av->JA, (size_t)std::max(Av->nnz, 1)); A.val.view(Av->val, (size_t)std::max(Av->nnz, 1));
+    SplitHost H;
+    const int st = build_split_host(A, seq, ns, strip_kb, lanes, false, H);
+    if (st != FASP_SUCCESS) return st == 1 ? -2.0 : -3.0;
+    const int n = A.row, L = H.L, PF = H.pfs;
+    std::vector<double> u((size_t)n), b((size_t)n), uref;
+    for (int i = 0; i < n; ++i) { u[(size_t)i] = std::sin(0.37 * i) + 0.1; b[(size_t)i] = std::cos(0.11 * i); }
+    uref = u;
+    for (int q = 0; q < ns; ++q) {   // the reference's sweep: t = b_i - sum_{j != i} a_ij u_j, u_i = t / a_ii
+        const int i = seq[q];
+        double t = b[(size_t)i], d = 0.0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) { if (A.ja[k] == i) d = A.val[k]; else t -= A.val[k] * uref[(size_t)A.ja[k]]; }
+        if (std::fabs(d) > SMALLREAL) uref[(size_t)i] = t / d;
+    }
+    std::vector<double> W((size_t)std::max(ns, 1)), rec((size_t)std::max(ns, 1));
+    std::vector<char> done((size_t)std::max(ns, 1), 0);
+    for (int p = 0; p < ns; ++p) {   // pass (1)
+        double s = 0.0;
+        for (int k = H.ria[p]; k < H.ria[p + 1]; ++k) s += H.rval[k] * u[(size_t)H.rja[k]];
+        rec[(size_t)p] = b[(size_t)H.tr[2 * (size_t)p + 1]] - s;
+    }
+    if (H.nolower) { for (int p = 0; p < ns; ++p) { const double d = H.dr[2 * (size_t)p]; if (H.tr[2 * (size_t)p] >= 0) u[(size_t)H.tr[2 * (size_t)p + 1]] = rec[(size_t)p] / d; } }
+    else
+    for (int s = 0; s < H.nstrips; ++s) {
+        const FlowStrip& F = H.strips[(size_t)s];
+        if (F.nrows + F.nghost + 1 > FLOW_LDS_ENT + 1) return -4.0;
+        auto operand = [&](int c, bool& ok) -> double {
+            if (c < F.nrows) { if (!done[(size_t)(F.row0 + c)]) ok = false; return W[(size_t)(F.row0 + c)]; }
+            if (c < F.nrows + F.nghost) { const int gp = H.gpos[(size_t)F.ghost0 + (size_t)(c - F.nrows)]; if (gp >= F.row0 || !done[(size_t)gp]) ok = false; return W[(size_t)gp]; }
+            if (c != F.nrows + F.nghost) ok = false;
+            return 0.0;
+        };
+        for (int ck = F.chunk0; ck < F.chunk0 + F.nchunk; ++ck) {
+            const int* cd = &H.chunks[4 * (size_t)ck];
+            const int lo = cd[0] & 0xffff, nr = (cd[0] >> 16) & 0xff, pf = (cd[0] >> 24) & 0xf, nl = nr * L, g0 = (PF - pf) / 2;
+            const unsigned char* sb = H.slots.data() + F.slot0 + 16ll * cd[1];
+            const unsigned short* cols = reinterpret_cast<const unsigned short*>(sb);
+            const double* vals = reinterpret_cast<const double*>(sb + 16ll * nl);
+            std::vector<double> un((size_t)nr);
+            for (int r = 0; r < nr; ++r) {
+                const int p = F.row0 + lo + r;
+                bool ok = true;
+                double tot = 0.0;
+                for (int sl = 0; sl < L; ++sl) {
+                    const int lane = r * L + sl;
+                    double sacc = 0.0;
+                    for (int k = H.tia[p] + sl; k < H.tia[p + 1]; k += L) sacc += H.tval[k] * operand(H.tja[k], ok);
+                    for (int q = 0; q < PF; ++q) {
+                        const int c = cols[lane * 8 + q];
+                        const double v = q / 2 >= g0 ? vals[(size_t)(q / 2 - g0) * 2 * nl + (size_t)lane * 2 + (q & 1)] : 0.0;
+                        if (q < PF - pf && c != F.nrows + F.nghost) ok = false;
+                        sacc += v * operand(c, ok);
+                    }
+                    tot += sacc;
+                }
+                if (!ok) return -5.0;
+                const double d = H.dr[2 * (size_t)p];
+                un[(size_t)r] = H.tr[2 * (size_t)p] < 0 ? u[(size_t)H.tr[2 * (size_t)p + 1]] : (rec[(size_t)p] - tot) / d;
+            }
+            for (int r = 0; r < nr; ++r) { const int p = F.row0 + lo + r; W[(size_t)p] = un[(size_t)r]; done[(size_t)p] = 1; u[(size_t)H.tr[2 * (size_t)p + 1]] = un[(size_t)r]; }
+        }
+    }
+    double diff = 0.0, big = 0.0;
+    for (int i = 0; i < n; ++i) { diff = std::max(diff, std::fabs(u[(size_t)i] - uref[(size_t)i])); big = std::max(big, std::fabs(uref[(size_t)i])); }
+    return big > 0.0 ? diff / big : diff;
+}

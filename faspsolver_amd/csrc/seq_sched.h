@@ -1,0 +1,34 @@
+// seq_sched.h -- what the host side of the sequential sweeps' split form (seq_sched.cpp) hands to the device side (seq_split.hip.h)
+#pragma once
+#include <vector>
+
+#include "fasp_internal.h"
+
+namespace fasp {
+
+struct FlowStrip {     // 32 bytes
+    long long slot0;   // byte offset of the strip's slot storage
+    int row0, nrows;   // positions [row0, row0 + nrows): LDS index = position - row0
+    int chunk0, nchunk;
+    int ghost0, nghost;   // gpos[ghost0 ..]: positions of the values read from earlier strips; LDS index = nrows + k; the 0.0 sits at nrows + nghost
+};
+constexpr int FLOW_LDS_ENT = 19 * 1024;        // doubles of LDS per strip: rows + ghosts + the constant 0.0
+constexpr int TRI_PFMAX = 8;                   // slot rounds a chunk can store; the kernels come with room for 4 (schedules that never need more) or 8
+constexpr int TRI_PF = 4;                      // slot rounds the lanes-per-row choice aims at
+
+struct SplitHost {
+    int ns = 0, L = 1, LR = 1, pfs = 4, nstrips = 0, nchunk = 0, maxent = 0;
+    bool nolower = false, flow_ok = true;
+    long long ntail = 0, nghost = 0, slot_bytes = 0, nrest = 0;
+    std::vector<FlowStrip> strips;
+    std::vector<int>       cptr;       // dependency class -> first entry of lchunks
+    Buf<int>               chunks;     // 4 ints per chunk: first local row | rows << 16 | rounds << 24, slot offset / 16, LDS index of the operand expected last, 0
+    Buf<int>               cstrip, lchunks, gpos, tia, tja, ria, rja, tr;
+    Buf<unsigned char>     slots;
+    Buf<double>            tval, rval, dr;
+};
+// Returns FASP_SUCCESS, 1 when a row of the sweep reads more earlier rows than a strip's LDS holds (no split form: the caller
+// falls back to whole-row level scheduling), or a negative error code.
+int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H);
+
+}  // namespace fasp

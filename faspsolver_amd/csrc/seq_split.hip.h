@@ -51,15 +51,10 @@
 // The per-row scalars travel as three small records: (b - rest, old u_i) from pass (1), (a_ii, 1 / a_ii) and
 // (tail count, row index) from the schedule.
 #pragma once
+#include "seq_sched.h"
 
 namespace fasp {
 
-struct FlowStrip {     // 32 bytes
-    long long slot0;   // byte offset of the strip's slot storage
-    int row0, nrows;   // positions [row0, row0 + nrows): LDS index = position - row0
-    int chunk0, nchunk;
-    int ghost0, nghost;   // gpos[ghost0 ..]: positions of the values read from earlier strips; LDS index = nrows + k; the 0.0 sits at nrows + nghost
-};
 struct FlowArgs {
     const FlowStrip*     strips;
     const int4*          chunks;   // {first local row | rows << 16 | rounds << 24, offset of the slots in 16-byte units, LDS index of the operand expected last, -}
@@ -80,8 +75,6 @@ struct FlowArgs {
     double               w;
 };
 constexpr unsigned long long FLOW_SENT = 0x7FF4DEADBEEF0001ull;   // a signalling NaN: no arithmetic result carries these bits
-constexpr int FLOW_LDS_ENT = 19 * 1024;        // doubles of LDS per strip: rows + ghosts + the constant 0.0
-constexpr int TRI_PFMAX = 8;                   // slot rounds a chunk can store; the kernels come with room for 4 (schedules that never need more) or 8
 
 // t / d from the stored reciprocal rd = RN(1 / d): q = RN(t rd), then one correction step with the exact remainder
 // (Markstein): q' = RN(q + (t - d q) rd) -- the correctly rounded quotient (the IEEE division the reference performs)
@@ -277,14 +270,22 @@ __device__ __forceinline__ bool flow_give_up(unsigned* sync, unsigned& spins, un
     return false;
 }
 
-// Workgroup size and register sets per compute wave: chunks of four rounds leave room for two sets in the 128 registers of a
-// 1024-thread workgroup (14 compute waves); chunks of eight rounds run in 512-thread workgroups (6 compute waves) with three
-// sets: the slots of the next TWO chunks of a wave are in flight.
+// Workgroup size and register sets per compute wave: 1024-thread workgroups (14 compute waves, 128 registers each) with two sets
+// -- the slots of a wave's NEXT chunk are in flight -- for chunks of four and of eight rounds alike (measured at 128^3 against
+// 512-thread workgroups with three sets for eight rounds: 6 compute waves do not keep up with classes of two or three rows of
+// 450 entries; sweep pair over all levels 3.96 -> 3.36 ms).
+#ifndef FLOW_NIMP
+#define FLOW_NIMP 2   // importer waves per workgroup
+#define FLOW_GB 4     // ghosts per lane and batch
+#endif
 #ifndef FLOW_NT8
-#define FLOW_NT8 512
-#define FLOW_NSET8 3
+#define FLOW_NT8 1024
+#define FLOW_NSET8 2
 #endif
 template <int PF> struct FlowGeom { static constexpr int NT = PF <= 4 ? 1024 : FLOW_NT8, NSET = PF <= 4 ? 2 : FLOW_NSET8; };
+#ifdef FLOW_TIMING
+__device__ unsigned long long g_flow_times[8192];   // start / end of every strip of the last launch (100 MHz clock)
+#endif
 template <int L, int PF, bool TAIL>
 __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
 {
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     extern __shared__ __attribute__((aligned(16))) double flow_lds[];
     __shared__ int s_strip;
-    constexpr int NW = FLOW_THREADS / 64, NIMP = 2, NWC = NW - NIMP;
+    constexpr int NW = FLOW_THREADS / 64, NIMP = FLOW_NIMP, GB = FLOW_GB, NWC = NW - NIMP;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -307,17 +308,20 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
         if (s >= a.nstrips) break;
         const FlowStrip S = flow_strip(a, s);
         const int nent = S.nrows + S.nghost;
+#ifdef FLOW_TIMING
+        const unsigned long long strip_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int i = tid; i < nent; i += FLOW_THREADS) flow_lds[i] = sent;
         if (tid == 0) flow_lds[nent] = 0.0;
         __syncthreads();
         if (wave < NIMP) {
-            // ---- importers: the strip's ghosts, in the order the strip needs them, 256 at a time, batches dealt to the two waves in turn;
+            // ---- importers: the strip's ghosts, in the order the strip needs them, 64 GB at a time, batches dealt to the importer waves in turn;
             // a ghost goes to LDS the moment it is seen
-            for (int g0 = wave * 256; g0 < S.nghost; g0 += NIMP * 256) {
-                int gp[4];
+            for (int g0 = wave * 64 * GB; g0 < S.nghost; g0 += NIMP * 64 * GB) {
+                int gp[GB];
                 unsigned pend = 0u;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < GB; ++k) {
                     const int g = g0 + k * 64 + lane;
                     gp[k] = g < S.nghost ? a.gpos[S.ghost0 + g] : 0;
                     if (g < S.nghost) pend |= 1u << k;
@@ -325,16 +329,16 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
                 unsigned spins = 0;
                 unsigned long long t0 = 0;
                 for (;;) {
-                    unsigned long long v[4];
+                    unsigned long long v[GB];   // (only what is still missing is asked for: every chip-wide poll is a fabric round trip)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = __hip_atomic_load((gu64*)(a.W + gp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int k = 0; k < GB; ++k) v[k] = ((pend >> k) & 1u) ? __hip_atomic_load((gu64*)(a.W + gp[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLOW_SENT;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    for (int k = 0; k < GB; ++k)
                         if (((pend >> k) & 1u) && v[k] != FLOW_SENT) { lds_put(S.nrows + g0 + k * 64 + lane, __longlong_as_double((long long)v[k])); pend &= ~(1u << k); }
                     if (!__builtin_amdgcn_ballot_w64(pend != 0u)) break;
                     if (flow_give_up(a.sync, spins, t0)) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) if ((pend >> k) & 1u) lds_put(S.nrows + g0 + k * 64 + lane, 0.0);
+                        for (int k = 0; k < GB; ++k) if ((pend >> k) & 1u) lds_put(S.nrows + g0 + k * 64 + lane, 0.0);
                         break;
                     }
                 }
@@ -462,6 +466,9 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
 #endif
         }
         __syncthreads();   // every role is done with this strip's LDS
+#ifdef FLOW_TIMING
+        if (tid == 0 && s < 4096) { g_flow_times[2 * s] = strip_t0; g_flow_times[2 * s + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     }
 }
 

@@ -1990,6 +1990,13 @@ void fasp_smoother_dcsr_jacobi(dvector* u, const int i_1, const int i_n, const i
     (void)hipMemcpy(u->val, x, sizeof(double) * n, hipMemcpyDeviceToHost);
 }
 
+#ifdef FLOW_TIMING
+extern "C" int fasp_hip_flow_times(unsigned long long* out, int n)   // (development build only: tools/perf_gs_one.py)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fasp::g_flow_times), sizeof(unsigned long long) * (size_t)std::min(n, 8192)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // development knob: override kernel selection / launch geometry at run time
 int fasp_hip_tune(const char* key, int value)
 {

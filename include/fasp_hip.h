@@ -710,10 +710,10 @@ int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
  *   upload: device_sort (per-row sorts of the long-row levels on the device, default 1);
  *   fusions: fuse_zr ((z, r) of PCG from the last level-0 Jacobi sweep), fuse_presmooth (first Jacobi sweep written with
  *     its right-hand side) -- both default 1, results identical (fuse_presmooth: bit for bit; fuse_zr: to rounding);
- *   sequential sweeps (a parallel pass + a sparse triangular solve, csrc/seq_split.hip.h): seq_block (the triangular
- *     solve in one workgroup where the dependency classes are narrow, default 1), seq_ulds (its new values in an LDS
- *     ring, default 1), seq_lanes (lanes per row, 0 = from the row lengths), seq_cluster (the solve of levels with wide dependency classes by a few workgroups on one XCD with a
- *     barrier per class, default 1), seq_help (helper workgroups reading ahead into the XCD's L2, default 3) -- same slots, same arithmetic, same bits;
+ *   sequential sweeps (a parallel pass + a sparse triangular solve, csrc/seq_split.hip.h): seq_flow (the triangular solve as a
+ *     dataflow over strips of the sweep sequence, default 1; 0 = one launch per dependency class), seq_strip_kb (slot bytes per
+ *     strip when a schedule is built, default 512), seq_lanes (lanes per row, 0 = from the row lengths) -- same slots, same
+ *     arithmetic, same bits;
  *     gs_multicolor = 1 selects the MULTICOLOUR Gauss-Seidel / SOR sweep -- NOT the reference's iteration (rows are
  *     relaxed colour by colour instead of in index order; faster, converges alike, other iteration counts). Default 0:
  *     the reference's sequential sweep, reproduced exactly;
