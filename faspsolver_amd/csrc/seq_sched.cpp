@@ -29,37 +29,9 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     Buf<int> lev((size_t)std::max(ns, 1)), nlow((size_t)std::max(ns, 1)), nrest((size_t)std::max(ns, 1));
     int nlev = ns > 0 ? 1 : 0;
     long long lower_total = 0;
-    for (int q = 0; q < ns; ++q) {
-        const int i = seq[q];
-        int l = 0, c = 0, dg = 0;
-        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
-            const int j = A.ja[k];
-            if (j == i) { ++dg; continue; }
-            if (j < n) { const int pj = pos[j]; if ((unsigned)pj < (unsigned)q) { l = std::max(l, lev[pj]); ++c; } }
-        }
-        lev[q] = l + 1; nlow[q] = c; nrest[q] = A.ia[i + 1] - A.ia[i] - c - dg;
-        nlev = std::max(nlev, l + 1);
-        lower_total += c;
-    }
-    lap("dependency classes");
-    // lanes per row of the triangular part: TRI_PF * L slots cover the lower entries of 90 % of the rows
-    int len90 = 0;
-    {
-        std::vector<long long> hist(258, 0);
-        for (int q = 0; q < ns; ++q) hist[std::min(nlow[q], 257)]++;
-        long long acc = 0;
-        for (int v = 0; v < 258; ++v) { acc += hist[v]; if (acc * 10 >= (long long)ns * 9) { len90 = v; break; } }
-    }
-    // wide classes (levels 1-2 of a 3-D problem: hundreds of rows each): what a chunk costs there is instructions, per LANE
-    // mostly: half the lanes with twice the rounds is less work per row.  Narrow classes (a few rows: the deep levels) are a
-    // latency chain: more lanes, shorter chains.
-    const bool wide = nlev > 0 && ns / nlev >= 128;
-    int L = 1;
-    while (L < 64 && (wide ? TRI_PFMAX : TRI_PF) * L < len90) L *= 2;
-    if (seq_lanes > 0) { L = 1; while (L < 64 && L < seq_lanes) L *= 2; }
-    const int rpw = 64 / L;   // rows per chunk (one wavefront)
-    // ---- strips: contiguous ranges of the sweep sequence, closed when the slot bytes reach the target or the LDS is full
-    // (own rows + distinct earlier rows read + the constant).  Sequential: one more pass over the lower entries.
+    // The ONE sequential pass over the matrix: dependency class and number of lower entries of every row, and the strips --
+    // contiguous ranges of the sweep sequence, closed when the lower part reaches the target size (12 bytes per entry + 40 per
+    // row) or the LDS is full (own rows + distinct earlier rows read + the constant).
     const long long target = std::max(16, strip_kb) * 1024ll;
     std::vector<int> sq0(1, 0), sng;   // first sequence index of every strip (+ end), ghosts per strip
     bool flow_ok = true;
@@ -71,16 +43,23 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
         long long bytes = 0;
         std::vector<int> fresh;
         for (int q = 0; q < ns; ++q) {
-            const int i = seq[q];
-            const int q0 = sq0.back();
-            const long long rb = 40 + 16ll * L * (1 + (std::min(TRI_PFMAX, (nlow[q] + L - 1) / L) + 1) / 2) + 12ll * std::max(0, nlow[q] - TRI_PFMAX * L);
+            const int i = seq[q], q0 = sq0.back();
+            int l = 0, c = 0, dg = 0;
             fresh.clear();
             for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
                 const int j = A.ja[k];
-                if (j == i || j >= n) continue;
+                if (j == i) { ++dg; continue; }
+                if (j >= n) continue;
                 const int pj = pos[j];
-                if ((unsigned)pj < (unsigned)q0 && gmark[pj] != sid) { gmark[pj] = sid; fresh.push_back(pj); }
+                if ((unsigned)pj < (unsigned)q) {
+                    l = std::max(l, lev[pj]); ++c;
+                    if (pj < q0 && gmark[pj] != sid) { gmark[pj] = sid; fresh.push_back(pj); }
+                }
             }
+            lev[q] = l + 1; nlow[q] = c; nrest[q] = A.ia[i + 1] - A.ia[i] - c - dg;
+            nlev = std::max(nlev, l + 1);
+            lower_total += c;
+            const long long rb = 40 + 12ll * c;
             if (rows > 0 && (bytes + rb > target || rows + 1 + ng + (int)fresh.size() + 1 > FLOW_LDS_ENT || rows >= 0xffff)) {
                 // close the strip in front of this row; the row opens the next one: every earlier row it reads is a ghost now
                 sng.push_back(ng);
@@ -98,7 +77,55 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
         }
         if (ns > 0) { sng.push_back(ng); sq0.push_back(ns); }
     }
-    lap("strips");
+    lap("classes and strips");
+    if (lower_total == 0) {
+        // No row of the sweep reads another one's new value (the C rows / the F rows of a 7-point level 0): the sweep is pass (1)
+        // and an elementwise update.  Positions = sequence order; nothing but the rest CSR and the per-row records is needed.
+        H.tia.alloc((size_t)ns + 1); H.ria.alloc((size_t)ns + 1);
+        H.ria[0] = 0;
+        long long nr = 0;
+        for (int q = 0; q < ns; ++q) { H.tia[q] = 0; nr += nrest[q]; if (nr > 0x7fffffffll) return ERROR_INPUT_PAR; H.ria[(size_t)q + 1] = (int)nr; }
+        H.tia[ns] = 0;
+        H.rja.alloc((size_t)std::max<long long>(nr, 1)); H.rval.alloc((size_t)std::max<long long>(nr, 1));
+        H.tr.alloc(2 * (size_t)std::max(ns, 1)); H.dr.alloc(2 * (size_t)std::max(ns, 1));
+        H.tja.alloc(1); H.tval.alloc(1); H.chunks.alloc(4); H.cstrip.alloc(1); H.lchunks.alloc(1); H.gpos.alloc(1); H.slots.alloc(16);
+#pragma omp parallel for schedule(static)
+        for (int q = 0; q < ns; ++q) {
+            const int i = seq[q];
+            size_t kr = (size_t)H.ria[q];
+            double dg = 0.0;
+            for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                if (A.ja[k] == i) { dg = A.val[k]; continue; }
+                H.rja[kr] = A.ja[k]; H.rval[kr] = A.val[k]; ++kr;
+            }
+            const bool alone = !(std::fabs(dg) > SMALLREAL);
+            H.dr[2 * (size_t)q] = dg; H.dr[2 * (size_t)q + 1] = alone ? 0.0 : 1.0 / dg;
+            H.tr[2 * (size_t)q] = alone ? (int)0x80000000 : 0; H.tr[2 * (size_t)q + 1] = i;
+        }
+        lap("rest (no lower entries)");
+        H.cptr.assign(2, 0);
+        H.ns = ns; H.L = 1; H.nolower = true; H.ntail = 0; H.pfs = 4; H.nstrips = 0; H.nchunk = 0; H.maxent = 0; H.nghost = 0; H.slot_bytes = 0; H.nrest = nr; H.flow_ok = true;
+        const double avg = ns > 0 ? (double)nr / ns : 0.0;
+        H.LR = 1;
+        while (H.LR < 64 && 4 * H.LR < avg) H.LR *= 2;
+        return FASP_SUCCESS;
+    }
+    // lanes per row of the triangular part: TRI_PF * L slots cover the lower entries of 90 % of the rows
+    int len90 = 0;
+    {
+        std::vector<long long> hist(258, 0);
+        for (int q = 0; q < ns; ++q) hist[std::min(nlow[q], 257)]++;
+        long long acc = 0;
+        for (int v = 0; v < 258; ++v) { acc += hist[v]; if (acc * 10 >= (long long)ns * 9) { len90 = v; break; } }
+    }
+    // wide classes (levels 1-2 of a 3-D problem: hundreds of rows each): what a chunk costs there is instructions, per LANE
+    // mostly: half the lanes with twice the rounds is less work per row.  Narrow classes (a few rows: the deep levels) are a
+    // latency chain: more lanes, shorter chains.
+    const bool wide = nlev > 0 && ns / nlev >= 128;
+    int L = 1;
+    while (L < 64 && (wide ? TRI_PFMAX : TRI_PF) * L < len90) L *= 2;
+    if (seq_lanes > 0) { L = 1; while (L < 64 && L < seq_lanes) L *= 2; }
+    const int rpw = 64 / L;   // rows per chunk (one wavefront)
     if (!flow_ok) { H.flow_ok = false; return 1; }   // (the caller falls back to whole-row level scheduling: build_schedule + k_seq_level)
     const int nstrips = (int)sq0.size() - 1;
     // rounds per chunk of this schedule: four where no row needs more (then the kernels with room for four run it)

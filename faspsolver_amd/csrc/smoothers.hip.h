@@ -131,26 +131,47 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     const int ns = H.ns;
     S.release();
     S.cptr = H.cptr;
+    // ONE device allocation per schedule (a large hipMalloc costs about a millisecond; there were eighteen), the arrays at
+    // 256-byte-aligned offsets inside it
+    struct Piece { void** dst; const void* src; size_t bytes, copy; };
+    std::vector<Piece> pieces;
+    auto piece = [&](auto** dst, const auto* src, size_t n, bool has_src = true) {
+        using TT = std::remove_pointer_t<std::remove_pointer_t<decltype(dst)>>;
+        pieces.push_back({reinterpret_cast<void**>(dst), src, sizeof(TT) * std::max<size_t>(n, 1), has_src ? sizeof(TT) * n : 0});
+    };
     FlowStrip* d_strips = nullptr; int* d_chunks = nullptr;
-    if ((st = split_upload(S, &d_strips, H.strips)) < 0) return st;
-    if ((st = split_upload(S, &d_chunks, H.chunks.data(), 4 * (size_t)H.nchunk)) < 0) return st;
+    static const unsigned zeros[64] = {};
+    piece(&d_strips, H.strips.data(), H.strips.size());
+    piece(&d_chunks, H.chunks.data(), 4 * (size_t)H.nchunk);
+    piece(&S.d_slots, H.slots.data(), (size_t)H.slot_bytes);
+    piece(&S.d_gpos, H.gpos.data(), (size_t)H.nghost);
+    piece(&S.d_cstrip, H.cstrip.data(), (size_t)H.nchunk);
+    piece(&S.d_lchunks, H.lchunks.data(), (size_t)H.nchunk);
+    piece(&S.d_tia, H.tia.data(), (size_t)ns + 1);
+    piece(&S.d_tja, H.tja.data(), (size_t)H.ntail);
+    piece(&S.d_tval, H.tval.data(), (size_t)H.ntail);
+    piece(&S.d_ria, H.ria.data(), (size_t)ns + 1);
+    piece(&S.d_rja, H.rja.data(), (size_t)H.nrest);
+    piece(&S.d_rval, H.rval.data(), (size_t)H.nrest);
+    piece(&S.d_dr, H.dr.data(), 2 * (size_t)ns);
+    piece(&S.d_tr, H.tr.data(), 2 * (size_t)ns);
+    piece(&S.d_rec, (const double*)nullptr, 2 * (size_t)ns, false);
+    piece(&S.d_W, (const double*)nullptr, (size_t)ns, false);
+    piece(&S.d_prog, zeros, 64);   // [0] ticket counter, [1] error word
+    size_t total = 0;
+    for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
+    char* base = nullptr;
+    HIPCK(hipMalloc((void**)&base, total));
+    S.owned.push_back(base);
+    size_t off = 0;
+    for (const Piece& q : pieces) {
+        *q.dst = base + off;
+        if (q.copy) HIPCK(hipMemcpyAsync(base + off, q.src, q.copy, hipMemcpyHostToDevice, g_ctx.stream));
+        off += (q.bytes + 255) & ~(size_t)255;
+    }
+    HIPCK(hipMemsetAsync(S.d_W, 0, sizeof(double) * (size_t)std::max(ns, 1), g_ctx.stream));
+    HIPCK(hipStreamSynchronize(g_ctx.stream));   // (the host arrays go away with H)
     S.d_strips = d_strips; S.d_chunks = d_chunks;
-    if ((st = split_upload(S, &S.d_slots, H.slots.data(), (size_t)H.slot_bytes)) < 0) return st;
-    if ((st = split_upload(S, &S.d_gpos, H.gpos.data(), (size_t)H.nghost)) < 0) return st;
-    if ((st = split_upload(S, &S.d_cstrip, H.cstrip.data(), (size_t)H.nchunk)) < 0) return st;
-    if ((st = split_upload(S, &S.d_lchunks, H.lchunks.data(), (size_t)H.nchunk)) < 0) return st;
-    if ((st = split_upload(S, &S.d_tia, H.tia.data(), (size_t)ns + 1)) < 0) return st;
-    if ((st = split_upload(S, &S.d_tja, H.tja.data(), (size_t)H.ntail)) < 0) return st;
-    if ((st = split_upload(S, &S.d_tval, H.tval.data(), (size_t)H.ntail)) < 0) return st;
-    if ((st = split_upload(S, &S.d_ria, H.ria.data(), (size_t)ns + 1)) < 0) return st;
-    if ((st = split_upload(S, &S.d_rja, H.rja.data(), (size_t)H.nrest)) < 0) return st;
-    if ((st = split_upload(S, &S.d_rval, H.rval.data(), (size_t)H.nrest)) < 0) return st;
-    if ((st = split_upload(S, &S.d_dr, H.dr.data(), 2 * (size_t)ns)) < 0) return st;
-    if ((st = split_upload(S, &S.d_tr, H.tr.data(), 2 * (size_t)ns)) < 0) return st;
-    HIPCK(hipMalloc((void**)&S.d_rec, sizeof(double) * 2 * (size_t)std::max(ns, 1))); S.owned.push_back(S.d_rec);
-    HIPCK(hipMalloc((void**)&S.d_W, sizeof(double) * (size_t)std::max(ns, 1))); S.owned.push_back(S.d_W);
-    HIPCK(hipMemset(S.d_W, 0, sizeof(double) * (size_t)std::max(ns, 1)));
-    if ((st = split_upload(S, &S.d_prog, std::vector<unsigned>(64, 0u))) < 0) return st;   // [0] ticket counter, [1] error word
     if (timing) std::printf("    [sweep schedule] %-28s %.3f s\n", "upload", wall_seconds() - t0);
     S.ns = ns; S.L = H.L; S.LR = H.LR; S.nolower = H.nolower; S.ntail = H.ntail; S.pfmax = H.pfs; S.nstrips = H.nstrips; S.nchunk = H.nchunk; S.maxent = H.maxent;
     S.nghost = H.nghost; S.slot_bytes = H.slot_bytes; S.flow_ok = H.flow_ok;

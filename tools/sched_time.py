@@ -14,3 +14,7 @@ H = fa.AMG(ia, ja, a, amgp); H.set_rhs(f)
 for rep in range(2):
     st, hist, stats = H.solve_resident(itp)
     print("solve", rep, st, stats.relres, f"{stats.solve_seconds*1e3:.1f} ms", flush=True)
+H2 = fa.AMG(ia, ja, a, amgp); H2.set_rhs(f)   # a second hierarchy in the same process: kernels loaded, what is left is the schedules
+for rep in range(2):
+    st, hist, stats = H2.solve_resident(itp)
+    print("second hierarchy, solve", rep, st, f"{stats.solve_seconds*1e3:.1f} ms", flush=True)
