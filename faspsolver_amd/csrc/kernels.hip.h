@@ -116,29 +116,6 @@ __device__ __forceinline__ double ld_val(const CsrArgs& a, int k)
 {
     return a.nt ? __builtin_nontemporal_load(a.val + k) : a.val[k];
 }
-// four consecutive entries per lane: one 16-byte (8-byte) load of columns, two 16-byte loads of values, at the natural
-// alignment of the ELEMENTS (global memory takes vector loads at dword / halfword alignment)
-typedef unsigned int   u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef unsigned short u16x4_u __attribute__((ext_vector_type(4), aligned(2)));
-typedef double         f64x2_u __attribute__((ext_vector_type(2), aligned(8)));
-__device__ __forceinline__ void ld_ja4(const CsrArgs& a, int k, int (&c)[4])
-{
-    if (a.ja16) {
-        const u16x4_u* p = reinterpret_cast<const u16x4_u*>(a.ja16 + k);
-        const u16x4_u v = a.nt ? __builtin_nontemporal_load(p) : *p;
-        c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
-    } else {
-        const u32x4_u* p = reinterpret_cast<const u32x4_u*>(a.ja + k);
-        const u32x4_u v = a.nt ? __builtin_nontemporal_load(p) : *p;
-        c[0] = (int)v[0]; c[1] = (int)v[1]; c[2] = (int)v[2]; c[3] = (int)v[3];
-    }
-}
-__device__ __forceinline__ void ld_val4(const CsrArgs& a, int k, double (&v)[4])
-{
-    const f64x2_u* p = reinterpret_cast<const f64x2_u*>(a.val + k);
-    const f64x2_u lo = a.nt ? __builtin_nontemporal_load(p) : p[0], hi = a.nt ? __builtin_nontemporal_load(p + 1) : p[1];
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
-}
 // Persistent-grid tile schedule.  Block b visits the virtual indices v = b, b + grid, ...;
 // v is mapped to a row tile so that the tiles an XCD works on (blocks b and b+8 share an
 // XCD) come in runs of G consecutive tiles: neighbouring rows, which gather the same x
@@ -231,51 +208,51 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
         if (t >= a.ntiles) continue;
         const int r = (t + a.tile0) * RPB + rloc;
         if (r < a.nrow) {
-            const int kb = a.ia[r], n = a.ia[r + 1] - kb;
+            const int kb = a.ia[r], ke = a.ia[r + 1];
             double s = 0.0;
-            // Round 4: a lane owns FOUR CONSECUTIVE entries per step (entries 4 (sl + L i) .. + 3 of the row): their columns are
-            // one 16-byte load (8 bytes with 16-bit columns), their values two -- three vector-memory instructions per four
-            // entries where rounds 1-3 issued eight (a 64-lane load costs the address unit the same whatever the bytes per
-            // lane: kernels2.hip.h).  Global loads need dword (halfword) alignment only, so the groups are counted from the
-            // row's first entry: which lane sums what does not depend on where the row lies in memory.  Two groups -- eight
-            // gathers -- in flight per lane; the last, partial group is the row's last four entries with the ones that
-            // belong to other groups masked.
-            auto prods = [&](const int (&c)[4], const double (&v)[4], const double (&x)[4], int from) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q >= from && (OP != OP_JACOBI || c[q] != r)) s += v[q] * x[q];
-            };
-            int e = 4 * sl;
-            for (; e + 4 * L + 3 < n; e += 8 * L) {
-                int c0[4], c1[4];
-                double v0[4], v1[4], x0[4], x1[4];
-                ld_ja4(a, kb + e, c0); ld_ja4(a, kb + e + 4 * L, c1);
-                ld_val4(a, kb + e, v0); ld_val4(a, kb + e + 4 * L, v1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x0[q] = a.x[c0[q]];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x1[q] = a.x[c1[q]];
-                prods(c0, v0, x0, 0);
-                prods(c1, v1, x1, 0);
-            }
-            for (; e + 3 < n; e += 4 * L) {
-                int c0[4];
-                double v0[4], x0[4];
-                ld_ja4(a, kb + e, c0); ld_val4(a, kb + e, v0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x0[q] = a.x[c0[q]];
-                prods(c0, v0, x0, 0);
-            }
-            if (e < n) {   // one to three entries left for this lane
-                if (n >= 4) {
-                    int c0[4];
-                    double v0[4], x0[4];
-                    ld_ja4(a, kb + n - 4, c0); ld_val4(a, kb + n - 4, v0);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x0[q] = a.x[c0[q]];
-                    prods(c0, v0, x0, e - (n - 4));
+            // 4 independent (JA, val) loads and x gathers in flight per lane; the adds stay
+            // in k order
+            int k = kb + sl;
+            for (; k + 3 * L < ke; k += 4 * L) {
+                const int    c0 = ld_ja(a, k);
+                const int    c1 = ld_ja(a, k + L);
+                const int    c2 = ld_ja(a, k + 2 * L);
+                const int    c3 = ld_ja(a, k + 3 * L);
+                const double v0 = ld_val(a, k);
+                const double v1 = ld_val(a, k + L);
+                const double v2 = ld_val(a, k + 2 * L);
+                const double v3 = ld_val(a, k + 3 * L);
+                const double x0 = a.x[c0], x1 = a.x[c1], x2 = a.x[c2], x3 = a.x[c3];
+                if (OP == OP_JACOBI) {
+                    if (c0 != r) s += v0 * x0;
+                    if (c1 != r) s += v1 * x1;
+                    if (c2 != r) s += v2 * x2;
+                    if (c3 != r) s += v3 * x3;
                 } else {
-                    for (int k = kb + e; k < kb + n; ++k) { const int c = ld_ja(a, k); if (OP != OP_JACOBI || c != r) s += ld_val(a, k) * a.x[c]; }
+                    s += v0 * x0;
+                    s += v1 * x1;
+                    s += v2 * x2;
+                    s += v3 * x3;
+                }
+            }
+            if (k < ke) {
+                // the last one to three strides in ONE round trip instead of one each: indices clamped into
+                // the row, padded values replaced by 0 (same adds in the same order, then + 0)
+                const int    kl = ke - 1;
+                const int    k1 = min(k + L, kl), k2 = min(k + 2 * L, kl);
+                const int    c0 = ld_ja(a, k), c1 = ld_ja(a, k1), c2 = ld_ja(a, k2);
+                const double v0 = ld_val(a, k);
+                const double w1 = ld_val(a, k1), w2 = ld_val(a, k2);
+                const double v1 = (k + L < ke) ? w1 : 0.0, v2 = (k + 2 * L < ke) ? w2 : 0.0;
+                const double x0 = a.x[c0], x1 = a.x[c1], x2 = a.x[c2];
+                if (OP == OP_JACOBI) {
+                    if (c0 != r) s += v0 * x0;
+                    if (c1 != r) s += v1 * x1;
+                    if (c2 != r) s += v2 * x2;
+                } else {
+                    s += v0 * x0;
+                    s += v1 * x1;
+                    s += v2 * x2;
                 }
             }
             s = subwave_sum<L>(s);
