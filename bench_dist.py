@@ -34,14 +34,17 @@ def main(args, rank, world, local_rank):
     if ndev <= 0:
         B.log("bench_dist: no HIP device")
         sys.exit(2)
-    if backend == "shm":   # validation transport: the ranks may share devices
+    if backend == "shm" or (backend == "ipc" and ndev < world):   # validation: the ranks may share devices
         os.environ["FASP_HIP_ALLOW_DEVICE_WRAP"] = "1"
-    dev = local_rank % ndev if backend == "shm" else local_rank
+    dev = local_rank % ndev if backend == "shm" or ndev < world else local_rank
     st = L.fasp_hip_set_device(dev)
     assert st == 0, f"set_device({dev}) -> {st}"
     if backend == "shm":
         name = f"fasp_bench_{os.environ.get('MASTER_PORT', '0')}"
         st = L.fasp_hip_comm_init_shm(rank, world, name.encode())
+    elif backend == "ipc":   # peer windows (csrc/comm_ipc.h): hipIpc-mapped device windows, one kernel per exchange, no RCCL call
+        name = f"fasp_bench_{os.environ.get('MASTER_PORT', '0')}"
+        st = L.fasp_hip_comm_init_ipc(rank, world, name.encode())
     else:
         idbuf = C.create_string_buffer(128)
         if rank == 0:
@@ -86,9 +89,11 @@ def main(args, rank, world, local_rank):
         B.log(f"P7({n}) on {world} ranks: one host setup {t_host:.2f} s, + partition/upload = {t_setup:.2f} s, levels {H.num_levels}, "
               f"first replicated level {info0['first_replicated']}, rank-0 rows {info0['nloc']} (+{info0['nghost']} ghosts)")
 
+    cst = (C.c_double * 8)()
     for _ in range(args.warmup):
         st, hist, stats = H.solve_resident(itp)
     L.fasp_hip_device_synchronize()
+    L.fasp_hip_comm_stats(cst, 1)   # counters from here on: the timed solves
     dist.barrier()
     t0 = time.perf_counter()
     spmv_ms = []
@@ -106,6 +111,23 @@ def main(args, rank, world, local_rank):
     lo = chk.clone(); hi = chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     assert torch.equal(lo, hi), "ranks disagree on iteration count / residual"
+    L.fasp_hip_comm_stats(cst, 1)
+    per_solve = [v / args.steps for v in cst]
+    # ONE more solve in the communicator's diagnostic mode: the stream is drained around every exchange / all-reduce /
+    # all-gather, so each call's time is its own and what is left of the solve is this rank's kernels.  A breakdown of a
+    # serialised solve (no overlap of the halo with the interior rows), never part of `value`.
+    L.fasp_hip_comm_timing(1)
+    dist.barrier()
+    td = time.perf_counter()
+    st_d, hist_d, stats_d = H.solve_resident(itp)
+    L.fasp_hip_device_synchronize()
+    t_diag = time.perf_counter() - td
+    L.fasp_hip_comm_timing(0)
+    L.fasp_hip_comm_stats(cst, 1)
+    diag = torch.tensor([t_diag, cst[5], cst[6], cst[7], stats_d.solve_seconds], dtype=torch.float64)
+    dmax = diag.clone(); dmin = diag.clone()
+    dist.all_reduce(dmax, op=dist.ReduceOp.MAX); dist.all_reduce(dmin, op=dist.ReduceOp.MIN)
+    levels_info = [H.dist_info(l) for l in range(H.num_levels)]
     x = H.get_solution()  # own rows filled, the rest zero
     xt = torch.from_numpy(x)
     dist.all_reduce(xt)   # disjoint row ranges: sum assembles the global solution
@@ -133,6 +155,19 @@ def main(args, rank, world, local_rank):
             "iterations": int(st), "relres": stats.relres, "setup_seconds": t_setup, "host_setup_seconds": t_host,
             "max_abs_error_vs_exact": err,
             "roofline": roof,
+            # what the N-GPU number is made of (per solve, rank 0's counts; times from ONE diagnostic solve, max / min over ranks)
+            "comm": {"transport": backend,
+                     "per_solve": {"halo_exchanges": per_solve[0], "allreduces": per_solve[1], "allgathers": per_solve[2],
+                                   "halo_MB_sent_rank0": per_solve[3] * 8e-6, "allgather_MB_rank0": per_solve[4] * 8e-6,
+                                   "allreduces_per_iteration": per_solve[1] / max(1, int(st))},
+                     "diagnostic_solve_ms": {"note": "one solve with the stream drained around every communicator call (serialised: no halo / interior overlap)",
+                                             "total_max": float(dmax[4]) * 1e3, "halo_exchange_max": float(dmax[1]) * 1e3, "halo_exchange_min": float(dmin[1]) * 1e3,
+                                             "allreduce_max": float(dmax[2]) * 1e3, "allreduce_min": float(dmin[2]) * 1e3,
+                                             "allgather_max": float(dmax[3]) * 1e3, "allgather_min": float(dmin[3]) * 1e3,
+                                             "kernels_and_host_rank_max": float(dmax[4] - dmin[1] - dmin[2] - dmin[3]) * 1e3},
+                     "coarse_cg_iterations": int(stats.coarse_iters), "vcycles": int(stats.vcycles),
+                     "levels": [{"level": l, "distributed": int(not i["replicated"]), "rows": i["nglobal"], "rank0_rows": i["nloc"],
+                                 "rank0_ghosts": i["nghost"], "rank0_sends": i["nsend"]} for l, i in enumerate(levels_info)]},
         }
         if not args.no_cpu_baseline:
             # the same routine as the single-GPU line: the oracle on this node's host cores, on rank 0 only, on a bounded

@@ -3,10 +3,15 @@
 // level boundary, scalar all-reduce of the Krylov dot products).  The reference has no
 // distributed path at all; this is new.
 //
-// Two transports behind one interface:
+// Three transports behind one interface:
 //   RCCL  (production): one process per GPU, grouped ncclSend/ncclRecv + ncclAllReduce on
 //         the compute stream, peer-to-peer over xGMI.  RCCL is dlopen'ed on first use so
 //         the single-GPU path does not depend on it.
+//   IPC   (round 4, opt-in: fasp_hip_comm_init_ipc / BENCH_COMM=ipc): peer windows -- every rank maps every peer's uncached
+//         device window (hipIpcGetMemHandle / hipIpcOpenMemHandle; over xGMI between the GPUs of a node, and between
+//         processes that share one GPU: how it is validated here), a halo exchange is ONE kernel that stores the boundary
+//         entries straight into the neighbours' mailboxes, announces them by a sequence word and polls / copies its own
+//         (comm_ipc.h, comm_ipc.hip); all-reduces of the Krylov scalars likewise, summed in rank order.  No RCCL call.
 //   SHM   (validation): host-staged through a POSIX shared-memory segment.  It lets the
 //         whole distributed solver (partition, halo plans, replicated levels, replicated
 //         host control flow) be exercised by several processes that share ONE GPU, which
@@ -28,12 +33,13 @@
 #include <string>
 #include <vector>
 
+#include "comm_ipc.h"
 #include "fasp_internal.h"
 
 namespace fasp {
 namespace {
 
-enum Backend { NONE = 0, RCCL = 1, SHM = 2 };
+enum Backend { NONE = 0, RCCL = 1, SHM = 2, IPC = 3 };
 Backend g_backend = NONE;
 int     g_rank = 0, g_size = 1;
 
@@ -178,15 +184,76 @@ void shm_raise_error()   // (raised before the collective's first barrier releas
     g_comm_failed = true;
 }
 
+
+// ------------------------------------------------------------------ IPC (peer windows)
+struct IpcState {
+    char*     win[IPC_MAX_RANKS] = {};       // win[me]: this rank's window; win[q]: peer q's, mapped
+    size_t    cap = 0;                       // doubles per mailbox
+    size_t    bytes = 0;
+    unsigned* counters = nullptr;            // device: 4 pairs of arrival counters (one pair per stream seen)
+    unsigned* err = nullptr;                 // pinned host word
+    hipStream_t streams[4] = {};
+    int       nstreams = 0;
+    unsigned long long seq_to[IPC_MAX_RANKS] = {}, seq_from[IPC_MAX_RANKS] = {}, red_epoch = 0;
+};
+IpcState g_ipc;
+size_t ipc_mbox_stride() { return g_ipc.cap * sizeof(double) + 256; }
+size_t ipc_mbox_off(int from, int par) { return ((size_t)from * 2 + (size_t)par) * ipc_mbox_stride(); }
+size_t ipc_ack_off(int from) { return (size_t)IPC_MAX_RANKS * 2 * ipc_mbox_stride() + (size_t)from * 256; }
+size_t ipc_red_off(int from, int par) { return ipc_ack_off(IPC_MAX_RANKS) + ((size_t)from * 2 + (size_t)par) * 512; }
+size_t ipc_window_bytes() { return ipc_red_off(IPC_MAX_RANKS, 0); }
+unsigned* ipc_counters_for(hipStream_t s)
+{
+    for (int i = 0; i < g_ipc.nstreams; ++i) if (g_ipc.streams[i] == s) return g_ipc.counters + 2 * i;
+    if (g_ipc.nstreams < 4) { g_ipc.streams[g_ipc.nstreams] = s; return g_ipc.counters + 2 * g_ipc.nstreams++; }
+    return g_ipc.counters;   // (more streams than the solver has: share)
+}
+// one exchange kernel: my messages into the peers' mailboxes, theirs out of mine
+int ipc_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int nrecv, hipStream_t stream)
+{
+    IpcXchgArgs a{};
+    long long total = 0;
+    for (int i = 0; i < nsend; ++i) {
+        if (!sends[i].count) continue;
+        const int q = sends[i].peer;
+        if (sends[i].count > g_ipc.cap || a.ns >= IPC_MAX_RANKS) { std::fprintf(stderr, "### ERROR: fasp_hip: message of %zu doubles exceeds the peer-window mailbox (%zu: FASP_HIP_IPC_CAP)\n", sends[i].count, g_ipc.cap); return ERROR_MISC; }
+        const unsigned long long seq = ++g_ipc.seq_to[q];
+        IpcSend& S = a.s[a.ns++];
+        char* box = g_ipc.win[q] + ipc_mbox_off(g_rank, (int)(seq & 1));
+        S.remote_data = reinterpret_cast<double*>(box);
+        S.remote_flag = reinterpret_cast<unsigned long long*>(box + g_ipc.cap * sizeof(double));
+        S.ack_in = reinterpret_cast<const unsigned long long*>(g_ipc.win[g_rank] + ipc_ack_off(q));
+        S.src = sends[i].buf; S.n = (long long)sends[i].count; S.seq = seq;
+        total += S.n;
+    }
+    for (int i = 0; i < nrecv; ++i) {
+        if (!recvs[i].count) continue;
+        const int q = recvs[i].peer;
+        if (recvs[i].count > g_ipc.cap || a.nr >= IPC_MAX_RANKS) return ERROR_MISC;
+        const unsigned long long seq = ++g_ipc.seq_from[q];
+        IpcRecv& R = a.r[a.nr++];
+        const char* box = g_ipc.win[g_rank] + ipc_mbox_off(q, (int)(seq & 1));
+        R.local_data = reinterpret_cast<const double*>(box);
+        R.local_flag = reinterpret_cast<const unsigned long long*>(box + g_ipc.cap * sizeof(double));
+        R.remote_ack = reinterpret_cast<unsigned long long*>(g_ipc.win[q] + ipc_ack_off(g_rank));
+        R.dst = recvs[i].buf; R.n = (long long)recvs[i].count; R.seq = seq;
+        total += R.n;
+    }
+    if (a.ns == 0 && a.nr == 0) return FASP_SUCCESS;
+    a.counters = ipc_counters_for(stream);
+    a.err = g_ipc.err;
+    return ipc_xchg_launch(a, total, stream) < 0 ? ERROR_MISC : FASP_SUCCESS;
+}
 }  // namespace
 
 int  comm_rank() { return g_rank; }
 int  comm_size() { return g_size; }
-bool comm_failed() { return g_comm_failed; }
-bool comm_shares_devices() { return g_backend == SHM; }
+bool comm_failed() { return g_comm_failed || (g_backend == IPC && g_ipc.err && *g_ipc.err != 0u); }
+static bool g_ipc_shared_device = false;
+bool comm_shares_devices() { return g_backend == SHM || (g_backend == IPC && g_ipc_shared_device); }
 void comm_mark_failed() { g_comm_failed = true; }
 
-int comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream)
+static int comm_allreduce_impl(double* dbuf, int n, unsigned maxmask, hipStream_t stream)
 {
     if (g_size <= 1) return FASP_SUCCESS;
     if (g_backend == SHM) {
@@ -210,6 +277,20 @@ int comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream)
         HCK(hipStreamSynchronize(stream));
         return FASP_SUCCESS;
     }
+    if (g_backend == IPC) {
+        if (n < 0 || n > IPC_RED_MAX) return ERROR_INPUT_PAR;
+        IpcRedArgs a{};
+        const unsigned long long ep = ++g_ipc.red_epoch;
+        const int par = (int)(ep & 1);
+        for (int q = 0; q < g_size; ++q) {
+            char* theirs = g_ipc.win[q] + ipc_red_off(g_rank, par);
+            const char* mine = g_ipc.win[g_rank] + ipc_red_off(q, par);
+            a.remote_val[q] = reinterpret_cast<double*>(theirs); a.remote_flag[q] = reinterpret_cast<unsigned long long*>(theirs + 256);
+            a.local_val[q] = reinterpret_cast<const double*>(mine); a.local_flag[q] = reinterpret_cast<const unsigned long long*>(mine + 256);
+        }
+        a.dbuf = dbuf; a.n = n; a.me = g_rank; a.nranks = g_size; a.maxmask = maxmask; a.epoch = ep; a.err = g_ipc.err;
+        return ipc_allreduce_launch(a, stream) < 0 ? ERROR_MISC : FASP_SUCCESS;
+    }
     int i = 0;
     NCK(g_rccl.GroupStart());
     while (i < n) {  // contiguous runs of equal reduction op
@@ -223,7 +304,7 @@ int comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream)
     return FASP_SUCCESS;
 }
 
-int comm_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int nrecv, hipStream_t stream)
+static int comm_exchange_impl(const CommXfer* sends, int nsend, const CommXfer* recvs, int nrecv, hipStream_t stream)
 {
     if (g_size <= 1) return FASP_SUCCESS;
     if (g_backend == SHM) {
@@ -264,6 +345,7 @@ int comm_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int n
         if (shm_barrier() < 0) return ERROR_MISC;
         return FASP_SUCCESS;
     }
+    if (g_backend == IPC) return ipc_exchange(sends, nsend, recvs, nrecv, stream);
     NCK(g_rccl.GroupStart());
     for (int i = 0; i < nrecv; ++i)
         if (recvs[i].count) NCK(g_rccl.Recv(recvs[i].buf, recvs[i].count, ncclDouble, recvs[i].peer, g_comm, stream));
@@ -273,7 +355,7 @@ int comm_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int n
     return FASP_SUCCESS;
 }
 
-int comm_allgatherv(const double* sendbuf, int sendcount, double* recvbuf, const int* counts,
+static int comm_allgatherv_impl(const double* sendbuf, int sendcount, double* recvbuf, const int* counts,
                     const int* displs, hipStream_t stream)
 {
     if (g_size <= 1) {
@@ -299,6 +381,25 @@ int comm_allgatherv(const double* sendbuf, int sendcount, double* recvbuf, const
         if (shm_barrier() < 0) return ERROR_MISC;
         return FASP_SUCCESS;
     }
+    if (g_backend == IPC) {   // my block into every peer's mailbox, theirs out of mine (blocks longer than a mailbox: in pieces)
+        long long done = 0, most = 0;
+        for (int r = 0; r < g_size; ++r) most = std::max<long long>(most, counts[r]);
+        if (recvbuf + displs[g_rank] != sendbuf)
+            HCK(hipMemcpyAsync(recvbuf + displs[g_rank], sendbuf, sizeof(double) * sendcount, hipMemcpyDeviceToDevice, stream));
+        while (done < most) {
+            const long long piece = std::min<long long>((long long)g_ipc.cap, most - done);
+            std::vector<CommXfer> sends, recvs;
+            for (int r = 0; r < g_size; ++r) {
+                if (r == g_rank) continue;
+                const long long ns = std::max<long long>(0, std::min<long long>(piece, sendcount - done)), nr = std::max<long long>(0, std::min<long long>(piece, counts[r] - done));
+                if (ns > 0) sends.push_back({r, const_cast<double*>(sendbuf) + done, (size_t)ns});
+                if (nr > 0) recvs.push_back({r, recvbuf + displs[r] + done, (size_t)nr});
+            }
+            if (ipc_exchange(sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size(), stream) < 0) return ERROR_MISC;
+            done += piece;
+        }
+        return FASP_SUCCESS;
+    }
     // all-gather with per-rank counts as a group of broadcasts
     NCK(g_rccl.GroupStart());
     for (int r = 0; r < g_size; ++r)
@@ -309,11 +410,54 @@ int comm_allgatherv(const double* sendbuf, int sendcount, double* recvbuf, const
     return FASP_SUCCESS;
 }
 
+
+// ---- counters and (diagnostic mode) times of the three primitives -------------------------------------------------------
+// fasp_hip_comm_stats: [0] halo exchanges, [1] all-reduces, [2] all-gathers, [3] doubles sent in exchanges, [4] doubles
+// contributed to all-gathers, [5..7] seconds in the three (diagnostic mode only: fasp_hip_comm_timing(1) drains the stream in
+// front of and behind every call, so a call's time is its own -- and the solve is serialised: a breakdown, not a benchmark).
+static double g_cstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static bool   g_comm_timing = false;
+struct CommTimer {
+    hipStream_t s; int slot; double t0 = 0.0;
+    CommTimer(hipStream_t s_, int slot_) : s(s_), slot(slot_) { if (g_comm_timing) { (void)hipStreamSynchronize(s); t0 = wall_seconds(); } }
+    ~CommTimer() { if (g_comm_timing) { (void)hipStreamSynchronize(s); g_cstat[slot] += wall_seconds() - t0; } }
+};
+int comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream)
+{
+    if (g_size <= 1) return FASP_SUCCESS;
+    g_cstat[1] += 1.0;
+    CommTimer t(stream, 6);
+    return comm_allreduce_impl(dbuf, n, maxmask, stream);
+}
+int comm_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int nrecv, hipStream_t stream)
+{
+    if (g_size <= 1) return FASP_SUCCESS;
+    g_cstat[0] += 1.0;
+    for (int i = 0; i < nsend; ++i) g_cstat[3] += (double)sends[i].count;
+    CommTimer t(stream, 5);
+    return comm_exchange_impl(sends, nsend, recvs, nrecv, stream);
+}
+int comm_allgatherv(const double* sendbuf, int sendcount, double* recvbuf, const int* counts, const int* displs, hipStream_t stream)
+{
+    if (g_size > 1) { g_cstat[2] += 1.0; g_cstat[4] += (double)sendcount; }
+    CommTimer t(stream, 7);
+    return comm_allgatherv_impl(sendbuf, sendcount, recvbuf, counts, displs, stream);
+}
+
 }  // namespace fasp
 
 using namespace fasp;
 
 extern "C" {
+
+int fasp_hip_comm_timing(int on) { g_comm_timing = on != 0; return FASP_SUCCESS; }
+int fasp_hip_comm_stats(double* out, int reset)
+{
+    if (out) for (int i = 0; i < 8; ++i) out[i] = g_cstat[i];
+    if (reset) for (double& v : g_cstat) v = 0.0;
+    return FASP_SUCCESS;
+}
+
 
 int fasp_hip_comm_unique_id(char* id_out)
 {
@@ -384,8 +528,66 @@ int fasp_hip_comm_init_shm(int rank, int nranks, const char* name)
     return shm_barrier();
 }
 
+// Peer windows (comm_ipc.h): the shared-memory segment /<name> carries the IPC handles and the barriers of start-up and
+// shut-down only; everything during a solve goes from device to device.
+int fasp_hip_comm_init_ipc(int rank, int nranks, const char* name)
+{
+    if (nranks <= 1) { g_rank = 0; g_size = 1; g_backend = NONE; return FASP_SUCCESS; }
+    if (nranks > IPC_MAX_RANKS) return ERROR_INPUT_PAR;
+    const int st = fasp_hip_comm_init_shm(rank, nranks, name);   // (segment, ready handshake, first barrier; the backend is switched below)
+    if (st < 0) return st;
+    size_t cap = 1u << 19;   // doubles per mailbox: 4 MB (a 512^2 halo plane is 2 MB)
+    if (const char* e = std::getenv("FASP_HIP_IPC_CAP")) { const long long v = std::atoll(e); if (v >= 1024) cap = (size_t)v; }
+    g_ipc = IpcState{};
+    g_ipc.cap = cap;
+    g_ipc.bytes = ipc_window_bytes();
+    void* w = nullptr;
+    bool ok = hipExtMallocWithFlags(&w, g_ipc.bytes, hipDeviceMallocUncached) == hipSuccess;
+    if (ok) ok = hipMemset(w, 0, g_ipc.bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    hipIpcMemHandle_t hnd;
+    if (ok) ok = hipIpcGetMemHandle(&hnd, w) == hipSuccess;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    char busid[64] = {0};
+    (void)hipDeviceGetPCIBusId(busid, sizeof(busid), dev);
+    struct Slot { hipIpcMemHandle_t h; char bus[64]; int ok; };
+    static_assert(sizeof(Slot) <= 4096 - 2048 - 64, "handle slot");
+    auto slot = [&](int r) { return reinterpret_cast<Slot*>(shm_box(r)); };   // (the mailbox area of the host-staged transport: unused here)
+    if (ok) { slot(rank)->h = hnd; std::memcpy(slot(rank)->bus, busid, sizeof(busid)); }
+    slot(rank)->ok = ok ? 1 : 0;
+    if (!ok) shm_raise_error();
+    if (shm_barrier() < 0) { std::fprintf(stderr, "### ERROR: fasp_hip: peer-window start-up failed (window allocation or IPC export on a rank)\n"); return ERROR_MISC; }
+    g_ipc.win[rank] = static_cast<char*>(w);
+    g_ipc_shared_device = false;
+    for (int q = 0; q < nranks && ok; ++q) {
+        if (q == rank) continue;
+        if (!std::strcmp(slot(q)->bus, busid)) g_ipc_shared_device = true;   // validation: several ranks on one GPU
+        void* p = nullptr;
+        ok = hipIpcOpenMemHandle(&p, slot(q)->h, hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+        g_ipc.win[q] = static_cast<char*>(p);
+    }
+    if (ok) ok = hipMalloc((void**)&g_ipc.counters, sizeof(unsigned) * 8) == hipSuccess && hipMemset(g_ipc.counters, 0, sizeof(unsigned) * 8) == hipSuccess;
+    if (ok) ok = hipHostMalloc((void**)&g_ipc.err, 64, hipHostMallocDefault) == hipSuccess;
+    if (ok) { std::memset(g_ipc.err, 0, 64); ok = hipDeviceSynchronize() == hipSuccess; }
+    if (!ok) { std::fprintf(stderr, "### ERROR: fasp_hip: rank %d cannot map its peers' windows (hipIpcOpenMemHandle)\n", rank); shm_raise_error(); }
+    if (shm_barrier() < 0) return ERROR_MISC;
+    g_backend = IPC;
+    return FASP_SUCCESS;
+}
+
 int fasp_hip_comm_finalize(void)
 {
+    if (g_backend == IPC && g_shm_base) {
+        (void)hipDeviceSynchronize();
+        (void)shm_barrier();   // nobody unmaps a window a peer may still write
+        for (int q = 0; q < g_size; ++q) if (q != g_rank && g_ipc.win[q]) (void)hipIpcCloseMemHandle(g_ipc.win[q]);
+        (void)shm_barrier();
+        if (g_ipc.win[g_rank]) (void)hipFree(g_ipc.win[g_rank]);
+        if (g_ipc.counters) (void)hipFree(g_ipc.counters);
+        if (g_ipc.err) (void)hipHostFree(g_ipc.err);
+        g_ipc = IpcState{};
+        g_backend = SHM;   // (the segment goes the way of the host-staged transport's)
+    }
     if (g_backend == RCCL && g_comm) {
         NCK(g_rccl.CommDestroy(g_comm));
         g_comm = nullptr;

@@ -735,6 +735,17 @@ int fasp_hip_comm_finalize(void);
 /* Validation transport: host-staged through the POSIX shared-memory segment /<name>, so
  * several processes sharing ONE GPU can run the distributed solver (tests only). */
 int fasp_hip_comm_init_shm(int rank, int nranks, const char* name);
+/* Peer windows (round 4; csrc/comm_ipc.h): every rank maps every peer's uncached device window through hipIpc handles exchanged
+ * in the shared-memory segment /<name>; a halo exchange is one kernel that stores this rank's boundary entries straight into the
+ * neighbours' mailboxes (xGMI stores between the GPUs of a node) and polls / copies its own; the Krylov scalars are reduced the
+ * same way, summed in rank order.  At most 8 ranks (one node); ranks may also share one GPU (validation).  FASP_HIP_IPC_CAP =
+ * doubles per mailbox (default 524 288). */
+int fasp_hip_comm_init_ipc(int rank, int nranks, const char* name);
+/* Counters of the communicator since the last reset: out[0] halo exchanges, [1] all-reduces, [2] all-gathers, [3] doubles sent in
+ * exchanges, [4] doubles contributed to all-gathers, [5..7] seconds spent in the three -- filled only in the diagnostic mode
+ * fasp_hip_comm_timing(1), which drains the stream around every call (a breakdown of a serialised solve, not a benchmark). */
+int fasp_hip_comm_stats(double* out8, int reset);
+int fasp_hip_comm_timing(int on);
 
 /* Row partition of a hierarchy over `nranks` GPUs as rank `rank` sees it (host only; levels
  * with fewer than min_rows rows are replicated).  fasp_hip_amg_upload() builds the same

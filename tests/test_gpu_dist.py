@@ -38,6 +38,9 @@ def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="s
                 time.sleep(0.05)
             ids = open(idfile, "rb").read()
             assert L.fasp_hip_comm_init(rank, world, ids) == 0
+        elif transport == "ipc":   # peer windows between processes that share the box's one GPU
+            assert L.fasp_hip_set_device(0) == 0
+            assert L.fasp_hip_comm_init_ipc(rank, world, name.encode()) == 0
         else:
             assert L.fasp_hip_set_device(0) == 0
             assert L.fasp_hip_comm_init_shm(rank, world, name.encode()) == 0
@@ -141,6 +144,19 @@ def test_distributed_other_krylov_methods_match_oracle(gpu, itsolver):
     """The other Krylov drivers on a row-partitioned level 0: they call halo(v) and then the operator, and the operator
     bundle turns that pair into one overlapped application (cycles.hip.h, csr_ops)."""
     _run_ranks(2, 24, 500, 1, itsolver=itsolver)
+
+
+@pytest.mark.parametrize("world,n,min_rows,cycle,shared,kw", [
+    (2, 24, 500, 1, False, {}), (3, 24, 2000, 1, True, {}), (4, 32, 3000, 2, False, {}), (2, 48, 3000, 1, True, {}),
+    (2, 24, 300, 1, False, {"amg_type": 2}), (2, 24, 500, 1, False, {"itsolver": 6}),
+    (3, 40, 40000, 1, False, {"tune": "coarse_mode=1,coarse_split_min=1024"})],
+    ids=["2 ranks V", "3 ranks one setup", "4 ranks W", "2 ranks 48^3", "SA hierarchy", "VFGMRES", "split-work replicated levels"])
+def test_peer_window_transport_matches_oracle(gpu, world, n, min_rows, cycle, shared, kw):
+    """The peer-window transport (comm_ipc.h: hipIpc-mapped uncached windows, one kernel per halo exchange that stores into the
+    neighbours' mailboxes, all-reduce by the same means, summed in rank order) between processes that share the box's one GPU:
+    the same partition / halo / replicated-level code as over RCCL, against the oracle -- iteration counts, residual histories,
+    every rank's rows of the solution, bit-identical scalars on all ranks."""
+    _run_ranks(world, n, min_rows, cycle, shared, transport="ipc", **kw)
 
 
 def test_rccl_transport_with_all_visible_gpus(gpu):
