@@ -268,6 +268,21 @@ def variable_leg(n, system, itp, amgp, timed_solves):
         return None
 
 
+def device_state():
+    """Clocks and temperatures of GPU 0 as rocm-smi reports them (memory clock, fabric clock, junction / HBM temperature, package
+    power) -- printed next to the measured ceilings: two boxes of the pool whose triad ceilings agree to 1 % have differed by 14 % on
+    the plain-CSR level-0 kernel; this is what can be read without privileges to tell them apart."""
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showtemp", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        pick = lambda k: str(card.get(k, "")).strip("()")
+        return {"mclk": pick("mclk clock speed:"), "fclk": pick("fclk clock speed:"), "sclk_idle": pick("sclk clock speed:"),
+                "temp_junction_C": pick("Temperature (Sensor junction) (C)"), "temp_hbm_C": pick("Temperature (Sensor memory) (C)"),
+                "package_power_W": pick("Current Socket Graphics Package Power (W)")}
+    except Exception as e:   # (no rocm-smi, no permission: the line just lacks the field)
+        return {"unavailable": repr(e)}
+
+
 TIMED_SOLVES = 3
 GS256_ITERS_REF = None   # filled in from tests/golden/p7_sweeps_256.npz when that fixture is present
 try:
@@ -460,8 +475,9 @@ def main():
         if L.fasp_hip_measure_ceilings(out3, C.c_size_t(1 << 30), 5) == 0:
             ceilings = {"unit": "GB/s", "read": out3[0], "copy": out3[1], "triad": out3[2],
                         "buffer_bytes": 1 << 30,
-                        "note": "16 bytes per lane, 1024-block grid, HIP events; roofline fractions use the nominal 8000 GB/s"}
-            log(f"device ceilings: read {out3[0]:.0f}, copy {out3[1]:.0f}, triad {out3[2]:.0f} GB/s")
+                        "note": "16 bytes per lane, 1024-block grid, HIP events; roofline fractions use the nominal 8000 GB/s",
+                        "device_state": device_state()}
+            log(f"device ceilings: read {out3[0]:.0f}, copy {out3[1]:.0f}, triad {out3[2]:.0f} GB/s; {ceilings['device_state']}")
     except Exception as e:
         log(f"ceiling measurement failed: {e!r}")
 

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/fasp_hip.h"
+#include "../../include/fasp_hip_dev.h"
 
 namespace fasp {
 
@@ -114,8 +115,6 @@ struct DistPlan {
     int                    first_replicated = 0;  // levels >= this are replicated
     std::vector<DistLevel> L;
 };
-// Brick-like renumbering of a level from its matrix graph (reorder.cpp): order[k] = old index of the row at new position k.
-void cluster_order(const HostCSR& A, int chunk, std::vector<int>& order);
 // Team size of the host-side OpenMP loops.  A process that does not set OMP_NUM_THREADS would start
 // one thread per hardware thread (hundreds on a GPU node) in every parallel region, and libgomp rebuilds
 // its pool whenever consecutive regions differ in size: measured 0.1 s PER REGION on the MI355X host,

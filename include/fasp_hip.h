@@ -686,46 +686,6 @@ int  fasp_hip_poisson7pt(int nx, int ny, int nz, dCSRmat* A, dvector* b, dvector
 int  fasp_hip_aniso27pt(int n, double kx, double ky, double kz, dCSRmat* A, dvector* b);
 void fasp_hip_free_system(dCSRmat* A, dvector* b, dvector* u);
 
-/* Timed micro-benchmark of one device kernel class on the resident level-0
- * matrix: returns mean milliseconds per launch over `reps` launches measured
- * with HIP events on the launch stream.  kind: 0 = SpMV, 1 = aAxpy(-1),
- * 2 = Jacobi sweep, 3 = dot, 4 = axpy. */
-double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps);
-/* development / test entry: one operator through the resident upload path (coding + kernel selection), ms per launch */
-double fasp_hip_time_matrix(const dCSRmat* A, int op, int reps, int* kind_out);
-/* development / test entry: brick-like cluster order of a square matrix from its graph (order[k] = old index at new position k) */
-int    fasp_hip_cluster_order(const dCSRmat* A, int chunk, int* order);
-/* test entry (host only, no GPU): build the sweep schedule of the rows seq[0..ns) of A (csrc/seq_sched.cpp) and walk it on the host as the
- * device kernels do, against the plain sequential Gauss-Seidel sweep: largest deviation relative to the largest entry; < 0: error
- * (-2: a row reads more earlier rows than a strip holds: no split form) */
-double fasp_hip_seq_schedule_selftest(const dCSRmat* A, const int* seq, int ns, int strip_kb, int lanes);
-/* measured device ceilings reported beside the roofline: out[0..2] = GB/s of a 16-byte-per-lane read, copy and
- * triad over buffers of `bytes` each (>= 512 MiB: beyond the Infinity Cache) */
-int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
-
-/* Run-time switches (A/B tests, profiling, and ONE behavioural mode):
- *   kernel selection / launch geometry: maxgrid, xcd, nt, kind, lanes, wrows, wcap (-1 = automatic), gen2 (0 round-1
- *     kernels, 1, 2 = default), compress (lossless matrix coding on/off), ja16, ws2_bpc, rpl, lds_tab, xcd_pat;
- *   coarse solve: spcg_persist, spcg_fused, spcg_batch, spcg_grid, small_lds, small_onewave (coarsest levels of <= 128
- *     rows: 2 = matrix in registers, four wavefronts (default), 1 = dense in LDS, one wavefront, 0 = the general kernel),
- *     lazy_coarse (the one-launch solvers' verdicts read once per application of the preconditioner, default 1;
- *     2 = replay every first application as if a coarse solve had given up: tests), coarse_mode / coarse_split_min
- *     (multi-GPU: replicated levels computed in row windows + all-gather);
- *   upload: device_sort (per-row sorts of the long-row levels on the device, default 1);
- *   fusions: fuse_zr ((z, r) of PCG from the last level-0 Jacobi sweep), fuse_presmooth (first Jacobi sweep written with
- *     its right-hand side) -- both default 1, results identical (fuse_presmooth: bit for bit; fuse_zr: to rounding);
- *   sequential sweeps (a parallel pass + a sparse triangular solve, csrc/seq_split.hip.h): seq_flow (the triangular solve as a
- *     dataflow over strips of the sweep sequence, default 1; 0 = one launch per dependency class), seq_strip_kb (slot bytes per
- *     strip when a schedule is built, default 512), seq_lanes (lanes per row, 0 = from the row lengths) -- same slots, same
- *     arithmetic, same bits;
- *     gs_multicolor = 1 selects the MULTICOLOUR Gauss-Seidel / SOR sweep -- NOT the reference's iteration (rows are
- *     relaxed colour by colour instead of in index order; faster, converges alike, other iteration counts). Default 0:
- *     the reference's sequential sweep, reproduced exactly;
- *   multi-GPU: halo_overlap (exchange beside the interior rows, default 1), split_rows (test mode: every operator in
- *     three row windows).
- * Unknown keys return ERROR_INPUT_PAR. */
-int fasp_hip_tune(const char* key, int value);
-
 /* Multi-GPU (1-D row partition, RCCL over xGMI).  The unique id is produced on
  * rank 0 and distributed by the caller (e.g. torch.distributed broadcast). */
 #define FASP_HIP_UNIQUE_ID_BYTES 128
@@ -741,27 +701,11 @@ int fasp_hip_comm_init_shm(int rank, int nranks, const char* name);
  * same way, summed in rank order.  At most 8 ranks (one node); ranks may also share one GPU (validation).  FASP_HIP_IPC_CAP =
  * doubles per mailbox (default 524 288). */
 int fasp_hip_comm_init_ipc(int rank, int nranks, const char* name);
-/* Counters of the communicator since the last reset: out[0] halo exchanges, [1] all-reduces, [2] all-gathers, [3] doubles sent in
- * exchanges, [4] doubles contributed to all-gathers, [5..7] seconds spent in the three -- filled only in the diagnostic mode
- * fasp_hip_comm_timing(1), which drains the stream around every call (a breakdown of a serialised solve, not a benchmark). */
-int fasp_hip_comm_stats(double* out8, int reset);
-int fasp_hip_comm_timing(int on);
-
-/* Row partition of a hierarchy over `nranks` GPUs as rank `rank` sees it (host only; levels
- * with fewer than min_rows rows are replicated).  fasp_hip_amg_upload() builds the same
- * plan from the communicator; these entry points expose it to tests.
- * info = {replicated, nglobal, row0, nloc, nghost, nsend, first_replicated_level, nranks};
- * get_matrix: the rank's local rows of A (0) / P (1) / R (2) in local column numbering;
- * get_list:   0 ghost global ids, 1 recv offsets, 2 send offsets, 3 send local ids,
- *             4 ownership offsets of the level. */
-int fasp_hip_dist_plan(fasp_hip_amg* h, int rank, int nranks, int min_rows);
-int fasp_hip_dist_level_info(const fasp_hip_amg* h, int level, int* info);
-int fasp_hip_dist_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view);
-int fasp_hip_dist_get_list(const fasp_hip_amg* h, int level, int which, ivector* view);
-/* one-rank exercise of every RCCL call the transport makes (0 = all results correct) */
-int  fasp_hip_comm_selftest(void);
 int fasp_hip_comm_rank(void);
 int fasp_hip_comm_size(void);
+
+/* Measurement and test entries (kernel timers, run-time switches of the A/B identity tests, partition inspection, self-tests):
+ * include/fasp_hip_dev.h -- in the library, but not part of the drop-in boundary. */
 
 /* Library/version string. */
 const char* fasp_hip_version(void);

@@ -1,5 +1,5 @@
 """libfasp_hip.so loads on a machine without a GPU and exports every symbol that
-include/fasp_hip.h declares; host-only entry points work; compute entry points refuse
+include/fasp_hip.h (the drop-in boundary) and include/fasp_hip_dev.h (measurement / test entries) declare; host-only entry points work; compute entry points refuse
 to run (there is no CPU fallback)."""
 import ctypes as C
 import os
@@ -12,7 +12,7 @@ from _libs import ROOT, T, poisson7pt
 
 
 def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "fasp_hip.h")).read()
+    src = open(os.path.join(ROOT, "include", "fasp_hip.h")).read() + open(os.path.join(ROOT, "include", "fasp_hip_dev.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b(fasp_[a-z0-9_A-Z]+)\s*\(", src)
     return sorted(set(names))

@@ -1,3 +1,7 @@
+// tools/lab/reorder.cpp -- EXPERIMENT, not part of libfasp_hip.so (moved out of csrc/ in round 4).  Breadth-first balls of `chunk` rows
+// over A's row pattern (A^T is not traversed: for the structurally symmetric levels it was tried on the two coincide); nothing in the
+// product renumbers a level.  Results: profiles/r03_cluster_order_xtile.txt; DESIGN.md section 8.  To use it again, add it to the library's
+// Makefile and declare fasp_hip_cluster_order in include/fasp_hip_dev.h (tools/lab/expt_cluster_order.py and expt_renumber.py call it).
 // reorder.cpp -- host side: brick-like renumbering of a coarse level from its matrix graph alone.
 //
 // Why: the wave-stream kernels (kernels2.hip.h) take 64 consecutive rows per wave; what a CU has to pull from its L2
