@@ -274,15 +274,20 @@ __device__ __forceinline__ bool flow_give_up(unsigned* sync, unsigned& spins, un
 // -- the slots of a wave's NEXT chunk are in flight -- for chunks of four and of eight rounds alike (measured at 128^3 against
 // 512-thread workgroups with three sets for eight rounds: 6 compute waves do not keep up with classes of two or three rows of
 // 450 entries; sweep pair over all levels 3.96 -> 3.36 ms).
-#ifndef FLOW_NIMP
-#define FLOW_NIMP 2   // importer waves per workgroup
-#define FLOW_GB 4     // ghosts per lane and batch
+// importer waves per workgroup / ghosts per lane and batch: levels with wide classes (chunks of four rounds) import as many values
+// as they compute -- four waves with one load in flight per lane pick a ghost up sooner than two with four (measured at 128^3:
+// level 1 556 -> 497 us, level 2 428 -> 388 us per ascending sweep); the deep levels keep their waves for the rows
+#ifndef FLOW_NIMP4
+#define FLOW_NIMP4 4
+#define FLOW_GB4 1
+#define FLOW_NIMP8 3
+#define FLOW_GB8 2
 #endif
 #ifndef FLOW_NT8
 #define FLOW_NT8 1024
 #define FLOW_NSET8 2
 #endif
-template <int PF> struct FlowGeom { static constexpr int NT = PF <= 4 ? 1024 : FLOW_NT8, NSET = PF <= 4 ? 2 : FLOW_NSET8; };
+template <int PF> struct FlowGeom { static constexpr int NT = PF <= 4 ? 1024 : FLOW_NT8, NSET = PF <= 4 ? 2 : FLOW_NSET8, NIMP = PF <= 4 ? FLOW_NIMP4 : FLOW_NIMP8, GB = PF <= 4 ? FLOW_GB4 : FLOW_GB8; };
 #ifdef FLOW_TIMING
 __device__ unsigned long long g_flow_times[8192];   // start / end of every strip of the last launch (100 MHz clock)
 #endif
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     extern __shared__ __attribute__((aligned(16))) double flow_lds[];
     __shared__ int s_strip;
-    constexpr int NW = FLOW_THREADS / 64, NIMP = FLOW_NIMP, GB = FLOW_GB, NWC = NW - NIMP;
+    constexpr int NW = FLOW_THREADS / 64, NIMP = FlowGeom<PF>::NIMP, GB = FlowGeom<PF>::GB, NWC = NW - NIMP;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
