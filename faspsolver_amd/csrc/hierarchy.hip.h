@@ -59,7 +59,12 @@ struct EventPair { hipEvent_t a, b; };
 
 using namespace fasp;
 
+// a sweep schedule under construction on a host thread of its own (smoothers.hip.h, sched_jobs_start)
+struct SchedJob { int level = 0, kind = 0, st = 0; SplitHost H; std::thread th; };
+
 struct fasp_hip_amg {
+    std::vector<std::unique_ptr<SchedJob>> sched_jobs;   // sequential smoothers: schedules being built side by side at the first sweep
+    bool                  sched_jobs_started = false;
     HostHierarchy         H;
     DistPlan              dist;        // row partition (nranks == 1: trivial)
     bool                  distributed = false;  // level 0 is row-partitioned over the ranks

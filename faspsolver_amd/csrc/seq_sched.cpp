@@ -2,6 +2,8 @@
 // the rest CSR and the per-row records of one (level, sweep kind), built once on first use.  Pure host code in a translation
 // unit of its own: the OpenMP loops below are compiled by g++ (the HIP translation unit is compiled by clang with
 // -fopenmp=libgomp, which parses the directives and generates NO parallel code -- measured: the fill ran on one thread).
+#include <omp.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -13,9 +15,10 @@
 
 namespace fasp {
 
-int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H)
+int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team)
 {
     HostThreads host_team;   // (bounded OpenMP team for the row-parallel loops below; the dependency pass itself is sequential)
+    if (team > 0) omp_set_num_threads(std::min(team, omp_get_max_threads()));   // (bounded OpenMP team for the row-parallel loops below; the dependency pass itself is sequential)
     const int n = A.row;
     double tl = wall_seconds();
     auto lap = [&](const char* what) { if (timing) { const double t = wall_seconds(); std::printf("    [sweep schedule] %-28s %.3f s\n", what, t - tl); tl = t; } };

@@ -29,6 +29,7 @@ struct SplitHost {
 };
 // Returns FASP_SUCCESS, 1 when a row of the sweep reads more earlier rows than a strip's LDS holds (no split form: the caller
 // falls back to whole-row level scheduling), or a negative error code.
-int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H);
+// team > 0: OpenMP team of this call (several schedules are built side by side, one host thread each: smoothers.hip.h)
+int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team = 0);
 
 }  // namespace fasp

@@ -121,12 +121,18 @@ static int split_upload(DevLevel::Sched& S, T** dst, const T* v, size_t n)
 template <class T>
 static int split_upload(DevLevel::Sched& S, T** dst, const std::vector<T>& v) { return split_upload(S, dst, v.data(), v.size()); }
 
+static int upload_split(SplitHost& H, DevLevel::Sched& S);
 static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::Sched& S)
 {
     const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
     SplitHost H;
-    int st = build_split_host(A, seq.data(), (int)seq.size(), g_tune.seq_strip_kb, g_tune.seq_lanes, timing, H);   // (seq_sched.cpp)
+    const int st = build_split_host(A, seq.data(), (int)seq.size(), g_tune.seq_strip_kb, g_tune.seq_lanes, timing, H);   // (seq_sched.cpp)
     if (st != FASP_SUCCESS) { S.flow_ok = false; return st; }
+    return upload_split(H, S);
+}
+static int upload_split(SplitHost& H, DevLevel::Sched& S)
+{
+    const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
     const double t0 = wall_seconds();
     const int ns = H.ns;
     S.release();
@@ -180,6 +186,66 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     return FASP_SUCCESS;
 }
 
+// rows of sweep `kind` in sweep order: 0 all ascending, 1 all descending, 2 C rows, 3 the others, 4 descending from n - 2 (SGS)
+static void sweep_sequence(const HostLevel& HL, int kind, std::vector<int>& seq)
+{
+    const int n = HL.A.row;
+    seq.clear();
+    seq.reserve((size_t)n);
+    const int* cf = HL.cfmark.n ? HL.cfmark.data() : nullptr;
+    switch (kind) {
+        case 0: for (int i = 0; i < n; ++i) seq.push_back(i); break;
+        case 1: for (int i = n - 1; i >= 0; --i) seq.push_back(i); break;
+        case 2: for (int i = 0; i < n; ++i) if (cf && cf[i] == 1) seq.push_back(i); break;
+        case 3: for (int i = 0; i < n; ++i) if (!cf || cf[i] != 1) seq.push_back(i); break;
+        default: for (int i = n - 2; i >= 0; --i) seq.push_back(i); break;
+    }
+}
+// The schedules a hierarchy's smoother is going to need -- two sweep kinds on every level but the coarsest -- are built SIDE BY
+// SIDE at the first sweep, one host thread each (the dependency pass of a schedule is sequential; fourteen of them are not): the
+// first solve of P7(128) with the reference's defaults pays for the longest one instead of for the sum.
+static void sched_jobs_start(fasp_hip_amg* h)
+{
+    if (h->sched_jobs_started) return;
+    h->sched_jobs_started = true;
+    if (g_tune.gs_multicolor || !g_tune.seq_jobs) return;
+    int k0 = -1, k1 = -1;
+    const int sm = h->param.smoother;
+    const int nl = (int)h->L.size();
+    std::vector<std::pair<int, int>> jobs;
+    for (int l = 0; l + 1 < nl; ++l) {
+        if (!h->L[l].replicated) return;   // (sequential sweeps run on whole levels only)
+        const bool has_cf = h->H.L[l].cfmark.n == (size_t)h->H.L[l].A.row;
+        switch (sm) {
+            case SMOOTHER_GS: if (h->param.smooth_order == CF_ORDER && has_cf) { k0 = 2; k1 = 3; } else { k0 = 0; k1 = 1; } break;
+            case SMOOTHER_SGS: k0 = 0; k1 = 4; break;
+            case SMOOTHER_SOR: case SMOOTHER_SSOR: case SMOOTHER_GSOR: case SMOOTHER_SGSOR: k0 = 0; k1 = 1; break;
+            case SMOOTHER_GSF: k0 = 3; k1 = -1; break;
+            default: return;
+        }
+        if (h->L[l].sched[k0].built == false) jobs.push_back({l, k0});
+        if (k1 >= 0 && !h->L[l].sched[k1].built) jobs.push_back({l, k1});
+    }
+    const int team = std::max(2, host_threads() * 2 / std::max<int>(1, (int)jobs.size()));
+    const int strip_kb = g_tune.seq_strip_kb, lanes = g_tune.seq_lanes;
+    for (const auto& lk : jobs) {
+        h->sched_jobs.emplace_back(new SchedJob);
+        SchedJob* J = h->sched_jobs.back().get();
+        J->level = lk.first; J->kind = lk.second;
+        const HostLevel* HL = &h->H.L[(size_t)lk.first];
+        J->th = std::thread([J, HL, team, strip_kb, lanes]() {
+            std::vector<int> seq;
+            sweep_sequence(*HL, J->kind, seq);
+            J->st = build_split_host(HL->A, seq.data(), (int)seq.size(), strip_kb, lanes, false, J->H, team);
+        });
+    }
+}
+static void sched_jobs_join(fasp_hip_amg* h)   // (hierarchy teardown)
+{
+    for (auto& J : h->sched_jobs) if (J && J->th.joinable()) J->th.join();
+    h->sched_jobs.clear();
+}
+
 // one sequential sweep of schedule `kind` with update formula `form` (see tri_update)
 static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
 {
@@ -192,19 +258,23 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     const bool multicolor = g_tune.gs_multicolor != 0;
     if (!S.built || S.multicolor != multicolor) {
         const HostCSR& A = h->H.L[level].A;
-        const int n = A.row;
         std::vector<int> seq;
-        seq.reserve(n);
-        const int* cf = h->H.L[level].cfmark.n ? h->H.L[level].cfmark.data() : nullptr;
-        switch (kind) {
-            case 0: for (int i = 0; i < n; ++i) seq.push_back(i); break;
-            case 1: for (int i = n - 1; i >= 0; --i) seq.push_back(i); break;
-            case 2: for (int i = 0; i < n; ++i) if (cf && cf[i] == 1) seq.push_back(i); break;
-            case 3: for (int i = 0; i < n; ++i) if (!cf || cf[i] != 1) seq.push_back(i); break;
-            default: for (int i = n - 2; i >= 0; --i) seq.push_back(i); break;
-        }
         const double t0 = wall_seconds();
-        int st = multicolor ? build_schedule(A, seq, S, true) : build_split(A, seq, S);
+        int st = 1000;
+        if (!multicolor) {
+            sched_jobs_start(h);
+            for (auto& J : h->sched_jobs)
+                if (J && J->level == level && J->kind == kind) {
+                    if (J->th.joinable()) J->th.join();
+                    st = J->st;
+                    if (st == FASP_SUCCESS) st = upload_split(J->H, S);
+                    else S.flow_ok = false;
+                    J.reset();
+                    break;
+                }
+        }
+        if (st == 1000 || st == 1) sweep_sequence(h->H.L[level], kind, seq);
+        if (st == 1000) st = multicolor ? build_schedule(A, seq, S, true) : build_split(A, seq, S);
         if (st < 0) return st;
         S.rowlevels = false;
         if (st == 1) {   // a row of this sweep reads more earlier rows than a strip's LDS holds: whole rows, one launch per dependency level
@@ -212,7 +282,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
             S.rowlevels = true;
         }
         if (std::getenv("FASP_HIP_SETUP_TIMING")) {
-            if (multicolor || S.rowlevels) std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind, multicolor ? "colours" : "whole-row dependency levels", (int)seq.size(), (int)S.ptr.size() - 1);
+            if (multicolor || S.rowlevels) std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind, multicolor ? "colours" : "whole-row dependency levels", (int)(seq.empty() ? S.ns : (int)seq.size()), (int)S.ptr.size() - 1);
             else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes, %d strips (%lld ghosts, at most %d values in LDS), %d chunks, %d lanes per row, "
                              "%.1f slot bytes per row (%lld tail entries), rest pass %d lanes per row%s, built in %.3f s\n",
                              level, kind, S.ns, (int)S.cptr.size() - 1, S.nstrips, S.nghost, S.maxent + 1, S.nchunk, S.L, S.ns ? (double)S.slot_bytes / S.ns : 0.0, S.ntail, S.LR,

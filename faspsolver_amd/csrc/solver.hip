@@ -424,6 +424,7 @@ int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgpara
 
 void fasp_hip_amg_destroy(fasp_hip_amg* h)
 {
+    if (h) sched_jobs_join(h);
     if (!h) return;
     if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
     for (auto& D : h->L) free_level(D);
@@ -2027,6 +2028,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "gs_multicolor")) g_tune.gs_multicolor = value;
     else if (!std::strcmp(key, "seq_flow")) { g_tune.seq_flow = value; if (value) g_flow_disabled = false; }
     else if (!std::strcmp(key, "seq_strip_kb")) g_tune.seq_strip_kb = value;
+    else if (!std::strcmp(key, "seq_jobs")) g_tune.seq_jobs = value;
     else if (!std::strcmp(key, "fuse_zr")) g_tune.fuse_zr = value;
     else if (!std::strcmp(key, "fuse_presmooth")) g_tune.fuse_presmooth = value;
     else if (!std::strcmp(key, "seq_lanes")) g_tune.seq_lanes = value;

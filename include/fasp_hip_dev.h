@@ -41,7 +41,7 @@ int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
  *   sequential sweeps (a parallel pass + a sparse triangular solve, csrc/seq_split.hip.h): seq_flow (the triangular solve as a
  *     dataflow over strips of the sweep sequence, default 1; 0 = one launch per dependency class), seq_strip_kb (slot bytes per
  *     strip when a schedule is built, default 512), seq_lanes (lanes per row, 0 = from the row lengths) -- same slots, same
- *     arithmetic, same bits;
+ *     arithmetic, same bits; seq_jobs (the schedules of all levels built side by side on host threads at the first sweep, default 1);
  *     gs_multicolor = 1 selects the MULTICOLOUR Gauss-Seidel / SOR sweep -- NOT the reference's iteration (rows are
  *     relaxed colour by colour instead of in index order; faster, converges alike, other iteration counts). Default 0:
  *     the reference's sequential sweep, reproduced exactly;
