@@ -65,8 +65,8 @@ from faspsolver_amd import _types as T  # noqa: E402
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # PMC traffic summaries of THIS command, one per workload (tools/profile.sh <tag> <workload> -> tools/summarize_prof.py);
 # a figure is attached to a roofline entry only when kernel name, workload and grid size all match the run
-TRAFFIC_JSONS = {"constant": os.path.join("profiles", "r03_rocprof", "traffic.json"),
-                 "variable": os.path.join("profiles", "r03_rocprof_var", "traffic.json")}
+TRAFFIC_JSONS = {"constant": os.path.join("profiles", "r04_rocprof", "traffic.json"),
+                 "variable": os.path.join("profiles", "r04_rocprof_var", "traffic.json")}
 
 # kernel family codes of fasp_hip_amg_kernel_info -> (rocprofv3 kernel name of the OP_MXV_DOT instantiation, description)
 KERNELS = {0: ("k_csr_rows", "k_csr_rows<L, OP_MXV_DOT> (sub-wavefront per row, plain CSR)"),
@@ -425,7 +425,7 @@ def main():
         sync()
         return time.perf_counter() - t0, st, hist, stats, float(np.mean(sp))
 
-    if args.only_variable:   # the profiled command of profiles/r03_rocprof_var (tools/profile.sh <tag> variable)
+    if args.only_variable:   # the profiled command of profiles/r04_rocprof_var (tools/profile.sh <tag> variable)
         print(json.dumps({"variable_coefficient": variable_leg(n, (ia, ja, a, f, ue), itp, amgp, timed_solves)}), flush=True)
         return
 
