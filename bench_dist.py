@@ -39,21 +39,32 @@ def main(args, rank, world, local_rank):
     dev = local_rank % ndev if backend == "shm" or ndev < world else local_rank
     st = L.fasp_hip_set_device(dev)
     assert st == 0, f"set_device({dev}) -> {st}"
+    name = f"fasp_bench_{os.environ.get('MASTER_PORT', '0')}"
     if backend == "shm":
-        name = f"fasp_bench_{os.environ.get('MASTER_PORT', '0')}"
         st = L.fasp_hip_comm_init_shm(rank, world, name.encode())
     elif backend == "ipc":   # peer windows (csrc/comm_ipc.h): hipIpc-mapped device windows, one kernel per exchange, no RCCL call
-        name = f"fasp_bench_{os.environ.get('MASTER_PORT', '0')}"
         st = L.fasp_hip_comm_init_ipc(rank, world, name.encode())
     else:
         idbuf = C.create_string_buffer(128)
-        if rank == 0:
-            st = L.fasp_hip_comm_unique_id(idbuf)
-            assert st == 0, f"ncclGetUniqueId -> {st}"
-        t = torch.tensor(list(idbuf.raw), dtype=torch.uint8)
-        dist.broadcast(t, 0)
-        ids = bytes(t.tolist())
-        st = L.fasp_hip_comm_init(rank, world, ids)
+        st = L.fasp_hip_comm_unique_id(idbuf) if rank == 0 else 0
+        ok = torch.tensor([1 if st == 0 else 0], dtype=torch.int32)
+        dist.broadcast(ok, 0)
+        if int(ok[0]):
+            t = torch.tensor(list(idbuf.raw), dtype=torch.uint8)
+            dist.broadcast(t, 0)
+            st = L.fasp_hip_comm_init(rank, world, bytes(t.tolist()))
+        else:
+            st = -1
+        # every rank must have its communicator, or none uses RCCL: fall back to the peer-window transport together
+        allok = torch.tensor([1 if st == 0 else 0], dtype=torch.int32)
+        dist.all_reduce(allok, op=dist.ReduceOp.MIN)
+        if not int(allok[0]):
+            if st == 0:
+                L.fasp_hip_comm_finalize()
+            if rank == 0:
+                B.log("bench_dist: RCCL communicator could not be created on every rank; falling back to the peer-window transport (BENCH_COMM=ipc)")
+            backend = "ipc"
+            st = L.fasp_hip_comm_init_ipc(rank, world, name.encode())
     assert st == 0, f"comm init -> {st}"
 
     n = args.n

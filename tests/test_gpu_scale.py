@@ -370,10 +370,9 @@ def test_xtile_kernel_is_bit_identical_to_wstream2(gpu, var):
 def test_sequential_smoothers_match_reference_64(gpu, tag, smoother, order, w, n, fixture):
     """The parity mode of the sequential smoothers at 64^3 and 128^3 against the REFERENCE's own runs
     (tests/golden/p7_sweeps*.npz, tools/gen_golden_sweeps.py): Gauss-Seidel in C/F order (the reference's defaults), in
-    natural order, SOR(1.1).  At 64^3 the deep levels run as one-workgroup triangular solves with the new values in an LDS
-    ring, the upper ones as one launch per dependency class; at 128^3 levels 0-2 have the wide classes that take the cluster
-    form, far entries and the helper workgroups (csrc/seq_split.hip.h): equal iteration counts, residual histories to 1e-8,
-    |relres - ref| <= 1e-10."""
+    natural order, SOR(1.1).  The triangular solves run as a dataflow over strips of the sweep sequence (csrc/seq_split.hip.h):
+    one or two strips per deep level at 64^3, hundreds per wide level (more strips than workgroups resident) at 128^3: equal
+    iteration counts, residual histories to 1e-8, |relres - ref| <= 1e-10."""
     z = np.load(os.path.join(G, fixture))
     ia, ja, a, f, ue = fa.poisson7pt(n)
     itp, amgp = _gs_params(smoother, order, w)
@@ -382,6 +381,28 @@ def test_sequential_smoothers_match_reference_64(gpu, tag, smoother, order, w, n
     assert st == int(z[f"{tag}_iters"])
     assert abs(stats.relres - float(z[f"{tag}_relres"])) <= RELRES_TOL
     assert _same_history(hist, z[f"{tag}_hist"])
+    step = max(1, len(x) // 4096)
+    xs = z[f"{tag}_xsample"]
+    assert np.abs(x[::step] - xs).max() <= X_TOL * np.abs(xs).max()
+    H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,smoother,order,w", [("gscf", T.SMOOTHER_GS, 1, 1.0), ("sor11", T.SMOOTHER_SOR, 0, 1.1)])
+def test_sequential_smoothers_match_reference_256(gpu, tag, smoother, order, w):
+    """The same at the size of the metric, P7(256): the reference's default smoother (12 iterations, relres 7.9576097848e-09) and
+    SOR(1.1) in natural order (10 iterations, 3.0722787533e-09) -- tests/golden/p7_sweeps_256.npz from the compiled reference
+    (tools/gen_golden_sweeps_256.py).  Level 0 in natural order is 2 800 strips of the dataflow solve, ten times what is resident."""
+    z = np.load(os.path.join(G, "p7_sweeps_256.npz"))
+    ia, ja, a, f, ue = fa.poisson7pt(256)
+    itp, amgp = _gs_params(smoother, order, w)
+    H = fa.AMG(ia, ja, a, amgp)
+    H.set_rhs(f)
+    st, hist, stats = H.solve_resident(itp)
+    assert st == int(z[f"{tag}_iters"])
+    assert abs(stats.relres - float(z[f"{tag}_relres"])) <= RELRES_TOL
+    assert _same_history(hist, z[f"{tag}_hist"])
+    x = H.get_solution()
     step = max(1, len(x) // 4096)
     xs = z[f"{tag}_xsample"]
     assert np.abs(x[::step] - xs).max() <= X_TOL * np.abs(xs).max()
