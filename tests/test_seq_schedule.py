@@ -76,3 +76,26 @@ def test_a_row_that_reads_more_than_a_strip_holds_is_reported():
     A = A.tocsr()
     r = _selftest(A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy(), np.arange(n))
     assert r == -2.0
+
+
+def test_rows_without_a_usable_diagonal_are_left_alone():
+    """ItrSmootherCSR.c leaves a row alone when |a_ii| <= SMALLREAL: a stored zero diagonal, a missing diagonal, a diagonal stored
+    twice (the last hit counts) -- in the middle of the dependency chain."""
+    import scipy.sparse as sp
+    n = 400
+    M = (sp.diags([-1.0, -1.0, 4.0, -1.0, -1.0], [-20, -1, 0, 1, 20], shape=(n, n))).tolil()
+    M[50, 50] = 0.0
+    M = M.tocoo()
+    rows, cols, vals = list(M.row), list(M.col), list(M.data)
+    keep = [(r, c, v) for r, c, v in zip(rows, cols, vals) if not (r == 120 and c == 120)]   # row 120: no diagonal entry at all
+    keep.append((50, 50, 0.0))                                                               # row 50: stored zero diagonal
+    keep += [(200, 200, 1.0), (200, 200, 5.0)]                                               # row 200: two more hits, the last one counts
+    keep.sort(key=lambda t: t[0])
+    ia = np.zeros(n + 1, np.int32)
+    for r, c, v in keep: ia[r + 1] += 1
+    ia = np.cumsum(ia).astype(np.int32)
+    ja = np.array([c for r, c, v in keep], np.int32); a = np.array([v for r, c, v in keep])
+    for seq in (np.arange(n), np.arange(n)[::-1]):
+        for kb in (16, 512):
+            res = _selftest(ia, ja, a, seq, kb)
+            assert 0.0 <= res <= 1e-12, (kb, res)
