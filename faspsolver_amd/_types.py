@@ -38,7 +38,7 @@ CLASSIC_AMG, SA_AMG, UA_AMG = 1, 2, 3
 V_CYCLE, W_CYCLE, AMLI_CYCLE, NL_AMLI_CYCLE, VW_CYCLE, WV_CYCLE = 1, 2, 3, 4, 12, 21
 SMOOTHER_JACOBI, SMOOTHER_GS, SMOOTHER_SGS, SMOOTHER_CG, SMOOTHER_SOR = 1, 2, 3, 4, 5
 SMOOTHER_SSOR, SMOOTHER_GSOR, SMOOTHER_SGSOR, SMOOTHER_POLY, SMOOTHER_L1DIAG = 6, 7, 8, 9, 10
-SMOOTHER_JACOBIF = 11
+SMOOTHER_JACOBIF, SMOOTHER_GSF = 11, 12
 COARSE_RS, COARSE_RSP, COARSE_CR, COARSE_AC, COARSE_MIS = 1, 2, 3, 4, 5
 INTERP_DIR, INTERP_STD, INTERP_ENG, INTERP_RDC, INTERP_EXT = 1, 2, 3, 4, 6
 NO_ORDER, CF_ORDER = 0, 1

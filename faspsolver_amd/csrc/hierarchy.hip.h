@@ -200,6 +200,7 @@ static int halo_exchange(DevLevel& D, double* v, hipStream_t stream = nullptr)
 // rows (the two ends of the block: with a 1-D partition of a grid in natural ordering, one plane each) follow when
 // the ghosts have arrived.  Three launches of the same kernel through its row window: the arithmetic of every row is
 // what the single launch does, only the partition of the fused dot product into per-block partials changes.
+static int g_seq_partition = std::getenv("FASP_HIP_SEQ_PARTITION") && std::atoi(std::getenv("FASP_HIP_SEQ_PARTITION")) != 0;   // sequential smoothers on row-partitioned levels (ranks take turns)
 static int g_halo_overlap = 1;   // fasp_hip_tune("halo_overlap", 0): exchange, then one launch (the round-1 sequence)
 
 // ---- replicated levels, "split" mode (fasp_hip_tune("coarse_mode", 1)) -----------------------------------------------
@@ -336,7 +337,8 @@ static int upload_hierarchy(fasp_hip_amg* h)
     if (const char* e = std::getenv("FASP_HIP_DIST_MIN_ROWS")) min_rows = std::atoi(e);
     // sequential (Gauss-Seidel / SOR) sweeps couple all rows of a level: such hierarchies
     // are not row-partitioned, every rank keeps (and computes) all levels
-    if (h->param.smoother != SMOOTHER_JACOBI && h->param.smoother != SMOOTHER_L1DIAG && h->param.smoother != SMOOTHER_POLY) min_rows = 2147483647;
+    const bool seq_ok = g_seq_partition && h->param.smoother != SMOOTHER_CG && h->param.smoother != SMOOTHER_JACOBIF;   // (sweeps by turns: smoothers.hip.h, seq_sweep)
+    if (h->param.smoother != SMOOTHER_JACOBI && h->param.smoother != SMOOTHER_L1DIAG && h->param.smoother != SMOOTHER_POLY && !seq_ok) min_rows = 2147483647;
     if (h->param.cycle_type == AMLI_CYCLE || h->param.cycle_type == NL_AMLI_CYCLE) min_rows = 2147483647;  // the recursive cycles run on whole levels
     {   // AMG_data.cycle_type of every level: the setup's cycle type for levels >= 1 (PreAMGSetupRS.c:325,
         // PreAMGSetupSA.c:495); the UA setup derives it from the operator complexity (PreAMGSetupUA.c:390-401)
@@ -377,8 +379,9 @@ static int upload_hierarchy(fasp_hip_amg* h)
     h->ev.resize(64);
     for (auto& e : h->ev) { HIPCK(hipEventCreate(&e.a)); HIPCK(hipEventCreate(&e.b)); }
     HIPCK(hipStreamSynchronize(g_ctx.stream));
-    // the local copies of the partitioned operators are only needed for the upload
-    for (auto& DL : h->dist.L) { DL.A = HostCSR(); DL.P = HostCSR(); DL.R = HostCSR(); }
+    // the local copies of the partitioned operators are only needed for the upload -- and, for sequential smoothers on partitioned
+    // levels, the local A for the sweep schedules (smoothers.hip.h, seq_sweep_local)
+    for (auto& DL : h->dist.L) { if (!seq_ok) DL.A = HostCSR(); DL.P = HostCSR(); DL.R = HostCSR(); }
     h->upload_seconds = wall_seconds() - t0;
     return FASP_SUCCESS;
 }

@@ -315,7 +315,7 @@ extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* s
     SplitHost H;
     const int st = build_split_host(A, seq, ns, strip_kb, lanes, false, H);
     if (st != FASP_SUCCESS) return st == 1 ? -2.0 : -3.0;
-    const int n = A.row, L = H.L, PF = H.pfs;
+    const int n = std::max(A.row, A.col), L = H.L, PF = H.pfs;   // (a rank's local rows of a partitioned level: columns beyond the rows are ghosts, never swept)
     std::vector<double> u((size_t)n), b((size_t)n), uref;
     for (int i = 0; i < n; ++i) { u[(size_t)i] = std::sin(0.37 * i) + 0.1; b[(size_t)i] = std::cos(0.11 * i); }
     uref = u;

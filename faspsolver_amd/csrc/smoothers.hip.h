@@ -186,19 +186,21 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S)
     return FASP_SUCCESS;
 }
 
-// rows of sweep `kind` in sweep order: 0 all ascending, 1 all descending, 2 C rows, 3 the others, 4 descending from n - 2 (SGS)
-static void sweep_sequence(const HostLevel& HL, int kind, std::vector<int>& seq)
+// rows of sweep `kind` in sweep order: 0 all ascending, 1 all descending, 2 C rows, 3 the others, 4 descending from n - 2 (SGS).
+// row0 / nloc / nglobal: the rows this rank owns of a row-partitioned level (local numbering in `seq`); whole level: 0 / n / n.
+static void sweep_sequence(const HostLevel& HL, int kind, std::vector<int>& seq, int row0 = 0, int nloc = -1)
 {
-    const int n = HL.A.row;
+    const int nglobal = HL.A.row;
+    if (nloc < 0) nloc = nglobal;
     seq.clear();
-    seq.reserve((size_t)n);
-    const int* cf = HL.cfmark.n ? HL.cfmark.data() : nullptr;
+    seq.reserve((size_t)nloc);
+    const int* cf = HL.cfmark.n ? HL.cfmark.data() + row0 : nullptr;
     switch (kind) {
-        case 0: for (int i = 0; i < n; ++i) seq.push_back(i); break;
-        case 1: for (int i = n - 1; i >= 0; --i) seq.push_back(i); break;
-        case 2: for (int i = 0; i < n; ++i) if (cf && cf[i] == 1) seq.push_back(i); break;
-        case 3: for (int i = 0; i < n; ++i) if (!cf || cf[i] != 1) seq.push_back(i); break;
-        default: for (int i = n - 2; i >= 0; --i) seq.push_back(i); break;
+        case 0: for (int i = 0; i < nloc; ++i) seq.push_back(i); break;
+        case 1: for (int i = nloc - 1; i >= 0; --i) seq.push_back(i); break;
+        case 2: for (int i = 0; i < nloc; ++i) if (cf && cf[i] == 1) seq.push_back(i); break;
+        case 3: for (int i = 0; i < nloc; ++i) if (!cf || cf[i] != 1) seq.push_back(i); break;
+        default: for (int i = nloc - 1; i >= 0; --i) if (row0 + i <= nglobal - 2) seq.push_back(i); break;
     }
 }
 // The schedules a hierarchy's smoother is going to need -- two sweep kinds on every level but the coarsest -- are built SIDE BY
@@ -246,8 +248,8 @@ static void sched_jobs_join(fasp_hip_amg* h)   // (hierarchy teardown)
     h->sched_jobs.clear();
 }
 
-// one sequential sweep of schedule `kind` with update formula `form` (see tri_update)
-static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
+// one sequential sweep of schedule `kind` with update formula `form` (see tri_update) over the rows THIS rank holds of the level
+static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, double w)
 {
     DevLevel& D = h->L[level];
     DevLevel::Sched& S = D.sched[kind];
@@ -257,11 +259,21 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     // (seq_split.hip.h), which reproduces the reference's sequential sweep.
     const bool multicolor = g_tune.gs_multicolor != 0;
     if (!S.built || S.multicolor != multicolor) {
-        const HostCSR& A = h->H.L[level].A;
+        // a row-partitioned level: the rank's own rows in local numbering -- ghost columns (>= the row count) are never "lower":
+        // they hold what the ranks swept before this one have sent (new values) or what the later ones still have (old values)
+        const HostCSR& A = D.replicated ? h->H.L[level].A : h->dist.L[level].A;
+        if (A.row != D.nloc || !A.ia.data()) {   // (the local operator is kept on the host only when the hierarchy was uploaded with seq_partition on)
+            std::printf("### ERROR: fasp_hip: sequential sweep on a partitioned level without its local host matrix (fasp_hip_tune(\"seq_partition\", 1) before the upload)\n");
+            return ERROR_AMG_SMOOTH_TYPE;
+        }
         std::vector<int> seq;
         const double t0 = wall_seconds();
         int st = 1000;
-        if (!multicolor) {
+        if (multicolor && !D.replicated) {
+            std::printf("### ERROR: fasp_hip: the multicolour sweep mode runs on whole levels only\n");
+            return ERROR_AMG_SMOOTH_TYPE;
+        }
+        if (!multicolor && D.replicated) {
             sched_jobs_start(h);
             for (auto& J : h->sched_jobs)
                 if (J && J->level == level && J->kind == kind) {
@@ -273,7 +285,7 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
                     break;
                 }
         }
-        if (st == 1000 || st == 1) sweep_sequence(h->H.L[level], kind, seq);
+        if (st == 1000 || st == 1) sweep_sequence(h->H.L[level], kind, seq, D.replicated ? 0 : D.row0, D.replicated ? -1 : D.nloc);
         if (st == 1000) st = multicolor ? build_schedule(A, seq, S, true) : build_split(A, seq, S);
         if (st < 0) return st;
         S.rowlevels = false;
@@ -398,6 +410,29 @@ static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
     }
     hipLaunchKernelGGL(k_split_scatter, dim3(sgrid), dim3(BLOCK), 0, g_ctx.stream, ns, fa, 0);
     return FASP_SUCCESS;
+}
+
+// A sequential sweep of a ROW-PARTITIONED level (round 4; fasp_hip_tune("seq_partition", 1) or FASP_HIP_SEQ_PARTITION=1 before the
+// upload -- by default hierarchies with sequential smoothers keep every level whole on every rank).  With contiguous row blocks in
+// rank order the sweep visits rank 0's rows, then rank 1's, ...: the ranks take turns -- halo exchange (a rank's ghosts then hold
+// the NEW values of the ranks before it and the OLD ones of the ranks after it, exactly what the sequential sweep reads), the rank
+// whose turn it is sweeps its rows (ghost columns belong to the parallel pass), the next exchange passes its boundary on.  The
+// same iteration as on one GPU, no parallelism across ranks in a sweep (there is none in the reference's order), the level's
+// matrix and vectors stay distributed.  Descending sweeps take the ranks in descending order.  Every rank enters every exchange.
+static int seq_sweep(fasp_hip_amg* h, int level, int kind, int form, double w)
+{
+    DevLevel& D = h->L[level];
+    if (D.replicated || comm_size() <= 1) return seq_sweep_local(h, level, kind, form, w);
+    const int P = comm_size(), me = comm_rank();
+    const bool descending = kind == 1 || kind == 4;
+    materialise_zero(D);
+    int st = FASP_SUCCESS;
+    for (int s = 0; s < P; ++s) {
+        const int turn = descending ? P - 1 - s : s;
+        if (halo_exchange(D, D.x) < 0) return ERROR_MISC;
+        if (turn == me && st >= 0) st = seq_sweep_local(h, level, kind, form, w);
+    }
+    return st;
 }
 
 // Smoother dispatch of PreMGSmoother.inl:49 (pre) / :155 (post).  Jacobi and L1-diag are
@@ -527,9 +562,9 @@ static int smooth(fasp_hip_amg* h, int level, bool post, int smoother, int order
         }
         return FASP_SUCCESS;
     }
-    if (!D.replicated) return ERROR_AMG_SMOOTH_TYPE;  // sequential sweeps are not distributed
+    if (!D.replicated && (smoother == SMOOTHER_CG || !g_seq_partition)) return ERROR_AMG_SMOOTH_TYPE;  // (CG smoothing, and sequential sweeps unless asked for, run on whole levels)
     if (smoother == SMOOTHER_CG) return cg_smooth(h, level, nsweeps);
-    const bool has_cf = h->H.L[level].cfmark.n == (size_t)n;
+    const bool has_cf = h->H.L[level].cfmark.n == (size_t)D.nglobal;
     if (smoother == SMOOTHER_GSF) {  // fasp_smoother_dcsr_gs_ff (ItrSmootherCSR.c:700): GS over the non-C rows, ascending, before and after
         if (!has_cf) {
             std::printf("### ERROR: fasp_hip: the F-point Gauss-Seidel smoother needs the C/F marker of a classical hierarchy\n");

@@ -2029,6 +2029,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_flow")) { g_tune.seq_flow = value; if (value) g_flow_disabled = false; }
     else if (!std::strcmp(key, "seq_strip_kb")) g_tune.seq_strip_kb = value;
     else if (!std::strcmp(key, "seq_jobs")) g_tune.seq_jobs = value;
+    else if (!std::strcmp(key, "seq_partition")) g_seq_partition = value;
     else if (!std::strcmp(key, "fuse_zr")) g_tune.fuse_zr = value;
     else if (!std::strcmp(key, "fuse_presmooth")) g_tune.fuse_presmooth = value;
     else if (!std::strcmp(key, "seq_lanes")) g_tune.seq_lanes = value;

@@ -46,7 +46,8 @@ int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
  *     relaxed colour by colour instead of in index order; faster, converges alike, other iteration counts). Default 0:
  *     the reference's sequential sweep, reproduced exactly;
  *   multi-GPU: halo_overlap (exchange beside the interior rows, default 1), split_rows (test mode: every operator in
- *     three row windows).
+ *     three row windows), seq_partition (set before the upload, or FASP_HIP_SEQ_PARTITION=1: hierarchies with Gauss-Seidel / SOR
+ *     smoothers are row-partitioned too and the ranks sweep by turns; default 0: such hierarchies keep every level whole).
  * Unknown keys return ERROR_INPUT_PAR. */
 int fasp_hip_tune(const char* key, int value);
 

@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="shm", idfile=None, amg_type=1, smoother=1, itsolver=1, tune=""):
+def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="shm", idfile=None, amg_type=1, smoother=1, itsolver=1, tune="", smooth_order=1, relaxation=0.6667):
     try:
         os.environ["FASP_HIP_DIST_MIN_ROWS"] = str(min_rows)
+        os.environ.setdefault("FASP_HIP_SHM_TIMEOUT_S", "60")   # (a rank that fails leaves its peers at a barrier: bound the wait)
         if tune:
             os.environ["FASP_HIP_TUNE"] = tune
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -46,7 +47,7 @@ def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="s
             assert L.fasp_hip_comm_init_shm(rank, world, name.encode()) == 0
         ia, ja, a, f, ue = fa.poisson7pt(n)
         itp = fa.param_solver_init(); itp.tol = 1e-8; itp.itsolver_type = itsolver
-        amgp = fa.param_amg_init(); amgp.smoother = smoother; amgp.relaxation = 0.6667
+        amgp = fa.param_amg_init(); amgp.smoother = smoother; amgp.relaxation = relaxation; amgp.smooth_order = smooth_order
         amgp.cycle_type = cycle; amgp.AMG_type = amg_type
         if shared:   # one host setup: rank 0 publishes, the others attach
             seg = name + "_hier"
@@ -80,13 +81,13 @@ def _worker(rank, world, name, n, min_rows, cycle, q, shared=False, transport="s
         q.put((rank, "fail", traceback.format_exc(), None, None, None))
 
 
-def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_type=1, smoother=1, itsolver=1, tune=""):
+def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_type=1, smoother=1, itsolver=1, tune="", smooth_order=1, relaxation=0.6667):
     import multiprocessing as mp
     import tempfile
     from _libs import T, default_params, orc_solve, poisson7pt
     ia, ja, a, f, ue = poisson7pt(n)
     itp, amgp = default_params()
-    itp.tol = 1e-8; itp.itsolver_type = itsolver; amgp.smoother = smoother; amgp.relaxation = 0.6667; amgp.cycle_type = cycle; amgp.AMG_type = amg_type
+    itp.tol = 1e-8; itp.itsolver_type = itsolver; amgp.smoother = smoother; amgp.relaxation = relaxation; amgp.smooth_order = smooth_order; amgp.cycle_type = cycle; amgp.AMG_type = amg_type
     s_ref, x_ref, h_ref, rr = orc_solve(ia, ja, a, f, itp, amgp)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -94,7 +95,7 @@ def _run_ranks(world, n, min_rows, cycle, shared=False, transport="shm", amg_typ
     idfile = os.path.join(tempfile.gettempdir(), name + ".ncclid")
     if os.path.exists(idfile):
         os.remove(idfile)
-    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q, shared, transport, idfile, amg_type, smoother, itsolver, tune)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, name, n, min_rows, cycle, q, shared, transport, idfile, amg_type, smoother, itsolver, tune, smooth_order, relaxation)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -157,6 +158,19 @@ def test_peer_window_transport_matches_oracle(gpu, world, n, min_rows, cycle, sh
     the same partition / halo / replicated-level code as over RCCL, against the oracle -- iteration counts, residual histories,
     every rank's rows of the solution, bit-identical scalars on all ranks."""
     _run_ranks(world, n, min_rows, cycle, shared, transport="ipc", **kw)
+
+
+@pytest.mark.parametrize("world,n,min_rows,smoother,order,cycle", [
+    (2, 24, 500, "GS", 1, 1), (3, 24, 800, "GS", 0, 1), (2, 20, 300, "SOR", 0, 2), (4, 32, 3000, "SGS", 0, 1), (2, 24, 500, "GSF", 1, 1)],
+    ids=["GS C/F order (the reference's default), 2 ranks", "GS natural order, 3 ranks", "SOR, W-cycle", "SGS, 4 ranks", "F-point GS"])
+def test_sequential_smoothers_on_partitioned_levels_match_oracle(gpu, world, n, min_rows, smoother, order, cycle):
+    """fasp_hip_tune("seq_partition", 1): Gauss-Seidel / SOR sweeps on ROW-PARTITIONED levels -- the ranks take turns in sweep
+    order, a halo exchange in front of every turn (smoothers.hip.h, seq_sweep): the reference's sequential iteration with the
+    level's matrix and vectors distributed.  Against the oracle's single-process solve: iteration count, residual history,
+    every rank's rows of the solution; level 0 really is partitioned."""
+    from _libs import T
+    sm = {"GS": T.SMOOTHER_GS, "SOR": T.SMOOTHER_SOR, "SGS": T.SMOOTHER_SGS, "GSF": T.SMOOTHER_GSF}[smoother]
+    _run_ranks(world, n, min_rows, cycle, smoother=sm, tune="seq_partition=1", smooth_order=order, relaxation=1.1 if smoother == "SOR" else 0.6667)
 
 
 def test_rccl_transport_with_all_visible_gpus(gpu):
