@@ -173,6 +173,17 @@ def test_sequential_smoothers_on_partitioned_levels_match_oracle(gpu, world, n, 
     _run_ranks(world, n, min_rows, cycle, smoother=sm, tune="seq_partition=1", smooth_order=order, relaxation=1.1 if smoother == "SOR" else 0.6667)
 
 
+def test_peer_windows_with_small_mailboxes_and_turn_taking_sweeps(gpu, monkeypatch):
+    """Two more corners of the peer-window transport: mailboxes of 1 024 doubles (FASP_HIP_IPC_CAP) -- the level-0 halo of P7(32)
+    fills one exactly, the all-gather at the first whole level goes through in pieces -- and the sequential smoothers on
+    partitioned levels (ranks sweeping by turns) over it."""
+    from _libs import T
+    monkeypatch.setenv("FASP_HIP_IPC_CAP", "1024")
+    _run_ranks(2, 32, 3000, 1, transport="ipc")
+    monkeypatch.delenv("FASP_HIP_IPC_CAP")
+    _run_ranks(3, 24, 800, 1, transport="ipc", smoother=T.SMOOTHER_GS, tune="seq_partition=1", smooth_order=1)
+
+
 def test_rccl_transport_with_all_visible_gpus(gpu):
     """The production transport with real peers: world = number of visible GPUs (skipped on a one-GPU box, where the
     shared-memory transport above drives the same partition / halo / replicated-level code).  Halo ncclSend / ncclRecv,
