@@ -685,15 +685,18 @@ struct BsrArgs {
     int           ntiles;
 };
 
+typedef double bsr_f64x2_u __attribute__((ext_vector_type(2), aligned(8)));    // a 16-byte global load at the alignment of its elements
+typedef double bsr_f64x2_t __attribute__((ext_vector_type(2), aligned(16)));   // a 16-byte LDS store
 template <int NB, int OP>
 __global__ __launch_bounds__(BLOCK) void k_bsr_wstream(BsrArgs a)
 {
     constexpr int NB2 = NB * NB;
     constexpr int RW = 64 / NB;                 // block rows per wave tile
     constexpr int CAPB = 1536 / NB2;            // blocks per LDS chunk: 12 KiB per wave, three workgroups per CU (2048: two, measured 0.49 of peak against 0.58 on P7(128) x B3; 1024 splits the tiles of 7-block rows in two: 0.40)
-    __shared__ double lds_all[4 * CAPB * NB2];
+    constexpr int SLAB = (CAPB * NB2 + 3) & ~1;   // (even, and one spare pair: 16-byte stores of an odd-length chunk)
+    __shared__ __attribute__((aligned(16))) double lds_all[4 * SLAB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* lds = lds_all + wave * CAPB * NB2;
+    double* lds = lds_all + wave * SLAB;
     const int lb = lane / NB, r = lane - lb * NB;
 
     for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
@@ -714,23 +717,36 @@ __global__ __launch_bounds__(BLOCK) void k_bsr_wstream(BsrArgs a)
             }
             if (OP == 2) acc = a.b[row];
         }
-        for (int lo = k0; lo < k1; lo += CAPB) {
+        // Round 4: the value stream -- 8 nb^2 of the 8 nb^2 + 4 bytes of a block -- travels as 16-byte loads (a 64-lane load costs the
+        // address unit the same whatever the bytes per lane: kernels2.hip.h), and the NEXT chunk of the tile is in flight, in
+        // registers, while this one is consumed from LDS.  (Block values are 8-byte aligned: global memory takes 16-byte loads
+        // there; chunk sizes are even numbers of doubles or end the tile.)
+        constexpr int NV = (CAPB * NB2 + 127) / 128;   // 16-byte loads per lane and chunk
+        bsr_f64x2_u pv[NV];
+        auto fetch = [&](int lo) {
             const int hi = min(lo + CAPB, k1);
             const int ne = (hi - lo) * NB2;
             const double* src = a.val + (size_t)lo * NB2;
-            for (int base = 0; base < ne; base += 512) {
-                double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = base + lane + 64 * u;
-                    v[u] = (e < ne) ? __builtin_nontemporal_load(src + e) : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = base + lane + 64 * u;
-                    if (e < ne) lds[e] = v[u];
-                }
+            for (int u = 0; u < NV; ++u) {
+                const int e = 2 * (lane + 64 * u);
+                bsr_f64x2_u v;
+                v[0] = 0.0; v[1] = 0.0;
+                if (e + 1 < ne) v = __builtin_nontemporal_load(reinterpret_cast<const bsr_f64x2_u*>(src + e));
+                else if (e < ne) v[0] = __builtin_nontemporal_load(src + e);
+                pv[u] = v;
             }
+        };
+        if (k0 < k1) fetch(k0);
+        for (int lo = k0; lo < k1; lo += CAPB) {
+            const int hi = min(lo + CAPB, k1);
+            const int ne = (hi - lo) * NB2;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int e = 2 * (lane + 64 * u);
+                if (e < ne) { bsr_f64x2_t w; w[0] = pv[u][0]; w[1] = pv[u][1]; *reinterpret_cast<bsr_f64x2_t*>(lds + e) = w; }   // (the slab has room for the odd last double's neighbour)
+            }
+            if (lo + CAPB < k1) fetch(lo + CAPB);
             wave_lds_sync();
             if (act) {
                 // four (nb <= 3: eight) blocks per round trip: their column indices first, then the entries of x they name, then the
