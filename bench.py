@@ -35,8 +35,9 @@ cpu_baseline = the oracle (oracle/liboracle.so, a plain-C restatement of the ref
 
 N > 1: `python bench.py --gpus N` starts `python -m torch.distributed.run --nproc-per-node N
 bench.py ...` as a child (unless the driver already did: WORLD_SIZE set); the matrix is
-row-partitioned, halos and dot products go over RCCL (faspsolver_amd/csrc/comm.cpp,
-dist_plan.cpp; bench_dist.py).
+row-partitioned, halos and dot products go over the first transport whose probe passes on every
+rank -- peer windows over hipIpc-mapped device memory, then RCCL, then host-staged shared memory
+(BENCH_COMM=auto; faspsolver_amd/comm_probe.py, csrc/comm.cpp, comm_ipc.hip, dist_plan.cpp; bench_dist.py).
 """
 import argparse
 import ctypes as C

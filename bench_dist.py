@@ -29,11 +29,31 @@ def main(args, rank, world, local_rank):
 
     L = fa.lib()
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
-    backend = os.environ.get("BENCH_COMM", "rccl")
-    ndev = L.fasp_hip_device_count()
+    backend = os.environ.get("BENCH_COMM", "auto")
+    ndev = torch.cuda.device_count()   # (counting does not initialise the GPU: the probes below run before this process does)
     if ndev <= 0:
         B.log("bench_dist: no HIP device")
         sys.exit(2)
+    if backend == "auto":
+        # Which transport carries this run is decided by trying them: every rank runs a small partitioned solve over each
+        # candidate in a child process (faspsolver_amd/comm_probe.py) and the ranks take the first that passed everywhere.
+        from faspsolver_amd import comm_probe as P
+        pname = f"fasp_probe_{os.environ.get('MASTER_PORT', '0')}"
+        if ndev < world:
+            os.environ["FASP_HIP_ALLOW_DEVICE_WRAP"] = "1"
+
+        def all_min(ok):
+            t = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t[0])
+        tp = time.perf_counter()
+        backend = P.choose_transport(P.candidates(ndev, world), lambda t: P.run_child(t, rank, world, local_rank % ndev, f"{pname}_{t}"),
+                                     all_min, (lambda s: B.log("bench_dist: " + s)) if rank == 0 else (lambda s: None))
+        if backend is None:
+            B.log("bench_dist: no transport passed its probe on every rank")
+            sys.exit(2)
+        if rank == 0:
+            B.log(f"bench_dist: transport {backend} (probes took {time.perf_counter() - tp:.1f} s)")
     if backend == "shm" or (backend == "ipc" and ndev < world):   # validation: the ranks may share devices
         os.environ["FASP_HIP_ALLOW_DEVICE_WRAP"] = "1"
     dev = local_rank % ndev if backend == "shm" or ndev < world else local_rank
