@@ -15,7 +15,7 @@
 
 namespace fasp {
 
-int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team)
+int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team, int spine)
 {
     HostThreads host_team;   // (bounded OpenMP team for the row-parallel loops below; the dependency pass itself is sequential)
     if (team > 0) omp_set_num_threads(std::min(team, omp_get_max_threads()));   // (bounded OpenMP team for the row-parallel loops below; the dependency pass itself is sequential)
@@ -129,13 +129,18 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     while (L < 64 && (wide ? 6 : TRI_PF) * L < len90) L *= 2;   // (six rounds on the wide levels: measured at 128^3 against eight, level 1 F rows 472 -> 424 us, level 2 381 -> 360)
     if (seq_lanes > 0) { L = 1; while (L < 64 && L < seq_lanes) L *= 2; }
     const int rpw = 64 / L;   // rows per chunk (one wavefront)
-    if (!flow_ok) { H.flow_ok = false; return 1; }   // (the caller falls back to whole-row level scheduling: build_schedule + k_seq_level)
-    const int nstrips = (int)sq0.size() - 1;
     // rounds per chunk of this schedule: four where no row needs more (then the kernels with room for four run it)
     int nlowmax = 0;
 #pragma omp parallel for schedule(static) reduction(max : nlowmax)
     for (int q = 0; q < ns; ++q) nlowmax = std::max(nlowmax, nlow[q]);
-    const int PFS = (nlowmax + L - 1) / L > 4 ? TRI_PFMAX : 4;
+    // spine rounds (seq_sched.h): on chain-bound levels whose rows take eight rounds anyway (measured at 128^3 on the levels of
+    // P7: per sweep 13-22 % less there; schedules of four rounds gain nothing from two more for a spine)
+    // and where the two rounds given to it do not push entries into the tails (read one by one, not prefetched): every row fits
+    const int KT = (spine == 2 ? L >= 2 : (spine == 1 && !wide && L >= 8 && (nlowmax + L - 1) / L > 4 && nlowmax <= (TRI_PFMAX - TRI_SPINE) * L + TRI_SPINE)) ? TRI_SPINE : 0;
+    auto rounds_of = [&](int mx) { return std::max(1, std::min(TRI_PFMAX, KT + (std::max(0, mx - KT) + L - 1) / L)); };   // rounds a chunk stores, counted from the last
+    if (!flow_ok) { H.flow_ok = false; return 1; }   // (the caller falls back to whole-row level scheduling: build_schedule + k_seq_level)
+    const int nstrips = (int)sq0.size() - 1;
+    const int PFS = (KT || (nlowmax + L - 1) / L > 4) ? TRI_PFMAX : 4;   // (a spine comes with eight rounds: the kernels with room for four have none)
     // ---- per strip: rows by (class, sequence), chunks; positions = strip base + local index
     Buf<int> newpos((size_t)std::max(ns, 1)), seqof((size_t)std::max(ns, 1));   // position of sequence index q; sequence index at position p
     std::vector<int> schunks((size_t)nstrips + 1, 0);
@@ -159,7 +164,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
                 const int l = lev[seqof[p]];
                 int e = p, mx = 0;
                 while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
-                const int pf = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L));
+                const int pf = rounds_of(mx);
                 by += 16ll * (e - p) * L * (1 + PFS / 2 - (PFS - pf) / 2);
                 ++nch; p = e;
             }
@@ -167,6 +172,26 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
         }
     }
     lap("order and chunks per strip");
+    // How the strips overlap in dependency depth: a strip works on class c only if c lies in the range of classes of its rows.  On
+    // a chain-bound level (classes of a few rows) the sweep is a front that moves through the strips; more workgroups than a
+    // few times the number of strips that share a class only wait -- and their importer waves poll memory while they do
+    // (measured on the deep levels of P7(256): 3-8 % per sweep with the launch capped at 2-16 workgroups).  Wide levels are
+    // not a front (every grid plane is at work at once): no cap there.
+    int par = nstrips;
+    if (nstrips > 1 && !wide) {
+        std::vector<int> diff((size_t)nlev + 2, 0);
+        for (int s = 0; s < nstrips; ++s) {
+            int lmin = lev[sq0[s]], lmax = lmin;
+            for (int q = sq0[s]; q < sq0[s + 1]; ++q) { lmin = std::min(lmin, lev[q]); lmax = std::max(lmax, lev[q]); }
+            diff[(size_t)lmin]++; diff[(size_t)lmax + 1]--;
+        }
+        int cur = 0, mx = 0;
+        for (int l = 0; l <= nlev; ++l) { cur += diff[(size_t)l]; mx = std::max(mx, cur); }
+        par = std::max(1, mx);
+        if (timing) std::printf("    [sweep schedule] at most %d of %d strips share a dependency class\n", par, nstrips);
+    }
+    H.par = std::max(1, par);
+    lap("strip overlap");
     std::vector<int> sghost((size_t)nstrips + 1, 0);
     for (int s = 0; s < nstrips; ++s) { schunks[(size_t)s + 1] += schunks[(size_t)s]; sbytes[(size_t)s + 1] += sbytes[(size_t)s]; sghost[(size_t)s + 1] = sghost[(size_t)s] + sng[(size_t)s]; }
     const int nchunk = nstrips ? schunks[(size_t)nstrips] : 0;
@@ -178,7 +203,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     long long ntail = 0, nrest_total = 0;
     for (int p = 0; p < ns; ++p) {
         const int q = seqof[p];
-        ntail += std::max(0, nlow[q] - TRI_PFMAX * L); nrest_total += nrest[q];
+        ntail += std::max(0, nlow[q] - std::min(KT, nlow[q]) - (TRI_PFMAX - KT) * L); nrest_total += nrest[q];
         if (ntail > 0x7fffffffll || nrest_total > 0x7fffffffll) return ERROR_INPUT_PAR;
         tia[(size_t)p + 1] = (int)ntail; ria[(size_t)p + 1] = (int)nrest_total;
     }
@@ -230,7 +255,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
                 const int l = lev[seqof[p]];
                 int e = p, mx = 0;
                 while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
-                const int pf = std::max(1, std::min(TRI_PFMAX, (mx + L - 1) / L)), nr = e - p, nl = nr * L;
+                const int pf = rounds_of(mx), nr = e - p, nl = nr * L;
                 pfmax = std::max(pfmax, pf);
                 int wown = -1, wghost = -1;   // the operand expected last: the chunk's highest own row, else its latest ghost
                 cstrip[(size_t)ck] = s; clev[(size_t)ck] = l;
@@ -255,13 +280,17 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
                     // still waits for sits in its last slots (k_tri_flow sums the complete rounds while it waits)
                     std::stable_sort(low.begin(), low.end(), [&](const std::pair<int, double>& x, const std::pair<int, double>& y) {   // by (class, sequence): the same order however the strips are cut
                         return lev[x.first] != lev[y.first] ? lev[x.first] < lev[y.first] : x.first < y.first; });
-                    // right-aligned in the PFS rounds: the row's LAST L entries fill the last round; what does not fit (the oldest) is the tail
-                    const int nlo = (int)low.size(), ntl = std::max(0, nlo - TRI_PFMAX * L), shift = PFS * L - (nlo - ntl);
+                    // the last KT entries: the spine (last lane, last rounds).  The others right-aligned in the rounds in front of the
+                    // spine: the LAST L of them fill the last of those rounds; what does not fit (the oldest) is the tail
+                    const int nlo = (int)low.size(), ksp = std::min(KT, nlo), nb = nlo - ksp;
+                    const int ntl = std::max(0, nb - (TRI_PFMAX - KT) * L), shift = (PFS - KT) * L - (nb - ntl);
                     for (int en = 0; en < nlo; ++en) {
                         const int c = lds_index(newpos[low[(size_t)en].first]);
                         if (c < F.nrows) wown = std::max(wown, c); else wghost = std::max(wghost, c);
                         if (en >= ntl) {
-                            const int e2 = en - ntl + shift, qe = e2 / L, lane = (pp - p) * L + e2 % L;   // round, lane of the chunk
+                            int qe, lane;   // round, lane of the chunk
+                            if (en >= nb) { qe = PFS - (nlo - en); lane = (pp - p) * L + L - 1; }
+                            else { const int e2 = en - ntl + shift; qe = e2 / L; lane = (pp - p) * L + e2 % L; }
                             cols[lane * 8 + qe] = (unsigned short)c;
                             vals[(size_t)(qe / 2 - g0) * 2 * nl + (size_t)lane * 2 + (qe & 1)] = low[(size_t)en].second;
                         } else { tja[kt] = c; tval[kt] = low[(size_t)en].second; ++kt; }
@@ -290,7 +319,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
         for (int c = 0; c < nchunk; ++c) lchunks[(size_t)cur[(size_t)clev[(size_t)c] - 1]++] = c;
     }
     lap("chunks by class");
-    H.ns = ns; H.L = L; H.nolower = lower_total == 0; H.ntail = ntail; H.pfs = PFS; (void)pfmax; H.nstrips = nstrips; H.nchunk = nchunk; H.maxent = maxent;
+    H.ns = ns; H.L = L; H.nolower = lower_total == 0; H.ntail = ntail; H.pfs = PFS; H.kt = KT; (void)pfmax; H.nstrips = nstrips; H.nchunk = nchunk; H.maxent = maxent;
     H.nghost = nghost; H.slot_bytes = slot_bytes; H.nrest = nrest_total; H.flow_ok = flow_ok;
     const double avg_rest = ns > 0 ? (double)nrest_total / ns : 0.0;
     H.LR = 1;
@@ -305,7 +334,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
 // Gauss-Seidel sweep, and compare with the plain sequential sweep over the same rows.  Returns the largest difference relative
 // to the largest entry (< 0: error).  Also checks what the kernels rely on: every operand of a chunk is produced by an earlier
 // chunk of the strip or by an earlier strip; slots of unused rounds point at the constant.
-extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* seq, int ns, int strip_kb, int lanes)
+extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* seq, int ns, int strip_kb, int lanes, int spine)
 {
     using namespace fasp;
     if (!Av || !seq || ns < 0) return -1.0;
@@ -313,9 +342,9 @@ extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* s
     A.row = Av->row; A.col = Av->col; A.nnz = Av->nnz;
     A.ia.view(Av->IA, (size_t)Av->row + 1); A.ja.view(Av->JA, (size_t)std::max(Av->nnz, 1)); A.val.view(Av->val, (size_t)std::max(Av->nnz, 1));
     SplitHost H;
-    const int st = build_split_host(A, seq, ns, strip_kb, lanes, false, H);
+    const int st = build_split_host(A, seq, ns, strip_kb, lanes, false, H, 0, spine < 0 ? 1 : spine);
     if (st != FASP_SUCCESS) return st == 1 ? -2.0 : -3.0;
-    const int n = std::max(A.row, A.col), L = H.L, PF = H.pfs;   // (a rank's local rows of a partitioned level: columns beyond the rows are ghosts, never swept)
+    const int n = std::max(A.row, A.col), L = H.L, PF = H.pfs, KT = H.kt;   // (a rank's local rows of a partitioned level: columns beyond the rows are ghosts, never swept)
     std::vector<double> u((size_t)n), b((size_t)n), uref;
     for (int i = 0; i < n; ++i) { u[(size_t)i] = std::sin(0.37 * i) + 0.1; b[(size_t)i] = std::cos(0.11 * i); }
     uref = u;
@@ -358,17 +387,25 @@ extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* s
                     const int lane = r * L + sl;
                     double sacc = 0.0;
                     for (int k = H.tia[p] + sl; k < H.tia[p + 1]; k += L) sacc += H.tval[k] * operand(H.tja[k], ok);
-                    for (int q = 0; q < PF; ++q) {
+                    for (int q = 0; q < PF - KT; ++q) {
                         const int c = cols[lane * 8 + q];
                         const double v = q / 2 >= g0 ? vals[(size_t)(q / 2 - g0) * 2 * nl + (size_t)lane * 2 + (q & 1)] : 0.0;
                         if (q < PF - pf && c != F.nrows + F.nghost) ok = false;
                         sacc += v * operand(c, ok);
                     }
+                    for (int q = PF - KT; q < PF; ++q)   // spine rounds: the last lane's only
+                        if (sl != L - 1 && cols[lane * 8 + q] != F.nrows + F.nghost) ok = false;
                     tot += sacc;
+                }
+                double T = rec[(size_t)p] - tot;
+                for (int q = PF - KT; q < PF; ++q) {   // the spine, in order
+                    const int lane = r * L + L - 1, c = cols[lane * 8 + q];
+                    const double v = q / 2 >= g0 ? vals[(size_t)(q / 2 - g0) * 2 * nl + (size_t)lane * 2 + (q & 1)] : 0.0;
+                    T -= v * operand(c, ok);
                 }
                 if (!ok) return -5.0;
                 const double d = H.dr[2 * (size_t)p];
-                un[(size_t)r] = H.tr[2 * (size_t)p] < 0 ? u[(size_t)H.tr[2 * (size_t)p + 1]] : (rec[(size_t)p] - tot) / d;
+                un[(size_t)r] = H.tr[2 * (size_t)p] < 0 ? u[(size_t)H.tr[2 * (size_t)p + 1]] : T / d;
             }
             for (int r = 0; r < nr; ++r) { const int p = F.row0 + lo + r; W[(size_t)p] = un[(size_t)r]; done[(size_t)p] = 1; u[(size_t)H.tr[2 * (size_t)p + 1]] = un[(size_t)r]; }
         }

@@ -15,9 +15,15 @@ struct FlowStrip {     // 32 bytes
 constexpr int FLOW_LDS_ENT = 19 * 1024;        // doubles of LDS per strip: rows + ghosts + the constant 0.0
 constexpr int TRI_PFMAX = 8;                   // slot rounds a chunk can store; the kernels come with room for 4 (schedules that never need more) or 8
 constexpr int TRI_PF = 4;                      // slot rounds the lanes-per-row choice aims at
+// The SPINE of a row (chain-bound levels -- classes of a few rows -- with eight or more lanes per row and eight rounds): its last TRI_SPINE lower
+// entries in (class, sequence) order, i.e. the operands that become available last, sit in the row's LAST lane in the last
+// TRI_SPINE rounds (the other lanes' slots of those rounds point at the constant).  The lanes' partial sums over everything else
+// meet in that lane BEFORE the chain arrives; what is left between the arrival of the last operand and the row's value is two
+// multiply-adds and the update -- not a six-step cross-lane sum.
+constexpr int TRI_SPINE = 2;
 
 struct SplitHost {
-    int ns = 0, L = 1, LR = 1, pfs = 4, nstrips = 0, nchunk = 0, maxent = 0;
+    int ns = 0, L = 1, LR = 1, pfs = 4, kt = 0, nstrips = 0, nchunk = 0, maxent = 0, par = 1;   // kt: spine rounds (below); par: strips that share a dependency class at most (chain-bound levels; else nstrips)
     bool nolower = false, flow_ok = true;
     long long ntail = 0, nghost = 0, slot_bytes = 0, nrest = 0;
     std::vector<FlowStrip> strips;
@@ -30,6 +36,7 @@ struct SplitHost {
 // Returns FASP_SUCCESS, 1 when a row of the sweep reads more earlier rows than a strip's LDS holds (no split form: the caller
 // falls back to whole-row level scheduling), or a negative error code.
 // team > 0: OpenMP team of this call (several schedules are built side by side, one host thread each: smoothers.hip.h)
-int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team = 0);
+// spine: 1 where it pays (above), 0 never, 2 wherever a row has two lanes or more (tests)
+int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team = 0, int spine = 1);
 
 }  // namespace fasp

@@ -72,6 +72,7 @@ struct FlowArgs {
     unsigned*            sync;     // [0] ticket counter, [1] error word
     int                  nstrips;
     int                  form;     // 0  u_i = t * (1/a_ii)   1  u_i = t / a_ii   2  u_i = w (t / a_ii) + (1 - w) u_i
+    int                  kt;       // spine rounds of the schedule (seq_sched.h): 0 or TRI_SPINE
     double               w;
 };
 constexpr unsigned long long FLOW_SENT = 0x7FF4DEADBEEF0001ull;   // a signalling NaN: no arithmetic result carries these bits
@@ -198,12 +199,16 @@ template <int PF>
 __device__ __forceinline__ int flow_col(const FlowSet<PF>& r, int q) { return (int)((q & 1) ? (r.cw[q >> 1] >> 16) : (r.cw[q >> 1] & 0xffffu)); }
 
 // the row arithmetic shared by both forms (identical bits): s = the lane's tail entries, then its slot products in slot order
-// (summed left to right from 0.0); the DPP tree; the update in the group's last lane.  Returns the new value (valid in lane L - 1).
-template <int L>
-__device__ __forceinline__ double flow_row(const FlowArgs& a, double t, double uo, double d, double rd, int tn, double s)
+// (summed left to right from 0.0) over the rounds in front of the spine; the DPP tree; in the group's last lane t - s, minus the
+// spine products one after the other (KT = 0: none), and the update.  Returns the new value (valid in lane L - 1).
+template <int L, int KT>
+__device__ __forceinline__ double flow_row(const FlowArgs& a, double t, double uo, double d, double rd, int tn, double s, double v0 = 0.0, double x0 = 0.0, double v1 = 0.0, double x1 = 0.0)
 {
+    static_assert(KT == 0 || KT == 2, "no spine, or two rounds of it");
     s = group_sum_last<L>(s);
-    const double un = tri_update(t - s, d, rd, false, a.form, a.w, uo);
+    double T = t - s;
+    if (KT) { T = __builtin_fma(-v0, x0, T); T = __builtin_fma(-v1, x1, T); }
+    const double un = tri_update(T, d, rd, false, a.form, a.w, uo);
     return tn < 0 ? uo : un;   // a row that is left alone keeps its value (pass (1) made sure it does not look like "not there yet")
 }
 
@@ -243,9 +248,16 @@ __global__ __launch_bounds__(64) void k_tri_level(FlowArgs a, const int* __restr
         const int p = S.row0 + r.lo + rloc;
         double s = 0.0;
         if (r.tn & 0x7fffffff) { const int kb = a.tia[p], ke = a.tia[p + 1]; s = seq_row_sum<L>(a.tja, a.tval, kb + sl, ke, -1, ldw); }
+        double un;
+        if (a.kt) {
 #pragma unroll
-        for (int q = 0; q < PF; ++q) s += r.v[q] * ldw(flow_col(r, q));
-        const double un = flow_row<L>(a, r.t, r.uo, r.d, r.rd, r.tn, s);
+            for (int q = 0; q < PF - TRI_SPINE; ++q) s += r.v[q] * ldw(flow_col(r, q));
+            un = flow_row<L, TRI_SPINE>(a, r.t, r.uo, r.d, r.rd, r.tn, s, r.v[PF - 2], ldw(flow_col(r, PF - 2)), r.v[PF - 1], ldw(flow_col(r, PF - 1)));
+        } else {
+#pragma unroll
+            for (int q = 0; q < PF; ++q) s += r.v[q] * ldw(flow_col(r, q));
+            un = flow_row<L, 0>(a, r.t, r.uo, r.d, r.rd, r.tn, s);
+        }
         if (sl == L - 1) a.W[p] = un;
     }
 }
@@ -363,7 +375,8 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
             auto fetch = [&](FlowSet<PF>& X, int ci) {   // (past the end: an empty chunk, every load out of range)
                 flow_fetch<L, PF>(B, X, ci < S.nchunk ? flow_chunk(a, S.chunk0 + ci) : make_int4(0, 0, zero_idx, 0), lane);
             };
-            auto run = [&](const FlowSet<PF>& X) {
+            auto run = [&](const FlowSet<PF>& X, auto ktc) {
+                constexpr int KT = decltype(ktc)::value, PB = PF - KT;   // spine rounds (seq_sched.h), rounds in front of them
                 const bool on = rloc < X.n;
                 const int pl = X.lo + rloc;
                 double x[PF];
@@ -393,56 +406,81 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
                     s = seq_row_sum<L>(a.tja, a.tval, kb + sl, ke, -1, ldw);
                 }
                 FT(2);
-                // The entries of a row sit in the order of their dependency classes, right-aligned in the PF rounds: what is still
+                // The entries of a row sit in the order of their dependency classes, right-aligned in the PB rounds: what is still
                 // missing is in the LAST round(s).  The rounds that are complete are summed while the wave waits.
-                int qr = PF;   // first round somebody still waits for (wave-uniform)
+                int qr = PB;   // first round somebody still waits for (wave-uniform)
 #pragma unroll
-                for (int q = PF - 1; q >= 0; --q)
+                for (int q = PB - 1; q >= 0; --q)
                     if (__builtin_amdgcn_ballot_w64(((pend >> q) & 1u) != 0u)) qr = q;
 #pragma unroll
-                for (int q = 0; q < PF; ++q)
+                for (int q = 0; q < PB; ++q)
                     if (q < qr) s += X.v[q] * x[q];
-                if (qr < PF) {
-                    // round after round, oldest first: a tight loop per round somebody misses (read, compare, branch; wave-uniform
-                    // control flow: every lane reads, the lanes that miss decide).  The waits for the older rounds end while the
-                    // chain is still on its way; only the last one is part of it.
-#pragma unroll
-                    for (int q = 0; q < PF; ++q) {
-                        const bool miss = ((pend >> q) & 1u) != 0u;
-                        if (q >= qr && __builtin_amdgcn_ballot_w64(miss)) {
-                            const int c = flow_col(X, q);
-                            double y;
-                            for (;;) {
-                                y = lds_get(c);
-                                if (!__builtin_amdgcn_ballot_w64(miss && !flow_ready(y))) break;
-                                if (flow_give_up(a.sync, spins, t0)) break;
-                            }
-                            if (miss) x[q] = y;
+                // a tight loop per round somebody misses (read, compare, branch; wave-uniform control flow: every lane reads, the
+                // lanes that miss decide)
+                auto await = [&](int q) {
+                    const bool miss = ((pend >> q) & 1u) != 0u;
+                    if (__builtin_amdgcn_ballot_w64(miss)) {
+                        const int c = flow_col(X, q);
+                        double y;
+                        for (;;) {
+                            y = lds_get(c);
+                            if (!__builtin_amdgcn_ballot_w64(miss && !flow_ready(y))) break;
+                            if (flow_give_up(a.sync, spins, t0)) break;
                         }
+                        if (miss) x[q] = y;
                     }
-                    __builtin_amdgcn_s_setprio(3);   // from here to the store of the row's value the wave is the chain
-                    switch (qr) {   // the remaining rounds, in order
-                        case 0: s += X.v[0] * x[0]; [[fallthrough]];
-                        case 1: s += X.v[1] * x[1]; [[fallthrough]];
-                        case 2: s += X.v[2] * x[2]; [[fallthrough]];
-                        case 3: s += X.v[3] * x[3]; if (PF == 4) break; [[fallthrough]];
-                        case 4: s += X.v[PF - 4] * x[PF - 4]; [[fallthrough]];
-                        case 5: s += X.v[PF - 3] * x[PF - 3]; [[fallthrough]];
-                        case 6: s += X.v[PF - 2] * x[PF - 2]; [[fallthrough]];
-                        default: s += X.v[PF - 1] * x[PF - 1]; break;
+                };
+                if (qr < PB) {
+                    // round after round, oldest first.  The waits for the older rounds end while the chain is still on its way;
+                    // only the last one is part of it.
+#pragma unroll
+                    for (int q = 0; q < PB; ++q)
+                        if (q >= qr) await(q);
+                    if constexpr (KT == 0) {
+                        __builtin_amdgcn_s_setprio(3);   // from here to the store of the row's value the wave is the chain
+                        switch (qr) {   // the remaining rounds, in order
+                            case 0: s += X.v[0] * x[0]; [[fallthrough]];
+                            case 1: s += X.v[1] * x[1]; [[fallthrough]];
+                            case 2: s += X.v[2] * x[2]; [[fallthrough]];
+                            case 3: s += X.v[3] * x[3]; if (PF == 4) break; [[fallthrough]];
+                            case 4: s += X.v[PF - 4] * x[PF - 4]; [[fallthrough]];
+                            case 5: s += X.v[PF - 3] * x[PF - 3]; [[fallthrough]];
+                            case 6: s += X.v[PF - 2] * x[PF - 2]; [[fallthrough]];
+                            default: s += X.v[PF - 1] * x[PF - 1]; break;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < PB; ++q)
+                            if (q >= qr) s += X.v[q] * x[q];
                     }
                 }
                 FT(1);
-                if (on) {
-                    double un = flow_row<L>(a, X.t, X.uo, X.d, X.rd, X.tn, s);
-                    if (sl == L - 1) {
-                        lds_put(pl, un);
-                        __hip_atomic_store((gu64*)(a.W + S.row0 + pl), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through: other strips poll it)
-                        a.u[X.row] = un;
-                    }
+                double un;
+                if (KT) {
+                    // the spine: everything else has met in the row's last lane before the operands the chain brings are there
+                    const double S0 = group_sum_last<L>(s);
+                    double Tt = X.t - S0;
+                    await(PF - 2);
+                    Tt = __builtin_fma(-X.v[PF - 2], x[PF - 2], Tt);
+                    await(PF - 1);
+                    __builtin_amdgcn_s_setprio(3);   // from here to the store of the row's value the wave is the chain
+                    Tt = __builtin_fma(-X.v[PF - 1], x[PF - 1], Tt);
+                    const double uu = tri_update(Tt, X.d, X.rd, false, a.form, a.w, X.uo);
+                    un = X.tn < 0 ? X.uo : uu;
+                } else un = flow_row<L, 0>(a, X.t, X.uo, X.d, X.rd, X.tn, s);
+                if (on && sl == L - 1) {
+                    lds_put(pl, un);
+                    __hip_atomic_store((gu64*)(a.W + S.row0 + pl), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through: other strips poll it)
+                    a.u[X.row] = un;
                 }
                 __builtin_amdgcn_s_setprio(0);
                 FT(3);
+            };
+            const bool spine = PF == 8 && a.kt != 0;   // (schedules of four rounds have none: seq_sched.cpp)
+            auto run_any = [&](const FlowSet<PF>& X) {
+                if constexpr (PF == 4) run(X, std::integral_constant<int, 0>{});
+                else if (spine) run(X, std::integral_constant<int, TRI_SPINE>{});
+                else run(X, std::integral_constant<int, 0>{});
             };
             // A set is TOUCHED (its last load's result named in an empty asm) before the next fetch is issued: whatever wait
             // the compiler derives for the set lands in front of the younger loads, not behind them.
@@ -452,16 +490,16 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
             for (int ci = w; ci < S.nchunk; ci += NSET * NWC) {
                 FT(4); asm volatile("" ::"v"(X0.tn)); FT(0);
                 if (NSET == 3) fetch(X2, ci + 2 * NWC); else fetch(X1, ci + NWC);
-                run(X0);
+                run_any(X0);
                 if (ci + NWC >= S.nchunk) break;
                 FT(4); asm volatile("" ::"v"(X1.tn)); FT(0);
                 if (NSET == 3) fetch(X0, ci + 3 * NWC); else fetch(X0, ci + 2 * NWC);
-                run(X1);
+                run_any(X1);
                 if (NSET == 3) {
                     if (ci + 2 * NWC >= S.nchunk) break;
                     FT(4); asm volatile("" ::"v"(X2.tn)); FT(0);
                     fetch(X1, ci + 4 * NWC);
-                    run(X2);
+                    run_any(X2);
                 }
             }
 #ifdef FLOW_TIMING

@@ -126,7 +126,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
 {
     const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
     SplitHost H;
-    const int st = build_split_host(A, seq.data(), (int)seq.size(), g_tune.seq_strip_kb, g_tune.seq_lanes, timing, H);   // (seq_sched.cpp)
+    const int st = build_split_host(A, seq.data(), (int)seq.size(), g_tune.seq_strip_kb, g_tune.seq_lanes, timing, H, 0, g_tune.seq_spine);   // (seq_sched.cpp)
     if (st != FASP_SUCCESS) { S.flow_ok = false; return st; }
     return upload_split(H, S);
 }
@@ -179,7 +179,7 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S)
     HIPCK(hipStreamSynchronize(g_ctx.stream));   // (the host arrays go away with H)
     S.d_strips = d_strips; S.d_chunks = d_chunks;
     if (timing) std::printf("    [sweep schedule] %-28s %.3f s\n", "upload", wall_seconds() - t0);
-    S.ns = ns; S.L = H.L; S.LR = H.LR; S.nolower = H.nolower; S.ntail = H.ntail; S.pfmax = H.pfs; S.nstrips = H.nstrips; S.nchunk = H.nchunk; S.maxent = H.maxent;
+    S.ns = ns; S.L = H.L; S.LR = H.LR; S.nolower = H.nolower; S.ntail = H.ntail; S.pfmax = H.pfs; S.kt = H.kt; S.par = H.par; S.nstrips = H.nstrips; S.nchunk = H.nchunk; S.maxent = H.maxent;
     S.nghost = H.nghost; S.slot_bytes = H.slot_bytes; S.flow_ok = H.flow_ok;
     S.built = true;
     S.multicolor = false;
@@ -229,16 +229,16 @@ static void sched_jobs_start(fasp_hip_amg* h)
         if (k1 >= 0 && !h->L[l].sched[k1].built) jobs.push_back({l, k1});
     }
     const int team = std::max(2, host_threads() * 2 / std::max<int>(1, (int)jobs.size()));
-    const int strip_kb = g_tune.seq_strip_kb, lanes = g_tune.seq_lanes;
+    const int strip_kb = g_tune.seq_strip_kb, lanes = g_tune.seq_lanes, spine = g_tune.seq_spine;
     for (const auto& lk : jobs) {
         h->sched_jobs.emplace_back(new SchedJob);
         SchedJob* J = h->sched_jobs.back().get();
         J->level = lk.first; J->kind = lk.second;
         const HostLevel* HL = &h->H.L[(size_t)lk.first];
-        J->th = std::thread([J, HL, team, strip_kb, lanes]() {
+        J->th = std::thread([J, HL, team, strip_kb, lanes, spine]() {
             std::vector<int> seq;
             sweep_sequence(*HL, J->kind, seq);
-            J->st = build_split_host(HL->A, seq.data(), (int)seq.size(), strip_kb, lanes, false, J->H, team);
+            J->st = build_split_host(HL->A, seq.data(), (int)seq.size(), strip_kb, lanes, false, J->H, team, spine);
         });
     }
 }
@@ -296,8 +296,8 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         if (std::getenv("FASP_HIP_SETUP_TIMING")) {
             if (multicolor || S.rowlevels) std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind, multicolor ? "colours" : "whole-row dependency levels", (int)(seq.empty() ? S.ns : (int)seq.size()), (int)S.ptr.size() - 1);
             else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes, %d strips (%lld ghosts, at most %d values in LDS), %d chunks, %d lanes per row, "
-                             "%.1f slot bytes per row (%lld tail entries), rest pass %d lanes per row%s, built in %.3f s\n",
-                             level, kind, S.ns, (int)S.cptr.size() - 1, S.nstrips, S.nghost, S.maxent + 1, S.nchunk, S.L, S.ns ? (double)S.slot_bytes / S.ns : 0.0, S.ntail, S.LR,
+                             "%d rounds (%d of them spine), %.1f slot bytes per row (%lld tail entries), rest pass %d lanes per row%s, built in %.3f s\n",
+                             level, kind, S.ns, (int)S.cptr.size() - 1, S.nstrips, S.nghost, S.maxent + 1, S.nchunk, S.L, S.pfmax, S.kt, S.ns ? (double)S.slot_bytes / S.ns : 0.0, S.ntail, S.LR,
                              "", wall_seconds() - t0);
         }
     }
@@ -331,7 +331,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
     FlowArgs fa{};
     fa.strips = (const FlowStrip*)S.d_strips; fa.chunks = (const int4*)S.d_chunks; fa.slots = S.d_slots; fa.gpos = S.d_gpos; fa.cstrip = S.d_cstrip;
     fa.tia = S.d_tia; fa.tja = S.d_tja; fa.tval = S.d_tval; fa.rec = S.d_rec; fa.dr = S.d_dr; fa.tr = S.d_tr; fa.W = S.d_W; fa.u = D.x;
-    fa.sync = S.d_prog; fa.nstrips = S.nstrips; fa.form = form; fa.w = w;
+    fa.sync = S.d_prog; fa.nstrips = S.nstrips; fa.form = form; fa.w = w; fa.kt = S.kt;
     // pass (1): everything that reads old values, all rows at once
     {
         const int rpb = BLOCK / S.LR;
@@ -369,7 +369,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
                 attr_set = true;                                                                                            \
             }                                                                                                               \
             const int nt = FlowGeom<PP>::NT, per_cu = std::max(1, std::min(2048 / nt, by_lds));                             \
-            const int grid = std::max(1, std::min(S.nstrips, per_cu * g_ctx.num_cu));                                       \
+            const int grid = std::max(1, std::min(std::min(S.nstrips, per_cu * g_ctx.num_cu), g_tune.seq_grid > 0 ? g_tune.seq_grid : g_tune.seq_grid < 0 || S.par >= S.nstrips ? 1 << 30 : 2 * S.par + 2)); \
             hipLaunchKernelGGL((k_tri_flow<LL, PP, TT>), dim3(grid), dim3(nt), dyn, g_ctx.stream, fa);                      \
         }
 #define FLOW_LAUNCH(LL)                                                                                                     \

@@ -2029,6 +2029,8 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_flow")) { g_tune.seq_flow = value; if (value) g_flow_disabled = false; }
     else if (!std::strcmp(key, "seq_strip_kb")) g_tune.seq_strip_kb = value;
     else if (!std::strcmp(key, "seq_jobs")) g_tune.seq_jobs = value;
+    else if (!std::strcmp(key, "seq_grid")) g_tune.seq_grid = value;     // workgroups of the dataflow solve at most (0: twice the strips the chain front is in at a time + 2, seq_sched.cpp; < 0: as many as are resident)
+    else if (!std::strcmp(key, "seq_spine")) g_tune.seq_spine = value;   // 0 never, 1 where the schedule chooses it, 2 wherever a row has two lanes (seq_sched.h); read when a schedule is built
     else if (!std::strcmp(key, "seq_partition")) g_seq_partition = value;
     else if (!std::strcmp(key, "fuse_zr")) g_tune.fuse_zr = value;
     else if (!std::strcmp(key, "fuse_presmooth")) g_tune.fuse_presmooth = value;

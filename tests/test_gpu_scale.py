@@ -225,17 +225,23 @@ def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
     r = np.random.default_rng(11).standard_normal(len(f))
     out = []
     try:
-        for flow, kb in ((1, 512), (0, 512), (1, 16), (1, 1 << 20)):
-            L.fasp_hip_tune(b"seq_flow", flow); L.fasp_hip_tune(b"seq_strip_kb", kb)
-            H = fa.AMG(ia, ja, a, amgp)    # (the strips are cut when a level's schedule is built: one hierarchy per setting)
-            out.append(H.precond(r))
-            out.append(H.precond(out[-1]))
-            H.close()
+        # spine (seq_sched.h: a row's last two operands in its last lane, after the cross-lane sum) is part of a schedule's
+        # arithmetic: 1 = where the schedule chooses it (the default), 2 = on every level with two lanes per row or more
+        for spine in (1, 2):
+            L.fasp_hip_tune(b"seq_spine", spine)
+            for flow, kb in ((1, 512), (0, 512), (1, 16), (1, 1 << 20)):
+                L.fasp_hip_tune(b"seq_flow", flow); L.fasp_hip_tune(b"seq_strip_kb", kb)
+                H = fa.AMG(ia, ja, a, amgp)    # (the strips are cut when a level's schedule is built: one hierarchy per setting)
+                out.append(H.precond(r))
+                out.append(H.precond(out[-1]))
+                H.close()
     finally:
-        L.fasp_hip_tune(b"seq_flow", 1); L.fasp_hip_tune(b"seq_strip_kb", 512)
+        L.fasp_hip_tune(b"seq_flow", 1); L.fasp_hip_tune(b"seq_strip_kb", 512); L.fasp_hip_tune(b"seq_spine", 1)
     assert np.all(np.isfinite(out[0]))
-    for k in range(2, len(out), 2):
-        assert np.array_equal(out[0], out[k]) and np.array_equal(out[1], out[k + 1])
+    for base in (0, 8):   # the four settings of one spine mode agree bit for bit
+        for k in range(base + 2, base + 8, 2):
+            assert np.array_equal(out[base], out[k]) and np.array_equal(out[base + 1], out[k + 1])
+    assert np.allclose(out[0], out[8], rtol=1e-10, atol=1e-13 * np.abs(out[0]).max())   # the two modes: the same sweep, rounded differently
 
 
 @pytest.mark.gpu

@@ -11,13 +11,13 @@ import faspsolver_amd as fa
 from faspsolver_amd import _types as T
 
 
-def _selftest(ia, ja, a, seq, strip_kb=512, lanes=0):
+def _selftest(ia, ja, a, seq, strip_kb=512, lanes=0, spine=-1):
     L = fa.lib()
     L.fasp_hip_seq_schedule_selftest.restype = C.c_double
-    L.fasp_hip_seq_schedule_selftest.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
+    L.fasp_hip_seq_schedule_selftest.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]
     A, keep = T.as_csr(ia, ja, a)
     seq = np.ascontiguousarray(seq, dtype=np.int32)
-    return L.fasp_hip_seq_schedule_selftest(C.byref(A), seq.ctypes.data_as(C.POINTER(C.c_int)), len(seq), strip_kb, lanes)
+    return L.fasp_hip_seq_schedule_selftest(C.byref(A), seq.ctypes.data_as(C.POINTER(C.c_int)), len(seq), strip_kb, lanes, spine)
 
 
 @pytest.mark.parametrize("strip_kb", [16, 512])
@@ -46,8 +46,9 @@ def test_schedule_on_every_level_of_a_hierarchy_with_cf_sweeps():
             seqs += [idx[cf == 1], idx[cf != 1]]
         for seq in seqs:
             for kb in (16, 512):
-                res = _selftest(lia, lja, lv, seq, kb)
-                assert 0.0 <= res <= 1e-12, (lev, kb, res)
+                for spine in (0, 1, 2):   # never / where the schedule chooses it (deep levels, >= 8 lanes) / wherever a row has two lanes
+                    res = _selftest(lia, lja, lv, seq, kb, 0, spine)
+                    assert 0.0 <= res <= 1e-12, (lev, kb, spine, res)
     H.close()
 
 
@@ -62,8 +63,9 @@ def test_schedule_with_tails_and_many_lanes():
     ia, ja, a = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
     for kb in (16, 512):
         for seq in (np.arange(n), np.arange(n)[::-1]):
-            res = _selftest(ia, ja, a, seq, kb)
-            assert 0.0 <= res <= 1e-12, (kb, res)
+            for spine in (0, 1):   # (a chain of 1500 classes of one row: the schedule chooses the spine form itself)
+                res = _selftest(ia, ja, a, seq, kb, 0, spine)
+                assert 0.0 <= res <= 1e-12, (kb, spine, res)
 
 
 def test_a_row_that_reads_more_than_a_strip_holds_is_reported():
@@ -97,5 +99,6 @@ def test_rows_without_a_usable_diagonal_are_left_alone():
     ja = np.array([c for r, c, v in keep], np.int32); a = np.array([v for r, c, v in keep])
     for seq in (np.arange(n), np.arange(n)[::-1]):
         for kb in (16, 512):
-            res = _selftest(ia, ja, a, seq, kb)
-            assert 0.0 <= res <= 1e-12, (kb, res)
+            for lanes, spine in ((0, -1), (8, 2)):
+                res = _selftest(ia, ja, a, seq, kb, lanes, spine)
+                assert 0.0 <= res <= 1e-12, (kb, lanes, spine, res)
