@@ -30,8 +30,10 @@ other_configs = configs 3 and 5 of BASELINE.json at full size and the reference'
            the mean of three timed solves each, with the reference's iteration count beside the measured one.
 cpu_baseline = the oracle (oracle/liboracle.so, a plain-C restatement of the reference's
            serial algorithm with OpenMP row loops) on the node's host cores, same problem, same
-           hierarchy, a bounded number of PCG iterations scaled to the full solve; once on all
-           cores and once on one thread.
+           hierarchy, a bounded number of PCG iterations scaled to the full solve; once on a team
+           (threads pinned one per physical core over both sockets, pages first touched by the thread
+           that reads them; the team size that is fastest on this host, of all physical cores and
+           halves of that) and once on one thread.
 
 N > 1: `python bench.py --gpus N` starts `python -m torch.distributed.run --nproc-per-node N
 bench.py ...` as a child (unless the driver already did: WORLD_SIZE set); the matrix is
@@ -117,8 +119,37 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def physical_cores():
+    """One logical CPU per physical core of the CPUs this process may run on, in CPU order (sockets one after the other)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        return list(range(os.cpu_count() or 1))
+    out = []
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+            first = int(sib.replace("-", ",").split(",")[0])
+        except Exception:
+            first = c
+        if first == c or first not in allowed:
+            out.append(c)
+    return out or allowed
+
+
+def baseline_threads():
+    """Threads of the all-core CPU baseline: every physical core (BENCH_CPU_THREADS caps it)."""
+    cap = int(os.environ.get("BENCH_CPU_THREADS", "0"))
+    n = len(physical_cores())
+    return max(1, min(n, cap) if cap > 0 else n)
+
+
 def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s, threads):
-    """Time the oracle on the host cores on a bounded sample of the same solve."""
+    """Time the oracle on the host cores on a bounded sample of the same solve.  threads > 1: the team is pinned, one thread
+    per physical core spread over the sockets, and the hierarchy is copied so that every page is first touched by the
+    thread that reads it (oracle/fasp_oracle.c, timing mode) -- what an OpenMP code does on a NUMA host.
+    threads = a list: one PCG iteration is timed at each count and the sample runs at the fastest (on a host that other
+    jobs share, the team that finishes first is not the largest)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _libs
     O = _libs.oracle()
@@ -127,38 +158,68 @@ def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s, threads):
     # which the host AMG setup reads afterwards (round 2's variable-coefficient setup ran on ONE thread behind the
     # one-thread baseline: 24.7 s instead of 10 s) -- restored on the way out
     omp_before = int(os.environ.get("OMP_NUM_THREADS", "0")) or host_cores()
-    O.orc_set_threads(threads)
     nl = H.num_levels
-    buf = C.create_string_buffer(O.orc_sizeof_amg())
-    O.orc_amg_borrow_begin(buf, nl)
-    keep = []
-    for l in range(nl):
-        vA = T.dCSRmat(); fa.lib().fasp_hip_amg_get_matrix(H.h, l, 0, C.byref(vA))
-        if l < nl - 1:
-            vP = T.dCSRmat(); vR = T.dCSRmat(); cf = T.ivector()
-            fa.lib().fasp_hip_amg_get_matrix(H.h, l, 1, C.byref(vP))
-            fa.lib().fasp_hip_amg_get_matrix(H.h, l, 2, C.byref(vR))
-            fa.lib().fasp_hip_amg_get_cfmark(H.h, l, C.byref(cf))
-            O.orc_amg_borrow_level(buf, l, C.byref(vA), C.byref(vP), C.byref(vR), cf.val)
-            keep += [vA, vP, vR, cf]
-        else:
-            O.orc_amg_borrow_level(buf, l, C.byref(vA), None, None, None)
-            keep += [vA]
-    O.orc_amg_borrow_end(buf)
     A, _k = T.as_csr(ia, ja, a)
     bv, _f = T.as_vec(f)
 
-    def run(maxit):
-        itp, amgp = workload_params()
-        itp.maxit = maxit
-        x = np.zeros(len(f))
-        xv, x = T.as_vec(x)
-        hist = np.zeros(600); nh = C.c_int(0); rr = C.c_double(0)
-        t0 = time.perf_counter()
-        st = O.orc_solve_with_hierarchy(buf, C.byref(A), C.byref(bv), C.byref(xv), C.byref(itp),
-                                        C.byref(amgp), T.dp(hist), 600, C.byref(nh), C.byref(rr))
-        return time.perf_counter() - t0, st, hist[:nh.value].copy(), rr.value
+    class Session:
+        def __init__(self, nthreads):
+            self.n = nthreads
+            O.orc_set_threads(nthreads)
+            self.buf = C.create_string_buffer(O.orc_sizeof_amg())
+            O.orc_amg_borrow_begin(self.buf, nl)
+            self.keep = []
+            for l in range(nl):
+                vA = T.dCSRmat(); fa.lib().fasp_hip_amg_get_matrix(H.h, l, 0, C.byref(vA))
+                if l < nl - 1:
+                    vP = T.dCSRmat(); vR = T.dCSRmat(); cf = T.ivector()
+                    fa.lib().fasp_hip_amg_get_matrix(H.h, l, 1, C.byref(vP))
+                    fa.lib().fasp_hip_amg_get_matrix(H.h, l, 2, C.byref(vR))
+                    fa.lib().fasp_hip_amg_get_cfmark(H.h, l, C.byref(cf))
+                    O.orc_amg_borrow_level(self.buf, l, C.byref(vA), C.byref(vP), C.byref(vR), cf.val)
+                    self.keep += [vA, vP, vR, cf]
+                else:
+                    O.orc_amg_borrow_level(self.buf, l, C.byref(vA), None, None, None)
+                    self.keep += [vA]
+            O.orc_amg_borrow_end(self.buf)
+            self.pinned = False
+            if nthreads > 1:
+                cores = physical_cores()
+                # thread t -> the t-th of `nthreads` cores spread evenly over the list (both sockets at any thread count)
+                pick = [cores[(t * len(cores)) // nthreads] for t in range(nthreads)] if nthreads <= len(cores) else cores
+                arr = (C.c_int * len(pick))(*pick)
+                self.pinned = O.orc_pin_threads(arr, len(pick)) == 0
+                O.orc_amg_place(self.buf)
 
+        def run(self, maxit):
+            itp, amgp = workload_params()
+            itp.maxit = maxit
+            x = np.zeros(len(f))
+            xv, x = T.as_vec(x)
+            hist = np.zeros(600); nh = C.c_int(0); rr = C.c_double(0)
+            t0 = time.perf_counter()
+            st = O.orc_solve_with_hierarchy(self.buf, C.byref(A), C.byref(bv), C.byref(xv), C.byref(itp),
+                                            C.byref(amgp), T.dp(hist), 600, C.byref(nh), C.byref(rr))
+            return time.perf_counter() - t0, st, hist[:nh.value].copy(), rr.value
+
+        def close(self):
+            O.orc_amg_borrow_free(self.buf)
+            if self.pinned:
+                O.orc_unpin_threads()
+
+    tried = None
+    if isinstance(threads, (list, tuple)):
+        tried = {}
+        for n in threads:
+            S = Session(n)
+            S.run(1)                      # (first touch of the work vectors)
+            tried[n] = S.run(1)[0]
+            S.close()
+        threads = min(tried, key=tried.get)
+    S = Session(threads)
+    run = S.run
+    if threads > 1:
+        run(1)
     t1, st1, h1, _ = run(1)  # 1 iteration (+ the initial preconditioner apply): sizes the sample
     per_it = max(t1 / 2.0, 1e-6)
     k = int(max(1, min(iters_gpu, budget_s / per_it)))
@@ -183,11 +244,26 @@ def cpu_baseline(H, ia, ja, a, f, iters_gpu, hist_gpu, budget_s, threads):
         rrk = None
     ncmp = min(len(hk) - 1, len(hist_gpu) - 1)
     hist_dev = float(np.max(np.abs(hk[:ncmp] - hist_gpu[:ncmp]) / hk[:ncmp])) if ncmp > 0 else None
-    O.orc_amg_borrow_free(buf)
+    pinned = S.pinned
+    S.close()
     O.orc_set_threads(omp_before)
-    return {"value": len(f) / t_full, "unit": "DOF/s", "cores": threads, "kind": "port",
-            "sample": sample, "seconds_full_solve_est": t_full, "cpu_model": cpu_model(),
-            "host_cores_visible": host_cores()}, its_cpu, rrk, hist_dev
+    out = {"value": len(f) / t_full, "unit": "DOF/s", "cores": threads, "kind": "port",
+           "sample": sample, "seconds_full_solve_est": t_full, "cpu_model": cpu_model(),
+           "host_cores_visible": host_cores(),
+           "placement": ("threads pinned one per physical core, pages first touched by the reading thread" if pinned else
+                         "one thread" if threads == 1 else "threads not pinned")}
+    if tried is not None:
+        out["seconds_per_iteration_by_threads"] = {str(n): round(v, 4) for n, v in tried.items()}
+    return out, its_cpu, rrk, hist_dev
+
+
+def baseline_candidates():
+    """Thread counts the all-core baseline tries: every physical core, and halves of it down to 8."""
+    top = baseline_threads()
+    c, n = [], top
+    while n >= 8:
+        c.append(n); n //= 2
+    return c or [top]
 
 
 def pmc_traffic(kernel_name, workload, n):
@@ -499,9 +575,8 @@ def main():
     }
     if not args.no_cpu_baseline:
         try:
-            allc = max(1, min(host_cores(), int(os.environ.get("BENCH_CPU_THREADS", "64"))))
             cb, its_cpu, rr_cpu, hist_dev = cpu_baseline(H, ia, ja, a, f, int(st), hist,
-                                                         float(os.environ.get("BENCH_CPU_BUDGET_S", "15")), allc)
+                                                         float(os.environ.get("BENCH_CPU_BUDGET_S", "15")), baseline_candidates())
             out["cpu_baseline"] = cb
             out["parity"] = {"iters_gpu": int(st), "iters_cpu": its_cpu, "relres_gpu": stats.relres,
                              "relres_cpu": rr_cpu, "max_rel_dev_residual_history": hist_dev}

@@ -204,9 +204,8 @@ def main(args, rank, world, local_rank):
             # the same routine as the single-GPU line: the oracle on this node's host cores, on rank 0 only, on a bounded
             # sample of the same solve (rank 0 holds the global host hierarchy it published)
             try:
-                allc = max(1, min(B.host_cores(), int(os.environ.get("BENCH_CPU_THREADS", "64"))))
                 cb, its_cpu, rr_cpu, hist_dev = B.cpu_baseline(H, ia, ja, a, f, int(st), hist,
-                                                               float(os.environ.get("BENCH_CPU_BUDGET_S", "15")), allc)
+                                                               float(os.environ.get("BENCH_CPU_BUDGET_S", "15")), B.baseline_candidates())
                 out["cpu_baseline"] = cb
                 out["parity"] = {"iters_gpu": int(st), "iters_cpu": its_cpu, "relres_gpu": stats.relres,
                                  "relres_cpu": rr_cpu, "max_rel_dev_residual_history": hist_dev}

@@ -41,6 +41,8 @@ typedef struct {
     /* AMG_data.cycle_type of every level (PreAMGSetupRS.c:325, PreAMGSetupUA.c:380-401): read by the
      * nonlinear AMLI cycle, which drops to a V-cycle where it is <= 1 */
     int level_cycle_type[ORC_MAX_LVL];
+    /* borrowed hierarchies only: the level matrices are this structure's own copies (orc_amg_place) */
+    int placed;
 } orc_amg;
 
 /* threads used by the row-parallel loops (1 = exact serial order everywhere,
@@ -161,6 +163,12 @@ void orc_amg_borrow_begin(orc_amg* mgl, int num_levels);
 void orc_amg_borrow_level(orc_amg* mgl, int l, const dCSRmat* A, const dCSRmat* P,
                           const dCSRmat* R, const int* cfmark);
 void orc_amg_borrow_end(orc_amg* mgl);
+/* cpu_baseline timing only (bench.py): pin the OpenMP team (thread t -> cpus[t mod n]) / undo it; replace the borrowed
+ * level matrices by copies whose pages are first touched by the threads that will read them (static row schedule) --
+ * what an OpenMP code on a multi-socket host does.  Arithmetic is untouched. */
+int  orc_pin_threads(const int* cpus, int n);
+void orc_unpin_threads(void);
+void orc_amg_place(orc_amg* mgl);
 void orc_amg_borrow_free(orc_amg* mgl);
 
 /* BSR path (config 3): UA-AMG on the condensed matrix + block Jacobi + Krylov.
