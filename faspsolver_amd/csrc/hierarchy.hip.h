@@ -29,11 +29,10 @@ struct DevLevel {
     // 1 descending, 2 ascending C rows, 3 ascending F rows, 4 descending from row n-2
     struct Sched {
         bool built = false, multicolor = false; int* d_order = nullptr; int* d_ptr = nullptr; std::vector<int> ptr;
-        // split form (seq_split.hip.h): strips / chunks / slots of the lower part, tail CSR, the rest as a CSR, per-position records and W
-        int ns = 0, L = 1, LR = 1, pfmax = 1, kt = 0, par = 1, nstrips = 0, nchunk = 0, maxent = 0; bool nolower = false, flow_ok = false, rowlevels = false; long long ntail = 0, nghost = 0, slot_bytes = 0;
+        // split form (seq_split.hip.h): strips / chunks / slots of the lower part (rows and virtual rows), the rest as a CSR, per-position records and W
+        int ns = 0, L = 1, LR = 1, pfmax = 1, kt = 0, par = 1, nstrips = 0, nchunk = 0, maxent = 0; bool nolower = false, flow_ok = false, rowlevels = false; int nrows = 0, nvirt = 0, nclasses = 0; long long nghost = 0, slot_bytes = 0;
         std::vector<int> cptr;   // split form: dependency class -> first entry of d_lchunks (k_tri_level)
         void* d_strips = nullptr; void* d_chunks = nullptr; unsigned char* d_slots = nullptr; int* d_gpos = nullptr; int* d_cstrip = nullptr; int* d_lchunks = nullptr;
-        int* d_tia = nullptr; int* d_tja = nullptr; double* d_tval = nullptr;
         int* d_ria = nullptr; int* d_rja = nullptr; double* d_rval = nullptr; double* d_rec = nullptr; double* d_dr = nullptr; int* d_tr = nullptr; double* d_W = nullptr; unsigned* d_prog = nullptr;
         std::vector<void*> owned;   // device arrays of the split form (d_order and d_ptr among them)
         void release()

@@ -1,4 +1,4 @@
-// seq_sched.cpp -- host side of the sequential sweeps' split form (seq_split.hip.h): strips, chunks, slots, ghost lists, tails,
+// seq_sched.cpp -- host side of the sequential sweeps' split form (seq_split.hip.h): strips, chunks, slots, ghost lists, virtual rows,
 // the rest CSR and the per-row records of one (level, sweep kind), built once on first use.  Pure host code in a translation
 // unit of its own: the OpenMP loops below are compiled by g++ (the HIP translation unit is compiled by clang with
 // -fopenmp=libgomp, which parses the directives and generates NO parallel code -- measured: the fill ran on one thread).
@@ -36,6 +36,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     // contiguous ranges of the sweep sequence, closed when the lower part reaches the target size (12 bytes per entry + 40 per
     // row) or the LDS is full (own rows + distinct earlier rows read + the constant).
     const long long target = std::max(16, strip_kb) * 1024ll;
+    constexpr int VCAP_MAX = (TRI_PFMAX - TRI_SPINE) * 64 + TRI_SPINE;   // slots of a work item with 64 lanes and a spine
     std::vector<int> sq0(1, 0), sng;   // first sequence index of every strip (+ end), ghosts per strip
     bool flow_ok = true;
     {
@@ -62,8 +63,11 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
             lev[q] = l + 1; nlow[q] = c; nrest[q] = A.ia[i + 1] - A.ia[i] - c - dg;
             nlev = std::max(nlev, l + 1);
             lower_total += c;
-            const long long rb = 40 + 12ll * c;
-            if (rows > 0 && (bytes + rb > target || rows + 1 + ng + (int)fresh.size() + 1 > FLOW_LDS_ENT || rows >= 0xffff)) {
+            // (a row of more entries than a work item holds comes with virtual rows, below: counted here as if the item were the largest
+            // possible -- the lanes per row are not known yet; verified once they are)
+            const int vx = c > VCAP_MAX ? (c - VCAP_MAX) / (VCAP_MAX - 1) + 1 : 0;
+            const long long rb = 40ll * (1 + vx) + 12ll * (c + vx);
+            if (rows > 0 && (bytes + rb > target || rows + 1 + vx + ng + (int)fresh.size() + 1 > FLOW_LDS_ENT || rows + 1 + vx >= 0xffff)) {
                 // close the strip in front of this row; the row opens the next one: every earlier row it reads is a ghost now
                 sng.push_back(ng);
                 sq0.push_back(q);
@@ -75,8 +79,8 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
                     if ((unsigned)pj < (unsigned)q && gmark[pj] != sid) { gmark[pj] = sid; ++ng; }
                 }
             } else ng += (int)fresh.size();
-            if (1 + ng + 1 > FLOW_LDS_ENT) flow_ok = false;   // one row that reads more than the LDS holds: no dataflow form for this sweep
-            ++rows; bytes += rb;
+            if (1 + vx + ng + 1 > FLOW_LDS_ENT) flow_ok = false;   // one row that reads more than the LDS holds: no dataflow form for this sweep
+            rows += 1 + vx; bytes += rb;
         }
         if (ns > 0) { sng.push_back(ng); sq0.push_back(ns); }
     }
@@ -84,14 +88,13 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     if (lower_total == 0) {
         // No row of the sweep reads another one's new value (the C rows / the F rows of a 7-point level 0): the sweep is pass (1)
         // and an elementwise update.  Positions = sequence order; nothing but the rest CSR and the per-row records is needed.
-        H.tia.alloc((size_t)ns + 1); H.ria.alloc((size_t)ns + 1);
+        H.ria.alloc((size_t)ns + 1);
         H.ria[0] = 0;
         long long nr = 0;
-        for (int q = 0; q < ns; ++q) { H.tia[q] = 0; nr += nrest[q]; if (nr > 0x7fffffffll) return ERROR_INPUT_PAR; H.ria[(size_t)q + 1] = (int)nr; }
-        H.tia[ns] = 0;
+        for (int q = 0; q < ns; ++q) { nr += nrest[q]; if (nr > 0x7fffffffll) return ERROR_INPUT_PAR; H.ria[(size_t)q + 1] = (int)nr; }
         H.rja.alloc((size_t)std::max<long long>(nr, 1)); H.rval.alloc((size_t)std::max<long long>(nr, 1));
         H.tr.alloc(2 * (size_t)std::max(ns, 1)); H.dr.alloc(2 * (size_t)std::max(ns, 1));
-        H.tja.alloc(1); H.tval.alloc(1); H.chunks.alloc(4); H.cstrip.alloc(1); H.lchunks.alloc(1); H.gpos.alloc(1); H.slots.alloc(16);
+        H.chunks.alloc(4); H.cstrip.alloc(1); H.lchunks.alloc(1); H.gpos.alloc(1); H.slots.alloc(16);
 #pragma omp parallel for schedule(static)
         for (int q = 0; q < ns; ++q) {
             const int i = seq[q];
@@ -107,7 +110,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
         }
         lap("rest (no lower entries)");
         H.cptr.assign(2, 0);
-        H.ns = ns; H.L = 1; H.nolower = true; H.ntail = 0; H.pfs = 4; H.nstrips = 0; H.nchunk = 0; H.maxent = 0; H.nghost = 0; H.slot_bytes = 0; H.nrest = nr; H.flow_ok = true;
+        H.ns = ns; H.nrows = ns; H.nvirt = 0; H.nclasses = nlev; H.L = 1; H.nolower = true; H.pfs = 4; H.nstrips = 0; H.nchunk = 0; H.maxent = 0; H.nghost = 0; H.slot_bytes = 0; H.nrest = nr; H.flow_ok = true;
         const double avg = ns > 0 ? (double)nr / ns : 0.0;
         H.LR = 1;
         while (H.LR < 64 && 4 * H.LR < avg) H.LR *= 2;
@@ -128,42 +131,102 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     int L = 1;
     while (L < 64 && (wide ? 6 : TRI_PF) * L < len90) L *= 2;   // (six rounds on the wide levels: measured at 128^3 against eight, level 1 F rows 472 -> 424 us, level 2 381 -> 360)
     if (seq_lanes > 0) { L = 1; while (L < 64 && L < seq_lanes) L *= 2; }
-    const int rpw = 64 / L;   // rows per chunk (one wavefront)
     // rounds per chunk of this schedule: four where no row needs more (then the kernels with room for four run it)
     int nlowmax = 0;
 #pragma omp parallel for schedule(static) reduction(max : nlowmax)
     for (int q = 0; q < ns; ++q) nlowmax = std::max(nlowmax, nlow[q]);
     // spine rounds (seq_sched.h): on chain-bound levels whose rows take eight rounds anyway (measured at 128^3 on the levels of
     // P7: per sweep 13-22 % less there; schedules of four rounds gain nothing from two more for a spine)
-    // and where the two rounds given to it do not push entries into the tails (read one by one, not prefetched): every row fits
-    const int KT = (spine == 2 ? L >= 2 : (spine == 1 && !wide && L >= 8 && (nlowmax + L - 1) / L > 4 && nlowmax <= (TRI_PFMAX - TRI_SPINE) * L + TRI_SPINE)) ? TRI_SPINE : 0;
+    int KT = (spine == 2 ? L >= 2 : (spine == 1 && !wide && L >= 8 && (nlowmax + L - 1) / L > 4)) ? TRI_SPINE : 0;
+    // A work item holds CAP lower entries.  A row with more is split (seq_sched.h, "virtual rows"); its virtual rows must fit its own slots.
+    auto cap_of = [&](int lanes) { return (TRI_PFMAX - KT) * lanes + KT; };
+    while (L < 64 && (long long)cap_of(L) * (cap_of(L) - 1) < nlowmax) L *= 2;
+    if ((long long)cap_of(L) * (cap_of(L) - 1) < nlowmax) { H.flow_ok = false; return 1; }
+    const int rpw = 64 / L;   // rows per chunk (one wavefront)
+    const int CAP = cap_of(L);
     auto rounds_of = [&](int mx) { return std::max(1, std::min(TRI_PFMAX, KT + (std::max(0, mx - KT) + L - 1) / L)); };   // rounds a chunk stores, counted from the last
     if (!flow_ok) { H.flow_ok = false; return 1; }   // (the caller falls back to whole-row level scheduling: build_schedule + k_seq_level)
     const int nstrips = (int)sq0.size() - 1;
     const int PFS = (KT || (nlowmax + L - 1) / L > 4) ? TRI_PFMAX : 4;   // (a spine comes with eight rounds: the kernels with room for four have none)
-    // ---- per strip: rows by (class, sequence), chunks; positions = strip base + local index
-    Buf<int> newpos((size_t)std::max(ns, 1)), seqof((size_t)std::max(ns, 1));   // position of sequence index q; sequence index at position p
+    // ---- virtual rows: V(q) per sequence index, their classes.  Classes are DOUBLED from here on: a row of class l is 2 l, a
+    // virtual row whose newest entry has class l' is 2 l' + 1 -- above everything it reads, below the row that reads it
+    // (l' <= l - 1), never in one chunk or one launch-per-class with it.
+    auto nvirt_of = [&](int c) { return c > CAP ? (c - CAP + CAP - 2) / (CAP - 1) : 0; };
+    Buf<int> voff((size_t)ns + 1);
+    voff[0] = 0;
+    for (int q = 0; q < ns; ++q) voff[(size_t)q + 1] = voff[q] + nvirt_of(nlow[q]);
+    const int nvirt = voff[ns];
+    if ((long long)ns + nvirt > 0x7fffffffll) return ERROR_INPUT_PAR;
+    const int npos = ns + nvirt;
+    Buf<int> vcls((size_t)std::max(nvirt, 1)), vcnt((size_t)std::max(nvirt, 1));   // class (doubled) and entry count of every virtual row
+    // the lower entries of a row in the order of their dependency classes (= the order in which they become available), by
+    // (class, sequence): the same order however the strips are cut
+    auto sorted_lower = [&](int q, std::vector<std::pair<int, double>>& low) {
+        const int i = seq[q];
+        low.clear();
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+            const int j = A.ja[k];
+            if (j == i || j >= n) continue;
+            const int pj = pos[j];
+            if ((unsigned)pj < (unsigned)q) low.emplace_back(pj, A.val[k]);
+        }
+        std::stable_sort(low.begin(), low.end(), [&](const std::pair<int, double>& x, const std::pair<int, double>& y) {
+            return lev[x.first] != lev[y.first] ? lev[x.first] < lev[y.first] : x.first < y.first; });
+    };
+    if (nvirt > 0) {
+#pragma omp parallel
+        {
+            std::vector<std::pair<int, double>> low;
+#pragma omp for schedule(dynamic, 64)
+            for (int q = 0; q < ns; ++q) {
+                const int V = voff[(size_t)q + 1] - voff[q];
+                if (!V) continue;
+                sorted_lower(q, low);
+                const int nlo = (int)low.size(), NV = nlo - (CAP - V);   // entries that go to the virtual rows: the oldest
+                for (int k = 0; k < V; ++k) {
+                    const int c = std::min(CAP, NV - k * CAP);
+                    vcnt[(size_t)voff[q] + k] = c;
+                    vcls[(size_t)voff[q] + k] = 2 * lev[low[(size_t)(k * CAP + c - 1)].first] + 1;
+                }
+            }
+        }
+    }
+    lap("virtual rows");
+    // ---- per strip: items (rows and virtual rows) by (class, sequence, part), chunks; positions = strip base + local index
+    Buf<int> newpos((size_t)std::max(ns, 1)), vpos((size_t)std::max(nvirt, 1));   // position of row q / of virtual row voff[q] + k
+    Buf<int> itq((size_t)std::max(npos, 1)), itk((size_t)std::max(npos, 1));       // item at position p: its row, its part (V(q): the row itself)
     std::vector<int> schunks((size_t)nstrips + 1, 0);
     std::vector<long long> sbytes((size_t)nstrips + 1, 0);
-#pragma omp parallel
+    auto item_class = [&](int q, int k) { const int V = voff[(size_t)q + 1] - voff[q]; return k < V ? vcls[(size_t)voff[q] + k] : 2 * lev[q]; };
+    auto item_count = [&](int q, int k) { const int V = voff[(size_t)q + 1] - voff[q]; return k < V ? vcnt[(size_t)voff[q] + k] : (V ? CAP : nlow[q]); };
+    int bad_strip = 0;
+#pragma omp parallel reduction(+ : bad_strip)
     {
         std::vector<int> cnt;
 #pragma omp for schedule(dynamic, 1)
         for (int s = 0; s < nstrips; ++s) {
-            const int q0 = sq0[s], q1 = sq0[s + 1];
-            int lmin = lev[q0], lmax = lev[q0];
-            for (int q = q0; q < q1; ++q) { lmin = std::min(lmin, lev[q]); lmax = std::max(lmax, lev[q]); }
+            const int q0 = sq0[s], q1 = sq0[s + 1], p0 = q0 + voff[q0], p1 = q1 + voff[q1];
+            if (p1 - p0 + sng[(size_t)s] + 1 > FLOW_LDS_ENT || p1 - p0 > 0xffff) ++bad_strip;
+            int lmin = 2 * lev[q0], lmax = 2 * lev[q0];
+            for (int q = q0; q < q1; ++q)
+                for (int k = 0, V = voff[(size_t)q + 1] - voff[q]; k <= V; ++k) { const int c = item_class(q, k); lmin = std::min(lmin, c); lmax = std::max(lmax, c); }
             cnt.assign((size_t)(lmax - lmin + 2), 0);
-            for (int q = q0; q < q1; ++q) cnt[(size_t)(lev[q] - lmin + 1)]++;
+            for (int q = q0; q < q1; ++q)
+                for (int k = 0, V = voff[(size_t)q + 1] - voff[q]; k <= V; ++k) cnt[(size_t)(item_class(q, k) - lmin + 1)]++;
             for (size_t l = 1; l < cnt.size(); ++l) cnt[l] += cnt[l - 1];
-            for (int q = q0; q < q1; ++q) { const int p = q0 + cnt[(size_t)(lev[q] - lmin)]++; newpos[q] = p; seqof[p] = q; }
-            // chunks: runs of one class, rpw rows at most
+            for (int q = q0; q < q1; ++q)
+                for (int k = 0, V = voff[(size_t)q + 1] - voff[q]; k <= V; ++k) {
+                    const int p = p0 + cnt[(size_t)(item_class(q, k) - lmin)]++;
+                    itq[p] = q; itk[p] = k;
+                    if (k < V) vpos[(size_t)voff[q] + k] = p; else newpos[q] = p;
+                }
+            // chunks: runs of one class, rpw items at most
             int nch = 0;
             long long by = 0;
-            for (int p = q0; p < q1;) {
-                const int l = lev[seqof[p]];
+            for (int p = p0; p < p1;) {
+                const int l = item_class(itq[p], itk[p]);
                 int e = p, mx = 0;
-                while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
+                while (e < p1 && e - p < rpw && item_class(itq[e], itk[e]) == l) { mx = std::max(mx, item_count(itq[e], itk[e])); ++e; }
                 const int pf = rounds_of(mx);
                 by += 16ll * (e - p) * L * (1 + PFS / 2 - (PFS - pf) / 2);
                 ++nch; p = e;
@@ -171,6 +234,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
             schunks[(size_t)s + 1] = nch; sbytes[(size_t)s + 1] = by;
         }
     }
+    if (bad_strip) { H.flow_ok = false; return 1; }   // (the estimate of the virtual rows in the strip cutting was too low: whole-row level scheduling)
     lap("order and chunks per strip");
     // How the strips overlap in dependency depth: a strip works on class c only if c lies in the range of classes of its rows.  On
     // a chain-bound level (classes of a few rows) the sweep is a front that moves through the strips; more workgroups than a
@@ -196,19 +260,19 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     for (int s = 0; s < nstrips; ++s) { schunks[(size_t)s + 1] += schunks[(size_t)s]; sbytes[(size_t)s + 1] += sbytes[(size_t)s]; sghost[(size_t)s + 1] = sghost[(size_t)s] + sng[(size_t)s]; }
     const int nchunk = nstrips ? schunks[(size_t)nstrips] : 0;
     const long long slot_bytes = nstrips ? sbytes[(size_t)nstrips] : 0, nghost = nstrips ? sghost[(size_t)nstrips] : 0;
-    // ---- tail and rest offsets by position
-    H.tia.alloc((size_t)ns + 1); H.ria.alloc((size_t)ns + 1);
-    Buf<int>&tia = H.tia, &ria = H.ria;
-    tia[0] = 0; ria[0] = 0;
-    long long ntail = 0, nrest_total = 0;
-    for (int p = 0; p < ns; ++p) {
-        const int q = seqof[p];
-        ntail += std::max(0, nlow[q] - std::min(KT, nlow[q]) - (TRI_PFMAX - KT) * L); nrest_total += nrest[q];
-        if (ntail > 0x7fffffffll || nrest_total > 0x7fffffffll) return ERROR_INPUT_PAR;
-        tia[(size_t)p + 1] = (int)ntail; ria[(size_t)p + 1] = (int)nrest_total;
+    // ---- rest offsets by position (virtual rows have no rest)
+    H.ria.alloc((size_t)npos + 1);
+    Buf<int>& ria = H.ria;
+    ria[0] = 0;
+    long long nrest_total = 0;
+    for (int p = 0; p < npos; ++p) {
+        const int q = itq[p];
+        if (itk[p] == voff[(size_t)q + 1] - voff[q]) nrest_total += nrest[q];
+        if (nrest_total > 0x7fffffffll) return ERROR_INPUT_PAR;
+        ria[(size_t)p + 1] = (int)nrest_total;
     }
     lap("offsets");
-    // ---- fill: chunk descriptors, slots, ghost lists, tails, the rest, the per-row records
+    // ---- fill: chunk descriptors, slots, ghost lists, the rest, the per-item records
     H.strips.assign((size_t)nstrips, FlowStrip{});
     std::vector<FlowStrip>& strips = H.strips;
     H.chunks.alloc(4 * (size_t)std::max(nchunk, 1));
@@ -220,28 +284,28 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     Buf<unsigned char>& slots = H.slots;
     H.gpos.alloc((size_t)std::max<long long>(nghost, 1));
     Buf<int>& gpos = H.gpos;
-    H.tja.alloc((size_t)std::max<long long>(ntail, 1)); H.rja.alloc((size_t)std::max<long long>(nrest_total, 1)); H.tr.alloc(2 * (size_t)std::max(ns, 1));
-    Buf<int>&tja = H.tja, &rja = H.rja, &tr = H.tr;
-    H.tval.alloc((size_t)std::max<long long>(ntail, 1)); H.rval.alloc((size_t)std::max<long long>(nrest_total, 1)); H.dr.alloc(2 * (size_t)std::max(ns, 1));
-    Buf<double>&tval = H.tval, &rval = H.rval, &dr = H.dr;
+    H.rja.alloc((size_t)std::max<long long>(nrest_total, 1)); H.tr.alloc(2 * (size_t)std::max(npos, 1));
+    Buf<int>&rja = H.rja, &tr = H.tr;
+    H.rval.alloc((size_t)std::max<long long>(nrest_total, 1)); H.dr.alloc(2 * (size_t)std::max(npos, 1));
+    Buf<double>&rval = H.rval, &dr = H.dr;
     int pfmax = 1, maxent = 0, bad = 0;
 #pragma omp parallel reduction(max : pfmax, maxent) reduction(+ : bad)
     {
         // ghost index of an earlier position: open addressing, emptied per strip by a stamp
         constexpr int HB = 1 << 16;   // (2 x FLOW_LDS_ENT rounded up: at most FLOW_LDS_ENT distinct keys)
         std::vector<int> hkey((size_t)HB, -1), hval((size_t)HB, 0), hstamp((size_t)HB, -1);
-        std::vector<std::pair<int, double>> low;
+        std::vector<std::pair<int, double>> low, ent;
 #pragma omp for schedule(dynamic, 1)
         for (int s = 0; s < nstrips; ++s) {
-            const int q0 = sq0[s], q1 = sq0[s + 1];
+            const int q0 = sq0[s], q1 = sq0[s + 1], p0 = q0 + voff[q0], p1 = q1 + voff[q1];
             FlowStrip& F = strips[(size_t)s];
-            F.slot0 = sbytes[(size_t)s]; F.row0 = q0; F.nrows = q1 - q0; F.chunk0 = schunks[(size_t)s]; F.nchunk = schunks[(size_t)s + 1] - schunks[(size_t)s];
+            F.slot0 = sbytes[(size_t)s]; F.row0 = p0; F.nrows = p1 - p0; F.chunk0 = schunks[(size_t)s]; F.nchunk = schunks[(size_t)s + 1] - schunks[(size_t)s];
             F.ghost0 = sghost[(size_t)s]; F.nghost = sng[(size_t)s];
             maxent = std::max(maxent, F.nrows + F.nghost);
             const int zero_idx = F.nrows + F.nghost;
             int ng = 0;
-            auto lds_index = [&](int p) -> int {   // position of a lower entry -> LDS index of this strip
-                if (p >= q0) return p - q0;
+            auto lds_index = [&](int p) -> int {   // position of an operand -> LDS index of this strip
+                if (p >= p0) return p - p0;
                 unsigned h = ((unsigned)p * 2654435761u) >> 16;
                 for (;; h = (h + 1) & (HB - 1)) {
                     if (hstamp[h] != s) { hstamp[h] = s; hkey[h] = p; hval[h] = ng; gpos[(size_t)F.ghost0 + ng] = p; return F.nrows + ng++; }
@@ -251,10 +315,10 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
             unsigned char* sb = slots.data() + F.slot0;
             long long off = 0;
             int ck = F.chunk0;
-            for (int p = q0; p < q1; ++ck) {
-                const int l = lev[seqof[p]];
+            for (int p = p0; p < p1; ++ck) {
+                const int l = item_class(itq[p], itk[p]);
                 int e = p, mx = 0;
-                while (e < q1 && e - p < rpw && lev[seqof[e]] == l) { mx = std::max(mx, nlow[seqof[e]]); ++e; }
+                while (e < p1 && e - p < rpw && item_class(itq[e], itk[e]) == l) { mx = std::max(mx, item_count(itq[e], itk[e])); ++e; }
                 const int pf = rounds_of(mx), nr = e - p, nl = nr * L;
                 pfmax = std::max(pfmax, pf);
                 int wown = -1, wghost = -1;   // the operand expected last: the chunk's highest own row, else its latest ghost
@@ -265,41 +329,53 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
                 const int g0 = (PFS - pf) / 2;   // value planes in front of g0 are not stored
                 for (long long t = 0; t < 2ll * nl * (PFS / 2 - g0); ++t) vals[t] = 0.0;
                 for (int pp = p; pp < e; ++pp) {
-                    const int q = seqof[pp], i = seq[q];
-                    size_t kt = (size_t)tia[pp], kr = (size_t)ria[pp];
+                    const int q = itq[pp], k = itk[pp], i = seq[q], V = voff[(size_t)q + 1] - voff[q];
+                    // the item's entries as (position, value), oldest first.  A virtual row: its slice of the row's oldest entries.  The row
+                    // itself: its virtual rows (coefficient 1: their values are sums of products), then its newest entries.
+                    ent.clear();
                     double dg = 0.0;
-                    low.clear();
-                    for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
-                        const int j = A.ja[k];
-                        if (j == i) { dg = A.val[k]; continue; }   // the last diagonal hit, as the reference's loop leaves it
-                        const int pj = j < n ? pos[j] : -1;
-                        if ((unsigned)pj < (unsigned)q) low.emplace_back(pj, A.val[k]);
-                        else { rja[kr] = j; rval[kr] = A.val[k]; ++kr; }
+                    if (k == V) {   // the row: also its rest (everything that reads old values) and its diagonal
+                        size_t kr = (size_t)ria[pp];
+                        low.clear();
+                        for (int kk = A.ia[i]; kk < A.ia[i + 1]; ++kk) {
+                            const int j = A.ja[kk];
+                            if (j == i) { dg = A.val[kk]; continue; }   // the last diagonal hit, as the reference's loop leaves it
+                            const int pj = j < n ? pos[j] : -1;
+                            if ((unsigned)pj < (unsigned)q) low.emplace_back(pj, A.val[kk]);
+                            else { rja[kr] = j; rval[kr] = A.val[kk]; ++kr; }
+                        }
+                        std::stable_sort(low.begin(), low.end(), [&](const std::pair<int, double>& x, const std::pair<int, double>& y) {   // by (class, sequence): the same order however the strips are cut
+                            return lev[x.first] != lev[y.first] ? lev[x.first] < lev[y.first] : x.first < y.first; });
+                        for (int v = 0; v < V; ++v) ent.emplace_back(vpos[(size_t)voff[q] + v], 1.0);
+                        const int first = V ? (int)low.size() - (CAP - V) : 0;
+                        for (int en = first; en < (int)low.size(); ++en) ent.emplace_back(newpos[low[(size_t)en].first], low[(size_t)en].second);
+                    } else {
+                        sorted_lower(q, low);
+                        for (int en = k * CAP; en < k * CAP + vcnt[(size_t)voff[q] + k]; ++en) ent.emplace_back(newpos[low[(size_t)en].first], low[(size_t)en].second);
                     }
-                    // lower entries in the order of their dependency classes (= the order in which they become available): what a row
-                    // still waits for sits in its last slots (k_tri_flow sums the complete rounds while it waits)
-                    std::stable_sort(low.begin(), low.end(), [&](const std::pair<int, double>& x, const std::pair<int, double>& y) {   // by (class, sequence): the same order however the strips are cut
-                        return lev[x.first] != lev[y.first] ? lev[x.first] < lev[y.first] : x.first < y.first; });
                     // the last KT entries: the spine (last lane, last rounds).  The others right-aligned in the rounds in front of the
-                    // spine: the LAST L of them fill the last of those rounds; what does not fit (the oldest) is the tail
-                    const int nlo = (int)low.size(), ksp = std::min(KT, nlo), nb = nlo - ksp;
-                    const int ntl = std::max(0, nb - (TRI_PFMAX - KT) * L), shift = (PFS - KT) * L - (nb - ntl);
+                    // spine: the LAST L of them fill the last of those rounds
+                    const int nlo = (int)ent.size(), ksp = std::min(KT, nlo), nb = nlo - ksp, shift = (PFS - KT) * L - nb;
+                    if (nb > (PFS - KT) * L) { ++bad; continue; }
                     for (int en = 0; en < nlo; ++en) {
-                        const int c = lds_index(newpos[low[(size_t)en].first]);
+                        const int c = lds_index(ent[(size_t)en].first);
                         if (c < F.nrows) wown = std::max(wown, c); else wghost = std::max(wghost, c);
-                        if (en >= ntl) {
-                            int qe, lane;   // round, lane of the chunk
-                            if (en >= nb) { qe = PFS - (nlo - en); lane = (pp - p) * L + L - 1; }
-                            else { const int e2 = en - ntl + shift; qe = e2 / L; lane = (pp - p) * L + e2 % L; }
-                            cols[lane * 8 + qe] = (unsigned short)c;
-                            vals[(size_t)(qe / 2 - g0) * 2 * nl + (size_t)lane * 2 + (qe & 1)] = low[(size_t)en].second;
-                        } else { tja[kt] = c; tval[kt] = low[(size_t)en].second; ++kt; }
+                        int qe, lane;   // round, lane of the chunk
+                        if (en >= nb) { qe = PFS - (nlo - en); lane = (pp - p) * L + L - 1; }
+                        else { const int e2 = en + shift; qe = e2 / L; lane = (pp - p) * L + e2 % L; }
+                        cols[lane * 8 + qe] = (unsigned short)c;
+                        vals[(size_t)(qe / 2 - g0) * 2 * nl + (size_t)lane * 2 + (qe & 1)] = ent[(size_t)en].second;
                     }
-                    const bool alone = !(std::fabs(dg) > SMALLREAL);
-                    dr[2 * (size_t)pp] = dg; dr[2 * (size_t)pp + 1] = alone ? 0.0 : 1.0 / dg;
-                    tr[2 * (size_t)pp] = (tia[(size_t)pp + 1] - tia[pp]) | (alone ? (int)0x80000000 : 0); tr[2 * (size_t)pp + 1] = i;
+                    if (k == V) {
+                        const bool alone = !(std::fabs(dg) > SMALLREAL);
+                        dr[2 * (size_t)pp] = dg; dr[2 * (size_t)pp + 1] = alone ? 0.0 : 1.0 / dg;
+                        tr[2 * (size_t)pp] = alone ? (int)0x80000000 : 0; tr[2 * (size_t)pp + 1] = i;
+                    } else {   // a virtual row: value = the sum of its products; no diagonal, no right-hand side, no row of u
+                        dr[2 * (size_t)pp] = 1.0; dr[2 * (size_t)pp + 1] = 1.0;
+                        tr[2 * (size_t)pp] = FLOW_VIRTUAL; tr[2 * (size_t)pp + 1] = -1;
+                    }
                 }
-                { int* cd = &chunks[4 * (size_t)ck]; cd[0] = (p - q0) | (nr << 16) | (pf << 24); cd[1] = (int)(off / 16); cd[2] = wown >= 0 ? wown : wghost >= 0 ? wghost : zero_idx; cd[3] = 0; }
+                { int* cd = &chunks[4 * (size_t)ck]; cd[0] = (p - p0) | (nr << 16) | (pf << 24); cd[1] = (int)(off / 16); cd[2] = wown >= 0 ? wown : wghost >= 0 ? wghost : zero_idx; cd[3] = 0; }
                 off += 16ll * nl * (1 + PFS / 2 - g0);
                 p = e;
             }
@@ -308,19 +384,20 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     }
     lap("fill");
     if (bad) { std::fprintf(stderr, "### ERROR: fasp_hip: inconsistent strip bookkeeping in the sweep schedule\n"); return ERROR_MISC; }
-    // chunks by dependency class (k_tri_level): a counting sort
-    H.cptr.assign((size_t)nlev + 1, 0);
-    for (int c = 0; c < nchunk; ++c) H.cptr[(size_t)clev[(size_t)c]]++;
-    for (int l = 0; l < nlev; ++l) H.cptr[(size_t)l + 1] += H.cptr[(size_t)l];
+    // chunks by dependency class (k_tri_level): a counting sort over the doubled classes
+    const int ncls = 2 * nlev + 2;
+    H.cptr.assign((size_t)ncls + 1, 0);
+    for (int c = 0; c < nchunk; ++c) H.cptr[(size_t)clev[(size_t)c] + 1]++;
+    for (int l = 0; l < ncls; ++l) H.cptr[(size_t)l + 1] += H.cptr[(size_t)l];
     H.lchunks.alloc((size_t)std::max(nchunk, 1));
     Buf<int>& lchunks = H.lchunks;
     {
         std::vector<int> cur(H.cptr.begin(), H.cptr.end() - 1);
-        for (int c = 0; c < nchunk; ++c) lchunks[(size_t)cur[(size_t)clev[(size_t)c] - 1]++] = c;
+        for (int c = 0; c < nchunk; ++c) lchunks[(size_t)cur[(size_t)clev[(size_t)c]]++] = c;
     }
     lap("chunks by class");
-    H.ns = ns; H.L = L; H.nolower = lower_total == 0; H.ntail = ntail; H.pfs = PFS; H.kt = KT; (void)pfmax; H.nstrips = nstrips; H.nchunk = nchunk; H.maxent = maxent;
-    H.nghost = nghost; H.slot_bytes = slot_bytes; H.nrest = nrest_total; H.flow_ok = flow_ok;
+    H.ns = npos; H.nrows = ns; H.nvirt = nvirt; H.L = L; H.nolower = lower_total == 0; H.pfs = PFS; H.kt = KT; (void)pfmax; H.nstrips = nstrips; H.nchunk = nchunk; H.maxent = maxent;
+    H.nghost = nghost; H.slot_bytes = slot_bytes; H.nrest = nrest_total; H.flow_ok = flow_ok; H.nclasses = nlev;
     const double avg_rest = ns > 0 ? (double)nrest_total / ns : 0.0;
     H.LR = 1;
     while (H.LR < 64 && 4 * H.LR < avg_rest) H.LR *= 2;
@@ -334,7 +411,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
 // Gauss-Seidel sweep, and compare with the plain sequential sweep over the same rows.  Returns the largest difference relative
 // to the largest entry (< 0: error).  Also checks what the kernels rely on: every operand of a chunk is produced by an earlier
 // chunk of the strip or by an earlier strip; slots of unused rounds point at the constant.
-extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* seq, int ns, int strip_kb, int lanes, int spine)
+extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* seq, int ns, int strip_kb, int lanes, int spine, int* info)
 {
     using namespace fasp;
     if (!Av || !seq || ns < 0) return -1.0;
@@ -344,6 +421,7 @@ extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* s
     SplitHost H;
     const int st = build_split_host(A, seq, ns, strip_kb, lanes, false, H, 0, spine < 0 ? 1 : spine);
     if (st != FASP_SUCCESS) return st == 1 ? -2.0 : -3.0;
+    if (info) { info[0] = H.L; info[1] = H.pfs; info[2] = H.kt; info[3] = H.nvirt; info[4] = H.nstrips; info[5] = H.nchunk; }
     const int n = std::max(A.row, A.col), L = H.L, PF = H.pfs, KT = H.kt;   // (a rank's local rows of a partitioned level: columns beyond the rows are ghosts, never swept)
     std::vector<double> u((size_t)n), b((size_t)n), uref;
     for (int i = 0; i < n; ++i) { u[(size_t)i] = std::sin(0.37 * i) + 0.1; b[(size_t)i] = std::cos(0.11 * i); }
@@ -354,14 +432,21 @@ extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* s
         for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) { if (A.ja[k] == i) d = A.val[k]; else t -= A.val[k] * uref[(size_t)A.ja[k]]; }
         if (std::fabs(d) > SMALLREAL) uref[(size_t)i] = t / d;
     }
-    std::vector<double> W((size_t)std::max(ns, 1)), rec((size_t)std::max(ns, 1));
-    std::vector<char> done((size_t)std::max(ns, 1), 0);
-    for (int p = 0; p < ns; ++p) {   // pass (1)
+    const int np = H.ns;   // positions: the rows of the sweep and the virtual rows
+    if (H.nrows != ns || np != ns + H.nvirt) return -6.0;
+    std::vector<double> W((size_t)std::max(np, 1)), rec((size_t)std::max(np, 1));
+    std::vector<char> done((size_t)std::max(np, 1), 0);
+    int nreal = 0;
+    for (int p = 0; p < np; ++p) {   // pass (1)
+        const int row = H.tr[2 * (size_t)p + 1];
+        if ((H.tr[2 * (size_t)p] & FLOW_VIRTUAL) != 0 && H.tr[2 * (size_t)p] >= 0) { if (row != -1 || H.ria[p] != H.ria[p + 1]) return -6.0; rec[(size_t)p] = 0.0; continue; }
+        ++nreal;
         double s = 0.0;
         for (int k = H.ria[p]; k < H.ria[p + 1]; ++k) s += H.rval[k] * u[(size_t)H.rja[k]];
-        rec[(size_t)p] = b[(size_t)H.tr[2 * (size_t)p + 1]] - s;
+        rec[(size_t)p] = b[(size_t)row] - s;
     }
-    if (H.nolower) { for (int p = 0; p < ns; ++p) { const double d = H.dr[2 * (size_t)p]; if (H.tr[2 * (size_t)p] >= 0) u[(size_t)H.tr[2 * (size_t)p + 1]] = rec[(size_t)p] / d; } }
+    if (nreal != ns) return -6.0;
+    if (H.nolower) { for (int p = 0; p < np; ++p) { const double d = H.dr[2 * (size_t)p]; if (H.tr[2 * (size_t)p] >= 0) u[(size_t)H.tr[2 * (size_t)p + 1]] = rec[(size_t)p] / d; } }
     else
     for (int s = 0; s < H.nstrips; ++s) {
         const FlowStrip& F = H.strips[(size_t)s];
@@ -386,7 +471,6 @@ extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* s
                 for (int sl = 0; sl < L; ++sl) {
                     const int lane = r * L + sl;
                     double sacc = 0.0;
-                    for (int k = H.tia[p] + sl; k < H.tia[p + 1]; k += L) sacc += H.tval[k] * operand(H.tja[k], ok);
                     for (int q = 0; q < PF - KT; ++q) {
                         const int c = cols[lane * 8 + q];
                         const double v = q / 2 >= g0 ? vals[(size_t)(q / 2 - g0) * 2 * nl + (size_t)lane * 2 + (q & 1)] : 0.0;
@@ -405,9 +489,14 @@ extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* s
                 }
                 if (!ok) return -5.0;
                 const double d = H.dr[2 * (size_t)p];
-                un[(size_t)r] = H.tr[2 * (size_t)p] < 0 ? u[(size_t)H.tr[2 * (size_t)p + 1]] : T / d;
+                const int flags = H.tr[2 * (size_t)p];
+                un[(size_t)r] = flags < 0 ? u[(size_t)H.tr[2 * (size_t)p + 1]] : (flags & FLOW_VIRTUAL) ? -T : T / d;
             }
-            for (int r = 0; r < nr; ++r) { const int p = F.row0 + lo + r; W[(size_t)p] = un[(size_t)r]; done[(size_t)p] = 1; u[(size_t)H.tr[2 * (size_t)p + 1]] = un[(size_t)r]; }
+            for (int r = 0; r < nr; ++r) {
+                const int p = F.row0 + lo + r;
+                W[(size_t)p] = un[(size_t)r]; done[(size_t)p] = 1;
+                if (H.tr[2 * (size_t)p + 1] >= 0) u[(size_t)H.tr[2 * (size_t)p + 1]] = un[(size_t)r];
+            }
         }
     }
     double diff = 0.0, big = 0.0;

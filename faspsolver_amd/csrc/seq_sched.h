@@ -21,17 +21,24 @@ constexpr int TRI_PF = 4;                      // slot rounds the lanes-per-row 
 // meet in that lane BEFORE the chain arrives; what is left between the arrival of the last operand and the row's value is two
 // multiply-adds and the update -- not a six-step cross-lane sum.
 constexpr int TRI_SPINE = 2;
+// VIRTUAL ROWS: a work item (a row's share of a chunk) holds CAP = (TRI_PFMAX - spine) L + spine lower entries.  A row with more
+// hands its OLDEST entries to virtual rows -- work items of their own, whose value is the plain sum of their products, kept in the
+// strip's LDS next to the rows' values -- and reads each of them as one more operand with coefficient 1.  The oldest entries are the
+// ones that are available long before the chain reaches the row: their sums are formed by other waves, ahead of time, out of
+// prefetched slots like everything else (round 4 until then: a "tail" CSR read entry by entry by the row's own wave).  A virtual
+// row sits in the class between its newest entry's and its row's (classes are doubled: rows even, virtual rows odd).
+constexpr int FLOW_VIRTUAL = 0x40000000;       // flag in tr[2 p]: position p is a virtual row (tr[2 p + 1] = -1: no row of u)
 
 struct SplitHost {
-    int ns = 0, L = 1, LR = 1, pfs = 4, kt = 0, nstrips = 0, nchunk = 0, maxent = 0, par = 1;   // kt: spine rounds (below); par: strips that share a dependency class at most (chain-bound levels; else nstrips)
+    int ns = 0, nrows = 0, nvirt = 0, nclasses = 0, L = 1, LR = 1, pfs = 4, kt = 0, nstrips = 0, nchunk = 0, maxent = 0, par = 1;   // ns: POSITIONS = rows of the sweep + virtual rows;   // kt: spine rounds (below); par: strips that share a dependency class at most (chain-bound levels; else nstrips)
     bool nolower = false, flow_ok = true;
-    long long ntail = 0, nghost = 0, slot_bytes = 0, nrest = 0;
+    long long nghost = 0, slot_bytes = 0, nrest = 0;
     std::vector<FlowStrip> strips;
-    std::vector<int>       cptr;       // dependency class -> first entry of lchunks
+    std::vector<int>       cptr;       // (doubled) dependency class -> first entry of lchunks
     Buf<int>               chunks;     // 4 ints per chunk: first local row | rows << 16 | rounds << 24, slot offset / 16, LDS index of the operand expected last, 0
-    Buf<int>               cstrip, lchunks, gpos, tia, tja, ria, rja, tr;
+    Buf<int>               cstrip, lchunks, gpos, ria, rja, tr;
     Buf<unsigned char>     slots;
-    Buf<double>            tval, rval, dr;
+    Buf<double>            rval, dr;
 };
 // Returns FASP_SUCCESS, 1 when a row of the sweep reads more earlier rows than a strip's LDS holds (no split form: the caller
 // falls back to whole-row level scheduling), or a negative error code.

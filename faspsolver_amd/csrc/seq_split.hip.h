@@ -47,9 +47,11 @@
 // dependency class and RIGHT-ALIGNED in the PF rounds of L lanes: its last L entries -- the ones it waits for -- are round
 // PF - 1, the L before them round PF - 2, ...; the leading rounds of a short row are empty.  Everything a chunk needs sits at addresses that follow
 // from its 8-byte descriptor: one memory round trip, perfectly coalesced, one chunk ahead.  Unused slots hold (index of
-// a constant 0.0, value 0).  Rows with more than 8 L lower entries keep the excess in a CSR tail (LDS indices too).
+// a constant 0.0, value 0).  A row with more lower entries than its slots hold hands the oldest to VIRTUAL ROWS (seq_sched.h):
+// work items of their own in the same strip whose value is the sum of their products, read by the row as one operand each; on
+// chain-bound schedules a row's last two entries sit in its last lane (the SPINE, seq_sched.h).
 // The per-row scalars travel as three small records: (b - rest, old u_i) from pass (1), (a_ii, 1 / a_ii) and
-// (tail count, row index) from the schedule.
+// (flags, row index) from the schedule.
 #pragma once
 #include "seq_sched.h"
 
@@ -61,12 +63,9 @@ struct FlowArgs {
     const unsigned char* slots;
     const int*           gpos;
     const int*           cstrip;   // strip of a chunk (k_tri_level)
-    const int*           tia;      // tail CSR (positions + 1 offsets; entries beyond the slots; columns are LDS indices)
-    const int*           tja;
-    const double*        tval;
     const double*        rec;      // 2 doubles per position, written by pass (1): b - rest, old u_i
     const double*        dr;       // 2 doubles per position: a_ii, 1 / a_ii rounded to nearest (0 for a row that is left alone)
-    const int*           tr;       // 2 ints per position: tail count | (row left alone) << 31, row index
+    const int*           tr;       // 2 ints per position: (row left alone) << 31 | (virtual row: FLOW_VIRTUAL), row index (-1: virtual row)
     double*              W;        // the new iterate of the swept rows, by position
     double*              u;        // the level's iterate (scatter target)
     unsigned*            sync;     // [0] ticket counter, [1] error word
@@ -130,7 +129,8 @@ __global__ __launch_bounds__(BLOCK) void k_split_rest(int nseq, const int* __res
         if (on && sl == L - 1) {
             const int r = tr[2 * (size_t)p + 1];
             f64x2_t o;
-            o[0] = b[r] - s; o[1] = u[r];
+            if (r >= 0) { o[0] = b[r] - s; o[1] = u[r]; }
+            else { o[0] = 0.0; o[1] = 0.0; }   // a virtual row (seq_sched.h): no right-hand side, no old value
             if ((unsigned long long)__double_as_longlong(o[1]) == FLOW_SENT) o[1] = __longlong_as_double((long long)(FLOW_SENT | 0x0008000000000000ull));   // (an untouched u_i must not look like "not there yet")
             *reinterpret_cast<f64x2_t*>(rec + 2 * (size_t)p) = o;
             W[p] = __longlong_as_double((long long)FLOW_SENT);
@@ -145,7 +145,8 @@ __global__ __launch_bounds__(BLOCK) void k_split_scatter(int nseq, FlowArgs a, i
         double v;
         if (final) v = tri_update(a.rec[2 * (size_t)p], a.dr[2 * (size_t)p], a.dr[2 * (size_t)p + 1], a.tr[2 * (size_t)p] < 0, a.form, a.w, a.rec[2 * (size_t)p + 1]);
         else v = a.W[p];
-        a.u[a.tr[2 * (size_t)p + 1]] = v;
+        const int r = a.tr[2 * (size_t)p + 1];
+        if (r >= 0) a.u[r] = v;
     }
 }
 
@@ -198,7 +199,7 @@ __device__ __forceinline__ void flow_fetch(const FlowBufs& B, FlowSet<PF>& r, in
 template <int PF>
 __device__ __forceinline__ int flow_col(const FlowSet<PF>& r, int q) { return (int)((q & 1) ? (r.cw[q >> 1] >> 16) : (r.cw[q >> 1] & 0xffffu)); }
 
-// the row arithmetic shared by both forms (identical bits): s = the lane's tail entries, then its slot products in slot order
+// the row arithmetic shared by both forms (identical bits): s = the lane's slot products in slot order
 // (summed left to right from 0.0) over the rounds in front of the spine; the DPP tree; in the group's last lane t - s, minus the
 // spine products one after the other (KT = 0: none), and the update.  Returns the new value (valid in lane L - 1).
 template <int L, int KT>
@@ -209,7 +210,8 @@ __device__ __forceinline__ double flow_row(const FlowArgs& a, double t, double u
     double T = t - s;
     if (KT) { T = __builtin_fma(-v0, x0, T); T = __builtin_fma(-v1, x1, T); }
     const double un = tri_update(T, d, rd, false, a.form, a.w, uo);
-    return tn < 0 ? uo : un;   // a row that is left alone keeps its value (pass (1) made sure it does not look like "not there yet")
+    // a row that is left alone keeps its value (pass (1) made sure it does not look like "not there yet"); a virtual row is the sum itself (t = 0)
+    return tn < 0 ? uo : (tn & FLOW_VIRTUAL) ? -T : un;
 }
 
 // descriptors are read through the scalar cache (constant address space: nothing in a launch writes them)
@@ -247,7 +249,6 @@ __global__ __launch_bounds__(64) void k_tri_level(FlowArgs a, const int* __restr
     if (rloc < r.n) {
         const int p = S.row0 + r.lo + rloc;
         double s = 0.0;
-        if (r.tn & 0x7fffffff) { const int kb = a.tia[p], ke = a.tia[p + 1]; s = seq_row_sum<L>(a.tja, a.tval, kb + sl, ke, -1, ldw); }
         double un;
         if (a.kt) {
 #pragma unroll
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(64) void k_tri_level(FlowArgs a, const int* __restr
 }
 
 // ---------------------------------------------------------------------------
-// k_tri_flow<L, PF, TAIL>: the dataflow solve (header of this file).
+// k_tri_flow<L, PF>: the dataflow solve (header of this file).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool flow_ready(double v) { return (unsigned long long)__double_as_longlong(v) != FLOW_SENT; }
 // a waiter that has spun for two seconds (or sees that somebody else has) raises the error word and goes on with what it
@@ -303,7 +304,7 @@ template <int PF> struct FlowGeom { static constexpr int NT = PF <= 4 ? 1024 : F
 #ifdef FLOW_TIMING
 __device__ unsigned long long g_flow_times[8192];   // start / end of every strip of the last launch (100 MHz clock)
 #endif
-template <int L, int PF, bool TAIL>
+template <int L, int PF>
 __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
 {
     constexpr int FLOW_THREADS = FlowGeom<PF>::NT, NSET = FlowGeom<PF>::NSET;
@@ -390,21 +391,7 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
                     x[q] = lds_get(flow_col(X, q));
                     if (flow_ready(x[q])) pend &= ~(1u << q);
                 }
-                // the tail (rows with more than PF * L lower entries: their OLDEST entries), one operand at a time
                 double s = 0.0;
-                if (TAIL && on && (X.tn & 0x7fffffff)) {
-                    auto ldw = [&](int c) -> double {
-                        unsigned sp = 0;
-                        unsigned long long tt = 0;
-                        for (;;) {
-                            const double y = lds_get(c);
-                            if (flow_ready(y)) return y;
-                            if (flow_give_up(a.sync, sp, tt)) return 0.0;
-                        }
-                    };
-                    const int p = S.row0 + pl, kb = a.tia[p], ke = a.tia[p + 1];
-                    s = seq_row_sum<L>(a.tja, a.tval, kb + sl, ke, -1, ldw);
-                }
                 FT(2);
                 // The entries of a row sit in the order of their dependency classes, right-aligned in the PB rounds: what is still
                 // missing is in the LAST round(s).  The rounds that are complete are summed while the wave waits.
@@ -466,12 +453,14 @@ __global__ __launch_bounds__(FlowGeom<PF>::NT) void k_tri_flow(FlowArgs a)
                     __builtin_amdgcn_s_setprio(3);   // from here to the store of the row's value the wave is the chain
                     Tt = __builtin_fma(-X.v[PF - 1], x[PF - 1], Tt);
                     const double uu = tri_update(Tt, X.d, X.rd, false, a.form, a.w, X.uo);
-                    un = X.tn < 0 ? X.uo : uu;
+                    un = X.tn < 0 ? X.uo : (X.tn & FLOW_VIRTUAL) ? -Tt : uu;
                 } else un = flow_row<L, 0>(a, X.t, X.uo, X.d, X.rd, X.tn, s);
                 if (on && sl == L - 1) {
                     lds_put(pl, un);
-                    __hip_atomic_store((gu64*)(a.W + S.row0 + pl), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through: other strips poll it)
-                    a.u[X.row] = un;
+                    if (X.row >= 0) {   // (a virtual row's value is read inside its strip only and is no entry of u)
+                        __hip_atomic_store((gu64*)(a.W + S.row0 + pl), (unsigned long long)__double_as_longlong(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through: other strips poll it)
+                        a.u[X.row] = un;
+                    }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 FT(3);

@@ -153,9 +153,6 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S)
     piece(&S.d_gpos, H.gpos.data(), (size_t)H.nghost);
     piece(&S.d_cstrip, H.cstrip.data(), (size_t)H.nchunk);
     piece(&S.d_lchunks, H.lchunks.data(), (size_t)H.nchunk);
-    piece(&S.d_tia, H.tia.data(), (size_t)ns + 1);
-    piece(&S.d_tja, H.tja.data(), (size_t)H.ntail);
-    piece(&S.d_tval, H.tval.data(), (size_t)H.ntail);
     piece(&S.d_ria, H.ria.data(), (size_t)ns + 1);
     piece(&S.d_rja, H.rja.data(), (size_t)H.nrest);
     piece(&S.d_rval, H.rval.data(), (size_t)H.nrest);
@@ -179,7 +176,7 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S)
     HIPCK(hipStreamSynchronize(g_ctx.stream));   // (the host arrays go away with H)
     S.d_strips = d_strips; S.d_chunks = d_chunks;
     if (timing) std::printf("    [sweep schedule] %-28s %.3f s\n", "upload", wall_seconds() - t0);
-    S.ns = ns; S.L = H.L; S.LR = H.LR; S.nolower = H.nolower; S.ntail = H.ntail; S.pfmax = H.pfs; S.kt = H.kt; S.par = H.par; S.nstrips = H.nstrips; S.nchunk = H.nchunk; S.maxent = H.maxent;
+    S.ns = ns; S.L = H.L; S.LR = H.LR; S.nolower = H.nolower; S.nvirt = H.nvirt; S.nrows = H.nrows; S.nclasses = H.nclasses; S.pfmax = H.pfs; S.kt = H.kt; S.par = H.par; S.nstrips = H.nstrips; S.nchunk = H.nchunk; S.maxent = H.maxent;
     S.nghost = H.nghost; S.slot_bytes = H.slot_bytes; S.flow_ok = H.flow_ok;
     S.built = true;
     S.multicolor = false;
@@ -296,8 +293,8 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         if (std::getenv("FASP_HIP_SETUP_TIMING")) {
             if (multicolor || S.rowlevels) std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind, multicolor ? "colours" : "whole-row dependency levels", (int)(seq.empty() ? S.ns : (int)seq.size()), (int)S.ptr.size() - 1);
             else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes, %d strips (%lld ghosts, at most %d values in LDS), %d chunks, %d lanes per row, "
-                             "%d rounds (%d of them spine), %.1f slot bytes per row (%lld tail entries), rest pass %d lanes per row%s, built in %.3f s\n",
-                             level, kind, S.ns, (int)S.cptr.size() - 1, S.nstrips, S.nghost, S.maxent + 1, S.nchunk, S.L, S.pfmax, S.kt, S.ns ? (double)S.slot_bytes / S.ns : 0.0, S.ntail, S.LR,
+                             "%d rounds (%d of them spine), %.1f slot bytes per row (%d virtual rows), rest pass %d lanes per row%s, built in %.3f s\n",
+                             level, kind, S.nrows, S.nclasses, S.nstrips, S.nghost, S.maxent + 1, S.nchunk, S.L, S.pfmax, S.kt, S.nrows ? (double)S.slot_bytes / S.nrows : 0.0, S.nvirt, S.LR,
                              "", wall_seconds() - t0);
         }
     }
@@ -330,7 +327,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
     if (ns == 0) return FASP_SUCCESS;
     FlowArgs fa{};
     fa.strips = (const FlowStrip*)S.d_strips; fa.chunks = (const int4*)S.d_chunks; fa.slots = S.d_slots; fa.gpos = S.d_gpos; fa.cstrip = S.d_cstrip;
-    fa.tia = S.d_tia; fa.tja = S.d_tja; fa.tval = S.d_tval; fa.rec = S.d_rec; fa.dr = S.d_dr; fa.tr = S.d_tr; fa.W = S.d_W; fa.u = D.x;
+    fa.rec = S.d_rec; fa.dr = S.d_dr; fa.tr = S.d_tr; fa.W = S.d_W; fa.u = D.x;
     fa.sync = S.d_prog; fa.nstrips = S.nstrips; fa.form = form; fa.w = w; fa.kt = S.kt;
     // pass (1): everything that reads old values, all rows at once
     {
@@ -360,22 +357,21 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         if (seq_err_check() < 0) return ERROR_MISC;   // an earlier sweep's time-out that has arrived meanwhile
         const size_t dyn = sizeof(double) * ((size_t)S.maxent + 1);
         const int by_lds = (int)((160 * 1024 - 64) / (dyn + 16));
-#define FLOW_ONE(LL, PP, TT)                                                                                                \
+#define FLOW_ONE(LL, PP)                                                                                                    \
         {                                                                                                                   \
             static bool attr_set = false;                                                                                   \
             if (!attr_set) {                                                                                                \
-                HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tri_flow<LL, PP, TT>),                            \
+                HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tri_flow<LL, PP>),                            \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (FLOW_LDS_ENT + 1)))); \
                 attr_set = true;                                                                                            \
             }                                                                                                               \
             const int nt = FlowGeom<PP>::NT, per_cu = std::max(1, std::min(2048 / nt, by_lds));                             \
             const int grid = std::max(1, std::min(std::min(S.nstrips, per_cu * g_ctx.num_cu), g_tune.seq_grid > 0 ? g_tune.seq_grid : g_tune.seq_grid < 0 || S.par >= S.nstrips ? 1 << 30 : 2 * S.par + 2)); \
-            hipLaunchKernelGGL((k_tri_flow<LL, PP, TT>), dim3(grid), dim3(nt), dyn, g_ctx.stream, fa);                      \
+            hipLaunchKernelGGL((k_tri_flow<LL, PP>), dim3(grid), dim3(nt), dyn, g_ctx.stream, fa);                      \
         }
 #define FLOW_LAUNCH(LL)                                                                                                     \
-        if (S.ntail) FLOW_ONE(LL, TRI_PFMAX, true)                                                                          \
-        else if (S.pfmax > 4) FLOW_ONE(LL, TRI_PFMAX, false)                                                                \
-        else FLOW_ONE(LL, 4, false)
+        if (S.pfmax > 4) FLOW_ONE(LL, TRI_PFMAX)                                                                            \
+        else FLOW_ONE(LL, 4)
         switch (L) {
             case 1: FLOW_LAUNCH(1); break;
             case 2: FLOW_LAUNCH(2); break;

@@ -21,8 +21,9 @@ double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps);
 double fasp_hip_time_matrix(const dCSRmat* A, int op, int reps, int* kind_out);
 /* test entry (host only, no GPU): build the sweep schedule of the rows seq[0..ns) of A (csrc/seq_sched.cpp) and walk it on the host as the
  * device kernels do, against the plain sequential Gauss-Seidel sweep: largest deviation relative to the largest entry; < 0: error
- * (-2: a row reads more earlier rows than a strip holds: no split form) */
-double fasp_hip_seq_schedule_selftest(const dCSRmat* A, const int* seq, int ns, int strip_kb, int lanes, int spine);
+ * (-2: a row reads more earlier rows than a strip holds: no split form).  spine: -1 / 1 where the schedule chooses it, 0 never, 2 wherever
+ * a row has two lanes; info (may be NULL): {lanes per row, rounds, spine rounds, virtual rows, strips, chunks} of the schedule */
+double fasp_hip_seq_schedule_selftest(const dCSRmat* A, const int* seq, int ns, int strip_kb, int lanes, int spine, int* info);
 /* measured device ceilings reported beside the roofline: out[0..2] = GB/s of a 16-byte-per-lane read, copy and
  * triad over buffers of `bytes` each (>= 512 MiB: beyond the Infinity Cache) */
 int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);

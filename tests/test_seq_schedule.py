@@ -11,13 +11,17 @@ import faspsolver_amd as fa
 from faspsolver_amd import _types as T
 
 
-def _selftest(ia, ja, a, seq, strip_kb=512, lanes=0, spine=-1):
+def _selftest(ia, ja, a, seq, strip_kb=512, lanes=0, spine=-1, info=None):
     L = fa.lib()
     L.fasp_hip_seq_schedule_selftest.restype = C.c_double
-    L.fasp_hip_seq_schedule_selftest.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.fasp_hip_seq_schedule_selftest.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     A, keep = T.as_csr(ia, ja, a)
     seq = np.ascontiguousarray(seq, dtype=np.int32)
-    return L.fasp_hip_seq_schedule_selftest(C.byref(A), seq.ctypes.data_as(C.POINTER(C.c_int)), len(seq), strip_kb, lanes, spine)
+    buf = (C.c_int * 8)()
+    r = L.fasp_hip_seq_schedule_selftest(C.byref(A), seq.ctypes.data_as(C.POINTER(C.c_int)), len(seq), strip_kb, lanes, spine, buf)
+    if info is not None:
+        info.update(lanes=buf[0], rounds=buf[1], spine=buf[2], virtual=buf[3], strips=buf[4], chunks=buf[5])
+    return r
 
 
 @pytest.mark.parametrize("strip_kb", [16, 512])
@@ -52,9 +56,11 @@ def test_schedule_on_every_level_of_a_hierarchy_with_cf_sweeps():
     H.close()
 
 
-def test_schedule_with_tails_and_many_lanes():
-    """A banded matrix whose rows couple to the 600 rows before them: 64 lanes per row, eight rounds and a tail of the oldest entries;
-    strips of 16 KB: one row per chunk, a few rows per strip, every row reads ghosts."""
+def test_schedule_with_virtual_rows_and_many_lanes():
+    """A banded matrix whose rows couple to the 600 rows before them: 64 lanes per row, eight rounds, and more entries than a work
+    item holds: the oldest go to VIRTUAL ROWS (seq_sched.h) -- sums of products formed by other waves, read as one operand each;
+    strips of 16 KB: one row per chunk, a few rows per strip, every row reads ghosts.  Forced down to 4 and 16 lanes per row a
+    row has up to 19 virtual rows."""
     import scipy.sparse as sp
     n, bw = 1500, 600
     offs = list(range(-bw, 0)) + list(range(1, bw + 1))
@@ -63,9 +69,13 @@ def test_schedule_with_tails_and_many_lanes():
     ia, ja, a = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
     for kb in (16, 512):
         for seq in (np.arange(n), np.arange(n)[::-1]):
-            for spine in (0, 1):   # (a chain of 1500 classes of one row: the schedule chooses the spine form itself)
-                res = _selftest(ia, ja, a, seq, kb, 0, spine)
-                assert 0.0 <= res <= 1e-12, (kb, spine, res)
+            for lanes, spine in ((0, 0), (0, 1), (16, 0), (16, 2), (4, 0), (4, 2)):   # (0, 1): a chain of 1500 classes of one row -- the schedule chooses the spine form itself
+                info = {}
+                res = _selftest(ia, ja, a, seq, kb, lanes, spine, info)
+                assert 0.0 <= res <= 1e-12, (kb, lanes, spine, res, info)
+                assert info["virtual"] > 0 and info["rounds"] == 8 and info["spine"] == (2 if spine else 0), info
+                if lanes:
+                    assert info["lanes"] == lanes and info["virtual"] > 2 * n, info
 
 
 def test_a_row_that_reads_more_than_a_strip_holds_is_reported():
