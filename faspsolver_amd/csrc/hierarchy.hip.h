@@ -59,7 +59,7 @@ struct EventPair { hipEvent_t a, b; };
 using namespace fasp;
 
 // a sweep schedule under construction on a host thread of its own (smoothers.hip.h, sched_jobs_start)
-struct SchedJob { int level = 0, kind = 0, st = 0; SplitHost H; std::thread th; };
+struct SchedJob { int level = 0, kind = 0, st = 0; bool uploaded = false; SplitHost H; DevLevel::Sched S; std::thread th; };   // S: the schedule on the device, uploaded by the job's own thread
 
 struct fasp_hip_amg {
     std::vector<std::unique_ptr<SchedJob>> sched_jobs;   // sequential smoothers: schedules being built side by side at the first sweep

@@ -121,7 +121,7 @@ static int split_upload(DevLevel::Sched& S, T** dst, const T* v, size_t n)
 template <class T>
 static int split_upload(DevLevel::Sched& S, T** dst, const std::vector<T>& v) { return split_upload(S, dst, v.data(), v.size()); }
 
-static int upload_split(SplitHost& H, DevLevel::Sched& S);
+static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream = nullptr);
 static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::Sched& S)
 {
     const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
@@ -130,8 +130,9 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
     if (st != FASP_SUCCESS) { S.flow_ok = false; return st; }
     return upload_split(H, S);
 }
-static int upload_split(SplitHost& H, DevLevel::Sched& S)
+static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
 {
+    if (!stream) stream = g_ctx.stream;
     const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
     const double t0 = wall_seconds();
     const int ns = H.ns;
@@ -169,11 +170,11 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S)
     size_t off = 0;
     for (const Piece& q : pieces) {
         *q.dst = base + off;
-        if (q.copy) HIPCK(hipMemcpyAsync(base + off, q.src, q.copy, hipMemcpyHostToDevice, g_ctx.stream));
+        if (q.copy) HIPCK(hipMemcpyAsync(base + off, q.src, q.copy, hipMemcpyHostToDevice, stream));
         off += (q.bytes + 255) & ~(size_t)255;
     }
-    HIPCK(hipMemsetAsync(S.d_W, 0, sizeof(double) * (size_t)std::max(ns, 1), g_ctx.stream));
-    HIPCK(hipStreamSynchronize(g_ctx.stream));   // (the host arrays go away with H)
+    HIPCK(hipMemsetAsync(S.d_W, 0, sizeof(double) * (size_t)std::max(ns, 1), stream));
+    HIPCK(hipStreamSynchronize(stream));   // (the host arrays go away with H)
     S.d_strips = d_strips; S.d_chunks = d_chunks;
     if (timing) std::printf("    [sweep schedule] %-28s %.3f s\n", "upload", wall_seconds() - t0);
     S.ns = ns; S.L = H.L; S.LR = H.LR; S.nolower = H.nolower; S.nvirt = H.nvirt; S.nrows = H.nrows; S.nclasses = H.nclasses; S.pfmax = H.pfs; S.kt = H.kt; S.par = H.par; S.nstrips = H.nstrips; S.nchunk = H.nchunk; S.maxent = H.maxent;
@@ -203,45 +204,79 @@ static void sweep_sequence(const HostLevel& HL, int kind, std::vector<int>& seq,
 // The schedules a hierarchy's smoother is going to need -- two sweep kinds on every level but the coarsest -- are built SIDE BY
 // SIDE at the first sweep, one host thread each (the dependency pass of a schedule is sequential; fourteen of them are not): the
 // first solve of P7(128) with the reference's defaults pays for the longest one instead of for the sum.
+// the two sweep kinds the hierarchy's smoother runs on level l (-1: none / not a sequential smoother)
+static bool sched_kinds(const fasp_hip_amg* h, int l, int& k0, int& k1)
+{
+    k0 = k1 = -1;
+    const bool has_cf = h->H.L[(size_t)l].cfmark.n == (size_t)h->H.L[(size_t)l].A.row;
+    switch (h->param.smoother) {
+        case SMOOTHER_GS: if (h->param.smooth_order == CF_ORDER && has_cf) { k0 = 2; k1 = 3; } else { k0 = 0; k1 = 1; } break;
+        case SMOOTHER_SGS: k0 = 0; k1 = 4; break;
+        case SMOOTHER_SOR: case SMOOTHER_SSOR: case SMOOTHER_GSOR: case SMOOTHER_SGSOR: k0 = 0; k1 = 1; break;
+        case SMOOTHER_GSF: k0 = 3; k1 = -1; break;
+        default: return false;
+    }
+    return true;
+}
+static void sched_job_launch(fasp_hip_amg* h, int level, int kind, int team)
+{
+    const int strip_kb = g_tune.seq_strip_kb, lanes = g_tune.seq_lanes, spine = g_tune.seq_spine;
+    h->sched_jobs.emplace_back(new SchedJob);
+    SchedJob* J = h->sched_jobs.back().get();
+    J->level = level; J->kind = kind;
+    const HostLevel* HL = &h->H.L[(size_t)level];
+    const int dev = g_ctx.device;
+    J->th = std::thread([J, HL, team, strip_kb, lanes, spine, dev]() {
+        std::vector<int> seq;
+        sweep_sequence(*HL, J->kind, seq);
+        J->st = build_split_host(HL->A, seq.data(), (int)seq.size(), strip_kb, lanes, false, J->H, team, spine);
+        // the schedule goes to the device from here, over a stream of its own: the first sweep finds it there
+        hipStream_t st = nullptr;
+        if (J->st == FASP_SUCCESS && hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+            J->st = upload_split(J->H, J->S, st);
+            J->uploaded = true;
+            (void)hipStreamDestroy(st);
+            J->H = SplitHost();
+        }
+    });
+}
 static void sched_jobs_start(fasp_hip_amg* h)
 {
     if (h->sched_jobs_started) return;
     h->sched_jobs_started = true;
     if (g_tune.gs_multicolor || !g_tune.seq_jobs) return;
-    int k0 = -1, k1 = -1;
-    const int sm = h->param.smoother;
     const int nl = (int)h->L.size();
     std::vector<std::pair<int, int>> jobs;
     for (int l = 0; l + 1 < nl; ++l) {
         if (!h->L[l].replicated) return;   // (sequential sweeps run on whole levels only)
-        const bool has_cf = h->H.L[l].cfmark.n == (size_t)h->H.L[l].A.row;
-        switch (sm) {
-            case SMOOTHER_GS: if (h->param.smooth_order == CF_ORDER && has_cf) { k0 = 2; k1 = 3; } else { k0 = 0; k1 = 1; } break;
-            case SMOOTHER_SGS: k0 = 0; k1 = 4; break;
-            case SMOOTHER_SOR: case SMOOTHER_SSOR: case SMOOTHER_GSOR: case SMOOTHER_SGSOR: k0 = 0; k1 = 1; break;
-            case SMOOTHER_GSF: k0 = 3; k1 = -1; break;
-            default: return;
-        }
+        int k0, k1;
+        if (!sched_kinds(h, l, k0, k1)) return;
         if (h->L[l].sched[k0].built == false) jobs.push_back({l, k0});
         if (k1 >= 0 && !h->L[l].sched[k1].built) jobs.push_back({l, k1});
     }
     const int team = std::max(2, host_threads() * 2 / std::max<int>(1, (int)jobs.size()));
-    const int strip_kb = g_tune.seq_strip_kb, lanes = g_tune.seq_lanes, spine = g_tune.seq_spine;
-    for (const auto& lk : jobs) {
-        h->sched_jobs.emplace_back(new SchedJob);
-        SchedJob* J = h->sched_jobs.back().get();
-        J->level = lk.first; J->kind = lk.second;
-        const HostLevel* HL = &h->H.L[(size_t)lk.first];
-        J->th = std::thread([J, HL, team, strip_kb, lanes, spine]() {
-            std::vector<int> seq;
-            sweep_sequence(*HL, J->kind, seq);
-            J->st = build_split_host(HL->A, seq.data(), (int)seq.size(), strip_kb, lanes, false, J->H, team, spine);
-        });
-    }
+    for (const auto& lk : jobs) sched_job_launch(h, lk.first, lk.second, team);
+}
+// The same for ONE level, while the host setup is still at work on the coarser ones (fasp_hip_amg_create: the thread that uploads
+// level l ahead of the setup calls this behind the upload): the greedy C/F passes of the setup are sequential, the cores are
+// there, and the first solve of P7(256) with the reference's defaults no longer waits 1.7 s for its schedules.
+static void sched_jobs_start_level(fasp_hip_amg* h, int l)
+{
+    if (g_tune.gs_multicolor || !g_tune.seq_jobs || !h->L[(size_t)l].replicated) return;
+    int k0, k1;
+    if (!sched_kinds(h, l, k0, k1)) return;
+    const int team = std::max(2, host_threads() / 8);
+    sched_job_launch(h, l, k0, team);
+    if (k1 >= 0) sched_job_launch(h, l, k1, team);
+    h->sched_jobs_started = true;   // (what the first sweep would start is under way)
 }
 static void sched_jobs_join(fasp_hip_amg* h)   // (hierarchy teardown)
 {
-    for (auto& J : h->sched_jobs) if (J && J->th.joinable()) J->th.join();
+    for (auto& J : h->sched_jobs) {
+        if (!J) continue;
+        if (J->th.joinable()) J->th.join();
+        if (J->uploaded) J->S.release();   // (a schedule nobody came for)
+    }
     h->sched_jobs.clear();
 }
 
@@ -276,8 +311,9 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
                 if (J && J->level == level && J->kind == kind) {
                     if (J->th.joinable()) J->th.join();
                     st = J->st;
-                    if (st == FASP_SUCCESS) st = upload_split(J->H, S);
-                    else S.flow_ok = false;
+                    if (st == FASP_SUCCESS && J->uploaded) { S.release(); S = std::move(J->S); J->S = DevLevel::Sched(); }
+                    else if (st == FASP_SUCCESS) st = upload_split(J->H, S);
+                    else { if (J->uploaded) J->S.release(); S.flow_ok = false; }
                     J.reset();
                     break;
                 }

@@ -336,6 +336,7 @@ struct AheadUpload {
     std::vector<int>        ready;
     bool                    done = false;
     int                     status = FASP_SUCCESS;
+    int                     coarsest = -1;   // set (under mu) in front of the last level's turn: that one is not smoothed
     std::thread             th;
     static void on_ready(int level, void* ctx)
     {
@@ -349,12 +350,13 @@ struct AheadUpload {
         HostThreads team;
         double t_first = -1.0;
         for (;;) {
-            int l = -1;
+            int l = -1, last = -1;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !ready.empty() || done; });
                 if (ready.empty()) return;
                 l = ready.front(); ready.erase(ready.begin());
+                last = coarsest;
             }
             if (t_first < 0) t_first = wall_seconds();
             const double t0 = wall_seconds();
@@ -363,6 +365,8 @@ struct AheadUpload {
                 try { st = upload_level(h, l, nullptr); }
                 catch (const std::bad_alloc&) { st = ERROR_ALLOC_MEM; }   // (a host buffer of the coding passes: never out of this thread)
                 if (st < 0) status = st;
+                // sequential smoothers: this level's sweep schedules, on host threads of their own beside the rest of the setup (smoothers.hip.h)
+                if (st >= 0 && l != last) sched_jobs_start_level(h, l);
             }
             if (std::getenv("FASP_HIP_SETUP_TIMING"))
                 std::printf("  [upload ahead] level %d: %.3f s (started %.3f s after the first)\n", l, wall_seconds() - t0, t0 - t_first);
@@ -401,7 +405,10 @@ int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgpara
         st = host_setup_rs(A, amgparam, h->H);
         g_on_level_ready = nullptr; g_on_level_ready_ctx = nullptr;
         lap("host setup");
-        if (st >= 0) AheadUpload::on_ready((int)h->H.L.size() - 1, &up);   // the coarsest level
+        if (st >= 0) {   // the coarsest level
+            { std::lock_guard<std::mutex> lk(up.mu); up.coarsest = (int)h->H.L.size() - 1; }
+            AheadUpload::on_ready((int)h->H.L.size() - 1, &up);
+        }
         { std::lock_guard<std::mutex> lk(up.mu); up.done = true; }
         up.cv.notify_one();
         up.th.join();
