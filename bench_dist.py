@@ -30,6 +30,9 @@ def main(args, rank, world, local_rank):
     L = fa.lib()
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
     backend = os.environ.get("BENCH_COMM", "auto")
+    tok = torch.tensor([int.from_bytes(os.urandom(4), "little") if rank == 0 else 0], dtype=torch.int64)
+    dist.broadcast(tok, 0)   # (names of this run only: nothing a crashed earlier run left in /dev/shm is picked up)
+    run_id = f"{os.environ.get('MASTER_PORT', '0')}_{int(tok[0]):08x}"
     ndev = torch.cuda.device_count()   # (counting does not initialise the GPU: the probes below run before this process does)
     if ndev <= 0:
         B.log("bench_dist: no HIP device")
@@ -38,7 +41,7 @@ def main(args, rank, world, local_rank):
         # Which transport carries this run is decided by trying them: every rank runs a small partitioned solve over each
         # candidate in a child process (faspsolver_amd/comm_probe.py) and the ranks take the first that passed everywhere.
         from faspsolver_amd import comm_probe as P
-        pname = f"fasp_probe_{os.environ.get('MASTER_PORT', '0')}"
+        pname = f"fasp_probe_{run_id}"
         if ndev < world:
             os.environ["FASP_HIP_ALLOW_DEVICE_WRAP"] = "1"
 
@@ -59,7 +62,7 @@ def main(args, rank, world, local_rank):
     dev = local_rank % ndev if backend == "shm" or ndev < world else local_rank
     st = L.fasp_hip_set_device(dev)
     assert st == 0, f"set_device({dev}) -> {st}"
-    name = f"fasp_bench_{os.environ.get('MASTER_PORT', '0')}"
+    name = f"fasp_bench_{run_id}"
     if backend == "shm":
         st = L.fasp_hip_comm_init_shm(rank, world, name.encode())
     elif backend == "ipc":   # peer windows (csrc/comm_ipc.h): hipIpc-mapped device windows, one kernel per exchange, no RCCL call
@@ -91,7 +94,7 @@ def main(args, rank, world, local_rank):
     # ONE host setup per node: rank 0 generates the system, runs the AMG setup and publishes
     # the host hierarchy in a shared-memory segment; the other ranks map it and upload the rows they own.
     itp, amgp = B.workload_params()
-    seg = f"fasp_hier_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+    seg = f"fasp_hier_{run_id}_{os.getuid()}"
     t0 = time.perf_counter()
     if rank == 0:
         ia, ja, a, f, ue = fa.poisson7pt(n)
