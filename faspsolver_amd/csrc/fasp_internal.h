@@ -67,6 +67,7 @@ struct Buf {
 
 struct HostCSR {
     int         row = 0, col = 0, nnz = 0;
+    bool        row_aligned = false;   // row i's diagonal is column i although col > row: a rank's rows of a partitioned level (ghost columns behind the own ones)
     Buf<int>    ia, ja;
     Buf<double> val;
     dCSRmat     view() const

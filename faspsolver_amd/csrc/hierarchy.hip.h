@@ -292,7 +292,12 @@ static int upload_level(fasp_hip_amg* h, int l, const DistLevel* DLp)
         std::printf("    [upload level %d] %-10s %8.3f s\n", l, what, now - tp);
         tp = now;
     };
-    if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;
+    if (!rep && g_tune.local_square) {   // (the flag only steers the lossless coding of the device copy)
+        HostCSR view;
+        view.row = A.row; view.col = A.col; view.nnz = A.nnz; view.row_aligned = true;
+        view.ia.view(const_cast<int*>(A.ia.data()), A.ia.n); view.ja.view(const_cast<int*>(A.ja.data()), A.ja.n); view.val.view(const_cast<double*>(A.val.data()), A.val.n);
+        if (upload_csr(view, D.A) < 0) return ERROR_ALLOC_MEM;
+    } else if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;
     lap("A");
     if (HL.has_coarse) {
         if (upload_csr(rep ? HL.P : DLp->P, D.P) < 0) return ERROR_ALLOC_MEM;

@@ -2036,6 +2036,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_flow")) { g_tune.seq_flow = value; if (value) g_flow_disabled = false; }
     else if (!std::strcmp(key, "seq_strip_kb")) g_tune.seq_strip_kb = value;
     else if (!std::strcmp(key, "seq_jobs")) g_tune.seq_jobs = value;
+    else if (!std::strcmp(key, "local_square")) g_tune.local_square = value;   // a rank's rows of a partitioned level are coded like a square operator (read at upload)
     else if (!std::strcmp(key, "seq_grid")) g_tune.seq_grid = value;     // workgroups of the dataflow solve at most (0: twice the strips the chain front is in at a time + 2, seq_sched.cpp; < 0: as many as are resident)
     else if (!std::strcmp(key, "seq_spine")) g_tune.seq_spine = value;   // 0 never, 1 where the schedule chooses it, 2 wherever a row has two lanes (seq_sched.h); read when a schedule is built
     else if (!std::strcmp(key, "seq_partition")) g_seq_partition = value;
@@ -2140,6 +2141,7 @@ double fasp_hip_time_matrix(const dCSRmat* A, int op, int reps, int* kind_out)
     if (!A || reps <= 0 || ctx_init() < 0) return -1.0;
     HostCSR M;
     M.row = A->row; M.col = A->col; M.nnz = A->nnz;
+    M.row_aligned = A->col > A->row && std::getenv("FASP_HIP_TIME_ROW_ALIGNED") != nullptr;   // (tools/perf_local_op.py: a rank's rows of a partitioned level)
     M.ia.view(A->IA, (size_t)A->row + 1); M.ja.view(A->JA, (size_t)std::max(A->nnz, 1)); M.val.view(A->val, (size_t)std::max(A->nnz, 1));
     DevCSR D;
     {
