@@ -42,13 +42,19 @@ int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
  *   sequential sweeps (a parallel pass + a sparse triangular solve, csrc/seq_split.hip.h): seq_flow (the triangular solve as a
  *     dataflow over strips of the sweep sequence, default 1; 0 = one launch per dependency class), seq_strip_kb (slot bytes per
  *     strip when a schedule is built, default 512), seq_lanes (lanes per row, 0 = from the row lengths) -- same slots, same
- *     arithmetic, same bits; seq_jobs (the schedules of all levels built side by side on host threads at the first sweep, default 1);
+ *     arithmetic, same bits; seq_spine (csrc/seq_sched.h: a row's last two operands in its last lane behind the cross-lane sum; 1 =
+ *     on chain-bound eight-round schedules (default), 0 never, 2 wherever a row has two lanes -- part of a schedule's arithmetic: the
+ *     modes agree to rounding, not bit for bit), seq_grid (workgroups of the dataflow solve at most; 0 = the schedule's own cap,
+ *     < 0 = every resident one), seq_jobs (the schedules built side by side on host threads -- behind the host setup for large
+ *     operators, else at the first sweep; default 1);
  *     gs_multicolor = 1 selects the MULTICOLOUR Gauss-Seidel / SOR sweep -- NOT the reference's iteration (rows are
  *     relaxed colour by colour instead of in index order; faster, converges alike, other iteration counts). Default 0:
  *     the reference's sequential sweep, reproduced exactly;
  *   multi-GPU: halo_overlap (exchange beside the interior rows, default 1), split_rows (test mode: every operator in
  *     three row windows), seq_partition (set before the upload, or FASP_HIP_SEQ_PARTITION=1: hierarchies with Gauss-Seidel / SOR
- *     smoothers are row-partitioned too and the ranks sweep by turns; default 0: such hierarchies keep every level whole).
+ *     smoothers are row-partitioned too and the ranks sweep by turns; default 0: such hierarchies keep every level whole),
+ *     local_square (a rank's rows of a partitioned level coded with row-relative column offsets like the square operator, default 1;
+ *     read at upload).
  * Unknown keys return ERROR_INPUT_PAR. */
 int fasp_hip_tune(const char* key, int value);
 
