@@ -1126,7 +1126,8 @@ void transpose_csr(const HostCSR& A, HostCSR& AT)
 // formed as (r*a)*p and accumulated with += in that order.  Rows are independent, so
 // they run in parallel with per-thread marker arrays (the reference's own OpenMP
 // branch does the same); the result is bit-identical to the serial sweep.
-void galerkin_rap(const HostCSR& R, const HostCSR& A, const HostCSR& P, HostCSR& C)
+// the marker form: per-thread full-length stamp arrays (levels whose markers are small: filling them costs nothing there)
+static void galerkin_rap_markers(const HostCSR& R, const HostCSR& A, const HostCSR& P, HostCSR& C)
 {
     const int nc = R.row, nf = A.row;
     const int *Ri = R.ia.data(), *Rj = R.ja.data(), *Ai = A.ia.data(), *Aj = A.ja.data(),
@@ -1214,6 +1215,146 @@ void galerkin_rap(const HostCSR& R, const HostCSR& A, const HostCSR& P, HostCSR&
                             }
                         } else {
                             for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) Cv[ppos[Pj[j3]]] += ra * Pv[j3];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (overflow) throw std::bad_alloc();
+    C.ia = std::move(cia);
+}
+
+// (Round 4: the per-thread markers -- "seen this fine row / this coarse column in the current row, and where" -- were three full-length
+// int arrays per thread, 134 MB each at level 0 of P7(256) and 4 GB over the team, filled before the first row.  They are small
+// open-addressing tables now, sized per row from the lengths of the rows it multiplies and validated by a per-row stamp: nothing
+// to fill, everything a row touches stays in the L1 / L2.  Discovery order and accumulation order are untouched.)
+namespace {
+struct RapTable {
+    std::vector<int> key, stamp, val;
+    void ensure(size_t cap) { if (key.size() < cap) { key.resize(cap); val.resize(cap); stamp.assign(cap, 0); } }   // (stamps of a grown table start over: the row that grows it has not used it yet)
+    // slot of k (inserted if absent: fresh = true); mask + 1 = power of two >= twice the number of keys of the row
+    inline int slot(int k, int st, unsigned mask, bool& fresh)
+    {
+        for (unsigned s = (((unsigned)k * 2654435761u) >> 11) & mask;; s = (s + 1) & mask) {
+            if (stamp[s] != st) { stamp[s] = st; key[s] = k; fresh = true; return (int)s; }
+            if (key[s] == k) { fresh = false; return (int)s; }
+        }
+    }
+};
+inline unsigned pow2_mask(long long need) { unsigned c = 16; while ((long long)c < need) c <<= 1; return c - 1; }
+}  // namespace
+
+void galerkin_rap(const HostCSR& R, const HostCSR& A, const HostCSR& P, HostCSR& C)
+{
+    const int nc = R.row, nf = A.row;
+    const int *Ri = R.ia.data(), *Rj = R.ja.data(), *Ai = A.ia.data(), *Aj = A.ja.data(),
+              *Pi = P.ia.data(), *Pj = P.ja.data();
+    const double *Rv = R.val.data(), *Av = A.val.data(), *Pv = P.val.data();
+    static const int table_min = std::getenv("FASP_HIP_RAP_TABLE_MIN") ? std::atoi(std::getenv("FASP_HIP_RAP_TABLE_MIN")) : 12000000;
+    if (nf < table_min) { galerkin_rap_markers(R, A, P, C); return; }   // (measured on P7(256): level 0, 16.8 M fine rows, 0.93 -> 0.46 s with the tables; level 1, 8.4 M, 0.45 -> 0.52 s; levels 2+ 0.11 -> 0.22 s)
+    int nthreads = omp_get_max_threads();
+    if (nc < 2000) nthreads = 1;
+
+    Buf<int> cia((size_t)nc + 1);
+    cia[0] = 0;
+    int*    Cj = nullptr;
+    double* Cv = nullptr;
+    bool    overflow = false;
+    // One parallel region for the symbolic and the numeric pass.  Stamps: symbolic 2 ic + 1, numeric 2 ic + 2 (never 0, never reused).
+    if (nc > 1000000000) throw std::bad_alloc();
+#pragma omp parallel num_threads(nthreads)
+    {
+        RapTable TA, TP;   // fine rows seen in this coarse row; coarse columns of this row -> position
+        std::vector<int> seen2;   // the fine rows of the current coarse row, in discovery order (symbolic pass)
+        auto mask_a = [&](int ic) {
+            long long ub2 = 0;
+            for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; ++j1) ub2 += Ai[Rj[j1] + 1] - Ai[Rj[j1]];
+            const unsigned ma = pow2_mask(2 * std::min<long long>(ub2, nf) + 2);
+            TA.ensure((size_t)ma + 1);
+            return ma;
+        };
+#pragma omp for schedule(dynamic, 256)
+        for (int ic = 0; ic < nc; ++ic) {
+            const unsigned ma = mask_a(ic);
+            const int st = 2 * ic + 1;
+            bool fresh;
+            seen2.clear();
+            long long ub3 = 1;   // entries of P behind the distinct fine rows (+ the diagonal): bounds the distinct coarse columns
+            for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; ++j1) {
+                const int i1 = Rj[j1];
+                for (int j2 = Ai[i1]; j2 < Ai[i1 + 1]; ++j2) {
+                    const int i2 = Aj[j2];
+                    (void)TA.slot(i2, st, ma, fresh);
+                    if (fresh) { seen2.push_back(i2); ub3 += Pi[i2 + 1] - Pi[i2]; }
+                }
+            }
+            const unsigned mp = pow2_mask(2 * std::min<long long>(ub3, nc) + 2);
+            TP.ensure((size_t)mp + 1);
+            int cnt = 1;
+            (void)TP.slot(ic, st, mp, fresh);
+            for (int i2 : seen2)
+                for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) {
+                    bool f3;
+                    (void)TP.slot(Pj[j3], st, mp, f3);
+                    cnt += f3 ? 1 : 0;
+                }
+            cia[ic + 1] = cnt;
+        }
+#pragma omp single
+        {
+            long long total = 0;
+            for (int ic = 0; ic < nc; ++ic) total += cia[ic + 1];
+            if (total > 2147483647LL) overflow = true;  // INT is 32-bit in the ABI
+            else {
+                for (int ic = 0; ic < nc; ++ic) cia[ic + 1] += cia[ic];
+                const int cnnz = cia[nc];
+                C.row = nc; C.col = nc; C.nnz = cnnz;
+                C.ja.alloc((size_t)cnnz);
+                C.val.alloc((size_t)cnnz);
+                Cj = C.ja.data();
+                Cv = C.val.data();
+            }
+        }  // implicit barrier
+        if (!overflow) {
+#pragma omp for schedule(dynamic, 256)
+            for (int ic = 0; ic < nc; ++ic) {
+                const unsigned ma = mask_a(ic), mp = pow2_mask(2ll * (cia[ic + 1] - cia[ic]) + 2);   // (the symbolic pass counted the row's columns)
+                TP.ensure((size_t)mp + 1);
+                const int st = 2 * ic + 2;
+                bool fresh;
+                int pos = cia[ic];
+                TP.val[(size_t)TP.slot(ic, st, mp, fresh)] = pos;
+                Cj[pos]    = ic;
+                Cv[pos]    = 0.0;
+                ++pos;
+                for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; ++j1) {
+                    const double r_entry = Rv[j1];
+                    const int    i1 = Rj[j1];
+                    for (int j2 = Ai[i1]; j2 < Ai[i1 + 1]; ++j2) {
+                        const double ra = r_entry * Av[j2];
+                        const int    i2 = Aj[j2];
+                        (void)TA.slot(i2, st, ma, fresh);
+                        if (fresh) {
+                            for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) {
+                                const double rap = ra * Pv[j3];
+                                const int    i3 = Pj[j3];
+                                bool f3;
+                                const int s3 = TP.slot(i3, st, mp, f3);
+                                if (f3) {
+                                    TP.val[(size_t)s3] = pos;
+                                    Cv[pos]    = rap;
+                                    Cj[pos]    = i3;
+                                    ++pos;
+                                } else {
+                                    Cv[TP.val[(size_t)s3]] += rap;
+                                }
+                            }
+                        } else {
+                            for (int j3 = Pi[i2]; j3 < Pi[i2 + 1]; ++j3) {
+                                bool f3;
+                                Cv[TP.val[(size_t)TP.slot(Pj[j3], st, mp, f3)]] += ra * Pv[j3];
+                            }
                         }
                     }
                 }
