@@ -24,6 +24,10 @@ constexpr double STAG_RATIO  = 1e-4;  // fasp_const.h:265
 
 constexpr int UNPT = -1, FGPT = 0, CGPT = 1, ISPT = 2;  // fasp_const.h:231-235
 
+// Large host arrays ask for transparent huge pages (the setup touches tens of gigabytes of fresh memory: one fault per 2 MB
+// instead of one per 4 KB); FASP_HIP_THP=0 switches the request off.  free() releases either kind.
+void* buf_malloc(size_t bytes);
+
 // Uninitialised, malloc-backed array (std::vector would zero-fill gigabytes).
 template <class T>
 struct Buf {
@@ -46,7 +50,8 @@ struct Buf {
     {
         release();
         n = n_;
-        p = static_cast<T*>(std::malloc((n_ ? n_ : 1) * sizeof(T)));
+        const size_t bytes = (n_ ? n_ : 1) * sizeof(T);
+        p = static_cast<T*>(buf_malloc(bytes));
         if (!p) throw std::bad_alloc();
     }
     void view(T* q, size_t n_) { release(); p = q; n = n_; own = false; }

@@ -20,6 +20,7 @@
 //   fasp_blas_dcsr_rap                                 base/src/BlaSpmvCSR.c:999
 //   list-of-lists helpers                              base/src/PreAMGUtil.inl:121,207
 #include <omp.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1780,6 +1781,19 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
     return status;
 }
 
+void* buf_malloc(size_t bytes)
+{
+    static const bool thp = !(std::getenv("FASP_HIP_THP") && std::atoi(std::getenv("FASP_HIP_THP")) == 0);
+    constexpr size_t HUGE = (size_t)2 << 20;
+    if (thp && bytes >= 4 * HUGE) {
+        void* q = nullptr;
+        if (posix_memalign(&q, HUGE, bytes) == 0 && q) {
+            (void)madvise(q, bytes, MADV_HUGEPAGE);
+            return q;
+        }
+    }
+    return std::malloc(bytes);
+}
 void (*g_on_level_ready)(int level, void* ctx) = nullptr;
 void* g_on_level_ready_ctx = nullptr;
 
