@@ -203,6 +203,11 @@ def main(args, rank, world, local_rank):
                      "levels": [{"level": l, "distributed": int(not i["replicated"]), "rows": i["nglobal"], "rank0_rows": i["nloc"],
                                  "rank0_ghosts": i["nghost"], "rank0_sends": i["nsend"]} for l, i in enumerate(levels_info)]},
         }
+        # the reference's own figures for this solve where they are pinned (tests/golden/configs_full.npz): what a first run on N GPUs is read against
+        pins = {256: (14, 6.3426837114e-09), 512: (31, 6.70717e-09)}
+        if n in pins:
+            out["parity_reference"] = {"iters_gpu": int(st), "iters_reference": pins[n][0], "relres_gpu": stats.relres, "relres_reference": pins[n][1],
+                                       "ok": bool(int(st) == pins[n][0] and abs(stats.relres - pins[n][1]) <= 1e-10)}
         if not args.no_cpu_baseline:
             # the same routine as the single-GPU line: the oracle on this node's host cores, on rank 0 only, on a bounded
             # sample of the same solve (rank 0 holds the global host hierarchy it published)
