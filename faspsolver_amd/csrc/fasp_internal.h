@@ -150,6 +150,7 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H);
 // When set, the classical setup reports every level as soon as its A, P, R and C/F marker are final (level l after
 // its Galerkin product; the coarsest one at the end): the device upload of level l then overlaps the setup of l + 1.
 extern void (*g_on_level_ready)(int level, void* ctx);
+extern void (*g_on_level_matrix)(int level, void* ctx);   // classical setup: the level's A is final (P, R, cfmark are not yet); same ctx
 extern void* g_on_level_ready_ctx;
 // Smoothed aggregation (PreAMGSetupSA.c:63: VMB aggregation, smoothed P and R).
 int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H);

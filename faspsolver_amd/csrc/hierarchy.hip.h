@@ -64,6 +64,7 @@ struct SchedJob { int level = 0, kind = 0, st = 0; bool uploaded = false; SplitH
 struct fasp_hip_amg {
     std::vector<std::unique_ptr<SchedJob>> sched_jobs;   // sequential smoothers: schedules being built side by side at the first sweep
     bool                  sched_jobs_started = false;
+    std::mutex            sched_mu;    // jobs are started from the setup thread (natural-order sweeps) or the upload thread (C/F-ordered ones)
     HostHierarchy         H;
     DistPlan              dist;        // row partition (nranks == 1: trivial)
     bool                  distributed = false;  // level 0 is row-partitioned over the ranks

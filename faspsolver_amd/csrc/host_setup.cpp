@@ -1685,6 +1685,7 @@ int host_setup_rs(const dCSRmat* A, AMG_param* param, HostHierarchy& H)
     try {
         while (H.L[lvl].A.row > min_cdof && lvl < max_lvls - 1) {
             HostLevel& Lv = H.L[lvl];
+            if (g_on_level_matrix) g_on_level_matrix(lvl, g_on_level_ready_ctx);   // A of this level is final (its P, R, cfmark are not yet)
             Pattern    S;
             static const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
             double tp = wall_seconds();
@@ -1795,6 +1796,7 @@ void* buf_malloc(size_t bytes)
     return std::malloc(bytes);
 }
 void (*g_on_level_ready)(int level, void* ctx) = nullptr;
+void (*g_on_level_matrix)(int level, void* ctx) = nullptr;
 void* g_on_level_ready_ctx = nullptr;
 
 int host_setup_sa(const dCSRmat* A, AMG_param* param, HostHierarchy& H)

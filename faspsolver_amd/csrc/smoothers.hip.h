@@ -260,12 +260,20 @@ static void sched_jobs_start(fasp_hip_amg* h)
 // The same for ONE level, while the host setup is still at work on the coarser ones (fasp_hip_amg_create: the thread that uploads
 // level l ahead of the setup calls this behind the upload): the greedy C/F passes of the setup are sequential, the cores are
 // there, and the first solve of P7(256) with the reference's defaults no longer waits 1.7 s for its schedules.
-static void sched_jobs_start_level(fasp_hip_amg* h, int l)
+// early = true: called when only the level's matrix is final -- sweeps in natural order need nothing else and start then
+// (the C/F-ordered ones wait for the marker: early = false, behind the level's upload)
+static void sched_jobs_start_level(fasp_hip_amg* h, int l, bool early = false)
 {
     if (g_tune.gs_multicolor || !g_tune.seq_jobs || !h->L[(size_t)l].replicated) return;
+    const int sm = h->param.smoother;
+    const bool natural = sm == SMOOTHER_SGS || sm == SMOOTHER_SOR || sm == SMOOTHER_SSOR || sm == SMOOTHER_GSOR || sm == SMOOTHER_SGSOR ||
+                         (sm == SMOOTHER_GS && h->param.smooth_order != CF_ORDER);
+    if (early != natural) return;
     int k0, k1;
-    if (!sched_kinds(h, l, k0, k1)) return;
+    if (early) { k0 = 0; k1 = sm == SMOOTHER_SGS ? 4 : 1; }
+    else if (!sched_kinds(h, l, k0, k1)) return;
     const int team = std::max(2, host_threads() / 8);
+    std::lock_guard<std::mutex> lk(h->sched_mu);
     sched_job_launch(h, l, k0, team);
     if (k1 >= 0) sched_job_launch(h, l, k1, team);
     h->sched_jobs_started = true;   // (what the first sweep would start is under way)

@@ -338,6 +338,11 @@ struct AheadUpload {
     int                     status = FASP_SUCCESS;
     int                     coarsest = -1;   // set (under mu) in front of the last level's turn: that one is not smoothed
     std::thread             th;
+    static void on_matrix(int level, void* ctx)   // (on the setup thread)
+    {
+        AheadUpload* self = static_cast<AheadUpload*>(ctx);
+        sched_jobs_start_level(self->h, level, true);
+    }
     static void on_ready(int level, void* ctx)
     {
         AheadUpload* self = static_cast<AheadUpload*>(ctx);
@@ -401,9 +406,9 @@ int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgpara
         AheadUpload up;
         up.h = h;
         up.th = std::thread([&up] { up.run(); });
-        g_on_level_ready = &AheadUpload::on_ready; g_on_level_ready_ctx = &up;
+        g_on_level_ready = &AheadUpload::on_ready; g_on_level_matrix = &AheadUpload::on_matrix; g_on_level_ready_ctx = &up;
         st = host_setup_rs(A, amgparam, h->H);
-        g_on_level_ready = nullptr; g_on_level_ready_ctx = nullptr;
+        g_on_level_ready = nullptr; g_on_level_matrix = nullptr; g_on_level_ready_ctx = nullptr;
         lap("host setup");
         if (st >= 0) {   // the coarsest level
             { std::lock_guard<std::mutex> lk(up.mu); up.coarsest = (int)h->H.L.size() - 1; }
