@@ -65,3 +65,39 @@ def test_probe_passes_over_transports_that_work_here(gpu, transport):
 def test_probe_reports_a_transport_that_cannot_start(gpu):
     # an unknown transport: every rank's child says so with exit code 2, nobody waits for anybody
     assert _probe_ranks("nosuch", 2, f"fasp_tprobe_{os.getpid()}_x") == [2, 2]
+
+
+def _choose_worker(rank, world, port, codes, q):
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+
+    def all_min(ok):
+        t = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t[0])
+    asked = []
+    got = P.choose_transport(["ipc", "rccl", "shm"], lambda t: (asked.append(t), codes[t][rank])[1], all_min)
+    q.put((rank, got, asked))
+    dist.destroy_process_group()
+
+
+def test_choose_transport_over_a_real_collective():
+    """Two processes, gloo, world_size 2 (the rendezvous of bench_dist.py): peer windows pass on rank 0 and time out on rank 1, RCCL
+    cannot start on rank 0 -> both ranks end up on shared memory, having asked the same three candidates in the same order."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    codes = {"ipc": [0, 124], "rccl": [2, 0], "shm": [0, 0]}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_choose_worker, args=(r, 2, port, codes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert [r[1] for r in res] == ["shm", "shm"]
+    assert all(r[2] == ["ipc", "rccl", "shm"] for r in res)
