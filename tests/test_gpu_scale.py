@@ -245,6 +245,30 @@ def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag,smoother,order,w", [("gsnat", T.SMOOTHER_GS, 0, 1.0), ("sor11", T.SMOOTHER_SOR, 0, 1.1), ("gscf", T.SMOOTHER_GS, 1, 1.0)])
+def test_sweeps_with_many_virtual_rows_match_reference(gpu, tag, smoother, order, w):
+    """Four lanes per row forced (fasp_hip_tune("seq_lanes", 4)): a work item holds 32 lower entries, so every row of the coarse
+    levels of P7(64) -- 60 to 400 entries -- hands its oldest entries to up to a dozen VIRTUAL ROWS (csrc/seq_sched.h), with and
+    without the spine.  Another association of every row sum, the same sweep: the reference's iteration count and residual
+    (tests/golden/p7_sweeps.npz) to the same bars as the default schedule."""
+    z = np.load(os.path.join(G, "p7_sweeps.npz"))
+    ia, ja, a, f, ue = fa.poisson7pt(64)
+    itp, amgp = _gs_params(smoother, order, w)
+    L = fa.lib()
+    try:
+        for spine in (0, 2):
+            L.fasp_hip_tune(b"seq_lanes", 4); L.fasp_hip_tune(b"seq_spine", spine)
+            H = fa.AMG(ia, ja, a, amgp)
+            st, x, hist, stats = H.solve(f, itp)
+            H.close()
+            assert st == int(z[f"{tag}_iters"]), (spine, st)
+            assert abs(stats.relres - float(z[f"{tag}_relres"])) <= RELRES_TOL
+            assert _same_history(hist, z[f"{tag}_hist"])
+    finally:
+        L.fasp_hip_tune(b"seq_lanes", 0); L.fasp_hip_tune(b"seq_spine", 1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("smoother,order,w", [(T.SMOOTHER_GS, 1, 1.0), (T.SMOOTHER_SOR, 0, 1.1)], ids=["GS-CF", "SOR-natural"])
 def test_multicolour_sweep_mode_converges_and_is_deterministic(gpu, smoother, order, w):
     """fasp_hip_tune("gs_multicolor", 1) -- the FLAGGED NON-PARITY mode: rows are relaxed colour by colour (greedy
