@@ -30,6 +30,7 @@ struct DevCSR {
     int     npat = 0, npent = 0;
     unsigned short* ja16 = nullptr;  // JA as 16-bit values (long-row operators with <= 65536 columns)
     int     nxrows = -1;             // k_csr_rowpat4 / 5: rows outside their wave's uniform pattern(s); -1: the pair sweep does not apply
+    int     plane = 0;               // square row-pattern-coded operators: the largest column offset of a pattern (the rows of a z-plane of a 3-D grid)
     // local operator of a row-partitioned level: the rows [win_lo, win_hi) read no ghost column (multiples of WIN_ALIGN
     // or the row count; win_hi < 0: no such window worth a split launch) -- they run while the halo is in flight
     int     win_lo = 0, win_hi = -1;
@@ -326,6 +327,37 @@ static bool build_rowpat(const HostCSR& M, Buf<unsigned short>& pat, std::vector
     return !collision;
 }
 
+// The "plane" of a square pattern-coded operator: the row distance P (a multiple of 8 tiles of the pair sweep) for which the
+// column offsets of the patterns are closest to multiples of P -- the rows of a z-plane of a 3-D grid numbered x-fastest, or of
+// whatever the coarse numbering has made of it.  With it an XCD can sweep ONE STRIP (P / 8 rows) of every plane: a row's z-neighbours
+// are in the same strip of the neighbouring planes, its x / y neighbours in the same strip except at the strip's edges
+// (kernels.hip.h, tile_of, xcd_map == -2).  Cost of a candidate = mean over the pattern entries of min(|o mod+- P|, P / 8) / (P / 8):
+// the share of rows whose neighbour lies in another XCD's strip.  0: no candidate below 0.2.
+static int grid_plane_of(const std::vector<int>& poff, int nrow)
+{
+    constexpr int UNIT = 8 * 2 * BLOCK;   // eight tiles of 2 * BLOCK rows
+    std::vector<int> cand;
+    for (int o : poff) {
+        const long long m = std::llabs((long long)o);
+        const long long c = (m + UNIT / 2) / UNIT * UNIT;
+        if (c >= UNIT && c <= nrow / 4 && std::find(cand.begin(), cand.end(), (int)c) == cand.end() && cand.size() < 64) cand.push_back((int)c);
+    }
+    int best = 0;
+    double best_cost = 0.2;
+    for (int P : cand) {
+        double cost = 0.0;
+        for (int o : poff) {
+            long long r = (long long)o % P;
+            if (r > P / 2) r -= P;
+            if (r < -P / 2) r += P;
+            cost += (double)std::min<long long>(std::llabs(r), P / 8) / (P / 8);
+        }
+        cost /= std::max<size_t>(poff.size(), 1);
+        if (cost < best_cost || (cost == best_cost && P > best)) { best_cost = cost; best = P; }
+    }
+    return best;
+}
+
 // 16-bit copy of the column indices (in the order of the device copy) for the operators the
 // sub-wavefront kernel serves: their time is the (JA, val) stream, 12 -> 10 bytes per entry.
 static int upload_ja16(DevCSR& D, const int* ja_dev_order)
@@ -537,6 +569,8 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
                 }
                 if (nx * 4 <= nr) D.nxrows = (int)nx;   // worth it when most rows are swept (the others go through the wave's queue)
             } else {
+                D.plane = grid_plane_of(poff, H.row);
+                if (std::getenv("FASP_HIP_SETUP_TIMING")) std::printf("        [upload_csr %d x %d, %d nnz] %d row patterns; grid plane for the XCD strips: %d rows\n", H.row, H.col, H.nnz, (int)pstart.size(), D.plane);
                 // k_csr_rowpat4 (kernels2.hip.h): the sweep computes the row pairs (2i, 2i+1) whose two rows have the
                 // pattern of row 128 w + 64 of their wave tile w; every other row goes on this list.
                 const int nr = H.row, npair = (nr + 1) / 2;
@@ -637,7 +671,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 512, seq_jobs = 1, seq_spine = 1, seq_grid = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 512, seq_jobs = 1, seq_spine = 1, seq_grid = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 1, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -743,8 +777,14 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         a.npat = M.npat; a.npent = M.npent; a.ncol = M.col; a.rowbase = nullptr;
         set_tiles(2 * BLOCK);
         a.xcd_map = a.ntiles >= 8 * 64 ? g_tune.rp_xcd : 16;  // slabs: x is fetched once per XCD (PMC: 0.18 GB instead of 0.45 GB per level-0 pass)
+        // strips instead of slabs where the operator says how long a grid plane is (kernels.hip.h, tile_of)
+        if (a.xcd_map == -1 && g_tune.rp_strip && M.plane >= 8 * 2 * BLOCK && M.plane % (8 * 2 * BLOCK) == 0 && a.ntiles >= 4 * (M.plane / (2 * BLOCK))) {
+            a.xcd_map = -2; a.tpp = M.plane / (2 * BLOCK); a.tiles_per_xcd = a.tpp / 8;
+        }
         if (OP == OP_JACOBI && a.partials) g_jacobi_dot_done = true;
-        return launch_persistent(k_csr_rowpat4<OP>, a.ntiles, a, g_tune.rp_bpc);
+        // (strips: three blocks per CU -- six planes of an XCD's strip in flight -- measured against two, four, five: level-0 t = A p
+        // 87-98 us against 95-105 with five; with four, 108)
+        return launch_persistent(k_csr_rowpat4<OP>, a.ntiles, a, a.xcd_map == -2 && g_tune.rp_bpc == 5 ? 3 : g_tune.rp_bpc);
     }
     // (measured on P7(256) level 0: prolongation, 1-6 entries per row, 140 -> 131 us; restriction, 7-13 entries per row,
     // 68 -> 80 us: the sweep pays for short lists only)

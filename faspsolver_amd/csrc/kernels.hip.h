@@ -53,6 +53,7 @@ struct CsrArgs {
     double        omega;     // OP_JACOBI
     int           ntiles;
     int           tiles_per_xcd;
+    int           tpp;      // xcd_map == -2: tiles per grid plane (tiles_per_xcd = tpp / 8: the strip of a plane one XCD sweeps)
     int           xcd_map;  // G > 0: an XCD works on runs of G consecutive tiles; 0: plain grid-stride
     int           nt;       // 1: non-temporal loads of JA / val
     // dictionary-coded matrices (k_csr_dict8): one byte per entry selects (column offset, value)
@@ -122,6 +123,7 @@ __device__ __forceinline__ double ld_val(const CsrArgs& a, int k)
 // entries, then hit the same XCD-private L2.  xcd_map = G (0: identity, plain grid-stride).
 __device__ __forceinline__ int tile_vmax(const CsrArgs& a)
 {
+    if (a.xcd_map == -2) return 8 * a.tiles_per_xcd * ((a.ntiles + a.tpp - 1) / a.tpp);  // strip mode: planes x strip
     if (a.xcd_map < 0) return 8 * a.tiles_per_xcd;  // slab mode
     if (a.xcd_map <= 0) return a.ntiles;
     const int span = 8 * a.xcd_map;
@@ -133,6 +135,14 @@ __device__ __forceinline__ int tile_of(const CsrArgs& a, int v)
     // consecutive tiles), so an x entry gathered by rows far apart in index but close in the
     // sweep (the +-nx*ny neighbours of a 3-D stencil) is fetched once per XCD and then hit in
     // that XCD's L2.  Pays when x dominates the traffic (compressed matrices).
+    // xcd_map == -2 (operators on a 3-D grid: rows x-fastest, tpp tiles per z-plane): every XCD sweeps ONE STRIP of every plane --
+    // tpp / 8 consecutive tiles, i.e. an eighth of the y range -- plane after plane.  What an XCD keeps of x between the sweep of
+    // plane z and of plane z + 1 is three strips (a few hundred KB at 256^3), not three planes next to the streams of y and the
+    // pattern ids in a 4 MB L2; an entry of x is fetched by the XCD whose strip holds it and by its two y-neighbours' edges.
+    if (a.xcd_map == -2) {
+        const int q = v >> 3, z = q / a.tiles_per_xcd;
+        return z * a.tpp + (v & 7) * a.tiles_per_xcd + (q - z * a.tiles_per_xcd);
+    }
     if (a.xcd_map < 0) return (v & 7) * a.tiles_per_xcd + (v >> 3);
     if (a.xcd_map <= 0) return v;
     const int G = a.xcd_map;
