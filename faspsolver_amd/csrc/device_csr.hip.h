@@ -671,7 +671,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 512, seq_jobs = 1, seq_spine = 1, seq_grid = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 1, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 512, seq_jobs = 1, seq_spine = 1, seq_grid = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 2, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -753,6 +753,12 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         a.ntiles = (w_hi - w_lo + rpb - 1) / rpb;
         a.tiles_per_xcd = (a.ntiles + 7) / 8;
     };
+    // XCD strips (kernels.hip.h, tile_of, xcd_map == -2) for a kernel with tiles of `rpb` rows, where the operator knows its grid plane
+    auto strips = [&](int rpb) {
+        if (!g_tune.rp_strip || M.plane < 8 * rpb || M.plane % (8 * rpb) != 0 || a.ntiles < 4 * (M.plane / rpb)) return false;
+        a.xcd_map = -2; a.tpp = M.plane / rpb; a.tiles_per_xcd = a.tpp / 8;
+        return true;
+    };
     if (M.code && g_tune.compress) M.kind = 4;  // dictionary-coded copy present: one byte per entry
     if (M.pat && g_tune.compress) M.kind = 5;   // row-pattern-coded copy present: two bytes per row
     if (g_tune.kind >= 0 && !(g_tune.kind == 4 && !M.code) && !(g_tune.kind == 5 && !M.pat)) M.kind = g_tune.kind;
@@ -778,9 +784,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         set_tiles(2 * BLOCK);
         a.xcd_map = a.ntiles >= 8 * 64 ? g_tune.rp_xcd : 16;  // slabs: x is fetched once per XCD (PMC: 0.18 GB instead of 0.45 GB per level-0 pass)
         // strips instead of slabs where the operator says how long a grid plane is (kernels.hip.h, tile_of)
-        if (a.xcd_map == -1 && g_tune.rp_strip && M.plane >= 8 * 2 * BLOCK && M.plane % (8 * 2 * BLOCK) == 0 && a.ntiles >= 4 * (M.plane / (2 * BLOCK))) {
-            a.xcd_map = -2; a.tpp = M.plane / (2 * BLOCK); a.tiles_per_xcd = a.tpp / 8;
-        }
+        if (a.xcd_map == -1) strips(2 * BLOCK);
         if (OP == OP_JACOBI && a.partials) g_jacobi_dot_done = true;
         // (strips: three blocks per CU -- six planes of an XCD's strip in flight -- measured against two, four, five: level-0 t = A p
         // 87-98 us against 95-105 with five; with four, 108)
@@ -795,6 +799,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         a.npat = M.npat; a.npent = M.npent; a.ncol = M.col; a.rowbase = M.rowbase;
         set_tiles(2 * BLOCK);
         a.xcd_map = a.ntiles >= 8 * 64 ? -1 : 16;
+        if (g_tune.rp_strip >= 2) strips(2 * BLOCK);
         return launch_rowpat5<OP>(a);
     }
     if (M.kind == 5) {
@@ -806,6 +811,7 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         a.plen = M.plen; a.ncol = M.col;
         if (g_tune.xcd_pat != 0) a.xcd_map = g_tune.xcd_pat;
         set_tiles(BLOCK * rpl);
+        if (g_tune.xcd_pat == 64 && g_tune.rp_strip >= 2) strips(BLOCK * rpl);
         (void)avg;
         if (lds && M.npat <= 64 && M.npent <= 512 && g_tune.lds_tab != 3) {  // small table: more resident blocks
             if (rpl == 1) return launch_persistent(k_csr_rowpat<OP, 2, 1>, a.ntiles, a);

@@ -304,6 +304,13 @@ static int upload_level(fasp_hip_amg* h, int l, const DistLevel* DLp)
         if (upload_csr(rep ? HL.P : DLp->P, D.P) < 0) return ERROR_ALLOC_MEM;
         lap("P");
         if (upload_csr(rep ? HL.R : DLp->R, D.R) < 0) return ERROR_ALLOC_MEM;
+        // the grid plane of the transfer operators (XCD strips of the coded kernels, device_csr.hip.h): P's rows are this level's, R's
+        // the next one's -- where the coarse rows are an exact fraction of the fine plane
+        if (D.A.plane > 0 && D.R.row > 0 && D.R.col > 0) {
+            D.P.plane = D.A.plane;
+            const long long pr = (long long)D.A.plane * D.R.row;
+            if (pr % D.R.col == 0) D.R.plane = (int)(pr / D.R.col);
+        }
         lap("R");
     }
     if (!rep) {   // interior windows (dist_launch), found with the partition (dist_plan.cpp)

@@ -2054,7 +2054,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;
     else if (!std::strcmp(key, "rp_stream")) g_tune.rp_stream = value;
     else if (!std::strcmp(key, "rp_xcd")) g_tune.rp_xcd = value;
-    else if (!std::strcmp(key, "rp_strip")) g_tune.rp_strip = value;   // coded square operators of a 3-D grid: an XCD sweeps a strip of every plane (1, default) or a slab of planes (0)
+    else if (!std::strcmp(key, "rp_strip")) g_tune.rp_strip = value;   // coded operators of a 3-D grid: an XCD sweeps a strip of every plane (1: the square ones, 2: the transfer operators too, default) or a slab of planes (0)
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
     else if (!std::strcmp(key, "lanes")) g_tune.lanes = value;
     else if (!std::strcmp(key, "wrows")) g_tune.wrows = value;

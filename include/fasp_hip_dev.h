@@ -30,7 +30,9 @@ int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
 
 /* Run-time switches (A/B tests, profiling, and ONE behavioural mode):
  *   kernel selection / launch geometry: maxgrid, xcd, nt, kind, lanes, wrows, wcap (-1 = automatic), gen2 (0 round-1
- *     kernels, 1, 2 = default), compress (lossless matrix coding on/off), ja16, ws2_bpc, rpl, lds_tab, xcd_pat;
+ *     kernels, 1, 2 = default), compress (lossless matrix coding on/off), ja16, ws2_bpc, rpl, lds_tab, xcd_pat, rp_strip (coded operators
+ *     of a 3-D grid: an XCD sweeps a strip of every grid plane -- 1: the square operators, 2 (default): the transfer operators too -- or,
+ *     0, a slab of planes);
  *   coarse solve: spcg_persist, spcg_fused, spcg_batch, spcg_grid, small_lds, small_onewave (coarsest levels of <= 128
  *     rows: 2 = matrix in registers, four wavefronts (default), 1 = dense in LDS, one wavefront, 0 = the general kernel),
  *     lazy_coarse (the one-launch solvers' verdicts read once per application of the preconditioner, default 1;
