@@ -1,5 +1,6 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""First and warm solve times of P7(n) with the sequential smoothers (sweep schedules built behind the setup): python tools/first_solve.py n"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import faspsolver_amd as fa
 from faspsolver_amd import _types as T
 n = int(sys.argv[1])

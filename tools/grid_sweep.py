@@ -1,7 +1,7 @@
 """Development: one sweep kind of one level of P7(n) with the dataflow solve's launch capped at g workgroups (fasp_hip_tune seq_grid).
 python tools/grid_sweep.py n level kind(10 ascending, 11 descending, 12 C rows, 13 F rows)"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import faspsolver_amd as fa
 n = int(sys.argv[1]); lev = int(sys.argv[2]); kind = int(sys.argv[3])
 L = fa.lib(); L.fasp_hip_tune(b"seq_spine", 0)
