@@ -346,17 +346,53 @@ def variable_leg(n, system, itp, amgp, timed_solves):
 
 
 def device_state():
-    """Clocks and temperatures of GPU 0 as rocm-smi reports them (memory clock, fabric clock, junction / HBM temperature, package
-    power) -- printed next to the measured ceilings: two boxes of the pool whose triad ceilings agree to 1 % have differed by 14 % on
-    the plain-CSR level-0 kernel; this is what can be read without privileges to tell them apart."""
+    """Clocks and temperatures of GPU 0 read from sysfs (memory clock, fabric clock, junction / HBM temperature, package power) --
+    printed next to the measured ceilings: two boxes of the pool whose triad ceilings agree to 1 % have differed by 14 % on the
+    plain-CSR level-0 kernel; this is what can be read without privileges to tell them apart.
+    No child process: rocm-smi is an `env python3` script, and under `rocprofv3 --pmc` (tools/profile.sh) a child
+    inherits the profiler's preload -- a GPU-initialised process replacing its program, which this pool must never see."""
+    import glob
     try:
-        out = subprocess.run(["rocm-smi", "--showclocks", "--showtemp", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
-        card = next(iter(json.loads(out).values()))
-        pick = lambda k: str(card.get(k, "")).strip("()")
-        return {"mclk": pick("mclk clock speed:"), "fclk": pick("fclk clock speed:"), "sclk_idle": pick("sclk clock speed:"),
-                "temp_junction_C": pick("Temperature (Sensor junction) (C)"), "temp_hbm_C": pick("Temperature (Sensor memory) (C)"),
-                "package_power_W": pick("Current Socket Graphics Package Power (W)")}
-    except Exception as e:   # (no rocm-smi, no permission: the line just lacks the field)
+        devs = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() == "0x1002" and os.path.exists(os.path.join(d, "pp_dpm_mclk")):
+                    devs.append(d)
+            except OSError:
+                pass
+        if not devs:
+            return {"unavailable": "no amdgpu device with pp_dpm_mclk under /sys/class/drm"}
+        d = devs[0]
+
+        def active(name):   # the line of a pp_dpm_* table that carries the '*'
+            try:
+                for ln in open(os.path.join(d, name)).read().splitlines():
+                    if ln.rstrip().endswith("*"):
+                        return ln.split(":", 1)[1].replace("*", "").strip()
+            except OSError:
+                pass
+            return ""
+
+        res = {"mclk": active("pp_dpm_mclk"), "fclk": active("pp_dpm_fclk"), "sclk_idle": active("pp_dpm_sclk"), "source": "sysfs"}
+        for h in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+            for lab in glob.glob(os.path.join(h, "temp*_label")):
+                try:
+                    name = open(lab).read().strip()
+                    val = int(open(lab.replace("_label", "_input")).read()) / 1000.0
+                except (OSError, ValueError):
+                    continue
+                if name == "junction":
+                    res["temp_junction_C"] = val
+                elif name == "mem":
+                    res["temp_hbm_C"] = val
+            for pw in ("power1_average", "power1_input"):
+                try:
+                    res["package_power_W"] = int(open(os.path.join(h, pw)).read()) / 1e6
+                    break
+                except (OSError, ValueError):
+                    continue
+        return res
+    except Exception as e:   # (no sysfs access: the line just lacks the field)
         return {"unavailable": repr(e)}
 
 
@@ -573,12 +609,37 @@ def main():
         "roofline_plain_csr": plain,
         "ceilings": ceilings,
     }
+    # The parity statement of the line: against the REFERENCE's own run of this solve (tests/golden/p7_scale.npz, written by
+    # tools/gen_golden_f5*.py from the compiled reference; a committed fixture, not the oracle): iteration count, final
+    # relative residual (absolute bar 1e-10; relative deviation printed beside it), the residual history.
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "p7_scale.npz"))
+        if f"n{n}_iters" in z.files:
+            it_ref, rr_ref = int(z[f"n{n}_iters"]), float(z[f"n{n}_relres"])
+            pr = {"iters_gpu": int(st), "iters_reference": it_ref, "relres_gpu": stats.relres, "relres_reference": rr_ref,
+                  "abs_dev_relres": abs(stats.relres - rr_ref), "rel_dev_relres": abs(stats.relres - rr_ref) / rr_ref,
+                  "source": "compiled reference (tests/golden/p7_scale.npz)"}
+            ok = int(st) == it_ref and abs(stats.relres - rr_ref) <= 1e-10 and abs(stats.relres - rr_ref) <= 1e-6 * rr_ref
+            if f"n{n}_hist" in z.files:
+                hr = z[f"n{n}_hist"]
+                hd = np.concatenate([hist[:-2], hist[-1:]])   # (the device history ends with recurrence and true residual of the last iteration)
+                if len(hd) == len(hr):
+                    pr["max_rel_dev_residual_history"] = float(np.max(np.abs(hd[:-1] - hr[:-1]) / hr[:-1]))
+                    ok = ok and pr["max_rel_dev_residual_history"] <= 1e-8
+                else:
+                    ok = False
+            pr["ok"] = bool(ok)
+            out["parity_reference"] = pr
+    except Exception as e:
+        log(f"parity_reference unavailable: {e!r}")
     if not args.no_cpu_baseline:
         try:
             cb, its_cpu, rr_cpu, hist_dev = cpu_baseline(H, ia, ja, a, f, int(st), hist,
                                                          float(os.environ.get("BENCH_CPU_BUDGET_S", "15")), baseline_candidates())
             out["cpu_baseline"] = cb
-            out["parity"] = {"iters_gpu": int(st), "iters_cpu": its_cpu, "relres_gpu": stats.relres,
+            out["parity"] = {"against": "the multi-thread CPU baseline of this run (the oracle in its TIMING mode: OpenMP-regrouped "
+                                        "reductions -- not the reference's serial sums; the reference itself: parity_reference)",
+                             "iters_gpu": int(st), "iters_cpu": its_cpu, "relres_gpu": stats.relres,
                              "relres_cpu": rr_cpu, "max_rel_dev_residual_history": hist_dev}
             cb1, _i, _r, _h = cpu_baseline(H, ia, ja, a, f, int(st), hist, 0.0, 1)
             out["cpu_baseline_1thread"] = cb1

@@ -206,7 +206,7 @@ unsigned* ipc_counters_for(hipStream_t s)
 {
     for (int i = 0; i < g_ipc.nstreams; ++i) if (g_ipc.streams[i] == s) return g_ipc.counters + 2 * i;
     if (g_ipc.nstreams < 4) { g_ipc.streams[g_ipc.nstreams] = s; return g_ipc.counters + 2 * g_ipc.nstreams++; }
-    return g_ipc.counters;   // (more streams than the solver has: share)
+    return nullptr;   // (more streams than the solver has: an error -- sharing a pair of last-block counters between streams is a race)
 }
 // one exchange kernel: my messages into the peers' mailboxes, theirs out of mine
 int ipc_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int nrecv, hipStream_t stream)
@@ -241,6 +241,7 @@ int ipc_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int nr
     }
     if (a.ns == 0 && a.nr == 0) return FASP_SUCCESS;
     a.counters = ipc_counters_for(stream);
+    if (!a.counters) { std::fprintf(stderr, "### ERROR: fasp_hip: peer-window exchanges issued on more than four streams\n"); return ERROR_MISC; }
     a.err = g_ipc.err;
     return ipc_xchg_launch(a, total, stream) < 0 ? ERROR_MISC : FASP_SUCCESS;
 }
@@ -556,7 +557,18 @@ int fasp_hip_comm_init_ipc(int rank, int nranks, const char* name)
     if (ok) { slot(rank)->h = hnd; std::memcpy(slot(rank)->bus, busid, sizeof(busid)); }
     slot(rank)->ok = ok ? 1 : 0;
     if (!ok) shm_raise_error();
-    if (shm_barrier() < 0) { std::fprintf(stderr, "### ERROR: fasp_hip: peer-window start-up failed (window allocation or IPC export on a rank)\n"); return ERROR_MISC; }
+    // a failed start-up leaves nothing behind: the window is freed, the peers' mappings closed, the segment given back
+    auto fail = [&]() {
+        (void)hipDeviceSynchronize();
+        for (int q = 0; q < nranks; ++q) if (q != rank && g_ipc.win[q]) (void)hipIpcCloseMemHandle(g_ipc.win[q]);
+        if (w) (void)hipFree(w);
+        if (g_ipc.counters) (void)hipFree(g_ipc.counters);
+        if (g_ipc.err) (void)hipHostFree(g_ipc.err);
+        g_ipc = IpcState{};
+        (void)fasp_hip_comm_finalize();   // (backend SHM at this point: unmaps / unlinks the segment, back to NONE)
+        return ERROR_MISC;
+    };
+    if (shm_barrier() < 0) { std::fprintf(stderr, "### ERROR: fasp_hip: peer-window start-up failed (window allocation or IPC export on a rank)\n"); return fail(); }
     g_ipc.win[rank] = static_cast<char*>(w);
     g_ipc_shared_device = false;
     for (int q = 0; q < nranks && ok; ++q) {
@@ -570,7 +582,7 @@ int fasp_hip_comm_init_ipc(int rank, int nranks, const char* name)
     if (ok) ok = hipHostMalloc((void**)&g_ipc.err, 64, hipHostMallocDefault) == hipSuccess;
     if (ok) { std::memset(g_ipc.err, 0, 64); ok = hipDeviceSynchronize() == hipSuccess; }
     if (!ok) { std::fprintf(stderr, "### ERROR: fasp_hip: rank %d cannot map its peers' windows (hipIpcOpenMemHandle)\n", rank); shm_raise_error(); }
-    if (shm_barrier() < 0) return ERROR_MISC;
+    if (shm_barrier() < 0) return fail();
     g_backend = IPC;
     return FASP_SUCCESS;
 }

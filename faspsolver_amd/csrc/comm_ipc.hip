@@ -50,13 +50,15 @@ __global__ __launch_bounds__(IPC_T) void k_ipc_xchg(IpcXchgArgs a)
     if (tid == 0) s_last = atomicAdd(a.counters, 1u) == gridDim.x - 1;
     __syncthreads();
     if (s_last) {
+        __threadfence_system();   // (release: the arrival counts of all blocks -- and through them their payload stores -- before the word)
         if (tid < a.ns) ipc_st(a.s[tid].remote_flag, a.s[tid].seq);
         if (tid == 0) a.counters[0] = 0u;   // (the next launch on this stream finds it reset)
     }
-    // get: wait for the peers' words, copy the payloads to the ghost entries
+    // get: wait for the peers' words, copy the payloads to the ghost entries.  The acquire fence sits BEHIND the barrier: every
+    // wave of the block -- not only the polling threads -- orders its payload loads after the word has been seen.
     if (tid < a.nr) (void)ipc_wait(a.r[tid].local_flag, a.r[tid].seq, true, a.err);
-    __threadfence_system();
     __syncthreads();
+    __threadfence_system();
     for (int m = 0; m < a.nr; ++m) {
         const IpcRecv& R = a.r[m];
         for (long long i = (long long)blockIdx.x * IPC_T + tid; i < R.n; i += (long long)gridDim.x * IPC_T) R.dst[i] = R.local_data[i];
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(IPC_T) void k_ipc_xchg(IpcXchgArgs a)
     if (tid == 0) s_last = atomicAdd(a.counters + 1, 1u) == gridDim.x - 1;
     __syncthreads();
     if (s_last) {   // every block has read its share: tell the senders
+        __threadfence_system();
         if (tid < a.nr) ipc_st(a.r[tid].remote_ack, a.r[tid].seq);
         if (tid == 0) a.counters[1] = 0u;
     }
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(64) void k_ipc_allreduce(IpcRedArgs a)
             __threadfence_system();
             ipc_st(a.remote_flag[q], a.epoch);
             (void)ipc_wait(a.local_flag[q], a.epoch, true, a.err);
-            __threadfence_system();
+            __threadfence_system();   // (acquire in the polling thread itself: it is the one that reads the payload)
             for (int i = 0; i < a.n; ++i) s_v[q][i] = a.local_val[q][i];
         }
     }

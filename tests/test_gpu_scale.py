@@ -1,10 +1,15 @@
 """Parity at scale (fixture F5): the HIP path through the C-ABI at 64^3, 128^3 and
 256^3 against numbers the REFERENCE produced -- tests/golden/p7_scale.npz, written by
 tools/gen_golden_f5.py from the compiled reference (64^3, 128^3, the variable-coefficient twin at 48^3 and
-96^3) and from BASELINE.md section 2 (256^3: 14 iterations, relres 6.3426837114e-09).
+96^3) and by tools/gen_golden_f5_256.py (round 5: the compiled reference run at 256^3 itself -- 14 iterations,
+relres 6.3426837114e-09 as BASELINE.md section 2 recorded, now with the whole residual history and a solution sample).
 
-Bars (north_star): equal iteration counts; |relres_gpu - relres_ref| <= 1e-10; level sizes equal; the
-residual history to rtol 1e-8; the solution to 1e-9 of its maximum.  Plus the kernel A/B identities at
+Bars (north_star): equal iteration counts; |relres_gpu - relres_ref| <= 1e-10 (absolute: SURVEY section 8(d)'s parity
+statement) AND <= 1e-6 * relres_ref (relative: what the device path achieves with its regrouped -- not the reference's
+serial -- dot products and row sums is 1e-8 .. 2e-7; a drift beyond 1e-6 fails here long before it reaches the absolute
+bar; north_star's literal "1e-10 relative" on a 6e-9 quantity would need the reference's left-to-right summation order
+in every reduction of 16.8 M terms); level sizes equal; the residual history to rtol 1e-8; the
+solution to 1e-9 of its maximum.  Plus the kernel A/B identities at
 sizes where the full-chip kernel variants (16-bit ids, slab schedule, exception lists, 16-byte staged
 streams) are the ones that run.
 """
@@ -18,6 +23,7 @@ from faspsolver_amd import _types as T
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RELRES_TOL = 1e-10   # north_star: final residual within 1e-10 of the reference's
+RELRES_RTOL = 1e-6   # ... and within 1e-6 of it in relative terms (drift guard; achieved: 1e-8 .. 2e-7)
 HIST_RTOL = 1e-8
 X_TOL = 1e-9
 
@@ -57,6 +63,7 @@ def test_p7_matches_reference_at_scale(gpu, n):
     ref_hist = z[f"n{n}_hist"]
     assert st == int(z[f"n{n}_iters"])
     assert abs(stats.relres - float(z[f"n{n}_relres"])) <= RELRES_TOL
+    assert abs(stats.relres - float(z[f"n{n}_relres"])) <= RELRES_RTOL * float(z[f"n{n}_relres"])
     assert _same_history(hist, ref_hist)
     step = max(1, len(x) // 4096)
     xs = z[f"n{n}_xsample"]
@@ -68,8 +75,9 @@ def test_p7_matches_reference_at_scale(gpu, n):
 
 @pytest.mark.gpu
 def test_p7_256_headline_iterations_and_residual(gpu):
-    """The benchmark configuration itself: 14 iterations and relres 6.3426837114e-09,
-    the reference's ten level sizes, and the plain-CSR kernels reproducing the coded ones on the same hierarchy."""
+    """The benchmark configuration itself against the compiled reference's own run at this size (tools/gen_golden_f5_256.py):
+    14 iterations, relres 6.3426837114e-09, the residual history to 1e-8, a 4096-entry sample of the solution and its norms to
+    1e-9, the reference's ten level sizes -- and the plain-CSR kernels reproducing the coded ones on the same hierarchy."""
     z = np.load(os.path.join(G, "p7_scale.npz"))
     n = 256
     ia, ja, a, f, ue = fa.poisson7pt(n)
@@ -80,8 +88,15 @@ def test_p7_256_headline_iterations_and_residual(gpu):
     st, hist, stats = H.solve_resident(itp)
     assert st == int(z["n256_iters"])
     assert abs(stats.relres - float(z["n256_relres"])) <= RELRES_TOL
+    assert abs(stats.relres - float(z["n256_relres"])) <= RELRES_RTOL * float(z["n256_relres"])
+    assert _same_history(hist, z["n256_hist"])
     x = H.get_solution()
     assert np.abs(x - ue).max() < 2e-5   # second-order discretisation error of the generator's exact solution
+    step = max(1, len(x) // 4096)
+    xs = z["n256_xsample"]
+    assert np.abs(x[::step] - xs).max() <= X_TOL * np.abs(xs).max()
+    s, mx, n2 = z["n256_xsum"]
+    assert abs(np.abs(x).max() - mx) <= X_TOL * mx and abs(np.sqrt((x * x).sum()) - n2) <= X_TOL * n2
     kinds = [H.kernel_info(l, 0)[0] for l in range(H.num_levels)]
     assert kinds[0] == 6 and kinds[1] == 6   # scalar-pattern sweep on the two coded levels
     L = fa.lib()
