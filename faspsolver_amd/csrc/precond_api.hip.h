@@ -83,6 +83,7 @@ dCSRmat fasp_dcsr_create(const int m, const int n, const int nnz)
 }
 void fasp_dcsr_free(dCSRmat* A)
 {
+    FASP_ENTRY();
     if (!A) return;
     std::free(A->IA); std::free(A->JA); std::free(A->val);
     A->row = A->col = A->nnz = 0; A->IA = A->JA = nullptr; A->val = nullptr;
@@ -90,6 +91,7 @@ void fasp_dcsr_free(dCSRmat* A)
 
 void fasp_param_amg_to_prec(precond_data* pcdata, const AMG_param* amgparam)
 {
+    FASP_ENTRY();
     pcdata->AMG_type = amgparam->AMG_type; pcdata->print_level = amgparam->print_level;
     pcdata->maxit = amgparam->maxit; pcdata->max_levels = amgparam->max_levels; pcdata->tol = amgparam->tol;
     pcdata->cycle_type = amgparam->cycle_type; pcdata->smoother = amgparam->smoother;
@@ -102,6 +104,7 @@ void fasp_param_amg_to_prec(precond_data* pcdata, const AMG_param* amgparam)
 }
 void fasp_param_prec_to_amg(AMG_param* amgparam, const precond_data* pcdata)
 {
+    FASP_ENTRY();
     amgparam->AMG_type = pcdata->AMG_type; amgparam->print_level = pcdata->print_level;
     amgparam->cycle_type = pcdata->cycle_type; amgparam->smoother = pcdata->smoother;
     amgparam->smooth_order = pcdata->smooth_order; amgparam->presmooth_iter = pcdata->presmooth_iter;
@@ -132,6 +135,7 @@ AMG_data* fasp_amg_data_create(short max_levels)
 // arrays: they go with the handle (and its device copy); b / x / w were allocated here and are freed here.
 void fasp_amg_data_free(AMG_data* mgl, AMG_param* param)
 {
+    FASP_ENTRY();
     if (!mgl) return;
     const int nl = std::max<int>(1, mgl[0].num_levels);
     fasp_hip_amg* h = handle_of_mgl(mgl);
@@ -155,6 +159,7 @@ void fasp_amg_data_free(AMG_data* mgl, AMG_param* param)
 // PreCSR.c:46
 precond* fasp_precond_setup(const short precond_type, AMG_param* amgparam, ILU_param* iluparam, dCSRmat* A)
 {
+    FASP_ENTRY();
     (void)iluparam;
     if (precond_type == PREC_NULL) return nullptr;
     if (!A) { std::printf("### ERROR: fasp_precond_setup: A == NULL\n"); std::exit(ERROR_INPUT_PAR); }
@@ -269,15 +274,18 @@ void smoother_standalone(const char* fn, dvector* u, int i_1, int i_n, int s, dC
 // ItrSmootherCSR.c:251: s = +1 ascending, -1 descending, u_i = t * (1 / a_ii)
 void fasp_smoother_dcsr_gs(dvector* u, const int i_1, const int i_n, const int s, dCSRmat* A, dvector* b, int L)
 {
+    FASP_ENTRY();
     smoother_standalone(__func__, u, i_1, i_n, s, A, b, L, SMOOTHER_GS, 1.0);
 }
 // ItrSmootherCSR.c:932
 void fasp_smoother_dcsr_sor(dvector* u, const int i_1, const int i_n, const int s, dCSRmat* A, dvector* b, int L, const double w)
 {
+    FASP_ENTRY();
     smoother_standalone(__func__, u, i_1, i_n, s, A, b, L, SMOOTHER_SOR, w);
 }
 // ItrSmootherCSR.c:1509 (order independent)
 void fasp_smoother_dcsr_L1diag(dvector* u, const int i_1, const int i_n, const int s, dCSRmat* A, dvector* b, int L)
 {
+    FASP_ENTRY();
     smoother_standalone(__func__, u, i_1, i_n, s, A, b, L, SMOOTHER_L1DIAG, 1.0);
 }

@@ -165,10 +165,22 @@ static inline int vec_grid(int n)
 // ===========================================================================
 // C ABI
 // ===========================================================================
+// ---------------------------------------------------------------------------
+// Threading contract of the boundary (SURVEY section 8b "Threading"; the serial reference, AuxThreads.c:29-57, lets different
+// threads solve on DISJOINT data).  The device side of this library is one context per process -- one stream, one set of
+// reduction buffers, the fasp_hip_tune switches -- so every computing entry point takes ONE process-wide lock for its whole
+// duration: calls from different host threads are SERIALISED, never interleaved.  The lock is recursive (an entry may call
+// another one, and a caller's precond / mxv_matfree callback may call back into the library on the same thread).
+// Concurrency across GPUs is one PROCESS per GPU, not threads.
+// ---------------------------------------------------------------------------
+static std::recursive_mutex g_entry_mutex;
+#define FASP_ENTRY() std::lock_guard<std::recursive_mutex> fasp_entry_lock_(g_entry_mutex)
+
 extern "C" {
 
 int fasp_hip_set_device(int device)
 {
+    FASP_ENTRY();
     if (g_ctx.ready && device != g_ctx.device) {
         std::fprintf(stderr, "### ERROR: fasp_hip: device already bound to %d\n", g_ctx.device);
         return ERROR_INPUT_PAR;
@@ -179,6 +191,7 @@ int fasp_hip_set_device(int device)
 
 int fasp_hip_device_count(void)
 {
+    FASP_ENTRY();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return ERROR_MISC;
     return n;
@@ -186,6 +199,7 @@ int fasp_hip_device_count(void)
 
 int fasp_hip_available(void)
 {
+    FASP_ENTRY();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
     return 1;
@@ -193,6 +207,7 @@ int fasp_hip_available(void)
 
 int fasp_hip_amg_create_host(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgparam)
 {
+    FASP_ENTRY();
     if (!out || !A || !amgparam) return ERROR_INPUT_PAR;
     *out = nullptr;
     int st = check_supported(nullptr, amgparam);
@@ -225,6 +240,7 @@ std::vector<std::pair<fasp_hip_amg*, ShmMapping>> g_attached;  // unmapped when 
 
 int fasp_hip_amg_publish(const fasp_hip_amg* h, const char* name)
 {
+    FASP_ENTRY();
     if (!h || !name || h->H.L.empty() || (int)h->H.L.size() > MAX_AMG_LVL) return ERROR_INPUT_PAR;
     const int nl = (int)h->H.L.size();
     ShmHierHeader hd;
@@ -271,6 +287,7 @@ int fasp_hip_amg_publish(const fasp_hip_amg* h, const char* name)
 
 int fasp_hip_amg_unpublish(const char* name)
 {
+    FASP_ENTRY();
     if (!name) return ERROR_INPUT_PAR;
     shm_unlink((std::string("/") + name).c_str());
     return FASP_SUCCESS;
@@ -278,6 +295,7 @@ int fasp_hip_amg_unpublish(const char* name)
 
 int fasp_hip_amg_attach(fasp_hip_amg** out, const char* name)
 {
+    FASP_ENTRY();
     if (!out || !name) return ERROR_INPUT_PAR;
     *out = nullptr;
     const std::string nm = std::string("/") + name;
@@ -317,6 +335,7 @@ int fasp_hip_amg_attach(fasp_hip_amg** out, const char* name)
 
 int fasp_hip_amg_upload(fasp_hip_amg* h)
 {
+    FASP_ENTRY();
     if (!h) return ERROR_INPUT_PAR;
     if (!h->L.empty()) return FASP_SUCCESS;
     int st = ctx_init();
@@ -382,6 +401,7 @@ struct AheadUpload {
 
 int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgparam)
 {
+    FASP_ENTRY();
     if (!out || !A || !amgparam) return ERROR_INPUT_PAR;
     *out = nullptr;
     int st = check_supported(nullptr, amgparam);
@@ -436,6 +456,7 @@ int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgpara
 
 void fasp_hip_amg_destroy(fasp_hip_amg* h)
 {
+    FASP_ENTRY();
     if (h) sched_jobs_join(h);
     if (!h) return;
     if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
@@ -470,6 +491,7 @@ void fasp_hip_amg_destroy(fasp_hip_amg* h)
 // dictionary) or 0 (stays plain CSR).  Returns 0 when the round trip is exact.
 int fasp_hip_coding_selftest(const dCSRmat* A, int* kind_out)
 {
+    FASP_ENTRY();
     if (!A || !kind_out) return ERROR_INPUT_PAR;
     HostCSR M;
     M.row = A->row; M.col = A->col; M.nnz = A->nnz;
@@ -520,6 +542,7 @@ int fasp_hip_amg_num_levels(const fasp_hip_amg* h) { return h ? (int)h->H.L.size
 // matrix data one pass of it reads (row pointers / indices / values, or their coded form)
 int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* kind, double* matrix_bytes)
 {
+    FASP_ENTRY();
     if (!h || level < 0 || level >= (int)h->L.size() || which < 0 || which > 2) return ERROR_INPUT_PAR;
     const DevLevel& D = h->L[level];
     const DevCSR& M = which == 0 ? D.A : which == 1 ? D.P : D.R;
@@ -544,6 +567,7 @@ int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* k
 
 int fasp_hip_amg_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view)
 {
+    FASP_ENTRY();
     if (!h || !view || level < 0 || level >= (int)h->H.L.size()) return ERROR_INPUT_PAR;
     const HostLevel& L = h->H.L[level];
     if (which != 0 && !L.has_coarse) return ERROR_INPUT_PAR;
@@ -553,6 +577,7 @@ int fasp_hip_amg_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat
 
 int fasp_hip_amg_get_cfmark(const fasp_hip_amg* h, int level, ivector* view)
 {
+    FASP_ENTRY();
     if (!h || !view || level < 0 || level >= (int)h->H.L.size() || !h->H.L[level].has_coarse)
         return ERROR_INPUT_PAR;
     view->row = h->H.L[level].A.row;
@@ -562,6 +587,7 @@ int fasp_hip_amg_get_cfmark(const fasp_hip_amg* h, int level, ivector* view)
 
 int fasp_hip_set_rhs(fasp_hip_amg* h, const dvector* b)
 {
+    FASP_ENTRY();
     if (!h || !b || h->L.empty()) return ERROR_INPUT_PAR;
     const DevLevel& D0 = h->L[0];
     if (b->row != D0.nglobal) return ERROR_MAT_SIZE;  // host vectors are global; a rank uploads its rows
@@ -572,6 +598,7 @@ int fasp_hip_set_rhs(fasp_hip_amg* h, const dvector* b)
 
 int fasp_hip_set_guess(fasp_hip_amg* h, const dvector* x)
 {
+    FASP_ENTRY();
     if (!h || h->L.empty()) return ERROR_INPUT_PAR;
     const DevLevel& D0 = h->L[0];
     if (x) {
@@ -586,6 +613,7 @@ int fasp_hip_set_guess(fasp_hip_amg* h, const dvector* x)
 
 int fasp_hip_get_solution(fasp_hip_amg* h, dvector* x)
 {
+    FASP_ENTRY();
     if (!h || !x || h->L.empty()) return ERROR_INPUT_PAR;
     const DevLevel& D0 = h->L[0];
     if (x->row != D0.nglobal) return ERROR_MAT_SIZE;  // a rank fills the rows it owns
@@ -596,6 +624,7 @@ int fasp_hip_get_solution(fasp_hip_amg* h, dvector* x)
 
 int fasp_hip_device_synchronize(void)
 {
+    FASP_ENTRY();
     if (!g_ctx.ready) return FASP_SUCCESS;
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     return FASP_SUCCESS;
@@ -604,6 +633,7 @@ int fasp_hip_device_synchronize(void)
 int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* hist, int hist_cap,
                             fasp_hip_stats* stats)
 {
+    FASP_ENTRY();
     if (!h || !itparam) return ERROR_INPUT_PAR;
     if (h->L.empty()) return ERROR_INPUT_PAR;  // hierarchy not uploaded
     int st = check_supported(itparam, &h->param);
@@ -688,6 +718,7 @@ int fasp_hip_solve_resident(fasp_hip_amg* h, const ITS_param* itparam, double* h
 int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_param* itparam, double* hist,
                    int hist_cap, fasp_hip_stats* stats)
 {
+    FASP_ENTRY();
     if (!h || !b || !x || !itparam) return ERROR_INPUT_PAR;
     double t0 = wall_seconds();
     int st = fasp_hip_set_rhs(h, b);
@@ -708,6 +739,7 @@ int fasp_hip_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const ITS_para
 int fasp_hip_amg_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const AMG_param* param, double* hist,
                        int hist_cap, fasp_hip_stats* stats)
 {
+    FASP_ENTRY();
     if (!h || !b || !x || h->L.empty()) return ERROR_INPUT_PAR;
     const AMG_param& p = param ? *param : h->param;
     int st = check_supported(nullptr, &p);
@@ -742,6 +774,7 @@ int fasp_hip_amg_solve(fasp_hip_amg* h, const dvector* b, dvector* x, const AMG_
 // unpreconditioned CPU GMRES there; this library has no CPU solve path).
 int fasp_solver_amg(dCSRmat* A, dvector* b, dvector* x, AMG_param* param)
 {
+    FASP_ENTRY();
     if (!A || !b || !x || !param) return ERROR_INPUT_PAR;
     const double t0 = wall_seconds();
     int st = check_supported(nullptr, param);
@@ -761,6 +794,7 @@ int fasp_solver_amg(dCSRmat* A, dvector* b, dvector* x, AMG_param* param)
 // initial guess of the finest level and receives the result.  void in the reference; the status is an extension.
 int fasp_solver_famg(const dCSRmat* A, const dvector* b, dvector* x, AMG_param* param)
 {
+    FASP_ENTRY();
     if (!A || !b || !x || !param) return ERROR_INPUT_PAR;
     const double t0 = wall_seconds();
     int st = check_supported(nullptr, param);
@@ -798,6 +832,7 @@ int fasp_solver_famg(const dCSRmat* A, const dvector* b, dvector* x, AMG_param* 
 
 int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z)
 {
+    FASP_ENTRY();
     if (!h || !r || !z || h->L.empty()) return ERROR_INPUT_PAR;
     const int m = h->L[0].nloc;
     r += h->L[0].row0; z += h->L[0].row0;  // global host vectors, own rows
@@ -813,12 +848,14 @@ int fasp_hip_precond_amg(fasp_hip_amg* h, const double* r, double* z)
 // ---- row-partition inspection (host only; used by the CPU-side distributed tests) ----
 int fasp_hip_dist_plan(fasp_hip_amg* h, int rank, int nranks, int min_rows)
 {
+    FASP_ENTRY();
     if (!h) return ERROR_INPUT_PAR;
     return build_dist_plan(h->H, rank, nranks, min_rows, h->dist);
 }
 
 int fasp_hip_dist_level_info(const fasp_hip_amg* h, int level, int* info)
 {
+    FASP_ENTRY();
     if (!h || !info || level < 0 || level >= (int)h->dist.L.size()) return ERROR_INPUT_PAR;
     const DistLevel& D = h->dist.L[level];
     info[0] = D.replicated; info[1] = D.nglobal; info[2] = D.row0; info[3] = D.nloc;
@@ -829,6 +866,7 @@ int fasp_hip_dist_level_info(const fasp_hip_amg* h, int level, int* info)
 
 int fasp_hip_dist_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view)
 {
+    FASP_ENTRY();
     if (!h || !view || level < 0 || level >= (int)h->dist.L.size()) return ERROR_INPUT_PAR;
     const DistLevel& D = h->dist.L[level];
     if (D.replicated) return fasp_hip_amg_get_matrix(h, level, which, view);
@@ -840,6 +878,7 @@ int fasp_hip_dist_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRma
 
 int fasp_hip_dist_get_list(const fasp_hip_amg* h, int level, int which, ivector* view)
 {
+    FASP_ENTRY();
     if (!h || !view || level < 0 || level >= (int)h->dist.L.size()) return ERROR_INPUT_PAR;
     const DistLevel& D = h->dist.L[level];
     if (which >= 5 && which <= 7) {   // interior window [lo, hi) of the local A (5), P (6), R (7); hi < 0: none
@@ -859,6 +898,7 @@ int fasp_hip_dist_get_list(const fasp_hip_amg* h, int level, int which, ivector*
 // SolCSR.c:476 -- the drop-in entry point
 int fasp_solver_dcsr_krylov_amg(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam, AMG_param* amgparam)
 {
+    FASP_ENTRY();
     if (!A || !b || !x || !itparam || !amgparam) return ERROR_INPUT_PAR;
     const double t0 = wall_seconds();
     int st = check_supported(itparam, amgparam);
@@ -880,6 +920,7 @@ int fasp_solver_dcsr_krylov_amg(dCSRmat* A, dvector* b, dvector* x, ITS_param* i
 // ---------------------------------------------------------------------------
 void fasp_hip_bsr_amg_destroy(fasp_hip_amg_bsr* h)
 {
+    FASP_ENTRY();
     if (!h) return;
     if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
     for (auto& Lv : h->L) {
@@ -901,6 +942,7 @@ void fasp_hip_bsr_amg_destroy(fasp_hip_amg_bsr* h)
 // host part only (no GPU needed): the hierarchy can be inspected, not solved with
 int fasp_hip_bsr_amg_create_host(fasp_hip_amg_bsr** out, const dBSRmat* A, AMG_param* amgparam)
 {
+    FASP_ENTRY();
     if (!out || !A || !amgparam) return ERROR_INPUT_PAR;
     *out = nullptr;
     int st = check_supported_bsr(nullptr, amgparam, A->nb);
@@ -915,6 +957,7 @@ int fasp_hip_bsr_amg_create_host(fasp_hip_amg_bsr** out, const dBSRmat* A, AMG_p
 
 int fasp_hip_bsr_amg_create(fasp_hip_amg_bsr** out, const dBSRmat* A, AMG_param* amgparam)
 {
+    FASP_ENTRY();
     if (!out || !A || !amgparam) return ERROR_INPUT_PAR;
     *out = nullptr;
     int st = check_supported_bsr(nullptr, amgparam, A->nb);
@@ -991,6 +1034,7 @@ int fasp_hip_bsr_amg_create(fasp_hip_amg_bsr** out, const dBSRmat* A, AMG_param*
 // [2] owned block rows, [3] ghost blocks, [4] first level kept whole, [5] block size
 int fasp_hip_bsr_dist_info(const fasp_hip_amg_bsr* h, int* info)
 {
+    FASP_ENTRY();
     if (!h || !info || h->L.empty()) return ERROR_INPUT_PAR;
     const BsrLevel& L0 = h->L[0];
     int first_rep = 0;
@@ -1003,6 +1047,7 @@ int fasp_hip_bsr_amg_num_levels(const fasp_hip_amg_bsr* h) { return h ? (int)h->
 
 int fasp_hip_bsr_amg_get_matrix(const fasp_hip_amg_bsr* h, int level, int which, dBSRmat* view)
 {
+    FASP_ENTRY();
     if (!h || !view || level < 0 || level >= (int)h->H.L.size()) return ERROR_INPUT_PAR;
     const HostLevelBSR& L = h->H.L[level];
     if (which != 0 && !L.has_coarse) return ERROR_INPUT_PAR;
@@ -1012,6 +1057,7 @@ int fasp_hip_bsr_amg_get_matrix(const fasp_hip_amg_bsr* h, int level, int which,
 
 const double* fasp_hip_bsr_amg_get_diaginv(const fasp_hip_amg_bsr* h, int level)
 {
+    FASP_ENTRY();
     if (!h || level < 0 || level >= (int)h->H.L.size() || !h->H.L[level].has_coarse) return nullptr;
     return h->H.L[level].diaginv.data();
 }
@@ -1019,6 +1065,7 @@ const double* fasp_hip_bsr_amg_get_diaginv(const fasp_hip_amg_bsr* h, int level)
 int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const ITS_param* itparam, double* hist,
                        int hist_cap, fasp_hip_stats* stats)
 {
+    FASP_ENTRY();
     if (!h || !b || !x || !itparam || h->L.empty()) return ERROR_INPUT_PAR;
     const int n = h->L[0].n;                                    // owned scalar rows
     const int nglob = h->L[0].nglobal * h->H.L[0].A.nb;          // b and x are the GLOBAL vectors: a rank reads / fills its rows
@@ -1080,6 +1127,7 @@ int fasp_hip_bsr_solve(fasp_hip_amg_bsr* h, const dvector* b, dvector* x, const 
 // SolBSR.c:349: UA-AMG setup on the host, hierarchy uploaded, Krylov loop on the device
 int fasp_solver_dbsr_krylov_amg(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam, AMG_param* amgparam)
 {
+    FASP_ENTRY();
     if (!A || !b || !x || !itparam || !amgparam) return ERROR_INPUT_PAR;
     const double t0 = wall_seconds();
     int st = check_supported_bsr(itparam, amgparam, A->nb);
@@ -1141,6 +1189,7 @@ struct TmpVec {
 // PreCSR.c:416 signature: z = B r, host vectors; data is the fasp_hip_amg* of fasp_hip_precond_setup
 void fasp_hip_precond_fct(double* r, double* z, void* data)
 {
+    FASP_ENTRY();
     fasp_hip_amg* h = static_cast<fasp_hip_amg*>(data);
     if (fasp_hip_precond_amg(h, r, z) < 0) {
         std::fprintf(stderr, "### ERROR: fasp_hip_precond_fct: device preconditioner failed\n");
@@ -1151,6 +1200,7 @@ void fasp_hip_precond_fct(double* r, double* z, void* data)
 // PreCSR.c:46 for PREC_AMG: hierarchy built and uploaded once, handed out as a `precond`
 precond* fasp_hip_precond_setup(dCSRmat* A, AMG_param* amgparam)
 {
+    FASP_ENTRY();
     fasp_hip_amg* h = nullptr;
     if (fasp_hip_amg_create(&h, A, amgparam) < 0) return nullptr;
     precond* pc = static_cast<precond*>(std::calloc(1, sizeof(precond)));
@@ -1163,6 +1213,7 @@ precond* fasp_hip_precond_setup(dCSRmat* A, AMG_param* amgparam)
 
 void fasp_hip_precond_free(precond* pc)
 {
+    FASP_ENTRY();
     if (!pc) return;
     if (pc->fct == fasp_hip_precond_fct) fasp_hip_amg_destroy(static_cast<fasp_hip_amg*>(pc->data));
     std::free(pc);
@@ -1266,48 +1317,56 @@ int krylov_plugin(const char* fn, int which, dCSRmat* A, dvector* b, dvector* u,
 int fasp_solver_dcsr_pcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
                          const int MaxIt, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin(__func__, 0, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 // KryPgmres.c:66
 int fasp_solver_dcsr_pgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                             const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin(__func__, 4, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 // KryPvgmres.c:66
 int fasp_solver_dcsr_pvgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                              const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin(__func__, 1, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 // KryPbcgs.c:62
 int fasp_solver_dcsr_pbcgs(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
                            const int MaxIt, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin(__func__, 3, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 // KryPminres.c:61
 int fasp_solver_dcsr_pminres(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
                              const int MaxIt, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin(__func__, 5, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 // KryPgcg.c:60
 int fasp_solver_dcsr_pgcg(dCSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
                           const int MaxIt, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin(__func__, 6, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 // KryPgcr.c:55
 int fasp_solver_dcsr_pgcr(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                           const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin(__func__, 7, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 // KryPvfgmres.c:67
 int fasp_solver_dcsr_pvfgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                               const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin(__func__, 2, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 
@@ -1315,6 +1374,7 @@ int fasp_solver_dcsr_pvfgmres(dCSRmat* A, dvector* b, dvector* x, precond* pc, c
 // z = B r with the resident block hierarchy (PreBSR.c:1149 signature); data = fasp_hip_amg_bsr*
 void fasp_hip_bsr_precond_fct(double* r, double* z, void* data)
 {
+    FASP_ENTRY();
     fasp_hip_amg_bsr* h = static_cast<fasp_hip_amg_bsr*>(data);
     if (!h || h->L.empty() || ctx_init() < 0) die_bsr(__func__);
     const int n = h->L[0].n;
@@ -1327,6 +1387,7 @@ void fasp_hip_bsr_precond_fct(double* r, double* z, void* data)
 
 precond* fasp_hip_bsr_precond_setup(dBSRmat* A, AMG_param* amgparam)
 {
+    FASP_ENTRY();
     fasp_hip_amg_bsr* h = nullptr;
     if (fasp_hip_bsr_amg_create(&h, A, amgparam) < 0) return nullptr;
     precond* pc = static_cast<precond*>(std::calloc(1, sizeof(precond)));
@@ -1337,6 +1398,7 @@ precond* fasp_hip_bsr_precond_setup(dBSRmat* A, AMG_param* amgparam)
 
 void fasp_hip_bsr_precond_free(precond* pc)
 {
+    FASP_ENTRY();
     if (!pc) return;
     if (pc->fct == fasp_hip_bsr_precond_fct) fasp_hip_bsr_amg_destroy(static_cast<fasp_hip_amg_bsr*>(pc->data));
     std::free(pc);
@@ -1414,26 +1476,31 @@ int krylov_plugin_bsr(const char* fn, int which, dBSRmat* A, dvector* b, dvector
 int fasp_solver_dbsr_pcg(dBSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
                          const int MaxIt, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin_bsr(__func__, 0, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 int fasp_solver_dbsr_pbcgs(dBSRmat* A, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
                            const int MaxIt, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin_bsr(__func__, 3, A, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 int fasp_solver_dbsr_pgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                             const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin_bsr(__func__, 4, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 int fasp_solver_dbsr_pvgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                              const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin_bsr(__func__, 1, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 int fasp_solver_dbsr_pvfgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                               const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_plugin_bsr(__func__, 2, A, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 
@@ -1443,6 +1510,7 @@ int fasp_solver_dbsr_pvfgmres(dBSRmat* A, dvector* b, dvector* x, precond* pc, c
 // ---------------------------------------------------------------------------
 void fasp_precond_diag(double* r, double* z, void* data)  // PreCSR.c:172 (host arrays)
 {
+    FASP_ENTRY();
     const dvector* diag = static_cast<const dvector*>(data);
     std::memcpy(z, r, sizeof(double) * (size_t)diag->row);
     for (int i = 0; i < diag->row; ++i)
@@ -1450,6 +1518,7 @@ void fasp_precond_diag(double* r, double* z, void* data)  // PreCSR.c:172 (host 
 }
 void fasp_precond_dbsr_diag(double* r, double* z, void* data)  // PreBSR.c:49 (host arrays): z_i = Dinv_i r_i
 {
+    FASP_ENTRY();
     const precond_diag_bsr* d = static_cast<const precond_diag_bsr*>(data);
     const int nb = d->nb, nb2 = nb * nb, m = d->diag.row / nb2;
     for (int i = 0; i < m; ++i)
@@ -1464,6 +1533,7 @@ void fasp_precond_dbsr_diag(double* r, double* z, void* data)  // PreBSR.c:49 (h
 // SolCSR.c:56
 int fasp_solver_dcsr_itsolver(dCSRmat* A, dvector* b, dvector* x, precond* pc, ITS_param* itparam)
 {
+    FASP_ENTRY();
     if (!itparam) return ERROR_INPUT_PAR;
     const short prtlvl = itparam->print_level, stop_type = itparam->stop_type, restart = (short)itparam->restart;
     const int MaxIt = itparam->maxit;
@@ -1490,6 +1560,7 @@ int fasp_solver_dcsr_itsolver(dCSRmat* A, dvector* b, dvector* x, precond* pc, I
 // SolCSR.c:245
 int fasp_solver_dcsr_krylov(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam)
 {
+    FASP_ENTRY();
     if (!itparam) return ERROR_INPUT_PAR;
     const double t0 = wall_seconds();
     const int status = fasp_solver_dcsr_itsolver(A, b, x, nullptr, itparam);
@@ -1499,6 +1570,7 @@ int fasp_solver_dcsr_krylov(dCSRmat* A, dvector* b, dvector* x, ITS_param* itpar
 // SolCSR.c:333: diagonal preconditioner from fasp_dcsr_getdiag(0, A, ..) -- the FIRST diagonal hit of each row
 int fasp_solver_dcsr_krylov_diag(dCSRmat* A, dvector* b, dvector* x, ITS_param* itparam)
 {
+    FASP_ENTRY();
     if (!A || !itparam || !A->IA || !A->JA || !A->val) return ERROR_INPUT_PAR;
     const double t0 = wall_seconds();
     const int n = std::min(A->row, A->col);
@@ -1515,6 +1587,7 @@ int fasp_solver_dcsr_krylov_diag(dCSRmat* A, dvector* b, dvector* x, ITS_param* 
 // SolBSR.c:64
 int fasp_solver_dbsr_itsolver(dBSRmat* A, dvector* b, dvector* x, precond* pc, ITS_param* itparam)
 {
+    FASP_ENTRY();
     if (!itparam) return ERROR_INPUT_PAR;
     const short prtlvl = itparam->print_level, stop_type = itparam->stop_type, restart = (short)itparam->restart;
     const int MaxIt = itparam->maxit;
@@ -1538,6 +1611,7 @@ int fasp_solver_dbsr_itsolver(dBSRmat* A, dvector* b, dvector* x, precond* pc, I
 // SolBSR.c:145
 int fasp_solver_dbsr_krylov(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam)
 {
+    FASP_ENTRY();
     if (!itparam) return ERROR_INPUT_PAR;
     const double t0 = wall_seconds();
     const int status = fasp_solver_dbsr_itsolver(A, b, x, nullptr, itparam);
@@ -1547,6 +1621,7 @@ int fasp_solver_dbsr_krylov(dBSRmat* A, dvector* b, dvector* x, ITS_param* itpar
 // SolBSR.c:186: block-diagonal preconditioner, inverse blocks by fasp_smat_inv
 int fasp_solver_dbsr_krylov_diag(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam)
 {
+    FASP_ENTRY();
     if (!A || !itparam || !A->IA || !A->JA || !A->val) return ERROR_INPUT_PAR;
     if (A->nb < 1 || A->nb > 7) {
         std::printf("### ERROR: fasp_hip: block-diagonal preconditioner needs 1 <= nb <= 7, got %d\n", A->nb);
@@ -1574,16 +1649,19 @@ int fasp_solver_dbsr_krylov_diag(dBSRmat* A, dvector* b, dvector* x, ITS_param* 
 // ---------------------------------------------------------------------------
 void fasp_hip_mxv_csr(const void* A, const double* x, double* y)  // SolMatFree.c: fasp_blas_mxv_csr
 {
+    FASP_ENTRY();
     fasp_blas_dcsr_mxv(static_cast<const dCSRmat*>(A), x, y);
 }
 void fasp_hip_mxv_bsr(const void* A, const double* x, double* y)  // SolMatFree.c: fasp_blas_mxv_bsr
 {
+    FASP_ENTRY();
     fasp_blas_dbsr_mxv(static_cast<const dBSRmat*>(A), x, y);
 }
 
 // SolMatFree.c:201
 void fasp_solver_matfree_init(int matrix_format, mxv_matfree* mf, void* A)
 {
+    FASP_ENTRY();
     switch (matrix_format) {
         case MAT_CSR: mf->fct = fasp_hip_mxv_csr; break;
         case MAT_BSR: mf->fct = fasp_hip_mxv_bsr; break;
@@ -1686,31 +1764,37 @@ int krylov_matfree(const char* fn, int which, mxv_matfree* mf, dvector* b, dvect
 int fasp_solver_pcg(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
                     const int MaxIt, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_matfree(__func__, 0, mf, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 int fasp_solver_pbcgs(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
                       const int MaxIt, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_matfree(__func__, 3, mf, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 int fasp_solver_pgcg(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
                      const int MaxIt, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_matfree(__func__, 6, mf, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 int fasp_solver_pgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                        const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_matfree(__func__, 4, mf, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 int fasp_solver_pvgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                         const int MaxIt, short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_matfree(__func__, 1, mf, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 int fasp_solver_pvfgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, const double tol, const double abstol,
                          const int MaxIt, const short restart, const short StopType, const short PrtLvl)
 {
+    FASP_ENTRY();
     return krylov_matfree(__func__, 2, mf, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
 // KryPminres.c:1283.  Refused: the restart branches of the reference's matrix-free MinRes call
@@ -1718,6 +1802,7 @@ int fasp_solver_pvfgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, c
 int fasp_solver_pminres(mxv_matfree*, dvector*, dvector*, precond*, const double, const double, const int, const short,
                         const short)
 {
+    FASP_ENTRY();
     std::printf("### ERROR: fasp_hip: fasp_solver_pminres (matrix-free MinRes) is not provided; "
                 "fasp_solver_dcsr_pminres is\n");
     return ERROR_SOLVER_TYPE;
@@ -1726,6 +1811,7 @@ int fasp_solver_pminres(mxv_matfree*, dvector*, dvector*, precond*, const double
 // SolMatFree.c:58: dispatch on itsolver_type
 int fasp_solver_itsolver(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, ITS_param* itparam)
 {
+    FASP_ENTRY();
     if (!itparam) return ERROR_INPUT_PAR;
     const short prtlvl = itparam->print_level, stop_type = itparam->stop_type;
     const int restart = itparam->restart, MaxIt = itparam->maxit;
@@ -1753,6 +1839,7 @@ int fasp_solver_itsolver(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, I
 // SolMatFree.c:157: Krylov method without preconditioner
 int fasp_solver_krylov(mxv_matfree* mf, dvector* b, dvector* x, ITS_param* itparam)
 {
+    FASP_ENTRY();
     if (!itparam) return ERROR_INPUT_PAR;
     const double t0 = wall_seconds();
     const int status = fasp_solver_itsolver(mf, b, x, nullptr, itparam);
@@ -1762,6 +1849,7 @@ int fasp_solver_krylov(mxv_matfree* mf, dvector* b, dvector* x, ITS_param* itpar
 
 void fasp_blas_dcsr_mxv(const dCSRmat* A, const double* x, double* y)
 {
+    FASP_ENTRY();
     TmpCSR M(A);
     if (!M.ok) die_no_device(__func__);
     TmpVec dx(x, A->col), dy(nullptr, A->row);
@@ -1771,6 +1859,7 @@ void fasp_blas_dcsr_mxv(const dCSRmat* A, const double* x, double* y)
 
 void fasp_blas_dcsr_aAxpy(const double alpha, const dCSRmat* A, const double* x, double* y)
 {
+    FASP_ENTRY();
     TmpCSR M(A);
     if (!M.ok) die_no_device(__func__);
     TmpVec dx(x, A->col), dy(y, A->row);
@@ -1780,6 +1869,7 @@ void fasp_blas_dcsr_aAxpy(const double alpha, const dCSRmat* A, const double* x,
 
 double fasp_blas_darray_dotprod(const int n, const double* x, const double* y)
 {
+    FASP_ENTRY();
     if (ctx_init() < 0) die_no_device(__func__);
     TmpVec dx(x, n), dy(y, n);
     double out = 0.0;
@@ -1789,6 +1879,7 @@ double fasp_blas_darray_dotprod(const int n, const double* x, const double* y)
 
 double fasp_blas_darray_norm2(const int n, const double* x)
 {
+    FASP_ENTRY();
     if (ctx_init() < 0) die_no_device(__func__);
     TmpVec dx(x, n);
     double out[2] = {0, 0};
@@ -1798,6 +1889,7 @@ double fasp_blas_darray_norm2(const int n, const double* x)
 
 double fasp_blas_darray_norminf(const int n, const double* x)
 {
+    FASP_ENTRY();
     if (ctx_init() < 0) die_no_device(__func__);
     TmpVec dx(x, n);
     double out[2] = {0, 0};
@@ -1807,6 +1899,7 @@ double fasp_blas_darray_norminf(const int n, const double* x)
 
 void fasp_blas_darray_axpy(const int n, const double a, const double* x, double* y)
 {
+    FASP_ENTRY();
     if (ctx_init() < 0) die_no_device(__func__);
     TmpVec dx(x, n), dy(y, n);
     d_axpy(n, a, dx.d, dy.d);
@@ -1815,6 +1908,7 @@ void fasp_blas_darray_axpy(const int n, const double a, const double* x, double*
 
 void fasp_blas_darray_axpby(const int n, const double a, const double* x, const double b, double* y)
 {
+    FASP_ENTRY();
     if (ctx_init() < 0) die_no_device(__func__);
     TmpVec dx(x, n), dy(y, n);
     d_axpby(n, a, dx.d, b, dy.d);
@@ -1825,6 +1919,7 @@ void fasp_blas_darray_axpby(const int n, const double a, const double* x, const 
 // alpha = y' A x (BlaSpmvCSR.c:839): the fused SpMV + dot epilogue the coarse-scaling step of the cycle uses
 double fasp_blas_dcsr_vmv(const dCSRmat* A, const double* x, const double* y)
 {
+    FASP_ENTRY();
     TmpCSR M(A);
     if (!M.ok) die_no_device(__func__);
     TmpVec dx(x, A->col), dy(y, A->row), dt(nullptr, A->row);
@@ -1846,16 +1941,19 @@ struct TmpUnitCSR {
 }  // namespace
 void fasp_blas_dcsr_mxv_agg(const dCSRmat* A, const double* x, double* y)  // BlaSpmvCSR.c:438
 {
+    FASP_ENTRY();
     TmpUnitCSR U(A);
     fasp_blas_dcsr_mxv(&U.view, x, y);
 }
 void fasp_blas_dcsr_aAxpy_agg(const double alpha, const dCSRmat* A, const double* x, double* y)  // BlaSpmvCSR.c:727
 {
+    FASP_ENTRY();
     TmpUnitCSR U(A);
     fasp_blas_dcsr_aAxpy(alpha, &U.view, x, y);
 }
 void fasp_blas_darray_ax(const int n, const double a, double* x)  // BlaArray.c:43
 {
+    FASP_ENTRY();
     if (a == 1.0) return;
     if (ctx_init() < 0) die_no_device(__func__);
     TmpVec dx(x, n);
@@ -1864,6 +1962,7 @@ void fasp_blas_darray_ax(const int n, const double a, double* x)  // BlaArray.c:
 }
 void fasp_blas_darray_axpyz(const int n, const double a, const double* x, const double* y, double* z)  // BlaArray.c:403
 {
+    FASP_ENTRY();
     if (ctx_init() < 0) die_no_device(__func__);
     TmpVec dx(x, n), dy(y, n), dz(nullptr, n);
     hipLaunchKernelGGL(k_axpyz, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, a, dx.d, dy.d, dz.d);
@@ -1882,18 +1981,21 @@ int norm1_nan(const char* fn, int n, const double* x, double out[2])
 }  // namespace
 double fasp_blas_darray_norm1(const int n, const double* x)  // BlaArray.c:663
 {
+    FASP_ENTRY();
     double out[2] = {0, 0};
     (void)norm1_nan(__func__, n, x, out);
     return out[0];
 }
 short fasp_dvec_isnan(const dvector* u)  // AuxVector.c:39
 {
+    FASP_ENTRY();
     double out[2] = {0, 0};
     (void)norm1_nan(__func__, u->row, u->val, out);
     return out[1] > 0.0 ? 1 : 0;
 }
 void fasp_darray_cp(const int n, const double* x, double* y)  // AuxArray.c:210: through HBM (upload, device copy, download)
 {
+    FASP_ENTRY();
     if (ctx_init() < 0) die_no_device(__func__);
     TmpVec dx(x, n), dy(nullptr, n);
     (void)hipMemcpyAsync(dy.d, dx.d, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, g_ctx.stream);
@@ -1901,6 +2003,7 @@ void fasp_darray_cp(const int n, const double* x, double* y)  // AuxArray.c:210:
 }
 void fasp_darray_set(const int n, double* x, const double val)  // AuxArray.c:41
 {
+    FASP_ENTRY();
     if (ctx_init() < 0) die_no_device(__func__);
     TmpVec dx(nullptr, n);
     hipLaunchKernelGGL(k_set, dim3(vec_grid(n)), dim3(BLOCK), 0, g_ctx.stream, n, val, dx.d);
@@ -1909,6 +2012,7 @@ void fasp_darray_set(const int n, double* x, const double val)  // AuxArray.c:41
 
 void fasp_blas_dbsr_mxv(const dBSRmat* A, const double* x, double* y)
 {
+    FASP_ENTRY();
     TmpBSR M(A);
     if (!M.ok) die_bsr(__func__);
     TmpVec dx(x, (size_t)A->COL * A->nb), dy(nullptr, (size_t)A->ROW * A->nb);
@@ -1919,6 +2023,7 @@ void fasp_blas_dbsr_mxv(const dBSRmat* A, const double* x, double* y)
 
 void fasp_blas_dbsr_aAxpy(const double alpha, const dBSRmat* A, const double* x, double* y)
 {
+    FASP_ENTRY();
     if (alpha == 0.0) return;  // BlaSpmvBSR.c:548
     TmpBSR M(A);
     if (!M.ok) die_bsr(__func__);
@@ -1932,6 +2037,7 @@ void fasp_blas_dbsr_aAxpy(const double alpha, const dBSRmat* A, const double* x,
 // nb = 2, 3, 4, Gauss-Jordan with full pivoting for 5..7; nb == 1: reciprocals
 dvector fasp_dbsr_getdiaginv(const dBSRmat* A)
 {
+    FASP_ENTRY();
     dvector out{0, nullptr};
     if (!A || A->nb < 1 || A->nb > 7) {
         std::fprintf(stderr, "### ERROR: fasp_dbsr_getdiaginv: block size %d not supported (1..7)\n", A ? A->nb : -1);
@@ -1945,6 +2051,7 @@ dvector fasp_dbsr_getdiaginv(const dBSRmat* A)
 
 void fasp_smoother_dbsr_jacobi1(dBSRmat* A, dvector* b, dvector* u, double* diaginv)
 {
+    FASP_ENTRY();
     TmpBSR M(A);
     if (!M.ok) die_bsr(__func__);
     const size_t n = (size_t)A->ROW * A->nb;
@@ -1956,6 +2063,7 @@ void fasp_smoother_dbsr_jacobi1(dBSRmat* A, dvector* b, dvector* u, double* diag
 
 double fasp_hip_time_bsr_mxv(const dBSRmat* A, int reps)
 {
+    FASP_ENTRY();
     TmpBSR M(A);
     if (!M.ok || reps <= 0) return -1.0;
     TmpVec dx(nullptr, (size_t)A->COL * A->nb), dy(nullptr, (size_t)A->ROW * A->nb);
@@ -1978,6 +2086,7 @@ double fasp_hip_time_bsr_mxv(const dBSRmat* A, int reps)
 void fasp_smoother_dcsr_jacobi(dvector* u, const int i_1, const int i_n, const int s, dCSRmat* A, dvector* b,
                                int L, const double w)
 {
+    FASP_ENTRY();
     (void)s;
     TmpCSR M(A);
     if (!M.ok) die_no_device(__func__);
@@ -2006,6 +2115,7 @@ void fasp_smoother_dcsr_jacobi(dvector* u, const int i_1, const int i_n, const i
 #ifdef FLOW_TIMING
 extern "C" int fasp_hip_flow_times(unsigned long long* out, int n)   // (development build only: tools/perf_gs_one.py)
 {
+    FASP_ENTRY();
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(fasp::g_flow_times), sizeof(unsigned long long) * (size_t)std::min(n, 8192)) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -2013,6 +2123,7 @@ extern "C" int fasp_hip_flow_times(unsigned long long* out, int n)   // (develop
 // development knob: override kernel selection / launch geometry at run time
 int fasp_hip_tune(const char* key, int value)
 {
+    FASP_ENTRY();
     if (!key) return ERROR_INPUT_PAR;
     if (!std::strcmp(key, "maxgrid")) g_tune.maxgrid = value;
     else if (!std::strcmp(key, "xcd")) g_tune.xcd = value;
@@ -2068,6 +2179,7 @@ int fasp_hip_tune(const char* key, int value)
 // counted), triad (two reads + one write counted).  Returns 0 or a negative error code.
 int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps)
 {
+    FASP_ENTRY();
     if (!out || bytes < (1u << 20) || reps <= 0) return ERROR_INPUT_PAR;
     if (ctx_init() != FASP_SUCCESS) return ERROR_MISC;
     f64x2_t *p = nullptr, *q = nullptr, *r = nullptr;
@@ -2101,6 +2213,7 @@ int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps)
 // timed micro-benchmark of one kernel class on a resident level
 double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps)
 {
+    FASP_ENTRY();
     if (!h || level < 0 || level >= (int)h->L.size() || reps <= 0) return -1.0;
     DevLevel& D = h->L[level];
     const int n = D.A.row;
@@ -2144,6 +2257,7 @@ double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps)
 // fused with (y, x).  Returns milliseconds per launch (< 0: error); *kind_out = kernel family as fasp_hip_amg_kernel_info.
 double fasp_hip_time_matrix(const dCSRmat* A, int op, int reps, int* kind_out)
 {
+    FASP_ENTRY();
     if (!A || reps <= 0 || ctx_init() < 0) return -1.0;
     HostCSR M;
     M.row = A->row; M.col = A->col; M.nnz = A->nnz;
