@@ -15,7 +15,174 @@
 
 namespace fasp {
 
-int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team, int spine)
+
+// ---------------------------------------------------------------------------
+// The chain form (seq_sched.h, seq_chain.hip.h).  Returns FASP_SUCCESS, 1 when the form does not apply (a row that is left alone,
+// more positions than 16-bit columns address), or a negative error code.  Everything is row-parallel: the sequential part of a
+// schedule -- the dependency classes, which decide WHETHER this form is taken -- has been done by the caller.
+// ---------------------------------------------------------------------------
+static int build_chain_host(const HostCSR& A, const int* seq, int ns, const Buf<int>& pos, int n1_blocks, bool timing, SplitHost& H)
+{
+    const int n = A.row;
+    if (ns <= 0 || ns > 65535 - 128) return 1;
+    const int nb = (ns + 63) / 64, npad = nb * 64;
+    double tl = wall_seconds();
+    auto lap = [&](const char* what) { if (timing) { const double t = wall_seconds(); std::printf("    [chain schedule] %-28s %.3f s\n", what, t - tl); tl = t; } };
+    // ---- how far back the lower entries reach, in blocks: the size of tier 1
+    std::vector<long long> hist(66, 0);
+    int alone_rows = 0;
+#pragma omp parallel
+    {
+        std::vector<long long> hl(66, 0);
+        int al = 0;
+#pragma omp for schedule(static) nowait
+        for (int q = 0; q < ns; ++q) {
+            const int i = seq[q], K = q >> 6;
+            double dg = 0.0;
+            for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                const int j = A.ja[k];
+                if (j == i) { dg = A.val[k]; continue; }
+                if (j >= n) continue;
+                const int pj = pos[j];
+                if ((unsigned)pj < (unsigned)q) hl[(size_t)std::min(65, K - (pj >> 6))]++;
+            }
+            if (!(std::fabs(dg) > SMALLREAL)) ++al;
+        }
+#pragma omp critical
+        { for (int d = 0; d < 66; ++d) hist[(size_t)d] += hl[(size_t)d]; alone_rows += al; }
+    }
+    if (alone_rows) return 1;   // (rows the reference leaves alone: the dataflow form handles them)
+    int n1b = n1_blocks;
+    if (n1b <= 0) {
+        // tier 1 is bound by what ONE compute unit streams (10 bytes per entry at some tens of GB/s against a block of 64 rows per
+        // 1.3 us): the widest window of 4 .. 32 blocks whose entries stay below ~64 per row
+        n1b = 4;
+        long long acc = 0;
+        for (int d = 2; d <= 33; ++d) {
+            acc += hist[(size_t)d];
+            if (d - 1 >= 4 && acc <= 64ll * ns) n1b = d - 1;
+        }
+    }
+    n1b = std::max(1, std::min(48, n1b));
+    ChainHost& C = H.C;
+    C.nb = nb; C.npad = npad; C.n1b = n1b;
+    C.rx = 64 * (n1b + CHAIN_HA + 3);
+    C.rg = 64 * (CHAIN_HA + 2);
+    // ---- per block: steps of the two tiers (longest row of the block), rest offsets by position
+    C.blk.alloc((size_t)nb);
+    Buf<int> nrest((size_t)npad);
+    auto tier_of = [&](int K, int pj) { const int db = K - (pj >> 6); return db <= 1 ? 0 : db <= n1b + 1 ? 1 : 2; };
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int K = 0; K < nb; ++K) {
+        int m1 = 0, m2 = 0;
+        for (int jl = 0; jl < 64; ++jl) {
+            const int q = K * 64 + jl;
+            if (q >= ns) { nrest[(size_t)q] = 0; continue; }
+            const int i = seq[q];
+            int c1 = 0, c2 = 0, cr = 0;
+            for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                const int j = A.ja[k];
+                if (j == i) continue;
+                const int pj = j < n ? pos[j] : -1;
+                if ((unsigned)pj < (unsigned)q) { const int t = tier_of(K, pj); c1 += t == 1; c2 += t == 2; }
+                else ++cr;
+            }
+            nrest[(size_t)q] = cr;
+            m1 = std::max(m1, c1); m2 = std::max(m2, c2);
+        }
+        // (steps come in groups of eight: the kernels fetch whole groups)
+        C.blk[(size_t)K].t1_n = (m1 + 7) & ~7; C.blk[(size_t)K].t2_n = (m2 + 7) & ~7;
+    }
+    long long o1 = 0, o2 = 0;
+    for (int K = 0; K < nb; ++K) {
+        C.blk[(size_t)K].t1_off = (int)o1; C.blk[(size_t)K].t2_off = (int)o2;
+        o1 += C.blk[(size_t)K].t1_n; o2 += C.blk[(size_t)K].t2_n;
+        if (o1 > 0x1ffffffll || o2 > 0x1ffffffll) return 1;
+    }
+    C.t1_steps = o1; C.t2_steps = o2;
+    H.ria.alloc((size_t)npad + 1);
+    H.ria[0] = 0;
+    long long nr = 0;
+    for (int q = 0; q < npad; ++q) { nr += nrest[(size_t)q]; if (nr > 0x7fffffffll) return ERROR_INPUT_PAR; H.ria[(size_t)q + 1] = (int)nr; }
+    lap("tiers and offsets");
+    // ---- fill
+    const size_t band_steps = (size_t)nb * 64 + CHAIN_PF;
+    C.band.alloc(band_steps * 128);
+    C.drd.alloc(2 * (size_t)npad);
+    C.t1v.alloc(std::max<size_t>((size_t)o1 * 64, 1)); C.t1c.alloc(std::max<size_t>((size_t)o1 * 64, 1));
+    C.t2v.alloc(std::max<size_t>((size_t)o2 * 64, 1)); C.t2c.alloc(std::max<size_t>((size_t)o2 * 64, 1));
+    H.rja.alloc((size_t)std::max<long long>(nr, 1)); H.rval.alloc((size_t)std::max<long long>(nr, 1));
+    H.tr.alloc(2 * (size_t)npad);
+    H.dr.alloc(2);   // (the split form's per-position pairs: here C.drd)
+    long long nband = 0, nt1 = 0, nt2 = 0;
+#pragma omp parallel reduction(+ : nband, nt1, nt2)
+    {
+        std::vector<std::pair<int, double>> e1, e2;
+#pragma omp for schedule(dynamic, 4)
+        for (int K = 0; K < nb + 1; ++K) {
+            if (K == nb) { std::memset(C.band.data() + (size_t)nb * 64 * 128, 0, sizeof(double) * CHAIN_PF * 128); continue; }
+            double* bd = C.band.data() + (size_t)K * 64 * 128;   // [step c][lane j]{TA, TB}: TA = l(64 K + j, 64 K + c), TB = l(64 (K + 1) + j, 64 K + c)
+            // TA of this block and TB of the PREVIOUS block's plane are written by the rows of this block: zero first (each plane half once)
+            for (int c = 0; c < 64; ++c) for (int j = 0; j < 64; ++j) bd[((size_t)c * 64 + j) * 2] = 0.0;
+            if (K > 0) { double* bp = bd - 64 * 128; for (int c = 0; c < 64; ++c) for (int j = 0; j < 64; ++j) bp[((size_t)c * 64 + j) * 2 + 1] = 0.0; }
+            if (K == nb - 1) for (int c = 0; c < 64; ++c) for (int j = 0; j < 64; ++j) bd[((size_t)c * 64 + j) * 2 + 1] = 0.0;   // (no block behind the last)
+            const ChainBlk B = C.blk[(size_t)K];
+            double* v1 = C.t1v.data() + (size_t)B.t1_off * 64; unsigned short* c1 = C.t1c.data() + (size_t)B.t1_off * 64;
+            double* v2 = C.t2v.data() + (size_t)B.t2_off * 64; unsigned short* c2 = C.t2c.data() + (size_t)B.t2_off * 64;
+            for (size_t t = 0; t < (size_t)B.t1_n * 64; ++t) { v1[t] = 0.0; c1[t] = (unsigned short)C.rx; }
+            for (size_t t = 0; t < (size_t)B.t2_n * 64; ++t) { v2[t] = 0.0; c2[t] = (unsigned short)npad; }
+            for (int jl = 0; jl < 64; ++jl) {
+                const int q = K * 64 + jl;
+                if (q >= ns) {   // padding row: x = 0 / 1, no row of u
+                    C.drd[2 * (size_t)q] = 1.0; C.drd[2 * (size_t)q + 1] = 1.0;
+                    H.tr[2 * (size_t)q] = 0; H.tr[2 * (size_t)q + 1] = -1;
+                    continue;
+                }
+                const int i = seq[q];
+                e1.clear(); e2.clear();
+                double dg = 0.0;
+                size_t kr = (size_t)H.ria[q];
+                for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
+                    const int j = A.ja[k];
+                    if (j == i) { dg = A.val[k]; continue; }   // the last diagonal hit, as the reference's loop leaves it
+                    const int pj = j < n ? pos[j] : -1;
+                    if ((unsigned)pj < (unsigned)q) {
+                        const int t = tier_of(K, pj);
+                        if (t == 0) {
+                            // (a column that occurs twice in a row -- no setup of this library produces one -- is merged: one coefficient per (row, column))
+                            const int c = pj & 63;
+                            double* slot = (pj >> 6) == K ? &bd[((size_t)c * 64 + jl) * 2] : &(bd - 64 * 128)[((size_t)c * 64 + jl) * 2 + 1];
+                            *slot += A.val[k];
+                            ++nband;
+                        } else if (t == 1) e1.emplace_back(pj, A.val[k]);
+                        else e2.emplace_back(pj, A.val[k]);
+                    } else { H.rja[kr] = j; H.rval[kr] = A.val[k]; ++kr; }
+                }
+                auto by_pos = [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; };
+                std::stable_sort(e1.begin(), e1.end(), by_pos); std::stable_sort(e2.begin(), e2.end(), by_pos);
+                nt1 += (long long)e1.size(); nt2 += (long long)e2.size();
+                // right-aligned: the newest columns are the last steps of the block
+                for (size_t t = 0; t < e1.size(); ++t) { const size_t st = (size_t)B.t1_n - e1.size() + t; v1[st * 64 + jl] = e1[t].second; c1[st * 64 + jl] = (unsigned short)(e1[t].first % C.rx); }
+                for (size_t t = 0; t < e2.size(); ++t) { const size_t st = (size_t)B.t2_n - e2.size() + t; v2[st * 64 + jl] = e2[t].second; c2[st * 64 + jl] = (unsigned short)e2[t].first; }
+                C.drd[2 * (size_t)q] = dg; C.drd[2 * (size_t)q + 1] = 1.0 / dg;
+                H.tr[2 * (size_t)q] = 0; H.tr[2 * (size_t)q + 1] = i;
+            }
+        }
+    }
+    C.nband = nband; C.nt1 = nt1; C.nt2 = nt2;
+    lap("fill");
+    H.chain = true;
+    H.ns = npad; H.nrows = ns; H.nvirt = 0; H.L = 64; H.nolower = false; H.pfs = 8; H.kt = 0; H.nstrips = 0; H.nchunk = 0; H.maxent = C.rx + C.rg;
+    H.nghost = 0; H.slot_bytes = 0; H.nrest = nr; H.flow_ok = true; H.par = 1;
+    H.cptr.assign(2, 0);
+    H.chunks.alloc(4); H.cstrip.alloc(1); H.lchunks.alloc(1); H.gpos.alloc(1); H.slots.alloc(16);
+    const double avg_rest = ns > 0 ? (double)nr / ns : 0.0;
+    H.LR = 1;
+    while (H.LR < 64 && 4 * H.LR < avg_rest) H.LR *= 2;
+    return FASP_SUCCESS;
+}
+
+int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team, int spine, int chain, int chain_n1)
 {
     HostThreads host_team;   // (bounded OpenMP team for the row-parallel loops below; the dependency pass itself is sequential)
     if (team > 0) omp_set_num_threads(std::min(team, omp_get_max_threads()));   // (bounded OpenMP team for the row-parallel loops below; the dependency pass itself is sequential)
@@ -115,6 +282,15 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
         H.LR = 1;
         while (H.LR < 64 && 4 * H.LR < avg) H.LR *= 2;
         return FASP_SUCCESS;
+    }
+    // ---- chain-bound sweeps (classes of a few rows: the deep levels) take the chain form where it applies (seq_sched.h): one
+    // wavefront walks the rows in sweep order at ~20 ns per row, whatever the dependency graph looks like -- against 0.4-0.8 us per
+    // dependency CLASS in the dataflow form below
+    H.nclasses = nlev;
+    if (chain == 2 || (chain == 1 && ns >= 256 && (long long)ns < 20ll * nlev)) {
+        const int st = build_chain_host(A, seq, ns, pos, chain_n1, timing, H);
+        if (st == FASP_SUCCESS) { H.nclasses = nlev; return FASP_SUCCESS; }
+        if (st < 0) return st;
     }
     // lanes per row of the triangular part: TRI_PF * L slots cover the lower entries of 90 % of the rows
     int len90 = 0;
@@ -501,5 +677,103 @@ extern "C" double fasp_hip_seq_schedule_selftest(const dCSRmat* Av, const int* s
     }
     double diff = 0.0, big = 0.0;
     for (int i = 0; i < n; ++i) { diff = std::max(diff, std::fabs(u[(size_t)i] - uref[(size_t)i])); big = std::max(big, std::fabs(uref[(size_t)i])); }
+    return big > 0.0 ? diff / big : diff;
+}
+
+// Host-side check of a CHAIN schedule (tests/test_seq_schedule.py, no GPU): build it (chain form wherever it applies), then walk it
+// the way k_tri_chain_ref does -- block after block, tier 2 and tier 1 as chains of fused multiply-adds in step order, the band's
+// 64 steps with two accumulators -- for one sweep with update formula `form` (0: t * (1 / a_ii), 1: t / a_ii, 2: SOR with w), and
+// compare with the plain sequential sweep over the same rows.  Returns the largest difference relative to the largest entry
+// (< 0: error; -2: the form does not apply).  Also checks what the kernels rely on: tier-1 columns lie in the n1b blocks in front
+// of the band (and their ring indices are unambiguous), tier-2 columns in front of those, padding entries point at the constants,
+// the band planes hold zeros where the kernels expect no-ops.  out_u (optional, length max(row, col)): the swept vector.
+extern "C" double fasp_hip_seq_chain_selftest(const dCSRmat* Av, const int* seq, int ns, int n1_blocks, int form, double w, int* info, double* out_u)
+{
+    using namespace fasp;
+    if (!Av || !seq || ns < 0) return -1.0;
+    HostCSR A;
+    A.row = Av->row; A.col = Av->col; A.nnz = Av->nnz;
+    A.ia.view(Av->IA, (size_t)Av->row + 1); A.ja.view(Av->JA, (size_t)std::max(Av->nnz, 1)); A.val.view(Av->val, (size_t)std::max(Av->nnz, 1));
+    SplitHost H;
+    const int st = build_split_host(A, seq, ns, 512, 0, false, H, 0, 1, 2, n1_blocks);
+    if (st != FASP_SUCCESS) return st == 1 ? -2.0 : -3.0;
+    if (!H.chain) return -2.0;
+    const ChainHost& C = H.C;
+    if (info) { info[0] = C.nb; info[1] = C.n1b; info[2] = C.rx; info[3] = C.rg; info[4] = (int)C.t1_steps; info[5] = (int)C.t2_steps; info[6] = (int)C.nband; info[7] = (int)C.nt1; info[8] = (int)C.nt2; info[9] = H.nclasses; }
+    const int n = std::max(A.row, A.col), nb = C.nb, npad = C.npad;
+    std::vector<double> u((size_t)n), b((size_t)n), uref;
+    for (int i = 0; i < n; ++i) { u[(size_t)i] = std::sin(0.37 * i) + 0.1; b[(size_t)i] = std::cos(0.11 * i); }
+    uref = u;
+    for (int q = 0; q < ns; ++q) {   // the reference's sweep
+        const int i = seq[q];
+        double t = b[(size_t)i], d = 0.0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) { if (A.ja[k] == i) d = A.val[k]; else t -= A.val[k] * uref[(size_t)A.ja[k]]; }
+        if (std::fabs(d) > SMALLREAL) uref[(size_t)i] = form == 0 ? t * (1.0 / d) : form == 1 ? t / d : w * (t / d) + (1 - w) * uref[(size_t)i];
+    }
+    if (H.nrows != ns || H.ns != npad || npad != nb * 64) return -6.0;
+    std::vector<double> W((size_t)npad + 1, 0.0), T((size_t)npad, 0.0), uo((size_t)npad, 0.0);
+    for (int p = 0; p < npad; ++p) {   // pass (1)
+        const int row = H.tr[2 * (size_t)p + 1];
+        if (p >= ns) { if (row != -1 || H.ria[p] != H.ria[p + 1]) return -6.0; continue; }
+        if (row != seq[p]) return -6.0;
+        double s = 0.0;
+        for (int k = H.ria[p]; k < H.ria[p + 1]; ++k) s += H.rval[k] * u[(size_t)H.rja[k]];
+        T[(size_t)p] = b[(size_t)row] - s; uo[(size_t)p] = u[(size_t)row];
+    }
+    auto update = [&](double t, double d, double rd, double ku) {
+        auto tdiv = [&]() { const double q = t * rd; const double r = std::fma(-d, q, t); return std::fma(r, rd, q); };
+        return form == 0 ? t * rd : form == 1 ? tdiv() : w * tdiv() + ku;
+    };
+    std::vector<double> accB(64, 0.0), accA(64), x(64);
+    for (int K = 0; K < nb; ++K) {
+        const ChainBlk B = C.blk[(size_t)K];
+        if ((B.t1_n & 7) || (B.t2_n & 7)) return -7.0;
+        for (int j = 0; j < 64; ++j) {
+            const int p = K * 64 + j;
+            double g2 = T[(size_t)p];
+            for (int s = 0; s < B.t2_n; ++s) {
+                const size_t e = ((size_t)B.t2_off + s) * 64 + j;
+                const int qp = C.t2c[e];
+                if (qp == npad) { if (C.t2v[e] != 0.0) return -7.0; }
+                else if (qp >= (K - 1 - C.n1b) * 64) return -7.0;   // tier 2 lies in front of tier 1's window
+                g2 = std::fma(-C.t2v[e], W[(size_t)qp], g2);
+            }
+            double s1 = 0.0;
+            const int base = std::max(0, (K - 1 - C.n1b) * 64);
+            for (int s = 0; s < B.t1_n; ++s) {
+                const size_t e = ((size_t)B.t1_off + s) * 64 + j;
+                const int r = C.t1c[e];
+                int qp;
+                if (r >= C.rx) { if (r != C.rx || C.t1v[e] != 0.0) return -7.0; qp = npad; }
+                else { qp = base + ((r - base % C.rx) + C.rx) % C.rx; if (qp >= (K - 1) * 64 || qp < base) return -7.0; }
+                s1 = std::fma(-C.t1v[e], W[(size_t)qp], s1);
+            }
+            accA[(size_t)j] = (g2 + s1) + accB[(size_t)j];
+            accB[(size_t)j] = 0.0;
+        }
+        const double* bd = C.band.data() + (size_t)K * 64 * 128;
+        for (int c = 0; c < 64; ++c) {
+            const int pc = K * 64 + c;
+            const double ku = form == 2 ? (1 - w) * uo[(size_t)pc] : 0.0;
+            const double xc = update(accA[(size_t)c], C.drd[2 * (size_t)pc], C.drd[2 * (size_t)pc + 1], ku);
+            x[(size_t)c] = xc;
+            for (int j = 0; j < 64; ++j) {
+                const double ta = bd[((size_t)c * 64 + j) * 2], tb = bd[((size_t)c * 64 + j) * 2 + 1];
+                if (j <= c && ta != 0.0) return -8.0;                        // accA_j keeps t_j once it is final
+                if ((K == nb - 1 || (K + 1) * 64 + j >= ns) && tb != 0.0) return -8.0;
+                if (j > c) accA[(size_t)j] = std::fma(-ta, xc, accA[(size_t)j]);
+                accB[(size_t)j] = std::fma(-tb, xc, accB[(size_t)j]);
+            }
+        }
+        for (int c = 0; c < 64; ++c) {
+            const int pc = K * 64 + c;
+            W[(size_t)pc] = x[(size_t)c];
+            if (H.tr[2 * (size_t)pc + 1] >= 0) u[(size_t)H.tr[2 * (size_t)pc + 1]] = x[(size_t)c];
+        }
+    }
+    for (size_t t = (size_t)nb * 64 * 128; t < C.band.n; ++t) if (C.band[t] != 0.0) return -8.0;   // the steps the chain wave fetches behind the last block
+    double diff = 0.0, big = 0.0;
+    for (int i = 0; i < n; ++i) { diff = std::max(diff, std::fabs(u[(size_t)i] - uref[(size_t)i])); big = std::max(big, std::fabs(uref[(size_t)i])); }
+    if (out_u) for (int i = 0; i < n; ++i) out_u[i] = u[(size_t)i];
     return big > 0.0 ? diff / big : diff;
 }

@@ -29,7 +29,36 @@ constexpr int TRI_SPINE = 2;
 // row sits in the class between its newest entry's and its row's (classes are doubled: rows even, virtual rows odd).
 constexpr int FLOW_VIRTUAL = 0x40000000;       // flag in tr[2 p]: position p is a virtual row (tr[2 p + 1] = -1: no row of u)
 
+// ---------------------------------------------------------------------------
+// CHAIN form (round 5, seq_chain.hip.h): the triangular solve of a chain-bound sweep -- dependency classes of a few rows, rows of
+// hundreds of lower entries: the deep levels -- as a BLOCKED substitution that keeps the dependency chain inside ONE wavefront.
+// Positions = sweep order, padded to blocks of 64 (lane j of the chain wave <-> row 64 K + j).  The lower entries of a row of
+// block K fall into three tiers by the block of their column:
+//   band    blocks K (the 64 x 64 triangle) and K - 1 (the full square): dense coefficient planes, one (TA, TB) pair per lane and
+//           step; the chain wave broadcasts x_c from lane c (v_readlane) and every lane does two multiply-adds -- no poll, no LDS
+//           round trip on the critical path;
+//   tier 1  blocks K - 1 - n1b .. K - 2: summed by helper waves of the chain's workgroup, x through a ring in LDS;
+//   tier 2  everything older: summed by the other workgroups of the launch, x through memory (W), results through memory (G2).
+// Both tiers are one lane per row, entries in column order, right-aligned in padded steps of 64 lanes (ELL per block).
+// Row arithmetic (every tier a chain of fused multiply-adds in column order): G2 = T - sum(tier 2), S1 = -sum(tier 1) from +0.0,
+// SB = -sum(block K - 1) from +0.0, t = ((G2 + S1) + SB) - sum(block K); then the update of tri_update.
+// ---------------------------------------------------------------------------
+constexpr int CHAIN_HA = 12;          // blocks the tier-1 helpers may run ahead of the chain
+constexpr int CHAIN_PF = 32;          // steps of band coefficients the chain wave keeps in flight (and zero steps behind the last block)
+struct ChainBlk { int t1_off, t1_n, t2_off, t2_n; };   // offsets / counts in steps of 64 lanes
+struct ChainHost {
+    int nb = 0, npad = 0, n1b = 0, rx = 0, rg = 0;
+    long long t1_steps = 0, t2_steps = 0, nband = 0, nt1 = 0, nt2 = 0;   // (entry counts: statistics)
+    Buf<double>         band;   // (nb * 64 + CHAIN_PF) steps x 64 lanes x (TA, TB)
+    Buf<double>         drd;    // npad x (a_ii, RN(1 / a_ii)); padding rows (1, 1)
+    Buf<ChainBlk>       blk;
+    Buf<double>         t1v, t2v;
+    Buf<unsigned short> t1c, t2c;   // tier 1: ring index of the column's position (padding: rx); tier 2: the position (padding: npad)
+};
+
 struct SplitHost {
+    bool chain = false;   // the chain form below instead of strips / chunks / slots (ria, rja, rval, tr of the rest pass are shared)
+    ChainHost C;
     int ns = 0, nrows = 0, nvirt = 0, nclasses = 0, L = 1, LR = 1, pfs = 4, kt = 0, nstrips = 0, nchunk = 0, maxent = 0, par = 1;   // ns: POSITIONS = rows of the sweep + virtual rows;   // kt: spine rounds (below); par: strips that share a dependency class at most (chain-bound levels; else nstrips)
     bool nolower = false, flow_ok = true;
     long long nghost = 0, slot_bytes = 0, nrest = 0;
@@ -44,6 +73,9 @@ struct SplitHost {
 // falls back to whole-row level scheduling), or a negative error code.
 // team > 0: OpenMP team of this call (several schedules are built side by side, one host thread each: smoothers.hip.h)
 // spine: 1 where it pays (above), 0 never, 2 wherever a row has two lanes or more (tests)
-int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team = 0, int spine = 1);
+// chain: 0 never the chain form, 1 where the sweep is chain-bound (few rows per dependency class) and the form applies, 2 wherever it applies;
+// chain_n1: blocks of tier 1 (0: chosen from the entries' distances)
+int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team = 0, int spine = 1,
+                     int chain = 0, int chain_n1 = 0);
 
 }  // namespace fasp

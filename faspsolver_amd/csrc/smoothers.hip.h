@@ -126,7 +126,7 @@ static int build_split(const HostCSR& A, const std::vector<int>& seq, DevLevel::
 {
     const bool timing = std::getenv("FASP_HIP_SETUP_TIMING") != nullptr;
     SplitHost H;
-    const int st = build_split_host(A, seq.data(), (int)seq.size(), g_tune.seq_strip_kb, g_tune.seq_lanes, timing, H, 0, g_tune.seq_spine);   // (seq_sched.cpp)
+    const int st = build_split_host(A, seq.data(), (int)seq.size(), g_tune.seq_strip_kb, g_tune.seq_lanes, timing, H, 0, g_tune.seq_spine, g_tune.seq_chain, g_tune.seq_chain_n1);   // (seq_sched.cpp)
     if (st != FASP_SUCCESS) { S.flow_ok = false; return st; }
     return upload_split(H, S);
 }
@@ -148,20 +148,48 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
     };
     FlowStrip* d_strips = nullptr; int* d_chunks = nullptr;
     static const unsigned zeros[64] = {};
-    piece(&d_strips, H.strips.data(), H.strips.size());
-    piece(&d_chunks, H.chunks.data(), 4 * (size_t)H.nchunk);
-    piece(&S.d_slots, H.slots.data(), (size_t)H.slot_bytes);
-    piece(&S.d_gpos, H.gpos.data(), (size_t)H.nghost);
-    piece(&S.d_cstrip, H.cstrip.data(), (size_t)H.nchunk);
-    piece(&S.d_lchunks, H.lchunks.data(), (size_t)H.nchunk);
-    piece(&S.d_ria, H.ria.data(), (size_t)ns + 1);
-    piece(&S.d_rja, H.rja.data(), (size_t)H.nrest);
-    piece(&S.d_rval, H.rval.data(), (size_t)H.nrest);
-    piece(&S.d_dr, H.dr.data(), 2 * (size_t)ns);
-    piece(&S.d_tr, H.tr.data(), 2 * (size_t)ns);
-    piece(&S.d_rec, (const double*)nullptr, 2 * (size_t)ns, false);
-    piece(&S.d_W, (const double*)nullptr, (size_t)ns, false);
-    piece(&S.d_prog, zeros, 64);   // [0] ticket counter, [1] error word
+    if (H.chain) {
+        // the chain form (seq_chain.hip.h): the rest pass's CSR and records as in the split form, positions padded to blocks of 64
+        const ChainHost& Cc = H.C;
+        piece(&S.d_ria, H.ria.data(), (size_t)ns + 1);
+        piece(&S.d_rja, H.rja.data(), (size_t)H.nrest);
+        piece(&S.d_rval, H.rval.data(), (size_t)H.nrest);
+        piece(&S.d_tr, H.tr.data(), 2 * (size_t)ns);
+        piece(&S.d_rec, (const double*)nullptr, 2 * (size_t)ns, false);
+        piece(&S.d_W, (const double*)nullptr, (size_t)ns + 64, false);      // W[npad] = 0.0: the operand of tier 2's padding entries
+        piece(&S.d_G2, (const double*)nullptr, (size_t)ns, false);
+        piece(&S.d_prog, zeros, 64);   // [0] role ticket, [1] error word, [2] tier-2 ticket
+        piece(&S.d_band, Cc.band.data(), Cc.band.n);
+        piece(&S.d_drd, Cc.drd.data(), Cc.drd.n);
+        ChainBlk* d_blk = nullptr;
+        piece(&d_blk, Cc.blk.data(), Cc.blk.n);
+        piece(&S.d_t1v, Cc.t1v.data(), (size_t)Cc.t1_steps * 64);
+        piece(&S.d_t1c, Cc.t1c.data(), (size_t)Cc.t1_steps * 64);
+        piece(&S.d_t2v, Cc.t2v.data(), (size_t)Cc.t2_steps * 64);
+        piece(&S.d_t2c, Cc.t2c.data(), (size_t)Cc.t2_steps * 64);
+        size_t total = 0;
+        for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
+        char* base = nullptr;
+        HIPCK(hipMalloc((void**)&base, total));
+        S.owned.push_back(base);
+        size_t off = 0;
+        for (const Piece& q : pieces) {
+            *q.dst = base + off;
+            if (q.copy) HIPCK(hipMemcpyAsync(base + off, q.src, q.copy, hipMemcpyHostToDevice, stream));
+            else HIPCK(hipMemsetAsync(base + off, 0, q.bytes, stream));
+            off += (q.bytes + 255) & ~(size_t)255;
+        }
+        HIPCK(hipStreamSynchronize(stream));
+        S.d_blk = d_blk;
+        if (timing) std::printf("    [chain schedule] %-28s %.3f s\n", "upload", wall_seconds() - t0);
+        S.chain = true; S.nb = Cc.nb; S.npad = Cc.npad; S.n1b = Cc.n1b; S.rx = Cc.rx; S.rg = Cc.rg; S.t1_steps = Cc.t1_steps; S.t2_steps = Cc.t2_steps;
+        S.nband = Cc.nband; S.nt1 = Cc.nt1; S.nt2 = Cc.nt2;
+        S.ns = ns; S.L = 64; S.LR = H.LR; S.nolower = false; S.nvirt = 0; S.nrows = H.nrows; S.nclasses = H.nclasses; S.pfmax = 8; S.kt = 0; S.par = 1; S.nstrips = 0; S.nchunk = 0; S.maxent = H.maxent;
+        S.nghost = 0; S.slot_bytes = 0; S.flow_ok = true;
+        S.built = true;
+        S.multicolor = false;
+        return FASP_SUCCESS;
+    }
     size_t total = 0;
     for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
     char* base = nullptr;
@@ -220,16 +248,16 @@ static bool sched_kinds(const fasp_hip_amg* h, int l, int& k0, int& k1)
 }
 static void sched_job_launch(fasp_hip_amg* h, int level, int kind, int team)
 {
-    const int strip_kb = g_tune.seq_strip_kb, lanes = g_tune.seq_lanes, spine = g_tune.seq_spine;
+    const int strip_kb = g_tune.seq_strip_kb, lanes = g_tune.seq_lanes, spine = g_tune.seq_spine, chain = g_tune.seq_chain, chain_n1 = g_tune.seq_chain_n1;
     h->sched_jobs.emplace_back(new SchedJob);
     SchedJob* J = h->sched_jobs.back().get();
     J->level = level; J->kind = kind;
     const HostLevel* HL = &h->H.L[(size_t)level];
     const int dev = g_ctx.device;
-    J->th = std::thread([J, HL, team, strip_kb, lanes, spine, dev]() {
+    J->th = std::thread([J, HL, team, strip_kb, lanes, spine, chain, chain_n1, dev]() {
         std::vector<int> seq;
         sweep_sequence(*HL, J->kind, seq);
-        J->st = build_split_host(HL->A, seq.data(), (int)seq.size(), strip_kb, lanes, false, J->H, team, spine);
+        J->st = build_split_host(HL->A, seq.data(), (int)seq.size(), strip_kb, lanes, false, J->H, team, spine, chain, chain_n1);
         // the schedule goes to the device from here, over a stream of its own: the first sweep finds it there
         hipStream_t st = nullptr;
         if (J->st == FASP_SUCCESS && hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
@@ -335,7 +363,9 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
             S.rowlevels = true;
         }
         if (std::getenv("FASP_HIP_SETUP_TIMING")) {
-            if (multicolor || S.rowlevels) std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind, multicolor ? "colours" : "whole-row dependency levels", (int)(seq.empty() ? S.ns : (int)seq.size()), (int)S.ptr.size() - 1);
+            if (S.chain) std::printf("  [sweep schedule] level %d, sweep kind %d: CHAIN form, %d rows in %d dependency classes, %d blocks of 64, band %lld entries, tier 1 (%d blocks, ring of %d) %lld entries in %lld steps, "
+                                     "tier 2 %lld entries in %lld steps, rest pass %d lanes per row, built in %.3f s\n", level, kind, S.nrows, S.nclasses, S.nb, S.nband, S.n1b, S.rx, S.nt1, S.t1_steps, S.nt2, S.t2_steps, S.LR, wall_seconds() - t0);
+            else if (multicolor || S.rowlevels) std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind, multicolor ? "colours" : "whole-row dependency levels", (int)(seq.empty() ? S.ns : (int)seq.size()), (int)S.ptr.size() - 1);
             else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes, %d strips (%lld ghosts, at most %d values in LDS), %d chunks, %d lanes per row, "
                              "%d rounds (%d of them spine), %.1f slot bytes per row (%d virtual rows), rest pass %d lanes per row%s, built in %.3f s\n",
                              level, kind, S.nrows, S.nclasses, S.nstrips, S.nghost, S.maxent + 1, S.nchunk, S.L, S.pfmax, S.kt, S.nrows ? (double)S.slot_bytes / S.nrows : 0.0, S.nvirt, S.LR,
@@ -367,7 +397,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         }
         return FASP_SUCCESS;
     }
-    const int ns = S.ns;
+    const int ns = S.chain ? S.nrows : S.ns;   // (chain form: S.ns = positions padded to blocks of 64; the rest pass runs over the rows)
     if (ns == 0) return FASP_SUCCESS;
     FlowArgs fa{};
     fa.strips = (const FlowStrip*)S.d_strips; fa.chunks = (const int4*)S.d_chunks; fa.slots = S.d_slots; fa.gpos = S.d_gpos; fa.cstrip = S.d_cstrip;
@@ -378,7 +408,8 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         const int rpb = BLOCK / S.LR;
         const int grid = std::max(1, std::min(MAXGRID, (ns + rpb - 1) / rpb));
 #define REST_LAUNCH(LL) hipLaunchKernelGGL((k_split_rest<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, ns, (const int*)S.d_tr, \
-        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)D.b, (const double*)D.x, S.d_rec, S.d_W, S.d_prog)
+        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)D.b, (const double*)D.x, S.d_rec, S.d_W, S.d_prog, \
+        S.chain ? S.d_G2 : (double*)nullptr, S.chain ? S.npad : 0)
         switch (S.LR) {
             case 1: REST_LAUNCH(1); break;
             case 2: REST_LAUNCH(2); break;
@@ -389,6 +420,29 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
             default: REST_LAUNCH(64); break;
         }
 #undef REST_LAUNCH
+    }
+    if (S.chain) {
+        // pass (2), the chain form (seq_chain.hip.h): one workgroup walks the rows, the others sum what lies far behind it
+        ChainArgs ca{};
+        ca.band = (const f64x2_t*)S.d_band; ca.drd = (const f64x2_t*)S.d_drd; ca.blk = (const ChainBlk*)S.d_blk;
+        ca.t1v = S.d_t1v; ca.t1c = S.d_t1c; ca.t2v = S.d_t2v; ca.t2c = S.d_t2c; ca.rec = S.d_rec; ca.tr = S.d_tr;
+        ca.W = S.d_W; ca.G2 = S.d_G2; ca.u = D.x; ca.sync = S.d_prog; ca.nb = S.nb; ca.npad = S.npad; ca.rx = S.rx; ca.rg = S.rg; ca.form = form; ca.w = w;
+        const bool plain = g_tune.seq_chain_ref || !g_tune.seq_flow || g_flow_disabled;
+        if (!plain && seq_err_check() < 0) return ERROR_MISC;   // an earlier sweep's time-out that has arrived meanwhile
+        const size_t dyn = sizeof(double) * ((size_t)S.rx + 1 + (size_t)S.rg);
+        // tier-2 workgroups: enough wavefronts for a block per ~1.3 us at some tens of us per block and wave; the rest of the chip stays free
+        const int far_wg = S.t2_steps > 0 ? (g_tune.seq_chain_grid > 0 ? g_tune.seq_chain_grid : 15) : 0;
+#define CHAIN_LAUNCH(FF)                                                                                              \
+        if (plain) hipLaunchKernelGGL((k_tri_chain_ref<FF>), dim3(1), dim3(64), 0, g_ctx.stream, ca, S.n1b);             \
+        else hipLaunchKernelGGL((k_tri_chain<FF>), dim3(1 + far_wg), dim3(CHAIN_NT), dyn, g_ctx.stream, ca)
+        switch (form) {
+            case 0: CHAIN_LAUNCH(0); break;
+            case 1: CHAIN_LAUNCH(1); break;
+            default: CHAIN_LAUNCH(2); break;
+        }
+#undef CHAIN_LAUNCH
+        if (!plain) seq_err_watch(S.d_prog + 1);
+        return FASP_SUCCESS;
     }
     const int sgrid = std::max(1, std::min(MAXGRID, (ns + BLOCK - 1) / BLOCK));
     if (S.nolower) {   // no row of the sweep reads another one's new value (the C rows / F rows of the 7-point level 0)

@@ -43,6 +43,7 @@
 #include "kernels2.hip.h"
 #include "small_solvers.hip.h"
 #include "seq_split.hip.h"
+#include "seq_chain.hip.h"
 
 namespace fasp {
 
@@ -2154,6 +2155,10 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_jobs")) g_tune.seq_jobs = value;
     else if (!std::strcmp(key, "local_square")) g_tune.local_square = value;   // a rank's rows of a partitioned level are coded like a square operator (read at upload)
     else if (!std::strcmp(key, "seq_grid")) g_tune.seq_grid = value;     // workgroups of the dataflow solve at most (0: twice the strips the chain front is in at a time + 2, seq_sched.cpp; < 0: as many as are resident)
+    else if (!std::strcmp(key, "seq_chain")) g_tune.seq_chain = value;   // chain form of the triangular solve (seq_chain.hip.h): 0 never, 1 on chain-bound sweeps, 2 wherever it applies; read when a schedule is built
+    else if (!std::strcmp(key, "seq_chain_n1")) g_tune.seq_chain_n1 = value;       // blocks of 64 rows in tier 1 (0: chosen from the entries' distances)
+    else if (!std::strcmp(key, "seq_chain_grid")) g_tune.seq_chain_grid = value;   // tier-2 workgroups of the chain launch (0: default)
+    else if (!std::strcmp(key, "seq_chain_ref")) g_tune.seq_chain_ref = value;     // 1: the plain one-wavefront form (k_tri_chain_ref: A/B, fallback)
     else if (!std::strcmp(key, "seq_spine")) g_tune.seq_spine = value;   // 0 never, 1 where the schedule chooses it, 2 wherever a row has two lanes (seq_sched.h); read when a schedule is built
     else if (!std::strcmp(key, "seq_partition")) g_seq_partition = value;
     else if (!std::strcmp(key, "fuse_zr")) g_tune.fuse_zr = value;

@@ -24,6 +24,13 @@ double fasp_hip_time_matrix(const dCSRmat* A, int op, int reps, int* kind_out);
  * (-2: a row reads more earlier rows than a strip holds: no split form).  spine: -1 / 1 where the schedule chooses it, 0 never, 2 wherever
  * a row has two lanes; info (may be NULL): {lanes per row, rounds, spine rounds, virtual rows, strips, chunks} of the schedule */
 double fasp_hip_seq_schedule_selftest(const dCSRmat* A, const int* seq, int ns, int strip_kb, int lanes, int spine, int* info);
+/* test entry (host only, no GPU): the CHAIN form of the same sweep (csrc/seq_chain.hip.h, round 5: blocked substitution, the dependency
+ * chain inside one wavefront) built wherever it applies and walked on the host as k_tri_chain_ref does, with the update formula `form`
+ * (0: t * (1 / a_ii) -- fasp_smoother_dcsr_gs; 1: t / a_ii -- the C/F-ordered sweep; 2: SOR with weight w), against the plain sequential
+ * sweep; < 0: error (-2: the form does not apply).  n1_blocks: blocks of 64 rows in tier 1 (0: chosen).  info (may be NULL, 10 ints):
+ * {blocks, tier-1 blocks, x ring, G ring, tier-1 steps, tier-2 steps, band entries, tier-1 entries, tier-2 entries, dependency classes};
+ * out_u (may be NULL, max(row, col) doubles): the swept vector (input: u_i = sin(0.37 i) + 0.1, b_i = cos(0.11 i)) */
+double fasp_hip_seq_chain_selftest(const dCSRmat* A, const int* seq, int ns, int n1_blocks, int form, double w, int* info, double* out_u);
 /* measured device ceilings reported beside the roofline: out[0..2] = GB/s of a 16-byte-per-lane read, copy and
  * triad over buffers of `bytes` each (>= 512 MiB: beyond the Infinity Cache) */
 int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);

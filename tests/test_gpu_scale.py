@@ -260,6 +260,61 @@ def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("smoother,order,w", [(T.SMOOTHER_GS, 1, 1.0), (T.SMOOTHER_GS, 0, 1.0), (T.SMOOTHER_SOR, 0, 1.1)],
+                         ids=["GS-CF", "GS-natural", "SOR-natural"])
+def test_chain_form_kernels_agree_bit_for_bit(gpu, smoother, order, w):
+    """Round 5: on chain-bound sweeps the triangular solve is a blocked substitution whose dependency chain stays inside one wavefront
+    (csrc/seq_chain.hip.h): k_tri_chain -- chain wave, exporter, tier-1 helpers through an LDS ring, tier-2 workgroups through memory,
+    every hand-off a polled sentinel -- against k_tri_chain_ref, the same arithmetic by ONE wavefront without any polling: identical
+    bits, with the tiers as the schedule cuts them and with one block of tier 1 (most entries in tier 2).  Forced onto every level
+    where the form applies (seq_chain = 2); against the dataflow form (seq_chain = 0) the same sweep rounded differently."""
+    n = 40
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _gs_params(smoother, order, w)
+    L = fa.lib()
+    r = np.random.default_rng(11).standard_normal(len(f))
+    out = {}
+    try:
+        for chain, n1, ref in ((2, 0, 0), (2, 0, 1), (2, 1, 0), (2, 1, 1), (0, 0, 0)):
+            L.fasp_hip_tune(b"seq_chain", chain); L.fasp_hip_tune(b"seq_chain_n1", n1); L.fasp_hip_tune(b"seq_chain_ref", ref)
+            H = fa.AMG(ia, ja, a, amgp)    # (the form is chosen when a level's schedule is built: one hierarchy per setting)
+            z1 = H.precond(r)
+            out[(chain, n1, ref)] = (z1, H.precond(z1))
+            H.close()
+    finally:
+        L.fasp_hip_tune(b"seq_chain", 1); L.fasp_hip_tune(b"seq_chain_n1", 0); L.fasp_hip_tune(b"seq_chain_ref", 0)
+    assert np.all(np.isfinite(out[(2, 0, 0)][0]))
+    for n1 in (0, 1):
+        for k in (0, 1):
+            assert np.array_equal(out[(2, n1, 0)][k], out[(2, n1, 1)][k]), (n1, k)
+    big = np.abs(out[(0, 0, 0)][0]).max()
+    for key in ((2, 0, 0), (2, 1, 0)):
+        assert np.allclose(out[key][0], out[(0, 0, 0)][0], rtol=1e-10, atol=1e-13 * big)
+    assert not np.array_equal(out[(2, 0, 0)][0], out[(0, 0, 0)][0])   # (the chain form really ran: another association of the row sums)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,smoother,order,w", [("gscf", T.SMOOTHER_GS, 1, 1.0), ("gsnat", T.SMOOTHER_GS, 0, 1.0), ("sor11", T.SMOOTHER_SOR, 0, 1.1)])
+def test_chain_form_everywhere_matches_reference_64(gpu, tag, smoother, order, w):
+    """The chain form forced onto EVERY level it applies to (up to 65 407 rows: levels 1.. of P7(64)), tier 1 cut to two blocks: the
+    reference's iteration counts and residuals (tests/golden/p7_sweeps.npz) to the same bars as the default schedules."""
+    z = np.load(os.path.join(G, "p7_sweeps.npz"))
+    ia, ja, a, f, ue = fa.poisson7pt(64)
+    itp, amgp = _gs_params(smoother, order, w)
+    L = fa.lib()
+    try:
+        L.fasp_hip_tune(b"seq_chain", 2); L.fasp_hip_tune(b"seq_chain_n1", 2)
+        H = fa.AMG(ia, ja, a, amgp)
+        st, x, hist, stats = H.solve(f, itp)
+        H.close()
+    finally:
+        L.fasp_hip_tune(b"seq_chain", 1); L.fasp_hip_tune(b"seq_chain_n1", 0)
+    assert st == int(z[f"{tag}_iters"]), st
+    assert abs(stats.relres - float(z[f"{tag}_relres"])) <= RELRES_TOL
+    assert _same_history(hist, z[f"{tag}_hist"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag,smoother,order,w", [("gsnat", T.SMOOTHER_GS, 0, 1.0), ("sor11", T.SMOOTHER_SOR, 0, 1.1), ("gscf", T.SMOOTHER_GS, 1, 1.0)])
 def test_sweeps_with_many_virtual_rows_match_reference(gpu, tag, smoother, order, w):
     """Four lanes per row forced (fasp_hip_tune("seq_lanes", 4)): a work item holds 32 lower entries, so every row of the coarse

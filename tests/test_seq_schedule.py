@@ -112,3 +112,99 @@ def test_rows_without_a_usable_diagonal_are_left_alone():
             for lanes, spine in ((0, -1), (8, 2)):
                 res = _selftest(ia, ja, a, seq, kb, lanes, spine)
                 assert 0.0 <= res <= 1e-12, (kb, lanes, spine, res)
+
+
+# ---- the chain form (csrc/seq_chain.hip.h, round 5): blocked substitution with the dependency chain inside one wavefront ----
+def _chain_selftest(ia, ja, a, seq, n1=0, form=1, w=1.0, info=None, out=None):
+    L = fa.lib()
+    L.fasp_hip_seq_chain_selftest.restype = C.c_double
+    L.fasp_hip_seq_chain_selftest.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    A, keep = T.as_csr(ia, ja, a)
+    seq = np.ascontiguousarray(seq, dtype=np.int32)
+    buf = (C.c_int * 10)()
+    r = L.fasp_hip_seq_chain_selftest(C.byref(A), seq.ctypes.data_as(C.POINTER(C.c_int)), len(seq), n1, form, w, buf,
+                                      out.ctypes.data_as(C.POINTER(C.c_double)) if out is not None else None)
+    if info is not None:
+        info.update(blocks=buf[0], n1b=buf[1], rx=buf[2], rg=buf[3], t1_steps=buf[4], t2_steps=buf[5], band=buf[6], t1=buf[7], t2=buf[8], classes=buf[9])
+    return r
+
+
+def _banded(n, bw, fill=1.0, seed=0):
+    """Rows couple to the bw rows on either side with probability `fill` (unsorted columns, diagonally dominant)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    offs = list(range(-bw, 0)) + list(range(1, bw + 1))
+    A = sp.diags([-1.0 / (2 * bw)] * len(offs), offs, shape=(n, n), format="lil")
+    if fill < 1.0:
+        A = A.tocoo()
+        keep = rng.random(A.nnz) < fill
+        A = sp.coo_matrix((A.data[keep] * (0.5 + rng.random(keep.sum())), (A.row[keep], A.col[keep])), shape=(n, n))
+    A = (A.tocsr() + 2.0 * sp.identity(n, format="csr")).tocsr()
+    ia, ja, a = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    for i in range(n):   # shuffle the entries of every row: the setup's rows are unsorted, the diagonal sits anywhere
+        p = rng.permutation(ia[i + 1] - ia[i]) + ia[i]
+        ja[ia[i]:ia[i + 1]], a[ia[i]:ia[i + 1]] = ja[p], a[p]
+    return ia, ja, a
+
+
+@pytest.mark.parametrize("form,w", [(0, 1.0), (1, 1.0), (2, 1.1)])
+def test_chain_schedule_reproduces_the_sequential_sweep(form, w):
+    """Banded matrices of the deep levels' kind (hundreds of lower entries per row, one or two rows per dependency class): every tier is
+    populated -- the band (two blocks), tier 1 (n1 blocks, forced small so that tier 2 exists) -- ascending, descending and subset
+    sweeps, sizes that are no multiple of 64."""
+    for n, bw, fill in ((1500, 600, 1.0), (1000, 700, 0.3), (333, 200, 0.5), (64, 10, 1.0), (65, 64, 1.0), (40, 5, 1.0)):
+        ia, ja, a = _banded(n, bw, fill, seed=n)
+        idx = np.arange(n)
+        for seq in (idx, idx[::-1], idx[idx % 3 != 1]):
+            for n1 in (0, 1, 4):
+                info = {}
+                r = _chain_selftest(ia, ja, a, seq, n1, form, w, info)
+                assert 0.0 <= r <= 1e-12, (n, bw, n1, r, info)
+                assert info["blocks"] == (len(seq) + 63) // 64 and info["rx"] == 64 * (info["n1b"] + 12 + 3), info
+                if bw >= 64 * (info["n1b"] + 3) and len(seq) > 64 * (info["n1b"] + 3):
+                    assert info["t2"] > 0 and info["t1"] > 0 and info["band"] > 0, info
+
+
+def test_chain_schedule_is_independent_of_the_tier_split():
+    """Tier 1 and tier 2 are both per-row chains of fused multiply-adds in column order, but G2 starts from the right-hand side and tier 1
+    from zero: the split point is part of a schedule's arithmetic (a regrouping of the same products: differences of an ulp or two), the
+    result is the sequential sweep either way."""
+    ia, ja, a = _banded(1200, 500, 0.6, seed=5)
+    outs = []
+    for n1 in (1, 2, 6, 0):
+        u = np.zeros(1200)
+        assert 0.0 <= _chain_selftest(ia, ja, a, np.arange(1200), n1, 1, 1.0, None, u) <= 1e-12
+        outs.append(u)
+    for u in outs[1:]:
+        assert np.abs(u - outs[0]).max() <= 1e-13 * np.abs(outs[0]).max()
+
+
+def test_chain_schedule_on_the_deep_levels_of_a_hierarchy():
+    """C-row, F-row and natural-order sweeps of the deeper levels of a classical hierarchy (P7(40): levels of 60-250 entries per row)."""
+    ia, ja, a, f, ue = fa.poisson7pt(40)
+    H = fa.AMG(ia, ja, a, fa.param_amg_init(), host_only=True)
+    done = 0
+    for lev in range(2, H.num_levels - 1):
+        r, c, lia, lja, lv = H.matrix(lev, 0)
+        cf = H.cfmark(lev)
+        idx = np.arange(r)
+        for seq in (idx, idx[::-1], idx[cf == 1], idx[cf != 1]):
+            if len(seq) == 0:
+                continue
+            for form, w in ((1, 1.0), (2, 1.1)):
+                info = {}
+                res = _chain_selftest(lia, lja, lv, seq, 0, form, w, info)
+                assert 0.0 <= res <= 1e-12, (lev, form, res, info)
+                done += 1
+    assert done >= 16
+    H.close()
+
+
+def test_chain_form_refuses_what_it_cannot_do():
+    """A row the reference leaves alone (|a_ii| <= 1e-20): the dataflow form handles it, the chain form says 'does not apply'."""
+    ia, ja, a = _banded(300, 100, 1.0)
+    a2 = a.copy()
+    i = 150
+    a2[ia[i]:ia[i + 1]][ja[ia[i]:ia[i + 1]] == i] = 0.0
+    assert _chain_selftest(ia, ja, a2, np.arange(300)) == -2.0
+    assert 0.0 <= _selftest(ia, ja, a2, np.arange(300)) <= 1e-12
