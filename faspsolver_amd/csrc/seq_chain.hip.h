@@ -14,9 +14,12 @@
 // What is not in the band -- columns older than the previous block -- reaches the chain as ONE number per row (G), formed ahead of
 // time by other wavefronts and read from LDS at the block boundary:
 //     tier 1 (the n1b blocks in front of the band): helper waves of the chain's workgroup, x through a ring in LDS that the chain
-//            wave fills block by block; a helper may run CHAIN_HA blocks ahead; a value is its own flag (signalling-NaN sentinel);
+//            wave fills block by block; a helper may run CHAIN_HA blocks ahead;
 //     tier 2 (everything older): the other workgroups of the launch, x through memory (W, written by the exporter wave of the
 //            chain's workgroup), results through memory (G2).  Tier 2 has n1b blocks of slack, tier 1 one block.
+// Nobody polls operands: the schedule tells every group of eight steps the newest block it reads, and a wave waits on ONE word -- blocks
+// in the ring (LDS) / blocks exported (memory) -- before it gathers; entries are in column order, so only a block's last groups wait.
+// G and G2 -- one number per row -- are their own flags (signalling-NaN sentinel), as in the dataflow form.
 // Roles are dealt by tickets (the workgroup that draws ticket 0 is the chain's: it is running by definition; blocks of both tiers
 // are drawn in order, so every block the chain waits for is in the hands of a running wave): no residency assumption.
 // k_tri_chain_ref is the plain form of the same arithmetic -- ONE wavefront, block after block, no polling -- the fallback after a
@@ -30,21 +33,21 @@ struct ChainArgs {
     const f64x2_t*        band;   // (nb * 64 + CHAIN_PF) steps x 64 lanes x (TA, TB)
     const f64x2_t*        drd;    // npad x (a_ii, 1 / a_ii)
     const ChainBlk*       blk;
-    const double*         t1v; const unsigned short* t1c;
-    const double*         t2v; const unsigned short* t2c;
+    const double*         t1v; const unsigned short* t1c; const int* t1need;   // values [step][lane]; columns [group of 8 steps][lane][8]; need: per group of eight steps, the newest BLOCK its entries read (-1: none)
+    const double*         t2v; const unsigned short* t2c; const int* t2need;
     const double*         rec;    // 2 doubles per position, written by pass (1): b - rest, old u_i
     const int*            tr;     // 2 ints per position: flags, row index (-1: padding)
-    double*               W;      // the new values by position (sentinel until written); W[npad] = 0.0 for the padding entries of tier 2
+    double*               W;      // the new values by position (sentinel until written); W[npad] = 0.0 for the padding entries of tier 2; W[npad + 64 ..+ 128): scratch
     double*               G2;     // tier 2's sums by position (sentinel until written)
     double*               u;
-    unsigned*             sync;   // [0] role ticket, [1] error word, [2] tier-2 block ticket
+    unsigned*             sync;   // [0] role ticket, [1] error word, [2] tier-2 block ticket, [4] blocks exported to W, [5] 1 + XCD of the chain's workgroup
     int                   nb, npad, rx, rg;
+    int                   has_t2; // 0: no row has a tier-2 entry (no tier-2 workgroups in the launch: tier 1 starts from pass (1)'s record itself)
     int                   form;   // as tri_update
     double                w;
 };
 
-constexpr int CHAIN_NT = 512;   // 8 waves (256 registers each: the chain wave keeps CHAIN_PF coefficient pairs in flight): chain, exporter, 6 tier-1 helpers (chain workgroup) / 8 tier-2 workers (the others)
-constexpr int CHAIN_U1 = 8, CHAIN_U2 = 8;   // steps per group of tier 1 / tier 2 (the schedules pad a block's steps to multiples of 8)
+constexpr int CHAIN_NT = 512;   // 8 waves (256 registers each: the chain wave keeps CHAIN_PF coefficient pairs in flight): chain, exporter, importer, 5 tier-1 helpers (chain workgroup) / 8 tier-2 workers (the others)
 
 template <int FORM>
 __device__ __forceinline__ double chain_update(double t, double d, double rd, double w, double ku)
@@ -77,48 +80,63 @@ __device__ __forceinline__ void chain_block(double& accA, double& accB, double d
 }
 
 
-// One lane's share of a tier: n steps (a multiple of U) of (value, column), acc <- fma(-value, x[column], acc) in step order.
-// Three register sets: the steps of the next TWO groups travel while this one gathers (the streams come from HBM: a microsecond).
-// A group's operands are read until none of them is the sentinel (wave-uniform retry; `get` = the gather, LDS or memory).
-template <int U, int NAP, class Get>
-__device__ __forceinline__ void chain_tier_sum(const double* v, const unsigned short* c, int n, double& acc, unsigned* sync, unsigned& spins, unsigned long long& t0, Get get)
+// One lane's share of a tier: n steps (a multiple of 8) of (value, column), acc <- fma(-value, x[column], acc) in step order, as a
+// pipeline over groups of eight steps: the (value, column) pairs of the next CHAIN_NS - 1 groups travel (streams from HBM: one to two
+// microseconds; 25 KB in flight per wave) while the operands of the next group are gathered (LDS, or memory) and this one is summed.
+// GATING instead of polling the operands: `need` = the newest block a group reads (one int per group, from the schedule; -1: none);
+// the wave waits -- on ONE word -- until that block has been published, then gathers without looking at what it gets.  Entries are
+// in column order and right-aligned: only a block's last groups ever wait.
+constexpr int CHAIN_NS = 6;   // register sets of (value, column) groups in flight
+constexpr int CHAIN_NX = 3;   // operand sets: the gathers of the next two groups are in flight while this one is summed
+// columns of a group: eight 16-bit indices per lane, side by side (one 16-byte load per lane and group)
+template <bool STREAM, class Gate, class Get>
+__device__ __forceinline__ void chain_tier_sum(const double* v, const u32x4_t* c, const int* need, int n, double& acc, Gate gate, Get get)
 {
-    double v0[U], v1[U], v2[U];
-    int c0[U], c1[U], c2[U];
-    auto fetch = [&](double (&vv)[U], int (&cc)[U], int s) {
+    constexpr int U = 8, NS = CHAIN_NS, NX = CHAIN_NX;
+    static_assert(NS % NX == 0, "the operand sets rotate with the register sets");
+    double vv[NS][U], xx[NX][U];
+    u32x4_t cc[NS];
+    int nn[NS];
+    auto fetch = [&](double (&vs)[U], u32x4_t& cs, int& ns, int s) {
         if (s < n) {
 #pragma unroll
-            for (int i = 0; i < U; ++i) { vv[i] = __builtin_nontemporal_load(v + (size_t)(s + i) * 64); cc[i] = __builtin_nontemporal_load(c + (size_t)(s + i) * 64); }
+            for (int i = 0; i < U; ++i) vs[i] = STREAM ? __builtin_nontemporal_load(v + (size_t)(s + i) * 64) : v[(size_t)(s + i) * 64];   // (tier 2 streams past the caches)
+            cs = STREAM ? __builtin_nontemporal_load(c + (size_t)(s >> 3) * 64) : c[(size_t)(s >> 3) * 64];
+            ns = need[s >> 3];
         }
     };
-    auto use = [&](const double (&vv)[U], const int (&cc)[U]) {
-        unsigned long long x[U];
-        for (;;) {
-            bool miss = false;
+    auto gather = [&](double (&xs)[U], const u32x4_t& cs, int ns, int s) {
+        if (s < n) {
+            gate(__builtin_amdgcn_readfirstlane(ns));
 #pragma unroll
-            for (int i = 0; i < U; ++i) { x[i] = get(cc[i]); miss |= x[i] == FLOW_SENT; }
-            if (!__builtin_amdgcn_ballot_w64(miss)) break;
-            if (flow_give_up(sync, spins, t0)) break;
-            if (NAP) __builtin_amdgcn_s_sleep(NAP);
+            for (int i = 0; i < U; ++i) xs[i] = get((int)((i & 1) ? (cs[i >> 1] >> 16) : (cs[i >> 1] & 0xffffu)));
         }
-#pragma unroll
-        for (int i = 0; i < U; ++i) acc = __builtin_fma(-vv[i], __longlong_as_double((long long)x[i]), acc);
     };
-    fetch(v0, c0, 0); fetch(v1, c1, U);
-    for (int s = 0; s < n; s += 3 * U) {
-        fetch(v2, c2, s + 2 * U); use(v0, c0);
-        if (s + U >= n) break;
-        fetch(v0, c0, s + 3 * U); use(v1, c1);
-        if (s + 2 * U >= n) break;
-        fetch(v1, c1, s + 4 * U); use(v2, c2);
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k) fetch(vv[k], cc[k], nn[k], k * U);
+    gather(xx[0], cc[0], nn[0], 0);
+    gather(xx[1], cc[1], nn[1], U);
+    for (int s0 = 0; s0 < n; s0 += NS * U) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int s = s0 + k * U;
+            if (s < n) {
+                fetch(vv[(k + NS - 1) % NS], cc[(k + NS - 1) % NS], nn[(k + NS - 1) % NS], s + (NS - 1) * U);
+                gather(xx[(k + 2) % NX], cc[(k + 2) % NS], nn[(k + 2) % NS], s + 2 * U);
+#pragma unroll
+                for (int i = 0; i < U; ++i) acc = __builtin_fma(-vv[k][i], xx[k % NX][i], acc);
+            }
+        }
     }
 }
 
 __device__ __forceinline__ bool chain_spin(unsigned* sync, unsigned& spins, unsigned long long& t0) { return flow_give_up(sync, spins, t0); }
 
-// ---- the chain wave
+// ---- the chain wave.  LDS words it publishes: s_k = the block it is in (helpers run at most CHAIN_HA blocks ahead), s_done = blocks
+// whose values are in the ring X (what tier 1 and the exporter wait for).  At a block boundary it takes the coming block's S1 (tier 1's
+// sum, from a helper) and G2 (tier 2's, brought in by the porter wave) from their rings in LDS: values that are their own flags.
 template <int FORM>
-__device__ __forceinline__ void chain_wave(const ChainArgs& a, double* X, double* G, int* s_k, int* s_exp, int lane)
+__device__ __forceinline__ void chain_wave(const ChainArgs& a, double* X, double* S1, double* G2r, int* s_k, int* s_done, int* s_exp, int lane)
 {
     const double sent = __longlong_as_double((long long)FLOW_SENT);
     auto lds_get = [&](double* p) -> double { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
@@ -129,83 +147,158 @@ __device__ __forceinline__ void chain_wave(const ChainArgs& a, double* X, double
     for (int i = 0; i < CHAIN_PF; ++i) cf[i] = bp[(size_t)i * 64];
     unsigned spins = 0;
     unsigned long long t0 = 0;
-    auto take_G = [&](int gi) -> double {   // this lane's G of the coming block; the slot is handed back (sentinel) for the block CHAIN_HA + 2 later
+#ifdef CHAIN_TIMING
+    long long ct[4] = {0, 0, 0, 0}, cl = clock64();
+#define CT(k) do { const long long n_ = clock64(); ct[k] += n_ - cl; cl = n_; } while (0)
+#else
+#define CT(k)
+#endif
+    auto take = [&](double* ring, int gi) -> double {   // this lane's number of the coming block; the slot is handed back for the block CHAIN_HA + 2 later
         double g;
         for (;;) {
-            g = lds_get(G + gi);
+            g = lds_get(ring + gi);
             if (!__builtin_amdgcn_ballot_w64(!flow_ready(g))) break;
             if (chain_spin(a.sync, spins, t0)) break;
         }
-        lds_put(G + gi, sent);
+        lds_put(ring + gi, sent);
         return g;
     };
-    int xi = lane, gi = lane, ri = lane + CHAIN_HA * 64;   // ring slots of this block's x, of the next block's G, of the block whose x slots are reset
-    while (ri >= a.rx) ri -= a.rx;
+    auto take_G = [&](int gi, double g2, double s1) -> double {   // (G2 + S1: the association of k_tri_chain_ref); g2, s1: what an early look at the slots found
+        if (__builtin_amdgcn_ballot_w64(!flow_ready(g2))) g2 = take(G2r, gi); else lds_put(G2r + gi, sent);
+        CT(3);
+        if (__builtin_amdgcn_ballot_w64(!flow_ready(s1))) s1 = take(S1, gi); else lds_put(S1 + gi, sent);
+        CT(1);
+        return g2 + s1;
+    };
+    int xi = lane, gi = lane;   // ring slots of this block's x, of the next block's S1 / G2
+    const int ringb = a.rx / 64;
     f64x2_t dr = a.drd[lane];
     double uo = FORM == 2 ? a.rec[2 * (size_t)lane + 1] : 0.0;
-    double accB = 0.0, accA = take_G(gi) + accB;
+    double accB = 0.0, accA = take_G(gi, sent, sent) + accB;
+    CT(2);
+#ifdef CHAIN_TIMING
+    ct[0] = ct[1] = ct[2] = ct[3] = 0;
+    const long long c_start = clock64();
+    const unsigned long long r_start = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) printf("[t] chain loop starts %llu\n", r_start % 100000000ull);
+#endif
+    __builtin_amdgcn_s_setprio(3);   // the chain wave IS the critical path: its instructions go first on its SIMD
     for (int K = 0; K < a.nb; ++K) {
-        // the x slots of block K + CHAIN_HA: nobody looks for that block's values yet (helpers run at most CHAIN_HA blocks ahead and
-        // read columns two blocks behind their rows), everybody who read the slots' previous owner is done (rx = 64 (n1b + CHAIN_HA + 3))
-        // -- and the exporter has taken that owner's values (it trails the chain by a block or two; checked, not assumed)
-        if (K + CHAIN_HA < a.nb && K > 0) {
-            const int owner = K + CHAIN_HA - a.rx / 64;
-            while (owner >= 0 && __hip_atomic_load(s_exp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= owner) { if (chain_spin(a.sync, spins, t0)) break; }
-            lds_put(X + ri, sent);   // (blocks 0 .. CHAIN_HA are sentinel from the start)
-        }
         if (lane == 0) __hip_atomic_store(s_k, K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const double d = dr[0], rd = dr[1], ku = FORM == 2 ? (1 - a.w) * uo : 0.0;
         const int pn = (K + 1 < a.nb ? K + 1 : K) * 64 + lane;
         dr = a.drd[pn];                                             // the next block's records travel behind the steps
         if (FORM == 2) uo = a.rec[2 * (size_t)pn + 1];
+        // an early look at the coming block's S1 and G2 (the helpers run ahead: normally there): their LDS round trip hides behind the steps
+        const int gn = gi + 64 >= a.rg ? gi + 64 - a.rg : gi + 64;
+        const double g2e = lds_get(G2r + gn), s1e = lds_get(S1 + gn);
+        CT(2);
         chain_block<FORM>(accA, accB, d, rd, a.w, ku, cf, bp + ((size_t)K * 64 + CHAIN_PF) * 64);
+        CT(0);
+        // the ring slots of block K held block K - rx / 64: every helper that read it is done (rx = 64 (n1b + CHAIN_HA + 3)), and the
+        // porter has exported it (it trails the chain by a block or two; checked, not assumed)
+        while (K >= ringb && __hip_atomic_load(s_exp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= K - ringb) { if (chain_spin(a.sync, spins, t0)) break; }
         lds_put(X + xi, chain_update<FORM>(accA, d, rd, a.w, ku));
+        if (lane == 0) __hip_atomic_store(s_done, K + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (behind the values: LDS operations of a wave complete in order)
         xi += 64; if (xi >= a.rx) xi -= a.rx;
-        ri += 64; if (ri >= a.rx) ri -= a.rx;
         gi += 64; if (gi >= a.rg) gi -= a.rg;
-        if (K + 1 < a.nb) { accA = take_G(gi) + accB; accB = 0.0; }
+        CT(2);
+        if (K + 1 < a.nb) { accA = take_G(gi, g2e, s1e) + accB; accB = 0.0; }
     }
+#ifdef CHAIN_TIMING
+    if (lane == 0) printf("[chain] %d blocks: per block %.0f cycles in the 64 steps, %.0f waiting for tier 1, %.0f for tier 2, %.0f other; %.3f ticks of clock64 per ns\n", a.nb, (double)ct[0] / a.nb, (double)ct[1] / a.nb, (double)ct[3] / a.nb, (double)ct[2] / a.nb,
+                          (double)(clock64() - c_start) / (10.0 * (double)(__builtin_amdgcn_s_memrealtime() - r_start)));
+#endif
 }
 
-// ---- exporter: the block's values from the ring to W (tier 2 polls it) and to u; touches the band a few blocks ahead into the L2
-__device__ __forceinline__ void chain_export(const ChainArgs& a, double* X, int* s_exp, int lane)
+// ---- exporter: the finished blocks from the ring to W and to u, then the count of exported blocks (sync[4]: what tier 2 waits for).
+// The count follows the stores at a distance: a block's stores are acknowledged a microsecond or two after they are issued -- waiting
+// for each block's before the next one is touched made the exporter slower than the chain (and with it tier 2's gates, and the chain).
+// While blocks keep coming the count trails by two blocks (stores of one wave complete in order: "all but the last four" are done);
+// the moment the exporter has nothing to do it drains and catches up.
+__device__ __forceinline__ void chain_export(const ChainArgs& a, double* X, int* s_done, int* s_exp, int lane)
 {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
-    constexpr int AHEAD = 4;
-    int xi = lane, touched = 0;
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    int xi = lane, published = 0;
     unsigned spins = 0;
     unsigned long long t0 = 0;
-    const char* bb = reinterpret_cast<const char*>(a.band);
-    const size_t band_bytes = ((size_t)a.nb * 64 + CHAIN_PF) * 1024;
-    for (int K = 0; K < a.nb; ++K) {
-        const size_t tb = (size_t)(K + AHEAD) * 65536;
-        if (tb + 65536 <= band_bytes) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) touched += *reinterpret_cast<const volatile int*>(bb + tb + ((size_t)i * 64 + lane) * 128);
-        }
-        double x;
-        for (;;) {
-            x = __hip_atomic_load(X + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!__builtin_amdgcn_ballot_w64(!flow_ready(x))) break;
+    auto publish = [&](int n) {
+        if (a.has_t2 && n > published) { published = n; if (lane == 0) __hip_atomic_store((gu32*)(a.sync + 4), (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    };
+    for (int ex = 0; ex < a.nb; ++ex) {
+        while (__hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= ex) {
+            if (published < ex) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish(ex); }   // idle: everything issued so far has arrived
             if (chain_spin(a.sync, spins, t0)) break;
             __builtin_amdgcn_s_sleep(1);
         }
-        const int p = K * 64 + lane;
-        __hip_atomic_store((gu64*)(a.W + p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double x = __hip_atomic_load(X + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int p = ex * 64 + lane;
         const int row = a.tr[2 * (size_t)p + 1];
-        if (row >= 0) a.u[row] = x;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the row index above: a load; from here on this wave has stores in flight only)
+        if (a.has_t2) __hip_atomic_store((gu64*)(a.W + p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through)
+        else a.W[p] = x;
+        *(row >= 0 ? a.u + row : a.W + a.npad + 64 + lane) = x;   // (padding rows write to scratch behind W: every block issues exactly two stores per lane)
         xi += 64; if (xi >= a.rx) xi -= a.rx;
-        if (lane == 0) __hip_atomic_store(s_exp, K + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (behind this wave's LDS reads of the block: LDS operations of a wave complete in order)
+        if (lane == 0) __hip_atomic_store(s_exp, ex + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (behind this wave's LDS read of the block)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish(a.nb);
+}
+
+// ---- importer: tier 2's sums (G2 in memory: values that are their own flags) into their ring in LDS, in block order, at most
+// CHAIN_HA + 1 blocks ahead of the chain; four blocks are asked for at a time (a poll is a round trip to memory: one block per poll
+// is slower than the chain).  Also pulls the band planes of the blocks up to four ahead of the chain into the L2, one dword per
+// 128-byte line: the chain wave's loads then cost an L2 hit.  Eight loads per block, paced by the chain itself -- a wave that streams
+// touches as fast as it can (tried: 32 in flight, tier 1's entries too) slows the chain wave's own loads down by more than it saves.
+__device__ __forceinline__ void chain_import(const ChainArgs& a, double* G2r, int* s_k, int lane)
+{
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    constexpr int NB = 4;
+    int gi = lane, im = 0, tb = 0, touched = 0;
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    const char* bb = reinterpret_cast<const char*>(a.band);
+    for (;;) {
+        const int k = __hip_atomic_load(s_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (im >= a.nb && k >= a.nb - 1) break;
+        const int lim = k + CHAIN_HA + 1;
+        bool moved = false;
+        if (tb < a.nb && tb <= k + 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) touched += *reinterpret_cast<const volatile int*>(bb + (size_t)tb * 65536 + ((size_t)i * 64 + lane) * 128);
+            ++tb;
+            moved = true;
+        }
+        unsigned long long g2[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int b = im + j, p = b * 64 + lane;
+            g2[j] = FLOW_SENT;
+            if (b < a.nb && b <= lim) g2[j] = a.has_t2 ? __hip_atomic_load((gu64*)(a.G2 + p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned long long)__double_as_longlong(a.rec[2 * (size_t)p]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (__builtin_amdgcn_ballot_w64(g2[j] == FLOW_SENT)) break;   // (in block order: the first one that is not there ends the turn)
+            __hip_atomic_store(G2r + gi, __longlong_as_double((long long)g2[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            gi += 64; if (gi >= a.rg) gi -= a.rg;
+            ++im;
+            moved = true;
+        }
+        if (!moved) { if (chain_spin(a.sync, spins, t0)) break; __builtin_amdgcn_s_sleep(4); }
     }
     if (touched == 0x7fffffff) a.sync[3] = 1u;   // (keeps the touches)
 }
 
-// ---- tier 1: helper waves of the chain's workgroup; blocks drawn in order from a counter in LDS
-__device__ __forceinline__ void chain_tier1(const ChainArgs& a, double* X, double* G, int* s_k, int* s_ticket, int lane)
+// ---- tier 1: helper waves of the chain's workgroup; blocks drawn in order from a counter in LDS; a block's sums go to the ring S1
+__device__ __forceinline__ void chain_tier1(const ChainArgs& a, double* X, double* S1, int* s_k, int* s_done, int* s_ticket, int lane)
 {
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
     unsigned spins = 0;
     unsigned long long t0 = 0;
+    int have = 0;   // blocks in the ring, as last seen
+#ifdef CHAIN_TIMING
+    long long ct[3] = {0, 0, 0}, cl = clock64(); int nblk = 0;
+#endif
     for (;;) {
         int K = 0;
         if (lane == 0) K = __hip_atomic_fetch_add(s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -215,72 +308,120 @@ __device__ __forceinline__ void chain_tier1(const ChainArgs& a, double* X, doubl
             if (chain_spin(a.sync, spins, t0)) break;
             __builtin_amdgcn_s_sleep(2);
         }
+        CT(0);
         const flow_int_cp q = (flow_int_cp)(unsigned long long)(a.blk + K);
         const int off = q[0], n = q[1];
-        const double* v = a.t1v + (size_t)off * 64 + lane;
-        const unsigned short* c = a.t1c + (size_t)off * 64 + lane;
         double acc = 0.0;
-        chain_tier_sum<CHAIN_U1, 0>(v, c, n, acc, a.sync, spins, t0, [&](int ci) -> unsigned long long {
-            return (unsigned long long)__double_as_longlong(__hip_atomic_load(X + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); });
-        // tier 2's sum of this row (memory; L1-bypassing polls), then G
-        const int p = K * 64 + lane;
-        unsigned long long g2;
-        for (;;) {
-            g2 = __hip_atomic_load((gu64*)(a.G2 + p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!__builtin_amdgcn_ballot_w64(g2 == FLOW_SENT)) break;
-            if (chain_spin(a.sync, spins, t0)) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        int gi = p % a.rg;
-        __hip_atomic_store(G + gi, __longlong_as_double((long long)g2) + acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        chain_tier_sum<false>(a.t1v + (size_t)off * 64 + lane, reinterpret_cast<const u32x4_t*>(a.t1c) + (size_t)(off >> 3) * 64 + lane, a.t1need + (off >> 3), n, acc,
+                       [&](int need) {
+                           while (need >= have) {
+                               have = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                               if (need < have || chain_spin(a.sync, spins, t0)) break;
+                           }
+                       },
+                       [&](int ci) -> double { return __hip_atomic_load(X + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); });
+        __hip_atomic_store(S1 + (K * 64 + lane) % a.rg, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        CT(1);
+#ifdef CHAIN_TIMING
+        ++nblk;
+#endif
     }
+#ifdef CHAIN_TIMING
+    if (lane == 0 && nblk) printf("[tier 1] %d blocks: per block %.0f cycles throttled / idle, %.0f in the sum (incl. waits for x)\n", nblk, (double)ct[0] / nblk, (double)ct[1] / nblk);
+#endif
 }
 
 // ---- tier 2: every wave of the other workgroups; blocks drawn in order from a counter in memory
-__device__ __forceinline__ void chain_tier2(const ChainArgs& a, int lane)
+__device__ __forceinline__ void chain_tier2(const ChainArgs& a, int lane, int wg)
 {
     typedef __attribute__((address_space(1))) unsigned      gu32;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     unsigned spins = 0;
     unsigned long long t0 = 0;
+    int have = 0;   // blocks exported, as last seen
+#ifdef CHAIN_TIMING
+    long long ct[3] = {0, 0, 0}, cl = clock64(), tw = 0; int nblk = 0;
+#endif
     for (;;) {
         unsigned Ku = 0;
         if (lane == 0) Ku = __hip_atomic_fetch_add((gu32*)(a.sync + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int K = (int)__builtin_amdgcn_readfirstlane(Ku);
         if (K >= a.nb) break;
+        CT(0);
         const flow_int_cp q = (flow_int_cp)(unsigned long long)(a.blk + K);
         const int off = q[2], n = q[3];
-        const double* v = a.t2v + (size_t)off * 64 + lane;
-        const unsigned short* c = a.t2c + (size_t)off * 64 + lane;
         const int p = K * 64 + lane;
         double acc = a.rec[2 * (size_t)p];   // b_i - (what reads old values): pass (1)
-        chain_tier_sum<CHAIN_U2, 4>(v, c, n, acc, a.sync, spins, t0, [&](int ci) -> unsigned long long {
-            return __hip_atomic_load((gu64*)(a.W + ci), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+        chain_tier_sum<true>(a.t2v + (size_t)off * 64 + lane, reinterpret_cast<const u32x4_t*>(a.t2c) + (size_t)(off >> 3) * 64 + lane, a.t2need + (off >> 3), n, acc,
+                       [&](int need) {
+#ifdef CHAIN_TIMING
+                           const long long w0 = clock64();
+#endif
+                           while (need >= have) {
+                               have = (int)__hip_atomic_load((gu32*)(a.sync + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                               if (need < have || chain_spin(a.sync, spins, t0)) break;
+                               __builtin_amdgcn_s_sleep(8);
+                           }
+#ifdef CHAIN_TIMING
+                           tw += clock64() - w0;
+#endif
+                       },
+                       [&](int ci) -> double { return __longlong_as_double((long long)__hip_atomic_load((gu64*)(a.W + ci), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); });
         __hip_atomic_store((gu64*)(a.G2 + p), (unsigned long long)__double_as_longlong(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CT(1);
+#ifdef CHAIN_TIMING
+        ++nblk;
+#endif
     }
+#ifdef CHAIN_TIMING
+    if (lane == 0 && nblk && wg <= 2 && (threadIdx.x >> 6) == 0) printf("[tier 2, workgroup %d] %d blocks: per block %.0f cycles in the sum, of which %.0f at the gate\n", wg, nblk, (double)ct[1] / nblk, (double)tw / nblk);
+#endif
 }
 
 template <int FORM>
 __global__ __launch_bounds__(CHAIN_NT) void k_tri_chain(ChainArgs a)
 {
     typedef __attribute__((address_space(1))) unsigned gu32;
-    extern __shared__ __attribute__((aligned(16))) double chain_lds[];   // X[rx + 1], G[rg]
-    __shared__ int s_role, s_k, s_ticket, s_exp;
+    extern __shared__ __attribute__((aligned(16))) double chain_lds[];   // X[rx + 1], S1[rg], G2r[rg]
+    __shared__ int s_role, s_k, s_ticket, s_exp, s_done;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CHAIN_TIMING
+    const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime();
+#define CTEND(what) do { if (lane == 0) printf("[t] %s wave %d: entered %llu, done %llu (10 ns ticks)\n", what, wave, t_enter % 100000000ull, __builtin_amdgcn_s_memrealtime() % 100000000ull); } while (0)
+#else
+#define CTEND(what)
+#endif
     if (tid == 0) s_role = (int)__hip_atomic_fetch_add((gu32*)a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int role = __builtin_amdgcn_readfirstlane(s_role);
-    if (role != 0) { chain_tier2(a, lane); return; }
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    if (role != 0) {
+        // Tier 2 streams hundreds of KB per block: on the chain's XCD it would push the band planes (pulled in ahead of the chain wave) out
+        // of the L2 they share.  The chain's workgroup -- running by the time anybody draws a later ticket -- says where it is; workgroups
+        // that find themselves on the same XCD leave (an eighth of them).
+        unsigned where = 0, spins = 0;
+        unsigned long long t0 = 0;
+        while (!(where = __hip_atomic_load((gu32*)(a.sync + 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (flow_give_up(a.sync, spins, t0)) break; __builtin_amdgcn_s_sleep(2); }
+        if (where == xcc + 1u && gridDim.x > 9) return;
+        chain_tier2(a, lane, role);
+        if (role <= 2 || role >= (int)gridDim.x - 2) CTEND("tier-2");
+        return;
+    }
+    if (tid == 0) __hip_atomic_store((gu32*)(a.sync + 5), xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double* X = chain_lds;
-    double* G = chain_lds + a.rx + 1;
+    double* S1 = chain_lds + a.rx + 1;
+    double* G2r = S1 + a.rg;
     const double sent = __longlong_as_double((long long)FLOW_SENT);
-    for (int i = tid; i < a.rx + 1 + a.rg; i += CHAIN_NT) chain_lds[i] = i == a.rx ? 0.0 : sent;
-    if (tid == 0) { s_k = 0; s_ticket = 0; s_exp = 0; }
+    for (int i = tid; i < a.rx + 1 + 2 * a.rg; i += CHAIN_NT) chain_lds[i] = i == a.rx ? 0.0 : sent;
+    if (tid == 0) { s_k = 0; s_ticket = 0; s_exp = 0; s_done = 0; }
     __syncthreads();
-    if (wave == 0) chain_wave<FORM>(a, X, G, &s_k, &s_exp, lane);
-    else if (wave == 1) chain_export(a, X, &s_exp, lane);
-    else chain_tier1(a, X, G, &s_k, &s_ticket, lane);
+    if (wave == 0) { chain_wave<FORM>(a, X, S1, G2r, &s_k, &s_done, &s_exp, lane); CTEND("chain"); }
+    else if (wave == 1) { chain_export(a, X, &s_done, &s_exp, lane); CTEND("exporter"); }
+    else if (wave == 2) { chain_import(a, G2r, &s_k, lane); CTEND("importer"); }
+    else { chain_tier1(a, X, S1, &s_k, &s_done, &s_ticket, lane); CTEND("tier-1"); }
 }
 
 // The plain form: ONE wavefront, block after block -- tier 2 and tier 1 of the block (x from W in memory, written by this wave in
@@ -295,14 +436,14 @@ __global__ __launch_bounds__(64) void k_tri_chain_ref(ChainArgs a, int n1b)
         const int p = K * 64 + lane;
         double g2 = a.rec[2 * (size_t)p];
         for (int s = 0; s < B.t2_n; ++s) {
-            const size_t e = ((size_t)B.t2_off + s) * 64 + lane;
-            g2 = __builtin_fma(-a.t2v[e], a.W[a.t2c[e]], g2);
+            const size_t e = ((size_t)B.t2_off + s) * 64 + lane, ec = (((size_t)(B.t2_off + s) >> 3) * 64 + lane) * 8 + (s & 7);   // (columns: eight per lane and group, side by side)
+            g2 = __builtin_fma(-a.t2v[e], a.W[a.t2c[ec]], g2);
         }
         double s1 = 0.0;
         const int base = (K - 1 - n1b) * 64;   // first position of tier 1's window (may be negative: then the ring index is the position)
         for (int s = 0; s < B.t1_n; ++s) {
-            const size_t e = ((size_t)B.t1_off + s) * 64 + lane;
-            const int r = a.t1c[e];
+            const size_t e = ((size_t)B.t1_off + s) * 64 + lane, ec = (((size_t)(B.t1_off + s) >> 3) * 64 + lane) * 8 + (s & 7);
+            const int r = a.t1c[ec];
             int qp;
             if (r >= a.rx) qp = a.npad;   // padding: the constant 0.0
             else { const int b0 = base > 0 ? base : 0; qp = b0 + ((r - b0 % a.rx) + a.rx) % a.rx; }

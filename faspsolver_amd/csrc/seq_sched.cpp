@@ -53,16 +53,13 @@ static int build_chain_host(const HostCSR& A, const int* seq, int ns, const Buf<
     }
     if (alone_rows) return 1;   // (rows the reference leaves alone: the dataflow form handles them)
     int n1b = n1_blocks;
-    if (n1b <= 0) {
-        // tier 1 is bound by what ONE compute unit streams (10 bytes per entry at some tens of GB/s against a block of 64 rows per
-        // 1.3 us): the widest window of 4 .. 32 blocks whose entries stay below ~64 per row
-        n1b = 4;
-        long long acc = 0;
-        for (int d = 2; d <= 33; ++d) {
-            acc += hist[(size_t)d];
-            if (d - 1 >= 4 && acc <= 64ll * ns) n1b = d - 1;
-        }
-    }
+    // Tier 1 is bound by what ONE compute unit streams (10 bytes per entry, padded to the block's longest row, against a block of 64
+    // rows per 2 us) and by its helpers' time; tier 2 needs the window as slack (exported -> gate -> last gathers -> G2 -> importer:
+    // 8-10 us = four to five blocks).  Measured on levels 5-8 of P7(256), all sweep kinds (profiles/r05_gs_chain.txt): six blocks beat
+    // four, eight, twelve and "as many as stay below 64 entries per row" (9-32 blocks on the wider levels) everywhere but on the
+    // F rows of the last level.
+    if (n1b <= 0) n1b = 6;
+    (void)hist;
     n1b = std::max(1, std::min(48, n1b));
     ChainHost& C = H.C;
     C.nb = nb; C.npad = npad; C.n1b = n1b;
@@ -111,6 +108,7 @@ static int build_chain_host(const HostCSR& A, const int* seq, int ns, const Buf<
     C.drd.alloc(2 * (size_t)npad);
     C.t1v.alloc(std::max<size_t>((size_t)o1 * 64, 1)); C.t1c.alloc(std::max<size_t>((size_t)o1 * 64, 1));
     C.t2v.alloc(std::max<size_t>((size_t)o2 * 64, 1)); C.t2c.alloc(std::max<size_t>((size_t)o2 * 64, 1));
+    C.t1need.alloc(std::max<size_t>((size_t)o1 / 8, 1)); C.t2need.alloc(std::max<size_t>((size_t)o2 / 8, 1));
     H.rja.alloc((size_t)std::max<long long>(nr, 1)); H.rval.alloc((size_t)std::max<long long>(nr, 1));
     H.tr.alloc(2 * (size_t)npad);
     H.dr.alloc(2);   // (the split form's per-position pairs: here C.drd)
@@ -131,6 +129,10 @@ static int build_chain_host(const HostCSR& A, const int* seq, int ns, const Buf<
             double* v2 = C.t2v.data() + (size_t)B.t2_off * 64; unsigned short* c2 = C.t2c.data() + (size_t)B.t2_off * 64;
             for (size_t t = 0; t < (size_t)B.t1_n * 64; ++t) { v1[t] = 0.0; c1[t] = (unsigned short)C.rx; }
             for (size_t t = 0; t < (size_t)B.t2_n * 64; ++t) { v2[t] = 0.0; c2[t] = (unsigned short)npad; }
+            auto cidx = [](size_t st, int lane) { return ((st >> 3) * 64 + (size_t)lane) * 8 + (st & 7); };   // columns: [group of 8 steps][lane][8] (one 16-byte load per lane and group)
+            int* nd1 = C.t1need.data() + B.t1_off / 8; int* nd2 = C.t2need.data() + B.t2_off / 8;
+            for (int g = 0; g < B.t1_n / 8; ++g) nd1[g] = -1;
+            for (int g = 0; g < B.t2_n / 8; ++g) nd2[g] = -1;
             for (int jl = 0; jl < 64; ++jl) {
                 const int q = K * 64 + jl;
                 if (q >= ns) {   // padding row: x = 0 / 1, no row of u
@@ -162,8 +164,8 @@ static int build_chain_host(const HostCSR& A, const int* seq, int ns, const Buf<
                 std::stable_sort(e1.begin(), e1.end(), by_pos); std::stable_sort(e2.begin(), e2.end(), by_pos);
                 nt1 += (long long)e1.size(); nt2 += (long long)e2.size();
                 // right-aligned: the newest columns are the last steps of the block
-                for (size_t t = 0; t < e1.size(); ++t) { const size_t st = (size_t)B.t1_n - e1.size() + t; v1[st * 64 + jl] = e1[t].second; c1[st * 64 + jl] = (unsigned short)(e1[t].first % C.rx); }
-                for (size_t t = 0; t < e2.size(); ++t) { const size_t st = (size_t)B.t2_n - e2.size() + t; v2[st * 64 + jl] = e2[t].second; c2[st * 64 + jl] = (unsigned short)e2[t].first; }
+                for (size_t t = 0; t < e1.size(); ++t) { const size_t st = (size_t)B.t1_n - e1.size() + t; v1[st * 64 + jl] = e1[t].second; c1[cidx(st, jl)] = (unsigned short)(e1[t].first % C.rx); nd1[st / 8] = std::max(nd1[st / 8], e1[t].first >> 6); }
+                for (size_t t = 0; t < e2.size(); ++t) { const size_t st = (size_t)B.t2_n - e2.size() + t; v2[st * 64 + jl] = e2[t].second; c2[cidx(st, jl)] = (unsigned short)e2[t].first; nd2[st / 8] = std::max(nd2[st / 8], e2[t].first >> 6); }
                 C.drd[2 * (size_t)q] = dg; C.drd[2 * (size_t)q + 1] = 1.0 / dg;
                 H.tr[2 * (size_t)q] = 0; H.tr[2 * (size_t)q + 1] = i;
             }
@@ -733,19 +735,21 @@ extern "C" double fasp_hip_seq_chain_selftest(const dCSRmat* Av, const int* seq,
             double g2 = T[(size_t)p];
             for (int s = 0; s < B.t2_n; ++s) {
                 const size_t e = ((size_t)B.t2_off + s) * 64 + j;
-                const int qp = C.t2c[e];
+                const int qp = C.t2c[(((size_t)(B.t2_off + s) >> 3) * 64 + (size_t)j) * 8 + (s & 7)];
                 if (qp == npad) { if (C.t2v[e] != 0.0) return -7.0; }
                 else if (qp >= (K - 1 - C.n1b) * 64) return -7.0;   // tier 2 lies in front of tier 1's window
+                if (qp != npad && (qp >> 6) > C.t2need[(size_t)(B.t2_off + s) / 8]) return -9.0;   // the gate of the group covers every entry
                 g2 = std::fma(-C.t2v[e], W[(size_t)qp], g2);
             }
             double s1 = 0.0;
             const int base = std::max(0, (K - 1 - C.n1b) * 64);
             for (int s = 0; s < B.t1_n; ++s) {
                 const size_t e = ((size_t)B.t1_off + s) * 64 + j;
-                const int r = C.t1c[e];
+                const int r = C.t1c[(((size_t)(B.t1_off + s) >> 3) * 64 + (size_t)j) * 8 + (s & 7)];
                 int qp;
                 if (r >= C.rx) { if (r != C.rx || C.t1v[e] != 0.0) return -7.0; qp = npad; }
                 else { qp = base + ((r - base % C.rx) + C.rx) % C.rx; if (qp >= (K - 1) * 64 || qp < base) return -7.0; }
+                if (qp != npad && (qp >> 6) > C.t1need[(size_t)(B.t1_off + s) / 8]) return -9.0;
                 s1 = std::fma(-C.t1v[e], W[(size_t)qp], s1);
             }
             accA[(size_t)j] = (g2 + s1) + accB[(size_t)j];

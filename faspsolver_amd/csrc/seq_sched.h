@@ -54,6 +54,7 @@ struct ChainHost {
     Buf<ChainBlk>       blk;
     Buf<double>         t1v, t2v;
     Buf<unsigned short> t1c, t2c;   // tier 1: ring index of the column's position (padding: rx); tier 2: the position (padding: npad)
+    Buf<int>            t1need, t2need;   // per group of eight steps: the newest block its entries read (-1: padding only)
 };
 
 struct SplitHost {

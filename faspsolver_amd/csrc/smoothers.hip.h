@@ -156,7 +156,7 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
         piece(&S.d_rval, H.rval.data(), (size_t)H.nrest);
         piece(&S.d_tr, H.tr.data(), 2 * (size_t)ns);
         piece(&S.d_rec, (const double*)nullptr, 2 * (size_t)ns, false);
-        piece(&S.d_W, (const double*)nullptr, (size_t)ns + 64, false);      // W[npad] = 0.0: the operand of tier 2's padding entries
+        piece(&S.d_W, (const double*)nullptr, (size_t)ns + 128, false);     // W[npad] = 0.0: the operand of tier 2's padding entries; W[npad + 64 ..): scratch of the exporter
         piece(&S.d_G2, (const double*)nullptr, (size_t)ns, false);
         piece(&S.d_prog, zeros, 64);   // [0] role ticket, [1] error word, [2] tier-2 ticket
         piece(&S.d_band, Cc.band.data(), Cc.band.n);
@@ -167,6 +167,8 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
         piece(&S.d_t1c, Cc.t1c.data(), (size_t)Cc.t1_steps * 64);
         piece(&S.d_t2v, Cc.t2v.data(), (size_t)Cc.t2_steps * 64);
         piece(&S.d_t2c, Cc.t2c.data(), (size_t)Cc.t2_steps * 64);
+        piece(&S.d_t1need, Cc.t1need.data(), (size_t)Cc.t1_steps / 8);
+        piece(&S.d_t2need, Cc.t2need.data(), (size_t)Cc.t2_steps / 8);
         size_t total = 0;
         for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
         char* base = nullptr;
@@ -190,6 +192,20 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
         S.multicolor = false;
         return FASP_SUCCESS;
     }
+    piece(&d_strips, H.strips.data(), H.strips.size());
+    piece(&d_chunks, H.chunks.data(), 4 * (size_t)H.nchunk);
+    piece(&S.d_slots, H.slots.data(), (size_t)H.slot_bytes);
+    piece(&S.d_gpos, H.gpos.data(), (size_t)H.nghost);
+    piece(&S.d_cstrip, H.cstrip.data(), (size_t)H.nchunk);
+    piece(&S.d_lchunks, H.lchunks.data(), (size_t)H.nchunk);
+    piece(&S.d_ria, H.ria.data(), (size_t)ns + 1);
+    piece(&S.d_rja, H.rja.data(), (size_t)H.nrest);
+    piece(&S.d_rval, H.rval.data(), (size_t)H.nrest);
+    piece(&S.d_dr, H.dr.data(), 2 * (size_t)ns);
+    piece(&S.d_tr, H.tr.data(), 2 * (size_t)ns);
+    piece(&S.d_rec, (const double*)nullptr, 2 * (size_t)ns, false);
+    piece(&S.d_W, (const double*)nullptr, (size_t)ns, false);
+    piece(&S.d_prog, zeros, 64);   // [0] ticket counter, [1] error word
     size_t total = 0;
     for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
     char* base = nullptr;
@@ -425,13 +441,13 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         // pass (2), the chain form (seq_chain.hip.h): one workgroup walks the rows, the others sum what lies far behind it
         ChainArgs ca{};
         ca.band = (const f64x2_t*)S.d_band; ca.drd = (const f64x2_t*)S.d_drd; ca.blk = (const ChainBlk*)S.d_blk;
-        ca.t1v = S.d_t1v; ca.t1c = S.d_t1c; ca.t2v = S.d_t2v; ca.t2c = S.d_t2c; ca.rec = S.d_rec; ca.tr = S.d_tr;
-        ca.W = S.d_W; ca.G2 = S.d_G2; ca.u = D.x; ca.sync = S.d_prog; ca.nb = S.nb; ca.npad = S.npad; ca.rx = S.rx; ca.rg = S.rg; ca.form = form; ca.w = w;
+        ca.t1v = S.d_t1v; ca.t1c = S.d_t1c; ca.t1need = S.d_t1need; ca.t2v = S.d_t2v; ca.t2c = S.d_t2c; ca.t2need = S.d_t2need; ca.rec = S.d_rec; ca.tr = S.d_tr;
+        ca.W = S.d_W; ca.G2 = S.d_G2; ca.u = D.x; ca.sync = S.d_prog; ca.nb = S.nb; ca.npad = S.npad; ca.rx = S.rx; ca.rg = S.rg; ca.has_t2 = S.t2_steps > 0; ca.form = form; ca.w = w;
         const bool plain = g_tune.seq_chain_ref || !g_tune.seq_flow || g_flow_disabled;
         if (!plain && seq_err_check() < 0) return ERROR_MISC;   // an earlier sweep's time-out that has arrived meanwhile
-        const size_t dyn = sizeof(double) * ((size_t)S.rx + 1 + (size_t)S.rg);
+        const size_t dyn = sizeof(double) * ((size_t)S.rx + 1 + 2 * (size_t)S.rg);
         // tier-2 workgroups: enough wavefronts for a block per ~1.3 us at some tens of us per block and wave; the rest of the chip stays free
-        const int far_wg = S.t2_steps > 0 ? (g_tune.seq_chain_grid > 0 ? g_tune.seq_chain_grid : 15) : 0;
+        const int far_wg = S.t2_steps > 0 ? (g_tune.seq_chain_grid > 0 ? g_tune.seq_chain_grid : 47) : 0;
 #define CHAIN_LAUNCH(FF)                                                                                              \
         if (plain) hipLaunchKernelGGL((k_tri_chain_ref<FF>), dim3(1), dim3(64), 0, g_ctx.stream, ca, S.n1b);             \
         else hipLaunchKernelGGL((k_tri_chain<FF>), dim3(1 + far_wg), dim3(CHAIN_NT), dyn, g_ctx.stream, ca)

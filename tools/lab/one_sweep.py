@@ -1,0 +1,8 @@
+import os, sys
+sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/faspsolver_amd') else os.getcwd())
+import faspsolver_amd as fa
+n = int(sys.argv[1]); lev = int(sys.argv[2]); kind = int(sys.argv[3])
+ia, ja, a, f, ue = fa.poisson7pt(n)
+H = fa.AMG(ia, ja, a, fa.param_amg_init())
+H.set_rhs(f)
+print("time", H.time_kernel(kind, lev, 1) * 1e3, "us", flush=True)
