@@ -251,6 +251,7 @@ int  comm_rank() { return g_rank; }
 int  comm_size() { return g_size; }
 bool comm_failed() { return g_comm_failed || (g_backend == IPC && g_ipc.err && *g_ipc.err != 0u); }
 static bool g_ipc_shared_device = false;
+bool comm_is_peer_window() { return g_backend == IPC; }
 bool comm_shares_devices() { return g_backend == SHM || (g_backend == IPC && g_ipc_shared_device); }
 void comm_mark_failed() { g_comm_failed = true; }
 

@@ -11,6 +11,7 @@ int  comm_size();
 bool comm_failed();       // sticky: a collective failed on this rank or (SHM transport) on a peer
 void comm_mark_failed();
 bool comm_shares_devices();   // validation transport: several ranks may sit on one GPU (no kernel may assume it owns the chip)
+bool comm_is_peer_window();   // the transport is hipIpc-mapped device windows (one small kernel per exchange / all-gather: comm_ipc.h)
 // sum-reduce (and max-reduce the entries whose bit is set in maxmask) n doubles in
 // place across all ranks, on `stream`.  No-op when comm_size() == 1.
 int  comm_allreduce(double* dbuf, int n, unsigned maxmask, hipStream_t stream);

@@ -215,8 +215,13 @@ static int g_halo_overlap = 1;   // fasp_hip_tune("halo_overlap", 0): exchange, 
 // is long against the collective's latency (DESIGN.md section 4 has the per-level model); the arithmetic of a row does
 // not depend on who computes it, so the iteration is the same one.  Operators with fewer rows than
 // `g_coarse_split_min` stay redundant.
-static int g_coarse_mode = 0, g_coarse_split_min = 16384;
-static bool coarse_split_active(const DevCSR& M) { return g_coarse_mode == 1 && comm_size() > 1 && M.row >= g_coarse_split_min; }
+// Round 5: mode -1 (the default) = split where the transport makes the all-gather cheap -- peer windows: one small kernel, no
+// library call -- and redundant otherwise (RCCL: a collective launch per operator; shared memory: a host round trip).
+static int g_coarse_mode = -1, g_coarse_split_min = 16384;
+static bool coarse_split_active(const DevCSR& M)
+{
+    return (g_coarse_mode == 1 || (g_coarse_mode < 0 && comm_is_peer_window())) && comm_size() > 1 && M.row >= g_coarse_split_min;
+}
 template <int OP>
 static int rep_launch(const DevCSR& M, CsrArgs a)
 {

@@ -2146,7 +2146,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "ja16")) g_tune.ja16 = value;
     else if (!std::strcmp(key, "device_sort")) g_device_sort = value;
     else if (!std::strcmp(key, "halo_overlap")) g_halo_overlap = value;
-    else if (!std::strcmp(key, "coarse_mode")) g_coarse_mode = value;            // replicated levels: 0 redundant work, 1 split rows + all-gather
+    else if (!std::strcmp(key, "coarse_mode")) g_coarse_mode = value;            // replicated levels: 0 redundant work, 1 split rows + all-gather, -1 (default) split over peer windows only
     else if (!std::strcmp(key, "coarse_split_min")) g_coarse_split_min = value;
     else if (!std::strcmp(key, "split_rows")) g_tune.split_rows = value;
     else if (!std::strcmp(key, "gs_multicolor")) g_tune.gs_multicolor = value;
@@ -2169,6 +2169,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
     else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;
     else if (!std::strcmp(key, "rp_stream")) g_tune.rp_stream = value;
+    else if (!std::strcmp(key, "rp_xshift")) g_tune.rp_xshift = value;   // coded pair sweep: offsets 0 / -1 / +1 out of the lane's own aligned load and wave shifts (1, default) or gathers of their own (0)
     else if (!std::strcmp(key, "rp_xcd")) g_tune.rp_xcd = value;
     else if (!std::strcmp(key, "rp_strip")) g_tune.rp_strip = value;   // coded operators of a 3-D grid: an XCD sweeps a strip of every plane (1: the square ones, 2: the transfer operators too, default) or a slab of planes (0)
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;

@@ -576,17 +576,23 @@ def test_config5_full_size_matches_reference(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("FASP_TEST_512") == "0", reason="switched off (FASP_TEST_512=0): 2 minutes of host setup, 50 GB of host memory")
 def test_config4_p7_512_on_one_gpu(gpu):
     """Config 4's system on ONE GPU: P7(512), 134 M DOF -- 31 iterations (the oracle's count on the same hierarchy,
     profiles/r03_check512_single_gpu.txt), the exact solution of the generator to discretisation-free 1e-5.
-    Runs by default (round 4); FASP_TEST_512=0 switches it off on hosts with less than ~60 GB of memory."""
+    FASP_TEST_512: "1" (the default) RUNS it and FAILS -- not skips -- when the host cannot hold the setup (~55 GB) or the
+    run takes longer than FASP_TEST_512_BUDGET_S (600 s): config 4 must not drop out of a driver run quietly; "0" switches the
+    test off on purpose (development hosts with little memory), which the skip reason then says."""
+    import time
+    mode = os.environ.get("FASP_TEST_512", "1")
+    if mode == "0":
+        pytest.skip("switched off on purpose (FASP_TEST_512=0): 2 minutes of host setup, 55 GB of host memory")
     try:
         avail_kb = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1])
     except Exception:
         avail_kb = 1 << 40
-    if avail_kb < 70 * (1 << 20):
-        pytest.skip(f"P7(512) needs ~55 GB of host memory for the setup, {avail_kb >> 20} GB available")
+    assert avail_kb >= 70 * (1 << 20), (f"P7(512) needs ~55 GB of host memory for the setup, {avail_kb >> 20} GB available: config 4 cannot be "
+                                        "checked on this host (FASP_TEST_512=0 switches the test off deliberately)")
+    t_start = time.perf_counter()
     n = 512
     ia, ja, a, f, ue = fa.poisson7pt(n)
     itp, amgp = _params()
@@ -598,3 +604,5 @@ def test_config4_p7_512_on_one_gpu(gpu):
     assert st == 31
     assert stats.relres <= 1e-8 and abs(stats.relres - 6.7071735872e-09) <= 1e-10
     assert np.max(np.abs(x - ue)) <= 1e-5
+    took = time.perf_counter() - t_start
+    assert took <= float(os.environ.get("FASP_TEST_512_BUDGET_S", "600")), f"P7(512) took {took:.0f} s (setup + solve): too slow for the driver's GPU step"
