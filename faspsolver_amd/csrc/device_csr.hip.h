@@ -671,7 +671,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 512, seq_jobs = 1, seq_spine = 1, seq_grid = 0, seq_chain = 1, seq_chain_n1 = 0, seq_chain_grid = 0, seq_chain_ref = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 2, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1, rp_xshift = 1; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 512, seq_jobs = 1, seq_spine = 1, seq_grid = 0, seq_chain = 1, seq_chain_n1 = 0, seq_chain_grid = 0, seq_chain_ref = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 2, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -772,7 +772,6 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
     // coded pair kernels: streaming hints on y / pattern ids / b where a vector does not fit the Infinity Cache beside the
     // others anyway (P7(256): level 0 yes -- 0.546 -> 0.519 GB, 93 -> 88 us; level 1, 67 MB vectors, no: 63 -> 73 us with hints)
     if (g_tune.rp_stream > 0 || (g_tune.rp_stream < 0 && (size_t)M.row * 8 > (size_t)96 << 20)) a.nt |= 4;
-    if (!g_tune.rp_xshift) a.nt |= 8;   // k_csr_rowpat4: the x-neighbours by misaligned gathers of their own, as before round 5 (A/B)
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
     a.ja16 = g_tune.ja16 ? M.ja16 : nullptr;
     if (M.kind == 1 || M.kind == 3) M.kind = 0;   // (block-level stream, one workgroup per row: measured slower, retired to tools/lab/)

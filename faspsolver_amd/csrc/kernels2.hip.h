@@ -551,21 +551,6 @@ __device__ __forceinline__ f64x2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t rs, uns
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0);
     return __builtin_bit_cast(f64x2_t, v);
 }
-// lane i takes lane i - 1's value (wave_shr:1) / lane i + 1's (wave_shl:1) across the whole wavefront; lane 0 / lane 63 keep their own
-__device__ __forceinline__ double wave_shr1_f64(double x)
-{
-    const long long b = __double_as_longlong(x);
-    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    const int l2 = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false), h2 = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)h2 << 32) | (unsigned)l2);
-}
-__device__ __forceinline__ double wave_shl1_f64(double x)
-{
-    const long long b = __double_as_longlong(x);
-    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    const int l2 = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false), h2 = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)h2 << 32) | (unsigned)l2);
-}
 
 // ---------------------------------------------------------------------------
 // k_csr_rowpat4<OP>: k_csr_rowpat3 without its divergent tail.  The sweep computes every row pair
@@ -588,7 +573,6 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
     int        qn = 0;   // wave-uniform
     const int  lane = threadIdx.x & 63;
     const bool stream = (a.nt & 4) != 0;   // wave-uniform: y, pattern ids and b with streaming (nt) hints
-    const bool xshift = (a.nt & 8) == 0;   // x-neighbours by wave shifts (fasp_hip_tune("rp_xshift", 0) sets the bit: A/B)
     constexpr bool NEG = (OP == OP_JACOBI || OP == OP_L1DIAG);
     const __amdgpu_buffer_rsrc_t xr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.x), 0, (int)((unsigned)a.ncol * 8u), 0x00020000);
@@ -690,31 +674,13 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat4(CsrArgs a)
         else if (OP == OP_L1DIAG) aux = *reinterpret_cast<const f64x2_t*>(a.diag + rs);
         double accA = NEG ? bb.x : 0.0, accB = NEG ? bb.y : 0.0;
         double xiA = 0.0, xiB = 0.0, dg = 0.0;
-        // Round 5: the x-neighbours come out of registers.  A lane's pair (x[ra], x[ra + 1]) -- offset 0 -- is one aligned 16-byte load;
-        // offset -1 is (the lane below's second value, this lane's first), offset +1 is (this lane's second, the lane above's first):
-        // two wave shifts (DPP) each instead of a misaligned 16-byte gather of their own -- two of the seven gathers of a 7-point row,
-        // a third to a half of a level-1 pattern.  The wave's edge lanes (0: offset -1; 63: offset +1) fetch theirs with ONE load in
-        // which every other lane is out of range (no memory access).  The same numbers in the same order: bit-identical.
-        f64x2_t x0 = {0.0, 0.0}, xm1 = {0.0, 0.0}, xp1 = {0.0, 0.0};
-        if (xshift) {
-            x0 = buf_load_f64x2(xr, baseA);
-            const f64x2_t edge = buf_load_f64x2(xr, lane == 0 ? baseA - 8u : lane == 63 ? baseA + 8u : 0xfffffff0u);
-            const double below = wave_shr1_f64(x0.y), above = wave_shl1_f64(x0.x);
-            xm1.x = lane == 0 ? edge.x : below; xm1.y = x0.x;
-            xp1.x = x0.y; xp1.y = lane == 63 ? edge.y : above;
-        }
         for (int k = 0; k < dlen; k += 8) {  // wave-uniform trip count; lists are padded to multiples of 8 (offset 0)
             int     of[8];
             f64x2_t xv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) of[u] = cpoff[dps + k + u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {   // (offsets are wave-uniform scalars: uniform branches)
-                if (xshift && of[u] == 0) xv[u] = x0;
-                else if (xshift && of[u] == -1) xv[u] = xm1;
-                else if (xshift && of[u] == 1) xv[u] = xp1;
-                else xv[u] = buf_load_f64x2(xr, baseA + (unsigned)(of[u] * 8));
-            }
+            for (int u = 0; u < 8; ++u) xv[u] = buf_load_f64x2(xr, baseA + (unsigned)(of[u] * 8));
             if (k == 0) flush();  // the previous step's result leaves behind this step's loads
             double w[8];
 #pragma unroll

@@ -2169,7 +2169,6 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
     else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;
     else if (!std::strcmp(key, "rp_stream")) g_tune.rp_stream = value;
-    else if (!std::strcmp(key, "rp_xshift")) g_tune.rp_xshift = value;   // coded pair sweep: offsets 0 / -1 / +1 out of the lane's own aligned load and wave shifts (1, default) or gathers of their own (0)
     else if (!std::strcmp(key, "rp_xcd")) g_tune.rp_xcd = value;
     else if (!std::strcmp(key, "rp_strip")) g_tune.rp_strip = value;   // coded operators of a 3-D grid: an XCD sweeps a strip of every plane (1: the square ones, 2: the transfer operators too, default) or a slab of planes (0)
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
