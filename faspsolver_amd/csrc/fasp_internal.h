@@ -92,6 +92,11 @@ struct HostLevel {
     bool     has_coarse = false;
 };
 
+// reorder.cpp: brick renumbering of a level (breadth-first balls of 64 rows inside chunks of `chunk` consecutive rows; order[k] = old
+// index of the row that gets the new index k) and the permutation of an operator's rows / columns (entries keep their storage order)
+void cluster_order(const HostCSR& A, int chunk, std::vector<int>& order);
+void permute_csr(const HostCSR& A, const int* rperm, const int* cinv, HostCSR& B);
+
 struct HostHierarchy {
     std::vector<HostLevel> L;
     double setup_seconds = 0.0;

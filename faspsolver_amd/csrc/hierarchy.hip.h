@@ -66,6 +66,8 @@ using namespace fasp;
 struct SchedJob { int level = 0, kind = 0, st = 0; bool uploaded = false; SplitHost H; DevLevel::Sched S; std::thread th; };   // S: the schedule on the device, uploaded by the job's own thread
 
 struct fasp_hip_amg {
+    // brick renumbering (upload_level): perm[l][k] = natural index of the row that level l's device copy numbers k (empty: natural order)
+    std::vector<std::vector<int>> perm;
     std::vector<std::unique_ptr<SchedJob>> sched_jobs;   // sequential smoothers: schedules being built side by side at the first sweep
     bool                  sched_jobs_started = false;
     std::mutex            sched_mu;    // jobs are started from the setup thread (natural-order sweeps) or the upload thread (C/F-ordered ones)
@@ -283,8 +285,63 @@ static int dist_launch(DevLevel& V, const DevCSR& M, CsrArgs a, const DevLevel* 
     return (hst < 0 || !local_ok) ? -1 : G;
 }
 
+// ---- brick renumbering of the uncoded mid levels (round 5; reorder.cpp) ---------------------------------------------------
+// Levels 1 .. n-2 whose operators are not row-pattern / dictionary coded are renumbered in breadth-first balls of 64 rows when the
+// smoother does not depend on the order of the rows (Jacobi, L1): A_l with rows and columns permuted, R_{l-1} / P_{l-1} and
+// R_l / P_l with the side that lives on level l permuted; the vectors of such a level simply live in the new order (level 0 and the
+// coarsest level -- whose safe CG sums dot products -- keep theirs).  Row sums keep their storage order: a cycle is bit-identical
+// with and without it (tests/test_gpu_scale.py::test_renumbered_levels_are_bit_transparent).  Not for the sequential smoothers (they
+// sweep in index order), the recursive cycles and coarse scaling (dot products on the mid levels), row-partitioned hierarchies.
+static bool renumber_allowed(const fasp_hip_amg* h)
+{
+    const AMG_param& p = h->param;
+    return g_tune.renumber != 0 && comm_size() == 1 && (p.smoother == SMOOTHER_JACOBI || p.smoother == SMOOTHER_L1DIAG) &&
+           (p.cycle_type == V_CYCLE || p.cycle_type == W_CYCLE || p.cycle_type == VW_CYCLE || p.cycle_type == WV_CYCLE) &&
+           p.coarse_scaling != 1 && p.AMG_type == CLASSIC_AMG;
+}
+static bool dev_coded(const DevCSR& M) { return M.pat != nullptr || M.code != nullptr; }
+
+// the transfer operators between levels l and l + 1 (P_l: rows of level l; R_l: rows of level l + 1), in the numberings of both
+static int upload_transfer(fasp_hip_amg* h, int l, const DistLevel* DLp)
+{
+    const HostLevel& HL = h->H.L[l];
+    DevLevel& D = h->L[l];
+    const bool rep = !DLp || DLp->replicated;
+    const std::vector<int>* pf = (size_t)l < h->perm.size() && !h->perm[(size_t)l].empty() ? &h->perm[(size_t)l] : nullptr;
+    const std::vector<int>* pc = (size_t)l + 1 < h->perm.size() && !h->perm[(size_t)l + 1].empty() ? &h->perm[(size_t)l + 1] : nullptr;
+    if (pf || pc) {
+        std::vector<int> invf, invc;
+        if (pf) { invf.resize(pf->size()); for (size_t k = 0; k < pf->size(); ++k) invf[(size_t)(*pf)[k]] = (int)k; }
+        if (pc) { invc.resize(pc->size()); for (size_t k = 0; k < pc->size(); ++k) invc[(size_t)(*pc)[k]] = (int)k; }
+        HostCSR T;
+        permute_csr(HL.P, pf ? pf->data() : nullptr, pc ? invc.data() : nullptr, T);
+        if (upload_csr(T, D.P) < 0) return ERROR_ALLOC_MEM;
+        HIPCK(hipStreamSynchronize(g_ctx.stream));   // (T goes away)
+        permute_csr(HL.R, pc ? pc->data() : nullptr, pf ? invf.data() : nullptr, T);
+        if (upload_csr(T, D.R) < 0) return ERROR_ALLOC_MEM;
+        HIPCK(hipStreamSynchronize(g_ctx.stream));
+    } else {
+        if (upload_csr(rep ? HL.P : DLp->P, D.P) < 0) return ERROR_ALLOC_MEM;
+        if (upload_csr(rep ? HL.R : DLp->R, D.R) < 0) return ERROR_ALLOC_MEM;
+    }
+    // the grid plane of the transfer operators (XCD strips of the coded kernels, device_csr.hip.h): P's rows are this level's, R's
+    // the next one's -- where the coarse rows are an exact fraction of the fine plane
+    if (D.A.plane > 0 && D.R.row > 0 && D.R.col > 0) {
+        D.P.plane = D.A.plane;
+        const long long pr = (long long)D.A.plane * D.R.row;
+        if (pr % D.R.col == 0) D.R.plane = (int)(pr / D.R.col);
+    }
+    if (!rep) {
+        D.R.win_lo = DLp->winR[0]; D.R.win_hi = DLp->winR[1];
+        D.P.win_lo = DLp->winP[0]; D.P.win_hi = DLp->winP[1];
+    }
+    return FASP_SUCCESS;
+}
+
 // One level to the device.  DL == nullptr: single rank, the level is whole (the overlapped upload of
 // fasp_hip_amg_create runs this from a second thread while the host setup builds the next levels).
+// With the renumbering allowed, the transfer operators of level l - 1 go up in THIS level's turn: only now is it known whether
+// level l is smoothed (has a coarser level) and how it is numbered.
 static int upload_level(fasp_hip_amg* h, int l, const DistLevel* DLp)
 {
     const HostLevel& HL = h->H.L[l];
@@ -302,36 +359,54 @@ static int upload_level(fasp_hip_amg* h, int l, const DistLevel* DLp)
         std::printf("    [upload level %d] %-10s %8.3f s\n", l, what, now - tp);
         tp = now;
     };
+    const bool renum = renumber_allowed(h);
+    if (h->perm.size() < h->L.size()) h->perm.resize(h->L.size());
+    HostCSR Aperm;                 // the level's matrix in its device numbering (when renumbered)
+    const HostCSR* Adev = &A;
     if (!rep && g_tune.local_square) {   // (the flag only steers the lossless coding of the device copy)
         HostCSR view;
         view.row = A.row; view.col = A.col; view.nnz = A.nnz; view.row_aligned = true;
         view.ia.view(const_cast<int*>(A.ia.data()), A.ia.n); view.ja.view(const_cast<int*>(A.ja.data()), A.ja.n); view.val.view(const_cast<double*>(A.val.data()), A.val.n);
         if (upload_csr(view, D.A) < 0) return ERROR_ALLOC_MEM;
-    } else if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;
+    } else {
+        // renumber this level?  Not level 0, not the coarsest, not behind a coded level (its coded transfer operators carry this level's
+        // numbering in their patterns), not a level that is coded itself (short rows: tried in natural order first).
+        // Levels of more than two million rows stay as they are: measured on the variable-coefficient twin of P7(256), level 1 (8.4 M rows,
+        // 19 entries per row) gains 3 % per operator and costs the upload thread six seconds (profiles/r05_renumber.txt).
+        bool want = renum && rep && l > 0 && HL.has_coarse && A.row >= 4096 && A.row <= 2000000 && !dev_coded(h->L[(size_t)l - 1].A);
+        bool uploaded = false;
+        if (want && compress_enabled() && (double)A.nnz <= 48.0 * A.row) {
+            if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;
+            if (dev_coded(D.A)) { want = false; uploaded = true; }
+            else { HIPCK(hipStreamSynchronize(g_ctx.stream)); D.A.release(); D.A = DevCSR(); }
+        }
+        if (want) {
+            std::vector<int>& pm = h->perm[(size_t)l];
+            cluster_order(A, std::max(4096, g_tune.renumber_chunk), pm);
+            std::vector<int> inv(pm.size());
+            for (size_t k = 0; k < pm.size(); ++k) inv[(size_t)pm[k]] = (int)k;
+            permute_csr(A, pm.data(), inv.data(), Aperm);
+            Adev = &Aperm;
+            lap("renumber");
+        }
+        if (!uploaded && upload_csr(*Adev, D.A) < 0) return ERROR_ALLOC_MEM;
+    }
     lap("A");
-    if (HL.has_coarse) {
-        if (upload_csr(rep ? HL.P : DLp->P, D.P) < 0) return ERROR_ALLOC_MEM;
-        lap("P");
-        if (upload_csr(rep ? HL.R : DLp->R, D.R) < 0) return ERROR_ALLOC_MEM;
-        // the grid plane of the transfer operators (XCD strips of the coded kernels, device_csr.hip.h): P's rows are this level's, R's
-        // the next one's -- where the coarse rows are an exact fraction of the fine plane
-        if (D.A.plane > 0 && D.R.row > 0 && D.R.col > 0) {
-            D.P.plane = D.A.plane;
-            const long long pr = (long long)D.A.plane * D.R.row;
-            if (pr % D.R.col == 0) D.R.plane = (int)(pr / D.R.col);
+    if (renum) {   // the transfer operators of the level above, now that this level's numbering is known
+        if (l > 0 && h->H.L[(size_t)l - 1].has_coarse && !h->L[(size_t)l - 1].P.ia) {
+            const int st = upload_transfer(h, l - 1, nullptr);
+            if (st < 0) return st;
+            lap("P, R of the level above");
         }
-        lap("R");
+    } else if (HL.has_coarse) {
+        const int st = upload_transfer(h, l, DLp);
+        if (st < 0) return st;
+        lap("P, R");
     }
-    if (!rep) {   // interior windows (dist_launch), found with the partition (dist_plan.cpp)
-        D.A.win_lo = DLp->winA[0]; D.A.win_hi = DLp->winA[1];
-        if (HL.has_coarse) {
-            D.R.win_lo = DLp->winR[0]; D.R.win_hi = DLp->winR[1];
-            D.P.win_lo = DLp->winP[0]; D.P.win_hi = DLp->winP[1];
-        }
-    }
+    if (!rep) { D.A.win_lo = DLp->winA[0]; D.A.win_hi = DLp->winA[1]; }   // interior windows (dist_launch), found with the partition (dist_plan.cpp)
     HIPCK(hipStreamSynchronize(g_ctx.stream));
     lap("sync");
-    if (upload_diag(A, D) < 0) return ERROR_ALLOC_MEM;
+    if (upload_diag(*Adev, D) < 0) return ERROR_ALLOC_MEM;
     lap("diag");
     const size_t n = D.nvec;
     if (l > 0) { if (alloc_vec(&D.b, n) < 0) return ERROR_ALLOC_MEM; }

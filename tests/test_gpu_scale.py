@@ -260,6 +260,52 @@ def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variable", [False, True], ids=["P7", "variable-kappa"])
+@pytest.mark.parametrize("smoother", [T.SMOOTHER_JACOBI, T.SMOOTHER_L1DIAG], ids=["jacobi", "l1"])
+def test_renumbered_levels_are_bit_transparent(gpu, variable, smoother):
+    """Round 5: the uncoded mid levels are renumbered in breadth-first balls of 64 rows at upload (csrc/reorder.cpp, hierarchy.hip.h:
+    A_l, R_l, P_l permuted, the level's vectors live in the new order; level 0 and the coarsest level keep theirs) when the smoother
+    does not depend on the order of the rows.  The stream kernels (levels of up to 48 entries per row) sum a row in its storage order:
+    their results are BIT-IDENTICAL with and without it.  The sub-wavefront kernel of the long-row levels works on a device copy whose
+    rows are sorted by COLUMN -- it never followed the storage order -- so there the association of a row sum follows the numbering:
+    the same products, differences of an ulp.  Hence: one cycle (V and W) to 1e-13 of its largest entry, equal iteration counts, residual
+    histories to 1e-9, solutions to 1e-11 -- with the default chunks and with small ones (balls across many seams); and the parity pins of
+    this file (reference runs at 64^3 .. 256^3) hold with the renumbering on, which is the default."""
+    n = 56
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    if variable:
+        ia, ja, a, f = fa.poisson7pt_var(n)
+    L = fa.lib()
+    r = np.random.default_rng(23).standard_normal(len(f))
+    out = {}
+    kinds = {}
+    try:
+        for cyc in (1, 2):
+            for ren, chunk in ((1, 262144), (0, 262144), (1, 4096)):
+                itp, amgp = _params()
+                amgp.smoother = smoother; amgp.cycle_type = cyc
+                L.fasp_hip_tune(b"renumber", ren); L.fasp_hip_tune(b"renumber_chunk", chunk)
+                H = fa.AMG(ia, ja, a, amgp)
+                z1 = H.precond(r)
+                st, x, hist, stats = H.solve(f, itp)
+                out[(cyc, ren, chunk)] = (z1, st, x, hist)
+                kinds[(cyc, ren, chunk)] = [H.kernel_info(l, 0)[0] for l in range(H.num_levels)]
+                H.close()
+    finally:
+        L.fasp_hip_tune(b"renumber", 1); L.fasp_hip_tune(b"renumber_chunk", 262144)
+    for cyc in (1, 2):
+        base = out[(cyc, 0, 262144)]
+        assert np.all(np.isfinite(base[0])) and base[1] > 0
+        for key in ((cyc, 1, 262144), (cyc, 1, 4096)):
+            z1, st, x, hist = out[key]
+            assert np.abs(z1 - base[0]).max() <= 1e-13 * np.abs(base[0]).max(), key
+            assert st == base[1] and np.allclose(hist[:-1], base[3][:-1], rtol=1e-9, atol=0.0), key
+            assert np.abs(x - base[2]).max() <= 1e-11 * np.abs(base[2]).max(), key
+        assert not np.array_equal(out[(cyc, 1, 262144)][0], base[0]) or not variable   # (something really was renumbered)
+    assert len(kinds[(1, 1, 262144)]) >= 5   # (levels 1 .. n-2 exist: something was there to renumber)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("smoother,order,w", [(T.SMOOTHER_GS, 1, 1.0), (T.SMOOTHER_GS, 0, 1.0), (T.SMOOTHER_SOR, 0, 1.1)],
                          ids=["GS-CF", "GS-natural", "SOR-natural"])
 def test_chain_form_kernels_agree_bit_for_bit(gpu, smoother, order, w):
