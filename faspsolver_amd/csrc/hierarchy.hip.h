@@ -373,7 +373,7 @@ static int upload_level(fasp_hip_amg* h, int l, const DistLevel* DLp)
         // numbering in their patterns), not a level that is coded itself (short rows: tried in natural order first).
         // Levels of more than two million rows stay as they are: measured on the variable-coefficient twin of P7(256), level 1 (8.4 M rows,
         // 19 entries per row) gains 3 % per operator and costs the upload thread six seconds (profiles/r05_renumber.txt).
-        bool want = renum && rep && l > 0 && HL.has_coarse && A.row >= 4096 && A.row <= 2000000 && !dev_coded(h->L[(size_t)l - 1].A);
+        bool want = renum && rep && l > 0 && HL.has_coarse && A.row >= 4096 && A.row <= 2000000 && (g_tune.renumber >= 2 || !dev_coded(h->L[(size_t)l - 1].A));   // (renumber = 2: also behind a coded level -- its transfer operators then lose their coding: A/B)
         bool uploaded = false;
         if (want && compress_enabled() && (double)A.nnz <= 48.0 * A.row) {
             if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;
