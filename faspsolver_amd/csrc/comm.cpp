@@ -208,8 +208,8 @@ unsigned* ipc_counters_for(hipStream_t s)
     if (g_ipc.nstreams < 4) { g_ipc.streams[g_ipc.nstreams] = s; return g_ipc.counters + 2 * g_ipc.nstreams++; }
     return nullptr;   // (more streams than the solver has: an error -- sharing a pair of last-block counters between streams is a race)
 }
-// one exchange kernel: my messages into the peers' mailboxes, theirs out of mine
-int ipc_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int nrecv, hipStream_t stream)
+// one exchange kernel: my messages into the peers' mailboxes, theirs out of mine (every message at most a mailbox long)
+int ipc_exchange_once(const CommXfer* sends, int nsend, const CommXfer* recvs, int nrecv, hipStream_t stream)
 {
     IpcXchgArgs a{};
     long long total = 0;
@@ -244,6 +244,23 @@ int ipc_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int nr
     if (!a.counters) { std::fprintf(stderr, "### ERROR: fasp_hip: peer-window exchanges issued on more than four streams\n"); return ERROR_MISC; }
     a.err = g_ipc.err;
     return ipc_xchg_launch(a, total, stream) < 0 ? ERROR_MISC : FASP_SUCCESS;
+}
+// Messages longer than a mailbox (FASP_HIP_IPC_CAP doubles: a halo plane of more than 4 MB) go in pieces, as the all-gather's blocks
+// do: sender and receiver of a pair know the same count, so both cut it the same way and number the pieces alike.
+int ipc_exchange(const CommXfer* sends, int nsend, const CommXfer* recvs, int nrecv, hipStream_t stream)
+{
+    size_t longest = 0;
+    for (int i = 0; i < nsend; ++i) longest = std::max(longest, sends[i].count);
+    for (int i = 0; i < nrecv; ++i) longest = std::max(longest, recvs[i].count);
+    if (longest <= g_ipc.cap) return ipc_exchange_once(sends, nsend, recvs, nrecv, stream);
+    std::vector<CommXfer> s((size_t)nsend), r((size_t)nrecv);
+    for (size_t off = 0; off < longest; off += g_ipc.cap) {
+        for (int i = 0; i < nsend; ++i) { s[(size_t)i] = sends[i]; s[(size_t)i].buf = sends[i].buf + std::min(off, sends[i].count); s[(size_t)i].count = sends[i].count > off ? std::min(g_ipc.cap, sends[i].count - off) : 0; }
+        for (int i = 0; i < nrecv; ++i) { r[(size_t)i] = recvs[i]; r[(size_t)i].buf = recvs[i].buf + std::min(off, recvs[i].count); r[(size_t)i].count = recvs[i].count > off ? std::min(g_ipc.cap, recvs[i].count - off) : 0; }
+        const int st = ipc_exchange_once(s.data(), nsend, r.data(), nrecv, stream);
+        if (st < 0) return st;
+    }
+    return FASP_SUCCESS;
 }
 }  // namespace
 

@@ -278,7 +278,8 @@ static void sched_job_launch(fasp_hip_amg* h, int level, int kind, int team)
         hipStream_t st = nullptr;
         if (J->st == FASP_SUCCESS && hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
             J->st = upload_split(J->H, J->S, st);
-            J->uploaded = true;
+            J->uploaded = J->st == FASP_SUCCESS;   // (a failed upload has released what it had allocated: nothing to hand over)
+            if (!J->uploaded) J->S.release();
             (void)hipStreamDestroy(st);
             J->H = SplitHost();
         }

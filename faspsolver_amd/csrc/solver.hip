@@ -440,6 +440,18 @@ int fasp_hip_amg_create(fasp_hip_amg** out, const dCSRmat* A, AMG_param* amgpara
         up.th.join();
         lap("wait for the level uploads");
         if (st >= 0) st = up.status;
+        // Schedules started early (sweeps in natural order start the moment a level's matrix is final) for the level that turned out to be
+        // the coarsest -- it is solved, not smoothed -- are given back now instead of holding device memory until the hierarchy goes.
+        {
+            const int last = (int)h->H.L.size() - 1;
+            std::lock_guard<std::mutex> lk(h->sched_mu);
+            for (auto& J : h->sched_jobs)
+                if (J && J->level >= last) {
+                    if (J->th.joinable()) J->th.join();
+                    if (J->uploaded) J->S.release();
+                    J.reset();
+                }
+        }
         if (st < 0) { h->L.resize(h->H.L.size()); fasp_hip_amg_destroy(h); return st; }
         h->param = *amgparam;
     } else {

@@ -180,6 +180,7 @@ def test_peer_windows_with_small_mailboxes_and_turn_taking_sweeps(gpu, monkeypat
     from _libs import T
     monkeypatch.setenv("FASP_HIP_IPC_CAP", "1024")
     _run_ranks(2, 32, 3000, 1, transport="ipc")
+    _run_ranks(2, 40, 3000, 1, transport="ipc")   # (round 5: the level-0 halo of P7(40) is 1 600 doubles -- longer than a mailbox: sent in two pieces)
     monkeypatch.delenv("FASP_HIP_IPC_CAP")
     _run_ranks(3, 24, 800, 1, transport="ipc", smoother=T.SMOOTHER_GS, tune="seq_partition=1", smooth_order=1)
 
