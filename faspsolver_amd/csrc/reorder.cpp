@@ -81,3 +81,31 @@ void cluster_order(const HostCSR& A, int chunk, std::vector<int>& order)
 
 }  // namespace fasp
 
+
+extern "C" {
+// test entries (host only; include/fasp_hip_dev.h): the brick order of a square matrix (order[k] = old index at new position k), and an
+// operator with rows / columns renumbered (rperm / cinv may be NULL; B's arrays are allocated with fasp_mem_calloc semantics: malloc)
+int fasp_hip_cluster_order(const dCSRmat* A, int chunk, int* order)
+{
+    if (!A || !order || A->row != A->col) return ERROR_INPUT_PAR;
+    fasp::HostCSR M;
+    M.row = A->row; M.col = A->col; M.nnz = A->nnz;
+    M.ia.view(A->IA, (size_t)A->row + 1); M.ja.view(A->JA, (size_t)std::max(A->nnz, 1)); M.val.view(A->val, (size_t)std::max(A->nnz, 1));
+    std::vector<int> o;
+    fasp::cluster_order(M, chunk, o);
+    std::copy(o.begin(), o.end(), order);
+    return FASP_SUCCESS;
+}
+int fasp_hip_permute_csr(const dCSRmat* A, const int* rperm, const int* cinv, int* ia, int* ja, double* val)
+{
+    if (!A || !ia || !ja || !val) return ERROR_INPUT_PAR;
+    fasp::HostCSR M, B;
+    M.row = A->row; M.col = A->col; M.nnz = A->nnz;
+    M.ia.view(A->IA, (size_t)A->row + 1); M.ja.view(A->JA, (size_t)std::max(A->nnz, 1)); M.val.view(A->val, (size_t)std::max(A->nnz, 1));
+    fasp::permute_csr(M, rperm, cinv, B);
+    std::copy(B.ia.data(), B.ia.data() + A->row + 1, ia);
+    std::copy(B.ja.data(), B.ja.data() + A->nnz, ja);
+    std::copy(B.val.data(), B.val.data() + A->nnz, val);
+    return FASP_SUCCESS;
+}
+}

@@ -30,6 +30,12 @@ double fasp_hip_seq_schedule_selftest(const dCSRmat* A, const int* seq, int ns, 
  * sweep; < 0: error (-2: the form does not apply).  n1_blocks: blocks of 64 rows in tier 1 (0: chosen).  info (may be NULL, 10 ints):
  * {blocks, tier-1 blocks, x ring, G ring, tier-1 steps, tier-2 steps, band entries, tier-1 entries, tier-2 entries, dependency classes};
  * out_u (may be NULL, max(row, col) doubles): the swept vector (input: u_i = sin(0.37 i) + 0.1, b_i = cos(0.11 i)) */
+/* test entries (host only, no GPU): the brick renumbering of the uncoded mid levels (csrc/reorder.cpp, round 5).  fasp_hip_cluster_order:
+ * order[k] = old index of the row that gets the new index k -- breadth-first balls of 64 rows grown inside chunks of `chunk` consecutive rows.
+ * fasp_hip_permute_csr: row k of the result is row rperm[k] of A (NULL: rows keep their numbers), column j becomes cinv[j] (NULL: kept); the
+ * entries of a row keep their storage order.  ia / ja / val: caller's arrays of row + 1 / nnz / nnz entries. */
+int fasp_hip_cluster_order(const dCSRmat* A, int chunk, int* order);
+int fasp_hip_permute_csr(const dCSRmat* A, const int* rperm, const int* cinv, int* ia, int* ja, double* val);
 double fasp_hip_seq_chain_selftest(const dCSRmat* A, const int* seq, int ns, int n1_blocks, int form, double w, int* info, double* out_u);
 /* measured device ceilings reported beside the roofline: out[0..2] = GB/s of a 16-byte-per-lane read, copy and
  * triad over buffers of `bytes` each (>= 512 MiB: beyond the Infinity Cache) */
