@@ -17,7 +17,7 @@ roofline = the level-0 SpMV kernel the solve runs (t = A p fused with the (t,p) 
            + y once) / mean launch time measured with HIP events on the launch stream inside
            the timed solves; frac = that / 8 TB/s, never above 1.  traffic = memory-side bytes
            per launch from the rocprofv3 PMC passes of this same command (tools/profile.sh ->
-           profiles/r04_rocprof/traffic.json, falling back to the previous round's: 2 x FETCH_SIZE +
+           profiles/r05_rocprof/traffic.json, falling back to the previous round's: 2 x FETCH_SIZE +
            WRITE_SIZE, separate passes).
 roofline_plain_csr = the same operator through the plain-CSR kernel (lossless coding switched
            off for these launches): SURVEY 8(d)'s algorithmic bytes 12 nnz + 4 (m+1) + 8 m + 8 m
@@ -68,8 +68,8 @@ from faspsolver_amd import _types as T  # noqa: E402
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # PMC traffic summaries of THIS command, one per workload (tools/profile.sh <tag> <workload> -> tools/summarize_prof.py);
 # a figure is attached to a roofline entry only when kernel name, workload and grid size all match the run
-TRAFFIC_JSONS = {"constant": os.path.join("profiles", "r04_rocprof", "traffic.json"),
-                 "variable": os.path.join("profiles", "r04_rocprof_var", "traffic.json")}
+TRAFFIC_JSONS = {"constant": [os.path.join("profiles", r + "_rocprof", "traffic.json") for r in ("r05", "r04")],
+                 "variable": [os.path.join("profiles", r + "_rocprof_var", "traffic.json") for r in ("r05", "r04")]}
 
 # kernel family codes of fasp_hip_amg_kernel_info -> (rocprofv3 kernel name of the OP_MXV_DOT instantiation, description)
 KERNELS = {0: ("k_csr_rows", "k_csr_rows<L, OP_MXV_DOT> (sub-wavefront per row, plain CSR)"),
@@ -269,18 +269,16 @@ def baseline_candidates():
 def pmc_traffic(kernel_name, workload, n):
     """(bytes per launch, source file) of a kernel from the committed PMC summary of this command for THIS workload
     and grid size; (None, None) when there is no pass of exactly this kernel instantiation on this workload."""
-    rel = TRAFFIC_JSONS.get(workload)
-    if rel is None:
-        return None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, rel)))
-        if tj.get("workload") != workload or int(tj.get("n", -1)) != int(n):
-            return None, None
-        rec = tj.get("kernels", {}).get(kernel_name)   # exact instantiation name, e.g. "k_csr_lstream<7, 512>"
-        if rec is not None:
-            return float(rec["bytes_per_launch"]), rel
-    except Exception:
-        pass
+    for rel in TRAFFIC_JSONS.get(workload, []):   # this round's summary, else the previous round's
+        try:
+            tj = json.load(open(os.path.join(ROOT, rel)))
+            if tj.get("workload") != workload or int(tj.get("n", -1)) != int(n):
+                continue
+            rec = tj.get("kernels", {}).get(kernel_name)   # exact instantiation name, e.g. "k_csr_lstream<7, 512>"
+            if rec is not None:
+                return float(rec["bytes_per_launch"]), rel
+        except Exception:
+            continue
     return None, None
 
 

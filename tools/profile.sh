@@ -5,7 +5,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export OMP_NUM_THREADS=${OMP_NUM_THREADS:-32}
-TAG=${1:-r04}
+TAG=${1:-r05}
 WL=${2:-constant}
 if [ "$WL" = "variable" ]; then
   OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_var
