@@ -37,7 +37,7 @@ struct DevLevel {
         // chain form (seq_chain.hip.h): band planes, per-position records, the two tiers, tier 2's sums
         bool chain = false; int nb = 0, npad = 0, n1b = 0, rx = 0, rg = 0; long long t1_steps = 0, t2_steps = 0, nband = 0, nt1 = 0, nt2 = 0;
         double* d_band = nullptr; double* d_drd = nullptr; void* d_blk = nullptr; double* d_t1v = nullptr; double* d_t2v = nullptr;
-        unsigned short* d_t1c = nullptr; unsigned short* d_t2c = nullptr; double* d_G2 = nullptr; int* d_t1need = nullptr; int* d_t2need = nullptr; int* d_bsched = nullptr; long long nrounds = 0;
+        unsigned short* d_t1c = nullptr; unsigned short* d_t2c = nullptr; double* d_G2 = nullptr; int* d_t1need = nullptr; int* d_t2need = nullptr;
         std::vector<void*> owned;   // device arrays of the split form (d_order and d_ptr among them)
         void release()
         {

@@ -33,7 +33,6 @@ struct ChainArgs {
     const f64x2_t*        band;   // (nb * 64 + CHAIN_PF) steps x 64 lanes x (TA, TB)
     const f64x2_t*        drd;    // npad x (a_ii, 1 / a_ii)
     const ChainBlk*       blk;
-    const int*            bsched; // CHAIN_BS ints per block: the order of its 64 steps (rounds: seq_sched.h)
     const double*         t1v; const unsigned short* t1c; const int* t1need;   // values [step][lane]; columns [group of 8 steps][lane][8]; need: per group of eight steps, the newest BLOCK its entries read (-1: none)
     const double*         t2v; const unsigned short* t2c; const int* t2need;
     const double*         rec;    // 2 doubles per position, written by pass (1): b - rest, old u_i
@@ -63,33 +62,23 @@ __device__ __forceinline__ double chain_bcast(double x, int c)   // lane c's val
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, c), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), c);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// The 64 steps of one block, in the block's ROUND order (seq_sched.h): step k applies the value of row c_k.  When a round opens (bit k of
-// the mask) every lane forms its update from what it has accumulated -- the rows of the round are final together --; the steps of a round
-// are a broadcast (v_readlane, lane from the schedule) and two multiply-adds each, alternating between two accumulators, and do not wait
-// for each other.  Coefficients through the ring cf (CHAIN_PF steps in flight; refilled from `next`).  X: the updates as of the last round
-// opened -- after the block, the block's values.
-struct ChainAcc { double a0, a1, b0, b1; };
+// the 64 steps of one block: coefficients through the ring cf (CHAIN_PF steps in flight; refilled from `next`)
 template <int FORM>
-__device__ __forceinline__ void chain_block(ChainAcc& A, double& X, double d, double rd, double w, double ku, f64x2_t (&cf)[CHAIN_PF], const f64x2_t* next,
-                                            const int (&tab)[16], unsigned mlo, unsigned mhi)
+__device__ __forceinline__ void chain_block(double& accA, double& accB, double d, double rd, double w, double ku, f64x2_t (&cf)[CHAIN_PF], const f64x2_t* next)
 {
 #pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        if (((k < 32 ? mlo : mhi) >> (k & 31)) & 1u) {   // (wave-uniform; a REAL branch: as a select the update's four dependent operations sit in every step's chain)
-            X = chain_update<FORM>(A.a0 + A.a1, d, rd, w, ku);
-            asm volatile("" : "+v"(X));
-        }
-        const int c = (tab[k >> 2] >> (8 * (k & 3))) & 0xff;
-        const unsigned long long b = (unsigned long long)__double_as_longlong(X);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, c), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), c);
-        const double sx = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-        if (k & 1) { A.a1 = __builtin_fma(-cf[k % CHAIN_PF][0], sx, A.a1); A.b1 = __builtin_fma(-cf[k % CHAIN_PF][1], sx, A.b1); }
-        else { A.a0 = __builtin_fma(-cf[k % CHAIN_PF][0], sx, A.a0); A.b0 = __builtin_fma(-cf[k % CHAIN_PF][1], sx, A.b0); }
-        asm volatile("" : "+v"(A.a0), "+v"(A.a1), "+v"(A.b0), "+v"(A.b1));   // (the accumulators exist here: code sinking would otherwise park their operands in scratch)
-        cf[k % CHAIN_PF] = next[(size_t)k * 64];     // (into the registers this step has just read)
-        __builtin_amdgcn_sched_barrier(0);   // a step is a step: left alone, the scheduler gathers the 64 loads of a block up front (256 registers and spills)
+    for (int c = 0; c < 64; ++c) {
+        const double x = chain_update<FORM>(accA, d, rd, w, ku);
+        const double sx = chain_bcast(x, c);
+        accA = __builtin_fma(-cf[c % CHAIN_PF][0], sx, accA);
+        accB = __builtin_fma(-cf[c % CHAIN_PF][1], sx, accB);
+        asm volatile("" : "+v"(accA), "+v"(accB));   // (both accumulators exist here: code sinking would otherwise park accB's operands in scratch)
+        cf[c % CHAIN_PF] = next[(size_t)c * 64];     // (into the registers this step has just read)
+        __builtin_amdgcn_sched_barrier(0);   // a step is a step: left alone, the scheduler gathers the 64 loads of a block up front (256 registers and
+                                             // spills) and defers accB's multiply-adds behind a table of spilled broadcasts
     }
 }
+
 
 // One lane's share of a tier: n steps (a multiple of 8) of (value, column), acc <- fma(-value, x[column], acc) in step order, as a
 // pipeline over groups of eight steps: the (value, column) pairs of the next CHAIN_NS - 1 groups travel (streams from HBM: one to two
@@ -147,7 +136,7 @@ __device__ __forceinline__ bool chain_spin(unsigned* sync, unsigned& spins, unsi
 // whose values are in the ring X (what tier 1 and the exporter wait for).  At a block boundary it takes the coming block's S1 (tier 1's
 // sum, from a helper) and G2 (tier 2's, brought in by the porter wave) from their rings in LDS: values that are their own flags.
 template <int FORM>
-__device__ __forceinline__ void chain_wave(const ChainArgs& a, double* Xr, double* S1, double* G2r, int* s_k, int* s_done, int* s_exp, int lane)
+__device__ __forceinline__ void chain_wave(const ChainArgs& a, double* X, double* S1, double* G2r, int* s_k, int* s_done, int* s_exp, int lane)
 {
     const double sent = __longlong_as_double((long long)FLOW_SENT);
     auto lds_get = [&](double* p) -> double { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
@@ -185,10 +174,7 @@ __device__ __forceinline__ void chain_wave(const ChainArgs& a, double* Xr, doubl
     const int ringb = a.rx / 64;
     f64x2_t dr = a.drd[lane];
     double uo = FORM == 2 ? a.rec[2 * (size_t)lane + 1] : 0.0;
-    ChainAcc A;
-    A.b0 = 0.0; A.b1 = 0.0; A.a1 = 0.0;
-    A.a0 = take_G(gi, sent, sent) + (A.b0 + A.b1);
-    double X = 0.0;
+    double accB = 0.0, accA = take_G(gi, sent, sent) + accB;
     CT(2);
 #ifdef CHAIN_TIMING
     ct[0] = ct[1] = ct[2] = ct[3] = 0;
@@ -206,23 +192,18 @@ __device__ __forceinline__ void chain_wave(const ChainArgs& a, double* Xr, doubl
         // an early look at the coming block's S1 and G2 (the helpers run ahead: normally there): their LDS round trip hides behind the steps
         const int gn = gi + 64 >= a.rg ? gi + 64 - a.rg : gi + 64;
         const double g2e = lds_get(G2r + gn), s1e = lds_get(S1 + gn);
-        int tab[16];   // the block's round schedule (seq_sched.h): through the scalar cache
-        const flow_int_cp bs = (flow_int_cp)(unsigned long long)(a.bsched + (size_t)K * CHAIN_BS);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tab[i] = bs[i];
-        const unsigned mlo = (unsigned)bs[16], mhi = (unsigned)bs[17];
         CT(2);
-        chain_block<FORM>(A, X, d, rd, a.w, ku, cf, bp + ((size_t)K * 64 + CHAIN_PF) * 64, tab, mlo, mhi);
+        chain_block<FORM>(accA, accB, d, rd, a.w, ku, cf, bp + ((size_t)K * 64 + CHAIN_PF) * 64);
         CT(0);
         // the ring slots of block K held block K - rx / 64: every helper that read it is done (rx = 64 (n1b + CHAIN_HA + 3)), and the
         // porter has exported it (it trails the chain by a block or two; checked, not assumed)
         while (K >= ringb && __hip_atomic_load(s_exp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= K - ringb) { if (chain_spin(a.sync, spins, t0)) break; }
-        lds_put(Xr + xi, X);
+        lds_put(X + xi, chain_update<FORM>(accA, d, rd, a.w, ku));
         if (lane == 0) __hip_atomic_store(s_done, K + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (behind the values: LDS operations of a wave complete in order)
         xi += 64; if (xi >= a.rx) xi -= a.rx;
         gi += 64; if (gi >= a.rg) gi -= a.rg;
         CT(2);
-        if (K + 1 < a.nb) { A.a0 = take_G(gi, g2e, s1e) + (A.b0 + A.b1); A.a1 = 0.0; A.b0 = 0.0; A.b1 = 0.0; }
+        if (K + 1 < a.nb) { accA = take_G(gi, g2e, s1e) + accB; accB = 0.0; }
     }
 #ifdef CHAIN_TIMING
     if (lane == 0) printf("[chain] %d blocks: per block %.0f cycles in the 64 steps, %.0f waiting for tier 1, %.0f for tier 2, %.0f other; %.3f ticks of clock64 per ns\n", a.nb, (double)ct[0] / a.nb, (double)ct[1] / a.nb, (double)ct[3] / a.nb, (double)ct[2] / a.nb,
@@ -449,7 +430,7 @@ template <int FORM>
 __global__ __launch_bounds__(64) void k_tri_chain_ref(ChainArgs a, int n1b)
 {
     const int lane = threadIdx.x;
-    double accB0 = 0.0, accB1 = 0.0;
+    double accB = 0.0;
     for (int K = 0; K < a.nb; ++K) {
         const ChainBlk B = a.blk[K];
         const int p = K * 64 + lane;
@@ -468,22 +449,20 @@ __global__ __launch_bounds__(64) void k_tri_chain_ref(ChainArgs a, int n1b)
             else { const int b0 = base > 0 ? base : 0; qp = b0 + ((r - b0 % a.rx) + a.rx) % a.rx; }
             s1 = __builtin_fma(-a.t1v[e], a.W[qp], s1);
         }
-        ChainAcc A;
-        A.a0 = (g2 + s1) + (accB0 + accB1); A.a1 = 0.0; A.b0 = 0.0; A.b1 = 0.0;
+        double accA = (g2 + s1) + accB;
+        accB = 0.0;
         const f64x2_t dr = a.drd[p];
         const double ku = FORM == 2 ? (1 - a.w) * a.rec[2 * (size_t)p + 1] : 0.0;
         const f64x2_t* bp = a.band + (size_t)K * 64 * 64 + lane;
-        const int* bs = a.bsched + (size_t)K * CHAIN_BS;
-        const unsigned long long mask = ((unsigned long long)(unsigned)bs[17] << 32) | (unsigned)bs[16];
-        double x = 0.0;
-        for (int k = 0; k < 64; ++k) {
-            if ((mask >> k) & 1ull) x = chain_update<FORM>(A.a0 + A.a1, dr[0], dr[1], a.w, ku);
-            const f64x2_t m = bp[(size_t)k * 64];
-            const double sx = __shfl(x, (bs[k >> 2] >> (8 * (k & 3))) & 0xff, 64);
-            if (k & 1) { A.a1 = __builtin_fma(-m[0], sx, A.a1); A.b1 = __builtin_fma(-m[1], sx, A.b1); }
-            else { A.a0 = __builtin_fma(-m[0], sx, A.a0); A.b0 = __builtin_fma(-m[1], sx, A.b0); }
+#pragma unroll 4
+        for (int c = 0; c < 64; ++c) {
+            const f64x2_t m = bp[(size_t)c * 64];
+            const double x = chain_update<FORM>(accA, dr[0], dr[1], a.w, ku);
+            const double sx = __shfl(x, c, 64);
+            accA = __builtin_fma(-m[0], sx, accA);
+            accB = __builtin_fma(-m[1], sx, accB);
         }
-        accB0 = A.b0; accB1 = A.b1;
+        const double x = chain_update<FORM>(accA, dr[0], dr[1], a.w, ku);
         a.W[p] = x;
         const int row = a.tr[2 * (size_t)p + 1];
         if (row >= 0) a.u[row] = x;

@@ -173,37 +173,6 @@ static int build_chain_host(const HostCSR& A, const int* seq, int ns, const Buf<
     }
     C.nband = nband; C.nt1 = nt1; C.nt2 = nt2;
     lap("fill");
-    // ---- rounds: the in-block dependency levels of every block's triangle, the block's planes in (round, row) order (seq_sched.h)
-    C.bsched.alloc((size_t)nb * CHAIN_BS);
-    long long nrounds = 0;
-#pragma omp parallel reduction(+ : nrounds)
-    {
-        std::vector<double> tmp(64 * 128);
-#pragma omp for schedule(dynamic, 8)
-        for (int K = 0; K < nb; ++K) {
-            double* bd = C.band.data() + (size_t)K * 64 * 128;
-            int rnd[64], ord[64], mx = 0;
-            for (int j = 0; j < 64; ++j) {
-                int r = 0;
-                for (int c = 0; c < j; ++c) if (bd[((size_t)c * 64 + j) * 2] != 0.0) r = std::max(r, rnd[c] + 1);
-                rnd[j] = r; mx = std::max(mx, r);
-            }
-            int k = 0;
-            unsigned long long mask = 0;
-            for (int r = 0; r <= mx; ++r) {
-                bool first = true;
-                for (int j = 0; j < 64; ++j) if (rnd[j] == r) { if (first) { mask |= 1ull << k; first = false; } ord[k++] = j; }
-            }
-            std::memcpy(tmp.data(), bd, sizeof(double) * 64 * 128);
-            for (int s2 = 0; s2 < 64; ++s2) std::memcpy(bd + (size_t)s2 * 128, tmp.data() + (size_t)ord[s2] * 128, sizeof(double) * 128);
-            int* bs = C.bsched.data() + (size_t)K * CHAIN_BS;
-            for (int w = 0; w < 16; ++w) bs[w] = ord[4 * w] | (ord[4 * w + 1] << 8) | (ord[4 * w + 2] << 16) | (ord[4 * w + 3] << 24);
-            bs[16] = (int)(unsigned)(mask & 0xffffffffull); bs[17] = (int)(unsigned)(mask >> 32); bs[18] = mx + 1; bs[19] = 0;
-            nrounds += mx + 1;
-        }
-    }
-    C.nrounds = nrounds;
-    lap("rounds");
     H.chain = true;
     H.ns = npad; H.nrows = ns; H.nvirt = 0; H.L = 64; H.nolower = false; H.pfs = 8; H.kt = 0; H.nstrips = 0; H.nchunk = 0; H.maxent = C.rx + C.rg;
     H.nghost = 0; H.slot_bytes = 0; H.nrest = nr; H.flow_ok = true; H.par = 1;
@@ -732,7 +701,7 @@ extern "C" double fasp_hip_seq_chain_selftest(const dCSRmat* Av, const int* seq,
     if (st != FASP_SUCCESS) return st == 1 ? -2.0 : -3.0;
     if (!H.chain) return -2.0;
     const ChainHost& C = H.C;
-    if (info) { info[0] = C.nb; info[1] = C.n1b; info[2] = C.rx; info[3] = C.rg; info[4] = (int)C.t1_steps; info[5] = (int)C.t2_steps; info[6] = (int)C.nband; info[7] = (int)C.nt1; info[8] = (int)C.nt2; info[9] = H.nclasses; info[10] = (int)C.nrounds; }
+    if (info) { info[0] = C.nb; info[1] = C.n1b; info[2] = C.rx; info[3] = C.rg; info[4] = (int)C.t1_steps; info[5] = (int)C.t2_steps; info[6] = (int)C.nband; info[7] = (int)C.nt1; info[8] = (int)C.nt2; info[9] = H.nclasses; }
     const int n = std::max(A.row, A.col), nb = C.nb, npad = C.npad;
     std::vector<double> u((size_t)n), b((size_t)n), uref;
     for (int i = 0; i < n; ++i) { u[(size_t)i] = std::sin(0.37 * i) + 0.1; b[(size_t)i] = std::cos(0.11 * i); }
@@ -757,7 +726,7 @@ extern "C" double fasp_hip_seq_chain_selftest(const dCSRmat* Av, const int* seq,
         auto tdiv = [&]() { const double q = t * rd; const double r = std::fma(-d, q, t); return std::fma(r, rd, q); };
         return form == 0 ? t * rd : form == 1 ? tdiv() : w * tdiv() + ku;
     };
-    std::vector<double> accB0(64, 0.0), accB1(64, 0.0), accA0(64), accA1(64), x(64);
+    std::vector<double> accB(64, 0.0), accA(64), x(64);
     for (int K = 0; K < nb; ++K) {
         const ChainBlk B = C.blk[(size_t)K];
         if ((B.t1_n & 7) || (B.t2_n & 7)) return -7.0;
@@ -783,39 +752,23 @@ extern "C" double fasp_hip_seq_chain_selftest(const dCSRmat* Av, const int* seq,
                 if (qp != npad && (qp >> 6) > C.t1need[(size_t)(B.t1_off + s) / 8]) return -9.0;
                 s1 = std::fma(-C.t1v[e], W[(size_t)qp], s1);
             }
-            accA0[(size_t)j] = (g2 + s1) + (accB0[(size_t)j] + accB1[(size_t)j]);
-            accA1[(size_t)j] = 0.0;
-            accB0[(size_t)j] = 0.0; accB1[(size_t)j] = 0.0;
+            accA[(size_t)j] = (g2 + s1) + accB[(size_t)j];
+            accB[(size_t)j] = 0.0;
         }
         const double* bd = C.band.data() + (size_t)K * 64 * 128;
-        const int* bs = C.bsched.data() + (size_t)K * CHAIN_BS;
-        const unsigned long long mask = ((unsigned long long)(unsigned)bs[17] << 32) | (unsigned)bs[16];
-        if (!(mask & 1ull)) return -8.0;
-        std::vector<char> seen(64, 0), final_(64, 0);
-        int rounds = 0;
-        for (int k = 0; k < 64; ++k) {
-            if ((mask >> k) & 1ull) {   // a round opens: the update of every lane from what it has accumulated
-                ++rounds;
-                for (int j = 0; j < 64; ++j) {
-                    const int pj = K * 64 + j;
-                    const double ku = form == 2 ? (1 - w) * uo[(size_t)pj] : 0.0;
-                    x[(size_t)j] = update(accA0[(size_t)j] + accA1[(size_t)j], C.drd[2 * (size_t)pj], C.drd[2 * (size_t)pj + 1], ku);
-                }
-                for (int k2 = k; k2 < 64 && (k2 == k || !((mask >> k2) & 1ull)); ++k2) final_[(size_t)((bs[k2 >> 2] >> (8 * (k2 & 3))) & 0xff)] = 1;
-            }
-            const int c = (bs[k >> 2] >> (8 * (k & 3))) & 0xff;
-            if (c >= 64 || seen[(size_t)c] || !final_[(size_t)c]) return -8.0;
-            seen[(size_t)c] = 1;
-            const double xc = x[(size_t)c];
+        for (int c = 0; c < 64; ++c) {
+            const int pc = K * 64 + c;
+            const double ku = form == 2 ? (1 - w) * uo[(size_t)pc] : 0.0;
+            const double xc = update(accA[(size_t)c], C.drd[2 * (size_t)pc], C.drd[2 * (size_t)pc + 1], ku);
+            x[(size_t)c] = xc;
             for (int j = 0; j < 64; ++j) {
-                const double ta = bd[((size_t)k * 64 + j) * 2], tb = bd[((size_t)k * 64 + j) * 2 + 1];
-                if (ta != 0.0 && (j <= c || final_[(size_t)j])) return -8.0;   // a row reads rows of EARLIER rounds only: its sum is complete when its round opens
+                const double ta = bd[((size_t)c * 64 + j) * 2], tb = bd[((size_t)c * 64 + j) * 2 + 1];
+                if (j <= c && ta != 0.0) return -8.0;                        // accA_j keeps t_j once it is final
                 if ((K == nb - 1 || (K + 1) * 64 + j >= ns) && tb != 0.0) return -8.0;
-                if (k & 1) { accA1[(size_t)j] = std::fma(-ta, xc, accA1[(size_t)j]); accB1[(size_t)j] = std::fma(-tb, xc, accB1[(size_t)j]); }
-                else { accA0[(size_t)j] = std::fma(-ta, xc, accA0[(size_t)j]); accB0[(size_t)j] = std::fma(-tb, xc, accB0[(size_t)j]); }
+                if (j > c) accA[(size_t)j] = std::fma(-ta, xc, accA[(size_t)j]);
+                accB[(size_t)j] = std::fma(-tb, xc, accB[(size_t)j]);
             }
         }
-        if (rounds != bs[18]) return -8.0;
         for (int c = 0; c < 64; ++c) {
             const int pc = K * 64 + c;
             W[(size_t)pc] = x[(size_t)c];

@@ -40,12 +40,10 @@ constexpr int FLOW_VIRTUAL = 0x40000000;       // flag in tr[2 p]: position p is
 //   tier 1  blocks K - 1 - n1b .. K - 2: summed by helper waves of the chain's workgroup, x through a ring in LDS;
 //   tier 2  everything older: summed by the other workgroups of the launch, x through memory (W), results through memory (G2).
 // Both tiers are one lane per row, entries in column order, right-aligned in padded steps of 64 lanes (ELL per block).
-// Row arithmetic (every tier a chain of fused multiply-adds in column order): G2 = T - sum(tier 2), S1 = -sum(tier 1) from +0.0; the band's
-// products in the block's STEP order (rounds, below), even steps into one accumulator, odd steps into another: SB = SB0 + SB1 (block K - 1,
-// both from +0.0), t = (((G2 + S1) + SB) - even steps of block K) + (- odd steps of block K, from +0.0); then the update of tri_update.
+// Row arithmetic (every tier a chain of fused multiply-adds in column order): G2 = T - sum(tier 2), S1 = -sum(tier 1) from +0.0,
+// SB = -sum(block K - 1) from +0.0, t = ((G2 + S1) + SB) - sum(block K); then the update of tri_update.
 // ---------------------------------------------------------------------------
 constexpr int CHAIN_HA = 12;          // blocks the tier-1 helpers may run ahead of the chain
-constexpr int CHAIN_BS = 20;          // ints of a block's round schedule (ChainHost::bsched)
 constexpr int CHAIN_PF = 32;          // steps of band coefficients the chain wave keeps in flight (and zero steps behind the last block)
 struct ChainBlk { int t1_off, t1_n, t2_off, t2_n; };   // offsets / counts in steps of 64 lanes
 struct ChainHost {
@@ -57,13 +55,6 @@ struct ChainHost {
     Buf<double>         t1v, t2v;
     Buf<unsigned short> t1c, t2c;   // tier 1: ring index of the column's position (padding: rx); tier 2: the position (padding: npad)
     Buf<int>            t1need, t2need;   // per group of eight steps: the newest block its entries read (-1: padding only)
-    // ROUNDS (in-block level scheduling): the 64 rows of a block in the order (round, row), a row's round = 1 + the largest round of the
-    // rows of the block it reads (0: none).  The planes of a block are stored in THAT order: step k applies row c_k's value.  The update
-    // (the division: three dependent operations) is formed once per ROUND for all lanes -- the rows of a round are final together --, the
-    // steps of a round are broadcasts and multiply-adds that do not wait for each other.  Per block 20 ints: 64 bytes c_k, a 64-bit mask
-    // (bit k: step k opens a round), the number of rounds, 0.
-    Buf<int>            bsched;
-    long long           nrounds = 0;
 };
 
 struct SplitHost {

@@ -169,7 +169,6 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
         piece(&S.d_t2c, Cc.t2c.data(), (size_t)Cc.t2_steps * 64);
         piece(&S.d_t1need, Cc.t1need.data(), (size_t)Cc.t1_steps / 8);
         piece(&S.d_t2need, Cc.t2need.data(), (size_t)Cc.t2_steps / 8);
-        piece(&S.d_bsched, Cc.bsched.data(), Cc.bsched.n);
         size_t total = 0;
         for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
         char* base = nullptr;
@@ -186,7 +185,7 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
         S.d_blk = d_blk;
         if (timing) std::printf("    [chain schedule] %-28s %.3f s\n", "upload", wall_seconds() - t0);
         S.chain = true; S.nb = Cc.nb; S.npad = Cc.npad; S.n1b = Cc.n1b; S.rx = Cc.rx; S.rg = Cc.rg; S.t1_steps = Cc.t1_steps; S.t2_steps = Cc.t2_steps;
-        S.nband = Cc.nband; S.nt1 = Cc.nt1; S.nt2 = Cc.nt2; S.nrounds = Cc.nrounds;
+        S.nband = Cc.nband; S.nt1 = Cc.nt1; S.nt2 = Cc.nt2;
         S.ns = ns; S.L = 64; S.LR = H.LR; S.nolower = false; S.nvirt = 0; S.nrows = H.nrows; S.nclasses = H.nclasses; S.pfmax = 8; S.kt = 0; S.par = 1; S.nstrips = 0; S.nchunk = 0; S.maxent = H.maxent;
         S.nghost = 0; S.slot_bytes = 0; S.flow_ok = true;
         S.built = true;
@@ -382,7 +381,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         }
         if (std::getenv("FASP_HIP_SETUP_TIMING")) {
             if (S.chain) std::printf("  [sweep schedule] level %d, sweep kind %d: CHAIN form, %d rows in %d dependency classes, %d blocks of 64, band %lld entries, tier 1 (%d blocks, ring of %d) %lld entries in %lld steps, "
-                                     "tier 2 %lld entries in %lld steps, %.1f rounds per block, rest pass %d lanes per row, built in %.3f s\n", level, kind, S.nrows, S.nclasses, S.nb, S.nband, S.n1b, S.rx, S.nt1, S.t1_steps, S.nt2, S.t2_steps, S.nb ? (double)S.nrounds / S.nb : 0.0, S.LR, wall_seconds() - t0);
+                                     "tier 2 %lld entries in %lld steps, rest pass %d lanes per row, built in %.3f s\n", level, kind, S.nrows, S.nclasses, S.nb, S.nband, S.n1b, S.rx, S.nt1, S.t1_steps, S.nt2, S.t2_steps, S.LR, wall_seconds() - t0);
             else if (multicolor || S.rowlevels) std::printf("  [sweep schedule] level %d, sweep kind %d, %s: %d rows in %d classes\n", level, kind, multicolor ? "colours" : "whole-row dependency levels", (int)(seq.empty() ? S.ns : (int)seq.size()), (int)S.ptr.size() - 1);
             else std::printf("  [sweep schedule] level %d, sweep kind %d: %d rows in %d dependency classes, %d strips (%lld ghosts, at most %d values in LDS), %d chunks, %d lanes per row, "
                              "%d rounds (%d of them spine), %.1f slot bytes per row (%d virtual rows), rest pass %d lanes per row%s, built in %.3f s\n",
@@ -442,7 +441,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
     if (S.chain) {
         // pass (2), the chain form (seq_chain.hip.h): one workgroup walks the rows, the others sum what lies far behind it
         ChainArgs ca{};
-        ca.band = (const f64x2_t*)S.d_band; ca.drd = (const f64x2_t*)S.d_drd; ca.blk = (const ChainBlk*)S.d_blk; ca.bsched = S.d_bsched;
+        ca.band = (const f64x2_t*)S.d_band; ca.drd = (const f64x2_t*)S.d_drd; ca.blk = (const ChainBlk*)S.d_blk;
         ca.t1v = S.d_t1v; ca.t1c = S.d_t1c; ca.t1need = S.d_t1need; ca.t2v = S.d_t2v; ca.t2c = S.d_t2c; ca.t2need = S.d_t2need; ca.rec = S.d_rec; ca.tr = S.d_tr;
         ca.W = S.d_W; ca.G2 = S.d_G2; ca.u = D.x; ca.sync = S.d_prog; ca.nb = S.nb; ca.npad = S.npad; ca.rx = S.rx; ca.rg = S.rg; ca.has_t2 = S.t2_steps > 0; ca.form = form; ca.w = w;
         const bool plain = g_tune.seq_chain_ref || !g_tune.seq_flow || g_flow_disabled;

@@ -27,8 +27,8 @@ double fasp_hip_seq_schedule_selftest(const dCSRmat* A, const int* seq, int ns, 
 /* test entry (host only, no GPU): the CHAIN form of the same sweep (csrc/seq_chain.hip.h, round 5: blocked substitution, the dependency
  * chain inside one wavefront) built wherever it applies and walked on the host as k_tri_chain_ref does, with the update formula `form`
  * (0: t * (1 / a_ii) -- fasp_smoother_dcsr_gs; 1: t / a_ii -- the C/F-ordered sweep; 2: SOR with weight w), against the plain sequential
- * sweep; < 0: error (-2: the form does not apply).  n1_blocks: blocks of 64 rows in tier 1 (0: chosen).  info (may be NULL, 12 ints):
- * {blocks, tier-1 blocks, x ring, G ring, tier-1 steps, tier-2 steps, band entries, tier-1 entries, tier-2 entries, dependency classes, rounds of all blocks};
+ * sweep; < 0: error (-2: the form does not apply).  n1_blocks: blocks of 64 rows in tier 1 (0: chosen).  info (may be NULL, 10 ints):
+ * {blocks, tier-1 blocks, x ring, G ring, tier-1 steps, tier-2 steps, band entries, tier-1 entries, tier-2 entries, dependency classes};
  * out_u (may be NULL, max(row, col) doubles): the swept vector (input: u_i = sin(0.37 i) + 0.1, b_i = cos(0.11 i)) */
 /* test entries (host only, no GPU): the brick renumbering of the uncoded mid levels (csrc/reorder.cpp, round 5).  fasp_hip_cluster_order:
  * order[k] = old index of the row that gets the new index k -- breadth-first balls of 64 rows grown inside chunks of `chunk` consecutive rows.

@@ -121,11 +121,11 @@ def _chain_selftest(ia, ja, a, seq, n1=0, form=1, w=1.0, info=None, out=None):
     L.fasp_hip_seq_chain_selftest.argtypes = [C.POINTER(T.dCSRmat), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     A, keep = T.as_csr(ia, ja, a)
     seq = np.ascontiguousarray(seq, dtype=np.int32)
-    buf = (C.c_int * 12)()
+    buf = (C.c_int * 10)()
     r = L.fasp_hip_seq_chain_selftest(C.byref(A), seq.ctypes.data_as(C.POINTER(C.c_int)), len(seq), n1, form, w, buf,
                                       out.ctypes.data_as(C.POINTER(C.c_double)) if out is not None else None)
     if info is not None:
-        info.update(blocks=buf[0], n1b=buf[1], rx=buf[2], rg=buf[3], t1_steps=buf[4], t2_steps=buf[5], band=buf[6], t1=buf[7], t2=buf[8], classes=buf[9], rounds=buf[10])
+        info.update(blocks=buf[0], n1b=buf[1], rx=buf[2], rg=buf[3], t1_steps=buf[4], t2_steps=buf[5], band=buf[6], t1=buf[7], t2=buf[8], classes=buf[9])
     return r
 
 
