@@ -43,7 +43,10 @@ constexpr int FLOW_VIRTUAL = 0x40000000;       // flag in tr[2 p]: position p is
 // Row arithmetic (every tier a chain of fused multiply-adds in column order): G2 = T - sum(tier 2), S1 = -sum(tier 1) from +0.0,
 // SB = -sum(block K - 1) from +0.0, t = ((G2 + S1) + SB) - sum(block K); then the update of tri_update.
 // ---------------------------------------------------------------------------
-constexpr int CHAIN_HA = 12;          // blocks the tier-1 helpers may run ahead of the chain
+#ifndef FASP_CHAIN_HA
+#define FASP_CHAIN_HA 12
+#endif
+constexpr int CHAIN_HA = FASP_CHAIN_HA;   // blocks the tier-1 helpers may run ahead of the chain
 constexpr int CHAIN_PF = 32;          // steps of band coefficients the chain wave keeps in flight (and zero steps behind the last block)
 struct ChainBlk { int t1_off, t1_n, t2_off, t2_n; };   // offsets / counts in steps of 64 lanes
 struct ChainHost {

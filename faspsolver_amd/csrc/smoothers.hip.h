@@ -447,8 +447,9 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         const bool plain = g_tune.seq_chain_ref || !g_tune.seq_flow || g_flow_disabled;
         if (!plain && seq_err_check() < 0) return ERROR_MISC;   // an earlier sweep's time-out that has arrived meanwhile
         const size_t dyn = sizeof(double) * ((size_t)S.rx + 1 + 2 * (size_t)S.rg);
-        // tier-2 workgroups: enough wavefronts for a block per ~1.3 us at some tens of us per block and wave; the rest of the chip stays free
-        const int far_wg = S.t2_steps > 0 ? (g_tune.seq_chain_grid > 0 ? g_tune.seq_chain_grid : 47) : 0;
+        // tier-2 workgroups: measured on levels 5-8 of P7(256) (profiles/r05_gs_chain.txt): 95 against 47 -- natural-order sweeps of the last two
+        // levels (560-680 tier-2 entries per row) 773 -> 651 and 652 -> 515 us, everything else unchanged; 191: no further gain; 15: 2 x slower there
+        const int far_wg = S.t2_steps > 0 ? (g_tune.seq_chain_grid > 0 ? g_tune.seq_chain_grid : 95) : 0;
 #define CHAIN_LAUNCH(FF)                                                                                              \
         if (plain) hipLaunchKernelGGL((k_tri_chain_ref<FF>), dim3(1), dim3(64), 0, g_ctx.stream, ca, S.n1b);             \
         else hipLaunchKernelGGL((k_tri_chain<FF>), dim3(1 + far_wg), dim3(CHAIN_NT), dyn, g_ctx.stream, ca)

@@ -8,7 +8,8 @@ mkdir -p build
 make -s -C faspsolver_amd/csrc
 /opt/rocm/bin/hipcc "$@" --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fopenmp=libgomp -Wno-unused-function -Wno-unused-result \
     -c faspsolver_amd/csrc/solver.hip -o build/solver_$tag.o
+g++ "$@" -O3 -fPIC -std=c++17 -ffp-contract=off -fopenmp -Wall -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -c faspsolver_amd/csrc/seq_sched.cpp -o build/seq_sched_$tag.o   # (the sweep schedules share constants with the kernels)
 cd faspsolver_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../../build/libfasp_hip_$tag.so host_setup.o dist_plan.o comm.o param_input.o seq_sched.o reorder.o comm_ipc.o ../../build/solver_$tag.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../../build/libfasp_hip_$tag.so host_setup.o dist_plan.o comm.o param_input.o ../../build/seq_sched_$tag.o reorder.o comm_ipc.o ../../build/solver_$tag.o \
     -L/opt/rocm/lib -lamdhip64 -lgomp -ldl -Wl,-rpath,/opt/rocm/lib
 echo built build/libfasp_hip_$tag.so
