@@ -204,6 +204,14 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     // The ONE sequential pass over the matrix: dependency class and number of lower entries of every row, and the strips --
     // contiguous ranges of the sweep sequence, closed when the lower part reaches the target size (12 bytes per entry + 40 per
     // row) or the LDS is full (own rows + distinct earlier rows read + the constant).
+    // Strip size: the caller's, or -- when it is the default of 512 KB -- what the levels of P7(256) measured best with once the deep
+    // levels had left for the chain form (profiles/r05_gs_chain.txt, tools/perf_gs_levels.py 256 seq_strip_kb=...): sweeps over ALL rows
+    // of a wide level (natural order: twice the lower entries per row of a C / F sweep) 1 MB (level 0 2277 -> 1930 us, level 1 2029 ->
+    // 1745), the long-row levels that stay in the dataflow form 256 KB (level 4: C rows 885 -> 756, F rows 620 -> 565), 512 KB otherwise.
+    if (strip_kb == 512) {
+        if (ns == n && n >= 1000000) strip_kb = 1024;
+        else if (n > 0 && (double)A.nnz / n >= 128.0) strip_kb = 256;
+    }
     const long long target = std::max(16, strip_kb) * 1024ll;
     constexpr int VCAP_MAX = (TRI_PFMAX - TRI_SPINE) * 64 + TRI_SPINE;   // slots of a work item with 64 lanes and a spine
     std::vector<int> sq0(1, 0), sng;   // first sequence index of every strip (+ end), ghosts per strip
