@@ -281,6 +281,10 @@ __device__ __forceinline__ bool flow_give_up(unsigned* sync, unsigned& spins, un
     if (!t0) { t0 = now; return false; }
     if (now - t0 > 200000000ull) {   // 2 s at 100 MHz
         __hip_atomic_store((gu32*)(sync + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ... and the process-wide word in host-mapped memory (its device address sits in sync[6..7], written at upload): the host reads
+        // it without a copy -- round 4 queued a 4-byte device-to-host copy behind every sweep (466 per GS-default solve of P7(256))
+        unsigned* herr = reinterpret_cast<unsigned*>(((unsigned long long)sync[7] << 32) | sync[6]);
+        if (herr) __hip_atomic_store(herr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return true;
     }
     return false;

@@ -82,17 +82,23 @@ static int build_schedule(const HostCSR& A, const std::vector<int>& seq, DevLeve
 // to pinned host memory behind every launch and looked at -- without waiting -- before the next sweep of that form and where
 // a solve synchronises anyway: the solve in which it happened fails loudly, the process goes on with one launch per
 // dependency class (k_tri_level).
-static unsigned* g_seq_herr = nullptr;
+static unsigned* g_seq_herr = nullptr;   // host-mapped: the kernels write it themselves (flow_give_up)
+static unsigned* g_seq_derr = nullptr;   // its device address
 static bool      g_flow_disabled = false;
-static bool seq_err_pending() { return g_seq_herr && *g_seq_herr != 0u; }
-static void seq_err_watch(const unsigned* d_err)
+static bool seq_err_pending() { return g_seq_herr && *reinterpret_cast<volatile unsigned*>(g_seq_herr) != 0u; }
+static unsigned* seq_err_device_word()   // (allocated on first use, by whichever thread uploads a schedule first; nullptr: no host-mapped memory -- then a time-out shows as a failed solve only)
 {
-    if (!g_seq_herr) {
-        if (hipHostMalloc((void**)&g_seq_herr, 64, hipHostMallocDefault) != hipSuccess) { g_seq_herr = nullptr; return; }
-        std::memset(g_seq_herr, 0, 64);
-    }
-    if (*g_seq_herr == 0u) (void)hipMemcpyAsync(g_seq_herr, d_err, sizeof(unsigned), hipMemcpyDeviceToHost, g_ctx.stream);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        unsigned* hp = nullptr;
+        if (hipHostMalloc((void**)&hp, 64, hipHostMallocMapped) != hipSuccess) return;
+        std::memset(hp, 0, 64);
+        if (hipHostGetDevicePointer((void**)&g_seq_derr, hp, 0) != hipSuccess) g_seq_derr = nullptr;
+        g_seq_herr = hp;
+    });
+    return g_seq_derr;
 }
+static void seq_err_watch(const unsigned*) {}   // (round 4: a device-to-host copy of the word behind every launch; the kernels write host memory now)
 static int seq_err_check()   // after a stream synchronisation (or between sweeps: whatever has arrived)
 {
     if (!seq_err_pending()) return FASP_SUCCESS;
@@ -181,6 +187,8 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
             else HIPCK(hipMemsetAsync(base + off, 0, q.bytes, stream));
             off += (q.bytes + 255) & ~(size_t)255;
         }
+        const unsigned long long herr_addr = (unsigned long long)seq_err_device_word();   // (alive until the synchronisation below)
+        HIPCK(hipMemcpyAsync(S.d_prog + 6, &herr_addr, 8, hipMemcpyHostToDevice, stream));
         HIPCK(hipStreamSynchronize(stream));
         S.d_blk = d_blk;
         if (timing) std::printf("    [chain schedule] %-28s %.3f s\n", "upload", wall_seconds() - t0);
@@ -218,6 +226,8 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
         off += (q.bytes + 255) & ~(size_t)255;
     }
     HIPCK(hipMemsetAsync(S.d_W, 0, sizeof(double) * (size_t)std::max(ns, 1), stream));
+    const unsigned long long herr_addr = (unsigned long long)seq_err_device_word();   // (alive until the synchronisation below)
+    HIPCK(hipMemcpyAsync(S.d_prog + 6, &herr_addr, 8, hipMemcpyHostToDevice, stream));
     HIPCK(hipStreamSynchronize(stream));   // (the host arrays go away with H)
     S.d_strips = d_strips; S.d_chunks = d_chunks;
     if (timing) std::printf("    [sweep schedule] %-28s %.3f s\n", "upload", wall_seconds() - t0);
@@ -449,7 +459,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         const size_t dyn = sizeof(double) * ((size_t)S.rx + 1 + 2 * (size_t)S.rg);
         // tier-2 workgroups: measured on levels 5-8 of P7(256) (profiles/r05_gs_chain.txt): 95 against 47 -- natural-order sweeps of the last two
         // levels (560-680 tier-2 entries per row) 773 -> 651 and 652 -> 515 us, everything else unchanged; 191: no further gain; 15: 2 x slower there
-        const int far_wg = S.t2_steps > 0 ? (g_tune.seq_chain_grid > 0 ? g_tune.seq_chain_grid : 95) : 0;
+        const int far_wg = S.t2_steps > 0 && !g_tune.seq_test_hang ? (g_tune.seq_chain_grid > 0 ? g_tune.seq_chain_grid : 95) : 0;   // (seq_test_hang: nobody sums tier 2 -- the time-out path, tests)
 #define CHAIN_LAUNCH(FF)                                                                                              \
         if (plain) hipLaunchKernelGGL((k_tri_chain_ref<FF>), dim3(1), dim3(64), 0, g_ctx.stream, ca, S.n1b);             \
         else hipLaunchKernelGGL((k_tri_chain<FF>), dim3(1 + far_wg), dim3(CHAIN_NT), dyn, g_ctx.stream, ca)

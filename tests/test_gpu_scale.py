@@ -340,6 +340,49 @@ def test_chain_form_kernels_agree_bit_for_bit(gpu, smoother, order, w):
 
 
 @pytest.mark.gpu
+def test_chain_form_time_out_fails_loudly_and_falls_back(gpu):
+    """Every poll of the chain form is bounded (two seconds): a launch whose tier-2 workgroups never come (fasp_hip_tune("seq_test_hang", 1):
+    the hook of this test) ends, the error word -- in host-mapped memory, written by the kernels themselves -- fails THAT application of the
+    preconditioner with an error code, and later sweeps take the plain one-wavefront form: the next application gives what the plain
+    form gives.  Run in a process of its own (the fallback is process-wide until fasp_hip_tune("seq_flow", 1) re-enables the dataflow forms)."""
+    code = r"""
+import numpy as np, faspsolver_amd as fa
+from faspsolver_amd import _types as T
+L = fa.lib()
+ia, ja, a, f, ue = fa.poisson7pt(40)
+amgp = fa.param_amg_init()
+r = np.random.default_rng(11).standard_normal(len(f))
+L.fasp_hip_tune(b"seq_chain", 2); L.fasp_hip_tune(b"seq_chain_n1", 1)
+L.fasp_hip_tune(b"seq_chain_ref", 1)
+H = fa.AMG(ia, ja, a, amgp); zref = H.precond(r); H.close()          # what the plain form gives
+L.fasp_hip_tune(b"seq_chain_ref", 0)
+H = fa.AMG(ia, ja, a, amgp)
+z0 = H.precond(r)
+assert np.array_equal(z0, zref)
+L.fasp_hip_tune(b"seq_test_hang", 1)
+try:
+    H.precond(r)
+    print("NO-ERROR")
+except RuntimeError as e:
+    print("FAILED-AS-EXPECTED", e)
+L.fasp_hip_tune(b"seq_test_hang", 0)
+z1 = H.precond(r)                                                      # plain form from here on
+print("FALLBACK-EQUAL", bool(np.array_equal(z1, zref)))
+L.fasp_hip_tune(b"seq_flow", 1)                                         # re-enabled
+z2 = H.precond(r)
+print("REENABLED-EQUAL", bool(np.array_equal(z2, zref)))
+H.close()
+"""
+    import subprocess, sys
+    env = dict(os.environ); env["PYTHONPATH"] = os.path.dirname(G.rstrip("/")).rsplit("/tests", 1)[0] + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "FAILED-AS-EXPECTED" in p.stdout and "NO-ERROR" not in p.stdout, p.stdout
+    assert "FALLBACK-EQUAL True" in p.stdout and "REENABLED-EQUAL True" in p.stdout, p.stdout
+    assert "timed out" in p.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag,smoother,order,w", [("gscf", T.SMOOTHER_GS, 1, 1.0), ("gsnat", T.SMOOTHER_GS, 0, 1.0), ("sor11", T.SMOOTHER_SOR, 0, 1.1)])
 def test_chain_form_everywhere_matches_reference_64(gpu, tag, smoother, order, w):
     """The chain form forced onto EVERY level it applies to (up to 65 407 rows: levels 1.. of P7(64)), tier 1 cut to two blocks: the
