@@ -11,19 +11,21 @@
 //     once it is final)   and   accB -= TB[j][c] x_c   (the NEXT block's rows against this block).  One link = one multiply-add,
 //     the update, one readlane: no poll, no LDS, no cross-lane sum.  After 64 steps the block's 64 values are the update of accA
 //     over all lanes at once (the same operations on the same inputs as the per-step candidates: identical bits).
-// What is not in the band -- columns older than the previous block -- reaches the chain as ONE number per row (G), formed ahead of
-// time by other wavefronts and read from LDS at the block boundary:
+// What is not in the band -- columns older than the previous block -- reaches the chain as TWO numbers per row (S1, G2), formed ahead
+// of time by other wavefronts and taken from rings in LDS at the block boundary:
 //     tier 1 (the n1b blocks in front of the band): helper waves of the chain's workgroup, x through a ring in LDS that the chain
-//            wave fills block by block; a helper may run CHAIN_HA blocks ahead;
-//     tier 2 (everything older): the other workgroups of the launch, x through memory (W, written by the exporter wave of the
-//            chain's workgroup), results through memory (G2).  Tier 2 has n1b blocks of slack, tier 1 one block.
+//            wave fills block by block; a helper may run CHAIN_HA blocks ahead; sums to the ring S1;
+//     tier 2 (everything older): the other workgroups of the launch (those on the chain's XCD step aside: they would stream through
+//            the L2 the band planes are waiting in), x through memory (W, written by the EXPORTER wave of the chain's workgroup),
+//            sums through memory (G2), brought into the ring G2r by the IMPORTER wave.  Tier 2 has n1b blocks of slack, tier 1 one.
 // Nobody polls operands: the schedule tells every group of eight steps the newest block it reads, and a wave waits on ONE word -- blocks
 // in the ring (LDS) / blocks exported (memory) -- before it gathers; entries are in column order, so only a block's last groups wait.
-// G and G2 -- one number per row -- are their own flags (signalling-NaN sentinel), as in the dataflow form.
+// S1 and G2 -- one number per row each -- are their own flags (signalling-NaN sentinel), as the values of the dataflow form are.
 // Roles are dealt by tickets (the workgroup that draws ticket 0 is the chain's: it is running by definition; blocks of both tiers
 // are drawn in order, so every block the chain waits for is in the hands of a running wave): no residency assumption.
 // k_tri_chain_ref is the plain form of the same arithmetic -- ONE wavefront, block after block, no polling -- the fallback after a
-// reported time-out and the A/B partner of the bit-identity test (tests/test_gpu_parity.py).
+// reported time-out (tests/test_gpu_scale.py::test_chain_form_time_out_fails_loudly_and_falls_back) and the A/B partner of the
+// bit-identity test (test_chain_form_kernels_agree_bit_for_bit).  Measurements and what was tried: profiles/r05_gs_chain.txt.
 #pragma once
 #include "seq_sched.h"
 
