@@ -30,7 +30,7 @@ struct DevLevel {
     struct Sched {
         bool built = false, multicolor = false; int* d_order = nullptr; int* d_ptr = nullptr; std::vector<int> ptr;
         // split form (seq_split.hip.h): strips / chunks / slots of the lower part (rows and virtual rows), the rest as a CSR, per-position records and W
-        int ns = 0, L = 1, LR = 1, pfmax = 1, kt = 0, par = 1, nstrips = 0, nchunk = 0, maxent = 0; bool nolower = false, flow_ok = false, rowlevels = false; int nrows = 0, nvirt = 0, nclasses = 0; long long nghost = 0, slot_bytes = 0;
+        int ns = 0, L = 1, LR = 1, pfmax = 1, kt = 0, par = 1, nstrips = 0, nchunk = 0, maxent = 0; bool nolower = false, flow_ok = false, rowlevels = false, independent = false; int nrows = 0, nvirt = 0, nclasses = 0; long long nghost = 0, slot_bytes = 0;
         std::vector<int> cptr;   // split form: dependency class -> first entry of d_lchunks (k_tri_level)
         void* d_strips = nullptr; void* d_chunks = nullptr; unsigned char* d_slots = nullptr; int* d_gpos = nullptr; int* d_cstrip = nullptr; int* d_lchunks = nullptr;
         int* d_ria = nullptr; int* d_rja = nullptr; double* d_rval = nullptr; double* d_rec = nullptr; double* d_dr = nullptr; int* d_tr = nullptr; double* d_W = nullptr; unsigned* d_prog = nullptr;

@@ -200,7 +200,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     // below, which therefore runs first with nothing but the matrix: class (dependency level) and number of lower entries per row
     Buf<int> lev((size_t)std::max(ns, 1)), nlow((size_t)std::max(ns, 1)), nrest((size_t)std::max(ns, 1));
     int nlev = ns > 0 ? 1 : 0;
-    long long lower_total = 0;
+    long long lower_total = 0, upper_total = 0;   // entries that read rows the sweep has visited / has yet to visit
     // The ONE sequential pass over the matrix: dependency class and number of lower entries of every row, and the strips --
     // contiguous ranges of the sweep sequence, closed when the lower part reaches the target size (12 bytes per entry + 40 per
     // row) or the LDS is full (own rows + distinct earlier rows read + the constant).
@@ -235,7 +235,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
                 if ((unsigned)pj < (unsigned)q) {
                     l = std::max(l, lev[pj]); ++c;
                     if (pj < q0 && gmark[pj] != sid) { gmark[pj] = sid; fresh.push_back(pj); }
-                }
+                } else if (pj > q) ++upper_total;
             }
             lev[q] = l + 1; nlow[q] = c; nrest[q] = A.ia[i + 1] - A.ia[i] - c - dg;
             nlev = std::max(nlev, l + 1);
@@ -287,6 +287,7 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
         }
         lap("rest (no lower entries)");
         H.cptr.assign(2, 0);
+        H.independent = upper_total == 0;   // no row of the sweep reads another row of the sweep at all: one pass that updates in place
         H.ns = ns; H.nrows = ns; H.nvirt = 0; H.nclasses = nlev; H.L = 1; H.nolower = true; H.pfs = 4; H.nstrips = 0; H.nchunk = 0; H.maxent = 0; H.nghost = 0; H.slot_bytes = 0; H.nrest = nr; H.flow_ok = true;
         const double avg = ns > 0 ? (double)nr / ns : 0.0;
         H.LR = 1;

@@ -64,7 +64,7 @@ struct SplitHost {
     bool chain = false;   // the chain form below instead of strips / chunks / slots (ria, rja, rval, tr of the rest pass are shared)
     ChainHost C;
     int ns = 0, nrows = 0, nvirt = 0, nclasses = 0, L = 1, LR = 1, pfs = 4, kt = 0, nstrips = 0, nchunk = 0, maxent = 0, par = 1;   // ns: POSITIONS = rows of the sweep + virtual rows;   // kt: spine rounds (below); par: strips that share a dependency class at most (chain-bound levels; else nstrips)
-    bool nolower = false, flow_ok = true;
+    bool nolower = false, flow_ok = true, independent = false;   // independent (with nolower): the rows of the sweep do not couple at all (C rows / F rows of a 7-point level 0)
     long long nghost = 0, slot_bytes = 0, nrest = 0;
     std::vector<FlowStrip> strips;
     std::vector<int>       cptr;       // (doubled) dependency class -> first entry of lchunks

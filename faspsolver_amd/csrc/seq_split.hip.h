@@ -141,6 +141,32 @@ __global__ __launch_bounds__(BLOCK) void k_split_rest(int nseq, const int* __res
     }
 }
 
+// A sweep whose rows do not couple at all (no row reads another row of the sweep, earlier or later: the C rows / the F rows of a
+// 7-point level 0): ONE pass, the update in place -- no records, no W, no scatter pass (round 5: 350 -> 250 us per sweep of 8.4 M rows)
+template <int L>
+__global__ __launch_bounds__(BLOCK) void k_split_direct(int nseq, const int* __restrict__ tr, const int* __restrict__ ria, const int* __restrict__ rja,
+                                                         const double* __restrict__ rval, const double* __restrict__ dr, const double* __restrict__ b,
+                                                         double* u, int form, double w)
+{
+    constexpr int RPB = BLOCK / L;
+    const int sl = threadIdx.x & (L - 1);
+    const int rloc = threadIdx.x / L;
+    for (int p0 = blockIdx.x * RPB; p0 < nseq; p0 += gridDim.x * RPB) {
+        const int p = p0 + rloc;
+        const bool on = p < nseq;
+        const int kb = on ? ria[p] : 0, ke = on ? ria[p + 1] : 0;
+        double s = seq_row_sum<L>(rja, rval, kb + sl, ke, -1, [&](int c) { return u[c]; });   // (columns outside the sweep: nobody writes them in this launch)
+        s = group_sum_last<L>(s);
+        if (on && sl == L - 1) {
+            const int r = tr[2 * (size_t)p + 1];
+            if (r >= 0) {
+                const f64x2_t d = *reinterpret_cast<const f64x2_t*>(dr + 2 * (size_t)p);
+                u[r] = tri_update(b[r] - s, d[0], d[1], tr[2 * (size_t)p] < 0, form, w, u[r]);
+            }
+        }
+    }
+}
+
 // u_i <- W_p (final == 0), or the update of a sweep without any lower entry straight from pass (1) (final == 1)
 __global__ __launch_bounds__(BLOCK) void k_split_scatter(int nseq, FlowArgs a, int final)
 {

@@ -231,7 +231,7 @@ static int upload_split(SplitHost& H, DevLevel::Sched& S, hipStream_t stream)
     HIPCK(hipStreamSynchronize(stream));   // (the host arrays go away with H)
     S.d_strips = d_strips; S.d_chunks = d_chunks;
     if (timing) std::printf("    [sweep schedule] %-28s %.3f s\n", "upload", wall_seconds() - t0);
-    S.ns = ns; S.L = H.L; S.LR = H.LR; S.nolower = H.nolower; S.nvirt = H.nvirt; S.nrows = H.nrows; S.nclasses = H.nclasses; S.pfmax = H.pfs; S.kt = H.kt; S.par = H.par; S.nstrips = H.nstrips; S.nchunk = H.nchunk; S.maxent = H.maxent;
+    S.ns = ns; S.L = H.L; S.LR = H.LR; S.nolower = H.nolower; S.independent = H.nolower && H.independent; S.nvirt = H.nvirt; S.nrows = H.nrows; S.nclasses = H.nclasses; S.pfmax = H.pfs; S.kt = H.kt; S.par = H.par; S.nstrips = H.nstrips; S.nchunk = H.nchunk; S.maxent = H.maxent;
     S.nghost = H.nghost; S.slot_bytes = H.slot_bytes; S.flow_ok = H.flow_ok;
     S.built = true;
     S.multicolor = false;
@@ -430,6 +430,23 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
     fa.strips = (const FlowStrip*)S.d_strips; fa.chunks = (const int4*)S.d_chunks; fa.slots = S.d_slots; fa.gpos = S.d_gpos; fa.cstrip = S.d_cstrip;
     fa.rec = S.d_rec; fa.dr = S.d_dr; fa.tr = S.d_tr; fa.W = S.d_W; fa.u = D.x;
     fa.sync = S.d_prog; fa.nstrips = S.nstrips; fa.form = form; fa.w = w; fa.kt = S.kt;
+    if (S.nolower && S.independent && !S.chain) {   // the rows of the sweep do not couple: one pass, in place
+        const int rpb = BLOCK / S.LR;
+        const int grid = std::max(1, std::min(MAXGRID, (ns + rpb - 1) / rpb));
+#define DIRECT_LAUNCH(LL) hipLaunchKernelGGL((k_split_direct<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, ns, (const int*)S.d_tr, \
+        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)S.d_dr, (const double*)D.b, D.x, form, w)
+        switch (S.LR) {
+            case 1: DIRECT_LAUNCH(1); break;
+            case 2: DIRECT_LAUNCH(2); break;
+            case 4: DIRECT_LAUNCH(4); break;
+            case 8: DIRECT_LAUNCH(8); break;
+            case 16: DIRECT_LAUNCH(16); break;
+            case 32: DIRECT_LAUNCH(32); break;
+            default: DIRECT_LAUNCH(64); break;
+        }
+#undef DIRECT_LAUNCH
+        return FASP_SUCCESS;
+    }
     // pass (1): everything that reads old values, all rows at once
     {
         const int rpb = BLOCK / S.LR;
