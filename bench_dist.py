@@ -33,7 +33,7 @@ def main(args, rank, world, local_rank):
     tok = torch.tensor([int.from_bytes(os.urandom(4), "little") if rank == 0 else 0], dtype=torch.int64)
     dist.broadcast(tok, 0)   # (names of this run only: nothing a crashed earlier run left in /dev/shm is picked up)
     run_id = f"{os.environ.get('MASTER_PORT', '0')}_{int(tok[0]):08x}"
-    ndev = torch.cuda.device_count()   # (counting does not initialise the GPU: the probes below run before this process does)
+    ndev = torch.cuda.device_count()   # (on this image counting the devices does not create a context: the probes below -- child processes -- run before this process touches its GPU)
     if ndev <= 0:
         B.log("bench_dist: no HIP device")
         sys.exit(2)

@@ -430,6 +430,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
     fa.strips = (const FlowStrip*)S.d_strips; fa.chunks = (const int4*)S.d_chunks; fa.slots = S.d_slots; fa.gpos = S.d_gpos; fa.cstrip = S.d_cstrip;
     fa.rec = S.d_rec; fa.dr = S.d_dr; fa.tr = S.d_tr; fa.W = S.d_W; fa.u = D.x;
     fa.sync = S.d_prog; fa.nstrips = S.nstrips; fa.form = form; fa.w = w; fa.kt = S.kt;
+    if (g_tune.seq_rest_lanes > 0) { int lr = 1; while (lr < 64 && lr < g_tune.seq_rest_lanes) lr *= 2; S.LR = lr; }   // (A/B)
     if (S.nolower && S.independent && !S.chain) {   // the rows of the sweep do not couple: one pass, in place
         const int rpb = BLOCK / S.LR;
         const int grid = std::max(1, std::min(MAXGRID, (ns + rpb - 1) / rpb));

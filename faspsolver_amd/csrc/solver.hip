@@ -2171,6 +2171,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "seq_chain_n1")) g_tune.seq_chain_n1 = value;       // blocks of 64 rows in tier 1 (0: chosen from the entries' distances)
     else if (!std::strcmp(key, "seq_chain_grid")) g_tune.seq_chain_grid = value;   // tier-2 workgroups of the chain launch (0: default)
     else if (!std::strcmp(key, "seq_test_hang")) g_tune.seq_test_hang = value;     // tests: the next chain launches go without their tier-2 workgroups -- every waiter runs into its bounded poll (2 s)
+    else if (!std::strcmp(key, "seq_rest_lanes")) g_tune.seq_rest_lanes = value;   // lanes per row of the rest pass (0: from the mean row length); read at launch
     else if (!std::strcmp(key, "seq_chain_ref")) g_tune.seq_chain_ref = value;     // 1: the plain one-wavefront form (k_tri_chain_ref: A/B, fallback)
     else if (!std::strcmp(key, "seq_spine")) g_tune.seq_spine = value;   // 0 never, 1 where the schedule chooses it, 2 wherever a row has two lanes (seq_sched.h); read when a schedule is built
     else if (!std::strcmp(key, "seq_partition")) g_seq_partition = value;
