@@ -395,9 +395,10 @@ def device_state():
 
 
 TIMED_SOLVES = 3
-GS256_ITERS_REF = None   # filled in from tests/golden/p7_sweeps_256.npz when that fixture is present
+GS256_ITERS_REF = SOR256_ITERS_REF = None   # filled in from tests/golden/p7_sweeps_256.npz when that fixture is present
 try:
     GS256_ITERS_REF = int(np.load(os.path.join(ROOT, "tests", "golden", "p7_sweeps_256.npz"))["gscf_iters"])
+    SOR256_ITERS_REF = int(np.load(os.path.join(ROOT, "tests", "golden", "p7_sweeps_256.npz"))["sor11_iters"])
 except Exception:
     pass
 
@@ -455,11 +456,16 @@ def other_configs_leg():
         log(f"config 5 leg failed: {e!r}")
     # the reference's default smoother (Gauss-Seidel, C/F order) in the parity mode, at 128^3 and at the size of the metric;
     # reference iteration counts: tests/golden/p7_sweeps_128.npz / p7_sweeps_256.npz (the compiled reference's own runs)
-    for n, its_ref in ((128, 8), (256, GS256_ITERS_REF)):
+    # ... and SOR(1.1) in natural order (north_star names SOR) at the size of the metric: 10 iterations in the compiled reference
+    for n, its_ref, key, what, mod in ((128, 8, "gs_defaults_128", "fasp_param_amg_init defaults (GS smoother in C/F order, the reference's sequential sweep)", None),
+                                       (256, GS256_ITERS_REF, "gs_defaults_256", "fasp_param_amg_init defaults (GS smoother in C/F order, the reference's sequential sweep)", None),
+                                       (256, SOR256_ITERS_REF, "sor11_256", "SOR(1.1) smoother in natural order (the reference's sequential sweep)", "sor")):
         try:
             ia, ja, a, f, ue = fa.poisson7pt(n)
             itp, amgp = fa.param_solver_init(), fa.param_amg_init()
             itp.tol = 1e-8
+            if mod == "sor":
+                amgp.smoother = T.SMOOTHER_SOR; amgp.relaxation = 1.1; amgp.smooth_order = 0
             t0 = time.perf_counter()
             H = fa.AMG(ia, ja, a, amgp)
             ts = time.perf_counter() - t0
@@ -469,13 +475,13 @@ def other_configs_leg():
                 st, hist, stats = H.solve_resident(itp)
                 secs.append(stats.solve_seconds)
             sec = float(np.mean(secs[1:]))
-            res[f"gs_defaults_{n}"] = {"workload": f"P7({n}), fasp_param_amg_init defaults (GS smoother in C/F order, the reference's sequential sweep) + PCG, rtol 1e-8",
+            res[key] = {"workload": f"P7({n}), {what} + PCG, rtol 1e-8",
                                        "ms_per_solve": sec * 1e3, "timed_solves": TIMED_SOLVES, "first_solve_ms": secs[0] * 1e3, "iterations": int(st),
                                        "iterations_reference": its_ref, "relres": stats.relres, "DOF_per_s": len(f) / sec, "setup_seconds": ts}
             H.close()
-            log(f"GS defaults at {n}^3: {st} iterations, {sec*1e3:.1f} ms (first solve, with the schedules: {secs[0]*1e3:.0f} ms)")
+            log(f"{key}: {st} iterations, {sec*1e3:.1f} ms (first solve, with the schedules: {secs[0]*1e3:.0f} ms)")
         except Exception as e:
-            log(f"GS-defaults leg at {n}^3 failed: {e!r}")
+            log(f"{key} leg failed: {e!r}")
     return res
 
 

@@ -295,10 +295,11 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
         return FASP_SUCCESS;
     }
     // ---- chain-bound sweeps (classes of a few rows: the deep levels) take the chain form where it applies (seq_sched.h): one
-    // wavefront walks the rows in sweep order at ~20 ns per row, whatever the dependency graph looks like -- against 0.4-0.8 us per
+    // wavefront walks the rows in sweep order at ~30 ns per row, whatever the dependency graph looks like -- against 0.4-0.8 us per
     // dependency CLASS in the dataflow form below
     H.nclasses = nlev;
-    if (chain == 2 || (chain == 1 && ns >= 256 && (long long)ns < 20ll * nlev)) {
+    // (break-even, measured on P7(256): the dataflow form pays 0.49-0.57 us per class at 29 rows per class, the chain form 31-36 ns per row)
+    if (chain == 2 || (chain == 1 && ns >= 256 && (long long)ns < 16ll * nlev)) {
         const int st = build_chain_host(A, seq, ns, pos, chain_n1, timing, H);
         if (st == FASP_SUCCESS) { H.nclasses = nlev; return FASP_SUCCESS; }
         if (st < 0) return st;

@@ -577,11 +577,13 @@ def test_sequential_smoothers_match_reference_64(gpu, tag, smoother, order, w, n
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,smoother,order,w", [("gscf", T.SMOOTHER_GS, 1, 1.0), ("sor11", T.SMOOTHER_SOR, 0, 1.1)])
+@pytest.mark.parametrize("tag,smoother,order,w", [("gscf", T.SMOOTHER_GS, 1, 1.0), ("sor11", T.SMOOTHER_SOR, 0, 1.1), ("gsnat", T.SMOOTHER_GS, 0, 1.0)])
 def test_sequential_smoothers_match_reference_256(gpu, tag, smoother, order, w):
-    """The same at the size of the metric, P7(256): the reference's default smoother (12 iterations, relres 7.9576097848e-09) and
-    SOR(1.1) in natural order (10 iterations, 3.0722787533e-09) -- tests/golden/p7_sweeps_256.npz from the compiled reference
-    (tools/gen_golden_sweeps_256.py).  Level 0 in natural order is 2 800 strips of the dataflow solve, ten times what is resident."""
+    """The same at the size of the metric, P7(256): the reference's default smoother (12 iterations, relres 7.9576097848e-09),
+    SOR(1.1) in natural order (10 iterations, 3.0722787533e-09) and, round 5, Gauss-Seidel in natural order (11 iterations,
+    1.3410360094e-09: the t * (1 / a_ii) form of fasp_smoother_dcsr_gs) -- tests/golden/p7_sweeps_256.npz from the compiled reference
+    (tools/gen_golden_sweeps_256.py).  Levels 0-4 run the dataflow form (level 0 in natural order: more strips than are resident),
+    levels 5-8 the chain form (csrc/seq_chain.hip.h)."""
     z = np.load(os.path.join(G, "p7_sweeps_256.npz"))
     ia, ja, a, f, ue = fa.poisson7pt(256)
     itp, amgp = _gs_params(smoother, order, w)

@@ -15,9 +15,12 @@ from gen_golden_sweeps import MODS  # noqa: E402
 
 if __name__ == "__main__":
     n = 256
-    out = {}
+    path = os.path.join(ROOT, "tests", "golden", "p7_sweeps_256.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}   # (tags already there are kept: a run adds what is missing)
     ia, ja, a, f, ue = G.ref_p7(n)
-    for tag in ("gscf", "sor11"):
+    for tag in ("gscf", "sor11", "gsnat"):   # (gsnat: round 5)
+        if f"{tag}_iters" in out:
+            continue
         st, xs, hist = G.solve(ia, ja, a, f, MODS[tag])
         out[f"{tag}_iters"] = np.array(st)
         out[f"{tag}_hist"] = hist
