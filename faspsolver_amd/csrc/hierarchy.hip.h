@@ -295,6 +295,7 @@ static int dist_launch(DevLevel& V, const DevCSR& M, CsrArgs a, const DevLevel* 
 static bool renumber_allowed(const fasp_hip_amg* h)
 {
     const AMG_param& p = h->param;
+    if (g_oneshot_upload) return false;   // (one solve per setup -- fasp_solver_dcsr_krylov_amg: like the matrix coding, it would cost more than it saves)
     return g_tune.renumber != 0 && comm_size() == 1 && (p.smoother == SMOOTHER_JACOBI || p.smoother == SMOOTHER_L1DIAG) &&
            (p.cycle_type == V_CYCLE || p.cycle_type == W_CYCLE || p.cycle_type == VW_CYCLE || p.cycle_type == WV_CYCLE) &&
            p.coarse_scaling != 1 && p.AMG_type == CLASSIC_AMG;
