@@ -39,8 +39,17 @@ struct DevCSR {
     int*    tptr = nullptr;
     int*    tcols = nullptr;
     long long ntcols = 0;            // entries of tcols
+    // numbering bridge (hierarchy.hip.h, brick renumbering behind a CODED level): the operator itself keeps the natural numbering on both
+    // sides -- its row patterns stay what they are -- and the side that lives on the renumbered level is permuted on the fly:
+    // bridge_dir 1 (restriction): the product goes to bscratch, y[k] = bscratch[bridge[k]]; 2 (prolongation): bscratch[bridge[k]] = x[k], then the
+    // product reads bscratch.  bridge = the level's order (new -> natural), owned by the level; bscratch owned here.
+    const int* bridge = nullptr;
+    double*    bscratch = nullptr;
+    int        bridge_dir = 0;
     void    release()
     {
+        if (bscratch) (void)hipFree(bscratch);
+        bscratch = nullptr; bridge = nullptr; bridge_dir = 0;
         if (lja16) (void)hipFree(lja16);
         if (tptr) (void)hipFree(tptr);
         if (tcols) (void)hipFree(tcols);
@@ -724,9 +733,46 @@ struct RowWin { int lo = 0, hi = -1, goff = 0; };
 // sweep of level 0).  Only the kernels of the fast paths do it; a launch that did sets this flag.
 static bool g_jacobi_dot_done = false;
 
+// numbering bridge of a transfer operator (DevCSR::bridge): gather behind a restriction -- with the next level's first Jacobi sweep from
+// the zero guess written along, zx_store's expression -- and scatter in front of a prolongation
+__global__ __launch_bounds__(BLOCK) void k_bridge_gather(int n, const int* __restrict__ perm, const double* __restrict__ s, double* __restrict__ y,
+                                                         double* __restrict__ zx, const double* __restrict__ zdiag, double zomega)
+{
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += gridDim.x * BLOCK) {
+        const double v = s[perm[k]];
+        y[k] = v;
+        if (zx) { const double di = zdiag[k]; zx[k] = (fabs(di) > 1e-20) ? (1 - zomega) * 0.0 + zomega * v / di : 0.0; }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_bridge_scatter(int n, const int* __restrict__ perm, const double* __restrict__ x, double* __restrict__ s)
+{
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += gridDim.x * BLOCK) s[perm[k]] = x[k];
+}
+
 template <int OP>
 static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
 {
+    if (M0.bridge && win.hi < 0) {
+        DevCSR Mn = M0;   // (shallow: the operator without its bridge)
+        Mn.bridge = nullptr; Mn.bscratch = nullptr; Mn.bridge_dir = 0;
+        if (M0.bridge_dir == 1 && OP == OP_MXV) {
+            CsrArgs b = a;
+            b.y = M0.bscratch; b.zx = nullptr; b.zdiag = nullptr;
+            const int G = launch_csr<OP>(Mn, b);
+            const int grid = std::max(1, std::min(MAXGRID, (M0.row + BLOCK - 1) / BLOCK));
+            hipLaunchKernelGGL(k_bridge_gather, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, M0.row, M0.bridge, (const double*)M0.bscratch, a.y, a.zx, a.zdiag, a.zomega);
+            return G;
+        }
+        if (M0.bridge_dir == 2 && (OP == OP_ADD || OP == OP_SUB || OP == OP_AXPY || OP == OP_MXV)) {
+            const int grid = std::max(1, std::min(MAXGRID, (M0.col + BLOCK - 1) / BLOCK));
+            hipLaunchKernelGGL(k_bridge_scatter, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, M0.col, M0.bridge, a.x, M0.bscratch);
+            CsrArgs b = a;
+            b.x = M0.bscratch;
+            return launch_csr<OP>(Mn, b);
+        }
+        std::fprintf(stderr, "### ERROR: fasp_hip: operation %d on a transfer operator with a numbering bridge (direction %d)\n", (int)OP, M0.bridge_dir);
+        std::abort();
+    }
     if (win.hi < 0 && g_tune.split_rows > 0 && M0.row >= 4 * WIN_ALIGN) {
         // test mode (fasp_hip_tune("split_rows", k)): every operator in three row windows, as dist_launch issues them
         const int lo = std::min(g_tune.split_rows, M0.row / 4) / WIN_ALIGN * WIN_ALIGN, hi = (M0.row - lo) / WIN_ALIGN * WIN_ALIGN;

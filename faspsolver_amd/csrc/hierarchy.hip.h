@@ -51,6 +51,7 @@ struct DevLevel {
     // ItrSmootherCSRpoly.c:101-109, work vectors r, rbar, v0, v1, vnew
     struct Poly { bool built = false; double* dinv = nullptr; double k[6] = {0, 0, 0, 0, 0, 0}; double* w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
     Poly    poly;
+    int*    d_perm = nullptr;  // brick renumbering behind a coded level: this level's order (new -> natural) on the device, for the numbering bridges of the transfer operators above
     int*    d_mark = nullptr;  // C/F marker on the device (Jacobi-F smoother), built on first use
     double* w2 = nullptr;      // AMLI cycle: the coarse residual r1 of the level above, built on first use
     double* kw[4] = {nullptr, nullptr, nullptr, nullptr};  // K-cycle work vectors r, x1, v1, v2 of this level
@@ -126,6 +127,8 @@ static void free_level(DevLevel& D)
     if (D.poly.dinv) (void)hipFree(D.poly.dinv);
     for (double* q : D.poly.w) if (q) (void)hipFree(q);
     if (D.d_mark) (void)hipFree(D.d_mark);
+    if (D.d_perm) (void)hipFree(D.d_perm);
+    D.d_perm = nullptr;
     if (D.w2) (void)hipFree(D.w2);
     for (double* q : D.kw) if (q) (void)hipFree(q);
     D = DevLevel();
@@ -310,7 +313,23 @@ static int upload_transfer(fasp_hip_amg* h, int l, const DistLevel* DLp)
     const bool rep = !DLp || DLp->replicated;
     const std::vector<int>* pf = (size_t)l < h->perm.size() && !h->perm[(size_t)l].empty() ? &h->perm[(size_t)l] : nullptr;
     const std::vector<int>* pc = (size_t)l + 1 < h->perm.size() && !h->perm[(size_t)l + 1].empty() ? &h->perm[(size_t)l + 1] : nullptr;
-    if (pf || pc) {
+    // Level l coded, level l + 1 renumbered: the transfer operators keep the natural numbering on BOTH sides -- permuted, their row
+    // patterns would be gone (measured: R_1 47 -> 126 us, P_1 102 -> 120 us on P7(256)) -- and a numbering bridge permutes the vector of
+    // level l + 1 on the fly (DevCSR::bridge: 1.4 M entries, a few microseconds).
+    const bool bridged = pc && !pf && dev_coded(D.A);
+    if (bridged) {
+        if (upload_csr(HL.P, D.P) < 0) return ERROR_ALLOC_MEM;
+        if (upload_csr(HL.R, D.R) < 0) return ERROR_ALLOC_MEM;
+        DevLevel& C = h->L[(size_t)l + 1];
+        if (!C.d_perm) {
+            HIPCK(hipMalloc(&C.d_perm, sizeof(int) * pc->size()));
+            HIPCK(hipMemcpy(C.d_perm, pc->data(), sizeof(int) * pc->size(), hipMemcpyHostToDevice));
+        }
+        HIPCK(hipMalloc(&D.R.bscratch, sizeof(double) * pc->size()));
+        HIPCK(hipMalloc(&D.P.bscratch, sizeof(double) * pc->size()));
+        D.R.bridge = C.d_perm; D.R.bridge_dir = 1;
+        D.P.bridge = C.d_perm; D.P.bridge_dir = 2;
+    } else if (pf || pc) {
         std::vector<int> invf, invc;
         if (pf) { invf.resize(pf->size()); for (size_t k = 0; k < pf->size(); ++k) invf[(size_t)(*pf)[k]] = (int)k; }
         if (pc) { invc.resize(pc->size()); for (size_t k = 0; k < pc->size(); ++k) invc[(size_t)(*pc)[k]] = (int)k; }
@@ -374,7 +393,7 @@ static int upload_level(fasp_hip_amg* h, int l, const DistLevel* DLp)
         // numbering in their patterns), not a level that is coded itself (short rows: tried in natural order first).
         // Levels of more than two million rows stay as they are: measured on the variable-coefficient twin of P7(256), level 1 (8.4 M rows,
         // 19 entries per row) gains 3 % per operator and costs the upload thread six seconds (profiles/r05_renumber.txt).
-        bool want = renum && rep && l > 0 && HL.has_coarse && A.row >= 4096 && A.row <= 2000000 && (g_tune.renumber >= 2 || !dev_coded(h->L[(size_t)l - 1].A));   // (renumber = 2: also behind a coded level -- its transfer operators then lose their coding: A/B)
+        bool want = renum && rep && l > 0 && HL.has_coarse && A.row >= 4096 && A.row <= 2000000 && (g_tune.renumber >= 2 || !dev_coded(h->L[(size_t)l - 1].A));   // (renumber = 2: also behind a coded level, whose transfer operators then take a numbering bridge, upload_transfer -- measured on P7(256): level 2 159 -> 132 us per product, the bridges 13 us each, 0.4 ms of 40 per solve for 1.5 s more setup: off by default, profiles/r05_renumber.txt)
         bool uploaded = false;
         if (want && compress_enabled() && (double)A.nnz <= 48.0 * A.row) {
             if (upload_csr(A, D.A) < 0) return ERROR_ALLOC_MEM;

@@ -2183,7 +2183,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "rp5_max")) g_tune.rp5_max = value;
     else if (!std::strcmp(key, "rp_bpc")) g_tune.rp_bpc = value;
     else if (!std::strcmp(key, "rp_stream")) g_tune.rp_stream = value;
-    else if (!std::strcmp(key, "renumber")) g_tune.renumber = value;             // brick renumbering of the uncoded mid levels at upload (order-independent smoothers only; hierarchy.hip.h): 1 on (default), 0 off; read when a hierarchy is uploaded
+    else if (!std::strcmp(key, "renumber")) g_tune.renumber = value;             // brick renumbering of the uncoded mid levels at upload (order-independent smoothers only; hierarchy.hip.h): 1 on (default), 2 also levels behind a coded one (whose transfer operators keep their coding and take a numbering bridge), 0 off; read when a hierarchy is uploaded
     else if (!std::strcmp(key, "renumber_chunk")) g_tune.renumber_chunk = value; // rows per chunk inside which the balls grow (reorder.cpp)
     else if (!std::strcmp(key, "rp_xcd")) g_tune.rp_xcd = value;
     else if (!std::strcmp(key, "rp_strip")) g_tune.rp_strip = value;   // coded operators of a 3-D grid: an XCD sweeps a strip of every plane (1: the square ones, 2: the transfer operators too, default) or a slab of planes (0)

@@ -281,7 +281,7 @@ def test_renumbered_levels_are_bit_transparent(gpu, variable, smoother):
     kinds = {}
     try:
         for cyc in (1, 2):
-            for ren, chunk in ((1, 262144), (0, 262144), (1, 4096)):
+            for ren, chunk in ((1, 262144), (0, 262144), (1, 4096), (2, 262144)):
                 itp, amgp = _params()
                 amgp.smoother = smoother; amgp.cycle_type = cyc
                 L.fasp_hip_tune(b"renumber", ren); L.fasp_hip_tune(b"renumber_chunk", chunk)
@@ -296,7 +296,7 @@ def test_renumbered_levels_are_bit_transparent(gpu, variable, smoother):
     for cyc in (1, 2):
         base = out[(cyc, 0, 262144)]
         assert np.all(np.isfinite(base[0])) and base[1] > 0
-        for key in ((cyc, 1, 262144), (cyc, 1, 4096)):
+        for key in ((cyc, 1, 262144), (cyc, 1, 4096), (cyc, 2, 262144)):   # (2: also behind the coded level 1, through a numbering bridge)
             z1, st, x, hist = out[key]
             assert np.abs(z1 - base[0]).max() <= 1e-13 * np.abs(base[0]).max(), key
             assert st == base[1] and np.allclose(hist[:-1], base[3][:-1], rtol=1e-9, atol=0.0), key

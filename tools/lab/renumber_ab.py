@@ -10,7 +10,7 @@ for var in (0,):
     ia, ja, a, f, ue = fa.poisson7pt(n)
     if var:
         ia, ja, a, f = fa.poisson7pt_var(n, (ia, ja, a, f, ue))
-    for ren in (2, 1, 2, 1):
+    for ren in (1, 2, 1, 2):
         L.fasp_hip_tune(b"renumber", ren)
         amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
         import time
