@@ -2134,6 +2134,7 @@ extern "C" int fasp_hip_flow_times(unsigned long long* out, int n)   // (develop
 #endif
 
 // development knob: override kernel selection / launch geometry at run time
+static int g_time_cold = 0;   // fasp_hip_tune("time_cold"): fasp_hip_time_kernel times every launch on its own behind a flush of the Infinity Cache
 int fasp_hip_tune(const char* key, int value)
 {
     FASP_ENTRY();
@@ -2185,6 +2186,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "rp_stream")) g_tune.rp_stream = value;
     else if (!std::strcmp(key, "renumber")) g_tune.renumber = value;             // brick renumbering of the uncoded mid levels at upload (order-independent smoothers only; hierarchy.hip.h): 1 on (default), 2 also levels behind a coded one (whose transfer operators keep their coding and take a numbering bridge), 0 off; read when a hierarchy is uploaded
     else if (!std::strcmp(key, "renumber_chunk")) g_tune.renumber_chunk = value; // rows per chunk inside which the balls grow (reorder.cpp)
+    else if (!std::strcmp(key, "time_cold")) g_time_cold = value;
     else if (!std::strcmp(key, "rp_xcd")) g_tune.rp_xcd = value;
     else if (!std::strcmp(key, "rp_strip")) g_tune.rp_strip = value;   // coded operators of a 3-D grid: an XCD sweeps a strip of every plane (1: the square ones, 2: the transfer operators too, default) or a slab of planes (0)
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
@@ -2251,6 +2253,9 @@ double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps)
             case 5: { CsrArgs a{}; a.x = x; a.y = y; a.dotv = x; a.partials = g_ctx.d_partials; launch_csr<OP_MXV_DOT>(D.A, a); } break;
             case 6: if (D.R.ia) d_mxv(D.R, w, h->L[level + 1].xa); break;
             case 7: if (D.P.ia) d_aAxpy(1.0, D.P, h->L[level + 1].xa, y); break;
+            case 8:   // the plain stream bound of a level: its values (and as many bytes again for every 4 of index data) read 16 bytes per lane
+                if (D.A.val) hipLaunchKernelGGL(k_read16, dim3(2048), dim3(BLOCK), 0, g_ctx.stream, (size_t)D.A.nnz / 2, (const f64x2_t*)D.A.val, y);
+                break;
             case 10: case 11: case 12: case 13: (void)seq_sweep(h, level, kind - 10, 1, 1.0); break;   // GS sweep: ascending, descending, C rows, F rows
             default: break;
         }
@@ -2260,6 +2265,31 @@ double fasp_hip_time_kernel(fasp_hip_amg* h, int kind, int level, int reps)
     (void)hipMemsetAsync(w, 0, sizeof(double) * n, g_ctx.stream);
     double* const keep_b = D.b; double* const keep_x = D.x;
     if (kind >= 10) { D.b = w; D.x = x; }   // the sweeps work on the level's own vectors: scratch ones while timing
+    if (g_time_cold) {
+        // as a solve meets the kernel: one event pair per launch, 512 MB of other data READ in between (1) -- nothing of the operator or the
+        // vectors waits in the Infinity Cache; back to back, a level of up to 256 MB is served from there -- or WRITTEN in between (2): the
+        // launch also pays for the write-back of what its predecessors left there
+        double* big = nullptr;
+        const size_t bigb = (size_t)512 << 20;
+        if (hipMalloc(&big, bigb + 4096) != hipSuccess) return -1.0;
+        (void)hipMemsetAsync(big, 0, bigb, g_ctx.stream);
+        double tot = 0.0;
+        for (int i = 0; i < reps + 1; ++i) {
+            if (g_time_cold >= 2) (void)hipMemsetAsync(big, 0, bigb, g_ctx.stream);
+            else hipLaunchKernelGGL(k_read16, dim3(1024), dim3(BLOCK), 0, g_ctx.stream, bigb / 16, (const f64x2_t*)big, big + bigb / 8);
+            (void)hipEventRecord(e0, g_ctx.stream);
+            run();
+            (void)hipEventRecord(e1, g_ctx.stream);
+            (void)hipEventSynchronize(e1);
+            float ms1 = 0.f;
+            (void)hipEventElapsedTime(&ms1, e0, e1);
+            if (i >= 1) tot += ms1;
+        }
+        (void)hipFree(big);
+        D.b = keep_b; D.x = keep_x;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return tot / reps;
+    }
     run(); run();
     (void)hipEventRecord(e0, g_ctx.stream);
     for (int i = 0; i < reps; ++i) run();
