@@ -8,13 +8,13 @@ OUT=${TMPDIR:-/tmp}/fasp_asan
 mkdir -p $OUT
 cd $ROOT/faspsolver_amd/csrc
 make -s
-for f in host_setup dist_plan comm param_input; do
+for f in host_setup dist_plan comm param_input seq_sched reorder; do
   g++ -O1 -g -fPIC -std=c++17 -ffp-contract=off -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer \
       -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -c $f.cpp -o $OUT/$f.o
 done
 GCCLIB=$(dirname $(gcc -print-file-name=libasan.so))
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o $OUT/libfasp_hip.so $OUT/host_setup.o $OUT/dist_plan.o \
-    $OUT/comm.o $OUT/param_input.o solver.o -L/opt/rocm/lib -lamdhip64 -lgomp -ldl -Wl,-rpath,/opt/rocm/lib -L$GCCLIB -lasan -lubsan
+    $OUT/comm.o $OUT/param_input.o $OUT/seq_sched.o $OUT/reorder.o comm_ipc.o solver.o -L/opt/rocm/lib -lamdhip64 -lgomp -ldl -Wl,-rpath,/opt/rocm/lib -L$GCCLIB -lasan -lubsan
 cat > $OUT/run.py <<PY
 import sys
 sys.path.insert(0, "$ROOT")
@@ -24,6 +24,7 @@ import pytest
 # tests that call the compiled REFERENCE are left out: it is not built with the sanitizer runtime
 sys.exit(pytest.main(["tests/test_host_setup_parallel.py", "tests/test_ua_amg.py", "tests/test_bsr_amg.py", "tests/test_sa_amg.py",
                       "tests/test_param_input.py", "tests/test_golden_fixtures.py", "tests/test_matrix_coding.py", "tests/test_dist_cpu.py",
+                      "tests/test_seq_schedule.py", "tests/test_host_reorder.py",
                       "-q", "-m", "not gpu", "-k", "not reference and not two_rank", "-p", "no:cacheprovider"]))
 PY
 cd $ROOT
