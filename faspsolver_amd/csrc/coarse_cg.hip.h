@@ -282,7 +282,7 @@ ITERATE:
             for (int q = 0; q < batch && fused && !persist; ++q) {
                 SpcgFusedArgs fa{};
                 fa.m = m; fa.first = first ? 1 : 0; fa.in = cur; fa.st = h->spcg_state; fa.bc = bc;
-                fa.ia = A.ia; fa.ja = A.ja; fa.ja16 = A.ja16; fa.val = A.val;
+                fa.ia = A.ia; fa.ja = A.ja; fa.ja16 = A.jbase ? nullptr : A.ja16; fa.val = A.val;
                 for (int k = 0; k < 2; ++k) { fa.r[k] = R[k]; fa.p[k] = P[k]; fa.t[k] = T[k]; }
                 fa.u = u; fa.u_best = u_best;
                 // two 512-thread blocks per CU are resident (126 VGPRs): one wave of blocks, block 0 included

@@ -28,7 +28,8 @@ struct DevCSR {
     int*    poff = nullptr;
     double* pval = nullptr;
     int     npat = 0, npent = 0;
-    unsigned short* ja16 = nullptr;  // JA as 16-bit values (long-row operators with <= 65536 columns)
+    unsigned short* ja16 = nullptr;  // JA as 16-bit values (long-row operators with <= 65536 columns, or whose rows each span less than 65536 columns: then relative to jbase)
+    int*            jbase = nullptr; // ja16 is relative to the row's smallest column (operators with more than 65536 columns); nullptr: absolute
     int     nxrows = -1;             // k_csr_rowpat4 / 5: rows outside their wave's uniform pattern(s); -1: the pair sweep does not apply
     int     plane = 0;               // square row-pattern-coded operators: the largest column offset of a pattern (the rows of a z-plane of a 3-D grid)
     // local operator of a row-partitioned level: the rows [win_lo, win_hi) read no ghost column (multiples of WIN_ALIGN
@@ -57,6 +58,8 @@ struct DevCSR {
         nxrows = -1;
         if (ja16) (void)hipFree(ja16);
         ja16 = nullptr;
+        if (jbase) (void)hipFree(jbase);
+        jbase = nullptr;
         if (ia) (void)hipFree(ia);
         if (ja) (void)hipFree(ja);
         if (val) (void)hipFree(val);
@@ -369,15 +372,44 @@ static int grid_plane_of(const std::vector<int>& poff, int nrow)
 
 // 16-bit copy of the column indices (in the order of the device copy) for the operators the
 // sub-wavefront kernel serves: their time is the (JA, val) stream, 12 -> 10 bytes per entry.
-static int upload_ja16(DevCSR& D, const int* ja_dev_order)
+// (Round 5: operators with MORE than 65536 columns whose every row spans less than 65536 of them -- levels 3 and 4 of P7(256): 257 139 and
+// 80 619 rows, spans of a few grid planes -- store their indices relative to the row's smallest column, 4 bytes per row more.)
+static bool rows_span_16bit(const int* ia, const int* ja, int row)
+{
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int i = 0; i < row; ++i) {
+        if (ia[i + 1] <= ia[i]) continue;
+        int lo = ja[ia[i]], hi = lo;
+        for (int k = ia[i] + 1; k < ia[i + 1]; ++k) { lo = std::min(lo, ja[k]); hi = std::max(hi, ja[k]); }
+        if (hi - lo >= 65536) ++bad;
+    }
+    return bad == 0;
+}
+static int upload_ja16(DevCSR& D, const int* ia_host, const int* ja_dev_order)
 {
     static const bool on = !(std::getenv("FASP_HIP_JA16") && std::atoi(std::getenv("FASP_HIP_JA16")) == 0);
-    if (!on || D.kind != 0 || D.col > 65536 || D.nnz < 4096) return FASP_SUCCESS;
+    if (!on || D.kind != 0 || D.nnz < 4096) return FASP_SUCCESS;
+    const bool relative = D.col > 65536;
+    if (relative && !rows_span_16bit(ia_host, ja_dev_order, D.row)) return FASP_SUCCESS;
     Buf<unsigned short> j16((size_t)D.nnz);
+    Buf<int> base(relative ? (size_t)D.row : 0);
 #pragma omp parallel for schedule(static)
-    for (int k = 0; k < D.nnz; ++k) j16[k] = (unsigned short)ja_dev_order[k];
+    for (int i = 0; i < D.row; ++i) {
+        int lo = 0;
+        if (relative) {
+            lo = ia_host[i + 1] > ia_host[i] ? ja_dev_order[ia_host[i]] : 0;
+            for (int k = ia_host[i]; k < ia_host[i + 1]; ++k) lo = std::min(lo, ja_dev_order[k]);
+            base[(size_t)i] = lo;
+        }
+        for (int k = ia_host[i]; k < ia_host[i + 1]; ++k) j16[k] = (unsigned short)(ja_dev_order[k] - lo);
+    }
     HIPCK(hipMalloc(&D.ja16, sizeof(unsigned short) * (size_t)D.nnz));
     HIPCK(hipMemcpy(D.ja16, j16.data(), sizeof(unsigned short) * (size_t)D.nnz, hipMemcpyHostToDevice));
+    if (relative) {
+        HIPCK(hipMalloc(&D.jbase, sizeof(int) * (size_t)D.row));
+        HIPCK(hipMemcpy(D.jbase, base.data(), sizeof(int) * (size_t)D.row, hipMemcpyHostToDevice));
+    }
     return FASP_SUCCESS;
 }
 
@@ -389,7 +421,7 @@ static int g_device_sort = 1;   // fasp_hip_tune("device_sort", 0): per-row sort
 constexpr int SORT_BLK = 256, SORT_MAXLEN = 16384;   // 16384 keys = 128 KB of LDS
 __global__ __launch_bounds__(SORT_BLK) void k_sort_rows(int nrow, const int* __restrict__ ia, const int* __restrict__ ja_in,
                                                         const double* __restrict__ val_in, int* __restrict__ ja_out,
-                                                        double* __restrict__ val_out, unsigned short* __restrict__ ja16)
+                                                        double* __restrict__ val_out, unsigned short* __restrict__ ja16, int* __restrict__ jbase)
 {
     extern __shared__ unsigned long long sort_keys[];
     const int tid = threadIdx.x;
@@ -409,12 +441,14 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_rows(int nrow, const int* __r
                 }
                 __syncthreads();
             }
+        const int base = (jbase && len > 0) ? (int)(sort_keys[0] >> 32) : 0;   // (sorted: the row's smallest column)
+        if (jbase && tid == 0) jbase[r] = base;
         for (int i = tid; i < len; i += SORT_BLK) {
             const unsigned long long key = sort_keys[i];
             const int col = (int)(key >> 32);
             ja_out[kb + i] = col;
             val_out[kb + i] = val_in[kb + (int)(unsigned)key];
-            if (ja16) ja16[kb + i] = (unsigned short)col;
+            if (ja16) ja16[kb + i] = (unsigned short)(col - base);
         }
         __syncthreads();
     }
@@ -429,8 +463,10 @@ static int upload_sorted_on_device(const HostCSR& H, DevCSR& D, int maxlen)
     int st = FASP_SUCCESS;
     if (hipMemcpyAsync(tj, H.ja.data(), sizeof(int) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream) != hipSuccess ||
         hipMemcpyAsync(tv, H.val.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream) != hipSuccess) st = ERROR_ALLOC_MEM;
-    const bool want16 = ja16_on && D.kind == 0 && D.col <= 65536 && D.nnz >= 4096;   // as upload_ja16
+    const bool relative = D.col > 65536;
+    const bool want16 = ja16_on && D.kind == 0 && D.nnz >= 4096 && (!relative || rows_span_16bit(H.ia.data(), H.ja.data(), H.row));   // as upload_ja16
     if (st >= 0 && want16 && hipMalloc(&D.ja16, sizeof(unsigned short) * (size_t)D.nnz) != hipSuccess) st = ERROR_ALLOC_MEM;
+    if (st >= 0 && want16 && relative && hipMalloc(&D.jbase, sizeof(int) * (size_t)std::max(D.row, 1)) != hipSuccess) st = ERROR_ALLOC_MEM;
     if (st >= 0) {
         int P = 64;
         while (P < maxlen) P <<= 1;
@@ -438,7 +474,7 @@ static int upload_sorted_on_device(const HostCSR& H, DevCSR& D, int maxlen)
         if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) st = ERROR_MISC;
         if (st >= 0) {
             const int grid = std::min(H.row, 256 * 64);
-            hipLaunchKernelGGL(k_sort_rows, dim3(grid), dim3(SORT_BLK), lds, g_ctx.stream, H.row, D.ia, tj, tv, D.ja, D.val, D.ja16);
+            hipLaunchKernelGGL(k_sort_rows, dim3(grid), dim3(SORT_BLK), lds, g_ctx.stream, H.row, D.ia, tj, tv, D.ja, D.val, D.ja16, D.jbase);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_ctx.stream) != hipSuccess) st = ERROR_MISC;
         }
     }
@@ -672,11 +708,11 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
             HIPCK(hipMemcpy(D.dpos, dp.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
         }
         D.sorted = true;
-        return upload_ja16(D, sj.data());
+        return upload_ja16(D, H.ia.data(), sj.data());
     }
     if (upload_plain() < 0) return ERROR_ALLOC_MEM;
     if (D.kind == 2 && !g_oneshot_upload && build_xtile(H, D) < 0) return ERROR_ALLOC_MEM;
-    return upload_ja16(D, H.ja.data());
+    return upload_ja16(D, H.ia.data(), H.ja.data());
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
@@ -820,6 +856,8 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
     if (g_tune.rp_stream > 0 || (g_tune.rp_stream < 0 && (size_t)M.row * 8 > (size_t)96 << 20)) a.nt |= 4;
     a.nrow = M.row; a.ia = M.ia; a.ja = M.ja; a.val = M.val; a.dpos = M.dpos;
     a.ja16 = g_tune.ja16 ? M.ja16 : nullptr;
+    a.jbase = g_tune.ja16 ? M.jbase : nullptr;
+    if (M.jbase && M.kind != 0) { a.ja16 = nullptr; a.jbase = nullptr; }   // (a tuning knob sent a sub-wavefront operator elsewhere: only k_csr_rows adds the row base)
     if (M.kind == 1 || M.kind == 3) M.kind = 0;   // (block-level stream, one workgroup per row: measured slower, retired to tools/lab/)
     const int rpb = M.kind >= 4 ? BLOCK : M.kind == 2 ? 4 * M.wrows : BLOCK / M.lanes;
     set_tiles(rpb);

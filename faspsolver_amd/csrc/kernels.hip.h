@@ -72,6 +72,7 @@ struct CsrArgs {
     const int*    stop;     // != nullptr: the launch returns at once when *stop != 0 (queued-ahead iterations)
     const int*    mark;     // OP_L1DIAG only, != nullptr: C/F marker, the sweep is Jacobi on the F points (0) with weight omega
     const unsigned short* ja16;  // != nullptr: the column indices once more as 16-bit values (operators with <= 65536 columns)
+    const int*            jbase; // != nullptr: ja16 is relative to this per-row base (operators with more columns whose rows span < 65536)
     // row window of a launch (distributed levels: interior rows while the halo is in flight, boundary rows after it):
     // the launch covers the tiles tile0 .. tile0 + ntiles of the kernel's own tile size, i.e. the rows [row_lo, nrow)
     int           tile0, row_lo;
@@ -219,15 +220,16 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
         const int r = (t + a.tile0) * RPB + rloc;
         if (r < a.nrow) {
             const int kb = a.ia[r], ke = a.ia[r + 1];
+            const int jb = a.jbase ? a.jbase[r] : 0;   // (16-bit indices relative to the row's smallest column)
             double s = 0.0;
             // 4 independent (JA, val) loads and x gathers in flight per lane; the adds stay
             // in k order
             int k = kb + sl;
             for (; k + 3 * L < ke; k += 4 * L) {
-                const int    c0 = ld_ja(a, k);
-                const int    c1 = ld_ja(a, k + L);
-                const int    c2 = ld_ja(a, k + 2 * L);
-                const int    c3 = ld_ja(a, k + 3 * L);
+                const int    c0 = jb + ld_ja(a, k);
+                const int    c1 = jb + ld_ja(a, k + L);
+                const int    c2 = jb + ld_ja(a, k + 2 * L);
+                const int    c3 = jb + ld_ja(a, k + 3 * L);
                 const double v0 = ld_val(a, k);
                 const double v1 = ld_val(a, k + L);
                 const double v2 = ld_val(a, k + 2 * L);
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rows(CsrArgs a)
                 // the row, padded values replaced by 0 (same adds in the same order, then + 0)
                 const int    kl = ke - 1;
                 const int    k1 = min(k + L, kl), k2 = min(k + 2 * L, kl);
-                const int    c0 = ld_ja(a, k), c1 = ld_ja(a, k1), c2 = ld_ja(a, k2);
+                const int    c0 = jb + ld_ja(a, k), c1 = jb + ld_ja(a, k1), c2 = jb + ld_ja(a, k2);
                 const double v0 = ld_val(a, k);
                 const double w1 = ld_val(a, k1), w2 = ld_val(a, k2);
                 const double v1 = (k + L < ke) ? w1 : 0.0, v2 = (k + 2 * L < ke) ? w2 : 0.0;

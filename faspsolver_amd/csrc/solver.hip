@@ -562,6 +562,7 @@ int fasp_hip_amg_kernel_info(const fasp_hip_amg* h, int level, int which, int* k
     if (!M.ia) return ERROR_INPUT_PAR;
     int k = M.kind;
     double bytes = 12.0 * M.nnz + 4.0 * (M.row + 1.0);
+    if (M.kind == 0 && M.ja16 && g_tune.ja16) bytes = 10.0 * M.nnz + 4.0 * (M.row + 1.0) + (M.jbase ? 4.0 * M.row : 0.0);   // 16-bit indices
     if (M.code && g_tune.compress) { k = 4; bytes = 1.0 * M.nnz + 4.0 * (M.row + 1.0) + (M.rowbase ? 4.0 * M.row : 0.0); }
     if (M.pat && g_tune.compress) { k = 5; bytes = 2.0 * M.row + (M.rowbase ? 4.0 * M.row : 0.0) + 12.0 * M.npent; }
     // second-generation kernels (kernels2.hip.h), same selection as launch_csr: 6 = k_csr_rowpat4, 7 = k_csr_lstream, 8 = k_csr_wstream2, 9 = k_csr_rowpat5, 10 = k_csr_xtile

@@ -217,6 +217,40 @@ def test_row_window_launches_are_bit_identical(gpu, var, smoother):
     H.close()
 
 
+@pytest.mark.gpu
+def test_relative_16bit_columns_are_bit_transparent(gpu):
+    """Round 5: the long-row levels (k_csr_rows) carry their column indices as 16-bit values -- absolute where the level has at most
+    65536 columns (round 2), and RELATIVE to the row's smallest column where it has more but every row spans less than 65536 of them
+    (levels 3 and 4 of P7(256); here level 3 of P7(176): ~83 000 rows of ~65 entries): 10 instead of 12 bytes per entry on levels that
+    are nothing but the (JA, val) stream.  Same kernel, same order of the sums: one cycle and a whole solve are BIT-IDENTICAL with the
+    16-bit copies switched off (fasp_hip_tune("ja16", 0): the 32-bit indices of the same device copy)."""
+    n = 176
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    itp, amgp = _params()
+    L = fa.lib()
+    H = fa.AMG(ia, ja, a, amgp)
+    r = np.random.default_rng(5).standard_normal(len(f))
+    try:
+        info = [(l, H.matrix(l, 0)[0], H.kernel_info(l, 0)) for l in range(H.num_levels - 1)]
+        rel = [l for l, rows, (kind, nbytes) in info if kind == 0 and rows > 65536]
+        assert rel, info   # (a sub-wavefront level with more than 65536 columns exists at this size)
+        for l in rel:
+            nnz = len(H.matrix(l, 0)[4])
+            assert H.kernel_info(l, 0)[1] < 10.6 * nnz, (l, H.kernel_info(l, 0), nnz)   # 10 bytes per entry + row pointers + row bases: the 16-bit copy is there
+        z1 = H.precond(r)
+        st1, x1, h1, _ = H.solve(f, itp)
+        L.fasp_hip_tune(b"ja16", 0)
+        for l in rel:
+            assert H.kernel_info(l, 0)[1] > 11.9 * len(H.matrix(l, 0)[4])
+        z0 = H.precond(r)
+        st0, x0, h0, _ = H.solve(f, itp)
+    finally:
+        L.fasp_hip_tune(b"ja16", 1)
+        H.close()
+    assert np.all(np.isfinite(z1)) and np.array_equal(z1, z0)
+    assert st1 == st0 and np.array_equal(x1, x0) and np.array_equal(np.asarray(h1), np.asarray(h0))
+
+
 def _gs_params(smoother, order, w=1.0):
     itp = fa.param_solver_init(); itp.tol = 1e-8
     amgp = fa.param_amg_init()
