@@ -16,14 +16,14 @@ H.set_rhs(f)
 for rep in range(2):
     for v in vals:
         L.fasp_hip_tune(key, v)
-        ts = []
+        ts, sp = [], []
         for _ in range(6):
             st, hist, stats = H.solve_resident(itp)
-            ts.append(stats.solve_seconds * 1e3)
+            ts.append(stats.solve_seconds * 1e3); sp.append(stats.spmv_ms * 1e3)
         out = []
         for cold in (0, 1):
             L.fasp_hip_tune(b"time_cold", cold)
             out.append(" ".join(f"L{l}:{H.time_kernel(0, l, 10) * 1e3:.0f}/{H.time_kernel(2, l, 10) * 1e3:.0f}" for l in range(2, H.num_levels - 1)))
         L.fasp_hip_tune(b"time_cold", 0)
-        print(f"{key.decode()} {v}: iters {st} relres {stats.relres:.10e} solve best {min(ts):.2f} mean {np.mean(ts[1:]):.2f} ms\n    SpMV/Jacobi us back to back: {out[0]}\n    cold: {out[1]}", flush=True)
+        print(f"{key.decode()} {v}: iters {st} relres {stats.relres:.10e} solve best {min(ts):.2f} mean {np.mean(ts[1:]):.2f} ms, t = A p inside the solve {np.mean(sp[1:]):.1f} us\n    SpMV/Jacobi us back to back: {out[0]}\n    cold: {out[1]}", flush=True)
 H.close()
