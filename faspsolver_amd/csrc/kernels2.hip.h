@@ -843,13 +843,18 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rowpat5(CsrArgs a)
             double xa[8], xb[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { ofA[u] = doA ? cpoff[psA + k + u] : 0; ofB[u] = doB ? cpoff[psB + k + u] : 0; }
-            if (doA) {
+            // only the gathers the lists have (wave-uniform counts: scalar branches) -- a prolongation's rows hold 1 and 2-6 entries, padded
+            // to 8: all 16 gathers of a chunk pair were issued for 3-7 operands (round 5: P of level 0 128 -> 94 us; the same in the square sweep, whose lists fill 7 of 8 and 19 of 24 slots, gains nothing)
+            const int nA = doA ? min(lenA - k, 8) : 0, nB = doB ? min(lenB - k, 8) : 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xa[u] = buf_load_f64(xr, baseA8 + (unsigned)(ofA[u] * 8));
+            for (int u = 0; u < 8; ++u) {
+                xa[u] = 0.0;
+                if (u < nA) xa[u] = buf_load_f64(xr, baseA8 + (unsigned)(ofA[u] * 8));
             }
-            if (doB) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xb[u] = buf_load_f64(xr, baseB8 + (unsigned)(ofB[u] * 8));
+            for (int u = 0; u < 8; ++u) {
+                xb[u] = 0.0;
+                if (u < nB) xb[u] = buf_load_f64(xr, baseB8 + (unsigned)(ofB[u] * 8));
             }
             if (k == 0) flush();  // the previous step's result leaves behind this step's first loads
             auto chunk = [&](int ps, int len, const double (&xv)[8], double& acc) {
