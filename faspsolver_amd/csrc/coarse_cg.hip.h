@@ -304,11 +304,23 @@ ITERATE:
                 else if (m <= 512 * 10) hipLaunchKernelGGL(k_spcg_step_reg<10>, dim3(1), dim3(512), 0, s, sa);
                 else hipLaunchKernelGGL(k_spcg_step, dim3(1), dim3(SMALL_BLOCK), 0, s, sa);
             }
+            // The persistent kernel normally ends because the recurrence's residual met the tolerance, and the reference then forms the TRUE
+            // residual (Check III, KrySPcg.c:258-275): a second wait of the host per coarse solve.  It is queued here, behind the kernel,
+            // into the scratch vector t -- the same kernels on the same u -- and its norm travels with the state: one wait (round 5).
+            bool spec_rr = false;
+            if (persist && g_tune.spcg_spec) {
+                d_resid(A, u, b, t);
+                if (d_dot_to(m, t, t, 14, false) < 0) return ERROR_MISC;
+                spec_rr = true;
+            }
             HIPCK(hipMemcpyAsync(g_ctx.h_part, h->spcg_state, sizeof(SpcgState), hipMemcpyDeviceToHost, s));
-            static_assert(sizeof(SpcgState) % 8 == 0 && sizeof(SpcgState) + 16 <= sizeof(double) * 64, "the error word travels behind the state");
+            static_assert(sizeof(SpcgState) % 8 == 0 && sizeof(SpcgState) + 24 <= sizeof(double) * 64, "the error word and the speculative norm travel behind the state");
             if (persist) HIPCK(hipMemcpyAsync(reinterpret_cast<char*>(g_ctx.h_part) + sizeof(SpcgState), h->persist.sync, 16, hipMemcpyDeviceToHost, s));
+            if (spec_rr) HIPCK(hipMemcpyAsync(reinterpret_cast<char*>(g_ctx.h_part) + sizeof(SpcgState) + 16, g_ctx.d_red + 14, 8, hipMemcpyDeviceToHost, s));
             HIPCK(hipStreamSynchronize(s));
             std::memcpy(&S, g_ctx.h_part, sizeof(S));
+            double spec_val = 0.0;
+            if (spec_rr) std::memcpy(&spec_val, reinterpret_cast<char*>(g_ctx.h_part) + sizeof(SpcgState) + 16, 8);
             if (persist) {   // a block that gave up waiting raised the error word -- also when block 0 itself never ran
                 unsigned ew[4];
                 std::memcpy(ew, reinterpret_cast<char*>(g_ctx.h_part) + sizeof(SpcgState), 16);
@@ -361,6 +373,7 @@ ITERATE:
             normu = std::sqrt(red[1]);
             reldiff = std::fabs(S.alpha) * std::sqrt(red[2]) / normu;
             if ((stag <= MAX_STAG) & (reldiff < maxdiff)) {  // Check II
+                spec_rr = false;   // (what follows works on r itself)
                 d_resid(A, u, b, r);
                 if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
                 absres = std::sqrt(red[0]);
@@ -371,11 +384,16 @@ ITERATE:
                 ++stag;
             }
             if (relres < tol) {  // Check III: true residual
-                d_resid(A, u, b, r);
-                if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+                if (spec_rr && S.stop != SPCG_HANG) red[0] = spec_val;   // formed behind the kernel, in t
+                else {
+                    spec_rr = false;
+                    d_resid(A, u, b, r);
+                    if (d_dot(m, r, r, red) < 0) return ERROR_MISC;
+                }
                 absres = std::sqrt(red[0]);
                 relres = absres / normr0;
                 if (relres < tol) break;
+                if (spec_rr) HIPCK(hipMemcpyAsync(r, t, sizeof(double) * m, hipMemcpyDeviceToDevice, s));   // the solve goes on from the true residual
                 if (more_step >= MAX_RESTART) { iter = ERROR_SOLVER_TOLSMALL; break; }
                 HIPCK(hipMemsetAsync(p, 0, sizeof(double) * m, s));
                 ++more_step;

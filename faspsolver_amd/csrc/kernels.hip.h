@@ -1039,6 +1039,25 @@ __global__ __launch_bounds__(BLOCK) void k_axpby(int n, double a, const double* 
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = a * x[n - 1] + b * y[n - 1];
 }
 
+// p = z + beta p with beta = (*num) / (*den) formed on the device (the host's `beta = temp2 / temp1`, KryPcg.c:340-343: one IEEE division
+// either way): the (z, r) of this and of the previous iteration never travel to the host in between (pcg.hip.h)
+__global__ __launch_bounds__(BLOCK) void k_axpby_beta(int n, const double* __restrict__ x, const double* __restrict__ num,
+                                                       const double* __restrict__ den, double* __restrict__ y)
+{
+    const double b = (*num) / (*den);
+    const int n2 = n >> 1;
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    double2*       y2 = reinterpret_cast<double2*>(y);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n2; i += gridDim.x * BLOCK) {
+        const double2 xv = x2[i];
+        double2       yv = y2[i];
+        yv.x = 1.0 * xv.x + b * yv.x;
+        yv.y = 1.0 * xv.y + b * yv.y;
+        y2[i] = yv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = 1.0 * x[n - 1] + b * y[n - 1];
+}
+
 // first Jacobi sweep from a zero initial guess: (1-w)*0 + w*b_i/d_i  ==  (w*b_i)/d_i exactly
 // (ItrSmootherCSR.c:148-170 with u == 0: t_i = b_i, no matrix pass needed)
 __global__ __launch_bounds__(BLOCK) void k_jacobi_zero(int n, double w, const double* __restrict__ b,
@@ -1096,10 +1115,13 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const 
                                                       double* __restrict__ partials, int full_norms,
                                                       double* __restrict__ temp2_out,
                                                       double* __restrict__ zx = nullptr,
-                                                      const double* __restrict__ zdiag = nullptr, double zomega = 0.0)
+                                                      const double* __restrict__ zdiag = nullptr, double zomega = 0.0,
+                                                      const double* __restrict__ temp1_dev = nullptr)
 {
     // zx != nullptr: r is about to be the right-hand side of a preconditioner whose first step is a Jacobi sweep
     // from zero -- written here, zx_i = (w r_i) / zdiag_i (k_jacobi_zero's expression), instead of re-reading r
+    // temp1_dev != nullptr: (z, r) stayed on the device (pcg.hip.h: no host round trip between the cycle and the next t = A p)
+    if (temp1_dev) temp1 = *temp1_dev;
     __shared__ double lds[5][4];
     __shared__ double bcast;
     double temp2;

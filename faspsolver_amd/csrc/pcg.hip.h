@@ -21,6 +21,7 @@ static void itinfo(int ptrlvl, int stop_type, int iter, double relres, double ab
     }
 }
 
+static bool g_pcg_nested = false;   // a top-level pcg_device is running with its (z, r) on the device (slots 12, 13 of d_red)
 struct PcgVecs { const double* b; double *u, *p, *t, *r; };
 static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int MaxIt, int StopType,
                       int PrtLvl, Hist& hist, PcgOut& out)
@@ -37,6 +38,12 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
     hipStream_t s = g_ctx.stream;
     const int G = vec_grid(m);
     int st;
+    // (z, r) on the device -- see below; declared here: the early exits jump over the place where it is decided
+    constexpr int ZR_SLOT = 12;   // slots 12, 13 of d_red
+    bool zr_dev = false;
+    int  zr_cur = 0;              // slot ZR_SLOT + zr_cur holds temp1
+    bool zr_pending = false;      // the host's temp1 is one iteration old: the newest value comes with the next round trip
+    struct NestGuard { bool on = false; void arm() { on = true; g_pcg_nested = true; } ~NestGuard() { if (on) g_pcg_nested = false; } } nest_guard;
 
     auto apply_pc = [&]() -> int {
         if (K.pc) return K.pc(r, &z);
@@ -101,12 +108,22 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
     HIPCK(hipMemcpyAsync(p, z, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
     if (d_dot(m, z, r, red, dist) < 0) return ERROR_MISC;
     temp1 = red[0];
+    // (z, r) stays on the device (round 5): the top-level solve keeps the value of this and of the previous iteration in two slots of
+    // d_red in turn; beta = temp2 / temp1 and alpha = temp1 / (t, p) are formed there (one IEEE division each, as on the host), and the
+    // host reads (z, r) with the scalars of the NEXT iteration's single round trip -- one wait per iteration instead of two.  Not for a
+    // nested solve (CG as a smoother: the outer solve's slots would be overwritten) nor when (z, r) is the stopping quantity.
+    zr_dev = g_tune.pcg_dev_beta && h != nullptr && StopType != STOP_REL_PRECRES && !g_pcg_nested;
+    if (zr_dev) {
+        HIPCK(hipMemcpyAsync(g_ctx.d_red + ZR_SLOT, g_ctx.d_red, sizeof(double), hipMemcpyDeviceToDevice, s));
+        nest_guard.arm();
+    }
 
     while (iter++ < MaxIt) {
         // t = A p with the partial sums of (t,p); timed for the roofline report
         {
             if (K.halo(p) < 0) return ERROR_MISC;
-            EventPair* ep = (h && h->ev_used < (int)h->ev.size()) ? &h->ev[h->ev_used++] : nullptr;
+            // (every fourth launch: an event pair costs the stream ~12 us of idle time around the launch it brackets)
+            EventPair* ep = (h && (g_tune.ev_every <= 1 || (iter % g_tune.ev_every) == 2 % g_tune.ev_every) && h->ev_used < (int)h->ev.size()) ? &h->ev[h->ev_used++] : nullptr;
             if (ep) (void)hipEventRecord(ep->a, s);
             int gdot = K.mxv_dot ? K.mxv_dot(p, t) : -1;
             if (ep) (void)hipEventRecord(ep->b, s);
@@ -121,11 +138,12 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
         double* const pre_x = (K.pre_x && StopType != STOP_REL_PRECRES) ? K.pre_x() : nullptr;
         hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, (const double*)(g_ctx.d_red + 8),
                            (const double*)nullptr, 0, p, t, u, r, g_ctx.d_partials, 0, (double*)nullptr,
-                           pre_x, K.pre_diag, K.pre_omega);
+                           pre_x, K.pre_diag, K.pre_omega, zr_dev ? (const double*)(g_ctx.d_red + ZR_SLOT + zr_cur) : (const double*)nullptr);
         bool r_is_updates = pre_x != nullptr;   // false again as soon as r is recomputed from u
         d_finalize(G, 1, 0u, 0, dist);
-        HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * 9, hipMemcpyDeviceToHost, s));
+        HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * (zr_dev ? ZR_SLOT + 2 : 9), hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
+        if (zr_pending) { temp1 = g_ctx.h_red[ZR_SLOT + zr_cur]; zr_pending = false; }   // (the value cg_update has just divided)
         temp2 = g_ctx.h_red[8];
         if (std::fabs(temp2) > SMALLREAL2) {
             alpha = temp1 / temp2;
@@ -201,6 +219,17 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
             if (r_is_updates && K.mark_presmoothed) K.mark_presmoothed();
             if (K.pc_zr) { if ((st = K.pc_zr(r, &z, &zr_G)) < 0) return st; }
             else if ((st = apply_pc()) < 0) return st;
+        }
+        if (zr_dev) {
+            // (z, r) into the other slot, beta on the device, no wait: the host learns the value with the next iteration's scalars
+            const int nxt = zr_cur ^ 1;
+            if (zr_G > 0) d_finalize(zr_G, 1, 0u, ZR_SLOT + nxt, dist);
+            else if (d_dot_to(m, z, r, ZR_SLOT + nxt, dist) < 0) return ERROR_MISC;
+            hipLaunchKernelGGL(k_axpby_beta, dim3(vec_grid(m / 2 + 1)), dim3(BLOCK), 0, s, m, (const double*)z,
+                               (const double*)(g_ctx.d_red + ZR_SLOT + nxt), (const double*)(g_ctx.d_red + ZR_SLOT + zr_cur), p);  // p = z + beta p
+            zr_cur = nxt;
+            zr_pending = true;
+            continue;
         }
         if (zr_G > 0) {
             d_finalize(zr_G, 1, 0u, 0, dist);

@@ -2188,6 +2188,9 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "renumber")) g_tune.renumber = value;             // brick renumbering of the uncoded mid levels at upload (order-independent smoothers only; hierarchy.hip.h): 1 on (default), 2 also levels behind a coded one (whose transfer operators keep their coding and take a numbering bridge), 0 off; read when a hierarchy is uploaded
     else if (!std::strcmp(key, "renumber_chunk")) g_tune.renumber_chunk = value; // rows per chunk inside which the balls grow (reorder.cpp)
     else if (!std::strcmp(key, "time_cold")) g_time_cold = value;
+    else if (!std::strcmp(key, "pcg_dev_beta")) g_tune.pcg_dev_beta = value;   // top-level PCG: (z, r), beta and alpha stay on the device, one host wait per iteration (1, default) or two (0)
+    else if (!std::strcmp(key, "spcg_spec")) g_tune.spcg_spec = value;         // persistent coarse CG: the true residual of Check III queued behind the kernel, one host wait per coarse solve (1, default) or two (0)
+    else if (!std::strcmp(key, "ev_every")) g_tune.ev_every = value;           // the level-0 t = A p launch inside a solve is bracketed by an event pair every n-th iteration (4; 1: every one)
     else if (!std::strcmp(key, "rp_xcd")) g_tune.rp_xcd = value;
     else if (!std::strcmp(key, "rp_strip")) g_tune.rp_strip = value;   // coded operators of a 3-D grid: an XCD sweeps a strip of every plane (1: the square ones, 2: the transfer operators too, default) or a slab of planes (0)
     else if (!std::strcmp(key, "host_parallel_min")) g_parallel_min_nnz = value;
