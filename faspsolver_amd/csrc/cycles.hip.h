@@ -536,6 +536,7 @@ static KOps csr_ops(fasp_hip_amg* h, int level, bool with_pc)
             ap.cycle_type != AMLI_CYCLE && ap.cycle_type != NL_AMLI_CYCLE && h->L.size() > 1) {
             K.pre_x = [Lv]() { return Lv->x; };
             K.pre_diag = Lv->diag; K.pre_omega = ap.relaxation;
+            K.pre_diag_uniform = Lv->diag_uniform; K.pre_diag_value = Lv->diag_value;
             K.mark_presmoothed = [h]() { h->pre_marked = true; };
         }
         K.pc_zr = [h](double* in, double** out, int* G) {

@@ -52,6 +52,8 @@ struct DevLevel {
     struct Poly { bool built = false; double* dinv = nullptr; double k[6] = {0, 0, 0, 0, 0, 0}; double* w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
     Poly    poly;
     int*    d_perm = nullptr;  // brick renumbering behind a coded level: this level's order (new -> natural) on the device, for the numbering bridges of the transfer operators above
+    bool    diag_uniform = false;  // every row has the same diagonal entry (bitwise): diag_value
+    double  diag_value = 0.0;
     int*    d_mark = nullptr;  // C/F marker on the device (Jacobi-F smoother), built on first use
     double* w2 = nullptr;      // AMLI cycle: the coarse residual r1 of the level above, built on first use
     double* kw[4] = {nullptr, nullptr, nullptr, nullptr};  // K-cycle work vectors r, x1, v1, v2 of this level
@@ -159,6 +161,13 @@ static int upload_diag(const HostCSR& A, DevLevel& D)
         if (hits > 1) ++ndup;
     }
     D.A.dup_diag = ndup > 0;
+    {   // one diagonal value for all rows (constant-coefficient operators): whoever only needs d_i can take it as a scalar and skip an
+        // 8-byte-per-row stream (k_cg_update's first Jacobi sweep of the new residual: 134 MB of 1.07 GB on P7(256))
+        bool same = n > 0;
+        for (int i = 1; i < n && same; ++i) same = std::memcmp(&d[(size_t)i], &d[0], sizeof(double)) == 0;
+        D.diag_uniform = same;
+        D.diag_value = same ? d[0] : 0.0;
+    }
     if (!D.A.sorted) {  // (storage indices of the host order: meaningless for a re-sorted device copy)
         HIPCK(hipMalloc(&D.A.dpos, sizeof(int) * std::max(n, 1)));
         HIPCK(hipMemcpy(D.A.dpos, dp.data(), sizeof(int) * n, hipMemcpyHostToDevice));

@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const 
                                                       double* __restrict__ temp2_out,
                                                       double* __restrict__ zx = nullptr,
                                                       const double* __restrict__ zdiag = nullptr, double zomega = 0.0,
-                                                      const double* __restrict__ temp1_dev = nullptr)
+                                                      const double* __restrict__ temp1_dev = nullptr, double zdiag_value = 0.0)
 {
     // zx != nullptr: r is about to be the right-hand side of a preconditioner whose first step is a Jacobi sweep
     // from zero -- written here, zx_i = (w r_i) / zdiag_i (k_jacobi_zero's expression), instead of re-reading r
@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const 
             u[i] = ui;
             r[i] = ri;
             if (zx) {
-                const double di = zdiag[i];
+                const double di = zdiag ? zdiag[i] : zdiag_value;   // (zdiag == nullptr: the same diagonal entry in every row)
                 zx[i] = (fabs(di) > 1e-20) ? (1 - zomega) * 0.0 + zomega * ri / di : 0.0;
             }
             q[0] += ri * ri;

@@ -29,6 +29,8 @@ struct KOps {
     // mark_presmoothed() tells the preconditioner that its next apply finds that sweep done
     std::function<double*()> pre_x;
     const double* pre_diag = nullptr;
+    bool   pre_diag_uniform = false;   // every entry of pre_diag is pre_diag_value: the kernel need not read the vector
+    double pre_diag_value = 0.0;
     double pre_omega = 0.0;
     std::function<void()> mark_presmoothed;
     std::function<int(double*, double**, int*)> pc_zr;                     // pc + partials of (out, in) in g_ctx.d_partials (count in *G, 0: none)

@@ -138,7 +138,8 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
         double* const pre_x = (K.pre_x && StopType != STOP_REL_PRECRES) ? K.pre_x() : nullptr;
         hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, (const double*)(g_ctx.d_red + 8),
                            (const double*)nullptr, 0, p, t, u, r, g_ctx.d_partials, 0, (double*)nullptr,
-                           pre_x, K.pre_diag, K.pre_omega, zr_dev ? (const double*)(g_ctx.d_red + ZR_SLOT + zr_cur) : (const double*)nullptr);
+                           pre_x, K.pre_diag_uniform ? (const double*)nullptr : K.pre_diag, K.pre_omega,
+                           zr_dev ? (const double*)(g_ctx.d_red + ZR_SLOT + zr_cur) : (const double*)nullptr, K.pre_diag_value);
         bool r_is_updates = pre_x != nullptr;   // false again as soon as r is recomputed from u
         d_finalize(G, 1, 0u, 0, dist);
         HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * (zr_dev ? ZR_SLOT + 2 : 9), hipMemcpyDeviceToHost, s));
