@@ -1041,10 +1041,27 @@ __global__ __launch_bounds__(BLOCK) void k_axpby(int n, double a, const double* 
 
 // p = z + beta p with beta = (*num) / (*den) formed on the device (the host's `beta = temp2 / temp1`, KryPcg.c:340-343: one IEEE division
 // either way): the (z, r) of this and of the previous iteration never travel to the host in between (pcg.hip.h)
+// npart > 0: the numerator is still npart per-block partials -- every block sums them in k_finalize's order (thread i takes i, i + 256, ...;
+// then the block tree: the same bits in every block), block 0 leaves the sum in *num_out for the next k_cg_update and for the host
 __global__ __launch_bounds__(BLOCK) void k_axpby_beta(int n, const double* __restrict__ x, const double* __restrict__ num,
-                                                       const double* __restrict__ den, double* __restrict__ y)
+                                                       const double* __restrict__ den, double* __restrict__ y,
+                                                       const double* __restrict__ partials = nullptr, int npart = 0,
+                                                       double* __restrict__ num_out = nullptr)
 {
-    const double b = (*num) / (*den);
+    double nu;
+    if (npart > 0) {
+        __shared__ double lds[4];
+        __shared__ double bcast;
+        double sacc = 0.0;
+        for (int i = threadIdx.x; i < npart; i += BLOCK) sacc += partials[i];
+        sacc = block_sum(sacc, lds);
+        if (threadIdx.x == 0) { bcast = sacc; if (blockIdx.x == 0) *num_out = sacc; }
+        __syncthreads();
+        nu = bcast;
+    } else {
+        nu = *num;
+    }
+    const double b = nu / (*den);
     const int n2 = n >> 1;
     const double2* x2 = reinterpret_cast<const double2*>(x);
     double2*       y2 = reinterpret_cast<double2*>(y);

@@ -43,6 +43,7 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
     bool zr_dev = false;
     int  zr_cur = 0;              // slot ZR_SLOT + zr_cur holds temp1
     bool zr_pending = false;      // the host's temp1 is one iteration old: the newest value comes with the next round trip
+    int  tp_G = 0;                // > 0: (t,p) is still this many per-block partials when k_cg_update starts
     struct NestGuard { bool on = false; void arm() { on = true; g_pcg_nested = true; } ~NestGuard() { if (on) g_pcg_nested = false; } } nest_guard;
 
     auto apply_pc = [&]() -> int {
@@ -127,7 +128,9 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
             if (ep) (void)hipEventRecord(ep->a, s);
             int gdot = K.mxv_dot ? K.mxv_dot(p, t) : -1;
             if (ep) (void)hipEventRecord(ep->b, s);
-            if (gdot >= 0) d_finalize(gdot, 1, 0u, 8, dist);
+            tp_G = 0;
+            if (gdot >= 0 && !(dist && comm_size() > 1) && g_tune.pcg_fold) tp_G = gdot;   // one rank: k_cg_update sums the partials itself (k_finalize's order) -- one launch less
+            else if (gdot >= 0) d_finalize(gdot, 1, 0u, 8, dist);
             else {  // format without a fused kernel: t = A p, then (t,p) into slot 8
                 K.mxv(p, t);
                 if (d_dot_to(m, t, p, 8, dist) < 0) return ERROR_MISC;
@@ -136,12 +139,16 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
         // alpha = temp1/(t,p) on device; u += alpha p; r -= alpha t; partial ||r||^2
         // (+ the preconditioner's first Jacobi sweep of the new r, when it has one: K.pre_x)
         double* const pre_x = (K.pre_x && StopType != STOP_REL_PRECRES) ? K.pre_x() : nullptr;
+        // (tp_G > 0: the (t,p) partials are read from d_partials by every block, so this kernel's own partials go to the second set)
+        double* const upd_partials = tp_G > 0 ? g_ctx.d_partials2 : g_ctx.d_partials;
         hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(BLOCK), 0, s, m, temp1, (const double*)(g_ctx.d_red + 8),
-                           (const double*)nullptr, 0, p, t, u, r, g_ctx.d_partials, 0, (double*)nullptr,
+                           (const double*)(tp_G > 0 ? g_ctx.d_partials : nullptr), tp_G, p, t, u, r, upd_partials, 0,
+                           tp_G > 0 ? g_ctx.d_red + 8 : (double*)nullptr,
                            pre_x, K.pre_diag_uniform ? (const double*)nullptr : K.pre_diag, K.pre_omega,
                            zr_dev ? (const double*)(g_ctx.d_red + ZR_SLOT + zr_cur) : (const double*)nullptr, K.pre_diag_value);
         bool r_is_updates = pre_x != nullptr;   // false again as soon as r is recomputed from u
-        d_finalize(G, 1, 0u, 0, dist);
+        if (tp_G > 0) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, s, (const double*)g_ctx.d_partials2, G, 1, 0u, g_ctx.d_red);
+        else d_finalize(G, 1, 0u, 0, dist);
         HIPCK(hipMemcpyAsync(g_ctx.h_red, g_ctx.d_red, sizeof(double) * (zr_dev ? ZR_SLOT + 2 : 9), hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
         if (zr_pending) { temp1 = g_ctx.h_red[ZR_SLOT + zr_cur]; zr_pending = false; }   // (the value cg_update has just divided)
@@ -224,10 +231,13 @@ static int pcg_device(KOps& K, const PcgVecs& V, double tol, double abstol, int 
         if (zr_dev) {
             // (z, r) into the other slot, beta on the device, no wait: the host learns the value with the next iteration's scalars
             const int nxt = zr_cur ^ 1;
-            if (zr_G > 0) d_finalize(zr_G, 1, 0u, ZR_SLOT + nxt, dist);
+            int fold = 0;   // > 0: k_axpby_beta sums the (z, r) partials itself (k_finalize's order) and block 0 leaves the sum in the slot
+            if (zr_G > 0 && !(dist && comm_size() > 1) && g_tune.pcg_fold) fold = zr_G;
+            else if (zr_G > 0) d_finalize(zr_G, 1, 0u, ZR_SLOT + nxt, dist);
             else if (d_dot_to(m, z, r, ZR_SLOT + nxt, dist) < 0) return ERROR_MISC;
             hipLaunchKernelGGL(k_axpby_beta, dim3(vec_grid(m / 2 + 1)), dim3(BLOCK), 0, s, m, (const double*)z,
-                               (const double*)(g_ctx.d_red + ZR_SLOT + nxt), (const double*)(g_ctx.d_red + ZR_SLOT + zr_cur), p);  // p = z + beta p
+                               (const double*)(g_ctx.d_red + ZR_SLOT + nxt), (const double*)(g_ctx.d_red + ZR_SLOT + zr_cur), p,
+                               (const double*)g_ctx.d_partials, fold, g_ctx.d_red + ZR_SLOT + nxt);  // p = z + beta p
             zr_cur = nxt;
             zr_pending = true;
             continue;

@@ -11,14 +11,14 @@ amgp = fa.param_amg_init(); amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation =
 H = fa.AMG(ia, ja, a, amgp)
 itp = fa.param_solver_init(); itp.tol = 1e-8
 H.set_rhs(f)
-cases = [("all as before", 0, 0, 1), ("beta on the device", 1, 0, 1), ("+ one wait per coarse solve", 1, 1, 1), ("+ an event pair every 4th iteration", 1, 1, 4)]
+cases = [("all as before", 0, 0, 1, 0), ("beta on the device", 1, 0, 1, 0), ("+ one wait per coarse solve", 1, 1, 1, 0), ("+ an event pair every 4th iteration", 1, 1, 4, 0), ("+ (t,p), (z,r) summed by their consumers", 1, 1, 4, 1)]
 for rep in range(3):
-    for name, b, sp, ev in cases:
-        L.fasp_hip_tune(b"pcg_dev_beta", b); L.fasp_hip_tune(b"spcg_spec", sp); L.fasp_hip_tune(b"ev_every", ev)
+    for name, b, sp, ev, fold in cases:
+        L.fasp_hip_tune(b"pcg_dev_beta", b); L.fasp_hip_tune(b"spcg_spec", sp); L.fasp_hip_tune(b"ev_every", ev); L.fasp_hip_tune(b"pcg_fold", fold)
         ts = []
         for _ in range(8):
             st, hist, stats = H.solve_resident(itp)
             ts.append(stats.solve_seconds * 1e3)
         print(f"{name:40s}: iters {st} relres {stats.relres:.10e} solve best {min(ts):.2f} mean {np.mean(ts[2:]):.2f} ms", flush=True)
-L.fasp_hip_tune(b"pcg_dev_beta", 1); L.fasp_hip_tune(b"spcg_spec", 1); L.fasp_hip_tune(b"ev_every", 4)
+L.fasp_hip_tune(b"pcg_dev_beta", 1); L.fasp_hip_tune(b"spcg_spec", 1); L.fasp_hip_tune(b"ev_every", 4); L.fasp_hip_tune(b"pcg_fold", 1)
 H.close()
