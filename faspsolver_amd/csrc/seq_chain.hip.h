@@ -44,6 +44,7 @@ struct ChainArgs {
     double*               u;
     unsigned*             sync;   // [0] role ticket, [1] error word, [2] tier-2 block ticket, [4] blocks exported to W, [5] 1 + XCD of the chain's workgroup
     int                   nb, npad, rx, rg;
+    int                   touch_lead; // > 0: a workgroup of its own on the chain's XCD pulls the band planes into the L2, this many blocks ahead of the exported count (0: the importer wave does, four blocks ahead)
     int                   has_t2; // 0: no row has a tier-2 entry (no tier-2 workgroups in the launch: tier 1 starts from pass (1)'s record itself)
     int                   form;   // as tri_update
     double                w;
@@ -266,7 +267,7 @@ __device__ __forceinline__ void chain_import(const ChainArgs& a, double* G2r, in
         if (im >= a.nb && k >= a.nb - 1) break;
         const int lim = k + CHAIN_HA + 1;
         bool moved = false;
-        if (tb < a.nb && tb <= k + 4) {
+        if (a.touch_lead <= 0 && tb < a.nb && tb <= k + 4) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) touched += *reinterpret_cast<const volatile int*>(bb + (size_t)tb * 65536 + ((size_t)i * 64 + lane) * 128);
             ++tb;
@@ -288,6 +289,33 @@ __device__ __forceinline__ void chain_import(const ChainArgs& a, double* G2r, in
             moved = true;
         }
         if (!moved) { if (chain_spin(a.sync, spins, t0)) break; __builtin_amdgcn_s_sleep(4); }
+    }
+    if (touched == 0x7fffffff) a.sync[3] = 1u;   // (keeps the touches)
+}
+
+// ---- toucher: one workgroup on the chain's XCD (a tier-2 workgroup that would have stepped aside).  A block's band planes are 64 KB =
+// 512 lines of 128 bytes: one dword per thread.  It follows the exported count (sync[4], a block or two behind the chain) at a distance of
+// touch_lead blocks and sleeps in between; it ends with the chain (exported count = nb), on the error word, or after two seconds.
+__device__ __forceinline__ void chain_touch(const ChainArgs& a, int tid)
+{
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    const char* bb = reinterpret_cast<const char*>(a.band);
+    int tb = 0, touched = 0;
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+        const int k = (int)__hip_atomic_load((gu32*)(a.sync + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k >= a.nb || tb >= a.nb) break;
+        if (__hip_atomic_load((gu32*)(a.sync + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const int lim = min(a.nb, k + a.touch_lead);
+        if (tb < lim) {
+            for (; tb < lim; ++tb) touched += *reinterpret_cast<const volatile int*>(bb + (size_t)tb * 65536 + (size_t)tid * 128);
+            spins = 0;
+        } else {
+            if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
+            if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;   // (100 MHz: two seconds without a new block -- the chain's own time-out reports it)
+            __builtin_amdgcn_s_sleep(8);
+        }
     }
     if (touched == 0x7fffffff) a.sync[3] = 1u;   // (keeps the touches)
 }
@@ -407,7 +435,17 @@ __global__ __launch_bounds__(CHAIN_NT) void k_tri_chain(ChainArgs a)
         unsigned where = 0, spins = 0;
         unsigned long long t0 = 0;
         while (!(where = __hip_atomic_load((gu32*)(a.sync + 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (flow_give_up(a.sync, spins, t0)) break; __builtin_amdgcn_s_sleep(2); }
-        if (where == xcc + 1u && gridDim.x > 9) return;
+        if (where == xcc + 1u && gridDim.x > 9) {
+            // ... all but the first of them (round 5): it pulls the band planes into this XCD's L2 well ahead of the chain.  Inside a cycle the
+            // planes come from memory, not from the Infinity Cache (where repeated sweeps of one level find them): the importer wave's touches,
+            // four blocks ahead and paced by its polls, arrive late then -- 64 steps in 6 500 cycles instead of 4 700 (profiles/r05_gs_chain.txt).
+            if (a.touch_lead <= 0) return;
+            if (tid == 0) s_role = (int)__hip_atomic_fetch_add((gu32*)(a.sync + 8), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(s_role) != 0) return;
+            chain_touch(a, tid);
+            return;
+        }
         chain_tier2(a, lane, role);
         if (role <= 2 || role >= (int)gridDim.x - 2) CTEND("tier-2");
         return;
