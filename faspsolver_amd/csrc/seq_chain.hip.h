@@ -45,6 +45,7 @@ struct ChainArgs {
     unsigned*             sync;   // [0] role ticket, [1] error word, [2] tier-2 block ticket, [4] blocks exported to W, [5] 1 + XCD of the chain's workgroup
     int                   nb, npad, rx, rg;
     int                   touch_lead; // > 0: a workgroup of its own on the chain's XCD pulls the band planes into the L2, this many blocks ahead of the exported count (0: the importer wave does, four blocks ahead)
+    int                   touch_t1;   // the toucher also pulls tier 1's entries
     int                   has_t2; // 0: no row has a tier-2 entry (no tier-2 workgroups in the launch: tier 1 starts from pass (1)'s record itself)
     int                   form;   // as tri_update
     double                w;
@@ -309,7 +310,16 @@ __device__ __forceinline__ void chain_touch(const ChainArgs& a, int tid)
         if (__hip_atomic_load((gu32*)(a.sync + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         const int lim = min(a.nb, k + a.touch_lead);
         if (tb < lim) {
-            for (; tb < lim; ++tb) touched += *reinterpret_cast<const volatile int*>(bb + (size_t)tb * 65536 + (size_t)tid * 128);
+            for (; tb < lim; ++tb) {
+                touched += *reinterpret_cast<const volatile int*>(bb + (size_t)tb * 65536 + (size_t)tid * 128);
+                if (a.touch_t1) {   // tier 1's values and columns of the block (the helper waves sit on the chain's CU: the same L2)
+                    const ChainBlk B = a.blk[tb];
+                    const char* v1 = reinterpret_cast<const char*>(a.t1v + (size_t)B.t1_off * 64);
+                    const char* c1 = reinterpret_cast<const char*>(a.t1c + (size_t)B.t1_off * 64);
+                    for (int l = tid; l < B.t1_n * 4; l += CHAIN_NT) touched += *reinterpret_cast<const volatile int*>(v1 + (size_t)l * 128);
+                    for (int l = tid; l < B.t1_n; l += CHAIN_NT) touched += *reinterpret_cast<const volatile int*>(c1 + (size_t)l * 128);
+                }
+            }
             spins = 0;
         } else {
             if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();

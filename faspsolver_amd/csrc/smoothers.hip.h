@@ -478,7 +478,8 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         // tier-2 workgroups: measured on levels 5-8 of P7(256) (profiles/r05_gs_chain.txt): 95 against 47 -- natural-order sweeps of the last two
         // levels (560-680 tier-2 entries per row) 773 -> 651 and 652 -> 515 us, everything else unchanged; 191: no further gain; 15: 2 x slower there
         const int far_wg = S.t2_steps > 0 && !g_tune.seq_test_hang ? (g_tune.seq_chain_grid > 0 ? g_tune.seq_chain_grid : 95) : 0;   // (seq_test_hang: nobody sums tier 2 -- the time-out path, tests)
-        ca.touch_lead = (far_wg > 8 && g_tune.seq_chain_touch > 0) ? g_tune.seq_chain_touch : 0;   // (a workgroup of the launch lands on the chain's XCD only when there are more than eight others)
+        ca.touch_lead = (far_wg > 8 && g_tune.seq_chain_touch > 0) ? g_tune.seq_chain_touch : 0;
+        ca.touch_t1 = g_tune.seq_chain_touch_t1;   // (tier 1's entries too: 298.7 -> 295.9 ms per GS-default solve of P7(256))   // (a workgroup of the launch lands on the chain's XCD only when there are more than eight others)
 #define CHAIN_LAUNCH(FF)                                                                                              \
         if (plain) hipLaunchKernelGGL((k_tri_chain_ref<FF>), dim3(1), dim3(64), 0, g_ctx.stream, ca, S.n1b);             \
         else hipLaunchKernelGGL((k_tri_chain<FF>), dim3(1 + far_wg), dim3(CHAIN_NT), dyn, g_ctx.stream, ca)
