@@ -251,6 +251,37 @@ def test_relative_16bit_columns_are_bit_transparent(gpu):
     assert st1 == st0 and np.array_equal(x1, x0) and np.array_equal(np.asarray(h1), np.asarray(h0))
 
 
+@pytest.mark.gpu
+def test_host_wait_reductions_are_bit_transparent(gpu):
+    """Round 5: a PCG iteration waits for the host twice instead of four times -- (z, r), beta and alpha stay on the device
+    (pcg_dev_beta), the true residual of the coarse safe CG's Check III is queued behind the persistent kernel (spcg_spec), (t,p) and
+    (z,r) are summed from their per-block partials by the kernels that divide by them (pcg_fold), the event pair around t = A p
+    brackets every fourth launch (ev_every) -- and the chain form of the sequential sweeps has its band planes touched ahead by a
+    workgroup of its own (seq_chain_touch).  None of it changes a bit: same divisions, same summation orders, same kernels on the
+    same data.  Jacobi and GS-CF solves of P7(128) with everything off against everything on: identical iterates and histories."""
+    n = 128
+    ia, ja, a, f, ue = fa.poisson7pt(n)
+    L = fa.lib()
+    keys = ((b"pcg_dev_beta", 1), (b"spcg_spec", 1), (b"pcg_fold", 1), (b"ev_every", 4), (b"seq_chain_touch", 8), (b"seq_chain_touch_t1", 1))
+    try:
+        for jac in (True, False):
+            itp, amgp = _params() if jac else _gs_params(T.SMOOTHER_GS, 1)
+            H = fa.AMG(ia, ja, a, amgp)
+            out = []
+            for on in (0, 1, 0):
+                for k, v in keys:
+                    L.fasp_hip_tune(k, v if on else (1 if k == b"ev_every" else 0))
+                st, x, hist, stats = H.solve(f, itp)
+                out.append((st, x, np.asarray(hist), stats.relres))
+            H.close()
+            assert out[0][0] == out[1][0] == out[2][0] > 0
+            assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][1], out[2][1]), jac
+            assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3], jac
+    finally:
+        for k, v in keys:
+            L.fasp_hip_tune(k, v)
+
+
 def _gs_params(smoother, order, w=1.0):
     itp = fa.param_solver_init(); itp.tol = 1e-8
     amgp = fa.param_amg_init()

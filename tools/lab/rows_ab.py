@@ -5,7 +5,7 @@ import numpy as np
 import faspsolver_amd as fa
 from faspsolver_amd import _types as T
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-key = (sys.argv[2] if len(sys.argv) > 2 else "rows_pipe").encode()
+key = (sys.argv[2] if len(sys.argv) > 2 else "ja16").encode()
 vals = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1]
 L = fa.lib()
 ia, ja, a, f, ue = fa.poisson7pt(n)
