@@ -115,8 +115,11 @@ __global__ __launch_bounds__(BLOCK) void k_split_rest(int nseq, const int* __res
                                                        const int* __restrict__ rja, const double* __restrict__ rval,
                                                        const double* __restrict__ b, const double* __restrict__ u,
                                                        double* __restrict__ rec, double* __restrict__ W, unsigned* __restrict__ sync,
-                                                       double* __restrict__ G2 = nullptr, int npad = 0)
+                                                       double* __restrict__ G2 = nullptr, int npad = 0, int zero_old = 0)
 {
+    // zero_old (round 5): the level's vector is all zeros -- the first sweep of a pre-smoothing step on every level of a cycle.  Every
+    // product of this pass is a zero then and the record is b_i itself: the rows' entries are not read (the reference subtracts the
+    // same zeros one by one).
     constexpr int RPB = BLOCK / L;
     if (blockIdx.x == 0 && threadIdx.x == 0) { sync[0] = 0u; sync[1] = 0u; sync[2] = 0u; sync[4] = 0u; sync[5] = 0u; sync[8] = 0u; }   // ticket counter and error word of the dataflow solve that follows (chain form: + the tier-2 ticket)
     if (G2)   // chain form (seq_chain.hip.h): tier 2's sums are "not yet" too, padding rows included
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_rest(int nseq, const int* __res
     for (int p0 = blockIdx.x * RPB; p0 < nseq; p0 += gridDim.x * RPB) {   // (whole wavefronts walk the loop: the DPP moves read neighbours)
         const int p = p0 + rloc;
         const bool on = p < nseq;
-        const int kb = on ? ria[p] : 0, ke = on ? ria[p + 1] : 0;
+        const int kb = (on && !zero_old) ? ria[p] : 0, ke = (on && !zero_old) ? ria[p + 1] : 0;
         double s = seq_row_sum<L>(rja, rval, kb + sl, ke, -1, [&](int c) { return u[c]; });
         s = group_sum_last<L>(s);
         if (on && sl == L - 1) {
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_rest(int nseq, const int* __res
 template <int L>
 __global__ __launch_bounds__(BLOCK) void k_split_direct(int nseq, const int* __restrict__ tr, const int* __restrict__ ria, const int* __restrict__ rja,
                                                          const double* __restrict__ rval, const double* __restrict__ dr, const double* __restrict__ b,
-                                                         double* u, int form, double w)
+                                                         double* u, int form, double w, int zero_old = 0)
 {
     constexpr int RPB = BLOCK / L;
     const int sl = threadIdx.x & (L - 1);
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_direct(int nseq, const int* __r
     for (int p0 = blockIdx.x * RPB; p0 < nseq; p0 += gridDim.x * RPB) {
         const int p = p0 + rloc;
         const bool on = p < nseq;
-        const int kb = on ? ria[p] : 0, ke = on ? ria[p + 1] : 0;
+        const int kb = (on && !zero_old) ? ria[p] : 0, ke = (on && !zero_old) ? ria[p + 1] : 0;   // (zero_old: as k_split_rest)
         double s = seq_row_sum<L>(rja, rval, kb + sl, ke, -1, [&](int c) { return u[c]; });   // (columns outside the sweep: nobody writes them in this launch)
         s = group_sum_last<L>(s);
         if (on && sl == L - 1) {

@@ -399,6 +399,9 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
                              "", wall_seconds() - t0);
         }
     }
+    // the level's vector is all zeros when this sweep starts (the first sweep of a pre-smoothing step; one rank -- in a sweep by turns the
+    // halo has been exchanged by then): pass (1) has nothing to read but b
+    const int zero_old = (D.x_zero && g_tune.seq_zero_skip && (D.replicated || comm_size() <= 1)) ? 1 : 0;
     materialise_zero(D);
     if (multicolor || S.rowlevels) {
         const int nlev = (int)S.ptr.size() - 1;
@@ -435,7 +438,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         const int rpb = BLOCK / S.LR;
         const int grid = std::max(1, std::min(MAXGRID, (ns + rpb - 1) / rpb));
 #define DIRECT_LAUNCH(LL) hipLaunchKernelGGL((k_split_direct<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, ns, (const int*)S.d_tr, \
-        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)S.d_dr, (const double*)D.b, D.x, form, w)
+        (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)S.d_dr, (const double*)D.b, D.x, form, w, zero_old)
         switch (S.LR) {
             case 1: DIRECT_LAUNCH(1); break;
             case 2: DIRECT_LAUNCH(2); break;
@@ -454,7 +457,7 @@ static int seq_sweep_local(fasp_hip_amg* h, int level, int kind, int form, doubl
         const int grid = std::max(1, std::min(MAXGRID, (ns + rpb - 1) / rpb));
 #define REST_LAUNCH(LL) hipLaunchKernelGGL((k_split_rest<LL>), dim3(grid), dim3(BLOCK), 0, g_ctx.stream, ns, (const int*)S.d_tr, \
         (const int*)S.d_ria, (const int*)S.d_rja, (const double*)S.d_rval, (const double*)D.b, (const double*)D.x, S.d_rec, S.d_W, S.d_prog, \
-        S.chain ? S.d_G2 : (double*)nullptr, S.chain ? S.npad : 0)
+        S.chain ? S.d_G2 : (double*)nullptr, S.chain ? S.npad : 0, zero_old)
         switch (S.LR) {
             case 1: REST_LAUNCH(1); break;
             case 2: REST_LAUNCH(2); break;

@@ -2191,6 +2191,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "pcg_dev_beta")) g_tune.pcg_dev_beta = value;   // top-level PCG: (z, r), beta and alpha stay on the device, one host wait per iteration (1, default) or two (0)
     else if (!std::strcmp(key, "seq_chain_touch")) g_tune.seq_chain_touch = value;   // chain form: blocks by which a workgroup of its own on the chain's XCD touches the band planes ahead (8; 0: the importer wave does, four ahead)
     else if (!std::strcmp(key, "seq_chain_touch_t1")) g_tune.seq_chain_touch_t1 = value;   // ... and tier 1's entries of those blocks (1, default)
+    else if (!std::strcmp(key, "seq_zero_skip")) g_tune.seq_zero_skip = value;   // sequential sweeps: the parallel pass of a sweep that starts from the zero vector reads b only (1, default) or every entry (0)
     else if (!std::strcmp(key, "pcg_fold")) g_tune.pcg_fold = value;           // one rank: (t,p) and (z,r) are summed from their partials by the kernels that divide by them (1, default) or by a k_finalize launch each (0)
     else if (!std::strcmp(key, "spcg_spec")) g_tune.spcg_spec = value;         // persistent coarse CG: the true residual of Check III queued behind the kernel, one host wait per coarse solve (1, default) or two (0)
     else if (!std::strcmp(key, "ev_every")) g_tune.ev_every = value;           // the level-0 t = A p launch inside a solve is bracketed by an event pair every n-th iteration (4; 1: every one)

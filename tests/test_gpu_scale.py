@@ -257,12 +257,13 @@ def test_host_wait_reductions_are_bit_transparent(gpu):
     (pcg_dev_beta), the true residual of the coarse safe CG's Check III is queued behind the persistent kernel (spcg_spec), (t,p) and
     (z,r) are summed from their per-block partials by the kernels that divide by them (pcg_fold), the event pair around t = A p
     brackets every fourth launch (ev_every) -- and the chain form of the sequential sweeps has its band planes touched ahead by a
-    workgroup of its own (seq_chain_touch).  None of it changes a bit: same divisions, same summation orders, same kernels on the
+    workgroup of its own (seq_chain_touch), and the parallel pass of a sweep that starts from the zero vector reads b only
+    (seq_zero_skip: the products it would have subtracted are zeros).  None of it changes a value: same divisions, same summation orders, same kernels on the
     same data.  Jacobi and GS-CF solves of P7(128) with everything off against everything on: identical iterates and histories."""
     n = 128
     ia, ja, a, f, ue = fa.poisson7pt(n)
     L = fa.lib()
-    keys = ((b"pcg_dev_beta", 1), (b"spcg_spec", 1), (b"pcg_fold", 1), (b"ev_every", 4), (b"seq_chain_touch", 8), (b"seq_chain_touch_t1", 1))
+    keys = ((b"pcg_dev_beta", 1), (b"spcg_spec", 1), (b"pcg_fold", 1), (b"ev_every", 4), (b"seq_chain_touch", 8), (b"seq_chain_touch_t1", 1), (b"seq_zero_skip", 1))
     try:
         for jac in (True, False):
             itp, amgp = _params() if jac else _gs_params(T.SMOOTHER_GS, 1)
