@@ -57,8 +57,10 @@ static int build_chain_host(const HostCSR& A, const int* seq, int ns, const Buf<
     // rows per 2 us) and by its helpers' time; tier 2 needs the window as slack (exported -> gate -> last gathers -> G2 -> importer:
     // 8-10 us = four to five blocks).  Measured on levels 5-8 of P7(256), all sweep kinds (profiles/r05_gs_chain.txt): six blocks beat
     // four, eight, twelve and "as many as stay below 64 entries per row" (9-32 blocks on the wider levels) everywhere but on the
-    // F rows of the last level.
-    if (n1b <= 0) n1b = 6;
+    // F rows of the last level.  That was measured on sweeps repeated back to back, tier 1's entries in the Infinity Cache; INSIDE a solve
+    // they stream from memory, through the chain's own compute unit, and the smaller window wins (whole solves, tools/lab/gs_build_ab.py:
+    // GS-CF at 256^3 291.2 / 288.3 / 285.2 / 284.0 / 283.7 ms for 6 / 5 / 4 / 3 / 2 blocks; SOR 258.2 -> 253.9; GS-CF at 128^3 48.5 -> 47.5).
+    if (n1b <= 0) n1b = 2;
     (void)hist;
     n1b = std::max(1, std::min(48, n1b));
     ChainHost& C = H.C;
