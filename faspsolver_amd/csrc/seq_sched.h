@@ -44,7 +44,7 @@ constexpr int FLOW_VIRTUAL = 0x40000000;       // flag in tr[2 p]: position p is
 // SB = -sum(block K - 1) from +0.0, t = ((G2 + S1) + SB) - sum(block K); then the update of tri_update.
 // ---------------------------------------------------------------------------
 #ifndef FASP_CHAIN_HA
-#define FASP_CHAIN_HA 12
+#define FASP_CHAIN_HA 4   // (whole GS-default solves of P7(256), tools/build_variant.sh ha<N> -DFASP_CHAIN_HA=<N>: 2-5 blocks 277 ms, 6 / 8 / 12 / 20 blocks 282-283 ms: helpers far ahead of the chain only wait -- and poll the LDS the chain wave lives on)
 #endif
 constexpr int CHAIN_HA = FASP_CHAIN_HA;   // blocks the tier-1 helpers may run ahead of the chain
 constexpr int CHAIN_PF = 32;          // steps of band coefficients the chain wave keeps in flight (and zero steps behind the last block)

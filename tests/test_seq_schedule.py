@@ -160,7 +160,7 @@ def test_chain_schedule_reproduces_the_sequential_sweep(form, w):
                 info = {}
                 r = _chain_selftest(ia, ja, a, seq, n1, form, w, info)
                 assert 0.0 <= r <= 1e-12, (n, bw, n1, r, info)
-                assert info["blocks"] == (len(seq) + 63) // 64 and info["rx"] == 64 * (info["n1b"] + 12 + 3), info
+                assert info["blocks"] == (len(seq) + 63) // 64 and info["rx"] == 64 * (info["n1b"] + (info["rg"] // 64 - 2) + 3), info   # (rg = 64 (CHAIN_HA + 2))
                 if bw * len(seq) // n >= 64 * (info["n1b"] + 3) and len(seq) > 64 * (info["n1b"] + 3):   # (the band in sweep positions reaches beyond tier 1)
                     assert info["t2"] > 0 and info["t1"] > 0 and info["band"] > 0, info
 
