@@ -51,7 +51,10 @@ struct ChainArgs {
     double                w;
 };
 
-constexpr int CHAIN_NT = 512;   // 8 waves (256 registers each: the chain wave keeps CHAIN_PF coefficient pairs in flight): chain, exporter, importer, 5 tier-1 helpers (chain workgroup) / 8 tier-2 workers (the others)
+#ifndef FASP_CHAIN_NT
+#define FASP_CHAIN_NT 512
+#endif
+constexpr int CHAIN_NT = FASP_CHAIN_NT;   // 8 waves (256 registers each: the chain wave keeps CHAIN_PF coefficient pairs in flight): chain, exporter, importer, 5 tier-1 helpers (chain workgroup) / 8 tier-2 workers (the others)
 
 template <int FORM>
 __device__ __forceinline__ double chain_update(double t, double d, double rd, double w, double ku)

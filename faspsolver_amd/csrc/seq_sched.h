@@ -47,7 +47,10 @@ constexpr int FLOW_VIRTUAL = 0x40000000;       // flag in tr[2 p]: position p is
 #define FASP_CHAIN_HA 4   // (whole GS-default solves of P7(256), tools/build_variant.sh ha<N> -DFASP_CHAIN_HA=<N>: 2-5 blocks 277 ms, 6 / 8 / 12 / 20 blocks 282-283 ms: helpers far ahead of the chain only wait -- and poll the LDS the chain wave lives on)
 #endif
 constexpr int CHAIN_HA = FASP_CHAIN_HA;   // blocks the tier-1 helpers may run ahead of the chain
-constexpr int CHAIN_PF = 32;          // steps of band coefficients the chain wave keeps in flight (and zero steps behind the last block)
+#ifndef FASP_CHAIN_PF
+#define FASP_CHAIN_PF 32
+#endif
+constexpr int CHAIN_PF = FASP_CHAIN_PF;          // steps of band coefficients the chain wave keeps in flight (and zero steps behind the last block)
 struct ChainBlk { int t1_off, t1_n, t2_off, t2_n; };   // offsets / counts in steps of 64 lanes
 struct ChainHost {
     int nb = 0, npad = 0, n1b = 0, rx = 0, rg = 0;
