@@ -739,6 +739,164 @@ FINISHED:
     return iter > MaxIt ? ERROR_SOLVER_MAXIT : iter;
 }
 
+// fasp_solver_pminres, KryPminres.c:1283-1650: the OLDER text of MinRes the reference keeps for mxv_matfree (oracle:
+// minres_mf_core).  Against minres_device: no iteration-0 line, |<r, B r>| at the start, absres is always ||r||_2, the
+// solution / stagnation checks run in every iteration, and the two restart branches take tz = tp WITHOUT the
+// preconditioner (:1524-1527, :1605-1608 read `if (pc == NULL) pc->fct(...) else cp`; without a preconditioner the
+// reference dereferences the null pointer there -- here that case copies as well).
+static int minres_mf_device(KOps& K, const double* b, double* u, double tol, double abstol, int MaxIt, int StopType,
+                            int PrtLvl, PcgOut* out)
+{
+    KVecOps V(K);
+    const int m = V.m;
+    const double maxdiff = tol * STAG_RATIO, sol_inf_tol = SMALLREAL;
+    int iter = 0, stag = 1, more_step = 1;
+    double absres0 = BIGREAL, absres = BIGREAL, normr0 = BIGREAL, relres = BIGREAL;
+    double normu2 = BIGREAL, normuu, normp, factor, alpha, alpha0, alpha1, temp2, red[8];
+    KCK(V.ensure(11));
+    double *p0 = V.vec(0), *p1 = V.vec(1), *p2 = V.vec(2), *z0 = V.vec(3), *z1 = V.vec(4), *t0 = V.vec(5),
+           *t1 = V.vec(6), *t = V.vec(7), *tp = V.vec(8), *tz = V.vec(9), *r = V.vec(10);
+    auto recheck = [&]() -> int {  // :1476-1497 == :1553-1573 (no default case)
+        KCK(V.resid(u, b, r));
+        KCK(V.dot(r, r, temp2));
+        absres = std::sqrt(temp2);
+        switch (StopType) {
+            case STOP_REL_RES: relres = std::sqrt(temp2) / normr0; break;
+            case STOP_REL_PRECRES:
+                KCK(V.pc(r, t)); KCK(V.dot(r, t, temp2)); temp2 = std::fabs(temp2);
+                relres = std::sqrt(temp2) / normr0; break;
+            case STOP_MOD_REL_RES: relres = std::sqrt(temp2) / normu2; break;
+        }
+        return 0;
+    };
+    auto restart = [&]() -> int {  // :1512-1543 == :1593-1624
+        KCK(V.zero(p0));
+        KCK(V.pc(r, p1));
+        KCK(V.mxv(p1, tp));
+        KCK(V.cp(tz, tp));
+        KCK(V.dot(tz, tp, normp));
+        normp = std::sqrt(normp);
+        KCK(V.cp(t, p1));
+        KCK(V.zero(t0)); KCK(V.zero(z0)); KCK(V.zero(t1)); KCK(V.zero(z1)); KCK(V.zero(p1));
+        d_axpy(m, 1 / normp, t, p1);
+        d_axpy(m, 1 / normp, tp, t1);
+        d_axpy(m, 1 / normp, tz, z1);
+        return 0;
+    };
+    if (PrtLvl > PRINT_NONE) std::printf("\nCalling MinRes solver (MatFree) ...\n");
+    KCK(V.zero(p0));
+    KCK(V.resid(u, b, r));
+    KCK(V.pc(r, p1));
+    switch (StopType) {
+        case STOP_REL_PRECRES:
+            KCK(V.dot(r, p1, temp2)); absres0 = std::sqrt(std::fabs(temp2));
+            normr0 = std::max(SMALLREAL, absres0); relres = absres0 / normr0; break;
+        case STOP_MOD_REL_RES:
+            KCK(V.nrm2(r, absres0)); KCK(V.nrm2(u, normu2)); normu2 = std::max(SMALLREAL, normu2);
+            relres = absres0 / normu2; break;
+        default:
+            KCK(V.nrm2(r, absres0)); normr0 = std::max(SMALLREAL, absres0); relres = absres0 / normr0; break;
+    }
+    if (relres < tol || absres0 < abstol) goto FINISHED;
+    KCK(V.mxv(p1, tp));
+    KCK(V.pc(tp, tz));
+    KCK(V.dot(tz, tp, normp));
+    normp = std::sqrt(std::fabs(normp));
+    KCK(V.cp(t, p1));
+    KCK(V.zero(p1));
+    d_axpy(m, 1 / normp, t, p1);
+    KCK(V.zero(t0)); KCK(V.zero(z0)); KCK(V.zero(t1)); KCK(V.zero(z1));
+    d_axpy(m, 1.0 / normp, tp, t1);
+    d_axpy(m, 1.0 / normp, tz, z1);
+
+    while (iter++ < MaxIt) {
+        KCK(V.dot(r, z1, alpha));
+        d_axpy(m, alpha, p1, u);
+        d_axpy(m, -alpha, t1, r);
+        KCK(V.mxv(z1, t));
+        KCK(V.dot(z1, t, alpha1));
+        KCK(V.mxv(z0, t));
+        KCK(V.dot(z1, t, alpha0));
+        KCK(V.cp(p2, z1));
+        d_axpy(m, -alpha1, p1, p2);
+        d_axpy(m, -alpha0, p0, p2);
+        KCK(V.mxv(p2, tp));
+        KCK(V.pc(tp, tz));
+        KCK(V.dot(tz, tp, normp));
+        normp = std::sqrt(std::fabs(normp));
+        KCK(V.cp(t, p2));
+        KCK(V.zero(p2));
+        d_axpy(m, 1 / normp, t, p2);
+        KCK(V.cp(p0, p1)); KCK(V.cp(p1, p2)); KCK(V.cp(t0, t1)); KCK(V.cp(z0, z1));
+        KCK(V.zero(t1)); KCK(V.zero(z1));
+        d_axpy(m, 1 / normp, tp, t1);
+        d_axpy(m, 1 / normp, tz, z1);
+        KCK(V.dot(r, r, temp2));
+        absres = std::sqrt(temp2);
+        if (d_norms(m, u, red, K.dist) < 0) return ERROR_MISC;  // ||u||^2, max|u|
+        normu2 = std::sqrt(red[0]);
+        switch (StopType) {
+            case STOP_REL_PRECRES:
+                KCK(V.pc(r, t)); KCK(V.dot(r, t, temp2)); temp2 = std::fabs(temp2);
+                relres = std::sqrt(temp2) / normr0; break;
+            case STOP_MOD_REL_RES: relres = std::sqrt(temp2) / normu2; break;
+            default: relres = std::sqrt(temp2) / normr0; break;
+        }
+        factor = absres / absres0;
+        itinfo(PrtLvl, StopType, iter, relres, absres, factor);
+        if (red[1] <= sol_inf_tol) {
+            if (PrtLvl > PRINT_MIN)
+                std::printf("### WARNING: Iteration stopped -- solution almost zero! [%s:%d]\n", "fasp_solver_pminres", 1460);
+            iter = ERROR_SOLVER_SOLSTAG;
+            break;
+        }
+        KCK(V.nrm2(p1, normuu));
+        normuu = std::fabs(alpha) * (normuu / normu2);
+        if (normuu < maxdiff) {
+            if (stag < MAX_STAG && PrtLvl >= PRINT_MORE) {
+                std::printf("||u-u'|| = %.10e and the comp. rel. res. = %.10e.\n", normuu, relres);
+                std::printf("### WARNING: Iteration restarted -- stagnation! [%s:%d]\n", "fasp_solver_pminres", 1473);
+            }
+            KCK(recheck());
+            if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+            if (relres < tol) break;
+            if (stag >= MAX_STAG) {
+                if (PrtLvl > PRINT_MIN)
+                    std::printf("### WARNING: Iteration stopped -- staggnation! [%s:%d]\n", "fasp_solver_pminres", 1505);
+                iter = ERROR_SOLVER_STAG;
+                break;
+            }
+            ++stag;
+            KCK(restart());
+        }
+        if (relres < tol) {
+            if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The computed relative residual = %.10e!\n", relres);
+            KCK(recheck());
+            if (PrtLvl >= PRINT_MORE) std::printf("### WARNING: The actual relative residual = %.10e!\n", relres);
+            if (relres < tol) break;
+            if (more_step >= MAX_RESTART) {
+                if (PrtLvl > PRINT_MIN)
+                    std::printf("### WARNING: The tolerence might be too small! [%s:%d]\n", "fasp_solver_pminres", 1581);
+                iter = ERROR_SOLVER_TOLSMALL;
+                break;
+            }
+            if (PrtLvl > PRINT_NONE)
+                std::printf("### WARNING: Iteration restarted -- stagnation! [%s:%d]\n", "fasp_solver_pminres", 1587);
+            ++more_step;
+            KCK(restart());
+        }
+        absres0 = absres;
+    }
+FINISHED:
+    if (PrtLvl > PRINT_NONE) {
+        if (iter > MaxIt) std::printf("### WARNING: MaxIt = %d reached with relative residual %.10e.\n", MaxIt, relres);
+        else if (iter >= 0) std::printf("Number of iterations = %d with relative residual %.10e.\n", iter, relres);
+    }
+    if (out) { out->relres = relres; out->absres = absres; out->normr0 = normr0; }
+    HIPCK(hipStreamSynchronize(V.s));
+    return iter > MaxIt ? ERROR_SOLVER_MAXIT : iter;
+}
+
 // fasp_solver_dcsr_pgcg, KryPgcg.c:60-195.  The reference allocates all MaxIt search directions
 // up front; here a direction is allocated when its iteration is reached.
 static int gcg_device(KOps& K, const double* b, double* u, double tol, double abstol, int MaxIt, int StopType,

@@ -1687,7 +1687,7 @@ void fasp_solver_matfree_init(int matrix_format, mxv_matfree* mf, void* A)
 }
 
 namespace {
-// which: 0 CG, 1 VGMRES, 2 VFGMRES, 3 BiCGstab, 4 GMRES, 6 GCG
+// which: 0 CG, 1 VGMRES, 2 VFGMRES, 3 BiCGstab, 4 GMRES, 5 MinRes, 6 GCG
 int krylov_matfree(const char* fn, int which, mxv_matfree* mf, dvector* b, dvector* u, precond* pc, double tol,
                    double abstol, int MaxIt, short restart, short StopType, short PrtLvl)
 {
@@ -1764,6 +1764,7 @@ int krylov_matfree(const char* fn, int which, mxv_matfree* mf, dvector* b, dvect
         case 2: st = gmres_mf_device(K, true, true, db.d, du.d, tol, MaxIt, restart, StopType, PrtLvl, &po); break;
         case 3: st = bicgstab_device(K, db.d, du.d, tol, MaxIt, PrtLvl, &H, &po); break;
         case 4: st = gmres_mf_device(K, false, false, db.d, du.d, tol, MaxIt, restart, StopType, PrtLvl, &po); break;
+        case 5: st = minres_mf_device(K, db.d, du.d, tol, abstol, MaxIt, StopType, PrtLvl, &po); break;
         case 6: st = gcg_device(K, db.d, du.d, tol, abstol, MaxIt, StopType, PrtLvl, &H, &po); break;
         default: st = ERROR_SOLVER_TYPE;
     }
@@ -1811,15 +1812,12 @@ int fasp_solver_pvfgmres(mxv_matfree* mf, dvector* b, dvector* x, precond* pc, c
     FASP_ENTRY();
     return krylov_matfree(__func__, 2, mf, b, x, pc, tol, abstol, MaxIt, restart, StopType, PrtLvl);
 }
-// KryPminres.c:1283.  Refused: the restart branches of the reference's matrix-free MinRes call
-// pc->fct exactly when pc == NULL (:1485, :1563) and skip the preconditioner otherwise.
-int fasp_solver_pminres(mxv_matfree*, dvector*, dvector*, precond*, const double, const double, const int, const short,
-                        const short)
+// KryPminres.c:1283: the reference's older MinRes text for mxv_matfree (minres_mf_device, krylov.hip.h)
+int fasp_solver_pminres(mxv_matfree* mf, dvector* b, dvector* u, precond* pc, const double tol, const double abstol,
+                        const int MaxIt, const short StopType, const short PrtLvl)
 {
     FASP_ENTRY();
-    std::printf("### ERROR: fasp_hip: fasp_solver_pminres (matrix-free MinRes) is not provided; "
-                "fasp_solver_dcsr_pminres is\n");
-    return ERROR_SOLVER_TYPE;
+    return krylov_matfree(__func__, 5, mf, b, u, pc, tol, abstol, MaxIt, 0, StopType, PrtLvl);
 }
 
 // SolMatFree.c:58: dispatch on itsolver_type

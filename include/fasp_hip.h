@@ -567,11 +567,12 @@ int  fasp_solver_dbsr_krylov(dBSRmat* A, dvector* b, dvector* x, ITS_param* itpa
 int  fasp_solver_dbsr_krylov_diag(dBSRmat* A, dvector* b, dvector* x, ITS_param* itparam);
 
 /* Matrix-free interface (SolMatFree.c:58/:157/:201; KryPcg.c:1260, KryPbcgs.c:1349, KryPgcg.c:213,
- * KryPgmres.c:1309, KryPvgmres.c:1468, KryPvfgmres.c:1026 -- the reference keeps older texts of CG and
- * GMRES for this interface; they are what runs here).  fasp_solver_matfree_init(MAT_CSR | MAT_BSR)
+ * KryPgmres.c:1309, KryPvgmres.c:1468, KryPvfgmres.c:1026, KryPminres.c:1283 -- the reference keeps older texts of
+ * CG, GMRES and MinRes for this interface; they are what runs here).  fasp_solver_matfree_init(MAT_CSR | MAT_BSR)
  * installs fasp_hip_mxv_csr / _bsr: such an operator is uploaded once and the iteration stays in HBM.
  * Any other mf->fct is called as a host function on host copies (one PCIe round trip per product).
- * fasp_solver_pminres returns ERROR_SOLVER_TYPE (see solver.hip). */
+ * fasp_solver_pminres: the reference's restart branches skip the preconditioner when one is given and dereference
+ * pc == NULL otherwise (KryPminres.c:1524, :1605); here both cases take tz = tp there (krylov.hip.h). */
 void fasp_hip_mxv_csr(const void* A, const double* x, double* y);
 void fasp_hip_mxv_bsr(const void* A, const double* x, double* y);
 void fasp_solver_matfree_init(int matrix_format, mxv_matfree* mf, void* A);

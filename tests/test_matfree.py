@@ -15,8 +15,8 @@ from test_plugin_krylov import diag_pc
 
 needs_ref = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
 NAMES = {0: "fasp_solver_pcg", 1: "fasp_solver_pvgmres", 2: "fasp_solver_pvfgmres", 3: "fasp_solver_pbcgs",
-         4: "fasp_solver_pgmres", 6: "fasp_solver_pgcg"}
-NO_RESTART = (0, 3, 6)
+         4: "fasp_solver_pgmres", 5: "fasp_solver_pminres", 6: "fasp_solver_pgcg"}
+NO_RESTART = (0, 3, 5, 6)
 MXV_FCT = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
@@ -53,7 +53,7 @@ def call_mf(lib_, which, mf, f, pc=None, tol=1e-8, maxit=300, restart=30, stop=1
 @needs_ref
 @pytest.mark.parametrize("with_pc", [False, True])
 @pytest.mark.parametrize("stop", [1, 2, 3])
-@pytest.mark.parametrize("which,restart", [(0, 30), (1, 30), (1, 5), (2, 30), (2, 4), (3, 30), (4, 30), (4, 6), (6, 30)])
+@pytest.mark.parametrize("which,restart", [(0, 30), (1, 30), (1, 5), (2, 30), (2, 4), (3, 30), (4, 30), (4, 6), (5, 30), (6, 30)])
 def test_oracle_matfree_equals_reference(which, restart, stop, with_pc):
     ia, ja, a, f, ue = poisson7pt(10)
     f = rhs(len(f))
@@ -71,7 +71,8 @@ def test_oracle_matfree_equals_reference(which, restart, stop, with_pc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("with_pc", [False, True])
 @pytest.mark.parametrize("which,restart,stop", [(0, 30, 1), (0, 30, 2), (0, 30, 3), (1, 30, 1), (1, 5, 1), (2, 30, 1), (2, 4, 2),
-                                                (3, 30, 1), (4, 30, 1), (4, 6, 3), (6, 30, 1)])
+                                                (3, 30, 1), (4, 30, 1), (4, 6, 3), (5, 30, 1), (5, 30, 2), (5, 30, 3),
+                                                (6, 30, 1)])
 def test_gpu_matfree_csr_matches_oracle(which, restart, stop, with_pc):
     ia, ja, a, f, ue = poisson7pt(14)
     f = rhs(len(f))
@@ -124,7 +125,7 @@ def test_gpu_matfree_bsr_and_dispatch():
     mf = MF(); L.fasp_solver_matfree_init(2, C.byref(mf), C.byref(A))
     L.fasp_solver_krylov.argtypes = [C.c_void_p, C.POINTER(T.dvector), C.POINTER(T.dvector), C.POINTER(T.ITS_param)]
     out = {}
-    for solver in (1, 2, 4, 5, 6, 7):
+    for solver in (1, 2, 3, 4, 5, 6, 7):
         itp, _ = default_params(); itp.tol = 1e-8; itp.itsolver_type = solver; itp.restart = 30; itp.maxit = 500
         x = np.zeros(n); bv, fk = T.as_vec(f); xv = T.dvector(n, T.dp(x))
         st = L.fasp_solver_krylov(C.addressof(mf), C.byref(bv), C.byref(xv), C.byref(itp))
@@ -133,9 +134,6 @@ def test_gpu_matfree_bsr_and_dispatch():
         L.fasp_blas_dbsr_mxv(C.byref(A), T.dp(x), T.dp(y))
         assert np.linalg.norm(f - y) <= 1.2e-8 * np.linalg.norm(f), solver
         out[solver] = x
-    itp, _ = default_params(); itp.itsolver_type = 3   # matrix-free MinRes: refused, see solver.hip
-    x = np.zeros(n); bv, fk = T.as_vec(f); xv = T.dvector(n, T.dp(x))
-    assert L.fasp_solver_krylov(C.addressof(mf), C.byref(bv), C.byref(xv), C.byref(itp)) == T.ERROR_SOLVER_TYPE
 
 
 @pytest.mark.gpu
