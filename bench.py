@@ -68,8 +68,8 @@ from faspsolver_amd import _types as T  # noqa: E402
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # PMC traffic summaries of THIS command, one per workload (tools/profile.sh <tag> <workload> -> tools/summarize_prof.py);
 # a figure is attached to a roofline entry only when kernel name, workload and grid size all match the run
-TRAFFIC_JSONS = {"constant": [os.path.join("profiles", r + "_rocprof", "traffic.json") for r in ("r05", "r04")],
-                 "variable": [os.path.join("profiles", r + "_rocprof_var", "traffic.json") for r in ("r05", "r04")]}
+TRAFFIC_JSONS = {"constant": [os.path.join("profiles", r + "_rocprof", "traffic.json") for r in ("r06", "r05", "r04")],
+                 "variable": [os.path.join("profiles", r + "_rocprof_var", "traffic.json") for r in ("r06", "r05", "r04")]}
 
 # kernel family codes of fasp_hip_amg_kernel_info -> (rocprofv3 kernel name of the OP_MXV_DOT instantiation, description)
 KERNELS = {0: ("k_csr_rows", "k_csr_rows<L, OP_MXV_DOT> (sub-wavefront per row, plain CSR)"),
@@ -280,6 +280,22 @@ def pmc_traffic(kernel_name, workload, n):
         except Exception:
             continue
     return None, None
+
+
+def solve_wide_traffic(workload, n):
+    """(HBM-side bytes per PCG iteration of the whole solve, source file) from the committed PMC summary of this command
+    (tools/summarize_prof.py: 2 x FETCH_SIZE + WRITE_SIZE summed over every kernel of the timed solves / iterations), or None."""
+    for rel in TRAFFIC_JSONS.get(workload, []):
+        try:
+            tj = json.load(open(os.path.join(ROOT, rel)))
+            if tj.get("workload") != workload or int(tj.get("n", -1)) != int(n):
+                continue
+            sw = tj.get("solve_wide")
+            if sw and sw.get("bytes_per_iteration"):
+                return float(sw["bytes_per_iteration"]), rel
+        except Exception:
+            continue
+    return None
 
 
 def roofline_entry(kind, moved_bytes, kernel_ms, launches, note=None, workload=None, n=None, lanes=None):
@@ -494,6 +510,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variable", action="store_true", help="skip the variable-coefficient second solve")
     ap.add_argument("--no-extra", action="store_true", help="skip the other configurations (configs 3 and 5 at full size, GS defaults at 128^3 and 256^3)")
+    ap.add_argument("--no-plain", action="store_true", help="skip the extra solves with the coding switched off (profiling runs)")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the read / copy / triad ceiling kernels (profiling runs)")
     ap.add_argument("--only-variable", action="store_true",
                     help="profiling runs: only the variable-coefficient solve (tools/profile.sh <tag> variable)")
     args = ap.parse_args()
@@ -570,26 +588,49 @@ def main():
                                 "roofline_plain_csr") if coded else None)
     roof["plain_csr_algorithmic_bytes"] = B
 
-    # The same operator through the plain-CSR kernel (coding switched off for these launches only)
+    # The same operator through the plain-CSR kernel, timed the same way as the coded one: INSIDE a solve (coding switched off for
+    # one warm-up and two timed solves: every coded operator of the hierarchy then runs its plain-CSR kernel; HIP events around the
+    # level-0 t = A p launches).  SURVEY 8(d)'s bytes over that time = north_star's "SpMV >= 60 % of the HBM roofline".
     plain = None
-    if coded:
+    if coded and not args.no_plain:
         try:
             L.fasp_hip_tune(b"compress", 0)
             pkind, _pb = H.kernel_info(0, 0)
-            ms_plain = float(H.time_kernel(5, 0, 20))   # level-0 t = A p fused with (t,p), 20 launches
+            el_p, st_p, _hp, stats_p, ms_plain = timed_solves(H, 1, 2)
             L.fasp_hip_tune(b"compress", 1)
-            plain = roofline_entry(pkind, float(B), ms_plain, 20, workload="constant", n=n)
-            log(f"plain-CSR level-0 SpMV: {ms_plain*1e3:.1f} us = {plain['achieved']:.0f} GB/s = {plain['frac']:.3f} of peak")
+            plain = roofline_entry(pkind, float(B), ms_plain, int(stats_p.spmv_launches) * 2, workload="constant", n=n)
+            plain["timed"] = "inside two solves with every coded operator on its plain-CSR kernel (HIP events around the level-0 launches)"
+            plain["solve_ms_per_step_all_plain_csr"] = 1e3 * el_p / 2
+            plain["iterations"] = int(st_p)
+            log(f"plain-CSR level-0 SpMV in-solve: {ms_plain*1e3:.1f} us = {plain['achieved']:.0f} GB/s = {plain['frac']:.3f} of peak; "
+                f"solve with plain CSR everywhere {1e3*el_p/2:.2f} ms, {st_p} iterations")
         except Exception as e:
             L.fasp_hip_tune(b"compress", 1)
             log(f"plain-CSR timing failed: {e!r}")
-    else:
+    elif not coded:
         plain = dict(roof)
+    # inside the object the driver keeps: what SURVEY 8(d) asks for next to what the coded kernel does
+    roof["frac_by_survey_8d_bytes"] = (B / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if kernel_ms > 0 else None
+    if coded:
+        roof["frac_by_survey_8d_bytes_note"] = ("not comparable (> 1): the coded operator does not read IA / JA / val; the plain-CSR kernel of "
+                                                "the same operator, same timing method: plain_csr")
+    roof["plain_csr"] = ({k: plain[k] for k in ("kernel", "achieved", "frac", "bytes_per_launch", "ms_per_launch", "launches_timed", "traffic",
+                                                "traffic_over_bytes", "timed", "solve_ms_per_step_all_plain_csr") if k in plain}
+                         if plain else None)
+    # solve-wide: HBM-side bytes per PCG iteration (PMC passes of this command, profiles/<round>_rocprof/traffic.json) over the time of
+    # an iteration in THIS run
+    sw = solve_wide_traffic("constant", n)
+    if sw and st > 0:
+        it_ms = ms_per_step / int(st)
+        roof["solve_wide"] = {"bytes_per_iteration": sw[0], "ms_per_iteration": it_ms, "achieved": sw[0] / (it_ms * 1e-3) / 1e9,
+                              "frac": sw[0] / (it_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "unit": "GB/s", "traffic_source": sw[1]}
+    else:
+        roof["solve_wide"] = None
 
     ceilings = None
     try:
         out3 = (C.c_double * 3)()
-        if L.fasp_hip_measure_ceilings(out3, C.c_size_t(1 << 30), 5) == 0:
+        if not args.no_ceilings and L.fasp_hip_measure_ceilings(out3, C.c_size_t(1 << 30), 5) == 0:
             ceilings = {"unit": "GB/s", "read": out3[0], "copy": out3[1], "triad": out3[2],
                         "buffer_bytes": 1 << 30,
                         "note": "16 bytes per lane, 1024-block grid, HIP events; roofline fractions use the nominal 8000 GB/s",
@@ -654,6 +695,11 @@ def main():
 
     if not args.no_variable:
         out["variable_coefficient"] = variable_leg(n, (ia, ja, a, f, ue), itp, amgp, timed_solves)
+        if out["variable_coefficient"]:   # the general-matrix number inside the keys the driver keeps
+            vc = out["variable_coefficient"]
+            out["roofline"]["variable_coefficient"] = {"ms_per_step": vc["ms_per_step"], "iterations": vc["iterations"],
+                                                       "level0_spmv_frac": vc["roofline"]["frac"], "level0_kernel": vc["roofline"]["kernel"]}
+            out["config"]["variable_coefficient_ms_per_step"] = vc["ms_per_step"]
     if not args.no_extra and args.gpus == 1:
         del ia, ja, a
         out["other_configs"] = other_configs_leg()

@@ -35,7 +35,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_time_bsr_mxv", "fasp_solver_dbsr_krylov_amg", "fasp_hip_bsr_amg_create", "fasp_hip_bsr_amg_create_host",
     "fasp_hip_bsr_amg_destroy", "fasp_hip_bsr_amg_num_levels", "fasp_hip_bsr_amg_get_matrix",
     "fasp_hip_bsr_amg_get_diaginv", "fasp_hip_bsr_solve",
-    "fasp_hip_set_device", "fasp_hip_device_count", "fasp_hip_available",
+    "fasp_hip_set_device", "fasp_hip_device_count", "fasp_hip_device_identity", "fasp_hip_available",
     "fasp_hip_amg_create", "fasp_hip_amg_create_host", "fasp_hip_amg_upload",
     "fasp_hip_amg_destroy", "fasp_hip_amg_num_levels", "fasp_hip_amg_get_matrix",
     "fasp_hip_amg_get_cfmark", "fasp_hip_solve", "fasp_hip_set_rhs", "fasp_hip_set_guess",

@@ -22,6 +22,34 @@ import sys
 import time
 
 
+def visible_gpu_count():
+    """Number of GPUs this process may use, WITHOUT touching the HIP runtime (a process that has initialised the GPU must not
+    start the probe children after an exec, and torch.cuda.device_count() initialises more than it says on some images):
+    the KFD topology (a node with simd_count > 0 is a GPU), cut down to the render nodes this process can open (a container
+    that is given one GPU of eight still sees all eight in the topology) and by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when one of them is set.  0 when there is no KFD (no GPU box)."""
+    import glob
+    import os
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(prop):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except OSError:
+            pass
+    render = [d for d in glob.glob("/dev/dri/renderD*") if os.access(d, os.R_OK | os.W_OK)]
+    if render:
+        n = min(n, len(render))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [t for t in v.split(",") if t.strip() != ""]
+            n = min(n, len(ids)) if n else 0
+    return n
+
+
 def choose_transport(candidates, probe, all_min, log=lambda s: None):
     """The first transport of `candidates` whose probe passed on EVERY rank (None if there is none).
     probe(name) -> this rank's exit code; all_min(ok) -> the minimum of `ok` over the ranks (a collective: every rank

@@ -405,6 +405,7 @@ static int precond_amg(fasp_hip_amg* h, double* r, double** z)
     p.polynomial_degree = u.polynomial_degree; p.coarse_solver = u.coarse_solver;
     p.coarse_scaling = u.coarse_scaling; p.tentative_smooth = u.tentative_smooth;
     p.amli_degree = u.amli_degree; p.nl_amli_krylov_type = u.nl_amli_krylov_type;
+    { const int rc = renumber_conflict(h, p); if (rc < 0) return rc; }
     DevLevel& D0 = h->L[0];
     const bool pre_marked = h->pre_marked;
     h->pre_marked = false;
@@ -462,6 +463,7 @@ static int amg_solve_device(fasp_hip_amg* h, const AMG_param& param, Hist& hist,
     hipStream_t s = g_ctx.stream;
     double red[2], relres1 = 1.0, absres0, absres = 0.0;
     int iter = 0, st;
+    if ((st = renumber_conflict(h, param)) < 0) return st;
     if (d_dot(m, h->b, h->b, red, dist) < 0) return ERROR_MISC;
     const double sumb = std::sqrt(red[0]);
     absres0 = sumb;

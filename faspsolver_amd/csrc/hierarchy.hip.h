@@ -304,13 +304,30 @@ static int dist_launch(DevLevel& V, const DevCSR& M, CsrArgs a, const DevLevel* 
 // coarsest level -- whose safe CG sums dot products -- keep theirs).  Row sums keep their storage order: a cycle is bit-identical
 // with and without it (tests/test_gpu_scale.py::test_renumbered_levels_are_bit_transparent).  Not for the sequential smoothers (they
 // sweep in index order), the recursive cycles and coarse scaling (dot products on the mid levels), row-partitioned hierarchies.
-static bool renumber_allowed(const fasp_hip_amg* h)
+static bool renumber_param_ok(const AMG_param& p)
 {
-    const AMG_param& p = h->param;
-    if (g_oneshot_upload) return false;   // (one solve per setup -- fasp_solver_dcsr_krylov_amg: like the matrix coding, it would cost more than it saves)
-    return g_tune.renumber != 0 && comm_size() == 1 && (p.smoother == SMOOTHER_JACOBI || p.smoother == SMOOTHER_L1DIAG) &&
+    return (p.smoother == SMOOTHER_JACOBI || p.smoother == SMOOTHER_L1DIAG) &&
            (p.cycle_type == V_CYCLE || p.cycle_type == W_CYCLE || p.cycle_type == VW_CYCLE || p.cycle_type == WV_CYCLE) &&
            p.coarse_scaling != 1 && p.AMG_type == CLASSIC_AMG;
+}
+static bool renumber_allowed(const fasp_hip_amg* h)
+{
+    if (g_oneshot_upload) return false;   // (one solve per setup -- fasp_solver_dcsr_krylov_amg: like the matrix coding, it would cost more than it saves)
+    return g_tune.renumber != 0 && comm_size() == 1 && renumber_param_ok(h->param);
+}
+// The numbering is decided ONCE, at upload, from the parameters of the setup; a later call may bring other ones (fasp_hip_amg_solve's
+// per-call AMG_param, a precond_data the caller edited between setup and apply).  Sweep schedules, C/F markers and polynomial
+// diagonals are built from the host hierarchy in natural order: applied to brick-ordered vectors they would be silently wrong.
+// Such a call is refused; fasp_hip_tune("renumber", 0) before the setup keeps every level natural.
+static int renumber_conflict(const fasp_hip_amg* h, const AMG_param& p)
+{
+    bool any = false;
+    for (const auto& pm : h->perm) any = any || !pm.empty();
+    if (!any || renumber_param_ok(p)) return FASP_SUCCESS;
+    std::printf("### ERROR: fasp_hip: this hierarchy was uploaded for an order-independent smoother (its mid levels are renumbered); "
+                "smoother %d / cycle %d / coarse_scaling %d need the natural order -- set them before the setup, or "
+                "fasp_hip_tune(\"renumber\", 0)\n", (int)p.smoother, (int)p.cycle_type, (int)p.coarse_scaling);
+    return ERROR_INPUT_PAR;
 }
 static bool dev_coded(const DevCSR& M) { return M.pat != nullptr || M.code != nullptr; }
 

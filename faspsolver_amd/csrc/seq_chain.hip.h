@@ -42,7 +42,7 @@ struct ChainArgs {
     double*               W;      // the new values by position (sentinel until written); W[npad] = 0.0 for the padding entries of tier 2; W[npad + 64 ..+ 128): scratch
     double*               G2;     // tier 2's sums by position (sentinel until written)
     double*               u;
-    unsigned*             sync;   // [0] role ticket, [1] error word, [2] tier-2 block ticket, [4] blocks exported to W, [5] 1 + XCD of the chain's workgroup
+    unsigned*             sync;   // [0] role ticket, [1] error word, [2] tier-2 block ticket, [4] blocks exported to W, [5] 1 + XCD of the chain's workgroup, [8] toucher ticket, [9] workgroups that stepped aside
     int                   nb, npad, rx, rg;
     int                   touch_lead; // > 0: a workgroup of its own on the chain's XCD pulls the band planes into the L2, this many blocks ahead of the exported count (0: the importer wave does, four blocks ahead)
     int                   touch_t1;   // the toucher also pulls tier 1's entries
@@ -54,6 +54,12 @@ struct ChainArgs {
 #ifndef FASP_CHAIN_NT
 #define FASP_CHAIN_NT 512
 #endif
+static_assert(FASP_CHAIN_NT >= 256 && FASP_CHAIN_NT <= 1024 && FASP_CHAIN_NT % 64 == 0, "the chain workgroup deals four roles to whole wavefronts (chain, exporter, importer, >= 1 helper)");
+static_assert(64 % CHAIN_PF == 0 && CHAIN_PF <= 64 && CHAIN_PF >= 1, "chain_block's register ring walks a block's 64 steps in whole turns of CHAIN_PF");
+static_assert(CHAIN_HA >= 1 && 64 * (48 + CHAIN_HA + 3) <= 65535, "tier 1's ring index is a 16-bit value (rx = 64 (n1b + CHAIN_HA + 3), n1b <= 48)");
+// compiler-only ordering between a payload and its flag (both relaxed atomics to DIFFERENT addresses: the hardware keeps a wave's LDS
+// operations, and its stores, in program order; nothing in the language keeps the compiler from swapping them -- ADVICE r5).  No instruction.
+#define CHAIN_CFENCE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
 constexpr int CHAIN_NT = FASP_CHAIN_NT;   // 8 waves (256 registers each: the chain wave keeps CHAIN_PF coefficient pairs in flight): chain, exporter, importer, 5 tier-1 helpers (chain workgroup) / 8 tier-2 workers (the others)
 
 template <int FORM>
@@ -205,7 +211,9 @@ __device__ __forceinline__ void chain_wave(const ChainArgs& a, double* X, double
         // the ring slots of block K held block K - rx / 64: every helper that read it is done (rx = 64 (n1b + CHAIN_HA + 3)), and the
         // porter has exported it (it trails the chain by a block or two; checked, not assumed)
         while (K >= ringb && __hip_atomic_load(s_exp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= K - ringb) { if (chain_spin(a.sync, spins, t0)) break; }
+        CHAIN_CFENCE();
         lds_put(X + xi, chain_update<FORM>(accA, d, rd, a.w, ku));
+        CHAIN_CFENCE();
         if (lane == 0) __hip_atomic_store(s_done, K + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (behind the values: LDS operations of a wave complete in order)
         xi += 64; if (xi >= a.rx) xi -= a.rx;
         gi += 64; if (gi >= a.rg) gi -= a.rg;
@@ -231,6 +239,7 @@ __device__ __forceinline__ void chain_export(const ChainArgs& a, double* X, int*
     unsigned spins = 0;
     unsigned long long t0 = 0;
     auto publish = [&](int n) {
+        CHAIN_CFENCE();
         if (a.has_t2 && n > published) { published = n; if (lane == 0) __hip_atomic_store((gu32*)(a.sync + 4), (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     };
     for (int ex = 0; ex < a.nb; ++ex) {
@@ -239,7 +248,9 @@ __device__ __forceinline__ void chain_export(const ChainArgs& a, double* X, int*
             if (chain_spin(a.sync, spins, t0)) break;
             __builtin_amdgcn_s_sleep(1);
         }
+        CHAIN_CFENCE();
         const double x = __hip_atomic_load(X + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        CHAIN_CFENCE();
         const int p = ex * 64 + lane;
         const int row = a.tr[2 * (size_t)p + 1];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the row index above: a load; from here on this wave has stores in flight only)
@@ -247,6 +258,7 @@ __device__ __forceinline__ void chain_export(const ChainArgs& a, double* X, int*
         else a.W[p] = x;
         *(row >= 0 ? a.u + row : a.W + a.npad + 64 + lane) = x;   // (padding rows write to scratch behind W: every block issues exactly two stores per lane)
         xi += 64; if (xi >= a.rx) xi -= a.rx;
+        CHAIN_CFENCE();
         if (lane == 0) __hip_atomic_store(s_exp, ex + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (behind this wave's LDS read of the block)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -287,6 +299,7 @@ __device__ __forceinline__ void chain_import(const ChainArgs& a, double* G2r, in
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (__builtin_amdgcn_ballot_w64(g2[j] == FLOW_SENT)) break;   // (in block order: the first one that is not there ends the turn)
+            CHAIN_CFENCE();
             __hip_atomic_store(G2r + gi, __longlong_as_double((long long)g2[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             gi += 64; if (gi >= a.rg) gi -= a.rg;
             ++im;
@@ -314,7 +327,7 @@ __device__ __forceinline__ void chain_touch(const ChainArgs& a, int tid)
         const int lim = min(a.nb, k + a.touch_lead);
         if (tb < lim) {
             for (; tb < lim; ++tb) {
-                touched += *reinterpret_cast<const volatile int*>(bb + (size_t)tb * 65536 + (size_t)tid * 128);
+                for (int l = tid; l < 512; l += CHAIN_NT) touched += *reinterpret_cast<const volatile int*>(bb + (size_t)tb * 65536 + (size_t)l * 128);
                 if (a.touch_t1) {   // tier 1's values and columns of the block (the helper waves sit on the chain's CU: the same L2)
                     const ChainBlk B = a.blk[tb];
                     const char* v1 = reinterpret_cast<const char*>(a.t1v + (size_t)B.t1_off * 64);
@@ -361,8 +374,10 @@ __device__ __forceinline__ void chain_tier1(const ChainArgs& a, double* X, doubl
                                have = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                if (need < have || chain_spin(a.sync, spins, t0)) break;
                            }
+                           CHAIN_CFENCE();
                        },
                        [&](int ci) -> double { return __hip_atomic_load(X + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); });
+        CHAIN_CFENCE();
         __hip_atomic_store(S1 + (K * 64 + lane) % a.rg, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         CT(1);
 #ifdef CHAIN_TIMING
@@ -405,6 +420,7 @@ __device__ __forceinline__ void chain_tier2(const ChainArgs& a, int lane, int wg
                                if (need < have || chain_spin(a.sync, spins, t0)) break;
                                __builtin_amdgcn_s_sleep(8);
                            }
+                           CHAIN_CFENCE();
 #ifdef CHAIN_TIMING
                            tw += clock64() - w0;
 #endif
@@ -448,7 +464,17 @@ __global__ __launch_bounds__(CHAIN_NT) void k_tri_chain(ChainArgs a)
         unsigned where = 0, spins = 0;
         unsigned long long t0 = 0;
         while (!(where = __hip_atomic_load((gu32*)(a.sync + 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (flow_give_up(a.sync, spins, t0)) break; __builtin_amdgcn_s_sleep(2); }
+        // (At most a quarter of the launch steps aside -- sync[9] counts them: with eight XCDs that is everybody who shares the chain's, an
+        // eighth; on a device or partition with ONE XCD, where every workgroup "shares" it, the other three quarters stay and sum tier 2
+        // instead of leaving the chain to its time-out: ADVICE r5.)
+        bool aside = false;
         if (where == xcc + 1u && gridDim.x > 9) {
+            if (tid == 0) s_role = (int)__hip_atomic_fetch_add((gu32*)(a.sync + 9), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            aside = (unsigned)__builtin_amdgcn_readfirstlane(s_role) < (gridDim.x - 1u) / 4u;
+            __syncthreads();
+        }
+        if (aside) {
             // ... all but the first of them (round 5): it pulls the band planes into this XCD's L2 well ahead of the chain.  Inside a cycle the
             // planes come from memory, not from the Infinity Cache (where repeated sweeps of one level find them): the importer wave's touches,
             // four blocks ahead and paced by its polls, arrive late then -- 64 steps in 6 500 cycles instead of 4 700 (profiles/r05_gs_chain.txt).

@@ -28,28 +28,15 @@ static int build_chain_host(const HostCSR& A, const int* seq, int ns, const Buf<
     const int nb = (ns + 63) / 64, npad = nb * 64;
     double tl = wall_seconds();
     auto lap = [&](const char* what) { if (timing) { const double t = wall_seconds(); std::printf("    [chain schedule] %-28s %.3f s\n", what, t - tl); tl = t; } };
-    // ---- how far back the lower entries reach, in blocks: the size of tier 1
-    std::vector<long long> hist(66, 0);
+    // ---- rows the reference leaves alone (no usable diagonal) have no chain form
     int alone_rows = 0;
-#pragma omp parallel
-    {
-        std::vector<long long> hl(66, 0);
-        int al = 0;
-#pragma omp for schedule(static) nowait
-        for (int q = 0; q < ns; ++q) {
-            const int i = seq[q], K = q >> 6;
-            double dg = 0.0;
-            for (int k = A.ia[i]; k < A.ia[i + 1]; ++k) {
-                const int j = A.ja[k];
-                if (j == i) { dg = A.val[k]; continue; }
-                if (j >= n) continue;
-                const int pj = pos[j];
-                if ((unsigned)pj < (unsigned)q) hl[(size_t)std::min(65, K - (pj >> 6))]++;
-            }
-            if (!(std::fabs(dg) > SMALLREAL)) ++al;
-        }
-#pragma omp critical
-        { for (int d = 0; d < 66; ++d) hist[(size_t)d] += hl[(size_t)d]; alone_rows += al; }
+#pragma omp parallel for schedule(static) reduction(+ : alone_rows)
+    for (int q = 0; q < ns; ++q) {
+        const int i = seq[q];
+        double dg = 0.0;
+        for (int k = A.ia[i]; k < A.ia[i + 1]; ++k)
+            if (A.ja[k] == i) dg = A.val[k];
+        if (!(std::fabs(dg) > SMALLREAL)) ++alone_rows;
     }
     if (alone_rows) return 1;   // (rows the reference leaves alone: the dataflow form handles them)
     int n1b = n1_blocks;
@@ -61,7 +48,6 @@ static int build_chain_host(const HostCSR& A, const int* seq, int ns, const Buf<
     // they stream from memory, through the chain's own compute unit, and the smaller window wins (whole solves, tools/lab/gs_build_ab.py:
     // GS-CF at 256^3 291.2 / 288.3 / 285.2 / 284.0 / 283.7 ms for 6 / 5 / 4 / 3 / 2 blocks; SOR 258.2 -> 253.9; GS-CF at 128^3 48.5 -> 47.5).
     if (n1b <= 0) n1b = 2;
-    (void)hist;
     n1b = std::max(1, std::min(48, n1b));
     ChainHost& C = H.C;
     C.nb = nb; C.npad = npad; C.n1b = n1b;
@@ -206,11 +192,12 @@ int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int
     // The ONE sequential pass over the matrix: dependency class and number of lower entries of every row, and the strips --
     // contiguous ranges of the sweep sequence, closed when the lower part reaches the target size (12 bytes per entry + 40 per
     // row) or the LDS is full (own rows + distinct earlier rows read + the constant).
-    // Strip size: the caller's, or -- when it is the default of 512 KB -- what the levels of P7(256) measured best with once the deep
+    // Strip size: the caller's, or -- when the caller leaves it to the schedule (<= 0, the default) -- what the levels of P7(256) measured best with once the deep
     // levels had left for the chain form (profiles/r05_gs_chain.txt, tools/perf_gs_levels.py 256 seq_strip_kb=...): sweeps over ALL rows
     // of a wide level (natural order: twice the lower entries per row of a C / F sweep) 1 MB (level 0 2277 -> 1930 us, level 1 2029 ->
     // 1745), the long-row levels that stay in the dataflow form 256 KB (level 4: C rows 885 -> 756, F rows 620 -> 565), 512 KB otherwise.
-    if (strip_kb == 512) {
+    if (strip_kb <= 0) {
+        strip_kb = 512;
         if (ns == n && n >= 1000000) strip_kb = 1024;
         else if (n > 0 && (double)A.nnz / n >= 128.0) strip_kb = 256;
     }

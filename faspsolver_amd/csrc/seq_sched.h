@@ -81,7 +81,7 @@ struct SplitHost {
 // team > 0: OpenMP team of this call (several schedules are built side by side, one host thread each: smoothers.hip.h)
 // spine: 1 where it pays (above), 0 never, 2 wherever a row has two lanes or more (tests)
 // chain: 0 never the chain form, 1 where the sweep is chain-bound (few rows per dependency class) and the form applies, 2 wherever it applies;
-// chain_n1: blocks of tier 1 (0: chosen from the entries' distances)
+// chain_n1: blocks of tier 1 (0: two, the value whole solves measured best with -- seq_sched.cpp); strip_kb <= 0: chosen by level shape
 int build_split_host(const HostCSR& A, const int* seq, int ns, int strip_kb, int seq_lanes, bool timing, SplitHost& H, int team = 0, int spine = 1,
                      int chain = 0, int chain_n1 = 0);
 

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_rest(int nseq, const int* __res
     // product of this pass is a zero then and the record is b_i itself: the rows' entries are not read (the reference subtracts the
     // same zeros one by one).
     constexpr int RPB = BLOCK / L;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { sync[0] = 0u; sync[1] = 0u; sync[2] = 0u; sync[4] = 0u; sync[5] = 0u; sync[8] = 0u; }   // ticket counter and error word of the dataflow solve that follows (chain form: + the tier-2 ticket)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sync[0] = 0u; sync[1] = 0u; sync[2] = 0u; sync[4] = 0u; sync[5] = 0u; sync[8] = 0u; sync[9] = 0u; }   // ticket counter and error word of the dataflow solve that follows (chain form: + the tier-2 ticket)
     if (G2)   // chain form (seq_chain.hip.h): tier 2's sums are "not yet" too, padding rows included
         for (int p = blockIdx.x * BLOCK + threadIdx.x; p < npad; p += gridDim.x * BLOCK) G2[p] = __longlong_as_double((long long)FLOW_SENT);
     const int sl = threadIdx.x & (L - 1);

@@ -198,6 +198,17 @@ int fasp_hip_device_count(void)
     return n;
 }
 
+// PCI bus id ("0000:c1:00.0") of the device this process is bound to (binding it to the default one if nothing is yet): how a
+// multi-rank run proves that its ranks sit on DIFFERENT devices (bench_dist.py, tests/test_gpu_dist.py).
+int fasp_hip_device_identity(char* out, int cap)
+{
+    FASP_ENTRY();
+    if (!out || cap < 16) return ERROR_INPUT_PAR;
+    if (ctx_init() < 0) return ERROR_MISC;
+    if (hipDeviceGetPCIBusId(out, cap, g_ctx.device) != hipSuccess) return ERROR_MISC;
+    return g_ctx.device;
+}
+
 int fasp_hip_available(void)
 {
     FASP_ENTRY();
@@ -2163,12 +2174,12 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "split_rows")) g_tune.split_rows = value;
     else if (!std::strcmp(key, "gs_multicolor")) g_tune.gs_multicolor = value;
     else if (!std::strcmp(key, "seq_flow")) { g_tune.seq_flow = value; if (value) g_flow_disabled = false; }
-    else if (!std::strcmp(key, "seq_strip_kb")) g_tune.seq_strip_kb = value;
+    else if (!std::strcmp(key, "seq_strip_kb")) g_tune.seq_strip_kb = value;   // KB of lower entries per strip of the dataflow solve (0, default: 256 / 512 / 1024 by level shape, seq_sched.cpp)
     else if (!std::strcmp(key, "seq_jobs")) g_tune.seq_jobs = value;
     else if (!std::strcmp(key, "local_square")) g_tune.local_square = value;   // a rank's rows of a partitioned level are coded like a square operator (read at upload)
     else if (!std::strcmp(key, "seq_grid")) g_tune.seq_grid = value;     // workgroups of the dataflow solve at most (0: twice the strips the chain front is in at a time + 2, seq_sched.cpp; < 0: as many as are resident)
     else if (!std::strcmp(key, "seq_chain")) g_tune.seq_chain = value;   // chain form of the triangular solve (seq_chain.hip.h): 0 never, 1 on chain-bound sweeps, 2 wherever it applies; read when a schedule is built
-    else if (!std::strcmp(key, "seq_chain_n1")) g_tune.seq_chain_n1 = value;       // blocks of 64 rows in tier 1 (0: chosen from the entries' distances)
+    else if (!std::strcmp(key, "seq_chain_n1")) g_tune.seq_chain_n1 = value;       // blocks of 64 rows in tier 1 (0: two)
     else if (!std::strcmp(key, "seq_chain_grid")) g_tune.seq_chain_grid = value;   // tier-2 workgroups of the chain launch (0: default)
     else if (!std::strcmp(key, "seq_test_hang")) g_tune.seq_test_hang = value;     // tests: the next chain launches go without their tier-2 workgroups -- every waiter runs into its bounded poll (2 s)
     else if (!std::strcmp(key, "seq_rest_lanes")) g_tune.seq_rest_lanes = value;   // lanes per row of the rest pass (0: from the mean row length); read at launch

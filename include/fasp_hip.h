@@ -458,6 +458,8 @@ const double* fasp_hip_bsr_amg_get_diaginv(const fasp_hip_amg_bsr* h, int level)
 int fasp_hip_set_device(int device);
 /* Number of visible GPUs, or a negative ERROR_* code. */
 int fasp_hip_device_count(void);
+/* PCI bus id of the device this process is bound to into out (cap >= 16); returns the device index or a negative ERROR_* code. */
+int fasp_hip_device_identity(char* out, int cap);
 /* 1 when a gfx950 device is usable, else 0 (never initialises a fallback). */
 int fasp_hip_available(void);
 

@@ -273,6 +273,31 @@ int ref_bsr_get_matrix(void* h, int l, int which, dBSRmat* view)
 double* ref_bsr_get_diaginv(void* h, int l) { return ((AMG_data_bsr*)h)[l].diaginv.val; }
 void ref_bsr_free(void* h, AMG_param* param) { fasp_amg_data_bsr_free((AMG_data_bsr*)h, param); }
 int ref_sizeof_bsr(void) { return (int)sizeof(dBSRmat); }
+/* z = B r through the reference's fasp_precond_dbsr_amg (PreBSR.c:1149), its precond_data_bsr filled field by field as
+ * fasp_solver_dbsr_krylov_amg does (SolBSR.c:399-415; the fields that function leaves unset are zero here) */
+void ref_bsr_precond(void* h, AMG_param* amgparam, dBSRmat* A, double* r, double* z)
+{
+    AMG_data_bsr*    mgl = (AMG_data_bsr*)h;
+    precond_data_bsr precdata;
+    memset(&precdata, 0, sizeof(precdata));
+    precdata.print_level      = amgparam->print_level;
+    precdata.maxit            = amgparam->maxit;
+    precdata.tol              = amgparam->tol;
+    precdata.cycle_type       = amgparam->cycle_type;
+    precdata.smoother         = amgparam->smoother;
+    precdata.presmooth_iter   = amgparam->presmooth_iter;
+    precdata.postsmooth_iter  = amgparam->postsmooth_iter;
+    precdata.coarsening_type  = amgparam->coarsening_type;
+    precdata.relaxation       = amgparam->relaxation;
+    precdata.coarse_scaling   = amgparam->coarse_scaling;
+    precdata.amli_degree      = amgparam->amli_degree;
+    precdata.amli_coef        = amgparam->amli_coef;
+    precdata.tentative_smooth = amgparam->tentative_smooth;
+    precdata.max_levels       = mgl[0].num_levels;
+    precdata.mgl_data         = mgl;
+    precdata.A                = A;
+    fasp_precond_dbsr_amg(r, z, &precdata);
+}
 
 
 /* fasp_param_input + fasp_param_init on an ini file (AuxInput.c:86, AuxParam.c:34) */

@@ -63,3 +63,24 @@ def test_bench_scaling_command_at_the_metric_size_two_ranks():
     assert out["n_gpus"] == 2 and out["iterations"] == 14
     pr = out["parity_reference"]
     assert pr["ok"] and pr["iters_reference"] == 14, pr
+
+
+@pytest.mark.gpu
+def test_ranks_on_distinct_devices_over_rccl_when_several_gpus_are_visible():
+    """with >= 2 devices visible, `python bench.py --gpus 2` at the metric's size must (i) put every rank on its own
+    device (PCI bus ids in comm.devices all different), (ii) carry the halos and all-reduces over RCCL (comm.transport == "rccl",
+    comm.rccl_ranks == 2) and (iii) hold the two-rank pins of P7(256): 14 iterations, the reference's residual.  On a box with ONE visible
+    device -- every box this repository has run on so far -- it SKIPS, and the reason says that no run with ranks on different GPUs has
+    happened yet."""
+    import faspsolver_amd as fa
+    ndev = fa.lib().fasp_hip_device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} GPU visible: ranks on DISTINCT devices over RCCL need at least two -- this path has never run on this box "
+                    "(the shared-device validation runs are the tests above)")
+    p, lines = _run_bench(256, 2, "rccl", steps=2, warmup=1, timeout=1500)   # (BENCH_COMM=rccl: north_star's transport, no probing)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(lines[0])
+    c = out["comm"]
+    assert c["ranks_on_distinct_devices"] and len(set(c["devices"])) == 2, c["devices"]
+    assert c["transport"] == "rccl" and c["rccl_ranks"] == 2, c
+    assert out["iterations"] == 14 and out["parity_reference"]["ok"], out["parity_reference"]

@@ -11,7 +11,7 @@ import pytest
 import faspsolver_amd as fa
 from faspsolver_amd import _types as T
 
-from _libs import (DATA, OrcBSR, bsr_arrays, bsr_params, bsr_protos, have_ref, orc_bsr_solve,
+from _libs import (DATA, OrcBSR, bsr_arrays, bsr_params, bsr_protos, default_params, have_ref, orc_bsr_solve,
                    poisson7pt_bsr, read_bsr, read_vec, ref_bsr_solve)
 
 needs_ref = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
@@ -310,6 +310,87 @@ def test_gpu_bsr_spe01_one_level():
     print("SPE01 true relres oracle %.6e gpu %.6e" % (r1, r2))
     assert 0.5 * r1 <= r2 <= 2.0 * r1
     G.free()
+
+
+# ---- SPE01 pinned BEFORE the amplification: tests/golden/spe01_pin.npz, written by tools/gen_golden_spe01.py from the
+# compiled reference -- one application of the block preconditioner on rhs_SPE01 and the first restart cycle of its inner GMRES(25)
+def _spe01_pin():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spe01_pin.npz"))
+
+
+def test_oracle_spe01_preconditioner_application_equals_reference_fixture():
+    """z = B rhs_SPE01 through the oracle's one-level cycle (orc_mgcycle_bsr: the coarse GMRES(25), 200 steps) is BIT-IDENTICAL to the
+    reference's fasp_precond_dbsr_amg (PreBSR.c:1149): the oracle is pinned on the shipped matrix of config 3, not only on synthetic ones."""
+    from _libs import BsrLvl, bsr_protos
+    z = _spe01_pin()
+    ia, ja, val, nb, f = spe01()
+    o, _ = bsr_protos()
+    _, amgp = bsr_params()
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    buf = C.create_string_buffer(o.orc_sizeof_amg_bsr())
+    assert o.orc_amg_setup_ua_bsr(buf, C.byref(A), C.byref(amgp)) >= 0
+    assert C.cast(buf, T.c_int_p)[0] == 1
+    L0 = BsrLvl.from_address(C.addressof(buf) + 8)
+    n = len(f)
+    np.ctypeslib.as_array(L0.b.val, (n,))[:] = f
+    np.ctypeslib.as_array(L0.x.val, (n,))[:] = 0.0
+    _, p = default_params()   # fasp_precond_dbsr_amg (PreBSR.c:1149) starts from fasp_param_amg_init and copies these eight fields
+    for k in ("cycle_type", "smoother", "smooth_order", "presmooth_iter", "postsmooth_iter", "relaxation", "coarse_scaling", "tentative_smooth"):
+        setattr(p, k, getattr(amgp, k))
+    o.orc_mgcycle_bsr.argtypes = [C.c_void_p, C.POINTER(T.AMG_param)]
+    for _ in range(int(z["spe01_amg_maxit"])):
+        o.orc_mgcycle_bsr(buf, C.byref(p))
+    assert np.array_equal(np.ctypeslib.as_array(L0.x.val, (n,)), z["spe01_z"])
+
+
+@pytest.mark.gpu
+def test_gpu_bsr_spe01_pinned_before_the_amplification():
+    """Config 3's shipped matrix on the device against the REFERENCE's own numbers (fixture): (a) fasp_blas_dbsr_mxv and the inverse
+    diagonal blocks bit for bit (tests/golden/bsr.npz); (b) the first restart cycle of the inner GMRES(25) -- x_k of
+    fasp_solver_dbsr_pvgmres(A, f, 0, NULL, MaxIt = k, restart 25), k = 1 .. 25: true residuals ||f - A x_k|| / ||f|| to 1e-8 relative
+    (the residual falls from 1.0 to 0.41 in that cycle: nothing is amplified yet), iterates to 1e-9 of their maximum;
+    (c) ONE application of the block preconditioner, z = B f (200 such steps = eight restart cycles): to 1e-6 of its maximum --
+    eight restarts of an unpreconditioned GMRES on this matrix (condition ~1e9) already carry the reduction-order differences of the
+    Gram-Schmidt sums that far; the factor-two end-state check of test_gpu_bsr_spe01_one_level stays as it is."""
+    import os
+    zb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bsr.npz"))
+    pin = _spe01_pin()
+    ia, ja, val, nb, f = spe01()
+    L = fa.lib()
+    A, keep = T.as_bsr(ia, ja, val, nb)
+    n = len(f)
+    # (a)
+    x = zb["spe01_x"].copy(); y = np.zeros(n)
+    L.fasp_blas_dbsr_mxv.argtypes = [C.POINTER(T.dBSRmat), T.c_double_p, T.c_double_p]
+    L.fasp_blas_dbsr_mxv(C.byref(A), T.dp(x), T.dp(y))
+    assert np.array_equal(y, zb["spe01_mxv"])
+    _, amgp = bsr_params()
+    G = fa.BSRAMG(ia, ja, val, nb, amgp)
+    assert G.num_levels == 1
+    G.free()
+    # (b)
+    M = bsr_dense(ia, ja, val, nb)
+    nf = np.linalg.norm(f)
+    for k in range(1, 26):
+        st, xk = _bsr_plugin(L, 1, ia, ja, val, nb, f, None, tol=1e-30, maxit=k, restart=25)
+        rk = np.linalg.norm(f - M @ xk) / nf
+        assert abs(rk - pin["spe01_inner_res"][k - 1]) <= 1e-8 * pin["spe01_inner_res"][k - 1], (k, rk, pin["spe01_inner_res"][k - 1])
+        assert np.abs(xk - pin["spe01_inner_x"][k - 1]).max() <= 1e-9 * np.abs(pin["spe01_inner_x"][k - 1]).max(), k
+    # (c)
+    _, amgp = bsr_params()
+    L.fasp_hip_bsr_precond_setup.restype = C.c_void_p
+    L.fasp_hip_bsr_precond_setup.argtypes = [C.POINTER(T.dBSRmat), C.POINTER(T.AMG_param)]
+    pc = L.fasp_hip_bsr_precond_setup(C.byref(A), C.byref(amgp))
+    assert pc
+    pcs = C.cast(pc, C.POINTER(T.precond)).contents
+    z = np.zeros(n); r = f.copy()
+    pcs.fct(T.dp(r), T.dp(z), pcs.data)
+    L.fasp_hip_bsr_precond_free.argtypes = [C.c_void_p]
+    L.fasp_hip_bsr_precond_free(pc)
+    dev = np.abs(z - pin["spe01_z"]).max() / np.abs(pin["spe01_z"]).max()
+    print("SPE01: one preconditioner application, max deviation from the reference / max|z| = %.3e" % dev)
+    assert dev <= 1e-6
 
 
 # ---- plug-in level for block matrices (fasp_solver_dbsr_pcg / _pbcgs / _pgmres / _pvgmres / _pvfgmres) ----

@@ -317,12 +317,52 @@ def test_sequential_sweep_kernels_agree_bit_for_bit(gpu, smoother, order, w):
                 out.append(H.precond(out[-1]))
                 H.close()
     finally:
-        L.fasp_hip_tune(b"seq_flow", 1); L.fasp_hip_tune(b"seq_strip_kb", 512); L.fasp_hip_tune(b"seq_spine", 1)
+        L.fasp_hip_tune(b"seq_flow", 1); L.fasp_hip_tune(b"seq_strip_kb", 0); L.fasp_hip_tune(b"seq_spine", 1)
     assert np.all(np.isfinite(out[0]))
     for base in (0, 8):   # the four settings of one spine mode agree bit for bit
         for k in range(base + 2, base + 8, 2):
             assert np.array_equal(out[base], out[k]) and np.array_equal(out[base + 1], out[k + 1])
     assert np.allclose(out[0], out[8], rtol=1e-10, atol=1e-13 * np.abs(out[0]).max())   # the two modes: the same sweep, rounded differently
+
+
+@pytest.mark.gpu
+def test_renumbered_hierarchy_refuses_order_dependent_parameters(gpu):
+    """the brick numbering of the mid levels is decided once, at upload, from the parameters of the SETUP.  A later call that
+    brings an order-dependent smoother / a recursive cycle / coarse scaling (fasp_hip_amg_solve's per-call AMG_param) would apply sweep
+    schedules, C/F markers and polynomial diagonals built in natural order to brick-ordered vectors: it is refused with
+    ERROR_INPUT_PAR instead of answering wrongly; the same call on a hierarchy uploaded with renumber = 0 runs and agrees with a
+    hierarchy that was set up for that smoother."""
+    ia, ja, a, f = fa.poisson7pt_var(40)
+    L = fa.lib()
+    itp, amgp = _params()
+    gs = fa.param_amg_init(); gs.smoother = T.SMOOTHER_GS; gs.maxit = 30; gs.tol = 1e-8; gs.print_level = 0
+    jac = fa.param_amg_init(); jac.smoother = T.SMOOTHER_JACOBI; jac.relaxation = 0.6667; jac.maxit = 60; jac.tol = 1e-8; jac.print_level = 0
+    H = fa.AMG(ia, ja, a, amgp)
+    try:
+        assert H.num_levels >= 4
+        st, x, hist, stats = H.amg_solve(f, jac)          # the setup's own kind of smoother: fine
+        assert st > 0
+        for bad in ("smoother", "cycle", "scaling"):
+            q = fa.param_amg_init(); q.smoother = T.SMOOTHER_JACOBI; q.relaxation = 0.6667; q.maxit = 5; q.print_level = 0
+            if bad == "smoother": q.smoother = T.SMOOTHER_GS
+            if bad == "cycle": q.cycle_type = 3          # AMLI
+            if bad == "scaling": q.coarse_scaling = 1
+            st, x, hist, stats = H.amg_solve(f, q)
+            assert st == T.ERROR_INPUT_PAR, (bad, st)
+    finally:
+        H.close()
+    L.fasp_hip_tune(b"renumber", 0)
+    try:
+        H = fa.AMG(ia, ja, a, amgp)
+        st0, x0, hist0, stats0 = H.amg_solve(f, gs)
+        H.close()
+    finally:
+        L.fasp_hip_tune(b"renumber", 1)
+    Hg = fa.AMG(ia, ja, a, gs)
+    st1, x1, hist1, stats1 = Hg.amg_solve(f, gs)
+    Hg.close()
+    assert st0 == st1 and st0 > 0
+    assert np.abs(x0 - x1).max() <= 1e-12 * np.abs(x1).max()
 
 
 @pytest.mark.gpu

@@ -294,5 +294,5 @@ def test_standalone_sweeps_with_distant_couplings(gpu, which):
             L.fasp_smoother_dcsr_sor.restype = None
             L.fasp_smoother_dcsr_sor(C.byref(uv), i1, i2, s, C.byref(A), C.byref(bv), 2, w)
     finally:
-        L.fasp_hip_tune(b"seq_strip_kb", 512)
+        L.fasp_hip_tune(b"seq_strip_kb", 0)
     assert np.abs(u - ref).max() <= 1e-12 * np.abs(ref).max()

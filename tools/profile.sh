@@ -5,14 +5,14 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export OMP_NUM_THREADS=${OMP_NUM_THREADS:-32}
-TAG=${1:-r05}
+TAG=${1:-r06}
 WL=${2:-constant}
 if [ "$WL" = "variable" ]; then
   OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_var
   ARGS="bench.py --only-variable"
 else
   OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-  ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variable --no-extra"
+  ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variable --no-extra --no-plain --no-ceilings"
 fi
 rm -rf $OUT; mkdir -p $OUT
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1

@@ -57,9 +57,25 @@ for k, v in dur.items():
     kernels[k] = {"bytes_per_launch": (2.0 * sum(top) / len(top) + sum(topw) / len(topw)) * 1024.0,
                   "fetch_KB_raw": sum(top) / len(top), "write_KB": sum(topw) / len(topw),
                   "mean_us_largest_half": sum(topd) / len(topd), "launches": len(v)}
-json.dump({"command": "python3 " + command, "workload": workload, "n": N,
+# solve-wide: every kernel of the solves (setup / upload kernels, fills and copies of the runtime, and the ceiling kernels left out),
+# 2 x FETCH_SIZE + WRITE_SIZE summed, over the PCG iterations of the run (k_cg_update runs once per iteration)
+def solve_kernel(k):
+    return not ("rocclr" in k or "k_sort_rows" in k or "k_read16" in k or "k_copy16" in k or "k_triad16" in k or k.startswith("k_reorder") or k.startswith("k_permute"))
+iters = len(dur.get("k_cg_update", []))
+fsum = sum(sum(v) for k, v in fetch.items() if solve_kernel(k))
+wsum = sum(sum(v) for k, v in write.items() if solve_kernel(k))
+tsum = sum(sum(v) for k, v in dur.items() if solve_kernel(k))
+solve_wide = None
+if iters and fsum and wsum:
+    solve_wide = {"iterations": iters, "bytes_per_iteration": (2.0 * fsum + wsum) * 1024.0 / iters, "kernel_us_per_iteration": tsum / iters,
+                  "note": "sum over all solve kernels of 2 x FETCH_SIZE + WRITE_SIZE (separate passes) / PCG iterations (= k_cg_update launches)"}
+json.dump({"command": "python3 " + command, "workload": workload, "n": N, "solve_wide": solve_wide,
            "note": "HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes); level-0 launches",
            "kernels": kernels}, open(os.path.join(root, "traffic.json"), "w"), indent=1)
+if solve_wide:
+    print(f"\n## solve-wide\n\n- {solve_wide['iterations']} PCG iterations, {solve_wide['bytes_per_iteration']/1e9:.2f} GB of HBM-side traffic and "
+          f"{solve_wide['kernel_us_per_iteration']:.0f} us of kernel time per iteration -> {solve_wide['bytes_per_iteration']/solve_wide['kernel_us_per_iteration']/1e3:.0f} GB/s "
+          f"= {solve_wide['bytes_per_iteration']/solve_wide['kernel_us_per_iteration']/1e3/8000:.2f} of 8 TB/s (profiled clocks)")
 print("\n## traffic per launch (level-0 launches)\n")
 for k, r in kernels.items():
     print(f"- {k}: {r['bytes_per_launch']/1e9:.3f} GB ({r['fetch_KB_raw']:.0f} KB FETCH_SIZE raw x 2 + {r['write_KB']:.0f} KB WRITE_SIZE), "
