@@ -47,8 +47,15 @@ struct DevCSR {
     const int* bridge = nullptr;
     double*    bscratch = nullptr;
     int        bridge_dir = 0;
+    // k_csr_estream (kernels3.hip.h): the entry-parallel decomposition of a long-row operator with 16-bit columns (build_estream)
+    int*       es_tab = nullptr;    // one allocation: wc[W + 1], centry[nc + 1], crow[nc + 1], hw0[W], np[W]
+    double*    es_part = nullptr;   // 2 W doubles + W counters behind them
+    int        es_W = 0, es_nc = 0;
     void    release()
     {
+        if (es_tab) (void)hipFree(es_tab);
+        if (es_part) (void)hipFree(es_part);
+        es_tab = nullptr; es_part = nullptr; es_W = es_nc = 0;
         if (bscratch) (void)hipFree(bscratch);
         bscratch = nullptr; bridge = nullptr; bridge_dir = 0;
         if (lja16) (void)hipFree(lja16);
@@ -404,7 +411,7 @@ static int upload_ja16(DevCSR& D, const int* ia_host, const int* ja_dev_order)
         }
         for (int k = ia_host[i]; k < ia_host[i + 1]; ++k) j16[k] = (unsigned short)(ja_dev_order[k] - lo);
     }
-    HIPCK(hipMalloc(&D.ja16, sizeof(unsigned short) * (size_t)D.nnz));
+    HIPCK(hipMalloc(&D.ja16, sizeof(unsigned short) * ((size_t)D.nnz + 8)));
     HIPCK(hipMemcpy(D.ja16, j16.data(), sizeof(unsigned short) * (size_t)D.nnz, hipMemcpyHostToDevice));
     if (relative) {
         HIPCK(hipMalloc(&D.jbase, sizeof(int) * (size_t)D.row));
@@ -465,7 +472,7 @@ static int upload_sorted_on_device(const HostCSR& H, DevCSR& D, int maxlen)
         hipMemcpyAsync(tv, H.val.data(), sizeof(double) * (size_t)H.nnz, hipMemcpyHostToDevice, g_ctx.stream) != hipSuccess) st = ERROR_ALLOC_MEM;
     const bool relative = D.col > 65536;
     const bool want16 = ja16_on && D.kind == 0 && D.nnz >= 4096 && (!relative || rows_span_16bit(H.ia.data(), H.ja.data(), H.row));   // as upload_ja16
-    if (st >= 0 && want16 && hipMalloc(&D.ja16, sizeof(unsigned short) * (size_t)D.nnz) != hipSuccess) st = ERROR_ALLOC_MEM;
+    if (st >= 0 && want16 && hipMalloc(&D.ja16, sizeof(unsigned short) * ((size_t)D.nnz + 8)) != hipSuccess) st = ERROR_ALLOC_MEM;
     if (st >= 0 && want16 && relative && hipMalloc(&D.jbase, sizeof(int) * (size_t)std::max(D.row, 1)) != hipSuccess) st = ERROR_ALLOC_MEM;
     if (st >= 0) {
         int P = 64;
@@ -565,12 +572,136 @@ static int build_xtile(const HostCSR& H, DevCSR& D)
     return FASP_SUCCESS;
 }
 
+// k_csr_estream's tables (kernels3.hip.h): the entries of a long-row operator cut into W equal wave ranges and those into chunks of at
+// most ES_CAP entries, with the row every chunk starts in, and for the rows that a wave boundary cuts who counts their parts.  Built
+// from the row pointers alone (the device copy's rows are sorted, its pointers are the host's).  W depends on the operator only --
+// not on the device -- so the association of every row sum is a property of the matrix.
+struct EsTables { int W = 0, nc = 0; std::vector<int> wc, centry, crow, hw0, np; };
+static void build_estream_host(const int* ia, int nrow, int nnz, int per_wave, int wmax, EsTables& T)
+{
+    int W = (int)std::min<long long>(wmax, ((long long)nnz + per_wave - 1) / per_wave);
+    W = std::max(32, (W + 31) / 32 * 32);   // 8 XCDs x 4 waves per workgroup
+    std::vector<int> ebeg((size_t)W + 1);
+    for (int w = 0; w <= W; ++w) ebeg[(size_t)w] = (int)(((long long)nnz * w / W) & ~7ll);
+    ebeg[(size_t)W] = nnz;
+    T.W = W;
+    T.wc.assign((size_t)W + 1, 0); T.hw0.assign((size_t)W, 0); T.np.assign((size_t)W, 0);
+    T.centry.clear();
+    T.centry.reserve((size_t)nnz / ES_CAP + (size_t)W + 2);
+    for (int w = 0; w < W; ++w) {
+        T.wc[(size_t)w] = (int)T.centry.size();
+        const int len = ebeg[(size_t)w + 1] - ebeg[(size_t)w];
+        if (len <= 0) continue;
+        const int nch = (len + ES_CAP - 1) / ES_CAP;
+        const int size = ((len + nch - 1) / nch + 7) & ~7;
+        for (int j = 0; j < nch && ebeg[(size_t)w] + j * size < ebeg[(size_t)w + 1]; ++j) T.centry.push_back(ebeg[(size_t)w] + j * size);
+    }
+    T.wc[(size_t)W] = (int)T.centry.size();
+    T.centry.push_back(nnz);
+    const int nc = T.nc = (int)T.centry.size() - 1;
+    T.crow.resize((size_t)nc + 1);
+    auto row_of = [&](int e) {   // the row entry e lies in (e < nnz): the last r with ia[r] <= e
+        return (int)(std::upper_bound(ia, ia + nrow + 1, e) - ia) - 1;
+    };
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c <= nc; ++c) T.crow[(size_t)c] = c == 0 ? 0 : c == nc ? nrow - 1 : std::min(nrow - 1, row_of(T.centry[(size_t)c]));
+    auto wave_of = [&](int e) { return (int)(std::upper_bound(ebeg.begin(), ebeg.end(), e) - ebeg.begin()) - 1; };
+    for (int w = 0; w < W; ++w) {
+        const int e0 = ebeg[(size_t)w], e1 = ebeg[(size_t)w + 1];
+        if (e1 <= e0) continue;
+        const int rh = e0 == 0 ? 0 : row_of(e0);
+        if (ia[rh] < e0) T.hw0[(size_t)w] = wave_of(ia[rh]);
+        if (e1 < nnz) {
+            const int rt = row_of(e1);
+            if (ia[rt] < e1 && ia[rt] >= e0) T.np[(size_t)w] = wave_of(ia[rt + 1] - 1) - w + 1;
+        }
+    }
+}
+
+static int build_estream(const int* ia, int nrow, int nnz, DevCSR& D)
+{
+    static const bool on = !(std::getenv("FASP_HIP_ESTREAM") && std::atoi(std::getenv("FASP_HIP_ESTREAM")) == 0);
+    if (!on || !D.ja16 || D.kind != 0 || nnz < 65536 || nrow < 1) return FASP_SUCCESS;
+    static const int per_wave = std::getenv("FASP_HIP_ESTREAM_PER_WAVE") ? std::atoi(std::getenv("FASP_HIP_ESTREAM_PER_WAVE")) : 3072;
+    static const int wmax = std::getenv("FASP_HIP_ESTREAM_WMAX") ? std::atoi(std::getenv("FASP_HIP_ESTREAM_WMAX")) : 6144;
+    EsTables T;
+    build_estream_host(ia, nrow, nnz, per_wave, wmax, T);
+    const int W = T.W, nc = T.nc;
+    const size_t nt = (size_t)W + 1 + 2 * ((size_t)nc + 1) + 2 * (size_t)W;
+    std::vector<int> tab(nt);
+    size_t o = 0;
+    std::copy(T.wc.begin(), T.wc.end(), tab.begin() + o); o += T.wc.size();
+    std::copy(T.centry.begin(), T.centry.end(), tab.begin() + o); o += T.centry.size();
+    std::copy(T.crow.begin(), T.crow.end(), tab.begin() + o); o += T.crow.size();
+    std::copy(T.hw0.begin(), T.hw0.end(), tab.begin() + o); o += T.hw0.size();
+    std::copy(T.np.begin(), T.np.end(), tab.begin() + o);
+    HIPCK(hipMalloc(&D.es_tab, sizeof(int) * nt));
+    HIPCK(hipMemcpy(D.es_tab, tab.data(), sizeof(int) * nt, hipMemcpyHostToDevice));
+    HIPCK(hipMalloc(&D.es_part, sizeof(double) * 2 * (size_t)W + sizeof(unsigned) * (size_t)W));
+    HIPCK(hipMemset(D.es_part, 0, sizeof(double) * 2 * (size_t)W + sizeof(unsigned) * (size_t)W));
+    D.es_W = W; D.es_nc = nc;
+    return FASP_SUCCESS;
+}
+
+// Host walk of k_csr_estream's control flow over the tables (CPU tests; no device): every entry is covered by exactly one chunk, every
+// row is finished exactly once -- inside one wave, or by parts whose count is what its first wave's table says -- and the sum of the
+// parts in wave order is the row's sum.  Returns 0, or the negative number of the first check that failed.
+static int estream_selftest_host(const int* ia, int nrow, int nnz, int per_wave, int wmax, int* info)
+{
+    EsTables T;
+    build_estream_host(ia, nrow, nnz, per_wave, wmax, T);
+    if (info) { info[0] = T.W; info[1] = T.nc; }
+    std::vector<int> done((size_t)nrow, 0), parts((size_t)T.W, 0);
+    std::vector<long long> covered((size_t)nrow, 0);   // entries of the row seen by chunks
+    long long cut_rows = 0;
+    for (int c = 0; c < T.nc; ++c) {
+        if (T.centry[(size_t)c + 1] <= T.centry[(size_t)c] || T.centry[(size_t)c + 1] - T.centry[(size_t)c] > ES_CAP) return -1;
+        if ((T.centry[(size_t)c] & 7) != 0) return -2;
+        if (T.crow[(size_t)c] > T.crow[(size_t)c + 1]) return -3;
+    }
+    if (T.centry[0] != 0 || T.centry[(size_t)T.nc] != nnz) return -4;
+    for (int w = 0; w < T.W; ++w) {
+        const int c0 = T.wc[(size_t)w], cend = T.wc[(size_t)w + 1];
+        if (c0 >= cend) continue;
+        const int e0w = T.centry[(size_t)c0], e1w = T.centry[(size_t)cend];
+        int pend_r = -1, pend_kb = 0;
+        for (int c = c0; c < cend; ++c) {
+            const int lo = T.centry[(size_t)c], hi = T.centry[(size_t)c + 1], rf = T.crow[(size_t)c], rl = T.crow[(size_t)c + 1];
+            for (int r = rf; r <= rl; ++r) {
+                const int kb = ia[r], ke = ia[r + 1];
+                covered[(size_t)r] += std::max(0, std::min(ke, hi) - std::max(kb, lo));
+                if (ke <= hi) {
+                    if (kb >= e0w) { if (done[(size_t)r]++) return -5; }
+                    else {
+                        const int w0 = T.hw0[(size_t)w];
+                        if (w0 < 0 || w0 >= w || T.np[(size_t)w0] < 2 || w0 + T.np[(size_t)w0] - 1 != w) return -6;   // this is the row's LAST part
+                        if (++parts[(size_t)w0] == T.np[(size_t)w0]) { if (done[(size_t)r]++) return -7; ++cut_rows; }
+                    }
+                } else if (c + 1 == cend) { pend_r = r; pend_kb = kb; }
+            }
+        }
+        if (pend_r >= 0 && pend_kb < e1w) {
+            const int w0 = pend_kb >= e0w ? w : T.hw0[(size_t)w];
+            if (w0 < 0 || w0 > w || T.np[(size_t)w0] < 2 || w0 + T.np[(size_t)w0] - 1 <= w) return -8;   // a first or a middle part: the last one comes later
+            if (++parts[(size_t)w0] == T.np[(size_t)w0]) return -9;   // (walking the waves in order, the last part is a finished row above)
+        }
+    }
+    for (int r = 0; r < nrow; ++r) {
+        if (done[(size_t)r] != 1) return -10;
+        if (covered[(size_t)r] != (long long)ia[r + 1] - ia[r]) return -11;
+    }
+    for (int w = 0; w < T.W; ++w)
+        if (parts[(size_t)w] != T.np[(size_t)w]) return -12;
+    if (info) info[2] = (int)cut_rows;
+    return 0;
+}
+
 static int upload_csr(const HostCSR& H, DevCSR& D)
 {
     D.row = H.row; D.col = H.col; D.nnz = H.nnz;
     HIPCK(hipMalloc(&D.ia, sizeof(int) * ((size_t)H.row + 1)));
     HIPCK(hipMalloc(&D.ja, sizeof(int) * std::max<size_t>(H.nnz, 1)));
-    HIPCK(hipMalloc(&D.val, sizeof(double) * std::max<size_t>(H.nnz, 1)));
+    HIPCK(hipMalloc(&D.val, sizeof(double) * (std::max<size_t>(H.nnz, 1) + 2)));   // (+ 16 bytes: k_csr_estream's last 16-byte piece)
     HIPCK(hipMemcpyAsync(D.ia, H.ia.data(), sizeof(int) * ((size_t)H.row + 1), hipMemcpyHostToDevice, g_ctx.stream));
     pick_kernel(D);
     auto upload_plain = [&]() -> int {
@@ -670,7 +801,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
         if (g_device_sort && maxlen <= SORT_MAXLEN) {
             const int st = upload_sorted_on_device(H, D, maxlen);
             lap("device sort");
-            return st;
+            return st < 0 ? st : build_estream(H.ia.data(), H.row, H.nnz, D);
         }
     }
     if (do_sort) {
@@ -708,15 +839,17 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
             HIPCK(hipMemcpy(D.dpos, dp.data(), sizeof(int) * (size_t)H.row, hipMemcpyHostToDevice));
         }
         D.sorted = true;
-        return upload_ja16(D, H.ia.data(), sj.data());
+        if (upload_ja16(D, H.ia.data(), sj.data()) < 0) return ERROR_ALLOC_MEM;
+        return build_estream(H.ia.data(), H.row, H.nnz, D);
     }
     if (upload_plain() < 0) return ERROR_ALLOC_MEM;
     if (D.kind == 2 && !g_oneshot_upload && build_xtile(H, D) < 0) return ERROR_ALLOC_MEM;
-    return upload_ja16(D, H.ia.data(), H.ja.data());
+    if (upload_ja16(D, H.ia.data(), H.ja.data()) < 0) return ERROR_ALLOC_MEM;
+    return build_estream(H.ia.data(), H.row, H.nnz, D);
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 0, seq_jobs = 1, seq_spine = 1, seq_grid = 0, seq_chain = 1, seq_chain_n1 = 0, seq_chain_grid = 0, seq_chain_ref = 0, seq_test_hang = 0, seq_rest_lanes = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 2, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1, renumber = 1, renumber_chunk = 262144, pcg_dev_beta = 1, spcg_spec = 1, ev_every = 4, pcg_fold = 1, seq_chain_touch = 8, seq_chain_touch_t1 = 1, seq_zero_skip = 1; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 0, seq_jobs = 1, seq_spine = 1, seq_grid = 0, seq_chain = 1, seq_chain_n1 = 0, seq_chain_grid = 0, seq_chain_ref = 0, seq_test_hang = 0, seq_rest_lanes = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 2, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1, renumber = 1, renumber_chunk = 262144, pcg_dev_beta = 1, spcg_spec = 1, ev_every = 4, pcg_fold = 1, seq_chain_touch = 8, seq_chain_touch_t1 = 1, seq_zero_skip = 1, estream = 1, es_nt = 0, es_bpc = 6; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -937,6 +1070,19 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         if (M.wrows == 64) return launch_persistent(k_csr_wstream<OP, 64, 1024>, a.ntiles, a);
         if (M.wrows == 32 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 32, 512>, a.ntiles, a);
         return launch_persistent(k_csr_wstream<OP, 32, 1024>, a.ntiles, a);
+    }
+    // long rows with 16-bit columns, whole-operator launches: the entry-parallel stream (kernels3.hip.h).  Not for the fused dot
+    // products (whichever wave completes a cut row would own its term of the sum) and not for row windows (they keep the row kernel).
+    if (M.es_tab && g_tune.estream && a.ja16 && win.hi < 0 && g_tune.split_rows <= 0 && OP != OP_MXV_DOT && !(OP == OP_JACOBI && a.partials)) {
+        const int W = M.es_W, nc = M.es_nc;
+        a.es_wc = M.es_tab; a.es_centry = a.es_wc + W + 1; a.es_crow = a.es_centry + nc + 1; a.es_hw0 = a.es_crow + nc + 1; a.es_np = a.es_hw0 + W;
+        a.es_part = M.es_part; a.es_cnt = reinterpret_cast<unsigned*>(M.es_part + 2 * (size_t)W);
+        const int lanes = M.lanes >= 64 ? 64 : M.lanes >= 32 ? 32 : 16;
+#define ES_LAUNCH(LL, NT) hipLaunchKernelGGL((k_csr_estream<LL, OP, NT>), dim3(W / 4), dim3(BLOCK), 0, g_ctx.stream, a)
+        if (g_tune.es_nt) { if (lanes == 64) ES_LAUNCH(64, 1); else if (lanes == 32) ES_LAUNCH(32, 1); else ES_LAUNCH(16, 1); }
+        else { if (lanes == 64) ES_LAUNCH(64, 0); else if (lanes == 32) ES_LAUNCH(32, 0); else ES_LAUNCH(16, 0); }
+#undef ES_LAUNCH
+        return W / 4;
     }
     switch (M.lanes) {
         case 2:  return launch_persistent(k_csr_rows<2, OP>, a.ntiles, a);

@@ -87,6 +87,14 @@ struct CsrArgs {
     const unsigned short* lja16;
     const int*    tptr;
     const int*    tcols;
+    // k_csr_estream (kernels3.hip.h): tables of the entry-parallel decomposition, built at upload (device_csr.hip.h, build_estream)
+    const int*    es_wc;      // first chunk of every wave range (W + 1)
+    const int*    es_centry;  // first entry of every chunk (chunks + 1; multiples of 8 but the last)
+    const int*    es_crow;    // the row that entry lies in (chunks + 1)
+    const int*    es_hw0;     // per wave: the wave in which the row its range begins inside of starts
+    const int*    es_np;      // per wave: parts of the row its range ends inside of, when that row starts in this wave (else 0)
+    double*       es_part;    // 2 per wave: head part, tail part
+    unsigned*     es_cnt;     // per wave: parts arrived (zero between launches)
 };
 
 __device__ __forceinline__ void zx_store(const CsrArgs& a, int r, double s)

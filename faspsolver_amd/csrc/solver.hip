@@ -41,6 +41,7 @@
 #include "fasp_internal.h"
 #include "kernels.hip.h"
 #include "kernels2.hip.h"
+#include "kernels3.hip.h"
 #include "small_solvers.hip.h"
 #include "seq_split.hip.h"
 #include "seq_chain.hip.h"
@@ -2197,6 +2198,8 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "renumber")) g_tune.renumber = value;             // brick renumbering of the uncoded mid levels at upload (order-independent smoothers only; hierarchy.hip.h): 1 on (default), 2 also levels behind a coded one (whose transfer operators keep their coding and take a numbering bridge), 0 off; read when a hierarchy is uploaded
     else if (!std::strcmp(key, "renumber_chunk")) g_tune.renumber_chunk = value; // rows per chunk inside which the balls grow (reorder.cpp)
     else if (!std::strcmp(key, "time_cold")) g_time_cold = value;
+    else if (!std::strcmp(key, "estream")) g_tune.estream = value;   // long-row operators: the entry-parallel stream kernel (1, default) or the row kernel (0); read at launch
+    else if (!std::strcmp(key, "es_nt")) g_tune.es_nt = value;       // ... its matrix stream with non-temporal loads
     else if (!std::strcmp(key, "pcg_dev_beta")) g_tune.pcg_dev_beta = value;   // top-level PCG: (z, r), beta and alpha stay on the device, one host wait per iteration (1, default) or two (0)
     else if (!std::strcmp(key, "seq_chain_touch")) g_tune.seq_chain_touch = value;   // chain form: blocks by which a workgroup of its own on the chain's XCD touches the band planes ahead (8; 0: the importer wave does, four ahead)
     else if (!std::strcmp(key, "seq_chain_touch_t1")) g_tune.seq_chain_touch_t1 = value;   // ... and tier 1's entries of those blocks (1, default)
@@ -2212,6 +2215,13 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "wcap")) g_tune.wcap = value;
     else return ERROR_INPUT_PAR;
     return FASP_SUCCESS;
+}
+
+// CPU test entry: the tables of k_csr_estream for a matrix with these row pointers, walked on the host (device_csr.hip.h)
+int fasp_hip_estream_selftest(const int* ia, int nrow, int nnz, int per_wave, int wmax, int* info)
+{
+    if (!ia || nrow < 1 || nnz < 1 || per_wave < 8 || wmax < 32) return ERROR_INPUT_PAR;
+    return estream_selftest_host(ia, nrow, nnz, per_wave, wmax, info);
 }
 
 // Measured device ceilings beside the roofline: a 16-byte-per-lane read, copy and triad over buffers of

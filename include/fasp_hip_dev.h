@@ -90,6 +90,10 @@ int fasp_hip_dist_plan(fasp_hip_amg* h, int rank, int nranks, int min_rows);
 int fasp_hip_dist_level_info(const fasp_hip_amg* h, int level, int* info);
 int fasp_hip_dist_get_matrix(const fasp_hip_amg* h, int level, int which, dCSRmat* view);
 int fasp_hip_dist_get_list(const fasp_hip_amg* h, int level, int which, ivector* view);
+/* k_csr_estream's decomposition tables (csrc/kernels3.hip.h) for a matrix with these row pointers, built and walked on the HOST the way the
+ * kernel walks them: 0 when every entry is covered once and every row is finished exactly once, else the negative number of the check
+ * that failed.  info (may be NULL) = {wave ranges, chunks, rows cut by a wave boundary}.  No GPU needed. */
+int  fasp_hip_estream_selftest(const int* ia, int nrow, int nnz, int per_wave, int wmax, int* info);
 /* one-rank exercise of every RCCL call the transport makes (0 = all results correct) */
 int  fasp_hip_comm_selftest(void);
 

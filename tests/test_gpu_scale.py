@@ -192,7 +192,10 @@ def test_row_window_launches_are_bit_identical(gpu, var, smoother):
     halo is in flight, then the two boundary windows (hierarchy.hip.h, dist_launch).  fasp_hip_tune("split_rows", k)
     issues every operator of a single-GPU hierarchy that way: each row is computed exactly as in the single launch, so
     one V-cycle agrees bit for bit (coded kernels, their exception lists, the plain stream kernels, the sub-wavefront
-    kernel), and a PCG solve -- whose fused (t, p) partials are now cut differently -- agrees to rounding."""
+    kernel), and a PCG solve -- whose fused (t, p) partials are now cut differently -- agrees to rounding.
+    (Round 6: whole-operator launches of the long-row levels go through the entry-parallel stream, k_csr_estream, whose row sums
+    associate differently from the row kernel's that the windows keep: the bit-for-bit statement is about windows of ONE kernel, so the
+    stream is switched off here; stream against row kernel, 1e-13: tests/test_gpu_estream.py and the last lines of this test.)"""
     n = 96
     if var:
         ia, ja, a, f = fa.poisson7pt_var(n)
@@ -204,14 +207,17 @@ def test_row_window_launches_are_bit_identical(gpu, var, smoother):
     L = fa.lib()
     r = np.random.default_rng(7).standard_normal(len(f))
     try:
+        with_stream = H.precond(r)
+        L.fasp_hip_tune(b"estream", 0)
         base = H.precond(r)
+        assert np.abs(with_stream - base).max() <= 1e-13 * np.abs(base).max()
         st0, x0, h0, s0 = H.solve(f, itp)
         for k in (1024, 5000, 300000):
             L.fasp_hip_tune(b"split_rows", k)
             assert np.array_equal(H.precond(r), base), k
         st1, x1, h1, s1 = H.solve(f, itp)
     finally:
-        L.fasp_hip_tune(b"split_rows", 0)
+        L.fasp_hip_tune(b"split_rows", 0); L.fasp_hip_tune(b"estream", 1)
     assert st1 == st0 and abs(s1.relres - s0.relres) <= 1e-6 * s0.relres   # (rounding of the re-cut dot partials, carried through the iteration)
     assert np.abs(x1 - x0).max() <= 1e-10 * np.abs(x0).max()
     H.close()
