@@ -48,14 +48,16 @@ struct DevCSR {
     double*    bscratch = nullptr;
     int        bridge_dir = 0;
     // k_csr_estream (kernels3.hip.h): the entry-parallel decomposition of a long-row operator with 16-bit columns (build_estream)
-    int*       es_tab = nullptr;    // one allocation: wc[W + 1], centry[nc + 1], crow[nc + 1], hw0[W], np[W]
+    int*       es_tab = nullptr;    // one allocation: wc[W + 1], centry[nc + 1], crow[nc + 1], hw0[W], np[W], cbase[nc] (relative columns only)
+    unsigned short* es_ja16 = nullptr;   // 16-bit columns relative to the chunk's smallest column (operators with > 65536 columns)
     double*    es_part = nullptr;   // 2 W doubles + W counters behind them
     int        es_W = 0, es_nc = 0;
     void    release()
     {
         if (es_tab) (void)hipFree(es_tab);
         if (es_part) (void)hipFree(es_part);
-        es_tab = nullptr; es_part = nullptr; es_W = es_nc = 0;
+        if (es_ja16) (void)hipFree(es_ja16);
+        es_tab = nullptr; es_part = nullptr; es_ja16 = nullptr; es_W = es_nc = 0;
         if (bscratch) (void)hipFree(bscratch);
         bscratch = nullptr; bridge = nullptr; bridge_dir = 0;
         if (lja16) (void)hipFree(lja16);
@@ -623,11 +625,12 @@ static int build_estream(const int* ia, int nrow, int nnz, DevCSR& D)
     static const bool on = !(std::getenv("FASP_HIP_ESTREAM") && std::atoi(std::getenv("FASP_HIP_ESTREAM")) == 0);
     if (!on || !D.ja16 || D.kind != 0 || nnz < 65536 || nrow < 1) return FASP_SUCCESS;
     static const int per_wave = std::getenv("FASP_HIP_ESTREAM_PER_WAVE") ? std::atoi(std::getenv("FASP_HIP_ESTREAM_PER_WAVE")) : 3072;
-    static const int wmax = std::getenv("FASP_HIP_ESTREAM_WMAX") ? std::atoi(std::getenv("FASP_HIP_ESTREAM_WMAX")) : 6144;
+    static const int wmax = std::getenv("FASP_HIP_ESTREAM_WMAX") ? std::atoi(std::getenv("FASP_HIP_ESTREAM_WMAX")) : 5120;   // (five workgroups of four waves per CU: what every instantiation keeps resident at once)
     EsTables T;
     build_estream_host(ia, nrow, nnz, per_wave, wmax, T);
     const int W = T.W, nc = T.nc;
-    const size_t nt = (size_t)W + 1 + 2 * ((size_t)nc + 1) + 2 * (size_t)W;
+    const bool relative = D.jbase != nullptr;
+    const size_t nt = (size_t)W + 1 + 2 * ((size_t)nc + 1) + 2 * (size_t)W + (relative ? (size_t)nc + 1 : 0);
     std::vector<int> tab(nt);
     size_t o = 0;
     std::copy(T.wc.begin(), T.wc.end(), tab.begin() + o); o += T.wc.size();
@@ -640,6 +643,28 @@ static int build_estream(const int* ia, int nrow, int nnz, DevCSR& D)
     HIPCK(hipMalloc(&D.es_part, sizeof(double) * 2 * (size_t)W + sizeof(unsigned) * (size_t)W));
     HIPCK(hipMemset(D.es_part, 0, sizeof(double) * 2 * (size_t)W + sizeof(unsigned) * (size_t)W));
     D.es_W = W; D.es_nc = nc;
+    if (relative) {
+        // more than 65536 columns: the row-relative 16-bit columns of the row kernel need every entry's ROW; the stream works on chunks,
+        // so it gets columns relative to the smallest column of the CHUNK (built on the device from the sorted 32-bit copy) -- when
+        // every chunk spans less than 65536 columns; otherwise the operator keeps the row kernel
+        int* cbase = D.es_tab + (size_t)W + 1 + 2 * ((size_t)nc + 1) + 2 * (size_t)W;
+        int* flag = cbase + nc;
+        const int* centry = D.es_tab + (size_t)W + 1;
+        HIPCK(hipMemsetAsync(flag, 0, sizeof(int), g_ctx.stream));
+        const int grid = std::max(1, std::min(MAXGRID, (nc + 3) / 4));
+        hipLaunchKernelGGL(k_es_chunk_base, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, nc, centry, (const int*)D.ja, cbase, flag);
+        int hflag = 0;
+        HIPCK(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
+        HIPCK(hipStreamSynchronize(g_ctx.stream));
+        if (hflag) {   // a chunk too wide for 16 bits
+            (void)hipFree(D.es_tab); (void)hipFree(D.es_part);
+            D.es_tab = nullptr; D.es_part = nullptr; D.es_W = D.es_nc = 0;
+            return FASP_SUCCESS;
+        }
+        HIPCK(hipMalloc(&D.es_ja16, sizeof(unsigned short) * ((size_t)nnz + 8)));
+        hipLaunchKernelGGL(k_es_chunk_cols, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, nc, centry, (const int*)D.ja, (const int*)cbase, D.es_ja16);
+        HIPCK(hipStreamSynchronize(g_ctx.stream));
+    }
     return FASP_SUCCESS;
 }
 
@@ -849,7 +874,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 0, seq_jobs = 1, seq_spine = 1, seq_grid = 0, seq_chain = 1, seq_chain_n1 = 0, seq_chain_grid = 0, seq_chain_ref = 0, seq_test_hang = 0, seq_rest_lanes = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 2, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1, renumber = 1, renumber_chunk = 262144, pcg_dev_beta = 1, spcg_spec = 1, ev_every = 4, pcg_fold = 1, seq_chain_touch = 8, seq_chain_touch_t1 = 1, seq_zero_skip = 1, estream = 1, es_nt = 0, es_bpc = 6; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 0, seq_jobs = 1, seq_spine = 1, seq_grid = 0, seq_chain = 1, seq_chain_n1 = 0, seq_chain_grid = 0, seq_chain_ref = 0, seq_test_hang = 0, seq_rest_lanes = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 2, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1, renumber = 1, renumber_chunk = 262144, pcg_dev_beta = 1, spcg_spec = 1, ev_every = 4, pcg_fold = 1, seq_chain_touch = 8, seq_chain_touch_t1 = 1, seq_zero_skip = 1, estream = 1, es_dbg = 0; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -1073,14 +1098,32 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
     }
     // long rows with 16-bit columns, whole-operator launches: the entry-parallel stream (kernels3.hip.h).  Not for the fused dot
     // products (whichever wave completes a cut row would own its term of the sum) and not for row windows (they keep the row kernel).
-    if (M.es_tab && g_tune.estream && a.ja16 && win.hi < 0 && g_tune.split_rows <= 0 && OP != OP_MXV_DOT && !(OP == OP_JACOBI && a.partials)) {
+    if (M.es_tab && g_tune.estream && a.ja16 && win.hi < 0 && g_tune.split_rows <= 0 && OP != OP_MXV_DOT && !(OP == OP_JACOBI && (a.partials || M.dup_diag))) {
         const int W = M.es_W, nc = M.es_nc;
         a.es_wc = M.es_tab; a.es_centry = a.es_wc + W + 1; a.es_crow = a.es_centry + nc + 1; a.es_hw0 = a.es_crow + nc + 1; a.es_np = a.es_hw0 + W;
         a.es_part = M.es_part; a.es_cnt = reinterpret_cast<unsigned*>(M.es_part + 2 * (size_t)W);
-        const int lanes = M.lanes >= 64 ? 64 : M.lanes >= 32 ? 32 : 16;
-#define ES_LAUNCH(LL, NT) hipLaunchKernelGGL((k_csr_estream<LL, OP, NT>), dim3(W / 4), dim3(BLOCK), 0, g_ctx.stream, a)
-        if (g_tune.es_nt) { if (lanes == 64) ES_LAUNCH(64, 1); else if (lanes == 32) ES_LAUNCH(32, 1); else ES_LAUNCH(16, 1); }
-        else { if (lanes == 64) ES_LAUNCH(64, 0); else if (lanes == 32) ES_LAUNCH(32, 0); else ES_LAUNCH(16, 0); }
+        a.es_cbase = M.es_ja16 ? a.es_np + W : nullptr; a.es_ja16 = M.es_ja16;
+        // lanes per row: so that the rows a 512-entry chunk touches normally fit one pass of 64 / L rows (kernels3.hip.h)
+        const double avg = M.row > 0 ? (double)M.nnz / M.row : 1.0;
+        const int lanes = avg >= 512.0 ? 32 : avg >= 256.0 ? 16 : avg >= 128.0 ? 8 : 4;
+        static bool attr_set = false;
+#define ES_ATTR(LL) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_estream<LL, OP>), hipFuncAttributeMaxDynamicSharedMemorySize, ES_LDS_BYTES)
+        if (!attr_set) { ES_ATTR(32); ES_ATTR(16); ES_ATTR(8); ES_ATTR(4); attr_set = true; }
+#undef ES_ATTR
+#define ES_LAUNCH(LL) hipLaunchKernelGGL((k_csr_estream<LL, OP>), dim3(W / 4), dim3(BLOCK), ES_LDS_BYTES, g_ctx.stream, a)
+#ifdef FASP_LAB_DEBUG
+        if (OP == OP_MXV && g_tune.es_dbg) {   // (tools/lab: which part of the kernel costs what)
+#define ES_DBG(LL, DD) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_estream<LL, OP_MXV, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, ES_LDS_BYTES); hipLaunchKernelGGL((k_csr_estream<LL, OP_MXV, DD>), dim3(W / 4), dim3(BLOCK), ES_LDS_BYTES, g_ctx.stream, a); } while (0)
+            const int dd = g_tune.es_dbg;
+            if (lanes == 32) { if (dd == 1) ES_DBG(32, 1); else if (dd == 2) ES_DBG(32, 2); else if (dd == 3) ES_DBG(32, 3); else if (dd == 4) ES_DBG(32, 4); else ES_DBG(32, 7); }
+            else if (lanes == 16) { if (dd == 1) ES_DBG(16, 1); else if (dd == 2) ES_DBG(16, 2); else if (dd == 3) ES_DBG(16, 3); else if (dd == 4) ES_DBG(16, 4); else ES_DBG(16, 7); }
+            else if (lanes == 8) { if (dd == 1) ES_DBG(8, 1); else if (dd == 2) ES_DBG(8, 2); else if (dd == 3) ES_DBG(8, 3); else if (dd == 4) ES_DBG(8, 4); else ES_DBG(8, 7); }
+            else { if (dd == 1) ES_DBG(4, 1); else if (dd == 2) ES_DBG(4, 2); else if (dd == 3) ES_DBG(4, 3); else if (dd == 4) ES_DBG(4, 4); else ES_DBG(4, 7); }
+#undef ES_DBG
+            return W / 4;
+        }
+#endif
+        if (lanes == 32) ES_LAUNCH(32); else if (lanes == 16) ES_LAUNCH(16); else if (lanes == 8) ES_LAUNCH(8); else ES_LAUNCH(4);
 #undef ES_LAUNCH
         return W / 4;
     }

@@ -93,6 +93,8 @@ struct CsrArgs {
     const int*    es_crow;    // the row that entry lies in (chunks + 1)
     const int*    es_hw0;     // per wave: the wave in which the row its range begins inside of starts
     const int*    es_np;      // per wave: parts of the row its range ends inside of, when that row starts in this wave (else 0)
+    const int*    es_cbase;   // per chunk: its smallest column (nullptr: the 16-bit columns are absolute)
+    const unsigned short* es_ja16;   // 16-bit columns relative to es_cbase (nullptr: ja16 as it is)
     double*       es_part;    // 2 per wave: head part, tail part
     unsigned*     es_cnt;     // per wave: parts arrived (zero between launches)
 };

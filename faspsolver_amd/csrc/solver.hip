@@ -2121,9 +2121,14 @@ void fasp_smoother_dcsr_jacobi(dvector* u, const int i_1, const int i_n, const i
         std::exit(ERROR_INPUT_PAR);
     }
     std::vector<double> d(n, 0.0);
-    for (int i = 0; i < n; ++i)
+    bool dup = false;
+    for (int i = 0; i < n; ++i) {
+        int hits = 0;
         for (int k = A->IA[i]; k < A->IA[i + 1]; ++k)
-            if (A->JA[k] == i) d[i] = A->val[k];
+            if (A->JA[k] == i) { d[i] = A->val[k]; ++hits; }
+        dup = dup || hits > 1;
+    }
+    M.D.dup_diag = dup;   // (a diagonal stored twice: the kernels that take the diagonal's product out of a full row sum do not apply)
     TmpVec du(u->val, n), du2(nullptr, n), db(b->val, n), dd(d.data(), n);
     double *x = du.d, *xo = du2.d;
     while (L--) {
@@ -2199,7 +2204,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "renumber_chunk")) g_tune.renumber_chunk = value; // rows per chunk inside which the balls grow (reorder.cpp)
     else if (!std::strcmp(key, "time_cold")) g_time_cold = value;
     else if (!std::strcmp(key, "estream")) g_tune.estream = value;   // long-row operators: the entry-parallel stream kernel (1, default) or the row kernel (0); read at launch
-    else if (!std::strcmp(key, "es_nt")) g_tune.es_nt = value;       // ... its matrix stream with non-temporal loads
+    else if (!std::strcmp(key, "es_dbg")) g_tune.es_dbg = value;     // (FASP_LAB_DEBUG builds: parts of the stream kernel switched off -- timings only)
     else if (!std::strcmp(key, "pcg_dev_beta")) g_tune.pcg_dev_beta = value;   // top-level PCG: (z, r), beta and alpha stay on the device, one host wait per iteration (1, default) or two (0)
     else if (!std::strcmp(key, "seq_chain_touch")) g_tune.seq_chain_touch = value;   // chain form: blocks by which a workgroup of its own on the chain's XCD touches the band planes ahead (8; 0: the importer wave does, four ahead)
     else if (!std::strcmp(key, "seq_chain_touch_t1")) g_tune.seq_chain_touch_t1 = value;   // ... and tier 1's entries of those blocks (1, default)

@@ -229,7 +229,10 @@ def test_relative_16bit_columns_are_bit_transparent(gpu):
     65536 columns (round 2), and RELATIVE to the row's smallest column where it has more but every row spans less than 65536 of them
     (levels 3 and 4 of P7(256); here level 3 of P7(176): ~83 000 rows of ~65 entries): 10 instead of 12 bytes per entry on levels that
     are nothing but the (JA, val) stream.  Same kernel, same order of the sums: one cycle and a whole solve are BIT-IDENTICAL with the
-    16-bit copies switched off (fasp_hip_tune("ja16", 0): the 32-bit indices of the same device copy)."""
+    16-bit copies switched off (fasp_hip_tune("ja16", 0): the 32-bit indices of the same device copy).
+    (Round 6: whole-operator launches of these levels go through k_csr_estream, which exists for the 16-bit form only -- with
+    columns relative to the CHUNK's smallest column on such levels; the statement about ONE kernel on two index widths is made with the
+    stream switched off, the stream is compared with the row kernel to 1e-13.)"""
     n = 176
     ia, ja, a, f, ue = fa.poisson7pt(n)
     itp, amgp = _params()
@@ -243,7 +246,10 @@ def test_relative_16bit_columns_are_bit_transparent(gpu):
         for l in rel:
             nnz = len(H.matrix(l, 0)[4])
             assert H.kernel_info(l, 0)[1] < 10.6 * nnz, (l, H.kernel_info(l, 0), nnz)   # 10 bytes per entry + row pointers + row bases: the 16-bit copy is there
+        zs = H.precond(r)
+        L.fasp_hip_tune(b"estream", 0)
         z1 = H.precond(r)
+        assert np.abs(zs - z1).max() <= 1e-13 * np.abs(z1).max()
         st1, x1, h1, _ = H.solve(f, itp)
         L.fasp_hip_tune(b"ja16", 0)
         for l in rel:
@@ -251,7 +257,7 @@ def test_relative_16bit_columns_are_bit_transparent(gpu):
         z0 = H.precond(r)
         st0, x0, h0, _ = H.solve(f, itp)
     finally:
-        L.fasp_hip_tune(b"ja16", 1)
+        L.fasp_hip_tune(b"ja16", 1); L.fasp_hip_tune(b"estream", 1)
         H.close()
     assert np.all(np.isfinite(z1)) and np.array_equal(z1, z0)
     assert st1 == st0 and np.array_equal(x1, x0) and np.array_equal(np.asarray(h1), np.asarray(h0))

@@ -1,5 +1,5 @@
 """Long-row levels of the P7(n) hierarchy, COLD (one launch behind a 512 MB read, as a V-cycle meets them): the row kernel
-(k_csr_rows) against the entry-parallel stream (k_csr_estream, default and non-temporal matrix loads) -- SpMV / y -= A x / Jacobi,
+(k_csr_rows) against the entry-parallel stream (k_csr_estream) -- SpMV / y -= A x / Jacobi,
 us per launch, and the plain 16-byte read of the level's values beside them.   python tools/lab/estream_ab.py [n] [var]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -19,12 +19,12 @@ print(f"P7({n}){' variable' if var else ''}: long-row levels {levels}; us per la
 for l in levels:
     kind, mb = H.kernel_info(l, 0)
     row = []
-    for es, nt in ((0, 0), (1, 0), (1, 1)):
-        L.fasp_hip_tune(b"estream", es); L.fasp_hip_tune(b"es_nt", nt)
+    for es in (0, 1):
+        L.fasp_hip_tune(b"estream", es)
         row.append([H.time_kernel(k, l, 8) * 1e3 for k in (0, 1, 2)])
     rd = H.time_kernel(8, l, 8) * 1e3
     r, c, *_ = H.matrix(l, 0)
     print(f"level {l}: {r:8d} rows {mb/1e6:7.1f} MB | rows " + " / ".join(f"{x:6.1f}" for x in row[0]) + " | estream " + " / ".join(f"{x:6.1f}" for x in row[1])
-          + " | estream nt " + " / ".join(f"{x:6.1f}" for x in row[2]) + f" | read {rd:6.1f}", flush=True)
-L.fasp_hip_tune(b"estream", 1); L.fasp_hip_tune(b"es_nt", 0); L.fasp_hip_tune(b"time_cold", 0)
+          + f" | read {rd:6.1f}", flush=True)
+L.fasp_hip_tune(b"estream", 1); L.fasp_hip_tune(b"time_cold", 0)
 H.close()
