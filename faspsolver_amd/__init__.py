@@ -49,7 +49,7 @@ EXPORTS = [  # every symbol include/fasp_hip.h declares
     "fasp_hip_dist_get_list",
     "fasp_blas_dcsr_vmv", "fasp_blas_dcsr_mxv_agg", "fasp_blas_dcsr_aAxpy_agg", "fasp_blas_darray_ax",
     "fasp_blas_darray_axpyz", "fasp_blas_darray_norm1", "fasp_darray_cp", "fasp_darray_set", "fasp_dvec_isnan",
-    "fasp_hip_time_matrix", "fasp_hip_bsr_dist_info", "fasp_hip_seq_schedule_selftest", "fasp_hip_seq_chain_selftest", "fasp_hip_cluster_order", "fasp_hip_permute_csr", "fasp_hip_comm_init_ipc", "fasp_hip_comm_stats", "fasp_hip_comm_timing", "fasp_hip_estream_selftest", "fasp_hip_pstream_selftest",
+    "fasp_hip_time_matrix", "fasp_hip_bsr_dist_info", "fasp_hip_seq_schedule_selftest", "fasp_hip_seq_chain_selftest", "fasp_hip_cluster_order", "fasp_hip_permute_csr", "fasp_hip_comm_init_ipc", "fasp_hip_comm_stats", "fasp_hip_comm_timing", "fasp_hip_estream_selftest",
 ]
 
 

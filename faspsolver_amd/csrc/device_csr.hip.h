@@ -52,21 +52,8 @@ struct DevCSR {
     unsigned short* es_ja16 = nullptr;   // 16-bit columns relative to the chunk's smallest column (operators with > 65536 columns)
     double*    es_part = nullptr;   // 2 W doubles + W counters behind them
     int        es_W = 0, es_nc = 0;
-    // k_csr_pstream (kernels4.hip.h): the panel-major copy of a long-row operator and its tables (build_pstream)
-    double*         ps_val = nullptr;
-    unsigned short* ps_col = nullptr;
-    int*            ps_tab = nullptr;   // one allocation: wg_seg, seg_panel, task_chunk, centry, csub, sptr, rp, rsub
-    double*         ps_S = nullptr;     // sub-row sums
-    int             ps_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // offsets of the tables inside ps_tab
-    int             ps_ns = 0, ps_nwg = 0, ps_lanes = 0, ps_pw = 0;
-    long long       ps_bytes = 0;       // what a launch streams (values, columns, tables)
     void    release()
     {
-        if (ps_val) (void)hipFree(ps_val);
-        if (ps_col) (void)hipFree(ps_col);
-        if (ps_tab) (void)hipFree(ps_tab);
-        if (ps_S) (void)hipFree(ps_S);
-        ps_val = nullptr; ps_col = nullptr; ps_tab = nullptr; ps_S = nullptr; ps_ns = ps_nwg = ps_lanes = 0;
         if (es_tab) (void)hipFree(es_tab);
         if (es_part) (void)hipFree(es_part);
         if (es_ja16) (void)hipFree(es_ja16);
@@ -636,7 +623,7 @@ static void build_estream_host(const int* ia, int nrow, int nnz, int per_wave, i
 static int build_estream(const int* ia, int nrow, int nnz, DevCSR& D)
 {
     static const bool on = !(std::getenv("FASP_HIP_ESTREAM") && std::atoi(std::getenv("FASP_HIP_ESTREAM")) == 0);
-    if (!on || !D.ja16 || D.kind != 0 || nnz < 65536 || nrow < 1) return FASP_SUCCESS;
+    if (!on || !D.ja16 || D.kind != 0 || nnz < 65536 || nrow < 1 || (double)nnz < 48.0 * nrow) return FASP_SUCCESS;   // (long rows: the small transfer operators that run on the row kernel have rows of 3-10 entries)
     static const int per_wave = std::getenv("FASP_HIP_ESTREAM_PER_WAVE") ? std::atoi(std::getenv("FASP_HIP_ESTREAM_PER_WAVE")) : 3072;
     static const int wmax = std::getenv("FASP_HIP_ESTREAM_WMAX") ? std::atoi(std::getenv("FASP_HIP_ESTREAM_WMAX")) : 5120;   // (five workgroups of four waves per CU: what every instantiation keeps resident at once)
     EsTables T;
@@ -731,264 +718,6 @@ static int estream_selftest_host(const int* ia, int nrow, int nnz, int per_wave,
     for (int w = 0; w < T.W; ++w)
         if (parts[(size_t)w] != T.np[(size_t)w]) return -12;
     if (info) info[2] = (int)cut_rows;
-    return 0;
-}
-
-// k_csr_pstream's data (kernels4.hip.h): the entries of a long-row operator in panel-major order (panels of PS_P columns; inside a
-// panel row by row, a row's entries in storage order; every panel padded to a multiple of 8 entries -- a pad is a sub-row of its own that
-// no row refers to), the sub-row table, the decomposition (256 workgroups x their panel segments x 16 wave tasks x chunks of <= 512
-// entries, all cuts at multiples of 8 entries; a sub-row cut by a task boundary becomes two), and per row the list of its sub-rows in
-// summation order.  Everything depends on the matrix only: the association of every row sum is a property of the operator.
-struct PsHost {
-    int ns = 0, nseg = 0, nc = 0, nwg = 0, pw = PS_P;
-    long long nent = 0;   // entries incl. pads
-    std::vector<int> wg_seg, seg_panel, task_chunk, centry, csub, sptr, rp, rsub;
-    Buf<double> pval;
-    Buf<unsigned short> pcol;
-};
-static int build_pstream_host(const HostCSR& H, int nwg, PsHost& T)
-{
-    // equal panels: ncol cut into the fewest panels of at most PS_P columns, all of the same width (a multiple of 8) -- a narrow last panel
-    // would hold sub-rows of a few entries each, and the workgroups that get them take several times as long (profiles/r06_estream.txt)
-    const int n = H.row, npan0 = (H.col + PS_P - 1) / PS_P;
-    const int PW = std::min(PS_P, (((H.col + npan0 - 1) / npan0) + 7) & ~7), npan = (H.col + PW - 1) / PW;
-    T.pw = PW;
-    const int* ia = H.ia.data(); const int* ja = H.ja.data(); const double* va = H.val.data();
-    // (1) per row: the panels it touches (ascending) and how many entries in each
-    std::vector<int> rq((size_t)n + 1, 0);
-#pragma omp parallel
-    {
-        std::vector<int> seen;
-#pragma omp for schedule(dynamic, 256)
-        for (int r = 0; r < n; ++r) {
-            seen.clear();
-            for (int k = ia[r]; k < ia[r + 1]; ++k) {
-                const int p = ja[k] / PW;
-                if (std::find(seen.begin(), seen.end(), p) == seen.end()) seen.push_back(p);
-            }
-            rq[(size_t)r + 1] = (int)seen.size();
-        }
-    }
-    for (int r = 0; r < n; ++r) rq[(size_t)r + 1] += rq[(size_t)r];
-    const int nq = rq[(size_t)n];
-    if (nq <= 0) return 1;
-    std::vector<int> qpan((size_t)nq), qcnt((size_t)nq), qstart((size_t)nq);
-#pragma omp parallel
-    {
-        std::vector<std::pair<int, int>> loc;
-#pragma omp for schedule(dynamic, 256)
-        for (int r = 0; r < n; ++r) {
-            loc.clear();
-            for (int k = ia[r]; k < ia[r + 1]; ++k) {
-                const int p = ja[k] / PW;
-                size_t j = 0;
-                while (j < loc.size() && loc[j].first != p) ++j;
-                if (j == loc.size()) loc.push_back({p, 0});
-                ++loc[j].second;
-            }
-            std::sort(loc.begin(), loc.end());
-            for (size_t j = 0; j < loc.size(); ++j) { qpan[(size_t)rq[r] + j] = loc[j].first; qcnt[(size_t)rq[r] + j] = loc[j].second; }
-        }
-    }
-    // (2) panel-major positions: panel p's entries start at pent[p] (a multiple of 8); inside, rows ascending
-    std::vector<long long> pent((size_t)npan + 1, 0);
-    for (int q = 0; q < nq; ++q) pent[(size_t)qpan[(size_t)q] + 1] += qcnt[(size_t)q];
-    std::vector<int> ppad((size_t)npan, 0);
-    for (int p = 0; p < npan; ++p) {
-        const long long c = pent[(size_t)p + 1];
-        ppad[(size_t)p] = (int)((8 - (c & 7)) & 7);
-        pent[(size_t)p + 1] = pent[(size_t)p] + c + ppad[(size_t)p];
-    }
-    const long long nent = pent[(size_t)npan];
-    if (nent >= 2147483000ll) return 1;
-    {
-        std::vector<long long> cur(pent.begin(), pent.end() - 1);
-        for (int q = 0; q < nq; ++q) { qstart[(size_t)q] = (int)cur[(size_t)qpan[(size_t)q]]; cur[(size_t)qpan[(size_t)q]] += qcnt[(size_t)q]; }
-    }
-    // (3) the entries
-    T.nent = nent;
-    T.pval.alloc((size_t)nent + 8); T.pcol.alloc((size_t)nent + 8);
-    for (int p = 0; p < npan; ++p)
-        for (int j = 0; j < ppad[(size_t)p]; ++j) { const size_t e = (size_t)(pent[(size_t)p + 1] - 1 - j); T.pval[e] = 0.0; T.pcol[e] = 0; }
-    for (size_t e = (size_t)nent; e < (size_t)nent + 8; ++e) { T.pval[e] = 0.0; T.pcol[e] = 0; }
-#pragma omp parallel
-    {
-        std::vector<int> cur;
-#pragma omp for schedule(dynamic, 256)
-        for (int r = 0; r < n; ++r) {
-            const int q0 = rq[r], q1 = rq[(size_t)r + 1];
-            cur.assign(qstart.begin() + q0, qstart.begin() + q1);
-            for (int k = ia[r]; k < ia[r + 1]; ++k) {
-                const int p = ja[k] / PW;
-                int j = 0;
-                while (qpan[(size_t)q0 + j] != p) ++j;
-                const int e = cur[(size_t)j]++;
-                T.pval[(size_t)e] = va[k];
-                T.pcol[(size_t)e] = (unsigned short)(ja[k] - p * PW);
-            }
-        }
-    }
-    // (4) the unsplit sub-rows in panel-major order: (start, row); pads as sub-rows of row -1
-    std::vector<std::pair<int, int>> us;   // (start entry, row)
-    us.reserve((size_t)nq + (size_t)npan);
-    {
-        std::vector<std::pair<int, int>> tmp((size_t)nq);
-#pragma omp parallel for schedule(static)
-        for (int r = 0; r < n; ++r)
-            for (int q = rq[r]; q < rq[(size_t)r + 1]; ++q) tmp[(size_t)q] = {qstart[(size_t)q], r};
-        std::sort(tmp.begin(), tmp.end());
-        size_t i = 0;
-        for (int p = 0; p < npan; ++p) {
-            const int pend_ = (int)pent[(size_t)p + 1], padstart = pend_ - ppad[(size_t)p];
-            while (i < tmp.size() && tmp[i].first < padstart) us.push_back(tmp[i++]);
-            if (ppad[(size_t)p]) us.push_back({padstart, -1});
-        }
-    }
-    // (5) workgroups -> panel segments -> wave tasks (every boundary a multiple of 8 entries)
-    T.nwg = nwg;
-    const long long Q = (((nent + nwg - 1) / nwg) + 7) & ~7ll;
-    T.wg_seg.assign((size_t)nwg + 1, 0);
-    std::vector<int> tb;   // task boundaries (entries), flattened: per segment PS_WAVES + 1 values
-    for (int b = 0, p = 0; b < nwg; ++b) {
-        T.wg_seg[(size_t)b] = (int)T.seg_panel.size();
-        const long long w0 = std::min(nent, Q * b), w1 = std::min(nent, Q * (b + 1));
-        long long e = w0;
-        while (e < w1) {
-            while (pent[(size_t)p + 1] <= e) ++p;
-            const long long s1 = std::min(w1, pent[(size_t)p + 1]), len = s1 - e;
-            T.seg_panel.push_back(p);
-            for (int t = 0; t <= PS_WAVES; ++t) tb.push_back(t == PS_WAVES ? (int)s1 : (int)(e + ((len * t / PS_WAVES) & ~7ll)));
-            e = s1;
-        }
-    }
-    T.wg_seg[(size_t)nwg] = (int)T.seg_panel.size();
-    T.nseg = (int)T.seg_panel.size();
-    // (6) cut the sub-rows at the task boundaries; chunks of every task
-    std::vector<int> cuts;   // all task boundaries, ascending (duplicates harmless)
-    cuts.reserve(tb.size());
-    for (int v : tb) cuts.push_back(v);
-    std::sort(cuts.begin(), cuts.end());
-    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
-    std::vector<int> srow;
-    T.sptr.clear(); T.sptr.reserve(us.size() + cuts.size() + 2);
-    srow.reserve(us.size() + cuts.size() + 2);
-    {
-        size_t ci = 0;
-        for (size_t i = 0; i < us.size(); ++i) {
-            const int s0 = us[i].first, s1 = i + 1 < us.size() ? us[i + 1].first : (int)nent;
-            T.sptr.push_back(s0); srow.push_back(us[i].second);
-            while (ci < cuts.size() && cuts[ci] <= s0) ++ci;
-            while (ci < cuts.size() && cuts[ci] < s1) { T.sptr.push_back(cuts[ci]); srow.push_back(us[i].second); ++ci; }
-        }
-    }
-    T.ns = (int)T.sptr.size();
-    T.sptr.push_back((int)nent);
-    T.sptr.push_back((int)nent);   // (slack: the window load of the last sub-rows)
-    T.task_chunk.assign((size_t)T.nseg * PS_WAVES + 1, 0);
-    for (int sg = 0; sg < T.nseg; ++sg)
-        for (int t = 0; t < PS_WAVES; ++t) {
-            T.task_chunk[(size_t)sg * PS_WAVES + t] = (int)T.centry.size();
-            const int e0 = tb[(size_t)sg * (PS_WAVES + 1) + t], e1 = tb[(size_t)sg * (PS_WAVES + 1) + t + 1], len = e1 - e0;
-            if (len <= 0) continue;
-            const int nch = (len + PS_CAP - 1) / PS_CAP, size = ((len + nch - 1) / nch + 7) & ~7;
-            if (nch > 62) return 1;   // (the kernel keeps a task's chunk table in one register per lane)
-            for (int j = 0; j < nch && e0 + j * size < e1; ++j) T.centry.push_back(e0 + j * size);
-        }
-    T.task_chunk[(size_t)T.nseg * PS_WAVES] = (int)T.centry.size();
-    T.nc = (int)T.centry.size();
-    T.centry.push_back((int)nent);
-    T.csub.resize((size_t)T.nc + 1);
-#pragma omp parallel for schedule(static)
-    for (int c = 0; c <= T.nc; ++c)
-        T.csub[(size_t)c] = c == T.nc ? T.ns : (int)(std::upper_bound(T.sptr.begin(), T.sptr.begin() + T.ns, T.centry[(size_t)c]) - T.sptr.begin()) - 1;
-    // (a chunk boundary inside a task that is not a task boundary: the sub-row containing it; a task boundary: the sub-row starting there)
-    // (7) per row its sub-rows, in panel-major (= summation) order
-    T.rp.assign((size_t)n + 1, 0);
-    for (int s2 = 0; s2 < T.ns; ++s2) if (srow[(size_t)s2] >= 0) ++T.rp[(size_t)srow[(size_t)s2] + 1];
-    for (int r = 0; r < n; ++r) T.rp[(size_t)r + 1] += T.rp[(size_t)r];
-    T.rsub.resize((size_t)std::max(1, T.rp[(size_t)n]));
-    {
-        std::vector<int> cur(T.rp.begin(), T.rp.end() - 1);
-        for (int s2 = 0; s2 < T.ns; ++s2) if (srow[(size_t)s2] >= 0) T.rsub[(size_t)cur[(size_t)srow[(size_t)s2]]++] = s2;
-    }
-    return 0;
-}
-
-static int build_pstream(const HostCSR& H, DevCSR& D)
-{
-    static const bool on = !(std::getenv("FASP_HIP_PSTREAM") && std::atoi(std::getenv("FASP_HIP_PSTREAM")) == 0);
-    if (!on || D.kind != 0 || H.nnz < 65536 || H.row < 1 || g_oneshot_upload || (double)H.nnz < 48.0 * H.row) return FASP_SUCCESS;   // (long rows: the small transfer operators on the row kernel have rows of 3-10 entries)
-    PsHost T;
-    if (build_pstream_host(H, 256, T) != 0) return FASP_SUCCESS;
-    const std::vector<int>* parts[8] = {&T.wg_seg, &T.seg_panel, &T.task_chunk, &T.centry, &T.csub, &T.sptr, &T.rp, &T.rsub};
-    size_t nt = 0;
-    for (int i = 0; i < 8; ++i) { D.ps_off[i] = (int)nt; nt += parts[i]->size(); }
-    std::vector<int> tab(nt);
-    for (int i = 0; i < 8; ++i) std::copy(parts[i]->begin(), parts[i]->end(), tab.begin() + D.ps_off[i]);
-    HIPCK(hipMalloc(&D.ps_tab, sizeof(int) * nt));
-    HIPCK(hipMemcpy(D.ps_tab, tab.data(), sizeof(int) * nt, hipMemcpyHostToDevice));
-    HIPCK(hipMalloc(&D.ps_val, sizeof(double) * ((size_t)T.nent + 8)));
-    HIPCK(hipMalloc(&D.ps_col, sizeof(unsigned short) * ((size_t)T.nent + 8)));
-    HIPCK(hipMemcpy(D.ps_val, T.pval.data(), sizeof(double) * ((size_t)T.nent + 8), hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(D.ps_col, T.pcol.data(), sizeof(unsigned short) * ((size_t)T.nent + 8), hipMemcpyHostToDevice));
-    HIPCK(hipMalloc(&D.ps_S, sizeof(double) * ((size_t)T.ns + 1)));
-    D.ps_ns = T.ns; D.ps_nwg = T.nwg; D.ps_pw = T.pw;
-    // lanes per sub-row: about an eighth of the mean sub-row -- the sub-rows a 512-entry chunk touches then fit one or two passes of 64 / L
-    const double avg = (double)T.nent / std::max(1, T.ns);
-    // (>= 128 entries per sub-row: the register form, "64"; below: sub-wavefront groups over the slab, few lanes so that one pass does)
-    D.ps_lanes = avg >= 128.0 ? 64 : avg >= 48.0 ? 4 : 2;
-    D.ps_bytes = (long long)T.nent * 10 + 4ll * (long long)(T.centry.size() + T.csub.size() + T.sptr.size() + T.rp.size() + T.rsub.size()) + 16ll * T.ns;
-    if (std::getenv("FASP_HIP_SETUP_TIMING"))
-        std::printf("        [pstream %d x %d, %d nnz] %d panels of %d columns, %d sub-rows (%.1f entries each, %d lanes), %d segments, %d chunks\n", H.row, H.col, H.nnz,
-                    (H.col + T.pw - 1) / T.pw, T.pw, T.ns, avg, D.ps_lanes, T.nseg, T.nc);
-    return FASP_SUCCESS;
-}
-
-// Host walk of k_csr_pstream + k_pcombine over the tables (CPU tests; no device): y = A x through the panel-major copy exactly as the
-// kernels go through it -- workgroup, segment, wave task, chunk, sub-rows of the chunk -- with every structural assumption checked
-// (chunks of at most PS_CAP entries starting at multiples of 8, a sub-row finished exactly once and inside its task, columns inside
-// their panel).  Returns 0 or the negative number of the check that failed; y receives the product.
-static int pstream_selftest_host(const HostCSR& H, const double* x, double* y, int* info)
-{
-    PsHost T;
-    if (build_pstream_host(H, 256, T) != 0) return -1;
-    if (info) { info[0] = T.ns; info[1] = T.nseg; info[2] = T.nc; info[3] = (int)(T.nent - H.nnz); }
-    std::vector<double> S((size_t)T.ns + 1, 0.0);
-    std::vector<int> done((size_t)T.ns + 1, 0);
-    long long covered = 0;
-    for (int b = 0; b < T.nwg; ++b)
-        for (int sg = T.wg_seg[(size_t)b]; sg < T.wg_seg[(size_t)b + 1]; ++sg) {
-            const int panel = T.seg_panel[(size_t)sg];
-            for (int t = 0; t < PS_WAVES; ++t) {
-                const int c0 = T.task_chunk[(size_t)sg * PS_WAVES + t], c1 = T.task_chunk[(size_t)sg * PS_WAVES + t + 1];
-                double acc = 0.0;
-                int open_row = -1;   // sub-row carried from the previous chunk
-                for (int c = c0; c < c1; ++c) {
-                    const int lo = T.centry[(size_t)c], hi = T.centry[(size_t)c + 1], rf = T.csub[(size_t)c], rl = T.csub[(size_t)c + 1];
-                    if (hi <= lo || hi - lo > PS_CAP || (lo & 7)) return -2;
-                    if (rf > rl) return -3;
-                    covered += hi - lo;
-                    for (int r = rf; r <= rl && r < T.ns; ++r) {
-                        const int kb = T.sptr[(size_t)r], ke = T.sptr[(size_t)r + 1];
-                        if (r != open_row) { if (open_row >= 0 && r == rf && c > c0) return -4; acc = 0.0; }   // (a carried sub-row is the chunk's first)
-                        for (int k = std::max(kb, lo); k < std::min(ke, hi); ++k) {
-                            if (T.pcol[(size_t)k] >= PS_P) return -5;
-                            const long long col = (long long)panel * T.pw + T.pcol[(size_t)k];
-                            acc += T.pval[(size_t)k] * (col < H.col ? x[col] : 0.0);
-                        }
-                        if (ke <= hi) { if (done[(size_t)r]++) return -6; S[(size_t)r] = acc; open_row = -1; acc = 0.0; }
-                        else { open_row = r; if (c + 1 == c1 && kb < hi) return -7; }   // (unfinished at the end of its task)
-                    }
-                }
-            }
-        }
-    if (covered != T.nent) return -8;
-    for (int s2 = 0; s2 < T.ns; ++s2) if (done[(size_t)s2] != 1) return -9;
-    for (int r = 0; r < H.row; ++r) {
-        double s = 0.0;
-        for (int q = T.rp[(size_t)r]; q < T.rp[(size_t)r + 1]; ++q) s += S[(size_t)T.rsub[(size_t)q]];
-        y[r] = s;
-    }
     return 0;
 }
 
@@ -1097,9 +826,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
         if (g_device_sort && maxlen <= SORT_MAXLEN) {
             const int st = upload_sorted_on_device(H, D, maxlen);
             lap("device sort");
-            if (st < 0) return st;
-            if (build_estream(H.ia.data(), H.row, H.nnz, D) < 0) return ERROR_ALLOC_MEM;
-            return build_pstream(H, D);
+            return st < 0 ? st : build_estream(H.ia.data(), H.row, H.nnz, D);
         }
     }
     if (do_sort) {
@@ -1138,18 +865,16 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
         }
         D.sorted = true;
         if (upload_ja16(D, H.ia.data(), sj.data()) < 0) return ERROR_ALLOC_MEM;
-        if (build_estream(H.ia.data(), H.row, H.nnz, D) < 0) return ERROR_ALLOC_MEM;
-        return build_pstream(H, D);
+        return build_estream(H.ia.data(), H.row, H.nnz, D);
     }
     if (upload_plain() < 0) return ERROR_ALLOC_MEM;
     if (D.kind == 2 && !g_oneshot_upload && build_xtile(H, D) < 0) return ERROR_ALLOC_MEM;
     if (upload_ja16(D, H.ia.data(), H.ja.data()) < 0) return ERROR_ALLOC_MEM;
-    if (build_estream(H.ia.data(), H.row, H.nnz, D) < 0) return ERROR_ALLOC_MEM;
-    return build_pstream(H, D);
+    return build_estream(H.ia.data(), H.row, H.nnz, D);
 }
 
 // development knobs (fasp_hip_tune): -1 = automatic
-struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 0, seq_jobs = 1, seq_spine = 1, seq_grid = 0, seq_chain = 1, seq_chain_n1 = 0, seq_chain_grid = 0, seq_chain_ref = 0, seq_test_hang = 0, seq_rest_lanes = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 2, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1, renumber = 1, renumber_chunk = 262144, pcg_dev_beta = 1, spcg_spec = 1, ev_every = 4, pcg_fold = 1, seq_chain_touch = 8, seq_chain_touch_t1 = 1, seq_zero_skip = 1, estream = 1, es_dbg = 0, pstream = 1, ps_lanes = 0; };
+struct Tuning { int gen2 = 2, ws2_bpc = 3, maxgrid = -1, xcd = 16, nt = 1, kind = -1, lanes = -1, wrows = -1, wcap = -1, compress = 1, rpl = -1, lds_tab = 1, xcd_pat = 64, spcg_batch = 16, small_lds = 1, ja16 = 1, spcg_fused = 1, spcg_grid = 0, spcg_persist = 1, split_rows = 0, gs_multicolor = 0, seq_flow = 1, seq_strip_kb = 0, seq_jobs = 1, seq_spine = 1, seq_grid = 0, seq_chain = 1, seq_chain_n1 = 0, seq_chain_grid = 0, seq_chain_ref = 0, seq_test_hang = 0, seq_rest_lanes = 0, local_square = 1, fuse_zr = 1, fuse_presmooth = 1, seq_lanes = 0, xtile = 1, rp5_max = 45, rp_bpc = 5, rp_xcd = -1, rp_strip = 2, spcg_test_hang = 0, small_onewave = 2, lazy_coarse = 1, rp_stream = -1, renumber = 1, renumber_chunk = 262144, pcg_dev_beta = 1, spcg_spec = 1, ev_every = 4, pcg_fold = 1, seq_chain_touch = 8, seq_chain_touch_t1 = 1, seq_zero_skip = 1, estream = 1, es_dbg = 0; };
 static Tuning g_tune;
 
 // Blocks of one kernel instantiation that are co-resident on a CU (VGPR / LDS / wave
@@ -1371,42 +1096,13 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
         if (M.wrows == 32 && M.wcap == 512) return launch_persistent(k_csr_wstream<OP, 32, 512>, a.ntiles, a);
         return launch_persistent(k_csr_wstream<OP, 32, 1024>, a.ntiles, a);
     }
-    // long rows, whole-operator launches: the panel stream (kernels4.hip.h) -- x from LDS, sub-row sums, then the combine kernel with the
-    // epilogue (every OP, the fused dot products included).  Row windows keep the row kernel.
-    if (M.ps_tab && g_tune.pstream && win.hi < 0 && g_tune.split_rows <= 0 && !(OP == OP_JACOBI && M.dup_diag)) {
-        PsArgs pa{};
-        pa.val = M.ps_val; pa.col = M.ps_col;
-        pa.wg_seg = M.ps_tab + M.ps_off[0]; pa.seg_panel = M.ps_tab + M.ps_off[1]; pa.task_chunk = M.ps_tab + M.ps_off[2];
-        pa.centry = M.ps_tab + M.ps_off[3]; pa.csub = M.ps_tab + M.ps_off[4]; pa.sptr = M.ps_tab + M.ps_off[5];
-        pa.x = a.x; pa.S = M.ps_S; pa.ncol = M.col; pa.ns = M.ps_ns; pa.pw = M.ps_pw; pa.stop = a.stop;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_pstream<64>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_pstream<32>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_pstream<16>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_pstream<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_pstream<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_pstream<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
-            attr_set = true;
-        }
-        const int lanes = g_tune.ps_lanes > 0 ? g_tune.ps_lanes : M.ps_lanes;
-        if (lanes >= 64) hipLaunchKernelGGL(k_csr_pstream<64>, dim3(M.ps_nwg), dim3(PS_NT), PS_LDS_BYTES, g_ctx.stream, pa);
-        else if (lanes >= 32) hipLaunchKernelGGL(k_csr_pstream<32>, dim3(M.ps_nwg), dim3(PS_NT), PS_LDS_BYTES, g_ctx.stream, pa);
-        else if (lanes >= 16) hipLaunchKernelGGL(k_csr_pstream<16>, dim3(M.ps_nwg), dim3(PS_NT), PS_LDS_BYTES, g_ctx.stream, pa);
-        else if (lanes >= 8) hipLaunchKernelGGL(k_csr_pstream<8>, dim3(M.ps_nwg), dim3(PS_NT), PS_LDS_BYTES, g_ctx.stream, pa);
-        else if (lanes >= 4) hipLaunchKernelGGL(k_csr_pstream<4>, dim3(M.ps_nwg), dim3(PS_NT), PS_LDS_BYTES, g_ctx.stream, pa);
-        else hipLaunchKernelGGL(k_csr_pstream<2>, dim3(M.ps_nwg), dim3(PS_NT), PS_LDS_BYTES, g_ctx.stream, pa);
-        PcArgs pc{};
-        pc.nrow = M.row; pc.rp = M.ps_tab + M.ps_off[6]; pc.rsub = M.ps_tab + M.ps_off[7]; pc.S = M.ps_S;
-        a.nrow = M.row;
-        const int grid = std::max(1, std::min(MAXGRID, (M.row + BLOCK - 1) / BLOCK));
-        if (OP == OP_JACOBI && a.partials) g_jacobi_dot_done = true;
-        hipLaunchKernelGGL(k_pcombine<OP>, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, pc, a);
-        return grid;
-    }
     // long rows with 16-bit columns, whole-operator launches: the entry-parallel stream (kernels3.hip.h).  Not for the fused dot
     // products (whichever wave completes a cut row would own its term of the sum) and not for row windows (they keep the row kernel).
-    if (M.es_tab && g_tune.estream && a.ja16 && win.hi < 0 && g_tune.split_rows <= 0 && OP != OP_MXV_DOT && !(OP == OP_JACOBI && (a.partials || M.dup_diag))) {
+    // Where it is the faster one (cold, P7(256): profiles/r06_estream.txt): mean rows below 256 entries -- levels 3 and 4 there, 66 -> 50 and
+    // 51 -> 48 us per product; on the longer rows the two tie (both sit on the gather rate of the texture-address pipe) and the row
+    // kernel's epilogue is lighter.  fasp_hip_tune("estream", 2): wherever the tables exist (tests, A/B runs); 0: never.
+    const bool es_rule = g_tune.estream >= 2 || (g_tune.estream == 1 && (double)M.nnz < 256.0 * M.row);
+    if (M.es_tab && es_rule && a.ja16 && win.hi < 0 && g_tune.split_rows <= 0 && OP != OP_MXV_DOT && !(OP == OP_JACOBI && (a.partials || M.dup_diag))) {
         const int W = M.es_W, nc = M.es_nc;
         a.es_wc = M.es_tab; a.es_centry = a.es_wc + W + 1; a.es_crow = a.es_centry + nc + 1; a.es_hw0 = a.es_crow + nc + 1; a.es_np = a.es_hw0 + W;
         a.es_part = M.es_part; a.es_cnt = reinterpret_cast<unsigned*>(M.es_part + 2 * (size_t)W);
@@ -1431,8 +1127,11 @@ static int launch_csr(const DevCSR& M0, CsrArgs a, RowWin win = RowWin())
             return W / 4;
         }
 #endif
+        static const bool es_log = std::getenv("FASP_HIP_ES_LOG") != nullptr;   // (debugging: every launch announced and waited for)
+        if (es_log) { std::fprintf(stderr, "[es rank %d] op %d rows %d cols %d nnz %d W %d chunks %d lanes %d rel %d x %p y %p b %p\n", comm_rank(), (int)OP, M.row, M.col, M.nnz, W, nc, lanes, M.es_ja16 != nullptr, (const void*)a.x, (void*)a.y, (const void*)a.b); std::fflush(stderr); }
         if (lanes == 32) ES_LAUNCH(32); else if (lanes == 16) ES_LAUNCH(16); else if (lanes == 8) ES_LAUNCH(8); else ES_LAUNCH(4);
 #undef ES_LAUNCH
+        if (es_log) { const hipError_t e = hipStreamSynchronize(g_ctx.stream); std::fprintf(stderr, "[es rank %d] done: %s\n", comm_rank(), hipGetErrorString(e)); std::fflush(stderr); }
         return W / 4;
     }
     switch (M.lanes) {

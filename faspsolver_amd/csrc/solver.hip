@@ -42,7 +42,6 @@
 #include "kernels.hip.h"
 #include "kernels2.hip.h"
 #include "kernels3.hip.h"
-#include "kernels4.hip.h"
 #include "small_solvers.hip.h"
 #include "seq_split.hip.h"
 #include "seq_chain.hip.h"
@@ -2204,9 +2203,7 @@ int fasp_hip_tune(const char* key, int value)
     else if (!std::strcmp(key, "renumber")) g_tune.renumber = value;             // brick renumbering of the uncoded mid levels at upload (order-independent smoothers only; hierarchy.hip.h): 1 on (default), 2 also levels behind a coded one (whose transfer operators keep their coding and take a numbering bridge), 0 off; read when a hierarchy is uploaded
     else if (!std::strcmp(key, "renumber_chunk")) g_tune.renumber_chunk = value; // rows per chunk inside which the balls grow (reorder.cpp)
     else if (!std::strcmp(key, "time_cold")) g_time_cold = value;
-    else if (!std::strcmp(key, "pstream")) g_tune.pstream = value;   // long-row operators: the panel stream (x panels in LDS + combine kernel; 1, default) or what is below it (0); read at launch
-    else if (!std::strcmp(key, "ps_lanes")) g_tune.ps_lanes = value; // ... lanes per sub-row (0: from the mean sub-row length)
-    else if (!std::strcmp(key, "estream")) g_tune.estream = value;   // long-row operators: the entry-parallel stream kernel (1, default) or the row kernel (0); read at launch
+    else if (!std::strcmp(key, "estream")) g_tune.estream = value;   // long-row operators: the entry-parallel stream kernel where it measured faster (1, default: mean rows below 256 entries), wherever its tables exist (2), never (0: the row kernel); read at launch
     else if (!std::strcmp(key, "es_dbg")) g_tune.es_dbg = value;     // (FASP_LAB_DEBUG builds: parts of the stream kernel switched off -- timings only)
     else if (!std::strcmp(key, "pcg_dev_beta")) g_tune.pcg_dev_beta = value;   // top-level PCG: (z, r), beta and alpha stay on the device, one host wait per iteration (1, default) or two (0)
     else if (!std::strcmp(key, "seq_chain_touch")) g_tune.seq_chain_touch = value;   // chain form: blocks by which a workgroup of its own on the chain's XCD touches the band planes ahead (8; 0: the importer wave does, four ahead)
@@ -2230,16 +2227,6 @@ int fasp_hip_estream_selftest(const int* ia, int nrow, int nnz, int per_wave, in
 {
     if (!ia || nrow < 1 || nnz < 1 || per_wave < 8 || wmax < 32) return ERROR_INPUT_PAR;
     return estream_selftest_host(ia, nrow, nnz, per_wave, wmax, info);
-}
-
-// CPU test entry: y = A x through the tables of k_csr_pstream, walked on the host the way the kernels walk them (device_csr.hip.h)
-int fasp_hip_pstream_selftest(const dCSRmat* A, const double* x, double* y, int* info)
-{
-    if (!A || !x || !y || A->row < 1 || A->nnz < 1) return ERROR_INPUT_PAR;
-    HostCSR M;
-    M.row = A->row; M.col = A->col; M.nnz = A->nnz;
-    M.ia.view(A->IA, (size_t)A->row + 1); M.ja.view(A->JA, (size_t)A->nnz); M.val.view(A->val, (size_t)A->nnz);
-    return pstream_selftest_host(M, x, y, info);
 }
 
 // Measured device ceilings beside the roofline: a 16-byte-per-lane read, copy and triad over buffers of

@@ -94,10 +94,6 @@ int fasp_hip_dist_get_list(const fasp_hip_amg* h, int level, int which, ivector*
  * kernel walks them: 0 when every entry is covered once and every row is finished exactly once, else the negative number of the check
  * that failed.  info (may be NULL) = {wave ranges, chunks, rows cut by a wave boundary}.  No GPU needed. */
 int  fasp_hip_estream_selftest(const int* ia, int nrow, int nnz, int per_wave, int wmax, int* info);
-/* y = A x through k_csr_pstream's panel-major copy and tables (csrc/kernels4.hip.h), built and walked on the HOST the way the two kernels
- * walk them, every structural assumption checked: 0, or the negative number of the failed check.  info (may be NULL) = {sub-rows,
- * segments, chunks, pad entries}.  No GPU needed. */
-int  fasp_hip_pstream_selftest(const dCSRmat* A, const double* x, double* y, int* info);
 /* one-rank exercise of every RCCL call the transport makes (0 = all results correct) */
 int  fasp_hip_comm_selftest(void);
 

@@ -1,4 +1,4 @@
-"""k_csr_pstream / k_pcombine (csrc/kernels4.hip.h) and k_csr_estream (csrc/kernels3.hip.h), round 6: the stream kernels of the long-row operators, through the C-ABI
+"""k_csr_estream (csrc/kernels3.hip.h, round 6): the entry-parallel stream kernel of the long-row operators, through the C-ABI
 (fasp_blas_dcsr_mxv / _aAxpy, BlaSpmvCSR.c:242 / :494; fasp_smoother_dcsr_jacobi, ItrSmootherCSR.c:98) against the CPU oracle's row
 sums on the same inputs, and against the row kernel it replaces (fasp_hip_tune("estream", 0)).
 
@@ -82,8 +82,8 @@ def test_estream_matches_oracle_and_row_kernel(gpu, name):
     oracle().orc_mxv(C.byref(A), T.dp(x), T.dp(y_ref))
     got = {}
     try:
-        for es in (2, 1, 0):   # 2: the panel stream (k_csr_pstream + k_pcombine), 1: the entry stream, 0: the row kernel
-            L.fasp_hip_tune(b"pstream", 1 if es == 2 else 0); L.fasp_hip_tune(b"estream", 1 if es >= 1 else 0)
+        for es in (2, 0):   # 2: the entry stream wherever its tables exist, 0: the row kernel
+            L.fasp_hip_tune(b"estream", es)
             y = np.full(n, 7.0)
             L.fasp_blas_dcsr_mxv(C.byref(A), T.dp(x), T.dp(y))
             assert np.all(y[lens == 0] == 0.0)
@@ -99,8 +99,7 @@ def test_estream_matches_oracle_and_row_kernel(gpu, name):
                 L.fasp_blas_dcsr_aAxpy(alpha, C.byref(A), T.dp(x), T.dp(y3))
                 assert np.all(np.abs(y1 - y3) <= 1e-13 * (rowabs + np.abs(y0)) + 1e-300), (name, es, alpha)
     finally:
-        L.fasp_hip_tune(b"estream", 1); L.fasp_hip_tune(b"pstream", 1)
-    assert np.all(np.abs(got[0] - got[1]) <= 2e-13 * np.maximum(rowabs, 1e-300) + 1e-300)
+        L.fasp_hip_tune(b"estream", 1)
     assert np.all(np.abs(got[0] - got[2]) <= 2e-13 * np.maximum(rowabs, 1e-300) + 1e-300)
 
 
@@ -122,12 +121,12 @@ def test_estream_jacobi_sweeps(gpu, name):
     f = rng.standard_normal(n)
     L = gpu.lib()
     try:
-        for es in (2, 1, 0):
-            L.fasp_hip_tune(b"pstream", 1 if es == 2 else 0); L.fasp_hip_tune(b"estream", 1 if es >= 1 else 0)
+        for es in (2, 0):
+            L.fasp_hip_tune(b"estream", es)
             u1 = rng.standard_normal(n); u2 = u1.copy()
             oracle().orc_smoother_jacobi(T.dp(u1), 0, n - 1, 1, C.byref(A), T.dp(f), 3, 0.8)
             uv = T.dvector(n, T.dp(u2)); bv = T.dvector(n, T.dp(f))
             L.fasp_smoother_dcsr_jacobi(C.byref(uv), n - 1, 0, -1, C.byref(A), C.byref(bv), 3, 0.8)
             assert np.allclose(u1, u2, rtol=1e-12, atol=1e-13 * np.max(np.abs(u1))), (name, es)
     finally:
-        L.fasp_hip_tune(b"estream", 1); L.fasp_hip_tune(b"pstream", 1)
+        L.fasp_hip_tune(b"estream", 1)

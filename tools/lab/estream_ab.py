@@ -19,12 +19,12 @@ print(f"P7({n}){' variable' if var else ''}: long-row levels {levels}; us per la
 for l in levels:
     kind, mb = H.kernel_info(l, 0)
     row = []
-    for es in (0, 1, 2):
-        L.fasp_hip_tune(b"pstream", 1 if es == 2 else 0); L.fasp_hip_tune(b"estream", 1 if es >= 1 else 0)
+    for es in (0, 2):
+        L.fasp_hip_tune(b"estream", es)
         row.append([H.time_kernel(k, l, 8) * 1e3 for k in (0, 1, 2)])
     rd = H.time_kernel(8, l, 8) * 1e3
     r, c, *_ = H.matrix(l, 0)
     print(f"level {l}: {r:8d} rows {mb/1e6:7.1f} MB | rows " + " / ".join(f"{x:6.1f}" for x in row[0]) + " | estream " + " / ".join(f"{x:6.1f}" for x in row[1])
-          + " | pstream+combine " + " / ".join(f"{x:6.1f}" for x in row[2]) + f" | read {rd:6.1f}", flush=True)
-L.fasp_hip_tune(b"estream", 1); L.fasp_hip_tune(b"pstream", 1); L.fasp_hip_tune(b"time_cold", 0)
+          + f" | read {rd:6.1f}", flush=True)
+L.fasp_hip_tune(b"estream", 1); L.fasp_hip_tune(b"time_cold", 0)
 H.close()
