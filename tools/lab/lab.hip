@@ -10,7 +10,6 @@
 #define FASP_LAB_DEBUG 1
 #include "../../faspsolver_amd/csrc/solver.hip"
 #include "../../faspsolver_amd/csrc/kernels2.hip.h"
-#include "retired_kernels.hip.h"
 
 #include <string>
 
@@ -223,20 +222,13 @@ int main(int argc, char** argv)
                     run_variant(C, "rowpat<MXV_DOT,2,1> (r1)", k_csr_rowpat<OP_MXV_DOT, 2, 1>, OP_MXV_DOT, 256, xcd, reps, true);
                     run_variant(C, "rowpat<JACOBI,2,1> (r1)", k_csr_rowpat<OP_JACOBI, 2, 1>, OP_JACOBI, 256, xcd, reps, true);
                     }
-                    run_variant(C, "rowpat2<MXV,2>", k_csr_rowpat2<OP_MXV, 2>, OP_MXV, 512, xcd, reps, true);
-                    run_variant(C, "rowpat2<MXV_DOT,2>", k_csr_rowpat2<OP_MXV_DOT, 2>, OP_MXV_DOT, 512, xcd, reps, true);
-                    run_variant(C, "rowpat2<JACOBI,2>", k_csr_rowpat2<OP_JACOBI, 2>, OP_JACOBI, 512, xcd, reps, true);
                     for (int g : {1024, 1280, 1536, 1792, 2048}) run_variant(C, "rowpat4g<MXV>", k_csr_rowpat4<OP_MXV>, OP_MXV, 512, xcd, reps, true, g);
                     for (int g : {1024, 1280, 1536, 1792, 2048}) run_variant(C, "rowpat4g<JACOBI>", k_csr_rowpat4<OP_JACOBI>, OP_JACOBI, 512, xcd, reps, true, g);
                     run_variant(C, "rowpat4<MXV>", k_csr_rowpat4<OP_MXV>, OP_MXV, 512, xcd, reps, true);
                     run_variant(C, "rowpat4<MXV_DOT>", k_csr_rowpat4<OP_MXV_DOT>, OP_MXV_DOT, 512, xcd, reps, true);
                     run_variant(C, "rowpat4<JACOBI>", k_csr_rowpat4<OP_JACOBI>, OP_JACOBI, 512, xcd, reps, true);
-                    run_variant(C, "rowpat3<MXV,2>", k_csr_rowpat3<OP_MXV, 2>, OP_MXV, 512, xcd, reps, true);
-                    run_variant(C, "rowpat3<MXV_DOT,2>", k_csr_rowpat3<OP_MXV_DOT, 2>, OP_MXV_DOT, 512, xcd, reps, true);
-                    run_variant(C, "rowpat3<JACOBI,2>", k_csr_rowpat3<OP_JACOBI, 2>, OP_JACOBI, 512, xcd, reps, true);
                 } else {
                     run_variant(C, "rowpat<MXV,1,1> (r1)", k_csr_rowpat<OP_MXV, 1, 1>, OP_MXV, 256, xcd, reps, true);
-                    run_variant(C, "rowpat2<MXV,1>", k_csr_rowpat2<OP_MXV, 1>, OP_MXV, 512, xcd, reps, true);
                 }
             }
         }
