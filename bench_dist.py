@@ -34,7 +34,7 @@ def main(args, rank, world, local_rank):
     dist.broadcast(tok, 0)   # (names of this run only: nothing a crashed earlier run left in /dev/shm is picked up)
     run_id = f"{os.environ.get('MASTER_PORT', '0')}_{int(tok[0]):08x}"
     from faspsolver_amd import comm_probe as P
-    ndev = P.visible_gpu_count()   # (KFD topology / *_VISIBLE_DEVICES: no HIP call -- the probes below, child processes, run before this process touches its GPU)
+    ndev = P.visible_gpu_count()   # (asked in a child process: this one has not touched the HIP runtime when the probe children start)
     if ndev <= 0:
         B.log("bench_dist: no HIP device")
         sys.exit(2)
@@ -62,7 +62,7 @@ def main(args, rank, world, local_rank):
     dev = local_rank % ndev if backend == "shm" or ndev < world else local_rank
     ndev_hip = L.fasp_hip_device_count()   # (first HIP call of this process: after the probe children)
     if ndev_hip != ndev:
-        B.log(f"bench_dist: rank {rank}: the KFD / render-node count says {ndev} device(s), the HIP runtime {ndev_hip}; using the runtime's")
+        B.log(f"bench_dist: rank {rank}: the counting child saw {ndev} device(s), this process sees {ndev_hip}; using this process's")
         ndev = max(ndev_hip, 1)
         dev = local_rank % ndev if backend == "shm" or ndev < world else local_rank
     st = L.fasp_hip_set_device(dev)

@@ -23,31 +23,24 @@ import time
 
 
 def visible_gpu_count():
-    """Number of GPUs this process may use, WITHOUT touching the HIP runtime (a process that has initialised the GPU must not
-    start the probe children after an exec, and torch.cuda.device_count() initialises more than it says on some images):
-    the KFD topology (a node with simd_count > 0 is a GPU), cut down to the render nodes this process can open (a container
-    that is given one GPU of eight still sees all eight in the topology) and by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
-    CUDA_VISIBLE_DEVICES when one of them is set.  0 when there is no KFD (no GPU box)."""
-    import glob
+    """Number of GPUs the HIP runtime of THIS environment offers, asked in a CHILD process (hipGetDeviceCount through the library):
+    the caller -- a rank that is about to start the probe children and must not have initialised the GPU before it does -- never touches
+    the runtime itself, and the answer is the runtime's own (the KFD topology and the render nodes list every GPU of the node even when
+    the container may use one of them: counting there sent rank 1 of a two-rank run on a one-GPU box to a device that does not exist).
+    0 when the child fails (no GPU, no library)."""
     import os
-    n = 0
-    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
-        try:
-            for line in open(prop):
-                k, _, v = line.partition(" ")
-                if k == "simd_count" and int(v) > 0:
-                    n += 1
-        except OSError:
-            pass
-    render = [d for d in glob.glob("/dev/dri/renderD*") if os.access(d, os.R_OK | os.W_OK)]
-    if render:
-        n = min(n, len(render))
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None:
-            ids = [t for t in v.split(",") if t.strip() != ""]
-            n = min(n, len(ids)) if n else 0
-    return n
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); import faspsolver_amd as fa; print('NDEV', fa.lib().fasp_hip_device_count())" % root
+    try:
+        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120).stdout
+        for line in out.splitlines():
+            if line.startswith("NDEV"):
+                return max(0, int(line.split()[1]))
+    except Exception:
+        pass
+    return 0
 
 
 def choose_transport(candidates, probe, all_min, log=lambda s: None):

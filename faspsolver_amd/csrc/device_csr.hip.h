@@ -414,6 +414,7 @@ static int upload_ja16(DevCSR& D, const int* ia_host, const int* ja_dev_order)
         for (int k = ia_host[i]; k < ia_host[i + 1]; ++k) j16[k] = (unsigned short)(ja_dev_order[k] - lo);
     }
     HIPCK(hipMalloc(&D.ja16, sizeof(unsigned short) * ((size_t)D.nnz + 8)));
+    HIPCK(hipMemset(D.ja16 + D.nnz, 0, sizeof(unsigned short) * 8));   // (k_csr_estream reads whole 16-byte pieces: the slack must hold valid columns)
     HIPCK(hipMemcpy(D.ja16, j16.data(), sizeof(unsigned short) * (size_t)D.nnz, hipMemcpyHostToDevice));
     if (relative) {
         HIPCK(hipMalloc(&D.jbase, sizeof(int) * (size_t)D.row));
@@ -475,6 +476,7 @@ static int upload_sorted_on_device(const HostCSR& H, DevCSR& D, int maxlen)
     const bool relative = D.col > 65536;
     const bool want16 = ja16_on && D.kind == 0 && D.nnz >= 4096 && (!relative || rows_span_16bit(H.ia.data(), H.ja.data(), H.row));   // as upload_ja16
     if (st >= 0 && want16 && hipMalloc(&D.ja16, sizeof(unsigned short) * ((size_t)D.nnz + 8)) != hipSuccess) st = ERROR_ALLOC_MEM;
+    if (st >= 0 && want16 && hipMemsetAsync(D.ja16 + D.nnz, 0, sizeof(unsigned short) * 8, g_ctx.stream) != hipSuccess) st = ERROR_MISC;   // (the slack k_csr_estream's last 16-byte piece reads)
     if (st >= 0 && want16 && relative && hipMalloc(&D.jbase, sizeof(int) * (size_t)std::max(D.row, 1)) != hipSuccess) st = ERROR_ALLOC_MEM;
     if (st >= 0) {
         int P = 64;
@@ -662,6 +664,7 @@ static int build_estream(const int* ia, int nrow, int nnz, DevCSR& D)
             return FASP_SUCCESS;
         }
         HIPCK(hipMalloc(&D.es_ja16, sizeof(unsigned short) * ((size_t)nnz + 8)));
+        HIPCK(hipMemsetAsync(D.es_ja16 + nnz, 0, sizeof(unsigned short) * 8, g_ctx.stream));
         hipLaunchKernelGGL(k_es_chunk_cols, dim3(grid), dim3(BLOCK), 0, g_ctx.stream, nc, centry, (const int*)D.ja, (const int*)cbase, D.es_ja16);
         HIPCK(hipStreamSynchronize(g_ctx.stream));
     }
@@ -727,6 +730,7 @@ static int upload_csr(const HostCSR& H, DevCSR& D)
     HIPCK(hipMalloc(&D.ia, sizeof(int) * ((size_t)H.row + 1)));
     HIPCK(hipMalloc(&D.ja, sizeof(int) * std::max<size_t>(H.nnz, 1)));
     HIPCK(hipMalloc(&D.val, sizeof(double) * (std::max<size_t>(H.nnz, 1) + 2)));   // (+ 16 bytes: k_csr_estream's last 16-byte piece)
+    HIPCK(hipMemsetAsync(D.val + std::max<size_t>(H.nnz, 1), 0, sizeof(double) * 2, g_ctx.stream));
     HIPCK(hipMemcpyAsync(D.ia, H.ia.data(), sizeof(int) * ((size_t)H.row + 1), hipMemcpyHostToDevice, g_ctx.stream));
     pick_kernel(D);
     auto upload_plain = [&]() -> int {

@@ -61,6 +61,10 @@ def _cases():
     out["relative-columns"] = (rng.integers(50, 700, 1500), 200000, 40000)
     # (e) equal rows of 512 entries: ranges and chunks end exactly on row boundaries
     out["aligned"] = (np.full(640, 512), 50000, None)
+    # (f), (g) the row lengths of the levels the kernel is SELECTED for (mean below 256: four and eight lanes per row), entry counts that
+    # are no multiple of 8 (the last 16-byte piece of the arrays reaches into their slack)
+    out["rows-of-100"] = (rng.integers(48, 160, 1501), 9000, None)
+    out["rows-of-180"] = (rng.integers(130, 250, 971), 971, None)
     return out
 
 
@@ -84,6 +88,10 @@ def test_estream_matches_oracle_and_row_kernel(gpu, name):
     try:
         for es in (2, 0):   # 2: the entry stream wherever its tables exist, 0: the row kernel
             L.fasp_hip_tune(b"estream", es)
+            # (poison what freed device memory holds: an uninitialised slack behind the operator's arrays must not matter)
+            junk = np.full(1 << 20, -0.5)
+            L.fasp_blas_darray_ax.argtypes = [C.c_int, C.c_double, T.c_double_p]
+            L.fasp_blas_darray_ax(len(junk), 2.0, T.dp(junk))
             y = np.full(n, 7.0)
             L.fasp_blas_dcsr_mxv(C.byref(A), T.dp(x), T.dp(y))
             assert np.all(y[lens == 0] == 0.0)
@@ -103,7 +111,7 @@ def test_estream_matches_oracle_and_row_kernel(gpu, name):
     assert np.all(np.abs(got[0] - got[2]) <= 2e-13 * np.maximum(rowabs, 1e-300) + 1e-300)
 
 
-@pytest.mark.parametrize("name", ["long-rows", "rows-across-waves", "relative-columns"])
+@pytest.mark.parametrize("name", ["long-rows", "rows-across-waves", "relative-columns", "rows-of-100", "rows-of-180"])
 def test_estream_jacobi_sweeps(gpu, name):
     """Weighted Jacobi (the diagonal entry is left out of the row sum by comparing columns: the device copy is sorted by column) on a
     square, diagonally dominant variant of the operator."""
