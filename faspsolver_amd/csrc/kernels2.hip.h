@@ -97,15 +97,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_lstream(CsrArgs a)
             return;
         }
     };
-    // Round 6: every load of the look-ahead is a buffer load issued UNCONDITIONALLY, its range cut to what exists (an empty range: nothing
-    // is fetched, the lanes read 0).  Under an `if` -- as rounds 2-5 had them -- the compiler's wait-count pass takes the worse of both
-    // paths at the join: it drained the gathers BEFORE the stream loads were issued and the stream before the sums (ISA: s_waitcnt
-    // vmcnt(0) on both sides), i.e. the pipeline described above was serialised (profiles/r06_estream.txt, section 2).
     auto load_ia = [&](int r0, int nr, int& kb, int& ke) {
-        // lanes < nr: the row's pointers; lane nr: (ia[r0 + nr], 0) -> a negative length; beyond: (0, 0)
-        const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(a.ia + max(r0, 0)), 0, r0 >= 0 ? (nr + 1) * 4 : 0, 0x00020000);
-        kb = __builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, 0, 0);
-        ke = __builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4 + 4, 0, 0);
+        kb = ke = 0;
+        if (r0 >= 0 && lane < nr) { kb = a.ia[r0 + lane]; ke = a.ia[r0 + lane + 1]; }
     };
     // span of a tile: [s0, k1), s0 = first entry rounded down to a multiple of 4 (16-byte aligned JA piece)
     auto span = [&](int r0, int nr, int kb, int ke, int& s0, int& k1) {
@@ -118,23 +112,26 @@ __global__ __launch_bounds__(BLOCK) void k_csr_lstream(CsrArgs a)
     i32x4_t qj[NJ];
     f64x2_t qv[NV];
     auto stage_load = [&](int s0, int k1) {
-        int n = k1 - s0;
-        if (n > CAP) n = 0;   // (an oversized tile is read from memory by its rows: nothing to stage)
-        const int n4 = (n + 3) & ~3;
-        const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(a.ja + s0), 0, n4 * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.val + s0), 0, n4 * 8, 0x00020000);
+        const int n = k1 - s0;
+        if (n > CAP) return;
+        const i32x4_t* pj = reinterpret_cast<const i32x4_t*>(a.ja + s0);
+        const f64x2_t* pv = reinterpret_cast<const f64x2_t*>(a.val + s0);
 #pragma unroll
         for (int q = 0; q < NJ; ++q)
-            qj[q] = __builtin_bit_cast(i32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rj, (lane + 64 * q) * 16, 0, 2));
+            if ((lane + 64 * q) * 4 < n) qj[q] = __builtin_nontemporal_load(pj + lane + 64 * q);
 #pragma unroll
         for (int q = 0; q < NV; ++q)
-            qv[q] = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(rv, (lane + 64 * q) * 16, 0, 2));
+            if ((lane + 64 * q) * 2 < n) qv[q] = __builtin_nontemporal_load(pv + lane + 64 * q);
     };
-    auto stage_store = [&]() {   // (the whole slab every time: zeros beyond the tile's span)
+    auto stage_store = [&](int s0, int k1) {
+        const int n = k1 - s0;
+        if (n > CAP) return;
 #pragma unroll
-        for (int q = 0; q < NJ; ++q) reinterpret_cast<i32x4_t*>(sj)[lane + 64 * q] = qj[q];
+        for (int q = 0; q < NJ; ++q)
+            if ((lane + 64 * q) * 4 < n) reinterpret_cast<i32x4_t*>(sj)[lane + 64 * q] = qj[q];
 #pragma unroll
-        for (int q = 0; q < NV; ++q) reinterpret_cast<f64x2_t*>(sv)[lane + 64 * q] = qv[q];
+        for (int q = 0; q < NV; ++q)
+            if ((lane + 64 * q) * 2 < n) reinterpret_cast<f64x2_t*>(sv)[lane + 64 * q] = qv[q];
     };
 
     int v = blockIdx.x;
@@ -145,8 +142,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_lstream(CsrArgs a)
     advance(v, r0B, nrB);
     load_ia(r0B, nrB, kbB, keB);
     span(r0A, nrA, kbA, keA, s0A, k1A);
-    stage_load(s0A, k1A);
-    stage_store();
+    if (r0A >= 0) { stage_load(s0A, k1A); stage_store(s0A, k1A); }
     wave_order();
 
     while (r0A >= 0) {
@@ -154,16 +150,8 @@ __global__ __launch_bounds__(BLOCK) void k_csr_lstream(CsrArgs a)
         const int  r = r0A + lane;
         const int  len = keA - kbA;            // 0 for lanes beyond the tile
         const int  o = kbA - s0A;
-        // The operands of the epilogue (b_i, a_ii, x_i / the old y_i / the dotted entry) are loaded HERE, in front of the gathers: the
-        // vector-memory counter retires in order, so a load behind the look-ahead's stream loads could only be waited for together with them
-        const int rr = min(r, a.nrow - 1);   // (lanes beyond the tile: a clamped row, never stored)
-        double eb = 0.0, ed = 0.0, ex = 0.0, ez = 0.0;
-        if (OP == OP_RESID || OP == OP_JACOBI || OP == OP_L1DIAG) eb = a.b[rr];
-        if (OP == OP_JACOBI || OP == OP_L1DIAG) { ed = a.diag[rr]; ex = a.x[rr]; }
-        if (OP == OP_ADD || OP == OP_SUB || OP == OP_AXPY) ex = a.y[rr];
-        if (OP == OP_MXV_DOT) ex = a.dotv[rr];
-        if (OP == OP_MXV && a.zx) ez = a.zdiag[rr];
-        double acc = (OP == OP_JACOBI || OP == OP_L1DIAG) ? eb : 0.0;
+        double acc = 0.0;
+        if ((OP == OP_JACOBI || OP == OP_L1DIAG) && lane < nrA) acc = a.b[r];
 
         // first round of gathers (rows of up to 8 entries need no second one); branch-free: lanes past
         // the end of their row read slab entry 0 and gather x[0], their products are dropped by a select
@@ -176,12 +164,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_lstream(CsrArgs a)
                 c[u] = (u < len) ? cc : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];   // (lanes past their row: x[0], dropped below; no wave-uniform skip: straight-line code)
+            for (int u = 0; u < 8; ++u) xv[u] = __any(u < len) ? a.x[c[u]] : 0.0;  // wave-uniform skip
         }
 
-        // look ahead: JA / val of B, row pointers of C -- right behind the gathers, nothing in between waits
+        // look ahead: JA / val of B, row pointers of C
         span(r0B, nrB, kbB, keB, s0B, k1B);
-        stage_load(s0B, k1B);
+        if (r0B >= 0) stage_load(s0B, k1B);
         int r0C, nrC, kbC, keC;
         advance(v, r0C, nrC);
         load_ia(r0C, nrC, kbC, keC);
@@ -222,24 +210,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_lstream(CsrArgs a)
                 else acc += pr;
             }
         }
-        if (lane < nrA) {   // row_epilogue's expressions on the operands loaded above
-            if (OP == OP_MXV) {
-                if (a.nt & 2) __builtin_nontemporal_store(acc, a.y + r); else a.y[r] = acc;
-                if (a.zx) a.zx[r] = (fabs(ez) > 1e-20) ? (1 - a.zomega) * 0.0 + a.zomega * acc / ez : 0.0;   // zx_store
-            } else if (OP == OP_RESID) a.y[r] = eb - acc;
-            else if (OP == OP_ADD) a.y[r] = ex + acc;
-            else if (OP == OP_SUB) a.y[r] = ex - acc;
-            else if (OP == OP_AXPY) a.y[r] = ex + acc * a.alpha;
-            else if (OP == OP_JACOBI) {
-                const double xn = (fabs(ed) > 1e-20) ? (1 - a.omega) * ex + a.omega * acc / ed : ex;
-                a.y[r] = xn;
-                if (a.partials) dotacc += xn * eb;   // last sweep of level 0 under PCG: (z, r) on the way out
-            } else if (OP == OP_L1DIAG) a.y[r] = l1_or_jacobi_f(a, r, acc, ed, ex);
-            else if (OP == OP_MXV_DOT) { a.y[r] = acc; dotacc += acc * ex; }
-        }
+        if (lane < nrA) row_epilogue<OP>(a, r, acc, dotacc);
 
         wave_order();
-        stage_store();
+        if (r0B >= 0) stage_store(s0B, k1B);
         wave_order();
         r0A = r0B; nrA = nrB; kbA = kbB; keA = keB; s0A = s0B; k1A = k1B;
         r0B = r0C; nrB = nrC; kbB = kbC; keB = keC;
@@ -285,12 +259,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
             return;
         }
     };
-    // (round 6: every load of the look-ahead and of the epilogue's operands is issued unconditionally, in front of or right behind the
-    // gathers -- see k_csr_lstream)
     auto load_ia = [&](int r0, int nr, int& kb, int& ke) {
-        const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(a.ia + max(r0, 0)), 0, r0 >= 0 ? (nr + 1) * 4 : 0, 0x00020000);
-        kb = __builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, 0, 0);
-        ke = __builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4 + 4, 0, 0);
+        kb = ke = 0;
+        if (r0 >= 0 && lane < nr) { kb = a.ia[r0 + lane]; ke = a.ia[r0 + lane + 1]; }
     };
     i32x4_t qj[NJ];
     f64x2_t qv[NV];
@@ -332,16 +303,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
     }
     wave_order();
     while (r0A >= 0) {
-        const int r = r0A + lane, rr = min(r, a.nrow - 1);
-        double eb = 0.0, ed = 0.0, ex = 0.0, ez = 0.0;   // the epilogue's operands, loaded before anything of this tile is waited for
-        if (OP == OP_RESID || OP == OP_JACOBI || OP == OP_L1DIAG) eb = a.b[rr];
-        if (OP == OP_JACOBI || OP == OP_L1DIAG) { ed = a.diag[rr]; ex = a.x[rr]; }
-        if (OP == OP_ADD || OP == OP_SUB || OP == OP_AXPY) ex = a.y[rr];
-        if (OP == OP_MXV_DOT) ex = a.dotv[rr];
-        if (OP == OP_MXV && a.zx) ez = a.zdiag[rr];
-        double acc = (OP == OP_JACOBI || OP == OP_L1DIAG) ? eb : 0.0;
-        int dk = -1;
-        if (OP == OP_JACOBI) { dk = a.dpos[rr]; if (lane >= nrA) dk = -1; }
+        const int r = r0A + lane;
+        double acc = ((OP == OP_JACOBI || OP == OP_L1DIAG) && lane < nrA) ? a.b[r] : 0.0;
+        const int dk = (OP == OP_JACOBI && lane < nrA) ? a.dpos[r] : -1;
         for (;;) {   // chunks of tile A; the slab holds [lo & ~3, hi)
             const int s = lo & ~3;
             // phase 1: lane = entry -- columns and values from the slab, x gathered, products back in place
@@ -367,9 +331,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
                 if (r0B >= 0) { nk0 = __builtin_amdgcn_readlane(kbB, 0); nk1 = __builtin_amdgcn_readlane(keB, nrB - 1); }
                 nlo = nk0; nhi = min(nlo + STEP, nk1);
                 advance(v, r0C, nrC);
+                load_ia(r0C, nrC, kbC, keC);
             }
-            stage_load(nlo & ~3, nhi);                       // (no next chunk: nlo = nhi = 0, an empty range)
-            load_ia(last ? r0C : -1, nrC, kbC, keC);          // (not the tile's last chunk: an empty range, the values are not used)
+            if (!last || r0B >= 0) stage_load(nlo & ~3, nhi);
 #pragma unroll
             for (int u = 0; u < 8; ++u) sv[lane + 64 * u] = w[u] * xv[u];   // (beyond the chunk: 0.0 * x[0], never summed)
             wave_order();
@@ -392,22 +356,8 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wstream2(CsrArgs a)
             }
             wave_order();
             if (last) {
-                if (lane < nrA) {   // row_epilogue's expressions on the operands loaded at the tile's start
-                    if (OP == OP_MXV) {
-                        if (a.nt & 2) __builtin_nontemporal_store(acc, a.y + r); else a.y[r] = acc;
-                        if (a.zx) a.zx[r] = (fabs(ez) > 1e-20) ? (1 - a.zomega) * 0.0 + a.zomega * acc / ez : 0.0;   // zx_store
-                    } else if (OP == OP_RESID) a.y[r] = eb - acc;
-                    else if (OP == OP_ADD) a.y[r] = ex + acc;
-                    else if (OP == OP_SUB) a.y[r] = ex - acc;
-                    else if (OP == OP_AXPY) a.y[r] = ex + acc * a.alpha;
-                    else if (OP == OP_JACOBI) {
-                        const double xn = (fabs(ed) > 1e-20) ? (1 - a.omega) * ex + a.omega * acc / ed : ex;
-                        a.y[r] = xn;
-                        if (a.partials) dotacc += xn * eb;
-                    } else if (OP == OP_L1DIAG) a.y[r] = l1_or_jacobi_f(a, r, acc, ed, ex);
-                    else if (OP == OP_MXV_DOT) { a.y[r] = acc; dotacc += acc * ex; }
-                }
-                stage_store();
+                if (lane < nrA) row_epilogue<OP>(a, r, acc, dotacc);
+                if (r0B >= 0) stage_store();
                 wave_order();
                 r0A = r0B; nrA = nrB; kbA = kbB; keA = keB;
                 r0B = r0C; nrB = nrC; kbB = kbC; keB = keC;
