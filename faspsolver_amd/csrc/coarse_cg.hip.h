@@ -135,7 +135,29 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         int LD = m; while (LD % 32 != 1) ++LD;     // row stride in doubles: conflict-free lane = row reads
         const size_t lds_w = sizeof(double) * (128 * (size_t)LD + 128);
         const bool one_wave = g_tune.small_onewave && m <= 128 && lds_w <= 148 * 1024;
-        if (one_wave && g_tune.small_onewave >= 2) {   // the matrix in registers (four wavefronts); small_onewave 1: dense in LDS, one wavefront
+        if (one_wave && g_tune.small_onewave >= 3) {   // the matrix in registers as 16 x 16 blocks, p broadcast inside the multiply-adds (k_spcg_dpp)
+            const int NBK = m <= 64 ? 4 : m <= 96 ? 6 : 8, DUP = NBK == 4 ? 4 : 2, RB = NBK / DUP;
+            if (!h->reg_img || h->reg_mc != -NBK) {   // the register image, once per hierarchy: group g = tid / 16 carries column block g % NBK and row blocks (g / NBK) RB ..
+                const HostCSR& Ah = h->H.L.back().A;
+                const int NT = 16 * NBK * DUP;   // threads of k_spcg_dpp
+                std::vector<double> img((size_t)RB * 16 * NT, 0.0);
+                for (int row = 0; row < m; ++row)
+                    for (int k = Ah.ia[row]; k < Ah.ia[row + 1]; ++k) {
+                        const int c = Ah.ja[k], cb = c >> 4, j = c & 15, rb = row >> 4, l = row & 15;
+                        const int half = rb / RB, kk = rb % RB, g = half * NBK + cb;
+                        img[(size_t)(kk * 16 + j) * NT + 16 * g + l] += Ah.val[k];
+                    }
+                if (h->reg_img) (void)hipFree(h->reg_img);
+                HIPCK(hipMalloc((void**)&h->reg_img, sizeof(double) * img.size()));
+                HIPCK(hipMemcpy(h->reg_img, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+                h->reg_mc = -NBK;   // (negative: k_spcg_dpp's layout)
+            }
+            a.img = h->reg_img;
+            if (NBK == 4) hipLaunchKernelGGL((k_spcg_dpp<4, 4>), dim3(1), dim3(256), 0, g_ctx.stream, a, LD);
+            else if (NBK == 6) hipLaunchKernelGGL((k_spcg_dpp<6, 2>), dim3(1), dim3(192), 0, g_ctx.stream, a, LD);
+            else hipLaunchKernelGGL((k_spcg_dpp<8, 2>), dim3(1), dim3(256), 0, g_ctx.stream, a, LD);
+        }
+        else if (one_wave && g_tune.small_onewave >= 2) {   // the matrix in registers (four wavefronts); small_onewave 1: dense in LDS, one wavefront
             const int MC = m <= 64 ? 32 : m <= 96 ? 48 : 64;
             if (!h->reg_img || h->reg_mc != MC) {   // the register image, once per hierarchy: thread t = (row t / 2, half t % 2), entry k = column 4 (k / 2) + 2 (t % 2) + k % 2
                 const HostCSR& Ah = h->H.L.back().A;

@@ -585,6 +585,9 @@ FINISHED:
 // order) -- O(1e-16) apart, like every reduction here.  Same exit and restart logic as k_spcg_small, line for line.
 // ---------------------------------------------------------------------------
 constexpr int SPCG_REG_NT = 256;
+#ifndef SPCG_REG_G
+#define SPCG_REG_G 12   // 16-byte reads of p in flight per thread (k_spcg_reg's product)
+#endif
 __device__ __forceinline__ double pair_swap(double x)   // the value of the other lane of the pair (2 i, 2 i + 1)
 {
     const long long b = __double_as_longlong(x);
@@ -594,7 +597,7 @@ __device__ __forceinline__ double pair_swap(double x)   // the value of the othe
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 #ifdef SR_TIMING
-#define SRT(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); srt[k] += now_ - srt_last; srt_last = now_; } while (0)
+#define SRT(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); srt[k] += now_ - srt_last; srt_last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SRT(k)
 #endif
@@ -646,11 +649,32 @@ __global__ __launch_bounds__(SPCG_REG_NT) void k_spcg_reg(SpcgArgs a, int LD)
         if (mine) pb[row] = x;
         __syncthreads();
         double s[4] = {0.0, 0.0, 0.0, 0.0};
+        // two columns per 16-byte read (even lanes one address, odd lanes the next: a two-address broadcast).  The reads go out in
+        // groups of SPCG_REG_G, the next group before the multiply-adds of the current one: left to itself the scheduler keeps two
+        // reads in flight (register pressure is what it minimises) and the product pays the LDS latency MC / 4 times over
+        constexpr int NRD = MC / 2, G0 = MC > 48 ? 8 : SPCG_REG_G /* (128 register pairs of matrix: shorter groups) */, G = NRD < G0 ? NRD : G0, NG = (NRD + G - 1) / G;
+        f64x2_t qa[G], qb[G];
 #pragma unroll
-        for (int k = 0; k < MC; k += 2) {   // two columns per 16-byte read (even lanes one address, odd lanes the next: a two-address broadcast)
-            const f64x2_t q = pmine[k];     // columns 2 k + 2 h, 2 k + 2 h + 1
-            s[k & 3] += Ar[k] * q[0];
-            s[(k + 1) & 3] += Ar[k + 1] * q[1];
+        for (int j = 0; j < G; ++j) qa[j] = pmine[2 * j];     // columns 4 j + 2 h, 4 j + 2 h + 1
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f64x2_t (&cur)[G] = (g & 1) ? qb : qa;
+            f64x2_t (&nxt)[G] = (g & 1) ? qa : qb;
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+                    if ((g + 1) * G + j < NRD) nxt[j] = pmine[2 * ((g + 1) * G + j)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int k = 2 * (g * G + j);
+                if (k < MC) {
+                    s[k & 3] += Ar[k] * cur[j][0];
+                    s[(k + 1) & 3] += Ar[k + 1] * cur[j][1];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const double sh_ = (s[0] + s[1]) + (s[2] + s[3]);
         const double so = pair_swap(sh_);
@@ -766,6 +790,274 @@ FINISHED:
 #endif
     if (mine) a.u[row] = u;
     if (tid == 0) {
+        spcg_report(a, iter, MaxIt, relres, absres);
+    }
+    (void)absres0;
+}
+
+// ---------------------------------------------------------------------------
+// k_spcg_dpp<NBK, DUP>: the same safe CG for coarsest levels of at most 16 NBK <= 128 rows, the matrix in registers as in
+// k_spcg_reg, with the BROADCAST of the direction inside the multiply-add and the iteration itself in ONE wavefront.
+// k_spcg_reg's product reads p from LDS as 16-byte broadcasts: 24 reads per wavefront and product at 89 rows, and a broadcast read
+// returns 1 KB to the register file like any other -- four wavefronts' reads queue behind one another on the one LDS pipeline for
+// 0.32 of the product's 0.43 us; and each of its three reductions per iteration crosses four wavefronts through LDS and a barrier
+// (stamps: profiles/r06_configs_3_5.txt).  gfx950's double-precision unit takes a data-parallel-primitive operand of its own:
+// v_fmac_f64_dpp ... row_newbcast:j multiplies by lane j's value of each row of 16 lanes (tools/micro/dppfma.hip: exact, 1.2 x the
+// time of a plain multiply-add).  So the matrix is cut into 16 x 16 blocks; a row of 16 lanes ("group") owns one COLUMN block cb and
+// multiplies RB = NBK / DUP row blocks of it by its lanes' 16 values of the vector -- no broadcast read at all.  What a product
+// leaves are partial row sums per column block, added in ascending column-block order.
+// Wavefront 0 carries the vectors (lane i: elements i and i + 64, k_spcg_wave's layout) and runs the reference's iteration with
+// reductions that never leave it (data-parallel-primitive moves + readlane); the other wavefronts only multiply: per product the
+// vector goes out through LDS (barrier A), everybody multiplies its blocks, the partials come back (barrier B).  Two barriers per
+// iteration and no cross-wavefront reduction, against k_spcg_reg's three barriers each with one.  Same exit and restart logic
+// as k_spcg_small.
+// ---------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ void dpp_fmac(double& acc, double x, double a)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(a), "n"(J));
+}
+// RB 16 x 16 blocks against the same 16 values of x: acc[k][j & 3] += a[16 k + j] * x(lane j of the row), j ascending, the blocks
+// interleaved (RB independent chains per j: no multiply-add waits for the previous one of its sum).  (The wait states a
+// data-parallel-primitive read needs behind a vector write of its operand or of EXEC are the compiler's to insert between ordinary
+// instructions; behind inline assembly it sees nothing, so they stand in front -- volatile statements keep their order.)
+template <int J, int RB>
+__device__ __forceinline__ void dpp_col(double (&acc)[RB][4], double x, const double* a)
+{
+#pragma unroll
+    for (int k = 0; k < RB; ++k) dpp_fmac<J>(acc[k][J & 3], x, a[16 * k + J]);
+}
+template <int RB>
+__device__ __forceinline__ void dpp_blocks16(double (&acc)[RB][4], double x, const double* a)
+{
+    asm volatile("s_nop 4");
+    dpp_col<0, RB>(acc, x, a);  dpp_col<1, RB>(acc, x, a);  dpp_col<2, RB>(acc, x, a);  dpp_col<3, RB>(acc, x, a);
+    dpp_col<4, RB>(acc, x, a);  dpp_col<5, RB>(acc, x, a);  dpp_col<6, RB>(acc, x, a);  dpp_col<7, RB>(acc, x, a);
+    dpp_col<8, RB>(acc, x, a);  dpp_col<9, RB>(acc, x, a);  dpp_col<10, RB>(acc, x, a); dpp_col<11, RB>(acc, x, a);
+    dpp_col<12, RB>(acc, x, a); dpp_col<13, RB>(acc, x, a); dpp_col<14, RB>(acc, x, a); dpp_col<15, RB>(acc, x, a);
+}
+// three sums over the wavefront at once, every lane ends with all three: the steps of the three interleaved (written one after the
+// other the compiler runs them one after the other, each step waiting for the previous one of its own sum)
+__device__ __forceinline__ void wave_allsum3(double& x, double& y, double& z)
+{
+#define FASP_SUM3_STEP(ctrl, mask) { const double tx = dpp_mov_f64(x, ctrl, mask), ty = dpp_mov_f64(y, ctrl, mask), tz = dpp_mov_f64(z, ctrl, mask); \
+                                     x += tx; y += ty; z += tz; __builtin_amdgcn_sched_barrier(0); }
+    __builtin_amdgcn_sched_barrier(0);
+    FASP_SUM3_STEP(0x111, 0xf) FASP_SUM3_STEP(0x112, 0xf) FASP_SUM3_STEP(0x114, 0xf) FASP_SUM3_STEP(0x118, 0xf)
+    FASP_SUM3_STEP(0x142, 0xa) FASP_SUM3_STEP(0x143, 0xc)
+#undef FASP_SUM3_STEP
+    x = wave_bcast63(x); y = wave_bcast63(y); z = wave_bcast63(z);
+}
+template <int NBK, int DUP>
+__global__ __launch_bounds__(16 * NBK * DUP) void k_spcg_dpp(SpcgArgs a, int LD)
+{
+#ifdef SR_TIMING
+    unsigned long long srt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, srt_last = __builtin_amdgcn_s_memrealtime();
+#endif
+    constexpr int RB = NBK / DUP, MP = 16 * NBK;   // row blocks per group, padded order
+    static_assert(RB * DUP == NBK && NBK * DUP <= 16 && (NBK * DUP) % 4 == 0 && NBK >= 4, "k_spcg_dpp: whole wavefronts of four groups, wavefront 0 = column blocks 0 .. 3");
+    __shared__ double part[NBK * MP];   // part[cb][row]: the row sums over column block cb
+    __shared__ double xbuf[MP];         // the vector of the coming product, from wavefront 0
+    __shared__ int    cmd;              // 1: a product follows, 0: the solve is over
+    const int m = a.A.m, tid = threadIdx.x;
+    const int g = tid >> 4, l = tid & 15, lane = tid & 63;
+    const int cb = g % NBK, half = g / NBK;
+    (void)LD;
+    double Ar[RB * 16];   // entry 16 k + j: A(16 (half RB + k) + l, 16 cb + j), from the image the host lays out once per hierarchy
+#pragma unroll
+    for (int k = 0; k < RB * 16; ++k) Ar[k] = a.img[(size_t)k * (16 * NBK * DUP) + tid];
+    double* const pw = part + cb * MP + 16 * (half * RB) + l;   // this lane's partials: row blocks half RB .. half RB + RB - 1
+    auto blocks = [&](double x) {   // x: element 16 cb + l of the vector
+        double acc[RB][4];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+        dpp_blocks16<RB>(acc, x, Ar);
+#pragma unroll
+        for (int k = 0; k < RB; ++k) pw[16 * k] = (acc[k][0] + acc[k][1]) + (acc[k][2] + acc[k][3]);
+    };
+    if (tid >= 64) {   // the wavefronts that only multiply
+        for (;;) {
+            __syncthreads();   // (A) the vector is out
+            if (cmd == 0) break;
+            blocks(xbuf[16 * cb + l]);
+            __syncthreads();   // (B) the partials are out
+        }
+        return;
+    }
+    // ---- wavefront 0: the iteration.  Lane i carries elements i and i + 64 (k_spcg_wave's layout); as a multiplying wavefront it is
+    // groups 0 .. 3 = column blocks 0 .. 3, whose elements are its lanes' first ones.
+    // The reference's loop (KrySPcg.c:160-330) asks for a product in five places: the initial residual, the iteration, the true
+    // residuals of Checks II and III, the residual of the best iterate.  Here they are ONE site that the control flow comes back to
+    // with `st` saying what the product is for: inlined five times the multiply-adds made 40 KB of code with the iteration jumping
+    // between its pieces, and a taken branch of this lone wavefront is an instruction fetch that nobody hides.
+    const int r0 = lane, r1 = lane + 64;
+    const bool h0 = r0 < m, h1 = r1 < m;
+    auto bcast = [&](double x, int from) -> double {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, from);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), from);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    auto sqrt3 = [&](double x0, double x1, double x2, double& y0, double& y1, double& y2) {   // (k_spcg_reg: three lanes side by side)
+        const double y = sqrt(lane == 0 ? x0 : lane == 1 ? x1 : x2);
+        y0 = bcast(y, 0); y1 = bcast(y, 1); y2 = bcast(y, 2);
+    };
+    auto div3 = [&](double n0, double d0, double n1, double d1, double n2, double d2, double& y0, double& y1, double& y2) {
+        const double y = (lane == 0 ? n0 : lane == 1 ? n1 : n2) / (lane == 0 ? d0 : lane == 1 ? d1 : d2);
+        y0 = bcast(y, 0); y1 = bcast(y, 1); y2 = bcast(y, 2);
+    };
+    enum { ST_INIT, ST_ITER, ST_CHK2, ST_CHK3, ST_BEST };
+    const double tol = a.tol, maxdiff = tol * 1e-4 /* STAG_RATIO */, sol_inf_tol = 1e-20;
+    const double BIG = 1e+20, SMALL = 1e-20, SMALL2 = 1e-40;
+    const int MaxIt = a.MaxIt, MAX_STAG = 20, MAX_RESTART = 20;
+    int iter = 0, stag = 1, more_step = 1, iter_best = 0, st = ST_INIT;
+    double absres0 = BIG, absres = BIG, relres = BIG, normu = 0.0, normr0 = BIG;
+    double reldiff = 0.0, alpha = 0.0, beta = 0.0, temp1 = 0.0, temp2, absres_best = BIG;
+    const double b0 = h0 ? a.b[r0] : 0.0, b1 = h1 ? a.b[r1] : 0.0;
+    double u0 = 0.0, u1 = 0.0, p0 = 0.0, p1 = 0.0, rr0 = b0, rr1 = b1, ub0 = 0.0, ub1 = 0.0;
+    double x0 = 0.0, x1 = 0.0, y0, y1, red0 = 0.0, q_rr = 0.0, q_uu, q_pp, q_mx, sq_pp, fac;
+    bool slow, leave = false, hot = false;
+    auto mxv = [&](double v0, double v1, double& w0, double& w1) {   // w = A v
+        xbuf[r0] = v0;
+        if (MP > 64) xbuf[r1 < MP ? r1 : r0] = r1 < MP ? v1 : v0;
+        if (lane == 0) cmd = 1;
+        __syncthreads();   // (A)
+        SRT(6);
+        blocks(v0);
+        SRT(7);
+        __syncthreads();   // (B)
+        SRT(8);
+        double q0[NBK], q1[NBK];
+#pragma unroll
+        for (int c = 0; c < NBK; ++c) { q0[c] = part[c * MP + r0]; q1[c] = part[c * MP + (r1 < MP ? r1 : r0)]; }   // (no second element: read the first again, dropped below)
+        w0 = q0[0]; w1 = q1[0];
+#pragma unroll
+        for (int c = 1; c < NBK; ++c) { w0 += q0[c]; w1 += q1[c]; }   // ascending column blocks
+        if (!(r1 < MP)) w1 = 0.0;
+    };
+    // the start of the iteration once the initial residual is in rr; true: converged at once (KrySPcg.c:140-150)
+    auto start = [&]() -> bool {
+        temp1 = wave_allsum(rr0 * rr0 + rr1 * rr1);
+        absres0 = sqrt(temp1);
+        normr0 = fmax(SMALL, absres0);
+        relres = absres0 / normr0;
+        p0 = rr0; p1 = rr1;
+        return relres < tol;
+    };
+    if (a.x_zero) {
+        if (start()) goto FINISHED;
+        hot = true;
+    } else {
+        u0 = h0 ? a.u[r0] : 0.0; u1 = h1 ? a.u[r1] : 0.0;
+        x0 = u0; x1 = u1; st = ST_INIT;
+    }
+    SRT(0);
+    // Outer loop: the products outside the iteration proper (initial residual, true residuals of Checks II and III, residual of the
+    // best iterate), each followed by the iteration loop below -- a loop of its own with one way round, so that what the compiler
+    // makes of an ordinary iteration is one straight piece of code.
+    for (;;) {
+        if (!hot) {
+            mxv(x0, x1, y0, y1);
+            if (st == ST_INIT) {
+                rr0 = b0 - y0; rr1 = b1 - y1;
+                if (start()) break;
+            } else if (st == ST_BEST) {
+                const double s0 = b0 - y0, s1 = b1 - y1;
+                absres_best = sqrt(wave_allsum(s0 * s0 + s1 * s1));
+                if (absres > absres_best + maxdiff || absres != absres) {
+                    u0 = ub0; u1 = ub1;
+                    relres = absres_best / normr0;
+                }
+                break;
+            } else {   // Checks II and III: r = b - A u
+                rr0 = b0 - y0; rr1 = b1 - y1;
+                red0 = wave_allsum(rr0 * rr0 + rr1 * rr1);
+                absres = sqrt(red0);
+                relres = absres / normr0;
+                leave = relres < tol;
+                if (!leave) {
+                    if (st == ST_CHK2) {
+                        if (stag >= MAX_STAG) { iter = -42; leave = true; }  // ERROR_SOLVER_STAG
+                        ++stag;
+                        // (Check III after Check II asks `relres < tol` of the residual just recomputed: it was not, a few lines up)
+                    } else {
+                        if (more_step >= MAX_RESTART) { iter = -44; leave = true; }  // ERROR_SOLVER_TOLSMALL
+                        ++more_step;
+                    }
+                }
+                if (!leave) {
+                    absres0 = absres;
+                    beta = red0 / temp1;   // (a check recomputed the residual: not the quotient the iteration formed)
+                    temp1 = red0;          // (z, r) with z = r
+                    p0 = 1.0 * rr0 + beta * 0.0; p1 = 1.0 * rr1 + beta * 0.0;  // fasp_blas_darray_axpby on the direction the check zeroed
+                }
+            }
+        }
+        hot = false;
+        // ---- the iteration (KrySPcg.c:160-330)
+        while (!leave) {
+            SRT(5);
+            if (__builtin_expect(!(iter++ < MaxIt), 0)) { leave = true; break; }
+            mxv(p0, p1, y0, y1);   // t = A p
+            SRT(1);
+            temp2 = wave_allsum(y0 * p0 + y1 * p1);
+            SRT(2);
+            if (__builtin_expect(!(fabs(temp2) > SMALL2), 0)) { leave = true; break; }
+            alpha = temp1 / temp2;
+            u0 = u0 + alpha * p0; u1 = u1 + alpha * p1;
+            rr0 = rr0 - alpha * y0; rr1 = rr1 - alpha * y1;
+            SRT(9);
+            q_rr = rr0 * rr0 + rr1 * rr1; q_uu = u0 * u0 + u1 * u1; q_pp = p0 * p0 + p1 * p1;
+            wave_allsum3(q_rr, q_uu, q_pp);
+            // (u has a NaN exactly when (u, u) is one; Check I's maximum is formed only when (u, u) does not settle it: k_spcg_reg)
+            q_mx = 1.0;
+            if (__builtin_expect(!(q_uu > 2.0 * m * 1e-40), 0)) q_mx = wave_allmax(fmax(fabs(u0), fabs(u1)));
+            SRT(3);
+            sqrt3(q_rr, q_uu, q_pp, absres, normu, sq_pp);
+            fac = fabs(alpha) * sq_pp;
+            div3(absres, normr0, fac, normu, q_rr, temp1, relres, reldiff, beta);   // relres, reldiff, and beta = rr / temp1 for the usual path
+            SRT(4);
+            red0 = q_rr;
+            if (__builtin_expect(q_uu != q_uu, 0)) {  // fasp_dvec_isnan(u), :185
+                absres = BIG;
+                leave = true; break;
+            }
+            {   // (selects, not a branch: most iterations of a converging solve improve on the best residual)
+                const bool better = absres < absres_best - maxdiff;
+                absres_best = better ? absres : absres_best;
+                iter_best = better ? iter : iter_best;
+                ub0 = better ? u0 : ub0; ub1 = better ? u1 : ub1;
+            }
+            // Checks I, II, III behind ONE test: none of them fires in an ordinary iteration
+            slow = (q_mx <= sol_inf_tol) | ((stag <= MAX_STAG) & (reldiff < maxdiff)) | (relres < tol);
+            if (__builtin_expect(slow, 0)) {
+                if (q_mx <= sol_inf_tol) {  // Check I
+                    iter = -43;             // ERROR_SOLVER_SOLSTAG
+                    leave = true; break;
+                }
+                x0 = u0; x1 = u1;           // the true residual: Check II if it asks for one, else Check III
+                st = ((stag <= MAX_STAG) & (reldiff < maxdiff)) ? ST_CHK2 : ST_CHK3;
+                break;
+            }
+            absres0 = absres;
+            temp1 = red0;  // (z, r) with z = r
+            p0 = 1.0 * rr0 + beta * p0; p1 = 1.0 * rr1 + beta * p1;  // fasp_blas_darray_axpby
+        }
+        if (leave) {   // the residual of the best iterate is one more product, unless the last iterate is the best one
+            if (iter == iter_best) break;
+            leave = false;
+            x0 = ub0; x1 = ub1; st = ST_BEST;
+        }
+    }
+FINISHED:
+    if (lane == 0) cmd = 0;
+    __syncthreads();   // (A) with nothing behind it: the multiplying wavefronts leave
+#ifdef SR_TIMING
+    if (tid == 0 && iter > 50) printf("[spcg_dpp] iters %d: setup %.2f us | per iteration: vector out + barrier A %.3f blocks %.3f barrier B %.3f partials in %.3f dot %.3f alpha + update %.3f reduce3 %.3f sqrt/div %.3f rest %.3f loop top %.3f us\n", iter, srt[0] * 0.01, srt[6] * 0.01 / iter, srt[7] * 0.01 / iter, srt[8] * 0.01 / iter, srt[1] * 0.01 / iter, srt[2] * 0.01 / iter, srt[9] * 0.01 / iter, srt[3] * 0.01 / iter, srt[4] * 0.01 / iter, srt[5] * 0.01 / iter, 0.0);
+#endif
+    if (h0) a.u[r0] = u0;
+    if (h1) a.u[r1] = u1;
+    if (lane == 0) {
         spcg_report(a, iter, MaxIt, relres, absres);
     }
     (void)absres0;
