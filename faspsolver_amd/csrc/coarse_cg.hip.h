@@ -153,9 +153,13 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
                 h->reg_mc = -NBK;   // (negative: k_spcg_dpp's layout)
             }
             a.img = h->reg_img;
-            if (NBK == 4) hipLaunchKernelGGL((k_spcg_dpp<4, 4>), dim3(1), dim3(256), 0, g_ctx.stream, a, LD);
-            else if (NBK == 6) hipLaunchKernelGGL((k_spcg_dpp<6, 2>), dim3(1), dim3(192), 0, g_ctx.stream, a, LD);
-            else hipLaunchKernelGGL((k_spcg_dpp<8, 2>), dim3(1), dim3(256), 0, g_ctx.stream, a, LD);
+            const bool ahead = g_tune.small_onewave >= 4;   // the direction goes out before the tests of the iteration (a wavefront more: the first one multiplies nothing)
+            if (NBK == 4 && ahead) hipLaunchKernelGGL((k_spcg_dpp<4, 4, true>), dim3(1), dim3(320), 0, g_ctx.stream, a, LD);
+            else if (NBK == 4) hipLaunchKernelGGL((k_spcg_dpp<4, 4, false>), dim3(1), dim3(256), 0, g_ctx.stream, a, LD);
+            else if (NBK == 6 && ahead) hipLaunchKernelGGL((k_spcg_dpp<6, 2, true>), dim3(1), dim3(256), 0, g_ctx.stream, a, LD);
+            else if (NBK == 6) hipLaunchKernelGGL((k_spcg_dpp<6, 2, false>), dim3(1), dim3(192), 0, g_ctx.stream, a, LD);
+            else if (ahead) hipLaunchKernelGGL((k_spcg_dpp<8, 2, true>), dim3(1), dim3(320), 0, g_ctx.stream, a, LD);
+            else hipLaunchKernelGGL((k_spcg_dpp<8, 2, false>), dim3(1), dim3(256), 0, g_ctx.stream, a, LD);
         }
         else if (one_wave && g_tune.small_onewave >= 2) {   // the matrix in registers (four wavefronts); small_onewave 1: dense in LDS, one wavefront
             const int MC = m <= 64 ? 32 : m <= 96 ? 48 : 64;

@@ -848,24 +848,34 @@ __device__ __forceinline__ void wave_allsum3(double& x, double& y, double& z)
 #undef FASP_SUM3_STEP
     x = wave_bcast63(x); y = wave_bcast63(y); z = wave_bcast63(z);
 }
-template <int NBK, int DUP>
-__global__ __launch_bounds__(16 * NBK * DUP) void k_spcg_dpp(SpcgArgs a, int LD)
+__device__ __forceinline__ void wave_allsum2(double& x, double& y)
+{
+#define FASP_SUM2_STEP(ctrl, mask) { const double tx = dpp_mov_f64(x, ctrl, mask), ty = dpp_mov_f64(y, ctrl, mask); x += tx; y += ty; __builtin_amdgcn_sched_barrier(0); }
+    __builtin_amdgcn_sched_barrier(0);
+    FASP_SUM2_STEP(0x111, 0xf) FASP_SUM2_STEP(0x112, 0xf) FASP_SUM2_STEP(0x114, 0xf) FASP_SUM2_STEP(0x118, 0xf)
+    FASP_SUM2_STEP(0x142, 0xa) FASP_SUM2_STEP(0x143, 0xc)
+#undef FASP_SUM2_STEP
+    x = wave_bcast63(x); y = wave_bcast63(y);
+}
+template <int NBK, int DUP, bool AHEAD>
+__global__ __launch_bounds__(16 * NBK * DUP + (AHEAD ? 64 : 0)) void k_spcg_dpp(SpcgArgs a, int LD)
 {
 #ifdef SR_TIMING
     unsigned long long srt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, srt_last = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int RB = NBK / DUP, MP = 16 * NBK;   // row blocks per group, padded order
-    static_assert(RB * DUP == NBK && NBK * DUP <= 16 && (NBK * DUP) % 4 == 0 && NBK >= 4, "k_spcg_dpp: whole wavefronts of four groups, wavefront 0 = column blocks 0 .. 3");
+    static_assert(RB * DUP == NBK && NBK * DUP <= 16 && (NBK * DUP) % 4 == 0 && NBK >= 4, "k_spcg_dpp: whole wavefronts of four groups, the first of them = column blocks 0 .. 3");
     __shared__ double part[NBK * MP];   // part[cb][row]: the row sums over column block cb
     __shared__ double xbuf[MP];         // the vector of the coming product, from wavefront 0
     __shared__ int    cmd;              // 1: a product follows, 0: the solve is over
-    const int m = a.A.m, tid = threadIdx.x;
-    const int g = tid >> 4, l = tid & 15, lane = tid & 63;
+    const int m = a.A.m, tid = threadIdx.x, lane = tid & 63;
+    const int ts = AHEAD ? (tid >= 64 ? tid - 64 : 0) : tid;   // AHEAD: wavefront 0 multiplies nothing, the groups start behind it
+    const int g = ts >> 4, l = ts & 15;
     const int cb = g % NBK, half = g / NBK;
     (void)LD;
     double Ar[RB * 16];   // entry 16 k + j: A(16 (half RB + k) + l, 16 cb + j), from the image the host lays out once per hierarchy
 #pragma unroll
-    for (int k = 0; k < RB * 16; ++k) Ar[k] = a.img[(size_t)k * (16 * NBK * DUP) + tid];
+    for (int k = 0; k < RB * 16; ++k) Ar[k] = a.img[(size_t)k * (16 * NBK * DUP) + ts];
     double* const pw = part + cb * MP + 16 * (half * RB) + l;   // this lane's partials: row blocks half RB .. half RB + RB - 1
     auto blocks = [&](double x) {   // x: element 16 cb + l of the vector
         double acc[RB][4];
@@ -875,7 +885,7 @@ __global__ __launch_bounds__(16 * NBK * DUP) void k_spcg_dpp(SpcgArgs a, int LD)
 #pragma unroll
         for (int k = 0; k < RB; ++k) pw[16 * k] = (acc[k][0] + acc[k][1]) + (acc[k][2] + acc[k][3]);
     };
-    if (tid >= 64) {   // the wavefronts that only multiply
+    if (tid >= 64) {   // the wavefronts that only multiply (AHEAD: all that multiply)
         for (;;) {
             __syncthreads();   // (A) the vector is out
             if (cmd == 0) break;
@@ -917,14 +927,16 @@ __global__ __launch_bounds__(16 * NBK * DUP) void k_spcg_dpp(SpcgArgs a, int LD)
     double u0 = 0.0, u1 = 0.0, p0 = 0.0, p1 = 0.0, rr0 = b0, rr1 = b1, ub0 = 0.0, ub1 = 0.0;
     double x0 = 0.0, x1 = 0.0, y0, y1, red0 = 0.0, q_rr = 0.0, q_uu, q_pp, q_mx, sq_pp, fac;
     bool slow, leave = false, hot = false;
-    auto mxv = [&](double v0, double v1, double& w0, double& w1) {   // w = A v
+    auto send = [&](double v0, double v1) {   // the vector of a product goes out
         xbuf[r0] = v0;
         if (MP > 64) xbuf[r1 < MP ? r1 : r0] = r1 < MP ? v1 : v0;
         if (lane == 0) cmd = 1;
         __syncthreads();   // (A)
         SRT(6);
-        blocks(v0);
+        if (!AHEAD) blocks(v0);
         SRT(7);
+    };
+    auto receive = [&](double& w0, double& w1) {   // its row sums come back
         __syncthreads();   // (B)
         SRT(8);
         double q0[NBK], q1[NBK];
@@ -935,6 +947,7 @@ __global__ __launch_bounds__(16 * NBK * DUP) void k_spcg_dpp(SpcgArgs a, int LD)
         for (int c = 1; c < NBK; ++c) { w0 += q0[c]; w1 += q1[c]; }   // ascending column blocks
         if (!(r1 < MP)) w1 = 0.0;
     };
+    auto mxv = [&](double v0, double v1, double& w0, double& w1) { send(v0, v1); receive(w0, w1); };   // w = A v
     // the start of the iteration once the initial residual is in rr; true: converged at once (KrySPcg.c:140-150)
     auto start = [&]() -> bool {
         temp1 = wave_allsum(rr0 * rr0 + rr1 * rr1);
@@ -995,6 +1008,72 @@ __global__ __launch_bounds__(16 * NBK * DUP) void k_spcg_dpp(SpcgArgs a, int LD)
         }
         hot = false;
         // ---- the iteration (KrySPcg.c:160-330)
+        if constexpr (AHEAD) {
+            // What the NEXT direction needs of an iteration is (t, p), alpha, the new residual, its square and beta; everything else
+            // -- (u, u) and (p, p), the three square roots, relres and reldiff, the NaN test, the best iterate, Checks I-III --
+            // decides only whether there IS a next iteration.  So the direction goes out first, and that rest is worked through while
+            // the other wavefronts multiply; in the rare iteration in which a test fires the product sent ahead is dropped (it has no
+            // side effect) and the iteration count and (z, r) step back to where the reference's loop stands at that test.
+            bool pend = false;
+            double uu_l = 0.0, pp_l = 0.0, temp1_old = temp1;
+            while (!leave) {
+                SRT(5);
+                const bool more = iter++ < MaxIt;
+                if (__builtin_expect(more, 1)) send(p0, p1);   // t = A p under way
+                if (pend) {   // the tests of iteration iter - 1
+                    pend = false;
+                    q_uu = uu_l; q_pp = pp_l;
+                    wave_allsum2(q_uu, q_pp);
+                    q_mx = 1.0;
+                    if (__builtin_expect(!(q_uu > 2.0 * m * 1e-40), 0)) q_mx = wave_allmax(fmax(fabs(u0), fabs(u1)));
+                    SRT(3);
+                    sqrt3(q_rr, q_uu, q_pp, absres, normu, sq_pp);
+                    fac = fabs(alpha) * sq_pp;
+                    div3(absres, normr0, fac, normu, 1.0, 1.0, relres, reldiff, y0);
+                    SRT(4);
+                    red0 = q_rr;
+                    const bool isnan = q_uu != q_uu;   // fasp_dvec_isnan(u), :185 (leaves before the best iterate is touched)
+                    {
+                        const bool better = !isnan & (absres < absres_best - maxdiff);
+                        absres_best = better ? absres : absres_best;
+                        iter_best = better ? iter - 1 : iter_best;
+                        ub0 = better ? u0 : ub0; ub1 = better ? u1 : ub1;
+                    }
+                    slow = isnan | (q_mx <= sol_inf_tol) | ((stag <= MAX_STAG) & (reldiff < maxdiff)) | (relres < tol);
+                    if (__builtin_expect(slow, 0)) {
+                        if (more) __syncthreads();   // (B) of the product sent ahead: dropped
+                        iter -= 1;
+                        temp1 = temp1_old;
+                        if (isnan) { absres = BIG; leave = true; break; }
+                        if (q_mx <= sol_inf_tol) {  // Check I
+                            iter = -43;             // ERROR_SOLVER_SOLSTAG
+                            leave = true; break;
+                        }
+                        x0 = u0; x1 = u1;           // the true residual: Check II if it asks for one, else Check III
+                        st = ((stag <= MAX_STAG) & (reldiff < maxdiff)) ? ST_CHK2 : ST_CHK3;
+                        break;
+                    }
+                    absres0 = absres;
+                }
+                if (__builtin_expect(!more, 0)) { leave = true; break; }
+                receive(y0, y1);
+                SRT(1);
+                temp2 = wave_allsum(y0 * p0 + y1 * p1);
+                SRT(2);
+                if (__builtin_expect(!(fabs(temp2) > SMALL2), 0)) { leave = true; break; }
+                alpha = temp1 / temp2;
+                u0 = u0 + alpha * p0; u1 = u1 + alpha * p1;
+                rr0 = rr0 - alpha * y0; rr1 = rr1 - alpha * y1;
+                uu_l = u0 * u0 + u1 * u1; pp_l = p0 * p0 + p1 * p1;
+                SRT(9);
+                q_rr = wave_allsum(rr0 * rr0 + rr1 * rr1);
+                beta = q_rr / temp1;
+                temp1_old = temp1;
+                temp1 = q_rr;  // (z, r) with z = r
+                p0 = 1.0 * rr0 + beta * p0; p1 = 1.0 * rr1 + beta * p1;  // fasp_blas_darray_axpby
+                pend = true;
+            }
+        } else
         while (!leave) {
             SRT(5);
             if (__builtin_expect(!(iter++ < MaxIt), 0)) { leave = true; break; }
@@ -1451,17 +1530,39 @@ __device__ __forceinline__ double gm_mgs_wave(int n, int i, int lane, const doub
     double wv[NE];
 #pragma unroll
     for (int k = 0; k < NE; ++k) wv[k] = (lane + 64 * k < n) ? pi[lane + 64 * k] : 0.0;
-    for (int j = 0; j < i; ++j) {
+    // basis vector j + 1 is read while the dot product with vector j is summed over the wavefront (the coefficient of one vector is
+    // needed before the next dot product, the vector itself is not): two register sets, the read of the next one unconditional
+    // (past the last vector: the last one again) so that it stays in flight across the use of the current one
+    auto load = [&](double (&pv)[NE], int j) {
         const double* pj = basis + (size_t)j * n;
-        double pv[NE], hs[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < NE; ++k) pv[k] = (lane + 64 * k < n) ? pj[lane + 64 * k] : 0.0;
+    };
+    auto step = [&](const double (&pv)[NE], int j) {
+        double hs[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < NE; ++k) hs[k & 3] += pv[k] * wv[k];
         const double h = wave_allsum((hs[0] + hs[1]) + (hs[2] + hs[3]));
         if (lane == 0) hcol[j * ldh] = h;
 #pragma unroll
         for (int k = 0; k < NE; ++k) wv[k] += -h * pv[k];
+    };
+    if constexpr (NE <= 12) {
+        double pa[NE], pb[NE];
+        if (i > 0) load(pa, 0);
+        for (int j = 0; j < i; j += 2) {
+            load(pb, min(j + 1, i - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            step(pa, j);
+            if (j + 1 < i) {
+                load(pa, min(j + 2, i - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                step(pb, j + 1);
+            }
+        }
+    } else {   // (sixteen elements per lane: no registers for a second set beside the matrix the kernel keeps)
+        double pa[NE];
+        for (int j = 0; j < i; ++j) { load(pa, j); step(pa, j); }
     }
     double ts[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1516,18 +1617,22 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
     // 5 297 iterations per solve).  Same blocks in the same order: identical bits.
     const bool oc = LV && A.nb == 3 && n <= 2 * SMALL_BLOCK && (n <= SMALL_BLOCK || a.cache2);
     double ca[GM_CB][3];
-    int    cj[GM_CB], cnt0 = 0, kb0 = 0, r0 = 0, cnt1 = 0, kb1 = 0, r1 = 0;
+    unsigned cj[GM_CB];   // low half: the block columns of row tid; high half: those of row tid + 512, whose values sit in LDS (at most 342 block rows)
+    int    cnt0 = 0, kb0 = 0, r0 = 0, cnt1 = 0, kb1 = 0, r1 = 0;
+    static_assert(GM_CB % 7 == 0, "k_gmres_small: the on-chip product works in groups of seven blocks");
     const int n1 = max(n - SMALL_BLOCK, 0);
     double* c1a = dyn + (size_t)(a.restart + 2) * n;                     // [n1][GM_CB][3]
     int*    c1j = reinterpret_cast<int*>(c1a + (size_t)n1 * GM_CB * 3);  // [n1][GM_CB]
     if (oc) {
+#pragma unroll
+        for (int q = 0; q < GM_CB; ++q) cj[q] = 0u;
         if (tid < n) {
             const int br = tid / 3;
             r0 = tid - br * 3; kb0 = A.ia[br]; cnt0 = A.ia[br + 1] - kb0;
 #pragma unroll
             for (int q = 0; q < GM_CB; ++q) {
                 const int k = kb0 + min(q, max(cnt0 - 1, 0));
-                cj[q] = A.ja[k];
+                cj[q] = (unsigned)A.ja[k];
                 const double* B = A.val + (size_t)k * 9 + r0 * 3;
                 ca[q][0] = B[0]; ca[q][1] = B[1]; ca[q][2] = B[2];
             }
@@ -1535,6 +1640,8 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
         if (tid < n1) {
             const int row = tid + SMALL_BLOCK, br = row / 3;
             r1 = row - br * 3; kb1 = A.ia[br]; cnt1 = A.ia[br + 1] - kb1;
+#pragma unroll
+            for (int q = 0; q < GM_CB; ++q) cj[q] |= (unsigned)A.ja[kb1 + min(q, max(cnt1 - 1, 0))] << 16;
             for (int q = 0; q < min(cnt1, GM_CB); ++q) {
                 c1j[tid * GM_CB + q] = A.ja[kb1 + q];
                 const double* B = A.val + (size_t)(kb1 + q) * 9 + r1 * 3;
@@ -1547,14 +1654,24 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
     auto rows_onchip = [&](const double* xin, const double* seed, auto&& f) {
         if (tid < n) {
             double acc = seed ? -seed[tid] : 0.0;
+            // the operands of seven blocks at a time, all of them (the column of a block the row does not have is that of its last
+            // one: a valid address), THEN the products, added in storage order by selects: a branch per block made fourteen LDS round
+            // trips one after the other of what is two
 #pragma unroll
-            for (int q = 0; q < GM_CB; ++q) {
-                if (q < cnt0) {
-                    const double* xb = xin + (size_t)cj[q] * 3;
-                    double sq = ca[q][0] * xb[0];
-                    sq = sq + ca[q][1] * xb[1];
-                    sq = sq + ca[q][2] * xb[2];
-                    acc += sq;
+            for (int q0 = 0; q0 < GM_CB; q0 += 7) {
+                double xv[7][3];
+#pragma unroll
+                for (int e = 0; e < 7; ++e) {
+                    const double* xb = xin + (size_t)(cj[q0 + e] & 0xffffu) * 3;
+                    xv[e][0] = xb[0]; xv[e][1] = xb[1]; xv[e][2] = xb[2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 7; ++e) {
+                    double sq = ca[q0 + e][0] * xv[e][0];
+                    sq = sq + ca[q0 + e][1] * xv[e][1];
+                    sq = sq + ca[q0 + e][2] * xv[e][2];
+                    acc = (q0 + e < cnt0) ? acc + sq : acc;
                 }
             }
             for (int k = kb0 + GM_CB; k < kb0 + cnt0; ++k) {   // (a row of more than GM_CB blocks: the rest from memory)
@@ -1571,21 +1688,27 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
             const int row = tid + SMALL_BLOCK;
             double acc = seed ? -seed[row] : 0.0;
             const int nq = min(cnt1, GM_CB);
-            for (int q0 = 0; q0 < nq; q0 += 4) {   // four blocks' operands in flight, added in storage order
-                double sq[4];
+            // four blocks' operands in flight (values from LDS, columns from registers: one round trip, not two), added in storage order
+            // by selects.  (Seven, as above, do not fit beside the first rows' matrix registers.)
+#pragma unroll
+            for (int q0 = 0; q0 < GM_CB; q0 += 4) {
+                double cv[4][3], xv[4][3];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int q = min(q0 + e, nq - 1);
-                    const double* C = c1a + ((size_t)tid * GM_CB + q) * 3;
-                    const double* xb = xin + (size_t)c1j[tid * GM_CB + q] * 3;
-                    double v = C[0] * xb[0];
-                    v = v + C[1] * xb[1];
-                    v = v + C[2] * xb[2];
-                    sq[e] = v;
+                    const int q = q0 + e < GM_CB ? q0 + e : GM_CB - 1;
+                    const double* C = c1a + ((size_t)tid * GM_CB + min(q, max(nq - 1, 0))) * 3;
+                    const double* xb = xin + (size_t)(cj[q] >> 16) * 3;
+                    cv[e][0] = C[0]; cv[e][1] = C[1]; cv[e][2] = C[2];
+                    xv[e][0] = xb[0]; xv[e][1] = xb[1]; xv[e][2] = xb[2];
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (q0 + e < nq) acc += sq[e];
+                for (int e = 0; e < 4; ++e) {
+                    double v = cv[e][0] * xv[e][0];
+                    v = v + cv[e][1] * xv[e][1];
+                    v = v + cv[e][2] * xv[e][2];
+                    acc = (q0 + e < nq) ? acc + v : acc;
+                }
             }
             for (int k = kb1 + GM_CB; k < kb1 + cnt1; ++k) {
                 const double* B = A.val + (size_t)k * 9 + r1 * 3;

@@ -1,7 +1,7 @@
 """The safe CG of coarsest levels of at most 128 rows (KrySPcg.c:60-365 as fasp_coarse_itsolver calls it, AuxParam/SolWrapper: tol =
 coarse tolerance, MaxIt = max(250, min(n^2, 1000))): the three single-workgroup forms of csrc/small_solvers.hip.h -- k_spcg_wave (the
 matrix dense in LDS), k_spcg_reg (in registers, p broadcast from LDS), k_spcg_dpp (in registers as 16 x 16 blocks, p broadcast inside
-the multiply-adds; the default) -- inside whole solves against the CPU oracle.
+the multiply-adds; form 4, the default: the same with the next direction sent before the tests of the iteration) -- inside whole solves against the CPU oracle.
 
 Config 5 of BASELINE.json (SA-AMG, W-cycle, VFGMRES(30) on the anisotropic 27-point operator) at sizes whose coarsest levels have 44, 80,
 126 and 128 rows: the three instantiations of k_spcg_dpp (<4,4>, <6,2>, <8,2>), one of them with every row in use.  A W-cycle visits
@@ -36,7 +36,7 @@ def test_small_coarse_cg_forms_match_oracle(gpu, n, rows):
     L = gpu.lib()
     got = {}
     try:
-        for form in (3, 2, 1):
+        for form in (4, 3, 2, 1):
             L.fasp_hip_tune(b"small_onewave", form)
             H = fa.AMG(ia, ja, a, amgp)
             assert H.matrix(H.num_levels - 1, 0)[0] == rows
@@ -47,7 +47,7 @@ def test_small_coarse_cg_forms_match_oracle(gpu, n, rows):
             assert np.abs(x - x_ref).max() <= 1e-9 * np.abs(x_ref).max(), form
             got[form] = stats.coarse_iters
     finally:
-        L.fasp_hip_tune(b"small_onewave", 3)
-    assert got[3] > 0
-    for form in (2, 1):
-        assert abs(got[form] - got[3]) <= 0.02 * got[3] + 2, got
+        L.fasp_hip_tune(b"small_onewave", 4)
+    assert got[4] > 0
+    for form in (3, 2, 1):
+        assert abs(got[form] - got[4]) <= 0.02 * got[4] + 2, got
