@@ -1066,6 +1066,8 @@ __global__ __launch_bounds__(16 * NBK * DUP + (AHEAD ? 64 : 0)) void k_spcg_dpp(
                 rr0 = rr0 - alpha * y0; rr1 = rr1 - alpha * y1;
                 uu_l = u0 * u0 + u1 * u1; pp_l = p0 * p0 + p1 * p1;
                 SRT(9);
+                // (Measured and dropped, config 5 on one box, 187.2 ms as it stands: (u, u) and (p, p) as passengers of this sum, three at
+                // once: 190.2; u += alpha p moved behind the send with the tests, the partial row sums added as a tree: 189.7.)
                 q_rr = wave_allsum(rr0 * rr0 + rr1 * rr1);
                 beta = q_rr / temp1;
                 temp1_old = temp1;

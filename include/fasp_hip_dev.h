@@ -45,9 +45,12 @@ int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
  *   kernel selection / launch geometry: maxgrid, xcd, nt, kind, lanes, wrows, wcap (-1 = automatic), gen2 (0 round-1
  *     kernels, 1, 2 = default), compress (lossless matrix coding on/off), ja16, ws2_bpc, rpl, lds_tab, xcd_pat, rp_strip (coded operators
  *     of a 3-D grid: an XCD sweeps a strip of every grid plane -- 1: the square operators, 2 (default): the transfer operators too -- or,
- *     0, a slab of planes);
+ *     0, a slab of planes), estream (k_csr_estream, the entry-parallel kernel of long-row operators: 1 (default) = where it measured
+ *     faster -- mean rows of fewer than 256 entries --, 2 = wherever its tables exist, 0 = the row kernels);
  *   coarse solve: spcg_persist, spcg_fused, spcg_batch, spcg_grid, small_lds, small_onewave (coarsest levels of <= 128
- *     rows: 2 = matrix in registers, four wavefronts (default), 1 = dense in LDS, one wavefront, 0 = the general kernel),
+ *     rows: 4 (default) = matrix in registers as 16 x 16 blocks, the direction broadcast inside the multiply-adds, the next
+ *     direction sent before the tests of the iteration (k_spcg_dpp<.., true>); 3 = the same without sending ahead; 2 = matrix
+ *     in registers, four wavefronts, p broadcast from LDS; 1 = dense in LDS, one wavefront; 0 = the general kernel),
  *     lazy_coarse (the one-launch solvers' verdicts read once per application of the preconditioner, default 1;
  *     2 = replay every first application as if a coarse solve had given up: tests), coarse_mode / coarse_split_min
  *     (multi-GPU: replicated levels computed in row windows + all-gather);
