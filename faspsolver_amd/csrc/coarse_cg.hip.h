@@ -366,7 +366,7 @@ ITERATE:
                 for (int q = 0; q < 8; ++q) std::printf(" %u", dbg[32 + q]);
                 std::printf(" | block 1:");
                 for (int q = 0; q < 8; ++q) std::printf(" %u", dbg[40 + q]);
-                std::printf("   (spmv meet read step(tail) pass1-2 pass3 reduce4 -)\n");
+                std::printf("   (spmv meet(second group of records + verdict) read step(tail) pass1-2 pass3 first-group-of-records(block 1) poll-rounds)\n");
             }
 #endif
             if (S.stop == SPCG_HANG) {

@@ -1913,6 +1913,9 @@ FINISHED:
 //   k_spcg_fused (coarse_cg.hip.h).  Every spin is bounded (SPCG_HANG + error word).
 // ---------------------------------------------------------------------------
 constexpr int SPCG_HANG = 8;
+#ifndef SPCG_POLL_GROUP
+#define SPCG_POLL_GROUP 6   // records a thread polls at once (k_spcg_persist; 12 = all of them: lab builds)
+#endif
 
 struct SpcgPersistArgs {
     int        m, max_steps, nblocks;
@@ -2034,6 +2037,10 @@ __device__ __forceinline__ void spcg_persist_body(const SpcgPersistArgs& a)
         const __amdgpu_buffer_rsrc_t tr =
             __builtin_amdgcn_make_buffer_rsrc(a.t2 + (size_t)par * 2 * m, 0, (int)((unsigned)m * 16u), 0x00020000);
         // ---- t = A p on the rows of this wave, p from LDS, matrix from registers ----
+        // (2.4 us of the iteration's 9.  Round 6, stamps of block 1 on one box each: the entries of a row dealt to the lanes so that the
+        // 32 addresses of a half-wavefront sit on 32 different bank pairs: 2.40 -> 2.35; two or four interleaved lane sums instead of
+        // the one chain of NE multiply-adds: 2.36 / 2.33 -- neither the LDS banks nor the dependent chain is what the product waits for;
+        // both removed again.)
         if (!lead && my_rows > 0 && my_stop == SPCG_RUN) {
             double acc = 0.0;
             int    j = 0;
@@ -2065,18 +2072,28 @@ __device__ __forceinline__ void spcg_persist_body(const SpcgPersistArgs& a)
         {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             bool hung = false;
+            // (block 0's verdict is asked for FIRST and looked at last: its round trip runs beside those of the records instead of
+            // behind them -- 0.5 of the exchange's 4 us were this one dependent load)
+            unsigned long long vr0 = 0ull;
+            if (tid == 0) vr0 = __hip_atomic_load(g_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll 1
-            for (int e0 = 0; e0 < E && !hung; e0 += 6) {   // six records in flight per thread (more spill: the registers hold the matrix)
+            for (int e0 = 0; e0 < E && !hung; e0 += SPCG_POLL_GROUP) {   // six records in flight per thread (more spill: the registers hold the matrix)
+#ifdef SPCG_PERSIST_STAMPS
+                if (e0 == 6 && !LEAD) STAMP(6);   // (lab: slot 6 = the first group of records, slot 0 continues with the second)
+#endif
                 unsigned pend = 0u;
 #pragma unroll
-                for (int e = 0; e < 6; ++e) if (tid + (e0 + e) * NT < m) pend |= 1u << e;
+                for (int e = 0; e < SPCG_POLL_GROUP; ++e) if (tid + (e0 + e) * NT < m) pend |= 1u << e;
                 while (pend) {
-                    pu32x4 q[6];
+#ifdef SPCG_PERSIST_STAMPS
+                    tk[7] += 1;   // poll rounds (two per step if every record is there at the first look)
+#endif
+                    pu32x4 q[SPCG_POLL_GROUP];
 #pragma unroll
-                    for (int e = 0; e < 6; ++e)
+                    for (int e = 0; e < SPCG_POLL_GROUP; ++e)
                         q[e] = __builtin_amdgcn_raw_buffer_load_b128(tr, ((pend >> e) & 1u) ? (tid + (e0 + e) * NT) * 16 : (int)0xfffffff0u, 0, 16 /* sc1 */);
 #pragma unroll
-                    for (int e = 0; e < 6; ++e)
+                    for (int e = 0; e < SPCG_POLL_GROUP; ++e)
                         if (((pend >> e) & 1u) && q[e].y == ep && q[e].w == ep) {
                             st[tid + (e0 + e) * NT] = __longlong_as_double((long long)(((unsigned long long)q[e].z << 32) | q[e].x));
                             pend &= ~(1u << e);
@@ -2086,8 +2103,8 @@ __device__ __forceinline__ void spcg_persist_body(const SpcgPersistArgs& a)
             }
             if (tid == 0 && !hung) {
                 int flag = -1;
-                for (;;) {
-                    const unsigned long long vr = __hip_atomic_load(g_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (bool first = true;; first = false) {
+                    const unsigned long long vr = first ? vr0 : __hip_atomic_load(g_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((unsigned)(vr >> 32) == ep) { flag = (int)(unsigned)vr; break; }
                     __builtin_amdgcn_s_sleep(1);
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { hung = true; break; }
