@@ -626,7 +626,7 @@ def main():
         roof["frac_by_survey_8d_bytes_note"] = ("not comparable (> 1): the coded operator does not read IA / JA / val; the plain-CSR kernel of "
                                                 "the same operator, same timing method: plain_csr")
     roof["plain_csr"] = ({k: plain[k] for k in ("kernel", "achieved", "frac", "bytes_per_launch", "ms_per_launch", "launches_timed", "traffic",
-                                                "traffic_over_bytes", "timed", "solve_ms_per_step_all_plain_csr") if k in plain}
+                                                "traffic_source", "traffic_over_bytes", "timed", "solve_ms_per_step_all_plain_csr") if k in plain}
                          if plain else None)
     # solve-wide: HBM-side bytes per PCG iteration (PMC passes of this command, profiles/<round>_rocprof/traffic.json) over the time of
     # an iteration in THIS run
