@@ -136,9 +136,8 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
         const size_t lds_w = sizeof(double) * (128 * (size_t)LD + 128);
         const bool one_wave = g_tune.small_onewave && m <= 128 && lds_w <= 148 * 1024;
         if (one_wave && g_tune.small_onewave >= 3) {   // the matrix in registers as 16 x 16 blocks, p broadcast inside the multiply-adds (k_spcg_dpp)
-            const bool ahead = g_tune.small_onewave >= 4;   // the direction goes out before the tests of the iteration (a wavefront more: the first one multiplies nothing)
-            const int NBK = m <= 64 ? 4 : m <= 96 ? 6 : 8, DUP = NBK == 4 ? 4 : (NBK == 6 && ahead && g_tune.small_onewave != 5) ? 3 : 2, RB = NBK / DUP;   // (5: lab, 6 x 2 groups with AHEAD)
-            if (!h->reg_img || h->reg_mc != -(NBK * 8 + DUP)) {   // the register image, once per hierarchy: group g = tid / 16 carries column block g % NBK and row blocks (g / NBK) RB ..
+            const int NBK = m <= 64 ? 4 : m <= 96 ? 6 : 8, DUP = NBK == 4 ? 4 : 2, RB = NBK / DUP;
+            if (!h->reg_img || h->reg_mc != -NBK) {   // the register image, once per hierarchy: group g = tid / 16 carries column block g % NBK and row blocks (g / NBK) RB ..
                 const HostCSR& Ah = h->H.L.back().A;
                 const int NT = 16 * NBK * DUP;   // threads of k_spcg_dpp
                 std::vector<double> img((size_t)RB * 16 * NT, 0.0);
@@ -151,12 +150,12 @@ static int coarse_spcg(fasp_hip_amg* h, DevLevel& D, double tol, int prtlvl)
                 if (h->reg_img) (void)hipFree(h->reg_img);
                 HIPCK(hipMalloc((void**)&h->reg_img, sizeof(double) * img.size()));
                 HIPCK(hipMemcpy(h->reg_img, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
-                h->reg_mc = -(NBK * 8 + DUP);   // (negative: k_spcg_dpp's layout)
+                h->reg_mc = -NBK;   // (negative: k_spcg_dpp's layout)
             }
             a.img = h->reg_img;
+            const bool ahead = g_tune.small_onewave >= 4;   // the direction goes out before the tests of the iteration (a wavefront more: the first one multiplies nothing)
             if (NBK == 4 && ahead) hipLaunchKernelGGL((k_spcg_dpp<4, 4, true>), dim3(1), dim3(320), 0, g_ctx.stream, a, LD);
             else if (NBK == 4) hipLaunchKernelGGL((k_spcg_dpp<4, 4, false>), dim3(1), dim3(256), 0, g_ctx.stream, a, LD);
-            else if (NBK == 6 && ahead && DUP == 3) hipLaunchKernelGGL((k_spcg_dpp<6, 3, true>), dim3(1), dim3(384), 0, g_ctx.stream, a, LD);   // 18 groups of two blocks: four and a half wavefronts
             else if (NBK == 6 && ahead) hipLaunchKernelGGL((k_spcg_dpp<6, 2, true>), dim3(1), dim3(256), 0, g_ctx.stream, a, LD);
             else if (NBK == 6) hipLaunchKernelGGL((k_spcg_dpp<6, 2, false>), dim3(1), dim3(192), 0, g_ctx.stream, a, LD);
             else if (ahead) hipLaunchKernelGGL((k_spcg_dpp<8, 2, true>), dim3(1), dim3(320), 0, g_ctx.stream, a, LD);

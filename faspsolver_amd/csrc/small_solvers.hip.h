@@ -858,25 +858,24 @@ __device__ __forceinline__ void wave_allsum2(double& x, double& y)
     x = wave_bcast63(x); y = wave_bcast63(y);
 }
 template <int NBK, int DUP, bool AHEAD>
-__global__ __launch_bounds__((16 * NBK * DUP + 63) / 64 * 64 + (AHEAD ? 64 : 0)) void k_spcg_dpp(SpcgArgs a, int LD)
+__global__ __launch_bounds__(16 * NBK * DUP + (AHEAD ? 64 : 0)) void k_spcg_dpp(SpcgArgs a, int LD)
 {
 #ifdef SR_TIMING
     unsigned long long srt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, srt_last = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int RB = NBK / DUP, MP = 16 * NBK;   // row blocks per group, padded order
-    static_assert(RB * DUP == NBK && NBK >= 4 && (AHEAD ? NBK * DUP <= 20 : (NBK * DUP <= 16 && (NBK * DUP) % 4 == 0)), "k_spcg_dpp: groups of sixteen lanes; without AHEAD whole wavefronts of them, the first one = column blocks 0 .. 3");
+    static_assert(RB * DUP == NBK && NBK * DUP <= 16 && (NBK * DUP) % 4 == 0 && NBK >= 4, "k_spcg_dpp: whole wavefronts of four groups, the first of them = column blocks 0 .. 3");
     __shared__ double part[NBK * MP];   // part[cb][row]: the row sums over column block cb
     __shared__ double xbuf[MP];         // the vector of the coming product, from wavefront 0
     __shared__ int    cmd;              // 1: a product follows, 0: the solve is over
     const int m = a.A.m, tid = threadIdx.x, lane = tid & 63;
     const int ts = AHEAD ? (tid >= 64 ? tid - 64 : 0) : tid;   // AHEAD: wavefront 0 multiplies nothing, the groups start behind it
     const int g = ts >> 4, l = ts & 15;
-    const bool live = g < NBK * DUP;   // (NBK DUP no multiple of four: the last wavefront's spare groups multiply zeros and store nothing)
-    const int cb = g % NBK, half = live ? g / NBK : 0;
+    const int cb = g % NBK, half = g / NBK;
     (void)LD;
     double Ar[RB * 16];   // entry 16 k + j: A(16 (half RB + k) + l, 16 cb + j), from the image the host lays out once per hierarchy
 #pragma unroll
-    for (int k = 0; k < RB * 16; ++k) Ar[k] = live ? a.img[(size_t)k * (16 * NBK * DUP) + ts] : 0.0;
+    for (int k = 0; k < RB * 16; ++k) Ar[k] = a.img[(size_t)k * (16 * NBK * DUP) + ts];
     double* const pw = part + cb * MP + 16 * (half * RB) + l;   // this lane's partials: row blocks half RB .. half RB + RB - 1
     auto blocks = [&](double x) {   // x: element 16 cb + l of the vector
         double acc[RB][4];
@@ -884,8 +883,7 @@ __global__ __launch_bounds__((16 * NBK * DUP + 63) / 64 * 64 + (AHEAD ? 64 : 0))
         for (int k = 0; k < RB; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
         dpp_blocks16<RB>(acc, x, Ar);
 #pragma unroll
-        for (int k = 0; k < RB; ++k)
-            if (live) pw[16 * k] = (acc[k][0] + acc[k][1]) + (acc[k][2] + acc[k][3]);
+        for (int k = 0; k < RB; ++k) pw[16 * k] = (acc[k][0] + acc[k][1]) + (acc[k][2] + acc[k][3]);
     };
     if (tid >= 64) {   // the wavefronts that only multiply (AHEAD: all that multiply)
         for (;;) {
@@ -1068,7 +1066,8 @@ __global__ __launch_bounds__((16 * NBK * DUP + 63) / 64 * 64 + (AHEAD ? 64 : 0))
                 rr0 = rr0 - alpha * y0; rr1 = rr1 - alpha * y1;
                 uu_l = u0 * u0 + u1 * u1; pp_l = p0 * p0 + p1 * p1;
                 SRT(9);
-                // (Measured and dropped, config 5 on one box, 187.2 ms as it stands: (u, u) and (p, p) as passengers of this sum, three at
+                // (Measured and dropped, config 5 on one box, 187.2 ms as it stands -- three groups of lanes per column block at 65-96 rows (18
+                // groups of two blocks, a wavefront more) instead of two: 191.5 against 190.6 on another box; (u, u) and (p, p) as passengers of this sum, three at
                 // once: 190.2; u += alpha p moved behind the send with the tests, the partial row sums added as a tree: 189.7.)
                 q_rr = wave_allsum(rr0 * rr0 + rr1 * rr1);
                 beta = q_rr / temp1;

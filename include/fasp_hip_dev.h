@@ -49,8 +49,7 @@ int fasp_hip_measure_ceilings(double* out, size_t bytes, int reps);
  *     faster -- mean rows of fewer than 256 entries --, 2 = wherever its tables exist, 0 = the row kernels);
  *   coarse solve: spcg_persist, spcg_fused, spcg_batch, spcg_grid, small_lds, small_onewave (coarsest levels of <= 128
  *     rows: 4 (default) = matrix in registers as 16 x 16 blocks, the direction broadcast inside the multiply-adds, the next
- *     direction sent before the tests of the iteration (k_spcg_dpp<.., true>; 5 = the same with two instead of three groups of
- *     lanes per column block at 65-96 rows); 3 = the same without sending ahead; 2 = matrix
+ *     direction sent before the tests of the iteration (k_spcg_dpp<.., true>); 3 = the same without sending ahead; 2 = matrix
  *     in registers, four wavefronts, p broadcast from LDS; 1 = dense in LDS, one wavefront; 0 = the general kernel),
  *     lazy_coarse (the one-launch solvers' verdicts read once per application of the preconditioner, default 1;
  *     2 = replay every first application as if a coarse solve had given up: tests), coarse_mode / coarse_split_min

@@ -36,7 +36,7 @@ def test_small_coarse_cg_forms_match_oracle(gpu, n, rows):
     L = gpu.lib()
     got = {}
     try:
-        for form in (5, 4, 3, 2, 1):   # (5: form 4 with two groups per column block at 65-96 rows instead of three)
+        for form in (4, 3, 2, 1):
             L.fasp_hip_tune(b"small_onewave", form)
             H = fa.AMG(ia, ja, a, amgp)
             assert H.matrix(H.num_levels - 1, 0)[0] == rows
@@ -49,5 +49,5 @@ def test_small_coarse_cg_forms_match_oracle(gpu, n, rows):
     finally:
         L.fasp_hip_tune(b"small_onewave", 4)
     assert got[4] > 0
-    for form in (5, 3, 2, 1):
+    for form in (3, 2, 1):
         assert abs(got[form] - got[4]) <= 0.02 * got[4] + 2, got
