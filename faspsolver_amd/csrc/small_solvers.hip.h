@@ -1530,43 +1530,55 @@ constexpr int GM_CB = 14;   // blocks of a row k_gmres_small holds on chip (nb =
 template <int NE>
 __device__ __forceinline__ double gm_mgs_wave(int n, int i, int lane, const double* basis, double* pi, double* hcol, int ldh)
 {
+    // NE = ceil(n / 64) exactly: elements k < NE - 1 exist in every lane, element NE - 1 in the lanes below n - 64 (NE - 1).  Every read
+    // is unconditional (the last element's index clamped into the vector, its value zeroed by a select): a read under a lane predicate is
+    // a block of its own for the compiler, and at the join behind it the wait-count pass no longer knows that the NEXT vector's reads were
+    // issued after this one's -- it waited for all of them (lgkmcnt(0)) in front of every dot product, which is what the two register
+    // sets are there to avoid.
+    const bool vl = lane + 64 * (NE - 1) < n;
+    const int  il = min(lane + 64 * (NE - 1), n - 1);
     double wv[NE];
 #pragma unroll
-    for (int k = 0; k < NE; ++k) wv[k] = (lane + 64 * k < n) ? pi[lane + 64 * k] : 0.0;
+    for (int k = 0; k < NE - 1; ++k) wv[k] = pi[lane + 64 * k];
+    { const double x = pi[il]; wv[NE - 1] = vl ? x : 0.0; }
     // basis vector j + 1 is read while the dot product with vector j is summed over the wavefront (the coefficient of one vector is
     // needed before the next dot product, the vector itself is not): two register sets, the read of the next one unconditional
     // (past the last vector: the last one again) so that it stays in flight across the use of the current one
     auto load = [&](double (&pv)[NE], int j) {
         const double* pj = basis + (size_t)j * n;
 #pragma unroll
-        for (int k = 0; k < NE; ++k) pv[k] = (lane + 64 * k < n) ? pj[lane + 64 * k] : 0.0;
+        for (int k = 0; k < NE - 1; ++k) pv[k] = pj[lane + 64 * k];
+        pv[NE - 1] = pj[il];
     };
-    auto step = [&](const double (&pv)[NE], int j) {
+    double hmine = 0.0;   // lane j keeps coefficient j; they leave together behind the loop (at most 30 of them)
+    auto step = [&](double (&pv)[NE], int j) {
+        pv[NE - 1] = vl ? pv[NE - 1] : 0.0;
         double hs[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < NE; ++k) hs[k & 3] += pv[k] * wv[k];
         const double h = wave_allsum((hs[0] + hs[1]) + (hs[2] + hs[3]));
-        if (lane == 0) hcol[j * ldh] = h;
+        hmine = (lane == j) ? h : hmine;
 #pragma unroll
         for (int k = 0; k < NE; ++k) wv[k] += -h * pv[k];
     };
     if constexpr (NE <= 12) {
         double pa[NE], pb[NE];
+        int j = 0;
         if (i > 0) load(pa, 0);
-        for (int j = 0; j < i; j += 2) {
-            load(pb, min(j + 1, i - 1));
+        for (; j + 1 < i; j += 2) {
+            load(pb, j + 1);
             __builtin_amdgcn_sched_barrier(0);
             step(pa, j);
-            if (j + 1 < i) {
-                load(pa, min(j + 2, i - 1));
-                __builtin_amdgcn_sched_barrier(0);
-                step(pb, j + 1);
-            }
+            load(pa, min(j + 2, i - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            step(pb, j + 1);
         }
-    } else {   // (sixteen elements per lane: no registers for a second set beside the matrix the kernel keeps)
+        if (j < i) step(pa, j);   // (an odd count: the last vector is the one read ahead)
+    } else {   // (more elements per lane: no registers for a second set beside the matrix the kernel keeps)
         double pa[NE];
         for (int j = 0; j < i; ++j) { load(pa, j); step(pa, j); }
     }
+    if (lane < i) hcol[lane * ldh] = hmine;
     double ts[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < NE; ++k) ts[k & 3] += wv[k] * wv[k];
@@ -1577,8 +1589,8 @@ __device__ __forceinline__ double gm_mgs_wave(int n, int i, int lane, const doub
         for (int k = 0; k < NE; ++k) wv[k] *= s;
     }
 #pragma unroll
-    for (int k = 0; k < NE; ++k)
-        if (lane + 64 * k < n) pi[lane + 64 * k] = wv[k];
+    for (int k = 0; k < NE - 1; ++k) pi[lane + 64 * k] = wv[k];
+    if (vl) pi[il] = wv[NE - 1];
     return t;
 }
 
@@ -1591,7 +1603,7 @@ template <class OP, bool LV>
 __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
 {
 #ifdef GM_TIMING
-    unsigned long long gmt[5] = {0, 0, 0, 0, 0}, gmt_last = __builtin_amdgcn_s_memrealtime();
+    unsigned long long gmt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gmt_last = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int R = SMALL_MAX_RESTART;
     extern __shared__ double dyn[];
@@ -1677,16 +1689,35 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
                     acc = (q0 + e < cnt0) ? acc + sq : acc;
                 }
             }
-            for (int k = kb0 + GM_CB; k < kb0 + cnt0; ++k) {   // (a row of more than GM_CB blocks: the rest from memory)
-                const double* B = A.val + (size_t)k * 9 + r0 * 3;
-                const double* xb = xin + (size_t)A.ja[k] * 3;
-                double sq = B[0] * xb[0];
-                sq = sq + B[1] * xb[1];
-                sq = sq + B[2] * xb[2];
-                acc += sq;
+            // a row of more than GM_CB blocks: the rest from memory (the L1 after the first product: nothing else of this kernel goes through
+            // it) -- a third of config 3's coarsest rows have up to nine such blocks, and one block per trip made their wavefronts the last
+            // at the barrier by 1.6 us.  Three blocks' columns and values in flight per trip, added in storage order by selects.
+            for (int k0 = kb0 + GM_CB; k0 < kb0 + cnt0; k0 += 3) {
+                int    jj[3];
+                double bv[3][3], xv[3][3];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const int kk = min(k0 + e, kb0 + cnt0 - 1);
+                    const double* B = A.val + (size_t)kk * 9 + r0 * 3;
+                    jj[e] = A.ja[kk];
+                    bv[e][0] = B[0]; bv[e][1] = B[1]; bv[e][2] = B[2];
+                }
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const double* xb = xin + (size_t)jj[e] * 3;
+                    xv[e][0] = xb[0]; xv[e][1] = xb[1]; xv[e][2] = xb[2];
+                }
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    double sq = bv[e][0] * xv[e][0];
+                    sq = sq + bv[e][1] * xv[e][1];
+                    sq = sq + bv[e][2] * xv[e][2];
+                    acc = (k0 + e < kb0 + cnt0) ? acc + sq : acc;
+                }
             }
             f(tid, acc);
         }
+        GMT(5);   // (lab: the first 512 rows are done)
         if (tid < n1) {
             const int row = tid + SMALL_BLOCK;
             double acc = seed ? -seed[row] : 0.0;
@@ -1723,6 +1754,7 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
             }
             f(row, acc);
         }
+        GMT(6);   // (lab: the rows beyond 512)
         __syncthreads();
     };
     auto g_mxv = [&](const double* xin, double* y) {
@@ -1768,11 +1800,14 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
                 // (config 3: 555 rows, 5 297 coarse iterations per solve).  Sums: per lane over ascending elements, then the
                 // wavefront's fixed DPP order.
                 if (tid < 64) {
-                    const int ne = (n + 63) >> 6;   // elements per lane
-                    if (ne <= 4) t = gm_mgs_wave<4>(n, i, tid, basis, pi, hh + (i - 1), R);
-                    else if (ne <= 8) t = gm_mgs_wave<8>(n, i, tid, basis, pi, hh + (i - 1), R);
-                    else if (ne <= 12) t = gm_mgs_wave<12>(n, i, tid, basis, pi, hh + (i - 1), R);
-                    else t = gm_mgs_wave<GM_NE>(n, i, tid, basis, pi, hh + (i - 1), R);
+                    const int ne = (n + 63) >> 6;   // elements per lane: the instantiation that has exactly as many
+                    switch (ne) {
+#define FASP_GM_CASE(q) case q: t = gm_mgs_wave<q>(n, i, tid, basis, pi, hh + (i - 1), R); break;
+                        FASP_GM_CASE(1) FASP_GM_CASE(2) FASP_GM_CASE(3) FASP_GM_CASE(4) FASP_GM_CASE(5) FASP_GM_CASE(6) FASP_GM_CASE(7) FASP_GM_CASE(8)
+                        FASP_GM_CASE(9) FASP_GM_CASE(10) FASP_GM_CASE(11) FASP_GM_CASE(12) FASP_GM_CASE(13) FASP_GM_CASE(14) FASP_GM_CASE(15)
+#undef FASP_GM_CASE
+                        default: t = gm_mgs_wave<GM_NE>(n, i, tid, basis, pi, hh + (i - 1), R); break;
+                    }
                 }
             } else {
             // modified Gram-Schmidt: a thread updates only its own elements between the dots
@@ -1797,6 +1832,8 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
             }
             }
             GMT(2);
+            // (Givens rotations with entry j and rotation j in lane j of wavefront 0 -- six readlanes per rotation instead of a walk through
+            // LDS -- measured the same 1.0 us per iteration: it is the chain of dependent products and sums, not the LDS round trips.)
             if (tid == 0) {  // Givens rotations on the new Hessenberg column
                 hh[i * R + (i - 1)] = t;
                 for (int j = 1; j < i; ++j) {
@@ -1878,7 +1915,7 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
 
 FINISHED:
 #ifdef GM_TIMING
-    if (tid == 0 && iter > 20) printf("[gmres_small] iters %d: other %.2f spmv %.2f mgs %.2f givens %.2f barrier %.2f us per iteration\n", iter, gmt[0] * 0.01 / iter, gmt[1] * 0.01 / iter, gmt[2] * 0.01 / iter, gmt[3] * 0.01 / iter, gmt[4] * 0.01 / iter);
+    if (tid == 0 && iter > 20) printf("[gmres_small] iters %d: other %.2f spmv %.2f (wavefront 0: rows < 512 %.2f, rows >= 512 %.2f, barrier %.2f) mgs %.2f givens %.2f barrier %.2f us per iteration\n", iter, gmt[0] * 0.01 / iter, (gmt[1] + gmt[5] + gmt[6]) * 0.01 / iter, gmt[5] * 0.01 / iter, gmt[6] * 0.01 / iter, gmt[1] * 0.01 / iter, gmt[2] * 0.01 / iter, gmt[3] * 0.01 / iter, gmt[4] * 0.01 / iter);
 #endif
     if (tid == 0) {
         a.out->iters = iter;
