@@ -1525,10 +1525,10 @@ constexpr int GM_CB = 14;   // blocks of a row k_gmres_small holds on chip (nb =
 // LV: the Krylov basis p[0..restart] and w live in dynamic LDS ((restart + 2) n doubles) instead of a.ws
 // Modified Gram-Schmidt of the new Krylov vector `pi` against basis vectors 0 .. i-1 (n doubles apart) in ONE wavefront:
 // NE elements per lane in registers, a dot product = NE multiply-adds per lane (four interleaved partial sums) + the
-// wavefront's DPP sum, no LDS partials, no barrier.  The coefficients go to hcol[j * ldh]; returns the norm of what is
+// wavefront's DPP sum, no LDS partials, no barrier.  Coefficient j comes back in lane j (hlane); returns the norm of what is
 // left and leaves pi normalised (KryPvgmres.c:207-233).
 template <int NE>
-__device__ __forceinline__ double gm_mgs_wave(int n, int i, int lane, const double* basis, double* pi, double* hcol, int ldh)
+__device__ __forceinline__ double gm_mgs_wave(int n, int i, int lane, const double* basis, double* pi, double& hlane)
 {
     // NE = ceil(n / 64) exactly: elements k < NE - 1 exist in every lane, element NE - 1 in the lanes below n - 64 (NE - 1).  Every read
     // is unconditional (the last element's index clamped into the vector, its value zeroed by a select): a read under a lane predicate is
@@ -1578,7 +1578,7 @@ __device__ __forceinline__ double gm_mgs_wave(int n, int i, int lane, const doub
         double pa[NE];
         for (int j = 0; j < i; ++j) { load(pa, j); step(pa, j); }
     }
-    if (lane < i) hcol[lane * ldh] = hmine;
+    hlane = hmine;   // (lane j < i: the coefficient against basis vector j -- the caller rotates the column where it sits)
     double ts[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < NE; ++k) ts[k & 3] += wv[k] * wv[k];
@@ -1619,6 +1619,7 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
     const int MaxIt = a.MaxIt, restart_max = a.restart, restart_min = 3, d = 3;
     int iter = 0, i = 0, Restart = a.restart;
     double r_norm, r_norm_old = 0.0, absres0, absres = 1e+20, relres, cr = 1.0, t;
+    double g_c = 0.0, g_s = 0.0;   // wavefront 0: lane j keeps Givens rotation j - 1 of the current restart cycle
     const double* b = a.b;
     double* x = a.x;
     double* const basis = LV ? dyn : a.ws;
@@ -1801,12 +1802,58 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
                 // wavefront's fixed DPP order.
                 if (tid < 64) {
                     const int ne = (n + 63) >> 6;   // elements per lane: the instantiation that has exactly as many
+                    double hl = 0.0;
                     switch (ne) {
-#define FASP_GM_CASE(q) case q: t = gm_mgs_wave<q>(n, i, tid, basis, pi, hh + (i - 1), R); break;
+#define FASP_GM_CASE(q) case q: t = gm_mgs_wave<q>(n, i, tid, basis, pi, hl); break;
                         FASP_GM_CASE(1) FASP_GM_CASE(2) FASP_GM_CASE(3) FASP_GM_CASE(4) FASP_GM_CASE(5) FASP_GM_CASE(6) FASP_GM_CASE(7) FASP_GM_CASE(8)
                         FASP_GM_CASE(9) FASP_GM_CASE(10) FASP_GM_CASE(11) FASP_GM_CASE(12) FASP_GM_CASE(13) FASP_GM_CASE(14) FASP_GM_CASE(15)
 #undef FASP_GM_CASE
-                        default: t = gm_mgs_wave<GM_NE>(n, i, tid, basis, pi, hh + (i - 1), R); break;
+                        default: t = gm_mgs_wave<GM_NE>(n, i, tid, basis, pi, hl); break;
+                    }
+                    GMT(2);
+                    // Givens rotations on the new Hessenberg column (KryPvgmres.c:236-259) where it sits.  Rotation j - 1 = (c, s) lives in
+                    // lane j since the iteration that formed it, entry h_j in lane j.  What the reference's loop carries from rotation to
+                    // rotation is ONE number -- tt_j = -s tt_{j-1} + c h_j, the entry the next rotation pairs with -- so that is all that
+                    // has to go from lane to lane (one wavefront shift, one product, one sum per rotation; c h_j is formed beforehand in
+                    // every lane at once); the other halves, s h_j + c tt_{j-1}, are one parallel step at the end.  Same products, same
+                    // sums.  One thread walking the column through LDS took 1.0 of an iteration's 7.4 us (config 3, 15 rotations on
+                    // average): a chain of LDS round trips and four dependent operations per rotation.
+                    auto rdl = [&](double x, int from) -> double {
+                        const unsigned long long bb = (unsigned long long)__double_as_longlong(x);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bb, from);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bb >> 32), from);
+                        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                    };
+                    auto shr1 = [&](double x) -> double {   // lane j takes lane j - 1's value (wave_shr:1; lane 0: 0)
+                        const long long bb = __double_as_longlong(x);
+                        int lo = (int)(bb & 0xffffffffll), hi = (int)(bb >> 32);
+                        lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+                        hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+                        return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+                    };
+                    const double rprev = rs[i - 1];
+                    const double bj = g_c * hl;          // c_{j-1} h_j
+                    const double ns = -g_s;
+                    double cur = hl;                     // tt_0 = h_0 in lane 0; lane j is right after step j
+                    for (int st = 1; st < i; ++st) {
+                        const double nc = ns * shr1(cur) + bj;
+                        cur = (tid >= 1) ? nc : cur;
+                    }
+                    const double np = g_s * hl + g_c * shr1(cur);   // the final entry j - 1, formed in lane j (1 <= j < i)
+                    const double curL = rdl(cur, i - 1);            // what the new rotation pairs with t
+                    double g = t * t;
+                    g += curL * curL;
+                    double gamma = sqrt(g);
+                    if (gamma == 0.0) gamma = epsmac;
+                    const double ci = curL / gamma, si = t / gamma;
+                    const double rsi = -si * rprev, rsp = ci * rprev;
+                    const double hfin = si * t + ci * curL;
+                    g_c = (tid == i) ? ci : g_c;
+                    g_s = (tid == i) ? si : g_s;
+                    if (tid >= 1 && tid < i) hh[(tid - 1) * R + (i - 1)] = np;
+                    if (tid == 0) {
+                        hh[(i - 1) * R + (i - 1)] = hfin; hh[i * R + (i - 1)] = t;
+                        c[i - 1] = ci; sn[i - 1] = si; rs[i] = rsi; rs[i - 1] = rsp; sc_rnorm = fabs(rsi);
                     }
                 }
             } else {
@@ -1831,10 +1878,8 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
                 for (int e = tid; e < n; e += SMALL_BLOCK) pi[e] *= s;
             }
             }
-            GMT(2);
-            // (Givens rotations with entry j and rotation j in lane j of wavefront 0 -- six readlanes per rotation instead of a walk through
-            // LDS -- measured the same 1.0 us per iteration: it is the chain of dependent products and sums, not the LDS round trips.)
-            if (tid == 0) {  // Givens rotations on the new Hessenberg column
+            if (!(n <= 64 * GM_NE)) GMT(2);
+            if (!(n <= 64 * GM_NE) && tid == 0) {  // Givens rotations on the new Hessenberg column
                 hh[i * R + (i - 1)] = t;
                 for (int j = 1; j < i; ++j) {
                     const double tt = hh[(j - 1) * R + (i - 1)];
