@@ -1521,6 +1521,9 @@ struct GmresArgs {
     int           cache2;   // LV only: rows beyond the first 512 have GM_CB * 28 bytes each of LDS behind the basis (k_gmres_small: the matrix held on chip)
 };
 constexpr int GM_CB = 14;   // blocks of a row k_gmres_small holds on chip (nb = 3)
+#ifndef GM_OV
+#define GM_OV 3             // blocks beyond them in flight per trip
+#endif
 
 // LV: the Krylov basis p[0..restart] and w live in dynamic LDS ((restart + 2) n doubles) instead of a.ws
 // Modified Gram-Schmidt of the new Krylov vector `pi` against basis vectors 0 .. i-1 (n doubles apart) in ONE wavefront:
@@ -1692,24 +1695,24 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
             }
             // a row of more than GM_CB blocks: the rest from memory (the L1 after the first product: nothing else of this kernel goes through
             // it) -- a third of config 3's coarsest rows have up to nine such blocks, and one block per trip made their wavefronts the last
-            // at the barrier by 1.6 us.  Three blocks' columns and values in flight per trip, added in storage order by selects.
-            for (int k0 = kb0 + GM_CB; k0 < kb0 + cnt0; k0 += 3) {
-                int    jj[3];
-                double bv[3][3], xv[3][3];
+            // at the barrier by 1.6 us.  GM_OV blocks' columns and values in flight per trip, added in storage order by selects.
+            for (int k0 = kb0 + GM_CB; k0 < kb0 + cnt0; k0 += GM_OV) {
+                int    jj[GM_OV];
+                double bv[GM_OV][3], xv[GM_OV][3];
 #pragma unroll
-                for (int e = 0; e < 3; ++e) {
+                for (int e = 0; e < GM_OV; ++e) {
                     const int kk = min(k0 + e, kb0 + cnt0 - 1);
                     const double* B = A.val + (size_t)kk * 9 + r0 * 3;
                     jj[e] = A.ja[kk];
                     bv[e][0] = B[0]; bv[e][1] = B[1]; bv[e][2] = B[2];
                 }
 #pragma unroll
-                for (int e = 0; e < 3; ++e) {
+                for (int e = 0; e < GM_OV; ++e) {
                     const double* xb = xin + (size_t)jj[e] * 3;
                     xv[e][0] = xb[0]; xv[e][1] = xb[1]; xv[e][2] = xb[2];
                 }
 #pragma unroll
-                for (int e = 0; e < 3; ++e) {
+                for (int e = 0; e < GM_OV; ++e) {
                     double sq = bv[e][0] * xv[e][0];
                     sq = sq + bv[e][1] * xv[e][1];
                     sq = sq + bv[e][2] * xv[e][2];
