@@ -1912,7 +1912,16 @@ __global__ __launch_bounds__(SMALL_BLOCK) void k_gmres_small(GmresArgs<OP> a)
             rs[i - 1] = rs[i - 1] / hh[(i - 1) * R + (i - 1)];
             for (int k = i - 2; k >= 0; k--) {
                 double tt = 0.0;
-                for (int j = k + 1; j < i; j++) tt -= hh[k * R + j] * rs[j];
+                int j = k + 1;
+                for (; j + 5 < i; j += 6) {   // six terms' operands in flight, subtracted in the reference's order (one term per LDS round trip
+                                              // made the 435 terms of a full restart 18 us: 0.6 us of every iteration on config 3)
+                    double hv[6], rv[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) { hv[e] = hh[k * R + j + e]; rv[e] = rs[j + e]; }
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) tt -= hv[e] * rv[e];
+                }
+                for (; j < i; j++) tt -= hh[k * R + j] * rs[j];
                 tt += rs[k];
                 rs[k] = tt / hh[k * R + k];
             }
