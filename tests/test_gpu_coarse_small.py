@@ -20,11 +20,13 @@ import _libs
 pytestmark = pytest.mark.gpu
 
 
-def _params():
+def _params(amg_tol=None):
     itp, amgp = _libs.default_params()
     itp.tol = 1e-8; itp.itsolver_type = 6; itp.restart = 30
     amgp.AMG_type = T.SA_AMG; amgp.cycle_type = T.W_CYCLE
     amgp.smoother = T.SMOOTHER_JACOBI; amgp.relaxation = 0.6667
+    if amg_tol is not None:
+        amgp.tol = amg_tol
     return itp, amgp
 
 
@@ -50,4 +52,33 @@ def test_small_coarse_cg_forms_match_oracle(gpu, n, rows):
         L.fasp_hip_tune(b"small_onewave", 4)
     assert got[4] > 0
     for form in (3, 2, 1):
+        assert abs(got[form] - got[4]) <= 0.02 * got[4] + 2, got
+
+
+@pytest.mark.parametrize("n", [10, 48])
+def test_small_coarse_cg_with_a_tolerance_it_cannot_reach(gpu, n):
+    """AMG_param.tol = 1e-14 makes the coarse tolerance 1e-18 (PreMGCycle.c: tol * 1e-4): no coarse solve converges by its residual
+    test, every one of them ends through the reference's stagnation and safety branches (Checks I-III with their true-residual
+    products and restarts, KrySPcg.c:195-300) -- in k_spcg_dpp's send-ahead form the branches in which a product sent ahead is
+    dropped and the iteration count and (z, r) step back.  Same verdicts as the oracle in all forms; forms 3 and 4 (the same
+    arithmetic with and without sending ahead) agree to the last bit."""
+    ia, ja, a, f = fa.aniso27pt(n)
+    s_ref, x_ref, h_ref, rr_ref = _libs.orc_solve(ia, ja, a, f, *_params(1e-14))
+    L = gpu.lib()
+    got, sol = {}, {}
+    try:
+        for form in (4, 3, 2, 1):
+            L.fasp_hip_tune(b"small_onewave", form)
+            itp, amgp = _params(1e-14)
+            H = fa.AMG(ia, ja, a, amgp)
+            st, x, hist, stats = H.solve(f, itp)
+            H.close()
+            assert st == s_ref, (form, st, s_ref)
+            assert abs(stats.relres - rr_ref) <= 1e-6 * rr_ref, (form, stats.relres, rr_ref)
+            assert np.abs(x - x_ref).max() <= 1e-9 * np.abs(x_ref).max(), form
+            got[form] = stats.coarse_iters; sol[form] = x
+    finally:
+        L.fasp_hip_tune(b"small_onewave", 4)
+    assert got[4] == got[3] and np.array_equal(sol[4], sol[3])
+    for form in (2, 1):
         assert abs(got[form] - got[4]) <= 0.02 * got[4] + 2, got
