@@ -1213,13 +1213,30 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update(int n, double temp1, const 
 // the previous step), then the partial sums of (p_next, p_i) -- or of (p_i, p_i) when
 // p_next == nullptr (the norm that ends the orthogonalisation, :232).  The whole chain of
 // i dependent dot -> axpy pairs runs without a host round trip.
+// npart > 0: h is still npart per-block partials of the previous step (in another buffer than `partials`) -- every block sums them in
+// k_finalize's order (thread i takes i, i + 256, ...; then the block tree: the same bits in every block), block 0 leaves the sum in
+// *h_out for the host's Hessenberg column: one launch per Gram-Schmidt step instead of two (k_axpby_beta's scheme)
 __global__ __launch_bounds__(BLOCK) void k_mgs_step(int n, const double* __restrict__ h_ptr,
                                                      const double* __restrict__ pj, double* __restrict__ pi,
                                                      const double* __restrict__ pnext,
-                                                     double* __restrict__ partials)
+                                                     double* __restrict__ partials,
+                                                     const double* __restrict__ prev_partials = nullptr, int npart = 0,
+                                                     double* __restrict__ h_out = nullptr)
 {
     __shared__ double lds[4];
-    const double a = -(*h_ptr);
+    double h;
+    if (npart > 0) {
+        __shared__ double bcast;
+        double sacc = 0.0;
+        for (int i = threadIdx.x; i < npart; i += BLOCK) sacc += prev_partials[i];
+        sacc = block_sum(sacc, lds);
+        if (threadIdx.x == 0) { bcast = sacc; if (blockIdx.x == 0) *h_out = sacc; }
+        __syncthreads();
+        h = bcast;
+    } else {
+        h = *h_ptr;
+    }
+    const double a = -h;
     double acc = 0.0;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const double v = pi[i] + a * pj[i];

@@ -189,13 +189,25 @@ static int gmres_device(KOps& K, const double* b, double* x, int mode_in, double
             if (K.halo(r) < 0) return ERROR_MISC;
             K.mxv(r, p[i]);
             // modified Gram-Schmidt on the device: hh_0 = (p_0, p_i); then i fused steps
-            hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, s, n, p[0], p[i], g_ctx.d_partials);
-            d_finalize_to(G, 1, 0u, gm_hh, dist);
-            for (j = 0; j < i; j++) {
-                hipLaunchKernelGGL(k_mgs_step, dim3(G), dim3(BLOCK), 0, s, n, (const double*)(gm_hh + j),
-                                   (const double*)p[j], p[i], (const double*)(j + 1 < i ? p[j + 1] : nullptr),
-                                   g_ctx.d_partials);
-                d_finalize_to(G, 1, 0u, gm_hh + j + 1, dist);
+            // One rank: a step sums the previous step's partials itself (two partial buffers in turn) -- i + 2 launches per column
+            // instead of 2 i + 2.  Several ranks: every coefficient is all-reduced, one k_finalize + collective each.
+            if (!(dist && comm_size() > 1) && g_tune.pcg_fold) {
+                double* const pb[2] = {g_ctx.d_partials, g_ctx.d_partials2 + 4 * MAXGRID};
+                hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, s, n, p[0], p[i], pb[0]);
+                for (j = 0; j < i; j++)
+                    hipLaunchKernelGGL(k_mgs_step, dim3(G), dim3(BLOCK), 0, s, n, (const double*)nullptr,
+                                       (const double*)p[j], p[i], (const double*)(j + 1 < i ? p[j + 1] : nullptr),
+                                       pb[(j + 1) & 1], (const double*)pb[j & 1], G, gm_hh + j);
+                hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, s, (const double*)pb[i & 1], G, 1, 0u, gm_hh + i);
+            } else {
+                hipLaunchKernelGGL(k_dot, dim3(G), dim3(BLOCK), 0, s, n, p[0], p[i], g_ctx.d_partials);
+                d_finalize_to(G, 1, 0u, gm_hh, dist);
+                for (j = 0; j < i; j++) {
+                    hipLaunchKernelGGL(k_mgs_step, dim3(G), dim3(BLOCK), 0, s, n, (const double*)(gm_hh + j),
+                                       (const double*)p[j], p[i], (const double*)(j + 1 < i ? p[j + 1] : nullptr),
+                                       g_ctx.d_partials);
+                    d_finalize_to(G, 1, 0u, gm_hh + j + 1, dist);
+                }
             }
             HIPCK(hipMemcpyAsync(g_ctx.h_part, gm_hh, sizeof(double) * (i + 1), hipMemcpyDeviceToHost, s));
             HIPCK(hipStreamSynchronize(s));
